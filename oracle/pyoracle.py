@@ -1,0 +1,201 @@
+"""ctypes bindings for the CPU checkers under oracle/ (TEST INFRASTRUCTURE ONLY).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  The product package (micro-aes_amd/) never does.
+
+Two checkers are exposed:
+
+* ``Oracle``      -- our plain-C restatement (oracle/uaes_oracle.c), run-time
+                     key size, always available after ``make -C oracle``.
+* ``Reference``   -- the REAL reference compiled from /root/reference by
+                     oracle/Makefile into oracle/_ref/libmicroaes_ref_<bits>.so
+                     (one library per compile-time key size, micro_aes.h:17).
+                     Present wherever the prebuilt files travelled.
+"""
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_u8p = C.POINTER(C.c_uint8)
+
+
+def _buf(b):
+    """bytes/bytearray -> ctypes array (copy); None -> NULL."""
+    if b is None:
+        return None
+    return (C.c_uint8 * max(len(b), 1)).from_buffer_copy(bytes(b) + (b"\0" if len(b) == 0 else b""))
+
+
+def _out(n):
+    return (C.c_uint8 * max(n, 1))()
+
+
+def build(quiet=True):
+    """(Re)build liboracle.so and, when /root/reference exists, oracle/_ref."""
+    subprocess.run(["make", "-C", HERE], check=True,
+                   stdout=subprocess.DEVNULL if quiet else None)
+
+
+class Oracle:
+    def __init__(self):
+        path = os.path.join(HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        L = self.L = C.CDLL(path)
+        sz, i, vp, u64 = C.c_size_t, C.c_int, C.c_void_p, C.c_uint64
+        L.orc_ecb_encrypt.argtypes = [i, vp, vp, sz, vp]; L.orc_ecb_encrypt.restype = None
+        L.orc_ecb_decrypt.argtypes = [i, vp, vp, sz, vp]; L.orc_ecb_decrypt.restype = C.c_char
+        L.orc_ctr_encrypt.argtypes = [i, vp, vp, vp, sz, vp]; L.orc_ctr_encrypt.restype = None
+        L.orc_ctr_xcrypt_at.argtypes = [i, vp, vp, u64, vp, sz, vp]; L.orc_ctr_xcrypt_at.restype = None
+        for f in (L.orc_xts_encrypt, L.orc_xts_decrypt):
+            f.argtypes = [i, vp, vp, vp, sz, vp]; f.restype = C.c_char
+        L.orc_xts_sectors.argtypes = [i, vp, u64, sz, sz, vp, vp, i]; L.orc_xts_sectors.restype = C.c_char
+        L.orc_gcm_encrypt.argtypes = [i, vp, vp, vp, sz, vp, sz, vp]; L.orc_gcm_encrypt.restype = None
+        L.orc_gcm_decrypt.argtypes = [i, vp, vp, vp, sz, vp, sz, vp]; L.orc_gcm_decrypt.restype = C.c_char
+        L.orc_gf128_mul.argtypes = [vp, vp]; L.orc_gf128_mul.restype = None
+        L.orc_ghash.argtypes = [vp, vp, sz, vp, sz, vp]; L.orc_ghash.restype = None
+        L.orc_fill_splitmix.argtypes = [u64, u64, sz, vp]; L.orc_fill_splitmix.restype = None
+        L.orc_setkey.argtypes = [vp, vp, i]; L.orc_setkey.restype = i
+        L.orc_encrypt_block.argtypes = [vp, vp, vp]; L.orc_encrypt_block.restype = None
+        L.orc_decrypt_block.argtypes = [vp, vp, vp]; L.orc_decrypt_block.restype = None
+
+    # -- block primitive ----------------------------------------------------
+    def encrypt_block(self, key, block, decrypt=False):
+        ks = _out(4 + 240)
+        assert self.L.orc_setkey(ks, _buf(key), len(key) * 8) == 0
+        o = _out(16)
+        (self.L.orc_decrypt_block if decrypt else self.L.orc_encrypt_block)(ks, _buf(block), o)
+        return bytes(o)
+
+    # -- modes --------------------------------------------------------------
+    def ecb_encrypt(self, key, pt):
+        o = _out((len(pt) + 15) // 16 * 16)
+        self.L.orc_ecb_encrypt(len(key) * 8, _buf(key), _buf(pt), len(pt), o)
+        return bytes(o)[: (len(pt) + 15) // 16 * 16]
+
+    def ecb_decrypt(self, key, ct):
+        o = _out(len(ct))
+        rc = self.L.orc_ecb_decrypt(len(key) * 8, _buf(key), _buf(ct), len(ct), o)
+        return ord(rc), bytes(o)[: len(ct)]
+
+    def ctr_encrypt(self, key, iv, data):
+        o = _out(len(data))
+        self.L.orc_ctr_encrypt(len(key) * 8, _buf(key), _buf(iv), _buf(data), len(data), o)
+        return bytes(o)[: len(data)]
+
+    def ctr_xcrypt_at(self, key, ctr0, block_offset, data):
+        o = _out(len(data))
+        self.L.orc_ctr_xcrypt_at(len(key) * 8, _buf(key), _buf(ctr0), block_offset,
+                                 _buf(data), len(data), o)
+        return bytes(o)[: len(data)]
+
+    def xts(self, keys, tweak, data, encrypt=True, prefill=0xCC):
+        o = (C.c_uint8 * max(len(data), 1))(*([prefill] * max(len(data), 1)))
+        f = self.L.orc_xts_encrypt if encrypt else self.L.orc_xts_decrypt
+        rc = f(len(keys) * 4, _buf(keys), _buf(tweak), _buf(data), len(data), o)
+        return ord(rc), bytes(o)[: len(data)]
+
+    def xts_sectors(self, keys, first_sector, sector_bytes, data, encrypt=True):
+        n = len(data) // sector_bytes
+        o = _out(len(data))
+        rc = self.L.orc_xts_sectors(len(keys) * 4, _buf(keys), first_sector, sector_bytes, n,
+                                    _buf(data), o, 1 if encrypt else 0)
+        return ord(rc), bytes(o)[: len(data)]
+
+    def gcm_encrypt(self, key, nonce, aad, pt):
+        o = _out(len(pt) + 16)
+        self.L.orc_gcm_encrypt(len(key) * 8, _buf(key), _buf(nonce), _buf(aad), len(aad),
+                               _buf(pt), len(pt), o)
+        return bytes(o)[: len(pt) + 16]
+
+    def gcm_decrypt(self, key, nonce, aad, ct_and_tag, prefill=0xCC):
+        n = len(ct_and_tag) - 16
+        o = (C.c_uint8 * max(n, 1))(*([prefill] * max(n, 1)))
+        rc = self.L.orc_gcm_decrypt(len(key) * 8, _buf(key), _buf(nonce), _buf(aad), len(aad),
+                                    _buf(ct_and_tag), n, o)
+        return ord(rc), bytes(o)[:n]
+
+    def gf128_mul(self, x, y):
+        yy = _buf(y)
+        self.L.orc_gf128_mul(_buf(x), yy)
+        return bytes(yy)[:16]
+
+    def ghash(self, H, aad, ct):
+        g = _out(16)
+        self.L.orc_ghash(_buf(H), _buf(aad), len(aad), _buf(ct), len(ct), g)
+        return bytes(g)
+
+    def splitmix(self, seed, nbytes, word0=0):
+        assert nbytes % 8 == 0
+        o = _out(nbytes)
+        self.L.orc_fill_splitmix(seed, word0, nbytes // 8, o)
+        return bytes(o)[:nbytes]
+
+
+class Reference:
+    """The compiled reference; one library per key size (micro_aes.h:17)."""
+
+    @staticmethod
+    def path(bits):
+        return os.path.join(HERE, "_ref", "libmicroaes_ref_%d.so" % bits)
+
+    @classmethod
+    def available(cls, bits=128):
+        return os.path.exists(cls.path(bits))
+
+    def __init__(self, bits):
+        self.bits = bits
+        L = self.L = C.CDLL(self.path(bits))
+        sz, vp = C.c_size_t, C.c_void_p
+        L.AES_ECB_encrypt.argtypes = [vp, vp, sz, vp]; L.AES_ECB_encrypt.restype = None
+        L.AES_ECB_decrypt.argtypes = [vp, vp, sz, vp]; L.AES_ECB_decrypt.restype = C.c_char
+        for f in (L.AES_CTR_encrypt, L.AES_CTR_decrypt):
+            f.argtypes = [vp, vp, vp, sz, vp]; f.restype = None
+        for f in (L.AES_XTS_encrypt, L.AES_XTS_decrypt):
+            f.argtypes = [vp, vp, vp, sz, vp]; f.restype = C.c_char
+        L.AES_GCM_encrypt.argtypes = [vp, vp, vp, sz, vp, sz, vp]; L.AES_GCM_encrypt.restype = None
+        L.AES_GCM_decrypt.argtypes = [vp, vp, vp, sz, vp, sz, vp]; L.AES_GCM_decrypt.restype = C.c_char
+
+    def _chk(self, key, mult=1):
+        assert len(key) * 8 == self.bits * mult, "key size does not match this reference build"
+
+    def ecb_encrypt(self, key, pt):
+        self._chk(key)
+        n = (len(pt) + 15) // 16 * 16
+        o = _out(n)
+        self.L.AES_ECB_encrypt(_buf(key), _buf(pt), len(pt), o)
+        return bytes(o)[:n]
+
+    def ecb_decrypt(self, key, ct):
+        self._chk(key)
+        o = _out(len(ct))
+        rc = self.L.AES_ECB_decrypt(_buf(key), _buf(ct), len(ct), o)
+        return ord(rc), bytes(o)[: len(ct)]
+
+    def ctr_encrypt(self, key, iv, data):
+        self._chk(key)
+        o = _out(len(data))
+        self.L.AES_CTR_encrypt(_buf(key), _buf(iv), _buf(data), len(data), o)
+        return bytes(o)[: len(data)]
+
+    def xts(self, keys, tweak, data, encrypt=True, prefill=0xCC):
+        self._chk(keys, 2)
+        o = (C.c_uint8 * max(len(data), 1))(*([prefill] * max(len(data), 1)))
+        f = self.L.AES_XTS_encrypt if encrypt else self.L.AES_XTS_decrypt
+        rc = f(_buf(keys), _buf(tweak), _buf(data), len(data), o)
+        return ord(rc), bytes(o)[: len(data)]
+
+    def gcm_encrypt(self, key, nonce, aad, pt):
+        self._chk(key)
+        o = _out(len(pt) + 16)
+        self.L.AES_GCM_encrypt(_buf(key), _buf(nonce), _buf(aad), len(aad), _buf(pt), len(pt), o)
+        return bytes(o)[: len(pt) + 16]
+
+    def gcm_decrypt(self, key, nonce, aad, ct_and_tag, prefill=0xCC):
+        self._chk(key)
+        n = len(ct_and_tag) - 16
+        o = (C.c_uint8 * max(n, 1))(*([prefill] * max(n, 1)))
+        rc = self.L.AES_GCM_decrypt(_buf(key), _buf(nonce), _buf(aad), len(aad),
+                                    _buf(ct_and_tag), n, o)
+        return ord(rc), bytes(o)[:n]

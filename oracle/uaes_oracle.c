@@ -1,0 +1,452 @@
+/*
+ * uaes_oracle.c -- CPU oracle for the uAES hot path (TEST INFRASTRUCTURE ONLY;
+ * see uaes_oracle.h for the parity-pinning statement and the usage rule).
+ *
+ * Written from FIPS-197 / SP 800-38A,D,E following the behaviour of the
+ * reference's functions cited at each definition (paths relative to the
+ * reference checkout, e.g. micro_aes.c:242).  Byte-oriented and deliberately
+ * simple: clarity over speed.
+ */
+#include "uaes_oracle.h"
+#include <string.h>
+
+/* ------------------------------------------------------------------------ */
+/* GF(2^8) and the S-box (reference: literal tables, micro_aes.c:41-65).      */
+/* Here the tables are derived: S(x) = affine(x^-1) per FIPS-197 sec. 5.1.1.  */
+/* ------------------------------------------------------------------------ */
+static uint8_t SB[256], ISB[256];
+static int tables_ready;
+
+static uint8_t gf_double(uint8_t a)           /* micro_aes.c:115 xtime */
+{
+    return (uint8_t)((a << 1) ^ ((a & 0x80) ? 0x1b : 0));
+}
+
+static uint8_t gf_mul(uint8_t a, uint8_t b)
+{
+    uint8_t p = 0;
+    while (b) {
+        if (b & 1) p ^= a;
+        a = gf_double(a);
+        b >>= 1;
+    }
+    return p;
+}
+
+static void make_tables(void)
+{
+    int x;
+    if (tables_ready) return;
+    for (x = 0; x < 256; ++x) {
+        uint8_t inv = 0, s;
+        int y;
+        if (x)
+            for (y = 1; y < 256; ++y)
+                if (gf_mul((uint8_t)x, (uint8_t)y) == 1) { inv = (uint8_t)y; break; }
+        s = inv;
+        s ^= (uint8_t)((inv << 1) | (inv >> 7));
+        s ^= (uint8_t)((inv << 2) | (inv >> 6));
+        s ^= (uint8_t)((inv << 3) | (inv >> 5));
+        s ^= (uint8_t)((inv << 4) | (inv >> 4));
+        s ^= 0x63;
+        SB[x] = s;
+        ISB[s] = (uint8_t)x;
+    }
+    tables_ready = 1;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Key schedule -- micro_aes.c:144-178                                        */
+/* ------------------------------------------------------------------------ */
+int orc_setkey(orc_key *ks, const uint8_t *key, int keybits)
+{
+    int nk, nwords, i;
+    uint8_t rcon = 1;
+    uint8_t *w = ks->rk;
+
+    if (keybits != 128 && keybits != 192 && keybits != 256) return -1;
+    make_tables();
+    nk = keybits / 32;
+    ks->nr = nk + 6;
+    nwords = 4 * (ks->nr + 1);
+    memcpy(w, key, (size_t)(4 * nk));
+    for (i = nk; i < nwords; ++i) {
+        uint8_t t[4];
+        memcpy(t, w + 4 * (i - 1), 4);
+        if (i % nk == 0) {                     /* RotWord, SubWord, Rcon      */
+            uint8_t t0 = t[0];
+            t[0] = (uint8_t)(SB[t[1]] ^ rcon);
+            t[1] = SB[t[2]];
+            t[2] = SB[t[3]];
+            t[3] = SB[t0];
+            rcon = gf_double(rcon);            /* wraps 0x80 -> 0x1b (:155)   */
+        } else if (nk == 8 && i % nk == 4) {   /* AES-256 extra SubWord (:165)*/
+            t[0] = SB[t[0]]; t[1] = SB[t[1]]; t[2] = SB[t[2]]; t[3] = SB[t[3]];
+        }
+        w[4 * i + 0] = (uint8_t)(w[4 * (i - nk) + 0] ^ t[0]);
+        w[4 * i + 1] = (uint8_t)(w[4 * (i - nk) + 1] ^ t[1]);
+        w[4 * i + 2] = (uint8_t)(w[4 * (i - nk) + 2] ^ t[2]);
+        w[4 * i + 3] = (uint8_t)(w[4 * (i - nk) + 3] ^ t[3]);
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Block cipher.  State byte i = column i/4, row i%4 (micro_aes.c:74-77).     */
+/* ------------------------------------------------------------------------ */
+static void xor16(uint8_t *dst, const uint8_t *src)   /* micro_aes.c:105 */
+{
+    int i;
+    for (i = 0; i < 16; ++i) dst[i] ^= src[i];
+}
+
+/* micro_aes.c:242-259: ARK(r) SubBytes ShiftRows [MixColumns | ARK(last)] */
+void orc_encrypt_block(const orc_key *ks, const uint8_t in[16], uint8_t out[16])
+{
+    uint8_t s[16], t[16];
+    int r, c;
+    memcpy(s, in, 16);
+    for (r = 0; r < ks->nr; ++r) {
+        xor16(s, ks->rk + 16 * r);
+        /* SubBytes (:187) fused with ShiftRows (:198): row k moves left by k */
+        for (c = 0; c < 4; ++c) {
+            t[4 * c + 0] = SB[s[4 * c + 0]];
+            t[4 * c + 1] = SB[s[4 * ((c + 1) & 3) + 1]];
+            t[4 * c + 2] = SB[s[4 * ((c + 2) & 3) + 2]];
+            t[4 * c + 3] = SB[s[4 * ((c + 3) & 3) + 3]];
+        }
+        if (r + 1 < ks->nr) {
+            for (c = 0; c < 4; ++c) {          /* MixColumns (:221)           */
+                uint8_t a0 = t[4 * c], a1 = t[4 * c + 1];
+                uint8_t a2 = t[4 * c + 2], a3 = t[4 * c + 3];
+                uint8_t all = (uint8_t)(a0 ^ a1 ^ a2 ^ a3);
+                s[4 * c + 0] = (uint8_t)(a0 ^ all ^ gf_double((uint8_t)(a0 ^ a1)));
+                s[4 * c + 1] = (uint8_t)(a1 ^ all ^ gf_double((uint8_t)(a1 ^ a2)));
+                s[4 * c + 2] = (uint8_t)(a2 ^ all ^ gf_double((uint8_t)(a2 ^ a3)));
+                s[4 * c + 3] = (uint8_t)(a3 ^ all ^ gf_double((uint8_t)(a3 ^ a0)));
+            }
+        } else {
+            memcpy(s, t, 16);
+        }
+    }
+    xor16(s, ks->rk + 16 * ks->nr);
+    memcpy(out, s, 16);
+}
+
+/* micro_aes.c:315-332: straightforward inverse cipher, same keys reversed */
+void orc_decrypt_block(const orc_key *ks, const uint8_t in[16], uint8_t out[16])
+{
+    uint8_t s[16], t[16];
+    int r, c;
+    memcpy(s, in, 16);
+    xor16(s, ks->rk + 16 * ks->nr);
+    for (r = ks->nr - 1; r >= 0; --r) {
+        /* InvShiftRows (:278) + InvSubBytes (:268): row k moves right by k */
+        for (c = 0; c < 4; ++c) {
+            t[4 * c + 0] = ISB[s[4 * c + 0]];
+            t[4 * c + 1] = ISB[s[4 * ((c + 3) & 3) + 1]];
+            t[4 * c + 2] = ISB[s[4 * ((c + 2) & 3) + 2]];
+            t[4 * c + 3] = ISB[s[4 * ((c + 1) & 3) + 3]];
+        }
+        xor16(t, ks->rk + 16 * r);
+        if (r > 0) {
+            for (c = 0; c < 4; ++c) {          /* InvMixColumns (:301)        */
+                uint8_t a0 = t[4 * c], a1 = t[4 * c + 1];
+                uint8_t a2 = t[4 * c + 2], a3 = t[4 * c + 3];
+                s[4 * c + 0] = (uint8_t)(gf_mul(a0, 14) ^ gf_mul(a1, 11) ^ gf_mul(a2, 13) ^ gf_mul(a3, 9));
+                s[4 * c + 1] = (uint8_t)(gf_mul(a0, 9) ^ gf_mul(a1, 14) ^ gf_mul(a2, 11) ^ gf_mul(a3, 13));
+                s[4 * c + 2] = (uint8_t)(gf_mul(a0, 13) ^ gf_mul(a1, 9) ^ gf_mul(a2, 14) ^ gf_mul(a3, 11));
+                s[4 * c + 3] = (uint8_t)(gf_mul(a0, 11) ^ gf_mul(a1, 13) ^ gf_mul(a2, 9) ^ gf_mul(a3, 14));
+            }
+        } else {
+            memcpy(s, t, 16);
+        }
+    }
+    memcpy(out, s, 16);
+}
+
+/* ------------------------------------------------------------------------ */
+/* ECB -- micro_aes.c:636-680 (N1)                                            */
+/* ------------------------------------------------------------------------ */
+void orc_ecb_encrypt(int keybits, const uint8_t *key,
+                     const void *pt, size_t len, void *ct)
+{
+    orc_key ks;
+    const uint8_t *x = (const uint8_t *)pt;
+    uint8_t *y = (uint8_t *)ct;
+    size_t n = len / 16, rem = len % 16, i;
+    if (orc_setkey(&ks, key, keybits)) return;
+    for (i = 0; i < n; ++i)
+        orc_encrypt_block(&ks, x + 16 * i, y + 16 * i);
+    if (rem) {                                 /* zero padding, :610-621     */
+        uint8_t last[16] = { 0 };
+        memcpy(last, x + 16 * n, rem);
+        orc_encrypt_block(&ks, last, y + 16 * n);
+    }
+}
+
+char orc_ecb_decrypt(int keybits, const uint8_t *key,
+                     const void *ct, size_t len, void *pt)
+{
+    orc_key ks;
+    const uint8_t *x = (const uint8_t *)ct;
+    uint8_t *y = (uint8_t *)pt;
+    size_t n = len / 16, rem = len % 16, i;
+    if (orc_setkey(&ks, key, keybits)) return ORC_E_DECRYPT;
+    for (i = 0; i < n; ++i)
+        orc_decrypt_block(&ks, x + 16 * i, y + 16 * i);
+    if (rem) {                                 /* reference copies the tail   */
+        memmove(y + 16 * n, x + 16 * n, rem);  /* through untouched (:664)    */
+        return ORC_E_DECRYPT;                  /* :679                        */
+    }
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------ */
+/* CTR -- micro_aes.c:919-990 with incBlock :421-427 (N2, N3)                 */
+/* ------------------------------------------------------------------------ */
+/* add `n` to the 56-bit big-endian counter in bytes 9..15; byte 8 and below
+ * never change (the carry chain of incBlock stops after byte 9)             */
+static void ctr56_add(uint8_t c[16], uint64_t n)
+{
+    uint64_t v = 0;
+    int i;
+    for (i = 9; i < 16; ++i) v = (v << 8) | c[i];
+    v = (v + n) & 0x00FFFFFFFFFFFFFFull;
+    for (i = 15; i >= 9; --i) { c[i] = (uint8_t)v; v >>= 8; }
+}
+
+static void ctr_stream(const orc_key *ks, uint8_t c[16],
+                       const uint8_t *x, size_t len, uint8_t *y)
+{
+    uint8_t e[16];
+    size_t n = len / 16, rem = len % 16, i, k;
+    for (i = 0; i < n; ++i) {
+        orc_encrypt_block(ks, c, e);
+        for (k = 0; k < 16; ++k) y[16 * i + k] = (uint8_t)(x[16 * i + k] ^ e[k]);
+        ctr56_add(c, 1);
+    }
+    if (rem) {                                 /* mixThenXor, :534-544        */
+        orc_encrypt_block(ks, c, e);
+        for (k = 0; k < rem; ++k) y[16 * n + k] = (uint8_t)(x[16 * n + k] ^ e[k]);
+    }
+}
+
+void orc_ctr_xcrypt_at(int keybits, const uint8_t *key, const uint8_t ctr0[16],
+                       uint64_t block_offset,
+                       const void *in, size_t len, void *out)
+{
+    orc_key ks;
+    uint8_t c[16];
+    if (orc_setkey(&ks, key, keybits)) return;
+    memcpy(c, ctr0, 16);
+    ctr56_add(c, block_offset);
+    ctr_stream(&ks, c, (const uint8_t *)in, len, (uint8_t *)out);
+}
+
+void orc_ctr_encrypt(int keybits, const uint8_t *key, const uint8_t *iv,
+                     const void *in, size_t len, void *out)
+{
+    uint8_t c[16] = { 0 };
+    memcpy(c, iv, 12);                         /* CTR_IV_LENGTH, :968-971     */
+    c[15] ^= 1;                                /* CTR_START_VALUE = 1         */
+    orc_ctr_xcrypt_at(keybits, key, c, 0, in, len, out);
+}
+
+/* ------------------------------------------------------------------------ */
+/* XTS -- micro_aes.c:1008-1093, doubleLblock :449-458 (N5)                   */
+/* ------------------------------------------------------------------------ */
+static void xts_double(uint8_t t[16])
+{
+    int i;
+    uint8_t carry = (uint8_t)(t[15] >> 7);
+    for (i = 15; i > 0; --i) t[i] = (uint8_t)((t[i] << 1) | (t[i - 1] >> 7));
+    t[0] = (uint8_t)((t[0] << 1) ^ (carry ? 0x87 : 0));
+}
+
+static void xex_block(const orc_key *k1, int enc, const uint8_t T[16], uint8_t *y)
+{
+    xor16(y, T);
+    if (enc) orc_encrypt_block(k1, y, y); else orc_decrypt_block(k1, y, y);
+    xor16(y, T);
+}
+
+static char xts_unit(int keybits, const uint8_t *keys, const uint8_t T0[16],
+                     const void *in, size_t len, void *out, int enc)
+{
+    orc_key k1, k2;
+    uint8_t T[16], *y = (uint8_t *)out;
+    size_t rem = len % 16, n, i;
+    if (len < 16) return ORC_E_DATALENGTH;     /* :1069, output untouched     */
+    if (orc_setkey(&k1, keys, keybits)) return ORC_E_ENCRYPT;
+    orc_setkey(&k2, keys + keybits / 8, keybits);
+    if (out != in) memmove(out, in, len);
+    n = len / 16 - (rem ? 1 : 0);
+    orc_encrypt_block(&k2, T0, T);             /* :1026-1027                  */
+    for (i = 0; i < n; ++i, y += 16) {
+        xex_block(&k1, enc, T, y);
+        xts_double(T);
+    }
+    if (rem) {                                 /* ciphertext stealing :1037   */
+        uint8_t L[16], tmp[16];
+        memcpy(L, T, 16);
+        if (enc) xts_double(T); else xts_double(L);   /* swapped on decrypt   */
+        xex_block(&k1, enc, L, y);
+        memcpy(tmp, y, 16);
+        memcpy(y, y + 16, rem);
+        memcpy(y + 16, tmp, rem);
+        xex_block(&k1, enc, T, y);
+    }
+    return ORC_OK;
+}
+
+static char xts_api(int keybits, const uint8_t *keys, const uint8_t *tweak,
+                    const void *in, size_t len, void *out, int enc)
+{
+    uint8_t T0[16] = { 0 };                    /* NULL tweak == sector 0      */
+    if (tweak) memcpy(T0, tweak, 16);
+    return xts_unit(keybits, keys, T0, in, len, out, enc);
+}
+
+char orc_xts_encrypt(int keybits, const uint8_t *keys, const uint8_t *tweak,
+                     const void *pt, size_t len, void *ct)
+{
+    return xts_api(keybits, keys, tweak, pt, len, ct, 1);
+}
+
+char orc_xts_decrypt(int keybits, const uint8_t *keys, const uint8_t *tweak,
+                     const void *ct, size_t len, void *pt)
+{
+    return xts_api(keybits, keys, tweak, ct, len, pt, 0);
+}
+
+char orc_xts_sectors(int keybits, const uint8_t *keys, uint64_t first_sector,
+                     size_t sector_bytes, size_t nsectors,
+                     const void *in, void *out, int encrypt)
+{
+    size_t s;
+    int b;
+    for (s = 0; s < nsectors; ++s) {
+        uint8_t T0[16] = { 0 };
+        uint64_t id = first_sector + s;        /* copyLint, :399-404          */
+        char rc;
+        for (b = 0; b < 8; ++b) T0[b] = (uint8_t)(id >> (8 * b));
+        rc = xts_unit(keybits, keys, T0,
+                      (const uint8_t *)in + s * sector_bytes, sector_bytes,
+                      (uint8_t *)out + s * sector_bytes, encrypt);
+        if (rc) return rc;
+    }
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------ */
+/* GCM -- mulGF128 :476-493, xMac :551-570, gHash :1127-1137, API :1164-1212  */
+/* ------------------------------------------------------------------------ */
+void orc_gf128_mul(const uint8_t x[16], uint8_t y[16])
+{
+    uint8_t z[16] = { 0 }, v[16];
+    int i, b, k;
+    memcpy(v, y, 16);
+    for (i = 0; i < 16; ++i) {
+        for (b = 7; b >= 0; --b) {
+            uint8_t lsb;
+            if ((x[i] >> b) & 1) xor16(z, v);
+            lsb = (uint8_t)(v[15] & 1);        /* v <- v * x  (:464-473)      */
+            for (k = 15; k > 0; --k) v[k] = (uint8_t)((v[k] >> 1) | (v[k - 1] << 7));
+            v[0] >>= 1;
+            if (lsb) v[0] ^= 0xe1;
+        }
+    }
+    memcpy(y, z, 16);
+}
+
+static void ghash_absorb(const uint8_t H[16], const uint8_t *x, size_t len,
+                         uint8_t acc[16])
+{
+    size_t n = len / 16, rem = len % 16, i, k;
+    for (i = 0; i < n; ++i) {
+        xor16(acc, x + 16 * i);
+        orc_gf128_mul(H, acc);
+    }
+    if (rem) {                                 /* zero padded partial block   */
+        for (k = 0; k < rem; ++k) acc[k] ^= x[16 * n + k];
+        orc_gf128_mul(H, acc);
+    }
+}
+
+void orc_ghash(const uint8_t H[16], const void *aad, size_t aad_len,
+               const void *ct, size_t ct_len, uint8_t gh[16])
+{
+    uint8_t lens[16];
+    uint64_t abits = (uint64_t)aad_len * 8, cbits = (uint64_t)ct_len * 8;
+    int i;
+    for (i = 0; i < 8; ++i) {                  /* N6: two BE 64-bit lengths   */
+        lens[7 - i] = (uint8_t)(abits >> (8 * i));
+        lens[15 - i] = (uint8_t)(cbits >> (8 * i));
+    }
+    ghash_absorb(H, (const uint8_t *)aad, aad_len, gh);
+    ghash_absorb(H, (const uint8_t *)ct, ct_len, gh);
+    ghash_absorb(H, lens, 16, gh);
+}
+
+static void gcm_setup(orc_key *ks, int keybits, const uint8_t *key,
+                      const uint8_t *nonce, uint8_t H[16], uint8_t J0[16])
+{
+    orc_setkey(ks, key, keybits);
+    memset(H, 0, 16);
+    orc_encrypt_block(ks, H, H);               /* :1144                       */
+    memcpy(J0, nonce, 12);                     /* GCM_NONCE_LEN == 12, :1150  */
+    J0[12] = J0[13] = J0[14] = 0;
+    J0[15] = 1;
+}
+
+void orc_gcm_encrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
+                     const void *aad, size_t aad_len,
+                     const void *pt, size_t len, void *ct_and_tag)
+{
+    orc_key ks;
+    uint8_t H[16], J0[16], c[16], G[16] = { 0 }, *out = (uint8_t *)ct_and_tag;
+    gcm_setup(&ks, keybits, key, nonce, H, J0);
+    memcpy(c, J0, 16);
+    ctr56_add(c, 1);                           /* N4: pre-increment, :939-941 */
+    ctr_stream(&ks, c, (const uint8_t *)pt, len, out);
+    orc_encrypt_block(&ks, J0, J0);            /* tag mask, :1173             */
+    orc_ghash(H, aad, aad_len, out, len, G);
+    xor16(G, J0);
+    memcpy(out + len, G, 16);
+}
+
+char orc_gcm_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
+                     const void *aad, size_t aad_len,
+                     const void *ct_and_tag, size_t len, void *pt)
+{
+    orc_key ks;
+    uint8_t H[16], J0[16], E[16], c[16], G[16] = { 0 };
+    const uint8_t *in = (const uint8_t *)ct_and_tag;
+    gcm_setup(&ks, keybits, key, nonce, H, J0);
+    orc_ghash(H, aad, aad_len, in, len, G);    /* N7: authenticate first      */
+    orc_encrypt_block(&ks, J0, E);
+    xor16(G, E);
+    if (memcmp(G, in + len, 16)) return ORC_E_AUTH;   /* pt left untouched    */
+    memcpy(c, J0, 16);
+    ctr56_add(c, 1);
+    ctr_stream(&ks, c, in, len, (uint8_t *)pt);
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Synthetic input of SURVEY.md section 8d                                    */
+/* ------------------------------------------------------------------------ */
+void orc_fill_splitmix(uint64_t seed, uint64_t word0, size_t nwords, void *dst)
+{
+    uint8_t *p = (uint8_t *)dst;
+    size_t i;
+    int b;
+    for (i = 0; i < nwords; ++i) {
+        uint64_t z = seed + (word0 + i + 1) * 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        for (b = 0; b < 8; ++b) p[8 * i + b] = (uint8_t)(z >> (8 * b));
+    }
+}

@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""Generate the committed parity fixtures under tests/golden/.
+
+Run in the BUILD CONTAINER (needs /root/reference and `make -C oracle`):
+
+    python tests/golden/make_fixtures.py [--big]
+
+What it writes (all of it DATA -- inputs and expected outputs; no reference
+source text):
+
+* ``GcmEncryptExtIV{128,192,256}.rsp`` -- the NIST CAVP GCM files held by the
+  reference's own harness (testvectors/), reduced to the sections that harness
+  actually runs (IVlen == 96 and Taglen == 128, aes_testvectors_GCM.h:86) so the
+  repo carries 3 x ~140 KB instead of 3 x ~3 MB.  Format unchanged.
+* ``XTSGenAES{128,256}.rsp`` -- NIST CAVP XTS files, unmodified.
+* ``main_kats.json`` -- the hot-path known answers of the reference's main.c
+  (main.c:16-34,49-50,58-60), re-verified here against the compiled reference.
+* ``ref_vectors.json`` -- outputs of the COMPILED REFERENCE (oracle/_ref) on
+  seeded inputs over the edge-case lengths (0, 1, 15, 16, 17, ... 4097, 65541)
+  for ECB/CTR/XTS/GCM at 128/192/256 bits, plus error-path behaviour (N1,N5,N7).
+* ``digests.json`` -- SHA-256 digests of the reference's output on the
+  BASELINE.json workloads.  Cheap ones are recomputed
+  here; the multi-GiB ones are recomputed only with --big (minutes of CPU).
+"""
+import hashlib
+import json
+import os
+import random
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from oracle.pyoracle import Oracle, Reference, build  # noqa: E402
+
+REF_TV = "/root/reference/testvectors"
+
+
+def filter_gcm(src, dst):
+    """keep only [IVlen = 96] + [Taglen = 128] sections"""
+    out, keep, hdr = [], False, {}
+    with open(src) as f:
+        lines = f.read().splitlines()
+    i = 0
+    preamble_done = False
+    while i < len(lines):
+        ln = lines[i]
+        if ln.startswith("["):
+            # a section header is a run of [...] lines
+            j, hdr = i, {}
+            while j < len(lines) and lines[j].startswith("["):
+                k, v = lines[j].strip("[]").split("=")
+                hdr[k.strip()] = int(v)
+                j += 1
+            keep = hdr.get("IVlen") == 96 and hdr.get("Taglen") == 128
+            if keep:
+                out.extend(lines[i:j])
+            preamble_done = True
+            i = j
+            continue
+        if not preamble_done or keep:
+            out.append(ln)
+        i += 1
+    with open(dst, "w") as f:
+        f.write("\n".join(out) + "\n")
+
+
+def splitmix(orc, seed, n):
+    return orc.splitmix(seed, (n + 7) // 8 * 8)[:n]
+
+
+def enc_out(b):
+    """full hex when small, digest + ends otherwise"""
+    if len(b) <= 160:
+        return {"hex": b.hex()}
+    return {"len": len(b), "sha256": hashlib.sha256(b).hexdigest(),
+            "head": b[:16].hex(), "tail": b[-16:].hex()}
+
+
+MAIN_PT = ("c9f775baafa36c25cd610d3c75a482eadda97ca4864cdfe06eaf70a0ec0d7191"
+           "d55027cf8f900214e634412583ff0b478EA2B7CA516745BFEA")
+MAIN_IV = "8EA2B7CA516745BFEAfc49904b496089"
+MAIN_KEY = ("279fb74a7572135e8f9b8ef6d1eee00369c4e0d86a7b0430d8cdb78070b4c55a"
+            "00112233445566778899AABBCCDDEEFF000102030405060708090A0B0C0D0E0F")
+MAIN_AUTH = "000102030405060708090A0B0C0D0E0F101112131415161718191A1B1C1D1E1F"
+MAIN_KATS = {
+    "ecb128": "5d00c273f8b2607da834632dcbb521f4697dd4ab20bb064532a6545e24e33ae9"
+              "f545176111f93773dbecd262841cf83b10d145e71b772cf7a12889cda84be795",
+    "ctr128": "6c6bae886c235d8c7997d45c1bf0bca248b4bca9eb396d1bf6945e5b7a4fc10f"
+              "488cfe76fd5eaeff2b8fb469f78fa61e285e4cf9b9aee3d0a8",
+    "xts128": "10f9301a157bfceb3eb9e7bd38500b7e959e21ba3cc1179ad7f7d7d99460e695"
+              "5e8bcb177571c7196de58ff28c381913e7c82d0adfd90c45ca",
+    "xts256": "40bfcc14845b1bb415dd13abf1e6f89d3bfd794cf6655ffd14c0d7e4177eeaf4"
+              "5dd95f05663fcfb447671154a91b9d00d1bd7a35c14c74109a",
+    "gcm128": "5ceab5b7c2d6dede555a23c7e3e632744075a51df482730ba31485ec987ddcc8"
+              "73acdcfc6759a47ba424d838e7c0cb71b9a4d8f4572e214118c8ab284ca845c1"
+              "4394618703cddf3afb",
+    "gcm256": "eb0f39c8cc86af343545fec3abc4d1fd26241218546289ec5ce5208e01873e90"
+              "e86772931b80d74922565b38d35fe11a387b347949dda0879ca5f20fc9357760"
+              "4b2f659e3b1d1b0f33",
+}
+
+
+def main_kats():
+    """main.c constants as a table; verified against the compiled reference."""
+    pt, iv = bytes.fromhex(MAIN_PT), bytes.fromhex(MAIN_IV)
+    key = bytes.fromhex(MAIN_KEY)
+    aad = bytes.fromhex(MAIN_AUTH)[1:]           # main.c:118  a = authKey + 1
+    r128, r256 = Reference(128), Reference(256)
+    kats = []
+
+    def add(name, mode, bits, k, extra, out):
+        kats.append(dict(name=name, mode=mode, keybits=bits, key=k.hex(),
+                         pt=pt.hex(), expect=out.lower(), **extra))
+
+    assert r128.ecb_encrypt(key[:16], pt).hex() == MAIN_KATS["ecb128"].lower()
+    add("main.c:139 ECB", "ecb", 128, key[:16], {}, MAIN_KATS["ecb128"])
+    assert r128.ctr_encrypt(key[:16], iv, pt).hex() == MAIN_KATS["ctr128"].lower()
+    add("main.c:167 CTR", "ctr", 128, key[:16], {"iv": iv[:12].hex()}, MAIN_KATS["ctr128"])
+    assert r128.xts(key[:32], iv, pt)[1].hex() == MAIN_KATS["xts128"].lower()
+    add("main.c:174 XTS-128", "xts", 128, key[:32], {"tweak": iv.hex()}, MAIN_KATS["xts128"])
+    assert r256.xts(key[:64], iv, pt)[1].hex() == MAIN_KATS["xts256"].lower()
+    add("main.c:174 XTS-256", "xts", 256, key[:64], {"tweak": iv.hex()}, MAIN_KATS["xts256"])
+    assert r128.gcm_encrypt(key[:16], iv, aad, pt).hex() == MAIN_KATS["gcm128"].lower()
+    add("main.c:191 GCM-128", "gcm", 128, key[:16], {"nonce": iv[:12].hex(), "aad": aad.hex()},
+        MAIN_KATS["gcm128"])
+    assert r256.gcm_encrypt(key[:32], iv, aad, pt).hex() == MAIN_KATS["gcm256"].lower()
+    add("main.c:191 GCM-256", "gcm", 256, key[:32], {"nonce": iv[:12].hex(), "aad": aad.hex()},
+        MAIN_KATS["gcm256"])
+    return kats
+
+
+LENGTHS = [0, 1, 15, 16, 17, 31, 32, 33, 47, 48, 57, 64, 255, 256, 257, 1000,
+           4095, 4096, 4097, 4111, 16384, 65541]
+
+
+def ref_vectors(orc):
+    rng = random.Random(0x75414553)
+    vecs = []
+    for bits in (128, 192, 256):
+        ref = Reference(bits)
+        kb = bits // 8
+        for n in LENGTHS:
+            seed = rng.getrandbits(32)
+            data = splitmix(orc, seed, n)
+            key = rng.randbytes(kb)
+            base = dict(keybits=bits, len=n, seed=seed)
+            # ECB (N1: zero padded output on encrypt; 0x1d on ragged decrypt)
+            ct = ref.ecb_encrypt(key, data)
+            rc, back = ref.ecb_decrypt(key, ct[:n] if n % 16 else ct)
+            vecs.append(dict(base, mode="ecb", key=key.hex(), out=enc_out(ct), dec_rc=rc))
+            # CTR
+            iv = rng.randbytes(12)
+            vecs.append(dict(base, mode="ctr", key=key.hex(), iv=iv.hex(),
+                             out=enc_out(ref.ctr_encrypt(key, iv, data))))
+            # XTS (N5: len < 16 -> rc 1, output untouched)
+            keys, tweak = rng.randbytes(2 * kb), rng.randbytes(16)
+            rc, ct = ref.xts(keys, tweak, data, True)
+            v = dict(base, mode="xts", key=keys.hex(), tweak=tweak.hex(), rc=rc)
+            if rc == 0:
+                v["out"] = enc_out(ct)
+                rc2, pt2 = ref.xts(keys, tweak, ct, False)
+                assert rc2 == 0 and pt2 == data
+            vecs.append(v)
+            # GCM (slow bit-serial GHASH in the reference: cap the size)
+            if n <= 16384:
+                nonce, aad = rng.randbytes(12), rng.randbytes(rng.choice([0, 1, 13, 16, 20, 32, 90]))
+                ct = ref.gcm_encrypt(key, nonce, aad, data)
+                rc, pt2 = ref.gcm_decrypt(key, nonce, aad, ct)
+                assert rc == 0 and pt2 == data
+                bad = bytearray(ct); bad[-1] ^= 1
+                rcb, ptb = ref.gcm_decrypt(key, nonce, aad, bytes(bad))
+                assert rcb == 0x1A and ptb == b"\xcc" * n      # N7
+                vecs.append(dict(base, mode="gcm", key=key.hex(), nonce=nonce.hex(),
+                                 aad=aad.hex(), out=enc_out(ct)))
+    # counter carry (N2): start the 56-bit counter near its wrap via the PT-side
+    # trick is impossible through the 12-byte-IV API (counter always starts at
+    # 1), so the carry is pinned by the 65541-byte CTR vectors (4097 blocks:
+    # byte 15 wraps 16 times, byte 14 increments) and by test_oracle's
+    # comparison of ctr56 arithmetic with python integers.
+    return vecs
+
+
+def digests(orc, big):
+    r128, r256 = Reference(128), Reference(256)
+    key16 = bytes(range(16))
+    key64 = bytes(range(64))
+    nonce = bytes(range(0xF0, 0xFC))
+    sha = lambda b: hashlib.sha256(b).hexdigest()
+    d = {}
+    # C1: AES-128-ECB 4 KiB seed 1
+    d["C1_ecb128_4KiB"] = dict(sha256=sha(r128.ecb_encrypt(key16, splitmix(orc, 1, 4096))),
+                               survey="35065e081a72459058663f1b9ffc2ae298a808909b970567a02c52653fa72924")
+    ct = r128.ctr_encrypt(key16, nonce, splitmix(orc, 2, 1 << 20))
+    d["ctr128_1MiB_seed2"] = dict(sha256=sha(ct), head=ct[:32].hex(),
+                                  survey="d0de5a73639234af5a0eb9a5a85c77719e4523c865555a4b55e68f3f61f8c34f")
+    # XTS-256, 4 KiB sectors, seed 3 continuous, tweak = LE64(sector) || 0^8
+    pt = splitmix(orc, 3, 3 * 4096)
+    secs = b"".join(r256.xts(key64, s.to_bytes(16, "little"), pt[s * 4096:(s + 1) * 4096])[1]
+                    for s in range(3))
+    d["xts256_sector0"] = dict(sha256=sha(secs[:4096]), head=secs[:16].hex(),
+                               survey="14d91b1f18d016a3d3c5eda716a25f5db3b551493b53156b8d958e4aa4c24eb4")
+    d["xts256_sectors0_2"] = dict(sha256=sha(secs),
+                                  survey="8c9780eb74e3a99e8806893a086df0554cce74892d8eff287f1210e9807a579c")
+    d["xts256_sector2"] = dict(sha256=sha(secs[8192:]),
+                               survey="4b896eaa6df5f5f8bef1e0df80ccd67bcc934b3a1e264ce069f990af9827d50b")
+    ct = r128.gcm_encrypt(key16, nonce, b"", splitmix(orc, 4, 1 << 20))
+    d["gcm128_1MiB_seed4"] = dict(tag=ct[-16:].hex(), sha256_ct_tag=sha(ct), sha256_ct=sha(ct[:-16]),
+                                  survey_tag="2d85782c7ee81e5a4d3465f7ba647310",
+                                  survey="51bdf5b9cdd300f1764429d082a32f53e76b0963cb0cd5949e8d970891094e3f")
+    # full-size BASELINE configs: values measured with the compiled reference
+    # during the survey; recomputed only with --big
+    d["C2_ctr128_1GiB_seed2"] = dict(
+        sha256="c0504cbc0d799823405099c425509d4b86b2208135a6b8ad424ef02a31398d40",
+        tail="67b2827a71b064885cf195bddc5f72542b78e93c82a83498405197fa73e73219",
+        source="SURVEY.md 8d (compiled reference)")
+    d["C3_xts256_2p20_sectors_seed3"] = dict(
+        sha256="ae8ad1b9ff34a249ada238324915b6f3a96ba7776ca5b5387b5afe2f110d0be2",
+        source="SURVEY.md 8d (compiled reference)")
+    d["C4_gcm128_1GiB_seed4"] = dict(
+        tag="84e8fd11a2f269c6800b2e2924c40635",
+        sha256_ct_tag="57d46720f63a632e37ae45207cf7471548a2fb912c4753b7f8909f0c992c9cd9",
+        source="SURVEY.md 8d (compiled reference)")
+    d["C5_ctr128_8GiB_seed2"] = dict(
+        sha256="5066df5498cacd8b639f3e4fcaed7f6a64c28460702890d4939ab49e66717c46",
+        source="SURVEY.md 8d (compiled reference)")
+    for k, v in d.items():
+        if "survey" in v:
+            assert v["sha256" if "sha256" in v else "sha256_ct_tag"] == v["survey"], k
+    if big:
+        h = hashlib.sha256()
+        step = 1 << 26
+        tail = b""
+        # 1 GiB in 64 MiB slices: CTR slices are independent given the block
+        # offset, and the reference API always starts at counter 1, so feed it
+        # the whole stream in one call instead (needs ~2 GiB RAM).
+        pt = splitmix(orc, 2, 1 << 30)
+        ct = r128.ctr_encrypt(key16, nonce, pt)
+        assert sha(ct) == d["C2_ctr128_1GiB_seed2"]["sha256"]
+        assert ct[-32:].hex() == d["C2_ctr128_1GiB_seed2"]["tail"]
+        d["C2_ctr128_1GiB_seed2"]["recomputed"] = True
+        del h, step, tail
+    return d
+
+
+def main():
+    big = "--big" in sys.argv
+    build()
+    orc = Oracle()
+    for bits in (128, 192, 256):
+        filter_gcm(os.path.join(REF_TV, "GcmEncryptExtIV%d.rsp" % bits),
+                   os.path.join(HERE, "GcmEncryptExtIV%d.rsp" % bits))
+    for bits in (128, 256):
+        with open(os.path.join(REF_TV, "XTSGenAES%d.rsp" % bits)) as f, \
+                open(os.path.join(HERE, "XTSGenAES%d.rsp" % bits), "w") as g:
+            g.write(f.read())
+    with open(os.path.join(HERE, "main_kats.json"), "w") as f:
+        json.dump(main_kats(), f, indent=1)
+    with open(os.path.join(HERE, "ref_vectors.json"), "w") as f:
+        json.dump(ref_vectors(orc), f, indent=0)
+    with open(os.path.join(HERE, "digests.json"), "w") as f:
+        json.dump(digests(orc, big), f, indent=1)
+    print("fixtures written to", HERE)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,208 @@
+"""CPU tests: pin the oracle (oracle/uaes_oracle.c) against every golden the
+reference's own tests hold for the hot path, against
+outputs of the compiled reference (tests/golden/ref_vectors.json) and, when
+oracle/_ref travelled, against the reference itself on fresh random inputs.
+"""
+import hashlib
+import json
+import os
+import random
+
+import pytest
+
+from oracle.pyoracle import Reference
+from tests.rsp import gcm_cases, xts_cases
+
+EXPECTED_COUNTS = {("gcm", 128): 375, ("gcm", 192): 375, ("gcm", 256): 375,
+                   ("xts", 128): 800, ("xts", 256): 600}
+
+
+def load(golden_dir, name):
+    with open(os.path.join(golden_dir, name)) as f:
+        return json.load(f)
+
+
+def check_out(got, spec):
+    if "hex" in spec:
+        assert got.hex() == spec["hex"]
+    else:
+        assert len(got) == spec["len"]
+        assert got[:16].hex() == spec["head"] and got[-16:].hex() == spec["tail"]
+        assert hashlib.sha256(got).hexdigest() == spec["sha256"]
+
+
+def test_fips197_appendix_c(orc):
+    pt = bytes.fromhex("00112233445566778899aabbccddeeff")
+    for bits, ct in ((128, "69c4e0d86a7b0430d8cdb78070b4c55a"),
+                     (192, "dda97ca4864cdfe06eaf70a0ec0d7191"),
+                     (256, "8ea2b7ca516745bfeafc49904b496089")):
+        key = bytes(range(bits // 8))
+        assert orc.encrypt_block(key, pt).hex() == ct
+        assert orc.encrypt_block(key, bytes.fromhex(ct), decrypt=True) == pt
+
+
+@pytest.mark.parametrize("bits", [128, 192, 256])
+def test_gcm_rsp(orc, bits):
+    cases = gcm_cases(bits)
+    assert len(cases) == EXPECTED_COUNTS[("gcm", bits)]
+    for c in cases:
+        out = orc.gcm_encrypt(c["Key"], c["IV"], c["AAD"], c["PT"])
+        assert out == c["CT"] + c["Tag"], c["Count"]
+        rc, pt = orc.gcm_decrypt(c["Key"], c["IV"], c["AAD"], c["CT"] + c["Tag"])
+        assert rc == 0 and pt == c["PT"]
+
+
+@pytest.mark.parametrize("bits", [128, 256])
+def test_xts_rsp(orc, bits):
+    cases = xts_cases(bits)
+    assert len(cases) == EXPECTED_COUNTS[("xts", bits)]
+    for c in cases:
+        rc, ct = orc.xts(c["Key"], c["i"], c["PT"], True)
+        assert rc == 0 and ct == c["CT"], c["COUNT"]
+        rc, pt = orc.xts(c["Key"], c["i"], c["CT"], False)
+        assert rc == 0 and pt == c["PT"], c["COUNT"]
+
+
+def test_main_c_kats(orc, golden_dir):
+    for k in load(golden_dir, "main_kats.json"):
+        key, pt, exp = bytes.fromhex(k["key"]), bytes.fromhex(k["pt"]), bytes.fromhex(k["expect"])
+        if k["mode"] == "ecb":
+            assert orc.ecb_encrypt(key, pt) == exp
+            rc, back = orc.ecb_decrypt(key, exp)
+            assert rc == 0 and back[: len(pt)] == pt
+        elif k["mode"] == "ctr":
+            assert orc.ctr_encrypt(key, bytes.fromhex(k["iv"]), pt) == exp
+            assert orc.ctr_encrypt(key, bytes.fromhex(k["iv"]), exp) == pt
+        elif k["mode"] == "xts":
+            tw = bytes.fromhex(k["tweak"])
+            assert orc.xts(key, tw, pt, True) == (0, exp)
+            assert orc.xts(key, tw, exp, False) == (0, pt)
+        elif k["mode"] == "gcm":
+            n, a = bytes.fromhex(k["nonce"]), bytes.fromhex(k["aad"])
+            assert orc.gcm_encrypt(key, n, a, pt) == exp
+            assert orc.gcm_decrypt(key, n, a, exp) == (0, pt)
+
+
+def test_reference_generated_vectors(orc, golden_dir):
+    """outputs of the compiled reference on seeded edge-length inputs"""
+    vecs = load(golden_dir, "ref_vectors.json")
+    assert len(vecs) > 200
+    for v in vecs:
+        n = v["len"]
+        data = orc.splitmix(v["seed"], (n + 7) // 8 * 8)[:n]
+        key = bytes.fromhex(v["key"])
+        if v["mode"] == "ecb":
+            ct = orc.ecb_encrypt(key, data)
+            check_out(ct, v["out"])
+            rc, _ = orc.ecb_decrypt(key, ct[:n] if n % 16 else ct)
+            assert rc == v["dec_rc"] == (0x1D if n % 16 else 0)
+        elif v["mode"] == "ctr":
+            check_out(orc.ctr_encrypt(key, bytes.fromhex(v["iv"]), data), v["out"])
+        elif v["mode"] == "xts":
+            rc, ct = orc.xts(key, bytes.fromhex(v["tweak"]), data, True)
+            assert rc == v["rc"]
+            if rc == 0:
+                check_out(ct, v["out"])
+                assert orc.xts(key, bytes.fromhex(v["tweak"]), ct, False) == (0, data)
+            else:
+                assert rc == 1 and ct == b"\xcc" * n       # N5: output untouched
+        elif v["mode"] == "gcm":
+            ct = orc.gcm_encrypt(key, bytes.fromhex(v["nonce"]), bytes.fromhex(v["aad"]), data)
+            check_out(ct, v["out"])
+            assert orc.gcm_decrypt(key, bytes.fromhex(v["nonce"]), bytes.fromhex(v["aad"]), ct) == (0, data)
+
+
+def test_baseline_digests_small(orc, golden_dir):
+    d = load(golden_dir, "digests.json")
+    key16, key64, nonce = bytes(range(16)), bytes(range(64)), bytes(range(0xF0, 0xFC))
+    sha = lambda b: hashlib.sha256(b).hexdigest()
+    assert sha(orc.ecb_encrypt(key16, orc.splitmix(1, 4096))) == d["C1_ecb128_4KiB"]["sha256"]
+    ct = orc.ctr_encrypt(key16, nonce, orc.splitmix(2, 1 << 20))
+    assert sha(ct) == d["ctr128_1MiB_seed2"]["sha256"] and ct[:32].hex() == d["ctr128_1MiB_seed2"]["head"]
+    rc, secs = orc.xts_sectors(key64, 0, 4096, orc.splitmix(3, 3 * 4096), True)
+    assert rc == 0
+    assert sha(secs[:4096]) == d["xts256_sector0"]["sha256"]
+    assert sha(secs) == d["xts256_sectors0_2"]["sha256"]
+    assert sha(secs[8192:]) == d["xts256_sector2"]["sha256"]
+    # the synthetic stream is position-addressable: sector 2 generated alone
+    pt2 = orc.splitmix(3, 4096, word0=2 * 512)
+    assert sha(orc.xts_sectors(key64, 2, 4096, pt2, True)[1]) == d["xts256_sector2"]["sha256"]
+
+
+def test_gcm_digest_1mib(orc, golden_dir):
+    d = load(golden_dir, "digests.json")["gcm128_1MiB_seed4"]
+    ct = orc.gcm_encrypt(bytes(range(16)), bytes(range(0xF0, 0xFC)), b"", orc.splitmix(4, 1 << 20))
+    assert ct[-16:].hex() == d["tag"]
+    assert hashlib.sha256(ct).hexdigest() == d["sha256_ct_tag"]
+
+
+def test_error_paths(orc):
+    key = bytes(range(16))
+    # N7: a flipped tag bit -> 0x1A and the plaintext buffer is left alone
+    ct = bytearray(orc.gcm_encrypt(key, bytes(12), b"hdr", b"x" * 40))
+    ct[-3] ^= 0x10
+    assert orc.gcm_decrypt(key, bytes(12), b"hdr", bytes(ct)) == (0x1A, b"\xcc" * 40)
+    # N5: XTS shorter than a block -> 1, untouched; NULL tweak == zero tweak
+    assert orc.xts(key * 2, bytes(16), b"123456789012345", True) == (1, b"\xcc" * 15)
+    assert orc.xts(key * 2, None, b"A" * 40, True) == orc.xts(key * 2, bytes(16), b"A" * 40, True)
+    # N1: ECB ragged
+    assert len(orc.ecb_encrypt(key, b"B" * 20)) == 32
+    assert orc.ecb_decrypt(key, b"B" * 20)[0] == 0x1D
+
+
+def test_counter_is_56_bit(orc):
+    """N2: bytes 9..15 are a 56-bit big-endian counter, byte 8 never changes"""
+    key = bytes(range(16))
+    c0 = bytes.fromhex("0011223344556677a8fffffffffffffe")
+    ks = orc.ctr_xcrypt_at(key, c0, 0, bytes(64))
+    expect = b"".join(orc.encrypt_block(key, bytes.fromhex(h)) for h in (
+        "0011223344556677a8fffffffffffffe", "0011223344556677a8ffffffffffffff",
+        "0011223344556677a800000000000000", "0011223344556677a800000000000001"))
+    assert ks == expect
+    # offset form == sequential form
+    assert orc.ctr_xcrypt_at(key, c0, 2, bytes(32)) == expect[32:]
+    rnd = random.Random(5)
+    data = rnd.randbytes(1000)
+    whole = orc.ctr_xcrypt_at(key, c0, 0, data)
+    assert whole == orc.ctr_xcrypt_at(key, c0, 0, data[:160]) + orc.ctr_xcrypt_at(key, c0, 10, data[160:])
+
+
+def test_gf128_properties(orc):
+    rnd = random.Random(9)
+    one = bytes([0x80] + [0] * 15)                       # the field's 1
+    for _ in range(20):
+        a, b, c = rnd.randbytes(16), rnd.randbytes(16), rnd.randbytes(16)
+        assert orc.gf128_mul(one, a) == a
+        assert orc.gf128_mul(a, b) == orc.gf128_mul(b, a)
+        ab_c = orc.gf128_mul(orc.gf128_mul(a, b), c)
+        assert ab_c == orc.gf128_mul(a, orc.gf128_mul(b, c))
+        xor = bytes(x ^ y for x, y in zip(b, c))
+        lhs = orc.gf128_mul(a, xor)
+        rhs = bytes(x ^ y for x, y in zip(orc.gf128_mul(a, b), orc.gf128_mul(a, c)))
+        assert lhs == rhs
+
+
+@pytest.mark.parametrize("bits", [128, 192, 256])
+def test_against_compiled_reference_random(orc, bits):
+    """oracle == the real reference on fresh random inputs (skipped if the
+    prebuilt oracle/_ref did not travel to this box)"""
+    if not Reference.available(bits):
+        pytest.skip("oracle/_ref not built here")
+    ref = Reference(bits)
+    rnd = random.Random(1000 + bits)
+    kb = bits // 8
+    for _ in range(60):
+        n = rnd.choice([0, 1, 5, 16, 17, 40, 64, 100, 255, 513, 2048, 3001])
+        data, key = rnd.randbytes(n), rnd.randbytes(kb)
+        assert orc.ecb_encrypt(key, data) == ref.ecb_encrypt(key, data)
+        blk = rnd.randbytes(n // 16 * 16)
+        assert orc.ecb_decrypt(key, blk) == ref.ecb_decrypt(key, blk)
+        iv = rnd.randbytes(12)
+        assert orc.ctr_encrypt(key, iv, data) == ref.ctr_encrypt(key, iv, data)
+        keys, tw = rnd.randbytes(2 * kb), rnd.randbytes(16)
+        for enc in (True, False):
+            assert orc.xts(keys, tw, data, enc) == ref.xts(keys, tw, data, enc)
+        aad = rnd.randbytes(rnd.choice([0, 3, 16, 31]))
+        ct = ref.gcm_encrypt(key, iv, aad, data)
+        assert orc.gcm_encrypt(key, iv, aad, data) == ct
+        assert orc.gcm_decrypt(key, iv, aad, ct) == ref.gcm_decrypt(key, iv, aad, ct) == (0, data)
