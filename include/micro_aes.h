@@ -1,0 +1,112 @@
+/*
+ * micro_aes.h -- drop-in replacement for the reference's public header, for
+ * the four modes served by the MI355X engine (ECB, CTR, XTS, GCM).
+ *
+ * Same function names, argument order, return types and configuration macros
+ * as polfosol/micro-AES v11 (micro_aes.h:17-129, :173-181, :239-249, :256-266,
+ * :294-308, :469-476), so that callers written against the reference -- its
+ * main.c and its testvectors/ harness -- compile unchanged and link against
+ * libmicro_aes_hip_<bits>.so instead of micro_aes.c.  Modes the engine does
+ * not implement have their macro set to 0, which is how the reference itself
+ * switches a mode (and the harness's test for it) off.
+ *
+ * The AES_* functions below are thin wrappers (uaes_compat.c) around the
+ * run-time-key-size C ABI in uaes_hip.h; buffers may be host or HIP device
+ * memory.  On an engine failure (no GPU, HIP error) the void functions print a
+ * diagnostic and abort() -- they never return unencrypted data -- and the
+ * char functions return M_ENCRYPTION_ERROR / M_DECRYPTION_ERROR.
+ */
+#ifndef MICRO_AES_H_
+#define MICRO_AES_H_
+
+#ifndef AES___
+#define AES___ 128          /* or 192 / 256; must match the library linked */
+#endif
+
+#define BLOCKCIPHERS 1
+#define AEAD_MODES   1
+
+#define ECB      1
+#define CTR      1
+#define CTR_NA   1
+#define XEX      1
+#define XTS      1
+#define GCM      1
+
+#define CBC      0          /* serial chains and MAC-only modes: not on the  */
+#define CFB      0          /* GPU hot path           */
+#define OFB      0
+#define KWA      0
+#define FPE      0
+#define CMAC     0
+#define CCM      0
+#define EAX      0
+#define EAXP     0
+#define SIV      0
+#define GCM_SIV  0
+#define OCB      0
+#define POLY1305 0
+#define CTS      0
+#define MICRO_RJNDL 0
+
+#define AES_PADDING     0   /* zero padding of a ragged ECB tail            */
+#define DECRYPTION      1
+#define PRESET_COUNTER  0   /* CTR takes a 12-byte IV; see uaes_ctr_xcrypt_at */
+
+enum constant_parameters_of_modes
+{
+    CTR_START_VALUE = 1,
+    CTR_IV_LENGTH   = 12,
+    GCM_NONCE_LEN   = 12,
+    GCM_TAG_LEN     = 16,
+#if AES___ == 256 || AES___ == 192
+    AES_KEYLENGTH   = AES___ / 8
+#else
+    AES_KEYLENGTH   = 16
+#endif
+};
+
+#include <stddef.h>
+#include <stdint.h>
+#include <string.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+void AES_ECB_encrypt(const uint8_t *key,
+                     const void *pntxt, const size_t ptextLen, void *crtxt);
+char AES_ECB_decrypt(const uint8_t *key,
+                     const void *crtxt, const size_t crtxtLen, void *pntxt);
+
+void AES_CTR_encrypt(const uint8_t *key, const uint8_t *iv,
+                     const void *pntxt, const size_t ptextLen, void *crtxt);
+void AES_CTR_decrypt(const uint8_t *key, const uint8_t *iv,
+                     const void *crtxt, const size_t crtxtLen, void *pntxt);
+
+char AES_XTS_encrypt(const uint8_t *keys, const uint8_t *tweak,
+                     const void *pntxt, const size_t ptextLen, void *crtxt);
+char AES_XTS_decrypt(const uint8_t *keys, const uint8_t *tweak,
+                     const void *crtxt, const size_t crtxtLen, void *pntxt);
+
+void AES_GCM_encrypt(const uint8_t *key, const uint8_t *nonce,
+                     const void *aData, const size_t aDataLen,
+                     const void *pntxt, const size_t ptextLen, void *crtxt);
+char AES_GCM_decrypt(const uint8_t *key, const uint8_t *nonce,
+                     const void *aData, const size_t aDataLen,
+                     const void *crtxt, const size_t crtxtLen, void *pntxt);
+
+#ifdef __cplusplus
+}
+#endif
+
+enum function_result_codes
+{
+    M_ENCRYPTION_ERROR     = 0x1E,
+    M_DECRYPTION_ERROR     = 0x1D,
+    M_AUTHENTICATION_ERROR = 0x1A,
+    M_DATALENGTH_ERROR     = 0x1L,
+    M_RESULT_SUCCESS       = 0
+};
+
+#endif /* MICRO_AES_H_ */

@@ -1,0 +1,147 @@
+/*
+ * uaes_hip.h -- C ABI of the MI355X-native AES engine (libuaes_hip.so).
+ *
+ * This is the drop-in boundary for the hot path of polfosol/micro-AES: the
+ * block-parallel mode drivers ECB / CTR / XTS / GCM.  Every entry point below
+ * names the reference interface it replaces (paths relative to the reference
+ * checkout).  Differences from the reference API, all of them additive:
+ *
+ *   - the key size is a run-time argument (`keybits` = 128/192/256) instead of
+ *     the compile-time macro AES___ (micro_aes.h:17).  include/micro_aes.h
+ *     restores the macro API on top of these functions;
+ *   - no global state: the reference keeps one static RoundKey
+ *     (micro_aes.c:72) and is not re-entrant; this library is thread-safe;
+ *   - data pointers may be HOST or DEVICE (HIP) pointers.  Host buffers are
+ *     staged through device memory; device buffers are used in place.
+ *     Keys, IVs, nonces and tweaks are always host pointers (<= 64 bytes);
+ *   - `in == out` is allowed everywhere (the reference memcpy()s in -> out and
+ *     works in place, micro_aes.h:520-526); partial overlap is undefined;
+ *   - *_dev variants enqueue on a caller-supplied hipStream_t and return
+ *     without synchronising: the form bench.py and multi-GPU sharding use.
+ *
+ * There is NO CPU fallback anywhere in this library: if no HIP device is
+ * usable every call fails loudly (UAES_E_HIP, message in uaes_last_error()).
+ *
+ * Return values: 0 on success; the reference's codes (micro_aes.h:469-476)
+ * for the reference's error conditions; negative for engine failures.
+ */
+#ifndef UAES_HIP_H_
+#define UAES_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UAES_OK                0
+#define UAES_E_DATALENGTH      1      /* M_DATALENGTH_ERROR     (0x1L)  */
+#define UAES_E_AUTHENTICATION  0x1A   /* M_AUTHENTICATION_ERROR         */
+#define UAES_E_DECRYPTION      0x1D   /* M_DECRYPTION_ERROR             */
+#define UAES_E_ENCRYPTION      0x1E   /* M_ENCRYPTION_ERROR             */
+#define UAES_E_HIP            (-1)    /* HIP runtime / device failure   */
+#define UAES_E_ARG            (-2)    /* bad keybits / NULL / alignment */
+
+/* ---- housekeeping ------------------------------------------------------ */
+/* Initialise the engine on the calling thread's current HIP device (idempotent;
+ * every other call does this lazily).                                        */
+int         uaes_init(void);
+/* Run the on-device primitive self test (FIPS-197 C.1 both directions, byte
+ * permute semantics, tweak arithmetic).  0 = pass, >0 = failure bitmask.     */
+int         uaes_selftest(void);
+/* Thread-local description of the last negative return value.               */
+const char *uaes_last_error(void);
+/* "uaes-hip <version> gfx950"                                               */
+const char *uaes_version(void);
+
+/* Host-side key schedule (KeyExpansion, micro_aes.c:144-178) as the kernels
+ * receive it: (nr+1)*4 little-endian words of encryption round keys and of
+ * the equivalent-inverse-cipher keys.  Returns nr (10/12/14) or a negative
+ * error.  Diagnostic: needs no GPU.                                         */
+int uaes_expand_key(int keybits, const uint8_t *key,
+                    uint32_t enc_words[60], uint32_t dec_words[60]);
+
+/* ---- ECB: replaces AES_ECB_encrypt / AES_ECB_decrypt --------------------
+ * micro_aes.h:173-181, micro_aes.c:636-680.  encrypt writes ceil(len/16)*16
+ * bytes (a trailing partial block is zero padded, AES_PADDING 0); decrypt
+ * processes floor(len/16) blocks, copies a ragged tail through unchanged and
+ * returns UAES_E_DECRYPTION if len % 16 != 0.                               */
+int uaes_ecb_encrypt(int keybits, const uint8_t *key,
+                     const void *pntxt, size_t ptextLen, void *crtxt);
+int uaes_ecb_decrypt(int keybits, const uint8_t *key,
+                     const void *crtxt, size_t crtxtLen, void *pntxt);
+
+/* ---- CTR: replaces AES_CTR_encrypt / AES_CTR_decrypt --------------------
+ * micro_aes.h:256-266, micro_aes.c:962-990.  iv = 12 bytes (CTR_IV_LENGTH);
+ * counter block = iv || 00000001 (CTR_START_VALUE); the counter is the
+ * reference's 56-bit big-endian integer in bytes 9..15 (incBlock,
+ * micro_aes.c:421-427).  Decrypt is the same function.                      */
+int uaes_ctr_xcrypt(int keybits, const uint8_t *key, const uint8_t *iv,
+                    const void *in, size_t len, void *out);
+/* Sharding extension: full 16-byte initial counter block (what the reference
+ * builds internally, or takes directly when PRESET_COUNTER is 1,
+ * micro_aes.h:100) plus a block offset added with the same 56-bit carry.
+ * Rank g of a sharded stream passes block_offset = g * blocks_per_shard.    */
+int uaes_ctr_xcrypt_at(int keybits, const uint8_t *key, const uint8_t ctr0[16],
+                       uint64_t block_offset,
+                       const void *in, size_t len, void *out);
+
+/* ---- XTS: replaces AES_XTS_encrypt / AES_XTS_decrypt --------------------
+ * micro_aes.h:239-249, micro_aes.c:1008-1093.  keys = key1 || key2
+ * (2*keybits/8 bytes; key2 encrypts the tweak).  tweak = 16 raw bytes, or
+ * NULL for data unit 0.  len < 16 -> UAES_E_DATALENGTH, output untouched.
+ * Ciphertext stealing when len % 16 != 0.                                   */
+int uaes_xts_encrypt(int keybits, const uint8_t *keys, const uint8_t *tweak,
+                     const void *pntxt, size_t ptextLen, void *crtxt);
+int uaes_xts_decrypt(int keybits, const uint8_t *keys, const uint8_t *tweak,
+                     const void *crtxt, size_t crtxtLen, void *pntxt);
+/* Batch extension: nsectors data units of sector_bytes each in one call; unit
+ * i uses the tweak block LE128(first_sector + i) -- the reference's own
+ * `sectid` convention (XTS_cipher, micro_aes.c:1017-1021).                  */
+int uaes_xts_sectors(int keybits, const uint8_t *keys, uint64_t first_sector,
+                     size_t sector_bytes, size_t nsectors,
+                     const void *in, void *out, int encrypt);
+
+/* ---- GCM: replaces AES_GCM_encrypt / AES_GCM_decrypt --------------------
+ * micro_aes.h:294-308, micro_aes.c:1164-1212.  12-byte nonce (GCM_NONCE_LEN),
+ * 16-byte tag (GCM_TAG_LEN) appended at crtxt + ptextLen.  decrypt takes
+ * CT || tag with crtxtLen excluding the tag, authenticates BEFORE decrypting
+ * and on mismatch returns UAES_E_AUTHENTICATION leaving pntxt untouched.     */
+int uaes_gcm_encrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
+                     const void *aData, size_t aDataLen,
+                     const void *pntxt, size_t ptextLen, void *crtxt);
+int uaes_gcm_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
+                     const void *aData, size_t aDataLen,
+                     const void *crtxt, size_t crtxtLen, void *pntxt);
+/* GHASH_H(aData, crtxt) of micro_aes.c:1127-1137 with an explicit H (test
+ * hook for the carry-less-multiply kernels); gh receives 16 bytes.           */
+int uaes_ghash(const uint8_t H[16], const void *aData, size_t aDataLen,
+               const void *crtxt, size_t crtxtLen, uint8_t gh[16]);
+
+/* ---- asynchronous, device-resident variants -----------------------------
+ * All data pointers are device pointers, 16-byte aligned; `stream` is a
+ * hipStream_t (NULL = default stream).  The call only enqueues work.  One
+ * XTS/GCM *_dev call may be in flight per device at a time (they share the
+ * engine's scratch buffer).                                                 */
+int uaes_ecb_dev(int keybits, const uint8_t *key, int decrypt,
+                 const void *d_in, size_t len, void *d_out, void *stream);
+int uaes_ctr_xcrypt_at_dev(int keybits, const uint8_t *key, const uint8_t ctr0[16],
+                           uint64_t block_offset,
+                           const void *d_in, size_t len, void *d_out, void *stream);
+int uaes_xts_sectors_dev(int keybits, const uint8_t *keys, uint64_t first_sector,
+                         size_t sector_bytes, size_t nsectors,
+                         const void *d_in, void *d_out, int encrypt, void *stream);
+int uaes_gcm_encrypt_dev(int keybits, const uint8_t *key, const uint8_t *nonce,
+                         const void *d_aad, size_t aad_len,
+                         const void *d_in, size_t len, void *d_out, void *stream);
+/* d_status (device int) receives 0 or UAES_E_AUTHENTICATION                 */
+int uaes_gcm_decrypt_dev(int keybits, const uint8_t *key, const uint8_t *nonce,
+                         const void *d_aad, size_t aad_len,
+                         const void *d_in, size_t len, void *d_out,
+                         int *d_status, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,263 @@
+"""micro-aes_amd -- Python host mirror of the MI355X AES engine.
+
+The product is ``lib/libuaes_hip.so`` (C ABI in ``include/uaes_hip.h``: hand
+written gfx950 kernels behind plain-C entry points).  This package is the thin
+host-side mirror of the reference's operator interface for the hot path --
+``AES_ECB_encrypt`` ... ``AES_GCM_decrypt`` with the reference's argument order
+(micro_aes.h:173-181, :239-249, :256-266, :294-308), minus the explicit lengths
+-- plus the device-resident entry points that bench.py and the multi-GPU
+sharding layer drive with ``torch`` tensors' raw pointers.  torch is only
+plumbing here (device memory, streams, torch.distributed).
+
+There is NO fallback: if the shared library is missing or no HIP device is
+usable, importing ``engine()`` / calling any function raises.
+
+The directory name carries a hyphen (it is the name the project was given), so
+import it through the alias module at the repo root::
+
+    import micro_aes_amd as uaes
+"""
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.join(HERE, "lib")
+CSRC = os.path.join(HERE, "csrc")
+
+M_RESULT_SUCCESS = 0
+M_DATALENGTH_ERROR = 1
+M_AUTHENTICATION_ERROR = 0x1A
+M_DECRYPTION_ERROR = 0x1D
+M_ENCRYPTION_ERROR = 0x1E
+
+EXPORTS = [
+    "uaes_init", "uaes_selftest", "uaes_last_error", "uaes_version", "uaes_expand_key",
+    "uaes_ecb_encrypt", "uaes_ecb_decrypt", "uaes_ctr_xcrypt", "uaes_ctr_xcrypt_at",
+    "uaes_xts_encrypt", "uaes_xts_decrypt", "uaes_xts_sectors",
+    "uaes_gcm_encrypt", "uaes_gcm_decrypt", "uaes_ghash",
+    "uaes_ecb_dev", "uaes_ctr_xcrypt_at_dev", "uaes_xts_sectors_dev",
+    "uaes_gcm_encrypt_dev", "uaes_gcm_decrypt_dev",
+]
+COMPAT_EXPORTS = [
+    "AES_ECB_encrypt", "AES_ECB_decrypt", "AES_CTR_encrypt", "AES_CTR_decrypt",
+    "AES_XTS_encrypt", "AES_XTS_decrypt", "AES_GCM_encrypt", "AES_GCM_decrypt",
+]
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def build(quiet=True):
+    """Compile the HIP kernels and the C host layer for gfx950, in-tree."""
+    subprocess.run(["make", "-C", CSRC, "-j8"], check=True,
+                   stdout=subprocess.DEVNULL if quiet else None)
+
+
+def lib_path(name="libuaes_hip.so"):
+    return os.path.join(LIB_DIR, name)
+
+
+_lib = None
+
+
+def engine():
+    """The loaded C-ABI library (ctypes.CDLL), prototypes attached."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise EngineError("HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; "
+                          "g.build()'` (there is no CPU fallback)" % path)
+    L = C.CDLL(path)
+    sz, i, vp, u64 = C.c_size_t, C.c_int, C.c_void_p, C.c_uint64
+    L.uaes_init.restype = i
+    L.uaes_selftest.restype = i
+    L.uaes_last_error.restype = C.c_char_p
+    L.uaes_version.restype = C.c_char_p
+    for n in ("uaes_ecb_encrypt", "uaes_ecb_decrypt"):
+        getattr(L, n).argtypes = [i, vp, vp, sz, vp]
+    L.uaes_ctr_xcrypt.argtypes = [i, vp, vp, vp, sz, vp]
+    L.uaes_ctr_xcrypt_at.argtypes = [i, vp, vp, u64, vp, sz, vp]
+    for n in ("uaes_xts_encrypt", "uaes_xts_decrypt"):
+        getattr(L, n).argtypes = [i, vp, vp, vp, sz, vp]
+    L.uaes_xts_sectors.argtypes = [i, vp, u64, sz, sz, vp, vp, i]
+    for n in ("uaes_gcm_encrypt", "uaes_gcm_decrypt"):
+        getattr(L, n).argtypes = [i, vp, vp, vp, sz, vp, sz, vp]
+    L.uaes_ghash.argtypes = [vp, vp, sz, vp, sz, vp]
+    L.uaes_ecb_dev.argtypes = [i, vp, i, vp, sz, vp, vp]
+    L.uaes_ctr_xcrypt_at_dev.argtypes = [i, vp, vp, u64, vp, sz, vp, vp]
+    L.uaes_xts_sectors_dev.argtypes = [i, vp, u64, sz, sz, vp, vp, i, vp]
+    L.uaes_gcm_encrypt_dev.argtypes = [i, vp, vp, vp, sz, vp, sz, vp, vp]
+    L.uaes_gcm_decrypt_dev.argtypes = [i, vp, vp, vp, sz, vp, sz, vp, vp, vp]
+    L.uaes_expand_key.argtypes = [i, vp, vp, vp]
+    for n in EXPORTS:
+        if n not in ("uaes_last_error", "uaes_version"):
+            getattr(L, n).restype = i
+    _lib = L
+    return L
+
+
+def _check(rc, what):
+    if rc < 0:
+        raise EngineError("%s failed (%d): %s" % (what, rc, engine().uaes_last_error().decode()))
+    return rc
+
+
+def _in(b):
+    b = bytes(b)
+    return (C.c_uint8 * max(len(b), 1)).from_buffer_copy(b if b else b"\0")
+
+
+def _out(n, fill=0):
+    buf = (C.c_uint8 * max(n, 1))()
+    if fill:
+        C.memset(buf, fill, max(n, 1))
+    return buf
+
+
+def _bits(key, mult=1):
+    bits = len(key) * 8 // mult
+    if bits not in (128, 192, 256):
+        raise ValueError("key must be %s bytes" % "/".join(str(mult * k) for k in (16, 24, 32)))
+    return bits
+
+
+# ---------------------------------------------------------------------------
+# host-buffer API: same names and argument meaning as the reference
+# ---------------------------------------------------------------------------
+def AES_ECB_encrypt(key, pntxt):
+    """micro_aes.c:636.  Returns ceil(len/16)*16 bytes (zero padded tail)."""
+    n = (len(pntxt) + 15) // 16 * 16
+    o = _out(n)
+    _check(engine().uaes_ecb_encrypt(_bits(key), _in(key), _in(pntxt), len(pntxt), o), "AES_ECB_encrypt")
+    return bytes(o)[:n]
+
+
+def AES_ECB_decrypt(key, crtxt):
+    """micro_aes.c:663.  Returns (code, plaintext); code 0x1D on a ragged length."""
+    o = _out(len(crtxt))
+    rc = _check(engine().uaes_ecb_decrypt(_bits(key), _in(key), _in(crtxt), len(crtxt), o), "AES_ECB_decrypt")
+    return rc, bytes(o)[: len(crtxt)]
+
+
+def AES_CTR_encrypt(key, iv, pntxt):
+    """micro_aes.c:962.  iv: 12 bytes; counter block = iv || 00000001."""
+    o = _out(len(pntxt))
+    _check(engine().uaes_ctr_xcrypt(_bits(key), _in(key), _in(iv), _in(pntxt), len(pntxt), o), "AES_CTR_encrypt")
+    return bytes(o)[: len(pntxt)]
+
+
+AES_CTR_decrypt = AES_CTR_encrypt            # micro_aes.c:986-990
+
+
+def ctr_xcrypt_at(key, ctr0, block_offset, data):
+    """Sharding extension: explicit 16-byte counter block + 56-bit block offset."""
+    o = _out(len(data))
+    _check(engine().uaes_ctr_xcrypt_at(_bits(key), _in(key), _in(ctr0), block_offset, _in(data), len(data), o),
+           "uaes_ctr_xcrypt_at")
+    return bytes(o)[: len(data)]
+
+
+def _xts(fn, name, keys, tweak, data, prefill):
+    o = _out(len(data), prefill)
+    rc = _check(fn(_bits(keys, 2), _in(keys), None if tweak is None else _in(tweak), _in(data), len(data), o), name)
+    return rc, bytes(o)[: len(data)]
+
+
+def AES_XTS_encrypt(keys, tweak, pntxt, prefill=0):
+    """micro_aes.c:1066.  Returns (code, ciphertext); code 1 if len < 16 (output untouched)."""
+    return _xts(engine().uaes_xts_encrypt, "AES_XTS_encrypt", keys, tweak, pntxt, prefill)
+
+
+def AES_XTS_decrypt(keys, tweak, crtxt, prefill=0):
+    """micro_aes.c:1085."""
+    return _xts(engine().uaes_xts_decrypt, "AES_XTS_decrypt", keys, tweak, crtxt, prefill)
+
+
+def xts_sectors(keys, first_sector, sector_bytes, data, encrypt=True):
+    """Batch extension: data unit i has tweak LE128(first_sector + i)."""
+    assert sector_bytes > 0 and len(data) % sector_bytes == 0
+    o = _out(len(data))
+    rc = _check(engine().uaes_xts_sectors(_bits(keys, 2), _in(keys), first_sector, sector_bytes,
+                                          len(data) // sector_bytes, _in(data), o, 1 if encrypt else 0),
+                "uaes_xts_sectors")
+    return rc, bytes(o)[: len(data)]
+
+
+def AES_GCM_encrypt(key, nonce, aData, pntxt):
+    """micro_aes.c:1164.  Returns ciphertext || 16-byte tag."""
+    o = _out(len(pntxt) + 16)
+    _check(engine().uaes_gcm_encrypt(_bits(key), _in(key), _in(nonce), _in(aData), len(aData),
+                                     _in(pntxt), len(pntxt), o), "AES_GCM_encrypt")
+    return bytes(o)[: len(pntxt) + 16]
+
+
+def AES_GCM_decrypt(key, nonce, aData, crtxt_and_tag, prefill=0):
+    """micro_aes.c:1192.  Returns (code, plaintext); code 0x1A and an untouched
+    (prefilled) buffer when authentication fails."""
+    n = len(crtxt_and_tag) - 16
+    o = _out(n, prefill)
+    rc = _check(engine().uaes_gcm_decrypt(_bits(key), _in(key), _in(nonce), _in(aData), len(aData),
+                                          _in(crtxt_and_tag), n, o), "AES_GCM_decrypt")
+    return rc, bytes(o)[:n]
+
+
+def ghash(H, aData, crtxt):
+    """gHash of micro_aes.c:1127 with an explicit subkey (test hook)."""
+    o = _out(16)
+    _check(engine().uaes_ghash(_in(H), _in(aData), len(aData), _in(crtxt), len(crtxt), o), "uaes_ghash")
+    return bytes(o)
+
+
+def selftest():
+    return _check(engine().uaes_selftest(), "uaes_selftest")
+
+
+# ---------------------------------------------------------------------------
+# device-resident API (torch tensors are only carriers of raw device pointers)
+# ---------------------------------------------------------------------------
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream(stream):
+    if stream is None:
+        import torch
+        stream = torch.cuda.current_stream()
+    return C.c_void_p(stream.cuda_stream)
+
+
+def ctr_xcrypt_dev(key, ctr0, block_offset, src, dst, nbytes=None, stream=None):
+    """Enqueue CTR over device tensors (uint8, contiguous).  No synchronisation."""
+    n = src.numel() * src.element_size() if nbytes is None else nbytes
+    _check(engine().uaes_ctr_xcrypt_at_dev(_bits(key), _in(key), _in(ctr0), block_offset,
+                                           _ptr(src), n, _ptr(dst), _stream(stream)), "uaes_ctr_xcrypt_at_dev")
+
+
+def ecb_dev(key, src, dst, decrypt=False, nbytes=None, stream=None):
+    n = src.numel() * src.element_size() if nbytes is None else nbytes
+    _check(engine().uaes_ecb_dev(_bits(key), _in(key), 1 if decrypt else 0, _ptr(src), n, _ptr(dst),
+                                 _stream(stream)), "uaes_ecb_dev")
+
+
+def xts_sectors_dev(keys, first_sector, sector_bytes, nsectors, src, dst, encrypt=True, stream=None):
+    _check(engine().uaes_xts_sectors_dev(_bits(keys, 2), _in(keys), first_sector, sector_bytes, nsectors,
+                                         _ptr(src), _ptr(dst), 1 if encrypt else 0, _stream(stream)),
+           "uaes_xts_sectors_dev")
+
+
+def gcm_encrypt_dev(key, nonce, aad, src, nbytes, dst, stream=None):
+    """dst must hold nbytes + 16 (tag appended)."""
+    _check(engine().uaes_gcm_encrypt_dev(_bits(key), _in(key), _in(nonce), _ptr(aad),
+                                         0 if aad is None else aad.numel(), _ptr(src), nbytes, _ptr(dst),
+                                         _stream(stream)), "uaes_gcm_encrypt_dev")
+
+
+def gcm_decrypt_dev(key, nonce, aad, src, nbytes, dst, status, stream=None):
+    """src holds nbytes + 16 (ciphertext || tag); status: int32 device tensor."""
+    _check(engine().uaes_gcm_decrypt_dev(_bits(key), _in(key), _in(nonce), _ptr(aad),
+                                         0 if aad is None else aad.numel(), _ptr(src), nbytes, _ptr(dst),
+                                         _ptr(status), _stream(stream)), "uaes_gcm_decrypt_dev")

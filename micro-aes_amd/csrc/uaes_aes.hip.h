@@ -1,0 +1,242 @@
+/*
+ * uaes_aes.hip.h -- the Rijndael round as gfx950 device code.
+ *
+ * What it reproduces: rijndaelEncrypt / rijndaelDecrypt of the reference
+ * (micro_aes.c:242-259, :315-332) -- AddRoundKey, SubBytes, ShiftRows,
+ * MixColumns on a 16-byte state whose byte i is column i/4, row i%4.
+ *
+ * How (MI355X-first, not a translation of the byte loops):
+ *  - one 16-byte block per lane, state = 4 little-endian column words;
+ *  - SubBytes+ShiftRows+MixColumns fused into 4 table lookups per column
+ *    (FIPS-197 sec. 5.1 algebra) served from LDS;
+ *  - the tables are replicated 32x so that lane l only ever touches LDS bank
+ *    (l mod 32): ds_read_b32 services a wave64 as two 32-lane groups and the
+ *    bank of byte address a is (a/4) mod 32 (MI355X_MICROARCH.md, LDS), so a
+ *    data-dependent lookup is conflict-free by construction;
+ *  - entry x of table k lives at  x*256 + (k&1)*128 + (k>>1)*65536 + 4*(l&31)
+ *    which lets ONE v_perm_b32 build the whole LDS address from the state
+ *    word (byte select -> bits 8..15) and a per-lane constant (bits 0..7 and
+ *    16..23): 1 VALU + 1 ds_read_b32 per S-box application;
+ *  - round keys are wave-uniform kernel arguments (SGPRs).
+ *
+ * LDS budget: encrypt 4 tables x 32 KiB = 128 KiB; decrypt Td0,Td1 (64 KiB,
+ * rows 2,3 reuse them through a 16-bit rotate) + inverse S-box 32 KiB.
+ */
+#ifndef UAES_AES_HIP_H_
+#define UAES_AES_HIP_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "uaes_device.h"
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+#define UAES_WG        1024u              /* threads per workgroup (16 waves)  */
+#define UAES_LDS_ENC   (128u * 1024u)
+#define UAES_LDS_DEC   (96u * 1024u)
+
+extern __shared__ __attribute__((aligned(16))) unsigned char uaes_lds[];
+
+/* Table reads use ABSOLUTE LDS addresses: the kernels declare no static LDS,
+ * so the dynamic segment starts at LDS address 0 (checked by k_selftest).
+ * Going through the `uaes_lds` symbol instead makes hipcc emit a
+ * `v_add_u32 v, 0, v` (the unresolved symbol offset) in front of every one of
+ * the ~160 lookups per block.                                               */
+typedef __attribute__((address_space(3))) const u32 lds_cu32;
+
+__device__ __forceinline__ u32 lds_word(u32 byte_addr)
+{
+    return *(lds_cu32 *)(uintptr_t)byte_addr;
+}
+
+/* three-input boolean ops in one VALU instruction (v_bitop3_b32, gfx950) */
+__device__ __forceinline__ u32 xor3(u32 a, u32 b, u32 c)
+{
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+}
+
+__device__ __forceinline__ u32 or_xor(u32 a, u32 b, u32 c)       /* (a | b) ^ c */
+{
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x56);
+}
+
+__device__ __forceinline__ u32 rotl32(u32 v, u32 n)
+{
+    return __builtin_amdgcn_alignbit(v, v, (32u - n) & 31u);
+}
+
+__device__ __forceinline__ u32 bswap32(u32 v)
+{
+    return __builtin_amdgcn_perm(0u, v, 0x00010203u);
+}
+
+/* per-lane address constants: bits 0..7 = bank slot (+128 for odd tables),
+ * bits 16..23 = 64 KiB region of the table pair                            */
+struct LaneConst {
+    u32 t[4];
+};
+
+__device__ __forceinline__ LaneConst make_lane_const()
+{
+    LaneConst lc;
+    const u32 slot = (threadIdx.x & 31u) << 2;
+#pragma unroll
+    for (u32 k = 0; k < 4; ++k)
+        lc.t[k] = slot | ((k & 1u) << 7) | ((k >> 1) << 16);
+    return lc;
+}
+
+/* lookup table TBL with byte BYTE of w as index */
+template <int TBL, int BYTE>
+__device__ __forceinline__ u32 tlook(u32 w, const LaneConst &lc)
+{
+    /* D.b0 = lc.b0, D.b1 = w.byte[BYTE], D.b2 = lc.b2, D.b3 = 0 */
+    const u32 addr = __builtin_amdgcn_perm(w, lc.t[TBL], 0x0c020000u | ((4u + BYTE) << 8));
+    return lds_word(addr);
+}
+
+/* ---- table construction (once per workgroup) --------------------------- */
+__device__ __forceinline__ void store_replicas(u32 byte_addr, u32 v)
+{
+    uint4 vv = make_uint4(v, v, v, v);
+    uint4 *dst = (uint4 *)(uaes_lds + byte_addr);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) dst[r] = vv;
+}
+
+/* Te_k[x] = rotl(Te0[x], 8k); Te0 bytes = {2S,S,S,3S} */
+__device__ __forceinline__ void fill_enc_tables(const u32 *__restrict__ te0)
+{
+    for (u32 i = threadIdx.x; i < 1024u; i += blockDim.x) {
+        const u32 x = i & 255u, k = i >> 8;
+        store_replicas(x * 256u + (k & 1u) * 128u + (k >> 1) * 65536u, rotl32(te0[x], 8u * k));
+    }
+    __syncthreads();
+}
+
+/* region 0: Td0 | Td1 interleaved; region 1 (first 128 B of each 256-B row
+ * only... kept dense: row stride 128 B): Si4                               */
+__device__ __forceinline__ void fill_dec_tables(const u32 *__restrict__ td0,
+                                                const u32 *__restrict__ si4)
+{
+    for (u32 i = threadIdx.x; i < 768u; i += blockDim.x) {
+        const u32 x = i & 255u, k = i >> 8;
+        if (k < 2)
+            store_replicas(x * 256u + k * 128u, rotl32(td0[x], 8u * k));
+        else
+            store_replicas(65536u + x * 128u, si4[x]);
+    }
+    __syncthreads();
+}
+
+/* inverse S-box lookup: dense 128-B rows at 64 KiB; index byte BYTE of w.
+ * address = 65536 + x*128 + slot = ((x<<7) | slot) + 65536                 */
+template <int BYTE>
+__device__ __forceinline__ u32 silook(u32 w, u32 slot)
+{
+    const u32 x = (w >> (8 * BYTE)) & 0xffu;
+    return lds_word(65536u + (x << 7) + slot);
+}
+
+/* ---- encryption rounds -------------------------------------------------- */
+/* one full round (SubBytes, ShiftRows, MixColumns, AddRoundKey rk) on U
+ * independent blocks                                                       */
+template <int U>
+__device__ __forceinline__ void enc_round(u32 (&s)[U][4], const u32 *rk, const LaneConst &lc)
+{
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const u32 a = s[u][0], b = s[u][1], c = s[u][2], d = s[u][3];
+        s[u][0] = xor3(xor3(tlook<0, 0>(a, lc), tlook<1, 1>(b, lc), tlook<2, 2>(c, lc)), tlook<3, 3>(d, lc), rk[0]);
+        s[u][1] = xor3(xor3(tlook<0, 0>(b, lc), tlook<1, 1>(c, lc), tlook<2, 2>(d, lc)), tlook<3, 3>(a, lc), rk[1]);
+        s[u][2] = xor3(xor3(tlook<0, 0>(c, lc), tlook<1, 1>(d, lc), tlook<2, 2>(a, lc)), tlook<3, 3>(b, lc), rk[2]);
+        s[u][3] = xor3(xor3(tlook<0, 0>(d, lc), tlook<1, 1>(a, lc), tlook<2, 2>(b, lc)), tlook<3, 3>(c, lc), rk[3]);
+    }
+}
+
+/* last round: SubBytes, ShiftRows, AddRoundKey.  S[x] sits in byte r of
+ * Te2 (r=0), Te3 (r=1), Te0 (r=2), Te1 (r=3).                              */
+__device__ __forceinline__ u32 pick4(u32 r0, u32 r1, u32 r2, u32 r3, u32 key)
+{
+    const u32 lo = __builtin_amdgcn_perm(r1, r0, 0x0c0c0500u);   /* r0.b0, r1.b1 */
+    const u32 hi = __builtin_amdgcn_perm(r3, r2, 0x07020c0cu);   /* r2.b2, r3.b3 */
+    return or_xor(lo, hi, key);
+}
+
+template <int U>
+__device__ __forceinline__ void enc_last_round(u32 (&s)[U][4], const u32 *rk, const LaneConst &lc)
+{
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const u32 a = s[u][0], b = s[u][1], c = s[u][2], d = s[u][3];
+        s[u][0] = pick4(tlook<2, 0>(a, lc), tlook<3, 1>(b, lc), tlook<0, 2>(c, lc), tlook<1, 3>(d, lc), rk[0]);
+        s[u][1] = pick4(tlook<2, 0>(b, lc), tlook<3, 1>(c, lc), tlook<0, 2>(d, lc), tlook<1, 3>(a, lc), rk[1]);
+        s[u][2] = pick4(tlook<2, 0>(c, lc), tlook<3, 1>(d, lc), tlook<0, 2>(a, lc), tlook<1, 3>(b, lc), rk[2]);
+        s[u][3] = pick4(tlook<2, 0>(d, lc), tlook<3, 1>(a, lc), tlook<0, 2>(b, lc), tlook<1, 3>(c, lc), rk[3]);
+    }
+}
+
+/* rounds FIRST..NR on states that already hold the input of round FIRST
+ * (i.e. after AddRoundKey(FIRST-1)); rk = all round keys                   */
+template <int NR, int U, int FIRST>
+__device__ __forceinline__ void enc_rounds_from(u32 (&s)[U][4], const uaesk_rk &rk, const LaneConst &lc)
+{
+#pragma unroll
+    for (int r = FIRST; r < NR; ++r) enc_round<U>(s, &rk.w[4 * r], lc);
+    enc_last_round<U>(s, &rk.w[4 * NR], lc);
+}
+
+/* full cipher on U blocks (state = plaintext words on entry) */
+template <int NR, int U>
+__device__ __forceinline__ void enc_blocks(u32 (&s)[U][4], const uaesk_rk &rk, const LaneConst &lc)
+{
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        s[u][0] ^= rk.w[0]; s[u][1] ^= rk.w[1]; s[u][2] ^= rk.w[2]; s[u][3] ^= rk.w[3];
+    }
+    enc_rounds_from<NR, U, 1>(s, rk, lc);
+}
+
+/* ---- decryption rounds (equivalent inverse cipher, FIPS-197 sec. 5.3.5) - */
+/* Td2 = rotl16(Td0), Td3 = rotl16(Td1): one rotate per column              */
+template <int U>
+__device__ __forceinline__ void dec_round(u32 (&s)[U][4], const u32 *dk, const LaneConst &lc)
+{
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const u32 a = s[u][0], b = s[u][1], c = s[u][2], d = s[u][3];
+        /* column j takes row r from column (j - r) mod 4 */
+        s[u][0] = xor3(tlook<0, 0>(a, lc), tlook<1, 1>(d, lc), dk[0]) ^ rotl32(tlook<0, 2>(c, lc) ^ tlook<1, 3>(b, lc), 16);
+        s[u][1] = xor3(tlook<0, 0>(b, lc), tlook<1, 1>(a, lc), dk[1]) ^ rotl32(tlook<0, 2>(d, lc) ^ tlook<1, 3>(c, lc), 16);
+        s[u][2] = xor3(tlook<0, 0>(c, lc), tlook<1, 1>(b, lc), dk[2]) ^ rotl32(tlook<0, 2>(a, lc) ^ tlook<1, 3>(d, lc), 16);
+        s[u][3] = xor3(tlook<0, 0>(d, lc), tlook<1, 1>(c, lc), dk[3]) ^ rotl32(tlook<0, 2>(b, lc) ^ tlook<1, 3>(a, lc), 16);
+    }
+}
+
+template <int U>
+__device__ __forceinline__ void dec_last_round(u32 (&s)[U][4], const u32 *dk, u32 slot)
+{
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const u32 a = s[u][0], b = s[u][1], c = s[u][2], d = s[u][3];
+        s[u][0] = pick4(silook<0>(a, slot), silook<1>(d, slot), silook<2>(c, slot), silook<3>(b, slot), dk[0]);
+        s[u][1] = pick4(silook<0>(b, slot), silook<1>(a, slot), silook<2>(d, slot), silook<3>(c, slot), dk[1]);
+        s[u][2] = pick4(silook<0>(c, slot), silook<1>(b, slot), silook<2>(a, slot), silook<3>(d, slot), dk[2]);
+        s[u][3] = pick4(silook<0>(d, slot), silook<1>(c, slot), silook<2>(b, slot), silook<3>(a, slot), dk[3]);
+    }
+}
+
+template <int NR, int U>
+__device__ __forceinline__ void dec_blocks(u32 (&s)[U][4], const uaesk_rk &dk, const LaneConst &lc)
+{
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        s[u][0] ^= dk.w[0]; s[u][1] ^= dk.w[1]; s[u][2] ^= dk.w[2]; s[u][3] ^= dk.w[3];
+    }
+#pragma unroll
+    for (int r = 1; r < NR; ++r) dec_round<U>(s, &dk.w[4 * r], lc);
+    dec_last_round<U>(s, &dk.w[4 * NR], lc.t[0]);
+}
+
+#endif

@@ -1,0 +1,77 @@
+/*
+ * uaes_compat.c -- the reference's compile-time-key-size API (micro_aes.h:173-
+ * 181, :239-249, :256-266, :294-308) on top of the run-time engine.  Built
+ * once per key size (-DAES___=128|192|256) into libmicro_aes_hip_<bits>.so.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "../../include/micro_aes.h"
+#include "../../include/uaes_hip.h"
+
+#define KB (AES_KEYLENGTH * 8)
+
+/* void functions cannot report failure: refuse loudly rather than hand back
+ * a buffer that was never encrypted                                         */
+static void must(const char *fn, int rc)
+{
+    if (rc == 0) return;
+    fprintf(stderr, "uaes-hip: %s failed (%d): %s\n", fn, rc, uaes_last_error());
+    abort();
+}
+
+static char soft(const char *fn, int rc, char engine_code)
+{
+    if (rc >= 0) return (char)rc;              /* 0 or one of the reference's codes */
+    fprintf(stderr, "uaes-hip: %s failed (%d): %s\n", fn, rc, uaes_last_error());
+    return engine_code;
+}
+
+void AES_ECB_encrypt(const uint8_t *key, const void *pntxt, const size_t ptextLen, void *crtxt)
+{
+    must("AES_ECB_encrypt", uaes_ecb_encrypt(KB, key, pntxt, ptextLen, crtxt));
+}
+
+char AES_ECB_decrypt(const uint8_t *key, const void *crtxt, const size_t crtxtLen, void *pntxt)
+{
+    return soft("AES_ECB_decrypt", uaes_ecb_decrypt(KB, key, crtxt, crtxtLen, pntxt), M_DECRYPTION_ERROR);
+}
+
+void AES_CTR_encrypt(const uint8_t *key, const uint8_t *iv,
+                     const void *pntxt, const size_t ptextLen, void *crtxt)
+{
+    must("AES_CTR_encrypt", uaes_ctr_xcrypt(KB, key, iv, pntxt, ptextLen, crtxt));
+}
+
+void AES_CTR_decrypt(const uint8_t *key, const uint8_t *iv,
+                     const void *crtxt, const size_t crtxtLen, void *pntxt)
+{
+    must("AES_CTR_decrypt", uaes_ctr_xcrypt(KB, key, iv, crtxt, crtxtLen, pntxt));
+}
+
+char AES_XTS_encrypt(const uint8_t *keys, const uint8_t *tweak,
+                     const void *pntxt, const size_t ptextLen, void *crtxt)
+{
+    return soft("AES_XTS_encrypt", uaes_xts_encrypt(KB, keys, tweak, pntxt, ptextLen, crtxt), M_ENCRYPTION_ERROR);
+}
+
+char AES_XTS_decrypt(const uint8_t *keys, const uint8_t *tweak,
+                     const void *crtxt, const size_t crtxtLen, void *pntxt)
+{
+    return soft("AES_XTS_decrypt", uaes_xts_decrypt(KB, keys, tweak, crtxt, crtxtLen, pntxt), M_DECRYPTION_ERROR);
+}
+
+void AES_GCM_encrypt(const uint8_t *key, const uint8_t *nonce,
+                     const void *aData, const size_t aDataLen,
+                     const void *pntxt, const size_t ptextLen, void *crtxt)
+{
+    must("AES_GCM_encrypt", uaes_gcm_encrypt(KB, key, nonce, aData, aDataLen, pntxt, ptextLen, crtxt));
+}
+
+char AES_GCM_decrypt(const uint8_t *key, const uint8_t *nonce,
+                     const void *aData, const size_t aDataLen,
+                     const void *crtxt, const size_t crtxtLen, void *pntxt)
+{
+    return soft("AES_GCM_decrypt", uaes_gcm_decrypt(KB, key, nonce, aData, aDataLen, crtxt, crtxtLen, pntxt),
+                M_DECRYPTION_ERROR);
+}

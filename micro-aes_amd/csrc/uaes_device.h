@@ -1,0 +1,87 @@
+/*
+ * uaes_device.h -- interface between the C host layer (uaes_engine.c) and the
+ * HIP kernels (uaes_kernels.hip).  Plain C types only; every entry point is a
+ * thin launcher that enqueues gfx950 kernels on the given stream and returns
+ * the hipError_t value (0 = success).  Nothing here touches host data.
+ */
+#ifndef UAES_DEVICE_H_
+#define UAES_DEVICE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Expanded key as little-endian words of the FIPS-197 byte stream.
+ * ek = encryption round keys; dk = equivalent-inverse-cipher round keys
+ * (dk[0] = ek[nr], dk[i] = InvMixColumns(ek[nr-i]), dk[nr] = ek[0]).      */
+typedef struct {
+    uint32_t w[60];
+} uaesk_rk;
+
+/* Read-only device tables uploaded once per context by the host layer. */
+typedef struct {
+    const uint32_t *te0;   /* 256 words: bytes {2S,S,S,3S}[x]              */
+    const uint32_t *td0;   /* 256 words: bytes {14Si,9Si,13Si,11Si}[x]     */
+    const uint32_t *si4;   /* 256 words: Si[x] replicated in all 4 bytes   */
+} uaesk_tables;
+
+/* 56-bit big-endian counter description (reference: incBlock with index 15
+ * carries through bytes 15..9 only, micro_aes.c:421-427).                 */
+typedef struct {
+    uint32_t w0, w1;       /* counter-block bytes 0..7 as LE words         */
+    uint32_t b8;           /* counter-block byte 8 (never changes)         */
+    uint64_t v0;           /* bytes 9..15 as a 56-bit big-endian integer   */
+} uaesk_ctr;
+
+int uaesk_device_info(int *cu_count, int *lds_bytes);
+
+/* ECB: nfull whole blocks, plus (enc only) one zero-padded tail block built
+ * from the `rem` trailing bytes (reference N1, micro_aes.c:648-651).       */
+int uaesk_ecb(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *keys,
+              int decrypt, const void *in, void *out, size_t nfull, unsigned rem);
+
+/* CTR keystream xor over len bytes (whole blocks + byte-granular tail).
+ * If gate != NULL the kernel does nothing unless *gate == 0 (used by GCM
+ * decrypt: authenticate first, micro_aes.c:1204-1208).                     */
+int uaesk_ctr_xcrypt(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek,
+                     const uaesk_ctr *ctr, const void *in, void *out, size_t len,
+                     const int *gate);
+
+/* XTS over nsectors data units of sector_bytes each (>= 16).  Unit i has the
+ * tweak block LE128(first_sector+i), or, if tweak16 != NULL (single unit),
+ * the raw 16 bytes at tweak16 (a HOST pointer, copied into the launch).
+ * scratch must hold uaesk_xts_scratch_bytes().                            */
+size_t uaesk_xts_scratch_bytes(size_t sector_bytes, size_t nsectors);
+int uaesk_xts(void *stream, const uaesk_tables *tb, int nr,
+              const uaesk_rk *k1, const uaesk_rk *k2_enc, int decrypt,
+              const uint8_t *tweak16, uint64_t first_sector,
+              size_t sector_bytes, size_t nsectors,
+              const void *in, void *out, void *scratch);
+
+/* GCM.  All pointers are device pointers except nonce12 (host).
+ * scratch must hold uaesk_gcm_scratch_bytes().  encrypt: CTR then GHASH, tag
+ * written at out+len.  decrypt: GHASH over in[0..len), compare with the tag
+ * at in+len, *status = 0 / 0x1A, CTR gated on *status.                     */
+size_t uaesk_gcm_scratch_bytes(void);
+int uaesk_gcm(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek,
+              int decrypt, const uint8_t *nonce12,
+              const void *aad, size_t aad_len,
+              const void *in, size_t len, void *out,
+              void *scratch, int *status);
+
+/* GHASH only: gh = GHASH_H(aad, ct) with H given (device), for tests.      */
+int uaesk_ghash(void *stream, const uint8_t *H_host,
+                const void *aad, size_t aad_len, const void *ct, size_t ct_len,
+                void *scratch, void *gh_out16);
+
+/* Device self-test of the primitives; writes a bitmask of failures.        */
+int uaesk_selftest(void *stream, const uaesk_tables *tb, const uaesk_rk *ek128,
+                   const uaesk_rk *dk128, unsigned *d_result);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,678 @@
+/*
+ * uaes_engine.c -- host layer of the MI355X AES engine (plain C).
+ *
+ * Mirrors the mode drivers of the reference (AES_ECB_*, AES_CTR_*, AES_XTS_*,
+ * AES_GCM_*; micro_aes.c:636-680, :962-990, :1066-1093, :1164-1212): argument
+ * checking, the reference's error behaviour, the key schedule
+ * (KeyExpansion, micro_aes.c:144-178 -- host side, <= 240 bytes of output),
+ * and buffer plumbing.  ALL block-cipher and GHASH work happens in the HIP
+ * kernels behind uaes_device.h; there is no CPU data path here to fall back
+ * to, and a missing/failed HIP device is reported, never papered over.
+ */
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+
+#include <pthread.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/uaes_hip.h"
+#include "uaes_device.h"
+
+#define UAES_VERSION "uaes-hip 0.1 gfx950"
+#define MAX_DEVICES  16
+
+/* ------------------------------------------------------------------------ */
+/* errors                                                                     */
+/* ------------------------------------------------------------------------ */
+static __thread char tls_err[256];
+
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(tls_err, sizeof tls_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIPCHK(call)                                                               \
+    do {                                                                           \
+        hipError_t e_ = (call);                                                    \
+        if (e_ != hipSuccess)                                                      \
+            return fail(UAES_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+#define KCHK(call)                                                                        \
+    do {                                                                                  \
+        int e_ = (call);                                                                  \
+        if (e_ != 0)                                                                      \
+            return fail(UAES_E_HIP, "%s failed: %s", #call, hipGetErrorString((hipError_t)e_)); \
+    } while (0)
+
+const char *uaes_last_error(void) { return tls_err; }
+const char *uaes_version(void) { return UAES_VERSION; }
+
+/* ------------------------------------------------------------------------ */
+/* S-box and lookup-table generation (FIPS-197 sec. 5.1.1 / 5.3.2).            */
+/* Built once from the field arithmetic with log/antilog tables over the      */
+/* generator 0x03, then uploaded to every device context.                     */
+/* ------------------------------------------------------------------------ */
+static uint8_t  h_sbox[256], h_isbox[256];
+static uint32_t h_te0[256], h_td0[256], h_si4[256];
+static pthread_once_t tables_once = PTHREAD_ONCE_INIT;
+
+static uint8_t xtime(uint8_t a) { return (uint8_t)((a << 1) ^ ((a >> 7) * 0x1b)); }
+
+static void build_host_tables(void)
+{
+    uint8_t alog[256], logt[256];
+    uint8_t a = 1;
+    int i;
+    for (i = 0; i < 255; ++i) {                 /* powers of the generator 3   */
+        alog[i] = a;
+        logt[a] = (uint8_t)i;
+        a = (uint8_t)(a ^ xtime(a));
+    }
+    alog[255] = alog[0];
+    for (i = 0; i < 256; ++i) {
+        uint8_t inv = i ? alog[(255 - logt[i]) % 255] : 0, s = inv, r = inv;
+        int k;
+        for (k = 0; k < 4; ++k) {               /* affine map: xor of 4 rotations + 0x63 */
+            r = (uint8_t)((r << 1) | (r >> 7));
+            s ^= r;
+        }
+        s ^= 0x63;
+        h_sbox[i] = s;
+        h_isbox[s] = (uint8_t)i;
+    }
+    for (i = 0; i < 256; ++i) {
+        uint8_t s = h_sbox[i], s2 = xtime(s), s3 = (uint8_t)(s2 ^ s);
+        uint8_t v = h_isbox[i], v2 = xtime(v), v4 = xtime(v2), v8 = xtime(v4);
+        uint8_t v9 = (uint8_t)(v8 ^ v), vb = (uint8_t)(v8 ^ v2 ^ v);
+        uint8_t vd = (uint8_t)(v8 ^ v4 ^ v), ve = (uint8_t)(v8 ^ v4 ^ v2);
+        h_te0[i] = (uint32_t)s2 | ((uint32_t)s << 8) | ((uint32_t)s << 16) | ((uint32_t)s3 << 24);
+        h_td0[i] = (uint32_t)ve | ((uint32_t)v9 << 8) | ((uint32_t)vd << 16) | ((uint32_t)vb << 24);
+        h_si4[i] = (uint32_t)v * 0x01010101u;
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* key schedule: KeyExpansion (micro_aes.c:144-178) on little-endian words,   */
+/* plus the equivalent-inverse-cipher keys (FIPS-197 sec. 5.3.5) for the      */
+/* table-driven decrypt kernels.                                              */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+    int      nr;
+    uaesk_rk ek, dk;
+} keysched;
+
+static uint32_t subword(uint32_t w)
+{
+    return (uint32_t)h_sbox[w & 0xff] | ((uint32_t)h_sbox[(w >> 8) & 0xff] << 8) |
+           ((uint32_t)h_sbox[(w >> 16) & 0xff] << 16) | ((uint32_t)h_sbox[w >> 24] << 24);
+}
+
+static uint32_t inv_mix_word(uint32_t w)
+{
+    /* InvMixColumns of one column = xor of Td0-rotations of S(byte): undo the
+     * S-box that Td0 applies by indexing with sbox[]                          */
+    uint32_t r = 0;
+    int b;
+    for (b = 0; b < 4; ++b) {
+        uint32_t t = h_td0[h_sbox[(w >> (8 * b)) & 0xff]];
+        r ^= (t << (8 * b)) | (b ? t >> (32 - 8 * b) : 0);
+    }
+    return r;
+}
+
+static int expand_key(keysched *ks, const uint8_t *key, int keybits)
+{
+    int nk, total, i;
+    uint8_t rcon = 1;
+    if (keybits != 128 && keybits != 192 && keybits != 256)
+        return fail(UAES_E_ARG, "keybits must be 128, 192 or 256 (got %d)", keybits);
+    if (!key) return fail(UAES_E_ARG, "NULL key");
+    pthread_once(&tables_once, build_host_tables);
+    nk = keybits / 32;
+    ks->nr = nk + 6;
+    total = 4 * (ks->nr + 1);
+    memset(&ks->ek, 0, sizeof ks->ek);
+    memset(&ks->dk, 0, sizeof ks->dk);
+    memcpy(ks->ek.w, key, (size_t)(4 * nk));     /* LE words of the byte stream */
+    for (i = nk; i < total; ++i) {
+        uint32_t t = ks->ek.w[i - 1];
+        if (i % nk == 0) {
+            t = subword((t >> 8) | (t << 24)) ^ rcon;      /* RotWord on LE words */
+            rcon = xtime(rcon);
+        } else if (nk == 8 && i % nk == 4) {
+            t = subword(t);
+        }
+        ks->ek.w[i] = ks->ek.w[i - nk] ^ t;
+    }
+    for (i = 0; i < 4; ++i) {
+        ks->dk.w[i] = ks->ek.w[4 * ks->nr + i];
+        ks->dk.w[4 * ks->nr + i] = ks->ek.w[i];
+    }
+    for (i = 1; i < ks->nr; ++i) {
+        int c;
+        for (c = 0; c < 4; ++c)
+            ks->dk.w[4 * i + c] = inv_mix_word(ks->ek.w[4 * (ks->nr - i) + c]);
+    }
+    return 0;
+}
+
+/* diagnostic export: lets the CPU test-suite check the schedule without a GPU */
+int uaes_expand_key(int keybits, const uint8_t *key, uint32_t enc_words[60], uint32_t dec_words[60])
+{
+    keysched ks;
+    int rc = expand_key(&ks, key, keybits);
+    if (rc) return rc;
+    if (enc_words) memcpy(enc_words, ks.ek.w, sizeof ks.ek.w);
+    if (dec_words) memcpy(dec_words, ks.dk.w, sizeof ks.dk.w);
+    return ks.nr;
+}
+
+/* ------------------------------------------------------------------------ */
+/* per-device context                                                         */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+    int             ready;
+    uaesk_tables    tb;
+    void           *d_tables;
+    void           *stage[2];
+    size_t          stage_cap[2];
+    void           *scratch;
+    size_t          scratch_cap;
+    void           *aad_stage;
+    size_t          aad_cap;
+    int            *d_status;
+    pthread_mutex_t mu;
+} context;
+
+static context g_ctx[MAX_DEVICES];
+static pthread_mutex_t g_init_mu = PTHREAD_MUTEX_INITIALIZER;
+
+static int get_context(context **out)
+{
+    int dev = 0, n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(UAES_E_HIP, "no usable HIP device (%s); this library has no CPU path",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    HIPCHK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= MAX_DEVICES) return fail(UAES_E_HIP, "device index %d out of range", dev);
+    context *c = &g_ctx[dev];
+    if (!c->ready) {
+        pthread_mutex_lock(&g_init_mu);
+        if (!c->ready) {
+            hipError_t err;
+            pthread_once(&tables_once, build_host_tables);
+            err = hipMalloc(&c->d_tables, 3 * 1024 + 64);
+            if (err == hipSuccess) err = hipMemcpy(c->d_tables, h_te0, 1024, hipMemcpyHostToDevice);
+            if (err == hipSuccess) err = hipMemcpy((char *)c->d_tables + 1024, h_td0, 1024, hipMemcpyHostToDevice);
+            if (err == hipSuccess) err = hipMemcpy((char *)c->d_tables + 2048, h_si4, 1024, hipMemcpyHostToDevice);
+            if (err != hipSuccess) {
+                pthread_mutex_unlock(&g_init_mu);
+                return fail(UAES_E_HIP, "context setup failed: %s", hipGetErrorString(err));
+            }
+            c->tb.te0 = (const uint32_t *)c->d_tables;
+            c->tb.td0 = (const uint32_t *)((char *)c->d_tables + 1024);
+            c->tb.si4 = (const uint32_t *)((char *)c->d_tables + 2048);
+            c->d_status = (int *)((char *)c->d_tables + 3072);
+            pthread_mutex_init(&c->mu, NULL);
+            uaesk_device_info(NULL, NULL);
+            c->ready = 1;
+        }
+        pthread_mutex_unlock(&g_init_mu);
+    }
+    *out = c;
+    return 0;
+}
+
+static int grow(void **buf, size_t *cap, size_t need)
+{
+    if (need <= *cap) return 0;
+    if (*buf) {
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipFree(*buf));
+        *buf = NULL;
+        *cap = 0;
+    }
+    need = (need + (1u << 20)) & ~(((size_t)1 << 20) - 1);
+    HIPCHK(hipMalloc(buf, need));
+    *cap = need;
+    return 0;
+}
+
+static int is_device_ptr(const void *p)
+{
+    hipPointerAttribute_t a;
+    if (!p) return 0;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();                 /* plain host memory: clear the sticky error */
+        return 0;
+    }
+    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+/* data buffers the kernels can use directly: device memory, 16-byte aligned */
+static int direct_ok(const void *p)
+{
+    return is_device_ptr(p) && (((uintptr_t)p) & 15u) == 0;
+}
+
+/* Resolve (in, out) to device pointers, staging whatever is host memory or
+ * misaligned.  in_len bytes are copied in; the caller copies out_len back
+ * with finish_io().                                                          */
+typedef struct {
+    const void *din;
+    void       *dout;
+    void       *user_out;
+    size_t      out_len;
+    int         copy_back;
+} io_plan;
+
+static int plan_io(context *c, const void *in, size_t in_len, void *out, size_t out_cap, io_plan *io)
+{
+    const int in_ok = direct_ok(in) || in_len == 0, out_ok = direct_ok(out) || out_cap == 0;
+    io->user_out = out;
+    io->copy_back = !out_ok;
+    io->din = in;
+    io->dout = out;
+    if (!in_ok) {
+        const size_t need = (in_len > out_cap ? in_len : out_cap) + 64;
+        if (grow(&c->stage[0], &c->stage_cap[0], need)) return UAES_E_HIP;
+        HIPCHK(hipMemcpy(c->stage[0], in, in_len, hipMemcpyDefault));
+        io->din = c->stage[0];
+        if (!out_ok) io->dout = c->stage[0];      /* run in place in the staging buffer */
+    } else if (!out_ok) {
+        if (grow(&c->stage[1], &c->stage_cap[1], out_cap + 64)) return UAES_E_HIP;
+        io->dout = c->stage[1];
+    }
+    return 0;
+}
+
+static int finish_io(io_plan *io, size_t out_len)
+{
+    HIPCHK(hipStreamSynchronize(NULL));
+    if (io->copy_back && out_len)
+        HIPCHK(hipMemcpy(io->user_out, io->dout, out_len, hipMemcpyDefault));
+    return 0;
+}
+
+#define LOCKED_BEGIN(c)  pthread_mutex_lock(&(c)->mu)
+#define LOCKED_END(c, rc) do { pthread_mutex_unlock(&(c)->mu); return (rc); } while (0)
+
+/* ------------------------------------------------------------------------ */
+/* housekeeping API                                                           */
+/* ------------------------------------------------------------------------ */
+int uaes_init(void)
+{
+    context *c;
+    return get_context(&c);
+}
+
+int uaes_selftest(void)
+{
+    context *c;
+    keysched ks;
+    uint8_t key[16];
+    unsigned result = 0;
+    int i, rc;
+    if ((rc = get_context(&c)) != 0) return rc;
+    for (i = 0; i < 16; ++i) key[i] = (uint8_t)i;
+    if ((rc = expand_key(&ks, key, 128)) != 0) return rc;
+    LOCKED_BEGIN(c);
+    rc = 0;
+    do {
+        unsigned *d = (unsigned *)c->d_status;
+        if (hipMemset(d, 0, 4) != hipSuccess) { rc = fail(UAES_E_HIP, "hipMemset failed"); break; }
+        int k = uaesk_selftest(NULL, &c->tb, &ks.ek, &ks.dk, d);
+        if (k) { rc = fail(UAES_E_HIP, "selftest launch: %s", hipGetErrorString((hipError_t)k)); break; }
+        hipError_t e = hipMemcpy(&result, d, 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { rc = fail(UAES_E_HIP, "selftest run: %s", hipGetErrorString(e)); break; }
+        rc = (int)result;
+    } while (0);
+    LOCKED_END(c, rc);
+}
+
+/* ------------------------------------------------------------------------ */
+/* ECB                                                                        */
+/* ------------------------------------------------------------------------ */
+static int ecb_common(int keybits, const uint8_t *key, int decrypt,
+                      const void *in, size_t len, void *out)
+{
+    context *c;
+    keysched ks;
+    io_plan io;
+    int rc;
+    const size_t rem = len % 16, nfull = len / 16;
+    const size_t out_len = decrypt ? len : (len + 15) / 16 * 16;
+    if ((rc = expand_key(&ks, key, keybits)) != 0) return rc;
+    if (len == 0) return 0;
+    if (!in || !out) return fail(UAES_E_ARG, "NULL data pointer");
+    if ((rc = get_context(&c)) != 0) return rc;
+    LOCKED_BEGIN(c);
+    do {
+        if ((rc = plan_io(c, in, len, out, out_len, &io)) != 0) break;
+        if (decrypt && rem && io.dout != io.din) {
+            /* ragged decrypt: the reference copies the tail through (:664) */
+            if (hipMemcpyAsync((char *)io.dout + nfull * 16, (const char *)io.din + nfull * 16, rem,
+                               hipMemcpyDeviceToDevice, NULL) != hipSuccess) {
+                rc = fail(UAES_E_HIP, "tail copy failed");
+                break;
+            }
+        }
+        int k = uaesk_ecb(NULL, &c->tb, ks.nr, decrypt ? &ks.dk : &ks.ek, decrypt,
+                          io.din, io.dout, nfull, decrypt ? 0 : (unsigned)rem);
+        if (k) { rc = fail(UAES_E_HIP, "ecb launch: %s", hipGetErrorString((hipError_t)k)); break; }
+        if ((rc = finish_io(&io, out_len)) != 0) break;
+        rc = (decrypt && rem) ? UAES_E_DECRYPTION : 0;           /* :679 */
+    } while (0);
+    LOCKED_END(c, rc);
+}
+
+int uaes_ecb_encrypt(int keybits, const uint8_t *key, const void *pntxt, size_t ptextLen, void *crtxt)
+{
+    return ecb_common(keybits, key, 0, pntxt, ptextLen, crtxt);
+}
+
+int uaes_ecb_decrypt(int keybits, const uint8_t *key, const void *crtxt, size_t crtxtLen, void *pntxt)
+{
+    return ecb_common(keybits, key, 1, crtxt, crtxtLen, pntxt);
+}
+
+int uaes_ecb_dev(int keybits, const uint8_t *key, int decrypt,
+                 const void *d_in, size_t len, void *d_out, void *stream)
+{
+    context *c;
+    keysched ks;
+    int rc;
+    if ((rc = expand_key(&ks, key, keybits)) != 0) return rc;
+    if ((rc = get_context(&c)) != 0) return rc;
+    if (decrypt && len % 16) return fail(UAES_E_ARG, "uaes_ecb_dev: ragged decrypt length");
+    KCHK(uaesk_ecb(stream, &c->tb, ks.nr, decrypt ? &ks.dk : &ks.ek, decrypt, d_in, d_out,
+                   len / 16, (unsigned)(len % 16)));
+    return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* CTR                                                                        */
+/* ------------------------------------------------------------------------ */
+static void make_ctr(uaesk_ctr *c, const uint8_t ctr0[16], uint64_t block_offset)
+{
+    uint64_t v = 0;
+    int i;
+    memcpy(&c->w0, ctr0, 4);
+    memcpy(&c->w1, ctr0 + 4, 4);
+    c->b8 = ctr0[8];
+    for (i = 9; i < 16; ++i) v = (v << 8) | ctr0[i];
+    c->v0 = (v + block_offset) & 0x00FFFFFFFFFFFFFFull;         /* 56-bit, N2 */
+}
+
+int uaes_ctr_xcrypt_at_dev(int keybits, const uint8_t *key, const uint8_t ctr0[16],
+                           uint64_t block_offset,
+                           const void *d_in, size_t len, void *d_out, void *stream)
+{
+    context *c;
+    keysched ks;
+    uaesk_ctr ctr;
+    int rc;
+    if ((rc = expand_key(&ks, key, keybits)) != 0) return rc;
+    if (!ctr0) return fail(UAES_E_ARG, "NULL counter block");
+    if ((rc = get_context(&c)) != 0) return rc;
+    make_ctr(&ctr, ctr0, block_offset);
+    KCHK(uaesk_ctr_xcrypt(stream, &c->tb, ks.nr, &ks.ek, &ctr, d_in, d_out, len, NULL));
+    return 0;
+}
+
+int uaes_ctr_xcrypt_at(int keybits, const uint8_t *key, const uint8_t ctr0[16],
+                       uint64_t block_offset, const void *in, size_t len, void *out)
+{
+    context *c;
+    keysched ks;
+    uaesk_ctr ctr;
+    io_plan io;
+    int rc;
+    if ((rc = expand_key(&ks, key, keybits)) != 0) return rc;
+    if (!ctr0) return fail(UAES_E_ARG, "NULL counter block");
+    if (len == 0) return 0;
+    if (!in || !out) return fail(UAES_E_ARG, "NULL data pointer");
+    if ((rc = get_context(&c)) != 0) return rc;
+    make_ctr(&ctr, ctr0, block_offset);
+    LOCKED_BEGIN(c);
+    do {
+        if ((rc = plan_io(c, in, len, out, len, &io)) != 0) break;
+        int k = uaesk_ctr_xcrypt(NULL, &c->tb, ks.nr, &ks.ek, &ctr, io.din, io.dout, len, NULL);
+        if (k) { rc = fail(UAES_E_HIP, "ctr launch: %s", hipGetErrorString((hipError_t)k)); break; }
+        rc = finish_io(&io, len);
+    } while (0);
+    LOCKED_END(c, rc);
+}
+
+int uaes_ctr_xcrypt(int keybits, const uint8_t *key, const uint8_t *iv,
+                    const void *in, size_t len, void *out)
+{
+    uint8_t ctr0[16] = { 0 };
+    if (!iv) return fail(UAES_E_ARG, "NULL iv");
+    memcpy(ctr0, iv, 12);                        /* CTR_IV_LENGTH, micro_aes.c:968-971 */
+    ctr0[15] ^= 1;                               /* CTR_START_VALUE                    */
+    return uaes_ctr_xcrypt_at(keybits, key, ctr0, 0, in, len, out);
+}
+
+/* ------------------------------------------------------------------------ */
+/* XTS                                                                        */
+/* ------------------------------------------------------------------------ */
+static int xts_keys(keysched *k1, keysched *k2, const uint8_t *keys, int keybits)
+{
+    int rc;
+    if (!keys) return fail(UAES_E_ARG, "NULL key pair");
+    if ((rc = expand_key(k1, keys, keybits)) != 0) return rc;
+    return expand_key(k2, keys + keybits / 8, keybits);          /* :1026-1029 */
+}
+
+static int xts_run(context *c, void *stream, keysched *k1, keysched *k2, int encrypt,
+                   const uint8_t *tweak16, uint64_t first_sector,
+                   size_t sector_bytes, size_t nsectors, const void *din, void *dout)
+{
+    const size_t need = uaesk_xts_scratch_bytes(sector_bytes, nsectors);
+    if (grow(&c->scratch, &c->scratch_cap, need)) return UAES_E_HIP;
+    KCHK(uaesk_xts(stream, &c->tb, k1->nr, encrypt ? &k1->ek : &k1->dk, &k2->ek, !encrypt,
+                   tweak16, first_sector, sector_bytes, nsectors, din, dout, c->scratch));
+    return 0;
+}
+
+static int xts_common(int keybits, const uint8_t *keys, const uint8_t *tweak, int raw_tweak,
+                      uint64_t first_sector, size_t sector_bytes, size_t nsectors,
+                      const void *in, void *out, int encrypt)
+{
+    context *c;
+    keysched k1, k2;
+    io_plan io;
+    uint8_t zero[16] = { 0 };
+    int rc;
+    const size_t total = sector_bytes * nsectors;
+    if ((rc = xts_keys(&k1, &k2, keys, keybits)) != 0) return rc;
+    if (sector_bytes < 16) return UAES_E_DATALENGTH;             /* :1069, untouched */
+    if (nsectors == 0) return 0;
+    if (!in || !out) return fail(UAES_E_ARG, "NULL data pointer");
+    if ((rc = get_context(&c)) != 0) return rc;
+    LOCKED_BEGIN(c);
+    do {
+        if ((rc = plan_io(c, in, total, out, total, &io)) != 0) break;
+        rc = xts_run(c, NULL, &k1, &k2, encrypt, raw_tweak ? (tweak ? tweak : zero) : NULL,
+                     first_sector, sector_bytes, nsectors, io.din, io.dout);
+        if (rc) break;
+        rc = finish_io(&io, total);
+    } while (0);
+    LOCKED_END(c, rc);
+}
+
+int uaes_xts_encrypt(int keybits, const uint8_t *keys, const uint8_t *tweak,
+                     const void *pntxt, size_t ptextLen, void *crtxt)
+{
+    return xts_common(keybits, keys, tweak, 1, 0, ptextLen, 1, pntxt, crtxt, 1);
+}
+
+int uaes_xts_decrypt(int keybits, const uint8_t *keys, const uint8_t *tweak,
+                     const void *crtxt, size_t crtxtLen, void *pntxt)
+{
+    return xts_common(keybits, keys, tweak, 1, 0, crtxtLen, 1, crtxt, pntxt, 0);
+}
+
+int uaes_xts_sectors(int keybits, const uint8_t *keys, uint64_t first_sector,
+                     size_t sector_bytes, size_t nsectors, const void *in, void *out, int encrypt)
+{
+    return xts_common(keybits, keys, NULL, 0, first_sector, sector_bytes, nsectors, in, out, encrypt);
+}
+
+int uaes_xts_sectors_dev(int keybits, const uint8_t *keys, uint64_t first_sector,
+                         size_t sector_bytes, size_t nsectors,
+                         const void *d_in, void *d_out, int encrypt, void *stream)
+{
+    context *c;
+    keysched k1, k2;
+    int rc;
+    if ((rc = xts_keys(&k1, &k2, keys, keybits)) != 0) return rc;
+    if (sector_bytes < 16) return UAES_E_DATALENGTH;
+    if ((rc = get_context(&c)) != 0) return rc;
+    return xts_run(c, stream, &k1, &k2, encrypt, NULL, first_sector, sector_bytes, nsectors, d_in, d_out);
+}
+
+/* ------------------------------------------------------------------------ */
+/* GCM                                                                        */
+/* ------------------------------------------------------------------------ */
+static int gcm_scratch(context *c)
+{
+    return grow(&c->scratch, &c->scratch_cap, uaesk_gcm_scratch_bytes());
+}
+
+/* AAD may be host memory: stage it (it is read byte-wise, no alignment need) */
+static int stage_aad(context *c, const void *aad, size_t aad_len, const void **d_aad)
+{
+    *d_aad = aad;
+    if (aad_len == 0) { *d_aad = NULL; return 0; }
+    if (!aad) return fail(UAES_E_ARG, "NULL aData with aDataLen != 0");
+    if (is_device_ptr(aad)) return 0;
+    if (grow(&c->aad_stage, &c->aad_cap, aad_len + 16)) return UAES_E_HIP;
+    HIPCHK(hipMemcpy(c->aad_stage, aad, aad_len, hipMemcpyHostToDevice));
+    *d_aad = c->aad_stage;
+    return 0;
+}
+
+int uaes_gcm_encrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
+                     const void *aData, size_t aDataLen,
+                     const void *pntxt, size_t ptextLen, void *crtxt)
+{
+    context *c;
+    keysched ks;
+    io_plan io;
+    const void *d_aad;
+    int rc;
+    if ((rc = expand_key(&ks, key, keybits)) != 0) return rc;
+    if (!nonce || !crtxt || (ptextLen && !pntxt)) return fail(UAES_E_ARG, "NULL pointer");
+    if ((rc = get_context(&c)) != 0) return rc;
+    LOCKED_BEGIN(c);
+    do {
+        if ((rc = gcm_scratch(c)) != 0) break;
+        if ((rc = stage_aad(c, aData, aDataLen, &d_aad)) != 0) break;
+        if ((rc = plan_io(c, pntxt, ptextLen, crtxt, ptextLen + 16, &io)) != 0) break;
+        int k = uaesk_gcm(NULL, &c->tb, ks.nr, &ks.ek, 0, nonce, d_aad, aDataLen,
+                          io.din, ptextLen, io.dout, c->scratch, NULL);
+        if (k) { rc = fail(UAES_E_HIP, "gcm launch: %s", hipGetErrorString((hipError_t)k)); break; }
+        rc = finish_io(&io, ptextLen + 16);
+    } while (0);
+    LOCKED_END(c, rc);
+}
+
+int uaes_gcm_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
+                     const void *aData, size_t aDataLen,
+                     const void *crtxt, size_t crtxtLen, void *pntxt)
+{
+    context *c;
+    keysched ks;
+    io_plan io;
+    const void *d_aad;
+    int rc, status = -1;
+    if ((rc = expand_key(&ks, key, keybits)) != 0) return rc;
+    if (!nonce || !crtxt || (crtxtLen && !pntxt)) return fail(UAES_E_ARG, "NULL pointer");
+    if ((rc = get_context(&c)) != 0) return rc;
+    LOCKED_BEGIN(c);
+    do {
+        if ((rc = gcm_scratch(c)) != 0) break;
+        if ((rc = stage_aad(c, aData, aDataLen, &d_aad)) != 0) break;
+        /* input is CT || tag; output is crtxtLen bytes */
+        if ((rc = plan_io(c, crtxt, crtxtLen + 16, pntxt, crtxtLen, &io)) != 0) break;
+        if (io.dout == io.din && io.copy_back) {
+            /* host -> host: decrypt into the second staging buffer so that a
+             * failed authentication can leave the caller's buffer untouched   */
+            if (grow(&c->stage[1], &c->stage_cap[1], crtxtLen + 64)) { rc = UAES_E_HIP; break; }
+            io.dout = c->stage[1];
+        }
+        int k = uaesk_gcm(NULL, &c->tb, ks.nr, &ks.ek, 1, nonce, d_aad, aDataLen,
+                          io.din, crtxtLen, io.dout, c->scratch, c->d_status);
+        if (k) { rc = fail(UAES_E_HIP, "gcm launch: %s", hipGetErrorString((hipError_t)k)); break; }
+        hipError_t e = hipMemcpy(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { rc = fail(UAES_E_HIP, "gcm run: %s", hipGetErrorString(e)); break; }
+        if (status != 0) { rc = UAES_E_AUTHENTICATION; break; }  /* N7: pntxt untouched */
+        rc = finish_io(&io, crtxtLen);
+    } while (0);
+    LOCKED_END(c, rc);
+}
+
+int uaes_gcm_encrypt_dev(int keybits, const uint8_t *key, const uint8_t *nonce,
+                         const void *d_aad, size_t aad_len,
+                         const void *d_in, size_t len, void *d_out, void *stream)
+{
+    context *c;
+    keysched ks;
+    int rc;
+    if ((rc = expand_key(&ks, key, keybits)) != 0) return rc;
+    if ((rc = get_context(&c)) != 0) return rc;
+    if ((rc = gcm_scratch(c)) != 0) return rc;
+    KCHK(uaesk_gcm(stream, &c->tb, ks.nr, &ks.ek, 0, nonce, d_aad, aad_len, d_in, len, d_out,
+                   c->scratch, NULL));
+    return 0;
+}
+
+int uaes_gcm_decrypt_dev(int keybits, const uint8_t *key, const uint8_t *nonce,
+                         const void *d_aad, size_t aad_len,
+                         const void *d_in, size_t len, void *d_out,
+                         int *d_status, void *stream)
+{
+    context *c;
+    keysched ks;
+    int rc;
+    if ((rc = expand_key(&ks, key, keybits)) != 0) return rc;
+    if (!d_status) return fail(UAES_E_ARG, "NULL d_status");
+    if ((rc = get_context(&c)) != 0) return rc;
+    if ((rc = gcm_scratch(c)) != 0) return rc;
+    KCHK(uaesk_gcm(stream, &c->tb, ks.nr, &ks.ek, 1, nonce, d_aad, aad_len, d_in, len, d_out,
+                   c->scratch, d_status));
+    return 0;
+}
+
+int uaes_ghash(const uint8_t H[16], const void *aData, size_t aDataLen,
+               const void *crtxt, size_t crtxtLen, uint8_t gh[16])
+{
+    context *c;
+    io_plan io;
+    const void *d_aad;
+    int rc;
+    if (!H || !gh) return fail(UAES_E_ARG, "NULL pointer");
+    if ((rc = get_context(&c)) != 0) return rc;
+    LOCKED_BEGIN(c);
+    do {
+        if ((rc = gcm_scratch(c)) != 0) break;
+        if ((rc = stage_aad(c, aData, aDataLen, &d_aad)) != 0) break;
+        if ((rc = plan_io(c, crtxt, crtxtLen, NULL, 0, &io)) != 0) break;
+        int k = uaesk_ghash(NULL, H, d_aad, aDataLen, io.din, crtxtLen, c->scratch, c->d_status + 4);
+        if (k) { rc = fail(UAES_E_HIP, "ghash launch: %s", hipGetErrorString((hipError_t)k)); break; }
+        hipError_t e = hipMemcpy(gh, c->d_status + 4, 16, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(UAES_E_HIP, "ghash run: %s", hipGetErrorString(e));
+    } while (0);
+    LOCKED_END(c, rc);
+}

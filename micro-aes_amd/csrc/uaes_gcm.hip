@@ -1,0 +1,445 @@
+/*
+ * uaes_gcm.hip -- GCM for gfx950: GHASH as a strided-Horner polynomial
+ * evaluation with LDS-resident multiplication tables, plus the GCM driver.
+ *
+ * Reference behaviour reproduced (micro_aes.c):
+ *   mulGF128 :476-493, xMac :551-570, gHash :1127-1137 (N6: AAD and CT are
+ *   zero-padded separately, then one block of two 64-bit BE bit lengths),
+ *   GCMsetup :1140-1152 (H = Enc(0), J0 = nonce || 00000001),
+ *   AES_GCM_encrypt :1164-1179 (CTR from J0+1, tag = Enc(J0) ^ GHASH),
+ *   AES_GCM_decrypt :1192-1212 (authenticate first; plaintext untouched and
+ *   0x1A returned on mismatch, N7).
+ *
+ * The reference multiplies bit-serially (128 shift/xor steps per block).
+ * gfx950 has no carry-less multiply instruction, so the design is:
+ *
+ *   GHASH(X_0..X_{M-1}) = sum_u X_u * H^(M-u).  With a stride S, lane j keeps
+ *   acc_j = sum_k X_{kS+j} * (H^S)^(K-1-k)  (acc <- acc*H^S ^ X), and
+ *   GHASH(X) = GHASH(acc_0..acc_{S-1}): the accumulators of one level are the
+ *   input blocks of the next, so the same kernel recurses with smaller
+ *   strides (2^17|..|2^12 -> 2^12 -> 256 -> 16 -> 1).  Multiplication by the
+ *   FIXED element H^S is GF(2)-linear in the other operand, hence 16 lookups
+ *   of 16 bytes in a 64 KiB byte-indexed table (ds_read_b128) + 15 XORs per
+ *   block on the bulk levels, and 32 lookups in an 8 KiB nibble-indexed table
+ *   on the three tiny last levels.  Tables and the powers H^(2^k) are built
+ *   on the GPU by one setup workgroup (wave-cooperative multiply: lane l
+ *   contributes coefficients l and l+64, butterfly XOR over the wave).
+ *
+ * HBM traffic: the bulk level reads each ciphertext block exactly once
+ * (16 B/block); everything else is O(2 MiB).
+ */
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include "uaes_aes.hip.h"
+#include "uaes_gf.h"
+#include "uaes_device.h"
+
+#define GH_T        256u            /* threads per GHASH workgroup            */
+#define GH_MAXLOG   17u             /* largest bulk stride 2^17               */
+#define GH_LOGB     12u             /* second-level stride 2^12               */
+#define GH_DIRECT   16384u          /* <= this many blocks: last kernel alone */
+
+/* scratch layout (bytes) */
+#define GS_H        0u
+#define GS_EJ0      16u
+#define GS_POW      64u                         /* 18 x 16                    */
+#define GS_TAB4_C   1024u                       /* H^256, 8 KiB               */
+#define GS_TAB4_D   (GS_TAB4_C + 8192u)         /* H^16                       */
+#define GS_TAB4_E   (GS_TAB4_D + 8192u)         /* H                          */
+#define GS_TAB8_A   32768u                      /* H^(2^logA), 64 KiB         */
+#define GS_TAB8_B   (GS_TAB8_A + 65536u)        /* H^4096, 64 KiB             */
+#define GS_ACC1     (GS_TAB8_B + 65536u)        /* 2^17 x 16 = 2 MiB          */
+#define GS_ACC2     (GS_ACC1 + (16u << GH_MAXLOG))
+#define GS_TOTAL    (GS_ACC2 + (16u << GH_LOGB))
+
+static inline hipStream_t S(void *s) { return (hipStream_t)s; }
+
+/* the sequence of GHASH input blocks: AAD blocks, CT blocks, length block */
+struct GSrc {
+    const unsigned char *aad;
+    u64 aad_len;
+    const unsigned char *ct;      /* 16-byte aligned */
+    u64 ct_len;
+    u32 has_len;
+};
+
+__device__ __forceinline__ uint4 load_bytes_padded(const unsigned char *p, u64 avail)
+{
+    u32 w[4] = { 0, 0, 0, 0 };
+    const u32 n = avail < 16 ? (u32)avail : 16u;
+    for (u32 i = 0; i < n; ++i) w[i >> 2] |= (u32)p[i] << (8 * (i & 3));
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+__device__ __forceinline__ uint4 load_vblock(const GSrc &s, u64 v)
+{
+    const u64 ab = (s.aad_len + 15) >> 4, cb = (s.ct_len + 15) >> 4;
+    if (v < ab) return load_bytes_padded(s.aad + v * 16, s.aad_len - v * 16);
+    v -= ab;
+    if (v < cb) {
+        if ((v + 1) * 16 <= s.ct_len) return ((const uint4 *)s.ct)[v];
+        return load_bytes_padded(s.ct + v * 16, s.ct_len - v * 16);
+    }
+    const u64 abits = s.aad_len * 8, cbits = s.ct_len * 8;      /* N6 */
+    return make_uint4(bswap32((u32)(abits >> 32)), bswap32((u32)abits),
+                      bswap32((u32)(cbits >> 32)), bswap32((u32)cbits));
+}
+
+__device__ __forceinline__ uint4 x4(uint4 a, uint4 b)
+{
+    return make_uint4(a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w);
+}
+
+/* a * M through the byte-indexed table of M (4096 entries of 16 B in LDS) */
+__device__ __forceinline__ uint4 tabmul8(const uint4 *T, uint4 a)
+{
+    const u32 w[4] = { a.x, a.y, a.z, a.w };
+    uint4 z = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        z = x4(z, T[j * 256 + ((w[j >> 2] >> (8 * (j & 3))) & 0xffu)]);
+    return z;
+}
+
+/* a * M through the nibble-indexed table of M (512 entries of 16 B) */
+__device__ __forceinline__ uint4 tabmul4(const uint4 *T, uint4 a)
+{
+    const u32 w[4] = { a.x, a.y, a.z, a.w };
+    uint4 z = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const u32 b = (w[j >> 2] >> (8 * (j & 3))) & 0xffu;
+        z = x4(z, T[(2 * j) * 16 + (b >> 4)]);
+        z = x4(z, T[(2 * j + 1) * 16 + (b & 15u)]);
+    }
+    return z;
+}
+
+/* ------------------------------------------------------------------------ */
+/* bulk level: stride S = gridDim.x * 256                                     */
+/* ------------------------------------------------------------------------ */
+#define GH_PF 4     /* blocks prefetched per lane */
+
+__global__ __launch_bounds__(GH_T) void k_ghash_pass(GSrc src, u64 nv, const uint4 *__restrict__ tab8,
+                                                     uint4 *__restrict__ accs)
+{
+    uint4 *T = (uint4 *)uaes_lds;
+    for (u32 i = threadIdx.x; i < 4096u; i += GH_T) T[i] = tab8[i];
+    __syncthreads();
+
+    const u64 stride = (u64)gridDim.x * GH_T;
+    const u64 j = (u64)blockIdx.x * GH_T + threadIdx.x;
+    const u64 steps = (nv + stride - 1) / stride;
+    const u64 pad = steps * stride - nv;           /* virtual zero blocks in front */
+    uint4 acc = make_uint4(0, 0, 0, 0);
+
+    u64 k = 0;
+    /* first (possibly padded) step, then whole groups of GH_PF with the loads
+     * issued ahead of the dependent multiply chain                          */
+    for (; k < steps && (k == 0 || (steps - k) % GH_PF != 0); ++k) {
+        const u64 u = k * stride + j;
+        uint4 x = make_uint4(0, 0, 0, 0);
+        if (u >= pad) x = load_vblock(src, u - pad);
+        acc = x4(tabmul8(T, acc), x);
+    }
+    for (; k < steps; k += GH_PF) {
+        uint4 x[GH_PF];
+#pragma unroll
+        for (int p = 0; p < GH_PF; ++p) x[p] = load_vblock(src, (k + p) * stride + j - pad);
+#pragma unroll
+        for (int p = 0; p < GH_PF; ++p) acc = x4(tabmul8(T, acc), x[p]);
+    }
+    accs[j] = acc;
+}
+
+/* ------------------------------------------------------------------------ */
+/* last levels (strides 256, 16, 1) + tag handling; one workgroup             */
+/* ------------------------------------------------------------------------ */
+/* mode 0: write tag = GHASH ^ EJ0 to tag_io (encrypt)
+ * mode 1: compare with the 16 bytes at tag_io, *status = 0 / 0x1A (decrypt)
+ * mode 2: write the raw GHASH value to tag_io (tests)                       */
+__global__ __launch_bounds__(GH_T) void k_ghash_final(GSrc src, u64 nv, const unsigned char *__restrict__ scratch,
+                                                      int mode, unsigned char *tag_io, int *status)
+{
+    uint4 *TC = (uint4 *)uaes_lds;            /* 3 x 512 entries */
+    uint4 *TD = TC + 512, *TE = TD + 512;
+    uint4 *buf = TE + 512;                    /* 256 + 16 */
+    const uint4 *g4 = (const uint4 *)(scratch + GS_TAB4_C);
+    for (u32 i = threadIdx.x; i < 1536u; i += GH_T) TC[i] = g4[i];
+    __syncthreads();
+
+    const u64 steps = (nv + GH_T - 1) / GH_T;
+    const u64 pad = steps * GH_T - nv;
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    for (u64 k = 0; k < steps; ++k) {
+        const u64 u = k * GH_T + threadIdx.x;
+        uint4 x = make_uint4(0, 0, 0, 0);
+        if (u >= pad) x = load_vblock(src, u - pad);
+        acc = x4(tabmul4(TC, acc), x);
+    }
+    buf[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        acc = make_uint4(0, 0, 0, 0);
+        for (u32 k = 0; k < 16; ++k) acc = x4(tabmul4(TD, acc), buf[k * 16 + threadIdx.x]);
+        buf[256 + threadIdx.x] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        acc = make_uint4(0, 0, 0, 0);
+        for (u32 k = 0; k < 16; ++k) acc = tabmul4(TE, x4(acc, buf[256 + k]));
+        if (mode != 2) acc = x4(acc, *(const uint4 *)(scratch + GS_EJ0));
+        const u32 w[4] = { acc.x, acc.y, acc.z, acc.w };
+        if (mode == 1) {
+            u32 diff = 0;
+            for (u32 i = 0; i < 16; ++i) diff |= (u32)tag_io[i] ^ ((w[i >> 2] >> (8 * (i & 3))) & 0xffu);
+            *status = diff ? 0x1A : 0;
+        } else {
+            for (u32 i = 0; i < 16; ++i) tag_io[i] = (unsigned char)(w[i >> 2] >> (8 * (i & 3)));
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* setup: H, Enc(J0), powers H^(2^k), multiplication tables                   */
+/* ------------------------------------------------------------------------ */
+__device__ __forceinline__ u64 shfl_xor64(u64 v, int off)
+{
+    const u32 lo = __shfl_xor((u32)v, off, 64), hi = __shfl_xor((u32)(v >> 32), off, 64);
+    return ((u64)hi << 32) | lo;
+}
+
+/* x*y computed by one whole wave; every lane returns the product */
+__device__ __forceinline__ Gf wave_gfmul(Gf x, Gf y, u32 lane)
+{
+    Gf z = gf_mul_slice(x, y, gf_mul_x64(y), lane);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        z.hi ^= shfl_xor64(z.hi, off);
+        z.lo ^= shfl_xor64(z.lo, off);
+    }
+    return z;
+}
+
+#define SETUP_LDS   (UAES_LDS_ENC + 16384u)
+
+/* logA: log2 of the bulk stride (12..17), 0 = no bulk level.  needB: build the
+ * H^4096 table.  h_given: skip AES, use hval as H and 0 as Enc(J0) (tests).   */
+template <int NR>
+__global__ __launch_bounds__(UAES_WG) void k_gcm_setup(uaesk_rk ek, uaesk_tables tb, uint4 j0,
+                                                       unsigned char *__restrict__ scratch,
+                                                       u32 logA, u32 needB, u32 h_given, uint4 hval)
+{
+    Gf *shPow = (Gf *)(uaes_lds + UAES_LDS_ENC);          /* 18 powers         */
+    Gf *shGen = shPow + 32;                                /* 5 x 128 generators */
+    uint4 *gH = (uint4 *)(scratch + GS_H);
+
+    if (!h_given) {
+        fill_enc_tables(tb.te0);
+        const LaneConst lc = make_lane_const();
+        if (threadIdx.x < 2) {
+            u32 s[1][4] = { { 0, 0, 0, 0 } };
+            if (threadIdx.x == 1) { s[0][0] = j0.x; s[0][1] = j0.y; s[0][2] = j0.z; s[0][3] = j0.w; }
+            enc_blocks<NR, 1>(s, ek, lc);
+            gH[threadIdx.x] = make_uint4(s[0][0], s[0][1], s[0][2], s[0][3]);
+            if (threadIdx.x == 0) shPow[0] = gf_from_words(s[0][0], s[0][1], s[0][2], s[0][3]);
+        }
+    } else if (threadIdx.x == 0) {
+        gH[0] = hval;
+        gH[1] = make_uint4(0, 0, 0, 0);
+        shPow[0] = gf_from_words(hval.x, hval.y, hval.z, hval.w);
+    }
+    __syncthreads();
+
+    if (threadIdx.x < 64) {                    /* squaring chain, wave 0 */
+        Gf p = shPow[0];
+        for (u32 k = 1; k <= GH_MAXLOG; ++k) {
+            p = wave_gfmul(p, p, threadIdx.x);
+            if (threadIdx.x == 0) shPow[k] = p;
+        }
+    }
+    __syncthreads();
+
+    /* generators M*x^q of the five tables: A (2^logA), B (2^12), C (2^8), D (2^4), E (2^0) */
+    const u32 logs[5] = { logA, GH_LOGB, 8u, 4u, 0u };
+    if (threadIdx.x < 640) {
+        const u32 t = threadIdx.x >> 7, q = threadIdx.x & 127u;
+        shGen[threadIdx.x] = gf_mul_xq128(shPow[logs[t]], q);
+    }
+    __syncthreads();
+
+    /* byte-indexed tables: entry (j, v) = sum_i bit(v, 7-i) * gen[8j+i] */
+    for (u32 t = 0; t < 2; ++t) {
+        if ((t == 0 && !logA) || (t == 1 && !needB)) continue;
+        uint4 *dst = (uint4 *)(scratch + (t == 0 ? GS_TAB8_A : GS_TAB8_B));
+        const Gf *gen = shGen + 128 * t;
+        const u32 v = threadIdx.x & 255u;
+#pragma unroll
+        for (u32 jj = 0; jj < 4; ++jj) {
+            const u32 j = (threadIdx.x >> 8) * 4 + jj;
+            Gf e = { 0, 0 };
+#pragma unroll
+            for (u32 i = 0; i < 8; ++i) {
+                const u64 m = 0 - (u64)((v >> (7 - i)) & 1u);
+                e.hi ^= gen[8 * j + i].hi & m;
+                e.lo ^= gen[8 * j + i].lo & m;
+            }
+            u32 w[4];
+            gf_to_words(e, w);
+            dst[j * 256 + v] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    }
+    /* nibble-indexed tables: entry (p, v) = sum_i bit(v, 3-i) * gen[4p+i] */
+    if (threadIdx.x < 512) {
+        const u32 p = threadIdx.x >> 4, v = threadIdx.x & 15u;
+        for (u32 t = 0; t < 3; ++t) {
+            uint4 *dst = (uint4 *)(scratch + GS_TAB4_C + 8192u * t);
+            const Gf *gen = shGen + 128 * (2 + t);
+            Gf e = { 0, 0 };
+#pragma unroll
+            for (u32 i = 0; i < 4; ++i) {
+                const u64 m = 0 - (u64)((v >> (3 - i)) & 1u);
+                e.hi ^= gen[4 * p + i].hi & m;
+                e.lo ^= gen[4 * p + i].lo & m;
+            }
+            u32 w[4];
+            gf_to_words(e, w);
+            dst[p * 16 + v] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    }
+    if (threadIdx.x <= GH_MAXLOG) {
+        u32 w[4];
+        gf_to_words(shPow[threadIdx.x], w);
+        ((uint4 *)(scratch + GS_POW))[threadIdx.x] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* host-side drivers                                                          */
+/* ------------------------------------------------------------------------ */
+struct GPlan {
+    u32 logA;       /* 0 = no bulk level */
+    u32 needB;
+};
+
+static GPlan plan_for(u64 nv)
+{
+    GPlan p = { 0, 0 };
+    if (nv <= GH_DIRECT) return p;
+    u32 lg = GH_LOGB;
+    while (lg < GH_MAXLOG && ((u64)64 << lg) < nv) ++lg;     /* ~64+ steps per lane */
+    p.logA = lg;
+    p.needB = ((u64)1 << lg) > GH_DIRECT;
+    return p;
+}
+
+static int run_ghash_levels(hipStream_t st, const GSrc &msg, u64 nv, const GPlan &pl,
+                            unsigned char *scratch, int mode, unsigned char *tag_io, int *status)
+{
+    GSrc cur = msg;
+    u64 n = nv;
+    hipError_t e;
+    if (pl.logA) {
+        e = hipFuncSetAttribute((const void *)k_ghash_pass, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        if (e != hipSuccess) return (int)e;
+        const u64 sA = (u64)1 << pl.logA;
+        hipLaunchKernelGGL(k_ghash_pass, dim3((unsigned)(sA / GH_T)), dim3(GH_T), 65536, st,
+                           cur, n, (const uint4 *)(scratch + GS_TAB8_A), (uint4 *)(scratch + GS_ACC1));
+        cur.aad = nullptr; cur.aad_len = 0; cur.ct = scratch + GS_ACC1; cur.ct_len = sA * 16; cur.has_len = 0;
+        n = sA;
+        if (pl.needB) {
+            const u64 sB = (u64)1 << GH_LOGB;
+            hipLaunchKernelGGL(k_ghash_pass, dim3((unsigned)(sB / GH_T)), dim3(GH_T), 65536, st,
+                               cur, n, (const uint4 *)(scratch + GS_TAB8_B), (uint4 *)(scratch + GS_ACC2));
+            cur.ct = scratch + GS_ACC2; cur.ct_len = sB * 16;
+            n = sB;
+        }
+    }
+    hipLaunchKernelGGL(k_ghash_final, dim3(1), dim3(GH_T), (1536 + 272) * 16, st,
+                       cur, n, (const unsigned char *)scratch, mode, tag_io, status);
+    return (int)hipGetLastError();
+}
+
+extern "C" size_t uaesk_gcm_scratch_bytes(void) { return GS_TOTAL; }
+
+template <int NR>
+static int launch_setup(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek, uint4 j0,
+                        unsigned char *scratch, const GPlan &pl, u32 h_given, uint4 hval)
+{
+    hipError_t e = hipFuncSetAttribute((const void *)k_gcm_setup<NR>, hipFuncAttributeMaxDynamicSharedMemorySize, SETUP_LDS);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((k_gcm_setup<NR>), dim3(1), dim3(UAES_WG), SETUP_LDS, st, *ek, *tb, j0, scratch,
+                       pl.logA, pl.needB, h_given, hval);
+    return (int)hipGetLastError();
+}
+
+extern "C" int uaesk_gcm(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek,
+                         int decrypt, const uint8_t *nonce12,
+                         const void *aad, size_t aad_len,
+                         const void *in, size_t len, void *out,
+                         void *scratch, int *status)
+{
+    hipStream_t st = S(stream);
+    unsigned char *sc = (unsigned char *)scratch;
+    /* J0 = nonce || 00000001 (GCMsetup, micro_aes.c:1150-1151) */
+    uint4 j0;
+    unsigned char j0b[16];
+    memcpy(j0b, nonce12, 12);
+    j0b[12] = j0b[13] = j0b[14] = 0; j0b[15] = 1;
+    memcpy(&j0, j0b, 16);
+    /* keystream counter starts at J0 + 1 (pre-increment, N4); the reference's
+     * incBlock carries through bytes 15..9, so this is a 56-bit counter      */
+    uaesk_ctr c;
+    memcpy(&c.w0, j0b, 4);
+    memcpy(&c.w1, j0b + 4, 4);
+    c.b8 = j0b[8];
+    c.v0 = ((uint64_t)j0b[9] << 48) | ((uint64_t)j0b[10] << 40) | ((uint64_t)j0b[11] << 32) | 2u;
+
+    GSrc msg;
+    msg.aad = (const unsigned char *)aad; msg.aad_len = aad_len;
+    msg.ct = (const unsigned char *)(decrypt ? in : out); msg.ct_len = len;
+    msg.has_len = 1;
+    const u64 nv = ((aad_len + 15) >> 4) + ((len + 15) >> 4) + 1;
+    const GPlan pl = plan_for(nv);
+
+    int rc;
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    switch (nr) {
+    case 10: rc = launch_setup<10>(st, tb, ek, j0, sc, pl, 0, z); break;
+    case 12: rc = launch_setup<12>(st, tb, ek, j0, sc, pl, 0, z); break;
+    case 14: rc = launch_setup<14>(st, tb, ek, j0, sc, pl, 0, z); break;
+    default: return (int)hipErrorInvalidValue;
+    }
+    if (rc) return rc;
+
+    if (!decrypt) {
+        rc = uaesk_ctr_xcrypt(stream, tb, nr, ek, &c, in, out, len, nullptr);
+        if (rc) return rc;
+        return run_ghash_levels(st, msg, nv, pl, sc, 0, (unsigned char *)out + len, nullptr);
+    }
+    rc = run_ghash_levels(st, msg, nv, pl, sc, 1, (unsigned char *)in + len, status);
+    if (rc) return rc;
+    return uaesk_ctr_xcrypt(stream, tb, nr, ek, &c, in, out, len, status);
+}
+
+extern "C" int uaesk_ghash(void *stream, const uint8_t *H_host,
+                           const void *aad, size_t aad_len, const void *ct, size_t ct_len,
+                           void *scratch, void *gh_out16)
+{
+    hipStream_t st = S(stream);
+    unsigned char *sc = (unsigned char *)scratch;
+    GSrc msg;
+    msg.aad = (const unsigned char *)aad; msg.aad_len = aad_len;
+    msg.ct = (const unsigned char *)ct; msg.ct_len = ct_len;
+    msg.has_len = 1;
+    const u64 nv = ((aad_len + 15) >> 4) + ((ct_len + 15) >> 4) + 1;
+    const GPlan pl = plan_for(nv);
+    uint4 h;
+    memcpy(&h, H_host, 16);
+    uaesk_rk dummy_rk;
+    uaesk_tables dummy_tb = { nullptr, nullptr, nullptr };
+    memset(&dummy_rk, 0, sizeof dummy_rk);
+    int rc = launch_setup<10>(st, &dummy_tb, &dummy_rk, make_uint4(0, 0, 0, 0), sc, pl, 1, h);
+    if (rc) return rc;
+    return run_ghash_levels(st, msg, nv, pl, sc, 2, (unsigned char *)gh_out16, nullptr);
+}

@@ -1,0 +1,91 @@
+"""Sharding of the block-parallel modes across the GPUs of one node.
+
+One process per GPU (``torch.distributed``, backend ``nccl`` = RCCL over xGMI).
+CTR, ECB and XTS are embarrassingly parallel over 16-byte blocks / data units,
+so a stream is cut into contiguous, unit-aligned shards and every rank runs the
+same single-GPU kernels on its own shard:
+
+* CTR -- rank g starts its keystream at ``block_offset = shard_start / 16``;
+  the offset is added to the initial counter with the reference's 56-bit
+  big-endian carry (incBlock, micro_aes.c:421-427), so the concatenation of
+  the shards is bit-identical to one ``AES_CTR_encrypt`` call over the whole
+  stream (micro_aes.c:962).
+* XTS -- shards are whole data units; rank g starts at ``first_sector +
+  shard_start / sector_bytes`` (the sectid convention, micro_aes.c:1017-1021).
+* ECB -- any block partition.
+
+There is NO collective on the data path.  ``gather`` is the optional final
+step north_star asks for (ciphertext all-gather over xGMI); it costs ~20x the
+encrypt itself (7 peers x 1 GiB over ~153 GB/s links vs. ~0.5 ms of kernel), so
+callers that keep data sharded should leave it off.
+
+The cipher is injected as a callable so that the partition/offset logic can be
+exercised on CPU (gloo, world_size 2) in tests with the oracle standing in for
+the device kernels; the default callables are the HIP engine's ``*_dev`` entry
+points.
+"""
+
+
+def shard_bounds(total_bytes, world, unit=16):
+    """Contiguous shards, each a multiple of `unit` except possibly the last.
+    Returns [(start, nbytes)] of length `world` (empty shards allowed)."""
+    units = (total_bytes + unit - 1) // unit
+    per = (units + world - 1) // world
+    out = []
+    for r in range(world):
+        start = min(r * per * unit, total_bytes)
+        end = min((r + 1) * per * unit, total_bytes)
+        out.append((start, end - start))
+    return out
+
+
+def ctr_shard_args(total_bytes, rank, world):
+    """(byte_start, nbytes, block_offset) of rank's CTR shard."""
+    start, n = shard_bounds(total_bytes, world, 16)[rank]
+    return start, n, start // 16
+
+
+def xts_shard_args(nsectors, sector_bytes, first_sector, rank, world):
+    """(byte_start, nsectors_local, first_sector_local) of rank's XTS shard."""
+    start, n = shard_bounds(nsectors * sector_bytes, world, sector_bytes)[rank]
+    return start, n // sector_bytes, first_sector + start // sector_bytes
+
+
+def ctr_xcrypt_sharded(key, ctr0, total_bytes, local_src, local_dst, rank, world,
+                       cipher=None, gather_into=None, group=None):
+    """Encrypt this rank's shard of a `total_bytes` CTR stream.
+
+    local_src/local_dst hold exactly this rank's shard.  cipher(key, ctr0,
+    block_offset, src, dst, nbytes) defaults to the HIP engine.  If
+    `gather_into` (a tensor of world * shard_capacity bytes) is given, the
+    ciphertext shards are all-gathered into it afterwards (RCCL).
+    """
+    if cipher is None:
+        from . import ctr_xcrypt_dev
+
+        def cipher(k, c, off, s, d, n):
+            ctr_xcrypt_dev(k, c, off, s, d, nbytes=n)
+    start, n, off = ctr_shard_args(total_bytes, rank, world)
+    if n:
+        cipher(key, ctr0, off, local_src, local_dst, n)
+    if gather_into is not None:
+        import torch.distributed as dist
+        dist.all_gather_into_tensor(gather_into, local_dst, group=group)
+    return start, n
+
+
+def xts_sectors_sharded(keys, first_sector, sector_bytes, nsectors, local_src, local_dst,
+                        rank, world, encrypt=True, cipher=None, gather_into=None, group=None):
+    """Encrypt/decrypt this rank's whole-data-unit shard of an XTS volume."""
+    if cipher is None:
+        from . import xts_sectors_dev
+
+        def cipher(k, first, sb, ns, s, d, enc):
+            xts_sectors_dev(k, first, sb, ns, s, d, encrypt=enc)
+    start, ns, first = xts_shard_args(nsectors, sector_bytes, first_sector, rank, world)
+    if ns:
+        cipher(keys, first, sector_bytes, ns, local_src, local_dst, encrypt)
+    if gather_into is not None:
+        import torch.distributed as dist
+        dist.all_gather_into_tensor(gather_into, local_dst, group=group)
+    return start, ns

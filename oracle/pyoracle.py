@@ -127,10 +127,17 @@ class Oracle:
         return bytes(g)
 
     def splitmix(self, seed, nbytes, word0=0):
-        assert nbytes % 8 == 0
-        o = _out(nbytes)
-        self.L.orc_fill_splitmix(seed, word0, nbytes // 8, o)
+        """first `nbytes` of the synthetic stream starting at 64-bit word `word0`"""
+        nw = (nbytes + 7) // 8
+        o = _out(nw * 8)
+        self.L.orc_fill_splitmix(seed, word0, nw, o)
         return bytes(o)[:nbytes]
+
+    def splitmix_into(self, seed, array, word0=0):
+        """fill a writable, C-contiguous numpy uint8 array (size % 8 == 0) in place"""
+        assert array.nbytes % 8 == 0 and array.flags["C_CONTIGUOUS"]
+        self.L.orc_fill_splitmix(seed, word0, array.nbytes // 8, C.c_void_p(array.ctypes.data))
+        return array
 
 
 class Reference:

@@ -1,0 +1,107 @@
+"""CPU tests of the product's host side: the C-ABI libraries load and export
+every symbol include/*.h declares, the host key schedule is right, the error
+behaviour without a GPU is loud, and nothing in the product references the
+oracle."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+import micro_aes_amd as uaes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b((?:uaes|AES)_[A-Za-z0-9_]+)\s*\(", text)))
+
+
+def test_runtime_library_exports_every_declared_symbol():
+    names = declared_functions("uaes_hip.h")
+    assert len(names) >= 20 and set(uaes.EXPORTS) == set(names)
+    L = C.CDLL(uaes.lib_path())
+    for n in names:
+        assert getattr(L, n) is not None
+
+
+@pytest.mark.parametrize("bits", [128, 192, 256])
+def test_compat_libraries_export_reference_api(bits):
+    names = declared_functions("micro_aes.h")
+    assert set(names) == set(uaes.COMPAT_EXPORTS)
+    L = C.CDLL(uaes.lib_path("libmicro_aes_hip_%d.so" % bits))
+    for n in names:
+        assert getattr(L, n) is not None
+
+
+def test_compat_header_compiles_as_c89_and_matches_reference_constants(tmp_path):
+    src = tmp_path / "t.c"
+    src.write_text('#include "micro_aes.h"\n#include <stdio.h>\n'
+                   'int main(void){printf("%d %d %d %d %d %d %d %d %d\\n", AES_KEYLENGTH, GCM_NONCE_LEN, GCM_TAG_LEN,'
+                   'CTR_IV_LENGTH, CTR_START_VALUE, (int)M_DATALENGTH_ERROR, M_AUTHENTICATION_ERROR,'
+                   'M_DECRYPTION_ERROR, M_ENCRYPTION_ERROR);return ECB&&CTR&&XTS&&GCM&&!CBC&&!CMAC?0:1;}\n')
+    for bits, kl in ((128, 16), (192, 24), (256, 32)):
+        exe = tmp_path / ("t%d" % bits)
+        subprocess.run(["gcc", "-std=c89", "-pedantic", "-Wall", "-Werror", "-DAES___=%d" % bits,
+                        "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+        out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+        assert [int(x) for x in out] == [kl, 12, 16, 12, 1, 1, 0x1A, 0x1D, 0x1E]
+
+
+@pytest.mark.parametrize("bits", [128, 192, 256])
+def test_host_key_schedule(orc, bits):
+    """uaes_expand_key == the oracle's schedule (itself pinned to the reference);
+    the decrypt schedule is the equivalent-inverse form of the same keys."""
+    import random
+    rnd = random.Random(bits)
+    L = uaes.engine()
+    for _ in range(10):
+        key = rnd.randbytes(bits // 8)
+        ek, dk = (C.c_uint32 * 60)(), (C.c_uint32 * 60)()
+        nr = L.uaes_expand_key(bits, key, ek, dk)
+        assert nr == bits // 32 + 6
+        ks = (C.c_uint8 * 244)()
+        assert orc.L.orc_setkey(ks, key, bits) == 0
+        want = bytes(ks)[4: 4 + 16 * (nr + 1)]
+        assert bytes(ek)[: 16 * (nr + 1)] == want
+        d = bytes(dk)
+        assert d[:16] == want[16 * nr:] and d[16 * nr: 16 * nr + 16] == want[:16]
+        # middle keys: MixColumns(dk[i]) == ek[nr-i]  <=>  dk[i] = InvMixColumns(ek[nr-i])
+        def mixcol(col):
+            x2 = lambda a: ((a << 1) ^ (0x1b if a & 0x80 else 0)) & 0xff
+            a = list(col)
+            t = a[0] ^ a[1] ^ a[2] ^ a[3]
+            return bytes(a[i] ^ t ^ x2(a[i] ^ a[(i + 1) % 4]) for i in range(4))
+        for i in range(1, nr):
+            for c in range(4):
+                col = d[16 * i + 4 * c: 16 * i + 4 * c + 4]
+                assert mixcol(col) == want[16 * (nr - i) + 4 * c: 16 * (nr - i) + 4 * c + 4]
+    assert L.uaes_expand_key(100, bytes(16), None, None) == -2
+    assert b"keybits" in L.uaes_last_error()
+
+
+def test_fails_loudly_without_gpu():
+    """no silent CPU path: on a box without a HIP device every data call errors"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(uaes.EngineError, match="no usable HIP device"):
+        uaes.AES_CTR_encrypt(bytes(16), bytes(12), b"abc")
+    with pytest.raises(uaes.EngineError):
+        uaes.selftest()
+
+
+def test_product_does_not_touch_the_oracle():
+    """the shipped path must not import, link or open anything under oracle/"""
+    pkg = os.path.join(ROOT, "micro-aes_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".c", ".h", ".hip", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle/" not in text.replace("the oracle", "") or "oracle/" not in re.sub(r"(#|//|/\*|\*|\"\"\").*", "", text), f
+                assert "pyoracle" not in text and "liboracle" not in text and "uaes_oracle" not in text, f
+    out = subprocess.run(["ldd", uaes.lib_path()], capture_output=True, text=True).stdout
+    assert "oracle" not in out

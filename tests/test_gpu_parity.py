@@ -1,0 +1,311 @@
+"""GPU parity tests (need a real MI355X): the HIP engine, driven through its
+C ABI, against (1) every golden vector the reference's own tests hold for the
+hot path, (2) outputs of the compiled reference (tests/golden/ref_vectors.json,
+digests.json) and (3) the CPU oracle on seeded inputs, with the reference's
+edge semantics (N1..N8 of SURVEY.md section 8a).  Bit-exact everywhere."""
+import ctypes as C
+import hashlib
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+import micro_aes_amd as uaes
+from tests.rsp import gcm_cases, xts_cases
+
+pytestmark = pytest.mark.gpu
+
+
+def load(golden_dir, name):
+    with open(os.path.join(golden_dir, name)) as f:
+        return json.load(f)
+
+
+def check_out(got, spec):
+    if "hex" in spec:
+        assert got.hex() == spec["hex"]
+    else:
+        assert len(got) == spec["len"]
+        assert got[:16].hex() == spec["head"] and got[-16:].hex() == spec["tail"]
+        assert hashlib.sha256(got).hexdigest() == spec["sha256"]
+
+
+def test_device_selftest():
+    assert uaes.selftest() == 0
+
+
+# ---- the reference's own vectors, through the reference-compatible AES_* API ----
+class Compat:
+    """libmicro_aes_hip_<bits>.so: the drop-in AES_* symbols (include/micro_aes.h)"""
+
+    def __init__(self, bits):
+        L = self.L = C.CDLL(uaes.lib_path("libmicro_aes_hip_%d.so" % bits))
+        sz, vp = C.c_size_t, C.c_void_p
+        L.AES_ECB_encrypt.argtypes = [vp, vp, sz, vp]; L.AES_ECB_encrypt.restype = None
+        L.AES_ECB_decrypt.argtypes = [vp, vp, sz, vp]; L.AES_ECB_decrypt.restype = C.c_char
+        for f in (L.AES_CTR_encrypt, L.AES_CTR_decrypt):
+            f.argtypes = [vp, vp, vp, sz, vp]; f.restype = None
+        for f in (L.AES_XTS_encrypt, L.AES_XTS_decrypt):
+            f.argtypes = [vp, vp, vp, sz, vp]; f.restype = C.c_char
+        L.AES_GCM_encrypt.argtypes = [vp, vp, vp, sz, vp, sz, vp]; L.AES_GCM_encrypt.restype = None
+        L.AES_GCM_decrypt.argtypes = [vp, vp, vp, sz, vp, sz, vp]; L.AES_GCM_decrypt.restype = C.c_char
+
+    @staticmethod
+    def buf(n, fill=0xCC):
+        b = (C.c_uint8 * max(n, 1))()
+        C.memset(b, fill, max(n, 1))
+        return b
+
+
+@pytest.mark.parametrize("bits", [128, 192, 256])
+def test_gcm_rsp_through_compat_api(bits):
+    cases = gcm_cases(bits)
+    assert len(cases) == 375                                   # the harness's own count
+    L = Compat(bits)
+    for c in cases:
+        n = len(c["PT"])
+        out = L.buf(n + 16)
+        L.L.AES_GCM_encrypt(c["Key"], c["IV"], c["AAD"], len(c["AAD"]), c["PT"], n, out)
+        assert bytes(out)[: n + 16] == c["CT"] + c["Tag"], c["Count"]
+        pt = L.buf(n)
+        rc = L.L.AES_GCM_decrypt(c["Key"], c["IV"], c["AAD"], len(c["AAD"]), c["CT"] + c["Tag"], n, pt)
+        assert ord(rc) == 0 and bytes(pt)[:n] == c["PT"], c["Count"]
+
+
+@pytest.mark.parametrize("bits,count", [(128, 800), (256, 600)])
+def test_xts_rsp_through_compat_api(bits, count):
+    cases = xts_cases(bits)
+    assert len(cases) == count
+    L = Compat(bits)
+    for c in cases:
+        n = len(c["PT"])
+        out = L.buf(n)
+        assert ord(L.L.AES_XTS_encrypt(c["Key"], c["i"], c["PT"], n, out)) == 0
+        assert bytes(out)[:n] == c["CT"], c["COUNT"]
+        out = L.buf(n)
+        assert ord(L.L.AES_XTS_decrypt(c["Key"], c["i"], c["CT"], n, out)) == 0
+        assert bytes(out)[:n] == c["PT"], c["COUNT"]
+
+
+def test_main_c_kats(golden_dir):
+    for k in load(golden_dir, "main_kats.json"):
+        key, pt, exp = bytes.fromhex(k["key"]), bytes.fromhex(k["pt"]), bytes.fromhex(k["expect"])
+        if k["mode"] == "ecb":
+            assert uaes.AES_ECB_encrypt(key, pt) == exp
+            rc, back = uaes.AES_ECB_decrypt(key, exp)
+            assert rc == 0 and back[: len(pt)] == pt
+        elif k["mode"] == "ctr":
+            iv = bytes.fromhex(k["iv"])
+            assert uaes.AES_CTR_encrypt(key, iv, pt) == exp and uaes.AES_CTR_decrypt(key, iv, exp) == pt
+        elif k["mode"] == "xts":
+            tw = bytes.fromhex(k["tweak"])
+            assert uaes.AES_XTS_encrypt(key, tw, pt) == (0, exp)
+            assert uaes.AES_XTS_decrypt(key, tw, exp) == (0, pt)
+        else:
+            n, a = bytes.fromhex(k["nonce"]), bytes.fromhex(k["aad"])
+            assert uaes.AES_GCM_encrypt(key, n, a, pt) == exp
+            assert uaes.AES_GCM_decrypt(key, n, a, exp) == (0, pt)
+
+
+def test_reference_generated_vectors(orc, golden_dir):
+    for v in load(golden_dir, "ref_vectors.json"):
+        n = v["len"]
+        data = orc.splitmix(v["seed"], n)
+        key = bytes.fromhex(v["key"])
+        if v["mode"] == "ecb":
+            ct = uaes.AES_ECB_encrypt(key, data)
+            check_out(ct, v["out"])
+            rc, back = uaes.AES_ECB_decrypt(key, ct[:n] if n % 16 else ct)
+            assert rc == v["dec_rc"]
+            if n % 16 == 0:
+                assert back == data
+        elif v["mode"] == "ctr":
+            check_out(uaes.AES_CTR_encrypt(key, bytes.fromhex(v["iv"]), data), v["out"])
+        elif v["mode"] == "xts":
+            rc, ct = uaes.AES_XTS_encrypt(key, bytes.fromhex(v["tweak"]), data, prefill=0xCC)
+            assert rc == v["rc"]
+            if rc == 0:
+                check_out(ct, v["out"])
+                assert uaes.AES_XTS_decrypt(key, bytes.fromhex(v["tweak"]), ct) == (0, data)
+            else:
+                assert ct == b"\xcc" * n                       # N5: untouched
+        else:
+            nonce, aad = bytes.fromhex(v["nonce"]), bytes.fromhex(v["aad"])
+            ct = uaes.AES_GCM_encrypt(key, nonce, aad, data)
+            check_out(ct, v["out"])
+            assert uaes.AES_GCM_decrypt(key, nonce, aad, ct) == (0, data)
+
+
+# ---- against the oracle on seeded inputs -------------------------------------------
+SIZES = [0, 1, 15, 16, 17, 100, 4095, 4096, 4097, 65536 + 3, (1 << 20) + 16, (4 << 20) + 9]
+
+
+@pytest.mark.parametrize("bits", [128, 192, 256])
+def test_ecb_ctr_vs_oracle(orc, bits):
+    rnd = random.Random(bits)
+    for n in SIZES:
+        key, iv = rnd.randbytes(bits // 8), rnd.randbytes(12)
+        data = orc.splitmix(n + bits, n)
+        ct = uaes.AES_ECB_encrypt(key, data)
+        assert ct == orc.ecb_encrypt(key, data)
+        assert uaes.AES_ECB_decrypt(key, ct) == orc.ecb_decrypt(key, ct)
+        assert uaes.AES_ECB_decrypt(key, data) == orc.ecb_decrypt(key, data)      # ragged: 0x1D + tail copied
+        assert uaes.AES_CTR_encrypt(key, iv, data) == orc.ctr_encrypt(key, iv, data)
+    # N2: 56-bit counter carry / wrap, and shard offsets
+    key = rnd.randbytes(bits // 8)
+    c0 = bytes.fromhex("0011223344556677a8fffffffffffff0")
+    data = orc.splitmix(9, 4096 * 3 + 7)
+    whole = uaes.ctr_xcrypt_at(key, c0, 0, data)
+    assert whole == orc.ctr_xcrypt_at(key, c0, 0, data)
+    assert whole[4096:] == uaes.ctr_xcrypt_at(key, c0, 256, data[4096:])
+    c1 = bytes.fromhex("00112233445566778800000000ffffff")            # byte-12 carry
+    assert uaes.ctr_xcrypt_at(key, c1, 0xFFFFFF00, data) == orc.ctr_xcrypt_at(key, c1, 0xFFFFFF00, data)
+
+
+@pytest.mark.parametrize("bits", [128, 192, 256])
+def test_xts_vs_oracle(orc, bits):
+    rnd = random.Random(bits + 1)
+    for n in [16, 17, 31, 32, 33, 100, 4096, 4097, 4111, 4112, 65536, 65536 + 1, (1 << 20) + 5]:
+        keys, tw = rnd.randbytes(bits // 4), rnd.randbytes(16)
+        data = orc.splitmix(n, n)
+        rc, ct = uaes.AES_XTS_encrypt(keys, tw, data)
+        assert (rc, ct) == orc.xts(keys, tw, data, True)
+        assert uaes.AES_XTS_decrypt(keys, tw, ct) == (0, data)
+    keys = rnd.randbytes(bits // 4)
+    assert uaes.AES_XTS_encrypt(keys, None, b"Q" * 48) == uaes.AES_XTS_encrypt(keys, bytes(16), b"Q" * 48)
+    # batched data units, including ciphertext stealing in every unit
+    for sector, count, first in [(4096, 33, 0), (512, 100, (1 << 40) + 7), (528, 9, 5), (16, 70, 1), (25, 40, 2)]:
+        vol = orc.splitmix(sector, sector * count)
+        rc, ct = uaes.xts_sectors(keys, first, sector, vol, True)
+        assert (rc, ct) == orc.xts_sectors(keys, first, sector, vol, True)
+        assert uaes.xts_sectors(keys, first, sector, ct, False) == (0, vol)
+
+
+@pytest.mark.parametrize("bits", [128, 192, 256])
+def test_gcm_vs_oracle(orc, bits):
+    rnd = random.Random(bits + 2)
+    for n in [0, 1, 16, 17, 4096, 65536 + 3, (256 << 10) - 16, (256 << 10), (1 << 20) + 16]:
+        key, nonce = rnd.randbytes(bits // 8), rnd.randbytes(12)
+        aad = rnd.randbytes(rnd.choice([0, 1, 16, 20, 4097]))
+        data = orc.splitmix(n + 1, n)
+        ct = uaes.AES_GCM_encrypt(key, nonce, aad, data)
+        assert ct == orc.gcm_encrypt(key, nonce, aad, data), n
+        assert uaes.AES_GCM_decrypt(key, nonce, aad, ct) == (0, data)
+        bad = bytearray(ct)
+        bad[rnd.randrange(len(bad))] ^= 0x40
+        assert uaes.AES_GCM_decrypt(key, nonce, aad, bytes(bad), prefill=0xCC) == (0x1A, b"\xcc" * n)   # N7
+
+
+def test_ghash_kernel_levels(orc):
+    """every level plan of the GHASH kernels: direct, one bulk level, two bulk levels"""
+    rnd = random.Random(77)
+    H = rnd.randbytes(16)
+    for nblocks, extra, alen in [(0, 0, 0), (1, 0, 5), (300, 7, 0), (16382, 0, 16), (16383, 0, 0), (16384, 1, 3),
+                                 (70000, 0, 0), (300000, 5, 33), (1500000, 0, 0)]:
+        ct = orc.splitmix(nblocks + 3, nblocks * 16 + extra)
+        aad = rnd.randbytes(alen)
+        assert uaes.ghash(H, aad, ct) == orc.ghash(H, aad, ct), (nblocks, extra, alen)
+
+
+# ---- BASELINE.json configurations ----------------------------------------------------
+def test_baseline_small_digests(orc, golden_dir):
+    d = load(golden_dir, "digests.json")
+    key16, key64, nonce = bytes(range(16)), bytes(range(64)), bytes(range(0xF0, 0xFC))
+    sha = lambda b: hashlib.sha256(b).hexdigest()
+    assert sha(uaes.AES_ECB_encrypt(key16, orc.splitmix(1, 4096))) == d["C1_ecb128_4KiB"]["sha256"]
+    assert sha(uaes.AES_CTR_encrypt(key16, nonce, orc.splitmix(2, 1 << 20))) == d["ctr128_1MiB_seed2"]["sha256"]
+    rc, secs = uaes.xts_sectors(key64, 0, 4096, orc.splitmix(3, 3 * 4096), True)
+    assert rc == 0 and sha(secs) == d["xts256_sectors0_2"]["sha256"]
+    ct = uaes.AES_GCM_encrypt(key16, nonce, b"", orc.splitmix(4, 1 << 20))
+    assert ct[-16:].hex() == d["gcm128_1MiB_seed4"]["tag"] and sha(ct) == d["gcm128_1MiB_seed4"]["sha256_ct_tag"]
+
+
+def _device_stream(orc, seed, nbytes):
+    import torch
+    host = np.empty(nbytes, dtype=np.uint8)
+    orc.splitmix_into(seed, host)
+    return torch.from_numpy(host).to("cuda:0")
+
+
+def _sha_of(t):
+    h = hashlib.sha256()
+    step = 1 << 28
+    for o in range(0, t.numel(), step):
+        h.update(t[o:o + step].cpu().numpy().tobytes())
+    return h.hexdigest()
+
+
+def test_C2_ctr128_1GiB_device_resident(orc, golden_dir):
+    """BASELINE configs[1]: bit-exact digest of the whole 1 GiB stream, plus the
+    size-independent properties (involution, shard concatenation)."""
+    import torch
+    d = load(golden_dir, "digests.json")["C2_ctr128_1GiB_seed2"]
+    key, ctr0 = bytes(range(16)), bytes(range(0xF0, 0xFC)) + b"\0\0\0\1"
+    src = _device_stream(orc, 2, 1 << 30)
+    dst = torch.empty_like(src)
+    uaes.ctr_xcrypt_dev(key, ctr0, 0, src, dst)
+    torch.cuda.synchronize()
+    assert bytes(dst[-32:].cpu().numpy()).hex() == d["tail"]
+    assert _sha_of(dst) == d["sha256"]
+    # shards: 8 x 128 MiB with block offsets == one call
+    sh = torch.empty_like(src)
+    for g in range(8):
+        lo, hi = g << 27, (g + 1) << 27
+        uaes.ctr_xcrypt_dev(key, ctr0, lo // 16, src[lo:hi], sh[lo:hi])
+    torch.cuda.synchronize()
+    assert torch.equal(sh, dst)
+    # involution, in place
+    uaes.ctr_xcrypt_dev(key, ctr0, 0, dst, dst)
+    torch.cuda.synchronize()
+    assert torch.equal(dst, src)
+
+
+def test_C3_xts256_sectors_device_resident(orc, golden_dir):
+    """BASELINE configs[2] at 2^18 sectors (1 GiB; the 2^20 digest is checked by
+    bench.py --workload xts): first sectors against the goldens, round trip, and
+    equality with per-range calls."""
+    import torch
+    d = load(golden_dir, "digests.json")
+    keys = bytes(range(64))
+    nsec = 1 << 18
+    src = _device_stream(orc, 3, nsec * 4096)
+    dst = torch.empty_like(src)
+    uaes.xts_sectors_dev(keys, 0, 4096, nsec, src, dst, encrypt=True)
+    torch.cuda.synchronize()
+    assert hashlib.sha256(dst[: 3 * 4096].cpu().numpy().tobytes()).hexdigest() == d["xts256_sectors0_2"]["sha256"]
+    tail = 1000
+    part = torch.empty(tail * 4096, dtype=torch.uint8, device="cuda:0")
+    uaes.xts_sectors_dev(keys, nsec - tail, 4096, tail, src[(nsec - tail) * 4096:], part, encrypt=True)
+    torch.cuda.synchronize()
+    assert torch.equal(part, dst[(nsec - tail) * 4096:])
+    rc, want = orc.xts_sectors(keys, nsec - 2, 4096, bytes(src[(nsec - 2) * 4096:].cpu().numpy()), True)
+    assert bytes(dst[(nsec - 2) * 4096:].cpu().numpy()) == want
+    uaes.xts_sectors_dev(keys, 0, 4096, nsec, dst, dst, encrypt=False)
+    torch.cuda.synchronize()
+    assert torch.equal(dst, src)
+
+
+def test_C4_gcm128_1GiB_device_resident(orc, golden_dir):
+    """BASELINE configs[3]: tag and digest of CT||tag for the 1 GiB message."""
+    import torch
+    d = load(golden_dir, "digests.json")["C4_gcm128_1GiB_seed4"]
+    key, nonce = bytes(range(16)), bytes(range(0xF0, 0xFC))
+    n = 1 << 30
+    src = _device_stream(orc, 4, n)
+    dst = torch.empty(n + 16, dtype=torch.uint8, device="cuda:0")
+    uaes.gcm_encrypt_dev(key, nonce, None, src, n, dst)
+    torch.cuda.synchronize()
+    assert bytes(dst[n:].cpu().numpy()).hex() == d["tag"]
+    assert _sha_of(dst) == d["sha256_ct_tag"]
+    status = torch.full((1,), -1, dtype=torch.int32, device="cuda:0")
+    back = torch.full((n,), 0xCC, dtype=torch.uint8, device="cuda:0")
+    uaes.gcm_decrypt_dev(key, nonce, None, dst, n, back, status)
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0 and torch.equal(back, src)
+    dst[12345] ^= 1
+    back.fill_(0xCC)
+    uaes.gcm_decrypt_dev(key, nonce, None, dst, n, back, status)
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0x1A and int(back.min().item()) == 0xCC     # untouched (N7)

@@ -1,0 +1,111 @@
+"""Multi-GPU sharding logic on CPU: partition arithmetic, and a world_size-2
+gloo run in which each rank processes its shard (the oracle stands in for the
+device kernels -- on the GPU box the default callables are the HIP engine) and
+the all-gathered stream must equal the single-call result."""
+import os
+import socket
+
+import pytest
+
+import micro_aes_amd.sharding as sh
+
+
+def test_shard_bounds():
+    for total in (0, 1, 15, 16, 17, 4096, 1 << 20, (1 << 20) + 5):
+        for world in (1, 2, 3, 8):
+            b = sh.shard_bounds(total, world, 16)
+            assert len(b) == world and sum(n for _, n in b) == total
+            pos = 0
+            for i, (s, n) in enumerate(b):
+                assert s == pos and (n == 0 or s % 16 == 0)
+                if s + n < total:
+                    assert n % 16 == 0
+                pos += n
+    # XTS: whole data units only
+    b = sh.shard_bounds(10 * 4096, 4, 4096)
+    assert [n // 4096 for _, n in b] == [3, 3, 3, 1]
+    assert sh.xts_shard_args(10, 4096, 100, 3, 4) == (9 * 4096, 1, 109)
+    assert sh.ctr_shard_args(1 << 30, 3, 8) == (3 << 27, 1 << 27, 3 << 23)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, total, q):
+    import torch
+    import torch.distributed as dist
+    from oracle.pyoracle import Oracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    orc = Oracle()
+    key, ctr0 = bytes(range(16)), bytes(range(0xF0, 0xFC)) + b"\x00\xff\xff\xfe"
+    stream = orc.splitmix(2, total)
+    cap = sh.shard_bounds(total, world, 16)[0][1]
+    start, n, off = sh.ctr_shard_args(total, rank, world)
+    src = torch.zeros(cap, dtype=torch.uint8)
+    src[:n] = torch.frombuffer(bytearray(stream[start:start + n]), dtype=torch.uint8)
+    dst = torch.zeros(cap, dtype=torch.uint8)
+
+    def cpu_cipher(k, c, boff, s, d, nbytes):       # test stand-in for uaes_ctr_xcrypt_at_dev
+        out = orc.ctr_xcrypt_at(k, c, boff, bytes(s[:nbytes].numpy()))
+        d[:nbytes] = torch.frombuffer(bytearray(out), dtype=torch.uint8)
+
+    gathered = torch.zeros(cap * world, dtype=torch.uint8)
+    sh.ctr_xcrypt_sharded(key, ctr0, total, src, dst, rank, world, cipher=cpu_cipher, gather_into=gathered)
+    got = b"".join(bytes(gathered[r * cap: r * cap + nn].numpy())
+                   for r, (_, nn) in enumerate(sh.shard_bounds(total, world, 16)))
+    want = orc.ctr_xcrypt_at(key, ctr0, 0, stream)
+
+    # XTS volume of 7 data units of 528 bytes, sharded by whole units
+    keys = bytes(range(64))
+    vol = orc.splitmix(3, 7 * 528)
+    xcap = sh.shard_bounds(7 * 528, world, 528)[0][1]
+    xs, ns, first = sh.xts_shard_args(7, 528, 1000, rank, world)
+    xsrc = torch.zeros(xcap, dtype=torch.uint8)
+    xsrc[: ns * 528] = torch.frombuffer(bytearray(vol[xs: xs + ns * 528]), dtype=torch.uint8)
+    xdst = torch.zeros(xcap, dtype=torch.uint8)
+
+    def cpu_xts(k, f, sb, nsec, s, d, enc):
+        rc, out = orc.xts_sectors(k, f, sb, bytes(s[: nsec * sb].numpy()), enc)
+        assert rc == 0
+        d[: nsec * sb] = torch.frombuffer(bytearray(out), dtype=torch.uint8)
+
+    xg = torch.zeros(xcap * world, dtype=torch.uint8)
+    sh.xts_sectors_sharded(keys, 1000, 528, 7, xsrc, xdst, rank, world, cipher=cpu_xts, gather_into=xg)
+    xgot = b"".join(bytes(xg[r * xcap: r * xcap + nn].numpy())
+                    for r, (_, nn) in enumerate(sh.shard_bounds(7 * 528, world, 528)))
+    xwant = orc.xts_sectors(keys, 1000, 528, vol, True)[1]
+    if rank == 0:
+        q.put((got == want, xgot == xwant))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_ctr_and_xts_sharded_world2_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    total = 100000 + 7                 # ragged tail lands on the last rank
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    import queue
+    import time
+    ok, t0 = None, time.time()
+    while ok is None and time.time() - t0 < 240:
+        try:
+            ok = q.get(timeout=2)
+        except queue.Empty:
+            assert all(p.exitcode in (None, 0) for p in procs), "a rank died"
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert ok == (True, True)
