@@ -1,0 +1,273 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X AES engine.
+
+Metric (BASELINE.json): GiB/s encrypted, AES-128-CTR over a 1 GiB synthetic
+buffer per GPU (configs[1]); with --gpus N each rank encrypts its own 1 GiB
+shard of an N GiB stream (configs[4], weak scaling, no data-path collective --
+the optional ciphertext all-gather is timed separately and never part of
+`value`).  A "step" is one full pass of the hot path over the resident buffer.
+
+    python bench.py                       # 1 GPU, defaults
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \\
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel against
+the 8 TB/s HBM peak with ALGORITHMIC bytes (32 B per 16-byte block: read the
+plaintext, write the ciphertext); `cpu_baseline` times the
+compiled REFERENCE (oracle/_ref, or the oracle restatement if that did not
+travel) on this box's host cores on a bounded sample of the same workload.
+Other workloads (--workload ecb|xts|gcm) are for profiling, not the bench line.
+"""
+import argparse
+import ctypes
+import hashlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GIB = 1 << 30
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
+KEY16 = bytes(range(16))
+KEY64 = bytes(range(64))
+NONCE = bytes(range(0xF0, 0xFC))
+CTR0 = NONCE + b"\x00\x00\x00\x01"   # iv || CTR_START_VALUE (micro_aes.c:968-971)
+
+
+def splitmix_device(torch, seed, nbytes, word0, device):
+    """SURVEY.md 8d synthetic stream, generated on the GPU (int64 wraps mod 2^64)."""
+    out = torch.empty(nbytes // 8, dtype=torch.int64, device=device)
+    chunk = 1 << 24
+
+    def s64(v):
+        v &= (1 << 64) - 1
+        return v - (1 << 64) if v >> 63 else v
+
+    def lsr(z, k):
+        return (z >> k) & ((1 << (64 - k)) - 1)
+
+    for o in range(0, out.numel(), chunk):
+        n = min(chunk, out.numel() - o)
+        w = torch.arange(word0 + o + 1, word0 + o + 1 + n, dtype=torch.int64, device=device)
+        z = w * s64(0x9E3779B97F4A7C15) + s64(seed)
+        z = (z ^ lsr(z, 30)) * s64(0xBF58476D1CE4E5B9)
+        z = (z ^ lsr(z, 27)) * s64(0x94D049BB133111EB)
+        out[o:o + n] = z ^ lsr(z, 31)
+    return out.view(torch.uint8)
+
+
+def sha_of(t):
+    h = hashlib.sha256()
+    step = 1 << 28
+    for o in range(0, t.numel(), step):
+        h.update(t[o:o + step].cpu().numpy().tobytes())
+    return h.hexdigest()
+
+
+def cpu_baseline(workload):
+    """Reference CPU path on this host: 1 core (the reference is single-threaded
+    and non re-entrant, micro_aes.c:72) and, via fork, all cores."""
+    import numpy as np
+    from oracle.pyoracle import Oracle, Reference
+    orc = Oracle()
+    use_ref = Reference.available(128)
+    sample = {"ctr": 512 << 20, "ecb": 512 << 20, "xts": 512 << 20, "gcm": 64 << 20}[workload]
+    buf = np.empty(sample, dtype=np.uint8)
+    orc.splitmix_into(2, buf)
+    out = np.empty(sample + 16, dtype=np.uint8)
+    src, dst = ctypes.c_void_p(buf.ctypes.data), ctypes.c_void_p(out.ctypes.data)
+    if use_ref:
+        L = Reference(256 if workload == "xts" else 128).L
+        fn = {"ctr": lambda n: L.AES_CTR_encrypt(KEY16, NONCE, src, n, dst),
+              "ecb": lambda n: L.AES_ECB_encrypt(KEY16, src, n, dst),
+              "xts": lambda n: [L.AES_XTS_encrypt(KEY64, (s).to_bytes(16, "little"),
+                                                  ctypes.c_void_p(buf.ctypes.data + s * 4096), 4096,
+                                                  ctypes.c_void_p(out.ctypes.data + s * 4096))
+                                for s in range(n // 4096)],
+              "gcm": lambda n: L.AES_GCM_encrypt(KEY16, NONCE, None, 0, src, n, dst)}[workload]
+    else:
+        L = orc.L
+        fn = {"ctr": lambda n: L.orc_ctr_encrypt(128, KEY16, NONCE, src, n, dst),
+              "ecb": lambda n: L.orc_ecb_encrypt(128, KEY16, src, n, dst),
+              "xts": lambda n: L.orc_xts_sectors(256, KEY64, 0, 4096, n // 4096, src, dst, 1),
+              "gcm": lambda n: L.orc_gcm_encrypt(128, KEY16, NONCE, None, 0, src, n, dst)}[workload]
+    t0 = time.perf_counter()
+    fn(sample)
+    t1 = time.perf_counter() - t0
+    res = {"value": round(sample / GIB / t1, 5), "unit": "GiB/s", "cores": 1,
+           "kind": "reference" if use_ref else "port",
+           "sample": "%d MiB of the same synthetic %s workload, single call, gcc -O3" % (sample >> 20, workload)}
+    # all cores: fork P processes over contiguous shards (throughput-equivalent;
+    # the reference API cannot start a CTR shard at an offset)
+    P = os.cpu_count() or 1
+    per = max((sample // 4) // 4096 * 4096, 4096)
+    t0 = time.perf_counter()
+    pids = []
+    for _ in range(P):
+        pid = os.fork()
+        if pid == 0:
+            fn(per)
+            os._exit(0)
+        pids.append(pid)
+    for pid in pids:
+        os.waitpid(pid, 0)
+    tp = time.perf_counter() - t0
+    res["all_cores"] = {"value": round(P * per / GIB / tp, 4), "unit": "GiB/s", "cores": P,
+                        "sample": "%d forked processes x %d MiB" % (P, per >> 20)}
+    try:
+        with open("/proc/cpuinfo") as f:
+            res["cpu"] = [l.split(":", 1)[1].strip() for l in f if l.startswith("model name")][0]
+    except Exception:
+        pass
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="ctr", choices=["ctr", "ecb", "xts", "gcm"])
+    ap.add_argument("--bytes", type=int, default=GIB, help="bytes per GPU")
+    ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--gather", action="store_true", help="also time the RCCL ciphertext all-gather")
+    a = ap.parse_args()
+
+    import torch
+    import micro_aes_amd as uaes
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("launch with torch.distributed.run --nproc-per-node %d" % a.gpus)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    n = a.bytes
+    seed = {"ctr": 2, "ecb": 1, "xts": 3, "gcm": 4}[a.workload]
+    # rank g owns bytes [g*n, (g+1)*n) of the world*n stream
+    src = splitmix_device(torch, seed, n, rank * (n // 8), dev)
+    dst = torch.empty(n + 16, dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream()
+
+    if a.workload == "ctr":
+        def step():
+            uaes.ctr_xcrypt_dev(KEY16, CTR0, rank * (n // 16), src, dst, nbytes=n, stream=st)
+    elif a.workload == "ecb":
+        def step():
+            uaes.ecb_dev(KEY16, src, dst, nbytes=n, stream=st)
+    elif a.workload == "xts":
+        def step():
+            uaes.xts_sectors_dev(KEY64, rank * (n // 4096), 4096, n // 4096, src, dst, stream=st)
+    else:
+        def step():
+            uaes.gcm_encrypt_dev(KEY16, NONCE, None, src, n, dst, stream=st)
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
+    t0 = time.perf_counter()
+    ev[0].record(st)
+    for i in range(a.steps):
+        step()
+        ev[i + 1].record(st)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    per_step_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(a.steps)]
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    gather_ms = None
+    if dist and a.gather:
+        full = torch.empty(world * n, dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(full, dst[:n])
+        torch.cuda.synchronize()
+        dist.barrier()
+        g0 = time.perf_counter()
+        dist.all_gather_into_tensor(full, dst[:n])
+        torch.cuda.synchronize()
+        dist.barrier()
+        gather_ms = (time.perf_counter() - g0) * 1e3
+        del full
+
+    verify = None
+    if not a.no_verify:
+        with open(os.path.join(ROOT, "tests", "golden", "digests.json")) as f:
+            gold = json.load(f)
+        if a.workload == "ctr" and n == GIB and rank == 0:
+            verify = sha_of(dst[:n]) == gold["C2_ctr128_1GiB_seed2"]["sha256"]
+        elif a.workload == "gcm" and n == GIB and rank == 0:
+            verify = bytes(dst[n:].cpu().numpy()).hex() == gold["C4_gcm128_1GiB_seed4"]["tag"]
+        elif a.workload == "xts" and n == 4 * GIB and rank == 0:
+            verify = sha_of(dst[:n]) == gold["C3_xts256_2p20_sectors_seed3"]["sha256"]
+        else:
+            # other ranks / sizes: head of the shard against the CPU oracle
+            from oracle.pyoracle import Oracle
+            orc = Oracle()
+            m = min(n, 1 << 16)
+            head = orc.splitmix(seed, m, word0=rank * (n // 8))
+            got = bytes(dst[:m].cpu().numpy())
+            if a.workload == "ctr":
+                verify = got == orc.ctr_xcrypt_at(KEY16, CTR0, rank * (n // 16), head)
+            elif a.workload == "ecb":
+                verify = got == orc.ecb_encrypt(KEY16, head)
+            elif a.workload == "xts":
+                verify = got == orc.xts_sectors(KEY64, rank * (n // 4096), 4096, head, True)[1]
+        if dist:
+            v = torch.tensor([1 if verify in (True, None) else 0], device=dev)
+            dist.all_reduce(v, op=dist.ReduceOp.MIN)
+            verify = bool(v.item())
+
+    if rank == 0:
+        total_gib = world * n * a.steps / GIB
+        kern_ms = sum(per_step_ms) / len(per_step_ms)
+        algo_bytes = 2.0 * n                       # read n + write n per launch
+        achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
+        names = {"ctr": "AES-128-CTR", "ecb": "AES-128-ECB", "xts": "AES-256-XTS 4 KiB sectors", "gcm": "AES-128-GCM"}
+        line = {
+            "metric": "GiB/s encrypted (AES-128-CTR, 1 GiB buffer per GPU)" if a.workload == "ctr"
+                      else "GiB/s encrypted (%s)" % names[a.workload],
+            "value": round(total_gib / elapsed, 2), "unit": "GiB/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "%s, %d MiB per GPU, device-resident, splitmix64 seed %d"
+                                   % (names[a.workload], n >> 20, seed),
+                       "parallelism": "shard%d" % world, "bytes_per_gpu": n},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel_ms": round(kern_ms, 4),
+                         "kernel_ms_min": round(min(per_step_ms), 4)},
+            "verified": verify,
+        }
+        if gather_ms is not None:
+            line["gather_ms"] = round(gather_ms, 3)
+        if not a.no_cpu and world == 1:
+            line["cpu_baseline"] = cpu_baseline(a.workload)
+        print(json.dumps(line))
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -67,6 +67,15 @@ def engine():
     global _lib
     if _lib is not None:
         return _lib
+    # torch wheels bundle their own HIP runtime (torch/lib/libamdhip64.so, same
+    # SONAME as /opt/rocm's).  Two HIP runtimes in one process do not work
+    # ("No HIP GPUs are available" from whichever initialises second), so when
+    # torch is installed let it load its runtime FIRST; our library then binds
+    # to that same copy.  A plain C caller simply uses the system ROCm.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     path = lib_path()
     if not os.path.exists(path):
         raise EngineError("HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; "
