@@ -15,6 +15,8 @@
  */
 #include <hip/hip_runtime.h>
 #include <string.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include "uaes_aes.hip.h"
 #include "uaes_gf.h"
 #include "uaes_device.h"
@@ -82,30 +84,32 @@ __device__ __forceinline__ void ctr_words(const uaesk_ctr &c, u64 i, u32 (&w)[4]
     w[3] = bswap32((u32)v);
 }
 
-template <int NR>
-__global__ __launch_bounds__(UAES_WG) void k_ctr(uaesk_rk rk, uaesk_tables tb, uaesk_ctr ctr,
+/* U = blocks per lane per iteration, NT = tables in LDS (4: one workgroup per
+ * CU, 2: two workgroups = 32 waves per CU, <= 64 VGPRs)                      */
+template <int NR, int U, int NT>
+__global__ __launch_bounds__(UAES_WG, (NT == 2 ? 8 : 4)) void k_ctr(uaesk_rk rk, uaesk_tables tb, uaesk_ctr ctr,
                                                  const uint4 *__restrict__ in, uint4 *__restrict__ out,
                                                  u64 nfull, u32 rem, const int *__restrict__ gate)
 {
     if (gate && *gate != 0) return;            /* GCM decrypt: tag mismatch -> untouched */
-    fill_enc_tables(tb.te0);
+    fill_enc_tables<NT>(tb.te0);
     const LaneConst lc = make_lane_const();
-    const u64 stride = (u64)gridDim.x * UAES_WG * UAES_U;
+    const u64 stride = (u64)gridDim.x * UAES_WG * U;
 
-    for (u64 base = (u64)blockIdx.x * UAES_WG * UAES_U; base < nfull; base += stride) {
-        u32 s[UAES_U][4];
-        uint4 d[UAES_U];
-        u64 idx[UAES_U];
+    for (u64 base = (u64)blockIdx.x * UAES_WG * U; base < nfull; base += stride) {
+        u32 s[U][4];
+        uint4 d[U];
+        u64 idx[U];
 #pragma unroll
-        for (int u = 0; u < UAES_U; ++u) {
+        for (int u = 0; u < U; ++u) {
             idx[u] = base + (u64)u * UAES_WG + threadIdx.x;
             d[u] = make_uint4(0, 0, 0, 0);
             if (idx[u] < nfull) d[u] = in[idx[u]];
             ctr_words(ctr, idx[u], s[u]);
         }
-        enc_blocks<NR, UAES_U>(s, rk, lc);
+        enc_blocks<NR, U, NT>(s, rk, lc);
 #pragma unroll
-        for (int u = 0; u < UAES_U; ++u)
+        for (int u = 0; u < U; ++u)
             if (idx[u] < nfull)
                 out[idx[u]] = make_uint4(d[u].x ^ s[u][0], d[u].y ^ s[u][1], d[u].z ^ s[u][2], d[u].w ^ s[u][3]);
     }
@@ -114,11 +118,243 @@ __global__ __launch_bounds__(UAES_WG) void k_ctr(uaesk_rk rk, uaesk_tables tb, u
     if (rem && blockIdx.x == 0 && threadIdx.x == 0) {
         u32 s1[1][4];
         ctr_words(ctr, nfull, s1[0]);
-        enc_blocks<NR, 1>(s1, rk, lc);
+        enc_blocks<NR, 1, NT>(s1, rk, lc);
         const unsigned char *src = (const unsigned char *)(in + nfull);
         unsigned char *dst = (unsigned char *)(out + nfull);
         for (u32 i = 0; i < rem; ++i)
             dst[i] = src[i] ^ (unsigned char)(s1[0][i >> 2] >> (8 * (i & 3)));
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* CTR with shared rounds 1-2                                                 */
+/* ------------------------------------------------------------------------ */
+/* Consecutive counter blocks differ only in their low bytes.  Cut the stream
+ * into GROUPS of 256 counters that share bytes 0..14 (group G, position p =
+ * counter byte 15), and pin every lane to one p for the whole kernel:
+ *
+ *   after AddRoundKey(0) only state byte 15 depends on p; after round 1 only
+ *   column 0 does:  col0 = A(G) ^ Te3[p ^ rk0.b15],  col1..3 = uniform(G);
+ *   after round 2 every column is  Te_k[one byte of col0] ^ U_c(G).
+ *
+ * A(G) changes only when counter bits 40..47 change, so the four round-2
+ * lookups on col0's bytes are per-LANE constants L_c, computed once; the
+ * uniform parts U_c(G) cost 27 lookups per GROUP (one lane of wave 0 per group,
+ * handed over through LDS).  A block therefore enters round 3 as L ^ U(G):
+ * 4 XORs instead of 32 table lookups -- 128 lookups per AES-128 block instead
+ * of 160 on a path whose bound is the LDS lookup rate (32 lanes/clk/CU).
+ *
+ * Workgroup = 16 waves = 4 quads; wave w owns positions p = 64*(w&3) + lane and
+ * walks groups (w>>2) + 4k of a 64-group chunk, four groups per iteration, so
+ * each wave-level load/store is still one contiguous 1 KiB segment.           */
+#define CTRS_CHUNK 64u                       /* groups per chunk               */
+#define CTRS_BUF   (UAES_LDS_ENC)            /* 2 x 64 x 32 B after the tables */
+#define UAES_LDS_CTRS (UAES_LDS_ENC + 2u * CTRS_CHUNK * 32u)
+
+/* Handles only chunks [chunk_lo, chunk_hi) that lie completely inside the
+ * stream, so the hot loop has no bounds checks; the (at most two) ragged edge
+ * chunks and the byte tail go to the generic k_ctr (launcher below).         */
+template <int NR>
+__global__ __launch_bounds__(UAES_WG, 4) void k_ctr_shared(uaesk_rk rk, uaesk_tables tb, uaesk_ctr ctr,
+                                                           const uint4 *__restrict__ in, uint4 *__restrict__ out,
+                                                           u64 chunk_lo, u64 chunk_hi, const int *__restrict__ gate)
+{
+    if (gate && *gate != 0) return;
+    fill_enc_tables<4>(tb.te0);
+    const LaneConst lc = make_lane_const();
+    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const u32 p = ((wave & 3u) << 6) | lane;               /* counter byte 15 of this lane */
+    const u32 quad = wave >> 2;
+    const u32 c0 = (u32)ctr.v0 & 0xffu;                    /* position of stream block 0   */
+    const u64 vbase = ctr.v0 - c0;                         /* group-aligned counter        */
+    uint4 *buf = (uint4 *)(uaes_lds + CTRS_BUF);
+    const u32 lane_blk = (quad << 8) | p;                  /* lane's block offset inside a 4-group stripe */
+
+    /* byte 15 after AddRoundKey(0), as a Te3 lookup operand in byte 3 */
+    const u32 x15 = ((p << 24) ^ rk.w[3]) & 0xff000000u;
+    u32 a_cur = 0, L0 = 0, L1 = 0, L2 = 0, L3 = 0;
+    bool have_l = false;
+    u32 parity = 0;
+
+    /* The unit of work of a wave is (chunk, m): four groups = 4 blocks per lane.
+     * Block index of (chunk, m, u, lane) = ((chunk*64 + 4*(4m+u)) << 8) - c0 [uniform]
+     *                                    + lane_blk                       [per lane].
+     * The plaintext of unit t+1 is requested before the rounds of unit t, so
+     * HBM latency hides under ~500 table lookups.                           */
+    u64 chunk = chunk_lo + blockIdx.x;
+    u32 m = 0;
+    uint4 d_cur[UAES_U], d_nxt[UAES_U];
+    if (chunk < chunk_hi) {
+#pragma unroll
+        for (int u = 0; u < UAES_U; ++u)
+            d_cur[u] = (in + ((((chunk * CTRS_CHUNK) + 4u * u) << 8) - c0))[lane_blk];
+    }
+
+    while (chunk < chunk_hi) {
+        if (m == 0) {
+            if (wave == 0) {
+                /* uniform part of rounds 1 and 2 for group (chunk*64 + lane) */
+                const u64 g = chunk * CTRS_CHUNK + lane;
+                const u64 v = (vbase + (g << 8)) & 0x00FFFFFFFFFFFFFFull;
+                const u32 s0 = ctr.w0 ^ rk.w[0], s1 = ctr.w1 ^ rk.w[1];
+                const u32 s2 = bswap32((ctr.b8 << 24) | (u32)(v >> 32)) ^ rk.w[2];
+                const u32 s3 = (bswap32((u32)v) ^ rk.w[3]) & 0x00ffffffu;      /* byte 15 excluded */
+                const u32 A = xor3(tlook<0, 0>(s0, lc), tlook<1, 1>(s1, lc), tlook<2, 2>(s2, lc)) ^ rk.w[4];
+                const u32 c1 = xor3(xor3(tlook<0, 0>(s1, lc), tlook<1, 1>(s2, lc), tlook<2, 2>(s3, lc)), tlook<3, 3>(s0, lc), rk.w[5]);
+                const u32 c2 = xor3(xor3(tlook<0, 0>(s2, lc), tlook<1, 1>(s3, lc), tlook<2, 2>(s0, lc)), tlook<3, 3>(s1, lc), rk.w[6]);
+                const u32 c3 = xor3(xor3(tlook<0, 0>(s3, lc), tlook<1, 1>(s0, lc), tlook<2, 2>(s1, lc)), tlook<3, 3>(s2, lc), rk.w[7]);
+                const u32 u0 = xor3(tlook<1, 1>(c1, lc), tlook<2, 2>(c2, lc), tlook<3, 3>(c3, lc)) ^ rk.w[8];
+                const u32 u1 = xor3(tlook<0, 0>(c1, lc), tlook<1, 1>(c2, lc), tlook<2, 2>(c3, lc)) ^ rk.w[9];
+                const u32 u2 = xor3(tlook<0, 0>(c2, lc), tlook<1, 1>(c3, lc), tlook<3, 3>(c1, lc)) ^ rk.w[10];
+                const u32 u3 = xor3(tlook<0, 0>(c3, lc), tlook<2, 2>(c1, lc), tlook<3, 3>(c2, lc)) ^ rk.w[11];
+                buf[(parity * CTRS_CHUNK + lane) * 2 + 0] = make_uint4(u0, u1, u2, u3);
+                buf[(parity * CTRS_CHUNK + lane) * 2 + 1] = make_uint4(A, 0, 0, 0);
+            }
+            __syncthreads();
+        }
+
+        /* request the next unit's plaintext (clamped to this kernel's last chunk) */
+        u64 nchunk = chunk;
+        u32 nm = m + 1;
+        if (nm == CTRS_CHUNK / 16u) { nm = 0; nchunk += gridDim.x; }
+        {
+            const u64 lc_chunk = nchunk < chunk_hi ? nchunk : chunk;
+            const u32 lm = nchunk < chunk_hi ? nm : m;
+#pragma unroll
+            for (int u = 0; u < UAES_U; ++u)
+                d_nxt[u] = (in + ((((lc_chunk * CTRS_CHUNK) + 4u * (lm * UAES_U + u)) << 8) - c0))[lane_blk];
+        }
+
+        u32 s[UAES_U][4];
+#pragma unroll
+        for (int u = 0; u < UAES_U; ++u) {
+            const u32 gl = quad + 4u * (m * UAES_U + u);                   /* group within the chunk */
+            const uint4 uu = buf[(parity * CTRS_CHUNK + gl) * 2 + 0];
+            const u32 A = buf[(parity * CTRS_CHUNK + gl) * 2 + 1].x;
+            if (!have_l || A != a_cur) {                                   /* wave-uniform; ~never after the first time */
+                const u32 col0 = A ^ tlook<3, 3>(x15, lc);
+                L0 = tlook<0, 0>(col0, lc);
+                L1 = tlook<3, 3>(col0, lc);
+                L2 = tlook<2, 2>(col0, lc);
+                L3 = tlook<1, 1>(col0, lc);
+                a_cur = A;
+                have_l = true;
+            }
+            s[u][0] = L0 ^ uu.x; s[u][1] = L1 ^ uu.y; s[u][2] = L2 ^ uu.z; s[u][3] = L3 ^ uu.w;
+        }
+        enc_rounds_from<NR, UAES_U, 3, 4>(s, rk, lc);
+#pragma unroll
+        for (int u = 0; u < UAES_U; ++u) {
+            (out + ((((chunk * CTRS_CHUNK) + 4u * (m * UAES_U + u)) << 8) - c0))[lane_blk] =
+                make_uint4(d_cur[u].x ^ s[u][0], d_cur[u].y ^ s[u][1], d_cur[u].z ^ s[u][2], d_cur[u].w ^ s[u][3]);
+            d_cur[u] = d_nxt[u];
+        }
+        if (nm == 0) parity ^= 1u;
+        chunk = nchunk;
+        m = nm;
+    }
+}
+
+/* Same as k_ctr_shared with two blocks per lane per unit, their rounds half a
+ * round out of phase (enc_rounds_skewed).                                   */
+template <int NR>
+__global__ __launch_bounds__(UAES_WG, 4) void k_ctr_shared2(uaesk_rk rk, uaesk_tables tb, uaesk_ctr ctr,
+                                                           const uint4 *__restrict__ in, uint4 *__restrict__ out,
+                                                           u64 chunk_lo, u64 chunk_hi, const int *__restrict__ gate)
+{
+    if (gate && *gate != 0) return;
+    fill_enc_tables<4>(tb.te0);
+    const LaneConst lc = make_lane_const();
+    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const u32 p = ((wave & 3u) << 6) | lane;               /* counter byte 15 of this lane */
+    const u32 quad = wave >> 2;
+    const u32 c0 = (u32)ctr.v0 & 0xffu;                    /* position of stream block 0   */
+    const u64 vbase = ctr.v0 - c0;                         /* group-aligned counter        */
+    uint4 *buf = (uint4 *)(uaes_lds + CTRS_BUF);
+    const u32 lane_blk = (quad << 8) | p;                  /* lane's block offset inside a 4-group stripe */
+
+    /* byte 15 after AddRoundKey(0), as a Te3 lookup operand in byte 3 */
+    const u32 x15 = ((p << 24) ^ rk.w[3]) & 0xff000000u;
+    u32 a_cur = 0, L0 = 0, L1 = 0, L2 = 0, L3 = 0;
+    bool have_l = false;
+    u32 parity = 0;
+
+    /* The unit of work of a wave is (chunk, m): four groups = 4 blocks per lane.
+     * Block index of (chunk, m, u, lane) = ((chunk*64 + 4*(4m+u)) << 8) - c0 [uniform]
+     *                                    + lane_blk                       [per lane].
+     * The plaintext of unit t+1 is requested before the rounds of unit t, so
+     * HBM latency hides under ~500 table lookups.                           */
+    u64 chunk = chunk_lo + blockIdx.x;
+    u32 m = 0;
+    uint4 d_cur[2], d_nxt[2];
+    if (chunk < chunk_hi) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            d_cur[u] = (in + ((((chunk * CTRS_CHUNK) + 4u * u) << 8) - c0))[lane_blk];
+    }
+
+    while (chunk < chunk_hi) {
+        if (m == 0) {
+            if (wave == 0) {
+                /* uniform part of rounds 1 and 2 for group (chunk*64 + lane) */
+                const u64 g = chunk * CTRS_CHUNK + lane;
+                const u64 v = (vbase + (g << 8)) & 0x00FFFFFFFFFFFFFFull;
+                const u32 s0 = ctr.w0 ^ rk.w[0], s1 = ctr.w1 ^ rk.w[1];
+                const u32 s2 = bswap32((ctr.b8 << 24) | (u32)(v >> 32)) ^ rk.w[2];
+                const u32 s3 = (bswap32((u32)v) ^ rk.w[3]) & 0x00ffffffu;      /* byte 15 excluded */
+                const u32 A = xor3(tlook<0, 0>(s0, lc), tlook<1, 1>(s1, lc), tlook<2, 2>(s2, lc)) ^ rk.w[4];
+                const u32 c1 = xor3(xor3(tlook<0, 0>(s1, lc), tlook<1, 1>(s2, lc), tlook<2, 2>(s3, lc)), tlook<3, 3>(s0, lc), rk.w[5]);
+                const u32 c2 = xor3(xor3(tlook<0, 0>(s2, lc), tlook<1, 1>(s3, lc), tlook<2, 2>(s0, lc)), tlook<3, 3>(s1, lc), rk.w[6]);
+                const u32 c3 = xor3(xor3(tlook<0, 0>(s3, lc), tlook<1, 1>(s0, lc), tlook<2, 2>(s1, lc)), tlook<3, 3>(s2, lc), rk.w[7]);
+                const u32 u0 = xor3(tlook<1, 1>(c1, lc), tlook<2, 2>(c2, lc), tlook<3, 3>(c3, lc)) ^ rk.w[8];
+                const u32 u1 = xor3(tlook<0, 0>(c1, lc), tlook<1, 1>(c2, lc), tlook<2, 2>(c3, lc)) ^ rk.w[9];
+                const u32 u2 = xor3(tlook<0, 0>(c2, lc), tlook<1, 1>(c3, lc), tlook<3, 3>(c1, lc)) ^ rk.w[10];
+                const u32 u3 = xor3(tlook<0, 0>(c3, lc), tlook<2, 2>(c1, lc), tlook<3, 3>(c2, lc)) ^ rk.w[11];
+                buf[(parity * CTRS_CHUNK + lane) * 2 + 0] = make_uint4(u0, u1, u2, u3);
+                buf[(parity * CTRS_CHUNK + lane) * 2 + 1] = make_uint4(A, 0, 0, 0);
+            }
+            __syncthreads();
+        }
+
+        /* request the next unit's plaintext (clamped to this kernel's last chunk) */
+        u64 nchunk = chunk;
+        u32 nm = m + 1;
+        if (nm == CTRS_CHUNK / 8u) { nm = 0; nchunk += gridDim.x; }
+        {
+            const u64 lc_chunk = nchunk < chunk_hi ? nchunk : chunk;
+            const u32 lm = nchunk < chunk_hi ? nm : m;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                d_nxt[u] = (in + ((((lc_chunk * CTRS_CHUNK) + 4u * (lm * 2u + u)) << 8) - c0))[lane_blk];
+        }
+
+        u32 s[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const u32 gl = quad + 4u * (m * 2u + u);                   /* group within the chunk */
+            const uint4 uu = buf[(parity * CTRS_CHUNK + gl) * 2 + 0];
+            const u32 A = buf[(parity * CTRS_CHUNK + gl) * 2 + 1].x;
+            if (!have_l || A != a_cur) {                                   /* wave-uniform; ~never after the first time */
+                const u32 col0 = A ^ tlook<3, 3>(x15, lc);
+                L0 = tlook<0, 0>(col0, lc);
+                L1 = tlook<3, 3>(col0, lc);
+                L2 = tlook<2, 2>(col0, lc);
+                L3 = tlook<1, 1>(col0, lc);
+                a_cur = A;
+                have_l = true;
+            }
+            s[u][0] = L0 ^ uu.x; s[u][1] = L1 ^ uu.y; s[u][2] = L2 ^ uu.z; s[u][3] = L3 ^ uu.w;
+        }
+        enc_rounds_skewed<NR, 3>(s[0], s[1], rk, lc);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            (out + ((((chunk * CTRS_CHUNK) + 4u * (m * 2u + u)) << 8) - c0))[lane_blk] =
+                make_uint4(d_cur[u].x ^ s[u][0], d_cur[u].y ^ s[u][1], d_cur[u].z ^ s[u][2], d_cur[u].w ^ s[u][3]);
+            d_cur[u] = d_nxt[u];
+        }
+        if (nm == 0) parity ^= 1u;
+        chunk = nchunk;
+        m = nm;
     }
 }
 
@@ -379,18 +615,96 @@ extern "C" int uaesk_ecb(void *stream, const uaesk_tables *tb, int nr, const uae
     return 0;
 }
 
+/* UAES_CTR_VARIANT (debug knob, read once): "u<U>t<NT>", e.g. u4t4 (default) */
+static int ctr_variant()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("UAES_CTR_VARIANT");
+        int u = 4, t = 4;
+        if (e && sscanf(e, "u%dt%d", &u, &t) == 2) v = u * 10 + t;
+        else if (e && !strcmp(e, "shared4")) v = 1;       /* lock-step, 4 blocks per lane */
+        else v = 0;                                        /* default: skewed, 2 blocks per lane */
+    }
+    return v;
+}
+
+template <int NR, int U, int NT>
+static int launch_ctr_v(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek, const uaesk_ctr *ctr,
+                        const void *in, void *out, size_t len, const int *gate)
+{
+    const unsigned lds = NT == 2 ? UAES_LDS_ENC2 : UAES_LDS_ENC;
+    hipError_t e = set_lds(k_ctr<NR, U, NT>, lds);
+    if (e != hipSuccess) return (int)e;
+    const u64 nfull = len / 16;
+    const u32 rem = (u32)(len % 16);
+    unsigned grid = grid_for(nfull + (rem ? 1 : 0), (u64)UAES_WG * U);
+    if (NT == 2) {
+        const u64 want = (nfull + (rem ? 1 : 0) + (u64)UAES_WG * U - 1) / ((u64)UAES_WG * U);
+        const u64 cap = 2ull * (g_cus > 0 ? g_cus : 256);
+        grid = (unsigned)(want < cap ? (want ? want : 1) : cap);
+    }
+    hipLaunchKernelGGL((k_ctr<NR, U, NT>), dim3(grid), dim3(UAES_WG), lds, st, *ek, *tb, *ctr,
+                       (const uint4 *)in, (uint4 *)out, nfull, rem, gate);
+    return (int)hipGetLastError();
+}
+
+/* Shared-round kernel on the whole 64-group chunks, generic kernel on the
+ * ragged prefix/suffix (each < 16384 blocks) and the byte tail.              */
+template <int NR>
+static int launch_ctr_shared(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek, const uaesk_ctr *ctr,
+                             const void *in, void *out, size_t len, const int *gate)
+{
+    const u64 nfull = len / 16;
+    const u64 per_chunk = (u64)CTRS_CHUNK * 256;
+    const u32 c0 = (u32)ctr->v0 & 0xffu;
+    const u64 chunk_lo = c0 ? 1 : 0;
+    const u64 chunk_hi = (c0 + nfull) / per_chunk;
+    if (chunk_hi <= chunk_lo + 3)            /* small message: one generic launch */
+        return launch_ctr_v<NR, 4, 4>(st, tb, ek, ctr, in, out, len, gate);
+
+    hipError_t e = set_lds(k_ctr_shared<NR>, UAES_LDS_CTRS);
+    if (e == hipSuccess) e = set_lds(k_ctr_shared2<NR>, UAES_LDS_CTRS);
+    if (e != hipSuccess) return (int)e;
+    const unsigned grid = grid_for(chunk_hi - chunk_lo, 1);
+    if (ctr_variant() == 1)
+        hipLaunchKernelGGL((k_ctr_shared<NR>), dim3(grid), dim3(UAES_WG), UAES_LDS_CTRS, st, *ek, *tb, *ctr,
+                           (const uint4 *)in, (uint4 *)out, chunk_lo, chunk_hi, gate);
+    else
+        hipLaunchKernelGGL((k_ctr_shared2<NR>), dim3(grid), dim3(UAES_WG), UAES_LDS_CTRS, st, *ek, *tb, *ctr,
+                           (const uint4 *)in, (uint4 *)out, chunk_lo, chunk_hi, gate);
+    e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+
+    const u64 pre_end = chunk_lo * per_chunk - (chunk_lo ? c0 : 0);     /* blocks [0, pre_end) */
+    if (pre_end) {
+        int rc = launch_ctr_v<NR, 4, 4>(st, tb, ek, ctr, in, out, (size_t)pre_end * 16, gate);
+        if (rc) return rc;
+    }
+    const u64 suf = chunk_hi * per_chunk - c0;                          /* blocks [suf, nfull) + tail */
+    if (suf * 16 < len) {
+        uaesk_ctr c2 = *ctr;
+        c2.v0 = (ctr->v0 + suf) & 0x00FFFFFFFFFFFFFFull;
+        return launch_ctr_v<NR, 4, 4>(st, tb, ek, &c2, (const char *)in + suf * 16, (char *)out + suf * 16,
+                                      len - (size_t)suf * 16, gate);
+    }
+    return 0;
+}
+
 template <int NR>
 static int launch_ctr(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek, const uaesk_ctr *ctr,
                       const void *in, void *out, size_t len, const int *gate)
 {
-    hipError_t e = set_lds(k_ctr<NR>, UAES_LDS_ENC);
-    if (e != hipSuccess) return (int)e;
-    const u64 nfull = len / 16;
-    const u32 rem = (u32)(len % 16);
-    const unsigned grid = grid_for(nfull + (rem ? 1 : 0), (u64)UAES_WG * UAES_U);
-    hipLaunchKernelGGL((k_ctr<NR>), dim3(grid), dim3(UAES_WG), UAES_LDS_ENC, st, *ek, *tb, *ctr,
-                       (const uint4 *)in, (uint4 *)out, nfull, rem, gate);
-    return (int)hipGetLastError();
+    if (ctr_variant() <= 1) return launch_ctr_shared<NR>(st, tb, ek, ctr, in, out, len, gate);
+    switch (NR == 10 ? ctr_variant() : 44) {       /* variants are compiled for AES-128 only */
+    case 24: return launch_ctr_v<NR, 2, 4>(st, tb, ek, ctr, in, out, len, gate);
+    case 84: return launch_ctr_v<NR, 8, 4>(st, tb, ek, ctr, in, out, len, gate);
+    case 64: return launch_ctr_v<NR, 6, 4>(st, tb, ek, ctr, in, out, len, gate);
+    case 22: return launch_ctr_v<NR, 2, 2>(st, tb, ek, ctr, in, out, len, gate);
+    case 12: return launch_ctr_v<NR, 1, 2>(st, tb, ek, ctr, in, out, len, gate);
+    case 42: return launch_ctr_v<NR, 4, 2>(st, tb, ek, ctr, in, out, len, gate);
+    default: return launch_ctr_v<NR, 4, 4>(st, tb, ek, ctr, in, out, len, gate);
+    }
 }
 
 extern "C" int uaesk_ctr_xcrypt(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek,
