@@ -126,6 +126,44 @@ __global__ __launch_bounds__(UAES_WG, (NT == 2 ? 8 : 4)) void k_ctr(uaesk_rk rk,
     }
 }
 
+/* The blocks in front of / behind the whole chunks of the shared-round kernels
+ * (each side < 16384 blocks) and the byte tail: spread evenly over all
+ * workgroups, one block per thread through the plain 10/12/14-round path, so
+ * no separate launch (and no second 128 KiB table fill) is needed.           */
+template <int NR>
+__device__ __forceinline__ void ctr_edges(const uaesk_rk &rk, const uaesk_ctr &ctr,
+                                          const uint4 *__restrict__ in, uint4 *__restrict__ out,
+                                          u64 chunk_lo, u64 chunk_hi, u64 nfull, u32 rem, const LaneConst &lc)
+{
+    const u32 c0 = (u32)ctr.v0 & 0xffu;
+    const u64 per_chunk = 64ull * 256ull;
+    const u64 pre_end = chunk_lo * per_chunk - (chunk_lo ? c0 : 0);         /* blocks [0, pre_end)     */
+    const u64 suf = chunk_hi * per_chunk - c0;                              /* blocks [suf, nfull)     */
+    const u64 nedge = pre_end + (nfull - suf);
+    const u64 per = (nedge + gridDim.x - 1) / gridDim.x;
+    const u64 lo = (u64)blockIdx.x * per;
+    u64 hi = lo + per;
+    if (hi > nedge) hi = nedge;
+    for (u64 e = lo + threadIdx.x; e < hi; e += UAES_WG) {
+        const u64 i = e < pre_end ? e : suf + (e - pre_end);
+        u32 s1[1][4];
+        ctr_words(ctr, i, s1[0]);
+        enc_blocks<NR, 1, 4>(s1, rk, lc);
+        const uint4 d = in[i];
+        out[i] = make_uint4(d.x ^ s1[0][0], d.y ^ s1[0][1], d.z ^ s1[0][2], d.w ^ s1[0][3]);
+    }
+    /* reference N3: len%16 tail bytes use Enc(ctr_final) (mixThenXor, :949) */
+    if (rem && blockIdx.x == 0 && threadIdx.x == 0) {
+        u32 s1[1][4];
+        ctr_words(ctr, nfull, s1[0]);
+        enc_blocks<NR, 1, 4>(s1, rk, lc);
+        const unsigned char *src = (const unsigned char *)(in + nfull);
+        unsigned char *dst = (unsigned char *)(out + nfull);
+        for (u32 i = 0; i < rem; ++i)
+            dst[i] = src[i] ^ (unsigned char)(s1[0][i >> 2] >> (8 * (i & 3)));
+    }
+}
+
 /* ------------------------------------------------------------------------ */
 /* CTR with shared rounds 1-2                                                 */
 /* ------------------------------------------------------------------------ */
@@ -157,11 +195,13 @@ __global__ __launch_bounds__(UAES_WG, (NT == 2 ? 8 : 4)) void k_ctr(uaesk_rk rk,
 template <int NR>
 __global__ __launch_bounds__(UAES_WG, 4) void k_ctr_shared(uaesk_rk rk, uaesk_tables tb, uaesk_ctr ctr,
                                                            const uint4 *__restrict__ in, uint4 *__restrict__ out,
-                                                           u64 chunk_lo, u64 chunk_hi, const int *__restrict__ gate)
+                                                           u64 chunk_lo, u64 chunk_hi, u64 nfull, u32 rem,
+                                                           const int *__restrict__ gate)
 {
     if (gate && *gate != 0) return;
     fill_enc_tables<4>(tb.te0);
     const LaneConst lc = make_lane_const();
+    ctr_edges<NR>(rk, ctr, in, out, chunk_lo, chunk_hi, nfull, rem, lc);
     const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const u32 p = ((wave & 3u) << 6) | lane;               /* counter byte 15 of this lane */
     const u32 quad = wave >> 2;
@@ -260,11 +300,13 @@ __global__ __launch_bounds__(UAES_WG, 4) void k_ctr_shared(uaesk_rk rk, uaesk_ta
 template <int NR>
 __global__ __launch_bounds__(UAES_WG, 4) void k_ctr_shared2(uaesk_rk rk, uaesk_tables tb, uaesk_ctr ctr,
                                                            const uint4 *__restrict__ in, uint4 *__restrict__ out,
-                                                           u64 chunk_lo, u64 chunk_hi, const int *__restrict__ gate)
+                                                           u64 chunk_lo, u64 chunk_hi, u64 nfull, u32 rem,
+                                                           const int *__restrict__ gate)
 {
     if (gate && *gate != 0) return;
     fill_enc_tables<4>(tb.te0);
     const LaneConst lc = make_lane_const();
+    ctr_edges<NR>(rk, ctr, in, out, chunk_lo, chunk_hi, nfull, rem, lc);
     const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const u32 p = ((wave & 3u) << 6) | lane;               /* counter byte 15 of this lane */
     const u32 quad = wave >> 2;
@@ -649,8 +691,8 @@ static int launch_ctr_v(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *
     return (int)hipGetLastError();
 }
 
-/* Shared-round kernel on the whole 64-group chunks, generic kernel on the
- * ragged prefix/suffix (each < 16384 blocks) and the byte tail.              */
+/* Shared-round kernel: whole 64-group chunks in the pipelined main loop, the
+ * ragged prefix/suffix and the byte tail in its prologue (ctr_edges).        */
 template <int NR>
 static int launch_ctr_shared(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek, const uaesk_ctr *ctr,
                              const void *in, void *out, size_t len, const int *gate)
@@ -667,28 +709,14 @@ static int launch_ctr_shared(hipStream_t st, const uaesk_tables *tb, const uaesk
     if (e == hipSuccess) e = set_lds(k_ctr_shared2<NR>, UAES_LDS_CTRS);
     if (e != hipSuccess) return (int)e;
     const unsigned grid = grid_for(chunk_hi - chunk_lo, 1);
+    const u32 rem = (u32)(len % 16);
     if (ctr_variant() == 1)
         hipLaunchKernelGGL((k_ctr_shared<NR>), dim3(grid), dim3(UAES_WG), UAES_LDS_CTRS, st, *ek, *tb, *ctr,
-                           (const uint4 *)in, (uint4 *)out, chunk_lo, chunk_hi, gate);
+                           (const uint4 *)in, (uint4 *)out, chunk_lo, chunk_hi, nfull, rem, gate);
     else
         hipLaunchKernelGGL((k_ctr_shared2<NR>), dim3(grid), dim3(UAES_WG), UAES_LDS_CTRS, st, *ek, *tb, *ctr,
-                           (const uint4 *)in, (uint4 *)out, chunk_lo, chunk_hi, gate);
-    e = hipGetLastError();
-    if (e != hipSuccess) return (int)e;
-
-    const u64 pre_end = chunk_lo * per_chunk - (chunk_lo ? c0 : 0);     /* blocks [0, pre_end) */
-    if (pre_end) {
-        int rc = launch_ctr_v<NR, 4, 4>(st, tb, ek, ctr, in, out, (size_t)pre_end * 16, gate);
-        if (rc) return rc;
-    }
-    const u64 suf = chunk_hi * per_chunk - c0;                          /* blocks [suf, nfull) + tail */
-    if (suf * 16 < len) {
-        uaesk_ctr c2 = *ctr;
-        c2.v0 = (ctr->v0 + suf) & 0x00FFFFFFFFFFFFFFull;
-        return launch_ctr_v<NR, 4, 4>(st, tb, ek, &c2, (const char *)in + suf * 16, (char *)out + suf * 16,
-                                      len - (size_t)suf * 16, gate);
-    }
-    return 0;
+                           (const uint4 *)in, (uint4 *)out, chunk_lo, chunk_hi, nfull, rem, gate);
+    return (int)hipGetLastError();
 }
 
 template <int NR>
