@@ -242,6 +242,14 @@ def main():
         kern_ms = sum(per_step_ms) / len(per_step_ms)
         algo_bytes = 2.0 * n                       # read n + write n per launch
         achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                t = json.load(f).get(a.workload)
+            if t and t["bytes_per_gpu"] == n:
+                traffic = t["traffic_bytes"]          # PMC pass of the same command, per launch
+        except Exception:
+            pass
         names = {"ctr": "AES-128-CTR", "ecb": "AES-128-ECB", "xts": "AES-256-XTS 4 KiB sectors", "gcm": "AES-128-GCM"}
         line = {
             "metric": "GiB/s encrypted (AES-128-CTR, 1 GiB buffer per GPU)" if a.workload == "ctr"
@@ -255,7 +263,8 @@ def main():
                                    % (names[a.workload], n >> 20, seed),
                        "parallelism": "shard%d" % world, "bytes_per_gpu": n},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "algorithmic_bytes": int(algo_bytes),
                          "kernel_ms": round(kern_ms, 4),
                          "kernel_ms_min": round(min(per_step_ms), 4)},
             "verified": verify,

@@ -20,7 +20,7 @@
 #define MICRO_AES_H_
 
 #ifndef AES___
-#define AES___ 128          /* or 192 / 256; must match the library linked */
+#define AES___ 128 /* or 192 / 256 (also settable with -DAES___=...); must match the library linked */
 #endif
 
 #define BLOCKCIPHERS 1

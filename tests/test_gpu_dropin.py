@@ -1,0 +1,44 @@
+"""Drop-in proof on the GPU: the reference's OWN callers -- its testvectors/
+harness (aes_testvectors.c) and its main.c -- compiled unchanged against
+include/micro_aes.h and linked to libmicro_aes_hip_<bits>.so (recipe:
+oracle/Makefile, target `dropin`; binaries travel in oracle/_ref/), must report
+the same verdicts and case counts as when they are built on micro_aes.c."""
+import os
+import re
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(ROOT, "oracle", "_ref")
+EXPECT = {128: {"GCM": 375, "XTS": 800}, 192: {"GCM": 375}, 256: {"GCM": 375, "XTS": 600}}
+
+
+@pytest.mark.parametrize("bits", [128, 192, 256])
+def test_reference_harness_runs_on_the_hip_library(bits, tmp_path, golden_dir):
+    exe = os.path.join(REF, "harness_hip_%d" % bits)
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/harness_hip_%d was not built (needs /root/reference at build time)" % bits)
+    for f in os.listdir(golden_dir):
+        if f.endswith(".rsp"):
+            os.symlink(os.path.join(golden_dir, f), tmp_path / f)
+    r = subprocess.run([exe], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = dict((m, int(n)) for m, n in re.findall(
+        r"Verifying vectors: AES%d-(\w+)\s+Nmber of tests:\s*(\d+), All Passed!" % bits, r.stdout))
+    assert got == EXPECT[bits], r.stdout
+
+
+@pytest.mark.parametrize("bits", [128, 192, 256])
+def test_reference_main_c_runs_on_the_hip_library(bits):
+    exe = os.path.join(REF, "main_hip_%d" % bits)
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/main_hip_%d was not built" % bits)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "FAILED" not in r.stdout, r.stdout + r.stderr
+    passed = re.findall(r"AES-%d (\w+) (?:en|de)cryption: PASSED!" % bits, r.stdout)
+    want = {128: ["ECB", "ECB", "CTR", "CTR", "XTS", "XTS", "GCM", "GCM"],
+            192: [], 256: ["XTS", "XTS", "GCM", "GCM"]}[bits]
+    assert passed == want, r.stdout
