@@ -76,6 +76,7 @@ __device__ __forceinline__ u32 bswap32(u32 v)
  * bits 16..23 = 64 KiB region of the table pair                            */
 struct LaneConst {
     u32 t[4];
+    u32 m1;          /* 0x0000ff00 held in a VGPR (all-VGPR bitop3 issues faster) */
 };
 
 __device__ __forceinline__ LaneConst make_lane_const()
@@ -85,6 +86,8 @@ __device__ __forceinline__ LaneConst make_lane_const()
 #pragma unroll
     for (u32 k = 0; k < 4; ++k)
         lc.t[k] = slot | ((k & 1u) << 7) | ((k >> 1) << 16);
+    lc.m1 = 0x0000ff00u;
+    asm volatile("" : "+v"(lc.m1));           /* keep it in a VGPR */
     return lc;
 }
 
@@ -92,8 +95,16 @@ __device__ __forceinline__ LaneConst make_lane_const()
 template <int TBL, int BYTE>
 __device__ __forceinline__ u32 tlook(u32 w, const LaneConst &lc)
 {
-    /* D.b0 = lc.b0, D.b1 = w.byte[BYTE], D.b2 = lc.b2, D.b3 = 0 */
-    const u32 addr = __builtin_amdgcn_perm(w, lc.t[TBL], 0x0c020000u | ((4u + BYTE) << 8));
+    u32 addr;
+    if (BYTE == 1) {
+        /* the index byte already sits at bits 8..15: (w & 0xff00) | lane constant is ONE
+         * v_bitop3_b32 on VGPR operands (~2.9 issue cycles vs ~4.5 for v_perm_b32,
+         * profiles/ubench/r01_valurate.log)                                          */
+        addr = __builtin_amdgcn_bitop3_b32(w, lc.m1, lc.t[TBL], 0xea);   /* (a & b) | c */
+    } else {
+        /* D.b0 = lc.b0, D.b1 = w.byte[BYTE], D.b2 = lc.b2, D.b3 = 0 */
+        addr = __builtin_amdgcn_perm(w, lc.t[TBL], 0x0c020000u | ((4u + BYTE) << 8));
+    }
     return lds_word(addr);
 }
 
@@ -264,9 +275,12 @@ __device__ __forceinline__ void combine16(const u32 (&t)[16], const u32 *rk, u32
  * and address building, so its LDS queue never drains (a wave can have at most
  * 15 LDS operations outstanding, and the compiler's default schedule for the
  * lock-step version drains them to zero every ~12 lookups).                 */
-template <int NR, int FIRST>
-__device__ __forceinline__ void enc_rounds_skewed(u32 (&sa)[4], u32 (&sb)[4], const uaesk_rk &rk, const LaneConst &lc)
+/* RKV: round keys FIRST..NR as an array indexed from 0 (may live in VGPRs: a
+ * v_bitop3_b32 with an SGPR operand issues ~1.5 cycles slower than all-VGPR) */
+template <int NR, int FIRST, typename RKV>
+__device__ __forceinline__ void enc_rounds_skewed(u32 (&sa)[4], u32 (&sb)[4], const RKV &rkv, const LaneConst &lc)
 {
+#define rkp(r) (&rkv.w[4 * ((r) - FIRST)])
     u32 ta[16], tb[16];
     issue16<false>(sa, ta, lc);
 #pragma unroll
@@ -274,17 +288,18 @@ __device__ __forceinline__ void enc_rounds_skewed(u32 (&sa)[4], u32 (&sb)[4], co
         __builtin_amdgcn_sched_barrier(0);
         issue16<false>(sb, tb, lc);
         __builtin_amdgcn_sched_barrier(0);
-        combine16<false>(ta, &rk.w[4 * r], sa);
+        combine16<false>(ta, rkp(r), sa);
         if (r + 1 < NR) issue16<false>(sa, ta, lc); else issue16<true>(sa, ta, lc);
         __builtin_amdgcn_sched_barrier(0);
-        combine16<false>(tb, &rk.w[4 * r], sb);
+        combine16<false>(tb, rkp(r), sb);
     }
     __builtin_amdgcn_sched_barrier(0);
     issue16<true>(sb, tb, lc);
     __builtin_amdgcn_sched_barrier(0);
-    combine16<true>(ta, &rk.w[4 * NR], sa);
+    combine16<true>(ta, rkp(NR), sa);
     __builtin_amdgcn_sched_barrier(0);
-    combine16<true>(tb, &rk.w[4 * NR], sb);
+    combine16<true>(tb, rkp(NR), sb);
+#undef rkp
 }
 
 /* ---- decryption rounds (equivalent inverse cipher, FIPS-197 sec. 5.3.5) - */

@@ -317,6 +317,11 @@ __global__ __launch_bounds__(UAES_WG, 4) void k_ctr_shared2(uaesk_rk rk, uaesk_t
 
     /* byte 15 after AddRoundKey(0), as a Te3 lookup operand in byte 3 */
     const u32 x15 = ((p << 24) ^ rk.w[3]) & 0xff000000u;
+    /* round keys 3..NR (wave-uniform: they stay in SGPRs; forcing them into VGPRs to
+     * speed up v_bitop3 issue measured 3 % SLOWER -- more VGPRs, lower clock)        */
+    struct { u32 w[4 * (NR - 2)]; } rkv;
+#pragma unroll
+    for (int i = 0; i < 4 * (NR - 2); ++i) rkv.w[i] = rk.w[12 + i];
     u32 a_cur = 0, L0 = 0, L1 = 0, L2 = 0, L3 = 0;
     bool have_l = false;
     u32 parity = 0;
@@ -387,7 +392,7 @@ __global__ __launch_bounds__(UAES_WG, 4) void k_ctr_shared2(uaesk_rk rk, uaesk_t
             }
             s[u][0] = L0 ^ uu.x; s[u][1] = L1 ^ uu.y; s[u][2] = L2 ^ uu.z; s[u][3] = L3 ^ uu.w;
         }
-        enc_rounds_skewed<NR, 3>(s[0], s[1], rk, lc);
+        enc_rounds_skewed<NR, 3>(s[0], s[1], rkv, lc);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             (out + ((((chunk * CTRS_CHUNK) + 4u * (m * 2u + u)) << 8) - c0))[lane_blk] =
