@@ -135,6 +135,9 @@ def main():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--gather", action="store_true", help="also time the RCCL ciphertext all-gather")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + --single-device: dry-run the multi-rank code path on a 1-GPU box")
+    ap.add_argument("--single-device", action="store_true", help="all ranks use cuda:0 (dry run only)")
     a = ap.parse_args()
 
     import torch
@@ -146,12 +149,18 @@ def main():
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             sys.exit("launch with torch.distributed.run --nproc-per-node %d" % a.gpus)
+    if a.single_device:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)       # RCCL over xGMI
+        else:
+            dist.init_process_group("gloo")
+    cdev = dev if a.backend == "nccl" else torch.device("cpu")   # where collective scalars live
 
     n = a.bytes
     seed = {"ctr": 2, "ecb": 1, "xts": 3, "gcm": 4}[a.workload]
@@ -192,12 +201,12 @@ def main():
     elapsed = time.perf_counter() - t0
     per_step_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(a.steps)]
     if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     gather_ms = None
-    if dist and a.gather:
+    if dist and a.gather and a.backend == "nccl":
         full = torch.empty(world * n, dtype=torch.uint8, device=dev)
         dist.all_gather_into_tensor(full, dst[:n])
         torch.cuda.synchronize()
@@ -233,7 +242,7 @@ def main():
             elif a.workload == "xts":
                 verify = got == orc.xts_sectors(KEY64, rank * (n // 4096), 4096, head, True)[1]
         if dist:
-            v = torch.tensor([1 if verify in (True, None) else 0], device=dev)
+            v = torch.tensor([1 if verify in (True, None) else 0], device=cdev)
             dist.all_reduce(v, op=dist.ReduceOp.MIN)
             verify = bool(v.item())
 
