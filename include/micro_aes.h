@@ -1,6 +1,7 @@
 /*
  * micro_aes.h -- drop-in replacement for the reference's public header, for
- * the four modes served by the MI355X engine (ECB, CTR, XTS, GCM).
+ * the modes served by the MI355X engine (ECB, CTR, XTS, GCM on the
+ * block-parallel hot path; CMAC and CCM for the remaining NIST .rsp files).
  *
  * Same function names, argument order, return types and configuration macros
  * as polfosol/micro-AES v11 (micro_aes.h:17-129, :173-181, :239-249, :256-266,
@@ -32,14 +33,14 @@
 #define XEX      1
 #define XTS      1
 #define GCM      1
+#define CMAC     1          /* serial CBC-MAC chains: one GPU lane (uaes_mac.hip) */
+#define CCM      1
 
 #define CBC      0          /* serial chains and MAC-only modes: not on the  */
 #define CFB      0          /* GPU hot path           */
 #define OFB      0
 #define KWA      0
 #define FPE      0
-#define CMAC     0
-#define CCM      0
 #define EAX      0
 #define EAXP     0
 #define SIV      0
@@ -57,6 +58,8 @@ enum constant_parameters_of_modes
 {
     CTR_START_VALUE = 1,
     CTR_IV_LENGTH   = 12,
+    CCM_NONCE_LEN   = 11,
+    CCM_TAG_LEN     = 16,
     GCM_NONCE_LEN   = 12,
     GCM_TAG_LEN     = 16,
 #if AES___ == 256 || AES___ == 192
@@ -95,6 +98,16 @@ void AES_GCM_encrypt(const uint8_t *key, const uint8_t *nonce,
 char AES_GCM_decrypt(const uint8_t *key, const uint8_t *nonce,
                      const void *aData, const size_t aDataLen,
                      const void *crtxt, const size_t crtxtLen, void *pntxt);
+
+void AES_CCM_encrypt(const uint8_t *key, const uint8_t *nonce,
+                     const void *aData, const size_t aDataLen,
+                     const void *pntxt, const size_t ptextLen, void *crtxt);
+char AES_CCM_decrypt(const uint8_t *key, const uint8_t *nonce,
+                     const void *aData, const size_t aDataLen,
+                     const void *crtxt, const size_t crtxtLen, void *pntxt);
+
+void AES_CMAC(const uint8_t *key,
+              const void *data, const size_t dataSize, uint8_t mac[16]);
 
 #ifdef __cplusplus
 }

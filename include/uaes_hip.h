@@ -119,6 +119,25 @@ int uaes_gcm_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
 int uaes_ghash(const uint8_t H[16], const void *aData, size_t aDataLen,
                const void *crtxt, size_t crtxtLen, uint8_t gh[16]);
 
+/* ---- CMAC: replaces AES_CMAC ----------------------------------------------
+ * micro_aes.h (CMAC section), micro_aes.c:1108-1118.  A CBC-MAC chain is serial:
+ * one GPU lane walks it (kept on the device so that no cipher code runs on the
+ * host); throughput is ~10 MB/s, meant for the short messages MACs are used on. */
+int uaes_cmac(int keybits, const uint8_t *key,
+              const void *data, size_t dataSize, uint8_t mac[16]);
+
+/* ---- CCM: replaces AES_CCM_encrypt / AES_CCM_decrypt ----------------------
+ * micro_aes.c:1268-1314.  11-byte nonce (CCM_NONCE_LEN), 16-byte tag
+ * (CCM_TAG_LEN) appended at crtxt + ptextLen.  Like the reference, decrypt
+ * runs CTR first and authenticates the result: on a mismatch it returns
+ * UAES_E_AUTHENTICATION and the (unauthenticated) text is left in pntxt.     */
+int uaes_ccm_encrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
+                     const void *aData, size_t aDataLen,
+                     const void *pntxt, size_t ptextLen, void *crtxt);
+int uaes_ccm_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
+                     const void *aData, size_t aDataLen,
+                     const void *crtxt, size_t crtxtLen, void *pntxt);
+
 /* ---- asynchronous, device-resident variants -----------------------------
  * All data pointers are device pointers, 16-byte aligned; `stream` is a
  * hipStream_t (NULL = default stream).  The call only enqueues work.  One

@@ -36,12 +36,14 @@ EXPORTS = [
     "uaes_ecb_encrypt", "uaes_ecb_decrypt", "uaes_ctr_xcrypt", "uaes_ctr_xcrypt_at",
     "uaes_xts_encrypt", "uaes_xts_decrypt", "uaes_xts_sectors",
     "uaes_gcm_encrypt", "uaes_gcm_decrypt", "uaes_ghash",
+    "uaes_cmac", "uaes_ccm_encrypt", "uaes_ccm_decrypt",
     "uaes_ecb_dev", "uaes_ctr_xcrypt_at_dev", "uaes_xts_sectors_dev",
     "uaes_gcm_encrypt_dev", "uaes_gcm_decrypt_dev",
 ]
 COMPAT_EXPORTS = [
     "AES_ECB_encrypt", "AES_ECB_decrypt", "AES_CTR_encrypt", "AES_CTR_decrypt",
     "AES_XTS_encrypt", "AES_XTS_decrypt", "AES_GCM_encrypt", "AES_GCM_decrypt",
+    "AES_CCM_encrypt", "AES_CCM_decrypt", "AES_CMAC",
 ]
 
 
@@ -96,6 +98,9 @@ def engine():
     for n in ("uaes_gcm_encrypt", "uaes_gcm_decrypt"):
         getattr(L, n).argtypes = [i, vp, vp, vp, sz, vp, sz, vp]
     L.uaes_ghash.argtypes = [vp, vp, sz, vp, sz, vp]
+    L.uaes_cmac.argtypes = [i, vp, vp, sz, vp]
+    for n in ("uaes_ccm_encrypt", "uaes_ccm_decrypt"):
+        getattr(L, n).argtypes = [i, vp, vp, vp, sz, vp, sz, vp]
     L.uaes_ecb_dev.argtypes = [i, vp, i, vp, sz, vp, vp]
     L.uaes_ctr_xcrypt_at_dev.argtypes = [i, vp, vp, u64, vp, sz, vp, vp]
     L.uaes_xts_sectors_dev.argtypes = [i, vp, u64, sz, sz, vp, vp, i, vp]
@@ -211,6 +216,31 @@ def AES_GCM_decrypt(key, nonce, aData, crtxt_and_tag, prefill=0):
     o = _out(n, prefill)
     rc = _check(engine().uaes_gcm_decrypt(_bits(key), _in(key), _in(nonce), _in(aData), len(aData),
                                           _in(crtxt_and_tag), n, o), "AES_GCM_decrypt")
+    return rc, bytes(o)[:n]
+
+
+def AES_CMAC(key, data):
+    """micro_aes.c:1108.  Returns the 16-byte CMAC."""
+    o = _out(16)
+    _check(engine().uaes_cmac(_bits(key), _in(key), _in(data), len(data), o), "AES_CMAC")
+    return bytes(o)
+
+
+def AES_CCM_encrypt(key, nonce, aData, pntxt):
+    """micro_aes.c:1268.  11-byte nonce; returns ciphertext || 16-byte tag."""
+    o = _out(len(pntxt) + 16)
+    _check(engine().uaes_ccm_encrypt(_bits(key), _in(key), _in(nonce), _in(aData), len(aData),
+                                     _in(pntxt), len(pntxt), o), "AES_CCM_encrypt")
+    return bytes(o)[: len(pntxt) + 16]
+
+
+def AES_CCM_decrypt(key, nonce, aData, crtxt_and_tag, prefill=0):
+    """micro_aes.c:1294.  Returns (code, text); like the reference the decrypted
+    text is returned even when the code is 0x1A."""
+    n = len(crtxt_and_tag) - 16
+    o = _out(n, prefill)
+    rc = _check(engine().uaes_ccm_decrypt(_bits(key), _in(key), _in(nonce), _in(aData), len(aData),
+                                          _in(crtxt_and_tag), n, o), "AES_CCM_decrypt")
     return rc, bytes(o)[:n]
 
 

@@ -75,3 +75,23 @@ char AES_GCM_decrypt(const uint8_t *key, const uint8_t *nonce,
     return soft("AES_GCM_decrypt", uaes_gcm_decrypt(KB, key, nonce, aData, aDataLen, crtxt, crtxtLen, pntxt),
                 M_DECRYPTION_ERROR);
 }
+
+void AES_CCM_encrypt(const uint8_t *key, const uint8_t *nonce,
+                     const void *aData, const size_t aDataLen,
+                     const void *pntxt, const size_t ptextLen, void *crtxt)
+{
+    must("AES_CCM_encrypt", uaes_ccm_encrypt(KB, key, nonce, aData, aDataLen, pntxt, ptextLen, crtxt));
+}
+
+char AES_CCM_decrypt(const uint8_t *key, const uint8_t *nonce,
+                     const void *aData, const size_t aDataLen,
+                     const void *crtxt, const size_t crtxtLen, void *pntxt)
+{
+    return soft("AES_CCM_decrypt", uaes_ccm_decrypt(KB, key, nonce, aData, aDataLen, crtxt, crtxtLen, pntxt),
+                M_DECRYPTION_ERROR);
+}
+
+void AES_CMAC(const uint8_t *key, const void *data, const size_t dataSize, uint8_t mac[16])
+{
+    must("AES_CMAC", uaes_cmac(KB, key, data, dataSize, mac));
+}

@@ -77,6 +77,17 @@ int uaesk_ghash(void *stream, const uint8_t *H_host,
                 const void *aad, size_t aad_len, const void *ct, size_t ct_len,
                 void *scratch, void *gh_out16);
 
+/* CMAC (AES_CMAC, micro_aes.c:1108): mac16 <- CMAC_K(data); all device pointers. */
+int uaesk_cmac(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek,
+               const void *data, size_t len, void *mac16);
+
+/* CCM (AES_CCM_encrypt/decrypt, micro_aes.c:1268-1314), 11-byte nonce (host),
+ * 16-byte tag at out+len / in+len; decrypt writes *status = 0 / 0x1A.        */
+int uaesk_ccm(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek,
+              int decrypt, const uint8_t *nonce11,
+              const void *aad, size_t aad_len,
+              const void *in, size_t len, void *out, int *status);
+
 /* Device self-test of the primitives; writes a bitmask of failures.        */
 int uaesk_selftest(void *stream, const uaesk_tables *tb, const uaesk_rk *ek128,
                    const uaesk_rk *dk128, unsigned *d_result);

@@ -1,0 +1,241 @@
+/*
+ * uaes_mac.hip -- the CBC-MAC based modes of the remaining NIST .rsp files
+ * (SURVEY.md section 8f-1): CMAC and the authentication half of CCM.
+ *
+ *   k_cmac     <- AES_CMAC :1108-1118, cMac :576-590, getSubkeys :593-605,
+ *                 doubleBblock :434-444
+ *   k_ccm_tag  <- CCMtag :1222-1256 (used by AES_CCM_encrypt/decrypt :1268-1314;
+ *                 the CTR half is k_ctr with the CCM/GCM pre-increment)
+ *
+ * A CBC-MAC is a strictly serial chain (M <- Enc(M ^ X_i)), so there is nothing
+ * to spread over lanes: one lane of one workgroup walks the message through the
+ * same LDS-resident T-tables as the block-parallel kernels (~1.5 us per block).
+ * These kernels exist for completeness of the drop-in API -- all cipher work
+ * stays on the GPU -- not for throughput.
+ */
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include "uaes_aes.hip.h"
+#include "uaes_device.h"
+
+static inline hipStream_t S(void *s) { return (hipStream_t)s; }
+
+struct Blk {
+    u32 w[4];
+};
+
+/* 16 bytes at p, zero padded after `avail` bytes */
+__device__ __forceinline__ Blk ld_block(const unsigned char *p, u64 avail)
+{
+    Blk b = { { 0, 0, 0, 0 } };
+    if (avail >= 16 && (((uintptr_t)p) & 15u) == 0) {
+        const uint4 v = *(const uint4 *)p;
+        b.w[0] = v.x; b.w[1] = v.y; b.w[2] = v.z; b.w[3] = v.w;
+        return b;
+    }
+    const u32 n = avail < 16 ? (u32)avail : 16u;
+    for (u32 i = 0; i < n; ++i) b.w[i >> 2] |= (u32)p[i] << (8 * (i & 3));
+    return b;
+}
+
+template <int NR>
+__device__ __forceinline__ void enc1(Blk &b, const uaesk_rk &rk, const LaneConst &lc)
+{
+    u32 s[1][4] = { { b.w[0], b.w[1], b.w[2], b.w[3] } };
+    enc_blocks<NR, 1, 4>(s, rk, lc);
+    b.w[0] = s[0][0]; b.w[1] = s[0][1]; b.w[2] = s[0][2]; b.w[3] = s[0][3];
+}
+
+/* big-endian doubling in GF(2^128) (doubleBblock): <<1, carry -> ^0x87 in the last byte */
+__device__ __forceinline__ Blk dbl_be(Blk b)
+{
+    u64 hi = ((u64)bswap32(b.w[0]) << 32) | bswap32(b.w[1]);
+    u64 lo = ((u64)bswap32(b.w[2]) << 32) | bswap32(b.w[3]);
+    const u64 carry = hi >> 63;
+    hi = (hi << 1) | (lo >> 63);
+    lo = (lo << 1) ^ (carry ? 0x87ull : 0ull);
+    Blk r;
+    r.w[0] = bswap32((u32)(hi >> 32)); r.w[1] = bswap32((u32)hi);
+    r.w[2] = bswap32((u32)(lo >> 32)); r.w[3] = bswap32((u32)lo);
+    return r;
+}
+
+__device__ __forceinline__ void xor_blk(Blk &a, const Blk &b)
+{
+    a.w[0] ^= b.w[0]; a.w[1] ^= b.w[1]; a.w[2] ^= b.w[2]; a.w[3] ^= b.w[3];
+}
+
+__device__ __forceinline__ void st_bytes(unsigned char *dst, const Blk &b)
+{
+    for (u32 i = 0; i < 16; ++i) dst[i] = (unsigned char)(b.w[i >> 2] >> (8 * (i & 3)));
+}
+
+/* M <- Enc(M ^ X_i) over the zero-padded 16-byte blocks of [p, p+len)   (xMac :551-570) */
+template <int NR>
+__device__ __forceinline__ void cbcmac_absorb(Blk &m, const unsigned char *p, u64 len,
+                                              const uaesk_rk &rk, const LaneConst &lc)
+{
+    for (u64 off = 0; off < len; off += 16) {
+        const Blk x = ld_block(p + off, len - off);
+        xor_blk(m, x);
+        enc1<NR>(m, rk, lc);
+    }
+}
+
+template <int NR>
+__global__ __launch_bounds__(UAES_WG) void k_cmac(uaesk_rk rk, uaesk_tables tb,
+                                                  const unsigned char *__restrict__ data, u64 len,
+                                                  unsigned char *__restrict__ mac)
+{
+    fill_enc_tables<4>(tb.te0);
+    if (threadIdx.x != 0) return;
+    const LaneConst lc = make_lane_const();
+    Blk k1 = { { 0, 0, 0, 0 } };
+    enc1<NR>(k1, rk, lc);                        /* L = Enc(0)                   */
+    k1 = dbl_be(k1);                             /* K1 = 2L                      */
+    const Blk k2 = dbl_be(k1);                   /* K2 = 4L                      */
+    const u32 s = len ? (u32)((len - 1) % 16) + 1 : 0;      /* size of the last block */
+    Blk m = { { 0, 0, 0, 0 } };
+    cbcmac_absorb<NR>(m, data, len - s, rk, lc);
+    Blk last = ld_block(data + (len - s), s);
+    if (s < 16) {
+        last.w[s >> 2] ^= 0x80u << (8 * (s & 3));            /* 10* padding, then K2 */
+        xor_blk(last, k2);
+    } else {
+        xor_blk(last, k1);
+    }
+    xor_blk(m, last);
+    enc1<NR>(m, rk, lc);
+    st_bytes(mac, m);
+}
+
+/* mode 0: write the tag to tag_io; mode 1: compare with tag_io, *status = 0 / 0x1A */
+template <int NR>
+__global__ __launch_bounds__(UAES_WG) void k_ccm_tag(uaesk_rk rk, uaesk_tables tb, uint4 iv4,
+                                                     const unsigned char *__restrict__ aad, u64 aad_len,
+                                                     const unsigned char *__restrict__ pt, u64 pt_len,
+                                                     int mode, unsigned char *tag_io, int *status)
+{
+    fill_enc_tables<4>(tb.te0);
+    if (threadIdx.x != 0) return;
+    const LaneConst lc = make_lane_const();
+    const Blk iv = { { iv4.x, iv4.y, iv4.z, iv4.w } };
+    unsigned char b0[16], a[16];
+    st_bytes(b0, iv);
+    b0[0] |= (16 - 2) << 2;                               /* CCM_TAG_LEN = 16 (:1230)          */
+    {
+        u64 n = pt_len;                                   /* xorBEint(M, ptextLen, LAST)      */
+        int pos = 15;
+        do { b0[pos--] ^= (unsigned char)n; } while (n >>= 8);
+    }
+    for (int i = 0; i < 16; ++i) a[i] = 0;
+    u64 s = 0;
+    Blk m;
+    if (aad_len) {
+        b0[0] |= 0x40;
+        m = ld_block(b0, 16);
+        enc1<NR>(m, rk, lc);
+        int p = 1;
+        if (aad_len > 0xFEFFull) { p += 4; a[0] = 0xFF; a[1] = 0xFE; }
+        {
+            u64 n = aad_len;                              /* xorBEint(A, aDataLen, p)          */
+            int pos = p;
+            do { a[pos--] ^= (unsigned char)n; } while (n >>= 8);
+        }
+        ++p;
+        s = 16 - p;
+        const u64 take = aad_len < s ? aad_len : s;
+        for (u64 i = 0; i < take; ++i) a[p + i] = aad[i];
+    } else {
+        m = ld_block(b0, 16);
+    }
+    {
+        const Blk ab = ld_block(a, 16);                   /* xMac(A, 16): also encrypts B0 when there is no AAD */
+        xor_blk(m, ab);
+        enc1<NR>(m, rk, lc);
+    }
+    if (aad_len > s) cbcmac_absorb<NR>(m, aad + s, aad_len - s, rk, lc);
+    cbcmac_absorb<NR>(m, pt, pt_len, rk, lc);
+    Blk e = iv;
+    enc1<NR>(e, rk, lc);                                  /* tag = Enc(iv) ^ CBC-MAC           */
+    xor_blk(m, e);
+    if (mode == 0) {
+        st_bytes(tag_io, m);
+    } else {
+        u32 diff = 0;
+        for (u32 i = 0; i < 16; ++i) diff |= (u32)tag_io[i] ^ ((m.w[i >> 2] >> (8 * (i & 3))) & 0xffu);
+        *status = diff ? 0x1A : 0;
+    }
+}
+
+#define DISPATCH_NR(nr, CALL)                         \
+    switch (nr) {                                     \
+    case 10: { constexpr int NR = 10; CALL; } break;  \
+    case 12: { constexpr int NR = 12; CALL; } break;  \
+    case 14: { constexpr int NR = 14; CALL; } break;  \
+    default: return (int)hipErrorInvalidValue;        \
+    }
+
+template <int NR>
+static int launch_cmac(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek,
+                       const void *data, size_t len, void *mac)
+{
+    hipError_t e = hipFuncSetAttribute((const void *)k_cmac<NR>, hipFuncAttributeMaxDynamicSharedMemorySize, UAES_LDS_ENC);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((k_cmac<NR>), dim3(1), dim3(UAES_WG), UAES_LDS_ENC, st, *ek, *tb,
+                       (const unsigned char *)data, (u64)len, (unsigned char *)mac);
+    return (int)hipGetLastError();
+}
+
+extern "C" int uaesk_cmac(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek,
+                          const void *data, size_t len, void *mac16)
+{
+    DISPATCH_NR(nr, return (launch_cmac<NR>(S(stream), tb, ek, data, len, mac16)));
+    return 0;
+}
+
+template <int NR>
+static int launch_ccm_tag(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek, uint4 iv,
+                          const void *aad, size_t aad_len, const void *pt, size_t pt_len,
+                          int mode, void *tag_io, int *status)
+{
+    hipError_t e = hipFuncSetAttribute((const void *)k_ccm_tag<NR>, hipFuncAttributeMaxDynamicSharedMemorySize, UAES_LDS_ENC);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((k_ccm_tag<NR>), dim3(1), dim3(UAES_WG), UAES_LDS_ENC, st, *ek, *tb, iv,
+                       (const unsigned char *)aad, (u64)aad_len, (const unsigned char *)pt, (u64)pt_len,
+                       mode, (unsigned char *)tag_io, status);
+    return (int)hipGetLastError();
+}
+
+/* nonce11 is a host pointer; everything else device memory.  encrypt: tag over
+ * `in` (the plaintext) written at out+len, then CTR in -> out.  decrypt: CTR
+ * in -> out first, then the tag over the decrypted text is compared with the
+ * 16 bytes at in+len: like the reference (:1304-1312, SABOTAGE is a no-op in
+ * its default build) the plaintext stays written even when *status = 0x1A.   */
+extern "C" int uaesk_ccm(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek,
+                         int decrypt, const uint8_t *nonce11,
+                         const void *aad, size_t aad_len,
+                         const void *in, size_t len, void *out, int *status)
+{
+    unsigned char ivb[16] = { 14 - 11 };                 /* iv = { 14 - CCM_NONCE_LEN, nonce, 0... } (:1273) */
+    memcpy(ivb + 1, nonce11, 11);
+    uint4 iv;
+    memcpy(&iv, ivb, 16);
+    uaesk_ctr c;
+    memcpy(&c.w0, ivb, 4);
+    memcpy(&c.w1, ivb + 4, 4);
+    c.b8 = ivb[8];
+    c.v0 = ((uint64_t)ivb[9] << 48) | ((uint64_t)ivb[10] << 40) | ((uint64_t)ivb[11] << 32) | 1u;   /* pre-increment */
+    int rc;
+    if (!decrypt) {
+        DISPATCH_NR(nr, rc = (launch_ccm_tag<NR>(S(stream), tb, ek, iv, aad, aad_len, in, len, 0,
+                                                 (unsigned char *)out + len, nullptr)));
+        if (rc) return rc;
+        return uaesk_ctr_xcrypt(stream, tb, nr, ek, &c, in, out, len, nullptr);
+    }
+    rc = uaesk_ctr_xcrypt(stream, tb, nr, ek, &c, in, out, len, nullptr);
+    if (rc) return rc;
+    DISPATCH_NR(nr, rc = (launch_ccm_tag<NR>(S(stream), tb, ek, iv, aad, aad_len, out, len, 1,
+                                             (unsigned char *)in + len, status)));
+    return rc;
+}

@@ -53,6 +53,9 @@ class Oracle:
         L.orc_xts_sectors.argtypes = [i, vp, u64, sz, sz, vp, vp, i]; L.orc_xts_sectors.restype = C.c_char
         L.orc_gcm_encrypt.argtypes = [i, vp, vp, vp, sz, vp, sz, vp]; L.orc_gcm_encrypt.restype = None
         L.orc_gcm_decrypt.argtypes = [i, vp, vp, vp, sz, vp, sz, vp]; L.orc_gcm_decrypt.restype = C.c_char
+        L.orc_cmac.argtypes = [i, vp, vp, sz, vp]; L.orc_cmac.restype = None
+        L.orc_ccm_encrypt.argtypes = [i, vp, vp, vp, sz, vp, sz, vp]; L.orc_ccm_encrypt.restype = None
+        L.orc_ccm_decrypt.argtypes = [i, vp, vp, vp, sz, vp, sz, vp]; L.orc_ccm_decrypt.restype = C.c_char
         L.orc_gf128_mul.argtypes = [vp, vp]; L.orc_gf128_mul.restype = None
         L.orc_ghash.argtypes = [vp, vp, sz, vp, sz, vp]; L.orc_ghash.restype = None
         L.orc_fill_splitmix.argtypes = [u64, u64, sz, vp]; L.orc_fill_splitmix.restype = None
@@ -116,6 +119,24 @@ class Oracle:
                                     _buf(ct_and_tag), n, o)
         return ord(rc), bytes(o)[:n]
 
+    def cmac(self, key, data):
+        o = _out(16)
+        self.L.orc_cmac(len(key) * 8, _buf(key), _buf(data), len(data), o)
+        return bytes(o)
+
+    def ccm_encrypt(self, key, nonce, aad, pt):
+        o = _out(len(pt) + 16)
+        self.L.orc_ccm_encrypt(len(key) * 8, _buf(key), _buf(nonce), _buf(aad), len(aad),
+                               _buf(pt), len(pt), o)
+        return bytes(o)[: len(pt) + 16]
+
+    def ccm_decrypt(self, key, nonce, aad, ct_and_tag, prefill=0xCC):
+        n = len(ct_and_tag) - 16
+        o = (C.c_uint8 * max(n, 1))(*([prefill] * max(n, 1)))
+        rc = self.L.orc_ccm_decrypt(len(key) * 8, _buf(key), _buf(nonce), _buf(aad), len(aad),
+                                    _buf(ct_and_tag), n, o)
+        return ord(rc), bytes(o)[:n]
+
     def gf128_mul(self, x, y):
         yy = _buf(y)
         self.L.orc_gf128_mul(_buf(x), yy)
@@ -163,6 +184,28 @@ class Reference:
             f.argtypes = [vp, vp, vp, sz, vp]; f.restype = C.c_char
         L.AES_GCM_encrypt.argtypes = [vp, vp, vp, sz, vp, sz, vp]; L.AES_GCM_encrypt.restype = None
         L.AES_GCM_decrypt.argtypes = [vp, vp, vp, sz, vp, sz, vp]; L.AES_GCM_decrypt.restype = C.c_char
+        L.AES_CCM_encrypt.argtypes = [vp, vp, vp, sz, vp, sz, vp]; L.AES_CCM_encrypt.restype = None
+        L.AES_CCM_decrypt.argtypes = [vp, vp, vp, sz, vp, sz, vp]; L.AES_CCM_decrypt.restype = C.c_char
+        L.AES_CMAC.argtypes = [vp, vp, sz, vp]; L.AES_CMAC.restype = None
+
+    def cmac(self, key, data):
+        self._chk(key)
+        o = _out(16)
+        self.L.AES_CMAC(_buf(key), _buf(data), len(data), o)
+        return bytes(o)
+
+    def ccm_encrypt(self, key, nonce, aad, pt):
+        self._chk(key)
+        o = _out(len(pt) + 16)
+        self.L.AES_CCM_encrypt(_buf(key), _buf(nonce), _buf(aad), len(aad), _buf(pt), len(pt), o)
+        return bytes(o)[: len(pt) + 16]
+
+    def ccm_decrypt(self, key, nonce, aad, ct_and_tag, prefill=0xCC):
+        self._chk(key)
+        n = len(ct_and_tag) - 16
+        o = (C.c_uint8 * max(n, 1))(*([prefill] * max(n, 1)))
+        rc = self.L.AES_CCM_decrypt(_buf(key), _buf(nonce), _buf(aad), len(aad), _buf(ct_and_tag), n, o)
+        return ord(rc), bytes(o)[:n]
 
     def _chk(self, key, mult=1):
         assert len(key) * 8 == self.bits * mult, "key size does not match this reference build"

@@ -435,6 +435,120 @@ char orc_gcm_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
 }
 
 /* ------------------------------------------------------------------------ */
+/* CMAC -- micro_aes.c:1108-1118, cMac :576-590, getSubkeys :593-605,         */
+/*         doubleBblock :434-444                                              */
+/* ------------------------------------------------------------------------ */
+static void double_be(uint8_t b[16])
+{
+    int i;
+    uint8_t carry = (uint8_t)(b[0] >> 7);
+    for (i = 0; i < 15; ++i) b[i] = (uint8_t)((b[i] << 1) | (b[i + 1] >> 7));
+    b[15] = (uint8_t)((b[15] << 1) ^ (carry ? 0x87 : 0));
+}
+
+/* M <- Enc(M ^ X_i) over zero padded blocks (xMac with mix = rijndaelEncrypt) */
+static void cbcmac_absorb(const orc_key *ks, const uint8_t *x, size_t len, uint8_t m[16])
+{
+    size_t off, k;
+    for (off = 0; off < len; off += 16) {
+        size_t n = len - off < 16 ? len - off : 16;
+        for (k = 0; k < n; ++k) m[k] ^= x[off + k];
+        orc_encrypt_block(ks, m, m);
+    }
+}
+
+void orc_cmac(int keybits, const uint8_t *key, const void *data, size_t len, uint8_t mac[16])
+{
+    orc_key ks;
+    uint8_t k1[16] = { 0 }, k2[16], last[16] = { 0 };
+    const uint8_t *x = (const uint8_t *)data;
+    size_t s = len ? (len - 1) % 16 + 1 : 0;
+    if (orc_setkey(&ks, key, keybits)) return;
+    orc_encrypt_block(&ks, k1, k1);
+    double_be(k1);
+    memcpy(k2, k1, 16);
+    double_be(k2);
+    memset(mac, 0, 16);
+    cbcmac_absorb(&ks, x, len - s, mac);
+    if (s) memcpy(last, x + len - s, s);
+    if (s < 16) { last[s] ^= 0x80; xor16(last, k2); } else { xor16(last, k1); }
+    xor16(mac, last);
+    orc_encrypt_block(&ks, mac, mac);
+}
+
+/* ------------------------------------------------------------------------ */
+/* CCM -- CCMtag :1222-1256, AES_CCM_encrypt/decrypt :1268-1314               */
+/* 11-byte nonce (CCM_NONCE_LEN), 16-byte tag (CCM_TAG_LEN)                   */
+/* ------------------------------------------------------------------------ */
+static void be_xor(uint8_t *buf, size_t num, int pos)          /* xorBEint :410 */
+{
+    do buf[pos--] ^= (uint8_t)num; while (num >>= 8);
+}
+
+static void ccm_tag(const orc_key *ks, const uint8_t iv[16], const uint8_t *aad, size_t alen,
+                    const uint8_t *pt, size_t plen, uint8_t m[16])
+{
+    uint8_t a[16] = { 0 }, e[16];
+    size_t s = 0;
+    int p = 1;
+    memcpy(m, iv, 16);
+    m[0] |= (16 - 2) << 2;
+    be_xor(m, plen, 15);
+    if (alen) {
+        m[0] |= 0x40;
+        orc_encrypt_block(ks, m, m);
+        if (alen > 0xFEFF) { p += 4; a[0] = 0xFF; a[1] = 0xFE; }
+        be_xor(a, alen, p);
+        ++p;
+        s = (size_t)(16 - p);
+        memcpy(a + p, aad, alen < s ? alen : s);
+    }
+    cbcmac_absorb(ks, a, 16, m);
+    if (alen > s) cbcmac_absorb(ks, aad + s, alen - s, m);
+    cbcmac_absorb(ks, pt, plen, m);
+    orc_encrypt_block(ks, iv, e);
+    xor16(m, e);
+}
+
+static void ccm_iv(const uint8_t *nonce, uint8_t iv[16])
+{
+    memset(iv, 0, 16);
+    iv[0] = 14 - 11;
+    memcpy(iv + 1, nonce, 11);
+}
+
+void orc_ccm_encrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
+                     const void *aad, size_t aad_len,
+                     const void *pt, size_t len, void *ct_and_tag)
+{
+    orc_key ks;
+    uint8_t iv[16], c[16], tag[16], *out = (uint8_t *)ct_and_tag;
+    if (orc_setkey(&ks, key, keybits)) return;
+    ccm_iv(nonce, iv);
+    ccm_tag(&ks, iv, (const uint8_t *)aad, aad_len, (const uint8_t *)pt, len, tag);
+    memcpy(c, iv, 16);
+    ctr56_add(c, 1);
+    ctr_stream(&ks, c, (const uint8_t *)pt, len, out);
+    memcpy(out + len, tag, 16);
+}
+
+char orc_ccm_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
+                     const void *aad, size_t aad_len,
+                     const void *ct_and_tag, size_t len, void *pt)
+{
+    orc_key ks;
+    uint8_t iv[16], c[16], tag[16];
+    const uint8_t *in = (const uint8_t *)ct_and_tag;
+    if (orc_setkey(&ks, key, keybits)) return ORC_E_DECRYPT;
+    ccm_iv(nonce, iv);
+    memcpy(c, iv, 16);
+    ctr56_add(c, 1);
+    ctr_stream(&ks, c, in, len, (uint8_t *)pt);        /* decrypt first (:1304) */
+    ccm_tag(&ks, iv, (const uint8_t *)aad, aad_len, (const uint8_t *)pt, len, tag);
+    return memcmp(tag, in + len, 16) ? ORC_E_AUTH : ORC_OK;    /* text stays (SABOTAGE no-op) */
+}
+
+/* ------------------------------------------------------------------------ */
 /* Synthetic input of SURVEY.md section 8d                                    */
 /* ------------------------------------------------------------------------ */
 void orc_fill_splitmix(uint64_t seed, uint64_t word0, size_t nwords, void *dst)

@@ -11,7 +11,8 @@
  *
  * Parity status: PINNED.  tests/test_oracle.py checks this code against
  *   - the NIST CAVP files the reference's harness consumes
- *     (GcmEncryptExtIV{128,192,256}.rsp, XTSGenAES{128,256}.rsp; the same
+ *     (GcmEncryptExtIV{128,192,256}.rsp, XTSGenAES{128,256}.rsp,
+ *     CMACGenAES{128,192,256}.rsp, VNT{128,192,256}.rsp; the same
  *     case filters as testvectors/aes_testvectors_GCM.h:86 and _XTS.h:84),
  *   - the known answers of the reference's main.c (main.c:16-34,49-50,58-60),
  *   - FIPS-197 appendix C,
@@ -87,6 +88,17 @@ void orc_gcm_encrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
                      const void *aad, size_t aad_len,
                      const void *pt, size_t len, void *ct_and_tag);
 char orc_gcm_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
+                     const void *aad, size_t aad_len,
+                     const void *ct_and_tag, size_t len, void *pt);
+
+/* micro_aes.c:1108-1118 AES_CMAC */
+void orc_cmac(int keybits, const uint8_t *key, const void *data, size_t len, uint8_t mac[16]);
+/* micro_aes.c:1268-1314.  11-byte nonce, 16-byte tag; decrypt runs CTR first and
+ * leaves the text in place on a tag mismatch (SABOTAGE is a no-op, :382)     */
+void orc_ccm_encrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
+                     const void *aad, size_t aad_len,
+                     const void *pt, size_t len, void *ct_and_tag);
+char orc_ccm_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
                      const void *aad, size_t aad_len,
                      const void *ct_and_tag, size_t len, void *pt);
 

@@ -12,7 +12,8 @@ source text):
   reference's own harness (testvectors/), reduced to the sections that harness
   actually runs (IVlen == 96 and Taglen == 128, aes_testvectors_GCM.h:86) so the
   repo carries 3 x ~140 KB instead of 3 x ~3 MB.  Format unchanged.
-* ``XTSGenAES{128,256}.rsp`` -- NIST CAVP XTS files, unmodified.
+* ``XTSGenAES{128,256}.rsp``, ``CMACGenAES{128,192,256}.rsp``, ``VNT{128,192,256}.rsp``
+  -- NIST CAVP XTS / CMAC / CCM files, unmodified.
 * ``main_kats.json`` -- the hot-path known answers of the reference's main.c
   (main.c:16-34,49-50,58-60), re-verified here against the compiled reference.
 * ``ref_vectors.json`` -- outputs of the COMPILED REFERENCE (oracle/_ref) on
@@ -95,6 +96,10 @@ MAIN_KATS = {
     "gcm128": "5ceab5b7c2d6dede555a23c7e3e632744075a51df482730ba31485ec987ddcc8"
               "73acdcfc6759a47ba424d838e7c0cb71b9a4d8f4572e214118c8ab284ca845c1"
               "4394618703cddf3afb",
+    "cmac128": "b887df1fd8c239c3e8a64d9822e21128",
+    "ccm128": "d2575123438338d70b2955537fdfcf41729870884e85af15f0a74975a72b337d"
+              "04d426de87594b9abe3e6dcf07f21c99db3999f81299d302ad1e5ba683e9039a"
+              "5483685f1bd2c3fa3b",
     "gcm256": "eb0f39c8cc86af343545fec3abc4d1fd26241218546289ec5ce5208e01873e90"
               "e86772931b80d74922565b38d35fe11a387b347949dda0879ca5f20fc9357760"
               "4b2f659e3b1d1b0f33",
@@ -127,6 +132,10 @@ def main_kats():
     assert r256.gcm_encrypt(key[:32], iv, aad, pt).hex() == MAIN_KATS["gcm256"].lower()
     add("main.c:191 GCM-256", "gcm", 256, key[:32], {"nonce": iv[:12].hex(), "aad": aad.hex()},
         MAIN_KATS["gcm256"])
+    assert r128.cmac(key[:16], pt).hex() == MAIN_KATS["cmac128"]
+    add("main.c:181 CMAC", "cmac", 128, key[:16], {}, MAIN_KATS["cmac128"])
+    assert r128.ccm_encrypt(key[:16], iv[:11], aad, pt).hex() == MAIN_KATS["ccm128"]
+    add("main.c:198 CCM", "ccm", 128, key[:16], {"nonce": iv[:11].hex(), "aad": aad.hex()}, MAIN_KATS["ccm128"])
     return kats
 
 
@@ -173,6 +182,16 @@ def ref_vectors(orc):
                 assert rcb == 0x1A and ptb == b"\xcc" * n      # N7
                 vecs.append(dict(base, mode="gcm", key=key.hex(), nonce=nonce.hex(),
                                  aad=aad.hex(), out=enc_out(ct)))
+            # CMAC and CCM
+            if n <= 16384:
+                vecs.append(dict(base, mode="cmac", key=key.hex(), out=enc_out(ref.cmac(key, data))))
+                nonce11 = rng.randbytes(11)
+                aad = rng.randbytes(rng.choice([0, 1, 13, 14, 15, 16, 30, 64, 300]))
+                ct = ref.ccm_encrypt(key, nonce11, aad, data)
+                rc, back = ref.ccm_decrypt(key, nonce11, aad, ct)
+                assert rc == 0 and back == data
+                vecs.append(dict(base, mode="ccm", key=key.hex(), nonce=nonce11.hex(), aad=aad.hex(),
+                                 out=enc_out(ct)))
     # counter carry (N2): start the 56-bit counter near its wrap via the PT-side
     # trick is impossible through the 12-byte-IV API (counter always starts at
     # 1), so the carry is pinned by the 65541-byte CTR vectors (4097 blocks:
@@ -250,9 +269,10 @@ def main():
     for bits in (128, 192, 256):
         filter_gcm(os.path.join(REF_TV, "GcmEncryptExtIV%d.rsp" % bits),
                    os.path.join(HERE, "GcmEncryptExtIV%d.rsp" % bits))
-    for bits in (128, 256):
-        with open(os.path.join(REF_TV, "XTSGenAES%d.rsp" % bits)) as f, \
-                open(os.path.join(HERE, "XTSGenAES%d.rsp" % bits), "w") as g:
+    plain = ["XTSGenAES128.rsp", "XTSGenAES256.rsp"]
+    plain += ["CMACGenAES%d.rsp" % b for b in (128, 192, 256)] + ["VNT%d.rsp" % b for b in (128, 192, 256)]
+    for name in plain:
+        with open(os.path.join(REF_TV, name)) as f, open(os.path.join(HERE, name), "w") as g:
             g.write(f.read())
     with open(os.path.join(HERE, "main_kats.json"), "w") as f:
         json.dump(main_kats(), f, indent=1)

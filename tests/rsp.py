@@ -7,6 +7,12 @@ themselves a parity check on the parser:
           Taglen >= GCM_TAG_LEN (16 bytes).
 * XTS  -- testvectors/aes_testvectors_XTS.h:84: run a case only if the key is
           2*AES_KEYLENGTH bytes and DataUnitLen == 8 * len(PT) (whole bytes).
+* CMAC -- testvectors/aes_testvectors_CMAC.h: every case whose key has
+          AES_KEYLENGTH bytes; "Msg = 00" with Mlen = 0 is the empty message;
+          only the first Tlen bytes of the MAC are compared.
+* CCM  -- testvectors/aes_testvectors_CCM.h:83: key of AES_KEYLENGTH bytes,
+          11-byte nonce (CCM_NONCE_LEN) and len(CT) - 16 == len(Payload),
+          i.e. Tlen == 16 (CCM_TAG_LEN).
 """
 import os
 
@@ -56,4 +62,51 @@ def xts_cases(keybits):
                                 and cur["DataUnitLen"] == 8 * len(cur["PT"])):
                             cases.append(cur)
                         cur = None
+    return cases
+
+
+def cmac_cases(keybits):
+    path = os.path.join(GOLDEN, "CMACGenAES%d.rsp" % keybits)
+    cases, cur = [], {}
+    with open(path) as f:
+        for ln in f:
+            ln = ln.strip()
+            if "=" not in ln or ln.startswith("#"):
+                continue
+            k, v = [t.strip() for t in ln.split("=", 1)]
+            if k in ("Count", "Klen", "Mlen", "Tlen"):
+                cur[k] = int(v)
+            elif k in ("Key", "Msg"):
+                cur[k] = bytes.fromhex(v)
+            elif k == "Mac":
+                cur[k] = bytes.fromhex(v)
+                if len(cur["Key"]) * 8 == keybits:
+                    if cur["Mlen"] == 0:
+                        cur["Msg"] = b""
+                    cases.append(cur)
+                cur = {}
+    return cases
+
+
+def ccm_cases(keybits):
+    path = os.path.join(GOLDEN, "VNT%d.rsp" % keybits)
+    cases, key, cur = [], None, {}
+    with open(path) as f:
+        for ln in f:
+            ln = ln.strip()
+            if "=" not in ln or ln.startswith("#") or ln.startswith("["):
+                continue
+            k, v = [t.strip() for t in ln.split("=", 1)]
+            if k == "Key":
+                key = bytes.fromhex(v)
+            elif k == "Count":
+                cur = {"Count": int(v), "Key": key}
+            elif k in ("Nonce", "Adata", "Payload"):
+                cur[k] = bytes.fromhex(v)
+            elif k == "CT" and "Payload" in cur:
+                cur[k] = bytes.fromhex(v)
+                if (len(cur["Key"]) * 8 == keybits and len(cur["Nonce"]) == 11
+                        and len(cur["CT"]) - 16 == len(cur["Payload"])):
+                    cases.append(cur)
+                cur = {}
     return cases

@@ -13,7 +13,8 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = os.path.join(ROOT, "oracle", "_ref")
-EXPECT = {128: {"GCM": 375, "XTS": 800}, 192: {"GCM": 375}, 256: {"GCM": 375, "XTS": 600}}
+EXPECT = {128: {"CMAC": 96, "GCM": 375, "CCM": 10, "XTS": 800}, 192: {"CMAC": 144, "GCM": 375, "CCM": 10},
+          256: {"CMAC": 96, "GCM": 375, "CCM": 10, "XTS": 600}}
 
 
 @pytest.mark.parametrize("bits", [128, 192, 256])
@@ -38,7 +39,7 @@ def test_reference_main_c_runs_on_the_hip_library(bits):
         pytest.skip("oracle/_ref/main_hip_%d was not built" % bits)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "FAILED" not in r.stdout, r.stdout + r.stderr
-    passed = re.findall(r"AES-%d (\w+) (?:en|de)cryption: PASSED!" % bits, r.stdout)
-    want = {128: ["ECB", "ECB", "CTR", "CTR", "XTS", "XTS", "GCM", "GCM"],
+    passed = re.findall(r"AES-%d (\w+) \w+: PASSED!" % bits, r.stdout)
+    want = {128: ["ECB", "ECB", "CTR", "CTR", "XTS", "XTS", "plaintext", "GCM", "GCM", "CCM", "CCM"],
             192: [], 256: ["XTS", "XTS", "GCM", "GCM"]}[bits]
     assert passed == want, r.stdout

@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 import micro_aes_amd as uaes
-from tests.rsp import gcm_cases, xts_cases
+from tests.rsp import ccm_cases, cmac_cases, gcm_cases, xts_cases
 
 pytestmark = pytest.mark.gpu
 
@@ -51,6 +51,9 @@ class Compat:
             f.argtypes = [vp, vp, vp, sz, vp]; f.restype = C.c_char
         L.AES_GCM_encrypt.argtypes = [vp, vp, vp, sz, vp, sz, vp]; L.AES_GCM_encrypt.restype = None
         L.AES_GCM_decrypt.argtypes = [vp, vp, vp, sz, vp, sz, vp]; L.AES_GCM_decrypt.restype = C.c_char
+        L.AES_CCM_encrypt.argtypes = [vp, vp, vp, sz, vp, sz, vp]; L.AES_CCM_encrypt.restype = None
+        L.AES_CCM_decrypt.argtypes = [vp, vp, vp, sz, vp, sz, vp]; L.AES_CCM_decrypt.restype = C.c_char
+        L.AES_CMAC.argtypes = [vp, vp, sz, vp]; L.AES_CMAC.restype = None
 
     @staticmethod
     def buf(n, fill=0xCC):
@@ -89,6 +92,32 @@ def test_xts_rsp_through_compat_api(bits, count):
         assert bytes(out)[:n] == c["PT"], c["COUNT"]
 
 
+@pytest.mark.parametrize("bits,count", [(128, 96), (192, 144), (256, 96)])
+def test_cmac_rsp_through_compat_api(bits, count):
+    cases = cmac_cases(bits)
+    assert len(cases) == count
+    L = Compat(bits)
+    for c in cases:
+        mac = L.buf(16)
+        L.L.AES_CMAC(c["Key"], c["Msg"] or b"\0", len(c["Msg"]), mac)
+        assert bytes(mac)[: c["Tlen"]] == c["Mac"], c["Count"]
+
+
+@pytest.mark.parametrize("bits", [128, 192, 256])
+def test_ccm_rsp_through_compat_api(bits):
+    cases = ccm_cases(bits)
+    assert len(cases) == 10
+    L = Compat(bits)
+    for c in cases:
+        n = len(c["Payload"])
+        out = L.buf(n + 16)
+        L.L.AES_CCM_encrypt(c["Key"], c["Nonce"], c["Adata"], len(c["Adata"]), c["Payload"], n, out)
+        assert bytes(out)[: n + 16] == c["CT"], c["Count"]
+        pt = L.buf(n)
+        rc = L.L.AES_CCM_decrypt(c["Key"], c["Nonce"], c["Adata"], len(c["Adata"]), c["CT"], n, pt)
+        assert ord(rc) == 0 and bytes(pt)[:n] == c["Payload"]
+
+
 def test_main_c_kats(golden_dir):
     for k in load(golden_dir, "main_kats.json"):
         key, pt, exp = bytes.fromhex(k["key"]), bytes.fromhex(k["pt"]), bytes.fromhex(k["expect"])
@@ -103,10 +132,16 @@ def test_main_c_kats(golden_dir):
             tw = bytes.fromhex(k["tweak"])
             assert uaes.AES_XTS_encrypt(key, tw, pt) == (0, exp)
             assert uaes.AES_XTS_decrypt(key, tw, exp) == (0, pt)
-        else:
+        elif k["mode"] == "gcm":
             n, a = bytes.fromhex(k["nonce"]), bytes.fromhex(k["aad"])
             assert uaes.AES_GCM_encrypt(key, n, a, pt) == exp
             assert uaes.AES_GCM_decrypt(key, n, a, exp) == (0, pt)
+        elif k["mode"] == "cmac":
+            assert uaes.AES_CMAC(key, pt) == exp
+        else:
+            n, a = bytes.fromhex(k["nonce"]), bytes.fromhex(k["aad"])
+            assert uaes.AES_CCM_encrypt(key, n, a, pt) == exp
+            assert uaes.AES_CCM_decrypt(key, n, a, exp) == (0, pt)
 
 
 def test_reference_generated_vectors(orc, golden_dir):
@@ -131,11 +166,18 @@ def test_reference_generated_vectors(orc, golden_dir):
                 assert uaes.AES_XTS_decrypt(key, bytes.fromhex(v["tweak"]), ct) == (0, data)
             else:
                 assert ct == b"\xcc" * n                       # N5: untouched
-        else:
+        elif v["mode"] == "gcm":
             nonce, aad = bytes.fromhex(v["nonce"]), bytes.fromhex(v["aad"])
             ct = uaes.AES_GCM_encrypt(key, nonce, aad, data)
             check_out(ct, v["out"])
             assert uaes.AES_GCM_decrypt(key, nonce, aad, ct) == (0, data)
+        elif v["mode"] == "cmac":
+            check_out(uaes.AES_CMAC(key, data), v["out"])
+        else:
+            nonce, aad = bytes.fromhex(v["nonce"]), bytes.fromhex(v["aad"])
+            ct = uaes.AES_CCM_encrypt(key, nonce, aad, data)
+            check_out(ct, v["out"])
+            assert uaes.AES_CCM_decrypt(key, nonce, aad, ct) == (0, data)
 
 
 # ---- against the oracle on seeded inputs -------------------------------------------
@@ -196,6 +238,23 @@ def test_gcm_vs_oracle(orc, bits):
         bad = bytearray(ct)
         bad[rnd.randrange(len(bad))] ^= 0x40
         assert uaes.AES_GCM_decrypt(key, nonce, aad, bytes(bad), prefill=0xCC) == (0x1A, b"\xcc" * n)   # N7
+
+
+@pytest.mark.parametrize("bits", [128, 192, 256])
+def test_cmac_ccm_vs_oracle(orc, bits):
+    rnd = random.Random(bits + 3)
+    for n in [0, 1, 15, 16, 17, 32, 100, 4096, 65536 + 3]:
+        key, nonce = rnd.randbytes(bits // 8), rnd.randbytes(11)
+        data = orc.splitmix(n + 5, n)
+        assert uaes.AES_CMAC(key, data) == orc.cmac(key, data), n
+        aad = rnd.randbytes(rnd.choice([0, 1, 14, 15, 16, 70000 if n == 100 else 31]))
+        ct = uaes.AES_CCM_encrypt(key, nonce, aad, data)
+        assert ct == orc.ccm_encrypt(key, nonce, aad, data), n
+        assert uaes.AES_CCM_decrypt(key, nonce, aad, ct) == (0, data)
+        bad = bytearray(ct)
+        bad[-1] ^= 1
+        # the reference decrypts first and leaves the text in place on a mismatch
+        assert uaes.AES_CCM_decrypt(key, nonce, aad, bytes(bad)) == (0x1A, data)
 
 
 def test_ghash_kernel_levels(orc):

@@ -11,10 +11,12 @@ import random
 import pytest
 
 from oracle.pyoracle import Reference
-from tests.rsp import gcm_cases, xts_cases
+from tests.rsp import ccm_cases, cmac_cases, gcm_cases, xts_cases
 
 EXPECTED_COUNTS = {("gcm", 128): 375, ("gcm", 192): 375, ("gcm", 256): 375,
-                   ("xts", 128): 800, ("xts", 256): 600}
+                   ("xts", 128): 800, ("xts", 256): 600,
+                   ("cmac", 128): 96, ("cmac", 192): 144, ("cmac", 256): 96,
+                   ("ccm", 128): 10, ("ccm", 192): 10, ("ccm", 256): 10}
 
 
 def load(golden_dir, name):
@@ -63,6 +65,23 @@ def test_xts_rsp(orc, bits):
         assert rc == 0 and pt == c["PT"], c["COUNT"]
 
 
+@pytest.mark.parametrize("bits", [128, 192, 256])
+def test_cmac_rsp(orc, bits):
+    cases = cmac_cases(bits)
+    assert len(cases) == EXPECTED_COUNTS[("cmac", bits)]
+    for c in cases:
+        assert orc.cmac(c["Key"], c["Msg"])[: c["Tlen"]] == c["Mac"], c["Count"]
+
+
+@pytest.mark.parametrize("bits", [128, 192, 256])
+def test_ccm_rsp(orc, bits):
+    cases = ccm_cases(bits)
+    assert len(cases) == EXPECTED_COUNTS[("ccm", bits)]
+    for c in cases:
+        assert orc.ccm_encrypt(c["Key"], c["Nonce"], c["Adata"], c["Payload"]) == c["CT"], c["Count"]
+        assert orc.ccm_decrypt(c["Key"], c["Nonce"], c["Adata"], c["CT"]) == (0, c["Payload"])
+
+
 def test_main_c_kats(orc, golden_dir):
     for k in load(golden_dir, "main_kats.json"):
         key, pt, exp = bytes.fromhex(k["key"]), bytes.fromhex(k["pt"]), bytes.fromhex(k["expect"])
@@ -81,6 +100,12 @@ def test_main_c_kats(orc, golden_dir):
             n, a = bytes.fromhex(k["nonce"]), bytes.fromhex(k["aad"])
             assert orc.gcm_encrypt(key, n, a, pt) == exp
             assert orc.gcm_decrypt(key, n, a, exp) == (0, pt)
+        elif k["mode"] == "cmac":
+            assert orc.cmac(key, pt) == exp
+        elif k["mode"] == "ccm":
+            n, a = bytes.fromhex(k["nonce"]), bytes.fromhex(k["aad"])
+            assert orc.ccm_encrypt(key, n, a, pt) == exp
+            assert orc.ccm_decrypt(key, n, a, exp) == (0, pt)
 
 
 def test_reference_generated_vectors(orc, golden_dir):
@@ -110,6 +135,12 @@ def test_reference_generated_vectors(orc, golden_dir):
             ct = orc.gcm_encrypt(key, bytes.fromhex(v["nonce"]), bytes.fromhex(v["aad"]), data)
             check_out(ct, v["out"])
             assert orc.gcm_decrypt(key, bytes.fromhex(v["nonce"]), bytes.fromhex(v["aad"]), ct) == (0, data)
+        elif v["mode"] == "cmac":
+            check_out(orc.cmac(key, data), v["out"])
+        elif v["mode"] == "ccm":
+            ct = orc.ccm_encrypt(key, bytes.fromhex(v["nonce"]), bytes.fromhex(v["aad"]), data)
+            check_out(ct, v["out"])
+            assert orc.ccm_decrypt(key, bytes.fromhex(v["nonce"]), bytes.fromhex(v["aad"]), ct) == (0, data)
 
 
 def test_baseline_digests_small(orc, golden_dir):
@@ -206,3 +237,10 @@ def test_against_compiled_reference_random(orc, bits):
         ct = ref.gcm_encrypt(key, iv, aad, data)
         assert orc.gcm_encrypt(key, iv, aad, data) == ct
         assert orc.gcm_decrypt(key, iv, aad, ct) == ref.gcm_decrypt(key, iv, aad, ct) == (0, data)
+        assert orc.cmac(key, data) == ref.cmac(key, data)
+        aad2 = rnd.randbytes(rnd.choice([0, 5, 14, 15, 33]))
+        cc = ref.ccm_encrypt(key, iv[:11], aad2, data)
+        assert orc.ccm_encrypt(key, iv[:11], aad2, data) == cc
+        bad = bytearray(cc); bad[-1] ^= 2
+        assert orc.ccm_decrypt(key, iv[:11], aad2, bytes(bad)) == ref.ccm_decrypt(key, iv[:11], aad2, bytes(bad))
+        assert orc.ccm_decrypt(key, iv[:11], aad2, bytes(bad))[0] == 0x1A
