@@ -17,7 +17,7 @@
  *   acc_j = sum_k X_{kS+j} * (H^S)^(K-1-k)  (acc <- acc*H^S ^ X), and
  *   GHASH(X) = GHASH(acc_0..acc_{S-1}): the accumulators of one level are the
  *   input blocks of the next, so the same kernel recurses with smaller
- *   strides (2^17|..|2^12 -> 2^12 -> 256 -> 16 -> 1).  Multiplication by the
+ *   strides (2^18|..|2^12 -> 2^14 -> 1024 -> 64 -> 4 -> 1).  Multiplication by the
  *   FIXED element H^S is GF(2)-linear in the other operand, hence 16 lookups
  *   of 16 bytes in a 64 KiB byte-indexed table (ds_read_b128) + 15 XORs per
  *   block on the bulk levels, and 32 lookups in an 8 KiB nibble-indexed table
@@ -34,21 +34,22 @@
 #include "uaes_gf.h"
 #include "uaes_device.h"
 
-#define GH_T        256u            /* threads of the last-levels workgroup   */
+#define GH_T        1024u           /* threads of the last-levels workgroup   */
 #define GH_PT       1024u           /* threads per bulk-level workgroup       */
 #define GH_MAXLOG   18u             /* largest bulk stride 2^18 (256 x 1024)  */
-#define GH_LOGB     12u             /* second-level stride 2^12               */
-#define GH_DIRECT   16384u          /* <= this many blocks: last kernel alone */
+#define GH_LOGB     14u             /* second-level stride 2^14 (16 x 1024)   */
+#define GH_DIRECT   32768u          /* <= this many blocks: last kernel alone */
 
 /* scratch layout (bytes) */
 #define GS_H        0u
 #define GS_EJ0      16u
 #define GS_POW      64u                         /* 18 x 16                    */
-#define GS_TAB4_C   1024u                       /* H^256, 8 KiB               */
-#define GS_TAB4_D   (GS_TAB4_C + 8192u)         /* H^16                       */
-#define GS_TAB4_E   (GS_TAB4_D + 8192u)         /* H                          */
-#define GS_TAB8_A   32768u                      /* H^(2^logA), 64 KiB         */
-#define GS_TAB8_B   (GS_TAB8_A + 65536u)        /* H^4096, 64 KiB             */
+#define GS_TAB4_C   1024u                       /* H^1024, 8 KiB nibble table */
+#define GS_TAB4_D   (GS_TAB4_C + 8192u)         /* H^64                       */
+#define GS_TAB4_E   (GS_TAB4_D + 8192u)         /* H^4                        */
+#define GS_TAB4_F   (GS_TAB4_E + 8192u)         /* H                          */
+#define GS_TAB8_A   36864u                      /* H^(2^logA), 64 KiB         */
+#define GS_TAB8_B   (GS_TAB8_A + 65536u)        /* H^(2^14), 64 KiB           */
 #define GS_ACC1     (GS_TAB8_B + 65536u)        /* 2^17 x 16 = 2 MiB          */
 #define GS_ACC2     (GS_ACC1 + (16u << GH_MAXLOG))
 #define GS_TOTAL    (GS_ACC2 + (16u << GH_LOGB))
@@ -164,18 +165,30 @@ __device__ __forceinline__ uint4 tabmul8_xor(uint4 a, uint4 x, const GhLane &gl)
     return make_uint4(z[0], z[1], z[2], z[3]);
 }
 
-/* a * M through the nibble-indexed table of M (512 entries of 16 B) */
+/* a * M through the nibble-indexed table of M (512 entries of 16 B, anywhere in LDS) */
 __device__ __forceinline__ uint4 tabmul4(const uint4 *T, uint4 a)
 {
     const u32 w[4] = { a.x, a.y, a.z, a.w };
-    uint4 z = make_uint4(0, 0, 0, 0);
+    const u32 base = (u32)(uintptr_t)(__attribute__((address_space(3))) const uint4 *)T;
+    u32x4 e[32];
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        const u32 b = (w[j >> 2] >> (8 * (j & 3))) & 0xffu;
-        z = x4(z, T[(2 * j) * 16 + (b >> 4)]);
-        z = x4(z, T[(2 * j + 1) * 16 + (b & 15u)]);
+        /* entry (2j, hi nibble) at j*512 + hi*16; entry (2j+1, lo nibble) at j*512 + 256 + lo*16 */
+        const u32 b = w[j >> 2] >> (8 * (j & 3));
+        const u32 ahi = (b & 0xf0u) + (base + j * 512u);
+        const u32 alo = ((b & 0x0fu) << 4) + (base + j * 512u + 256u);
+        e[2 * j] = *(lds_cu128 *)(uintptr_t)ahi;
+        e[2 * j + 1] = *(lds_cu128 *)(uintptr_t)alo;
     }
-    return z;
+    u32 z[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        u32 t = xor3(e[0][d], e[1][d], e[2][d]);
+#pragma unroll
+        for (int k = 3; k < 31; k += 2) t = xor3(t, e[k][d], e[k + 1][d]);
+        z[d] = t ^ e[31][d];
+    }
+    return make_uint4(z[0], z[1], z[2], z[3]);
 }
 
 /* ------------------------------------------------------------------------ */
@@ -221,15 +234,18 @@ __global__ __launch_bounds__(GH_PT) void k_ghash_pass(GSrc src, u64 nv, const ui
 /* ------------------------------------------------------------------------ */
 /* mode 0: write tag = GHASH ^ EJ0 to tag_io (encrypt)
  * mode 1: compare with the 16 bytes at tag_io, *status = 0 / 0x1A (decrypt)
- * mode 2: write the raw GHASH value to tag_io (tests)                       */
+ * mode 2: write the raw GHASH value to tag_io (tests)
+ * Levels inside the workgroup: stride 1024 -> 64 -> 4 -> 1 (nibble tables).   */
+#define GHF_LDS ((4u * 512u + 1024u + 64u + 4u) * 16u)
+
 __global__ __launch_bounds__(GH_T) void k_ghash_final(GSrc src, u64 nv, const unsigned char *__restrict__ scratch,
                                                       int mode, unsigned char *tag_io, int *status)
 {
-    uint4 *TC = (uint4 *)uaes_lds;            /* 3 x 512 entries */
-    uint4 *TD = TC + 512, *TE = TD + 512;
-    uint4 *buf = TE + 512;                    /* 256 + 16 */
+    uint4 *TC = (uint4 *)uaes_lds;            /* 4 x 512 entries: H^1024, H^64, H^4, H */
+    uint4 *TD = TC + 512, *TE = TD + 512, *TF = TE + 512;
+    uint4 *buf = TF + 512;                    /* 1024 + 64 + 4 */
     const uint4 *g4 = (const uint4 *)(scratch + GS_TAB4_C);
-    for (u32 i = threadIdx.x; i < 1536u; i += GH_T) TC[i] = g4[i];
+    for (u32 i = threadIdx.x; i < 2048u; i += GH_T) TC[i] = g4[i];
     __syncthreads();
 
     const u64 steps = (nv + GH_T - 1) / GH_T;
@@ -243,15 +259,21 @@ __global__ __launch_bounds__(GH_T) void k_ghash_final(GSrc src, u64 nv, const un
     }
     buf[threadIdx.x] = acc;
     __syncthreads();
-    if (threadIdx.x < 16) {
+    if (threadIdx.x < 64) {
         acc = make_uint4(0, 0, 0, 0);
-        for (u32 k = 0; k < 16; ++k) acc = x4(tabmul4(TD, acc), buf[k * 16 + threadIdx.x]);
-        buf[256 + threadIdx.x] = acc;
+        for (u32 k = 0; k < 16; ++k) acc = x4(tabmul4(TD, acc), buf[k * 64 + threadIdx.x]);
+        buf[1024 + threadIdx.x] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        acc = make_uint4(0, 0, 0, 0);
+        for (u32 k = 0; k < 16; ++k) acc = x4(tabmul4(TE, acc), buf[1024 + k * 4 + threadIdx.x]);
+        buf[1088 + threadIdx.x] = acc;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         acc = make_uint4(0, 0, 0, 0);
-        for (u32 k = 0; k < 16; ++k) acc = tabmul4(TE, x4(acc, buf[256 + k]));
+        for (u32 k = 0; k < 4; ++k) acc = tabmul4(TF, x4(acc, buf[1088 + k]));
         if (mode != 2) acc = x4(acc, *(const uint4 *)(scratch + GS_EJ0));
         const u32 w[4] = { acc.x, acc.y, acc.z, acc.w };
         if (mode == 1) {
@@ -295,7 +317,7 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_setup(uaesk_rk ek, uaesk_tables
                                                        u32 logA, u32 needB, u32 h_given, uint4 hval)
 {
     Gf *shPow = (Gf *)(uaes_lds + UAES_LDS_ENC);          /* 18 powers         */
-    Gf *shGen = shPow + 32;                                /* 5 x 128 generators */
+    Gf *shGen = shPow + 32;                                /* 6 x 128 generators */
     uint4 *gH = (uint4 *)(scratch + GS_H);
 
     if (!h_given) {
@@ -324,9 +346,9 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_setup(uaesk_rk ek, uaesk_tables
     }
     __syncthreads();
 
-    /* generators M*x^q of the five tables: A (2^logA), B (2^12), C (2^8), D (2^4), E (2^0) */
-    const u32 logs[5] = { logA, GH_LOGB, 8u, 4u, 0u };
-    if (threadIdx.x < 640) {
+    /* generators M*x^q of the six tables: A (2^logA), B (2^14), C (2^10), D (2^6), E (2^2), F (2^0) */
+    const u32 logs[6] = { logA, GH_LOGB, 10u, 6u, 2u, 0u };
+    if (threadIdx.x < 768) {
         const u32 t = threadIdx.x >> 7, q = threadIdx.x & 127u;
         shGen[threadIdx.x] = gf_mul_xq128(shPow[logs[t]], q);
     }
@@ -356,7 +378,7 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_setup(uaesk_rk ek, uaesk_tables
     /* nibble-indexed tables: entry (p, v) = sum_i bit(v, 3-i) * gen[4p+i] */
     if (threadIdx.x < 512) {
         const u32 p = threadIdx.x >> 4, v = threadIdx.x & 15u;
-        for (u32 t = 0; t < 3; ++t) {
+        for (u32 t = 0; t < 4; ++t) {
             uint4 *dst = (uint4 *)(scratch + GS_TAB4_C + 8192u * t);
             const Gf *gen = shGen + 128 * (2 + t);
             Gf e = { 0, 0 };
@@ -419,7 +441,7 @@ static int run_ghash_levels(hipStream_t st, const GSrc &msg, u64 nv, const GPlan
             n = sB;
         }
     }
-    hipLaunchKernelGGL(k_ghash_final, dim3(1), dim3(GH_T), (1536 + 272) * 16, st,
+    hipLaunchKernelGGL(k_ghash_final, dim3(1), dim3(GH_T), GHF_LDS, st,
                        cur, n, (const unsigned char *)scratch, mode, tag_io, status);
     return (int)hipGetLastError();
 }

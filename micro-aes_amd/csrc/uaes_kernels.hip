@@ -662,16 +662,16 @@ extern "C" int uaesk_ecb(void *stream, const uaesk_tables *tb, int nr, const uae
     return 0;
 }
 
-/* UAES_CTR_VARIANT (debug knob, read once): "u<U>t<NT>", e.g. u4t4 (default) */
+/* UAES_CTR_VARIANT (debug knob for A/B runs, read once):
+ *   unset / "skewed"  k_ctr_shared2 -- shared rounds 1-2, two blocks per lane half a round apart
+ *   "shared4"         k_ctr_shared  -- shared rounds 1-2, four blocks per lane in lock step
+ *   "generic"         k_ctr         -- every round of every block (what short messages use)   */
 static int ctr_variant()
 {
     static int v = -1;
     if (v < 0) {
         const char *e = getenv("UAES_CTR_VARIANT");
-        int u = 4, t = 4;
-        if (e && sscanf(e, "u%dt%d", &u, &t) == 2) v = u * 10 + t;
-        else if (e && !strcmp(e, "shared4")) v = 1;       /* lock-step, 4 blocks per lane */
-        else v = 0;                                        /* default: skewed, 2 blocks per lane */
+        v = (e && !strcmp(e, "shared4")) ? 1 : (e && !strcmp(e, "generic")) ? 2 : 0;
     }
     return v;
 }
@@ -728,16 +728,8 @@ template <int NR>
 static int launch_ctr(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek, const uaesk_ctr *ctr,
                       const void *in, void *out, size_t len, const int *gate)
 {
-    if (ctr_variant() <= 1) return launch_ctr_shared<NR>(st, tb, ek, ctr, in, out, len, gate);
-    switch (NR == 10 ? ctr_variant() : 44) {       /* variants are compiled for AES-128 only */
-    case 24: return launch_ctr_v<NR, 2, 4>(st, tb, ek, ctr, in, out, len, gate);
-    case 84: return launch_ctr_v<NR, 8, 4>(st, tb, ek, ctr, in, out, len, gate);
-    case 64: return launch_ctr_v<NR, 6, 4>(st, tb, ek, ctr, in, out, len, gate);
-    case 22: return launch_ctr_v<NR, 2, 2>(st, tb, ek, ctr, in, out, len, gate);
-    case 12: return launch_ctr_v<NR, 1, 2>(st, tb, ek, ctr, in, out, len, gate);
-    case 42: return launch_ctr_v<NR, 4, 2>(st, tb, ek, ctr, in, out, len, gate);
-    default: return launch_ctr_v<NR, 4, 4>(st, tb, ek, ctr, in, out, len, gate);
-    }
+    if (ctr_variant() == 2) return launch_ctr_v<NR, 4, 4>(st, tb, ek, ctr, in, out, len, gate);
+    return launch_ctr_shared<NR>(st, tb, ek, ctr, in, out, len, gate);
 }
 
 extern "C" int uaesk_ctr_xcrypt(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek,

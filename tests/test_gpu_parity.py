@@ -261,8 +261,9 @@ def test_ghash_kernel_levels(orc):
     """every level plan of the GHASH kernels: direct, one bulk level, two bulk levels"""
     rnd = random.Random(77)
     H = rnd.randbytes(16)
-    for nblocks, extra, alen in [(0, 0, 0), (1, 0, 5), (300, 7, 0), (16382, 0, 16), (16383, 0, 0), (16384, 1, 3),
-                                 (70000, 0, 0), (300000, 5, 33), (1500000, 0, 0)]:
+    for nblocks, extra, alen in [(0, 0, 0), (1, 0, 5), (300, 7, 0), (1023, 0, 0), (1024, 3, 16), (32766, 0, 16),
+                                 (32767, 0, 0), (32768, 1, 3), (70000, 0, 0), (300000, 5, 33), (1500000, 0, 0),
+                                 (3000000, 9, 17)]:
         ct = orc.splitmix(nblocks + 3, nblocks * 16 + extra)
         aad = rnd.randbytes(alen)
         assert uaes.ghash(H, aad, ct) == orc.ghash(H, aad, ct), (nblocks, extra, alen)
