@@ -302,6 +302,20 @@ __device__ __forceinline__ void enc_rounds_skewed(u32 (&sa)[4], u32 (&sb)[4], co
 #undef rkp
 }
 
+/* full cipher on two blocks, skewed (state = plaintext words on entry) */
+struct RkView {
+    const u32 *w;
+};
+
+template <int NR>
+__device__ __forceinline__ void enc_blocks_skewed(u32 (&sa)[4], u32 (&sb)[4], const uaesk_rk &rk, const LaneConst &lc)
+{
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { sa[c] ^= rk.w[c]; sb[c] ^= rk.w[c]; }
+    const RkView v = { rk.w + 4 };
+    enc_rounds_skewed<NR, 1>(sa, sb, v, lc);
+}
+
 /* ---- decryption rounds (equivalent inverse cipher, FIPS-197 sec. 5.3.5) - */
 /* Td2 = rotl16(Td0), Td3 = rotl16(Td1): one rotate per column              */
 template <int U>

@@ -47,7 +47,12 @@ __global__ __launch_bounds__(UAES_WG) void k_ecb(uaesk_rk rk, uaesk_tables tb,
             if (idx[u] < nfull) d = in[idx[u]];
             s[u][0] = d.x; s[u][1] = d.y; s[u][2] = d.z; s[u][3] = d.w;
         }
-        if (DEC) dec_blocks<NR, UAES_U>(s, rk, lc); else enc_blocks<NR, UAES_U>(s, rk, lc);
+        if (DEC) {
+            dec_blocks<NR, UAES_U>(s, rk, lc);
+        } else {                                   /* two pairs, each half a round out of phase */
+            enc_blocks_skewed<NR>(s[0], s[1], rk, lc);
+            enc_blocks_skewed<NR>(s[2], s[3], rk, lc);
+        }
 #pragma unroll
         for (int u = 0; u < UAES_U; ++u)
             if (idx[u] < nfull) out[idx[u]] = make_uint4(s[u][0], s[u][1], s[u][2], s[u][3]);
@@ -443,7 +448,9 @@ __global__ __launch_bounds__(UAES_WG) void k_xts_tweaks(uaesk_rk k2, uaesk_table
 }
 
 /* main pass: one wave per chunk; lane l handles blocks l, l+64, l+128, l+192
- * of the chunk so each wave-level load/store is a contiguous 1 KiB segment. */
+ * of the chunk so each wave-level load/store is a contiguous 1 KiB segment.
+ * The next chunk's data and tweak are requested before this chunk's rounds;
+ * encryption runs the four blocks as two skewed pairs (enc_blocks_skewed).   */
 template <int NR, bool DEC>
 __global__ __launch_bounds__(UAES_WG) void k_xts(uaesk_rk k1, uaesk_tables tb,
                                                  const uint4 *__restrict__ chunk_tw,
@@ -460,39 +467,65 @@ __global__ __launch_bounds__(UAES_WG) void k_xts(uaesk_rk k1, uaesk_tables tb,
     const u64 nwaves = (u64)gridDim.x * (UAES_WG / 64);
     const u64 nchunks = nsectors * chunks_per_sector;
 
-    for (u64 ch = wave; ch < nchunks; ch += nwaves) {
+    /* state of the chunk being fetched */
+    uint4 dn[UAES_U], tbn = make_uint4(0, 0, 0, 0);
+    u32 cntn = 0;
+    u64 offn = 0;                                    /* byte offset of the chunk's first block */
+    auto fetch = [&](u64 ch) {
         const u64 sct = ch / chunks_per_sector;
-        const u64 c = ch - sct * chunks_per_sector;
-        const u64 first = c * XTS_CHUNK;                       /* first block of chunk in unit */
+        const u64 first = (ch - sct * chunks_per_sector) * XTS_CHUNK;
         const u64 left = main_blocks - first;
-        const u32 cnt = left < XTS_CHUNK ? (u32)left : XTS_CHUNK;
-        const uint4 tb4 = chunk_tw[ch];
+        cntn = left < XTS_CHUNK ? (u32)left : XTS_CHUNK;
+        offn = sct * sector_bytes + first * 16;
+        tbn = chunk_tw[ch];
+        const uint4 *src = (const uint4 *)(in + offn);
+#pragma unroll
+        for (int u = 0; u < UAES_U; ++u) {
+            const u32 j = lane + 64u * u;
+            const u32 jc = j < cntn ? j : (cntn ? cntn - 1 : 0);     /* clamped: no branch before the load */
+            dn[u] = cntn ? src[jc] : make_uint4(0, 0, 0, 0);
+        }
+    };
+
+    u64 ch = wave;
+    if (ch < nchunks) fetch(ch);
+    while (ch < nchunks) {
+        uint4 d[UAES_U];
+#pragma unroll
+        for (int u = 0; u < UAES_U; ++u) d[u] = dn[u];
+        const uint4 tb4 = tbn;
+        const u32 cnt = cntn;
+        const u64 off = offn;
+        const u64 nxt = ch + nwaves;
+        if (nxt < nchunks) fetch(nxt);
+
         Tw t;
         t.lo = tb4.x | ((u64)tb4.y << 32);
         t.hi = tb4.z | ((u64)tb4.w << 32);
         t = tw_mul_pow(t, lane);
-
-        const uint4 *src = (const uint4 *)(in + sct * sector_bytes) + first;
-        uint4 *dst = (uint4 *)(out + sct * sector_bytes) + first;
         u32 s[UAES_U][4], tw[UAES_U][4];
 #pragma unroll
         for (int u = 0; u < UAES_U; ++u) {
-            const u32 j = lane + 64u * u;
-            uint4 d = make_uint4(0, 0, 0, 0);
-            if (j < cnt) d = src[j];
             tw[u][0] = (u32)t.lo; tw[u][1] = (u32)(t.lo >> 32);
             tw[u][2] = (u32)t.hi; tw[u][3] = (u32)(t.hi >> 32);
-            s[u][0] = d.x ^ tw[u][0]; s[u][1] = d.y ^ tw[u][1];
-            s[u][2] = d.z ^ tw[u][2]; s[u][3] = d.w ^ tw[u][3];
+            s[u][0] = d[u].x ^ tw[u][0]; s[u][1] = d[u].y ^ tw[u][1];
+            s[u][2] = d[u].z ^ tw[u][2]; s[u][3] = d[u].w ^ tw[u][3];
             t = tw_mul_pow64(t);
         }
-        if (DEC) dec_blocks<NR, UAES_U>(s, k1, lc); else enc_blocks<NR, UAES_U>(s, k1, lc);
+        if (DEC) {
+            dec_blocks<NR, UAES_U>(s, k1, lc);
+        } else {
+            enc_blocks_skewed<NR>(s[0], s[1], k1, lc);
+            enc_blocks_skewed<NR>(s[2], s[3], k1, lc);
+        }
+        uint4 *dst = (uint4 *)(out + off);
 #pragma unroll
         for (int u = 0; u < UAES_U; ++u) {
             const u32 j = lane + 64u * u;
             if (j < cnt)
                 dst[j] = make_uint4(s[u][0] ^ tw[u][0], s[u][1] ^ tw[u][1], s[u][2] ^ tw[u][2], s[u][3] ^ tw[u][3]);
         }
+        ch = nxt;
     }
 }
 
