@@ -1,0 +1,115 @@
+"""GPU tests of the boundary's promises beyond plain parity: in-place operation
+(the reference works in place, micro_aes.h:520-526), unaligned and mixed
+host/device pointers, concurrent host threads (the reference is not re-entrant,
+micro_aes.c:72 -- this library must be), and streams > 4 GiB (64-bit indexing)."""
+import ctypes as C
+import random
+import threading
+
+import numpy as np
+import pytest
+
+import micro_aes_amd as uaes
+
+pytestmark = pytest.mark.gpu
+
+
+def test_in_place_host_buffers(orc):
+    L = uaes.engine()
+    rnd = random.Random(11)
+    key, keys, iv = rnd.randbytes(16), rnd.randbytes(64), rnd.randbytes(12)
+    for n in (16, 100, 4096, 70001):
+        data = orc.splitmix(n, n)
+        buf = (C.c_uint8 * (n + 32)).from_buffer_copy(data + bytes(32))
+        assert L.uaes_ctr_xcrypt(128, key, iv, buf, n, buf) == 0
+        assert bytes(buf)[:n] == orc.ctr_encrypt(key, iv, data)
+        buf = (C.c_uint8 * (n + 32)).from_buffer_copy(data + bytes(32))
+        assert L.uaes_ecb_encrypt(128, key, buf, n, buf) == 0
+        assert bytes(buf)[: (n + 15) // 16 * 16] == orc.ecb_encrypt(key, data)
+        buf = (C.c_uint8 * (n + 32)).from_buffer_copy(data + bytes(32))
+        assert L.uaes_xts_encrypt(256, keys, None, buf, n, buf) == 0
+        assert bytes(buf)[:n] == orc.xts(keys, None, data, True)[1]
+        assert L.uaes_xts_decrypt(256, keys, None, buf, n, buf) == 0
+        assert bytes(buf)[:n] == data
+        buf = (C.c_uint8 * (n + 32)).from_buffer_copy(data + bytes(32))
+        assert L.uaes_gcm_encrypt(128, key, iv, b"aad", 3, buf, n, buf) == 0
+        assert bytes(buf)[: n + 16] == orc.gcm_encrypt(key, iv, b"aad", data)
+        assert L.uaes_gcm_decrypt(128, key, iv, b"aad", 3, buf, n, buf) == 0
+        assert bytes(buf)[:n] == data
+
+
+def test_unaligned_and_mixed_pointers(orc):
+    import torch
+    L = uaes.engine()
+    key, iv = bytes(range(16)), bytes(range(12))
+    n = 100003
+    data = orc.splitmix(3, n)
+    want = orc.ctr_encrypt(key, iv, data)
+    dev = torch.zeros(n + 64, dtype=torch.uint8, device="cuda:0")
+    dev[3:3 + n] = torch.frombuffer(bytearray(data), dtype=torch.uint8).to("cuda:0")
+    out = torch.zeros(n + 64, dtype=torch.uint8, device="cuda:0")
+    # device -> device, both misaligned by different amounts
+    assert L.uaes_ctr_xcrypt(128, key, iv, C.c_void_p(dev.data_ptr() + 3), n, C.c_void_p(out.data_ptr() + 5)) == 0
+    torch.cuda.synchronize()
+    assert bytes(out[5:5 + n].cpu().numpy()) == want and int(out[:5].sum()) == 0 and int(out[5 + n:].sum()) == 0
+    # device -> host and host -> device
+    hbuf = (C.c_uint8 * n)()
+    assert L.uaes_ctr_xcrypt(128, key, iv, C.c_void_p(dev.data_ptr() + 3), n, hbuf) == 0
+    assert bytes(hbuf) == want
+    out.zero_()
+    assert L.uaes_ctr_xcrypt(128, key, iv, data, n, C.c_void_p(out.data_ptr() + 16)) == 0
+    torch.cuda.synchronize()
+    assert bytes(out[16:16 + n].cpu().numpy()) == want
+    # GCM with device AAD and a host payload
+    aad = torch.frombuffer(bytearray(b"device resident header"), dtype=torch.uint8).to("cuda:0")
+    ct = (C.c_uint8 * (n + 16))()
+    assert L.uaes_gcm_encrypt(128, key, iv, C.c_void_p(aad.data_ptr()), aad.numel(), data, n, ct) == 0
+    assert bytes(ct) == orc.gcm_encrypt(key, iv, b"device resident header", data)
+
+
+def test_concurrent_host_threads(orc):
+    rnd = random.Random(5)
+    jobs = []
+    for t in range(8):
+        key, iv = rnd.randbytes(16 + 8 * (t % 3)), rnd.randbytes(12)
+        data = orc.splitmix(100 + t, 200000 + 17 * t)
+        jobs.append((key, iv, data, orc.ctr_encrypt(key, iv, data), orc.gcm_encrypt(key, iv, b"", data[:5000])))
+    errors = []
+
+    def work(job):
+        key, iv, data, want_ctr, want_gcm = job
+        for _ in range(5):
+            if uaes.AES_CTR_encrypt(key, iv, data) != want_ctr:
+                errors.append("ctr")
+            if uaes.AES_GCM_encrypt(key, iv, b"", data[:5000]) != want_gcm:
+                errors.append("gcm")
+
+    threads = [threading.Thread(target=work, args=(j,)) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors
+
+
+def test_ctr_stream_larger_than_4GiB(orc):
+    """block indices and byte offsets beyond 2^32 (one 5 GiB call)"""
+    import torch
+    n = 5 << 30
+    key, ctr0 = bytes(range(16)), bytes(range(0xF0, 0xFC)) + b"\xff\xff\xff\xf0"    # low word wraps inside the call
+    src = torch.empty(n, dtype=torch.uint8, device="cuda:0")
+    piece = np.empty(1 << 28, dtype=np.uint8)
+    orc.splitmix_into(9, piece)
+    pt = torch.from_numpy(piece).to("cuda:0")
+    for o in range(0, n, 1 << 28):
+        src[o:o + (1 << 28)] = pt
+    dst = torch.empty_like(src)
+    uaes.ctr_xcrypt_dev(key, ctr0, 0, src, dst)
+    torch.cuda.synchronize()
+    for off in (0, (1 << 32) - 4096, (1 << 32) + 65536, n - 8192):
+        got = bytes(dst[off:off + 8192].cpu().numpy())
+        want = orc.ctr_xcrypt_at(key, ctr0, off // 16, bytes(src[off:off + 8192].cpu().numpy()))
+        assert got == want, off
+    uaes.ctr_xcrypt_dev(key, ctr0, 0, dst, dst)
+    torch.cuda.synchronize()
+    assert torch.equal(dst[: 1 << 30], src[: 1 << 30]) and torch.equal(dst[-(1 << 30):], src[-(1 << 30):])
