@@ -160,6 +160,21 @@ int uaes_gcm_decrypt_dev(int keybits, const uint8_t *key, const uint8_t *nonce,
                          const void *d_in, size_t len, void *d_out,
                          int *d_status, void *stream);
 
+/* ---- sharded GCM (multi-GPU) ------------------------------------------------
+ * One message, cut into 16-byte aligned ciphertext shards, one per GPU.  Each
+ * rank encrypts its shard with uaes_ctr_xcrypt_at_dev(ctr0 = nonce || 00000001,
+ * block_offset = 1 + shard_offset/16) -- the CCM_GCM pre-increment of CTR_cipher
+ * (micro_aes.c:939-941) -- and calls this function on the resulting ciphertext.
+ * It returns 16 bytes: the shard's share of  Enc(J0) ^ GHASH(aData, crtxt)
+ * (gHash, micro_aes.c:1127-1137; the first shard carries aData and Enc(J0), the
+ * last one the length block).  The tag of AES_GCM_encrypt is the XOR of all
+ * shards' shares -- a 16-byte-per-GPU exchange (RCCL all-gather), the only
+ * collective GCM needs.  All data pointers are device pointers.               */
+int uaes_gcm_partial_dev(int keybits, const uint8_t *key, const uint8_t *nonce,
+                         const void *d_aad, uint64_t total_aad_len,
+                         const void *d_ct_shard, size_t shard_len, uint64_t shard_offset,
+                         uint64_t total_len, void *d_partial16, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

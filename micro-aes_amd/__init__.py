@@ -38,7 +38,7 @@ EXPORTS = [
     "uaes_gcm_encrypt", "uaes_gcm_decrypt", "uaes_ghash",
     "uaes_cmac", "uaes_ccm_encrypt", "uaes_ccm_decrypt",
     "uaes_ecb_dev", "uaes_ctr_xcrypt_at_dev", "uaes_xts_sectors_dev",
-    "uaes_gcm_encrypt_dev", "uaes_gcm_decrypt_dev",
+    "uaes_gcm_encrypt_dev", "uaes_gcm_decrypt_dev", "uaes_gcm_partial_dev",
 ]
 COMPAT_EXPORTS = [
     "AES_ECB_encrypt", "AES_ECB_decrypt", "AES_CTR_encrypt", "AES_CTR_decrypt",
@@ -106,6 +106,7 @@ def engine():
     L.uaes_xts_sectors_dev.argtypes = [i, vp, u64, sz, sz, vp, vp, i, vp]
     L.uaes_gcm_encrypt_dev.argtypes = [i, vp, vp, vp, sz, vp, sz, vp, vp]
     L.uaes_gcm_decrypt_dev.argtypes = [i, vp, vp, vp, sz, vp, sz, vp, vp, vp]
+    L.uaes_gcm_partial_dev.argtypes = [i, vp, vp, vp, u64, vp, sz, u64, u64, vp, vp]
     L.uaes_expand_key.argtypes = [i, vp, vp, vp]
     for n in EXPORTS:
         if n not in ("uaes_last_error", "uaes_version"):
@@ -300,3 +301,11 @@ def gcm_decrypt_dev(key, nonce, aad, src, nbytes, dst, status, stream=None):
     _check(engine().uaes_gcm_decrypt_dev(_bits(key), _in(key), _in(nonce), _ptr(aad),
                                          0 if aad is None else aad.numel(), _ptr(src), nbytes, _ptr(dst),
                                          _ptr(status), _stream(stream)), "uaes_gcm_decrypt_dev")
+
+
+def gcm_partial_dev(key, nonce, aad, total_aad_len, ct_shard, shard_len, shard_offset, total_len, partial,
+                    stream=None):
+    """This shard's 16-byte share of the GCM tag (see uaes_gcm_partial_dev)."""
+    _check(engine().uaes_gcm_partial_dev(_bits(key), _in(key), _in(nonce), _ptr(aad), total_aad_len,
+                                         _ptr(ct_shard), shard_len, shard_offset, total_len, _ptr(partial),
+                                         _stream(stream)), "uaes_gcm_partial_dev")

@@ -72,6 +72,14 @@ int uaesk_gcm(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek,
               const void *in, size_t len, void *out,
               void *scratch, int *status);
 
+/* Sharded GCM: the weighted partial GHASH of one 16-byte-aligned ciphertext
+ * shard (first shard: + AAD and Enc(J0); last shard: + length block).  The tag
+ * of the whole message is the XOR of all shards' 16-byte results.           */
+int uaesk_gcm_partial(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek,
+                      const uint8_t *nonce12, const void *aad, uint64_t total_aad_len,
+                      const void *ct_shard, size_t shard_len, uint64_t shard_offset,
+                      uint64_t total_len, void *scratch, void *partial16);
+
 /* GHASH only: gh = GHASH_H(aad, ct) with H given (device), for tests.      */
 int uaesk_ghash(void *stream, const uint8_t *H_host,
                 const void *aad, size_t aad_len, const void *ct, size_t ct_len,

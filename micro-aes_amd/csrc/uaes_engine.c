@@ -655,6 +655,26 @@ int uaes_gcm_decrypt_dev(int keybits, const uint8_t *key, const uint8_t *nonce,
     return 0;
 }
 
+int uaes_gcm_partial_dev(int keybits, const uint8_t *key, const uint8_t *nonce,
+                         const void *d_aad, uint64_t total_aad_len,
+                         const void *d_ct_shard, size_t shard_len, uint64_t shard_offset,
+                         uint64_t total_len, void *d_partial16, void *stream)
+{
+    context *c;
+    keysched ks;
+    int rc;
+    if ((rc = expand_key(&ks, key, keybits)) != 0) return rc;
+    if (!nonce || !d_partial16) return fail(UAES_E_ARG, "NULL pointer");
+    if (shard_offset % 16 || shard_offset + shard_len > total_len)
+        return fail(UAES_E_ARG, "shard [%llu, +%zu) is not a 16-byte aligned slice of %llu bytes",
+                    (unsigned long long)shard_offset, shard_len, (unsigned long long)total_len);
+    if ((rc = get_context(&c)) != 0) return rc;
+    if ((rc = gcm_scratch(c)) != 0) return rc;
+    KCHK(uaesk_gcm_partial(stream, &c->tb, ks.nr, &ks.ek, nonce, d_aad, total_aad_len,
+                           d_ct_shard, shard_len, shard_offset, total_len, c->scratch, d_partial16));
+    return 0;
+}
+
 int uaes_ghash(const uint8_t H[16], const void *aData, size_t aDataLen,
                const void *crtxt, size_t crtxtLen, uint8_t gh[16])
 {

@@ -52,7 +52,9 @@
 #define GS_TAB8_B   (GS_TAB8_A + 65536u)        /* H^(2^14), 64 KiB           */
 #define GS_ACC1     (GS_TAB8_B + 65536u)        /* 2^17 x 16 = 2 MiB          */
 #define GS_ACC2     (GS_ACC1 + (16u << GH_MAXLOG))
-#define GS_TOTAL    (GS_ACC2 + (16u << GH_LOGB))
+#define GS_POW64    (GS_ACC2 + (16u << GH_LOGB))   /* H^(2^k), k = 0..63 (sharded GCM) */
+#define GS_PART     (GS_POW64 + 1024u)              /* raw GHASH of a shard             */
+#define GS_TOTAL    (GS_PART + 64u)
 
 static inline hipStream_t S(void *s) { return (hipStream_t)s; }
 
@@ -63,6 +65,8 @@ struct GSrc {
     const unsigned char *ct;      /* 16-byte aligned */
     u64 ct_len;
     u32 has_len;
+    u64 len_aad, len_ct;          /* byte lengths written into the length block (totals of the
+                                     whole message when this is one shard of it) */
 };
 
 __device__ __forceinline__ uint4 load_bytes_padded(const unsigned char *p, u64 avail)
@@ -82,7 +86,7 @@ __device__ __forceinline__ uint4 load_vblock(const GSrc &s, u64 v)
         if ((v + 1) * 16 <= s.ct_len) return ((const uint4 *)s.ct)[v];
         return load_bytes_padded(s.ct + v * 16, s.ct_len - v * 16);
     }
-    const u64 abits = s.aad_len * 8, cbits = s.ct_len * 8;      /* N6 */
+    const u64 abits = s.len_aad * 8, cbits = s.len_ct * 8;      /* N6 */
     return make_uint4(bswap32((u32)(abits >> 32)), bswap32((u32)abits),
                       bswap32((u32)(cbits >> 32)), bswap32((u32)cbits));
 }
@@ -314,7 +318,7 @@ __device__ __forceinline__ Gf wave_gfmul(Gf x, Gf y, u32 lane)
 template <int NR>
 __global__ __launch_bounds__(UAES_WG) void k_gcm_setup(uaesk_rk ek, uaesk_tables tb, uint4 j0,
                                                        unsigned char *__restrict__ scratch,
-                                                       u32 logA, u32 needB, u32 h_given, uint4 hval)
+                                                       u32 logA, u32 needB, u32 h_given, uint4 hval, u32 want_pow64)
 {
     Gf *shPow = (Gf *)(uaes_lds + UAES_LDS_ENC);          /* 18 powers         */
     Gf *shGen = shPow + 32;                                /* 6 x 128 generators */
@@ -339,9 +343,18 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_setup(uaesk_rk ek, uaesk_tables
 
     if (threadIdx.x < 64) {                    /* squaring chain, wave 0 */
         Gf p = shPow[0];
-        for (u32 k = 1; k <= GH_MAXLOG; ++k) {
-            p = wave_gfmul(p, p, threadIdx.x);
-            if (threadIdx.x == 0) shPow[k] = p;
+        uint4 *g64 = (uint4 *)(scratch + GS_POW64);
+        const u32 last = want_pow64 ? 63u : GH_MAXLOG;
+        for (u32 k = 0; k <= last; ++k) {
+            if (k) p = wave_gfmul(p, p, threadIdx.x);
+            if (threadIdx.x == 0) {
+                if (k <= GH_MAXLOG) shPow[k] = p;
+                if (want_pow64) {
+                    u32 w[4];
+                    gf_to_words(p, w);
+                    g64[k] = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+            }
         }
     }
     __syncthreads();
@@ -450,12 +463,12 @@ extern "C" size_t uaesk_gcm_scratch_bytes(void) { return GS_TOTAL; }
 
 template <int NR>
 static int launch_setup(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek, uint4 j0,
-                        unsigned char *scratch, const GPlan &pl, u32 h_given, uint4 hval)
+                        unsigned char *scratch, const GPlan &pl, u32 h_given, uint4 hval, u32 want_pow64 = 0)
 {
     hipError_t e = hipFuncSetAttribute((const void *)k_gcm_setup<NR>, hipFuncAttributeMaxDynamicSharedMemorySize, SETUP_LDS);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL((k_gcm_setup<NR>), dim3(1), dim3(UAES_WG), SETUP_LDS, st, *ek, *tb, j0, scratch,
-                       pl.logA, pl.needB, h_given, hval);
+                       pl.logA, pl.needB, h_given, hval, want_pow64);
     return (int)hipGetLastError();
 }
 
@@ -484,7 +497,7 @@ extern "C" int uaesk_gcm(void *stream, const uaesk_tables *tb, int nr, const uae
     GSrc msg;
     msg.aad = (const unsigned char *)aad; msg.aad_len = aad_len;
     msg.ct = (const unsigned char *)(decrypt ? in : out); msg.ct_len = len;
-    msg.has_len = 1;
+    msg.has_len = 1; msg.len_aad = aad_len; msg.len_ct = len;
     const u64 nv = ((aad_len + 15) >> 4) + ((len + 15) >> 4) + 1;
     const GPlan pl = plan_for(nv);
 
@@ -517,7 +530,7 @@ extern "C" int uaesk_ghash(void *stream, const uint8_t *H_host,
     GSrc msg;
     msg.aad = (const unsigned char *)aad; msg.aad_len = aad_len;
     msg.ct = (const unsigned char *)ct; msg.ct_len = ct_len;
-    msg.has_len = 1;
+    msg.has_len = 1; msg.len_aad = aad_len; msg.len_ct = ct_len;
     const u64 nv = ((aad_len + 15) >> 4) + ((ct_len + 15) >> 4) + 1;
     const GPlan pl = plan_for(nv);
     uint4 h;
@@ -528,4 +541,87 @@ extern "C" int uaesk_ghash(void *stream, const uint8_t *H_host,
     int rc = launch_setup<10>(st, &dummy_tb, &dummy_rk, make_uint4(0, 0, 0, 0), sc, pl, 1, h);
     if (rc) return rc;
     return run_ghash_levels(st, msg, nv, pl, sc, 2, (unsigned char *)gh_out16, nullptr);
+}
+
+
+/* ------------------------------------------------------------------------ */
+/* sharded GCM (multi-GPU): weighted partial GHASH of one shard               */
+/* ------------------------------------------------------------------------ */
+/* out16 <- P * H^e (^ Enc(J0) on the first shard), P = raw GHASH of the shard at
+ * scratch+GS_PART, H^(2^k) at scratch+GS_POW64; one wave (square-and-multiply
+ * with the wave-cooperative product).                                        */
+__global__ __launch_bounds__(64) void k_gcm_weight(const unsigned char *__restrict__ scratch, u64 e,
+                                                   u32 add_ej0, u32 zero, unsigned char *__restrict__ out16)
+{
+    const uint4 p4 = *(const uint4 *)(scratch + GS_PART);
+    Gf acc = gf_from_words(p4.x, p4.y, p4.z, p4.w);
+    if (zero) { acc.hi = 0; acc.lo = 0; }
+    const uint4 *pw = (const uint4 *)(scratch + GS_POW64);
+    for (u32 k = 0; k < 64; ++k) {
+        if ((e >> k) & 1) {                                   /* wave-uniform */
+            const uint4 h = pw[k];
+            acc = wave_gfmul(acc, gf_from_words(h.x, h.y, h.z, h.w), threadIdx.x);
+        }
+    }
+    if (threadIdx.x == 0) {
+        u32 w[4];
+        gf_to_words(acc, w);
+        if (add_ej0) {
+            const uint4 ej = *(const uint4 *)(scratch + GS_EJ0);
+            w[0] ^= ej.x; w[1] ^= ej.y; w[2] ^= ej.z; w[3] ^= ej.w;
+        }
+        for (u32 i = 0; i < 16; ++i) out16[i] = (unsigned char)(w[i >> 2] >> (8 * (i & 3)));
+    }
+}
+
+/* The GHASH input of a message is the block sequence [AAD][CT][lengths], M
+ * blocks; GHASH = sum X_v * H^(M-v).  A shard owning blocks [lo, hi) computes
+ * P = sum X_v * H^(hi-v) with the ordinary levels and weights it by H^(M-hi);
+ * the tag is the XOR of all shards' results (Enc(J0) rides on the first).
+ * Shards are 16-byte aligned slices of the ciphertext; the first one also
+ * carries the AAD, the last one the length block (with the TOTAL lengths).  */
+extern "C" int uaesk_gcm_partial(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek,
+                                 const uint8_t *nonce12, const void *aad, uint64_t total_aad_len,
+                                 const void *ct_shard, size_t shard_len, uint64_t shard_offset,
+                                 uint64_t total_len, void *scratch, void *partial16)
+{
+    hipStream_t st = S(stream);
+    unsigned char *sc = (unsigned char *)scratch;
+    if (shard_offset % 16 || shard_offset + shard_len > total_len) return (int)hipErrorInvalidValue;
+    const bool first = shard_offset == 0, last = shard_offset + shard_len == total_len;
+    const u64 a_blk = (total_aad_len + 15) >> 4, c_blk = (total_len + 15) >> 4;
+    const u64 m_total = a_blk + c_blk + 1;
+    const u64 lo = first ? 0 : a_blk + shard_offset / 16;
+    const u64 hi = a_blk + ((shard_offset + shard_len + 15) >> 4) + (last ? 1 : 0);
+    const u64 nv = hi - lo;
+
+    uint4 j0;
+    unsigned char j0b[16];
+    memcpy(j0b, nonce12, 12);
+    j0b[12] = j0b[13] = j0b[14] = 0; j0b[15] = 1;
+    memcpy(&j0, j0b, 16);
+
+    GSrc msg;
+    msg.aad = first ? (const unsigned char *)aad : nullptr;
+    msg.aad_len = first ? total_aad_len : 0;
+    msg.ct = (const unsigned char *)ct_shard; msg.ct_len = shard_len;
+    msg.has_len = last ? 1 : 0;
+    msg.len_aad = total_aad_len; msg.len_ct = total_len;
+    const GPlan pl = plan_for(nv ? nv : 1);
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    int rc;
+    switch (nr) {
+    case 10: rc = launch_setup<10>(st, tb, ek, j0, sc, pl, 0, z, 1); break;
+    case 12: rc = launch_setup<12>(st, tb, ek, j0, sc, pl, 0, z, 1); break;
+    case 14: rc = launch_setup<14>(st, tb, ek, j0, sc, pl, 0, z, 1); break;
+    default: return (int)hipErrorInvalidValue;
+    }
+    if (rc) return rc;
+    if (nv) {
+        rc = run_ghash_levels(st, msg, nv, pl, sc, 2, sc + GS_PART, nullptr);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(k_gcm_weight, dim3(1), dim3(64), 0, st, (const unsigned char *)sc, m_total - hi,
+                       (u32)first, (u32)(nv == 0), (unsigned char *)partial16);
+    return (int)hipGetLastError();
 }

@@ -14,7 +14,15 @@ same single-GPU kernels on its own shard:
   shard_start / sector_bytes`` (the sectid convention, micro_aes.c:1017-1021).
 * ECB -- any block partition.
 
-There is NO collective on the data path.  ``gather`` is the optional final
+* GCM -- CTR shards as above (counter block ``nonce || 00000001``, block offset
+  ``1 + shard_start/16``: the CCM_GCM pre-increment, micro_aes.c:939-941); for
+  the tag every rank computes its 16-byte share of ``Enc(J0) ^ GHASH`` over its
+  own ciphertext shard (``uaes_gcm_partial_dev``: the shard's GHASH weighted by
+  ``H^(blocks after the shard)``; the first shard carries the AAD and Enc(J0), the
+  last one the length block) and the shares are XORed after a 16-byte-per-rank
+  all-gather -- the one real exchange step on this path.
+
+There is NO collective on the bulk data path.  ``gather`` is the optional final
 step north_star asks for (ciphertext all-gather over xGMI); it costs ~20x the
 encrypt itself (7 peers x 1 GiB over ~153 GB/s links vs. ~0.5 ms of kernel), so
 callers that keep data sharded should leave it off.
@@ -89,3 +97,59 @@ def xts_sectors_sharded(keys, first_sector, sector_bytes, nsectors, local_src, l
         import torch.distributed as dist
         dist.all_gather_into_tensor(gather_into, local_dst, group=group)
     return start, ns
+
+
+def gcm_shard_roles(total_len, rank, world):
+    """(byte_start, nbytes, participates) of rank's GCM shard.  Rank 0 always
+    participates (it owns the AAD / Enc(J0) and, for a short message, the length
+    block); a later rank with an empty shard contributes nothing."""
+    start, n = shard_bounds(total_len, world, 16)[rank]
+    return start, n, (rank == 0 or n > 0)
+
+
+def gcm_encrypt_sharded(key, nonce, aad, total_aad_len, total_len, local_src, local_dst, rank, world,
+                        cipher=None, partial=None, gather=None):
+    """Encrypt this rank's shard of ONE GCM message and return the 16-byte tag
+    (identical on every rank).
+
+    cipher(key, ctr0, block_offset, src, dst, nbytes) and
+    partial(key, nonce, aad, total_aad_len, ct_shard, nbytes, shard_start, total_len) -> 16 bytes
+    default to the HIP engine; gather(share: bytes) -> list of all ranks' shares
+    defaults to torch.distributed.all_gather (RCCL over xGMI).
+    """
+    if cipher is None or partial is None:
+        import torch
+        from . import ctr_xcrypt_dev, gcm_partial_dev
+
+        def cipher(k, c, off, s, d, n):
+            ctr_xcrypt_dev(k, c, off, s, d, nbytes=n)
+
+        def partial(k, no, a, ta, ct, n, start, total):
+            out = torch.zeros(16, dtype=torch.uint8, device=ct.device)
+            gcm_partial_dev(k, no, a, ta, ct, n, start, total, out)
+            return out
+    start, n, takes_part = gcm_shard_roles(total_len, rank, world)
+    ctr0 = bytes(nonce) + b"\x00\x00\x00\x01"
+    if n:
+        cipher(key, ctr0, 1 + start // 16, local_src, local_dst, n)
+    share = partial(key, nonce, aad if rank == 0 else None, total_aad_len, local_dst, n, start, total_len) \
+        if takes_part else None
+    if gather is None:
+        import torch
+        import torch.distributed as dist
+        mine = share if share is not None else torch.zeros(16, dtype=torch.uint8, device=local_dst.device)
+        allp = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allp, mine)
+        shares = [bytes(t.cpu().numpy()) for t in allp]
+    else:
+        if share is None:
+            mine = bytes(16)
+        elif hasattr(share, "cpu"):
+            mine = bytes(share.cpu().numpy())
+        else:
+            mine = bytes(share)
+        shares = gather(mine)
+    tag = bytes(16)
+    for sh in shares:
+        tag = bytes(a ^ b for a, b in zip(tag, sh))
+    return tag

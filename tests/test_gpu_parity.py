@@ -257,6 +257,33 @@ def test_cmac_ccm_vs_oracle(orc, bits):
         assert uaes.AES_CCM_decrypt(key, nonce, aad, bytes(bad)) == (0x1A, data)
 
 
+@pytest.mark.parametrize("total,world,alen", [(0, 2, 5), (16, 2, 0), (1000, 3, 20), ((3 << 20) + 5, 4, 33),
+                                                (40 << 20, 8, 0)])
+def test_sharded_gcm_partials(orc, total, world, alen):
+    """multi-GPU GCM on one device: each 'rank' runs CTR + uaes_gcm_partial_dev on its
+    shard; the XOR of the 16-byte shares must be the single-call tag"""
+    import torch
+    import micro_aes_amd.sharding as sh
+    rnd = random.Random(total + world)
+    key, nonce, aad = rnd.randbytes(16), rnd.randbytes(12), rnd.randbytes(alen)
+    data = orc.splitmix(total + 3, total)
+    want = uaes.AES_GCM_encrypt(key, nonce, aad, data)
+    if total <= (4 << 20):
+        assert want == orc.gcm_encrypt(key, nonce, aad, data)
+    d_aad = torch.frombuffer(bytearray(aad), dtype=torch.uint8).to("cuda:0") if alen else None
+    shares, pieces = [], []
+    for rank in range(world):
+        start, n, _ = sh.gcm_shard_roles(total, rank, world)
+        src = torch.frombuffer(bytearray(data[start:start + n] + bytes(16)), dtype=torch.uint8).to("cuda:0")
+        dst = torch.zeros_like(src)
+        tag = sh.gcm_encrypt_sharded(key, nonce, d_aad, alen, total, src, dst, rank, world,
+                                     gather=lambda share: shares.append(share) or list(shares))
+        torch.cuda.synchronize()
+        pieces.append(bytes(dst[:n].cpu().numpy()))
+    assert b"".join(pieces) == want[:-16]
+    assert tag == want[-16:]
+
+
 def test_ghash_kernel_levels(orc):
     """every level plan of the GHASH kernels: direct, one bulk level, two bulk levels"""
     rnd = random.Random(77)

@@ -109,3 +109,62 @@ def test_ctr_and_xts_sharded_world2_gloo():
         p.join(60)
         assert p.exitcode == 0
     assert ok == (True, True)
+
+
+def _oracle_partial(orc, key, nonce, aad, total_aad_len, ct, n, start, total):
+    """CPU stand-in for uaes_gcm_partial_dev, from the oracle's primitives"""
+    H = orc.encrypt_block(key, bytes(16))
+    first, last = start == 0, start + n == total
+    a_blk, c_blk = (total_aad_len + 15) // 16, (total + 15) // 16
+    m_total = a_blk + c_blk + 1
+    blocks = []
+    if first and aad:
+        blocks += [aad[i:i + 16].ljust(16, b"\0") for i in range(0, len(aad), 16)]
+    blocks += [ct[i:i + 16].ljust(16, b"\0") for i in range(0, n, 16)]
+    if last:
+        blocks.append((total_aad_len * 8).to_bytes(8, "big") + (total * 8).to_bytes(8, "big"))
+    hi = a_blk + (start + n + 15) // 16 + (1 if last else 0)
+    acc = bytes(16)
+    for b in blocks:
+        acc = orc.gf128_mul(bytes(x ^ y for x, y in zip(acc, b)), H)
+    e, p = m_total - hi, H
+    one = bytes([0x80] + [0] * 15)
+    w = one
+    while e:
+        if e & 1:
+            w = orc.gf128_mul(w, p)
+        p = orc.gf128_mul(p, p)
+        e >>= 1
+    acc = orc.gf128_mul(acc, w)
+    if first:
+        j0 = nonce + b"\0\0\0\1"
+        acc = bytes(x ^ y for x, y in zip(acc, orc.encrypt_block(key, j0)))
+    return acc
+
+
+@pytest.mark.parametrize("total,world", [(0, 2), (5, 3), (16, 2), (1000, 3), (4096 + 7, 4), (100000, 8)])
+def test_sharded_gcm_math(orc, total, world):
+    """tag = XOR of per-shard weighted partial GHASHes == single-call GCM (oracle stand-ins, no GPU)"""
+    import random
+    rnd = random.Random(total + world)
+    key, nonce, aad = rnd.randbytes(16), rnd.randbytes(12), rnd.randbytes(rnd.choice([0, 3, 16, 40]))
+    data = orc.splitmix(total + 1, total)
+    want = orc.gcm_encrypt(key, nonce, aad, data)
+    pieces, shares = [], []
+
+    def cipher(k, c, off, s, d, n):
+        d[:n] = orc.ctr_xcrypt_at(k, c, off, bytes(s[:n]))
+
+    def partial(k, no, a, ta, ct, n, start, tot):
+        return _oracle_partial(orc, k, no, a, ta, bytes(ct[:n]), n, start, tot)
+
+    for rank in range(world):
+        start, n, _ = sh.gcm_shard_roles(total, rank, world)
+        src, dst = bytearray(data[start:start + n]), bytearray(n)
+        # gather stand-in: collect this rank's share, return what is known so far
+        tag = sh.gcm_encrypt_sharded(key, nonce, aad, len(aad), total, src, dst, rank, world,
+                                     cipher=cipher, partial=partial,
+                                     gather=lambda share: shares.append(share) or list(shares))
+        pieces.append(bytes(dst))
+    assert b"".join(pieces) == want[:-16]
+    assert tag == want[-16:]            # after the last rank every share has been collected
