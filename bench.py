@@ -67,6 +67,30 @@ def sha_of(t):
     return h.hexdigest()
 
 
+def usable_cores():
+    """cores this process may actually use: affinity mask capped by the cgroup CPU quota"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                        n = min(n, max(1, q // int(g.read())))
+            break
+        except Exception:
+            continue
+    return max(1, min(n, 128))
+
+
 def cpu_baseline(workload):
     """Reference CPU path on this host: 1 core (the reference is single-threaded
     and non re-entrant, micro_aes.c:72) and, via fork, all cores."""
@@ -102,8 +126,8 @@ def cpu_baseline(workload):
            "sample": "%d MiB of the same synthetic %s workload, single call, gcc -O3" % (sample >> 20, workload)}
     # all cores: fork P processes over contiguous shards (throughput-equivalent;
     # the reference API cannot start a CTR shard at an offset)
-    P = os.cpu_count() or 1
-    per = max((sample // 4) // 4096 * 4096, 4096)
+    P = usable_cores()
+    per = max((sample // 16) // 4096 * 4096, 4096)
     t0 = time.perf_counter()
     pids = []
     for _ in range(P):
