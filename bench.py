@@ -98,7 +98,7 @@ def cpu_baseline(workload):
     from oracle.pyoracle import Oracle, Reference
     orc = Oracle()
     use_ref = Reference.available(128)
-    sample = {"ctr": 512 << 20, "ecb": 512 << 20, "xts": 512 << 20, "gcm": 64 << 20}[workload]
+    sample = {"ctr": 512 << 20, "ecb": 512 << 20, "xts": 512 << 20, "gcm": 64 << 20}.get(workload, 256 << 20)
     buf = np.empty(sample, dtype=np.uint8)
     orc.splitmix_into(2, buf)
     out = np.empty(sample + 16, dtype=np.uint8)
@@ -154,7 +154,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="ctr", choices=["ctr", "ecb", "xts", "gcm"])
+    ap.add_argument("--workload", default="ctr", choices=["ctr", "ecb", "xts", "gcm", "cbc-dec", "cfb-dec"])
     ap.add_argument("--bytes", type=int, default=GIB, help="bytes per GPU")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
@@ -187,7 +187,7 @@ def main():
     cdev = dev if a.backend == "nccl" else torch.device("cpu")   # where collective scalars live
 
     n = a.bytes
-    seed = {"ctr": 2, "ecb": 1, "xts": 3, "gcm": 4}[a.workload]
+    seed = {"ctr": 2, "ecb": 1, "xts": 3, "gcm": 4, "cbc-dec": 5, "cfb-dec": 6}[a.workload]
     # rank g owns bytes [g*n, (g+1)*n) of the world*n stream
     src = splitmix_device(torch, seed, n, rank * (n // 8), dev)
     dst = torch.empty(n + 16, dtype=torch.uint8, device=dev)
@@ -202,9 +202,19 @@ def main():
     elif a.workload == "xts":
         def step():
             uaes.xts_sectors_dev(KEY64, rank * (n // 4096), 4096, n // 4096, src, dst, stream=st)
-    else:
+    elif a.workload == "gcm":
         def step():
             uaes.gcm_encrypt_dev(KEY16, NONCE, None, src, n, dst, stream=st)
+    else:
+        # block-parallel decrypt directions of the feedback modes, through the host-pointer C ABI
+        # with device pointers (synchronous call: launch + stream sync)
+        import ctypes as C
+        L = uaes.engine()
+        fn = L.uaes_cbc_decrypt if a.workload == "cbc-dec" else L.uaes_cfb_decrypt
+        iv16 = bytes(range(16))
+
+        def step():
+            assert fn(128, KEY16, iv16, C.c_void_p(src.data_ptr()), n, C.c_void_p(dst.data_ptr())) == 0
 
     for _ in range(a.warmup):
         step()
@@ -265,6 +275,10 @@ def main():
                 verify = got == orc.ecb_encrypt(KEY16, head)
             elif a.workload == "xts":
                 verify = got == orc.xts_sectors(KEY64, rank * (n // 4096), 4096, head, True)[1]
+            elif a.workload == "cbc-dec":
+                verify = got[: m - 32] == orc.cbc(KEY16, bytes(range(16)), head, False)[1][: m - 32]
+            elif a.workload == "cfb-dec":
+                verify = got == orc.cfb(KEY16, bytes(range(16)), head, False)
         if dist:
             v = torch.tensor([1 if verify in (True, None) else 0], device=cdev)
             dist.all_reduce(v, op=dist.ReduceOp.MIN)
@@ -283,7 +297,8 @@ def main():
                 traffic = t["traffic_bytes"]          # PMC pass of the same command, per launch
         except Exception:
             pass
-        names = {"ctr": "AES-128-CTR", "ecb": "AES-128-ECB", "xts": "AES-256-XTS 4 KiB sectors", "gcm": "AES-128-GCM"}
+        names = {"ctr": "AES-128-CTR", "ecb": "AES-128-ECB", "xts": "AES-256-XTS 4 KiB sectors", "gcm": "AES-128-GCM",
+                 "cbc-dec": "AES-128-CBC decrypt", "cfb-dec": "AES-128-CFB decrypt"}
         line = {
             "metric": "GiB/s encrypted (AES-128-CTR, 1 GiB buffer per GPU)" if a.workload == "ctr"
                       else "GiB/s encrypted (%s)" % names[a.workload],

@@ -1,7 +1,8 @@
 /*
  * micro_aes.h -- drop-in replacement for the reference's public header, for
  * the modes served by the MI355X engine (ECB, CTR, XTS, GCM on the
- * block-parallel hot path; CMAC and CCM for the remaining NIST .rsp files).
+ * block-parallel hot path; CMAC and CCM for the remaining NIST .rsp files;
+ * CBC, CFB, OFB with their parallel decrypt directions).
  *
  * Same function names, argument order, return types and configuration macros
  * as polfosol/micro-AES v11 (micro_aes.h:17-129, :173-181, :239-249, :256-266,
@@ -36,9 +37,10 @@
 #define CMAC     1          /* serial CBC-MAC chains: one GPU lane (uaes_mac.hip) */
 #define CCM      1
 
-#define CBC      0          /* serial chains and MAC-only modes: not on the  */
-#define CFB      0          /* GPU hot path           */
-#define OFB      0
+#define CBC      1          /* feedback modes: decrypt of CBC/CFB is block-   */
+#define CFB      1          /* parallel, the rest one GPU lane (uaes_chain.hip) */
+#define OFB      1
+#define CTS      1          /* CBC ciphertext stealing, CS3 (micro_aes.h:57)  */
 #define KWA      0
 #define FPE      0
 #define EAX      0
@@ -47,7 +49,6 @@
 #define GCM_SIV  0
 #define OCB      0
 #define POLY1305 0
-#define CTS      0
 #define MICRO_RJNDL 0
 
 #define AES_PADDING     0   /* zero padding of a ragged ECB tail            */
@@ -97,6 +98,21 @@ void AES_GCM_encrypt(const uint8_t *key, const uint8_t *nonce,
                      const void *pntxt, const size_t ptextLen, void *crtxt);
 char AES_GCM_decrypt(const uint8_t *key, const uint8_t *nonce,
                      const void *aData, const size_t aDataLen,
+                     const void *crtxt, const size_t crtxtLen, void *pntxt);
+
+char AES_CBC_encrypt(const uint8_t *key, const uint8_t iVec[16],
+                     const void *pntxt, const size_t ptextLen, void *crtxt);
+char AES_CBC_decrypt(const uint8_t *key, const uint8_t iVec[16],
+                     const void *crtxt, const size_t crtxtLen, void *pntxt);
+
+void AES_CFB_encrypt(const uint8_t *key, const uint8_t iVec[16],
+                     const void *pntxt, const size_t ptextLen, void *crtxt);
+void AES_CFB_decrypt(const uint8_t *key, const uint8_t iVec[16],
+                     const void *crtxt, const size_t crtxtLen, void *pntxt);
+
+void AES_OFB_encrypt(const uint8_t *key, const uint8_t iVec[16],
+                     const void *pntxt, const size_t ptextLen, void *crtxt);
+void AES_OFB_decrypt(const uint8_t *key, const uint8_t iVec[16],
                      const void *crtxt, const size_t crtxtLen, void *pntxt);
 
 void AES_CCM_encrypt(const uint8_t *key, const uint8_t *nonce,

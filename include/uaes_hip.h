@@ -138,6 +138,23 @@ int uaes_ccm_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
                      const void *aData, size_t aDataLen,
                      const void *crtxt, size_t crtxtLen, void *pntxt);
 
+/* ---- CBC / CFB / OFB: replace AES_CBC_*, AES_CFB_*, AES_OFB_* -------------
+ * micro_aes.c:697-782 (CBC with CS3 ciphertext stealing, CTS 1: the last two
+ * blocks are always swapped, len < 16 -> UAES_E_DATALENGTH), :799-845 (CFB),
+ * :861-893 (OFB; decrypt is the same function).  iVec = 16 bytes.  The
+ * decrypt directions of CBC and CFB are block-parallel kernels; the encrypt
+ * directions and OFB are serial chains walked by one GPU lane (~10 MB/s).     */
+int uaes_cbc_encrypt(int keybits, const uint8_t *key, const uint8_t *iVec,
+                     const void *pntxt, size_t ptextLen, void *crtxt);
+int uaes_cbc_decrypt(int keybits, const uint8_t *key, const uint8_t *iVec,
+                     const void *crtxt, size_t crtxtLen, void *pntxt);
+int uaes_cfb_encrypt(int keybits, const uint8_t *key, const uint8_t *iVec,
+                     const void *pntxt, size_t ptextLen, void *crtxt);
+int uaes_cfb_decrypt(int keybits, const uint8_t *key, const uint8_t *iVec,
+                     const void *crtxt, size_t crtxtLen, void *pntxt);
+int uaes_ofb_xcrypt(int keybits, const uint8_t *key, const uint8_t *iVec,
+                    const void *in, size_t len, void *out);
+
 /* ---- asynchronous, device-resident variants -----------------------------
  * All data pointers are device pointers, 16-byte aligned; `stream` is a
  * hipStream_t (NULL = default stream).  The call only enqueues work.  One

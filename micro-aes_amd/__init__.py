@@ -37,6 +37,7 @@ EXPORTS = [
     "uaes_xts_encrypt", "uaes_xts_decrypt", "uaes_xts_sectors",
     "uaes_gcm_encrypt", "uaes_gcm_decrypt", "uaes_ghash",
     "uaes_cmac", "uaes_ccm_encrypt", "uaes_ccm_decrypt",
+    "uaes_cbc_encrypt", "uaes_cbc_decrypt", "uaes_cfb_encrypt", "uaes_cfb_decrypt", "uaes_ofb_xcrypt",
     "uaes_ecb_dev", "uaes_ctr_xcrypt_at_dev", "uaes_xts_sectors_dev",
     "uaes_gcm_encrypt_dev", "uaes_gcm_decrypt_dev", "uaes_gcm_partial_dev",
 ]
@@ -44,6 +45,7 @@ COMPAT_EXPORTS = [
     "AES_ECB_encrypt", "AES_ECB_decrypt", "AES_CTR_encrypt", "AES_CTR_decrypt",
     "AES_XTS_encrypt", "AES_XTS_decrypt", "AES_GCM_encrypt", "AES_GCM_decrypt",
     "AES_CCM_encrypt", "AES_CCM_decrypt", "AES_CMAC",
+    "AES_CBC_encrypt", "AES_CBC_decrypt", "AES_CFB_encrypt", "AES_CFB_decrypt", "AES_OFB_encrypt", "AES_OFB_decrypt",
 ]
 
 
@@ -99,6 +101,8 @@ def engine():
         getattr(L, n).argtypes = [i, vp, vp, vp, sz, vp, sz, vp]
     L.uaes_ghash.argtypes = [vp, vp, sz, vp, sz, vp]
     L.uaes_cmac.argtypes = [i, vp, vp, sz, vp]
+    for n in ("uaes_cbc_encrypt", "uaes_cbc_decrypt", "uaes_cfb_encrypt", "uaes_cfb_decrypt", "uaes_ofb_xcrypt"):
+        getattr(L, n).argtypes = [i, vp, vp, vp, sz, vp]
     for n in ("uaes_ccm_encrypt", "uaes_ccm_decrypt"):
         getattr(L, n).argtypes = [i, vp, vp, vp, sz, vp, sz, vp]
     L.uaes_ecb_dev.argtypes = [i, vp, i, vp, sz, vp, vp]
@@ -218,6 +222,40 @@ def AES_GCM_decrypt(key, nonce, aData, crtxt_and_tag, prefill=0):
     rc = _check(engine().uaes_gcm_decrypt(_bits(key), _in(key), _in(nonce), _in(aData), len(aData),
                                           _in(crtxt_and_tag), n, o), "AES_GCM_decrypt")
     return rc, bytes(o)[:n]
+
+
+def _fb(fn, name, key, iVec, data, prefill=0):
+    o = _out(len(data), prefill)
+    rc = _check(fn(_bits(key), _in(key), _in(iVec), _in(data), len(data), o), name)
+    return rc, bytes(o)[: len(data)]
+
+
+def AES_CBC_encrypt(key, iVec, pntxt, prefill=0):
+    """micro_aes.c:697 (CS3 ciphertext stealing).  Returns (code, ciphertext); code 1 if len < 16."""
+    return _fb(engine().uaes_cbc_encrypt, "AES_CBC_encrypt", key, iVec, pntxt, prefill)
+
+
+def AES_CBC_decrypt(key, iVec, crtxt, prefill=0):
+    """micro_aes.c:746."""
+    return _fb(engine().uaes_cbc_decrypt, "AES_CBC_decrypt", key, iVec, crtxt, prefill)
+
+
+def AES_CFB_encrypt(key, iVec, pntxt):
+    """micro_aes.c:825."""
+    return _fb(engine().uaes_cfb_encrypt, "AES_CFB_encrypt", key, iVec, pntxt)[1]
+
+
+def AES_CFB_decrypt(key, iVec, crtxt):
+    """micro_aes.c:839."""
+    return _fb(engine().uaes_cfb_decrypt, "AES_CFB_decrypt", key, iVec, crtxt)[1]
+
+
+def AES_OFB_encrypt(key, iVec, data):
+    """micro_aes.c:861; decrypt is the same function (:887)."""
+    return _fb(engine().uaes_ofb_xcrypt, "AES_OFB_encrypt", key, iVec, data)[1]
+
+
+AES_OFB_decrypt = AES_OFB_encrypt
 
 
 def AES_CMAC(key, data):

@@ -1,0 +1,292 @@
+/*
+ * uaes_chain.hip -- the feedback modes: CBC (with CS3
+ * ciphertext stealing), CFB and OFB.
+ *
+ *   k_cbc_dec / k_cfb_dec   block-PARALLEL directions:
+ *                             CBC  P_i = Dec(C_i) ^ C_{i-1}   (micro_aes.c:746-782)
+ *                             CFB  P_i = Enc(C_{i-1}) ^ C_i   (micro_aes.c:799-817, mode 0)
+ *                           same launch shape as k_ecb (persistent 1024-thread
+ *                           workgroups, 4 blocks per lane, 1 KiB wave accesses).
+ *   k_chain_serial          the inherently serial directions -- CBC encrypt
+ *                           (:697-744), CFB encrypt (:799-817, mode 1), OFB
+ *                           (:861-893) -- and the CTS pair of CBC decrypt: one
+ *                           lane walks the chain (north_star: "CBC/CFB/OFB stay
+ *                           single-GPU because the chain is serial").
+ *
+ * The parallel kernels read C_{i-1} from the INPUT buffer, so they must not run
+ * in place; the host layer gives them a private copy of the input when
+ * in == out (the reference itself works in place, serially).
+ */
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include "uaes_aes.hip.h"
+#include "uaes_device.h"
+
+#define UAES_U 4
+static inline hipStream_t S(void *s) { return (hipStream_t)s; }
+
+/* ------------------------------------------------------------------------ */
+/* parallel decrypt directions                                                */
+/* ------------------------------------------------------------------------ */
+/* CFB=false: CBC decrypt of blocks [0, n): out_i = Dec(in_i) ^ prev_i
+ * CFB=true : CFB decrypt of blocks [0, n): out_i = Enc(prev_i) ^ in_i, plus
+ *            `rem` tail bytes out = Enc(prev_n)[0..rem) ^ in   (mixThenXor, :816)
+ * prev_0 = iv, prev_i = in_{i-1}.                                            */
+template <int NR, bool CFB>
+__global__ __launch_bounds__(UAES_WG) void k_fb_dec(uaesk_rk rk, uaesk_tables tb, uint4 iv,
+                                                    const uint4 *__restrict__ in, uint4 *__restrict__ out,
+                                                    u64 n, u32 rem)
+{
+    if (CFB) fill_enc_tables(tb.te0); else fill_dec_tables(tb.td0, tb.si4);
+    const LaneConst lc = make_lane_const();
+    const u64 stride = (u64)gridDim.x * UAES_WG * UAES_U;
+    for (u64 base = (u64)blockIdx.x * UAES_WG * UAES_U; base < n; base += stride) {
+        u32 s[UAES_U][4];
+        uint4 x[UAES_U], prev[UAES_U];
+        u64 idx[UAES_U];
+#pragma unroll
+        for (int u = 0; u < UAES_U; ++u) {
+            idx[u] = base + (u64)u * UAES_WG + threadIdx.x;
+            const u64 i = idx[u] < n ? idx[u] : n - 1;
+            x[u] = in[i];
+            prev[u] = i ? in[i - 1] : iv;
+            const uint4 src = CFB ? prev[u] : x[u];
+            s[u][0] = src.x; s[u][1] = src.y; s[u][2] = src.z; s[u][3] = src.w;
+        }
+        if (CFB) enc_blocks<NR, UAES_U>(s, rk, lc); else dec_blocks<NR, UAES_U>(s, rk, lc);
+#pragma unroll
+        for (int u = 0; u < UAES_U; ++u) {
+            const uint4 m = CFB ? x[u] : prev[u];
+            if (idx[u] < n) out[idx[u]] = make_uint4(s[u][0] ^ m.x, s[u][1] ^ m.y, s[u][2] ^ m.z, s[u][3] ^ m.w);
+        }
+    }
+    if (CFB && rem && blockIdx.x == 0 && threadIdx.x == 0) {
+        const uint4 p = n ? in[n - 1] : iv;
+        u32 s1[1][4] = { { p.x, p.y, p.z, p.w } };
+        enc_blocks<NR, 1>(s1, rk, lc);
+        const unsigned char *src = (const unsigned char *)(in + n);
+        unsigned char *dst = (unsigned char *)(out + n);
+        for (u32 i = 0; i < rem; ++i) dst[i] = src[i] ^ (unsigned char)(s1[0][i >> 2] >> (8 * (i & 3)));
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* serial directions: one lane                                                */
+/* ------------------------------------------------------------------------ */
+struct Blk {
+    u32 w[4];
+};
+
+__device__ __forceinline__ Blk ldb(const unsigned char *p, u32 nbytes)        /* zero padded */
+{
+    Blk b = { { 0, 0, 0, 0 } };
+    if (nbytes >= 16 && (((uintptr_t)p) & 15u) == 0) {
+        const uint4 v = *(const uint4 *)p;
+        b.w[0] = v.x; b.w[1] = v.y; b.w[2] = v.z; b.w[3] = v.w;
+        return b;
+    }
+    for (u32 i = 0; i < (nbytes < 16 ? nbytes : 16u); ++i) b.w[i >> 2] |= (u32)p[i] << (8 * (i & 3));
+    return b;
+}
+
+__device__ __forceinline__ void stb(unsigned char *p, const Blk &b, u32 nbytes)
+{
+    if (nbytes >= 16 && (((uintptr_t)p) & 15u) == 0) {
+        *(uint4 *)p = make_uint4(b.w[0], b.w[1], b.w[2], b.w[3]);
+        return;
+    }
+    for (u32 i = 0; i < (nbytes < 16 ? nbytes : 16u); ++i) p[i] = (unsigned char)(b.w[i >> 2] >> (8 * (i & 3)));
+}
+
+__device__ __forceinline__ void xb(Blk &a, const Blk &b)
+{
+    a.w[0] ^= b.w[0]; a.w[1] ^= b.w[1]; a.w[2] ^= b.w[2]; a.w[3] ^= b.w[3];
+}
+
+template <int NR>
+__device__ __forceinline__ void encb(Blk &b, const uaesk_rk &rk, const LaneConst &lc)
+{
+    u32 s[1][4] = { { b.w[0], b.w[1], b.w[2], b.w[3] } };
+    enc_blocks<NR, 1>(s, rk, lc);
+    b.w[0] = s[0][0]; b.w[1] = s[0][1]; b.w[2] = s[0][2]; b.w[3] = s[0][3];
+}
+
+template <int NR>
+__device__ __forceinline__ void decb(Blk &b, const uaesk_rk &dk, const LaneConst &lc)
+{
+    u32 s[1][4] = { { b.w[0], b.w[1], b.w[2], b.w[3] } };
+    dec_blocks<NR, 1>(s, dk, lc);
+    b.w[0] = s[0][0]; b.w[1] = s[0][1]; b.w[2] = s[0][2]; b.w[3] = s[0][3];
+}
+
+/* first r bytes of a, the rest of b */
+__device__ __forceinline__ Blk splice(const Blk &a, const Blk &b, u32 r)
+{
+    Blk o;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        u32 v = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const u32 i = 4 * w + k;
+            v |= ((((i < r) ? a.w[w] : b.w[w]) >> (8 * k)) & 0xffu) << (8 * k);
+        }
+        o.w[w] = v;
+    }
+    return o;
+}
+
+enum { CH_CBC_ENC = 0, CH_CFB_ENC = 1, CH_OFB = 2, CH_CBC_DEC_CTS = 3 };
+
+/* OP = CH_CBC_ENC     whole message, CS3 ciphertext stealing (AES_CBC_encrypt :697-744); len >= 16
+ *      CH_CFB_ENC     whole message (:799-817 mode 1)
+ *      CH_OFB         whole message (:861-886)
+ *      CH_CBC_DEC_CTS the last two blocks {X full, Z r bytes} of AES_CBC_decrypt (:770-778):
+ *                     in/out point at X; iv = the block before X (or the IV)          */
+template <int NR, int OP>
+__global__ __launch_bounds__(UAES_WG) void k_chain_serial(uaesk_rk rk, uaesk_tables tb, uint4 iv4,
+                                                          const uint4 *__restrict__ iv_dev,   /* overrides iv4 if set */
+                                                          const unsigned char *__restrict__ in,
+                                                          unsigned char *__restrict__ out, u64 len)
+{
+    if (OP == CH_CBC_DEC_CTS) fill_dec_tables(tb.td0, tb.si4); else fill_enc_tables(tb.te0);
+    if (threadIdx.x != 0) return;
+    const LaneConst lc = make_lane_const();
+    if (iv_dev) iv4 = *iv_dev;
+    Blk iv = { { iv4.x, iv4.y, iv4.z, iv4.w } };
+
+    if (OP == CH_CBC_ENC) {
+        u64 n = len / 16;
+        u32 r = (u32)(len % 16);
+        if (n > 1 && !r) { --n; r = 16; }                 /* CS3: always swap the last two (:706) */
+        for (u64 i = 0; i < n; ++i) {
+            Blk b = ldb(in + 16 * i, 16);
+            xb(b, iv);
+            encb<NR>(b, rk, lc);
+            stb(out + 16 * i, b, 16);
+            iv = b;
+        }
+        if (r) {                                          /* iv == C_{n-1} here */
+            Blk l = ldb(in + 16 * n, r);                  /* the last (short or swapped) chunk, zero padded */
+            stb(out + 16 * n, iv, r);                     /* its place takes the head of C_{n-1} ("stolen") */
+            xb(l, iv);
+            encb<NR>(l, rk, lc);
+            stb(out + 16 * (n - 1), l, 16);
+        }
+    } else if (OP == CH_CFB_ENC) {
+        const u64 n = len / 16;
+        const u32 r = (u32)(len % 16);
+        for (u64 i = 0; i < n; ++i) {
+            encb<NR>(iv, rk, lc);
+            const Blk b = ldb(in + 16 * i, 16);
+            xb(iv, b);                                    /* C_i = Enc(C_{i-1}) ^ P_i = next feedback */
+            stb(out + 16 * i, iv, 16);
+        }
+        if (r) {
+            encb<NR>(iv, rk, lc);
+            const Blk b = ldb(in + 16 * n, r);
+            xb(iv, b);
+            stb(out + 16 * n, iv, r);
+        }
+    } else if (OP == CH_OFB) {
+        const u64 n = (len + 15) / 16;
+        for (u64 i = 0; i < n; ++i) {
+            const u32 take = (len - 16 * i) < 16 ? (u32)(len - 16 * i) : 16u;
+            encb<NR>(iv, rk, lc);                          /* O_i = Enc(O_{i-1}) */
+            Blk b = ldb(in + 16 * i, take);
+            xb(b, iv);
+            stb(out + 16 * i, b, take);
+        }
+    } else {                                              /* CH_CBC_DEC_CTS; rk = decryption keys */
+        const u32 r = (u32)len;                           /* size of Z, 1..16 */
+        const Blk x = ldb(in, 16), z = ldb(in + 16, r);
+        Blk y = x;
+        decb<NR>(y, rk, lc);                              /* Y = Dec(X) */
+        Blk p2 = y;
+        xb(p2, z);                                        /* P2 = Y ^ Z (first r bytes) */
+        Blk c = splice(z, y, r);                          /* Z | tail of Y */
+        decb<NR>(c, rk, lc);
+        xb(c, iv);
+        stb(out, c, 16);
+        stb(out + 16, p2, r);
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* launchers                                                                  */
+/* ------------------------------------------------------------------------ */
+#define DISPATCH_NR(nr, CALL)                         \
+    switch (nr) {                                     \
+    case 10: { constexpr int NR = 10; CALL; } break;  \
+    case 12: { constexpr int NR = 12; CALL; } break;  \
+    case 14: { constexpr int NR = 14; CALL; } break;  \
+    default: return (int)hipErrorInvalidValue;        \
+    }
+
+static unsigned cu_count()
+{
+    static int cus = 0;
+    if (!cus) uaesk_device_info(&cus, nullptr);
+    return cus > 0 ? (unsigned)cus : 256u;
+}
+
+template <int NR, bool CFB>
+static int launch_fb_dec(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *k, uint4 iv,
+                         const void *in, void *out, u64 n, u32 rem)
+{
+    const unsigned lds = CFB ? UAES_LDS_ENC : UAES_LDS_DEC;
+    hipError_t e = hipFuncSetAttribute((const void *)k_fb_dec<NR, CFB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    u64 want = (n + (u64)UAES_WG * UAES_U - 1) / ((u64)UAES_WG * UAES_U);
+    if (!want) want = 1;
+    const unsigned grid = (unsigned)(want < cu_count() ? want : cu_count());
+    hipLaunchKernelGGL((k_fb_dec<NR, CFB>), dim3(grid), dim3(UAES_WG), lds, st, *k, *tb, iv,
+                       (const uint4 *)in, (uint4 *)out, n, rem);
+    return (int)hipGetLastError();
+}
+
+template <int NR, int OP>
+static int launch_serial(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *k, uint4 iv,
+                         const void *in, void *out, u64 len, const uint4 *iv_dev = nullptr)
+{
+    const unsigned lds = OP == CH_CBC_DEC_CTS ? UAES_LDS_DEC : UAES_LDS_ENC;
+    hipError_t e = hipFuncSetAttribute((const void *)k_chain_serial<NR, OP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((k_chain_serial<NR, OP>), dim3(1), dim3(UAES_WG), lds, st, *k, *tb, iv, iv_dev,
+                       (const unsigned char *)in, (unsigned char *)out, len);
+    return (int)hipGetLastError();
+}
+
+/* mode: 0 CBC encrypt, 1 CBC decrypt, 2 CFB encrypt, 3 CFB decrypt, 4 OFB.
+ * ek / dk: encryption / equivalent-inverse keys; iv16: host pointer.
+ * Parallel directions (1, 3) require in != out.  CBC needs len >= 16.        */
+extern "C" int uaesk_feedback(void *stream, const uaesk_tables *tb, int nr,
+                              const uaesk_rk *ek, const uaesk_rk *dk, int mode, const uint8_t *iv16,
+                              const void *in, size_t len, void *out)
+{
+    hipStream_t st = S(stream);
+    uint4 iv;
+    memcpy(&iv, iv16, 16);
+    if (len == 0) return 0;
+    switch (mode) {
+    case 0: DISPATCH_NR(nr, return (launch_serial<NR, CH_CBC_ENC>(st, tb, ek, iv, in, out, len))); break;
+    case 2: DISPATCH_NR(nr, return (launch_serial<NR, CH_CFB_ENC>(st, tb, ek, iv, in, out, len))); break;
+    case 4: DISPATCH_NR(nr, return (launch_serial<NR, CH_OFB>(st, tb, ek, iv, in, out, len))); break;
+    case 3: DISPATCH_NR(nr, return (launch_fb_dec<NR, true>(st, tb, ek, iv, in, out, len / 16, (u32)(len % 16)))); break;
+    case 1: {
+        u64 n = len / 16;
+        u32 r = (u32)(len % 16);
+        if (n > 1 && !r) { --n; r = 16; }                 /* CS3 (:756) */
+        if (r) --n;                                       /* hold the last two blocks (:764) */
+        int rc = 0;
+        if (n) { DISPATCH_NR(nr, rc = (launch_fb_dec<NR, false>(st, tb, dk, iv, in, out, n, 0))); }
+        if (rc || !r) return rc;
+        /* the block before X is the IV or C_{n-1}, which lives in device memory */
+        const uint4 *prev = n ? (const uint4 *)((const char *)in + 16 * (n - 1)) : nullptr;
+        DISPATCH_NR(nr, return (launch_serial<NR, CH_CBC_DEC_CTS>(st, tb, dk, iv, (const char *)in + 16 * n,
+                                                                 (char *)out + 16 * n, r, prev)));
+    } break;
+    default: return (int)hipErrorInvalidValue;
+    }
+    return 0;
+}

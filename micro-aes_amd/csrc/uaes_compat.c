@@ -95,3 +95,39 @@ void AES_CMAC(const uint8_t *key, const void *data, const size_t dataSize, uint8
 {
     must("AES_CMAC", uaes_cmac(KB, key, data, dataSize, mac));
 }
+
+char AES_CBC_encrypt(const uint8_t *key, const uint8_t iVec[16],
+                     const void *pntxt, const size_t ptextLen, void *crtxt)
+{
+    return soft("AES_CBC_encrypt", uaes_cbc_encrypt(KB, key, iVec, pntxt, ptextLen, crtxt), M_ENCRYPTION_ERROR);
+}
+
+char AES_CBC_decrypt(const uint8_t *key, const uint8_t iVec[16],
+                     const void *crtxt, const size_t crtxtLen, void *pntxt)
+{
+    return soft("AES_CBC_decrypt", uaes_cbc_decrypt(KB, key, iVec, crtxt, crtxtLen, pntxt), M_DECRYPTION_ERROR);
+}
+
+void AES_CFB_encrypt(const uint8_t *key, const uint8_t iVec[16],
+                     const void *pntxt, const size_t ptextLen, void *crtxt)
+{
+    must("AES_CFB_encrypt", uaes_cfb_encrypt(KB, key, iVec, pntxt, ptextLen, crtxt));
+}
+
+void AES_CFB_decrypt(const uint8_t *key, const uint8_t iVec[16],
+                     const void *crtxt, const size_t crtxtLen, void *pntxt)
+{
+    must("AES_CFB_decrypt", uaes_cfb_decrypt(KB, key, iVec, crtxt, crtxtLen, pntxt));
+}
+
+void AES_OFB_encrypt(const uint8_t *key, const uint8_t iVec[16],
+                     const void *pntxt, const size_t ptextLen, void *crtxt)
+{
+    must("AES_OFB_encrypt", uaes_ofb_xcrypt(KB, key, iVec, pntxt, ptextLen, crtxt));
+}
+
+void AES_OFB_decrypt(const uint8_t *key, const uint8_t iVec[16],
+                     const void *crtxt, const size_t crtxtLen, void *pntxt)
+{
+    must("AES_OFB_decrypt", uaes_ofb_xcrypt(KB, key, iVec, crtxt, crtxtLen, pntxt));
+}

@@ -96,6 +96,13 @@ int uaesk_ccm(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek,
               const void *aad, size_t aad_len,
               const void *in, size_t len, void *out, int *status);
 
+/* Feedback modes (micro_aes.c:697-893).  mode: 0 CBC encrypt (CS3 stealing),
+ * 1 CBC decrypt, 2 CFB encrypt, 3 CFB decrypt, 4 OFB.  iv16 is a host pointer.
+ * The block-parallel directions (1, 3) need in != out.                       */
+int uaesk_feedback(void *stream, const uaesk_tables *tb, int nr,
+                   const uaesk_rk *ek, const uaesk_rk *dk, int mode, const uint8_t *iv16,
+                   const void *in, size_t len, void *out);
+
 /* Device self-test of the primitives; writes a bitmask of failures.        */
 int uaesk_selftest(void *stream, const uaesk_tables *tb, const uaesk_rk *ek128,
                    const uaesk_rk *dk128, unsigned *d_result);

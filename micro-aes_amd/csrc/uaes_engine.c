@@ -772,3 +772,69 @@ int uaes_ccm_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
     } while (0);
     LOCKED_END(c, rc);
 }
+
+/* ------------------------------------------------------------------------ */
+/* CBC / CFB / OFB                                   */
+/* ------------------------------------------------------------------------ */
+/* mode: 0 CBC enc, 1 CBC dec, 2 CFB enc, 3 CFB dec, 4 OFB */
+static int feedback_common(int keybits, const uint8_t *key, const uint8_t *iVec, int mode,
+                           const void *in, size_t len, void *out)
+{
+    context *c;
+    keysched ks;
+    io_plan io;
+    int rc;
+    if ((rc = expand_key(&ks, key, keybits)) != 0) return rc;
+    if (!iVec) return fail(UAES_E_ARG, "NULL iVec");
+    if (mode <= 1 && len < 16) return UAES_E_DATALENGTH;          /* CTS: data size >= BLOCKSIZE (:708, :758) */
+    if (len == 0) return 0;
+    if (!in || !out) return fail(UAES_E_ARG, "NULL data pointer");
+    if ((rc = get_context(&c)) != 0) return rc;
+    LOCKED_BEGIN(c);
+    do {
+        if ((rc = plan_io(c, in, len, out, len, &io)) != 0) break;
+        if ((mode == 1 || mode == 3) && io.din == io.dout) {
+            /* the parallel directions read C_{i-1} from the input: give them a private copy */
+            if (grow(&c->stage[1], &c->stage_cap[1], len + 64)) { rc = UAES_E_HIP; break; }
+            if (hipMemcpyAsync(c->stage[1], io.din, len, hipMemcpyDeviceToDevice, NULL) != hipSuccess) {
+                rc = fail(UAES_E_HIP, "input copy failed");
+                break;
+            }
+            io.din = c->stage[1];
+        }
+        int k = uaesk_feedback(NULL, &c->tb, ks.nr, &ks.ek, &ks.dk, mode, iVec, io.din, len, io.dout);
+        if (k) { rc = fail(UAES_E_HIP, "feedback-mode launch: %s", hipGetErrorString((hipError_t)k)); break; }
+        rc = finish_io(&io, len);
+    } while (0);
+    LOCKED_END(c, rc);
+}
+
+int uaes_cbc_encrypt(int keybits, const uint8_t *key, const uint8_t *iVec,
+                     const void *pntxt, size_t ptextLen, void *crtxt)
+{
+    return feedback_common(keybits, key, iVec, 0, pntxt, ptextLen, crtxt);
+}
+
+int uaes_cbc_decrypt(int keybits, const uint8_t *key, const uint8_t *iVec,
+                     const void *crtxt, size_t crtxtLen, void *pntxt)
+{
+    return feedback_common(keybits, key, iVec, 1, crtxt, crtxtLen, pntxt);
+}
+
+int uaes_cfb_encrypt(int keybits, const uint8_t *key, const uint8_t *iVec,
+                     const void *pntxt, size_t ptextLen, void *crtxt)
+{
+    return feedback_common(keybits, key, iVec, 2, pntxt, ptextLen, crtxt);
+}
+
+int uaes_cfb_decrypt(int keybits, const uint8_t *key, const uint8_t *iVec,
+                     const void *crtxt, size_t crtxtLen, void *pntxt)
+{
+    return feedback_common(keybits, key, iVec, 3, crtxt, crtxtLen, pntxt);
+}
+
+int uaes_ofb_xcrypt(int keybits, const uint8_t *key, const uint8_t *iVec,
+                    const void *in, size_t len, void *out)
+{
+    return feedback_common(keybits, key, iVec, 4, in, len, out);
+}

@@ -53,6 +53,10 @@ class Oracle:
         L.orc_xts_sectors.argtypes = [i, vp, u64, sz, sz, vp, vp, i]; L.orc_xts_sectors.restype = C.c_char
         L.orc_gcm_encrypt.argtypes = [i, vp, vp, vp, sz, vp, sz, vp]; L.orc_gcm_encrypt.restype = None
         L.orc_gcm_decrypt.argtypes = [i, vp, vp, vp, sz, vp, sz, vp]; L.orc_gcm_decrypt.restype = C.c_char
+        for f in (L.orc_cbc_encrypt, L.orc_cbc_decrypt):
+            f.argtypes = [i, vp, vp, vp, sz, vp]; f.restype = C.c_char
+        L.orc_cfb.argtypes = [i, vp, vp, i, vp, sz, vp]; L.orc_cfb.restype = None
+        L.orc_ofb.argtypes = [i, vp, vp, vp, sz, vp]; L.orc_ofb.restype = None
         L.orc_cmac.argtypes = [i, vp, vp, sz, vp]; L.orc_cmac.restype = None
         L.orc_ccm_encrypt.argtypes = [i, vp, vp, vp, sz, vp, sz, vp]; L.orc_ccm_encrypt.restype = None
         L.orc_ccm_decrypt.argtypes = [i, vp, vp, vp, sz, vp, sz, vp]; L.orc_ccm_decrypt.restype = C.c_char
@@ -118,6 +122,22 @@ class Oracle:
         rc = self.L.orc_gcm_decrypt(len(key) * 8, _buf(key), _buf(nonce), _buf(aad), len(aad),
                                     _buf(ct_and_tag), n, o)
         return ord(rc), bytes(o)[:n]
+
+    def cbc(self, key, iv, data, encrypt=True, prefill=0xCC):
+        o = (C.c_uint8 * max(len(data), 1))(*([prefill] * max(len(data), 1)))
+        f = self.L.orc_cbc_encrypt if encrypt else self.L.orc_cbc_decrypt
+        rc = f(len(key) * 8, _buf(key), _buf(iv), _buf(data), len(data), o)
+        return ord(rc), bytes(o)[: len(data)]
+
+    def cfb(self, key, iv, data, encrypt=True):
+        o = _out(len(data))
+        self.L.orc_cfb(len(key) * 8, _buf(key), _buf(iv), 1 if encrypt else 0, _buf(data), len(data), o)
+        return bytes(o)[: len(data)]
+
+    def ofb(self, key, iv, data):
+        o = _out(len(data))
+        self.L.orc_ofb(len(key) * 8, _buf(key), _buf(iv), _buf(data), len(data), o)
+        return bytes(o)[: len(data)]
 
     def cmac(self, key, data):
         o = _out(16)
@@ -187,6 +207,29 @@ class Reference:
         L.AES_CCM_encrypt.argtypes = [vp, vp, vp, sz, vp, sz, vp]; L.AES_CCM_encrypt.restype = None
         L.AES_CCM_decrypt.argtypes = [vp, vp, vp, sz, vp, sz, vp]; L.AES_CCM_decrypt.restype = C.c_char
         L.AES_CMAC.argtypes = [vp, vp, sz, vp]; L.AES_CMAC.restype = None
+        for f in (L.AES_CBC_encrypt, L.AES_CBC_decrypt):
+            f.argtypes = [vp, vp, vp, sz, vp]; f.restype = C.c_char
+        for f in (L.AES_CFB_encrypt, L.AES_CFB_decrypt, L.AES_OFB_encrypt, L.AES_OFB_decrypt):
+            f.argtypes = [vp, vp, vp, sz, vp]; f.restype = None
+
+    def cbc(self, key, iv, data, encrypt=True, prefill=0xCC):
+        self._chk(key)
+        o = (C.c_uint8 * max(len(data), 1))(*([prefill] * max(len(data), 1)))
+        f = self.L.AES_CBC_encrypt if encrypt else self.L.AES_CBC_decrypt
+        rc = f(_buf(key), _buf(iv), _buf(data), len(data), o)
+        return ord(rc), bytes(o)[: len(data)]
+
+    def cfb(self, key, iv, data, encrypt=True):
+        self._chk(key)
+        o = _out(len(data))
+        (self.L.AES_CFB_encrypt if encrypt else self.L.AES_CFB_decrypt)(_buf(key), _buf(iv), _buf(data), len(data), o)
+        return bytes(o)[: len(data)]
+
+    def ofb(self, key, iv, data):
+        self._chk(key)
+        o = _out(len(data))
+        self.L.AES_OFB_encrypt(_buf(key), _buf(iv), _buf(data), len(data), o)
+        return bytes(o)[: len(data)]
 
     def cmac(self, key, data):
         self._chk(key)

@@ -435,6 +435,109 @@ char orc_gcm_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
 }
 
 /* ------------------------------------------------------------------------ */
+/* CBC with CS3 ciphertext stealing -- micro_aes.c:697-782 (CTS 1)             */
+/* ------------------------------------------------------------------------ */
+char orc_cbc_encrypt(int keybits, const uint8_t *key, const uint8_t iv[16],
+                     const void *pt, size_t len, void *ct)
+{
+    orc_key ks;
+    const uint8_t *x = (const uint8_t *)pt;
+    uint8_t *y = (uint8_t *)ct, chain[16];
+    size_t n = len / 16, r = len % 16, i;
+    if (n > 1 && !r) { --n; r = 16; }          /* the last two blocks are always swapped */
+    if (n == 0) return ORC_E_DATALENGTH;
+    if (orc_setkey(&ks, key, keybits)) return ORC_E_ENCRYPT;
+    memcpy(chain, iv, 16);
+    for (i = 0; i < n; ++i) {
+        uint8_t b[16];
+        memcpy(b, x + 16 * i, 16);
+        xor16(b, chain);
+        orc_encrypt_block(&ks, b, chain);
+        memcpy(y + 16 * i, chain, 16);
+    }
+    if (r) {
+        uint8_t last[16] = { 0 };
+        memcpy(last, x + 16 * n, r);           /* P_n, zero padded                       */
+        memcpy(y + 16 * n, chain, r);          /* its slot gets the head of C_{n-1}      */
+        xor16(last, chain);
+        orc_encrypt_block(&ks, last, y + 16 * (n - 1));
+    }
+    return ORC_OK;
+}
+
+char orc_cbc_decrypt(int keybits, const uint8_t *key, const uint8_t iv[16],
+                     const void *ct, size_t len, void *pt)
+{
+    orc_key ks;
+    const uint8_t *x = (const uint8_t *)ct;
+    uint8_t *y = (uint8_t *)pt, prev[16], cur[16];
+    size_t n = len / 16, r = len % 16, i;
+    if (n > 1 && !r) { --n; r = 16; }
+    if (n == 0) return ORC_E_DATALENGTH;
+    if (r) --n;                                /* hold the last two blocks               */
+    if (orc_setkey(&ks, key, keybits)) return ORC_E_DECRYPT;
+    memcpy(prev, iv, 16);
+    for (i = 0; i < n; ++i) {
+        memcpy(cur, x + 16 * i, 16);
+        orc_decrypt_block(&ks, cur, y + 16 * i);
+        xor16(y + 16 * i, prev);
+        memcpy(prev, cur, 16);
+    }
+    if (r) {
+        uint8_t xx[16], z[16] = { 0 }, yy[16], c[16];
+        size_t k;
+        memcpy(xx, x + 16 * n, 16);
+        memcpy(z, x + 16 * n + 16, r);
+        orc_decrypt_block(&ks, xx, yy);        /* Y = Dec(X)                             */
+        memcpy(c, yy, 16);
+        memcpy(c, z, r);                       /* Z | tail of Y                          */
+        for (k = 0; k < r; ++k) y[16 * n + 16 + k] = (uint8_t)(yy[k] ^ z[k]);
+        orc_decrypt_block(&ks, c, c);
+        xor16(c, prev);
+        memcpy(y + 16 * n, c, 16);
+    }
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------ */
+/* CFB -- micro_aes.c:799-845;  OFB -- micro_aes.c:861-893                     */
+/* ------------------------------------------------------------------------ */
+void orc_cfb(int keybits, const uint8_t *key, const uint8_t iv[16], int encrypt,
+             const void *in, size_t len, void *out)
+{
+    orc_key ks;
+    const uint8_t *x = (const uint8_t *)in;
+    uint8_t *y = (uint8_t *)out, fb[16], e[16];
+    size_t off, k;
+    if (orc_setkey(&ks, key, keybits)) return;
+    memcpy(fb, iv, 16);
+    for (off = 0; off < len; off += 16) {
+        size_t n = len - off < 16 ? len - off : 16;
+        uint8_t c[16] = { 0 };
+        orc_encrypt_block(&ks, fb, e);
+        memcpy(c, x + off, n);                 /* input block (ciphertext when decrypting) */
+        for (k = 0; k < n; ++k) y[off + k] = (uint8_t)(e[k] ^ c[k]);
+        if (n == 16) memcpy(fb, encrypt ? y + off : c, 16);      /* feedback = ciphertext */
+    }
+}
+
+void orc_ofb(int keybits, const uint8_t *key, const uint8_t iv[16],
+             const void *in, size_t len, void *out)
+{
+    orc_key ks;
+    const uint8_t *x = (const uint8_t *)in;
+    uint8_t *y = (uint8_t *)out, o[16];
+    size_t off, k;
+    if (orc_setkey(&ks, key, keybits)) return;
+    memcpy(o, iv, 16);
+    for (off = 0; off < len; off += 16) {
+        size_t n = len - off < 16 ? len - off : 16;
+        orc_encrypt_block(&ks, o, o);
+        for (k = 0; k < n; ++k) y[off + k] = (uint8_t)(x[off + k] ^ o[k]);
+    }
+}
+
+/* ------------------------------------------------------------------------ */
 /* CMAC -- micro_aes.c:1108-1118, cMac :576-590, getSubkeys :593-605,         */
 /*         doubleBblock :434-444                                              */
 /* ------------------------------------------------------------------------ */

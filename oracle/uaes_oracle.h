@@ -91,6 +91,17 @@ char orc_gcm_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
                      const void *aad, size_t aad_len,
                      const void *ct_and_tag, size_t len, void *pt);
 
+/* micro_aes.c:697-782 CBC with CS3 ciphertext stealing (len < 16 -> 1) */
+char orc_cbc_encrypt(int keybits, const uint8_t *key, const uint8_t iv[16],
+                     const void *pt, size_t len, void *ct);
+char orc_cbc_decrypt(int keybits, const uint8_t *key, const uint8_t iv[16],
+                     const void *ct, size_t len, void *pt);
+/* micro_aes.c:799-845 CFB (encrypt != 0 / decrypt), :861-893 OFB */
+void orc_cfb(int keybits, const uint8_t *key, const uint8_t iv[16], int encrypt,
+             const void *in, size_t len, void *out);
+void orc_ofb(int keybits, const uint8_t *key, const uint8_t iv[16],
+             const void *in, size_t len, void *out);
+
 /* micro_aes.c:1108-1118 AES_CMAC */
 void orc_cmac(int keybits, const uint8_t *key, const void *data, size_t len, uint8_t mac[16]);
 /* micro_aes.c:1268-1314.  11-byte nonce, 16-byte tag; decrypt runs CTR first and

@@ -96,6 +96,12 @@ MAIN_KATS = {
     "gcm128": "5ceab5b7c2d6dede555a23c7e3e632744075a51df482730ba31485ec987ddcc8"
               "73acdcfc6759a47ba424d838e7c0cb71b9a4d8f4572e214118c8ab284ca845c1"
               "4394618703cddf3afb",
+    "cbc128": "65c48fdf9fbd626128f2d8bac3f7125175e7f4821fda026370011632779d7403"
+              "c119ef461ac4e1bc8a7e36bf92b3b3d17E9E2D298E154BC42D",
+    "cfb128": "edab3105e673bc9eb9102539a9f457bc245c14e1bff81b5b4a4a147c988cb0a6"
+              "3f9c56525efbe64a876ad1d761d3fc9359fb4f5b2354acd490",
+    "ofb128": "edab3105e673bc9eb9102539a9f457bcd28c8e4c92995f5cd9426926be1e775d"
+              "e22b8ce4d0278b18181b8bec93b9726f959aa5d701d46102f0",
     "cmac128": "b887df1fd8c239c3e8a64d9822e21128",
     "ccm128": "d2575123438338d70b2955537fdfcf41729870884e85af15f0a74975a72b337d"
               "04d426de87594b9abe3e6dcf07f21c99db3999f81299d302ad1e5ba683e9039a"
@@ -132,6 +138,12 @@ def main_kats():
     assert r256.gcm_encrypt(key[:32], iv, aad, pt).hex() == MAIN_KATS["gcm256"].lower()
     add("main.c:191 GCM-256", "gcm", 256, key[:32], {"nonce": iv[:12].hex(), "aad": aad.hex()},
         MAIN_KATS["gcm256"])
+    assert r128.cbc(key[:16], iv, pt)[1].hex() == MAIN_KATS["cbc128"].lower()
+    add("main.c:146 CBC (CTS)", "cbc", 128, key[:16], {"iv": iv.hex()}, MAIN_KATS["cbc128"])
+    assert r128.cfb(key[:16], iv, pt).hex() == MAIN_KATS["cfb128"]
+    add("main.c:153 CFB", "cfb", 128, key[:16], {"iv": iv.hex()}, MAIN_KATS["cfb128"])
+    assert r128.ofb(key[:16], iv, pt).hex() == MAIN_KATS["ofb128"]
+    add("main.c:160 OFB", "ofb", 128, key[:16], {"iv": iv.hex()}, MAIN_KATS["ofb128"])
     assert r128.cmac(key[:16], pt).hex() == MAIN_KATS["cmac128"]
     add("main.c:181 CMAC", "cmac", 128, key[:16], {}, MAIN_KATS["cmac128"])
     assert r128.ccm_encrypt(key[:16], iv[:11], aad, pt).hex() == MAIN_KATS["ccm128"]
@@ -182,6 +194,18 @@ def ref_vectors(orc):
                 assert rcb == 0x1A and ptb == b"\xcc" * n      # N7
                 vecs.append(dict(base, mode="gcm", key=key.hex(), nonce=nonce.hex(),
                                  aad=aad.hex(), out=enc_out(ct)))
+            # CBC (CS3), CFB, OFB
+            iv16 = rng.randbytes(16)
+            rc, ct = ref.cbc(key, iv16, data, True)
+            v = dict(base, mode="cbc", key=key.hex(), iv=iv16.hex(), rc=rc)
+            if rc == 0:
+                v["out"] = enc_out(ct)
+                assert ref.cbc(key, iv16, ct, False) == (0, data)
+            vecs.append(v)
+            ct = ref.cfb(key, iv16, data, True)
+            assert ref.cfb(key, iv16, ct, False) == data
+            vecs.append(dict(base, mode="cfb", key=key.hex(), iv=iv16.hex(), out=enc_out(ct)))
+            vecs.append(dict(base, mode="ofb", key=key.hex(), iv=iv16.hex(), out=enc_out(ref.ofb(key, iv16, data))))
             # CMAC and CCM
             if n <= 16384:
                 vecs.append(dict(base, mode="cmac", key=key.hex(), out=enc_out(ref.cmac(key, data))))

@@ -138,10 +138,19 @@ def test_main_c_kats(golden_dir):
             assert uaes.AES_GCM_decrypt(key, n, a, exp) == (0, pt)
         elif k["mode"] == "cmac":
             assert uaes.AES_CMAC(key, pt) == exp
-        else:
+        elif k["mode"] == "ccm":
             n, a = bytes.fromhex(k["nonce"]), bytes.fromhex(k["aad"])
             assert uaes.AES_CCM_encrypt(key, n, a, pt) == exp
             assert uaes.AES_CCM_decrypt(key, n, a, exp) == (0, pt)
+        elif k["mode"] == "cbc":
+            assert uaes.AES_CBC_encrypt(key, bytes.fromhex(k["iv"]), pt) == (0, exp)
+            assert uaes.AES_CBC_decrypt(key, bytes.fromhex(k["iv"]), exp) == (0, pt)
+        elif k["mode"] == "cfb":
+            assert uaes.AES_CFB_encrypt(key, bytes.fromhex(k["iv"]), pt) == exp
+            assert uaes.AES_CFB_decrypt(key, bytes.fromhex(k["iv"]), exp) == pt
+        else:
+            assert uaes.AES_OFB_encrypt(key, bytes.fromhex(k["iv"]), pt) == exp
+            assert uaes.AES_OFB_decrypt(key, bytes.fromhex(k["iv"]), exp) == pt
 
 
 def test_reference_generated_vectors(orc, golden_dir):
@@ -173,11 +182,25 @@ def test_reference_generated_vectors(orc, golden_dir):
             assert uaes.AES_GCM_decrypt(key, nonce, aad, ct) == (0, data)
         elif v["mode"] == "cmac":
             check_out(uaes.AES_CMAC(key, data), v["out"])
-        else:
+        elif v["mode"] == "ccm":
             nonce, aad = bytes.fromhex(v["nonce"]), bytes.fromhex(v["aad"])
             ct = uaes.AES_CCM_encrypt(key, nonce, aad, data)
             check_out(ct, v["out"])
             assert uaes.AES_CCM_decrypt(key, nonce, aad, ct) == (0, data)
+        elif v["mode"] == "cbc":
+            rc, ct = uaes.AES_CBC_encrypt(key, bytes.fromhex(v["iv"]), data, prefill=0xCC)
+            assert rc == v["rc"]
+            if rc == 0:
+                check_out(ct, v["out"])
+                assert uaes.AES_CBC_decrypt(key, bytes.fromhex(v["iv"]), ct) == (0, data)
+            else:
+                assert ct == b"\xcc" * n
+        elif v["mode"] == "cfb":
+            ct = uaes.AES_CFB_encrypt(key, bytes.fromhex(v["iv"]), data)
+            check_out(ct, v["out"])
+            assert uaes.AES_CFB_decrypt(key, bytes.fromhex(v["iv"]), ct) == data
+        else:
+            check_out(uaes.AES_OFB_encrypt(key, bytes.fromhex(v["iv"]), data), v["out"])
 
 
 # ---- against the oracle on seeded inputs -------------------------------------------
@@ -282,6 +305,24 @@ def test_sharded_gcm_partials(orc, total, world, alen):
         pieces.append(bytes(dst[:n].cpu().numpy()))
     assert b"".join(pieces) == want[:-16]
     assert tag == want[-16:]
+
+
+@pytest.mark.parametrize("bits", [128, 192, 256])
+def test_feedback_modes_vs_oracle(orc, bits):
+    """CBC (CS3) / CFB decrypt are block-parallel kernels: check them on large inputs too"""
+    rnd = random.Random(bits + 4)
+    for n in [16, 17, 31, 32, 33, 48, 100, 4096, 4097, (1 << 20) + 5, 4 << 20]:
+        key, iv = rnd.randbytes(bits // 8), rnd.randbytes(16)
+        ct_in = orc.splitmix(n + 9, n)                 # decrypt directions work on any input
+        assert uaes.AES_CBC_decrypt(key, iv, ct_in) == orc.cbc(key, iv, ct_in, False), n
+        assert uaes.AES_CFB_decrypt(key, iv, ct_in) == orc.cfb(key, iv, ct_in, False), n
+        if n <= 4097:                                   # serial directions: ~1.5 us per block
+            assert uaes.AES_CBC_encrypt(key, iv, ct_in) == orc.cbc(key, iv, ct_in, True), n
+            assert uaes.AES_CFB_encrypt(key, iv, ct_in) == orc.cfb(key, iv, ct_in, True), n
+            assert uaes.AES_OFB_encrypt(key, iv, ct_in) == orc.ofb(key, iv, ct_in), n
+    assert uaes.AES_CBC_encrypt(key, iv, b"123456789012345", prefill=0xCC) == (1, b"\xcc" * 15)
+    assert uaes.AES_CBC_decrypt(key, iv, b"123456789012345", prefill=0xCC) == (1, b"\xcc" * 15)
+    assert uaes.AES_CFB_encrypt(key, iv, b"") == b"" and uaes.AES_OFB_encrypt(key, iv, b"abc") == orc.ofb(key, iv, b"abc")
 
 
 def test_ghash_kernel_levels(orc):

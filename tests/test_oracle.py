@@ -106,6 +106,14 @@ def test_main_c_kats(orc, golden_dir):
             n, a = bytes.fromhex(k["nonce"]), bytes.fromhex(k["aad"])
             assert orc.ccm_encrypt(key, n, a, pt) == exp
             assert orc.ccm_decrypt(key, n, a, exp) == (0, pt)
+        elif k["mode"] == "cbc":
+            assert orc.cbc(key, bytes.fromhex(k["iv"]), pt, True) == (0, exp)
+            assert orc.cbc(key, bytes.fromhex(k["iv"]), exp, False) == (0, pt)
+        elif k["mode"] == "cfb":
+            assert orc.cfb(key, bytes.fromhex(k["iv"]), pt, True) == exp
+            assert orc.cfb(key, bytes.fromhex(k["iv"]), exp, False) == pt
+        elif k["mode"] == "ofb":
+            assert orc.ofb(key, bytes.fromhex(k["iv"]), pt) == exp
 
 
 def test_reference_generated_vectors(orc, golden_dir):
@@ -141,6 +149,20 @@ def test_reference_generated_vectors(orc, golden_dir):
             ct = orc.ccm_encrypt(key, bytes.fromhex(v["nonce"]), bytes.fromhex(v["aad"]), data)
             check_out(ct, v["out"])
             assert orc.ccm_decrypt(key, bytes.fromhex(v["nonce"]), bytes.fromhex(v["aad"]), ct) == (0, data)
+        elif v["mode"] == "cbc":
+            rc, ct = orc.cbc(key, bytes.fromhex(v["iv"]), data, True)
+            assert rc == v["rc"]
+            if rc == 0:
+                check_out(ct, v["out"])
+                assert orc.cbc(key, bytes.fromhex(v["iv"]), ct, False) == (0, data)
+            else:
+                assert rc == 1 and ct == b"\xcc" * n
+        elif v["mode"] == "cfb":
+            ct = orc.cfb(key, bytes.fromhex(v["iv"]), data, True)
+            check_out(ct, v["out"])
+            assert orc.cfb(key, bytes.fromhex(v["iv"]), ct, False) == data
+        elif v["mode"] == "ofb":
+            check_out(orc.ofb(key, bytes.fromhex(v["iv"]), data), v["out"])
 
 
 def test_baseline_digests_small(orc, golden_dir):
@@ -238,6 +260,11 @@ def test_against_compiled_reference_random(orc, bits):
         assert orc.gcm_encrypt(key, iv, aad, data) == ct
         assert orc.gcm_decrypt(key, iv, aad, ct) == ref.gcm_decrypt(key, iv, aad, ct) == (0, data)
         assert orc.cmac(key, data) == ref.cmac(key, data)
+        iv16 = rnd.randbytes(16)
+        for enc in (True, False):
+            assert orc.cbc(key, iv16, data, enc) == ref.cbc(key, iv16, data, enc)
+            assert orc.cfb(key, iv16, data, enc) == ref.cfb(key, iv16, data, enc)
+        assert orc.ofb(key, iv16, data) == ref.ofb(key, iv16, data)
         aad2 = rnd.randbytes(rnd.choice([0, 5, 14, 15, 33]))
         cc = ref.ccm_encrypt(key, iv[:11], aad2, data)
         assert orc.ccm_encrypt(key, iv[:11], aad2, data) == cc
