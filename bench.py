@@ -111,13 +111,17 @@ def cpu_baseline(workload):
                                                   ctypes.c_void_p(buf.ctypes.data + s * 4096), 4096,
                                                   ctypes.c_void_p(out.ctypes.data + s * 4096))
                                 for s in range(n // 4096)],
-              "gcm": lambda n: L.AES_GCM_encrypt(KEY16, NONCE, None, 0, src, n, dst)}[workload]
+              "gcm": lambda n: L.AES_GCM_encrypt(KEY16, NONCE, None, 0, src, n, dst),
+              "cbc-dec": lambda n: L.AES_CBC_decrypt(KEY16, bytes(range(16)), src, n, dst),
+              "cfb-dec": lambda n: L.AES_CFB_decrypt(KEY16, bytes(range(16)), src, n, dst)}[workload]
     else:
         L = orc.L
         fn = {"ctr": lambda n: L.orc_ctr_encrypt(128, KEY16, NONCE, src, n, dst),
               "ecb": lambda n: L.orc_ecb_encrypt(128, KEY16, src, n, dst),
               "xts": lambda n: L.orc_xts_sectors(256, KEY64, 0, 4096, n // 4096, src, dst, 1),
-              "gcm": lambda n: L.orc_gcm_encrypt(128, KEY16, NONCE, None, 0, src, n, dst)}[workload]
+              "gcm": lambda n: L.orc_gcm_encrypt(128, KEY16, NONCE, None, 0, src, n, dst),
+              "cbc-dec": lambda n: L.orc_cbc_decrypt(128, KEY16, bytes(range(16)), src, n, dst),
+              "cfb-dec": lambda n: L.orc_cfb(128, KEY16, bytes(range(16)), 0, src, n, dst)}[workload]
     t0 = time.perf_counter()
     fn(sample)
     t1 = time.perf_counter() - t0
@@ -239,7 +243,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    gather_ms = None
+    gather_ms, gathered_ok = None, None
     if dist and a.gather and a.backend == "nccl":
         full = torch.empty(world * n, dtype=torch.uint8, device=dev)
         dist.all_gather_into_tensor(full, dst[:n])
@@ -250,7 +254,26 @@ def main():
         torch.cuda.synchronize()
         dist.barrier()
         gather_ms = (time.perf_counter() - g0) * 1e3
+        if rank == 0 and a.workload == "ctr" and n == GIB and world == 8 and not a.no_verify:
+            # BASELINE configs[4]: the concatenated 8 GiB stream against the reference's digest (C5)
+            with open(os.path.join(ROOT, "tests", "golden", "digests.json")) as f:
+                gathered_ok = sha_of(full) == json.load(f)["C5_ctr128_8GiB_seed2"]["sha256"]
         del full
+
+    # measured HBM stream-copy ceiling on this GPU (read n + write n), for context next to the 8 TB/s spec
+    copy_gbs = None
+    if world == 1:
+        tmp = torch.empty(n, dtype=torch.uint8, device=dev)
+        for _ in range(3):
+            tmp.copy_(src)
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record(st)
+        for _ in range(10):
+            tmp.copy_(src)
+        c1.record(st)
+        torch.cuda.synchronize()
+        copy_gbs = 2.0 * n * 10 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+        del tmp
 
     verify = None
     if not a.no_verify:
@@ -314,11 +337,14 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes": int(algo_bytes),
                          "kernel_ms": round(kern_ms, 4),
-                         "kernel_ms_min": round(min(per_step_ms), 4)},
+                         "kernel_ms_min": round(min(per_step_ms), 4),
+                         "measured_copy_ceiling_gbs": None if copy_gbs is None else round(copy_gbs, 1)},
             "verified": verify,
         }
         if gather_ms is not None:
             line["gather_ms"] = round(gather_ms, 3)
+        if gathered_ok is not None:
+            line["gathered_stream_digest_ok"] = gathered_ok
         if not a.no_cpu and world == 1:
             line["cpu_baseline"] = cpu_baseline(a.workload)
         print(json.dumps(line))
