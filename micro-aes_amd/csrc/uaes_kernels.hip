@@ -131,6 +131,9 @@ __global__ __launch_bounds__(UAES_WG, (NT == 2 ? 8 : 4)) void k_ctr(uaesk_rk rk,
     }
 }
 
+#define CTRS_CHUNK 64u                       /* groups (of 256 counters) per chunk: one barrier each;
+                                                256 measured no faster (profiles/r01_sweep_ctr_variants.log) */
+
 /* The blocks in front of / behind the whole chunks of the shared-round kernels
  * (each side < 16384 blocks) and the byte tail: spread evenly over all
  * workgroups, one block per thread through the plain 10/12/14-round path, so
@@ -141,7 +144,7 @@ __device__ __forceinline__ void ctr_edges(const uaesk_rk &rk, const uaesk_ctr &c
                                           u64 chunk_lo, u64 chunk_hi, u64 nfull, u32 rem, const LaneConst &lc)
 {
     const u32 c0 = (u32)ctr.v0 & 0xffu;
-    const u64 per_chunk = 64ull * 256ull;
+    const u64 per_chunk = (u64)CTRS_CHUNK * 256ull;
     const u64 pre_end = chunk_lo * per_chunk - (chunk_lo ? c0 : 0);         /* blocks [0, pre_end)     */
     const u64 suf = chunk_hi * per_chunk - c0;                              /* blocks [suf, nfull)     */
     const u64 nedge = pre_end + (nfull - suf);
@@ -182,7 +185,7 @@ __device__ __forceinline__ void ctr_edges(const uaesk_rk &rk, const uaesk_ctr &c
  *
  * A(G) changes only when counter bits 40..47 change, so the four round-2
  * lookups on col0's bytes are per-LANE constants L_c, computed once; the
- * uniform parts U_c(G) cost 27 lookups per GROUP (one lane of wave 0 per group,
+ * uniform parts U_c(G) cost 27 lookups per GROUP (one lane of waves 0..3 per group,
  * handed over through LDS).  A block therefore enters round 3 as L ^ U(G):
  * 4 XORs instead of 32 table lookups -- 128 lookups per AES-128 block instead
  * of 160 on a path whose bound is the LDS lookup rate (32 lanes/clk/CU).
@@ -190,7 +193,6 @@ __device__ __forceinline__ void ctr_edges(const uaesk_rk &rk, const uaesk_ctr &c
  * Workgroup = 16 waves = 4 quads; wave w owns positions p = 64*(w&3) + lane and
  * walks groups (w>>2) + 4k of a 64-group chunk, four groups per iteration, so
  * each wave-level load/store is still one contiguous 1 KiB segment.           */
-#define CTRS_CHUNK 64u                       /* groups per chunk               */
 #define CTRS_BUF   (UAES_LDS_ENC)            /* 2 x 64 x 32 B after the tables */
 #define UAES_LDS_CTRS (UAES_LDS_ENC + 2u * CTRS_CHUNK * 32u)
 
@@ -237,9 +239,10 @@ __global__ __launch_bounds__(UAES_WG, 4) void k_ctr_shared(uaesk_rk rk, uaesk_ta
 
     while (chunk < chunk_hi) {
         if (m == 0) {
-            if (wave == 0) {
-                /* uniform part of rounds 1 and 2 for group (chunk*64 + lane) */
-                const u64 g = chunk * CTRS_CHUNK + lane;
+            if (wave < CTRS_CHUNK / 64u) {
+                /* uniform part of rounds 1 and 2 for group (chunk*CTRS_CHUNK + 64*wave + lane) */
+                const u32 gi = wave * 64u + lane;
+                const u64 g = chunk * CTRS_CHUNK + gi;
                 const u64 v = (vbase + (g << 8)) & 0x00FFFFFFFFFFFFFFull;
                 const u32 s0 = ctr.w0 ^ rk.w[0], s1 = ctr.w1 ^ rk.w[1];
                 const u32 s2 = bswap32((ctr.b8 << 24) | (u32)(v >> 32)) ^ rk.w[2];
@@ -252,8 +255,8 @@ __global__ __launch_bounds__(UAES_WG, 4) void k_ctr_shared(uaesk_rk rk, uaesk_ta
                 const u32 u1 = xor3(tlook<0, 0>(c1, lc), tlook<1, 1>(c2, lc), tlook<2, 2>(c3, lc)) ^ rk.w[9];
                 const u32 u2 = xor3(tlook<0, 0>(c2, lc), tlook<1, 1>(c3, lc), tlook<3, 3>(c1, lc)) ^ rk.w[10];
                 const u32 u3 = xor3(tlook<0, 0>(c3, lc), tlook<2, 2>(c1, lc), tlook<3, 3>(c2, lc)) ^ rk.w[11];
-                buf[(parity * CTRS_CHUNK + lane) * 2 + 0] = make_uint4(u0, u1, u2, u3);
-                buf[(parity * CTRS_CHUNK + lane) * 2 + 1] = make_uint4(A, 0, 0, 0);
+                buf[(parity * CTRS_CHUNK + gi) * 2 + 0] = make_uint4(u0, u1, u2, u3);
+                buf[(parity * CTRS_CHUNK + gi) * 2 + 1] = make_uint4(A, 0, 0, 0);
             }
             __syncthreads();
         }
@@ -347,9 +350,10 @@ __global__ __launch_bounds__(UAES_WG, 4) void k_ctr_shared2(uaesk_rk rk, uaesk_t
 
     while (chunk < chunk_hi) {
         if (m == 0) {
-            if (wave == 0) {
-                /* uniform part of rounds 1 and 2 for group (chunk*64 + lane) */
-                const u64 g = chunk * CTRS_CHUNK + lane;
+            if (wave < CTRS_CHUNK / 64u) {
+                /* uniform part of rounds 1 and 2 for group (chunk*CTRS_CHUNK + 64*wave + lane) */
+                const u32 gi = wave * 64u + lane;
+                const u64 g = chunk * CTRS_CHUNK + gi;
                 const u64 v = (vbase + (g << 8)) & 0x00FFFFFFFFFFFFFFull;
                 const u32 s0 = ctr.w0 ^ rk.w[0], s1 = ctr.w1 ^ rk.w[1];
                 const u32 s2 = bswap32((ctr.b8 << 24) | (u32)(v >> 32)) ^ rk.w[2];
@@ -362,8 +366,8 @@ __global__ __launch_bounds__(UAES_WG, 4) void k_ctr_shared2(uaesk_rk rk, uaesk_t
                 const u32 u1 = xor3(tlook<0, 0>(c1, lc), tlook<1, 1>(c2, lc), tlook<2, 2>(c3, lc)) ^ rk.w[9];
                 const u32 u2 = xor3(tlook<0, 0>(c2, lc), tlook<1, 1>(c3, lc), tlook<3, 3>(c1, lc)) ^ rk.w[10];
                 const u32 u3 = xor3(tlook<0, 0>(c3, lc), tlook<2, 2>(c1, lc), tlook<3, 3>(c2, lc)) ^ rk.w[11];
-                buf[(parity * CTRS_CHUNK + lane) * 2 + 0] = make_uint4(u0, u1, u2, u3);
-                buf[(parity * CTRS_CHUNK + lane) * 2 + 1] = make_uint4(A, 0, 0, 0);
+                buf[(parity * CTRS_CHUNK + gi) * 2 + 0] = make_uint4(u0, u1, u2, u3);
+                buf[(parity * CTRS_CHUNK + gi) * 2 + 1] = make_uint4(A, 0, 0, 0);
             }
             __syncthreads();
         }
