@@ -476,10 +476,14 @@ static int xts_keys(keysched *k1, keysched *k2, const uint8_t *keys, int keybits
 
 static int xts_run(context *c, void *stream, keysched *k1, keysched *k2, int encrypt,
                    const uint8_t *tweak16, uint64_t first_sector,
-                   size_t sector_bytes, size_t nsectors, const void *din, void *dout)
+                   size_t sector_bytes, size_t nsectors, const void *din, void *dout,
+                   int stream_owned_lock)       /* 1: caller does not hold c->mu (the *_dev path) */
 {
     const size_t need = uaesk_xts_scratch_bytes(sector_bytes, nsectors);
-    if (grow(&c->scratch, &c->scratch_cap, need)) return UAES_E_HIP;
+    if (stream_owned_lock) pthread_mutex_lock(&c->mu);
+    const int g = grow(&c->scratch, &c->scratch_cap, need);
+    if (stream_owned_lock) pthread_mutex_unlock(&c->mu);
+    if (g) return UAES_E_HIP;
     KCHK(uaesk_xts(stream, &c->tb, k1->nr, encrypt ? &k1->ek : &k1->dk, &k2->ek, !encrypt,
                    tweak16, first_sector, sector_bytes, nsectors, din, dout, c->scratch));
     return 0;
@@ -504,7 +508,7 @@ static int xts_common(int keybits, const uint8_t *keys, const uint8_t *tweak, in
     do {
         if ((rc = plan_io(c, in, total, out, total, &io)) != 0) break;
         rc = xts_run(c, NULL, &k1, &k2, encrypt, raw_tweak ? (tweak ? tweak : zero) : NULL,
-                     first_sector, sector_bytes, nsectors, io.din, io.dout);
+                     first_sector, sector_bytes, nsectors, io.din, io.dout, 0);
         if (rc) break;
         rc = finish_io(&io, total);
     } while (0);
@@ -539,7 +543,7 @@ int uaes_xts_sectors_dev(int keybits, const uint8_t *keys, uint64_t first_sector
     if ((rc = xts_keys(&k1, &k2, keys, keybits)) != 0) return rc;
     if (sector_bytes < 16) return UAES_E_DATALENGTH;
     if ((rc = get_context(&c)) != 0) return rc;
-    return xts_run(c, stream, &k1, &k2, encrypt, NULL, first_sector, sector_bytes, nsectors, d_in, d_out);
+    return xts_run(c, stream, &k1, &k2, encrypt, NULL, first_sector, sector_bytes, nsectors, d_in, d_out, 1);
 }
 
 /* ------------------------------------------------------------------------ */
@@ -548,6 +552,17 @@ int uaes_xts_sectors_dev(int keybits, const uint8_t *keys, uint64_t first_sector
 static int gcm_scratch(context *c)
 {
     return grow(&c->scratch, &c->scratch_cap, uaesk_gcm_scratch_bytes());
+}
+
+/* the *_dev entry points do not hold the context lock while the GPU works (they only
+ * enqueue), but growing the shared scratch buffer must not race with another thread */
+static int gcm_scratch_locked(context *c)
+{
+    int rc;
+    pthread_mutex_lock(&c->mu);
+    rc = gcm_scratch(c);
+    pthread_mutex_unlock(&c->mu);
+    return rc;
 }
 
 /* AAD may be host memory: stage it (it is read byte-wise, no alignment need) */
@@ -632,7 +647,7 @@ int uaes_gcm_encrypt_dev(int keybits, const uint8_t *key, const uint8_t *nonce,
     int rc;
     if ((rc = expand_key(&ks, key, keybits)) != 0) return rc;
     if ((rc = get_context(&c)) != 0) return rc;
-    if ((rc = gcm_scratch(c)) != 0) return rc;
+    if ((rc = gcm_scratch_locked(c)) != 0) return rc;
     KCHK(uaesk_gcm(stream, &c->tb, ks.nr, &ks.ek, 0, nonce, d_aad, aad_len, d_in, len, d_out,
                    c->scratch, NULL));
     return 0;
@@ -649,7 +664,7 @@ int uaes_gcm_decrypt_dev(int keybits, const uint8_t *key, const uint8_t *nonce,
     if ((rc = expand_key(&ks, key, keybits)) != 0) return rc;
     if (!d_status) return fail(UAES_E_ARG, "NULL d_status");
     if ((rc = get_context(&c)) != 0) return rc;
-    if ((rc = gcm_scratch(c)) != 0) return rc;
+    if ((rc = gcm_scratch_locked(c)) != 0) return rc;
     KCHK(uaesk_gcm(stream, &c->tb, ks.nr, &ks.ek, 1, nonce, d_aad, aad_len, d_in, len, d_out,
                    c->scratch, d_status));
     return 0;
@@ -669,7 +684,7 @@ int uaes_gcm_partial_dev(int keybits, const uint8_t *key, const uint8_t *nonce,
         return fail(UAES_E_ARG, "shard [%llu, +%zu) is not a 16-byte aligned slice of %llu bytes",
                     (unsigned long long)shard_offset, shard_len, (unsigned long long)total_len);
     if ((rc = get_context(&c)) != 0) return rc;
-    if ((rc = gcm_scratch(c)) != 0) return rc;
+    if ((rc = gcm_scratch_locked(c)) != 0) return rc;
     KCHK(uaesk_gcm_partial(stream, &c->tb, ks.nr, &ks.ek, nonce, d_aad, total_aad_len,
                            d_ct_shard, shard_len, shard_offset, total_len, c->scratch, d_partial16));
     return 0;

@@ -663,10 +663,28 @@ static unsigned grid_for(u64 work_items, u64 per_wg)
     return (unsigned)(want < cap ? want : cap);
 }
 
+/* > 64 KiB of dynamic LDS needs the attribute; set it once per (kernel, device).
+ * Keyed by the kernel's address: instantiations share C++ types, so a per-type
+ * static would be wrong.  A racing first call merely sets the attribute twice. */
+static hipError_t set_lds_ptr(const void *kern, unsigned bytes)
+{
+    static const void *seen[16][64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    int free_slot = -1;
+    for (int i = 0; i < 64; ++i) {
+        if (seen[dev][i] == kern) return hipSuccess;
+        if (!seen[dev][i]) { free_slot = i; break; }
+    }
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess && free_slot >= 0) seen[dev][free_slot] = kern;
+    return e;
+}
+
 template <typename K>
 static hipError_t set_lds(K kern, unsigned bytes)
 {
-    return hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    return set_lds_ptr((const void *)kern, bytes);
 }
 
 #define DISPATCH_NR(nr, CALL)                         \
