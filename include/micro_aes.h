@@ -36,6 +36,7 @@
 #define GCM      1
 #define CMAC     1          /* serial CBC-MAC chains: one GPU lane (uaes_mac.hip) */
 #define CCM      1
+#define GCM_SIV  1          /* RFC 8452: POLYVAL through the GHASH kernels, LE32 counter */
 
 #define CBC      1          /* feedback modes: decrypt of CBC/CFB is block-   */
 #define CFB      1          /* parallel, the rest one GPU lane (uaes_chain.hip) */
@@ -46,7 +47,6 @@
 #define EAX      0
 #define EAXP     0
 #define SIV      0
-#define GCM_SIV  0
 #define OCB      0
 #define POLY1305 0
 #define MICRO_RJNDL 0
@@ -63,6 +63,8 @@ enum constant_parameters_of_modes
     CCM_TAG_LEN     = 16,
     GCM_NONCE_LEN   = 12,
     GCM_TAG_LEN     = 16,
+    SIVGCM_NONCE_LEN = 12,
+    SIVGCM_TAG_LEN  = 16,
 #if AES___ == 256 || AES___ == 192
     AES_KEYLENGTH   = AES___ / 8
 #else
@@ -119,6 +121,13 @@ void AES_CCM_encrypt(const uint8_t *key, const uint8_t *nonce,
                      const void *aData, const size_t aDataLen,
                      const void *pntxt, const size_t ptextLen, void *crtxt);
 char AES_CCM_decrypt(const uint8_t *key, const uint8_t *nonce,
+                     const void *aData, const size_t aDataLen,
+                     const void *crtxt, const size_t crtxtLen, void *pntxt);
+
+void GCM_SIV_encrypt(const uint8_t *key, const uint8_t *nonce,
+                     const void *aData, const size_t aDataLen,
+                     const void *pntxt, const size_t ptextLen, void *crtxt);
+char GCM_SIV_decrypt(const uint8_t *key, const uint8_t *nonce,
                      const void *aData, const size_t aDataLen,
                      const void *crtxt, const size_t crtxtLen, void *pntxt);
 

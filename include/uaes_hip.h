@@ -155,6 +155,20 @@ int uaes_cfb_decrypt(int keybits, const uint8_t *key, const uint8_t *iVec,
 int uaes_ofb_xcrypt(int keybits, const uint8_t *key, const uint8_t *iVec,
                     const void *in, size_t len, void *out);
 
+/* ---- GCM-SIV: replaces GCM_SIV_encrypt / GCM_SIV_decrypt ---------------------
+ * RFC 8452; micro_aes.c:1418-1516.  12-byte nonce, 16-byte tag appended.  Per-
+ * nonce keys are derived with AES (GCM_SIVsetup), the tag is AES over POLYVAL
+ * (run through the GHASH kernels with byte-reversed blocks), the text is CTR
+ * with a 32-bit little-endian counter seeded by the tag.  decrypt returns
+ * UAES_E_AUTHENTICATION on a mismatch and, like the reference, leaves the
+ * decrypted text in pntxt.                                                   */
+int uaes_gcmsiv_encrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
+                        const void *aData, size_t aDataLen,
+                        const void *pntxt, size_t ptextLen, void *crtxt);
+int uaes_gcmsiv_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
+                        const void *aData, size_t aDataLen,
+                        const void *crtxt, size_t crtxtLen, void *pntxt);
+
 /* ---- asynchronous, device-resident variants -----------------------------
  * All data pointers are device pointers, 16-byte aligned; `stream` is a
  * hipStream_t (NULL = default stream).  The call only enqueues work.  One

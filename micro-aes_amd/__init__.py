@@ -36,7 +36,7 @@ EXPORTS = [
     "uaes_ecb_encrypt", "uaes_ecb_decrypt", "uaes_ctr_xcrypt", "uaes_ctr_xcrypt_at",
     "uaes_xts_encrypt", "uaes_xts_decrypt", "uaes_xts_sectors",
     "uaes_gcm_encrypt", "uaes_gcm_decrypt", "uaes_ghash",
-    "uaes_cmac", "uaes_ccm_encrypt", "uaes_ccm_decrypt",
+    "uaes_cmac", "uaes_ccm_encrypt", "uaes_ccm_decrypt", "uaes_gcmsiv_encrypt", "uaes_gcmsiv_decrypt",
     "uaes_cbc_encrypt", "uaes_cbc_decrypt", "uaes_cfb_encrypt", "uaes_cfb_decrypt", "uaes_ofb_xcrypt",
     "uaes_ecb_dev", "uaes_ctr_xcrypt_at_dev", "uaes_xts_sectors_dev",
     "uaes_gcm_encrypt_dev", "uaes_gcm_decrypt_dev", "uaes_gcm_partial_dev",
@@ -44,7 +44,7 @@ EXPORTS = [
 COMPAT_EXPORTS = [
     "AES_ECB_encrypt", "AES_ECB_decrypt", "AES_CTR_encrypt", "AES_CTR_decrypt",
     "AES_XTS_encrypt", "AES_XTS_decrypt", "AES_GCM_encrypt", "AES_GCM_decrypt",
-    "AES_CCM_encrypt", "AES_CCM_decrypt", "AES_CMAC",
+    "AES_CCM_encrypt", "AES_CCM_decrypt", "AES_CMAC", "GCM_SIV_encrypt", "GCM_SIV_decrypt",
     "AES_CBC_encrypt", "AES_CBC_decrypt", "AES_CFB_encrypt", "AES_CFB_decrypt", "AES_OFB_encrypt", "AES_OFB_decrypt",
 ]
 
@@ -103,7 +103,7 @@ def engine():
     L.uaes_cmac.argtypes = [i, vp, vp, sz, vp]
     for n in ("uaes_cbc_encrypt", "uaes_cbc_decrypt", "uaes_cfb_encrypt", "uaes_cfb_decrypt", "uaes_ofb_xcrypt"):
         getattr(L, n).argtypes = [i, vp, vp, vp, sz, vp]
-    for n in ("uaes_ccm_encrypt", "uaes_ccm_decrypt"):
+    for n in ("uaes_ccm_encrypt", "uaes_ccm_decrypt", "uaes_gcmsiv_encrypt", "uaes_gcmsiv_decrypt"):
         getattr(L, n).argtypes = [i, vp, vp, vp, sz, vp, sz, vp]
     L.uaes_ecb_dev.argtypes = [i, vp, i, vp, sz, vp, vp]
     L.uaes_ctr_xcrypt_at_dev.argtypes = [i, vp, vp, u64, vp, sz, vp, vp]
@@ -280,6 +280,23 @@ def AES_CCM_decrypt(key, nonce, aData, crtxt_and_tag, prefill=0):
     o = _out(n, prefill)
     rc = _check(engine().uaes_ccm_decrypt(_bits(key), _in(key), _in(nonce), _in(aData), len(aData),
                                           _in(crtxt_and_tag), n, o), "AES_CCM_decrypt")
+    return rc, bytes(o)[:n]
+
+
+def GCM_SIV_encrypt(key, nonce, aData, pntxt):
+    """micro_aes.c:1473 (RFC 8452).  Returns ciphertext || 16-byte tag."""
+    o = _out(len(pntxt) + 16)
+    _check(engine().uaes_gcmsiv_encrypt(_bits(key), _in(key), _in(nonce), _in(aData), len(aData),
+                                        _in(pntxt), len(pntxt), o), "GCM_SIV_encrypt")
+    return bytes(o)[: len(pntxt) + 16]
+
+
+def GCM_SIV_decrypt(key, nonce, aData, crtxt_and_tag, prefill=0):
+    """micro_aes.c:1494.  Returns (code, text)."""
+    n = len(crtxt_and_tag) - 16
+    o = _out(n, prefill)
+    rc = _check(engine().uaes_gcmsiv_decrypt(_bits(key), _in(key), _in(nonce), _in(aData), len(aData),
+                                             _in(crtxt_and_tag), n, o), "GCM_SIV_decrypt")
     return rc, bytes(o)[:n]
 
 

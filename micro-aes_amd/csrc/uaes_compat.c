@@ -131,3 +131,18 @@ void AES_OFB_decrypt(const uint8_t *key, const uint8_t iVec[16],
 {
     must("AES_OFB_decrypt", uaes_ofb_xcrypt(KB, key, iVec, crtxt, crtxtLen, pntxt));
 }
+
+void GCM_SIV_encrypt(const uint8_t *key, const uint8_t *nonce,
+                     const void *aData, const size_t aDataLen,
+                     const void *pntxt, const size_t ptextLen, void *crtxt)
+{
+    must("GCM_SIV_encrypt", uaes_gcmsiv_encrypt(KB, key, nonce, aData, aDataLen, pntxt, ptextLen, crtxt));
+}
+
+char GCM_SIV_decrypt(const uint8_t *key, const uint8_t *nonce,
+                     const void *aData, const size_t aDataLen,
+                     const void *crtxt, const size_t crtxtLen, void *pntxt)
+{
+    return soft("GCM_SIV_decrypt", uaes_gcmsiv_decrypt(KB, key, nonce, aData, aDataLen, crtxt, crtxtLen, pntxt),
+                M_DECRYPTION_ERROR);
+}

@@ -34,6 +34,10 @@ typedef struct {
     uint32_t w0, w1;       /* counter-block bytes 0..7 as LE words         */
     uint32_t b8;           /* counter-block byte 8 (never changes)         */
     uint64_t v0;           /* bytes 9..15 as a 56-bit big-endian integer   */
+    /* le32 != 0: the GCM-SIV flavour of CTR_cipher (SIVGCM_CTR, micro_aes.c:935-938):
+     * a 32-bit LITTLE-endian counter in bytes 0..3 (w0, wraps mod 2^32), the other
+     * twelve bytes (w1, w2, w3) fixed.  b8 / v0 are ignored.                 */
+    uint32_t le32, w2, w3;
 } uaesk_ctr;
 
 int uaesk_device_info(int *cu_count, int *lds_bytes);
@@ -79,6 +83,14 @@ int uaesk_gcm_partial(void *stream, const uaesk_tables *tb, int nr, const uaesk_
                       const uint8_t *nonce12, const void *aad, uint64_t total_aad_len,
                       const void *ct_shard, size_t shard_len, uint64_t shard_offset,
                       uint64_t total_len, void *scratch, void *partial16);
+
+/* POLYVAL of RFC 8452 (polyval, micro_aes.c:1421-1432) through the GHASH levels:
+ * POLYVAL(H, X) = rev(GHASH(mulX(rev(H)), rev(X_i)...)); hg_host must already be
+ * mulX_GHASH(ByteReverse(H)); pv_out16 receives the RAW GHASH value (the caller
+ * byte-reverses it).  Length block = LE64(aad bits) || LE64(pt bits).        */
+int uaesk_polyval(void *stream, const uint8_t *hg_host,
+                  const void *aad, size_t aad_len, const void *pt, size_t pt_len,
+                  void *scratch, void *pv_out16);
 
 /* GHASH only: gh = GHASH_H(aad, ct) with H given (device), for tests.      */
 int uaesk_ghash(void *stream, const uint8_t *H_host,

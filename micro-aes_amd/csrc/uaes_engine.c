@@ -406,6 +406,7 @@ static void make_ctr(uaesk_ctr *c, const uint8_t ctr0[16], uint64_t block_offset
 {
     uint64_t v = 0;
     int i;
+    memset(c, 0, sizeof *c);
     memcpy(&c->w0, ctr0, 4);
     memcpy(&c->w1, ctr0 + 4, 4);
     c->b8 = ctr0[8];
@@ -852,4 +853,158 @@ int uaes_ofb_xcrypt(int keybits, const uint8_t *key, const uint8_t *iVec,
                     const void *in, size_t len, void *out)
 {
     return feedback_common(keybits, key, iVec, 4, in, len, out);
+}
+
+/* ------------------------------------------------------------------------ */
+/* GCM-SIV (RFC 8452; micro_aes.c:1418-1516)          */
+/* ------------------------------------------------------------------------ */
+/* Host orchestration only: every AES block (key derivation, tag encryption, the
+ * LE32 counter stream) and POLYVAL run in kernels.  The host moves 16..96-byte
+ * values between the steps and does the RFC's byte reversals / x-multiplication
+ * of the POLYVAL key (plain integer bit operations on 16 bytes).             */
+static void rev16_bytes(uint8_t b[16])
+{
+    int i;
+    for (i = 0; i < 8; ++i) { uint8_t t = b[i]; b[i] = b[15 - i]; b[15 - i] = t; }
+}
+
+/* v <- v * x in GHASH's field (right shift of the big-endian block, 0xe1 fold) */
+static void ghash_mulx(uint8_t v[16])
+{
+    int k;
+    const uint8_t lsb = (uint8_t)(v[15] & 1);
+    for (k = 15; k > 0; --k) v[k] = (uint8_t)((v[k] >> 1) | (v[k - 1] << 7));
+    v[0] >>= 1;
+    if (lsb) v[0] ^= 0xe1;
+}
+
+typedef struct {
+    keysched enc;           /* message-encryption key schedule              */
+    uint8_t  hg[16];        /* mulX_GHASH(ByteReverse(message-authentication key)) */
+} sivkeys;
+
+/* GCM_SIVsetup (:1435-1450): blocks LE32(i) || nonce under the main key, the
+ * first 8 bytes of each; auth key = first 16 bytes, cipher key = last KEYSIZE */
+static int gcmsiv_derive(context *c, int keybits, const uint8_t *key, const uint8_t *nonce, sivkeys *out)
+{
+    keysched master;
+    uint8_t blocks[6 * 16], derived[6 * 8];
+    const int kbytes = keybits / 8, n = 2 + keybits / 64;
+    int rc, i;
+    if ((rc = expand_key(&master, key, keybits)) != 0) return rc;
+    memset(blocks, 0, sizeof blocks);
+    for (i = 0; i < n; ++i) {
+        blocks[16 * i] = (uint8_t)i;
+        memcpy(blocks + 16 * i + 4, nonce, 12);
+    }
+    if (grow(&c->aad_stage, &c->aad_cap, 256)) return UAES_E_HIP;
+    HIPCHK(hipMemcpy(c->aad_stage, blocks, (size_t)(16 * n), hipMemcpyHostToDevice));
+    KCHK(uaesk_ecb(NULL, &c->tb, master.nr, &master.ek, 0, c->aad_stage, c->aad_stage, (size_t)n, 0));
+    HIPCHK(hipMemcpy(blocks, c->aad_stage, (size_t)(16 * n), hipMemcpyDeviceToHost));
+    for (i = 0; i < n; ++i) memcpy(derived + 8 * i, blocks + 16 * i, 8);
+    memcpy(out->hg, derived, 16);
+    rev16_bytes(out->hg);
+    ghash_mulx(out->hg);
+    return expand_key(&out->enc, derived + 8 * n - kbytes, keybits);
+}
+
+/* tag = Enc_k((POLYVAL ^ nonce) with the top bit cleared)   (GCM_SIVtag :1453-1460);
+ * d_pt: device plaintext; result in tag[16] (host)                          */
+static int gcmsiv_tag(context *c, const sivkeys *k, const uint8_t *nonce,
+                      const void *d_aad, size_t aad_len, const void *d_pt, size_t len, uint8_t tag[16])
+{
+    uint8_t s[16];
+    int i;
+    uint8_t *slot = (uint8_t *)(c->d_status + 4);
+    KCHK(uaesk_polyval(NULL, k->hg, d_aad, aad_len, d_pt, len, c->scratch, slot));
+    HIPCHK(hipMemcpy(s, slot, 16, hipMemcpyDeviceToHost));
+    rev16_bytes(s);
+    for (i = 0; i < 12; ++i) s[i] ^= nonce[i];
+    s[15] &= 0x7F;
+    HIPCHK(hipMemcpy(slot, s, 16, hipMemcpyHostToDevice));
+    KCHK(uaesk_ecb(NULL, &c->tb, k->enc.nr, &k->enc.ek, 0, slot, slot, 1, 0));
+    HIPCHK(hipMemcpy(tag, slot, 16, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+static void gcmsiv_ctr(uaesk_ctr *ctr, const uint8_t tag[16])
+{
+    memset(ctr, 0, sizeof *ctr);
+    ctr->le32 = 1;
+    memcpy(&ctr->w0, tag, 4);
+    memcpy(&ctr->w1, tag + 4, 4);
+    memcpy(&ctr->w2, tag + 8, 4);
+    memcpy(&ctr->w3, tag + 12, 4);
+    ctr->w3 |= 0x80000000u;                      /* c[LAST] |= 0x80 (:936) */
+}
+
+int uaes_gcmsiv_encrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
+                        const void *aData, size_t aDataLen,
+                        const void *pntxt, size_t ptextLen, void *crtxt)
+{
+    context *c;
+    sivkeys k;
+    io_plan io;
+    const void *d_aad;
+    uaesk_ctr ctr;
+    uint8_t tag[16];
+    int rc;
+    if (keybits != 128 && keybits != 192 && keybits != 256)
+        return fail(UAES_E_ARG, "keybits must be 128, 192 or 256 (got %d)", keybits);
+    if (!key || !nonce || !crtxt || (ptextLen && !pntxt)) return fail(UAES_E_ARG, "NULL pointer");
+    if ((rc = get_context(&c)) != 0) return rc;
+    LOCKED_BEGIN(c);
+    do {
+        if ((rc = gcm_scratch(c)) != 0) break;
+        if ((rc = gcmsiv_derive(c, keybits, key, nonce, &k)) != 0) break;
+        /* aad_stage was used for the derivation blocks: stage the AAD after it */
+        if ((rc = stage_aad(c, aData, aDataLen, &d_aad)) != 0) break;
+        if ((rc = plan_io(c, pntxt, ptextLen, crtxt, ptextLen + 16, &io)) != 0) break;
+        if ((rc = gcmsiv_tag(c, &k, nonce, d_aad, aDataLen, io.din, ptextLen, tag)) != 0) break;
+        gcmsiv_ctr(&ctr, tag);
+        int kk = uaesk_ctr_xcrypt(NULL, &c->tb, k.enc.nr, &k.enc.ek, &ctr, io.din, io.dout, ptextLen, NULL);
+        if (kk) { rc = fail(UAES_E_HIP, "gcm-siv ctr launch: %s", hipGetErrorString((hipError_t)kk)); break; }
+        if (hipMemcpyAsync((char *)io.dout + ptextLen, tag, 16, hipMemcpyHostToDevice, NULL) != hipSuccess) {
+            rc = fail(UAES_E_HIP, "tag copy failed");
+            break;
+        }
+        rc = finish_io(&io, ptextLen + 16);
+    } while (0);
+    LOCKED_END(c, rc);
+}
+
+int uaes_gcmsiv_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
+                        const void *aData, size_t aDataLen,
+                        const void *crtxt, size_t crtxtLen, void *pntxt)
+{
+    context *c;
+    sivkeys k;
+    io_plan io;
+    const void *d_aad;
+    uaesk_ctr ctr;
+    uint8_t tag_in[16], tag[16];
+    int rc;
+    if (keybits != 128 && keybits != 192 && keybits != 256)
+        return fail(UAES_E_ARG, "keybits must be 128, 192 or 256 (got %d)", keybits);
+    if (!key || !nonce || !crtxt || (crtxtLen && !pntxt)) return fail(UAES_E_ARG, "NULL pointer");
+    if ((rc = get_context(&c)) != 0) return rc;
+    LOCKED_BEGIN(c);
+    do {
+        if ((rc = gcm_scratch(c)) != 0) break;
+        if ((rc = gcmsiv_derive(c, keybits, key, nonce, &k)) != 0) break;
+        if ((rc = stage_aad(c, aData, aDataLen, &d_aad)) != 0) break;
+        if ((rc = plan_io(c, crtxt, crtxtLen + 16, pntxt, crtxtLen, &io)) != 0) break;
+        if (hipMemcpy(tag_in, (const char *)io.din + crtxtLen, 16, hipMemcpyDeviceToHost) != hipSuccess) {
+            rc = fail(UAES_E_HIP, "tag read failed");
+            break;
+        }
+        /* like the reference: decrypt with the RECEIVED tag as counter, then authenticate (:1500-1502) */
+        gcmsiv_ctr(&ctr, tag_in);
+        int kk = uaesk_ctr_xcrypt(NULL, &c->tb, k.enc.nr, &k.enc.ek, &ctr, io.din, io.dout, crtxtLen, NULL);
+        if (kk) { rc = fail(UAES_E_HIP, "gcm-siv ctr launch: %s", hipGetErrorString((hipError_t)kk)); break; }
+        if ((rc = gcmsiv_tag(c, &k, nonce, d_aad, aDataLen, io.dout, crtxtLen, tag)) != 0) break;
+        if ((rc = finish_io(&io, crtxtLen)) != 0) break;          /* text stays (SABOTAGE is a no-op) */
+        rc = memcmp(tag, tag_in, 16) ? UAES_E_AUTHENTICATION : 0;
+    } while (0);
+    LOCKED_END(c, rc);
 }

@@ -67,6 +67,7 @@ struct GSrc {
     u32 has_len;
     u64 len_aad, len_ct;          /* byte lengths written into the length block (totals of the
                                      whole message when this is one shard of it) */
+    u32 rev;                      /* POLYVAL: every input block byte-reversed, LE length block */
 };
 
 __device__ __forceinline__ uint4 load_bytes_padded(const unsigned char *p, u64 avail)
@@ -77,7 +78,12 @@ __device__ __forceinline__ uint4 load_bytes_padded(const unsigned char *p, u64 a
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-__device__ __forceinline__ uint4 load_vblock(const GSrc &s, u64 v)
+__device__ __forceinline__ uint4 rev16(uint4 b)
+{
+    return make_uint4(bswap32(b.w), bswap32(b.z), bswap32(b.y), bswap32(b.x));
+}
+
+__device__ __forceinline__ uint4 load_vblock_fwd(const GSrc &s, u64 v)
 {
     const u64 ab = (s.aad_len + 15) >> 4, cb = (s.ct_len + 15) >> 4;
     if (v < ab) return load_bytes_padded(s.aad + v * 16, s.aad_len - v * 16);
@@ -87,8 +93,16 @@ __device__ __forceinline__ uint4 load_vblock(const GSrc &s, u64 v)
         return load_bytes_padded(s.ct + v * 16, s.ct_len - v * 16);
     }
     const u64 abits = s.len_aad * 8, cbits = s.len_ct * 8;      /* N6 */
+    if (s.rev)                                                  /* POLYVAL: two little-endian 64-bit lengths */
+        return make_uint4((u32)abits, (u32)(abits >> 32), (u32)cbits, (u32)(cbits >> 32));
     return make_uint4(bswap32((u32)(abits >> 32)), bswap32((u32)abits),
                       bswap32((u32)(cbits >> 32)), bswap32((u32)cbits));
+}
+
+__device__ __forceinline__ uint4 load_vblock(const GSrc &s, u64 v)
+{
+    const uint4 b = load_vblock_fwd(s, v);
+    return s.rev ? rev16(b) : b;
 }
 
 __device__ __forceinline__ uint4 x4(uint4 a, uint4 b)
@@ -445,6 +459,7 @@ static int run_ghash_levels(hipStream_t st, const GSrc &msg, u64 nv, const GPlan
         hipLaunchKernelGGL(k_ghash_pass, dim3((unsigned)(sA / GH_PT)), dim3(GH_PT), 65536, st,
                            cur, n, (const uint4 *)(scratch + GS_TAB8_A), (uint4 *)(scratch + GS_ACC1));
         cur.aad = nullptr; cur.aad_len = 0; cur.ct = scratch + GS_ACC1; cur.ct_len = sA * 16; cur.has_len = 0;
+        cur.rev = 0;
         n = sA;
         if (pl.needB) {
             const u64 sB = (u64)1 << GH_LOGB;
@@ -489,6 +504,7 @@ extern "C" int uaesk_gcm(void *stream, const uaesk_tables *tb, int nr, const uae
     /* keystream counter starts at J0 + 1 (pre-increment, N4); the reference's
      * incBlock carries through bytes 15..9, so this is a 56-bit counter      */
     uaesk_ctr c;
+    memset(&c, 0, sizeof c);
     memcpy(&c.w0, j0b, 4);
     memcpy(&c.w1, j0b + 4, 4);
     c.b8 = j0b[8];
@@ -497,7 +513,7 @@ extern "C" int uaesk_gcm(void *stream, const uaesk_tables *tb, int nr, const uae
     GSrc msg;
     msg.aad = (const unsigned char *)aad; msg.aad_len = aad_len;
     msg.ct = (const unsigned char *)(decrypt ? in : out); msg.ct_len = len;
-    msg.has_len = 1; msg.len_aad = aad_len; msg.len_ct = len;
+    msg.has_len = 1; msg.len_aad = aad_len; msg.len_ct = len; msg.rev = 0;
     const u64 nv = ((aad_len + 15) >> 4) + ((len + 15) >> 4) + 1;
     const GPlan pl = plan_for(nv);
 
@@ -530,7 +546,7 @@ extern "C" int uaesk_ghash(void *stream, const uint8_t *H_host,
     GSrc msg;
     msg.aad = (const unsigned char *)aad; msg.aad_len = aad_len;
     msg.ct = (const unsigned char *)ct; msg.ct_len = ct_len;
-    msg.has_len = 1; msg.len_aad = aad_len; msg.len_ct = ct_len;
+    msg.has_len = 1; msg.len_aad = aad_len; msg.len_ct = ct_len; msg.rev = 0;
     const u64 nv = ((aad_len + 15) >> 4) + ((ct_len + 15) >> 4) + 1;
     const GPlan pl = plan_for(nv);
     uint4 h;
@@ -606,7 +622,7 @@ extern "C" int uaesk_gcm_partial(void *stream, const uaesk_tables *tb, int nr, c
     msg.aad_len = first ? total_aad_len : 0;
     msg.ct = (const unsigned char *)ct_shard; msg.ct_len = shard_len;
     msg.has_len = last ? 1 : 0;
-    msg.len_aad = total_aad_len; msg.len_ct = total_len;
+    msg.len_aad = total_aad_len; msg.len_ct = total_len; msg.rev = 0;
     const GPlan pl = plan_for(nv ? nv : 1);
     const uint4 z = make_uint4(0, 0, 0, 0);
     int rc;
@@ -624,4 +640,27 @@ extern "C" int uaesk_gcm_partial(void *stream, const uaesk_tables *tb, int nr, c
     hipLaunchKernelGGL(k_gcm_weight, dim3(1), dim3(64), 0, st, (const unsigned char *)sc, m_total - hi,
                        (u32)first, (u32)(nv == 0), (unsigned char *)partial16);
     return (int)hipGetLastError();
+}
+
+
+extern "C" int uaesk_polyval(void *stream, const uint8_t *hg_host,
+                             const void *aad, size_t aad_len, const void *pt, size_t pt_len,
+                             void *scratch, void *pv_out16)
+{
+    hipStream_t st = S(stream);
+    unsigned char *sc = (unsigned char *)scratch;
+    GSrc msg;
+    msg.aad = (const unsigned char *)aad; msg.aad_len = aad_len;
+    msg.ct = (const unsigned char *)pt; msg.ct_len = pt_len;
+    msg.has_len = 1; msg.len_aad = aad_len; msg.len_ct = pt_len; msg.rev = 1;
+    const u64 nv = ((aad_len + 15) >> 4) + ((pt_len + 15) >> 4) + 1;
+    const GPlan pl = plan_for(nv);
+    uint4 h;
+    memcpy(&h, hg_host, 16);
+    uaesk_rk dummy_rk;
+    uaesk_tables dummy_tb = { nullptr, nullptr, nullptr };
+    memset(&dummy_rk, 0, sizeof dummy_rk);
+    int rc = launch_setup<10>(st, &dummy_tb, &dummy_rk, make_uint4(0, 0, 0, 0), sc, pl, 1, h);
+    if (rc) return rc;
+    return run_ghash_levels(st, msg, nv, pl, sc, 2, (unsigned char *)pv_out16, nullptr);
 }

@@ -82,6 +82,11 @@ __global__ __launch_bounds__(UAES_WG) void k_ecb(uaesk_rk rk, uaesk_tables tb,
  * big-endian (v0 + i) mod 2^56 (reference N2)                               */
 __device__ __forceinline__ void ctr_words(const uaesk_ctr &c, u64 i, u32 (&w)[4])
 {
+    if (c.le32) {                              /* GCM-SIV: LE32 counter in bytes 0..3 (wave-uniform branch) */
+        w[0] = c.w0 + (u32)i;
+        w[1] = c.w1; w[2] = c.w2; w[3] = c.w3;
+        return;
+    }
     const u64 v = (c.v0 + i) & 0x00FFFFFFFFFFFFFFull;
     w[0] = c.w0;
     w[1] = c.w1;
@@ -783,7 +788,8 @@ template <int NR>
 static int launch_ctr(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek, const uaesk_ctr *ctr,
                       const void *in, void *out, size_t len, const int *gate)
 {
-    if (ctr_variant() == 2) return launch_ctr_v<NR, 4, 4>(st, tb, ek, ctr, in, out, len, gate);
+    if (ctr_variant() == 2 || ctr->le32)       /* the shared-round kernels assume the 56-bit BE counter */
+        return launch_ctr_v<NR, 4, 4>(st, tb, ek, ctr, in, out, len, gate);
     return launch_ctr_shared<NR>(st, tb, ek, ctr, in, out, len, gate);
 }
 

@@ -222,6 +222,7 @@ extern "C" int uaesk_ccm(void *stream, const uaesk_tables *tb, int nr, const uae
     uint4 iv;
     memcpy(&iv, ivb, 16);
     uaesk_ctr c;
+    memset(&c, 0, sizeof c);
     memcpy(&c.w0, ivb, 4);
     memcpy(&c.w1, ivb + 4, 4);
     c.b8 = ivb[8];

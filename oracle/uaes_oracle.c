@@ -652,6 +652,114 @@ char orc_ccm_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
 }
 
 /* ------------------------------------------------------------------------ */
+/* GCM-SIV -- RFC 8452; divideLblock/dotGF128 :499-529, polyval :1421-1432,    */
+/*            GCM_SIVsetup :1435-1450, GCM_SIVtag :1453-1460, API :1473-1515   */
+/* ------------------------------------------------------------------------ */
+/* POLYVAL's field: blocks are 128-bit LITTLE-endian integers, bit j = x^j.
+ * dot(a, b) = a * b * x^-128: walk the bits of a from x^127 down to x^0, dividing
+ * b by x before each test (a right shift; a dropped x^0 re-enters as 0xe1<<120). */
+static void polyval_dot(const uint8_t a[16], uint8_t b[16])
+{
+    uint64_t lo = 0, hi = 0, rlo = 0, rhi = 0;
+    int i, j;
+    for (i = 0; i < 8; ++i) { lo |= (uint64_t)b[i] << (8 * i); hi |= (uint64_t)b[8 + i] << (8 * i); }
+    for (j = 127; j >= 0; --j) {
+        const uint64_t drop = lo & 1;
+        lo = (lo >> 1) | (hi << 63);
+        hi >>= 1;
+        if (drop) hi ^= (uint64_t)0xe1 << 56;
+        if ((a[j >> 3] >> (j & 7)) & 1) { rlo ^= lo; rhi ^= hi; }
+    }
+    for (i = 0; i < 8; ++i) { b[i] = (uint8_t)(rlo >> (8 * i)); b[8 + i] = (uint8_t)(rhi >> (8 * i)); }
+}
+
+static void polyval_absorb(const uint8_t H[16], const uint8_t *x, size_t len, uint8_t acc[16])
+{
+    size_t off, k;
+    for (off = 0; off < len; off += 16) {
+        size_t n = len - off < 16 ? len - off : 16;
+        for (k = 0; k < n; ++k) acc[k] ^= x[off + k];
+        polyval_dot(H, acc);
+    }
+}
+
+static void gcmsiv_keys(int keybits, const uint8_t *key, const uint8_t *nonce,
+                        uint8_t auth[16], orc_key *enc)
+{
+    orc_key master;
+    uint8_t blk[16], out[16], derived[48];
+    int i, n = 2 + keybits / 64;
+    orc_setkey(&master, key, keybits);
+    for (i = 0; i < n; ++i) {
+        memset(blk, 0, 16);
+        blk[0] = (uint8_t)i;
+        memcpy(blk + 4, nonce, 12);
+        orc_encrypt_block(&master, blk, out);
+        memcpy(derived + 8 * i, out, 8);
+    }
+    memcpy(auth, derived, 16);
+    orc_setkey(enc, derived + 8 * n - keybits / 8, keybits);
+}
+
+static void gcmsiv_tag(const orc_key *enc, const uint8_t auth[16], const uint8_t *nonce,
+                       const uint8_t *aad, size_t alen, const uint8_t *pt, size_t plen, uint8_t tag[16])
+{
+    uint8_t lens[16], s[16] = { 0 };
+    uint64_t abits = (uint64_t)alen * 8, pbits = (uint64_t)plen * 8;
+    int i;
+    for (i = 0; i < 8; ++i) { lens[i] = (uint8_t)(abits >> (8 * i)); lens[8 + i] = (uint8_t)(pbits >> (8 * i)); }
+    polyval_absorb(auth, aad, alen, s);
+    polyval_absorb(auth, pt, plen, s);
+    polyval_absorb(auth, lens, 16, s);
+    for (i = 0; i < 12; ++i) s[i] ^= nonce[i];
+    s[15] &= 0x7F;
+    orc_encrypt_block(enc, s, tag);
+}
+
+/* CTR with a 32-bit little-endian counter in bytes 0..3 (SIVGCM_CTR, :935-938) */
+static void ctr32le_stream(const orc_key *ks, const uint8_t tag[16], const uint8_t *x, size_t len, uint8_t *y)
+{
+    uint8_t c[16], e[16];
+    size_t off, k;
+    uint32_t ctr;
+    memcpy(c, tag, 16);
+    c[15] |= 0x80;
+    ctr = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16) | ((uint32_t)c[3] << 24);
+    for (off = 0; off < len; off += 16, ++ctr) {
+        size_t n = len - off < 16 ? len - off : 16;
+        c[0] = (uint8_t)ctr; c[1] = (uint8_t)(ctr >> 8); c[2] = (uint8_t)(ctr >> 16); c[3] = (uint8_t)(ctr >> 24);
+        orc_encrypt_block(ks, c, e);
+        for (k = 0; k < n; ++k) y[off + k] = (uint8_t)(x[off + k] ^ e[k]);
+    }
+}
+
+void orc_gcmsiv_encrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
+                        const void *aad, size_t aad_len,
+                        const void *pt, size_t len, void *ct_and_tag)
+{
+    orc_key enc;
+    uint8_t auth[16], tag[16], *out = (uint8_t *)ct_and_tag;
+    gcmsiv_keys(keybits, key, nonce, auth, &enc);
+    gcmsiv_tag(&enc, auth, nonce, (const uint8_t *)aad, aad_len, (const uint8_t *)pt, len, tag);
+    ctr32le_stream(&enc, tag, (const uint8_t *)pt, len, out);
+    memcpy(out + len, tag, 16);
+}
+
+char orc_gcmsiv_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
+                        const void *aad, size_t aad_len,
+                        const void *ct_and_tag, size_t len, void *pt)
+{
+    orc_key enc;
+    uint8_t auth[16], tag[16], given[16];
+    const uint8_t *in = (const uint8_t *)ct_and_tag;
+    gcmsiv_keys(keybits, key, nonce, auth, &enc);
+    memcpy(given, in + len, 16);
+    ctr32le_stream(&enc, given, in, len, (uint8_t *)pt);          /* decrypt first (:1500) */
+    gcmsiv_tag(&enc, auth, nonce, (const uint8_t *)aad, aad_len, (const uint8_t *)pt, len, tag);
+    return memcmp(tag, given, 16) ? ORC_E_AUTH : ORC_OK;
+}
+
+/* ------------------------------------------------------------------------ */
 /* Synthetic input of SURVEY.md section 8d                                    */
 /* ------------------------------------------------------------------------ */
 void orc_fill_splitmix(uint64_t seed, uint64_t word0, size_t nwords, void *dst)

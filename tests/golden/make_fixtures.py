@@ -13,7 +13,8 @@ source text):
   actually runs (IVlen == 96 and Taglen == 128, aes_testvectors_GCM.h:86) so the
   repo carries 3 x ~140 KB instead of 3 x ~3 MB.  Format unchanged.
 * ``XTSGenAES{128,256}.rsp``, ``CMACGenAES{128,192,256}.rsp``, ``VNT{128,192,256}.rsp``
-  -- NIST CAVP XTS / CMAC / CCM files, unmodified.
+  -- NIST CAVP XTS / CMAC / CCM files, unmodified; ``SIV_GCM_ACVP.tv`` -- the 102 ACVP
+  AES-GCM-SIV vectors the reference's harness holds, unmodified.
 * ``main_kats.json`` -- the hot-path known answers of the reference's main.c
   (main.c:16-34,49-50,58-60), re-verified here against the compiled reference.
 * ``ref_vectors.json`` -- outputs of the COMPILED REFERENCE (oracle/_ref) on
@@ -102,6 +103,9 @@ MAIN_KATS = {
               "3f9c56525efbe64a876ad1d761d3fc9359fb4f5b2354acd490",
     "ofb128": "edab3105e673bc9eb9102539a9f457bcd28c8e4c92995f5cd9426926be1e775d"
               "e22b8ce4d0278b18181b8bec93b9726f959aa5d701d46102f0",
+    "gcmsiv128": "2f1488496ada3f709760420ac72e5acfa977f6add4c55ac685f1b9dff8f381e0"
+                 "2a64bbdd64cdd778525462949bb0b141db908c5cfa3657503666f879ac879fcb"
+                 "f25c15d496a1e6f7f8",
     "cmac128": "b887df1fd8c239c3e8a64d9822e21128",
     "ccm128": "d2575123438338d70b2955537fdfcf41729870884e85af15f0a74975a72b337d"
               "04d426de87594b9abe3e6dcf07f21c99db3999f81299d302ad1e5ba683e9039a"
@@ -144,6 +148,18 @@ def main_kats():
     add("main.c:153 CFB", "cfb", 128, key[:16], {"iv": iv.hex()}, MAIN_KATS["cfb128"])
     assert r128.ofb(key[:16], iv, pt).hex() == MAIN_KATS["ofb128"]
     add("main.c:160 OFB", "ofb", 128, key[:16], {"iv": iv.hex()}, MAIN_KATS["ofb128"])
+    assert r128.gcmsiv_encrypt(key[:16], iv[:12], aad, pt).hex() == MAIN_KATS["gcmsiv128"]
+    add("main.c:219 GCM-SIV", "gcmsiv", 128, key[:16], {"nonce": iv[:12].hex(), "aad": aad.hex()}, MAIN_KATS["gcmsiv128"])
+    # the two RFC 8452 vectors of main.c:275-297 (own plaintexts)
+    for name, k, n, a, p_, c in (
+            ("main.c:276 RFC-8452 #1", "ee8e1ed9ff2540ae8f2ba9f50bc2f27c", "752abad3e0afb5f434dc4310", "6578616d706c65",
+             "48656c6c6f20776f726c64", "5d349ead175ef6b1def6fd4fbcdeb7e4793f4a1d7e4faa70100af1"),
+            ("main.c:286 RFC-8452 #2", "01000000000000000000000000000000", "030000000000000000000000", "01",
+             "0200000000000000000000000000000003000000000000000000000000000000",
+             "620048ef3c1e73e57e02bb8562c416a319e73e4caac8e96a1ecb2933145a1d71e6af6a7f87287da059a71684ed3498e1")):
+        kk, nn, aa, pp = (bytes.fromhex(x) for x in (k, n, a, p_))
+        assert r128.gcmsiv_encrypt(kk, nn, aa, pp).hex() == c
+        kats.append(dict(name=name, mode="gcmsiv", keybits=128, key=k, pt=p_, nonce=n, aad=a, expect=c))
     assert r128.cmac(key[:16], pt).hex() == MAIN_KATS["cmac128"]
     add("main.c:181 CMAC", "cmac", 128, key[:16], {}, MAIN_KATS["cmac128"])
     assert r128.ccm_encrypt(key[:16], iv[:11], aad, pt).hex() == MAIN_KATS["ccm128"]
@@ -206,6 +222,13 @@ def ref_vectors(orc):
             assert ref.cfb(key, iv16, ct, False) == data
             vecs.append(dict(base, mode="cfb", key=key.hex(), iv=iv16.hex(), out=enc_out(ct)))
             vecs.append(dict(base, mode="ofb", key=key.hex(), iv=iv16.hex(), out=enc_out(ref.ofb(key, iv16, data))))
+            # GCM-SIV (bit-serial POLYVAL in the reference: cap the size)
+            if n <= 16384:
+                nonce, aad = rng.randbytes(12), rng.randbytes(rng.choice([0, 1, 15, 16, 17, 100]))
+                ct = ref.gcmsiv_encrypt(key, nonce, aad, data)
+                assert ref.gcmsiv_decrypt(key, nonce, aad, ct) == (0, data)
+                vecs.append(dict(base, mode="gcmsiv", key=key.hex(), nonce=nonce.hex(), aad=aad.hex(),
+                                 out=enc_out(ct)))
             # CMAC and CCM
             if n <= 16384:
                 vecs.append(dict(base, mode="cmac", key=key.hex(), out=enc_out(ref.cmac(key, data))))
@@ -295,6 +318,7 @@ def main():
                    os.path.join(HERE, "GcmEncryptExtIV%d.rsp" % bits))
     plain = ["XTSGenAES128.rsp", "XTSGenAES256.rsp"]
     plain += ["CMACGenAES%d.rsp" % b for b in (128, 192, 256)] + ["VNT%d.rsp" % b for b in (128, 192, 256)]
+    plain += ["SIV_GCM_ACVP.tv"]
     for name in plain:
         with open(os.path.join(REF_TV, name)) as f, open(os.path.join(HERE, name), "w") as g:
             g.write(f.read())

@@ -110,3 +110,24 @@ def ccm_cases(keybits):
                     cases.append(cur)
                 cur = {}
     return cases
+
+
+def gcmsiv_cases(keybits):
+    """SIV_GCM_ACVP.tv, filter of testvectors/aes_testvectors_GCMSIV.h: key of AES_KEYLENGTH bytes"""
+    path = os.path.join(GOLDEN, "SIV_GCM_ACVP.tv")
+    cases, cur = [], {}
+    with open(path) as f:
+        for ln in f:
+            ln = ln.strip()
+            if "=" not in ln or ln.startswith("#"):
+                continue
+            k, v = [t.strip() for t in ln.split("=", 1)]
+            if k == "Count":
+                cur = {"Count": int(v)}
+            elif k in ("pt", "key", "aad", "iv", "ct"):
+                cur[k] = bytes.fromhex(v)
+                if k == "ct":
+                    if len(cur["key"]) * 8 == keybits:
+                        cases.append(cur)
+                    cur = {}
+    return cases

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = os.path.join(ROOT, "oracle", "_ref")
-EXPECT = {128: {"CMAC": 96, "GCM": 375, "CCM": 10, "XTS": 800}, 192: {"CMAC": 144, "GCM": 375, "CCM": 10},
+EXPECT = {128: {"CMAC": 96, "GCM": 375, "CCM": 10, "GCM-SIV": 102, "XTS": 800}, 192: {"CMAC": 144, "GCM": 375, "CCM": 10},
           256: {"CMAC": 96, "GCM": 375, "CCM": 10, "XTS": 600}}
 
 
@@ -23,12 +23,12 @@ def test_reference_harness_runs_on_the_hip_library(bits, tmp_path, golden_dir):
     if not os.path.exists(exe):
         pytest.skip("oracle/_ref/harness_hip_%d was not built (needs /root/reference at build time)" % bits)
     for f in os.listdir(golden_dir):
-        if f.endswith(".rsp"):
+        if f.endswith((".rsp", ".tv")):
             os.symlink(os.path.join(golden_dir, f), tmp_path / f)
     r = subprocess.run([exe], cwd=tmp_path, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     got = dict((m, int(n)) for m, n in re.findall(
-        r"Verifying vectors: AES%d-(\w+)\s+Nmber of tests:\s*(\d+), All Passed!" % bits, r.stdout))
+        r"Verifying vectors: AES%d-([\w-]+)\s+Nmber of tests:\s*(\d+), All Passed!" % bits, r.stdout))
     assert got == EXPECT[bits], r.stdout
 
 
@@ -41,6 +41,6 @@ def test_reference_main_c_runs_on_the_hip_library(bits):
     assert r.returncode == 0 and "FAILED" not in r.stdout, r.stdout + r.stderr
     passed = re.findall(r"AES-%d (\w+) \w+: PASSED!" % bits, r.stdout)
     want = {128: ["ECB", "ECB", "CBC", "CBC", "CFB", "CFB", "OFB", "OFB", "CTR", "CTR", "XTS", "XTS", "plaintext",
-                  "GCM", "GCM", "CCM", "CCM"],
+                  "GCM", "GCM", "CCM", "CCM", "GCMSIV", "GCMSIV", "GCMSIV", "GCMSIV", "GCMSIV", "GCMSIV"],
             192: [], 256: ["XTS", "XTS", "GCM", "GCM"]}[bits]
     assert passed == want, r.stdout

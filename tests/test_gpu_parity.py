@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 import micro_aes_amd as uaes
-from tests.rsp import ccm_cases, cmac_cases, gcm_cases, xts_cases
+from tests.rsp import ccm_cases, cmac_cases, gcm_cases, gcmsiv_cases, xts_cases
 
 pytestmark = pytest.mark.gpu
 
@@ -118,6 +118,30 @@ def test_ccm_rsp_through_compat_api(bits):
         assert ord(rc) == 0 and bytes(pt)[:n] == c["Payload"]
 
 
+def test_gcmsiv_acvp_vectors():
+    cases = gcmsiv_cases(128)
+    assert len(cases) == 102
+    for c in cases:
+        assert uaes.GCM_SIV_encrypt(c["key"], c["iv"], c["aad"], c["pt"]) == c["ct"], c["Count"]
+        assert uaes.GCM_SIV_decrypt(c["key"], c["iv"], c["aad"], c["ct"]) == (0, c["pt"])
+
+
+@pytest.mark.parametrize("bits", [128, 192, 256])
+def test_gcmsiv_vs_oracle(orc, bits):
+    rnd = random.Random(bits + 6)
+    for n in [0, 1, 16, 17, 100, 4096, 65536 + 3, (1 << 20) + 16]:
+        key, nonce = rnd.randbytes(bits // 8), rnd.randbytes(12)
+        aad = rnd.randbytes(rnd.choice([0, 1, 16, 20, 4097]))
+        data = orc.splitmix(n + 2, n)
+        ct = uaes.GCM_SIV_encrypt(key, nonce, aad, data)
+        assert ct == orc.gcmsiv_encrypt(key, nonce, aad, data), n
+        assert uaes.GCM_SIV_decrypt(key, nonce, aad, ct) == (0, data)
+        bad = bytearray(ct)
+        bad[0 if n else -1] ^= 0x01
+        rc, _ = uaes.GCM_SIV_decrypt(key, nonce, aad, bytes(bad))
+        assert rc == 0x1A
+
+
 def test_main_c_kats(golden_dir):
     for k in load(golden_dir, "main_kats.json"):
         key, pt, exp = bytes.fromhex(k["key"]), bytes.fromhex(k["pt"]), bytes.fromhex(k["expect"])
@@ -142,6 +166,10 @@ def test_main_c_kats(golden_dir):
             n, a = bytes.fromhex(k["nonce"]), bytes.fromhex(k["aad"])
             assert uaes.AES_CCM_encrypt(key, n, a, pt) == exp
             assert uaes.AES_CCM_decrypt(key, n, a, exp) == (0, pt)
+        elif k["mode"] == "gcmsiv":
+            n, a = bytes.fromhex(k["nonce"]), bytes.fromhex(k["aad"])
+            assert uaes.GCM_SIV_encrypt(key, n, a, pt) == exp
+            assert uaes.GCM_SIV_decrypt(key, n, a, exp) == (0, pt)
         elif k["mode"] == "cbc":
             assert uaes.AES_CBC_encrypt(key, bytes.fromhex(k["iv"]), pt) == (0, exp)
             assert uaes.AES_CBC_decrypt(key, bytes.fromhex(k["iv"]), exp) == (0, pt)
@@ -187,6 +215,11 @@ def test_reference_generated_vectors(orc, golden_dir):
             ct = uaes.AES_CCM_encrypt(key, nonce, aad, data)
             check_out(ct, v["out"])
             assert uaes.AES_CCM_decrypt(key, nonce, aad, ct) == (0, data)
+        elif v["mode"] == "gcmsiv":
+            nonce, aad = bytes.fromhex(v["nonce"]), bytes.fromhex(v["aad"])
+            ct = uaes.GCM_SIV_encrypt(key, nonce, aad, data)
+            check_out(ct, v["out"])
+            assert uaes.GCM_SIV_decrypt(key, nonce, aad, ct) == (0, data)
         elif v["mode"] == "cbc":
             rc, ct = uaes.AES_CBC_encrypt(key, bytes.fromhex(v["iv"]), data, prefill=0xCC)
             assert rc == v["rc"]
