@@ -16,7 +16,7 @@ the 8 TB/s HBM peak with ALGORITHMIC bytes (32 B per 16-byte block: read the
 plaintext, write the ciphertext); `cpu_baseline` times the
 compiled REFERENCE (oracle/_ref, or the oracle restatement if that did not
 travel) on this box's host cores on a bounded sample of the same workload.
-Other workloads (--workload ecb|xts|gcm) are for profiling, not the bench line.
+Other workloads (--workload ecb|xts|gcm|ocb|...) are for profiling, not the bench line.
 """
 import argparse
 import ctypes
@@ -112,6 +112,8 @@ def cpu_baseline(workload):
                                                   ctypes.c_void_p(out.ctypes.data + s * 4096))
                                 for s in range(n // 4096)],
               "gcm": lambda n: L.AES_GCM_encrypt(KEY16, NONCE, None, 0, src, n, dst),
+              "ocb": lambda n: L.AES_OCB_encrypt(KEY16, NONCE, None, 0, src, n, dst),
+              "ocb-dec": lambda n: L.AES_OCB_encrypt(KEY16, NONCE, None, 0, src, n, dst),
               "cbc-dec": lambda n: L.AES_CBC_decrypt(KEY16, bytes(range(16)), src, n, dst),
               "cfb-dec": lambda n: L.AES_CFB_decrypt(KEY16, bytes(range(16)), src, n, dst)}[workload]
     else:
@@ -120,6 +122,8 @@ def cpu_baseline(workload):
               "ecb": lambda n: L.orc_ecb_encrypt(128, KEY16, src, n, dst),
               "xts": lambda n: L.orc_xts_sectors(256, KEY64, 0, 4096, n // 4096, src, dst, 1),
               "gcm": lambda n: L.orc_gcm_encrypt(128, KEY16, NONCE, None, 0, src, n, dst),
+              "ocb": lambda n: L.orc_ocb_encrypt(128, KEY16, NONCE, None, 0, src, n, dst),
+              "ocb-dec": lambda n: L.orc_ocb_encrypt(128, KEY16, NONCE, None, 0, src, n, dst),
               "cbc-dec": lambda n: L.orc_cbc_decrypt(128, KEY16, bytes(range(16)), src, n, dst),
               "cfb-dec": lambda n: L.orc_cfb(128, KEY16, bytes(range(16)), 0, src, n, dst)}[workload]
     t0 = time.perf_counter()
@@ -158,7 +162,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="ctr", choices=["ctr", "ecb", "xts", "gcm", "cbc-dec", "cfb-dec"])
+    ap.add_argument("--workload", default="ctr", choices=["ctr", "ecb", "xts", "gcm", "ocb", "ocb-dec", "cbc-dec", "cfb-dec"])
     ap.add_argument("--bytes", type=int, default=GIB, help="bytes per GPU")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
@@ -191,7 +195,7 @@ def main():
     cdev = dev if a.backend == "nccl" else torch.device("cpu")   # where collective scalars live
 
     n = a.bytes
-    seed = {"ctr": 2, "ecb": 1, "xts": 3, "gcm": 4, "cbc-dec": 5, "cfb-dec": 6}[a.workload]
+    seed = {"ctr": 2, "ecb": 1, "xts": 3, "gcm": 4, "cbc-dec": 5, "cfb-dec": 6, "ocb": 7, "ocb-dec": 7}[a.workload]
     # rank g owns bytes [g*n, (g+1)*n) of the world*n stream
     src = splitmix_device(torch, seed, n, rank * (n // 8), dev)
     dst = torch.empty(n + 16, dtype=torch.uint8, device=dev)
@@ -209,6 +213,16 @@ def main():
     elif a.workload == "gcm":
         def step():
             uaes.gcm_encrypt_dev(KEY16, NONCE, None, src, n, dst, stream=st)
+    elif a.workload == "ocb":
+        def step():
+            uaes.ocb_dev(KEY16, NONCE, None, src, n, dst, stream=st)
+    elif a.workload == "ocb-dec":
+        ocb_ct = torch.empty(n + 16, dtype=torch.uint8, device=dev)
+        ocb_status = torch.full((1,), -1, dtype=torch.int32, device=dev)
+        uaes.ocb_dev(KEY16, NONCE, None, src, n, ocb_ct, stream=st)
+
+        def step():
+            uaes.ocb_dev(KEY16, NONCE, None, ocb_ct, n, dst, decrypt=True, status=ocb_status, stream=st)
     else:
         # block-parallel decrypt directions of the feedback modes, through the host-pointer C ABI
         # with device pointers (synchronous call: launch + stream sync)
@@ -298,6 +312,11 @@ def main():
                 verify = got == orc.ecb_encrypt(KEY16, head)
             elif a.workload == "xts":
                 verify = got == orc.xts_sectors(KEY64, rank * (n // 4096), 4096, head, True)[1]
+            elif a.workload == "ocb":
+                # the head of an OCB ciphertext does not depend on what follows it
+                verify = got[: m - 16] == orc.ocb_encrypt(KEY16, NONCE, b"", head)[: m - 16]
+            elif a.workload == "ocb-dec":
+                verify = got == head and int(ocb_status.item()) == 0
             elif a.workload == "cbc-dec":
                 verify = got[: m - 32] == orc.cbc(KEY16, bytes(range(16)), head, False)[1][: m - 32]
             elif a.workload == "cfb-dec":
@@ -321,7 +340,8 @@ def main():
         except Exception:
             pass
         names = {"ctr": "AES-128-CTR", "ecb": "AES-128-ECB", "xts": "AES-256-XTS 4 KiB sectors", "gcm": "AES-128-GCM",
-                 "cbc-dec": "AES-128-CBC decrypt", "cfb-dec": "AES-128-CFB decrypt"}
+                 "cbc-dec": "AES-128-CBC decrypt", "cfb-dec": "AES-128-CFB decrypt",
+                 "ocb": "AES-128-OCB", "ocb-dec": "AES-128-OCB decrypt"}
         line = {
             "metric": "GiB/s encrypted (AES-128-CTR, 1 GiB buffer per GPU)" if a.workload == "ctr"
                       else "GiB/s encrypted (%s)" % names[a.workload],

@@ -47,7 +47,7 @@
 #define EAX      0
 #define EAXP     0
 #define SIV      0
-#define OCB      0
+#define OCB      1          /* RFC 7253: block-parallel, offsets from the Gray code (uaes_ocb.hip) */
 #define POLY1305 0
 #define MICRO_RJNDL 0
 
@@ -63,6 +63,8 @@ enum constant_parameters_of_modes
     CCM_TAG_LEN     = 16,
     GCM_NONCE_LEN   = 12,
     GCM_TAG_LEN     = 16,
+    OCB_NONCE_LEN   = 12,
+    OCB_TAG_LEN     = 16,
     SIVGCM_NONCE_LEN = 12,
     SIVGCM_TAG_LEN  = 16,
 #if AES___ == 256 || AES___ == 192
@@ -121,6 +123,13 @@ void AES_CCM_encrypt(const uint8_t *key, const uint8_t *nonce,
                      const void *aData, const size_t aDataLen,
                      const void *pntxt, const size_t ptextLen, void *crtxt);
 char AES_CCM_decrypt(const uint8_t *key, const uint8_t *nonce,
+                     const void *aData, const size_t aDataLen,
+                     const void *crtxt, const size_t crtxtLen, void *pntxt);
+
+void AES_OCB_encrypt(const uint8_t *key, const uint8_t *nonce,
+                     const void *aData, const size_t aDataLen,
+                     const void *pntxt, const size_t ptextLen, void *crtxt);
+char AES_OCB_decrypt(const uint8_t *key, const uint8_t *nonce,
                      const void *aData, const size_t aDataLen,
                      const void *crtxt, const size_t crtxtLen, void *pntxt);
 

@@ -169,6 +169,18 @@ int uaes_gcmsiv_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
                         const void *aData, size_t aDataLen,
                         const void *crtxt, size_t crtxtLen, void *pntxt);
 
+/* ---- OCB: replaces AES_OCB_encrypt / AES_OCB_decrypt --------------------------
+ * RFC 7253; micro_aes.c:1693-1811.  12-byte nonce, 16-byte tag appended.  Block-
+ * parallel in both directions: Offset_i is computed per lane from the Gray code of
+ * i instead of being chained.  decrypt returns UAES_E_AUTHENTICATION on a mismatch
+ * and, like the reference, leaves the decrypted text in pntxt.                  */
+int uaes_ocb_encrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
+                     const void *aData, size_t aDataLen,
+                     const void *pntxt, size_t ptextLen, void *crtxt);
+int uaes_ocb_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
+                     const void *aData, size_t aDataLen,
+                     const void *crtxt, size_t crtxtLen, void *pntxt);
+
 /* ---- asynchronous, device-resident variants -----------------------------
  * All data pointers are device pointers, 16-byte aligned; `stream` is a
  * hipStream_t (NULL = default stream).  The call only enqueues work.  One
@@ -190,6 +202,11 @@ int uaes_gcm_decrypt_dev(int keybits, const uint8_t *key, const uint8_t *nonce,
                          const void *d_aad, size_t aad_len,
                          const void *d_in, size_t len, void *d_out,
                          int *d_status, void *stream);
+
+/* decrypt != 0: d_in = CT || tag, d_status (device int) receives 0 or 0x1A    */
+int uaes_ocb_dev(int keybits, const uint8_t *key, const uint8_t *nonce, int decrypt,
+                 const void *d_aad, size_t aad_len,
+                 const void *d_in, size_t len, void *d_out, int *d_status, void *stream);
 
 /* ---- sharded GCM (multi-GPU) ------------------------------------------------
  * One message, cut into 16-byte aligned ciphertext shards, one per GPU.  Each

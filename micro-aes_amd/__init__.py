@@ -37,6 +37,7 @@ EXPORTS = [
     "uaes_xts_encrypt", "uaes_xts_decrypt", "uaes_xts_sectors",
     "uaes_gcm_encrypt", "uaes_gcm_decrypt", "uaes_ghash",
     "uaes_cmac", "uaes_ccm_encrypt", "uaes_ccm_decrypt", "uaes_gcmsiv_encrypt", "uaes_gcmsiv_decrypt",
+    "uaes_ocb_encrypt", "uaes_ocb_decrypt", "uaes_ocb_dev",
     "uaes_cbc_encrypt", "uaes_cbc_decrypt", "uaes_cfb_encrypt", "uaes_cfb_decrypt", "uaes_ofb_xcrypt",
     "uaes_ecb_dev", "uaes_ctr_xcrypt_at_dev", "uaes_xts_sectors_dev",
     "uaes_gcm_encrypt_dev", "uaes_gcm_decrypt_dev", "uaes_gcm_partial_dev",
@@ -45,6 +46,7 @@ COMPAT_EXPORTS = [
     "AES_ECB_encrypt", "AES_ECB_decrypt", "AES_CTR_encrypt", "AES_CTR_decrypt",
     "AES_XTS_encrypt", "AES_XTS_decrypt", "AES_GCM_encrypt", "AES_GCM_decrypt",
     "AES_CCM_encrypt", "AES_CCM_decrypt", "AES_CMAC", "GCM_SIV_encrypt", "GCM_SIV_decrypt",
+    "AES_OCB_encrypt", "AES_OCB_decrypt",
     "AES_CBC_encrypt", "AES_CBC_decrypt", "AES_CFB_encrypt", "AES_CFB_decrypt", "AES_OFB_encrypt", "AES_OFB_decrypt",
 ]
 
@@ -103,8 +105,10 @@ def engine():
     L.uaes_cmac.argtypes = [i, vp, vp, sz, vp]
     for n in ("uaes_cbc_encrypt", "uaes_cbc_decrypt", "uaes_cfb_encrypt", "uaes_cfb_decrypt", "uaes_ofb_xcrypt"):
         getattr(L, n).argtypes = [i, vp, vp, vp, sz, vp]
-    for n in ("uaes_ccm_encrypt", "uaes_ccm_decrypt", "uaes_gcmsiv_encrypt", "uaes_gcmsiv_decrypt"):
+    for n in ("uaes_ccm_encrypt", "uaes_ccm_decrypt", "uaes_gcmsiv_encrypt", "uaes_gcmsiv_decrypt",
+              "uaes_ocb_encrypt", "uaes_ocb_decrypt"):
         getattr(L, n).argtypes = [i, vp, vp, vp, sz, vp, sz, vp]
+    L.uaes_ocb_dev.argtypes = [i, vp, vp, i, vp, sz, vp, sz, vp, vp, vp]
     L.uaes_ecb_dev.argtypes = [i, vp, i, vp, sz, vp, vp]
     L.uaes_ctr_xcrypt_at_dev.argtypes = [i, vp, vp, u64, vp, sz, vp, vp]
     L.uaes_xts_sectors_dev.argtypes = [i, vp, u64, sz, sz, vp, vp, i, vp]
@@ -300,6 +304,23 @@ def GCM_SIV_decrypt(key, nonce, aData, crtxt_and_tag, prefill=0):
     return rc, bytes(o)[:n]
 
 
+def AES_OCB_encrypt(key, nonce, aData, pntxt):
+    """micro_aes.c:1774 (RFC 7253, 12-byte nonce).  Returns ciphertext || 16-byte tag."""
+    o = _out(len(pntxt) + 16)
+    _check(engine().uaes_ocb_encrypt(_bits(key), _in(key), _in(nonce), _in(aData), len(aData),
+                                     _in(pntxt), len(pntxt), o), "AES_OCB_encrypt")
+    return bytes(o)[: len(pntxt) + 16]
+
+
+def AES_OCB_decrypt(key, nonce, aData, crtxt_and_tag, prefill=0):
+    """micro_aes.c:1797.  Returns (code, text); the text is written even on 0x1A."""
+    n = len(crtxt_and_tag) - 16
+    o = _out(n, prefill)
+    rc = _check(engine().uaes_ocb_decrypt(_bits(key), _in(key), _in(nonce), _in(aData), len(aData),
+                                          _in(crtxt_and_tag), n, o), "AES_OCB_decrypt")
+    return rc, bytes(o)[:n]
+
+
 def ghash(H, aData, crtxt):
     """gHash of micro_aes.c:1127 with an explicit subkey (test hook)."""
     o = _out(16)
@@ -356,6 +377,13 @@ def gcm_decrypt_dev(key, nonce, aad, src, nbytes, dst, status, stream=None):
     _check(engine().uaes_gcm_decrypt_dev(_bits(key), _in(key), _in(nonce), _ptr(aad),
                                          0 if aad is None else aad.numel(), _ptr(src), nbytes, _ptr(dst),
                                          _ptr(status), _stream(stream)), "uaes_gcm_decrypt_dev")
+
+
+def ocb_dev(key, nonce, aad, src, nbytes, dst, decrypt=False, status=None, stream=None):
+    """encrypt: dst holds nbytes + 16; decrypt: src holds nbytes + 16, status = int32 device tensor."""
+    _check(engine().uaes_ocb_dev(_bits(key), _in(key), _in(nonce), 1 if decrypt else 0, _ptr(aad),
+                                 0 if aad is None else aad.numel(), _ptr(src), nbytes, _ptr(dst),
+                                 _ptr(status), _stream(stream)), "uaes_ocb_dev")
 
 
 def gcm_partial_dev(key, nonce, aad, total_aad_len, ct_shard, shard_len, shard_offset, total_len, partial,

@@ -146,3 +146,18 @@ char GCM_SIV_decrypt(const uint8_t *key, const uint8_t *nonce,
     return soft("GCM_SIV_decrypt", uaes_gcmsiv_decrypt(KB, key, nonce, aData, aDataLen, crtxt, crtxtLen, pntxt),
                 M_DECRYPTION_ERROR);
 }
+
+void AES_OCB_encrypt(const uint8_t *key, const uint8_t *nonce,
+                     const void *aData, const size_t aDataLen,
+                     const void *pntxt, const size_t ptextLen, void *crtxt)
+{
+    must("AES_OCB_encrypt", uaes_ocb_encrypt(KB, key, nonce, aData, aDataLen, pntxt, ptextLen, crtxt));
+}
+
+char AES_OCB_decrypt(const uint8_t *key, const uint8_t *nonce,
+                     const void *aData, const size_t aDataLen,
+                     const void *crtxt, const size_t crtxtLen, void *pntxt)
+{
+    return soft("AES_OCB_decrypt", uaes_ocb_decrypt(KB, key, nonce, aData, aDataLen, crtxt, crtxtLen, pntxt),
+                M_DECRYPTION_ERROR);
+}

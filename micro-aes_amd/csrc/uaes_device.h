@@ -115,6 +115,15 @@ int uaesk_feedback(void *stream, const uaesk_tables *tb, int nr,
                    const uaesk_rk *ek, const uaesk_rk *dk, int mode, const uint8_t *iv16,
                    const void *in, size_t len, void *out);
 
+/* OCB (AES_OCB_encrypt/decrypt, micro_aes.c:1693-1811): 12-byte nonce (host), 16-byte
+ * tag at out+len (encrypt) / read at in+len (decrypt, *status = 0 / 0x1A; the text
+ * is written either way, as in the reference).  dk = equivalent-inverse keys.  */
+size_t uaesk_ocb_scratch_bytes(void);
+int uaesk_ocb(void *stream, const uaesk_tables *tb, int nr,
+              const uaesk_rk *ek, const uaesk_rk *dk, int decrypt, const uint8_t *nonce12,
+              const void *aad, size_t aad_len, const void *in, size_t len, void *out,
+              void *scratch, int *status);
+
 /* Device self-test of the primitives; writes a bitmask of failures.        */
 int uaesk_selftest(void *stream, const uaesk_tables *tb, const uaesk_rk *ek128,
                    const uaesk_rk *dk128, unsigned *d_result);

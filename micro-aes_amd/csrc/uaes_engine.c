@@ -1008,3 +1008,66 @@ int uaes_gcmsiv_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
     } while (0);
     LOCKED_END(c, rc);
 }
+
+/* ------------------------------------------------------------------------ */
+/* OCB (RFC 7253; AES_OCB_encrypt / AES_OCB_decrypt, micro_aes.c:1774-1811)     */
+/* ------------------------------------------------------------------------ */
+static int ocb_common(int keybits, const uint8_t *key, const uint8_t *nonce, int decrypt,
+                      const void *aData, size_t aDataLen, const void *in, size_t len, void *out)
+{
+    context *c;
+    keysched ks;
+    io_plan io;
+    const void *d_aad;
+    int rc, status = -1;
+    if ((rc = expand_key(&ks, key, keybits)) != 0) return rc;
+    if (!nonce || (!decrypt && !out) || (len && (!in || !out)) || (decrypt && !in))
+        return fail(UAES_E_ARG, "NULL pointer");
+    if ((rc = get_context(&c)) != 0) return rc;
+    LOCKED_BEGIN(c);
+    do {
+        if ((rc = gcm_scratch(c)) != 0) break;        /* >= uaesk_ocb_scratch_bytes() */
+        if ((rc = stage_aad(c, aData, aDataLen, &d_aad)) != 0) break;
+        if ((rc = plan_io(c, in, len + (decrypt ? 16 : 0), out, len + (decrypt ? 0 : 16), &io)) != 0) break;
+        int k = uaesk_ocb(NULL, &c->tb, ks.nr, &ks.ek, &ks.dk, decrypt, nonce, d_aad, aDataLen,
+                          io.din, len, io.dout, c->scratch, c->d_status);
+        if (k) { rc = fail(UAES_E_HIP, "ocb launch: %s", hipGetErrorString((hipError_t)k)); break; }
+        if (decrypt) {
+            hipError_t e = hipMemcpy(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) { rc = fail(UAES_E_HIP, "ocb run: %s", hipGetErrorString(e)); break; }
+        }
+        if ((rc = finish_io(&io, len + (decrypt ? 0 : 16))) != 0) break;   /* text stays on a bad tag */
+        if (decrypt && status != 0) rc = UAES_E_AUTHENTICATION;
+    } while (0);
+    LOCKED_END(c, rc);
+}
+
+int uaes_ocb_encrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
+                     const void *aData, size_t aDataLen,
+                     const void *pntxt, size_t ptextLen, void *crtxt)
+{
+    return ocb_common(keybits, key, nonce, 0, aData, aDataLen, pntxt, ptextLen, crtxt);
+}
+
+int uaes_ocb_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
+                     const void *aData, size_t aDataLen,
+                     const void *crtxt, size_t crtxtLen, void *pntxt)
+{
+    return ocb_common(keybits, key, nonce, 1, aData, aDataLen, crtxt, crtxtLen, pntxt);
+}
+
+int uaes_ocb_dev(int keybits, const uint8_t *key, const uint8_t *nonce, int decrypt,
+                 const void *d_aad, size_t aad_len,
+                 const void *d_in, size_t len, void *d_out, int *d_status, void *stream)
+{
+    context *c;
+    keysched ks;
+    int rc;
+    if ((rc = expand_key(&ks, key, keybits)) != 0) return rc;
+    if (decrypt && !d_status) return fail(UAES_E_ARG, "NULL d_status");
+    if ((rc = get_context(&c)) != 0) return rc;
+    if ((rc = gcm_scratch_locked(c)) != 0) return rc;
+    KCHK(uaesk_ocb(stream, &c->tb, ks.nr, &ks.ek, &ks.dk, decrypt, nonce, d_aad, aad_len, d_in, len, d_out,
+                   c->scratch, d_status));
+    return 0;
+}

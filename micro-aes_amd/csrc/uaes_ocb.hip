@@ -1,0 +1,413 @@
+/*
+ * uaes_ocb.hip -- OCB (RFC 7253), the remaining block-parallel AEAD of the
+ * reference.
+ *
+ *   k_ocb_setup  <- getSubkeys :593-604 (L_*, L_$, L_0 ...), the nonce part of
+ *                   OCB_cipher :1705-1719 (K_top, stretch, Offset_0)
+ *   k_ocb        <- the block loop of OCB_cipher :1721-1730 with getDelta :1662-1680
+ *   k_ocb_final  <- the partial block :1736-1741, the tag :1743-1744 and the
+ *                   PMAC of the associated data :1746-1760
+ *
+ * The reference walks the blocks one by one and recomputes Offset_i from scratch
+ * for every i (getDelta doubles L up to 64 times per block).  Here the offsets are
+ * never chained:  Offset_i = Offset_0 ^ XOR{ L_j : bit j of gray(i) },  gray(i) =
+ * i ^ (i >> 1).  For i = 256 c + l the low eight bits of gray(i) depend on the lane
+ * position l only (plus bit 0 of c, which toggles L_7), the rest on the chunk
+ * number c, so a lane holds four constant 16-byte masks and a wave carries one
+ * uniform mask per 256-block chunk that moves to the next chunk with two XORs
+ * (gray(c+1) ^ gray(c) = 1 << ntz(c+1)).  The checksum is XOR-reduced per lane,
+ * per wave, then with four 32-bit atomics per wave.
+ *
+ * Block i (1-based, as in the RFC) of the text sits at byte offset 16 (i - 1).
+ */
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include "uaes_aes.hip.h"
+#include "uaes_device.h"
+
+static inline hipStream_t S(void *s) { return (hipStream_t)s; }
+
+#define OCB_NL       64u                      /* table rows: 0 L_*, 1 L_$, 2+j L_j      */
+#define OCB_LDS_L    (128u * 1024u)           /* L table in LDS, after the cipher tables */
+#define OCB_LDS_ACC  (OCB_LDS_L + OCB_NL * 16u)
+#define OCB_LDS      (OCB_LDS_ACC + 16u)
+#define OCB_CHUNK    256u                     /* blocks per chunk: one wave x 4 per lane */
+#define OCB_RUN      16u                      /* consecutive chunks a wave takes at once */
+#define UAES_U       4                        /* blocks per lane per chunk               */
+/* scratch rows (uint4): [0..63] L table, [64] Offset_0, [65] checksum accumulator     */
+#define OCB_ROW_OFF0 64u
+#define OCB_ROW_SUM  65u
+
+struct B16 {
+    u32 w[4];
+};
+
+__device__ __forceinline__ B16 b16(uint4 v) { B16 b = { { v.x, v.y, v.z, v.w } }; return b; }
+__device__ __forceinline__ uint4 u4(const B16 &b) { return make_uint4(b.w[0], b.w[1], b.w[2], b.w[3]); }
+__device__ __forceinline__ void bx(B16 &a, const B16 &b)
+{
+    a.w[0] ^= b.w[0]; a.w[1] ^= b.w[1]; a.w[2] ^= b.w[2]; a.w[3] ^= b.w[3];
+}
+
+__device__ __forceinline__ B16 lds_row(u32 row)
+{
+    return b16(*(const uint4 *)(uaes_lds + OCB_LDS_L + 16u * row));
+}
+
+/* a wave-uniform block, moved to scalar registers */
+__device__ __forceinline__ B16 uniform(const B16 &b)
+{
+    B16 r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r.w[q] = (u32)__builtin_amdgcn_readfirstlane((int)b.w[q]);
+    return r;
+}
+
+/* doubleBblock (:434-443): the block as a 128-bit big-endian integer, << 1, carry -> ^0x87 */
+__device__ __forceinline__ B16 ocb_double(const B16 &b)
+{
+    u64 hi = ((u64)bswap32(b.w[0]) << 32) | bswap32(b.w[1]);
+    u64 lo = ((u64)bswap32(b.w[2]) << 32) | bswap32(b.w[3]);
+    const u64 carry = hi >> 63;
+    hi = (hi << 1) | (lo >> 63);
+    lo = (lo << 1) ^ (carry ? 0x87ull : 0ull);
+    B16 r;
+    r.w[0] = bswap32((u32)(hi >> 32)); r.w[1] = bswap32((u32)hi);
+    r.w[2] = bswap32((u32)(lo >> 32)); r.w[3] = bswap32((u32)lo);
+    return r;
+}
+
+template <int NR>
+__device__ __forceinline__ void ocb_enc1(B16 &b, const uaesk_rk &rk, const LaneConst &lc)
+{
+    u32 s[1][4] = { { b.w[0], b.w[1], b.w[2], b.w[3] } };
+    enc_blocks<NR, 1, 4>(s, rk, lc);
+    b.w[0] = s[0][0]; b.w[1] = s[0][1]; b.w[2] = s[0][2]; b.w[3] = s[0][3];
+}
+
+/* XOR of the L_j selected by the bits of g, j counted from `first` (LDS table) */
+__device__ __forceinline__ B16 ocb_gray_sum(u64 g, u32 first)
+{
+    B16 d = { { 0, 0, 0, 0 } };
+    while (g) {
+        const u32 j = (u32)__builtin_ctzll(g);
+        g &= g - 1;
+        bx(d, lds_row(2u + first + j));
+    }
+    return d;
+}
+
+/* Offset_i - Offset_0 for an arbitrary index (the tails; one lane) */
+__device__ __forceinline__ B16 ocb_delta(u64 i) { return ocb_gray_sum(i ^ (i >> 1), 0); }
+
+__device__ __forceinline__ void ocb_tables_to_lds(const uint4 *__restrict__ scr)
+{
+    if (threadIdx.x < OCB_NL) ((uint4 *)(uaes_lds + OCB_LDS_L))[threadIdx.x] = scr[threadIdx.x];
+    if (threadIdx.x == OCB_NL) *(uint4 *)(uaes_lds + OCB_LDS_ACC) = make_uint4(0, 0, 0, 0);
+}
+
+__device__ __forceinline__ void wave_xor_reduce(u32 (&v)[4])
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] ^= __shfl_xor(v[k], off, 64);
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* per-call setup: L table, Offset_0, cleared checksum                         */
+/* ------------------------------------------------------------------------ */
+template <int NR>
+__global__ __launch_bounds__(UAES_WG) void k_ocb_setup(uaesk_rk ek, uaesk_tables tb,
+                                                       uint4 nonce_block, u32 bottom,
+                                                       uint4 *__restrict__ scr)
+{
+    fill_enc_tables(tb.te0);
+    const LaneConst lc = make_lane_const();
+    if (threadIdx.x != 0) return;
+    B16 l = { { 0, 0, 0, 0 } };
+    ocb_enc1<NR>(l, ek, lc);                          /* L_* = Enc(0)                  */
+    for (u32 j = 0; j < OCB_NL; ++j) {                /* L_$, L_0, L_1, ... by doubling */
+        scr[j] = u4(l);
+        l = ocb_double(l);
+    }
+    B16 kt = b16(nonce_block);
+    ocb_enc1<NR>(kt, ek, lc);                         /* K_top                         */
+    const u64 hi = ((u64)bswap32(kt.w[0]) << 32) | bswap32(kt.w[1]);
+    const u64 lo = ((u64)bswap32(kt.w[2]) << 32) | bswap32(kt.w[3]);
+    const u64 ext = hi ^ ((hi << 8) | (lo >> 56));    /* Stretch = K_top || ext        */
+    const u64 ohi = bottom ? (hi << bottom) | (lo >> (64u - bottom)) : hi;
+    const u64 olo = bottom ? (lo << bottom) | (ext >> (64u - bottom)) : lo;
+    scr[OCB_ROW_OFF0] = make_uint4(bswap32((u32)(ohi >> 32)), bswap32((u32)ohi),
+                                   bswap32((u32)(olo >> 32)), bswap32((u32)olo));
+    scr[OCB_ROW_SUM] = make_uint4(0, 0, 0, 0);
+}
+
+/* ------------------------------------------------------------------------ */
+/* the block loop                                                              */
+/* ------------------------------------------------------------------------ */
+template <int NR, bool DEC>
+__global__ __launch_bounds__(UAES_WG) void k_ocb(uaesk_rk rk, uaesk_tables tb,
+                                                 uint4 *__restrict__ scr, u64 nblocks,
+                                                 const uint4 *__restrict__ in, uint4 *__restrict__ out)
+{
+    ocb_tables_to_lds(scr);
+    if (DEC) fill_dec_tables(tb.td0, tb.si4); else fill_enc_tables(tb.te0);
+    const LaneConst lc = make_lane_const();
+    const u32 lane = threadIdx.x & 63u;
+    const u64 wave = (u64)blockIdx.x * (UAES_WG / 64) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const u64 nwaves = (u64)gridDim.x * (UAES_WG / 64);
+    const u64 nchunks = (nblocks >> 8) + 1;           /* indices 0..nblocks, index 0 unused */
+
+    /* Offset_i - Offset_0 for i = 256 c + 64 u + lane splits into a lane part (bits 0..5 of
+     * gray(lane), bit 5 taken as lane bit 5), a part that depends on u only (L_5..L_7) and
+     * the chunk part; the last two are wave-uniform and live in scalar registers.        */
+    const B16 lm = ocb_gray_sum(lane ^ (lane >> 1), 0);
+    const B16 off0 = uniform(b16(scr[OCB_ROW_OFF0]));
+    const B16 l5 = uniform(lds_row(2u + 5u)), l6 = uniform(lds_row(2u + 6u)), l7 = uniform(lds_row(2u + 7u));
+
+    auto chunk_of = [&](u64 k) { return ((k / OCB_RUN) * nwaves + wave) * OCB_RUN + (k % OCB_RUN); };
+    /* live positions inside chunk c: [lo, hi] (index 0 does not exist, indices end at nblocks) */
+    auto span = [&](u64 c, u32 &lo, u32 &hi) {
+        lo = c == 0 ? 1u : 0u;
+        const u64 left = nblocks - c * OCB_CHUNK;
+        hi = left < OCB_CHUNK - 1 ? (u32)left : OCB_CHUNK - 1;
+    };
+
+    uint4 dn[UAES_U];
+    auto fetch = [&](u64 c) {
+        u32 lo, hi;
+        span(c, lo, hi);
+        const unsigned char *base = (const unsigned char *)in + c * (OCB_CHUNK * 16u) - 16;
+#pragma unroll
+        for (int u = 0; u < UAES_U; ++u) {
+            u32 j = 64u * u + lane;
+            j = j < lo ? lo : (j > hi ? hi : j);              /* clamped: no branch before the load */
+            dn[u] = *(const uint4 *)(base + 16u * j);
+        }
+    };
+
+    u32 sum[4] = { 0, 0, 0, 0 };
+    B16 cm = off0;                                    /* chunk mask */
+    u64 k = 0, c = chunk_of(0);
+    if (c < nchunks) fetch(c);
+    while (c < nchunks) {
+        if ((k % OCB_RUN) == 0) {                     /* first chunk of a run: c is even */
+            cm = off0;
+            bx(cm, ocb_gray_sum(c ^ (c >> 1), 8));
+            cm = uniform(cm);
+        }
+        uint4 d[UAES_U];
+#pragma unroll
+        for (int u = 0; u < UAES_U; ++u) d[u] = dn[u];
+        const u64 cn = chunk_of(k + 1);
+        if (cn < nchunks) fetch(cn);
+
+        B16 um[UAES_U];                               /* uniform masks: chunk ^ u part */
+#pragma unroll
+        for (int u = 0; u < UAES_U; ++u) {
+            um[u] = cm;
+            if (u & 1) bx(um[u], l5);
+            if ((u ^ (u >> 1)) & 1) bx(um[u], l6);
+            if (u >> 1) bx(um[u], l7);
+        }
+        u32 lo, hi;
+        span(c, lo, hi);
+        auto live = [&](int u) -> u32 {
+            const u32 j = 64u * u + lane;
+            return (j >= lo && j <= hi) ? 0xffffffffu : 0u;
+        };
+        u32 s[UAES_U][4];
+#pragma unroll
+        for (int u = 0; u < UAES_U; ++u) {
+            s[u][0] = xor3(d[u].x, um[u].w[0], lm.w[0]); s[u][1] = xor3(d[u].y, um[u].w[1], lm.w[1]);
+            s[u][2] = xor3(d[u].z, um[u].w[2], lm.w[2]); s[u][3] = xor3(d[u].w, um[u].w[3], lm.w[3]);
+            if (!DEC) {
+                const u32 lv = live(u);
+                sum[0] ^= d[u].x & lv; sum[1] ^= d[u].y & lv;
+                sum[2] ^= d[u].z & lv; sum[3] ^= d[u].w & lv;
+            }
+        }
+        if (DEC) {
+            dec_blocks<NR, UAES_U>(s, rk, lc);
+        } else {
+            enc_blocks_skewed<NR>(s[0], s[1], rk, lc);
+            enc_blocks_skewed<NR>(s[2], s[3], rk, lc);
+        }
+        unsigned char *obase = (unsigned char *)out + c * (OCB_CHUNK * 16u) - 16;
+#pragma unroll
+        for (int u = 0; u < UAES_U; ++u) {
+            const u32 lv = live(u);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s[u][q] = xor3(s[u][q], um[u].w[q], lm.w[q]);
+            if (DEC) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sum[q] ^= s[u][q] & lv;
+            }
+            if (lv) *(uint4 *)(obase + 16u * (64u * u + lane)) = make_uint4(s[u][0], s[u][1], s[u][2], s[u][3]);
+        }
+        /* next chunk of the run: bit 0 of c flips (L_7), gray(c) gains or loses bit ntz(c+1) */
+        ++k;
+        bx(cm, l7);
+        bx(cm, lds_row(2u + 8u + (u32)__builtin_ctzll(c + 1)));
+        cm = uniform(cm);
+        c = cn;
+    }
+    wave_xor_reduce(sum);
+    if (lane == 0 && (sum[0] | sum[1] | sum[2] | sum[3])) {
+        u32 *acc = (u32 *)(scr + OCB_ROW_SUM);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) atomicXor(acc + q, sum[q]);
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* tails, PMAC of the associated data, tag                                     */
+/* ------------------------------------------------------------------------ */
+__device__ __forceinline__ B16 ocb_load_bytes(const unsigned char *p, u32 n)
+{
+    B16 b = { { 0, 0, 0, 0 } };
+    if (n == 16 && (((uintptr_t)p) & 15u) == 0) return b16(*(const uint4 *)p);
+    for (u32 i = 0; i < n; ++i) b.w[i >> 2] |= (u32)p[i] << (8 * (i & 3));
+    return b;
+}
+
+template <int NR>
+__global__ __launch_bounds__(UAES_WG) void k_ocb_final(uaesk_rk ek, uaesk_tables tb,
+                                                       uint4 *__restrict__ scr, int decrypt,
+                                                       const unsigned char *__restrict__ aad, u64 aad_len,
+                                                       const unsigned char *in, unsigned char *out, u64 len,
+                                                       int *status)
+{
+    ocb_tables_to_lds(scr);
+    fill_enc_tables(tb.te0);
+    const LaneConst lc = make_lane_const();
+
+    /* HASH(K, A): Sum ^= Enc(A_i ^ Offset_i), Offset from zero (:1749-1754); all threads */
+    u32 h[4] = { 0, 0, 0, 0 };
+    const u64 na = aad_len >> 4;
+    for (u64 i = threadIdx.x + 1; i <= na; i += UAES_WG) {
+        B16 b = ocb_load_bytes(aad + 16 * (i - 1), 16);
+        bx(b, ocb_delta(i));
+        ocb_enc1<NR>(b, ek, lc);
+        h[0] ^= b.w[0]; h[1] ^= b.w[1]; h[2] ^= b.w[2]; h[3] ^= b.w[3];
+    }
+    if (threadIdx.x == 0 && (aad_len & 15u)) {        /* A_* || 1 || 0.., Offset_* = Offset_m ^ L_* (:1755-1760) */
+        const u32 r = (u32)(aad_len & 15u);
+        B16 b = ocb_load_bytes(aad + 16 * na, r);
+        b.w[r >> 2] ^= 0x80u << (8 * (r & 3));
+        bx(b, ocb_delta(na));
+        bx(b, lds_row(0));
+        ocb_enc1<NR>(b, ek, lc);
+        h[0] ^= b.w[0]; h[1] ^= b.w[1]; h[2] ^= b.w[2]; h[3] ^= b.w[3];
+    }
+    wave_xor_reduce(h);
+    if ((threadIdx.x & 63u) == 0) {
+        u32 *acc = (u32 *)(uaes_lds + OCB_LDS_ACC);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) atomicXor(acc + q, h[q]);
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+
+    const u64 n = len >> 4;
+    const u32 r = (u32)(len & 15u);
+    B16 d = b16(scr[OCB_ROW_OFF0]);
+    bx(d, ocb_delta(n));                              /* Offset_m */
+    B16 ck = b16(scr[OCB_ROW_SUM]);
+    if (r) {                                          /* :1736-1741 */
+        bx(d, lds_row(0));                            /* Offset_* = Offset_m ^ L_* */
+        B16 pad = d;
+        ocb_enc1<NR>(pad, ek, lc);
+        for (u32 i = 0; i < r; ++i) {
+            const u32 x = in[16 * n + i];
+            const u32 y = x ^ ((pad.w[i >> 2] >> (8 * (i & 3))) & 0xffu);
+            ck.w[i >> 2] ^= (decrypt ? y : x) << (8 * (i & 3));
+            out[16 * n + i] = (unsigned char)y;
+        }
+        ck.w[r >> 2] ^= 0x80u << (8 * (r & 3));
+    }
+    bx(ck, d);
+    bx(ck, lds_row(1));                               /* ^ L_$ */
+    ocb_enc1<NR>(ck, ek, lc);
+    bx(ck, b16(*(const uint4 *)(uaes_lds + OCB_LDS_ACC)));
+    if (!decrypt) {
+        for (u32 i = 0; i < 16; ++i) out[len + i] = (unsigned char)(ck.w[i >> 2] >> (8 * (i & 3)));
+    } else {
+        u32 diff = 0;
+        for (u32 i = 0; i < 16; ++i) diff |= (u32)in[len + i] ^ ((ck.w[i >> 2] >> (8 * (i & 3))) & 0xffu);
+        *status = diff ? 0x1A : 0;
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* launcher                                                                    */
+/* ------------------------------------------------------------------------ */
+static unsigned cu_count()
+{
+    static int cus = 0;
+    if (!cus) uaesk_device_info(&cus, nullptr);
+    return cus > 0 ? (unsigned)cus : 256u;
+}
+
+static hipError_t want_lds(const void *kern)
+{
+    return hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OCB_LDS);
+}
+
+template <int NR>
+static int launch_ocb(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek, const uaesk_rk *dk,
+                      int decrypt, uint4 nb, u32 bottom, const void *aad, size_t aad_len,
+                      const void *in, size_t len, void *out, void *scratch, int *status)
+{
+    uint4 *scr = (uint4 *)scratch;
+    hipError_t e = want_lds((const void *)k_ocb_setup<NR>);
+    if (e == hipSuccess) e = want_lds((const void *)k_ocb_final<NR>);
+    if (e == hipSuccess) e = want_lds(decrypt ? (const void *)k_ocb<NR, true> : (const void *)k_ocb<NR, false>);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((k_ocb_setup<NR>), dim3(1), dim3(UAES_WG), OCB_LDS, st, *ek, *tb, nb, bottom, scr);
+    const u64 nblocks = len >> 4;
+    if (nblocks) {
+        const u64 nchunks = (nblocks >> 8) + 1;
+        const u64 runs = (nchunks + OCB_RUN - 1) / OCB_RUN;
+        u64 grid = (runs + UAES_WG / 64 - 1) / (UAES_WG / 64);
+        if (grid > cu_count()) grid = cu_count();
+        if (decrypt)
+            hipLaunchKernelGGL((k_ocb<NR, true>), dim3((unsigned)grid), dim3(UAES_WG), OCB_LDS, st, *dk, *tb, scr,
+                               nblocks, (const uint4 *)in, (uint4 *)out);
+        else
+            hipLaunchKernelGGL((k_ocb<NR, false>), dim3((unsigned)grid), dim3(UAES_WG), OCB_LDS, st, *ek, *tb, scr,
+                               nblocks, (const uint4 *)in, (uint4 *)out);
+    }
+    hipLaunchKernelGGL((k_ocb_final<NR>), dim3(1), dim3(UAES_WG), OCB_LDS, st, *ek, *tb, scr, decrypt,
+                       (const unsigned char *)aad, (u64)aad_len, (const unsigned char *)in, (unsigned char *)out,
+                       (u64)len, status);
+    return (int)hipGetLastError();
+}
+
+extern "C" size_t uaesk_ocb_scratch_bytes(void) { return 16u * (OCB_ROW_SUM + 1u); }
+
+/* nonce12 is a host pointer; everything else device memory (in/out 16-byte aligned).
+ * encrypt: tag written at out+len.  decrypt: tag read at in+len, *status = 0 / 0x1A,
+ * the text is written either way (as in the reference, :1804-1809).             */
+extern "C" int uaesk_ocb(void *stream, const uaesk_tables *tb, int nr,
+                         const uaesk_rk *ek, const uaesk_rk *dk, int decrypt, const uint8_t *nonce12,
+                         const void *aad, size_t aad_len, const void *in, size_t len, void *out,
+                         void *scratch, int *status)
+{
+    uint8_t kt[16];
+    memset(kt, 0, sizeof kt);
+    memcpy(kt + 4, nonce12, 12);
+    kt[3] |= 1;                                       /* :1710 (tag length 128 encodes as 0 in the top 7 bits) */
+    const u32 bottom = kt[15] & 63u;
+    kt[15] &= 0xC0;
+    uint4 nb;
+    memcpy(&nb, kt, 16);
+    switch (nr) {
+    case 10: return launch_ocb<10>(S(stream), tb, ek, dk, decrypt, nb, bottom, aad, aad_len, in, len, out, scratch, status);
+    case 12: return launch_ocb<12>(S(stream), tb, ek, dk, decrypt, nb, bottom, aad, aad_len, in, len, out, scratch, status);
+    case 14: return launch_ocb<14>(S(stream), tb, ek, dk, decrypt, nb, bottom, aad, aad_len, in, len, out, scratch, status);
+    default: return (int)hipErrorInvalidValue;
+    }
+}

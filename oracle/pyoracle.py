@@ -62,6 +62,8 @@ class Oracle:
         L.orc_ccm_decrypt.argtypes = [i, vp, vp, vp, sz, vp, sz, vp]; L.orc_ccm_decrypt.restype = C.c_char
         L.orc_gcmsiv_encrypt.argtypes = [i, vp, vp, vp, sz, vp, sz, vp]; L.orc_gcmsiv_encrypt.restype = None
         L.orc_gcmsiv_decrypt.argtypes = [i, vp, vp, vp, sz, vp, sz, vp]; L.orc_gcmsiv_decrypt.restype = C.c_char
+        L.orc_ocb_encrypt.argtypes = [i, vp, vp, vp, sz, vp, sz, vp]; L.orc_ocb_encrypt.restype = None
+        L.orc_ocb_decrypt.argtypes = [i, vp, vp, vp, sz, vp, sz, vp]; L.orc_ocb_decrypt.restype = C.c_char
         L.orc_gf128_mul.argtypes = [vp, vp]; L.orc_gf128_mul.restype = None
         L.orc_ghash.argtypes = [vp, vp, sz, vp, sz, vp]; L.orc_ghash.restype = None
         L.orc_fill_splitmix.argtypes = [u64, u64, sz, vp]; L.orc_fill_splitmix.restype = None
@@ -172,6 +174,19 @@ class Oracle:
                                        _buf(ct_and_tag), n, o)
         return ord(rc), bytes(o)[:n]
 
+    def ocb_encrypt(self, key, nonce, aad, pt):
+        o = _out(len(pt) + 16)
+        self.L.orc_ocb_encrypt(len(key) * 8, _buf(key), _buf(nonce), _buf(aad), len(aad),
+                               _buf(pt), len(pt), o)
+        return bytes(o)[: len(pt) + 16]
+
+    def ocb_decrypt(self, key, nonce, aad, ct_and_tag, prefill=0xCC):
+        n = len(ct_and_tag) - 16
+        o = (C.c_uint8 * max(n, 1))(*([prefill] * max(n, 1)))
+        rc = self.L.orc_ocb_decrypt(len(key) * 8, _buf(key), _buf(nonce), _buf(aad), len(aad),
+                                    _buf(ct_and_tag), n, o)
+        return ord(rc), bytes(o)[:n]
+
     def gf128_mul(self, x, y):
         yy = _buf(y)
         self.L.orc_gf128_mul(_buf(x), yy)
@@ -222,12 +237,27 @@ class Reference:
         L.AES_CCM_encrypt.argtypes = [vp, vp, vp, sz, vp, sz, vp]; L.AES_CCM_encrypt.restype = None
         L.AES_CCM_decrypt.argtypes = [vp, vp, vp, sz, vp, sz, vp]; L.AES_CCM_decrypt.restype = C.c_char
         L.AES_CMAC.argtypes = [vp, vp, sz, vp]; L.AES_CMAC.restype = None
+        L.AES_OCB_encrypt.argtypes = [vp, vp, vp, sz, vp, sz, vp]; L.AES_OCB_encrypt.restype = None
+        L.AES_OCB_decrypt.argtypes = [vp, vp, vp, sz, vp, sz, vp]; L.AES_OCB_decrypt.restype = C.c_char
         L.GCM_SIV_encrypt.argtypes = [vp, vp, vp, sz, vp, sz, vp]; L.GCM_SIV_encrypt.restype = None
         L.GCM_SIV_decrypt.argtypes = [vp, vp, vp, sz, vp, sz, vp]; L.GCM_SIV_decrypt.restype = C.c_char
         for f in (L.AES_CBC_encrypt, L.AES_CBC_decrypt):
             f.argtypes = [vp, vp, vp, sz, vp]; f.restype = C.c_char
         for f in (L.AES_CFB_encrypt, L.AES_CFB_decrypt, L.AES_OFB_encrypt, L.AES_OFB_decrypt):
             f.argtypes = [vp, vp, vp, sz, vp]; f.restype = None
+
+    def ocb_encrypt(self, key, nonce, aad, pt):
+        self._chk(key)
+        o = _out(len(pt) + 16)
+        self.L.AES_OCB_encrypt(_buf(key), _buf(nonce), _buf(aad), len(aad), _buf(pt), len(pt), o)
+        return bytes(o)[: len(pt) + 16]
+
+    def ocb_decrypt(self, key, nonce, aad, ct_and_tag, prefill=0xCC):
+        self._chk(key)
+        n = len(ct_and_tag) - 16
+        o = (C.c_uint8 * max(n, 1))(*([prefill] * max(n, 1)))
+        rc = self.L.AES_OCB_decrypt(_buf(key), _buf(nonce), _buf(aad), len(aad), _buf(ct_and_tag), n, o)
+        return ord(rc), bytes(o)[:n]
 
     def gcmsiv_encrypt(self, key, nonce, aad, pt):
         self._chk(key)

@@ -760,6 +760,133 @@ char orc_gcmsiv_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
 }
 
 /* ------------------------------------------------------------------------ */
+/* OCB -- RFC 7253 as the reference fixes it (12-byte nonce, 16-byte tag):      */
+/*        getDelta :1662-1680, OCB_cipher :1693-1762, API :1774-1811,          */
+/*        doubleBblock :434-443                                               */
+/* ------------------------------------------------------------------------ */
+static void be_double(uint8_t b[16])
+{
+    int i, carry = b[0] >> 7;
+    for (i = 0; i < 15; ++i) b[i] = (uint8_t)((b[i] << 1) | (b[i + 1] >> 7));
+    b[15] = (uint8_t)((b[15] << 1) ^ (carry ? 0x87 : 0));
+}
+
+typedef struct {
+    orc_key k;
+    uint8_t Lstar[16], Ldollar[16], L[64][16];
+} ocb_ctx;
+
+static void ocb_setup(ocb_ctx *o, int keybits, const uint8_t *key)
+{
+    int j;
+    orc_setkey(&o->k, key, keybits);
+    memset(o->Lstar, 0, 16);
+    orc_encrypt_block(&o->k, o->Lstar, o->Lstar);         /* L_* = Enc(0)          */
+    memcpy(o->Ldollar, o->Lstar, 16); be_double(o->Ldollar);
+    memcpy(o->L[0], o->Ldollar, 16);  be_double(o->L[0]);
+    for (j = 1; j < 64; ++j) { memcpy(o->L[j], o->L[j - 1], 16); be_double(o->L[j]); }
+}
+
+static int ntz64(uint64_t i) { int n = 0; while (!(i & 1)) { i >>= 1; ++n; } return n; }
+
+/* Offset_0 from the nonce: Ktop = Enc(0^7 1-padded nonce with the low 6 bits cleared),
+ * Stretch = Ktop || (Ktop[0..7] ^ Ktop[1..8]), Offset_0 = Stretch[bottom .. bottom+127] */
+static void ocb_offset0(const ocb_ctx *o, const uint8_t *nonce, uint8_t off[16])
+{
+    uint8_t kt[24];
+    int i, bottom = nonce[11] & 63, sh = bottom & 7, by = bottom >> 3;
+    memset(kt, 0, sizeof kt);
+    memcpy(kt + 4, nonce, 12);
+    kt[3] |= 1;                               /* taglen 128 mod 128 = 0 in the top 7 bits */
+    kt[15] &= 0xC0;
+    orc_encrypt_block(&o->k, kt, kt);
+    for (i = 0; i < 8; ++i) kt[16 + i] = (uint8_t)(kt[i] ^ kt[i + 1]);
+    for (i = 0; i < 16; ++i)
+        off[i] = (uint8_t)(((kt[by + i] << 8 | kt[by + i + 1]) >> (8 - sh)) & 0xff);
+}
+
+static void ocb_hash(const ocb_ctx *o, const uint8_t *a, size_t alen, uint8_t sum[16])
+{
+    uint8_t off[16] = { 0 }, t[16];
+    uint64_t i, m = alen / 16;
+    size_t r = alen % 16;
+    memset(sum, 0, 16);
+    for (i = 1; i <= m; ++i, a += 16) {
+        xor16(off, o->L[ntz64(i)]);
+        memcpy(t, a, 16); xor16(t, off);
+        orc_encrypt_block(&o->k, t, t);
+        xor16(sum, t);
+    }
+    if (r) {
+        xor16(off, o->Lstar);
+        memset(t, 0, 16); memcpy(t, a, r); t[r] = 0x80;
+        xor16(t, off);
+        orc_encrypt_block(&o->k, t, t);
+        xor16(sum, t);
+    }
+}
+
+static void ocb_crypt(const ocb_ctx *o, const uint8_t *nonce, int decrypt,
+                      const uint8_t *aad, size_t alen, const uint8_t *in, size_t len,
+                      uint8_t *out, uint8_t tag[16])
+{
+    uint8_t off[16], sum[16] = { 0 }, t[16], h[16];
+    uint64_t i, m = len / 16;
+    size_t r = len % 16, k;
+    ocb_offset0(o, nonce, off);
+    for (i = 1; i <= m; ++i, in += 16, out += 16) {
+        xor16(off, o->L[ntz64(i)]);
+        memcpy(t, in, 16);
+        if (!decrypt) xor16(sum, t);
+        xor16(t, off);
+        if (decrypt) orc_decrypt_block(&o->k, t, t); else orc_encrypt_block(&o->k, t, t);
+        xor16(t, off);
+        if (decrypt) xor16(sum, t);
+        memcpy(out, t, 16);
+    }
+    if (r) {
+        xor16(off, o->Lstar);
+        orc_encrypt_block(&o->k, off, t);                  /* Pad = Enc(Offset_*)   */
+        for (k = 0; k < r; ++k) {
+            const uint8_t x = in[k], y = (uint8_t)(x ^ t[k]);
+            sum[k] ^= decrypt ? y : x;
+            out[k] = y;
+        }
+        sum[r] ^= 0x80;
+    }
+    xor16(sum, off);
+    xor16(sum, o->Ldollar);
+    orc_encrypt_block(&o->k, sum, tag);
+    ocb_hash(o, aad, alen, h);
+    xor16(tag, h);
+}
+
+void orc_ocb_encrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
+                     const void *aad, size_t aad_len,
+                     const void *pt, size_t len, void *ct_and_tag)
+{
+    ocb_ctx o;
+    uint8_t tag[16];
+    ocb_setup(&o, keybits, key);
+    ocb_crypt(&o, nonce, 0, (const uint8_t *)aad, aad_len, (const uint8_t *)pt, len, (uint8_t *)ct_and_tag, tag);
+    memcpy((uint8_t *)ct_and_tag + len, tag, 16);
+}
+
+/* like the reference, the text is decrypted before the tag is known to be good and stays
+ * in pt on a mismatch (SABOTAGE is a no-op, :382)                                      */
+char orc_ocb_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
+                     const void *aad, size_t aad_len,
+                     const void *ct_and_tag, size_t len, void *pt)
+{
+    ocb_ctx o;
+    uint8_t tag[16], given[16];
+    memcpy(given, (const uint8_t *)ct_and_tag + len, 16);
+    ocb_setup(&o, keybits, key);
+    ocb_crypt(&o, nonce, 1, (const uint8_t *)aad, aad_len, (const uint8_t *)ct_and_tag, len, (uint8_t *)pt, tag);
+    return memcmp(tag, given, 16) ? ORC_E_AUTH : ORC_OK;
+}
+
+/* ------------------------------------------------------------------------ */
 /* Synthetic input of SURVEY.md section 8d                                    */
 /* ------------------------------------------------------------------------ */
 void orc_fill_splitmix(uint64_t seed, uint64_t word0, size_t nwords, void *dst)

@@ -121,6 +121,14 @@ char orc_gcmsiv_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
                         const void *aad, size_t aad_len,
                         const void *ct_and_tag, size_t len, void *pt);
 
+/* micro_aes.c:1774-1811 AES_OCB_encrypt/decrypt (RFC 7253); 12-byte nonce, 16-byte tag */
+void orc_ocb_encrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
+                     const void *aad, size_t aad_len,
+                     const void *pt, size_t len, void *ct_and_tag);
+char orc_ocb_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
+                     const void *aad, size_t aad_len,
+                     const void *ct_and_tag, size_t len, void *pt);
+
 /* SURVEY.md section 8d synthetic input: 64-bit LE word w of the stream is
  * splitmix64(seed + (w+1)*0x9E3779B97F4A7C15); fills [word0, word0+nwords) */
 void orc_fill_splitmix(uint64_t seed, uint64_t word0, size_t nwords, void *dst);

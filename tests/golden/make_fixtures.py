@@ -14,7 +14,8 @@ source text):
   repo carries 3 x ~140 KB instead of 3 x ~3 MB.  Format unchanged.
 * ``XTSGenAES{128,256}.rsp``, ``CMACGenAES{128,192,256}.rsp``, ``VNT{128,192,256}.rsp``
   -- NIST CAVP XTS / CMAC / CCM files, unmodified; ``SIV_GCM_ACVP.tv`` -- the 102 ACVP
-  AES-GCM-SIV vectors the reference's harness holds, unmodified.
+  AES-GCM-SIV vectors the reference's harness holds, unmodified; ``OCB_AES128.tv`` -- its
+  OpenSSL OCB vectors, unmodified.
 * ``main_kats.json`` -- the hot-path known answers of the reference's main.c
   (main.c:16-34,49-50,58-60), re-verified here against the compiled reference.
 * ``ref_vectors.json`` -- outputs of the COMPILED REFERENCE (oracle/_ref) on
@@ -106,6 +107,9 @@ MAIN_KATS = {
     "gcmsiv128": "2f1488496ada3f709760420ac72e5acfa977f6add4c55ac685f1b9dff8f381e0"
                  "2a64bbdd64cdd778525462949bb0b141db908c5cfa3657503666f879ac879fcb"
                  "f25c15d496a1e6f7f8",
+    "ocb128": "fc254896eb785b05dd87f240722dd93561f5a0ef6aff2eb65953da0b26257ed0"
+              "d69cb496e9a0cb1bf646151aa07e629a28d99f0ffd7ea7535c39f440df33c988"
+              "c55cbcc8ac086ffa23",
     "cmac128": "b887df1fd8c239c3e8a64d9822e21128",
     "ccm128": "d2575123438338d70b2955537fdfcf41729870884e85af15f0a74975a72b337d"
               "04d426de87594b9abe3e6dcf07f21c99db3999f81299d302ad1e5ba683e9039a"
@@ -150,6 +154,15 @@ def main_kats():
     add("main.c:160 OFB", "ofb", 128, key[:16], {"iv": iv.hex()}, MAIN_KATS["ofb128"])
     assert r128.gcmsiv_encrypt(key[:16], iv[:12], aad, pt).hex() == MAIN_KATS["gcmsiv128"]
     add("main.c:219 GCM-SIV", "gcmsiv", 128, key[:16], {"nonce": iv[:12].hex(), "aad": aad.hex()}, MAIN_KATS["gcmsiv128"])
+    assert r128.ocb_encrypt(key[:16], iv[:12], aad, pt).hex() == MAIN_KATS["ocb128"]
+    add("main.c:205 OCB", "ocb", 128, key[:16], {"nonce": iv[:12].hex(), "aad": aad.hex()}, MAIN_KATS["ocb128"])
+    # the RFC 7253 vector of main.c:262-273 (own plaintext)
+    o_k, o_n = bytes.fromhex("000102030405060708090A0B0C0D0E0F"), bytes.fromhex("BBAA99887766554433221107")
+    o_a = o_p = bytes.fromhex("000102030405060708090A0B0C0D0E0F1011121314151617")
+    o_c = "1ca2207308c87c010756104d8840ce1952f09673a448a122c92c62241051f57356d7f3c90bb0e07f"
+    assert r128.ocb_encrypt(o_k, o_n, o_a, o_p).hex() == o_c
+    kats.append(dict(name="main.c:264 RFC-7253", mode="ocb", keybits=128, key=o_k.hex(), pt=o_p.hex(),
+                     nonce=o_n.hex(), aad=o_a.hex(), expect=o_c))
     # the two RFC 8452 vectors of main.c:275-297 (own plaintexts)
     for name, k, n, a, p_, c in (
             ("main.c:276 RFC-8452 #1", "ee8e1ed9ff2540ae8f2ba9f50bc2f27c", "752abad3e0afb5f434dc4310", "6578616d706c65",
@@ -222,6 +235,11 @@ def ref_vectors(orc):
             assert ref.cfb(key, iv16, ct, False) == data
             vecs.append(dict(base, mode="cfb", key=key.hex(), iv=iv16.hex(), out=enc_out(ct)))
             vecs.append(dict(base, mode="ofb", key=key.hex(), iv=iv16.hex(), out=enc_out(ref.ofb(key, iv16, data))))
+            # OCB
+            nonce, aad = rng.randbytes(12), rng.randbytes(rng.choice([0, 1, 15, 16, 17, 100, 4096 + 5]))
+            ct = ref.ocb_encrypt(key, nonce, aad, data)
+            assert ref.ocb_decrypt(key, nonce, aad, ct) == (0, data)
+            vecs.append(dict(base, mode="ocb", key=key.hex(), nonce=nonce.hex(), aad=aad.hex(), out=enc_out(ct)))
             # GCM-SIV (bit-serial POLYVAL in the reference: cap the size)
             if n <= 16384:
                 nonce, aad = rng.randbytes(12), rng.randbytes(rng.choice([0, 1, 15, 16, 17, 100]))
@@ -318,7 +336,7 @@ def main():
                    os.path.join(HERE, "GcmEncryptExtIV%d.rsp" % bits))
     plain = ["XTSGenAES128.rsp", "XTSGenAES256.rsp"]
     plain += ["CMACGenAES%d.rsp" % b for b in (128, 192, 256)] + ["VNT%d.rsp" % b for b in (128, 192, 256)]
-    plain += ["SIV_GCM_ACVP.tv"]
+    plain += ["SIV_GCM_ACVP.tv", "OCB_AES128.tv"]
     for name in plain:
         with open(os.path.join(REF_TV, name)) as f, open(os.path.join(HERE, name), "w") as g:
             g.write(f.read())

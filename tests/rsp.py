@@ -131,3 +131,27 @@ def gcmsiv_cases(keybits):
                         cases.append(cur)
                     cur = {}
     return cases
+
+
+def ocb_cases(keybits):
+    """OCB_AES128.tv (OpenSSL evp format), filter of testvectors/aes_testvectors_OCB.h:86-88: key of
+    AES_KEYLENGTH bytes, 12-byte nonce, 16-byte tag (the last Tag line of a stanza wins)"""
+    path = os.path.join(GOLDEN, "OCB_AES128.tv")
+    cases, cur = [], {}
+
+    def flush():
+        if {"Key", "IV", "Tag", "Plaintext", "Ciphertext"} <= set(cur) and "Result" not in cur:
+            if len(cur["Key"]) * 8 == keybits and len(cur["IV"]) == 12 and len(cur["Tag"]) == 16:
+                cases.append(dict(key=cur["Key"], iv=cur["IV"], aad=cur.get("AAD", b""), pt=cur["Plaintext"],
+                                  ct=cur["Ciphertext"] + cur["Tag"]))
+    with open(path) as f:
+        for ln in f:
+            ln = ln.strip()
+            if ln.startswith("Cipher ="):
+                flush()
+                cur = {}
+            elif "=" in ln and not ln.startswith("#"):
+                k, v = [t.strip() for t in ln.split("=", 1)]
+                cur[k] = v if k in ("Result", "Operation") else bytes.fromhex(v)
+    flush()
+    return cases

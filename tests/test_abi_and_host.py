@@ -42,7 +42,7 @@ def test_compat_header_compiles_as_c89_and_matches_reference_constants(tmp_path)
     src.write_text('#include "micro_aes.h"\n#include <stdio.h>\n'
                    'int main(void){printf("%d %d %d %d %d %d %d %d %d\\n", AES_KEYLENGTH, GCM_NONCE_LEN, GCM_TAG_LEN,'
                    'CTR_IV_LENGTH, CTR_START_VALUE, (int)M_DATALENGTH_ERROR, M_AUTHENTICATION_ERROR,'
-                   'M_DECRYPTION_ERROR, M_ENCRYPTION_ERROR);return ECB&&CTR&&XTS&&GCM&&CMAC&&CCM&&CBC&&CTS&&CFB&&OFB&&GCM_SIV&&!EAX&&!KWA?0:1;}\n')
+                   'M_DECRYPTION_ERROR, M_ENCRYPTION_ERROR);return ECB&&CTR&&XTS&&GCM&&CMAC&&CCM&&CBC&&CTS&&CFB&&OFB&&GCM_SIV&&OCB&&!EAX&&!KWA?0:1;}\n')
     for bits, kl in ((128, 16), (192, 24), (256, 32)):
         exe = tmp_path / ("t%d" % bits)
         subprocess.run(["gcc", "-std=c89", "-pedantic", "-Wall", "-Werror", "-DAES___=%d" % bits,

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = os.path.join(ROOT, "oracle", "_ref")
-EXPECT = {128: {"CMAC": 96, "GCM": 375, "CCM": 10, "GCM-SIV": 102, "XTS": 800}, 192: {"CMAC": 144, "GCM": 375, "CCM": 10},
+EXPECT = {128: {"CMAC": 96, "GCM": 375, "CCM": 10, "OCB": 16, "GCM-SIV": 102, "XTS": 800}, 192: {"CMAC": 144, "GCM": 375, "CCM": 10},
           256: {"CMAC": 96, "GCM": 375, "CCM": 10, "XTS": 600}}
 
 
@@ -41,6 +41,7 @@ def test_reference_main_c_runs_on_the_hip_library(bits):
     assert r.returncode == 0 and "FAILED" not in r.stdout, r.stdout + r.stderr
     passed = re.findall(r"AES-%d (\w+) \w+: PASSED!" % bits, r.stdout)
     want = {128: ["ECB", "ECB", "CBC", "CBC", "CFB", "CFB", "OFB", "OFB", "CTR", "CTR", "XTS", "XTS", "plaintext",
-                  "GCM", "GCM", "CCM", "CCM", "GCMSIV", "GCMSIV", "GCMSIV", "GCMSIV", "GCMSIV", "GCMSIV"],
+                  "GCM", "GCM", "CCM", "CCM", "OCB", "OCB", "GCMSIV", "GCMSIV",
+                  "OCB", "OCB", "GCMSIV", "GCMSIV", "GCMSIV", "GCMSIV"],
             192: [], 256: ["XTS", "XTS", "GCM", "GCM"]}[bits]
     assert passed == want, r.stdout

@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 import micro_aes_amd as uaes
-from tests.rsp import ccm_cases, cmac_cases, gcm_cases, gcmsiv_cases, xts_cases
+from tests.rsp import ccm_cases, cmac_cases, gcm_cases, gcmsiv_cases, ocb_cases, xts_cases
 
 pytestmark = pytest.mark.gpu
 
@@ -142,6 +142,33 @@ def test_gcmsiv_vs_oracle(orc, bits):
         assert rc == 0x1A
 
 
+def test_ocb_openssl_vectors():
+    cases = ocb_cases(128)
+    assert len(cases) == 16
+    for c in cases:
+        assert uaes.AES_OCB_encrypt(c["key"], c["iv"], c["aad"], c["pt"]) == c["ct"]
+        assert uaes.AES_OCB_decrypt(c["key"], c["iv"], c["aad"], c["ct"]) == (0, c["pt"])
+
+
+@pytest.mark.parametrize("bits", [128, 192, 256])
+def test_ocb_vs_oracle(orc, bits):
+    """chunk (256-block) and run (16-chunk) edges of the Gray-code offsets, ragged tails, long AAD"""
+    rnd = random.Random(bits + 7)
+    sizes = [0, 1, 15, 16, 17, 255 * 16, 256 * 16, 256 * 16 + 5, 4095 * 16, 4096 * 16, 4097 * 16 + 3,
+             (1 << 20) + 16, (3 << 20) + 7, (16 << 20) - 16]
+    for n in sizes:
+        key, nonce = rnd.randbytes(bits // 8), rnd.randbytes(11) + bytes([rnd.randrange(256)])
+        aad = rnd.randbytes(rnd.choice([0, 1, 16, 20, 4097, 70000]))
+        data = orc.splitmix(n + 9, n)
+        ct = uaes.AES_OCB_encrypt(key, nonce, aad, data)
+        assert ct == orc.ocb_encrypt(key, nonce, aad, data), n
+        assert uaes.AES_OCB_decrypt(key, nonce, aad, ct) == (0, data), n
+        bad = bytearray(ct)
+        bad[n // 2 if n else -1] ^= 0x10
+        rc, txt = uaes.AES_OCB_decrypt(key, nonce, aad, bytes(bad))
+        assert (rc, txt) == orc.ocb_decrypt(key, nonce, aad, bytes(bad)) and rc == 0x1A
+
+
 def test_main_c_kats(golden_dir):
     for k in load(golden_dir, "main_kats.json"):
         key, pt, exp = bytes.fromhex(k["key"]), bytes.fromhex(k["pt"]), bytes.fromhex(k["expect"])
@@ -166,6 +193,10 @@ def test_main_c_kats(golden_dir):
             n, a = bytes.fromhex(k["nonce"]), bytes.fromhex(k["aad"])
             assert uaes.AES_CCM_encrypt(key, n, a, pt) == exp
             assert uaes.AES_CCM_decrypt(key, n, a, exp) == (0, pt)
+        elif k["mode"] == "ocb":
+            n, a = bytes.fromhex(k["nonce"]), bytes.fromhex(k["aad"])
+            assert uaes.AES_OCB_encrypt(key, n, a, pt) == exp
+            assert uaes.AES_OCB_decrypt(key, n, a, exp) == (0, pt)
         elif k["mode"] == "gcmsiv":
             n, a = bytes.fromhex(k["nonce"]), bytes.fromhex(k["aad"])
             assert uaes.GCM_SIV_encrypt(key, n, a, pt) == exp
@@ -215,6 +246,11 @@ def test_reference_generated_vectors(orc, golden_dir):
             ct = uaes.AES_CCM_encrypt(key, nonce, aad, data)
             check_out(ct, v["out"])
             assert uaes.AES_CCM_decrypt(key, nonce, aad, ct) == (0, data)
+        elif v["mode"] == "ocb":
+            nonce, aad = bytes.fromhex(v["nonce"]), bytes.fromhex(v["aad"])
+            ct = uaes.AES_OCB_encrypt(key, nonce, aad, data)
+            check_out(ct, v["out"])
+            assert uaes.AES_OCB_decrypt(key, nonce, aad, ct) == (0, data)
         elif v["mode"] == "gcmsiv":
             nonce, aad = bytes.fromhex(v["nonce"]), bytes.fromhex(v["aad"])
             ct = uaes.GCM_SIV_encrypt(key, nonce, aad, data)

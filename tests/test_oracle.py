@@ -11,7 +11,7 @@ import random
 import pytest
 
 from oracle.pyoracle import Reference
-from tests.rsp import ccm_cases, cmac_cases, gcm_cases, gcmsiv_cases, xts_cases
+from tests.rsp import ccm_cases, cmac_cases, gcm_cases, gcmsiv_cases, ocb_cases, xts_cases
 
 EXPECTED_COUNTS = {("gcm", 128): 375, ("gcm", 192): 375, ("gcm", 256): 375,
                    ("xts", 128): 800, ("xts", 256): 600,
@@ -90,6 +90,14 @@ def test_gcmsiv_acvp(orc):
         assert orc.gcmsiv_decrypt(c["key"], c["iv"], c["aad"], c["ct"]) == (0, c["pt"])
 
 
+def test_ocb_openssl_vectors(orc):
+    cases = ocb_cases(128)
+    assert len(cases) == 16 and not ocb_cases(256)
+    for c in cases:
+        assert orc.ocb_encrypt(c["key"], c["iv"], c["aad"], c["pt"]) == c["ct"]
+        assert orc.ocb_decrypt(c["key"], c["iv"], c["aad"], c["ct"]) == (0, c["pt"])
+
+
 def test_main_c_kats(orc, golden_dir):
     for k in load(golden_dir, "main_kats.json"):
         key, pt, exp = bytes.fromhex(k["key"]), bytes.fromhex(k["pt"]), bytes.fromhex(k["expect"])
@@ -114,6 +122,10 @@ def test_main_c_kats(orc, golden_dir):
             n, a = bytes.fromhex(k["nonce"]), bytes.fromhex(k["aad"])
             assert orc.ccm_encrypt(key, n, a, pt) == exp
             assert orc.ccm_decrypt(key, n, a, exp) == (0, pt)
+        elif k["mode"] == "ocb":
+            n, a = bytes.fromhex(k["nonce"]), bytes.fromhex(k["aad"])
+            assert orc.ocb_encrypt(key, n, a, pt) == exp
+            assert orc.ocb_decrypt(key, n, a, exp) == (0, pt)
         elif k["mode"] == "gcmsiv":
             n, a = bytes.fromhex(k["nonce"]), bytes.fromhex(k["aad"])
             assert orc.gcmsiv_encrypt(key, n, a, pt) == exp
@@ -161,6 +173,10 @@ def test_reference_generated_vectors(orc, golden_dir):
             ct = orc.ccm_encrypt(key, bytes.fromhex(v["nonce"]), bytes.fromhex(v["aad"]), data)
             check_out(ct, v["out"])
             assert orc.ccm_decrypt(key, bytes.fromhex(v["nonce"]), bytes.fromhex(v["aad"]), ct) == (0, data)
+        elif v["mode"] == "ocb":
+            ct = orc.ocb_encrypt(key, bytes.fromhex(v["nonce"]), bytes.fromhex(v["aad"]), data)
+            check_out(ct, v["out"])
+            assert orc.ocb_decrypt(key, bytes.fromhex(v["nonce"]), bytes.fromhex(v["aad"]), ct) == (0, data)
         elif v["mode"] == "gcmsiv":
             ct = orc.gcmsiv_encrypt(key, bytes.fromhex(v["nonce"]), bytes.fromhex(v["aad"]), data)
             check_out(ct, v["out"])
@@ -276,6 +292,9 @@ def test_against_compiled_reference_random(orc, bits):
         assert orc.gcm_encrypt(key, iv, aad, data) == ct
         assert orc.gcm_decrypt(key, iv, aad, ct) == ref.gcm_decrypt(key, iv, aad, ct) == (0, data)
         assert orc.cmac(key, data) == ref.cmac(key, data)
+        ov = ref.ocb_encrypt(key, iv, aad, data)
+        assert orc.ocb_encrypt(key, iv, aad, data) == ov
+        assert orc.ocb_decrypt(key, iv, aad, ov) == ref.ocb_decrypt(key, iv, aad, ov) == (0, data)
         sv = ref.gcmsiv_encrypt(key, iv, aad, data)
         assert orc.gcmsiv_encrypt(key, iv, aad, data) == sv
         assert orc.gcmsiv_decrypt(key, iv, aad, sv) == ref.gcmsiv_decrypt(key, iv, aad, sv) == (0, data)
