@@ -181,6 +181,24 @@ int uaes_ocb_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
                      const void *aData, size_t aDataLen,
                      const void *crtxt, size_t crtxtLen, void *pntxt);
 
+/* ---- streamed GCM: one message fed in pieces -----------------
+ * For texts larger than device (or host) memory: state = key schedule, block
+ * position of the counter and the running GHASH value, which stays on the GPU
+ * (Y <- Y * H^m ^ GHASH(piece), m = blocks in the piece).  The result is
+ * bit-identical to one AES_GCM_encrypt / AES_GCM_decrypt call over the whole
+ * text (micro_aes.c:1164-1212).  Every piece but the last must be a multiple of
+ * 16 bytes; buffers may be host or device memory.  A decrypting stream releases
+ * text before the tag is checked -- unlike AES_GCM_decrypt (N7) -- so the caller
+ * must discard it if finish() returns UAES_E_AUTHENTICATION.  finish() and abort()
+ * free the stream.                                                           */
+typedef struct uaes_gcm_stream uaes_gcm_stream;
+int  uaes_gcm_stream_begin(uaes_gcm_stream **s, int keybits, const uint8_t *key, const uint8_t *nonce,
+                           const void *aData, size_t aDataLen, int decrypt);
+int  uaes_gcm_stream_update(uaes_gcm_stream *s, const void *in, size_t len, void *out);
+/* encrypting stream: tag <- the 16-byte tag; decrypting stream: tag = the received tag */
+int  uaes_gcm_stream_finish(uaes_gcm_stream *s, uint8_t tag[16]);
+void uaes_gcm_stream_abort(uaes_gcm_stream *s);
+
 /* ---- asynchronous, device-resident variants -----------------------------
  * All data pointers are device pointers, 16-byte aligned; `stream` is a
  * hipStream_t (NULL = default stream).  The call only enqueues work.  One

@@ -38,6 +38,7 @@ EXPORTS = [
     "uaes_gcm_encrypt", "uaes_gcm_decrypt", "uaes_ghash",
     "uaes_cmac", "uaes_ccm_encrypt", "uaes_ccm_decrypt", "uaes_gcmsiv_encrypt", "uaes_gcmsiv_decrypt",
     "uaes_ocb_encrypt", "uaes_ocb_decrypt", "uaes_ocb_dev",
+    "uaes_gcm_stream_begin", "uaes_gcm_stream_update", "uaes_gcm_stream_finish", "uaes_gcm_stream_abort",
     "uaes_cbc_encrypt", "uaes_cbc_decrypt", "uaes_cfb_encrypt", "uaes_cfb_decrypt", "uaes_ofb_xcrypt",
     "uaes_ecb_dev", "uaes_ctr_xcrypt_at_dev", "uaes_xts_sectors_dev",
     "uaes_gcm_encrypt_dev", "uaes_gcm_decrypt_dev", "uaes_gcm_partial_dev",
@@ -108,6 +109,11 @@ def engine():
     for n in ("uaes_ccm_encrypt", "uaes_ccm_decrypt", "uaes_gcmsiv_encrypt", "uaes_gcmsiv_decrypt",
               "uaes_ocb_encrypt", "uaes_ocb_decrypt"):
         getattr(L, n).argtypes = [i, vp, vp, vp, sz, vp, sz, vp]
+    L.uaes_gcm_stream_begin.argtypes = [C.POINTER(vp), i, vp, vp, vp, sz, i]
+    L.uaes_gcm_stream_update.argtypes = [vp, vp, sz, vp]
+    L.uaes_gcm_stream_finish.argtypes = [vp, vp]
+    L.uaes_gcm_stream_abort.argtypes = [vp]
+    L.uaes_gcm_stream_abort.restype = None
     L.uaes_ocb_dev.argtypes = [i, vp, vp, i, vp, sz, vp, sz, vp, vp, vp]
     L.uaes_ecb_dev.argtypes = [i, vp, i, vp, sz, vp, vp]
     L.uaes_ctr_xcrypt_at_dev.argtypes = [i, vp, vp, u64, vp, sz, vp, vp]
@@ -319,6 +325,33 @@ def AES_OCB_decrypt(key, nonce, aData, crtxt_and_tag, prefill=0):
     rc = _check(engine().uaes_ocb_decrypt(_bits(key), _in(key), _in(nonce), _in(aData), len(aData),
                                           _in(crtxt_and_tag), n, o), "AES_OCB_decrypt")
     return rc, bytes(o)[:n]
+
+
+class GcmStream:
+    """One GCM message fed in pieces (uaes_gcm_stream_*): same bytes as AES_GCM_encrypt/decrypt."""
+
+    def __init__(self, key, nonce, aData=b"", decrypt=False):
+        self._h = C.c_void_p()
+        _check(engine().uaes_gcm_stream_begin(C.byref(self._h), _bits(key), _in(key), _in(nonce), _in(aData),
+                                              len(aData), 1 if decrypt else 0), "uaes_gcm_stream_begin")
+        self._decrypt = decrypt
+
+    def update(self, piece):
+        o = _out(len(piece))
+        _check(engine().uaes_gcm_stream_update(self._h, _in(piece), len(piece), o), "uaes_gcm_stream_update")
+        return bytes(o)[: len(piece)]
+
+    def finish(self, tag=None):
+        """encrypt: returns the tag; decrypt: returns 0 or M_AUTHENTICATION_ERROR for the given tag."""
+        t = (C.c_uint8 * 16)(*(tag if self._decrypt else bytes(16)))
+        h, self._h = self._h, None
+        rc = _check(engine().uaes_gcm_stream_finish(h, t), "uaes_gcm_stream_finish")
+        return rc if self._decrypt else bytes(t)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            engine().uaes_gcm_stream_abort(self._h)
+            self._h = None
 
 
 def ghash(H, aData, crtxt):

@@ -84,6 +84,15 @@ int uaesk_gcm_partial(void *stream, const uaesk_tables *tb, int nr, const uaesk_
                       const void *ct_shard, size_t shard_len, uint64_t shard_offset,
                       uint64_t total_len, void *scratch, void *partial16);
 
+/* Streamed GCM: the running GHASH value stays in `scratch` (one
+ * scratch buffer per stream).  absorb kind 0 = AAD (restarts the hash), 1 = a piece of
+ * ciphertext (multiple of 16 bytes unless last), 2 = the length block.  tag:
+ * write Y ^ Enc(J0) to tag_io, or compare with it (*status = 0 / 0x1A).       */
+int uaesk_gcm_stream_absorb(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek,
+                            const uint8_t *nonce12, int kind, const void *data, size_t len,
+                            uint64_t total_aad_len, uint64_t total_ct_len, void *scratch);
+int uaesk_gcm_stream_tag(void *stream, void *scratch, int compare, void *tag_io, int *status);
+
 /* POLYVAL of RFC 8452 (polyval, micro_aes.c:1421-1432) through the GHASH levels:
  * POLYVAL(H, X) = rev(GHASH(mulX(rev(H)), rev(X_i)...)); hg_host must already be
  * mulX_GHASH(ByteReverse(H)); pv_out16 receives the RAW GHASH value (the caller

@@ -1071,3 +1071,119 @@ int uaes_ocb_dev(int keybits, const uint8_t *key, const uint8_t *nonce, int decr
                    c->scratch, d_status));
     return 0;
 }
+
+/* ------------------------------------------------------------------------ */
+/* streamed GCM: begin / update ... / finish                  */
+/* ------------------------------------------------------------------------ */
+struct uaes_gcm_stream {
+    keysched  ks;
+    uint8_t   nonce[12];
+    int       decrypt, closed, device;
+    uint64_t  aad_len, done;        /* bytes of text absorbed so far */
+    void     *scratch;              /* uaesk_gcm_scratch_bytes() + 64: tables, running GHASH, tag, status */
+};
+
+static void *stream_tag_slot(uaes_gcm_stream *s) { return (char *)s->scratch + uaesk_gcm_scratch_bytes(); }
+static int *stream_status_slot(uaes_gcm_stream *s) { return (int *)((char *)stream_tag_slot(s) + 16); }
+
+int uaes_gcm_stream_begin(uaes_gcm_stream **out, int keybits, const uint8_t *key, const uint8_t *nonce,
+                          const void *aData, size_t aDataLen, int decrypt)
+{
+    context *c;
+    uaes_gcm_stream *s;
+    const void *d_aad;
+    int rc;
+    if (!out || !nonce) return fail(UAES_E_ARG, "NULL pointer");
+    *out = NULL;
+    if ((s = (uaes_gcm_stream *)calloc(1, sizeof *s)) == NULL) return fail(UAES_E_HIP, "out of host memory");
+    if ((rc = expand_key(&s->ks, key, keybits)) != 0 || (rc = get_context(&c)) != 0) { free(s); return rc; }
+    memcpy(s->nonce, nonce, 12);
+    s->decrypt = decrypt != 0;
+    s->aad_len = aDataLen;
+    if (hipGetDevice(&s->device) != hipSuccess ||
+        hipMalloc(&s->scratch, uaesk_gcm_scratch_bytes() + 64) != hipSuccess) {
+        free(s);
+        return fail(UAES_E_HIP, "stream scratch allocation failed");
+    }
+    LOCKED_BEGIN(c);
+    do {
+        if ((rc = stage_aad(c, aData, aDataLen, &d_aad)) != 0) break;
+        int k = uaesk_gcm_stream_absorb(NULL, &c->tb, s->ks.nr, &s->ks.ek, s->nonce, 0, d_aad, aDataLen,
+                                        0, 0, s->scratch);
+        if (k) { rc = fail(UAES_E_HIP, "gcm stream launch: %s", hipGetErrorString((hipError_t)k)); break; }
+        if (hipStreamSynchronize(NULL) != hipSuccess) { rc = fail(UAES_E_HIP, "gcm stream begin failed"); break; }
+    } while (0);
+    pthread_mutex_unlock(&c->mu);
+    if (rc) { (void)hipFree(s->scratch); free(s); return rc; }
+    *out = s;
+    return 0;
+}
+
+int uaes_gcm_stream_update(uaes_gcm_stream *s, const void *in, size_t len, void *outp)
+{
+    context *c;
+    io_plan io;
+    uaesk_ctr ctr;
+    uint8_t j0[16];
+    int rc;
+    if (!s || (len && (!in || !outp))) return fail(UAES_E_ARG, "NULL pointer");
+    if (s->closed) return fail(UAES_E_ARG, "the stream already took its last (ragged) piece");
+    if (len == 0) return 0;
+    if ((rc = get_context(&c)) != 0) return rc;
+    memcpy(j0, s->nonce, 12);
+    j0[12] = j0[13] = j0[14] = 0; j0[15] = 1;
+    make_ctr(&ctr, j0, 1 + s->done / 16);            /* keystream block i uses J0 + 1 + i (N4) */
+    LOCKED_BEGIN(c);
+    do {
+        int k;
+        if ((rc = plan_io(c, in, len, outp, len, &io)) != 0) break;
+        if (s->decrypt) {                             /* hash the ciphertext before it may be overwritten */
+            k = uaesk_gcm_stream_absorb(NULL, &c->tb, s->ks.nr, &s->ks.ek, s->nonce, 1, io.din, len, 0, 0, s->scratch);
+            if (!k) k = uaesk_ctr_xcrypt(NULL, &c->tb, s->ks.nr, &s->ks.ek, &ctr, io.din, io.dout, len, NULL);
+        } else {
+            k = uaesk_ctr_xcrypt(NULL, &c->tb, s->ks.nr, &s->ks.ek, &ctr, io.din, io.dout, len, NULL);
+            if (!k) k = uaesk_gcm_stream_absorb(NULL, &c->tb, s->ks.nr, &s->ks.ek, s->nonce, 1, io.dout, len, 0, 0, s->scratch);
+        }
+        if (k) { rc = fail(UAES_E_HIP, "gcm stream launch: %s", hipGetErrorString((hipError_t)k)); break; }
+        rc = finish_io(&io, len);
+    } while (0);
+    pthread_mutex_unlock(&c->mu);
+    if (rc == 0) {
+        s->done += len;
+        if (len % 16) s->closed = 1;
+    }
+    return rc;
+}
+
+int uaes_gcm_stream_finish(uaes_gcm_stream *s, uint8_t tag[16])
+{
+    context *c;
+    int rc, status = -1;
+    if (!s || !tag) return fail(UAES_E_ARG, "NULL pointer");
+    if ((rc = get_context(&c)) != 0) return rc;
+    LOCKED_BEGIN(c);
+    do {
+        hipError_t e = hipSuccess;
+        int k = uaesk_gcm_stream_absorb(NULL, &c->tb, s->ks.nr, &s->ks.ek, s->nonce, 2, NULL, 0,
+                                        s->aad_len, s->done, s->scratch);
+        if (!k && s->decrypt) e = hipMemcpyAsync(stream_tag_slot(s), tag, 16, hipMemcpyHostToDevice, NULL);
+        if (!k && e == hipSuccess)
+            k = uaesk_gcm_stream_tag(NULL, s->scratch, s->decrypt, stream_tag_slot(s), stream_status_slot(s));
+        if (k || e != hipSuccess) { rc = fail(UAES_E_HIP, "gcm stream finish launch failed"); break; }
+        if (s->decrypt) e = hipMemcpy(&status, stream_status_slot(s), sizeof status, hipMemcpyDeviceToHost);
+        else e = hipMemcpy(tag, stream_tag_slot(s), 16, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { rc = fail(UAES_E_HIP, "gcm stream finish: %s", hipGetErrorString(e)); break; }
+        if (s->decrypt && status != 0) rc = UAES_E_AUTHENTICATION;
+    } while (0);
+    pthread_mutex_unlock(&c->mu);
+    uaes_gcm_stream_abort(s);
+    return rc;
+}
+
+void uaes_gcm_stream_abort(uaes_gcm_stream *s)
+{
+    if (!s) return;
+    if (s->scratch) (void)hipFree(s->scratch);
+    memset(s, 0, sizeof *s);                          /* key schedule */
+    free(s);
+}

@@ -54,6 +54,7 @@
 #define GS_ACC2     (GS_ACC1 + (16u << GH_MAXLOG))
 #define GS_POW64    (GS_ACC2 + (16u << GH_LOGB))   /* H^(2^k), k = 0..63 (sharded GCM) */
 #define GS_PART     (GS_POW64 + 1024u)              /* raw GHASH of a shard             */
+#define GS_RUN      (GS_PART + 16u)                 /* running GHASH of a streamed message */
 #define GS_TOTAL    (GS_PART + 64u)
 
 static inline hipStream_t S(void *s) { return (hipStream_t)s; }
@@ -642,6 +643,96 @@ extern "C" int uaesk_gcm_partial(void *stream, const uaesk_tables *tb, int nr, c
     return (int)hipGetLastError();
 }
 
+
+/* ------------------------------------------------------------------------ */
+/* streamed GCM: the running GHASH value Y lives at scratch+GS_RUN            */
+/* ------------------------------------------------------------------------ */
+/* Y <- Y * H^m ^ P  (P = raw GHASH of the m blocks just absorbed, at GS_PART):
+ * Horner over whole pieces of the message.  One wave.                        */
+__global__ __launch_bounds__(64) void k_gcm_fold(unsigned char *__restrict__ scratch, u64 m, u32 reset)
+{
+    const uint4 y4 = *(const uint4 *)(scratch + GS_RUN);
+    Gf acc = gf_from_words(y4.x, y4.y, y4.z, y4.w);
+    if (reset) { acc.hi = 0; acc.lo = 0; }
+    const uint4 *pw = (const uint4 *)(scratch + GS_POW64);
+    for (u32 k = 0; k < 64; ++k) {
+        if ((m >> k) & 1) {                                   /* wave-uniform */
+            const uint4 h = pw[k];
+            acc = wave_gfmul(acc, gf_from_words(h.x, h.y, h.z, h.w), threadIdx.x);
+        }
+    }
+    if (threadIdx.x == 0) {
+        u32 w[4];
+        gf_to_words(acc, w);
+        if (m) {
+            const uint4 p4 = *(const uint4 *)(scratch + GS_PART);
+            w[0] ^= p4.x; w[1] ^= p4.y; w[2] ^= p4.z; w[3] ^= p4.w;
+        }
+        *(uint4 *)(scratch + GS_RUN) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+/* tag = Y ^ Enc(J0): write it (mode 0) or compare with tag_io (mode 1) */
+__global__ __launch_bounds__(64) void k_gcm_stream_tag(const unsigned char *__restrict__ scratch, int mode,
+                                                       unsigned char *tag_io, int *status)
+{
+    if (threadIdx.x != 0) return;
+    const uint4 t = x4(*(const uint4 *)(scratch + GS_RUN), *(const uint4 *)(scratch + GS_EJ0));
+    const u32 w[4] = { t.x, t.y, t.z, t.w };
+    if (mode == 1) {
+        u32 diff = 0;
+        for (u32 i = 0; i < 16; ++i) diff |= (u32)tag_io[i] ^ ((w[i >> 2] >> (8 * (i & 3))) & 0xffu);
+        *status = diff ? 0x1A : 0;
+    } else {
+        for (u32 i = 0; i < 16; ++i) tag_io[i] = (unsigned char)(w[i >> 2] >> (8 * (i & 3)));
+    }
+}
+
+/* Absorb one piece of the GHASH input into the running value.  kind 0: the AAD
+ * (first piece: Y restarts at 0), kind 1: `len` bytes of ciphertext (a multiple of
+ * 16 unless it is the last piece), kind 2: the length block with the totals.   */
+extern "C" int uaesk_gcm_stream_absorb(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek,
+                                       const uint8_t *nonce12, int kind, const void *data, size_t len,
+                                       uint64_t total_aad_len, uint64_t total_ct_len, void *scratch)
+{
+    hipStream_t st = S(stream);
+    unsigned char *sc = (unsigned char *)scratch;
+    uint4 j0;
+    unsigned char j0b[16];
+    memcpy(j0b, nonce12, 12);
+    j0b[12] = j0b[13] = j0b[14] = 0; j0b[15] = 1;
+    memcpy(&j0, j0b, 16);
+
+    GSrc msg;
+    memset(&msg, 0, sizeof msg);
+    if (kind == 0) { msg.aad = (const unsigned char *)data; msg.aad_len = len; }
+    else if (kind == 1) { msg.ct = (const unsigned char *)data; msg.ct_len = len; }
+    else { msg.has_len = 1; msg.len_aad = total_aad_len; msg.len_ct = total_ct_len; }
+    const u64 nv = kind == 2 ? 1 : (len + 15) >> 4;
+    const GPlan pl = plan_for(nv ? nv : 1);
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    int rc;
+    switch (nr) {
+    case 10: rc = launch_setup<10>(st, tb, ek, j0, sc, pl, 0, z, 1); break;
+    case 12: rc = launch_setup<12>(st, tb, ek, j0, sc, pl, 0, z, 1); break;
+    case 14: rc = launch_setup<14>(st, tb, ek, j0, sc, pl, 0, z, 1); break;
+    default: return (int)hipErrorInvalidValue;
+    }
+    if (rc) return rc;
+    if (nv) {
+        rc = run_ghash_levels(st, msg, nv, pl, sc, 2, sc + GS_PART, nullptr);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(k_gcm_fold, dim3(1), dim3(64), 0, st, sc, nv, (u32)(kind == 0));
+    return (int)hipGetLastError();
+}
+
+extern "C" int uaesk_gcm_stream_tag(void *stream, void *scratch, int compare, void *tag_io, int *status)
+{
+    hipLaunchKernelGGL(k_gcm_stream_tag, dim3(1), dim3(64), 0, S(stream), (const unsigned char *)scratch,
+                       compare ? 1 : 0, (unsigned char *)tag_io, status);
+    return (int)hipGetLastError();
+}
 
 extern "C" int uaesk_polyval(void *stream, const uint8_t *hg_host,
                              const void *aad, size_t aad_len, const void *pt, size_t pt_len,

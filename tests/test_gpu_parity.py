@@ -142,6 +142,39 @@ def test_gcmsiv_vs_oracle(orc, bits):
         assert rc == 0x1A
 
 
+@pytest.mark.parametrize("bits", [128, 256])
+def test_gcm_stream_equals_one_shot(orc, bits):
+    """a message fed in pieces (tiny, odd multiples of 16, > 32768 blocks to reach the bulk GHASH
+    levels, ragged last piece) gives the bytes and the tag of one AES_GCM_encrypt call"""
+    rnd = random.Random(bits + 8)
+    for pieces, aad_len in [([16], 0), ([5], 3), ([16, 16, 7], 20), ([4096, 16, 65536, 1], 0),
+                            ([(1 << 20) + 16, 48, (600 << 10), 12345], 4097), ([0, 32, 0, 16], 16)]:
+        key, nonce, aad = rnd.randbytes(bits // 8), rnd.randbytes(12), rnd.randbytes(aad_len)
+        n = sum(pieces)
+        data = orc.splitmix(n + 11, n)
+        want = orc.gcm_encrypt(key, nonce, aad, data)
+        st = uaes.GcmStream(key, nonce, aad)
+        got, off = b"", 0
+        for p in pieces:
+            got += st.update(data[off:off + p])
+            off += p
+        tag = st.finish()
+        assert got + tag == want, pieces
+        st = uaes.GcmStream(key, nonce, aad, decrypt=True)
+        back, off = b"", 0
+        for p in pieces:
+            back += st.update(want[off:off + p])
+            off += p
+        assert st.finish(want[n:]) == 0 and back == data
+        st = uaes.GcmStream(key, nonce, aad, decrypt=True)
+        st.update(want[:n])
+        assert st.finish(bytes([want[n] ^ 1]) + want[n + 1:]) == 0x1A
+    st = uaes.GcmStream(bytes(16), bytes(12))
+    st.update(b"abc")
+    with pytest.raises(uaes.EngineError):
+        st.update(b"x" * 16)                     # a ragged piece closes the stream
+
+
 def test_ocb_openssl_vectors():
     cases = ocb_cases(128)
     assert len(cases) == 16
