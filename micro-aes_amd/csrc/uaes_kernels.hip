@@ -15,6 +15,7 @@
  */
 #include <hip/hip_runtime.h>
 #include <string.h>
+#include <mutex>
 #include <stdio.h>
 #include <stdlib.h>
 #include "uaes_aes.hip.h"
@@ -426,11 +427,12 @@ __global__ __launch_bounds__(UAES_WG, 4) void k_ctr_shared2(uaesk_rk rk, uaesk_t
 #define XTS_CHUNK 256u      /* blocks per chunk = one wave x 4 blocks per lane */
 
 /* pre-pass: one thread per data unit.  T0 = Enc_key2(tweak) (:1026-1027),
- * then the tweak at the start of every 256-block chunk of the unit.         */
+ * then the tweak at the start of every 256-block chunk of the unit; for units of
+ * many chunks (serial != 0 only below XTS_SERIAL_CPS) k_xts_expand does the latter. */
 template <int NR>
 __global__ __launch_bounds__(UAES_WG) void k_xts_tweaks(uaesk_rk k2, uaesk_tables tb,
                                                         uint4 raw_tweak, u32 use_raw, u64 first_sector,
-                                                        u64 nsectors, u64 chunks_per_sector,
+                                                        u64 nsectors, u64 chunks_per_sector, u32 serial,
                                                         uint4 *__restrict__ chunk_tw)
 {
     fill_enc_tables(tb.te0);
@@ -448,11 +450,61 @@ __global__ __launch_bounds__(UAES_WG) void k_xts_tweaks(uaesk_rk k2, uaesk_table
         Tw t;
         t.lo = s[0][0] | ((u64)s[0][1] << 32);
         t.hi = s[0][2] | ((u64)s[0][3] << 32);
-        for (u64 c = 0; c < chunks_per_sector; ++c) {
+        for (u64 c = 0; c < (serial ? chunks_per_sector : 1); ++c) {
             chunk_tw[sct * chunks_per_sector + c] =
                 make_uint4((u32)t.lo, (u32)(t.lo >> 32), (u32)t.hi, (u32)(t.hi >> 32));
             t = tw_mul_pow64(tw_mul_pow64(tw_mul_pow64(tw_mul_pow64(t))));
         }
+    }
+}
+
+/* Chunk tweaks of LONG data units (the reference API is one unit per call, so a bulk
+ * AES_XTS_encrypt is one unit of many chunks): instead of walking T <- T * alpha^256
+ * down the unit, one wave takes 64 consecutive chunks.  The tweak of its first chunk,
+ * T0 * alpha^(2^14 r), is a product of T0 with the host-made constants
+ * alpha^(2^(14+i)) (bits i of r), each product computed by the whole wave (lane l
+ * contributes coefficients l and l+64, butterfly XOR); lane j then shifts by 256 j.  */
+#define XTS_POW_N 40
+struct XtsPow {
+    u64 lo[XTS_POW_N], hi[XTS_POW_N];
+};
+
+__device__ __forceinline__ Tw wave_tw_mul(Tw x, u64 elo, u64 ehi, u32 lane)
+{
+    const Tw xl = tw_mul_pow(x, lane), xh = tw_mul_pow64(xl);
+    Tw z = { 0, 0 };
+    if ((elo >> lane) & 1) z = xl;
+    if ((ehi >> lane) & 1) { z.lo ^= xh.lo; z.hi ^= xh.hi; }
+    u32 w[4] = { (u32)z.lo, (u32)(z.lo >> 32), (u32)z.hi, (u32)(z.hi >> 32) };
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w[q] ^= __shfl_xor(w[q], off, 64);
+    }
+    z.lo = w[0] | ((u64)w[1] << 32);
+    z.hi = w[2] | ((u64)w[3] << 32);
+    return z;
+}
+
+__global__ __launch_bounds__(UAES_WG) void k_xts_expand(XtsPow pw, u64 nsectors, u64 chunks_per_sector,
+                                                        uint4 *__restrict__ chunk_tw)
+{
+    const u32 lane = threadIdx.x & 63u;
+    const u64 groups = (chunks_per_sector + 63) / 64;
+    const u64 nwaves = (u64)gridDim.x * (UAES_WG / 64);
+    for (u64 w = (u64)blockIdx.x * (UAES_WG / 64) + (threadIdx.x >> 6); w < nsectors * groups; w += nwaves) {
+        const u64 sct = w / groups, r = w - sct * groups;
+        const uint4 t0 = chunk_tw[sct * chunks_per_sector];
+        Tw t;
+        t.lo = t0.x | ((u64)t0.y << 32);
+        t.hi = t0.z | ((u64)t0.w << 32);
+        for (u32 i = 0; i < XTS_POW_N; ++i)
+            if ((r >> i) & 1) t = wave_tw_mul(t, pw.lo[i], pw.hi[i], lane);       /* wave-uniform */
+        for (u32 q = 0; q < 4 * lane; ++q) t = tw_mul_pow64(t);                   /* * alpha^(256 lane) */
+        const u64 c = r * 64 + lane;
+        if (c != 0 && c < chunks_per_sector)
+            chunk_tw[sct * chunks_per_sector + c] =
+                make_uint4((u32)t.lo, (u32)(t.lo >> 32), (u32)t.hi, (u32)(t.hi >> 32));
     }
 }
 
@@ -802,6 +854,29 @@ extern "C" int uaesk_ctr_xcrypt(void *stream, const uaesk_tables *tb, int nr, co
     return 0;
 }
 
+#define XTS_SERIAL_CPS 128u      /* up to this many chunks per unit the pre-pass thread walks them itself */
+
+/* alpha^(2^(14+i)), i < XTS_POW_N: repeated squaring from alpha^(2^14) = 256 word shifts of 1 */
+static const XtsPow *xts_pow_table()
+{
+    static XtsPow tab;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        Tw e = { 1, 0 };
+        for (int i = 0; i < 256; ++i) e = tw_mul_pow64(e);
+        for (int i = 0; i < XTS_POW_N; ++i) {
+            tab.lo[i] = e.lo; tab.hi[i] = e.hi;
+            Tw a = e, acc = { 0, 0 };
+            for (int b = 0; b < 128; ++b) {          /* e * e, bit-serial */
+                if (((b < 64 ? e.lo : e.hi) >> (b & 63)) & 1) { acc.lo ^= a.lo; acc.hi ^= a.hi; }
+                a = tw_mul_pow(a, 1);
+            }
+            e = acc;
+        }
+    });
+    return &tab;
+}
+
 static void xts_geometry(size_t sector_bytes, u64 *main_blocks, u32 *rem, u64 *cps)
 {
     const u32 r = (u32)(sector_bytes % 16);
@@ -834,9 +909,14 @@ static int launch_xts(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *k1
 
     uint4 raw = make_uint4(0, 0, 0, 0);
     if (tweak16) memcpy(&raw, tweak16, 16);
+    const bool serial = cps <= XTS_SERIAL_CPS;
+    if (!serial && ((cps + 63) / 64) >> XTS_POW_N) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL((k_xts_tweaks<NR>), dim3(grid_for(nsectors, UAES_WG)), dim3(UAES_WG), UAES_LDS_ENC, st,
-                       *k2, *tb, raw, (u32)(tweak16 != nullptr), first_sector, (u64)nsectors, cps,
+                       *k2, *tb, raw, (u32)(tweak16 != nullptr), first_sector, (u64)nsectors, cps, (u32)serial,
                        (uint4 *)scratch);
+    if (!serial)
+        hipLaunchKernelGGL(k_xts_expand, dim3(grid_for((u64)nsectors * ((cps + 63) / 64), UAES_WG / 64)),
+                           dim3(UAES_WG), 0, st, *xts_pow_table(), (u64)nsectors, cps, (uint4 *)scratch);
     if (mb > 0) {
         const u64 nchunks = (u64)nsectors * ((mb + XTS_CHUNK - 1) / XTS_CHUNK);
         hipLaunchKernelGGL((k_xts<NR, DEC>), dim3(grid_for(nchunks, UAES_WG / 64)), dim3(UAES_WG), lds, st,

@@ -32,7 +32,7 @@ static inline hipStream_t S(void *s) { return (hipStream_t)s; }
 #define OCB_LDS_ACC  (OCB_LDS_L + OCB_NL * 16u)
 #define OCB_LDS      (OCB_LDS_ACC + 16u)
 #define OCB_CHUNK    256u                     /* blocks per chunk: one wave x 4 per lane */
-#define OCB_RUN      16u                      /* consecutive chunks a wave takes at once */
+#define OCB_RUN_MAX  16u                      /* most consecutive chunks a wave takes at once */
 #define UAES_U       4                        /* blocks per lane per chunk               */
 /* scratch rows (uint4): [0..63] L table, [64] Offset_0, [65] checksum accumulator     */
 #define OCB_ROW_OFF0 64u
@@ -149,9 +149,11 @@ __global__ __launch_bounds__(UAES_WG) void k_ocb_setup(uaesk_rk ek, uaesk_tables
 /* ------------------------------------------------------------------------ */
 template <int NR, bool DEC>
 __global__ __launch_bounds__(UAES_WG) void k_ocb(uaesk_rk rk, uaesk_tables tb,
-                                                 uint4 *__restrict__ scr, u64 nblocks,
+                                                 uint4 *__restrict__ scr, u64 nblocks, u32 run,
                                                  const uint4 *__restrict__ in, uint4 *__restrict__ out)
 {
+    /* run (a power of two <= OCB_RUN_MAX) = consecutive chunks per wave; short texts use
+     * short runs so that every CU gets work                                        */
     ocb_tables_to_lds(scr);
     if (DEC) fill_dec_tables(tb.td0, tb.si4); else fill_enc_tables(tb.te0);
     const LaneConst lc = make_lane_const();
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(UAES_WG) void k_ocb(uaesk_rk rk, uaesk_tables tb,
     const B16 off0 = uniform(b16(scr[OCB_ROW_OFF0]));
     const B16 l5 = uniform(lds_row(2u + 5u)), l6 = uniform(lds_row(2u + 6u)), l7 = uniform(lds_row(2u + 7u));
 
-    auto chunk_of = [&](u64 k) { return ((k / OCB_RUN) * nwaves + wave) * OCB_RUN + (k % OCB_RUN); };
+    auto chunk_of = [&](u64 k) { return ((k / run) * nwaves + wave) * run + (k % run); };
     /* live positions inside chunk c: [lo, hi] (index 0 does not exist, indices end at nblocks) */
     auto span = [&](u64 c, u32 &lo, u32 &hi) {
         lo = c == 0 ? 1u : 0u;
@@ -193,9 +195,10 @@ __global__ __launch_bounds__(UAES_WG) void k_ocb(uaesk_rk rk, uaesk_tables tb,
     u64 k = 0, c = chunk_of(0);
     if (c < nchunks) fetch(c);
     while (c < nchunks) {
-        if ((k % OCB_RUN) == 0) {                     /* first chunk of a run: c is even */
+        if ((k % run) == 0) {                         /* first chunk of a run */
             cm = off0;
             bx(cm, ocb_gray_sum(c ^ (c >> 1), 8));
+            if (c & 1) bx(cm, l7);
             cm = uniform(cm);
         }
         uint4 d[UAES_U];
@@ -370,15 +373,17 @@ static int launch_ocb(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek
     const u64 nblocks = len >> 4;
     if (nblocks) {
         const u64 nchunks = (nblocks >> 8) + 1;
-        const u64 runs = (nchunks + OCB_RUN - 1) / OCB_RUN;
+        u32 run = OCB_RUN_MAX;
+        while (run > 1 && nchunks / run < (u64)cu_count() * (UAES_WG / 64)) run >>= 1;
+        const u64 runs = (nchunks + run - 1) / run;
         u64 grid = (runs + UAES_WG / 64 - 1) / (UAES_WG / 64);
         if (grid > cu_count()) grid = cu_count();
         if (decrypt)
             hipLaunchKernelGGL((k_ocb<NR, true>), dim3((unsigned)grid), dim3(UAES_WG), OCB_LDS, st, *dk, *tb, scr,
-                               nblocks, (const uint4 *)in, (uint4 *)out);
+                               nblocks, run, (const uint4 *)in, (uint4 *)out);
         else
             hipLaunchKernelGGL((k_ocb<NR, false>), dim3((unsigned)grid), dim3(UAES_WG), OCB_LDS, st, *ek, *tb, scr,
-                               nblocks, (const uint4 *)in, (uint4 *)out);
+                               nblocks, run, (const uint4 *)in, (uint4 *)out);
     }
     hipLaunchKernelGGL((k_ocb_final<NR>), dim3(1), dim3(UAES_WG), OCB_LDS, st, *ek, *tb, scr, decrypt,
                        (const unsigned char *)aad, (u64)aad_len, (const unsigned char *)in, (unsigned char *)out,

@@ -41,6 +41,7 @@ class Compat:
     """libmicro_aes_hip_<bits>.so: the drop-in AES_* symbols (include/micro_aes.h)"""
 
     def __init__(self, bits):
+        uaes.engine()       # imports torch first: its bundled HIP runtime must be the one both bind to
         L = self.L = C.CDLL(uaes.lib_path("libmicro_aes_hip_%d.so" % bits))
         sz, vp = C.c_size_t, C.c_void_p
         L.AES_ECB_encrypt.argtypes = [vp, vp, sz, vp]; L.AES_ECB_encrypt.restype = None
@@ -140,6 +141,26 @@ def test_gcmsiv_vs_oracle(orc, bits):
         bad[0 if n else -1] ^= 0x01
         rc, _ = uaes.GCM_SIV_decrypt(key, nonce, aad, bytes(bad))
         assert rc == 0x1A
+
+
+@pytest.mark.parametrize("bits", [128, 256])
+def test_xts_long_data_units(orc, bits):
+    """one data unit of many 256-block chunks (the reference API is one unit per call): the chunk
+    tweaks come from the parallel expansion, not from walking the unit"""
+    rnd = random.Random(bits + 9)
+    for n in [9 * 4096, 64 * 4096, 65 * 4096 + 16, (1 << 20) + 33, (4 << 20) + 4096 * 63 + 17, 16 << 20]:
+        keys, tweak = rnd.randbytes(bits // 4), rnd.randbytes(16)
+        data = orc.splitmix(n + 13, n)
+        rc, ct = uaes.AES_XTS_encrypt(keys, tweak, data)
+        assert (rc, ct) == orc.xts(keys, tweak, data, True), n
+        assert uaes.AES_XTS_decrypt(keys, tweak, ct) == (0, data), n
+    # several long units in one call
+    keys = rnd.randbytes(bits // 4)
+    sb, ns = 200 * 4096 + 48, 3
+    data = orc.splitmix(77, sb * ns)
+    rc, ct = uaes.xts_sectors(keys, 1234567, sb, data, encrypt=True)
+    assert (rc, ct) == orc.xts_sectors(keys, 1234567, sb, data, True)
+    assert uaes.xts_sectors(keys, 1234567, sb, ct, encrypt=False) == (0, data)
 
 
 @pytest.mark.parametrize("bits", [128, 256])
