@@ -30,13 +30,15 @@ static inline hipStream_t S(void *s) { return (hipStream_t)s; }
 #define OCB_NL       64u                      /* table rows: 0 L_*, 1 L_$, 2+j L_j      */
 #define OCB_LDS_L    (128u * 1024u)           /* L table in LDS, after the cipher tables */
 #define OCB_LDS_ACC  (OCB_LDS_L + OCB_NL * 16u)
-#define OCB_LDS      (OCB_LDS_ACC + 16u)
+#define OCB_LDS      (OCB_LDS_ACC + 32u)        /* two 16-byte accumulators */
 #define OCB_CHUNK    256u                     /* blocks per chunk: one wave x 4 per lane */
 #define OCB_RUN_MAX  16u                      /* most consecutive chunks a wave takes at once */
 #define UAES_U       4                        /* blocks per lane per chunk               */
-/* scratch rows (uint4): [0..63] L table, [64] Offset_0, [65] checksum accumulator     */
+/* scratch rows (uint4): [0..63] L table, [64] Offset_0, [65..] one checksum share per
+ * workgroup of k_ocb (plain stores: thousands of same-address atomics cost 0.2 ms) */
 #define OCB_ROW_OFF0 64u
-#define OCB_ROW_SUM  65u
+#define OCB_ROW_PART 65u
+#define OCB_MAX_WGS  1024u
 
 struct B16 {
     u32 w[4];
@@ -103,7 +105,8 @@ __device__ __forceinline__ B16 ocb_delta(u64 i) { return ocb_gray_sum(i ^ (i >> 
 __device__ __forceinline__ void ocb_tables_to_lds(const uint4 *__restrict__ scr)
 {
     if (threadIdx.x < OCB_NL) ((uint4 *)(uaes_lds + OCB_LDS_L))[threadIdx.x] = scr[threadIdx.x];
-    if (threadIdx.x == OCB_NL) *(uint4 *)(uaes_lds + OCB_LDS_ACC) = make_uint4(0, 0, 0, 0);
+    if (threadIdx.x == OCB_NL || threadIdx.x == OCB_NL + 1)
+        *(uint4 *)(uaes_lds + OCB_LDS_ACC + 16u * (threadIdx.x - OCB_NL)) = make_uint4(0, 0, 0, 0);
 }
 
 __device__ __forceinline__ void wave_xor_reduce(u32 (&v)[4])
@@ -141,7 +144,6 @@ __global__ __launch_bounds__(UAES_WG) void k_ocb_setup(uaesk_rk ek, uaesk_tables
     const u64 olo = bottom ? (lo << bottom) | (ext >> (64u - bottom)) : lo;
     scr[OCB_ROW_OFF0] = make_uint4(bswap32((u32)(ohi >> 32)), bswap32((u32)ohi),
                                    bswap32((u32)(olo >> 32)), bswap32((u32)olo));
-    scr[OCB_ROW_SUM] = make_uint4(0, 0, 0, 0);
 }
 
 /* ------------------------------------------------------------------------ */
@@ -258,11 +260,13 @@ __global__ __launch_bounds__(UAES_WG) void k_ocb(uaesk_rk rk, uaesk_tables tb,
         c = cn;
     }
     wave_xor_reduce(sum);
-    if (lane == 0 && (sum[0] | sum[1] | sum[2] | sum[3])) {
-        u32 *acc = (u32 *)(scr + OCB_ROW_SUM);
+    if (lane == 0) {
+        u32 *acc = (u32 *)(uaes_lds + OCB_LDS_ACC);
 #pragma unroll
         for (int q = 0; q < 4; ++q) atomicXor(acc + q, sum[q]);
     }
+    __syncthreads();
+    if (threadIdx.x == 0) scr[OCB_ROW_PART + blockIdx.x] = *(const uint4 *)(uaes_lds + OCB_LDS_ACC);
 }
 
 /* ------------------------------------------------------------------------ */
@@ -278,7 +282,7 @@ __device__ __forceinline__ B16 ocb_load_bytes(const unsigned char *p, u32 n)
 
 template <int NR>
 __global__ __launch_bounds__(UAES_WG) void k_ocb_final(uaesk_rk ek, uaesk_tables tb,
-                                                       uint4 *__restrict__ scr, int decrypt,
+                                                       uint4 *__restrict__ scr, u32 nparts, int decrypt,
                                                        const unsigned char *__restrict__ aad, u64 aad_len,
                                                        const unsigned char *in, unsigned char *out, u64 len,
                                                        int *status)
@@ -306,10 +310,17 @@ __global__ __launch_bounds__(UAES_WG) void k_ocb_final(uaesk_rk ek, uaesk_tables
         h[0] ^= b.w[0]; h[1] ^= b.w[1]; h[2] ^= b.w[2]; h[3] ^= b.w[3];
     }
     wave_xor_reduce(h);
+    /* checksum shares of the k_ocb workgroups */
+    u32 cs[4] = { 0, 0, 0, 0 };
+    if (threadIdx.x < nparts) {
+        const uint4 v = scr[OCB_ROW_PART + threadIdx.x];
+        cs[0] = v.x; cs[1] = v.y; cs[2] = v.z; cs[3] = v.w;
+    }
+    wave_xor_reduce(cs);
     if ((threadIdx.x & 63u) == 0) {
         u32 *acc = (u32 *)(uaes_lds + OCB_LDS_ACC);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) atomicXor(acc + q, h[q]);
+        for (int q = 0; q < 4; ++q) { atomicXor(acc + q, h[q]); atomicXor(acc + 4 + q, cs[q]); }
     }
     __syncthreads();
     if (threadIdx.x != 0) return;
@@ -318,7 +329,7 @@ __global__ __launch_bounds__(UAES_WG) void k_ocb_final(uaesk_rk ek, uaesk_tables
     const u32 r = (u32)(len & 15u);
     B16 d = b16(scr[OCB_ROW_OFF0]);
     bx(d, ocb_delta(n));                              /* Offset_m */
-    B16 ck = b16(scr[OCB_ROW_SUM]);
+    B16 ck = b16(*(const uint4 *)(uaes_lds + OCB_LDS_ACC + 16u));
     if (r) {                                          /* :1736-1741 */
         bx(d, lds_row(0));                            /* Offset_* = Offset_m ^ L_* */
         B16 pad = d;
@@ -371,13 +382,17 @@ static int launch_ocb(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL((k_ocb_setup<NR>), dim3(1), dim3(UAES_WG), OCB_LDS, st, *ek, *tb, nb, bottom, scr);
     const u64 nblocks = len >> 4;
+    u32 nparts = 0;
     if (nblocks) {
         const u64 nchunks = (nblocks >> 8) + 1;
+        /* at least 8 runs per wave, so that an uneven split costs at most 1/8 */
         u32 run = OCB_RUN_MAX;
-        while (run > 1 && nchunks / run < (u64)cu_count() * (UAES_WG / 64)) run >>= 1;
+        while (run > 1 && nchunks / run < 8ull * cu_count() * (UAES_WG / 64)) run >>= 1;
         const u64 runs = (nchunks + run - 1) / run;
         u64 grid = (runs + UAES_WG / 64 - 1) / (UAES_WG / 64);
         if (grid > cu_count()) grid = cu_count();
+        if (grid > OCB_MAX_WGS) grid = OCB_MAX_WGS;
+        nparts = (u32)grid;
         if (decrypt)
             hipLaunchKernelGGL((k_ocb<NR, true>), dim3((unsigned)grid), dim3(UAES_WG), OCB_LDS, st, *dk, *tb, scr,
                                nblocks, run, (const uint4 *)in, (uint4 *)out);
@@ -385,13 +400,13 @@ static int launch_ocb(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek
             hipLaunchKernelGGL((k_ocb<NR, false>), dim3((unsigned)grid), dim3(UAES_WG), OCB_LDS, st, *ek, *tb, scr,
                                nblocks, run, (const uint4 *)in, (uint4 *)out);
     }
-    hipLaunchKernelGGL((k_ocb_final<NR>), dim3(1), dim3(UAES_WG), OCB_LDS, st, *ek, *tb, scr, decrypt,
+    hipLaunchKernelGGL((k_ocb_final<NR>), dim3(1), dim3(UAES_WG), OCB_LDS, st, *ek, *tb, scr, nparts, decrypt,
                        (const unsigned char *)aad, (u64)aad_len, (const unsigned char *)in, (unsigned char *)out,
                        (u64)len, status);
     return (int)hipGetLastError();
 }
 
-extern "C" size_t uaesk_ocb_scratch_bytes(void) { return 16u * (OCB_ROW_SUM + 1u); }
+extern "C" size_t uaesk_ocb_scratch_bytes(void) { return 16u * (OCB_ROW_PART + OCB_MAX_WGS); }
 
 /* nonce12 is a host pointer; everything else device memory (in/out 16-byte aligned).
  * encrypt: tag written at out+len.  decrypt: tag read at in+len, *status = 0 / 0x1A,

@@ -513,6 +513,25 @@ def test_C2_ctr128_1GiB_device_resident(orc, golden_dir):
     assert torch.equal(dst, src)
 
 
+@pytest.mark.parametrize("mib,extra", [(74, 5), (64, 0), (20, 16 * 777 + 3)])
+def test_ctr_split_between_shared_round_and_generic_kernels(orc, mib, extra):
+    """sizes whose last round of 256 KiB chunks is thin: whole rounds run on the shared-round kernel,
+    the remainder (with its own counter offset) on the generic one; counter byte 15 starts at 0xfe"""
+    import hashlib
+    import torch
+    n = (mib << 20) + extra
+    key, ctr0 = bytes(range(16, 32)), bytes(range(0xE0, 0xEC)) + b"\xff\xff\xff\xfe"
+    src = _device_stream(orc, 21, (n + 7) // 8 * 8)[:n]
+    dst = torch.empty_like(src)
+    uaes.ctr_xcrypt_dev(key, ctr0, 0, src, dst, nbytes=n)
+    torch.cuda.synchronize()
+    want = orc.ctr_xcrypt_at(key, ctr0, 0, bytes(src.cpu().numpy()))
+    assert hashlib.sha256(bytes(dst.cpu().numpy())).hexdigest() == hashlib.sha256(want).hexdigest()
+    uaes.ctr_xcrypt_dev(key, ctr0, 0, dst, dst, nbytes=n)
+    torch.cuda.synchronize()
+    assert torch.equal(dst, src)
+
+
 def test_C3_xts256_sectors_device_resident(orc, golden_dir):
     """BASELINE configs[2] at 2^18 sectors (1 GiB; the 2^20 digest is checked by
     bench.py --workload xts): first sectors against the goldens, round trip, and
