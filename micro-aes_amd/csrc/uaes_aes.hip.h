@@ -19,8 +19,10 @@
  *    16..23): 1 VALU + 1 ds_read_b32 per S-box application;
  *  - round keys are wave-uniform kernel arguments (SGPRs).
  *
- * LDS budget: encrypt 4 tables x 32 KiB = 128 KiB; decrypt Td0,Td1 (64 KiB,
- * rows 2,3 reuse them through a 16-bit rotate) + inverse S-box 32 KiB.
+ * LDS budget: 4 tables x 32 KiB = 128 KiB in both directions (Te0..Te3 or
+ * Td0..Td3).  The inverse cipher's last round needs plain Si[x], which no Td
+ * byte holds -- but 14 ^ 9 ^ 13 ^ 11 = 1 in GF(2^8), so Si[x] is the XOR of the
+ * four bytes of Td0[x]: a fold in registers instead of a fifth table.
  */
 #ifndef UAES_AES_HIP_H_
 #define UAES_AES_HIP_H_
@@ -35,7 +37,7 @@ typedef uint64_t u64;
 #define UAES_WG        1024u              /* threads per workgroup (16 waves)  */
 #define UAES_LDS_ENC   (128u * 1024u)
 #define UAES_LDS_ENC2  (64u * 1024u)     /* two-table variant                 */
-#define UAES_LDS_DEC   (96u * 1024u)
+#define UAES_LDS_DEC   (128u * 1024u)
 
 extern __shared__ __attribute__((aligned(16))) unsigned char uaes_lds[];
 
@@ -128,28 +130,10 @@ __device__ __forceinline__ void fill_enc_tables(const u32 *__restrict__ te0)
     __syncthreads();
 }
 
-/* region 0: Td0 | Td1 interleaved; region 1 (first 128 B of each 256-B row
- * only... kept dense: row stride 128 B): Si4                               */
-__device__ __forceinline__ void fill_dec_tables(const u32 *__restrict__ td0,
-                                                const u32 *__restrict__ si4)
+/* Td_k[x] = rotl(Td0[x], 8k); Td0 bytes = {14Si, 9Si, 13Si, 11Si}; same layout as Te */
+__device__ __forceinline__ void fill_dec_tables(const u32 *__restrict__ td0)
 {
-    for (u32 i = threadIdx.x; i < 768u; i += blockDim.x) {
-        const u32 x = i & 255u, k = i >> 8;
-        if (k < 2)
-            store_replicas(x * 256u + k * 128u, rotl32(td0[x], 8u * k));
-        else
-            store_replicas(65536u + x * 128u, si4[x]);
-    }
-    __syncthreads();
-}
-
-/* inverse S-box lookup: dense 128-B rows at 64 KiB; index byte BYTE of w.
- * address = 65536 + x*128 + slot = ((x<<7) | slot) + 65536                 */
-template <int BYTE>
-__device__ __forceinline__ u32 silook(u32 w, u32 slot)
-{
-    const u32 x = (w >> (8 * BYTE)) & 0xffu;
-    return lds_word(65536u + (x << 7) + slot);
+    fill_enc_tables<4>(td0);
 }
 
 /* ---- encryption rounds -------------------------------------------------- */
@@ -197,14 +181,6 @@ __device__ __forceinline__ u32 last_col(u32 a, u32 b, u32 c, u32 d, u32 key, con
     return or_xor(lo, hi, key);
 }
 
-/* used by the decrypt path (inverse S-box words carry Si in every byte) */
-__device__ __forceinline__ u32 pick4(u32 r0, u32 r1, u32 r2, u32 r3, u32 key)
-{
-    const u32 lo = __builtin_amdgcn_perm(r1, r0, 0x0c0c0500u);
-    const u32 hi = __builtin_amdgcn_perm(r3, r2, 0x07020c0cu);
-    return or_xor(lo, hi, key);
-}
-
 template <int U, int NT = 4>
 __device__ __forceinline__ void enc_last_round(u32 (&s)[U][4], const u32 *rk, const LaneConst &lc)
 {
@@ -240,33 +216,51 @@ __device__ __forceinline__ void enc_blocks(u32 (&s)[U][4], const uaesk_rk &rk, c
 }
 
 /* ---- split-phase rounds (software pipelining across two blocks) ---------- */
-/* issue the 16 lookups of one round of one block; results are consumed later */
-template <bool LAST>
+/* issue the 16 lookups of one round of one block; results are consumed later.
+ * DEC: the equivalent inverse cipher (FIPS-197 sec. 5.3.5): column c takes row r
+ * from column (c - r) mod 4 instead of (c + r); its last round reads Td0 only.   */
+template <bool LAST, bool DEC = false>
 __device__ __forceinline__ void issue16(const u32 (&s)[4], u32 (&t)[16], const LaneConst &lc)
 {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const u32 a = s[c], b = s[(c + 1) & 3], cc = s[(c + 2) & 3], d = s[(c + 3) & 3];
+        const u32 a = s[c], b = s[(DEC ? c + 3 : c + 1) & 3], cc = s[(c + 2) & 3], d = s[(DEC ? c + 1 : c + 3) & 3];
         if (!LAST) {
             t[4 * c + 0] = tlook<0, 0>(a, lc); t[4 * c + 1] = tlook<1, 1>(b, lc);
             t[4 * c + 2] = tlook<2, 2>(cc, lc); t[4 * c + 3] = tlook<3, 3>(d, lc);
-        } else {
+        } else if (!DEC) {
             t[4 * c + 0] = tlook<2, 0>(a, lc); t[4 * c + 1] = tlook<3, 1>(b, lc);
             t[4 * c + 2] = tlook<0, 2>(cc, lc); t[4 * c + 3] = tlook<1, 3>(d, lc);
+        } else {
+            t[4 * c + 0] = tlook<0, 0>(a, lc); t[4 * c + 1] = tlook<0, 1>(b, lc);
+            t[4 * c + 2] = tlook<0, 2>(cc, lc); t[4 * c + 3] = tlook<0, 3>(d, lc);
         }
     }
 }
 
-template <bool LAST>
+/* Si[x0] | Si[x1] << 16 (bytes 1 and 3 are junk) from the Td0 words of x0 and x1:
+ * g = t ^ rot16(t) has b0^b2 | b1^b3 in its low half; pair the two low halves and
+ * fold the odd bytes onto the even ones.                                        */
+__device__ __forceinline__ u32 fold2(u32 t0, u32 t1)
+{
+    const u32 g0 = t0 ^ __builtin_amdgcn_alignbit(t0, t0, 16), g1 = t1 ^ __builtin_amdgcn_alignbit(t1, t1, 16);
+    const u32 p = __builtin_amdgcn_perm(g1, g0, 0x05040100u);       /* g0.b0 g0.b1 g1.b0 g1.b1 */
+    return p ^ (p >> 8);
+}
+
+template <bool LAST, bool DEC = false>
 __device__ __forceinline__ void combine16(const u32 (&t)[16], const u32 *rk, u32 (&s)[4])
 {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         if (!LAST)
             s[c] = xor3(xor3(t[4 * c], t[4 * c + 1], t[4 * c + 2]), t[4 * c + 3], rk[c]);
-        else
+        else if (!DEC)
             s[c] = or_xor(__builtin_amdgcn_perm(t[4 * c + 1], t[4 * c], 0x0c0c0500u),
                           __builtin_amdgcn_perm(t[4 * c + 3], t[4 * c + 2], 0x07020c0cu), rk[c]);
+        else                                          /* rows 0,1 | rows 2,3 -> bytes 0..3 */
+            s[c] = __builtin_amdgcn_perm(fold2(t[4 * c + 2], t[4 * c + 3]), fold2(t[4 * c], t[4 * c + 1]),
+                                         0x06040200u) ^ rk[c];
     }
 }
 
@@ -277,28 +271,28 @@ __device__ __forceinline__ void combine16(const u32 (&t)[16], const u32 *rk, u32
  * lock-step version drains them to zero every ~12 lookups).                 */
 /* RKV: round keys FIRST..NR as an array indexed from 0 (may live in VGPRs: a
  * v_bitop3_b32 with an SGPR operand issues ~1.5 cycles slower than all-VGPR) */
-template <int NR, int FIRST, typename RKV>
+template <int NR, int FIRST, typename RKV, bool DEC = false>
 __device__ __forceinline__ void enc_rounds_skewed(u32 (&sa)[4], u32 (&sb)[4], const RKV &rkv, const LaneConst &lc)
 {
 #define rkp(r) (&rkv.w[4 * ((r) - FIRST)])
     u32 ta[16], tb[16];
-    issue16<false>(sa, ta, lc);
+    issue16<false, DEC>(sa, ta, lc);
 #pragma unroll
     for (int r = FIRST; r < NR; ++r) {
         __builtin_amdgcn_sched_barrier(0);
-        issue16<false>(sb, tb, lc);
+        issue16<false, DEC>(sb, tb, lc);
         __builtin_amdgcn_sched_barrier(0);
-        combine16<false>(ta, rkp(r), sa);
-        if (r + 1 < NR) issue16<false>(sa, ta, lc); else issue16<true>(sa, ta, lc);
+        combine16<false, DEC>(ta, rkp(r), sa);
+        if (r + 1 < NR) issue16<false, DEC>(sa, ta, lc); else issue16<true, DEC>(sa, ta, lc);
         __builtin_amdgcn_sched_barrier(0);
-        combine16<false>(tb, rkp(r), sb);
+        combine16<false, DEC>(tb, rkp(r), sb);
     }
     __builtin_amdgcn_sched_barrier(0);
-    issue16<true>(sb, tb, lc);
+    issue16<true, DEC>(sb, tb, lc);
     __builtin_amdgcn_sched_barrier(0);
-    combine16<true>(ta, rkp(NR), sa);
+    combine16<true, DEC>(ta, rkp(NR), sa);
     __builtin_amdgcn_sched_barrier(0);
-    combine16<true>(tb, rkp(NR), sb);
+    combine16<true, DEC>(tb, rkp(NR), sb);
 #undef rkp
 }
 
@@ -316,45 +310,39 @@ __device__ __forceinline__ void enc_blocks_skewed(u32 (&sa)[4], u32 (&sb)[4], co
     enc_rounds_skewed<NR, 1>(sa, sb, v, lc);
 }
 
-/* ---- decryption rounds (equivalent inverse cipher, FIPS-197 sec. 5.3.5) - */
-/* Td2 = rotl16(Td0), Td3 = rotl16(Td1): one rotate per column              */
-template <int U>
-__device__ __forceinline__ void dec_round(u32 (&s)[U][4], const u32 *dk, const LaneConst &lc)
+/* ---- decryption (equivalent inverse cipher, FIPS-197 sec. 5.3.5) ---------- */
+/* two blocks, skewed; dk = equivalent-inverse round keys (uaesk_rk of uaes_device.h) */
+template <int NR>
+__device__ __forceinline__ void dec_blocks_skewed(u32 (&sa)[4], u32 (&sb)[4], const uaesk_rk &dk, const LaneConst &lc)
 {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const u32 a = s[u][0], b = s[u][1], c = s[u][2], d = s[u][3];
-        /* column j takes row r from column (j - r) mod 4 */
-        s[u][0] = xor3(tlook<0, 0>(a, lc), tlook<1, 1>(d, lc), dk[0]) ^ rotl32(tlook<0, 2>(c, lc) ^ tlook<1, 3>(b, lc), 16);
-        s[u][1] = xor3(tlook<0, 0>(b, lc), tlook<1, 1>(a, lc), dk[1]) ^ rotl32(tlook<0, 2>(d, lc) ^ tlook<1, 3>(c, lc), 16);
-        s[u][2] = xor3(tlook<0, 0>(c, lc), tlook<1, 1>(b, lc), dk[2]) ^ rotl32(tlook<0, 2>(a, lc) ^ tlook<1, 3>(d, lc), 16);
-        s[u][3] = xor3(tlook<0, 0>(d, lc), tlook<1, 1>(c, lc), dk[3]) ^ rotl32(tlook<0, 2>(b, lc) ^ tlook<1, 3>(a, lc), 16);
-    }
+    for (int c = 0; c < 4; ++c) { sa[c] ^= dk.w[c]; sb[c] ^= dk.w[c]; }
+    const RkView v = { dk.w + 4 };
+    enc_rounds_skewed<NR, 1, RkView, true>(sa, sb, v, lc);
 }
 
-template <int U>
-__device__ __forceinline__ void dec_last_round(u32 (&s)[U][4], const u32 *dk, u32 slot)
-{
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const u32 a = s[u][0], b = s[u][1], c = s[u][2], d = s[u][3];
-        s[u][0] = pick4(silook<0>(a, slot), silook<1>(d, slot), silook<2>(c, slot), silook<3>(b, slot), dk[0]);
-        s[u][1] = pick4(silook<0>(b, slot), silook<1>(a, slot), silook<2>(d, slot), silook<3>(c, slot), dk[1]);
-        s[u][2] = pick4(silook<0>(c, slot), silook<1>(b, slot), silook<2>(a, slot), silook<3>(d, slot), dk[2]);
-        s[u][3] = pick4(silook<0>(d, slot), silook<1>(c, slot), silook<2>(b, slot), silook<3>(a, slot), dk[3]);
-    }
-}
-
+/* U blocks: pairs run skewed, a single block runs the same code against a dummy partner-free path */
 template <int NR, int U>
 __device__ __forceinline__ void dec_blocks(u32 (&s)[U][4], const uaesk_rk &dk, const LaneConst &lc)
 {
+    if (U % 2 == 0) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-        s[u][0] ^= dk.w[0]; s[u][1] ^= dk.w[1]; s[u][2] ^= dk.w[2]; s[u][3] ^= dk.w[3];
+        for (int u = 0; u < U; u += 2) dec_blocks_skewed<NR>(s[u], s[(u + 1) % U], dk, lc);
+        return;
     }
 #pragma unroll
-    for (int r = 1; r < NR; ++r) dec_round<U>(s, &dk.w[4 * r], lc);
-    dec_last_round<U>(s, &dk.w[4 * NR], lc.t[0]);
+    for (int u = 0; u < U; ++u) {
+        u32 t[16];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s[u][c] ^= dk.w[c];
+#pragma unroll
+        for (int r = 1; r < NR; ++r) {
+            issue16<false, true>(s[u], t, lc);
+            combine16<false, true>(t, &dk.w[4 * r], s[u]);
+        }
+        issue16<true, true>(s[u], t, lc);
+        combine16<true, true>(t, &dk.w[4 * NR], s[u]);
+    }
 }
 
 #endif

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(UAES_WG) void k_fb_dec(uaesk_rk rk, uaesk_tables tb
                                                     const uint4 *__restrict__ in, uint4 *__restrict__ out,
                                                     u64 n, u32 rem)
 {
-    if (CFB) fill_enc_tables(tb.te0); else fill_dec_tables(tb.td0, tb.si4);
+    if (CFB) fill_enc_tables(tb.te0); else fill_dec_tables(tb.td0);
     const LaneConst lc = make_lane_const();
     const u64 stride = (u64)gridDim.x * UAES_WG * UAES_U;
     for (u64 base = (u64)blockIdx.x * UAES_WG * UAES_U; base < n; base += stride) {
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(UAES_WG) void k_chain_serial(uaesk_rk rk, uaesk_tab
                                                           const unsigned char *__restrict__ in,
                                                           unsigned char *__restrict__ out, u64 len)
 {
-    if (OP == CH_CBC_DEC_CTS) fill_dec_tables(tb.td0, tb.si4); else fill_enc_tables(tb.te0);
+    if (OP == CH_CBC_DEC_CTS) fill_dec_tables(tb.td0); else fill_enc_tables(tb.te0);
     if (threadIdx.x != 0) return;
     const LaneConst lc = make_lane_const();
     if (iv_dev) iv4 = *iv_dev;

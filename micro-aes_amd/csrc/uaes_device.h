@@ -24,8 +24,7 @@ typedef struct {
 /* Read-only device tables uploaded once per context by the host layer. */
 typedef struct {
     const uint32_t *te0;   /* 256 words: bytes {2S,S,S,3S}[x]              */
-    const uint32_t *td0;   /* 256 words: bytes {14Si,9Si,13Si,11Si}[x]     */
-    const uint32_t *si4;   /* 256 words: Si[x] replicated in all 4 bytes   */
+    const uint32_t *td0;   /* 256 words: bytes {14Si,9Si,13Si,11Si}[x] (their XOR is Si[x]) */
 } uaesk_tables;
 
 /* 56-bit big-endian counter description (reference: incBlock with index 15

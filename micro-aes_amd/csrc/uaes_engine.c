@@ -61,7 +61,7 @@ const char *uaes_version(void) { return UAES_VERSION; }
 /* generator 0x03, then uploaded to every device context.                     */
 /* ------------------------------------------------------------------------ */
 static uint8_t  h_sbox[256], h_isbox[256];
-static uint32_t h_te0[256], h_td0[256], h_si4[256];
+static uint32_t h_te0[256], h_td0[256];
 static pthread_once_t tables_once = PTHREAD_ONCE_INIT;
 
 static uint8_t xtime(uint8_t a) { return (uint8_t)((a << 1) ^ ((a >> 7) * 0x1b)); }
@@ -95,7 +95,6 @@ static void build_host_tables(void)
         uint8_t vd = (uint8_t)(v8 ^ v4 ^ v), ve = (uint8_t)(v8 ^ v4 ^ v2);
         h_te0[i] = (uint32_t)s2 | ((uint32_t)s << 8) | ((uint32_t)s << 16) | ((uint32_t)s3 << 24);
         h_td0[i] = (uint32_t)ve | ((uint32_t)v9 << 8) | ((uint32_t)vd << 16) | ((uint32_t)vb << 24);
-        h_si4[i] = (uint32_t)v * 0x01010101u;
     }
 }
 
@@ -213,14 +212,12 @@ static int get_context(context **out)
             err = hipMalloc(&c->d_tables, 3 * 1024 + 64);
             if (err == hipSuccess) err = hipMemcpy(c->d_tables, h_te0, 1024, hipMemcpyHostToDevice);
             if (err == hipSuccess) err = hipMemcpy((char *)c->d_tables + 1024, h_td0, 1024, hipMemcpyHostToDevice);
-            if (err == hipSuccess) err = hipMemcpy((char *)c->d_tables + 2048, h_si4, 1024, hipMemcpyHostToDevice);
             if (err != hipSuccess) {
                 pthread_mutex_unlock(&g_init_mu);
                 return fail(UAES_E_HIP, "context setup failed: %s", hipGetErrorString(err));
             }
             c->tb.te0 = (const uint32_t *)c->d_tables;
             c->tb.td0 = (const uint32_t *)((char *)c->d_tables + 1024);
-            c->tb.si4 = (const uint32_t *)((char *)c->d_tables + 2048);
             c->d_status = (int *)((char *)c->d_tables + 3072);
             pthread_mutex_init(&c->mu, NULL);
             uaesk_device_info(NULL, NULL);

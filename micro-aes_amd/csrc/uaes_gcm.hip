@@ -553,7 +553,7 @@ extern "C" int uaesk_ghash(void *stream, const uint8_t *H_host,
     uint4 h;
     memcpy(&h, H_host, 16);
     uaesk_rk dummy_rk;
-    uaesk_tables dummy_tb = { nullptr, nullptr, nullptr };
+    uaesk_tables dummy_tb = { nullptr, nullptr };
     memset(&dummy_rk, 0, sizeof dummy_rk);
     int rc = launch_setup<10>(st, &dummy_tb, &dummy_rk, make_uint4(0, 0, 0, 0), sc, pl, 1, h);
     if (rc) return rc;
@@ -749,7 +749,7 @@ extern "C" int uaesk_polyval(void *stream, const uint8_t *hg_host,
     uint4 h;
     memcpy(&h, hg_host, 16);
     uaesk_rk dummy_rk;
-    uaesk_tables dummy_tb = { nullptr, nullptr, nullptr };
+    uaesk_tables dummy_tb = { nullptr, nullptr };
     memset(&dummy_rk, 0, sizeof dummy_rk);
     int rc = launch_setup<10>(st, &dummy_tb, &dummy_rk, make_uint4(0, 0, 0, 0), sc, pl, 1, h);
     if (rc) return rc;

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(UAES_WG) void k_ecb(uaesk_rk rk, uaesk_tables tb,
                                                  const uint4 *__restrict__ in, uint4 *__restrict__ out,
                                                  u64 nfull, u32 rem)
 {
-    if (DEC) fill_dec_tables(tb.td0, tb.si4); else fill_enc_tables(tb.te0);
+    if (DEC) fill_dec_tables(tb.td0); else fill_enc_tables(tb.te0);
     const LaneConst lc = make_lane_const();
     const u64 stride = (u64)gridDim.x * UAES_WG * UAES_U;
 
@@ -526,7 +526,7 @@ __global__ __launch_bounds__(UAES_WG) void k_xts(uaesk_rk k1, uaesk_tables tb,
                                                  const unsigned char *__restrict__ in,
                                                  unsigned char *__restrict__ out)
 {
-    if (DEC) fill_dec_tables(tb.td0, tb.si4); else fill_enc_tables(tb.te0);
+    if (DEC) fill_dec_tables(tb.td0); else fill_enc_tables(tb.te0);
     const LaneConst lc = make_lane_const();
     const u32 lane = threadIdx.x & 63u;
     const u64 wave = (u64)blockIdx.x * (UAES_WG / 64) + (threadIdx.x >> 6);
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(UAES_WG) void k_xts_cts(uaesk_rk k1, uaesk_tables t
                                                      const unsigned char *__restrict__ in,
                                                      unsigned char *__restrict__ out)
 {
-    if (DEC) fill_dec_tables(tb.td0, tb.si4); else fill_enc_tables(tb.te0);
+    if (DEC) fill_dec_tables(tb.td0); else fill_enc_tables(tb.te0);
     const LaneConst lc = make_lane_const();
     const u64 stride = (u64)gridDim.x * UAES_WG;
     for (u64 sct = (u64)blockIdx.x * UAES_WG + threadIdx.x; sct < nsectors; sct += stride) {
@@ -680,7 +680,7 @@ __global__ __launch_bounds__(UAES_WG) void k_selftest(uaesk_rk ek, uaesk_rk dk, 
     enc_blocks<10, 1>(s, ek, lc);
     if (s[0][0] != 0xd8e0c469u || s[0][1] != 0x30047b6au || s[0][2] != 0x80b7cdd8u || s[0][3] != 0x5ac5b470u) bad |= 16;
     __syncthreads();
-    fill_dec_tables(tb.td0, tb.si4);
+    fill_dec_tables(tb.td0);
     dec_blocks<10, 1>(s, dk, lc);
     if (s[0][0] != 0x33221100u || s[0][1] != 0x77665544u || s[0][2] != 0xbbaa9988u || s[0][3] != 0xffeeddccu) bad |= 32;
     /* XTS tweak arithmetic: alpha^k by shifting == k doublings */

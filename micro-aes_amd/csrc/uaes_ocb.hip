@@ -157,7 +157,7 @@ __global__ __launch_bounds__(UAES_WG) void k_ocb(uaesk_rk rk, uaesk_tables tb,
     /* run (a power of two <= OCB_RUN_MAX) = consecutive chunks per wave; short texts use
      * short runs so that every CU gets work                                        */
     ocb_tables_to_lds(scr);
-    if (DEC) fill_dec_tables(tb.td0, tb.si4); else fill_enc_tables(tb.te0);
+    if (DEC) fill_dec_tables(tb.td0); else fill_enc_tables(tb.te0);
     const LaneConst lc = make_lane_const();
     const u32 lane = threadIdx.x & 63u;
     const u64 wave = (u64)blockIdx.x * (UAES_WG / 64) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
