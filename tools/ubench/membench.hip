@@ -61,6 +61,7 @@ __global__ void k_fill(u64 *p, u64 nwords)
     }
 }
 
+static int g_reps = 40;
 static unsigned char sbox[256];
 static void make_sbox()
 {
@@ -83,7 +84,7 @@ static void run(const char *name, const uaesk_rk &rk, const u32 *te0, const uint
     u64 *d_cyc, h_cyc = 0; (void)hipMalloc(&d_cyc, 8);
     for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(UAES_WG), UAES_LDS_ENC, 0, rk, te0, in, out, nblk, d_cyc);
     (void)hipEventRecord(e0);
-    const int reps = 40;
+    const int reps = g_reps;
     for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(UAES_WG), UAES_LDS_ENC, 0, rk, te0, in, out, nblk, d_cyc);
     (void)hipEventRecord(e1); (void)hipDeviceSynchronize();
     float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= reps;
@@ -93,7 +94,7 @@ static void run(const char *name, const uaesk_rk &rk, const u32 *te0, const uint
            (double)h_cyc * 256 / nblk);
 }
 
-int main(int argc, char **)
+int main(int argc, char **argv)
 {
     make_sbox();
     u32 te0[256];
@@ -112,6 +113,16 @@ int main(int argc, char **)
         (void)hipDeviceSynchronize();
         printf("input: splitmix64 stream\n");
     } else printf("input: constant 0x5a bytes\n");
+    if (argc > 3) {                                  /* membench random <mode> <reps>: one long run (clock polling) */
+        g_reps = atoi(argv[3]);
+        switch (atoi(argv[2])) {
+        case 0: run<0>("load + store", rk, d_te0, in, out, nblk); break;
+        case 3: run<3>("no load, no store", rk, d_te0, in, out, nblk); break;
+        case 1: run<1>("no load", rk, d_te0, in, out, nblk); break;
+        default: run<2>("no store", rk, d_te0, in, out, nblk); break;
+        }
+        return 0;
+    }
     for (int pass = 0; pass < 3; ++pass) {           /* the first pass also warms the clocks up */
         printf("pass %d\n", pass);
         run<0>("load + store", rk, d_te0, in, out, nblk);
