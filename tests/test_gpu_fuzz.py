@@ -1,0 +1,257 @@
+"""Seeded differential fuzzing of the C ABI against the CPU oracle: random key sizes,
+sizes drawn around the kernels' internal boundaries (16 B blocks, 256-block chunks, 16-chunk
+runs, 256 KiB CTR chunks and whole rounds of them, GHASH level plans), host or device
+pointers, aligned or not, in place or not.  Every case is reproducible from its printed tuple."""
+import ctypes as C
+import random
+
+import pytest
+
+import micro_aes_amd as uaes
+
+pytestmark = pytest.mark.gpu
+
+EDGES = [0, 1, 15, 16, 17, 31, 32, 48, 255, 256, 4095, 4096, 4097, 65535, 65536, 65537,
+         256 * 16, 256 * 16 * 16, 256 * 16 * 16 + 16, 1 << 18, (1 << 18) + 16, 3 << 18, 1 << 20]
+
+
+def pick_size(rnd, cap):
+    r = rnd.random()
+    if r < 0.5:
+        n = rnd.choice(EDGES) + rnd.choice([0, 0, 0, 1, 16, -1, -16, 5])
+    elif r < 0.8:
+        n = rnd.randrange(0, 70000)
+    else:
+        n = rnd.randrange(0, cap)
+    return max(0, min(n, cap))
+
+
+class Buffers:
+    """input/output placement for one case: host or device memory, offset from a 16-byte
+    boundary or not, output aliased with the input or not"""
+
+    def __init__(self, rnd, data, out_len):
+        import torch
+        self.torch = torch
+        self.n_in, self.n_out = len(data), out_len
+        self.dev_in, self.dev_out = rnd.random() < 0.5, rnd.random() < 0.5
+        self.off_in, self.off_out = rnd.choice([0, 0, 1, 3, 8]), rnd.choice([0, 0, 2, 5, 8])
+        self.alias = rnd.random() < 0.3
+        cap = max(len(data), out_len) + 64
+        self.guard = 0xA5
+        if self.alias:
+            self.dev_out, self.off_out = self.dev_in, self.off_in
+        if self.dev_in:
+            self.tin = torch.full((cap,), self.guard, dtype=torch.uint8, device="cuda:0")
+            if data:
+                self.tin[self.off_in:self.off_in + len(data)] = torch.frombuffer(bytearray(data), dtype=torch.uint8).to("cuda:0")
+            self.pin = C.c_void_p(self.tin.data_ptr() + self.off_in)
+        else:
+            self.hin = self._host(cap)
+            C.memmove(C.addressof(self.hin) + self.off_in, data, len(data))
+            self.pin = C.c_void_p(C.addressof(self.hin) + self.off_in)
+        if self.alias:
+            self.pout = self.pin
+        elif self.dev_out:
+            self.tout = torch.full((cap,), self.guard, dtype=torch.uint8, device="cuda:0")
+            self.pout = C.c_void_p(self.tout.data_ptr() + self.off_out)
+        else:
+            self.hout = self._host(cap)
+            self.pout = C.c_void_p(C.addressof(self.hout) + self.off_out)
+
+    def _host(self, cap):
+        b = (C.c_uint8 * cap)()
+        C.memset(b, self.guard, cap)
+        return b
+
+    def result(self, n=None):
+        """(output bytes, guard bytes behind them intact?)"""
+        n = self.n_out if n is None else n
+        if self.alias:
+            src, off, dev = (self.tin if self.dev_in else self.hin), self.off_in, self.dev_in
+        else:
+            src, off, dev = (self.tout if self.dev_out else self.hout), self.off_out, self.dev_out
+        if dev:
+            self.torch.cuda.synchronize()
+            raw = bytes(src.cpu().numpy())
+        else:
+            raw = bytes(src)
+        tail = raw[off + max(n, self.n_in if self.alias else 0):]
+        return raw[off:off + n], all(b == self.guard for b in tail[:16])
+
+    def describe(self):
+        return dict(dev_in=self.dev_in, dev_out=self.dev_out, off_in=self.off_in, off_out=self.off_out, alias=self.alias)
+
+
+def run_cases(seed, count, body):
+    rnd = random.Random(seed)
+    for i in range(count):
+        body(rnd, i)
+
+
+def test_fuzz_ctr_ecb(orc):
+    L = uaes.engine()
+
+    def body(rnd, i):
+        bits = rnd.choice([128, 192, 256])
+        key = rnd.randbytes(bits // 8)
+        n = pick_size(rnd, 3 << 20)
+        data = orc.splitmix(1000 + i, n)
+        # CTR with a random start counter (56-bit carries) and block offset
+        ctr0 = rnd.randbytes(9) + rnd.choice([bytes(7), b"\xff" * 7, rnd.randbytes(7), b"\0\0\0\xff\xff\xff\xfe"])
+        off = rnd.choice([0, 1, 255, 256, 1 << 20, (1 << 32) - 3])
+        b = Buffers(rnd, data, n)
+        info = ("ctr", bits, n, off, ctr0.hex(), b.describe())
+        assert L.uaes_ctr_xcrypt_at(bits, key, ctr0, off, b.pin, n, b.pout) == 0, info
+        got, guard_ok = b.result()
+        assert got == orc.ctr_xcrypt_at(key, ctr0, off, data) and guard_ok, info
+        # ECB: N1 zero padding on encrypt, 0x1D on a ragged decrypt
+        padded = (n + 15) // 16 * 16
+        b = Buffers(rnd, data, padded)
+        info = ("ecb", bits, n, b.describe())
+        assert L.uaes_ecb_encrypt(bits, key, b.pin, n, b.pout) == 0, info
+        got, guard_ok = b.result()
+        want = orc.ecb_encrypt(key, data)
+        assert got == want and guard_ok, info
+        b = Buffers(rnd, want, padded)
+        assert L.uaes_ecb_decrypt(bits, key, b.pin, padded, b.pout) == 0, info
+        assert b.result()[0][:n] == data, info
+
+    run_cases(101, 150, body)
+
+
+def test_fuzz_xts(orc):
+    L = uaes.engine()
+
+    def body(rnd, i):
+        bits = rnd.choice([128, 192, 256])
+        keys, tweak = rnd.randbytes(bits // 4), rnd.randbytes(16)
+        n = max(16, pick_size(rnd, 2 << 20))
+        data = orc.splitmix(2000 + i, n)
+        b = Buffers(rnd, data, n)
+        info = ("xts", bits, n, b.describe())
+        assert L.uaes_xts_encrypt(bits, keys, tweak, b.pin, n, b.pout) == 0, info
+        got, guard_ok = b.result()
+        rc, want = orc.xts(keys, tweak, data, True)
+        assert rc == 0 and got == want and guard_ok, info
+        b = Buffers(rnd, want, n)
+        assert L.uaes_xts_decrypt(bits, keys, tweak, b.pin, n, b.pout) == 0, info
+        assert b.result()[0] == data, info
+        # batched data units of a random size (ciphertext stealing when ragged)
+        sb = rnd.choice([16, 17, 31, 512, 520, 4096, 4099, 65536 + 7])
+        ns = rnd.randrange(1, 40 if sb < 5000 else 4)
+        first = rnd.choice([0, 1, (1 << 32) - 1, rnd.getrandbits(60)])
+        data = orc.splitmix(2500 + i, sb * ns)
+        b = Buffers(rnd, data, sb * ns)
+        info = ("xts_sectors", bits, sb, ns, first, b.describe())
+        assert L.uaes_xts_sectors(bits, keys, first, sb, ns, b.pin, b.pout, 1) == 0, info
+        got, guard_ok = b.result()
+        assert got == orc.xts_sectors(keys, first, sb, data, True)[1] and guard_ok, info
+
+    run_cases(202, 100, body)
+
+
+def test_fuzz_aead(orc):
+    L = uaes.engine()
+    modes = {
+        "gcm": (L.uaes_gcm_encrypt, L.uaes_gcm_decrypt, orc.gcm_encrypt, 300 << 10),
+        "ocb": (L.uaes_ocb_encrypt, L.uaes_ocb_decrypt, orc.ocb_encrypt, 2 << 20),
+        "gcmsiv": (L.uaes_gcmsiv_encrypt, L.uaes_gcmsiv_decrypt, orc.gcmsiv_encrypt, 40 << 10),
+    }
+
+    def body(rnd, i):
+        name = rnd.choice(list(modes))
+        enc, dec, ref, cap = modes[name]
+        bits = rnd.choice([128, 192, 256])
+        key, nonce = rnd.randbytes(bits // 8), rnd.randbytes(12)
+        aad = rnd.randbytes(rnd.choice([0, 0, 1, 15, 16, 17, 100, 4096, 5000]))
+        n = pick_size(rnd, cap)
+        data = orc.splitmix(3000 + i, n)
+        want = ref(key, nonce, aad, data)
+        b = Buffers(rnd, data, n + 16)
+        info = (name, bits, n, len(aad), b.describe())
+        assert enc(bits, key, nonce, aad, len(aad), b.pin, n, b.pout) == 0, info
+        got, guard_ok = b.result()
+        assert got == want and guard_ok, info
+        b = Buffers(rnd, want, n)
+        assert dec(bits, key, nonce, aad, len(aad), b.pin, n, b.pout) == 0, info
+        assert b.result()[0] == data, info
+        # one flipped bit anywhere (text, tag or aad) must be rejected
+        bad = bytearray(want)
+        where = rnd.randrange(len(bad))
+        bad[where] ^= 1 << rnd.randrange(8)
+        b = Buffers(rnd, bytes(bad), n)
+        assert dec(bits, key, nonce, aad, len(aad), b.pin, n, b.pout) == 0x1A, info + (where,)
+        if name == "gcm" and not b.alias:            # N7: plaintext buffer untouched
+            assert all(x == b.guard for x in b.result()[0]), info
+
+    run_cases(303, 160, body)
+
+
+def test_fuzz_feedback_and_macs(orc):
+    L = uaes.engine()
+
+    def body(rnd, i):
+        bits = rnd.choice([128, 192, 256])
+        key, iv = rnd.randbytes(bits // 8), rnd.randbytes(16)
+        n = pick_size(rnd, 40 << 10)
+        data = orc.splitmix(4000 + i, n)
+        # CFB / OFB: any length
+        for name, f_enc, f_dec, want in (
+                ("cfb", L.uaes_cfb_encrypt, L.uaes_cfb_decrypt, orc.cfb(key, iv, data, True)),
+                ("ofb", L.uaes_ofb_xcrypt, L.uaes_ofb_xcrypt, orc.ofb(key, iv, data))):
+            b = Buffers(rnd, data, n)
+            info = (name, bits, n, b.describe())
+            assert f_enc(bits, key, iv, b.pin, n, b.pout) == 0, info
+            got, guard_ok = b.result()
+            assert got == want and guard_ok, info
+            b = Buffers(rnd, want, n)
+            assert f_dec(bits, key, iv, b.pin, n, b.pout) == 0, info
+            assert b.result()[0] == data, info
+        # CBC with CS3 stealing: len >= 16
+        if n >= 16:
+            rc, want = orc.cbc(key, iv, data, True)
+            b = Buffers(rnd, data, n)
+            info = ("cbc", bits, n, b.describe())
+            assert L.uaes_cbc_encrypt(bits, key, iv, b.pin, n, b.pout) == 0 and rc == 0, info
+            got, guard_ok = b.result()
+            assert got == want and guard_ok, info
+            b = Buffers(rnd, want, n)
+            assert L.uaes_cbc_decrypt(bits, key, iv, b.pin, n, b.pout) == 0, info
+            assert b.result()[0] == data, info
+        # CMAC
+        mac = (C.c_uint8 * 16)()
+        b = Buffers(rnd, data, 0)
+        assert L.uaes_cmac(bits, key, b.pin, n, mac) == 0
+        assert bytes(mac) == orc.cmac(key, data), ("cmac", bits, n, b.describe())
+
+    run_cases(404, 80, body)
+
+
+def test_fuzz_ctr_large_sizes_piecewise(orc):
+    """60-200 MiB texts (several rounds of 256 KiB chunks plus thin last rounds): one call equals
+    three calls over random 16-byte-aligned cuts with the block offset advanced, and the first and
+    last 64 KiB equal the oracle's"""
+    import torch
+    rnd = random.Random(505)
+    for _ in range(5):
+        bits = rnd.choice([128, 256])
+        key = rnd.randbytes(bits // 8)
+        n = rnd.randrange(60 << 20, 200 << 20) // 16 * 16 + rnd.choice([0, 0, 7])
+        ctr0 = rnd.randbytes(12) + b"\xff\xff" + rnd.randbytes(2)
+        src = torch.randint(0, 256, (n,), dtype=torch.uint8, device="cuda:0")
+        one = torch.empty_like(src)
+        uaes.ctr_xcrypt_dev(key, ctr0, 5, src, one, nbytes=n)
+        cuts = sorted(rnd.randrange(0, n // 16) * 16 for _ in range(2))
+        parts = torch.empty_like(src)
+        for lo, hi in zip([0] + cuts, cuts + [n]):
+            if hi > lo:
+                uaes.ctr_xcrypt_dev(key, ctr0, 5 + lo // 16, src[lo:hi], parts[lo:hi], nbytes=hi - lo)
+        torch.cuda.synchronize()
+        assert torch.equal(one, parts), (bits, n, cuts)
+        m = 1 << 16
+        head = bytes(src[:m].cpu().numpy())
+        assert bytes(one[:m].cpu().numpy()) == orc.ctr_xcrypt_at(key, ctr0, 5, head)
+        t0 = (n - m) // 16 * 16
+        tail = bytes(src[t0:].cpu().numpy())
+        assert bytes(one[t0:].cpu().numpy()) == orc.ctr_xcrypt_at(key, ctr0, 5 + t0 // 16, tail)
