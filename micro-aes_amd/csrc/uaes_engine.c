@@ -177,14 +177,25 @@ int uaes_expand_key(int keybits, const uint8_t *key, uint32_t enc_words[60], uin
 /* ------------------------------------------------------------------------ */
 /* per-device context                                                         */
 /* ------------------------------------------------------------------------ */
+/* Device scratch (GHASH tables and accumulators, XTS chunk tweaks, OCB offsets) is private
+ * to the stream a call is enqueued on: work on one stream is ordered, work on different
+ * streams may overlap, so several *_dev calls can be in flight per device.             */
+#define SCRATCH_SLOTS 8
+
 typedef struct {
     int             ready;
     uaesk_tables    tb;
     void           *d_tables;
     void           *stage[2];
     size_t          stage_cap[2];
-    void           *scratch;
-    size_t          scratch_cap;
+    void           *scratch;        /* scratch of the call being set up (one of the slots below) */
+    struct {
+        void  *stream;              /* hipStream_t the slot belongs to (NULL = default stream) */
+        int    used;
+        void  *buf;
+        size_t cap;
+    } slot[SCRATCH_SLOTS];
+    int             next_victim;
     void           *aad_stage;
     size_t          aad_cap;
     int            *d_status;
@@ -241,6 +252,26 @@ static int grow(void **buf, size_t *cap, size_t need)
     need = (need + (1u << 20)) & ~(((size_t)1 << 20) - 1);
     HIPCHK(hipMalloc(buf, need));
     *cap = need;
+    return 0;
+}
+
+/* scratch of at least `need` bytes for work enqueued on `stream`; caller holds c->mu */
+static int scratch_for(context *c, void *stream, size_t need)
+{
+    int i, k = -1;
+    for (i = 0; i < SCRATCH_SLOTS && k < 0; ++i)
+        if (c->slot[i].used && c->slot[i].stream == stream) k = i;
+    for (i = 0; i < SCRATCH_SLOTS && k < 0; ++i)
+        if (!c->slot[i].used) k = i;
+    if (k < 0) {                                  /* all taken: drain the device, recycle one */
+        HIPCHK(hipDeviceSynchronize());
+        k = c->next_victim;
+        c->next_victim = (c->next_victim + 1) % SCRATCH_SLOTS;
+    }
+    c->slot[k].used = 1;
+    c->slot[k].stream = stream;
+    if (grow(&c->slot[k].buf, &c->slot[k].cap, need)) return UAES_E_HIP;
+    c->scratch = c->slot[k].buf;
     return 0;
 }
 
@@ -478,12 +509,14 @@ static int xts_run(context *c, void *stream, keysched *k1, keysched *k2, int enc
                    int stream_owned_lock)       /* 1: caller does not hold c->mu (the *_dev path) */
 {
     const size_t need = uaesk_xts_scratch_bytes(sector_bytes, nsectors);
+    void *scr;
     if (stream_owned_lock) pthread_mutex_lock(&c->mu);
-    const int g = grow(&c->scratch, &c->scratch_cap, need);
+    const int g = scratch_for(c, stream, need);
+    scr = c->scratch;
     if (stream_owned_lock) pthread_mutex_unlock(&c->mu);
     if (g) return UAES_E_HIP;
     KCHK(uaesk_xts(stream, &c->tb, k1->nr, encrypt ? &k1->ek : &k1->dk, &k2->ek, !encrypt,
-                   tweak16, first_sector, sector_bytes, nsectors, din, dout, c->scratch));
+                   tweak16, first_sector, sector_bytes, nsectors, din, dout, scr));
     return 0;
 }
 
@@ -547,18 +580,19 @@ int uaes_xts_sectors_dev(int keybits, const uint8_t *keys, uint64_t first_sector
 /* ------------------------------------------------------------------------ */
 /* GCM                                                                        */
 /* ------------------------------------------------------------------------ */
-static int gcm_scratch(context *c)
+static int gcm_scratch(context *c)               /* synchronous API: default stream, lock held */
 {
-    return grow(&c->scratch, &c->scratch_cap, uaesk_gcm_scratch_bytes());
+    return scratch_for(c, NULL, uaesk_gcm_scratch_bytes());
 }
 
 /* the *_dev entry points do not hold the context lock while the GPU works (they only
  * enqueue), but growing the shared scratch buffer must not race with another thread */
-static int gcm_scratch_locked(context *c)
+static int gcm_scratch_locked(context *c, void *stream, void **scr)
 {
     int rc;
     pthread_mutex_lock(&c->mu);
-    rc = gcm_scratch(c);
+    rc = scratch_for(c, stream, uaesk_gcm_scratch_bytes());
+    *scr = c->scratch;
     pthread_mutex_unlock(&c->mu);
     return rc;
 }
@@ -642,12 +676,13 @@ int uaes_gcm_encrypt_dev(int keybits, const uint8_t *key, const uint8_t *nonce,
 {
     context *c;
     keysched ks;
+    void *scr;
     int rc;
     if ((rc = expand_key(&ks, key, keybits)) != 0) return rc;
     if ((rc = get_context(&c)) != 0) return rc;
-    if ((rc = gcm_scratch_locked(c)) != 0) return rc;
+    if ((rc = gcm_scratch_locked(c, stream, &scr)) != 0) return rc;
     KCHK(uaesk_gcm(stream, &c->tb, ks.nr, &ks.ek, 0, nonce, d_aad, aad_len, d_in, len, d_out,
-                   c->scratch, NULL));
+                   scr, NULL));
     return 0;
 }
 
@@ -658,13 +693,14 @@ int uaes_gcm_decrypt_dev(int keybits, const uint8_t *key, const uint8_t *nonce,
 {
     context *c;
     keysched ks;
+    void *scr;
     int rc;
     if ((rc = expand_key(&ks, key, keybits)) != 0) return rc;
     if (!d_status) return fail(UAES_E_ARG, "NULL d_status");
     if ((rc = get_context(&c)) != 0) return rc;
-    if ((rc = gcm_scratch_locked(c)) != 0) return rc;
+    if ((rc = gcm_scratch_locked(c, stream, &scr)) != 0) return rc;
     KCHK(uaesk_gcm(stream, &c->tb, ks.nr, &ks.ek, 1, nonce, d_aad, aad_len, d_in, len, d_out,
-                   c->scratch, d_status));
+                   scr, d_status));
     return 0;
 }
 
@@ -675,6 +711,7 @@ int uaes_gcm_partial_dev(int keybits, const uint8_t *key, const uint8_t *nonce,
 {
     context *c;
     keysched ks;
+    void *scr;
     int rc;
     if ((rc = expand_key(&ks, key, keybits)) != 0) return rc;
     if (!nonce || !d_partial16) return fail(UAES_E_ARG, "NULL pointer");
@@ -682,9 +719,9 @@ int uaes_gcm_partial_dev(int keybits, const uint8_t *key, const uint8_t *nonce,
         return fail(UAES_E_ARG, "shard [%llu, +%zu) is not a 16-byte aligned slice of %llu bytes",
                     (unsigned long long)shard_offset, shard_len, (unsigned long long)total_len);
     if ((rc = get_context(&c)) != 0) return rc;
-    if ((rc = gcm_scratch_locked(c)) != 0) return rc;
+    if ((rc = gcm_scratch_locked(c, stream, &scr)) != 0) return rc;
     KCHK(uaesk_gcm_partial(stream, &c->tb, ks.nr, &ks.ek, nonce, d_aad, total_aad_len,
-                           d_ct_shard, shard_len, shard_offset, total_len, c->scratch, d_partial16));
+                           d_ct_shard, shard_len, shard_offset, total_len, scr, d_partial16));
     return 0;
 }
 
@@ -1059,13 +1096,14 @@ int uaes_ocb_dev(int keybits, const uint8_t *key, const uint8_t *nonce, int decr
 {
     context *c;
     keysched ks;
+    void *scr;
     int rc;
     if ((rc = expand_key(&ks, key, keybits)) != 0) return rc;
     if (decrypt && !d_status) return fail(UAES_E_ARG, "NULL d_status");
     if ((rc = get_context(&c)) != 0) return rc;
-    if ((rc = gcm_scratch_locked(c)) != 0) return rc;
+    if ((rc = gcm_scratch_locked(c, stream, &scr)) != 0) return rc;
     KCHK(uaesk_ocb(stream, &c->tb, ks.nr, &ks.ek, &ks.dk, decrypt, nonce, d_aad, aad_len, d_in, len, d_out,
-                   c->scratch, d_status));
+                   scr, d_status));
     return 0;
 }
 

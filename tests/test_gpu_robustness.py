@@ -113,3 +113,42 @@ def test_ctr_stream_larger_than_4GiB(orc):
     uaes.ctr_xcrypt_dev(key, ctr0, 0, dst, dst)
     torch.cuda.synchronize()
     assert torch.equal(dst[: 1 << 30], src[: 1 << 30]) and torch.equal(dst[-(1 << 30):], src[-(1 << 30):])
+
+
+def test_dev_calls_on_different_streams_do_not_share_scratch(orc):
+    """GCM / OCB / XTS *_dev calls enqueued on four streams at once (each call builds its own GHASH
+    tables, offsets or chunk tweaks in device scratch) give the results of running them one by one"""
+    import torch
+    rnd = random.Random(77)
+    n = 3 << 20
+    jobs = []
+    for i in range(4):
+        key, nonce = rnd.randbytes(16), rnd.randbytes(12)
+        src = torch.randint(0, 256, (n,), dtype=torch.uint8, device="cuda:0")
+        jobs.append(dict(key=key, nonce=nonce, keys2=rnd.randbytes(32), src=src, st=torch.cuda.Stream(),
+                         gcm=torch.empty(n + 16, dtype=torch.uint8, device="cuda:0"),
+                         ocb=torch.empty(n + 16, dtype=torch.uint8, device="cuda:0"),
+                         xts=torch.empty(n, dtype=torch.uint8, device="cuda:0")))
+    want = []
+    for j in jobs:                                   # reference results, one at a time on the default stream
+        g, o, x = torch.empty_like(j["gcm"]), torch.empty_like(j["ocb"]), torch.empty_like(j["xts"])
+        uaes.gcm_encrypt_dev(j["key"], j["nonce"], None, j["src"], n, g)
+        uaes.ocb_dev(j["key"], j["nonce"], None, j["src"], n, o)
+        uaes.xts_sectors_dev(j["keys2"], 9, n, 1, j["src"], x)
+        torch.cuda.synchronize()
+        want.append((g, o, x))
+    for _ in range(10):
+        for j in jobs:
+            j["gcm"].zero_(); j["ocb"].zero_(); j["xts"].zero_()
+        torch.cuda.synchronize()
+        for j in jobs:
+            uaes.gcm_encrypt_dev(j["key"], j["nonce"], None, j["src"], n, j["gcm"], stream=j["st"])
+            uaes.ocb_dev(j["key"], j["nonce"], None, j["src"], n, j["ocb"], stream=j["st"])
+            uaes.xts_sectors_dev(j["keys2"], 9, n, 1, j["src"], j["xts"], stream=j["st"])
+        torch.cuda.synchronize()
+        for j, (g, o, x) in zip(jobs, want):
+            assert torch.equal(j["gcm"], g) and torch.equal(j["ocb"], o) and torch.equal(j["xts"], x)
+    # and the first one against the oracle's tag
+    j = jobs[0]
+    head = bytes(j["src"][:4096].cpu().numpy())
+    assert bytes(want[0][0][:4096].cpu().numpy()) == orc.gcm_encrypt(j["key"], j["nonce"], b"", head)[:4096]
