@@ -36,7 +36,6 @@ typedef uint64_t u64;
 
 #define UAES_WG        1024u              /* threads per workgroup (16 waves)  */
 #define UAES_LDS_ENC   (128u * 1024u)
-#define UAES_LDS_ENC2  (64u * 1024u)     /* two-table variant                 */
 #define UAES_LDS_DEC   (128u * 1024u)
 
 extern __shared__ __attribute__((aligned(16))) unsigned char uaes_lds[];
@@ -120,10 +119,9 @@ __device__ __forceinline__ void store_replicas(u32 byte_addr, u32 v)
 }
 
 /* Te_k[x] = rotl(Te0[x], 8k); Te0 bytes = {2S,S,S,3S} */
-template <int NT = 4>
 __device__ __forceinline__ void fill_enc_tables(const u32 *__restrict__ te0)
 {
-    for (u32 i = threadIdx.x; i < 256u * NT; i += blockDim.x) {
+    for (u32 i = threadIdx.x; i < 1024u; i += blockDim.x) {
         const u32 x = i & 255u, k = i >> 8;
         store_replicas(x * 256u + (k & 1u) * 128u + (k >> 1) * 65536u, rotl32(te0[x], 8u * k));
     }
@@ -133,86 +131,70 @@ __device__ __forceinline__ void fill_enc_tables(const u32 *__restrict__ te0)
 /* Td_k[x] = rotl(Td0[x], 8k); Td0 bytes = {14Si, 9Si, 13Si, 11Si}; same layout as Te */
 __device__ __forceinline__ void fill_dec_tables(const u32 *__restrict__ td0)
 {
-    fill_enc_tables<4>(td0);
+    fill_enc_tables(td0);
 }
 
 /* ---- encryption rounds -------------------------------------------------- */
-/* NT = number of LDS-resident tables: 4 (Te0..Te3, 128 KiB, one workgroup per
- * CU) or 2 (Te0,Te1, 64 KiB: rows 2 and 3 reuse them through one 16-bit
- * rotate per column, Te2 = rotl16(Te0), Te3 = rotl16(Te1); two workgroups =
- * 32 waves per CU, +2 VALU per column).                                     */
-
 /* one full round (SubBytes, ShiftRows, MixColumns, AddRoundKey rk) of one column */
-template <int NT>
 __device__ __forceinline__ u32 enc_col(u32 a, u32 b, u32 c, u32 d, u32 key, const LaneConst &lc)
 {
-    if (NT == 4)
-        return xor3(xor3(tlook<0, 0>(a, lc), tlook<1, 1>(b, lc), tlook<2, 2>(c, lc)), tlook<3, 3>(d, lc), key);
-    return xor3(tlook<0, 0>(a, lc), tlook<1, 1>(b, lc), key) ^ rotl32(tlook<0, 2>(c, lc) ^ tlook<1, 3>(d, lc), 16);
+    return xor3(xor3(tlook<0, 0>(a, lc), tlook<1, 1>(b, lc), tlook<2, 2>(c, lc)), tlook<3, 3>(d, lc), key);
 }
 
-template <int U, int NT = 4>
+template <int U>
 __device__ __forceinline__ void enc_round(u32 (&s)[U][4], const u32 *rk, const LaneConst &lc)
 {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const u32 a = s[u][0], b = s[u][1], c = s[u][2], d = s[u][3];
-        s[u][0] = enc_col<NT>(a, b, c, d, rk[0], lc);
-        s[u][1] = enc_col<NT>(b, c, d, a, rk[1], lc);
-        s[u][2] = enc_col<NT>(c, d, a, b, rk[2], lc);
-        s[u][3] = enc_col<NT>(d, a, b, c, rk[3], lc);
+        s[u][0] = enc_col(a, b, c, d, rk[0], lc);
+        s[u][1] = enc_col(b, c, d, a, rk[1], lc);
+        s[u][2] = enc_col(c, d, a, b, rk[2], lc);
+        s[u][3] = enc_col(d, a, b, c, rk[3], lc);
     }
 }
 
-/* last round: SubBytes, ShiftRows, AddRoundKey.  With four tables S[x] sits
- * in byte r of Te2 (r=0), Te3 (r=1), Te0 (r=2), Te1 (r=3); with two tables
- * rows 0 and 1 take byte 1 of Te0 and move it with the same v_perm.         */
-template <int NT>
+/* last round: SubBytes, ShiftRows, AddRoundKey.  S[x] sits in byte r of Te2 (r=0),
+ * Te3 (r=1), Te0 (r=2), Te1 (r=3).                                               */
 __device__ __forceinline__ u32 last_col(u32 a, u32 b, u32 c, u32 d, u32 key, const LaneConst &lc)
 {
-    u32 lo, hi;
-    if (NT == 4) {
-        lo = __builtin_amdgcn_perm(tlook<3, 1>(b, lc), tlook<2, 0>(a, lc), 0x0c0c0500u);   /* r0.b0, r1.b1 */
-        hi = __builtin_amdgcn_perm(tlook<1, 3>(d, lc), tlook<0, 2>(c, lc), 0x07020c0cu);   /* r2.b2, r3.b3 */
-    } else {
-        lo = __builtin_amdgcn_perm(tlook<0, 1>(b, lc), tlook<0, 0>(a, lc), 0x0c0c0501u);   /* r0.b1, r1.b1 */
-        hi = __builtin_amdgcn_perm(tlook<1, 3>(d, lc), tlook<0, 2>(c, lc), 0x07020c0cu);   /* r2.b2, r3.b3 */
-    }
+    const u32 lo = __builtin_amdgcn_perm(tlook<3, 1>(b, lc), tlook<2, 0>(a, lc), 0x0c0c0500u);   /* r0.b0, r1.b1 */
+    const u32 hi = __builtin_amdgcn_perm(tlook<1, 3>(d, lc), tlook<0, 2>(c, lc), 0x07020c0cu);   /* r2.b2, r3.b3 */
     return or_xor(lo, hi, key);
 }
 
-template <int U, int NT = 4>
+template <int U>
 __device__ __forceinline__ void enc_last_round(u32 (&s)[U][4], const u32 *rk, const LaneConst &lc)
 {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const u32 a = s[u][0], b = s[u][1], c = s[u][2], d = s[u][3];
-        s[u][0] = last_col<NT>(a, b, c, d, rk[0], lc);
-        s[u][1] = last_col<NT>(b, c, d, a, rk[1], lc);
-        s[u][2] = last_col<NT>(c, d, a, b, rk[2], lc);
-        s[u][3] = last_col<NT>(d, a, b, c, rk[3], lc);
+        s[u][0] = last_col(a, b, c, d, rk[0], lc);
+        s[u][1] = last_col(b, c, d, a, rk[1], lc);
+        s[u][2] = last_col(c, d, a, b, rk[2], lc);
+        s[u][3] = last_col(d, a, b, c, rk[3], lc);
     }
 }
 
 /* rounds FIRST..NR on states that already hold the input of round FIRST
  * (i.e. after AddRoundKey(FIRST-1)); rk = all round keys                   */
-template <int NR, int U, int FIRST, int NT = 4>
+template <int NR, int U, int FIRST>
 __device__ __forceinline__ void enc_rounds_from(u32 (&s)[U][4], const uaesk_rk &rk, const LaneConst &lc)
 {
 #pragma unroll
-    for (int r = FIRST; r < NR; ++r) enc_round<U, NT>(s, &rk.w[4 * r], lc);
-    enc_last_round<U, NT>(s, &rk.w[4 * NR], lc);
+    for (int r = FIRST; r < NR; ++r) enc_round<U>(s, &rk.w[4 * r], lc);
+    enc_last_round<U>(s, &rk.w[4 * NR], lc);
 }
 
 /* full cipher on U blocks (state = plaintext words on entry) */
-template <int NR, int U, int NT = 4>
+template <int NR, int U>
 __device__ __forceinline__ void enc_blocks(u32 (&s)[U][4], const uaesk_rk &rk, const LaneConst &lc)
 {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         s[u][0] ^= rk.w[0]; s[u][1] ^= rk.w[1]; s[u][2] ^= rk.w[2]; s[u][3] ^= rk.w[3];
     }
-    enc_rounds_from<NR, U, 1, NT>(s, rk, lc);
+    enc_rounds_from<NR, U, 1>(s, rk, lc);
 }
 
 /* ---- split-phase rounds (software pipelining across two blocks) ---------- */

@@ -95,15 +95,14 @@ __device__ __forceinline__ void ctr_words(const uaesk_ctr &c, u64 i, u32 (&w)[4]
     w[3] = bswap32((u32)v);
 }
 
-/* U = blocks per lane per iteration, NT = tables in LDS (4: one workgroup per
- * CU, 2: two workgroups = 32 waves per CU, <= 64 VGPRs)                      */
-template <int NR, int U, int NT>
-__global__ __launch_bounds__(UAES_WG, (NT == 2 ? 8 : 4)) void k_ctr(uaesk_rk rk, uaesk_tables tb, uaesk_ctr ctr,
+/* the generic CTR kernel: work items are single blocks, U = 4 per lane per iteration */
+template <int NR, int U>
+__global__ __launch_bounds__(UAES_WG, 4) void k_ctr(uaesk_rk rk, uaesk_tables tb, uaesk_ctr ctr,
                                                  const uint4 *__restrict__ in, uint4 *__restrict__ out,
                                                  u64 nfull, u32 rem, const int *__restrict__ gate)
 {
     if (gate && *gate != 0) return;            /* GCM decrypt: tag mismatch -> untouched */
-    fill_enc_tables<NT>(tb.te0);
+    fill_enc_tables(tb.te0);
     const LaneConst lc = make_lane_const();
     const u64 stride = (u64)gridDim.x * UAES_WG * U;
 
@@ -118,11 +117,11 @@ __global__ __launch_bounds__(UAES_WG, (NT == 2 ? 8 : 4)) void k_ctr(uaesk_rk rk,
             if (idx[u] < nfull) d[u] = in[idx[u]];
             ctr_words(ctr, idx[u], s[u]);
         }
-        if (NT == 4 && U == 4) {                   /* two pairs, each half a round out of phase (as k_ecb) */
+        if (U == 4) {                              /* two pairs, each half a round out of phase (as k_ecb) */
             enc_blocks_skewed<NR>(s[0], s[1], rk, lc);
             enc_blocks_skewed<NR>(s[2 % U], s[3 % U], rk, lc);
         } else {
-            enc_blocks<NR, U, NT>(s, rk, lc);
+            enc_blocks<NR, U>(s, rk, lc);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -134,7 +133,7 @@ __global__ __launch_bounds__(UAES_WG, (NT == 2 ? 8 : 4)) void k_ctr(uaesk_rk rk,
     if (rem && blockIdx.x == 0 && threadIdx.x == 0) {
         u32 s1[1][4];
         ctr_words(ctr, nfull, s1[0]);
-        enc_blocks<NR, 1, NT>(s1, rk, lc);
+        enc_blocks<NR, 1>(s1, rk, lc);
         const unsigned char *src = (const unsigned char *)(in + nfull);
         unsigned char *dst = (unsigned char *)(out + nfull);
         for (u32 i = 0; i < rem; ++i)
@@ -167,7 +166,7 @@ __device__ __forceinline__ void ctr_edges(const uaesk_rk &rk, const uaesk_ctr &c
         const u64 i = e < pre_end ? e : suf + (e - pre_end);
         u32 s1[1][4];
         ctr_words(ctr, i, s1[0]);
-        enc_blocks<NR, 1, 4>(s1, rk, lc);
+        enc_blocks<NR, 1>(s1, rk, lc);
         const uint4 d = in[i];
         out[i] = make_uint4(d.x ^ s1[0][0], d.y ^ s1[0][1], d.z ^ s1[0][2], d.w ^ s1[0][3]);
     }
@@ -175,7 +174,7 @@ __device__ __forceinline__ void ctr_edges(const uaesk_rk &rk, const uaesk_ctr &c
     if (rem && blockIdx.x == 0 && threadIdx.x == 0) {
         u32 s1[1][4];
         ctr_words(ctr, nfull, s1[0]);
-        enc_blocks<NR, 1, 4>(s1, rk, lc);
+        enc_blocks<NR, 1>(s1, rk, lc);
         const unsigned char *src = (const unsigned char *)(in + nfull);
         unsigned char *dst = (unsigned char *)(out + nfull);
         for (u32 i = 0; i < rem; ++i)
@@ -217,7 +216,7 @@ __global__ __launch_bounds__(UAES_WG, 4) void k_ctr_shared(uaesk_rk rk, uaesk_ta
                                                            const int *__restrict__ gate)
 {
     if (gate && *gate != 0) return;
-    fill_enc_tables<4>(tb.te0);
+    fill_enc_tables(tb.te0);
     const LaneConst lc = make_lane_const();
     ctr_edges<NR>(rk, ctr, in, out, chunk_lo, chunk_hi, nfull, rem, lc);
     const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -301,7 +300,7 @@ __global__ __launch_bounds__(UAES_WG, 4) void k_ctr_shared(uaesk_rk rk, uaesk_ta
             }
             s[u][0] = L0 ^ uu.x; s[u][1] = L1 ^ uu.y; s[u][2] = L2 ^ uu.z; s[u][3] = L3 ^ uu.w;
         }
-        enc_rounds_from<NR, UAES_U, 3, 4>(s, rk, lc);
+        enc_rounds_from<NR, UAES_U, 3>(s, rk, lc);
 #pragma unroll
         for (int u = 0; u < UAES_U; ++u) {
             (out + ((((chunk * CTRS_CHUNK) + 4u * (m * UAES_U + u)) << 8) - c0))[lane_blk] =
@@ -323,7 +322,7 @@ __global__ __launch_bounds__(UAES_WG, 4) void k_ctr_shared2(uaesk_rk rk, uaesk_t
                                                            const int *__restrict__ gate)
 {
     if (gate && *gate != 0) return;
-    fill_enc_tables<4>(tb.te0);
+    fill_enc_tables(tb.te0);
     const LaneConst lc = make_lane_const();
     ctr_edges<NR>(rk, ctr, in, out, chunk_lo, chunk_hi, nfull, rem, lc);
     const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -793,22 +792,17 @@ static int ctr_variant()
     return v;
 }
 
-template <int NR, int U, int NT>
+template <int NR, int U>
 static int launch_ctr_v(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek, const uaesk_ctr *ctr,
                         const void *in, void *out, size_t len, const int *gate)
 {
-    const unsigned lds = NT == 2 ? UAES_LDS_ENC2 : UAES_LDS_ENC;
-    hipError_t e = set_lds(k_ctr<NR, U, NT>, lds);
+    const unsigned lds = UAES_LDS_ENC;
+    hipError_t e = set_lds(k_ctr<NR, U>, lds);
     if (e != hipSuccess) return (int)e;
     const u64 nfull = len / 16;
     const u32 rem = (u32)(len % 16);
-    unsigned grid = grid_for(nfull + (rem ? 1 : 0), (u64)UAES_WG * U);
-    if (NT == 2) {
-        const u64 want = (nfull + (rem ? 1 : 0) + (u64)UAES_WG * U - 1) / ((u64)UAES_WG * U);
-        const u64 cap = 2ull * (g_cus > 0 ? g_cus : 256);
-        grid = (unsigned)(want < cap ? (want ? want : 1) : cap);
-    }
-    hipLaunchKernelGGL((k_ctr<NR, U, NT>), dim3(grid), dim3(UAES_WG), lds, st, *ek, *tb, *ctr,
+    const unsigned grid = grid_for(nfull + (rem ? 1 : 0), (u64)UAES_WG * U);
+    hipLaunchKernelGGL((k_ctr<NR, U>), dim3(grid), dim3(UAES_WG), lds, st, *ek, *tb, *ctr,
                        (const uint4 *)in, (uint4 *)out, nfull, rem, gate);
     return (int)hipGetLastError();
 }
@@ -834,7 +828,7 @@ static int launch_ctr_shared(hipStream_t st, const uaesk_tables *tb, const uaesk
     const bool all_here = (nchunks % grid) * 10 >= (u64)grid * 7;
     const u64 rounds = nchunks / grid + (all_here ? 1 : 0);
     if (rounds == 0)
-        return launch_ctr_v<NR, 4, 4>(st, tb, ek, ctr, in, out, len, gate);
+        return launch_ctr_v<NR, 4>(st, tb, ek, ctr, in, out, len, gate);
     if (!all_here) chunk_hi = chunk_lo + rounds * grid;
     /* blocks [0, head) and, when everything runs here, the byte tail; the rest below */
     const u64 head = all_here ? nfull : chunk_hi * per_chunk - c0;
@@ -852,7 +846,7 @@ static int launch_ctr_shared(hipStream_t st, const uaesk_tables *tb, const uaesk
     if (!all_here && head * 16 < len) {
         uaesk_ctr rest = *ctr;
         rest.v0 = (ctr->v0 + head) & 0x00ffffffffffffffull;        /* 56-bit counter (N2) */
-        return launch_ctr_v<NR, 4, 4>(st, tb, ek, &rest, (const unsigned char *)in + head * 16,
+        return launch_ctr_v<NR, 4>(st, tb, ek, &rest, (const unsigned char *)in + head * 16,
                                       (unsigned char *)out + head * 16, len - head * 16, gate);
     }
     return (int)hipGetLastError();
@@ -863,7 +857,7 @@ static int launch_ctr(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek
                       const void *in, void *out, size_t len, const int *gate)
 {
     if (ctr_variant() == 2 || ctr->le32)       /* the shared-round kernels assume the 56-bit BE counter */
-        return launch_ctr_v<NR, 4, 4>(st, tb, ek, ctr, in, out, len, gate);
+        return launch_ctr_v<NR, 4>(st, tb, ek, ctr, in, out, len, gate);
     return launch_ctr_shared<NR>(st, tb, ek, ctr, in, out, len, gate);
 }
 

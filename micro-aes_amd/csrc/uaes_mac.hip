@@ -42,7 +42,7 @@ template <int NR>
 __device__ __forceinline__ void enc1(Blk &b, const uaesk_rk &rk, const LaneConst &lc)
 {
     u32 s[1][4] = { { b.w[0], b.w[1], b.w[2], b.w[3] } };
-    enc_blocks<NR, 1, 4>(s, rk, lc);
+    enc_blocks<NR, 1>(s, rk, lc);
     b.w[0] = s[0][0]; b.w[1] = s[0][1]; b.w[2] = s[0][2]; b.w[3] = s[0][3];
 }
 
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(UAES_WG) void k_cmac(uaesk_rk rk, uaesk_tables tb,
                                                   const unsigned char *__restrict__ data, u64 len,
                                                   unsigned char *__restrict__ mac)
 {
-    fill_enc_tables<4>(tb.te0);
+    fill_enc_tables(tb.te0);
     if (threadIdx.x != 0) return;
     const LaneConst lc = make_lane_const();
     Blk k1 = { { 0, 0, 0, 0 } };
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(UAES_WG) void k_ccm_tag(uaesk_rk rk, uaesk_tables t
                                                      const unsigned char *__restrict__ pt, u64 pt_len,
                                                      int mode, unsigned char *tag_io, int *status)
 {
-    fill_enc_tables<4>(tb.te0);
+    fill_enc_tables(tb.te0);
     if (threadIdx.x != 0) return;
     const LaneConst lc = make_lane_const();
     const Blk iv = { { iv4.x, iv4.y, iv4.z, iv4.w } };

@@ -83,7 +83,7 @@ template <int NR>
 __device__ __forceinline__ void ocb_enc1(B16 &b, const uaesk_rk &rk, const LaneConst &lc)
 {
     u32 s[1][4] = { { b.w[0], b.w[1], b.w[2], b.w[3] } };
-    enc_blocks<NR, 1, 4>(s, rk, lc);
+    enc_blocks<NR, 1>(s, rk, lc);
     b.w[0] = s[0][0]; b.w[1] = s[0][1]; b.w[2] = s[0][2]; b.w[3] = s[0][3];
 }
 
