@@ -206,115 +206,11 @@ __device__ __forceinline__ void ctr_edges(const uaesk_rk &rk, const uaesk_ctr &c
 #define CTRS_BUF   (UAES_LDS_ENC)            /* 2 x 64 x 32 B after the tables */
 #define UAES_LDS_CTRS (UAES_LDS_ENC + 2u * CTRS_CHUNK * 32u)
 
-/* Handles only chunks [chunk_lo, chunk_hi) that lie completely inside the
- * stream, so the hot loop has no bounds checks; the (at most two) ragged edge
- * chunks and the byte tail go to the generic k_ctr (launcher below).         */
-template <int NR>
-__global__ __launch_bounds__(UAES_WG, 4) void k_ctr_shared(uaesk_rk rk, uaesk_tables tb, uaesk_ctr ctr,
-                                                           const uint4 *__restrict__ in, uint4 *__restrict__ out,
-                                                           u64 chunk_lo, u64 chunk_hi, u64 nfull, u32 rem,
-                                                           const int *__restrict__ gate)
-{
-    if (gate && *gate != 0) return;
-    fill_enc_tables(tb.te0);
-    const LaneConst lc = make_lane_const();
-    ctr_edges<NR>(rk, ctr, in, out, chunk_lo, chunk_hi, nfull, rem, lc);
-    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const u32 p = ((wave & 3u) << 6) | lane;               /* counter byte 15 of this lane */
-    const u32 quad = wave >> 2;
-    const u32 c0 = (u32)ctr.v0 & 0xffu;                    /* position of stream block 0   */
-    const u64 vbase = ctr.v0 - c0;                         /* group-aligned counter        */
-    uint4 *buf = (uint4 *)(uaes_lds + CTRS_BUF);
-    const u32 lane_blk = (quad << 8) | p;                  /* lane's block offset inside a 4-group stripe */
-
-    /* byte 15 after AddRoundKey(0), as a Te3 lookup operand in byte 3 */
-    const u32 x15 = ((p << 24) ^ rk.w[3]) & 0xff000000u;
-    u32 a_cur = 0, L0 = 0, L1 = 0, L2 = 0, L3 = 0;
-    bool have_l = false;
-    u32 parity = 0;
-
-    /* The unit of work of a wave is (chunk, m): four groups = 4 blocks per lane.
-     * Block index of (chunk, m, u, lane) = ((chunk*64 + 4*(4m+u)) << 8) - c0 [uniform]
-     *                                    + lane_blk                       [per lane].
-     * The plaintext of unit t+1 is requested before the rounds of unit t, so
-     * HBM latency hides under ~500 table lookups.                           */
-    u64 chunk = chunk_lo + blockIdx.x;
-    u32 m = 0;
-    uint4 d_cur[UAES_U], d_nxt[UAES_U];
-    if (chunk < chunk_hi) {
-#pragma unroll
-        for (int u = 0; u < UAES_U; ++u)
-            d_cur[u] = (in + ((((chunk * CTRS_CHUNK) + 4u * u) << 8) - c0))[lane_blk];
-    }
-
-    while (chunk < chunk_hi) {
-        if (m == 0) {
-            if (wave < CTRS_CHUNK / 64u) {
-                /* uniform part of rounds 1 and 2 for group (chunk*CTRS_CHUNK + 64*wave + lane) */
-                const u32 gi = wave * 64u + lane;
-                const u64 g = chunk * CTRS_CHUNK + gi;
-                const u64 v = (vbase + (g << 8)) & 0x00FFFFFFFFFFFFFFull;
-                const u32 s0 = ctr.w0 ^ rk.w[0], s1 = ctr.w1 ^ rk.w[1];
-                const u32 s2 = bswap32((ctr.b8 << 24) | (u32)(v >> 32)) ^ rk.w[2];
-                const u32 s3 = (bswap32((u32)v) ^ rk.w[3]) & 0x00ffffffu;      /* byte 15 excluded */
-                const u32 A = xor3(tlook<0, 0>(s0, lc), tlook<1, 1>(s1, lc), tlook<2, 2>(s2, lc)) ^ rk.w[4];
-                const u32 c1 = xor3(xor3(tlook<0, 0>(s1, lc), tlook<1, 1>(s2, lc), tlook<2, 2>(s3, lc)), tlook<3, 3>(s0, lc), rk.w[5]);
-                const u32 c2 = xor3(xor3(tlook<0, 0>(s2, lc), tlook<1, 1>(s3, lc), tlook<2, 2>(s0, lc)), tlook<3, 3>(s1, lc), rk.w[6]);
-                const u32 c3 = xor3(xor3(tlook<0, 0>(s3, lc), tlook<1, 1>(s0, lc), tlook<2, 2>(s1, lc)), tlook<3, 3>(s2, lc), rk.w[7]);
-                const u32 u0 = xor3(tlook<1, 1>(c1, lc), tlook<2, 2>(c2, lc), tlook<3, 3>(c3, lc)) ^ rk.w[8];
-                const u32 u1 = xor3(tlook<0, 0>(c1, lc), tlook<1, 1>(c2, lc), tlook<2, 2>(c3, lc)) ^ rk.w[9];
-                const u32 u2 = xor3(tlook<0, 0>(c2, lc), tlook<1, 1>(c3, lc), tlook<3, 3>(c1, lc)) ^ rk.w[10];
-                const u32 u3 = xor3(tlook<0, 0>(c3, lc), tlook<2, 2>(c1, lc), tlook<3, 3>(c2, lc)) ^ rk.w[11];
-                buf[(parity * CTRS_CHUNK + gi) * 2 + 0] = make_uint4(u0, u1, u2, u3);
-                buf[(parity * CTRS_CHUNK + gi) * 2 + 1] = make_uint4(A, 0, 0, 0);
-            }
-            __syncthreads();
-        }
-
-        /* request the next unit's plaintext (clamped to this kernel's last chunk) */
-        u64 nchunk = chunk;
-        u32 nm = m + 1;
-        if (nm == CTRS_CHUNK / 16u) { nm = 0; nchunk += gridDim.x; }
-        {
-            const u64 lc_chunk = nchunk < chunk_hi ? nchunk : chunk;
-            const u32 lm = nchunk < chunk_hi ? nm : m;
-#pragma unroll
-            for (int u = 0; u < UAES_U; ++u)
-                d_nxt[u] = (in + ((((lc_chunk * CTRS_CHUNK) + 4u * (lm * UAES_U + u)) << 8) - c0))[lane_blk];
-        }
-
-        u32 s[UAES_U][4];
-#pragma unroll
-        for (int u = 0; u < UAES_U; ++u) {
-            const u32 gl = quad + 4u * (m * UAES_U + u);                   /* group within the chunk */
-            const uint4 uu = buf[(parity * CTRS_CHUNK + gl) * 2 + 0];
-            const u32 A = buf[(parity * CTRS_CHUNK + gl) * 2 + 1].x;
-            if (!have_l || A != a_cur) {                                   /* wave-uniform; ~never after the first time */
-                const u32 col0 = A ^ tlook<3, 3>(x15, lc);
-                L0 = tlook<0, 0>(col0, lc);
-                L1 = tlook<3, 3>(col0, lc);
-                L2 = tlook<2, 2>(col0, lc);
-                L3 = tlook<1, 1>(col0, lc);
-                a_cur = A;
-                have_l = true;
-            }
-            s[u][0] = L0 ^ uu.x; s[u][1] = L1 ^ uu.y; s[u][2] = L2 ^ uu.z; s[u][3] = L3 ^ uu.w;
-        }
-        enc_rounds_from<NR, UAES_U, 3>(s, rk, lc);
-#pragma unroll
-        for (int u = 0; u < UAES_U; ++u) {
-            (out + ((((chunk * CTRS_CHUNK) + 4u * (m * UAES_U + u)) << 8) - c0))[lane_blk] =
-                make_uint4(d_cur[u].x ^ s[u][0], d_cur[u].y ^ s[u][1], d_cur[u].z ^ s[u][2], d_cur[u].w ^ s[u][3]);
-            d_cur[u] = d_nxt[u];
-        }
-        if (nm == 0) parity ^= 1u;
-        chunk = nchunk;
-        m = nm;
-    }
-}
-
-/* Same as k_ctr_shared with two blocks per lane per unit, their rounds half a
- * round out of phase (enc_rounds_skewed).                                   */
+/* The hot loop handles only chunks [chunk_lo, chunk_hi) that lie completely inside
+ * the stream, so it has no bounds checks; the blocks before and after them (up to
+ * block nfull) and a byte tail run in the prologue (ctr_edges).  Two blocks per lane,
+ * half a round out of phase (enc_rounds_skewed); a lock-step four-block version
+ * measured 4 % slower (profiles/r01_sweep_ctr_variants.log).                     */
 template <int NR>
 __global__ __launch_bounds__(UAES_WG, 4) void k_ctr_shared2(uaesk_rk rk, uaesk_tables tb, uaesk_ctr ctr,
                                                            const uint4 *__restrict__ in, uint4 *__restrict__ out,
@@ -778,20 +674,6 @@ extern "C" int uaesk_ecb(void *stream, const uaesk_tables *tb, int nr, const uae
     return 0;
 }
 
-/* UAES_CTR_VARIANT (debug knob for A/B runs, read once):
- *   unset / "skewed"  k_ctr_shared2 -- shared rounds 1-2, two blocks per lane half a round apart
- *   "shared4"         k_ctr_shared  -- shared rounds 1-2, four blocks per lane in lock step
- *   "generic"         k_ctr         -- every round of every block (what short messages use)   */
-static int ctr_variant()
-{
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("UAES_CTR_VARIANT");
-        v = (e && !strcmp(e, "shared4")) ? 1 : (e && !strcmp(e, "generic")) ? 2 : 0;
-    }
-    return v;
-}
-
 template <int NR, int U>
 static int launch_ctr_v(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek, const uaesk_ctr *ctr,
                         const void *in, void *out, size_t len, const int *gate)
@@ -834,15 +716,10 @@ static int launch_ctr_shared(hipStream_t st, const uaesk_tables *tb, const uaesk
     const u64 head = all_here ? nfull : chunk_hi * per_chunk - c0;
     const u32 tail_bytes = all_here ? (u32)(len % 16) : 0u;
 
-    hipError_t e = set_lds(k_ctr_shared<NR>, UAES_LDS_CTRS);
-    if (e == hipSuccess) e = set_lds(k_ctr_shared2<NR>, UAES_LDS_CTRS);
+    hipError_t e = set_lds(k_ctr_shared2<NR>, UAES_LDS_CTRS);
     if (e != hipSuccess) return (int)e;
-    if (ctr_variant() == 1)
-        hipLaunchKernelGGL((k_ctr_shared<NR>), dim3(grid), dim3(UAES_WG), UAES_LDS_CTRS, st, *ek, *tb, *ctr,
-                           (const uint4 *)in, (uint4 *)out, chunk_lo, chunk_hi, head, tail_bytes, gate);
-    else
-        hipLaunchKernelGGL((k_ctr_shared2<NR>), dim3(grid), dim3(UAES_WG), UAES_LDS_CTRS, st, *ek, *tb, *ctr,
-                           (const uint4 *)in, (uint4 *)out, chunk_lo, chunk_hi, head, tail_bytes, gate);
+    hipLaunchKernelGGL((k_ctr_shared2<NR>), dim3(grid), dim3(UAES_WG), UAES_LDS_CTRS, st, *ek, *tb, *ctr,
+                       (const uint4 *)in, (uint4 *)out, chunk_lo, chunk_hi, head, tail_bytes, gate);
     if (!all_here && head * 16 < len) {
         uaesk_ctr rest = *ctr;
         rest.v0 = (ctr->v0 + head) & 0x00ffffffffffffffull;        /* 56-bit counter (N2) */
@@ -856,7 +733,7 @@ template <int NR>
 static int launch_ctr(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek, const uaesk_ctr *ctr,
                       const void *in, void *out, size_t len, const int *gate)
 {
-    if (ctr_variant() == 2 || ctr->le32)       /* the shared-round kernels assume the 56-bit BE counter */
+    if (ctr->le32)                             /* the shared-round kernel assumes the 56-bit BE counter */
         return launch_ctr_v<NR, 4>(st, tb, ek, ctr, in, out, len, gate);
     return launch_ctr_shared<NR>(st, tb, ek, ctr, in, out, len, gate);
 }
