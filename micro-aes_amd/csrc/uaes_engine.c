@@ -331,6 +331,15 @@ static int finish_io(io_plan *io, size_t out_len)
     return 0;
 }
 
+/* the *_dev entry points hand their pointers straight to the kernels (uint4 accesses) */
+static int dev_ptrs_ok(const void *in, const void *out, size_t len)
+{
+    if (len && (!in || !out)) return fail(UAES_E_ARG, "NULL device pointer");
+    if ((((uintptr_t)in) | ((uintptr_t)out)) & 15u)
+        return fail(UAES_E_ARG, "device pointers of the *_dev API must be 16-byte aligned");
+    return 0;
+}
+
 #define LOCKED_BEGIN(c)  pthread_mutex_lock(&(c)->mu)
 #define LOCKED_END(c, rc) do { pthread_mutex_unlock(&(c)->mu); return (rc); } while (0)
 
@@ -420,6 +429,7 @@ int uaes_ecb_dev(int keybits, const uint8_t *key, int decrypt,
     keysched ks;
     int rc;
     if ((rc = expand_key(&ks, key, keybits)) != 0) return rc;
+    if ((rc = dev_ptrs_ok(d_in, d_out, len)) != 0) return rc;
     if ((rc = get_context(&c)) != 0) return rc;
     if (decrypt && len % 16) return fail(UAES_E_ARG, "uaes_ecb_dev: ragged decrypt length");
     KCHK(uaesk_ecb(stream, &c->tb, ks.nr, decrypt ? &ks.dk : &ks.ek, decrypt, d_in, d_out,
@@ -451,6 +461,7 @@ int uaes_ctr_xcrypt_at_dev(int keybits, const uint8_t *key, const uint8_t ctr0[1
     uaesk_ctr ctr;
     int rc;
     if ((rc = expand_key(&ks, key, keybits)) != 0) return rc;
+    if ((rc = dev_ptrs_ok(d_in, d_out, len)) != 0) return rc;
     if (!ctr0) return fail(UAES_E_ARG, "NULL counter block");
     if ((rc = get_context(&c)) != 0) return rc;
     make_ctr(&ctr, ctr0, block_offset);
@@ -572,6 +583,7 @@ int uaes_xts_sectors_dev(int keybits, const uint8_t *keys, uint64_t first_sector
     keysched k1, k2;
     int rc;
     if ((rc = xts_keys(&k1, &k2, keys, keybits)) != 0) return rc;
+    if ((rc = dev_ptrs_ok(d_in, d_out, sector_bytes * nsectors)) != 0) return rc;
     if (sector_bytes < 16) return UAES_E_DATALENGTH;
     if ((rc = get_context(&c)) != 0) return rc;
     return xts_run(c, stream, &k1, &k2, encrypt, NULL, first_sector, sector_bytes, nsectors, d_in, d_out, 1);
@@ -679,6 +691,8 @@ int uaes_gcm_encrypt_dev(int keybits, const uint8_t *key, const uint8_t *nonce,
     void *scr;
     int rc;
     if ((rc = expand_key(&ks, key, keybits)) != 0) return rc;
+    if (!nonce || !d_out) return fail(UAES_E_ARG, "NULL pointer");
+    if ((rc = dev_ptrs_ok(d_in, d_out, len)) != 0) return rc;
     if ((rc = get_context(&c)) != 0) return rc;
     if ((rc = gcm_scratch_locked(c, stream, &scr)) != 0) return rc;
     KCHK(uaesk_gcm(stream, &c->tb, ks.nr, &ks.ek, 0, nonce, d_aad, aad_len, d_in, len, d_out,
@@ -696,6 +710,8 @@ int uaes_gcm_decrypt_dev(int keybits, const uint8_t *key, const uint8_t *nonce,
     void *scr;
     int rc;
     if ((rc = expand_key(&ks, key, keybits)) != 0) return rc;
+    if (!nonce || !d_in) return fail(UAES_E_ARG, "NULL pointer");
+    if ((rc = dev_ptrs_ok(d_in, d_out, len)) != 0) return rc;
     if (!d_status) return fail(UAES_E_ARG, "NULL d_status");
     if ((rc = get_context(&c)) != 0) return rc;
     if ((rc = gcm_scratch_locked(c, stream, &scr)) != 0) return rc;
@@ -715,6 +731,7 @@ int uaes_gcm_partial_dev(int keybits, const uint8_t *key, const uint8_t *nonce,
     int rc;
     if ((rc = expand_key(&ks, key, keybits)) != 0) return rc;
     if (!nonce || !d_partial16) return fail(UAES_E_ARG, "NULL pointer");
+    if (((uintptr_t)d_ct_shard) & 15u) return fail(UAES_E_ARG, "the ciphertext shard must be 16-byte aligned");
     if (shard_offset % 16 || shard_offset + shard_len > total_len)
         return fail(UAES_E_ARG, "shard [%llu, +%zu) is not a 16-byte aligned slice of %llu bytes",
                     (unsigned long long)shard_offset, shard_len, (unsigned long long)total_len);
@@ -1099,6 +1116,8 @@ int uaes_ocb_dev(int keybits, const uint8_t *key, const uint8_t *nonce, int decr
     void *scr;
     int rc;
     if ((rc = expand_key(&ks, key, keybits)) != 0) return rc;
+    if (!nonce || (decrypt ? !d_in : !d_out)) return fail(UAES_E_ARG, "NULL pointer");
+    if ((rc = dev_ptrs_ok(d_in, d_out, len)) != 0) return rc;
     if (decrypt && !d_status) return fail(UAES_E_ARG, "NULL d_status");
     if ((rc = get_context(&c)) != 0) return rc;
     if ((rc = gcm_scratch_locked(c, stream, &scr)) != 0) return rc;

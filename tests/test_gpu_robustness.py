@@ -152,3 +152,15 @@ def test_dev_calls_on_different_streams_do_not_share_scratch(orc):
     j = jobs[0]
     head = bytes(j["src"][:4096].cpu().numpy())
     assert bytes(want[0][0][:4096].cpu().numpy()) == orc.gcm_encrypt(j["key"], j["nonce"], b"", head)[:4096]
+
+
+def test_dev_api_rejects_misaligned_pointers():
+    import torch
+    t = torch.zeros(4096 + 32, dtype=torch.uint8, device="cuda:0")
+    key = bytes(16)
+    with pytest.raises(uaes.EngineError, match="16-byte aligned"):
+        uaes.ecb_dev(key, t[1:1 + 4096], t[16:16 + 4096], nbytes=4096)
+    with pytest.raises(uaes.EngineError, match="16-byte aligned"):
+        uaes.ctr_xcrypt_dev(key, bytes(16), 0, t[:4096], t[3:3 + 4096], nbytes=4096)
+    with pytest.raises(uaes.EngineError, match="16-byte aligned"):
+        uaes.ocb_dev(key, bytes(12), None, t[8:8 + 1024], 1024, t[2048:])
