@@ -513,14 +513,16 @@ def test_C2_ctr128_1GiB_device_resident(orc, golden_dir):
     assert torch.equal(dst, src)
 
 
-@pytest.mark.parametrize("mib,extra", [(74, 5), (64, 0), (20, 16 * 777 + 3)])
-def test_ctr_split_between_shared_round_and_generic_kernels(orc, mib, extra):
+@pytest.mark.parametrize("mib,extra,low7", [(74, 5, "00ffffffffffe"), (64, 0, "00ffffffffffe"), (20, 16 * 777 + 3, "00ffffffffffe"),
+                                            (70, 0, "fffffffffffff0"), (130, 9, "00ffffffff0001")])
+def test_ctr_split_between_shared_round_and_generic_kernels(orc, mib, extra, low7):
     """sizes whose last round of 256 KiB chunks is thin: whole rounds run on the shared-round kernel,
-    the remainder (with its own counter offset) on the generic one; counter byte 15 starts at 0xfe"""
+    the remainder (with its own counter offset) on the generic one; the start counters carry out of
+    32 bits, wrap the 56-bit counter (N2) and change counter bits 40..47 inside the launch"""
     import hashlib
     import torch
     n = (mib << 20) + extra
-    key, ctr0 = bytes(range(16, 32)), bytes(range(0xE0, 0xEC)) + b"\xff\xff\xff\xfe"
+    key, ctr0 = bytes(range(16, 32)), bytes(range(0xE0, 0xE9)) + bytes.fromhex(low7.rjust(14, "0"))
     src = _device_stream(orc, 21, (n + 7) // 8 * 8)[:n]
     dst = torch.empty_like(src)
     uaes.ctr_xcrypt_dev(key, ctr0, 0, src, dst, nbytes=n)
