@@ -581,3 +581,37 @@ def test_C4_gcm128_1GiB_device_resident(orc, golden_dir):
     uaes.gcm_decrypt_dev(key, nonce, None, dst, n, back, status)
     torch.cuda.synchronize()
     assert int(status.item()) == 0x1A and int(back.min().item()) == 0xCC     # untouched (N7)
+
+
+def test_large_single_calls_against_the_oracle(orc):
+    """the largest texts the oracle still finishes in seconds: one XTS data unit of 192 MiB (+ a ragged
+    end: 12288 groups of 64 chunk tweaks from the parallel expansion, then ciphertext stealing) and one
+    OCB text of 128 MiB (offsets up to L_23, every run length)"""
+    import hashlib
+    import torch
+
+    def sha(b):
+        return hashlib.sha256(b).hexdigest()
+
+    n = (192 << 20) + 16 + 5
+    keys, tweak = bytes(range(64)), bytes(range(100, 116))
+    src = _device_stream(orc, 31, (n + 7) // 8 * 8)[:n]
+    dst = torch.empty_like(src)
+    L = uaes.engine()
+    assert L.uaes_xts_encrypt(256, keys, tweak, C.c_void_p(src.data_ptr()), n, C.c_void_p(dst.data_ptr())) == 0
+    rc, want = orc.xts(keys, tweak, bytes(src.cpu().numpy()), True)
+    assert rc == 0 and sha(bytes(dst.cpu().numpy())) == sha(want)
+    back = torch.empty_like(src)
+    assert L.uaes_xts_decrypt(256, keys, tweak, C.c_void_p(dst.data_ptr()), n, C.c_void_p(back.data_ptr())) == 0
+    assert torch.equal(back, src)
+    del dst, back
+
+    n = (128 << 20) + 16 * 3 + 7
+    key, nonce, aad = bytes(range(16)), bytes(range(50, 62)), b"associated data"
+    src = src[:n]
+    out = torch.empty(n + 16, dtype=torch.uint8, device="cuda:0")
+    assert L.uaes_ocb_encrypt(128, key, nonce, aad, len(aad), C.c_void_p(src.data_ptr()), n, C.c_void_p(out.data_ptr())) == 0
+    assert sha(bytes(out.cpu().numpy())) == sha(orc.ocb_encrypt(key, nonce, aad, bytes(src.cpu().numpy())))
+    pt = torch.empty(n, dtype=torch.uint8, device="cuda:0")
+    assert L.uaes_ocb_decrypt(128, key, nonce, aad, len(aad), C.c_void_p(out.data_ptr()), n, C.c_void_p(pt.data_ptr())) == 0
+    assert torch.equal(pt, src)
