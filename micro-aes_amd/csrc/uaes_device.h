@@ -89,7 +89,8 @@ int uaesk_gcm_partial(void *stream, const uaesk_tables *tb, int nr, const uaesk_
  * write Y ^ Enc(J0) to tag_io, or compare with it (*status = 0 / 0x1A).       */
 int uaesk_gcm_stream_absorb(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek,
                             const uint8_t *nonce12, int kind, const void *data, size_t len,
-                            uint64_t total_aad_len, uint64_t total_ct_len, void *scratch);
+                            uint64_t total_aad_len, uint64_t total_ct_len, void *scratch,
+                            unsigned *plan_state);   /* per stream, starts at 0: which tables scratch holds */
 int uaesk_gcm_stream_tag(void *stream, void *scratch, int compare, void *tag_io, int *status);
 
 /* POLYVAL of RFC 8452 (polyval, micro_aes.c:1421-1432) through the GHASH levels:

@@ -1134,6 +1134,7 @@ struct uaes_gcm_stream {
     uint8_t   nonce[12];
     int       decrypt, closed, device;
     uint64_t  aad_len, done;        /* bytes of text absorbed so far */
+    unsigned  plan_state;           /* which GHASH tables the scratch holds (uaesk_gcm_stream_absorb) */
     void     *scratch;              /* uaesk_gcm_scratch_bytes() + 64: tables, running GHASH, tag, status */
 };
 
@@ -1163,7 +1164,7 @@ int uaes_gcm_stream_begin(uaes_gcm_stream **out, int keybits, const uint8_t *key
     do {
         if ((rc = stage_aad(c, aData, aDataLen, &d_aad)) != 0) break;
         int k = uaesk_gcm_stream_absorb(NULL, &c->tb, s->ks.nr, &s->ks.ek, s->nonce, 0, d_aad, aDataLen,
-                                        0, 0, s->scratch);
+                                        0, 0, s->scratch, &s->plan_state);
         if (k) { rc = fail(UAES_E_HIP, "gcm stream launch: %s", hipGetErrorString((hipError_t)k)); break; }
         if (hipStreamSynchronize(NULL) != hipSuccess) { rc = fail(UAES_E_HIP, "gcm stream begin failed"); break; }
     } while (0);
@@ -1192,11 +1193,11 @@ int uaes_gcm_stream_update(uaes_gcm_stream *s, const void *in, size_t len, void 
         int k;
         if ((rc = plan_io(c, in, len, outp, len, &io)) != 0) break;
         if (s->decrypt) {                             /* hash the ciphertext before it may be overwritten */
-            k = uaesk_gcm_stream_absorb(NULL, &c->tb, s->ks.nr, &s->ks.ek, s->nonce, 1, io.din, len, 0, 0, s->scratch);
+            k = uaesk_gcm_stream_absorb(NULL, &c->tb, s->ks.nr, &s->ks.ek, s->nonce, 1, io.din, len, 0, 0, s->scratch, &s->plan_state);
             if (!k) k = uaesk_ctr_xcrypt(NULL, &c->tb, s->ks.nr, &s->ks.ek, &ctr, io.din, io.dout, len, NULL);
         } else {
             k = uaesk_ctr_xcrypt(NULL, &c->tb, s->ks.nr, &s->ks.ek, &ctr, io.din, io.dout, len, NULL);
-            if (!k) k = uaesk_gcm_stream_absorb(NULL, &c->tb, s->ks.nr, &s->ks.ek, s->nonce, 1, io.dout, len, 0, 0, s->scratch);
+            if (!k) k = uaesk_gcm_stream_absorb(NULL, &c->tb, s->ks.nr, &s->ks.ek, s->nonce, 1, io.dout, len, 0, 0, s->scratch, &s->plan_state);
         }
         if (k) { rc = fail(UAES_E_HIP, "gcm stream launch: %s", hipGetErrorString((hipError_t)k)); break; }
         rc = finish_io(&io, len);
@@ -1219,7 +1220,7 @@ int uaes_gcm_stream_finish(uaes_gcm_stream *s, uint8_t tag[16])
     do {
         hipError_t e = hipSuccess;
         int k = uaesk_gcm_stream_absorb(NULL, &c->tb, s->ks.nr, &s->ks.ek, s->nonce, 2, NULL, 0,
-                                        s->aad_len, s->done, s->scratch);
+                                        s->aad_len, s->done, s->scratch, &s->plan_state);
         if (!k && s->decrypt) e = hipMemcpyAsync(stream_tag_slot(s), tag, 16, hipMemcpyHostToDevice, NULL);
         if (!k && e == hipSuccess)
             k = uaesk_gcm_stream_tag(NULL, s->scratch, s->decrypt, stream_tag_slot(s), stream_status_slot(s));

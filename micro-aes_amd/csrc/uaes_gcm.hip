@@ -693,7 +693,8 @@ __global__ __launch_bounds__(64) void k_gcm_stream_tag(const unsigned char *__re
  * 16 unless it is the last piece), kind 2: the length block with the totals.   */
 extern "C" int uaesk_gcm_stream_absorb(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek,
                                        const uint8_t *nonce12, int kind, const void *data, size_t len,
-                                       uint64_t total_aad_len, uint64_t total_ct_len, void *scratch)
+                                       uint64_t total_aad_len, uint64_t total_ct_len, void *scratch,
+                                       unsigned *plan_state)
 {
     hipStream_t st = S(stream);
     unsigned char *sc = (unsigned char *)scratch;
@@ -711,14 +712,21 @@ extern "C" int uaesk_gcm_stream_absorb(void *stream, const uaesk_tables *tb, int
     const u64 nv = kind == 2 ? 1 : (len + 15) >> 4;
     const GPlan pl = plan_for(nv ? nv : 1);
     const uint4 z = make_uint4(0, 0, 0, 0);
-    int rc;
-    switch (nr) {
-    case 10: rc = launch_setup<10>(st, tb, ek, j0, sc, pl, 0, z, 1); break;
-    case 12: rc = launch_setup<12>(st, tb, ek, j0, sc, pl, 0, z, 1); break;
-    case 14: rc = launch_setup<14>(st, tb, ek, j0, sc, pl, 0, z, 1); break;
-    default: return (int)hipErrorInvalidValue;
+    int rc = 0;
+    /* the tables in this stream's scratch survive between pieces: rebuild them only when the
+     * level plan asks for one that is not there (plan_state: bit 31 valid, bit 8 B table, low byte logA) */
+    const unsigned have = plan_state ? *plan_state : 0u;
+    const bool ok = (have >> 31) && (!pl.logA || (have & 0xffu) == pl.logA) && (!pl.needB || ((have >> 8) & 1u));
+    if (!ok) {
+        switch (nr) {
+        case 10: rc = launch_setup<10>(st, tb, ek, j0, sc, pl, 0, z, 1); break;
+        case 12: rc = launch_setup<12>(st, tb, ek, j0, sc, pl, 0, z, 1); break;
+        case 14: rc = launch_setup<14>(st, tb, ek, j0, sc, pl, 0, z, 1); break;
+        default: return (int)hipErrorInvalidValue;
+        }
+        if (rc) return rc;
+        if (plan_state) *plan_state = 0x80000000u | (pl.needB ? 0x100u : 0u) | pl.logA;
     }
-    if (rc) return rc;
     if (nv) {
         rc = run_ghash_levels(st, msg, nv, pl, sc, 2, sc + GS_PART, nullptr);
         if (rc) return rc;

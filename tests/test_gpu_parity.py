@@ -169,7 +169,8 @@ def test_gcm_stream_equals_one_shot(orc, bits):
     levels, ragged last piece) gives the bytes and the tag of one AES_GCM_encrypt call"""
     rnd = random.Random(bits + 8)
     for pieces, aad_len in [([16], 0), ([5], 3), ([16, 16, 7], 20), ([4096, 16, 65536, 1], 0),
-                            ([(1 << 20) + 16, 48, (600 << 10), 12345], 4097), ([0, 32, 0, 16], 16)]:
+                            ([(1 << 20) + 16, 48, (600 << 10), 12345], 4097), ([0, 32, 0, 16], 16),
+                            ([40 << 10, 2 << 20, 64, 5 << 20, 2 << 20, 100], 1)]:   # level plans change back and forth
         key, nonce, aad = rnd.randbytes(bits // 8), rnd.randbytes(12), rnd.randbytes(aad_len)
         n = sum(pieces)
         data = orc.splitmix(n + 11, n)
