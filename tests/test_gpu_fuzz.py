@@ -170,13 +170,20 @@ def test_fuzz_aead(orc):
         n = pick_size(rnd, cap)
         data = orc.splitmix(3000 + i, n)
         want = ref(key, nonce, aad, data)
+        aad_arg = aad
+        if aad and rnd.random() < 0.4:               # associated data in device memory, oddly aligned
+            import torch
+            off = rnd.choice([0, 1, 7])
+            taad = torch.zeros(len(aad) + 16, dtype=torch.uint8, device="cuda:0")
+            taad[off:off + len(aad)] = torch.frombuffer(bytearray(aad), dtype=torch.uint8).to("cuda:0")
+            aad_arg = C.c_void_p(taad.data_ptr() + off)
         b = Buffers(rnd, data, n + 16)
-        info = (name, bits, n, len(aad), b.describe())
-        assert enc(bits, key, nonce, aad, len(aad), b.pin, n, b.pout) == 0, info
+        info = (name, bits, n, len(aad), not isinstance(aad_arg, bytes), b.describe())
+        assert enc(bits, key, nonce, aad_arg, len(aad), b.pin, n, b.pout) == 0, info
         got, guard_ok = b.result()
         assert got == want and guard_ok, info
         b = Buffers(rnd, want, n)
-        assert dec(bits, key, nonce, aad, len(aad), b.pin, n, b.pout) == 0, info
+        assert dec(bits, key, nonce, aad_arg, len(aad), b.pin, n, b.pout) == 0, info
         assert b.result()[0] == data, info
         # one flipped bit anywhere (text, tag or aad) must be rejected
         bad = bytearray(want)
