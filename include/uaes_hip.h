@@ -203,7 +203,9 @@ void uaes_gcm_stream_abort(uaes_gcm_stream *s);
  * All data pointers are device pointers, 16-byte aligned; `stream` is a
  * hipStream_t (NULL = default stream).  The call only enqueues work.  Scratch
  * (GHASH tables, XTS chunk tweaks, OCB offsets) is kept per stream, so calls on
- * different streams may overlap; up to 8 streams per device without a drain.   */
+ * different streams may overlap; up to 8 streams per device without a drain.
+ * Calls that target the SAME stream must not be issued from two threads at once
+ * (a call enqueues several dependent kernels).                                  */
 int uaes_ecb_dev(int keybits, const uint8_t *key, int decrypt,
                  const void *d_in, size_t len, void *d_out, void *stream);
 int uaes_ctr_xcrypt_at_dev(int keybits, const uint8_t *key, const uint8_t ctr0[16],
