@@ -616,3 +616,31 @@ def test_large_single_calls_against_the_oracle(orc):
     pt = torch.empty(n, dtype=torch.uint8, device="cuda:0")
     assert L.uaes_ocb_decrypt(128, key, nonce, aad, len(aad), C.c_void_p(out.data_ptr()), n, C.c_void_p(pt.data_ptr())) == 0
     assert torch.equal(pt, src)
+
+
+def test_gcm_beyond_4GiB_equals_its_shards():
+    """64-bit indexing in CTR and GHASH: one 5 GiB + 40 B GCM message against five shards of it
+    (counter offsets above 2^28 blocks, weighted partial tags XORed) -- the oracle is too slow here,
+    the two code paths check each other; the head is pinned by the other tests"""
+    import torch
+    import micro_aes_amd.sharding as sh
+    total, world = (5 << 30) + 40, 5
+    key, nonce = bytes(range(16)), bytes(range(40, 52))
+    aad = torch.arange(23, dtype=torch.uint8, device="cuda:0")
+    src = torch.randint(0, 256, (total,), dtype=torch.uint8, device="cuda:0")
+    one = torch.empty(total + 16, dtype=torch.uint8, device="cuda:0")
+    uaes.gcm_encrypt_dev(key, nonce, aad, src, total, one)
+    torch.cuda.synchronize()
+    parts = torch.empty(total + 16, dtype=torch.uint8, device="cuda:0")
+    shares = []
+    for rank in range(world):
+        start, n, _ = sh.gcm_shard_roles(total, rank, world)
+        tag = sh.gcm_encrypt_sharded(key, nonce, aad, 23, total, src[start:start + n], parts[start:start + n], rank, world,
+                                     gather=lambda share: shares.append(share) or list(shares))
+    torch.cuda.synchronize()
+    assert torch.equal(one[:total], parts[:total])
+    assert tag == bytes(one[total:].cpu().numpy())
+    status = torch.full((1,), -1, dtype=torch.int32, device="cuda:0")
+    uaes.gcm_decrypt_dev(key, nonce, aad, one, total, parts, status)
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0 and torch.equal(parts[:total], src)
