@@ -228,6 +228,21 @@ int uaes_ocb_dev(int keybits, const uint8_t *key, const uint8_t *nonce, int decr
                  const void *d_aad, size_t aad_len,
                  const void *d_in, size_t len, void *d_out, int *d_status, void *stream);
 
+/* ---- one process, several GPUs -------------------------------------------------
+ * The text is cut into aligned slices, one per device; one host thread per device
+ * runs the single-device call on its slice with the counter / sector offset
+ * advanced (the 56-bit add of incBlock, micro_aes.c:421-427; the sectid convention
+ * of XTS_cipher, :1017-1021), so the result is the single-device result.  devices
+ * = ndev HIP device ordinals, or NULL for 0..ndev-1.  With host buffers every
+ * slice travels over its own device's PCIe link.  Pointers may be host memory
+ * or memory any of the devices can reach.                                      */
+int uaes_mgpu_ctr_xcrypt_at(int ndev, const int *devices, int keybits, const uint8_t *key,
+                            const uint8_t ctr0[16], uint64_t block_offset,
+                            const void *in, size_t len, void *out);
+int uaes_mgpu_xts_sectors(int ndev, const int *devices, int keybits, const uint8_t *keys,
+                          uint64_t first_sector, size_t sector_bytes, size_t nsectors,
+                          const void *in, void *out, int encrypt);
+
 /* ---- sharded GCM (multi-GPU) ------------------------------------------------
  * One message, cut into 16-byte aligned ciphertext shards, one per GPU.  Each
  * rank encrypts its shard with uaes_ctr_xcrypt_at_dev(ctr0 = nonce || 00000001,

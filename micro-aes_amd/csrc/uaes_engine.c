@@ -1242,3 +1242,111 @@ void uaes_gcm_stream_abort(uaes_gcm_stream *s)
     memset(s, 0, sizeof *s);                          /* key schedule */
     free(s);
 }
+
+/* ------------------------------------------------------------------------ */
+/* one process, several GPUs (extension 3)                       */
+/* ------------------------------------------------------------------------ */
+/* The text is cut into 16-byte (CTR) or data-unit (XTS) aligned slices, one per
+ * device; one host thread per device binds it (hipSetDevice is per thread) and
+ * runs the ordinary single-device call on its slice with the counter / sector
+ * offset advanced -- the per-device contexts make that safe.  With host buffers
+ * every device moves its slice over its own PCIe link, which is what scales.  */
+typedef struct {
+    int         device, keybits, mode, encrypt, rc;       /* mode 0 CTR, 1 XTS sectors */
+    const uint8_t *key;
+    uint8_t     ctr0[16];
+    uint64_t    offset;                                   /* block offset / first sector */
+    size_t      sector_bytes, nsectors;
+    const void *in;
+    void       *out;
+    size_t      len;
+    char        err[256];
+} mgpu_job;
+
+static void *mgpu_worker(void *arg)
+{
+    mgpu_job *j = (mgpu_job *)arg;
+    hipError_t e = hipSetDevice(j->device);
+    if (e != hipSuccess) {
+        j->rc = UAES_E_HIP;
+        snprintf(j->err, sizeof j->err, "hipSetDevice(%d): %s", j->device, hipGetErrorString(e));
+        return NULL;
+    }
+    j->rc = j->mode == 0
+        ? uaes_ctr_xcrypt_at(j->keybits, j->key, j->ctr0, j->offset, j->in, j->len, j->out)
+        : uaes_xts_sectors(j->keybits, j->key, j->offset, j->sector_bytes, j->nsectors, j->in, j->out, j->encrypt);
+    if (j->rc < 0) snprintf(j->err, sizeof j->err, "device %d: %s", j->device, uaes_last_error());
+    return NULL;
+}
+
+static int mgpu_run(mgpu_job *jobs, int n)
+{
+    pthread_t th[MAX_DEVICES];
+    int i, started = 0, rc = 0;
+    for (i = 0; i < n; ++i) {
+        if (pthread_create(&th[i], NULL, mgpu_worker, &jobs[i]) != 0) { rc = fail(UAES_E_HIP, "pthread_create failed"); break; }
+        ++started;
+    }
+    for (i = 0; i < started; ++i) pthread_join(th[i], NULL);
+    for (i = 0; i < started && rc == 0; ++i)
+        if (jobs[i].rc) rc = jobs[i].rc < 0 ? fail(jobs[i].rc, "%s", jobs[i].err) : jobs[i].rc;
+    return rc;
+}
+
+static int mgpu_devices(int ndev, const int *devices, int *out)
+{
+    int i, avail = 0;
+    if (ndev < 1 || ndev > MAX_DEVICES) return fail(UAES_E_ARG, "ndev must be 1..%d (got %d)", MAX_DEVICES, ndev);
+    if (hipGetDeviceCount(&avail) != hipSuccess || avail <= 0)
+        return fail(UAES_E_HIP, "no usable HIP device; this library has no CPU path");
+    for (i = 0; i < ndev; ++i) {
+        out[i] = devices ? devices[i] : i;
+        if (out[i] < 0 || out[i] >= avail) return fail(UAES_E_ARG, "device %d is not one of the %d visible", out[i], avail);
+    }
+    return 0;
+}
+
+int uaes_mgpu_ctr_xcrypt_at(int ndev, const int *devices, int keybits, const uint8_t *key,
+                            const uint8_t ctr0[16], uint64_t block_offset,
+                            const void *in, size_t len, void *out)
+{
+    mgpu_job jobs[MAX_DEVICES];
+    int dev[MAX_DEVICES], i, rc, n = 0;
+    const size_t blocks = (len + 15) / 16;
+    if (!key || !ctr0 || (len && (!in || !out))) return fail(UAES_E_ARG, "NULL pointer");
+    if ((rc = mgpu_devices(ndev, devices, dev)) != 0) return rc;
+    memset(jobs, 0, sizeof jobs);
+    for (i = 0; i < ndev; ++i) {
+        const size_t b0 = blocks * (size_t)i / (size_t)ndev, b1 = blocks * (size_t)(i + 1) / (size_t)ndev;
+        const size_t lo = b0 * 16, hi = b1 * 16 < len ? b1 * 16 : len;
+        if (hi <= lo) continue;
+        jobs[n].device = dev[i]; jobs[n].keybits = keybits; jobs[n].key = key; jobs[n].mode = 0;
+        memcpy(jobs[n].ctr0, ctr0, 16);
+        jobs[n].offset = block_offset + b0;
+        jobs[n].in = (const char *)in + lo; jobs[n].out = (char *)out + lo; jobs[n].len = hi - lo;
+        ++n;
+    }
+    return n ? mgpu_run(jobs, n) : 0;
+}
+
+int uaes_mgpu_xts_sectors(int ndev, const int *devices, int keybits, const uint8_t *keys,
+                          uint64_t first_sector, size_t sector_bytes, size_t nsectors,
+                          const void *in, void *out, int encrypt)
+{
+    mgpu_job jobs[MAX_DEVICES];
+    int dev[MAX_DEVICES], i, rc, n = 0;
+    if (!keys || (nsectors && (!in || !out))) return fail(UAES_E_ARG, "NULL pointer");
+    if (sector_bytes < 16) return UAES_E_DATALENGTH;
+    if ((rc = mgpu_devices(ndev, devices, dev)) != 0) return rc;
+    memset(jobs, 0, sizeof jobs);
+    for (i = 0; i < ndev; ++i) {
+        const size_t s0 = nsectors * (size_t)i / (size_t)ndev, s1 = nsectors * (size_t)(i + 1) / (size_t)ndev;
+        if (s1 <= s0) continue;
+        jobs[n].device = dev[i]; jobs[n].keybits = keybits; jobs[n].key = keys; jobs[n].mode = 1;
+        jobs[n].encrypt = encrypt; jobs[n].offset = first_sector + s0;
+        jobs[n].sector_bytes = sector_bytes; jobs[n].nsectors = s1 - s0;
+        jobs[n].in = (const char *)in + s0 * sector_bytes; jobs[n].out = (char *)out + s0 * sector_bytes;
+        ++n;
+    }
+    return n ? mgpu_run(jobs, n) : 0;
+}

@@ -164,3 +164,33 @@ def test_dev_api_rejects_misaligned_pointers():
         uaes.ctr_xcrypt_dev(key, bytes(16), 0, t[:4096], t[3:3 + 4096], nbytes=4096)
     with pytest.raises(uaes.EngineError, match="16-byte aligned"):
         uaes.ocb_dev(key, bytes(12), None, t[8:8 + 1024], 1024, t[2048:])
+
+
+def test_single_process_multi_gpu_entry_points(orc):
+    """uaes_mgpu_*: slices of one text on several devices from one process.  On a 1-GPU box the device
+    list names device 0 three times, which still exercises the slicing, the counter / sector offsets and
+    the per-device worker threads; the result must be the single-call result."""
+    L = uaes.engine()
+    rnd = random.Random(99)
+    key, keys = rnd.randbytes(32), rnd.randbytes(64)
+    ctr0 = rnd.randbytes(12) + b"\xff\xff\xff\xf0"
+    devs = (C.c_int * 3)(0, 0, 0)
+    for n in (0, 5, 16, 47, 100003, (3 << 20) + 9):
+        data = orc.splitmix(n + 1, n)
+        out = (C.c_uint8 * max(n, 1))()
+        assert L.uaes_mgpu_ctr_xcrypt_at(3, devs, 256, key, ctr0, 7, data, n, out) == 0
+        assert bytes(out)[:n] == orc.ctr_xcrypt_at(key, ctr0, 7, data), n
+        assert L.uaes_mgpu_ctr_xcrypt_at(1, None, 256, key, ctr0, 7, data, n, out) == 0
+        assert bytes(out)[:n] == orc.ctr_xcrypt_at(key, ctr0, 7, data), n
+    for sb, ns in ((512, 1), (512, 2), (4096 + 17, 7), (16, 100)):
+        data = orc.splitmix(sb + ns, sb * ns)
+        out = (C.c_uint8 * (sb * ns))()
+        assert L.uaes_mgpu_xts_sectors(3, devs, 256, keys, (1 << 40) + 5, sb, ns, data, out, 1) == 0
+        rc, want = orc.xts_sectors(keys, (1 << 40) + 5, sb, data, True)
+        assert rc == 0 and bytes(out) == want, (sb, ns)
+        back = (C.c_uint8 * (sb * ns))()
+        assert L.uaes_mgpu_xts_sectors(3, devs, 256, keys, (1 << 40) + 5, sb, ns, out, back, 0) == 0
+        assert bytes(back) == data
+    bad = (C.c_int * 1)(9)
+    assert L.uaes_mgpu_ctr_xcrypt_at(1, bad, 128, key, ctr0, 0, b"x" * 16, 16, out) == -2       # UAES_E_ARG
+    assert b"not one of" in L.uaes_last_error()
