@@ -29,33 +29,37 @@ static inline hipStream_t S(void *s) { return (hipStream_t)s; }
 /* ------------------------------------------------------------------------ */
 /* ECB                                                                        */
 /* ------------------------------------------------------------------------ */
-template <int NR, bool DEC>
+/* U = blocks per lane per iteration: 4 (two skewed pairs) for bulk texts, 1 for short ones, where
+ * spreading the blocks over four times as many CUs beats instruction-level parallelism          */
+template <int NR, bool DEC, int U>
 __global__ __launch_bounds__(UAES_WG) void k_ecb(uaesk_rk rk, uaesk_tables tb,
                                                  const uint4 *__restrict__ in, uint4 *__restrict__ out,
                                                  u64 nfull, u32 rem)
 {
     if (DEC) fill_dec_tables(tb.td0); else fill_enc_tables(tb.te0);
     const LaneConst lc = make_lane_const();
-    const u64 stride = (u64)gridDim.x * UAES_WG * UAES_U;
+    const u64 stride = (u64)gridDim.x * UAES_WG * U;
 
-    for (u64 base = (u64)blockIdx.x * UAES_WG * UAES_U; base < nfull; base += stride) {
-        u32 s[UAES_U][4];
-        u64 idx[UAES_U];
+    for (u64 base = (u64)blockIdx.x * UAES_WG * U; base < nfull; base += stride) {
+        u32 s[U][4];
+        u64 idx[U];
 #pragma unroll
-        for (int u = 0; u < UAES_U; ++u) {
+        for (int u = 0; u < U; ++u) {
             idx[u] = base + (u64)u * UAES_WG + threadIdx.x;
             uint4 d = make_uint4(0, 0, 0, 0);
             if (idx[u] < nfull) d = in[idx[u]];
             s[u][0] = d.x; s[u][1] = d.y; s[u][2] = d.z; s[u][3] = d.w;
         }
         if (DEC) {
-            dec_blocks<NR, UAES_U>(s, rk, lc);
-        } else {                                   /* two pairs, each half a round out of phase */
+            dec_blocks<NR, U>(s, rk, lc);
+        } else if (U == 4) {                       /* two pairs, each half a round out of phase */
             enc_blocks_skewed<NR>(s[0], s[1], rk, lc);
-            enc_blocks_skewed<NR>(s[2], s[3], rk, lc);
+            enc_blocks_skewed<NR>(s[2 % U], s[3 % U], rk, lc);
+        } else {
+            enc_blocks<NR, U>(s, rk, lc);
         }
 #pragma unroll
-        for (int u = 0; u < UAES_U; ++u)
+        for (int u = 0; u < U; ++u)
             if (idx[u] < nfull) out[idx[u]] = make_uint4(s[u][0], s[u][1], s[u][2], s[u][3]);
     }
 
@@ -424,8 +428,9 @@ __global__ __launch_bounds__(UAES_WG) void k_xts(uaesk_rk k1, uaesk_tables tb,
     if (DEC) fill_dec_tables(tb.td0); else fill_enc_tables(tb.te0);
     const LaneConst lc = make_lane_const();
     const u32 lane = threadIdx.x & 63u;
-    const u64 wave = (u64)blockIdx.x * (UAES_WG / 64) + (threadIdx.x >> 6);
-    const u64 nwaves = (u64)gridDim.x * (UAES_WG / 64);
+    /* launched with 16 waves per workgroup, or 4 for short texts (more CUs, see launch_xts) */
+    const u64 wave = (u64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const u64 nwaves = (u64)gridDim.x * (blockDim.x >> 6);
     const u64 nchunks = nsectors * chunks_per_sector;
 
     /* state of the chunk being fetched */
@@ -652,16 +657,27 @@ static hipError_t set_lds(K kern, unsigned bytes)
     default: return (int)hipErrorInvalidValue;        \
     }
 
+/* short texts: one block per lane, so that up to four times as many CUs take part */
+static bool short_text(u64 nblocks)
+{
+    return grid_for(nblocks, (u64)UAES_WG * UAES_U) * 2 <= grid_for(~0ull, 1);
+}
+
 template <int NR, bool DEC>
 static int launch_ecb(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *keys,
                       const void *in, void *out, size_t nfull, unsigned rem)
 {
     const unsigned lds = DEC ? UAES_LDS_DEC : UAES_LDS_ENC;
-    hipError_t e = set_lds(k_ecb<NR, DEC>, lds);
+    hipError_t e = set_lds(k_ecb<NR, DEC, UAES_U>, lds);
+    if (e == hipSuccess) e = set_lds(k_ecb<NR, DEC, 1>, lds);
     if (e != hipSuccess) return (int)e;
-    const unsigned grid = grid_for(nfull + (rem ? 1 : 0), (u64)UAES_WG * UAES_U);
-    hipLaunchKernelGGL((k_ecb<NR, DEC>), dim3(grid), dim3(UAES_WG), lds, st, *keys, *tb,
-                       (const uint4 *)in, (uint4 *)out, (u64)nfull, (u32)rem);
+    const u64 items = nfull + (rem ? 1 : 0);
+    if (short_text(items))
+        hipLaunchKernelGGL((k_ecb<NR, DEC, 1>), dim3(grid_for(items, UAES_WG)), dim3(UAES_WG), lds, st, *keys, *tb,
+                           (const uint4 *)in, (uint4 *)out, (u64)nfull, (u32)rem);
+    else
+        hipLaunchKernelGGL((k_ecb<NR, DEC, UAES_U>), dim3(grid_for(items, (u64)UAES_WG * UAES_U)), dim3(UAES_WG), lds, st,
+                           *keys, *tb, (const uint4 *)in, (uint4 *)out, (u64)nfull, (u32)rem);
     return (int)hipGetLastError();
 }
 
@@ -675,7 +691,7 @@ extern "C" int uaesk_ecb(void *stream, const uaesk_tables *tb, int nr, const uae
 }
 
 template <int NR, int U>
-static int launch_ctr_v(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek, const uaesk_ctr *ctr,
+static int launch_ctr_u(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek, const uaesk_ctr *ctr,
                         const void *in, void *out, size_t len, const int *gate)
 {
     const unsigned lds = UAES_LDS_ENC;
@@ -687,6 +703,15 @@ static int launch_ctr_v(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *
     hipLaunchKernelGGL((k_ctr<NR, U>), dim3(grid), dim3(UAES_WG), lds, st, *ek, *tb, *ctr,
                        (const uint4 *)in, (uint4 *)out, nfull, rem, gate);
     return (int)hipGetLastError();
+}
+
+/* the generic kernel: four blocks per lane, or one for short texts (see short_text) */
+template <int NR, int U>
+static int launch_ctr_v(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek, const uaesk_ctr *ctr,
+                        const void *in, void *out, size_t len, const int *gate)
+{
+    if (short_text((len + 15) / 16)) return launch_ctr_u<NR, 1>(st, tb, ek, ctr, in, out, len, gate);
+    return launch_ctr_u<NR, U>(st, tb, ek, ctr, in, out, len, gate);
 }
 
 /* Shared-round kernel: whole 64-group chunks in the pipelined main loop, the
@@ -812,7 +837,10 @@ static int launch_xts(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *k1
                            dim3(UAES_WG), 0, st, *xts_pow_table(), (u64)nsectors, cps, (uint4 *)scratch);
     if (mb > 0) {
         const u64 nchunks = (u64)nsectors * ((mb + XTS_CHUNK - 1) / XTS_CHUNK);
-        hipLaunchKernelGGL((k_xts<NR, DEC>), dim3(grid_for(nchunks, UAES_WG / 64)), dim3(UAES_WG), lds, st,
+        /* one wave per 256-block chunk: a short text on 16-wave workgroups would sit on a few CUs,
+         * so below half a GPU's worth of chunks the workgroups shrink to 4 waves              */
+        const unsigned wg = grid_for(nchunks, UAES_WG / 64) * 2 <= grid_for(~0ull, 1) ? 256u : UAES_WG;
+        hipLaunchKernelGGL((k_xts<NR, DEC>), dim3(grid_for(nchunks, wg / 64)), dim3(wg), lds, st,
                            *k1, *tb, (const uint4 *)scratch, (u64)nsectors, cps, mb, (u64)sector_bytes,
                            (const unsigned char *)in, (unsigned char *)out);
     }

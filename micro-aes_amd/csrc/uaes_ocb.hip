@@ -123,7 +123,7 @@ __device__ __forceinline__ void wave_xor_reduce(u32 (&v)[4])
 /* ------------------------------------------------------------------------ */
 template <int NR>
 __global__ __launch_bounds__(UAES_WG) void k_ocb_setup(uaesk_rk ek, uaesk_tables tb,
-                                                       uint4 nonce_block, u32 bottom,
+                                                       uint4 nonce_block, u32 bottom, u32 nrows,
                                                        uint4 *__restrict__ scr)
 {
     fill_enc_tables(tb.te0);
@@ -131,7 +131,8 @@ __global__ __launch_bounds__(UAES_WG) void k_ocb_setup(uaesk_rk ek, uaesk_tables
     if (threadIdx.x != 0) return;
     B16 l = { { 0, 0, 0, 0 } };
     ocb_enc1<NR>(l, ek, lc);                          /* L_* = Enc(0)                  */
-    for (u32 j = 0; j < OCB_NL; ++j) {                /* L_$, L_0, L_1, ... by doubling */
+    for (u32 j = 0; j < nrows; ++j) {                 /* L_$, L_0, L_1, ... by doubling: only as far as
+                                                         the block indices of this call reach */
         scr[j] = u4(l);
         l = ocb_double(l);
     }
@@ -160,8 +161,9 @@ __global__ __launch_bounds__(UAES_WG) void k_ocb(uaesk_rk rk, uaesk_tables tb,
     if (DEC) fill_dec_tables(tb.td0); else fill_enc_tables(tb.te0);
     const LaneConst lc = make_lane_const();
     const u32 lane = threadIdx.x & 63u;
-    const u64 wave = (u64)blockIdx.x * (UAES_WG / 64) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const u64 nwaves = (u64)gridDim.x * (UAES_WG / 64);
+    /* launched with 16 waves per workgroup, or 4 for short texts (more CUs, see launch_ocb) */
+    const u64 wave = (u64)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const u64 nwaves = (u64)gridDim.x * (blockDim.x >> 6);
     const u64 nchunks = (nblocks >> 8) + 1;           /* indices 0..nblocks, index 0 unused */
 
     /* Offset_i - Offset_0 for i = 256 c + 64 u + lane splits into a lane part (bits 0..5 of
@@ -380,7 +382,12 @@ static int launch_ocb(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek
     if (e == hipSuccess) e = want_lds((const void *)k_ocb_final<NR>);
     if (e == hipSuccess) e = want_lds(decrypt ? (const void *)k_ocb<NR, true> : (const void *)k_ocb<NR, false>);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((k_ocb_setup<NR>), dim3(1), dim3(UAES_WG), OCB_LDS, st, *ek, *tb, nb, bottom, scr);
+    /* row 2+j holds L_j; block indices below 2^b (text or AAD) reach L_0..L_b; L_0..L_7 always */
+    u64 span = (u64)(len >> 4) | (u64)(aad_len >> 4) | 255u;
+    u32 bits = 0;
+    while (span) { ++bits; span >>= 1; }
+    const u32 nrows = 2u + bits + 2u < OCB_NL ? 2u + bits + 2u : OCB_NL;
+    hipLaunchKernelGGL((k_ocb_setup<NR>), dim3(1), dim3(UAES_WG), OCB_LDS, st, *ek, *tb, nb, bottom, nrows, scr);
     const u64 nblocks = len >> 4;
     u32 nparts = 0;
     if (nblocks) {
@@ -389,15 +396,17 @@ static int launch_ocb(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek
         u32 run = OCB_RUN_MAX;
         while (run > 1 && nchunks / run < 8ull * cu_count() * (UAES_WG / 64)) run >>= 1;
         const u64 runs = (nchunks + run - 1) / run;
-        u64 grid = (runs + UAES_WG / 64 - 1) / (UAES_WG / 64);
+        /* short texts: 4-wave workgroups, so that the few chunks spread over more CUs */
+        const unsigned wg = (runs + UAES_WG / 64 - 1) / (UAES_WG / 64) * 2 <= cu_count() ? 256u : UAES_WG;
+        u64 grid = (runs + wg / 64 - 1) / (wg / 64);
         if (grid > cu_count()) grid = cu_count();
         if (grid > OCB_MAX_WGS) grid = OCB_MAX_WGS;
         nparts = (u32)grid;
         if (decrypt)
-            hipLaunchKernelGGL((k_ocb<NR, true>), dim3((unsigned)grid), dim3(UAES_WG), OCB_LDS, st, *dk, *tb, scr,
+            hipLaunchKernelGGL((k_ocb<NR, true>), dim3((unsigned)grid), dim3(wg), OCB_LDS, st, *dk, *tb, scr,
                                nblocks, run, (const uint4 *)in, (uint4 *)out);
         else
-            hipLaunchKernelGGL((k_ocb<NR, false>), dim3((unsigned)grid), dim3(UAES_WG), OCB_LDS, st, *ek, *tb, scr,
+            hipLaunchKernelGGL((k_ocb<NR, false>), dim3((unsigned)grid), dim3(wg), OCB_LDS, st, *ek, *tb, scr,
                                nblocks, run, (const uint4 *)in, (uint4 *)out);
     }
     hipLaunchKernelGGL((k_ocb_final<NR>), dim3(1), dim3(UAES_WG), OCB_LDS, st, *ek, *tb, scr, nparts, decrypt,
