@@ -644,3 +644,21 @@ def test_gcm_beyond_4GiB_equals_its_shards():
     uaes.gcm_decrypt_dev(key, nonce, aad, one, total, parts, status)
     torch.cuda.synchronize()
     assert int(status.item()) == 0 and torch.equal(parts[:total], src)
+
+
+def test_gmac_of_a_bulk_text(orc):
+    """authentication only (empty plaintext, the text as AAD): aligned device AAD takes whole-block
+    loads, a misaligned one the byte path; both against the oracle, sizes around the level plans"""
+    import torch
+    L = uaes.engine()
+    key, nonce = bytes(range(16, 32)), bytes(range(12))
+    for n in (1, 16, 4097, (1 << 20) + 5, (6 << 20) + 16):
+        data = orc.splitmix(n + 77, n)
+        want = orc.gcm_encrypt(key, nonce, data, b"")
+        t = torch.zeros(n + 32, dtype=torch.uint8, device="cuda:0")
+        for off in (0, 16, 3):
+            t[off:off + n] = torch.frombuffer(bytearray(data), dtype=torch.uint8).to("cuda:0")
+            tag = (C.c_uint8 * 16)()
+            assert L.uaes_gcm_encrypt(128, key, nonce, C.c_void_p(t.data_ptr() + off), n, None, 0, tag) == 0
+            assert bytes(tag) == want, (n, off)
+            assert L.uaes_gcm_decrypt(128, key, nonce, C.c_void_p(t.data_ptr() + off), n, tag, 0, None) == 0
