@@ -32,20 +32,20 @@ static inline hipStream_t S(void *s) { return (hipStream_t)s; }
  * CFB=true : CFB decrypt of blocks [0, n): out_i = Enc(prev_i) ^ in_i, plus
  *            `rem` tail bytes out = Enc(prev_n)[0..rem) ^ in   (mixThenXor, :816)
  * prev_0 = iv, prev_i = in_{i-1}.                                            */
-template <int NR, bool CFB>
+template <int NR, bool CFB, int U>                 /* U blocks per lane: 4 for bulk texts, 1 for short ones */
 __global__ __launch_bounds__(UAES_WG) void k_fb_dec(uaesk_rk rk, uaesk_tables tb, uint4 iv,
                                                     const uint4 *__restrict__ in, uint4 *__restrict__ out,
                                                     u64 n, u32 rem)
 {
     if (CFB) fill_enc_tables(tb.te0); else fill_dec_tables(tb.td0);
     const LaneConst lc = make_lane_const();
-    const u64 stride = (u64)gridDim.x * UAES_WG * UAES_U;
-    for (u64 base = (u64)blockIdx.x * UAES_WG * UAES_U; base < n; base += stride) {
-        u32 s[UAES_U][4];
-        uint4 x[UAES_U], prev[UAES_U];
-        u64 idx[UAES_U];
+    const u64 stride = (u64)gridDim.x * UAES_WG * U;
+    for (u64 base = (u64)blockIdx.x * UAES_WG * U; base < n; base += stride) {
+        u32 s[U][4];
+        uint4 x[U], prev[U];
+        u64 idx[U];
 #pragma unroll
-        for (int u = 0; u < UAES_U; ++u) {
+        for (int u = 0; u < U; ++u) {
             idx[u] = base + (u64)u * UAES_WG + threadIdx.x;
             const u64 i = idx[u] < n ? idx[u] : n - 1;
             x[u] = in[i];
@@ -53,9 +53,16 @@ __global__ __launch_bounds__(UAES_WG) void k_fb_dec(uaesk_rk rk, uaesk_tables tb
             const uint4 src = CFB ? prev[u] : x[u];
             s[u][0] = src.x; s[u][1] = src.y; s[u][2] = src.z; s[u][3] = src.w;
         }
-        if (CFB) enc_blocks<NR, UAES_U>(s, rk, lc); else dec_blocks<NR, UAES_U>(s, rk, lc);
+        if (!CFB) {
+            dec_blocks<NR, U>(s, rk, lc);
+        } else if (U == 4) {                       /* two pairs, each half a round out of phase */
+            enc_blocks_skewed<NR>(s[0], s[1], rk, lc);
+            enc_blocks_skewed<NR>(s[2 % U], s[3 % U], rk, lc);
+        } else {
+            enc_blocks<NR, U>(s, rk, lc);
+        }
 #pragma unroll
-        for (int u = 0; u < UAES_U; ++u) {
+        for (int u = 0; u < U; ++u) {
             const uint4 m = CFB ? x[u] : prev[u];
             if (idx[u] < n) out[idx[u]] = make_uint4(s[u][0] ^ m.x, s[u][1] ^ m.y, s[u][2] ^ m.z, s[u][3] ^ m.w);
         }
@@ -230,19 +237,29 @@ static unsigned cu_count()
     return cus > 0 ? (unsigned)cus : 256u;
 }
 
+template <int NR, bool CFB, int U>
+static int launch_fb_dec_u(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *k, uint4 iv,
+                           const void *in, void *out, u64 n, u32 rem)
+{
+    const unsigned lds = CFB ? UAES_LDS_ENC : UAES_LDS_DEC;
+    hipError_t e = hipFuncSetAttribute((const void *)k_fb_dec<NR, CFB, U>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    u64 want = (n + (u64)UAES_WG * U - 1) / ((u64)UAES_WG * U);
+    if (!want) want = 1;
+    const unsigned grid = (unsigned)(want < cu_count() ? want : cu_count());
+    hipLaunchKernelGGL((k_fb_dec<NR, CFB, U>), dim3(grid), dim3(UAES_WG), lds, st, *k, *tb, iv,
+                       (const uint4 *)in, (uint4 *)out, n, rem);
+    return (int)hipGetLastError();
+}
+
+/* short texts take one block per lane so that up to four times as many CUs take part */
 template <int NR, bool CFB>
 static int launch_fb_dec(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *k, uint4 iv,
                          const void *in, void *out, u64 n, u32 rem)
 {
-    const unsigned lds = CFB ? UAES_LDS_ENC : UAES_LDS_DEC;
-    hipError_t e = hipFuncSetAttribute((const void *)k_fb_dec<NR, CFB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    u64 want = (n + (u64)UAES_WG * UAES_U - 1) / ((u64)UAES_WG * UAES_U);
-    if (!want) want = 1;
-    const unsigned grid = (unsigned)(want < cu_count() ? want : cu_count());
-    hipLaunchKernelGGL((k_fb_dec<NR, CFB>), dim3(grid), dim3(UAES_WG), lds, st, *k, *tb, iv,
-                       (const uint4 *)in, (uint4 *)out, n, rem);
-    return (int)hipGetLastError();
+    const u64 wgs4 = (n + (u64)UAES_WG * UAES_U - 1) / ((u64)UAES_WG * UAES_U);
+    if (wgs4 * 2 <= cu_count()) return launch_fb_dec_u<NR, CFB, 1>(st, tb, k, iv, in, out, n, rem);
+    return launch_fb_dec_u<NR, CFB, UAES_U>(st, tb, k, iv, in, out, n, rem);
 }
 
 template <int NR, int OP>
