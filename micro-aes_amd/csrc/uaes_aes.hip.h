@@ -76,8 +76,38 @@ __device__ __forceinline__ u32 bswap32(u32 v)
 /* per-lane address constants: bits 0..7 = bank slot (+128 for odd tables),
  * bits 16..23 = 64 KiB region of the table pair                            */
 struct LaneConst {
+    static constexpr int LAY = 0;
     u32 t[4];
     u32 m1;          /* 0x0000ff00 held in a VGPR (all-VGPR bitop3 issues faster) */
+};
+
+/* ---- the 64 KiB layout ("split halves") -----------------------------------
+ * Every table is replicated 16x instead of 32x: entry x of table k lives at
+ *     x*256 + (k&1)*128 + (k>>1)*64 + 4*(l&15)
+ * i.e. Te0/Te1 own banks 0..15 and Te2/Te3 banks 16..31.  ds_read_b32 serves
+ * lanes {0..31} then {32..63}; inside each group of 32 the lanes come in two
+ * TYPES, h = (l>>4)&1, and at every lookup instruction the two types read
+ * tables from OPPOSITE bank halves, so the lookup stays conflict-free:
+ *   type 0 (natural): instruction slot r takes byte r of its register through Te_r;
+ *   type 1 (shifted): slot r takes byte r+2 through Te_{r+2} (mod 4).
+ * Both are valid MixColumns terms; a type-1 lane simply produces output column
+ * j+2 where a type-0 lane produces column j, so its registers hold the columns
+ * rotated by two after every ODD round and aligned again after every even one
+ * (NR is even: the result is aligned).  The only cost is the round key of the
+ * odd rounds, whose words 0<->2 and 1<->3 swap on type-1 lanes (one extra XOR per
+ * column with a per-lane delta).  The last round and the inverse cipher follow the
+ * same rule through per-lane v_perm selectors (uaes_aes.hip.h: tlook, combine16).
+ * 64 KiB of tables let TWO 1024-thread workgroups share a CU (32 waves), which
+ * overlaps the LDS pipe and the VALU far better than 16 waves do.            */
+#define UAES_LDS_T64   (64u * 1024u)
+
+struct LaneConst2 {
+    static constexpr int LAY = 1;
+    u32 t[4];        /* address byte 0 for "table k" (type 1: table k+2)            */
+    u32 sel[4];      /* v_perm selector taking "byte b" (type 1: byte b+2) to bits 8..15 */
+    u32 selA, selB;  /* last-round merges (swapped on type-1 lanes)                  */
+    u32 selD;        /* decrypt last round: order of the two folded halves           */
+    u32 hmask;       /* ~0 on type-1 lanes                                           */
 };
 
 __device__ __forceinline__ LaneConst make_lane_const()
@@ -92,7 +122,43 @@ __device__ __forceinline__ LaneConst make_lane_const()
     return lc;
 }
 
+__device__ __forceinline__ LaneConst2 make_lane_const2()
+{
+    LaneConst2 lc;
+    const u32 h = (threadIdx.x >> 4) & 1u, slot = (threadIdx.x & 15u) << 2;
+#pragma unroll
+    for (u32 k = 0; k < 4; ++k) {
+        const u32 kk = (k + 2u * h) & 3u;
+        lc.t[k] = slot | ((kk & 1u) << 7) | ((kk >> 1) << 6);
+        lc.sel[k] = 0x0c0c0000u | ((4u + kk) << 8);
+    }
+    lc.selA = h ? 0x07020c0cu : 0x0c0c0500u;
+    lc.selB = h ? 0x0c0c0500u : 0x07020c0cu;
+    lc.selD = h ? 0x02000604u : 0x06040200u;
+    lc.hmask = 0u - h;
+    return lc;
+}
+
 /* lookup table TBL with byte BYTE of w as index */
+template <int TBL, int BYTE>
+__device__ __forceinline__ u32 tlook(u32 w, const LaneConst2 &lc)
+{
+    return lds_word(__builtin_amdgcn_perm(w, lc.t[TBL], lc.sel[BYTE]));
+}
+
+/* the true table TBL at true byte BYTE whatever the lane type (for rare, non-uniform
+ * lookups: may bank-conflict with the other half of the lanes)                   */
+template <int TBL, int BYTE>
+__device__ __forceinline__ u32 tlook_true(u32 w, const LaneConst2 &lc)
+{
+    const u32 c = (lc.t[0] & 0x3cu) | ((TBL & 1u) << 7) | ((TBL >> 1) << 6);
+    return lds_word(__builtin_amdgcn_perm(w, c, 0x0c0c0000u | ((4u + BYTE) << 8)));
+}
+template <int TBL, int BYTE>
+__device__ __forceinline__ u32 tlook(u32 w, const LaneConst &lc);
+template <int TBL, int BYTE>
+__device__ __forceinline__ u32 tlook_true(u32 w, const LaneConst &lc) { return tlook<TBL, BYTE>(w, lc); }
+
 template <int TBL, int BYTE>
 __device__ __forceinline__ u32 tlook(u32 w, const LaneConst &lc)
 {
@@ -128,81 +194,45 @@ __device__ __forceinline__ void fill_enc_tables(const u32 *__restrict__ te0)
     __syncthreads();
 }
 
+/* 64 KiB layout: 16 replicas (64 B) per entry */
+__device__ __forceinline__ void fill_tables64(const u32 *__restrict__ t0)
+{
+    for (u32 i = threadIdx.x; i < 1024u; i += blockDim.x) {
+        const u32 x = i & 255u, k = i >> 8;
+        const u32 v = rotl32(t0[x], 8u * k);
+        const uint4 vv = make_uint4(v, v, v, v);
+        uint4 *dst = (uint4 *)(uaes_lds + x * 256u + (k & 1u) * 128u + (k >> 1) * 64u);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[r] = vv;
+    }
+    __syncthreads();
+}
+
 /* Td_k[x] = rotl(Td0[x], 8k); Td0 bytes = {14Si, 9Si, 13Si, 11Si}; same layout as Te */
 __device__ __forceinline__ void fill_dec_tables(const u32 *__restrict__ td0)
 {
     fill_enc_tables(td0);
 }
 
-/* ---- encryption rounds -------------------------------------------------- */
-/* one full round (SubBytes, ShiftRows, MixColumns, AddRoundKey rk) of one column */
-__device__ __forceinline__ u32 enc_col(u32 a, u32 b, u32 c, u32 d, u32 key, const LaneConst &lc)
+/* ---- rounds --------------------------------------------------------------- */
+/* Round-key word c for the state produced by round `r` (LaneConst2: after an odd
+ * round the columns of a type-1 lane sit two places on, so it needs word c^2).    */
+template <typename LC>
+__device__ __forceinline__ void key_delta(const u32 *rk, const LC &lc, bool odd, u32 (&d)[2])
 {
-    return xor3(xor3(tlook<0, 0>(a, lc), tlook<1, 1>(b, lc), tlook<2, 2>(c, lc)), tlook<3, 3>(d, lc), key);
-}
-
-template <int U>
-__device__ __forceinline__ void enc_round(u32 (&s)[U][4], const u32 *rk, const LaneConst &lc)
-{
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const u32 a = s[u][0], b = s[u][1], c = s[u][2], d = s[u][3];
-        s[u][0] = enc_col(a, b, c, d, rk[0], lc);
-        s[u][1] = enc_col(b, c, d, a, rk[1], lc);
-        s[u][2] = enc_col(c, d, a, b, rk[2], lc);
-        s[u][3] = enc_col(d, a, b, c, rk[3], lc);
+    d[0] = d[1] = 0;
+    if (LC::LAY == 1 && odd) {
+        d[0] = (rk[0] ^ rk[2]) & ((const LaneConst2 &)lc).hmask;
+        d[1] = (rk[1] ^ rk[3]) & ((const LaneConst2 &)lc).hmask;
     }
 }
 
-/* last round: SubBytes, ShiftRows, AddRoundKey.  S[x] sits in byte r of Te2 (r=0),
- * Te3 (r=1), Te0 (r=2), Te1 (r=3).                                               */
-__device__ __forceinline__ u32 last_col(u32 a, u32 b, u32 c, u32 d, u32 key, const LaneConst &lc)
-{
-    const u32 lo = __builtin_amdgcn_perm(tlook<3, 1>(b, lc), tlook<2, 0>(a, lc), 0x0c0c0500u);   /* r0.b0, r1.b1 */
-    const u32 hi = __builtin_amdgcn_perm(tlook<1, 3>(d, lc), tlook<0, 2>(c, lc), 0x07020c0cu);   /* r2.b2, r3.b3 */
-    return or_xor(lo, hi, key);
-}
-
-template <int U>
-__device__ __forceinline__ void enc_last_round(u32 (&s)[U][4], const u32 *rk, const LaneConst &lc)
-{
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const u32 a = s[u][0], b = s[u][1], c = s[u][2], d = s[u][3];
-        s[u][0] = last_col(a, b, c, d, rk[0], lc);
-        s[u][1] = last_col(b, c, d, a, rk[1], lc);
-        s[u][2] = last_col(c, d, a, b, rk[2], lc);
-        s[u][3] = last_col(d, a, b, c, rk[3], lc);
-    }
-}
-
-/* rounds FIRST..NR on states that already hold the input of round FIRST
- * (i.e. after AddRoundKey(FIRST-1)); rk = all round keys                   */
-template <int NR, int U, int FIRST>
-__device__ __forceinline__ void enc_rounds_from(u32 (&s)[U][4], const uaesk_rk &rk, const LaneConst &lc)
-{
-#pragma unroll
-    for (int r = FIRST; r < NR; ++r) enc_round<U>(s, &rk.w[4 * r], lc);
-    enc_last_round<U>(s, &rk.w[4 * NR], lc);
-}
-
-/* full cipher on U blocks (state = plaintext words on entry) */
-template <int NR, int U>
-__device__ __forceinline__ void enc_blocks(u32 (&s)[U][4], const uaesk_rk &rk, const LaneConst &lc)
-{
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        s[u][0] ^= rk.w[0]; s[u][1] ^= rk.w[1]; s[u][2] ^= rk.w[2]; s[u][3] ^= rk.w[3];
-    }
-    enc_rounds_from<NR, U, 1>(s, rk, lc);
-}
-
-/* ---- split-phase rounds (software pipelining across two blocks) ---------- */
 /* issue the 16 lookups of one round of one block; results are consumed later.
  * DEC: the equivalent inverse cipher (FIPS-197 sec. 5.3.5): column c takes row r
- * from column (c - r) mod 4 instead of (c + r); its last round reads Td0 only.   */
-template <bool LAST, bool DEC = false>
-__device__ __forceinline__ void issue16(const u32 (&s)[4], u32 (&t)[16], const LaneConst &lc)
+ * from column (c - r) mod 4 instead of (c + r); its last round reads Td0 only.
+ * Last encryption round: S[x] sits in byte r of Te2 (r=0), Te3 (r=1), Te0 (r=2), Te1 (r=3). */
+template <bool LAST, bool DEC, typename LC>
+__device__ __forceinline__ void issue16(const u32 (&s)[4], u32 (&t)[16], const LC &lc)
 {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -222,7 +252,8 @@ __device__ __forceinline__ void issue16(const u32 (&s)[4], u32 (&t)[16], const L
 
 /* Si[x0] | Si[x1] << 16 (bytes 1 and 3 are junk) from the Td0 words of x0 and x1:
  * g = t ^ rot16(t) has b0^b2 | b1^b3 in its low half; pair the two low halves and
- * fold the odd bytes onto the even ones.                                        */
+ * fold the odd bytes onto the even ones.  (Invariant under rot16 of t: a type-1
+ * lane of the 64 KiB layout reads Td2 = rot16(Td0) here.)                      */
 __device__ __forceinline__ u32 fold2(u32 t0, u32 t1)
 {
     const u32 g0 = t0 ^ __builtin_amdgcn_alignbit(t0, t0, 16), g1 = t1 ^ __builtin_amdgcn_alignbit(t1, t1, 16);
@@ -230,22 +261,70 @@ __device__ __forceinline__ u32 fold2(u32 t0, u32 t1)
     return p ^ (p >> 8);
 }
 
-template <bool LAST, bool DEC = false>
-__device__ __forceinline__ void combine16(const u32 (&t)[16], const u32 *rk, u32 (&s)[4])
+/* `odd`: the round number producing this state is odd (matters to LaneConst2 only) */
+template <bool LAST, bool DEC, typename LC>
+__device__ __forceinline__ void combine16(const u32 (&t)[16], const u32 *rk, u32 (&s)[4], const LC &lc, bool odd)
 {
+    u32 dl[2];
+    key_delta(rk, lc, !LAST && odd, dl);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        if (!LAST)
+        if (!LAST) {
             s[c] = xor3(xor3(t[4 * c], t[4 * c + 1], t[4 * c + 2]), t[4 * c + 3], rk[c]);
-        else if (!DEC)
-            s[c] = or_xor(__builtin_amdgcn_perm(t[4 * c + 1], t[4 * c], 0x0c0c0500u),
-                          __builtin_amdgcn_perm(t[4 * c + 3], t[4 * c + 2], 0x07020c0cu), rk[c]);
-        else                                          /* rows 0,1 | rows 2,3 -> bytes 0..3 */
-            s[c] = __builtin_amdgcn_perm(fold2(t[4 * c + 2], t[4 * c + 3]), fold2(t[4 * c], t[4 * c + 1]),
-                                         0x06040200u) ^ rk[c];
+            if (LC::LAY == 1 && odd) s[c] ^= dl[c & 1];
+        } else if (!DEC) {
+            if (LC::LAY == 1) {
+                const LaneConst2 &l2 = (const LaneConst2 &)lc;
+                s[c] = or_xor(__builtin_amdgcn_perm(t[4 * c + 1], t[4 * c], l2.selA),
+                              __builtin_amdgcn_perm(t[4 * c + 3], t[4 * c + 2], l2.selB), rk[c]);
+            } else {
+                s[c] = or_xor(__builtin_amdgcn_perm(t[4 * c + 1], t[4 * c], 0x0c0c0500u),
+                              __builtin_amdgcn_perm(t[4 * c + 3], t[4 * c + 2], 0x07020c0cu), rk[c]);
+            }
+        } else {                                      /* rows 0,1 | rows 2,3 -> bytes 0..3 */
+            const u32 seld = LC::LAY == 1 ? ((const LaneConst2 &)lc).selD : 0x06040200u;
+            s[c] = __builtin_amdgcn_perm(fold2(t[4 * c + 2], t[4 * c + 3]), fold2(t[4 * c], t[4 * c + 1]), seld) ^ rk[c];
+        }
     }
 }
 
+/* rounds FIRST..NR on U blocks in lock step; states hold the input of round FIRST
+ * (i.e. after AddRoundKey(FIRST-1)); rk = all round keys                          */
+template <int NR, int U, int FIRST, bool DEC, typename LC>
+__device__ __forceinline__ void rounds_from(u32 (&s)[U][4], const uaesk_rk &rk, const LC &lc)
+{
+    u32 t[U][16];
+#pragma unroll
+    for (int r = FIRST; r < NR; ++r) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) issue16<false, DEC>(s[u], t[u], lc);
+#pragma unroll
+        for (int u = 0; u < U; ++u) combine16<false, DEC>(t[u], &rk.w[4 * r], s[u], lc, (r & 1) != 0);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) issue16<true, DEC>(s[u], t[u], lc);
+#pragma unroll
+    for (int u = 0; u < U; ++u) combine16<true, DEC>(t[u], &rk.w[4 * NR], s[u], lc, false);
+}
+
+template <int NR, int U, int FIRST, typename LC>
+__device__ __forceinline__ void enc_rounds_from(u32 (&s)[U][4], const uaesk_rk &rk, const LC &lc)
+{
+    rounds_from<NR, U, FIRST, false>(s, rk, lc);
+}
+
+/* full cipher on U blocks (state = plaintext words on entry) */
+template <int NR, int U, typename LC>
+__device__ __forceinline__ void enc_blocks(u32 (&s)[U][4], const uaesk_rk &rk, const LC &lc)
+{
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        s[u][0] ^= rk.w[0]; s[u][1] ^= rk.w[1]; s[u][2] ^= rk.w[2]; s[u][3] ^= rk.w[3];
+    }
+    rounds_from<NR, U, 1, false>(s, rk, lc);
+}
+
+/* ---- split-phase rounds (software pipelining across two blocks) ---------- */
 /* rounds FIRST..NR of two blocks A and B, half a round out of phase: while the
  * 16 lookups of one block are in flight the wave does the other block's XORs
  * and address building, so its LDS queue never drains (a wave can have at most
@@ -253,8 +332,8 @@ __device__ __forceinline__ void combine16(const u32 (&t)[16], const u32 *rk, u32
  * lock-step version drains them to zero every ~12 lookups).                 */
 /* RKV: round keys FIRST..NR as an array indexed from 0 (may live in VGPRs: a
  * v_bitop3_b32 with an SGPR operand issues ~1.5 cycles slower than all-VGPR) */
-template <int NR, int FIRST, typename RKV, bool DEC = false>
-__device__ __forceinline__ void enc_rounds_skewed(u32 (&sa)[4], u32 (&sb)[4], const RKV &rkv, const LaneConst &lc)
+template <int NR, int FIRST, typename RKV, bool DEC = false, typename LC = LaneConst>
+__device__ __forceinline__ void enc_rounds_skewed(u32 (&sa)[4], u32 (&sb)[4], const RKV &rkv, const LC &lc)
 {
 #define rkp(r) (&rkv.w[4 * ((r) - FIRST)])
     u32 ta[16], tb[16];
@@ -264,17 +343,17 @@ __device__ __forceinline__ void enc_rounds_skewed(u32 (&sa)[4], u32 (&sb)[4], co
         __builtin_amdgcn_sched_barrier(0);
         issue16<false, DEC>(sb, tb, lc);
         __builtin_amdgcn_sched_barrier(0);
-        combine16<false, DEC>(ta, rkp(r), sa);
+        combine16<false, DEC>(ta, rkp(r), sa, lc, (r & 1) != 0);
         if (r + 1 < NR) issue16<false, DEC>(sa, ta, lc); else issue16<true, DEC>(sa, ta, lc);
         __builtin_amdgcn_sched_barrier(0);
-        combine16<false, DEC>(tb, rkp(r), sb);
+        combine16<false, DEC>(tb, rkp(r), sb, lc, (r & 1) != 0);
     }
     __builtin_amdgcn_sched_barrier(0);
     issue16<true, DEC>(sb, tb, lc);
     __builtin_amdgcn_sched_barrier(0);
-    combine16<true, DEC>(ta, rkp(NR), sa);
+    combine16<true, DEC>(ta, rkp(NR), sa, lc, false);
     __builtin_amdgcn_sched_barrier(0);
-    combine16<true, DEC>(tb, rkp(NR), sb);
+    combine16<true, DEC>(tb, rkp(NR), sb, lc, false);
 #undef rkp
 }
 
@@ -283,29 +362,29 @@ struct RkView {
     const u32 *w;
 };
 
-template <int NR>
-__device__ __forceinline__ void enc_blocks_skewed(u32 (&sa)[4], u32 (&sb)[4], const uaesk_rk &rk, const LaneConst &lc)
+template <int NR, typename LC>
+__device__ __forceinline__ void enc_blocks_skewed(u32 (&sa)[4], u32 (&sb)[4], const uaesk_rk &rk, const LC &lc)
 {
 #pragma unroll
     for (int c = 0; c < 4; ++c) { sa[c] ^= rk.w[c]; sb[c] ^= rk.w[c]; }
     const RkView v = { rk.w + 4 };
-    enc_rounds_skewed<NR, 1>(sa, sb, v, lc);
+    enc_rounds_skewed<NR, 1, RkView, false, LC>(sa, sb, v, lc);
 }
 
 /* ---- decryption (equivalent inverse cipher, FIPS-197 sec. 5.3.5) ---------- */
 /* two blocks, skewed; dk = equivalent-inverse round keys (uaesk_rk of uaes_device.h) */
-template <int NR>
-__device__ __forceinline__ void dec_blocks_skewed(u32 (&sa)[4], u32 (&sb)[4], const uaesk_rk &dk, const LaneConst &lc)
+template <int NR, typename LC>
+__device__ __forceinline__ void dec_blocks_skewed(u32 (&sa)[4], u32 (&sb)[4], const uaesk_rk &dk, const LC &lc)
 {
 #pragma unroll
     for (int c = 0; c < 4; ++c) { sa[c] ^= dk.w[c]; sb[c] ^= dk.w[c]; }
     const RkView v = { dk.w + 4 };
-    enc_rounds_skewed<NR, 1, RkView, true>(sa, sb, v, lc);
+    enc_rounds_skewed<NR, 1, RkView, true, LC>(sa, sb, v, lc);
 }
 
-/* U blocks: pairs run skewed, a single block runs the same code against a dummy partner-free path */
-template <int NR, int U>
-__device__ __forceinline__ void dec_blocks(u32 (&s)[U][4], const uaesk_rk &dk, const LaneConst &lc)
+/* U blocks: pairs run skewed, a single block runs round by round */
+template <int NR, int U, typename LC>
+__device__ __forceinline__ void dec_blocks(u32 (&s)[U][4], const uaesk_rk &dk, const LC &lc)
 {
     if (U % 2 == 0) {
 #pragma unroll
@@ -314,17 +393,10 @@ __device__ __forceinline__ void dec_blocks(u32 (&s)[U][4], const uaesk_rk &dk, c
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        u32 t[16];
 #pragma unroll
         for (int c = 0; c < 4; ++c) s[u][c] ^= dk.w[c];
-#pragma unroll
-        for (int r = 1; r < NR; ++r) {
-            issue16<false, true>(s[u], t, lc);
-            combine16<false, true>(t, &dk.w[4 * r], s[u]);
-        }
-        issue16<true, true>(s[u], t, lc);
-        combine16<true, true>(t, &dk.w[4 * NR], s[u]);
     }
+    rounds_from<NR, U, 1, true>(s, dk, lc);
 }
 
 #endif
