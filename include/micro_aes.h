@@ -51,7 +51,9 @@
 #define POLY1305 0
 #define MICRO_RJNDL 0
 
-#define AES_PADDING     0   /* zero padding of a ragged ECB tail            */
+#ifndef AES_PADDING          /* micro_aes.h:79 -- 0 zeros, 1 PKCS#7, 2 ISO/IEC 7816-4; a caller */
+#define AES_PADDING     0   /* built with -DAES_PADDING=1|2 gets that ECB padding (see below)   */
+#endif
 #define DECRYPTION      1
 #define PRESET_COUNTER  0   /* CTR takes a 12-byte IV; see uaes_ctr_xcrypt_at */
 
@@ -84,6 +86,17 @@ extern "C" {
 
 void AES_ECB_encrypt(const uint8_t *key,
                      const void *pntxt, const size_t ptextLen, void *crtxt);
+/* the same with padBlock's other two paddings (micro_aes.c:610-621): both ALWAYS append a
+ * block, so crtxt must hold (ptextLen / 16 + 1) * 16 bytes                              */
+void AES_ECB_encrypt_pkcs7(const uint8_t *key,
+                           const void *pntxt, const size_t ptextLen, void *crtxt);
+void AES_ECB_encrypt_iso7816(const uint8_t *key,
+                             const void *pntxt, const size_t ptextLen, void *crtxt);
+#if AES_PADDING == 1
+#define AES_ECB_encrypt AES_ECB_encrypt_pkcs7
+#elif AES_PADDING == 2
+#define AES_ECB_encrypt AES_ECB_encrypt_iso7816
+#endif
 char AES_ECB_decrypt(const uint8_t *key,
                      const void *crtxt, const size_t crtxtLen, void *pntxt);
 
@@ -142,6 +155,14 @@ char GCM_SIV_decrypt(const uint8_t *key, const uint8_t *nonce,
 
 void AES_CMAC(const uint8_t *key,
               const void *data, const size_t dataSize, uint8_t mac[16]);
+
+/* Not in the reference: what happens when a `void` function above cannot do its work
+ * (no usable HIP device, an allocation or launch failure -- there is no CPU path).  The
+ * default handler prints the reason and abort()s; install another to unwind instead.
+ * Returns the previous handler (NULL = the default).  fn = API name, rc = engine code
+ * (include/uaes_hip.h), msg = uaes_last_error().                                      */
+typedef void (*uaes_failure_handler)(const char *fn, int rc, const char *msg);
+uaes_failure_handler uaes_compat_set_failure_handler(uaes_failure_handler h);
 
 #ifdef __cplusplus
 }

@@ -54,6 +54,21 @@ int         uaes_selftest(void);
 const char *uaes_last_error(void);
 /* "uaes-hip <version> gfx950"                                               */
 const char *uaes_version(void);
+/* What CCM / GCM-SIV / OCB decryption leaves in pntxt when the tag is wrong.  These three
+ * modes decrypt before they authenticate; the reference's default build then returns 0x1A
+ * WITH the unauthenticated text in place (SABOTAGE is a no-op, micro_aes.c:1306-1312,
+ * :1500-1511, :1803-1810) and that is this library's default too, so results are
+ * bit-identical.  on != 0 selects the reference's INCREASE_SECURITY behaviour instead: the
+ * buffer is zeroed.  Process-wide; returns the previous setting.  (GCM never releases
+ * unauthenticated text; the *_dev calls report through d_status and leave the decision to
+ * the caller.)                                                                          */
+int         uaes_set_wipe_on_auth_failure(int on);
+/* The *_dev calls keep a device scratch buffer (GHASH tables, XTS chunk tweaks) per
+ * hipStream_t they have been used with (8 per device; beyond that the least recently
+ * used one is recycled after a device-wide drain).  Call this when a stream will not
+ * be used with the library any more -- before or after hipStreamDestroy -- to give
+ * its buffer back.  Waits for the device's outstanding work.                       */
+int         uaes_stream_release(void *stream);
 
 /* Host-side key schedule (KeyExpansion, micro_aes.c:144-178) as the kernels
  * receive it: (nr+1)*4 little-endian words of encryption round keys and of
@@ -71,6 +86,12 @@ int uaes_ecb_encrypt(int keybits, const uint8_t *key,
                      const void *pntxt, size_t ptextLen, void *crtxt);
 int uaes_ecb_decrypt(int keybits, const uint8_t *key,
                      const void *crtxt, size_t crtxtLen, void *pntxt);
+/* padding = the reference's compile-time AES_PADDING (micro_aes.h:79; padBlock,
+ * micro_aes.c:610-621): 0 as above; 1 PKCS#7 (n bytes of value n), 2 ISO/IEC 7816-4
+ * (0x80, zeros).  1 and 2 always append a block: (ptextLen / 16 + 1) * 16 bytes are
+ * written.  Decryption does not strip padding (nor does the reference's, :676-679). */
+int uaes_ecb_encrypt_padded(int keybits, const uint8_t *key, int padding,
+                            const void *pntxt, size_t ptextLen, void *crtxt);
 
 /* ---- CTR: replaces AES_CTR_encrypt / AES_CTR_decrypt --------------------
  * micro_aes.h:256-266, micro_aes.c:962-990.  iv = 12 bytes (CTR_IV_LENGTH);

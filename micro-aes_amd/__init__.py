@@ -32,8 +32,9 @@ M_DECRYPTION_ERROR = 0x1D
 M_ENCRYPTION_ERROR = 0x1E
 
 EXPORTS = [
-    "uaes_init", "uaes_selftest", "uaes_last_error", "uaes_version", "uaes_expand_key",
-    "uaes_ecb_encrypt", "uaes_ecb_decrypt", "uaes_ctr_xcrypt", "uaes_ctr_xcrypt_at",
+    "uaes_init", "uaes_selftest", "uaes_last_error", "uaes_version", "uaes_expand_key", "uaes_stream_release",
+    "uaes_set_wipe_on_auth_failure",
+    "uaes_ecb_encrypt", "uaes_ecb_encrypt_padded", "uaes_ecb_decrypt", "uaes_ctr_xcrypt", "uaes_ctr_xcrypt_at",
     "uaes_xts_encrypt", "uaes_xts_decrypt", "uaes_xts_sectors",
     "uaes_gcm_encrypt", "uaes_gcm_decrypt", "uaes_ghash",
     "uaes_cmac", "uaes_ccm_encrypt", "uaes_ccm_decrypt", "uaes_gcmsiv_encrypt", "uaes_gcmsiv_decrypt",
@@ -45,7 +46,8 @@ EXPORTS = [
     "uaes_gcm_encrypt_dev", "uaes_gcm_decrypt_dev", "uaes_gcm_partial_dev",
 ]
 COMPAT_EXPORTS = [
-    "AES_ECB_encrypt", "AES_ECB_decrypt", "AES_CTR_encrypt", "AES_CTR_decrypt",
+    "AES_ECB_encrypt", "AES_ECB_encrypt_pkcs7", "AES_ECB_encrypt_iso7816", "AES_ECB_decrypt",
+    "AES_CTR_encrypt", "AES_CTR_decrypt", "uaes_compat_set_failure_handler",
     "AES_XTS_encrypt", "AES_XTS_decrypt", "AES_GCM_encrypt", "AES_GCM_decrypt",
     "AES_CCM_encrypt", "AES_CCM_decrypt", "AES_CMAC", "GCM_SIV_encrypt", "GCM_SIV_decrypt",
     "AES_OCB_encrypt", "AES_OCB_decrypt",
@@ -96,6 +98,8 @@ def engine():
     L.uaes_version.restype = C.c_char_p
     for n in ("uaes_ecb_encrypt", "uaes_ecb_decrypt"):
         getattr(L, n).argtypes = [i, vp, vp, sz, vp]
+    L.uaes_stream_release.argtypes = [vp]
+    L.uaes_ecb_encrypt_padded.argtypes = [i, vp, i, vp, sz, vp]
     L.uaes_ctr_xcrypt.argtypes = [i, vp, vp, vp, sz, vp]
     L.uaes_ctr_xcrypt_at.argtypes = [i, vp, vp, u64, vp, sz, vp]
     for n in ("uaes_xts_encrypt", "uaes_xts_decrypt"):
@@ -143,6 +147,14 @@ def _in(b):
     return (C.c_uint8 * max(len(b), 1)).from_buffer_copy(b if b else b"\0")
 
 
+def _fixed(b, n, what):
+    """a fixed-size argument (iv, nonce, tweak, counter block): the C side copies exactly n bytes"""
+    b = bytes(b)
+    if len(b) != n:
+        raise ValueError("%s must be exactly %d bytes (got %d)" % (what, n, len(b)))
+    return (C.c_uint8 * n).from_buffer_copy(b)
+
+
 def _out(n, fill=0):
     buf = (C.c_uint8 * max(n, 1))()
     if fill:
@@ -160,11 +172,15 @@ def _bits(key, mult=1):
 # ---------------------------------------------------------------------------
 # host-buffer API: same names and argument meaning as the reference
 # ---------------------------------------------------------------------------
-def AES_ECB_encrypt(key, pntxt):
-    """micro_aes.c:636.  Returns ceil(len/16)*16 bytes (zero padded tail)."""
-    n = (len(pntxt) + 15) // 16 * 16
+def AES_ECB_encrypt(key, pntxt, padding=0):
+    """micro_aes.c:636.  padding = the reference's AES_PADDING (micro_aes.h:79): 0 returns
+    ceil(len/16)*16 bytes (zero padded tail), 1 (PKCS#7) / 2 (ISO 7816-4) always add a block."""
+    if padding not in (0, 1, 2):
+        raise ValueError("padding must be 0, 1 or 2")
+    n = (len(pntxt) // 16 + 1) * 16 if padding else (len(pntxt) + 15) // 16 * 16
     o = _out(n)
-    _check(engine().uaes_ecb_encrypt(_bits(key), _in(key), _in(pntxt), len(pntxt), o), "AES_ECB_encrypt")
+    _check(engine().uaes_ecb_encrypt_padded(_bits(key), _in(key), padding, _in(pntxt), len(pntxt), o),
+           "AES_ECB_encrypt")
     return bytes(o)[:n]
 
 
@@ -178,7 +194,7 @@ def AES_ECB_decrypt(key, crtxt):
 def AES_CTR_encrypt(key, iv, pntxt):
     """micro_aes.c:962.  iv: 12 bytes; counter block = iv || 00000001."""
     o = _out(len(pntxt))
-    _check(engine().uaes_ctr_xcrypt(_bits(key), _in(key), _in(iv), _in(pntxt), len(pntxt), o), "AES_CTR_encrypt")
+    _check(engine().uaes_ctr_xcrypt(_bits(key), _in(key), _fixed(iv, 12, "iv"), _in(pntxt), len(pntxt), o), "AES_CTR_encrypt")
     return bytes(o)[: len(pntxt)]
 
 
@@ -188,14 +204,14 @@ AES_CTR_decrypt = AES_CTR_encrypt            # micro_aes.c:986-990
 def ctr_xcrypt_at(key, ctr0, block_offset, data):
     """Sharding extension: explicit 16-byte counter block + 56-bit block offset."""
     o = _out(len(data))
-    _check(engine().uaes_ctr_xcrypt_at(_bits(key), _in(key), _in(ctr0), block_offset, _in(data), len(data), o),
+    _check(engine().uaes_ctr_xcrypt_at(_bits(key), _in(key), _fixed(ctr0, 16, "ctr0"), block_offset, _in(data), len(data), o),
            "uaes_ctr_xcrypt_at")
     return bytes(o)[: len(data)]
 
 
 def _xts(fn, name, keys, tweak, data, prefill):
     o = _out(len(data), prefill)
-    rc = _check(fn(_bits(keys, 2), _in(keys), None if tweak is None else _in(tweak), _in(data), len(data), o), name)
+    rc = _check(fn(_bits(keys, 2), _in(keys), None if tweak is None else _fixed(tweak, 16, "tweak"), _in(data), len(data), o), name)
     return rc, bytes(o)[: len(data)]
 
 
@@ -222,7 +238,7 @@ def xts_sectors(keys, first_sector, sector_bytes, data, encrypt=True):
 def AES_GCM_encrypt(key, nonce, aData, pntxt):
     """micro_aes.c:1164.  Returns ciphertext || 16-byte tag."""
     o = _out(len(pntxt) + 16)
-    _check(engine().uaes_gcm_encrypt(_bits(key), _in(key), _in(nonce), _in(aData), len(aData),
+    _check(engine().uaes_gcm_encrypt(_bits(key), _in(key), _fixed(nonce, 12, "nonce"), _in(aData), len(aData),
                                      _in(pntxt), len(pntxt), o), "AES_GCM_encrypt")
     return bytes(o)[: len(pntxt) + 16]
 
@@ -232,14 +248,14 @@ def AES_GCM_decrypt(key, nonce, aData, crtxt_and_tag, prefill=0):
     (prefilled) buffer when authentication fails."""
     n = len(crtxt_and_tag) - 16
     o = _out(n, prefill)
-    rc = _check(engine().uaes_gcm_decrypt(_bits(key), _in(key), _in(nonce), _in(aData), len(aData),
+    rc = _check(engine().uaes_gcm_decrypt(_bits(key), _in(key), _fixed(nonce, 12, "nonce"), _in(aData), len(aData),
                                           _in(crtxt_and_tag), n, o), "AES_GCM_decrypt")
     return rc, bytes(o)[:n]
 
 
 def _fb(fn, name, key, iVec, data, prefill=0):
     o = _out(len(data), prefill)
-    rc = _check(fn(_bits(key), _in(key), _in(iVec), _in(data), len(data), o), name)
+    rc = _check(fn(_bits(key), _in(key), _fixed(iVec, 16, "iVec"), _in(data), len(data), o), name)
     return rc, bytes(o)[: len(data)]
 
 
@@ -281,7 +297,7 @@ def AES_CMAC(key, data):
 def AES_CCM_encrypt(key, nonce, aData, pntxt):
     """micro_aes.c:1268.  11-byte nonce; returns ciphertext || 16-byte tag."""
     o = _out(len(pntxt) + 16)
-    _check(engine().uaes_ccm_encrypt(_bits(key), _in(key), _in(nonce), _in(aData), len(aData),
+    _check(engine().uaes_ccm_encrypt(_bits(key), _in(key), _fixed(nonce, 11, "CCM nonce"), _in(aData), len(aData),
                                      _in(pntxt), len(pntxt), o), "AES_CCM_encrypt")
     return bytes(o)[: len(pntxt) + 16]
 
@@ -291,7 +307,7 @@ def AES_CCM_decrypt(key, nonce, aData, crtxt_and_tag, prefill=0):
     text is returned even when the code is 0x1A."""
     n = len(crtxt_and_tag) - 16
     o = _out(n, prefill)
-    rc = _check(engine().uaes_ccm_decrypt(_bits(key), _in(key), _in(nonce), _in(aData), len(aData),
+    rc = _check(engine().uaes_ccm_decrypt(_bits(key), _in(key), _fixed(nonce, 11, "CCM nonce"), _in(aData), len(aData),
                                           _in(crtxt_and_tag), n, o), "AES_CCM_decrypt")
     return rc, bytes(o)[:n]
 
@@ -299,7 +315,7 @@ def AES_CCM_decrypt(key, nonce, aData, crtxt_and_tag, prefill=0):
 def GCM_SIV_encrypt(key, nonce, aData, pntxt):
     """micro_aes.c:1473 (RFC 8452).  Returns ciphertext || 16-byte tag."""
     o = _out(len(pntxt) + 16)
-    _check(engine().uaes_gcmsiv_encrypt(_bits(key), _in(key), _in(nonce), _in(aData), len(aData),
+    _check(engine().uaes_gcmsiv_encrypt(_bits(key), _in(key), _fixed(nonce, 12, "nonce"), _in(aData), len(aData),
                                         _in(pntxt), len(pntxt), o), "GCM_SIV_encrypt")
     return bytes(o)[: len(pntxt) + 16]
 
@@ -308,7 +324,7 @@ def GCM_SIV_decrypt(key, nonce, aData, crtxt_and_tag, prefill=0):
     """micro_aes.c:1494.  Returns (code, text)."""
     n = len(crtxt_and_tag) - 16
     o = _out(n, prefill)
-    rc = _check(engine().uaes_gcmsiv_decrypt(_bits(key), _in(key), _in(nonce), _in(aData), len(aData),
+    rc = _check(engine().uaes_gcmsiv_decrypt(_bits(key), _in(key), _fixed(nonce, 12, "nonce"), _in(aData), len(aData),
                                              _in(crtxt_and_tag), n, o), "GCM_SIV_decrypt")
     return rc, bytes(o)[:n]
 
@@ -316,7 +332,7 @@ def GCM_SIV_decrypt(key, nonce, aData, crtxt_and_tag, prefill=0):
 def AES_OCB_encrypt(key, nonce, aData, pntxt):
     """micro_aes.c:1774 (RFC 7253, 12-byte nonce).  Returns ciphertext || 16-byte tag."""
     o = _out(len(pntxt) + 16)
-    _check(engine().uaes_ocb_encrypt(_bits(key), _in(key), _in(nonce), _in(aData), len(aData),
+    _check(engine().uaes_ocb_encrypt(_bits(key), _in(key), _fixed(nonce, 12, "nonce"), _in(aData), len(aData),
                                      _in(pntxt), len(pntxt), o), "AES_OCB_encrypt")
     return bytes(o)[: len(pntxt) + 16]
 
@@ -325,7 +341,7 @@ def AES_OCB_decrypt(key, nonce, aData, crtxt_and_tag, prefill=0):
     """micro_aes.c:1797.  Returns (code, text); the text is written even on 0x1A."""
     n = len(crtxt_and_tag) - 16
     o = _out(n, prefill)
-    rc = _check(engine().uaes_ocb_decrypt(_bits(key), _in(key), _in(nonce), _in(aData), len(aData),
+    rc = _check(engine().uaes_ocb_decrypt(_bits(key), _in(key), _fixed(nonce, 12, "nonce"), _in(aData), len(aData),
                                           _in(crtxt_and_tag), n, o), "AES_OCB_decrypt")
     return rc, bytes(o)[:n]
 
@@ -335,7 +351,7 @@ class GcmStream:
 
     def __init__(self, key, nonce, aData=b"", decrypt=False):
         self._h = C.c_void_p()
-        _check(engine().uaes_gcm_stream_begin(C.byref(self._h), _bits(key), _in(key), _in(nonce), _in(aData),
+        _check(engine().uaes_gcm_stream_begin(C.byref(self._h), _bits(key), _in(key), _fixed(nonce, 12, "nonce"), _in(aData),
                                               len(aData), 1 if decrypt else 0), "uaes_gcm_stream_begin")
         self._decrypt = decrypt
 
@@ -346,7 +362,7 @@ class GcmStream:
 
     def finish(self, tag=None):
         """encrypt: returns the tag; decrypt: returns 0 or M_AUTHENTICATION_ERROR for the given tag."""
-        t = (C.c_uint8 * 16)(*(tag if self._decrypt else bytes(16)))
+        t = _fixed(tag if self._decrypt else bytes(16), 16, "tag")
         h, self._h = self._h, None
         rc = _check(engine().uaes_gcm_stream_finish(h, t), "uaes_gcm_stream_finish")
         return rc if self._decrypt else bytes(t)
@@ -360,7 +376,7 @@ class GcmStream:
 def ghash(H, aData, crtxt):
     """gHash of micro_aes.c:1127 with an explicit subkey (test hook)."""
     o = _out(16)
-    _check(engine().uaes_ghash(_in(H), _in(aData), len(aData), _in(crtxt), len(crtxt), o), "uaes_ghash")
+    _check(engine().uaes_ghash(_fixed(H, 16, "H"), _in(aData), len(aData), _in(crtxt), len(crtxt), o), "uaes_ghash")
     return bytes(o)
 
 
@@ -385,7 +401,7 @@ def _stream(stream):
 def ctr_xcrypt_dev(key, ctr0, block_offset, src, dst, nbytes=None, stream=None):
     """Enqueue CTR over device tensors (uint8, contiguous).  No synchronisation."""
     n = src.numel() * src.element_size() if nbytes is None else nbytes
-    _check(engine().uaes_ctr_xcrypt_at_dev(_bits(key), _in(key), _in(ctr0), block_offset,
+    _check(engine().uaes_ctr_xcrypt_at_dev(_bits(key), _in(key), _fixed(ctr0, 16, "ctr0"), block_offset,
                                            _ptr(src), n, _ptr(dst), _stream(stream)), "uaes_ctr_xcrypt_at_dev")
 
 
@@ -403,21 +419,21 @@ def xts_sectors_dev(keys, first_sector, sector_bytes, nsectors, src, dst, encryp
 
 def gcm_encrypt_dev(key, nonce, aad, src, nbytes, dst, stream=None):
     """dst must hold nbytes + 16 (tag appended)."""
-    _check(engine().uaes_gcm_encrypt_dev(_bits(key), _in(key), _in(nonce), _ptr(aad),
+    _check(engine().uaes_gcm_encrypt_dev(_bits(key), _in(key), _fixed(nonce, 12, "nonce"), _ptr(aad),
                                          0 if aad is None else aad.numel(), _ptr(src), nbytes, _ptr(dst),
                                          _stream(stream)), "uaes_gcm_encrypt_dev")
 
 
 def gcm_decrypt_dev(key, nonce, aad, src, nbytes, dst, status, stream=None):
     """src holds nbytes + 16 (ciphertext || tag); status: int32 device tensor."""
-    _check(engine().uaes_gcm_decrypt_dev(_bits(key), _in(key), _in(nonce), _ptr(aad),
+    _check(engine().uaes_gcm_decrypt_dev(_bits(key), _in(key), _fixed(nonce, 12, "nonce"), _ptr(aad),
                                          0 if aad is None else aad.numel(), _ptr(src), nbytes, _ptr(dst),
                                          _ptr(status), _stream(stream)), "uaes_gcm_decrypt_dev")
 
 
 def ocb_dev(key, nonce, aad, src, nbytes, dst, decrypt=False, status=None, stream=None):
     """encrypt: dst holds nbytes + 16; decrypt: src holds nbytes + 16, status = int32 device tensor."""
-    _check(engine().uaes_ocb_dev(_bits(key), _in(key), _in(nonce), 1 if decrypt else 0, _ptr(aad),
+    _check(engine().uaes_ocb_dev(_bits(key), _in(key), _fixed(nonce, 12, "nonce"), 1 if decrypt else 0, _ptr(aad),
                                  0 if aad is None else aad.numel(), _ptr(src), nbytes, _ptr(dst),
                                  _ptr(status), _stream(stream)), "uaes_ocb_dev")
 
@@ -425,6 +441,6 @@ def ocb_dev(key, nonce, aad, src, nbytes, dst, decrypt=False, status=None, strea
 def gcm_partial_dev(key, nonce, aad, total_aad_len, ct_shard, shard_len, shard_offset, total_len, partial,
                     stream=None):
     """This shard's 16-byte share of the GCM tag (see uaes_gcm_partial_dev)."""
-    _check(engine().uaes_gcm_partial_dev(_bits(key), _in(key), _in(nonce), _ptr(aad), total_aad_len,
+    _check(engine().uaes_gcm_partial_dev(_bits(key), _in(key), _fixed(nonce, 12, "nonce"), _ptr(aad), total_aad_len,
                                          _ptr(ct_shard), shard_len, shard_offset, total_len, _ptr(partial),
                                          _stream(stream)), "uaes_gcm_partial_dev")

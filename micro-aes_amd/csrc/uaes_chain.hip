@@ -153,8 +153,8 @@ enum { CH_CBC_ENC = 0, CH_CFB_ENC = 1, CH_OFB = 2, CH_CBC_DEC_CTS = 3 };
 template <int NR, int OP>
 __global__ __launch_bounds__(UAES_WG) void k_chain_serial(uaesk_rk rk, uaesk_tables tb, uint4 iv4,
                                                           const uint4 *__restrict__ iv_dev,   /* overrides iv4 if set */
-                                                          const unsigned char *__restrict__ in,
-                                                          unsigned char *__restrict__ out, u64 len)
+                                                          const unsigned char *in,
+                                                          unsigned char *out, u64 len)
 {
     if (OP == CH_CBC_DEC_CTS) fill_dec_tables(tb.td0); else fill_enc_tables(tb.te0);
     if (threadIdx.x != 0) return;

@@ -11,13 +11,32 @@
 
 #define KB (AES_KEYLENGTH * 8)
 
-/* void functions cannot report failure: refuse loudly rather than hand back
- * a buffer that was never encrypted                                         */
+/* The reference's `void` functions cannot report failure, and there is no CPU path
+ * to fall back to.  An engine failure (no device, hipMalloc, a launch error) goes to
+ * a process-wide handler; the default prints and abort()s rather than hand back a
+ * buffer that was never encrypted.  A host application can install its own with
+ * uaes_compat_set_failure_handler (longjmp out, raise a language-level exception,
+ * mark a connection dead ...).  If a handler RETURNS, the call returns to its caller
+ * with the output buffer in an unspecified state: the handler has taken
+ * responsibility for not using it.                                               */
+static void default_failure(const char *fn, int rc, const char *msg)
+{
+    fprintf(stderr, "uaes-hip: %s failed (%d): %s\n", fn, rc, msg);
+    abort();
+}
+
+static uaes_failure_handler g_on_failure = default_failure;
+
+uaes_failure_handler uaes_compat_set_failure_handler(uaes_failure_handler h)
+{
+    uaes_failure_handler old = __atomic_exchange_n(&g_on_failure, h ? h : default_failure, __ATOMIC_ACQ_REL);
+    return old == default_failure ? NULL : old;
+}
+
 static void must(const char *fn, int rc)
 {
     if (rc == 0) return;
-    fprintf(stderr, "uaes-hip: %s failed (%d): %s\n", fn, rc, uaes_last_error());
-    abort();
+    __atomic_load_n(&g_on_failure, __ATOMIC_ACQUIRE)(fn, rc, uaes_last_error());
 }
 
 static char soft(const char *fn, int rc, char engine_code)
@@ -27,9 +46,23 @@ static char soft(const char *fn, int rc, char engine_code)
     return engine_code;
 }
 
+/* AES_PADDING (micro_aes.h:79, padBlock micro_aes.c:610-621) is a compile-time choice of the
+ * CALLER's build in the reference; here every library carries all three and
+ * include/micro_aes.h maps AES_ECB_encrypt onto the one the caller's AES_PADDING names. */
+#undef AES_ECB_encrypt
 void AES_ECB_encrypt(const uint8_t *key, const void *pntxt, const size_t ptextLen, void *crtxt)
 {
-    must("AES_ECB_encrypt", uaes_ecb_encrypt(KB, key, pntxt, ptextLen, crtxt));
+    must("AES_ECB_encrypt", uaes_ecb_encrypt_padded(KB, key, 0, pntxt, ptextLen, crtxt));
+}
+
+void AES_ECB_encrypt_pkcs7(const uint8_t *key, const void *pntxt, const size_t ptextLen, void *crtxt)
+{
+    must("AES_ECB_encrypt", uaes_ecb_encrypt_padded(KB, key, 1, pntxt, ptextLen, crtxt));
+}
+
+void AES_ECB_encrypt_iso7816(const uint8_t *key, const void *pntxt, const size_t ptextLen, void *crtxt)
+{
+    must("AES_ECB_encrypt", uaes_ecb_encrypt_padded(KB, key, 2, pntxt, ptextLen, crtxt));
 }
 
 char AES_ECB_decrypt(const uint8_t *key, const void *crtxt, const size_t crtxtLen, void *pntxt)

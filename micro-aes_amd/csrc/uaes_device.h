@@ -41,10 +41,12 @@ typedef struct {
 
 int uaesk_device_info(int *cu_count, int *lds_bytes);
 
-/* ECB: nfull whole blocks, plus (enc only) one zero-padded tail block built
- * from the `rem` trailing bytes (reference N1, micro_aes.c:648-651).       */
+/* ECB: nfull whole blocks, plus (enc only) one padded tail block built from the
+ * `rem` trailing bytes (reference N1, micro_aes.c:648-651).  padding = the
+ * reference's AES_PADDING (padBlock, micro_aes.c:610-621): 0 zeros and only when
+ * rem != 0, 1 PKCS#7, 2 ISO/IEC 7816-4 -- the latter two always add a block.  */
 int uaesk_ecb(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *keys,
-              int decrypt, const void *in, void *out, size_t nfull, unsigned rem);
+              int decrypt, const void *in, void *out, size_t nfull, unsigned rem, unsigned padding);
 
 /* CTR keystream xor over len bytes (whole blocks + byte-granular tail).
  * If gate != NULL the kernel does nothing unless *gate == 0 (used by GCM

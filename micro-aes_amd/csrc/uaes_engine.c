@@ -56,6 +56,33 @@ const char *uaes_last_error(void) { return tls_err; }
 const char *uaes_version(void) { return UAES_VERSION; }
 
 /* ------------------------------------------------------------------------ */
+/* policy switch: what a failed authentication leaves in the caller's buffer   */
+/* ------------------------------------------------------------------------ */
+/* The reference's default build decrypts CCM / GCM-SIV / OCB BEFORE it authenticates and its
+ * SABOTAGE() is a no-op (micro_aes.c:1306-1312, :1500-1511, :1803-1810), so a forged message
+ * leaves attacker-chosen plaintext in pntxt next to the 0x1A; with INCREASE_SECURITY it wipes
+ * the buffer.  Default here = the reference's default (bit-identical behaviour); switching
+ * this on gives the INCREASE_SECURITY behaviour: on 0x1A the output is all zero bytes.
+ * (GCM never releases unauthenticated text in either build: N7.)                          */
+static int g_wipe_on_auth_failure = 0;
+
+int uaes_set_wipe_on_auth_failure(int on)
+{
+    return __atomic_exchange_n(&g_wipe_on_auth_failure, on != 0, __ATOMIC_ACQ_REL);
+}
+
+static int wipe_on_auth_failure(void) { return __atomic_load_n(&g_wipe_on_auth_failure, __ATOMIC_ACQUIRE); }
+
+/* tag comparison whose run time does not depend on where the tags differ */
+static int tags_differ(const uint8_t *a, const uint8_t *b, size_t n)
+{
+    unsigned acc = 0;
+    size_t i;
+    for (i = 0; i < n; ++i) acc |= (unsigned)(a[i] ^ b[i]);
+    return acc != 0;
+}
+
+/* ------------------------------------------------------------------------ */
 /* S-box and lookup-table generation (FIPS-197 sec. 5.1.1 / 5.3.2).            */
 /* Built once from the field arithmetic with log/antilog tables over the      */
 /* generator 0x03, then uploaded to every device context.                     */
@@ -192,10 +219,13 @@ typedef struct {
     struct {
         void  *stream;              /* hipStream_t the slot belongs to (NULL = default stream) */
         int    used;
+        int    pins;                /* callers between "got this buffer" and "launch issued"   */
+        unsigned long tick;         /* last use, for LRU recycling                             */
         void  *buf;
         size_t cap;
     } slot[SCRATCH_SLOTS];
-    int             next_victim;
+    unsigned long   tick;
+    pthread_cond_t  cv;             /* signalled when a pin is dropped                         */
     void           *aad_stage;
     size_t          aad_cap;
     void           *pin[2];         /* pinned bounce buffers for short host texts (in, out) */
@@ -233,6 +263,7 @@ static int get_context(context **out)
             c->tb.td0 = (const uint32_t *)((char *)c->d_tables + 1024);
             c->d_status = (int *)((char *)c->d_tables + 3072);
             pthread_mutex_init(&c->mu, NULL);
+            pthread_cond_init(&c->cv, NULL);
             uaesk_device_info(NULL, NULL);
             c->ready = 1;
         }
@@ -257,24 +288,65 @@ static int grow(void **buf, size_t *cap, size_t need)
     return 0;
 }
 
-/* scratch of at least `need` bytes for work enqueued on `stream`; caller holds c->mu */
+/* Scratch of at least `need` bytes for work about to be enqueued on `stream`; the caller
+ * holds c->mu.  The slot comes back PINNED: until scratch_unpin() it is never recycled for
+ * another stream, regrown or freed, so a *_dev caller may drop c->mu, enqueue its kernels and
+ * unpin afterwards.  Once the launch is issued the buffer is protected by stream order and by
+ * the hipDeviceSynchronize() that precedes every recycling / regrowing.  With all slots taken
+ * the least recently used unpinned one is recycled; uaes_stream_release() gives a slot back. */
+static int scratch_pin(context *c, void *stream, size_t need, void **buf, int *slot_out)
+{
+    for (;;) {
+        int i, k = -1;
+        for (i = 0; i < SCRATCH_SLOTS && k < 0; ++i)
+            if (c->slot[i].used && c->slot[i].stream == stream) k = i;
+        for (i = 0; i < SCRATCH_SLOTS && k < 0; ++i)
+            if (!c->slot[i].used) k = i;
+        if (k < 0) {                              /* all taken: recycle the LRU slot nobody is about to use */
+            for (i = 0; i < SCRATCH_SLOTS; ++i)
+                if (c->slot[i].pins == 0 && (k < 0 || c->slot[i].tick < c->slot[k].tick)) k = i;
+            if (k < 0) { pthread_cond_wait(&c->cv, &c->mu); continue; }
+            HIPCHK(hipDeviceSynchronize());       /* everything already issued on the old stream is done */
+            c->slot[k].stream = stream;
+        }
+        if (need > c->slot[k].cap && c->slot[k].pins > 0) {
+            pthread_cond_wait(&c->cv, &c->mu);    /* another caller of this stream is about to launch on it */
+            continue;
+        }
+        c->slot[k].used = 1;
+        c->slot[k].stream = stream;
+        c->slot[k].tick = ++c->tick;
+        if (grow(&c->slot[k].buf, &c->slot[k].cap, need)) return UAES_E_HIP;
+        c->slot[k].pins++;
+        *buf = c->scratch = c->slot[k].buf;
+        *slot_out = k;
+        return 0;
+    }
+}
+
+static void scratch_unpin_locked(context *c, int k)
+{
+    if (k >= 0 && c->slot[k].pins > 0) {
+        c->slot[k].pins--;
+        pthread_cond_broadcast(&c->cv);
+    }
+}
+
+static void scratch_unpin(context *c, int k)
+{
+    pthread_mutex_lock(&c->mu);
+    scratch_unpin_locked(c, k);
+    pthread_mutex_unlock(&c->mu);
+}
+
+/* synchronous API: the caller keeps c->mu until its work has finished, so nothing can
+ * recycle the slot meanwhile and no pin needs to outlive this call                   */
 static int scratch_for(context *c, void *stream, size_t need)
 {
-    int i, k = -1;
-    for (i = 0; i < SCRATCH_SLOTS && k < 0; ++i)
-        if (c->slot[i].used && c->slot[i].stream == stream) k = i;
-    for (i = 0; i < SCRATCH_SLOTS && k < 0; ++i)
-        if (!c->slot[i].used) k = i;
-    if (k < 0) {                                  /* all taken: drain the device, recycle one */
-        HIPCHK(hipDeviceSynchronize());
-        k = c->next_victim;
-        c->next_victim = (c->next_victim + 1) % SCRATCH_SLOTS;
-    }
-    c->slot[k].used = 1;
-    c->slot[k].stream = stream;
-    if (grow(&c->slot[k].buf, &c->slot[k].cap, need)) return UAES_E_HIP;
-    c->scratch = c->slot[k].buf;
-    return 0;
+    void *buf;
+    int k, rc = scratch_pin(c, stream, need, &buf, &k);
+    if (rc == 0) scratch_unpin_locked(c, k);
+    return rc;
 }
 
 static int is_device_ptr(const void *p)
@@ -369,6 +441,20 @@ static int finish_io(io_plan *io, size_t out_len)
     return 0;
 }
 
+/* a decrypt-then-verify mode found a bad tag: hand the text over as the reference's default
+ * build does, or (uaes_set_wipe_on_auth_failure) hand over zeros instead               */
+static int finish_io_unauthenticated(io_plan *io, size_t out_len)
+{
+    context *c = io->ctx;
+    if (!wipe_on_auth_failure()) return finish_io(io, out_len);
+    HIPCHK(hipStreamSynchronize(NULL));
+    c->pin_busy = 0;
+    if (out_len == 0) return 0;
+    if (io->out_is_host) memset(io->user_out, 0, out_len);
+    else HIPCHK(hipMemset(io->user_out, 0, out_len));
+    return 0;
+}
+
 /* the *_dev entry points hand their pointers straight to the kernels (uint4 accesses) */
 static int dev_ptrs_ok(const void *in, const void *out, size_t len)
 {
@@ -384,6 +470,26 @@ static int dev_ptrs_ok(const void *in, const void *out, size_t len)
 /* ------------------------------------------------------------------------ */
 /* housekeeping API                                                           */
 /* ------------------------------------------------------------------------ */
+int uaes_stream_release(void *stream)
+{
+    context *c;
+    int rc, i;
+    if ((rc = get_context(&c)) != 0) return rc;
+    LOCKED_BEGIN(c);
+    rc = 0;
+    for (i = 0; i < SCRATCH_SLOTS; ++i) {
+        if (!c->slot[i].used || c->slot[i].stream != stream) continue;
+        while (c->slot[i].pins > 0) pthread_cond_wait(&c->cv, &c->mu);
+        if (c->slot[i].buf) {
+            if (hipDeviceSynchronize() != hipSuccess || hipFree(c->slot[i].buf) != hipSuccess)
+                rc = fail(UAES_E_HIP, "uaes_stream_release: freeing the scratch failed");
+        }
+        memset(&c->slot[i], 0, sizeof c->slot[i]);
+        break;
+    }
+    LOCKED_END(c, rc);
+}
+
 int uaes_init(void)
 {
     context *c;
@@ -417,7 +523,7 @@ int uaes_selftest(void)
 /* ------------------------------------------------------------------------ */
 /* ECB                                                                        */
 /* ------------------------------------------------------------------------ */
-static int ecb_common(int keybits, const uint8_t *key, int decrypt,
+static int ecb_common(int keybits, const uint8_t *key, int decrypt, int padding,
                       const void *in, size_t len, void *out)
 {
     context *c;
@@ -425,10 +531,11 @@ static int ecb_common(int keybits, const uint8_t *key, int decrypt,
     io_plan io;
     int rc;
     const size_t rem = len % 16, nfull = len / 16;
-    const size_t out_len = decrypt ? len : (len + 15) / 16 * 16;
+    const size_t out_len = decrypt ? len : (padding ? (len / 16 + 1) * 16 : (len + 15) / 16 * 16);
     if ((rc = expand_key(&ks, key, keybits)) != 0) return rc;
-    if (len == 0) return 0;
-    if (!in || !out) return fail(UAES_E_ARG, "NULL data pointer");
+    if (padding < 0 || padding > 2) return fail(UAES_E_ARG, "padding must be 0 (zeros), 1 (PKCS#7) or 2 (ISO/IEC 7816-4)");
+    if (out_len == 0) return 0;
+    if ((len && !in) || !out) return fail(UAES_E_ARG, "NULL data pointer");
     if ((rc = get_context(&c)) != 0) return rc;
     LOCKED_BEGIN(c);
     do {
@@ -442,7 +549,7 @@ static int ecb_common(int keybits, const uint8_t *key, int decrypt,
             }
         }
         int k = uaesk_ecb(NULL, &c->tb, ks.nr, decrypt ? &ks.dk : &ks.ek, decrypt,
-                          io.din, io.dout, nfull, decrypt ? 0 : (unsigned)rem);
+                          io.din, io.dout, nfull, decrypt ? 0 : (unsigned)rem, decrypt ? 0 : (unsigned)padding);
         if (k) { rc = fail(UAES_E_HIP, "ecb launch: %s", hipGetErrorString((hipError_t)k)); break; }
         if ((rc = finish_io(&io, out_len)) != 0) break;
         rc = (decrypt && rem) ? UAES_E_DECRYPTION : 0;           /* :679 */
@@ -452,12 +559,18 @@ static int ecb_common(int keybits, const uint8_t *key, int decrypt,
 
 int uaes_ecb_encrypt(int keybits, const uint8_t *key, const void *pntxt, size_t ptextLen, void *crtxt)
 {
-    return ecb_common(keybits, key, 0, pntxt, ptextLen, crtxt);
+    return ecb_common(keybits, key, 0, 0, pntxt, ptextLen, crtxt);
+}
+
+int uaes_ecb_encrypt_padded(int keybits, const uint8_t *key, int padding,
+                            const void *pntxt, size_t ptextLen, void *crtxt)
+{
+    return ecb_common(keybits, key, 0, padding, pntxt, ptextLen, crtxt);
 }
 
 int uaes_ecb_decrypt(int keybits, const uint8_t *key, const void *crtxt, size_t crtxtLen, void *pntxt)
 {
-    return ecb_common(keybits, key, 1, crtxt, crtxtLen, pntxt);
+    return ecb_common(keybits, key, 1, 0, crtxt, crtxtLen, pntxt);
 }
 
 int uaes_ecb_dev(int keybits, const uint8_t *key, int decrypt,
@@ -471,7 +584,7 @@ int uaes_ecb_dev(int keybits, const uint8_t *key, int decrypt,
     if ((rc = get_context(&c)) != 0) return rc;
     if (decrypt && len % 16) return fail(UAES_E_ARG, "uaes_ecb_dev: ragged decrypt length");
     KCHK(uaesk_ecb(stream, &c->tb, ks.nr, decrypt ? &ks.dk : &ks.ek, decrypt, d_in, d_out,
-                   len / 16, (unsigned)(len % 16)));
+                   len / 16, (unsigned)(len % 16), 0));
     return 0;
 }
 
@@ -558,14 +671,16 @@ static int xts_run(context *c, void *stream, keysched *k1, keysched *k2, int enc
                    int stream_owned_lock)       /* 1: caller does not hold c->mu (the *_dev path) */
 {
     const size_t need = uaesk_xts_scratch_bytes(sector_bytes, nsectors);
-    void *scr;
+    void *scr = NULL;
+    int slot = -1, k;
     if (stream_owned_lock) pthread_mutex_lock(&c->mu);
-    const int g = scratch_for(c, stream, need);
-    scr = c->scratch;
+    const int g = scratch_pin(c, stream, need, &scr, &slot);
     if (stream_owned_lock) pthread_mutex_unlock(&c->mu);
     if (g) return UAES_E_HIP;
-    KCHK(uaesk_xts(stream, &c->tb, k1->nr, encrypt ? &k1->ek : &k1->dk, &k2->ek, !encrypt,
-                   tweak16, first_sector, sector_bytes, nsectors, din, dout, scr));
+    k = uaesk_xts(stream, &c->tb, k1->nr, encrypt ? &k1->ek : &k1->dk, &k2->ek, !encrypt,
+                  tweak16, first_sector, sector_bytes, nsectors, din, dout, scr);
+    if (stream_owned_lock) scratch_unpin(c, slot); else scratch_unpin_locked(c, slot);
+    if (k) return fail(UAES_E_HIP, "xts launch: %s", hipGetErrorString((hipError_t)k));
     return 0;
 }
 
@@ -637,15 +752,23 @@ static int gcm_scratch(context *c)               /* synchronous API: default str
 
 /* the *_dev entry points do not hold the context lock while the GPU works (they only
  * enqueue), but growing the shared scratch buffer must not race with another thread */
-static int gcm_scratch_locked(context *c, void *stream, void **scr)
+static int gcm_scratch_locked(context *c, void *stream, void **scr, int *slot)
 {
     int rc;
     pthread_mutex_lock(&c->mu);
-    rc = scratch_for(c, stream, uaesk_gcm_scratch_bytes());
-    *scr = c->scratch;
+    rc = scratch_pin(c, stream, uaesk_gcm_scratch_bytes(), scr, slot);
     pthread_mutex_unlock(&c->mu);
     return rc;
 }
+
+/* enqueue with the pinned scratch, then drop the pin */
+#define KCHK_PINNED(c, slot, call)                                                        \
+    do {                                                                                  \
+        int e_ = (call);                                                                  \
+        scratch_unpin((c), (slot));                                                       \
+        if (e_ != 0)                                                                      \
+            return fail(UAES_E_HIP, "%s failed: %s", #call, hipGetErrorString((hipError_t)e_)); \
+    } while (0)
 
 /* AAD may be host memory: stage it (it is read byte-wise, no alignment need) */
 static int stage_aad(context *c, const void *aad, size_t aad_len, const void **d_aad)
@@ -727,14 +850,14 @@ int uaes_gcm_encrypt_dev(int keybits, const uint8_t *key, const uint8_t *nonce,
     context *c;
     keysched ks;
     void *scr;
-    int rc;
+    int rc, slot;
     if ((rc = expand_key(&ks, key, keybits)) != 0) return rc;
     if (!nonce || !d_out) return fail(UAES_E_ARG, "NULL pointer");
     if ((rc = dev_ptrs_ok(d_in, d_out, len)) != 0) return rc;
     if ((rc = get_context(&c)) != 0) return rc;
-    if ((rc = gcm_scratch_locked(c, stream, &scr)) != 0) return rc;
-    KCHK(uaesk_gcm(stream, &c->tb, ks.nr, &ks.ek, 0, nonce, d_aad, aad_len, d_in, len, d_out,
-                   scr, NULL));
+    if ((rc = gcm_scratch_locked(c, stream, &scr, &slot)) != 0) return rc;
+    KCHK_PINNED(c, slot, uaesk_gcm(stream, &c->tb, ks.nr, &ks.ek, 0, nonce, d_aad, aad_len, d_in, len, d_out,
+                                   scr, NULL));
     return 0;
 }
 
@@ -746,15 +869,15 @@ int uaes_gcm_decrypt_dev(int keybits, const uint8_t *key, const uint8_t *nonce,
     context *c;
     keysched ks;
     void *scr;
-    int rc;
+    int rc, slot;
     if ((rc = expand_key(&ks, key, keybits)) != 0) return rc;
     if (!nonce || !d_in) return fail(UAES_E_ARG, "NULL pointer");
     if ((rc = dev_ptrs_ok(d_in, d_out, len)) != 0) return rc;
     if (!d_status) return fail(UAES_E_ARG, "NULL d_status");
     if ((rc = get_context(&c)) != 0) return rc;
-    if ((rc = gcm_scratch_locked(c, stream, &scr)) != 0) return rc;
-    KCHK(uaesk_gcm(stream, &c->tb, ks.nr, &ks.ek, 1, nonce, d_aad, aad_len, d_in, len, d_out,
-                   scr, d_status));
+    if ((rc = gcm_scratch_locked(c, stream, &scr, &slot)) != 0) return rc;
+    KCHK_PINNED(c, slot, uaesk_gcm(stream, &c->tb, ks.nr, &ks.ek, 1, nonce, d_aad, aad_len, d_in, len, d_out,
+                                   scr, d_status));
     return 0;
 }
 
@@ -766,7 +889,7 @@ int uaes_gcm_partial_dev(int keybits, const uint8_t *key, const uint8_t *nonce,
     context *c;
     keysched ks;
     void *scr;
-    int rc;
+    int rc, slot;
     if ((rc = expand_key(&ks, key, keybits)) != 0) return rc;
     if (!nonce || !d_partial16) return fail(UAES_E_ARG, "NULL pointer");
     if (((uintptr_t)d_ct_shard) & 15u) return fail(UAES_E_ARG, "the ciphertext shard must be 16-byte aligned");
@@ -774,9 +897,9 @@ int uaes_gcm_partial_dev(int keybits, const uint8_t *key, const uint8_t *nonce,
         return fail(UAES_E_ARG, "shard [%llu, +%zu) is not a 16-byte aligned slice of %llu bytes",
                     (unsigned long long)shard_offset, shard_len, (unsigned long long)total_len);
     if ((rc = get_context(&c)) != 0) return rc;
-    if ((rc = gcm_scratch_locked(c, stream, &scr)) != 0) return rc;
-    KCHK(uaesk_gcm_partial(stream, &c->tb, ks.nr, &ks.ek, nonce, d_aad, total_aad_len,
-                           d_ct_shard, shard_len, shard_offset, total_len, scr, d_partial16));
+    if ((rc = gcm_scratch_locked(c, stream, &scr, &slot)) != 0) return rc;
+    KCHK_PINNED(c, slot, uaesk_gcm_partial(stream, &c->tb, ks.nr, &ks.ek, nonce, d_aad, total_aad_len,
+                                           d_ct_shard, shard_len, shard_offset, total_len, scr, d_partial16));
     return 0;
 }
 
@@ -872,7 +995,7 @@ int uaes_ccm_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
         if (e != hipSuccess) { rc = fail(UAES_E_HIP, "ccm run: %s", hipGetErrorString(e)); break; }
         /* the reference decrypts before it authenticates and (SABOTAGE being a
          * no-op in its default build) leaves the text in place on a mismatch   */
-        if ((rc = finish_io(&io, crtxtLen)) != 0) break;
+        if ((rc = status ? finish_io_unauthenticated(&io, crtxtLen) : finish_io(&io, crtxtLen)) != 0) break;
         rc = status ? UAES_E_AUTHENTICATION : 0;
     } while (0);
     LOCKED_END(c, rc);
@@ -988,7 +1111,7 @@ static int gcmsiv_derive(context *c, int keybits, const uint8_t *key, const uint
     }
     if (grow(&c->aad_stage, &c->aad_cap, 256)) return UAES_E_HIP;
     HIPCHK(hipMemcpy(c->aad_stage, blocks, (size_t)(16 * n), hipMemcpyHostToDevice));
-    KCHK(uaesk_ecb(NULL, &c->tb, master.nr, &master.ek, 0, c->aad_stage, c->aad_stage, (size_t)n, 0));
+    KCHK(uaesk_ecb(NULL, &c->tb, master.nr, &master.ek, 0, c->aad_stage, c->aad_stage, (size_t)n, 0, 0));
     HIPCHK(hipMemcpy(blocks, c->aad_stage, (size_t)(16 * n), hipMemcpyDeviceToHost));
     for (i = 0; i < n; ++i) memcpy(derived + 8 * i, blocks + 16 * i, 8);
     memcpy(out->hg, derived, 16);
@@ -1011,7 +1134,7 @@ static int gcmsiv_tag(context *c, const sivkeys *k, const uint8_t *nonce,
     for (i = 0; i < 12; ++i) s[i] ^= nonce[i];
     s[15] &= 0x7F;
     HIPCHK(hipMemcpy(slot, s, 16, hipMemcpyHostToDevice));
-    KCHK(uaesk_ecb(NULL, &c->tb, k->enc.nr, &k->enc.ek, 0, slot, slot, 1, 0));
+    KCHK(uaesk_ecb(NULL, &c->tb, k->enc.nr, &k->enc.ek, 0, slot, slot, 1, 0, 0));
     HIPCHK(hipMemcpy(tag, slot, 16, hipMemcpyDeviceToHost));
     return 0;
 }
@@ -1092,8 +1215,11 @@ int uaes_gcmsiv_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
         int kk = uaesk_ctr_xcrypt(NULL, &c->tb, k.enc.nr, &k.enc.ek, &ctr, io.din, io.dout, crtxtLen, NULL);
         if (kk) { rc = fail(UAES_E_HIP, "gcm-siv ctr launch: %s", hipGetErrorString((hipError_t)kk)); break; }
         if ((rc = gcmsiv_tag(c, &k, nonce, d_aad, aDataLen, io.dout, crtxtLen, tag)) != 0) break;
-        if ((rc = finish_io(&io, crtxtLen)) != 0) break;          /* text stays (SABOTAGE is a no-op) */
-        rc = memcmp(tag, tag_in, 16) ? UAES_E_AUTHENTICATION : 0;
+        {   /* text stays (SABOTAGE is a no-op) unless uaes_set_wipe_on_auth_failure(1) */
+            const int bad = tags_differ(tag, tag_in, 16);
+            if ((rc = bad ? finish_io_unauthenticated(&io, crtxtLen) : finish_io(&io, crtxtLen)) != 0) break;
+            rc = bad ? UAES_E_AUTHENTICATION : 0;
+        }
     } while (0);
     LOCKED_END(c, rc);
 }
@@ -1125,7 +1251,9 @@ static int ocb_common(int keybits, const uint8_t *key, const uint8_t *nonce, int
             hipError_t e = hipMemcpy(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost);
             if (e != hipSuccess) { rc = fail(UAES_E_HIP, "ocb run: %s", hipGetErrorString(e)); break; }
         }
-        if ((rc = finish_io(&io, len + (decrypt ? 0 : 16))) != 0) break;   /* text stays on a bad tag */
+        /* decrypt: the text stays on a bad tag, as in the reference, unless wiping is switched on */
+        if ((rc = (decrypt && status != 0) ? finish_io_unauthenticated(&io, len)
+                                           : finish_io(&io, len + (decrypt ? 0 : 16))) != 0) break;
         if (decrypt && status != 0) rc = UAES_E_AUTHENTICATION;
     } while (0);
     LOCKED_END(c, rc);
@@ -1152,15 +1280,15 @@ int uaes_ocb_dev(int keybits, const uint8_t *key, const uint8_t *nonce, int decr
     context *c;
     keysched ks;
     void *scr;
-    int rc;
+    int rc, slot;
     if ((rc = expand_key(&ks, key, keybits)) != 0) return rc;
     if (!nonce || (decrypt ? !d_in : !d_out)) return fail(UAES_E_ARG, "NULL pointer");
     if ((rc = dev_ptrs_ok(d_in, d_out, len)) != 0) return rc;
     if (decrypt && !d_status) return fail(UAES_E_ARG, "NULL d_status");
     if ((rc = get_context(&c)) != 0) return rc;
-    if ((rc = gcm_scratch_locked(c, stream, &scr)) != 0) return rc;
-    KCHK(uaesk_ocb(stream, &c->tb, ks.nr, &ks.ek, &ks.dk, decrypt, nonce, d_aad, aad_len, d_in, len, d_out,
-                   scr, d_status));
+    if ((rc = gcm_scratch_locked(c, stream, &scr, &slot)) != 0) return rc;
+    KCHK_PINNED(c, slot, uaesk_ocb(stream, &c->tb, ks.nr, &ks.ek, &ks.dk, decrypt, nonce, d_aad, aad_len, d_in, len,
+                                   d_out, scr, d_status));
     return 0;
 }
 
@@ -1212,7 +1340,24 @@ int uaes_gcm_stream_begin(uaes_gcm_stream **out, int keybits, const uint8_t *key
     return 0;
 }
 
-int uaes_gcm_stream_update(uaes_gcm_stream *s, const void *in, size_t len, void *outp)
+/* A stream's scratch lives on the device it was begun on; update / finish may be called
+ * from a thread that is bound to another device (a multi-GPU worker): bind the stream's
+ * device for the duration of the call and restore the caller's afterwards.            */
+static int stream_enter(const uaes_gcm_stream *s, int *prev)
+{
+    HIPCHK(hipGetDevice(prev));
+    if (*prev != s->device) HIPCHK(hipSetDevice(s->device));
+    return 0;
+}
+
+static int stream_leave(const uaes_gcm_stream *s, int prev, int rc)
+{
+    if (prev != s->device && hipSetDevice(prev) != hipSuccess && rc == 0)
+        rc = fail(UAES_E_HIP, "could not restore the caller's HIP device %d", prev);
+    return rc;
+}
+
+static int gcm_stream_update_on_device(uaes_gcm_stream *s, const void *in, size_t len, void *outp)
 {
     context *c;
     io_plan io;
@@ -1248,12 +1393,22 @@ int uaes_gcm_stream_update(uaes_gcm_stream *s, const void *in, size_t len, void 
     return rc;
 }
 
+int uaes_gcm_stream_update(uaes_gcm_stream *s, const void *in, size_t len, void *outp)
+{
+    int prev, rc;
+    if (!s) return fail(UAES_E_ARG, "NULL pointer");
+    if ((rc = stream_enter(s, &prev)) != 0) return rc;
+    return stream_leave(s, prev, gcm_stream_update_on_device(s, in, len, outp));
+}
+
 int uaes_gcm_stream_finish(uaes_gcm_stream *s, uint8_t tag[16])
 {
     context *c;
-    int rc, status = -1;
+    int rc, status = -1, prev, device;
     if (!s || !tag) return fail(UAES_E_ARG, "NULL pointer");
-    if ((rc = get_context(&c)) != 0) return rc;
+    if ((rc = stream_enter(s, &prev)) != 0) return rc;
+    device = s->device;
+    if ((rc = get_context(&c)) != 0) { uaes_gcm_stream_abort(s); goto restore; }
     LOCKED_BEGIN(c);
     do {
         hipError_t e = hipSuccess;
@@ -1270,13 +1425,25 @@ int uaes_gcm_stream_finish(uaes_gcm_stream *s, uint8_t tag[16])
     } while (0);
     pthread_mutex_unlock(&c->mu);
     uaes_gcm_stream_abort(s);
+restore:
+    if (prev != device && hipSetDevice(prev) != hipSuccess && rc == 0)
+        rc = fail(UAES_E_HIP, "could not restore the caller's HIP device %d", prev);
     return rc;
 }
 
 void uaes_gcm_stream_abort(uaes_gcm_stream *s)
 {
+    int prev = -1;
     if (!s) return;
-    if (s->scratch) (void)hipFree(s->scratch);
+    if (s->scratch) {
+        /* hipFree works from any current device, but must not run while kernels that use the
+         * buffer are in flight: the stream's work is on the default stream of ITS device      */
+        if (hipGetDevice(&prev) == hipSuccess && prev != s->device && hipSetDevice(s->device) != hipSuccess) prev = -1;
+        (void)hipStreamSynchronize(NULL);
+        if (hipFree(s->scratch) != hipSuccess)
+            (void)fail(UAES_E_HIP, "uaes_gcm_stream_abort: hipFree of the stream scratch failed");
+        if (prev >= 0 && prev != s->device) (void)hipSetDevice(prev);
+    }
     memset(s, 0, sizeof *s);                          /* key schedule */
     free(s);
 }

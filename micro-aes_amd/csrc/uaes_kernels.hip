@@ -33,8 +33,8 @@ static inline hipStream_t S(void *s) { return (hipStream_t)s; }
  * spreading the blocks over four times as many CUs beats instruction-level parallelism          */
 template <int NR, bool DEC, int U>
 __global__ __launch_bounds__(UAES_WG) void k_ecb(uaesk_rk rk, uaesk_tables tb,
-                                                 const uint4 *__restrict__ in, uint4 *__restrict__ out,
-                                                 u64 nfull, u32 rem)
+                                                 const uint4 *in, uint4 *out,
+                                                 u64 nfull, u32 rem, u32 padding)
 {
     if (DEC) fill_dec_tables(tb.td0); else fill_enc_tables(tb.te0);
     const LaneConst lc = make_lane_const();
@@ -65,12 +65,17 @@ __global__ __launch_bounds__(UAES_WG) void k_ecb(uaesk_rk rk, uaesk_tables tb,
 
     /* reference N1: a trailing partial block is zero padded and ENCRYPTED into
      * a full output block (micro_aes.c:648-651); decrypt never gets here with
-     * rem != 0 (host copies the ragged tail through and reports 0x1D).       */
-    if (!DEC && rem && blockIdx.x == 0 && threadIdx.x == 0) {
+     * rem != 0 (host copies the ragged tail through and reports 0x1D).
+     * padBlock (micro_aes.c:610-621): AES_PADDING 1 = PKCS#7 (n bytes of value n,
+     * a whole block of 0x10 when rem == 0), 2 = ISO/IEC 7816-4 (0x80 then zeros);
+     * both ALWAYS add a block.                                                 */
+    if (!DEC && (rem || padding) && blockIdx.x == 0 && threadIdx.x == 0) {
         const unsigned char *src = (const unsigned char *)(in + nfull);
         unsigned char pad[16];
+        const unsigned char fillv = padding == 1 ? (unsigned char)(16u - rem) : 0;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) pad[i] = (u32)i < rem ? src[i] : 0;
+        for (int i = 0; i < 16; ++i) pad[i] = (u32)i < rem ? src[i] : fillv;
+        if (padding == 2) pad[rem] = 0x80;
         u32 s1[1][4];
 #pragma unroll
         for (int w = 0; w < 4; ++w)
@@ -102,7 +107,7 @@ __device__ __forceinline__ void ctr_words(const uaesk_ctr &c, u64 i, u32 (&w)[4]
 /* the generic CTR kernel: work items are single blocks, U = 4 per lane per iteration */
 template <int NR, int U>
 __global__ __launch_bounds__(UAES_WG, 4) void k_ctr(uaesk_rk rk, uaesk_tables tb, uaesk_ctr ctr,
-                                                 const uint4 *__restrict__ in, uint4 *__restrict__ out,
+                                                 const uint4 *in, uint4 *out,
                                                  u64 nfull, u32 rem, const int *__restrict__ gate)
 {
     if (gate && *gate != 0) return;            /* GCM decrypt: tag mismatch -> untouched */
@@ -154,7 +159,7 @@ __global__ __launch_bounds__(UAES_WG, 4) void k_ctr(uaesk_rk rk, uaesk_tables tb
  * no separate launch (and no second 128 KiB table fill) is needed.           */
 template <int NR>
 __device__ __forceinline__ void ctr_edges(const uaesk_rk &rk, const uaesk_ctr &ctr,
-                                          const uint4 *__restrict__ in, uint4 *__restrict__ out,
+                                          const uint4 *in, uint4 *out,
                                           u64 chunk_lo, u64 chunk_hi, u64 nfull, u32 rem, const LaneConst &lc)
 {
     const u32 c0 = (u32)ctr.v0 & 0xffu;
@@ -217,7 +222,7 @@ __device__ __forceinline__ void ctr_edges(const uaesk_rk &rk, const uaesk_ctr &c
  * measured 4 % slower (profiles/r01_sweep_ctr_variants.log).                     */
 template <int NR>
 __global__ __launch_bounds__(UAES_WG, 4) void k_ctr_shared2(uaesk_rk rk, uaesk_tables tb, uaesk_ctr ctr,
-                                                           const uint4 *__restrict__ in, uint4 *__restrict__ out,
+                                                           const uint4 *in, uint4 *out,
                                                            u64 chunk_lo, u64 chunk_hi, u64 nfull, u32 rem,
                                                            const int *__restrict__ gate)
 {
@@ -412,18 +417,43 @@ __global__ __launch_bounds__(UAES_WG) void k_xts_expand(XtsPow pw, u64 nsectors,
     }
 }
 
+/* 16-byte accesses at addresses that are only known to be byte aligned (data units whose
+ * size is not a multiple of 16 start at odd offsets from the second unit on): a packed
+ * type tells the compiler the truth and it picks what the memory system allows.     */
+struct __attribute__((packed, aligned(1))) Unaligned16 {
+    u32 x, y, z, w;
+};
+
+template <bool ALIGNED>
+__device__ __forceinline__ uint4 load16(const unsigned char *p)
+{
+    if (ALIGNED) return *(const uint4 *)p;
+    const Unaligned16 v = *(const Unaligned16 *)p;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+template <bool ALIGNED>
+__device__ __forceinline__ void store16(unsigned char *p, uint4 v)
+{
+    if (ALIGNED) { *(uint4 *)p = v; return; }
+    Unaligned16 u;
+    u.x = v.x; u.y = v.y; u.z = v.z; u.w = v.w;
+    *(Unaligned16 *)p = u;
+}
+
 /* main pass: one wave per chunk; lane l handles blocks l, l+64, l+128, l+192
  * of the chunk so each wave-level load/store is a contiguous 1 KiB segment.
  * The next chunk's data and tweak are requested before this chunk's rounds;
  * encryption runs the four blocks as two skewed pairs (enc_blocks_skewed).   */
-template <int NR, bool DEC>
+/* in == out is allowed (every lane reads its blocks before it writes them): no __restrict__ */
+template <int NR, bool DEC, bool ALIGNED>
 __global__ __launch_bounds__(UAES_WG) void k_xts(uaesk_rk k1, uaesk_tables tb,
                                                  const uint4 *__restrict__ chunk_tw,
                                                  u64 nsectors, u64 chunks_per_sector,
                                                  u64 main_blocks,      /* whole blocks handled here, per unit */
                                                  u64 sector_bytes,
-                                                 const unsigned char *__restrict__ in,
-                                                 unsigned char *__restrict__ out)
+                                                 const unsigned char *in,
+                                                 unsigned char *out)
 {
     if (DEC) fill_dec_tables(tb.td0); else fill_enc_tables(tb.te0);
     const LaneConst lc = make_lane_const();
@@ -444,12 +474,12 @@ __global__ __launch_bounds__(UAES_WG) void k_xts(uaesk_rk k1, uaesk_tables tb,
         cntn = left < XTS_CHUNK ? (u32)left : XTS_CHUNK;
         offn = sct * sector_bytes + first * 16;
         tbn = chunk_tw[ch];
-        const uint4 *src = (const uint4 *)(in + offn);
+        const unsigned char *src = in + offn;
 #pragma unroll
         for (int u = 0; u < UAES_U; ++u) {
             const u32 j = lane + 64u * u;
             const u32 jc = j < cntn ? j : (cntn ? cntn - 1 : 0);     /* clamped: no branch before the load */
-            dn[u] = cntn ? src[jc] : make_uint4(0, 0, 0, 0);
+            dn[u] = cntn ? load16<ALIGNED>(src + 16u * jc) : make_uint4(0, 0, 0, 0);
         }
     };
 
@@ -484,12 +514,13 @@ __global__ __launch_bounds__(UAES_WG) void k_xts(uaesk_rk k1, uaesk_tables tb,
             enc_blocks_skewed<NR>(s[0], s[1], k1, lc);
             enc_blocks_skewed<NR>(s[2], s[3], k1, lc);
         }
-        uint4 *dst = (uint4 *)(out + off);
+        unsigned char *dst = out + off;
 #pragma unroll
         for (int u = 0; u < UAES_U; ++u) {
             const u32 j = lane + 64u * u;
             if (j < cnt)
-                dst[j] = make_uint4(s[u][0] ^ tw[u][0], s[u][1] ^ tw[u][1], s[u][2] ^ tw[u][2], s[u][3] ^ tw[u][3]);
+                store16<ALIGNED>(dst + 16u * j, make_uint4(s[u][0] ^ tw[u][0], s[u][1] ^ tw[u][1],
+                                                           s[u][2] ^ tw[u][2], s[u][3] ^ tw[u][3]));
         }
         ch = nxt;
     }
@@ -503,8 +534,8 @@ __global__ __launch_bounds__(UAES_WG) void k_xts_cts(uaesk_rk k1, uaesk_tables t
                                                      const uint4 *__restrict__ chunk_tw,
                                                      u64 nsectors, u64 chunks_per_sector,
                                                      u64 m, u32 r, u64 sector_bytes,
-                                                     const unsigned char *__restrict__ in,
-                                                     unsigned char *__restrict__ out)
+                                                     const unsigned char *in,
+                                                     unsigned char *out)
 {
     if (DEC) fill_dec_tables(tb.td0); else fill_enc_tables(tb.te0);
     const LaneConst lc = make_lane_const();
@@ -524,7 +555,7 @@ __global__ __launch_bounds__(UAES_WG) void k_xts_cts(uaesk_rk k1, uaesk_tables t
 
         const unsigned char *src = in + sct * sector_bytes + m * 16;
         unsigned char *dst = out + sct * sector_bytes + m * 16;
-        const uint4 d = *(const uint4 *)src;
+        const uint4 d = load16<false>(src);          /* units of ragged size start at odd addresses */
         unsigned char tail[16];
         for (u32 i = 0; i < r; ++i) tail[i] = src[16 + i];
 
@@ -550,8 +581,8 @@ __global__ __launch_bounds__(UAES_WG) void k_xts_cts(uaesk_rk k1, uaesk_tables t
         s[0][0] = p[0] ^ (u32)tbk.lo; s[0][1] = p[1] ^ (u32)(tbk.lo >> 32);
         s[0][2] = p[2] ^ (u32)tbk.hi; s[0][3] = p[3] ^ (u32)(tbk.hi >> 32);
         if (DEC) dec_blocks<NR, 1>(s, k1, lc); else enc_blocks<NR, 1>(s, k1, lc);
-        *(uint4 *)dst = make_uint4(s[0][0] ^ (u32)tbk.lo, s[0][1] ^ (u32)(tbk.lo >> 32),
-                                   s[0][2] ^ (u32)tbk.hi, s[0][3] ^ (u32)(tbk.hi >> 32));
+        store16<false>(dst, make_uint4(s[0][0] ^ (u32)tbk.lo, s[0][1] ^ (u32)(tbk.lo >> 32),
+                                       s[0][2] ^ (u32)tbk.hi, s[0][3] ^ (u32)(tbk.hi >> 32)));
         for (u32 i = 0; i < r; ++i) dst[16 + i] = (unsigned char)(cc[i >> 2] >> (8 * (i & 3)));
     }
 }
@@ -665,28 +696,30 @@ static bool short_text(u64 nblocks)
 
 template <int NR, bool DEC>
 static int launch_ecb(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *keys,
-                      const void *in, void *out, size_t nfull, unsigned rem)
+                      const void *in, void *out, size_t nfull, unsigned rem, unsigned padding)
 {
     const unsigned lds = DEC ? UAES_LDS_DEC : UAES_LDS_ENC;
     hipError_t e = set_lds(k_ecb<NR, DEC, UAES_U>, lds);
     if (e == hipSuccess) e = set_lds(k_ecb<NR, DEC, 1>, lds);
     if (e != hipSuccess) return (int)e;
-    const u64 items = nfull + (rem ? 1 : 0);
+    const u64 items = nfull + ((rem || padding) ? 1 : 0);
     if (short_text(items))
         hipLaunchKernelGGL((k_ecb<NR, DEC, 1>), dim3(grid_for(items, UAES_WG)), dim3(UAES_WG), lds, st, *keys, *tb,
-                           (const uint4 *)in, (uint4 *)out, (u64)nfull, (u32)rem);
+                           (const uint4 *)in, (uint4 *)out, (u64)nfull, (u32)rem, (u32)padding);
     else
         hipLaunchKernelGGL((k_ecb<NR, DEC, UAES_U>), dim3(grid_for(items, (u64)UAES_WG * UAES_U)), dim3(UAES_WG), lds, st,
-                           *keys, *tb, (const uint4 *)in, (uint4 *)out, (u64)nfull, (u32)rem);
+                           *keys, *tb, (const uint4 *)in, (uint4 *)out, (u64)nfull, (u32)rem, (u32)padding);
     return (int)hipGetLastError();
 }
 
 extern "C" int uaesk_ecb(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *keys,
-                         int decrypt, const void *in, void *out, size_t nfull, unsigned rem)
+                         int decrypt, const void *in, void *out, size_t nfull, unsigned rem, unsigned padding)
 {
-    if (nfull == 0 && rem == 0) return 0;
-    if (decrypt) { DISPATCH_NR(nr, return (launch_ecb<NR, true>(S(stream), tb, keys, in, out, nfull, 0))); }
-    else         { DISPATCH_NR(nr, return (launch_ecb<NR, false>(S(stream), tb, keys, in, out, nfull, rem))); }
+    if (decrypt) padding = 0;
+    if (nfull == 0 && rem == 0 && padding == 0) return 0;
+    if (padding > 2) return (int)hipErrorInvalidValue;
+    if (decrypt) { DISPATCH_NR(nr, return (launch_ecb<NR, true>(S(stream), tb, keys, in, out, nfull, 0, 0))); }
+    else         { DISPATCH_NR(nr, return (launch_ecb<NR, false>(S(stream), tb, keys, in, out, nfull, rem, padding))); }
     return 0;
 }
 
@@ -821,7 +854,8 @@ static int launch_xts(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *k1
     xts_geometry(sector_bytes, &mb, &r, &cps);
     const unsigned lds = DEC ? UAES_LDS_DEC : UAES_LDS_ENC;
     hipError_t e = set_lds(k_xts_tweaks<NR>, UAES_LDS_ENC);
-    if (e == hipSuccess) e = set_lds(k_xts<NR, DEC>, lds);
+    if (e == hipSuccess) e = set_lds(k_xts<NR, DEC, true>, lds);
+    if (e == hipSuccess) e = set_lds(k_xts<NR, DEC, false>, lds);
     if (e == hipSuccess) e = set_lds(k_xts_cts<NR, DEC>, lds);
     if (e != hipSuccess) return (int)e;
 
@@ -840,9 +874,15 @@ static int launch_xts(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *k1
         /* one wave per 256-block chunk: a short text on 16-wave workgroups would sit on a few CUs,
          * so below half a GPU's worth of chunks the workgroups shrink to 4 waves              */
         const unsigned wg = grid_for(nchunks, UAES_WG / 64) * 2 <= grid_for(~0ull, 1) ? 256u : UAES_WG;
-        hipLaunchKernelGGL((k_xts<NR, DEC>), dim3(grid_for(nchunks, wg / 64)), dim3(wg), lds, st,
-                           *k1, *tb, (const uint4 *)scratch, (u64)nsectors, cps, mb, (u64)sector_bytes,
-                           (const unsigned char *)in, (unsigned char *)out);
+        /* every block address is a multiple of 16 unless units of ragged size follow one another */
+        if (sector_bytes % 16 == 0 || nsectors == 1)
+            hipLaunchKernelGGL((k_xts<NR, DEC, true>), dim3(grid_for(nchunks, wg / 64)), dim3(wg), lds, st,
+                               *k1, *tb, (const uint4 *)scratch, (u64)nsectors, cps, mb, (u64)sector_bytes,
+                               (const unsigned char *)in, (unsigned char *)out);
+        else
+            hipLaunchKernelGGL((k_xts<NR, DEC, false>), dim3(grid_for(nchunks, wg / 64)), dim3(wg), lds, st,
+                               *k1, *tb, (const uint4 *)scratch, (u64)nsectors, cps, mb, (u64)sector_bytes,
+                               (const unsigned char *)in, (unsigned char *)out);
     }
     if (r) {
         hipLaunchKernelGGL((k_xts_cts<NR, DEC>), dim3(grid_for(nsectors, UAES_WG)), dim3(UAES_WG), lds, st,

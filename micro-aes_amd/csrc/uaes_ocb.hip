@@ -153,7 +153,7 @@ __global__ __launch_bounds__(UAES_WG) void k_ocb_setup(uaesk_rk ek, uaesk_tables
 template <int NR, bool DEC>
 __global__ __launch_bounds__(UAES_WG) void k_ocb(uaesk_rk rk, uaesk_tables tb,
                                                  uint4 *__restrict__ scr, u64 nblocks, u32 run,
-                                                 const uint4 *__restrict__ in, uint4 *__restrict__ out)
+                                                 const uint4 *in, uint4 *out)
 {
     /* run (a power of two <= OCB_RUN_MAX) = consecutive chunks per wave; short texts use
      * short runs so that every CU gets work                                        */

@@ -45,6 +45,7 @@ class Oracle:
         L = self.L = C.CDLL(path)
         sz, i, vp, u64 = C.c_size_t, C.c_int, C.c_void_p, C.c_uint64
         L.orc_ecb_encrypt.argtypes = [i, vp, vp, sz, vp]; L.orc_ecb_encrypt.restype = None
+        L.orc_ecb_encrypt_padded.argtypes = [i, vp, i, vp, sz, vp]; L.orc_ecb_encrypt_padded.restype = None
         L.orc_ecb_decrypt.argtypes = [i, vp, vp, sz, vp]; L.orc_ecb_decrypt.restype = C.c_char
         L.orc_ctr_encrypt.argtypes = [i, vp, vp, vp, sz, vp]; L.orc_ctr_encrypt.restype = None
         L.orc_ctr_xcrypt_at.argtypes = [i, vp, vp, u64, vp, sz, vp]; L.orc_ctr_xcrypt_at.restype = None
@@ -80,10 +81,11 @@ class Oracle:
         return bytes(o)
 
     # -- modes --------------------------------------------------------------
-    def ecb_encrypt(self, key, pt):
-        o = _out((len(pt) + 15) // 16 * 16)
-        self.L.orc_ecb_encrypt(len(key) * 8, _buf(key), _buf(pt), len(pt), o)
-        return bytes(o)[: (len(pt) + 15) // 16 * 16]
+    def ecb_encrypt(self, key, pt, padding=0):
+        n = (len(pt) // 16 + 1) * 16 if padding else (len(pt) + 15) // 16 * 16
+        o = _out(n)
+        self.L.orc_ecb_encrypt_padded(len(key) * 8, _buf(key), padding, _buf(pt), len(pt), o)
+        return bytes(o)[:n]
 
     def ecb_decrypt(self, key, ct):
         o = _out(len(ct))
@@ -214,17 +216,21 @@ class Oracle:
 class Reference:
     """The compiled reference; one library per key size (micro_aes.h:17)."""
 
-    @staticmethod
-    def path(bits):
-        return os.path.join(HERE, "_ref", "libmicroaes_ref_%d.so" % bits)
+    PAD_SUFFIX = {0: "", 1: "_pkcs7", 2: "_iso7816"}
 
     @classmethod
-    def available(cls, bits=128):
-        return os.path.exists(cls.path(bits))
+    def path(cls, bits, padding=0):
+        return os.path.join(HERE, "_ref", "libmicroaes_ref_%d%s.so" % (bits, cls.PAD_SUFFIX[padding]))
 
-    def __init__(self, bits):
+    @classmethod
+    def available(cls, bits=128, padding=0):
+        return os.path.exists(cls.path(bits, padding))
+
+    def __init__(self, bits, padding=0):
+        """padding: a build with AES_PADDING (micro_aes.h:79) patched to 1 / 2 (oracle/Makefile)"""
         self.bits = bits
-        L = self.L = C.CDLL(self.path(bits))
+        self.padding = padding
+        L = self.L = C.CDLL(self.path(bits, padding))
         sz, vp = C.c_size_t, C.c_void_p
         L.AES_ECB_encrypt.argtypes = [vp, vp, sz, vp]; L.AES_ECB_encrypt.restype = None
         L.AES_ECB_decrypt.argtypes = [vp, vp, sz, vp]; L.AES_ECB_decrypt.restype = C.c_char
@@ -315,7 +321,7 @@ class Reference:
 
     def ecb_encrypt(self, key, pt):
         self._chk(key)
-        n = (len(pt) + 15) // 16 * 16
+        n = (len(pt) // 16 + 1) * 16 if self.padding else (len(pt) + 15) // 16 * 16
         o = _out(n)
         self.L.AES_ECB_encrypt(_buf(key), _buf(pt), len(pt), o)
         return bytes(o)[:n]

@@ -168,8 +168,13 @@ void orc_decrypt_block(const orc_key *ks, const uint8_t in[16], uint8_t out[16])
 /* ------------------------------------------------------------------------ */
 /* ECB -- micro_aes.c:636-680 (N1)                                            */
 /* ------------------------------------------------------------------------ */
-void orc_ecb_encrypt(int keybits, const uint8_t *key,
-                     const void *pt, size_t len, void *ct)
+/* padding = the reference's compile-time AES_PADDING (micro_aes.h:79), padBlock
+ * micro_aes.c:610-621: 0 -> a ragged tail is zero padded, nothing is added to whole
+ * blocks; 1 -> PKCS#7: the 16 - rem missing bytes all hold the value 16 - rem;
+ * 2 -> ISO/IEC 7816-4: one 0x80 byte, then zeros.  With 1 and 2 padBlock returns
+ * true even for rem == 0, so a whole extra block is encrypted (:648-651).         */
+void orc_ecb_encrypt_padded(int keybits, const uint8_t *key, int padding,
+                            const void *pt, size_t len, void *ct)
 {
     orc_key ks;
     const uint8_t *x = (const uint8_t *)pt;
@@ -178,11 +183,19 @@ void orc_ecb_encrypt(int keybits, const uint8_t *key,
     if (orc_setkey(&ks, key, keybits)) return;
     for (i = 0; i < n; ++i)
         orc_encrypt_block(&ks, x + 16 * i, y + 16 * i);
-    if (rem) {                                 /* zero padding, :610-621     */
-        uint8_t last[16] = { 0 };
-        memcpy(last, x + 16 * n, rem);
+    if (rem || padding) {
+        uint8_t last[16];
+        memset(last, padding == 1 ? (int)(16 - rem) : 0, sizeof last);
+        if (rem) memcpy(last, x + 16 * n, rem);
+        if (padding == 2) last[rem] = 0x80;
         orc_encrypt_block(&ks, last, y + 16 * n);
     }
+}
+
+void orc_ecb_encrypt(int keybits, const uint8_t *key,
+                     const void *pt, size_t len, void *ct)
+{
+    orc_ecb_encrypt_padded(keybits, key, 0, pt, len, ct);
 }
 
 char orc_ecb_decrypt(int keybits, const uint8_t *key,

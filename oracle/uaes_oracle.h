@@ -53,6 +53,8 @@ void orc_encrypt_block(const orc_key *ks, const uint8_t in[16], uint8_t out[16])
 void orc_decrypt_block(const orc_key *ks, const uint8_t in[16], uint8_t out[16]);
 
 /* micro_aes.c:636-680.  encrypt writes ceil(len/16)*16 bytes (zero padding, N1) */
+void orc_ecb_encrypt_padded(int keybits, const uint8_t *key, int padding,
+                            const void *pt, size_t len, void *ct);
 void orc_ecb_encrypt(int keybits, const uint8_t *key,
                      const void *pt, size_t len, void *ct);
 char orc_ecb_decrypt(int keybits, const uint8_t *key,

@@ -21,6 +21,8 @@ source text):
 * ``ref_vectors.json`` -- outputs of the COMPILED REFERENCE (oracle/_ref) on
   seeded inputs over the edge-case lengths (0, 1, 15, 16, 17, ... 4097, 65541)
   for ECB/CTR/XTS/GCM at 128/192/256 bits, plus error-path behaviour (N1,N5,N7).
+* ``ecb_padding_vectors.json`` -- AES_ECB_encrypt of reference builds with AES_PADDING 1 / 2
+  (micro_aes.h:79) on seeded inputs, and the main.c AES-192 PKCS#7 known answer (main.c:86,139).
 * ``digests.json`` -- SHA-256 digests of the reference's output on the
   BASELINE.json workloads.  Cheap ones are recomputed
   here; the multi-GiB ones are recomputed only with --big (minutes of CPU).
@@ -327,6 +329,30 @@ def digests(orc, big):
     return d
 
 
+def ecb_padding_vectors(orc):
+    """AES_ECB_encrypt of reference builds with AES_PADDING 1 (PKCS#7, the AES-192 build that
+    main.c:139 tests) and 2 (ISO/IEC 7816-4), padBlock micro_aes.c:610-621, plus the main.c KAT"""
+    rng = random.Random(0x70616421)
+    vecs = []
+    main_c_192 = ("af1893f0fbb09a437f6b0fd4f49778907bb85cccf1e9d2e3ebe5bae935107868"
+                  "c6d72cb2ca375c12ce6b6b1141141fd0d268d14db351d6805aabb99427341da9")
+    key = bytes.fromhex("279fb74a7572135e8f9b8ef6d1eee00369c4e0d86a7b0430d8cdb78070b4c55a")
+    pt = bytes.fromhex("c9f775baafa36c25cd610d3c75a482eadda97ca4864cdfe06eaf70a0ec0d7191"
+                       "d55027cf8f900214e634412583ff0b478EA2B7CA516745BFEA")
+    r = Reference(192, padding=1)
+    assert r.ecb_encrypt(key[:24], pt).hex() == main_c_192           # main.c:86-87,139-141
+    vecs.append(dict(name="main.c:139 ECB AES-192 PKCS#7", keybits=192, padding=1, key=key[:24].hex(),
+                     pt=pt.hex(), out=main_c_192))
+    for bits, padding in ((192, 1), (128, 2)):
+        ref = Reference(bits, padding=padding)
+        for n in [0, 1, 15, 16, 17, 31, 32, 33, 255, 256, 4095, 4096, 4097, 65541]:
+            seed = rng.getrandbits(32)
+            k = rng.randbytes(bits // 8)
+            vecs.append(dict(keybits=bits, padding=padding, len=n, seed=seed, key=k.hex(),
+                             out=enc_out(ref.ecb_encrypt(k, splitmix(orc, seed, n)))))
+    return vecs
+
+
 def main():
     big = "--big" in sys.argv
     build()
@@ -344,6 +370,8 @@ def main():
         json.dump(main_kats(), f, indent=1)
     with open(os.path.join(HERE, "ref_vectors.json"), "w") as f:
         json.dump(ref_vectors(orc), f, indent=0)
+    with open(os.path.join(HERE, "ecb_padding_vectors.json"), "w") as f:
+        json.dump(ecb_padding_vectors(orc), f, indent=0)
     with open(os.path.join(HERE, "digests.json"), "w") as f:
         json.dump(digests(orc, big), f, indent=1)
     print("fixtures written to", HERE)

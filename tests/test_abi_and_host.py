@@ -94,6 +94,51 @@ def test_fails_loudly_without_gpu():
         uaes.selftest()
 
 
+def test_void_functions_report_engine_failures_to_the_installed_handler():
+    """the reference's `void` API cannot return an error; the compat library hands an engine
+    failure to a replaceable handler (default: print + abort).  Without a GPU every call fails,
+    which is exactly the case to observe here."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    L = C.CDLL(uaes.lib_path("libmicro_aes_hip_128.so"))
+    HANDLER = C.CFUNCTYPE(None, C.c_char_p, C.c_int, C.c_char_p)
+    seen = []
+    cb = HANDLER(lambda fn, rc, msg: seen.append((fn.decode(), rc, msg.decode())))
+    L.uaes_compat_set_failure_handler.restype = C.c_void_p
+    L.uaes_compat_set_failure_handler.argtypes = [HANDLER]
+    assert L.uaes_compat_set_failure_handler(cb) is None          # the default was installed
+    out = (C.c_uint8 * 32)()
+    L.AES_CTR_encrypt(bytes(16), bytes(12), b"0123456789abcdef", C.c_size_t(16), out)
+    L.AES_ECB_encrypt_pkcs7(bytes(16), b"0123456789abcdef", C.c_size_t(16), out)
+    assert [s[0] for s in seen] == ["AES_CTR_encrypt", "AES_ECB_encrypt"]
+    assert all(rc == -1 and "no usable HIP device" in msg for _, rc, msg in seen)
+    # char-returning functions keep returning the reference's codes
+    L.AES_XTS_encrypt.restype = C.c_char
+    assert ord(L.AES_XTS_encrypt(bytes(32), bytes(16), b"0123456789abcdef", C.c_size_t(16), out)) == 0x1E
+    # the default handler aborts the process
+    code = ("import ctypes as C; L = C.CDLL(%r); o = (C.c_uint8 * 32)(); "
+            "L.AES_CTR_encrypt(bytes(16), bytes(12), b'0123456789abcdef', C.c_size_t(16), o)"
+            % uaes.lib_path("libmicro_aes_hip_128.so"))
+    r = subprocess.run([os.sys.executable, "-c", code], capture_output=True, text=True)
+    assert r.returncode == -6 and "AES_CTR_encrypt failed" in r.stderr       # SIGABRT
+
+
+def test_python_wrappers_reject_wrong_sized_nonces():
+    """the C side copies a fixed number of bytes: short or long iv / nonce / tweak / counter
+    blocks are refused before any call is made (no GPU needed)"""
+    k = bytes(16)
+    for call in (lambda: uaes.AES_CTR_encrypt(k, bytes(11), b"x"), lambda: uaes.AES_CTR_encrypt(k, bytes(16), b"x"),
+                 lambda: uaes.ctr_xcrypt_at(k, bytes(12), 0, b"x"), lambda: uaes.AES_XTS_encrypt(bytes(32), bytes(8), bytes(16)),
+                 lambda: uaes.AES_GCM_encrypt(k, bytes(16), b"", b"x"), lambda: uaes.AES_GCM_decrypt(k, bytes(8), b"", bytes(17)),
+                 lambda: uaes.AES_CCM_encrypt(k, bytes(12), b"", b"x"), lambda: uaes.AES_OCB_encrypt(k, bytes(15), b"", b"x"),
+                 lambda: uaes.GCM_SIV_encrypt(k, bytes(13), b"", b"x"), lambda: uaes.AES_CBC_encrypt(k, bytes(12), bytes(16)),
+                 lambda: uaes.GcmStream(k, bytes(16)), lambda: uaes.ghash(bytes(15), b"", b"x"),
+                 lambda: uaes.AES_ECB_encrypt(k, b"x", padding=3)):
+        with pytest.raises(ValueError):
+            call()
+
+
 def test_product_does_not_touch_the_oracle():
     """the shipped path must not import, link or open anything under oracle/"""
     pkg = os.path.join(ROOT, "micro-aes_amd")

@@ -1,0 +1,105 @@
+"""BASELINE.json configurations at their FULL sizes under `pytest -m gpu` (one MI355X):
+
+  C3  AES-256-XTS over 2^20 sectors of 4 KiB: SHA-256 of all 4 GiB of ciphertext against the
+      digest the compiled reference produced (tests/golden/digests.json);
+  C5  the 8 GiB AES-128-CTR stream as its eight 1 GiB shards, each with the counter offset
+      g * 2^26 its GPU would use (uaes_ctr_xcrypt_at, incBlock's 56-bit add micro_aes.c:421-427),
+      processed one after another on this GPU: SHA-256 of the concatenation against the
+      reference's digest of the whole stream -- everything C5 needs except eight physical GPUs;
+  and bench.py's N-rank code path, dry-run with two gloo ranks sharing the one GPU.
+
+Inputs are generated on the GPU (bench.splitmix_device, the SURVEY 8d stream)."""
+import hashlib
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+import micro_aes_amd as uaes
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GIB = 1 << 30
+
+
+def _digests(golden_dir):
+    with open(os.path.join(golden_dir, "digests.json")) as f:
+        return json.load(f)
+
+
+def _update(h, t):
+    step = 1 << 28
+    for o in range(0, t.numel(), step):
+        h.update(t[o:o + step].cpu().numpy().tobytes())
+
+
+def test_C3_xts256_all_2p20_sectors(golden_dir):
+    import torch
+    import bench
+    dev = torch.device("cuda", 0)
+    nsec = 1 << 20
+    src = bench.splitmix_device(torch, 3, nsec * 4096, 0, dev)
+    dst = torch.empty_like(src)
+    uaes.xts_sectors_dev(bytes(range(64)), 0, 4096, nsec, src, dst, encrypt=True)
+    torch.cuda.synchronize()
+    h = hashlib.sha256()
+    _update(h, dst)
+    assert h.hexdigest() == _digests(golden_dir)["C3_xts256_2p20_sectors_seed3"]["sha256"]
+    # and back, in place
+    uaes.xts_sectors_dev(bytes(range(64)), 0, 4096, nsec, dst, dst, encrypt=False)
+    torch.cuda.synchronize()
+    assert torch.equal(dst, src)
+
+
+def test_C5_ctr128_8GiB_as_eight_shards(golden_dir):
+    import torch
+    import bench
+    dev = torch.device("cuda", 0)
+    key, ctr0 = bytes(range(16)), bytes(range(0xF0, 0xFC)) + b"\0\0\0\1"
+    h = hashlib.sha256()
+    dst = torch.empty(GIB, dtype=torch.uint8, device=dev)
+    for g in range(8):
+        # GPU g owns bytes [g * 2^30, (g+1) * 2^30) of the stream and counter offset g * 2^26
+        src = bench.splitmix_device(torch, 2, GIB, g * (GIB // 8), dev)
+        uaes.ctr_xcrypt_dev(key, ctr0, g * (GIB // 16), src, dst)
+        torch.cuda.synchronize()
+        if g == 0:
+            assert hashlib.sha256(dst.cpu().numpy().tobytes()).hexdigest() == \
+                _digests(golden_dir)["C2_ctr128_1GiB_seed2"]["sha256"]
+        _update(h, dst)
+        del src
+    assert h.hexdigest() == _digests(golden_dir)["C5_ctr128_8GiB_seed2"]["sha256"]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.parametrize("workload", ["ctr", "xts"])
+def test_bench_two_rank_dry_run(workload):
+    """bench.py --gpus 2 as the driver launches it, but gloo + --single-device so that both
+    ranks share cuda:0: shard offsets, barrier-bracketed timing, MAX over ranks, per-rank
+    verification against the oracle, one JSON line from rank 0."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--backend", "gloo", "--single-device", "--bytes", str(64 << 20), "--settle-ms", "0",
+           "--workload", workload]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak"
+    assert line["verified"] is True
+    assert line["value"] > 0 and line["config"]["parallelism"] == "shard2"
+    assert "cpu_baseline" not in line            # rank 0 at N=1 only

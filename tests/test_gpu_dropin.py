@@ -45,3 +45,15 @@ def test_reference_main_c_runs_on_the_hip_library(bits):
                   "OCB", "OCB", "GCMSIV", "GCMSIV", "GCMSIV", "GCMSIV"],
             192: [], 256: ["XTS", "XTS", "GCM", "GCM"]}[bits]
     assert passed == want, r.stdout
+
+
+def test_reference_main_c_aes192_pkcs7_check_runs_on_the_hip_library():
+    """main.c's only AES-192 check on the hot path (main.c:139) is compiled when AES_PADDING is 1:
+    the same main.c built with -DAES_PADDING=1 against include/micro_aes.h, which then binds
+    AES_ECB_encrypt to the PKCS#7 entry point of libmicro_aes_hip_192.so"""
+    exe = os.path.join(REF, "main_hip_192_pkcs7")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/main_hip_192_pkcs7 was not built")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "FAILED" not in r.stdout, r.stdout + r.stderr
+    assert re.findall(r"AES-192 (\w+) \w+: PASSED!", r.stdout) == ["ECB", "ECB"], r.stdout

@@ -353,6 +353,31 @@ def test_ecb_ctr_vs_oracle(orc, bits):
     assert uaes.ctr_xcrypt_at(key, c1, 0xFFFFFF00, data) == orc.ctr_xcrypt_at(key, c1, 0xFFFFFF00, data)
 
 
+def test_ecb_padding_modes(orc, golden_dir):
+    """AES_PADDING 1 (PKCS#7) and 2 (ISO/IEC 7816-4) of padBlock, micro_aes.c:610-621: the
+    reference-generated vectors (incl. main.c's AES-192 answer), the oracle over edge lengths
+    for every key size, and the compat symbols a caller built with -DAES_PADDING=n binds to."""
+    for v in load(golden_dir, "ecb_padding_vectors.json"):
+        key = bytes.fromhex(v["key"])
+        data = bytes.fromhex(v["pt"]) if "pt" in v else orc.splitmix(v["seed"], (v["len"] + 7) // 8 * 8)[: v["len"]]
+        check_out(uaes.AES_ECB_encrypt(key, data, padding=v["padding"]),
+                  v["out"] if isinstance(v["out"], dict) else {"hex": v["out"]})
+    rnd = random.Random(5150)
+    for bits in (128, 192, 256):
+        lib = C.CDLL(uaes.lib_path("libmicro_aes_hip_%d.so" % bits))
+        for padding, sym in ((1, "AES_ECB_encrypt_pkcs7"), (2, "AES_ECB_encrypt_iso7816")):
+            for n in (0, 1, 15, 16, 17, 4095, 4096, 65537, (4 << 20) + 5, 4 << 20):
+                key, data = rnd.randbytes(bits // 8), rnd.randbytes(n)
+                want = orc.ecb_encrypt(key, data, padding=padding)
+                assert uaes.AES_ECB_encrypt(key, data, padding=padding) == want
+                if n <= 65537:
+                    out = (C.c_uint8 * len(want))()
+                    getattr(lib, sym)(key, data, C.c_size_t(n), out)
+                    assert bytes(out) == want
+                    rc, back = uaes.AES_ECB_decrypt(key, want)
+                    assert rc == 0 and back[:n] == data and len(back) == len(want)
+
+
 @pytest.mark.parametrize("bits", [128, 192, 256])
 def test_xts_vs_oracle(orc, bits):
     rnd = random.Random(bits + 1)

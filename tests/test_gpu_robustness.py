@@ -194,3 +194,104 @@ def test_single_process_multi_gpu_entry_points(orc):
     bad = (C.c_int * 1)(9)
     assert L.uaes_mgpu_ctr_xcrypt_at(1, bad, 128, key, ctr0, 0, b"x" * 16, 16, out) == -2       # UAES_E_ARG
     assert b"not one of" in L.uaes_last_error()
+
+
+def test_more_streams_than_scratch_slots_from_several_threads(orc):
+    """Twelve streams (the engine keeps 8 scratch slots per device) driven by four host threads:
+    a slot handed to a caller stays pinned until its launch is issued, so recycling the least
+    recently used slot can never take a buffer another thread is about to launch on (round-1
+    advisor finding).  Every result must equal the one-at-a-time result; then the slots are
+    given back with uaes_stream_release."""
+    import torch
+    rnd = random.Random(4242)
+    n = 1 << 20
+    streams = [torch.cuda.Stream() for _ in range(12)]
+    jobs = []
+    for i, st in enumerate(streams):
+        key, nonce, keys2 = rnd.randbytes(16), rnd.randbytes(12), rnd.randbytes(64)
+        src = torch.randint(0, 256, (n,), dtype=torch.uint8, device="cuda:0")
+        g, x = torch.empty(n + 16, dtype=torch.uint8, device="cuda:0"), torch.empty(n, dtype=torch.uint8, device="cuda:0")
+        uaes.gcm_encrypt_dev(key, nonce, None, src, n, g)
+        uaes.xts_sectors_dev(keys2, i, 4096, n // 4096, src, x)
+        torch.cuda.synchronize()
+        jobs.append(dict(key=key, nonce=nonce, keys2=keys2, src=src, st=st, first=i, want=(g, x),
+                         gcm=torch.zeros_like(g), xts=torch.zeros_like(x)))
+    errors = []
+
+    def worker(mine):
+        try:
+            for _ in range(25):
+                for j in mine:
+                    uaes.gcm_encrypt_dev(j["key"], j["nonce"], None, j["src"], n, j["gcm"], stream=j["st"])
+                    uaes.xts_sectors_dev(j["keys2"], j["first"], 4096, n // 4096, j["src"], j["xts"], stream=j["st"])
+        except Exception as e:            # noqa: BLE001
+            errors.append(e)
+
+    th = [threading.Thread(target=worker, args=(jobs[k::4],)) for k in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errors, errors
+    for j in jobs:
+        assert torch.equal(j["gcm"], j["want"][0]) and torch.equal(j["xts"], j["want"][1])
+    L = uaes.engine()
+    for st in streams:
+        assert L.uaes_stream_release(C.c_void_p(st.cuda_stream)) == 0
+    assert L.uaes_stream_release(C.c_void_p(streams[0].cuda_stream)) == 0      # idempotent
+    # and the streams still work afterwards
+    j = jobs[0]
+    j["gcm"].zero_()
+    uaes.gcm_encrypt_dev(j["key"], j["nonce"], None, j["src"], n, j["gcm"], stream=j["st"])
+    torch.cuda.synchronize()
+    assert torch.equal(j["gcm"], j["want"][0])
+
+
+def test_wipe_on_auth_failure_switch(orc):
+    """CCM / GCM-SIV / OCB decrypt before they authenticate.  Default = the reference's default
+    build: 0x1A with the text in place.  uaes_set_wipe_on_auth_failure(1) = its INCREASE_SECURITY
+    build: 0x1A with zeros.  GCM never writes (N7) either way."""
+    L = uaes.engine()
+    rnd = random.Random(31)
+    key, n12, n11 = rnd.randbytes(16), rnd.randbytes(12), rnd.randbytes(11)
+    data = rnd.randbytes(1000)
+    cases = [(uaes.AES_CCM_encrypt, uaes.AES_CCM_decrypt, n11), (uaes.GCM_SIV_encrypt, uaes.GCM_SIV_decrypt, n12),
+             (uaes.AES_OCB_encrypt, uaes.AES_OCB_decrypt, n12)]
+    try:
+        for enc, dec, nonce in cases:
+            bad = bytearray(enc(key, nonce, b"hdr", data))
+            bad[-1] ^= 1
+            assert L.uaes_set_wipe_on_auth_failure(0) in (0, 1)
+            rc, text = dec(key, nonce, b"hdr", bytes(bad), prefill=0xCC)
+            assert rc == 0x1A and text != b"\xcc" * len(data) and text != bytes(len(data))    # released, as the reference does
+            assert L.uaes_set_wipe_on_auth_failure(1) == 0
+            rc, text = dec(key, nonce, b"hdr", bytes(bad), prefill=0xCC)
+            assert rc == 0x1A and text == bytes(len(data))
+            good = enc(key, nonce, b"hdr", data)
+            assert dec(key, nonce, b"hdr", good) == (0, data)                               # unaffected
+            assert L.uaes_set_wipe_on_auth_failure(0) == 1
+        bad = bytearray(uaes.AES_GCM_encrypt(key, n12, b"hdr", data))
+        bad[3] ^= 1
+        assert uaes.AES_GCM_decrypt(key, n12, b"hdr", bytes(bad), prefill=0xCC) == (0x1A, b"\xcc" * len(data))
+    finally:
+        L.uaes_set_wipe_on_auth_failure(0)
+
+
+@pytest.mark.parametrize("sector_bytes,nsectors", [(17, 64), (31, 9), (520, 33), (4099, 70), (65537, 3)])
+def test_xts_units_of_ragged_size_on_device_pointers(orc, sector_bytes, nsectors):
+    """data units whose size is not a multiple of 16: from the second unit on every block sits at
+    an odd address (the kernel then uses byte-aligned 16-byte accesses), both directions, in place"""
+    import torch
+    keys = bytes(range(1, 65))
+    total = sector_bytes * nsectors
+    data = orc.splitmix(sector_bytes, (total + 7) // 8 * 8)[:total]
+    src = torch.frombuffer(bytearray(data + bytes(16)), dtype=torch.uint8).to("cuda:0")
+    dst = torch.zeros_like(src)
+    uaes.xts_sectors_dev(keys, 1 << 33, sector_bytes, nsectors, src, dst, encrypt=True)
+    torch.cuda.synchronize()
+    rc, want = orc.xts_sectors(keys, 1 << 33, sector_bytes, data, True)
+    assert rc == 0 and bytes(dst[:total].cpu().numpy()) == want and int(dst[total:].sum()) == 0
+    uaes.xts_sectors_dev(keys, 1 << 33, sector_bytes, nsectors, dst, dst, encrypt=False)
+    torch.cuda.synchronize()
+    assert bytes(dst[:total].cpu().numpy()) == data

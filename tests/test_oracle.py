@@ -267,6 +267,36 @@ def test_gf128_properties(orc):
         assert lhs == rhs
 
 
+def test_ecb_padding_vectors(orc, golden_dir):
+    """padBlock with AES_PADDING 1 / 2 (micro_aes.c:610-621): outputs of reference builds with the
+    macro patched (tests/golden/make_fixtures.py), among them main.c's AES-192 PKCS#7 answer"""
+    vecs = load(golden_dir, "ecb_padding_vectors.json")
+    assert len(vecs) == 29 and vecs[0]["name"].startswith("main.c:139")
+    for v in vecs:
+        key = bytes.fromhex(v["key"])
+        data = bytes.fromhex(v["pt"]) if "pt" in v else orc.splitmix(v["seed"], (v["len"] + 7) // 8 * 8)[: v["len"]]
+        ct = orc.ecb_encrypt(key, data, padding=v["padding"])
+        assert len(ct) == (len(data) // 16 + 1) * 16
+        check_out(ct, v["out"] if isinstance(v["out"], dict) else {"hex": v["out"]})
+        # the reference's decrypt does not strip the padding (:676-679): the padded text comes back
+        rc, back = orc.ecb_decrypt(key, ct)
+        pad = len(ct) - len(data)
+        want = bytes([pad]) * pad if v["padding"] == 1 else b"\x80" + bytes(pad - 1)
+        assert rc == 0 and back == data + want
+
+
+@pytest.mark.parametrize("bits,padding", [(192, 1), (128, 2)])
+def test_padded_ecb_against_compiled_reference(orc, bits, padding):
+    if not Reference.available(bits, padding):
+        pytest.skip("oracle/_ref not built here")
+    ref = Reference(bits, padding=padding)
+    rnd = random.Random(77 + padding)
+    for _ in range(80):
+        n = rnd.choice([0, 1, 7, 15, 16, 17, 32, 100, 511, 512, 3001])
+        data, key = rnd.randbytes(n), rnd.randbytes(bits // 8)
+        assert orc.ecb_encrypt(key, data, padding=padding) == ref.ecb_encrypt(key, data)
+
+
 @pytest.mark.parametrize("bits", [128, 192, 256])
 def test_against_compiled_reference_random(orc, bits):
     """oracle == the real reference on fresh random inputs (skipped if the
