@@ -122,15 +122,17 @@ __device__ __forceinline__ LaneConst make_lane_const()
     return lc;
 }
 
-__device__ __forceinline__ LaneConst2 make_lane_const2()
+/* base: LDS byte address of the 64 KiB of tables, a multiple of 65536 (it rides in byte 2
+ * of the per-lane constants, which the v_perm copies into the address)                */
+__device__ __forceinline__ LaneConst2 make_lane_const2(u32 base = 0)
 {
     LaneConst2 lc;
     const u32 h = (threadIdx.x >> 4) & 1u, slot = (threadIdx.x & 15u) << 2;
 #pragma unroll
     for (u32 k = 0; k < 4; ++k) {
         const u32 kk = (k + 2u * h) & 3u;
-        lc.t[k] = slot | ((kk & 1u) << 7) | ((kk >> 1) << 6);
-        lc.sel[k] = 0x0c0c0000u | ((4u + kk) << 8);
+        lc.t[k] = base | slot | ((kk & 1u) << 7) | ((kk >> 1) << 6);
+        lc.sel[k] = 0x0c020000u | ((4u + kk) << 8);
     }
     lc.selA = h ? 0x07020c0cu : 0x0c0c0500u;
     lc.selB = h ? 0x0c0c0500u : 0x07020c0cu;
@@ -151,8 +153,8 @@ __device__ __forceinline__ u32 tlook(u32 w, const LaneConst2 &lc)
 template <int TBL, int BYTE>
 __device__ __forceinline__ u32 tlook_true(u32 w, const LaneConst2 &lc)
 {
-    const u32 c = (lc.t[0] & 0x3cu) | ((TBL & 1u) << 7) | ((TBL >> 1) << 6);
-    return lds_word(__builtin_amdgcn_perm(w, c, 0x0c0c0000u | ((4u + BYTE) << 8)));
+    const u32 c = (lc.t[0] & 0xffff003cu) | ((TBL & 1u) << 7) | ((TBL >> 1) << 6);
+    return lds_word(__builtin_amdgcn_perm(w, c, 0x0c020000u | ((4u + BYTE) << 8)));
 }
 template <int TBL, int BYTE>
 __device__ __forceinline__ u32 tlook(u32 w, const LaneConst &lc);
@@ -195,13 +197,13 @@ __device__ __forceinline__ void fill_enc_tables(const u32 *__restrict__ te0)
 }
 
 /* 64 KiB layout: 16 replicas (64 B) per entry */
-__device__ __forceinline__ void fill_tables64(const u32 *__restrict__ t0)
+__device__ __forceinline__ void fill_tables64(const u32 *__restrict__ t0, u32 base = 0)
 {
     for (u32 i = threadIdx.x; i < 1024u; i += blockDim.x) {
         const u32 x = i & 255u, k = i >> 8;
         const u32 v = rotl32(t0[x], 8u * k);
         const uint4 vv = make_uint4(v, v, v, v);
-        uint4 *dst = (uint4 *)(uaes_lds + x * 256u + (k & 1u) * 128u + (k >> 1) * 64u);
+        uint4 *dst = (uint4 *)(uaes_lds + base + x * 256u + (k & 1u) * 128u + (k >> 1) * 64u);
 #pragma unroll
         for (int r = 0; r < 4; ++r) dst[r] = vv;
     }

@@ -1,0 +1,232 @@
+/*
+ * uaes_ctr.hip.h -- the counter-mode core shared by the CTR kernel (uaes_kernels.hip)
+ * and the fused GCM encrypt kernel (uaes_gcm.hip).
+ *
+ *   ctr_words        <- the counter block of stream block i (incBlock, micro_aes.c:421-427)
+ *   ctr_edges        <- blocks outside the whole chunks + the byte tail (mixThenXor, :949)
+ *   ctr_shared_loop  <- CTR_cipher (:943-949) with rounds 1-2 shared between the 256
+ *                       counters of a group
+ */
+#ifndef UAES_CTR_HIP_H_
+#define UAES_CTR_HIP_H_
+
+#include "uaes_aes.hip.h"
+
+/* counter block for stream block i: bytes 0..8 fixed, bytes 9..15 = 56-bit
+ * big-endian (v0 + i) mod 2^56 (reference N2)                               */
+__device__ __forceinline__ void ctr_words(const uaesk_ctr &c, u64 i, u32 (&w)[4])
+{
+    if (c.le32) {                              /* GCM-SIV: LE32 counter in bytes 0..3 (wave-uniform branch) */
+        w[0] = c.w0 + (u32)i;
+        w[1] = c.w1; w[2] = c.w2; w[3] = c.w3;
+        return;
+    }
+    const u64 v = (c.v0 + i) & 0x00FFFFFFFFFFFFFFull;
+    w[0] = c.w0;
+    w[1] = c.w1;
+    w[2] = bswap32((c.b8 << 24) | (u32)(v >> 32));
+    w[3] = bswap32((u32)v);
+}
+
+/* one block through the plain NR-round path: out[i] = in[i] ^ Enc(counter i); returns the ciphertext */
+template <int NR, typename LC>
+__device__ __forceinline__ uint4 ctr_one_block(const uaesk_rk &rk, const uaesk_ctr &ctr, const uint4 *in, uint4 *out,
+                                               u64 i, const LC &lc)
+{
+    u32 s1[1][4];
+    ctr_words(ctr, i, s1[0]);
+    enc_blocks<NR, 1>(s1, rk, lc);
+    const uint4 d = in[i];
+    const uint4 c = make_uint4(d.x ^ s1[0][0], d.y ^ s1[0][1], d.z ^ s1[0][2], d.w ^ s1[0][3]);
+    out[i] = c;
+    return c;
+}
+
+/* reference N3: len%16 tail bytes use Enc(ctr_final) (mixThenXor, :949); one thread */
+template <int NR, typename LC>
+__device__ __forceinline__ void ctr_byte_tail(const uaesk_rk &rk, const uaesk_ctr &ctr, const uint4 *in, uint4 *out,
+                                              u64 nfull, u32 rem, const LC &lc)
+{
+    u32 s1[1][4];
+    ctr_words(ctr, nfull, s1[0]);
+    enc_blocks<NR, 1>(s1, rk, lc);
+    const unsigned char *src = (const unsigned char *)(in + nfull);
+    unsigned char *dst = (unsigned char *)(out + nfull);
+    for (u32 i = 0; i < rem; ++i)
+        dst[i] = src[i] ^ (unsigned char)(s1[0][i >> 2] >> (8 * (i & 3)));
+}
+
+/* Blocks [0, pre_end) and [suf, nfull) and the byte tail, spread evenly over all
+ * workgroups, one block per thread through the plain 10/12/14-round path, so no
+ * separate launch (and no second table fill) is needed.                         */
+template <int NR, typename LC>
+__device__ __forceinline__ void ctr_edge_blocks(const uaesk_rk &rk, const uaesk_ctr &ctr, const uint4 *in, uint4 *out,
+                                                u64 pre_end, u64 suf, u64 nfull, u32 rem, const LC &lc)
+{
+    const u64 nedge = pre_end + (nfull - suf);
+    const u64 per = (nedge + gridDim.x - 1) / gridDim.x;
+    const u64 lo = (u64)blockIdx.x * per;
+    u64 hi = lo + per;
+    if (hi > nedge) hi = nedge;
+    for (u64 e = lo + threadIdx.x; e < hi; e += UAES_WG)
+        (void)ctr_one_block<NR>(rk, ctr, in, out, e < pre_end ? e : suf + (e - pre_end), lc);
+    if (rem && blockIdx.x == 0 && threadIdx.x == 0) ctr_byte_tail<NR>(rk, ctr, in, out, nfull, rem, lc);
+}
+
+#define CTRS_CHUNK 64u                       /* groups (of 256 counters) per U-buffer refill: one barrier each;
+                                                256 measured no faster (profiles/r01_sweep_ctr_variants.log) */
+
+/* ------------------------------------------------------------------------ */
+/* CTR with shared rounds 1-2                                                 */
+/* ------------------------------------------------------------------------ */
+/* Consecutive counter blocks differ only in their low bytes.  Cut the stream
+ * into GROUPS of 256 counters that share bytes 0..14 (group G, position p =
+ * counter byte 15), and pin every lane to one p for the whole kernel:
+ *
+ *   after AddRoundKey(0) only state byte 15 depends on p; after round 1 only
+ *   column 0 does:  col0 = A(G) ^ Te3[p ^ rk0.b15],  col1..3 = uniform(G);
+ *   after round 2 every column is  Te_k[one byte of col0] ^ U_c(G).
+ *
+ * A(G) changes only when counter bits 40..47 change, so the four round-2
+ * lookups on col0's bytes are per-LANE constants L_c, computed once; the
+ * uniform parts U_c(G) cost 27 lookups per GROUP (one lane of wave 0 per group,
+ * handed over through LDS).  A block therefore enters round 3 as L ^ U(G):
+ * 4 XORs instead of 32 table lookups -- 128 lookups per AES-128 block instead
+ * of 160 on a path whose bound is the LDS lookup rate (32 lanes/clk/CU).
+ *
+ * Workgroup = 16 waves = 4 quads; wave w owns positions p = 64*(w&3) + lane.  One
+ * ITERATION of the workgroup covers 8 consecutive groups (2048 blocks): quad q
+ * takes groups q and q+4 of them, two blocks per lane, half a round out of phase
+ * (enc_rounds_skewed), so each wave-level load/store is one contiguous 1 KiB
+ * segment.  Which 8 groups iteration `it` of workgroup b takes is the GEOMETRY:
+ *
+ *   chunked     64-group chunks dealt round-robin: chunk = chunk_lo + b + grid*(it/8),
+ *               groups 64*chunk + 8*(it%8) ...            (the CTR kernel)
+ *   interleaved 8-group stripes dealt round-robin: groups g_lo + 8*(b + grid*it) ...
+ *               Block (b, it, q, u, p) then sits at  j + S*it  with the lane index
+ *               j = 2048 b + 256 (q + 4u) + p and S = 2048 grid: exactly the strided
+ *               Horner layout of GHASH, so a lane can fold its own ciphertext
+ *               blocks as it produces them (the fused GCM kernel).
+ *
+ * U-buffer: the uniform parts of the next 8 iterations (64 groups), double buffered,
+ * one s_barrier per 8 iterations.                                                */
+struct CtrGeo {
+    u64 first;          /* chunked: chunk_lo;  interleaved: g_lo (first group)        */
+    u64 iters;          /* iterations of THIS workgroup                               */
+    u32 interleaved;
+};
+
+__device__ __forceinline__ u64 ctr_geo_group0(const CtrGeo &g, u64 it)
+{
+    if (g.interleaved) return g.first + 8ull * ((u64)blockIdx.x + (u64)gridDim.x * it);
+    return 64ull * (g.first + blockIdx.x + (u64)gridDim.x * (it >> 3)) + 8ull * (it & 7);
+}
+
+/* FOLD: functor called once per iteration with the two ciphertext blocks of this lane
+ * (u = 0, 1), in stream order per lane; `void operator()(uint4 c0, uint4 c1)`.       */
+struct CtrNoFold {
+    __device__ __forceinline__ void operator()(const uint4 &, const uint4 &) const {}
+};
+
+/* lds_buf: byte offset of 2 x 64 x 32 B of LDS for the U-buffer */
+template <int NR, typename LC, typename FOLD>
+__device__ __forceinline__ void ctr_shared_loop(const uaesk_rk &rk, const uaesk_ctr &ctr, const uint4 *in, uint4 *out,
+                                                const CtrGeo &geo, u32 lds_buf, const LC &lc, FOLD &fold)
+{
+    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const u32 p = ((wave & 3u) << 6) | lane;               /* counter byte 15 of this lane */
+    const u32 quad = wave >> 2;
+    const u32 c0 = (u32)ctr.v0 & 0xffu;                    /* position of stream block 0   */
+    const u64 vbase = ctr.v0 - c0;                         /* group-aligned counter        */
+    uint4 *buf = (uint4 *)(uaes_lds + lds_buf);
+    const u32 lane_blk = (quad << 8) | p;                  /* lane's block offset inside the 8-group stripe */
+
+    /* byte 15 after AddRoundKey(0), as a Te3 lookup operand in byte 3 */
+    const u32 x15 = ((p << 24) ^ rk.w[3]) & 0xff000000u;
+    /* round keys 3..NR (wave-uniform: they stay in SGPRs; forcing them into VGPRs to
+     * speed up v_bitop3 issue measured 3 % SLOWER -- more VGPRs, lower clock)        */
+    struct { u32 w[4 * (NR - 2)]; } rkv;
+#pragma unroll
+    for (int i = 0; i < 4 * (NR - 2); ++i) rkv.w[i] = rk.w[12 + i];
+    u32 a_cur = 0, L0 = 0, L1 = 0, L2 = 0, L3 = 0;
+    bool have_l = false;
+    u32 parity = 0;
+
+    /* Block index of (it, u, lane) = ((group0(it) + 4u) << 8) - c0 [uniform] + lane_blk [per lane].
+     * The plaintext of iteration it+1 is requested before the rounds of iteration it, so
+     * HBM latency hides under ~260 table lookups.                                       */
+    u64 it = 0;
+    uint4 d_cur[2], d_nxt[2];
+    if (it < geo.iters) {
+        const u64 g0 = ctr_geo_group0(geo, 0);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) d_cur[u] = (in + (((g0 + 4u * u) << 8) - c0))[lane_blk];
+    }
+
+    while (it < geo.iters) {
+        if ((it & 7) == 0) {
+            if (wave == 0) {
+                /* uniform part of rounds 1 and 2 for the 64 groups of iterations it .. it+7:
+                 * lane gi handles group group0(it + gi/8) + gi%8                          */
+                const u32 gi = lane;
+                const u64 g = ctr_geo_group0(geo, it + (gi >> 3)) + (gi & 7u);
+                const u64 v = (vbase + (g << 8)) & 0x00FFFFFFFFFFFFFFull;
+                const u32 s0 = ctr.w0 ^ rk.w[0], s1 = ctr.w1 ^ rk.w[1];
+                const u32 s2 = bswap32((ctr.b8 << 24) | (u32)(v >> 32)) ^ rk.w[2];
+                const u32 s3 = (bswap32((u32)v) ^ rk.w[3]) & 0x00ffffffu;      /* byte 15 excluded */
+#define TL(k, b, w) tlook_true<k, b>(w, lc)
+                const u32 A = xor3(TL(0, 0, s0), TL(1, 1, s1), TL(2, 2, s2)) ^ rk.w[4];
+                const u32 c1 = xor3(xor3(TL(0, 0, s1), TL(1, 1, s2), TL(2, 2, s3)), TL(3, 3, s0), rk.w[5]);
+                const u32 c2 = xor3(xor3(TL(0, 0, s2), TL(1, 1, s3), TL(2, 2, s0)), TL(3, 3, s1), rk.w[6]);
+                const u32 c3 = xor3(xor3(TL(0, 0, s3), TL(1, 1, s0), TL(2, 2, s1)), TL(3, 3, s2), rk.w[7]);
+                const u32 u0 = xor3(TL(1, 1, c1), TL(2, 2, c2), TL(3, 3, c3)) ^ rk.w[8];
+                const u32 u1 = xor3(TL(0, 0, c1), TL(1, 1, c2), TL(2, 2, c3)) ^ rk.w[9];
+                const u32 u2 = xor3(TL(0, 0, c2), TL(1, 1, c3), TL(3, 3, c1)) ^ rk.w[10];
+                const u32 u3 = xor3(TL(0, 0, c3), TL(2, 2, c1), TL(3, 3, c2)) ^ rk.w[11];
+                buf[(parity * CTRS_CHUNK + gi) * 2 + 0] = make_uint4(u0, u1, u2, u3);
+                buf[(parity * CTRS_CHUNK + gi) * 2 + 1] = make_uint4(A, 0, 0, 0);
+            }
+            __syncthreads();
+        }
+
+        /* request the next iteration's plaintext (clamped to this workgroup's last one) */
+        const u64 g0 = ctr_geo_group0(geo, it);
+        {
+            const u64 gn = ctr_geo_group0(geo, it + 1 < geo.iters ? it + 1 : it);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) d_nxt[u] = (in + (((gn + 4u * u) << 8) - c0))[lane_blk];
+        }
+
+        u32 s[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const u32 gl = 8u * ((u32)it & 7u) + quad + 4u * u;            /* slot in the U-buffer */
+            const uint4 uu = buf[(parity * CTRS_CHUNK + gl) * 2 + 0];
+            const u32 A = buf[(parity * CTRS_CHUNK + gl) * 2 + 1].x;
+            if (!have_l || A != a_cur) {                                   /* wave-uniform; ~never after the first time */
+                const u32 col0 = A ^ TL(3, 3, x15);
+                L0 = TL(0, 0, col0);
+                L1 = TL(3, 3, col0);
+                L2 = TL(2, 2, col0);
+                L3 = TL(1, 1, col0);
+                a_cur = A;
+                have_l = true;
+            }
+#undef TL
+            s[u][0] = L0 ^ uu.x; s[u][1] = L1 ^ uu.y; s[u][2] = L2 ^ uu.z; s[u][3] = L3 ^ uu.w;
+        }
+        enc_rounds_skewed<NR, 3>(s[0], s[1], rkv, lc);
+        uint4 ct[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            ct[u] = make_uint4(d_cur[u].x ^ s[u][0], d_cur[u].y ^ s[u][1], d_cur[u].z ^ s[u][2], d_cur[u].w ^ s[u][3]);
+            (out + (((g0 + 4u * u) << 8) - c0))[lane_blk] = ct[u];
+            d_cur[u] = d_nxt[u];
+        }
+        fold(ct[0], ct[1]);
+        ++it;
+        if ((it & 7) == 0) parity ^= 1u;
+    }
+}
+
+#endif

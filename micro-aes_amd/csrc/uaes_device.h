@@ -71,6 +71,7 @@ int uaesk_xts(void *stream, const uaesk_tables *tb, int nr,
  * written at out+len.  decrypt: GHASH over in[0..len), compare with the tag
  * at in+len, *status = 0 / 0x1A, CTR gated on *status.                     */
 size_t uaesk_gcm_scratch_bytes(void);
+size_t uaesk_gcm_stream_scratch_bytes(void);     /* what the streamed API needs (no fused-pass buffers) */
 int uaesk_gcm(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek,
               int decrypt, const uint8_t *nonce12,
               const void *aad, size_t aad_len,

@@ -1301,10 +1301,10 @@ struct uaes_gcm_stream {
     int       decrypt, closed, device;
     uint64_t  aad_len, done;        /* bytes of text absorbed so far */
     unsigned  plan_state;           /* which GHASH tables the scratch holds (uaesk_gcm_stream_absorb) */
-    void     *scratch;              /* uaesk_gcm_scratch_bytes() + 64: tables, running GHASH, tag, status */
+    void     *scratch;              /* uaesk_gcm_stream_scratch_bytes() + 64: tables, running GHASH, tag, status */
 };
 
-static void *stream_tag_slot(uaes_gcm_stream *s) { return (char *)s->scratch + uaesk_gcm_scratch_bytes(); }
+static void *stream_tag_slot(uaes_gcm_stream *s) { return (char *)s->scratch + uaesk_gcm_stream_scratch_bytes(); }
 static int *stream_status_slot(uaes_gcm_stream *s) { return (int *)((char *)stream_tag_slot(s) + 16); }
 
 int uaes_gcm_stream_begin(uaes_gcm_stream **out, int keybits, const uint8_t *key, const uint8_t *nonce,
@@ -1322,7 +1322,7 @@ int uaes_gcm_stream_begin(uaes_gcm_stream **out, int keybits, const uint8_t *key
     s->decrypt = decrypt != 0;
     s->aad_len = aDataLen;
     if (hipGetDevice(&s->device) != hipSuccess ||
-        hipMalloc(&s->scratch, uaesk_gcm_scratch_bytes() + 64) != hipSuccess) {
+        hipMalloc(&s->scratch, uaesk_gcm_stream_scratch_bytes() + 64) != hipSuccess) {
         free(s);
         return fail(UAES_E_HIP, "stream scratch allocation failed");
     }

@@ -31,6 +31,7 @@
 #include <hip/hip_runtime.h>
 #include <string.h>
 #include "uaes_aes.hip.h"
+#include "uaes_ctr.hip.h"
 #include "uaes_gf.h"
 #include "uaes_device.h"
 
@@ -55,7 +56,11 @@
 #define GS_POW64    (GS_ACC2 + (16u << GH_LOGB))   /* H^(2^k), k = 0..63 (sharded GCM) */
 #define GS_PART     (GS_POW64 + 1024u)              /* raw GHASH of a shard             */
 #define GS_RUN      (GS_PART + 16u)                 /* running GHASH of a streamed message */
-#define GS_TOTAL    (GS_PART + 64u)
+#define GS_SMALL    (GS_PART + 64u)                 /* everything the streamed / sharded paths need */
+#define GF_MAXLOG   20u                             /* fused encrypt: lanes of the whole grid, 2048 per workgroup */
+#define GS_TAB8_F   GS_SMALL                        /* H^(2048 * workgroups), 64 KiB (fused encrypt) */
+#define GS_ACCF     (GS_TAB8_F + 65536u)            /* its per-lane accumulators, up to 2^20 x 16    */
+#define GS_TOTAL    (GS_ACCF + (16u << GF_MAXLOG))
 
 static inline hipStream_t S(void *s) { return (hipStream_t)s; }
 
@@ -332,14 +337,16 @@ __device__ __forceinline__ Gf wave_gfmul(Gf x, Gf y, u32 lane)
 #define SETUP_LDS   (UAES_LDS_ENC + 16384u)
 
 /* logA: log2 of the bulk stride (12..17), 0 = no bulk level.  needB: build the
- * H^4096 table.  h_given: skip AES, use hval as H and 0 as Enc(J0) (tests).   */
+ * H^4096 table.  h_given: skip AES, use hval as H and 0 as Enc(J0) (tests).
+ * logF != 0: also build the table of H^(2^logF) for the fused encrypt kernel.   */
 template <int NR>
 __global__ __launch_bounds__(UAES_WG) void k_gcm_setup(uaesk_rk ek, uaesk_tables tb, uint4 j0,
                                                        unsigned char *__restrict__ scratch,
-                                                       u32 logA, u32 needB, u32 h_given, uint4 hval, u32 want_pow64)
+                                                       u32 logA, u32 needB, u32 h_given, uint4 hval, u32 want_pow64,
+                                                       u32 logF)
 {
-    Gf *shPow = (Gf *)(uaes_lds + UAES_LDS_ENC);          /* 18 powers         */
-    Gf *shGen = shPow + 32;                                /* 6 x 128 generators */
+    Gf *shPow = (Gf *)(uaes_lds + UAES_LDS_ENC);          /* up to 21 powers   */
+    Gf *shGen = shPow + 32;                                /* 7 x 128 generators */
     uint4 *gH = (uint4 *)(scratch + GS_H);
 
     if (!h_given) {
@@ -362,11 +369,11 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_setup(uaesk_rk ek, uaesk_tables
     if (threadIdx.x < 64) {                    /* squaring chain, wave 0 */
         Gf p = shPow[0];
         uint4 *g64 = (uint4 *)(scratch + GS_POW64);
-        const u32 last = want_pow64 ? 63u : GH_MAXLOG;
+        const u32 last = want_pow64 ? 63u : (logF > GH_MAXLOG ? logF : GH_MAXLOG);
         for (u32 k = 0; k <= last; ++k) {
             if (k) p = wave_gfmul(p, p, threadIdx.x);
             if (threadIdx.x == 0) {
-                if (k <= GH_MAXLOG) shPow[k] = p;
+                if (k <= GF_MAXLOG) shPow[k] = p;
                 if (want_pow64) {
                     u32 w[4];
                     gf_to_words(p, w);
@@ -377,19 +384,19 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_setup(uaesk_rk ek, uaesk_tables
     }
     __syncthreads();
 
-    /* generators M*x^q of the six tables: A (2^logA), B (2^14), C (2^10), D (2^6), E (2^2), F (2^0) */
-    const u32 logs[6] = { logA, GH_LOGB, 10u, 6u, 2u, 0u };
-    if (threadIdx.x < 768) {
+    /* generators M*x^q of the tables: A (2^logA), B (2^14), C (2^10), D (2^6), E (2^2), F (2^0), fused (2^logF) */
+    const u32 logs[7] = { logA, GH_LOGB, 10u, 6u, 2u, 0u, logF };
+    if (threadIdx.x < 896) {
         const u32 t = threadIdx.x >> 7, q = threadIdx.x & 127u;
         shGen[threadIdx.x] = gf_mul_xq128(shPow[logs[t]], q);
     }
     __syncthreads();
 
     /* byte-indexed tables: entry (j, v) = sum_i bit(v, 7-i) * gen[8j+i] */
-    for (u32 t = 0; t < 2; ++t) {
-        if ((t == 0 && !logA) || (t == 1 && !needB)) continue;
-        uint4 *dst = (uint4 *)(scratch + (t == 0 ? GS_TAB8_A : GS_TAB8_B));
-        const Gf *gen = shGen + 128 * t;
+    for (u32 t = 0; t < 3; ++t) {
+        if ((t == 0 && !logA) || (t == 1 && !needB) || (t == 2 && !logF)) continue;
+        uint4 *dst = (uint4 *)(scratch + (t == 0 ? GS_TAB8_A : t == 1 ? GS_TAB8_B : GS_TAB8_F));
+        const Gf *gen = shGen + 128 * (t == 2 ? 6 : t);
         const u32 v = threadIdx.x & 255u;
 #pragma unroll
         for (u32 jj = 0; jj < 4; ++jj) {
@@ -429,6 +436,123 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_setup(uaesk_rk ek, uaesk_tables
         gf_to_words(shPow[threadIdx.x], w);
         ((uint4 *)(scratch + GS_POW))[threadIdx.x] = make_uint4(w[0], w[1], w[2], w[3]);
     }
+}
+
+/* ------------------------------------------------------------------------ */
+/* fused encrypt: CTR with shared rounds + GHASH of the ciphertext in one pass  */
+/* ------------------------------------------------------------------------ */
+/* The separate GHASH pass re-reads the gigabyte the CTR kernel has just written (1.5x the
+ * algorithmic HBM traffic).  Here every lane folds its ciphertext blocks into its own
+ * GHASH accumulators while they are still in registers:
+ *
+ *   the interleaved geometry of ctr_shared_loop puts block (b, it, q, u, p) at  j + S it,
+ *   j = 2048 b + 256 (q + 4u) + p,  S = 2048 * workgroups  -- the strided-Horner layout of
+ *   the GHASH levels -- so  acc_j <- acc_j * H^S ^ C  per block (tabmul8_xor, the 64 KiB
+ *   byte table of H^S in LDS next to the 64 KiB split-halves AES tables), and the middle
+ *   of the message is represented by its S accumulators, acc_0..acc_{S-1}, as S blocks.
+ *
+ * Message layout: [AAD blocks][head: ciphertext blocks up to the first group boundary of
+ * the counter, < 256][middle: `iters` whole rounds of S blocks][tail blocks + ragged
+ * bytes][length block].  The nfront = AAD + head blocks in front of the middle are the
+ * INITIAL values of the last nfront accumulators (they sit exactly one stride before those
+ * lanes' first blocks); a head block is encrypted by the lane that absorbs it.  The tail is
+ * encrypted in the prologue (spread over all workgroups) and hashed, behind the S
+ * accumulators, by the ordinary levels: GHASH([acc_0..acc_{S-1}][tail][lengths]).
+ *
+ * LDS: [0, 64K) GHASH table, [64K, 128K) AES tables, then the U-buffer.             */
+#define GF_LDS_AES    65536u
+#define GF_LDS_BUF    131072u
+#define GF_LDS_TOTAL  (GF_LDS_BUF + 2u * CTRS_CHUNK * 32u)
+
+/* tabmul8_xor in two halves of 8 lookups: 32 registers of table entries in flight instead
+ * of 64 (the fused kernel shares its 128-register budget with the cipher's two states)   */
+__device__ __forceinline__ uint4 tabmul8_xor_half(uint4 a, uint4 x, const GhLane &gl)
+{
+    u32 r[4];
+    gh_rotate(a, gl.g, r);
+    u32 z[4] = { x.x, x.y, x.z, x.w };
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        u32x4 e[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int t = 8 * h + i;
+            const u32 sel = 0x0c0c0000u | ((4u + (t & 3)) << 8) | (u32)(t & 3);
+            e[i] = *(lds_cu128 *)(uintptr_t)__builtin_amdgcn_perm(r[t >> 2], gl.so[t >> 2], sel);
+        }
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+#pragma unroll
+            for (int i = 0; i < 8; i += 2) z[w] = xor3(z[w], e[i][w], e[i + 1][w]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    return make_uint4(z[0], z[1], z[2], z[3]);
+}
+
+struct GhFold {
+    uint4 acc[2];
+    GhLane gl;
+    __device__ __forceinline__ void operator()(const uint4 &c0, const uint4 &c1)
+    {
+        __builtin_amdgcn_sched_barrier(0);
+        acc[0] = tabmul8_xor_half(acc[0], c0, gl);
+        acc[1] = tabmul8_xor_half(acc[1], c1, gl);
+    }
+};
+
+template <int NR>
+__global__ __launch_bounds__(UAES_WG) void k_gcm_enc_fused(uaesk_rk rk, uaesk_tables tb, uaesk_ctr ctr,
+                                                           const uint4 *in, uint4 *out,
+                                                           u64 g_lo, u64 iters, u64 h1, u64 nfull, u32 rem,
+                                                           GSrc front, u64 nfront,
+                                                           const uint4 *__restrict__ tab8, uint4 *__restrict__ accs)
+{
+    uint4 *T = (uint4 *)uaes_lds;                  /* LDS address 0 (absolute addressing in tabmul8_xor) */
+    for (u32 i = threadIdx.x; i < 4096u; i += UAES_WG) T[i] = tab8[i];
+    fill_tables64(tb.te0, GF_LDS_AES);             /* ends with a barrier */
+    const LaneConst2 lc = make_lane_const2(GF_LDS_AES);
+    GhFold fold;
+    fold.gl = gh_lane_setup();
+
+    /* tail blocks [h1, nfull) and the ragged bytes */
+    ctr_edge_blocks<NR>(rk, ctr, in, out, 0, h1, nfull, rem, lc);
+
+    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const u32 p = ((wave & 3u) << 6) | lane, quad = wave >> 2;
+    const u64 S = 2048ull * gridDim.x;
+    const u64 ablk = (front.aad_len + 15) >> 4;
+    u64 j[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        j[u] = 2048ull * blockIdx.x + 256u * (quad + 4u * u) + p;
+        fold.acc[u] = make_uint4(0, 0, 0, 0);
+        if (j[u] >= S - nfront) {                  /* a block in front of the middle: AAD, or a head block */
+            const u64 f = j[u] - (S - nfront);
+            fold.acc[u] = f < ablk ? load_vblock_fwd(front, f) : ctr_one_block<NR>(rk, ctr, in, out, f - ablk, lc);
+        }
+    }
+    CtrGeo geo;
+    geo.first = g_lo;
+    geo.iters = iters;
+    geo.interleaved = 1;
+    ctr_shared_loop<NR>(rk, ctr, in, out, geo, GF_LDS_BUF, lc, fold);
+    accs[j[0]] = fold.acc[0];
+    accs[j[1]] = fold.acc[1];
+}
+
+template <int NR>
+static int launch_fused(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek, const uaesk_ctr *c,
+                        const void *in, void *out, unsigned grid, u64 g_lo, u64 iters, u64 h1, u64 nfull, u32 rem,
+                        const GSrc &front, u64 nfront, unsigned char *sc)
+{
+    hipError_t e = hipFuncSetAttribute((const void *)k_gcm_enc_fused<NR>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       GF_LDS_TOTAL);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((k_gcm_enc_fused<NR>), dim3(grid), dim3(UAES_WG), GF_LDS_TOTAL, st, *ek, *tb, *c,
+                       (const uint4 *)in, (uint4 *)out, g_lo, iters, h1, nfull, rem, front, nfront,
+                       (const uint4 *)(sc + GS_TAB8_F), (uint4 *)(sc + GS_ACCF));
+    return (int)hipGetLastError();
 }
 
 /* ------------------------------------------------------------------------ */
@@ -479,15 +603,17 @@ static int run_ghash_levels(hipStream_t st, const GSrc &msg, u64 nv, const GPlan
 }
 
 extern "C" size_t uaesk_gcm_scratch_bytes(void) { return GS_TOTAL; }
+extern "C" size_t uaesk_gcm_stream_scratch_bytes(void) { return GS_SMALL; }
 
 template <int NR>
 static int launch_setup(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek, uint4 j0,
-                        unsigned char *scratch, const GPlan &pl, u32 h_given, uint4 hval, u32 want_pow64 = 0)
+                        unsigned char *scratch, const GPlan &pl, u32 h_given, uint4 hval, u32 want_pow64 = 0,
+                        u32 logF = 0)
 {
     hipError_t e = hipFuncSetAttribute((const void *)k_gcm_setup<NR>, hipFuncAttributeMaxDynamicSharedMemorySize, SETUP_LDS);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL((k_gcm_setup<NR>), dim3(1), dim3(UAES_WG), SETUP_LDS, st, *ek, *tb, j0, scratch,
-                       pl.logA, pl.needB, h_given, hval, want_pow64);
+                       pl.logA, pl.needB, h_given, hval, want_pow64, logF);
     return (int)hipGetLastError();
 }
 
@@ -519,10 +645,52 @@ extern "C" int uaesk_gcm(void *stream, const uaesk_tables *tb, int nr, const uae
     msg.ct = (const unsigned char *)(decrypt ? in : out); msg.ct_len = len;
     msg.has_len = 1; msg.len_aad = aad_len; msg.len_ct = len; msg.rev = 0;
     const u64 nv = ((aad_len + 15) >> 4) + ((len + 15) >> 4) + 1;
-    const GPlan pl = plan_for(nv);
 
     int rc;
     const uint4 z = make_uint4(0, 0, 0, 0);
+
+    /* Encrypt, long text: CTR and GHASH in one pass (k_gcm_enc_fused).  Needs a power-of-two
+     * number of lanes in the grid (S = 2048 * CUs: 2^19 on MI355X), at least two whole rounds of
+     * S blocks, and the AAD + head blocks to fit in front of one round.  Decrypt authenticates
+     * BEFORE it writes (N7), so it keeps the two-pass order.                              */
+    if (!decrypt) {
+        int cus = 0;
+        if (uaesk_device_info(&cus, nullptr) != 0) cus = 0;
+        const u64 Sl = 2048ull * (u64)(cus > 0 ? cus : 0);
+        u32 logF = 0;
+        while (((u64)1 << logF) < Sl) ++logF;
+        const u64 nfull = len / 16, ablk = (aad_len + 15) >> 4;
+        const u32 c0 = (u32)c.v0 & 0xffu;
+        const u64 h0 = (256u - c0) & 255u;
+        if (Sl && ((u64)1 << logF) == Sl && logF <= GF_MAXLOG && nfull >= h0 + 2 * Sl && ablk + h0 <= Sl) {
+            const u64 iters = (nfull - h0) / Sl, h1 = h0 + iters * Sl;
+            GSrc fin;                                   /* [accumulators][tail][lengths] */
+            fin.aad = sc + GS_ACCF; fin.aad_len = Sl * 16;
+            fin.ct = (const unsigned char *)out + h1 * 16; fin.ct_len = len - h1 * 16;
+            fin.has_len = 1; fin.len_aad = aad_len; fin.len_ct = len; fin.rev = 0;
+            const u64 nvf = Sl + ((fin.ct_len + 15) >> 4) + 1;
+            const GPlan plf = plan_for(nvf);
+            GSrc front = msg;                           /* [AAD][head] in front of the middle */
+            front.ct_len = h0 * 16; front.has_len = 0;
+            switch (nr) {
+            case 10: rc = launch_setup<10>(st, tb, ek, j0, sc, plf, 0, z, 0, logF); break;
+            case 12: rc = launch_setup<12>(st, tb, ek, j0, sc, plf, 0, z, 0, logF); break;
+            case 14: rc = launch_setup<14>(st, tb, ek, j0, sc, plf, 0, z, 0, logF); break;
+            default: return (int)hipErrorInvalidValue;
+            }
+            if (rc) return rc;
+            const u64 g_lo = c0 ? 1 : 0;
+            switch (nr) {
+            case 10: rc = launch_fused<10>(st, tb, ek, &c, in, out, (unsigned)cus, g_lo, iters, h1, nfull, (u32)(len % 16), front, ablk + h0, sc); break;
+            case 12: rc = launch_fused<12>(st, tb, ek, &c, in, out, (unsigned)cus, g_lo, iters, h1, nfull, (u32)(len % 16), front, ablk + h0, sc); break;
+            default: rc = launch_fused<14>(st, tb, ek, &c, in, out, (unsigned)cus, g_lo, iters, h1, nfull, (u32)(len % 16), front, ablk + h0, sc); break;
+            }
+            if (rc) return rc;
+            return run_ghash_levels(st, fin, nvf, plf, sc, 0, (unsigned char *)out + len, nullptr);
+        }
+    }
+
+    const GPlan pl = plan_for(nv);
     switch (nr) {
     case 10: rc = launch_setup<10>(st, tb, ek, j0, sc, pl, 0, z); break;
     case 12: rc = launch_setup<12>(st, tb, ek, j0, sc, pl, 0, z); break;

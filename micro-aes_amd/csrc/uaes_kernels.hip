@@ -19,6 +19,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include "uaes_aes.hip.h"
+#include "uaes_ctr.hip.h"
 #include "uaes_gf.h"
 #include "uaes_device.h"
 
@@ -86,24 +87,8 @@ __global__ __launch_bounds__(UAES_WG) void k_ecb(uaesk_rk rk, uaesk_tables tb,
 }
 
 /* ------------------------------------------------------------------------ */
-/* CTR                                                                        */
+/* CTR (counter arithmetic, edges and the shared-round loop: uaes_ctr.hip.h)   */
 /* ------------------------------------------------------------------------ */
-/* counter block for stream block i: bytes 0..8 fixed, bytes 9..15 = 56-bit
- * big-endian (v0 + i) mod 2^56 (reference N2)                               */
-__device__ __forceinline__ void ctr_words(const uaesk_ctr &c, u64 i, u32 (&w)[4])
-{
-    if (c.le32) {                              /* GCM-SIV: LE32 counter in bytes 0..3 (wave-uniform branch) */
-        w[0] = c.w0 + (u32)i;
-        w[1] = c.w1; w[2] = c.w2; w[3] = c.w3;
-        return;
-    }
-    const u64 v = (c.v0 + i) & 0x00FFFFFFFFFFFFFFull;
-    w[0] = c.w0;
-    w[1] = c.w1;
-    w[2] = bswap32((c.b8 << 24) | (u32)(v >> 32));
-    w[3] = bswap32((u32)v);
-}
-
 /* the generic CTR kernel: work items are single blocks, U = 4 per lane per iteration */
 template <int NR, int U>
 __global__ __launch_bounds__(UAES_WG, 4) void k_ctr(uaesk_rk rk, uaesk_tables tb, uaesk_ctr ctr,
@@ -139,87 +124,17 @@ __global__ __launch_bounds__(UAES_WG, 4) void k_ctr(uaesk_rk rk, uaesk_tables tb
     }
 
     /* reference N3: len%16 tail bytes use Enc(ctr_final) (mixThenXor, :949) */
-    if (rem && blockIdx.x == 0 && threadIdx.x == 0) {
-        u32 s1[1][4];
-        ctr_words(ctr, nfull, s1[0]);
-        enc_blocks<NR, 1>(s1, rk, lc);
-        const unsigned char *src = (const unsigned char *)(in + nfull);
-        unsigned char *dst = (unsigned char *)(out + nfull);
-        for (u32 i = 0; i < rem; ++i)
-            dst[i] = src[i] ^ (unsigned char)(s1[0][i >> 2] >> (8 * (i & 3)));
-    }
+    if (rem && blockIdx.x == 0 && threadIdx.x == 0) ctr_byte_tail<NR>(rk, ctr, in, out, nfull, rem, lc);
 }
 
-#define CTRS_CHUNK 64u                       /* groups (of 256 counters) per chunk: one barrier each;
-                                                256 measured no faster (profiles/r01_sweep_ctr_variants.log) */
-
-/* The blocks in front of / behind the whole chunks of the shared-round kernels
- * (each side < 16384 blocks) and the byte tail: spread evenly over all
- * workgroups, one block per thread through the plain 10/12/14-round path, so
- * no separate launch (and no second 128 KiB table fill) is needed.           */
-template <int NR>
-__device__ __forceinline__ void ctr_edges(const uaesk_rk &rk, const uaesk_ctr &ctr,
-                                          const uint4 *in, uint4 *out,
-                                          u64 chunk_lo, u64 chunk_hi, u64 nfull, u32 rem, const LaneConst &lc)
-{
-    const u32 c0 = (u32)ctr.v0 & 0xffu;
-    const u64 per_chunk = (u64)CTRS_CHUNK * 256ull;
-    const u64 pre_end = chunk_lo * per_chunk - (chunk_lo ? c0 : 0);         /* blocks [0, pre_end)     */
-    const u64 suf = chunk_hi * per_chunk - c0;                              /* blocks [suf, nfull)     */
-    const u64 nedge = pre_end + (nfull - suf);
-    const u64 per = (nedge + gridDim.x - 1) / gridDim.x;
-    const u64 lo = (u64)blockIdx.x * per;
-    u64 hi = lo + per;
-    if (hi > nedge) hi = nedge;
-    for (u64 e = lo + threadIdx.x; e < hi; e += UAES_WG) {
-        const u64 i = e < pre_end ? e : suf + (e - pre_end);
-        u32 s1[1][4];
-        ctr_words(ctr, i, s1[0]);
-        enc_blocks<NR, 1>(s1, rk, lc);
-        const uint4 d = in[i];
-        out[i] = make_uint4(d.x ^ s1[0][0], d.y ^ s1[0][1], d.z ^ s1[0][2], d.w ^ s1[0][3]);
-    }
-    /* reference N3: len%16 tail bytes use Enc(ctr_final) (mixThenXor, :949) */
-    if (rem && blockIdx.x == 0 && threadIdx.x == 0) {
-        u32 s1[1][4];
-        ctr_words(ctr, nfull, s1[0]);
-        enc_blocks<NR, 1>(s1, rk, lc);
-        const unsigned char *src = (const unsigned char *)(in + nfull);
-        unsigned char *dst = (unsigned char *)(out + nfull);
-        for (u32 i = 0; i < rem; ++i)
-            dst[i] = src[i] ^ (unsigned char)(s1[0][i >> 2] >> (8 * (i & 3)));
-    }
-}
-
-/* ------------------------------------------------------------------------ */
-/* CTR with shared rounds 1-2                                                 */
-/* ------------------------------------------------------------------------ */
-/* Consecutive counter blocks differ only in their low bytes.  Cut the stream
- * into GROUPS of 256 counters that share bytes 0..14 (group G, position p =
- * counter byte 15), and pin every lane to one p for the whole kernel:
- *
- *   after AddRoundKey(0) only state byte 15 depends on p; after round 1 only
- *   column 0 does:  col0 = A(G) ^ Te3[p ^ rk0.b15],  col1..3 = uniform(G);
- *   after round 2 every column is  Te_k[one byte of col0] ^ U_c(G).
- *
- * A(G) changes only when counter bits 40..47 change, so the four round-2
- * lookups on col0's bytes are per-LANE constants L_c, computed once; the
- * uniform parts U_c(G) cost 27 lookups per GROUP (one lane of waves 0..3 per group,
- * handed over through LDS).  A block therefore enters round 3 as L ^ U(G):
- * 4 XORs instead of 32 table lookups -- 128 lookups per AES-128 block instead
- * of 160 on a path whose bound is the LDS lookup rate (32 lanes/clk/CU).
- *
- * Workgroup = 16 waves = 4 quads; wave w owns positions p = 64*(w&3) + lane and
- * walks groups (w>>2) + 4k of a 64-group chunk, four groups per iteration, so
- * each wave-level load/store is still one contiguous 1 KiB segment.           */
 #define CTRS_BUF   (UAES_LDS_ENC)            /* 2 x 64 x 32 B after the tables */
 #define UAES_LDS_CTRS (UAES_LDS_ENC + 2u * CTRS_CHUNK * 32u)
 
-/* The hot loop handles only chunks [chunk_lo, chunk_hi) that lie completely inside
- * the stream, so it has no bounds checks; the blocks before and after them (up to
- * block nfull) and a byte tail run in the prologue (ctr_edges).  Two blocks per lane,
- * half a round out of phase (enc_rounds_skewed); a lock-step four-block version
- * measured 4 % slower (profiles/r01_sweep_ctr_variants.log).                     */
+/* The shared-round CTR kernel (uaes_ctr.hip.h, chunked geometry): the hot loop handles
+ * only chunks [chunk_lo, chunk_hi) that lie completely inside the stream, so it has no
+ * bounds checks; the blocks before and after them (up to block nfull) and a byte tail
+ * run in the prologue.  A lock-step four-block version measured 4 % slower
+ * (profiles/r01_sweep_ctr_variants.log).                                            */
 template <int NR>
 __global__ __launch_bounds__(UAES_WG, 4) void k_ctr_shared2(uaesk_rk rk, uaesk_tables tb, uaesk_ctr ctr,
                                                            const uint4 *in, uint4 *out,
@@ -229,104 +144,19 @@ __global__ __launch_bounds__(UAES_WG, 4) void k_ctr_shared2(uaesk_rk rk, uaesk_t
     if (gate && *gate != 0) return;
     fill_enc_tables(tb.te0);
     const LaneConst lc = make_lane_const();
-    ctr_edges<NR>(rk, ctr, in, out, chunk_lo, chunk_hi, nfull, rem, lc);
-    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const u32 p = ((wave & 3u) << 6) | lane;               /* counter byte 15 of this lane */
-    const u32 quad = wave >> 2;
-    const u32 c0 = (u32)ctr.v0 & 0xffu;                    /* position of stream block 0   */
-    const u64 vbase = ctr.v0 - c0;                         /* group-aligned counter        */
-    uint4 *buf = (uint4 *)(uaes_lds + CTRS_BUF);
-    const u32 lane_blk = (quad << 8) | p;                  /* lane's block offset inside a 4-group stripe */
-
-    /* byte 15 after AddRoundKey(0), as a Te3 lookup operand in byte 3 */
-    const u32 x15 = ((p << 24) ^ rk.w[3]) & 0xff000000u;
-    /* round keys 3..NR (wave-uniform: they stay in SGPRs; forcing them into VGPRs to
-     * speed up v_bitop3 issue measured 3 % SLOWER -- more VGPRs, lower clock)        */
-    struct { u32 w[4 * (NR - 2)]; } rkv;
-#pragma unroll
-    for (int i = 0; i < 4 * (NR - 2); ++i) rkv.w[i] = rk.w[12 + i];
-    u32 a_cur = 0, L0 = 0, L1 = 0, L2 = 0, L3 = 0;
-    bool have_l = false;
-    u32 parity = 0;
-
-    /* The unit of work of a wave is (chunk, m): four groups = 4 blocks per lane.
-     * Block index of (chunk, m, u, lane) = ((chunk*64 + 4*(4m+u)) << 8) - c0 [uniform]
-     *                                    + lane_blk                       [per lane].
-     * The plaintext of unit t+1 is requested before the rounds of unit t, so
-     * HBM latency hides under ~500 table lookups.                           */
-    u64 chunk = chunk_lo + blockIdx.x;
-    u32 m = 0;
-    uint4 d_cur[2], d_nxt[2];
-    if (chunk < chunk_hi) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-            d_cur[u] = (in + ((((chunk * CTRS_CHUNK) + 4u * u) << 8) - c0))[lane_blk];
+    {
+        const u32 c0 = (u32)ctr.v0 & 0xffu;
+        const u64 per_chunk = (u64)CTRS_CHUNK * 256ull;
+        ctr_edge_blocks<NR>(rk, ctr, in, out, chunk_lo * per_chunk - (chunk_lo ? c0 : 0),   /* blocks [0, pre_end) */
+                            chunk_hi * per_chunk - c0, nfull, rem, lc);                      /* blocks [suf, nfull) */
     }
-
-    while (chunk < chunk_hi) {
-        if (m == 0) {
-            if (wave < CTRS_CHUNK / 64u) {
-                /* uniform part of rounds 1 and 2 for group (chunk*CTRS_CHUNK + 64*wave + lane) */
-                const u32 gi = wave * 64u + lane;
-                const u64 g = chunk * CTRS_CHUNK + gi;
-                const u64 v = (vbase + (g << 8)) & 0x00FFFFFFFFFFFFFFull;
-                const u32 s0 = ctr.w0 ^ rk.w[0], s1 = ctr.w1 ^ rk.w[1];
-                const u32 s2 = bswap32((ctr.b8 << 24) | (u32)(v >> 32)) ^ rk.w[2];
-                const u32 s3 = (bswap32((u32)v) ^ rk.w[3]) & 0x00ffffffu;      /* byte 15 excluded */
-                const u32 A = xor3(tlook<0, 0>(s0, lc), tlook<1, 1>(s1, lc), tlook<2, 2>(s2, lc)) ^ rk.w[4];
-                const u32 c1 = xor3(xor3(tlook<0, 0>(s1, lc), tlook<1, 1>(s2, lc), tlook<2, 2>(s3, lc)), tlook<3, 3>(s0, lc), rk.w[5]);
-                const u32 c2 = xor3(xor3(tlook<0, 0>(s2, lc), tlook<1, 1>(s3, lc), tlook<2, 2>(s0, lc)), tlook<3, 3>(s1, lc), rk.w[6]);
-                const u32 c3 = xor3(xor3(tlook<0, 0>(s3, lc), tlook<1, 1>(s0, lc), tlook<2, 2>(s1, lc)), tlook<3, 3>(s2, lc), rk.w[7]);
-                const u32 u0 = xor3(tlook<1, 1>(c1, lc), tlook<2, 2>(c2, lc), tlook<3, 3>(c3, lc)) ^ rk.w[8];
-                const u32 u1 = xor3(tlook<0, 0>(c1, lc), tlook<1, 1>(c2, lc), tlook<2, 2>(c3, lc)) ^ rk.w[9];
-                const u32 u2 = xor3(tlook<0, 0>(c2, lc), tlook<1, 1>(c3, lc), tlook<3, 3>(c1, lc)) ^ rk.w[10];
-                const u32 u3 = xor3(tlook<0, 0>(c3, lc), tlook<2, 2>(c1, lc), tlook<3, 3>(c2, lc)) ^ rk.w[11];
-                buf[(parity * CTRS_CHUNK + gi) * 2 + 0] = make_uint4(u0, u1, u2, u3);
-                buf[(parity * CTRS_CHUNK + gi) * 2 + 1] = make_uint4(A, 0, 0, 0);
-            }
-            __syncthreads();
-        }
-
-        /* request the next unit's plaintext (clamped to this kernel's last chunk) */
-        u64 nchunk = chunk;
-        u32 nm = m + 1;
-        if (nm == CTRS_CHUNK / 8u) { nm = 0; nchunk += gridDim.x; }
-        {
-            const u64 lc_chunk = nchunk < chunk_hi ? nchunk : chunk;
-            const u32 lm = nchunk < chunk_hi ? nm : m;
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-                d_nxt[u] = (in + ((((lc_chunk * CTRS_CHUNK) + 4u * (lm * 2u + u)) << 8) - c0))[lane_blk];
-        }
-
-        u32 s[2][4];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const u32 gl = quad + 4u * (m * 2u + u);                   /* group within the chunk */
-            const uint4 uu = buf[(parity * CTRS_CHUNK + gl) * 2 + 0];
-            const u32 A = buf[(parity * CTRS_CHUNK + gl) * 2 + 1].x;
-            if (!have_l || A != a_cur) {                                   /* wave-uniform; ~never after the first time */
-                const u32 col0 = A ^ tlook<3, 3>(x15, lc);
-                L0 = tlook<0, 0>(col0, lc);
-                L1 = tlook<3, 3>(col0, lc);
-                L2 = tlook<2, 2>(col0, lc);
-                L3 = tlook<1, 1>(col0, lc);
-                a_cur = A;
-                have_l = true;
-            }
-            s[u][0] = L0 ^ uu.x; s[u][1] = L1 ^ uu.y; s[u][2] = L2 ^ uu.z; s[u][3] = L3 ^ uu.w;
-        }
-        enc_rounds_skewed<NR, 3>(s[0], s[1], rkv, lc);
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            (out + ((((chunk * CTRS_CHUNK) + 4u * (m * 2u + u)) << 8) - c0))[lane_blk] =
-                make_uint4(d_cur[u].x ^ s[u][0], d_cur[u].y ^ s[u][1], d_cur[u].z ^ s[u][2], d_cur[u].w ^ s[u][3]);
-            d_cur[u] = d_nxt[u];
-        }
-        if (nm == 0) parity ^= 1u;
-        chunk = nchunk;
-        m = nm;
-    }
+    CtrGeo geo;
+    geo.first = chunk_lo;
+    geo.interleaved = 0;
+    const u64 nchunks = chunk_hi - chunk_lo;
+    geo.iters = 8ull * (nchunks / gridDim.x + (blockIdx.x < nchunks % gridDim.x ? 1 : 0));
+    CtrNoFold nofold;
+    ctr_shared_loop<NR>(rk, ctr, in, out, geo, CTRS_BUF, lc, nofold);
 }
 
 /* ------------------------------------------------------------------------ */

@@ -585,6 +585,46 @@ def test_C3_xts256_sectors_device_resident(orc, golden_dir):
     assert torch.equal(dst, src)
 
 
+@pytest.mark.parametrize("bits", [128, 192, 256])
+def test_gcm_fused_encrypt_pass(orc, bits):
+    """Long GCM encryptions take the one-pass kernel (CTR + GHASH of the ciphertext in registers,
+    k_gcm_enc_fused): sizes around its thresholds (two rounds of 2^19 blocks + the head), ragged
+    tails, AAD of every shape (it becomes initial accumulator values), against the oracle and
+    against the two-pass decrypt (which re-hashes the ciphertext with the separate GHASH levels)."""
+    import torch
+    rnd = random.Random(900 + bits)
+    key, nonce = rnd.randbytes(bits // 8), rnd.randbytes(12)
+    S16 = 16 << 19                                     # one round of the grid in bytes (8 MiB)
+    cases = [(2 * S16 + 254 * 16, 0), (2 * S16 + 254 * 16 - 16, 0), (2 * S16 + 254 * 16 + 16, 5), (3 * S16 + 12345, 13),
+             (2 * S16 + 5000, 16), (5 * S16 - 1, 4096 + 7), (2 * S16 + S16 // 2, 1 << 20)]
+    for i, (n, alen) in enumerate(cases):
+        pt = orc.splitmix(1000 + i, (n + 7) // 8 * 8)[:n]
+        aad = rnd.randbytes(alen)
+        src = torch.frombuffer(bytearray(pt + bytes(16)), dtype=torch.uint8).to("cuda:0")
+        dst = torch.zeros(n + 16 + 16, dtype=torch.uint8, device="cuda:0")
+        a = torch.frombuffer(bytearray(aad), dtype=torch.uint8).to("cuda:0") if alen else None
+        uaes.gcm_encrypt_dev(key, nonce, a, src, n, dst)
+        torch.cuda.synchronize()
+        got = bytes(dst[: n + 16].cpu().numpy())
+        assert int(dst[n + 16:].sum()) == 0
+        if i < 4 or bits == 128:
+            want = orc.gcm_encrypt(key, nonce, aad, pt)
+            assert got[-16:] == want[-16:], (n, alen)
+            assert hashlib.sha256(got).digest() == hashlib.sha256(want).digest(), (n, alen)
+        status = torch.full((1,), -1, dtype=torch.int32, device="cuda:0")
+        back = torch.zeros(n + 16, dtype=torch.uint8, device="cuda:0")
+        uaes.gcm_decrypt_dev(key, nonce, a, dst, n, back, status)
+        torch.cuda.synchronize()
+        assert int(status.item()) == 0 and bytes(back[:n].cpu().numpy()) == pt, (n, alen)
+        # in place
+        work = src.clone()
+        big = torch.zeros(n + 32, dtype=torch.uint8, device="cuda:0")
+        big[:n] = work[:n]
+        uaes.gcm_encrypt_dev(key, nonce, a, big, n, big)
+        torch.cuda.synchronize()
+        assert bytes(big[: n + 16].cpu().numpy()) == got
+
+
 def test_C4_gcm128_1GiB_device_resident(orc, golden_dir):
     """BASELINE configs[3]: tag and digest of CT||tag for the 1 GiB message."""
     import torch
