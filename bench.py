@@ -345,12 +345,16 @@ def main():
         kern_ms = sum(per_step_ms) / len(per_step_ms)
         algo_bytes = 2.0 * n                       # read n + write n per launch
         achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
-        traffic = None
+        # HBM bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE need their own
+        # runs under the profiler, tools/profile.sh); this run cannot measure them itself, so the
+        # line names where the figure was taken from.
+        traffic, traffic_source = None, None
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
                 t = json.load(f).get(a.workload)
             if t and t["bytes_per_gpu"] == n:
-                traffic = t["traffic_bytes"]          # PMC pass of the same command, per launch
+                traffic = t["traffic_bytes"]
+                traffic_source = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, recorded in %s (not measured in this run)" % t["source"]
         except Exception:
             pass
         names = {"ctr": "AES-128-CTR", "ecb": "AES-128-ECB", "xts": "AES-256-XTS 4 KiB sectors", "gcm": "AES-128-GCM",
@@ -369,6 +373,7 @@ def main():
                        "parallelism": "shard%d" % world, "bytes_per_gpu": n},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_source": traffic_source,
                          "algorithmic_bytes": int(algo_bytes),
                          "kernel_ms": round(kern_ms, 4),
                          "kernel_ms_min": round(min(per_step_ms), 4),
