@@ -98,28 +98,22 @@ __device__ __forceinline__ void ctr_edge_blocks(const uaesk_rk &rk, const uaesk_
  * ITERATION of the workgroup covers 8 consecutive groups (2048 blocks): quad q
  * takes groups q and q+4 of them, two blocks per lane, half a round out of phase
  * (enc_rounds_skewed), so each wave-level load/store is one contiguous 1 KiB
- * segment.  Which 8 groups iteration `it` of workgroup b takes is the GEOMETRY:
- *
- *   chunked     64-group chunks dealt round-robin: chunk = chunk_lo + b + grid*(it/8),
- *               groups 64*chunk + 8*(it%8) ...            (the CTR kernel)
- *   interleaved 8-group stripes dealt round-robin: groups g_lo + 8*(b + grid*it) ...
- *               Block (b, it, q, u, p) then sits at  j + S*it  with the lane index
- *               j = 2048 b + 256 (q + 4u) + p and S = 2048 grid: exactly the strided
- *               Horner layout of GHASH, so a lane can fold its own ciphertext
- *               blocks as it produces them (the fused GCM kernel).
+ * segment.  The 8-group stripes are dealt round-robin: iteration `it` of workgroup b
+ * takes groups g_lo + 8*(b + grid*it) ...  Block (b, it, q, u, p) then sits at  j + S*it
+ * with the lane index j = 2048 b + 256 (q + 4u) + p and S = 2048 grid: exactly the strided
+ * Horner layout of GHASH, so a lane can fold its own ciphertext blocks as it produces them
+ * (the fused GCM kernel), and every workgroup gets floor or ceil of stripes/grid stripes.
  *
  * U-buffer: the uniform parts of the next 8 iterations (64 groups), double buffered,
  * one s_barrier per 8 iterations.                                                */
 struct CtrGeo {
-    u64 first;          /* chunked: chunk_lo;  interleaved: g_lo (first group)        */
-    u64 iters;          /* iterations of THIS workgroup                               */
-    u32 interleaved;
+    u64 first;          /* g_lo: first group of the striped region                    */
+    u64 iters;          /* iterations (stripes) of THIS workgroup                     */
 };
 
 __device__ __forceinline__ u64 ctr_geo_group0(const CtrGeo &g, u64 it)
 {
-    if (g.interleaved) return g.first + 8ull * ((u64)blockIdx.x + (u64)gridDim.x * it);
-    return 64ull * (g.first + blockIdx.x + (u64)gridDim.x * (it >> 3)) + 8ull * (it & 7);
+    return g.first + 8ull * ((u64)blockIdx.x + (u64)gridDim.x * it);
 }
 
 /* FOLD: functor called once per iteration with the two ciphertext blocks of this lane

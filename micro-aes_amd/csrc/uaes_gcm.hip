@@ -535,7 +535,6 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_enc_fused(uaesk_rk rk, uaesk_ta
     CtrGeo geo;
     geo.first = g_lo;
     geo.iters = iters;
-    geo.interleaved = 1;
     ctr_shared_loop<NR>(rk, ctr, in, out, geo, GF_LDS_BUF, lc, fold);
     accs[j[0]] = fold.acc[0];
     accs[j[1]] = fold.acc[1];

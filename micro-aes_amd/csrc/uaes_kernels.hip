@@ -130,31 +130,29 @@ __global__ __launch_bounds__(UAES_WG, 4) void k_ctr(uaesk_rk rk, uaesk_tables tb
 #define CTRS_BUF   (UAES_LDS_ENC)            /* 2 x 64 x 32 B after the tables */
 #define UAES_LDS_CTRS (UAES_LDS_ENC + 2u * CTRS_CHUNK * 32u)
 
-/* The shared-round CTR kernel (uaes_ctr.hip.h, chunked geometry): the hot loop handles
- * only chunks [chunk_lo, chunk_hi) that lie completely inside the stream, so it has no
- * bounds checks; the blocks before and after them (up to block nfull) and a byte tail
- * run in the prologue.  A lock-step four-block version measured 4 % slower
- * (profiles/r01_sweep_ctr_variants.log).                                            */
+/* The shared-round CTR kernel (uaes_ctr.hip.h): the hot loop handles only whole 8-group
+ * stripes (2048 blocks, 32 KiB) that lie completely inside the stream, so it has no bounds
+ * checks; the blocks before and after them (up to block nfull) and a byte tail run in the
+ * prologue.  The stripes are dealt round-robin over the workgroups, so every workgroup gets
+ * floor or ceil of stripes/grid and the kernel's time follows the text size in 32 KiB steps
+ * (round 1 dealt 256 KiB chunks: 80 MiB ran 10 % slower than 64 MiB,
+ * profiles/r02_ctr_size_sweep_stripes_vs_chunks.log).  A lock-step four-block version
+ * measured 4 % slower (profiles/r01_sweep_ctr_variants.log).                            */
 template <int NR>
 __global__ __launch_bounds__(UAES_WG, 4) void k_ctr_shared2(uaesk_rk rk, uaesk_tables tb, uaesk_ctr ctr,
                                                            const uint4 *in, uint4 *out,
-                                                           u64 chunk_lo, u64 chunk_hi, u64 nfull, u32 rem,
+                                                           u64 g_lo, u64 stripes, u64 nfull, u32 rem,
                                                            const int *__restrict__ gate)
 {
     if (gate && *gate != 0) return;
     fill_enc_tables(tb.te0);
     const LaneConst lc = make_lane_const();
-    {
-        const u32 c0 = (u32)ctr.v0 & 0xffu;
-        const u64 per_chunk = (u64)CTRS_CHUNK * 256ull;
-        ctr_edge_blocks<NR>(rk, ctr, in, out, chunk_lo * per_chunk - (chunk_lo ? c0 : 0),   /* blocks [0, pre_end) */
-                            chunk_hi * per_chunk - c0, nfull, rem, lc);                      /* blocks [suf, nfull) */
-    }
+    const u32 c0 = (u32)ctr.v0 & 0xffu;
     CtrGeo geo;
-    geo.first = chunk_lo;
-    geo.interleaved = 0;
-    const u64 nchunks = chunk_hi - chunk_lo;
-    geo.iters = 8ull * (nchunks / gridDim.x + (blockIdx.x < nchunks % gridDim.x ? 1 : 0));
+    geo.first = g_lo;
+    geo.iters = stripes / gridDim.x + (blockIdx.x < stripes % gridDim.x ? 1 : 0);
+    ctr_edge_blocks<NR>(rk, ctr, in, out, g_lo * 256 - (g_lo ? c0 : 0),              /* blocks [0, pre_end) */
+                        (g_lo + 8 * stripes) * 256 - c0, nfull, rem, lc);           /* blocks [suf, nfull) */
     CtrNoFold nofold;
     ctr_shared_loop<NR>(rk, ctr, in, out, geo, CTRS_BUF, lc, nofold);
 }
@@ -577,43 +575,24 @@ static int launch_ctr_v(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *
     return launch_ctr_u<NR, U>(st, tb, ek, ctr, in, out, len, gate);
 }
 
-/* Shared-round kernel: whole 64-group chunks in the pipelined main loop, the
- * ragged prefix/suffix and the byte tail in its prologue (ctr_edges).        */
+/* Shared-round kernel: whole 8-group stripes in the pipelined main loop, the ragged
+ * prefix/suffix and the byte tail in its prologue.  Below one and a half grids of stripes
+ * (12 MiB on MI355X) the generic kernel's one-block work items spread better
+ * (profiles/r02_ctr_size_sweep_stripes_vs_chunks.log: 8 MiB 637 vs 598 GiB/s).          */
 template <int NR>
 static int launch_ctr_shared(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek, const uaesk_ctr *ctr,
                              const void *in, void *out, size_t len, const int *gate)
 {
     const u64 nfull = len / 16;
-    const u64 per_chunk = (u64)CTRS_CHUNK * 256;
     const u32 c0 = (u32)ctr->v0 & 0xffu;
-    const u64 chunk_lo = c0 ? 1 : 0;
-    u64 chunk_hi = (c0 + nfull) / per_chunk;
-    /* The kernel's time is quantised: every workgroup walks whole 256 KiB chunks, one round
-     * of `grid` chunks takes t_r however many of them exist.  A last round that is at least
-     * ~70 % full is worth it; otherwise only the whole rounds go here and what is left
-     * (fewer than 0.7 grid chunks and the ragged end) takes the generic kernel, whose work
-     * items are single blocks at ~0.76 of this kernel's rate (16 MiB: 0.042 -> 0.018 ms).  */
     const unsigned grid = grid_for(~0ull, 1);
-    const u64 nchunks = chunk_hi > chunk_lo ? chunk_hi - chunk_lo : 0;
-    const bool all_here = (nchunks % grid) * 10 >= (u64)grid * 7;
-    const u64 rounds = nchunks / grid + (all_here ? 1 : 0);
-    if (rounds == 0)
-        return launch_ctr_v<NR, 4>(st, tb, ek, ctr, in, out, len, gate);
-    if (!all_here) chunk_hi = chunk_lo + rounds * grid;
-    /* blocks [0, head) and, when everything runs here, the byte tail; the rest below */
-    const u64 head = all_here ? nfull : chunk_hi * per_chunk - c0;
-    const u32 tail_bytes = all_here ? (u32)(len % 16) : 0u;
-
+    const u64 g_lo = c0 ? 1 : 0, groups = (c0 + nfull) / 256;
+    const u64 n8 = groups > g_lo ? (groups - g_lo) / 8 : 0;
+    if (n8 * 2 < (u64)grid * 3) return launch_ctr_v<NR, 4>(st, tb, ek, ctr, in, out, len, gate);
     hipError_t e = set_lds(k_ctr_shared2<NR>, UAES_LDS_CTRS);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL((k_ctr_shared2<NR>), dim3(grid), dim3(UAES_WG), UAES_LDS_CTRS, st, *ek, *tb, *ctr,
-                       (const uint4 *)in, (uint4 *)out, chunk_lo, chunk_hi, head, tail_bytes, gate);
-    if (!all_here && head * 16 < len) {
-        uaesk_ctr rest = *ctr;
-        rest.v0 = (ctr->v0 + head) & 0x00ffffffffffffffull;        /* 56-bit counter (N2) */
-        return launch_ctr_v<NR, 4>(st, tb, ek, &rest, (const unsigned char *)in + head * 16,
-                                      (unsigned char *)out + head * 16, len - head * 16, gate);
-    }
+                       (const uint4 *)in, (uint4 *)out, g_lo, n8, nfull, (u32)(len % 16), gate);
     return (int)hipGetLastError();
 }
 
