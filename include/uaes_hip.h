@@ -164,7 +164,10 @@ int uaes_ccm_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
  * blocks are always swapped, len < 16 -> UAES_E_DATALENGTH), :799-845 (CFB),
  * :861-893 (OFB; decrypt is the same function).  iVec = 16 bytes.  The
  * decrypt directions of CBC and CFB are block-parallel kernels; the encrypt
- * directions and OFB are serial chains walked by one GPU lane (~10 MB/s).     */
+ * directions and OFB are serial chains: one wave walks the chain, the four lanes of a
+ * quad share each block encryption (~0.8 us per block, latency-bound: a single stream
+ * is slower than the reference's CPU loop -- use the *_batch calls below when there
+ * are many independent messages).                                                */
 int uaes_cbc_encrypt(int keybits, const uint8_t *key, const uint8_t *iVec,
                      const void *pntxt, size_t ptextLen, void *crtxt);
 int uaes_cbc_decrypt(int keybits, const uint8_t *key, const uint8_t *iVec,
@@ -175,6 +178,17 @@ int uaes_cfb_decrypt(int keybits, const uint8_t *key, const uint8_t *iVec,
                      const void *crtxt, size_t crtxtLen, void *pntxt);
 int uaes_ofb_xcrypt(int keybits, const uint8_t *key, const uint8_t *iVec,
                     const void *in, size_t len, void *out);
+
+/* Batches of INDEPENDENT chains, one GPU lane per message -- where a GPU serves the serial
+ * modes well.  nmsg messages of msg_bytes each, stored back to back (message m at
+ * m * msg_bytes).  uaes_cbc_encrypt_batch: crtxt[m] = AES_CBC_encrypt(key, ivs + 16 m, message
+ * m) bit for bit, CS3 swap included; msg_bytes must be a multiple of 16.  uaes_cmac_batch:
+ * macs + 16 m = AES_CMAC(key, message m), any msg_bytes.  Data pointers host or device; ivs
+ * host, or 16-byte aligned device memory.                                              */
+int uaes_cbc_encrypt_batch(int keybits, const uint8_t *key, const uint8_t *ivs, size_t nmsg,
+                           size_t msg_bytes, const void *pntxt, void *crtxt);
+int uaes_cmac_batch(int keybits, const uint8_t *key, size_t nmsg, size_t msg_bytes,
+                    const void *data, uint8_t *macs);
 
 /* ---- GCM-SIV: replaces GCM_SIV_encrypt / GCM_SIV_decrypt ---------------------
  * RFC 8452; micro_aes.c:1418-1516.  12-byte nonce, 16-byte tag appended.  Per-

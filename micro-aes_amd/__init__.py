@@ -41,7 +41,7 @@ EXPORTS = [
     "uaes_ocb_encrypt", "uaes_ocb_decrypt", "uaes_ocb_dev",
     "uaes_mgpu_ctr_xcrypt_at", "uaes_mgpu_xts_sectors",
     "uaes_gcm_stream_begin", "uaes_gcm_stream_update", "uaes_gcm_stream_finish", "uaes_gcm_stream_abort",
-    "uaes_cbc_encrypt", "uaes_cbc_decrypt", "uaes_cfb_encrypt", "uaes_cfb_decrypt", "uaes_ofb_xcrypt",
+    "uaes_cbc_encrypt_batch", "uaes_cmac_batch", "uaes_cbc_encrypt", "uaes_cbc_decrypt", "uaes_cfb_encrypt", "uaes_cfb_decrypt", "uaes_ofb_xcrypt",
     "uaes_ecb_dev", "uaes_ctr_xcrypt_at_dev", "uaes_xts_sectors_dev",
     "uaes_gcm_encrypt_dev", "uaes_gcm_decrypt_dev", "uaes_gcm_partial_dev",
 ]
@@ -99,6 +99,8 @@ def engine():
     for n in ("uaes_ecb_encrypt", "uaes_ecb_decrypt"):
         getattr(L, n).argtypes = [i, vp, vp, sz, vp]
     L.uaes_stream_release.argtypes = [vp]
+    L.uaes_cbc_encrypt_batch.argtypes = [i, vp, vp, sz, sz, vp, vp]
+    L.uaes_cmac_batch.argtypes = [i, vp, sz, sz, vp, vp]
     L.uaes_ecb_encrypt_padded.argtypes = [i, vp, i, vp, sz, vp]
     L.uaes_ctr_xcrypt.argtypes = [i, vp, vp, vp, sz, vp]
     L.uaes_ctr_xcrypt_at.argtypes = [i, vp, vp, u64, vp, sz, vp]
@@ -267,6 +269,35 @@ def AES_CBC_encrypt(key, iVec, pntxt, prefill=0):
 def AES_CBC_decrypt(key, iVec, crtxt, prefill=0):
     """micro_aes.c:746."""
     return _fb(engine().uaes_cbc_decrypt, "AES_CBC_decrypt", key, iVec, crtxt, prefill)
+
+
+def cbc_encrypt_batch(key, ivs, messages):
+    """Independent CBC chains, one GPU lane each: == [AES_CBC_encrypt(key, iv, m)[1] for iv, m in ...]."""
+    n = len(messages)
+    if n == 0:
+        return []
+    size = len(messages[0])
+    if any(len(m) != size for m in messages) or len(ivs) != n or any(len(v) != 16 for v in ivs):
+        raise ValueError("equal-sized messages and one 16-byte IV per message")
+    o = _out(n * size)
+    _check(engine().uaes_cbc_encrypt_batch(_bits(key), _in(key), _in(b"".join(ivs)), n, size,
+                                           _in(b"".join(messages)), o), "uaes_cbc_encrypt_batch")
+    raw = bytes(o)
+    return [raw[i * size:(i + 1) * size] for i in range(n)]
+
+
+def cmac_batch(key, messages):
+    """Independent CMACs, one GPU lane each: == [AES_CMAC(key, m) for m in messages]."""
+    n = len(messages)
+    if n == 0:
+        return []
+    size = len(messages[0])
+    if any(len(m) != size for m in messages):
+        raise ValueError("equal-sized messages")
+    o = _out(n * 16)
+    _check(engine().uaes_cmac_batch(_bits(key), _in(key), n, size, _in(b"".join(messages)), o), "uaes_cmac_batch")
+    raw = bytes(o)
+    return [raw[16 * i:16 * i + 16] for i in range(n)]
 
 
 def AES_CFB_encrypt(key, iVec, pntxt):

@@ -401,4 +401,78 @@ __device__ __forceinline__ void dec_blocks(u32 (&s)[U][4], const uaesk_rk &dk, c
     rounds_from<NR, U, 1, true>(s, dk, lc);
 }
 
+/* ---- one block at a time, four lanes per block (the serial chains) ---------------- */
+/* CBC/CFB encryption, OFB and the CBC-MACs are chains: block i+1 cannot start before block i
+ * is done, so what counts is the LATENCY of one block.  One lane alone issues 16 address
+ * computations + 16 lookups + 8 combines per round (~250 cycles); here the four lanes of a
+ * quad share the block: lane c computes output column c (4 lookups), then the quad exchanges
+ * the four new columns with three DPP quad_perm moves.  Every lane keeps the state as a
+ * ROTATED VIEW (w0..w3 = columns c, c+1, c+2, c+3), which is exactly what its four lookups
+ * need (row r comes from column c+r) and what the quad_perm rotations deliver, so no
+ * per-lane register indexing is needed.  The callers keep a plain replicated block in all
+ * lanes: entry = AddRoundKey(0) + 12 selects, exit = 4 quad broadcasts.
+ *
+ * Tables: the 128 KiB layout with only slots 0..3 filled (4 KiB of stores by one wave instead
+ * of 128 KiB by sixteen): lane c reads slot c, so the quad's four lookups never conflict and
+ * the other fifteen quads of the wave, which run the same data redundantly, broadcast.
+ * Round keys live in LDS after the table region (lane c needs word 4r + c of round r).   */
+#define UAES_LDS_QUAD  (UAES_LDS_ENC + 256u)          /* tables + 60 key words */
+
+__device__ __forceinline__ void quad_fill_tables(const u32 *__restrict__ t0, const uaesk_rk &rk)
+{
+    for (u32 i = threadIdx.x; i < 1024u; i += blockDim.x) {
+        const u32 x = i & 255u, k = i >> 8;
+        const u32 v = rotl32(t0[x], 8u * k);
+        *(uint4 *)(uaes_lds + x * 256u + (k & 1u) * 128u + (k >> 1) * 65536u) = make_uint4(v, v, v, v);
+    }
+    for (u32 i = threadIdx.x; i < 60u; i += blockDim.x) ((u32 *)(uaes_lds + UAES_LDS_ENC))[i] = rk.w[i];
+    __syncthreads();
+}
+
+__device__ __forceinline__ LaneConst quad_lane_const()
+{
+    LaneConst lc;
+    const u32 slot = (threadIdx.x & 3u) << 2;
+#pragma unroll
+    for (u32 k = 0; k < 4; ++k) lc.t[k] = slot | ((k & 1u) << 7) | ((k >> 1) << 16);
+    lc.m1 = 0x0000ff00u;
+    asm volatile("" : "+v"(lc.m1));
+    return lc;
+}
+
+template <int CTRL>
+__device__ __forceinline__ u32 quad_perm(u32 v)
+{
+    return (u32)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, true);
+}
+
+/* t = the block (replicated in the quad's four lanes) -> its encryption, replicated again */
+template <int NR>
+__device__ __forceinline__ void quad_encrypt(u32 (&t)[4], const uaesk_rk &rk, const LaneConst &lc)
+{
+    const u32 c = threadIdx.x & 3u;
+    const u32 kaddr = UAES_LDS_ENC + 4u * c;                    /* + 16 r: this lane's word of round key r */
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t[j] ^= rk.w[j];
+    /* rotated view: w[k] = column (c + k) mod 4 */
+    u32 w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const u32 a = t[k], b = t[(k + 1) & 3], cc = t[(k + 2) & 3], d = t[(k + 3) & 3];
+        w[k] = c == 0 ? a : c == 1 ? b : c == 2 ? cc : d;
+    }
+#pragma unroll
+    for (int r = 1; r < NR; ++r) {
+        const u32 key = lds_word(kaddr + 16u * r);
+        const u32 n = xor3(xor3(tlook<0, 0>(w[0], lc), tlook<1, 1>(w[1], lc), tlook<2, 2>(w[2], lc)),
+                           tlook<3, 3>(w[3], lc), key);
+        w[0] = n; w[1] = quad_perm<0x39>(n); w[2] = quad_perm<0x4E>(n); w[3] = quad_perm<0x93>(n);
+    }
+    const u32 key = lds_word(kaddr + 16u * NR);
+    const u32 lo = __builtin_amdgcn_perm(tlook<3, 1>(w[1], lc), tlook<2, 0>(w[0], lc), 0x0c0c0500u);
+    const u32 hi = __builtin_amdgcn_perm(tlook<1, 3>(w[3], lc), tlook<0, 2>(w[2], lc), 0x07020c0cu);
+    const u32 n = or_xor(lo, hi, key);
+    t[0] = quad_perm<0x00>(n); t[1] = quad_perm<0x55>(n); t[2] = quad_perm<0xAA>(n); t[3] = quad_perm<0xFF>(n);
+}
+
 #endif

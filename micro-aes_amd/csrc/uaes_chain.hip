@@ -78,7 +78,7 @@ __global__ __launch_bounds__(UAES_WG) void k_fb_dec(uaesk_rk rk, uaesk_tables tb
 }
 
 /* ------------------------------------------------------------------------ */
-/* serial directions: one lane                                                */
+/* serial directions: one wave, a quad of lanes per block encryption          */
 /* ------------------------------------------------------------------------ */
 struct Blk {
     u32 w[4];
@@ -98,6 +98,7 @@ __device__ __forceinline__ Blk ldb(const unsigned char *p, u32 nbytes)        /*
 
 __device__ __forceinline__ void stb(unsigned char *p, const Blk &b, u32 nbytes)
 {
+    if (threadIdx.x != 0) return;                  /* every lane holds the same block: one stores */
     if (nbytes >= 16 && (((uintptr_t)p) & 15u) == 0) {
         *(uint4 *)p = make_uint4(b.w[0], b.w[1], b.w[2], b.w[3]);
         return;
@@ -110,12 +111,12 @@ __device__ __forceinline__ void xb(Blk &a, const Blk &b)
     a.w[0] ^= b.w[0]; a.w[1] ^= b.w[1]; a.w[2] ^= b.w[2]; a.w[3] ^= b.w[3];
 }
 
+/* one block, shared by the four lanes of a quad (quad_encrypt, uaes_aes.hip.h); every lane of
+ * the wave holds the same block before and after                                          */
 template <int NR>
 __device__ __forceinline__ void encb(Blk &b, const uaesk_rk &rk, const LaneConst &lc)
 {
-    u32 s[1][4] = { { b.w[0], b.w[1], b.w[2], b.w[3] } };
-    enc_blocks<NR, 1>(s, rk, lc);
-    b.w[0] = s[0][0]; b.w[1] = s[0][1]; b.w[2] = s[0][2]; b.w[3] = s[0][3];
+    quad_encrypt<NR>(b.w, rk, lc);
 }
 
 template <int NR>
@@ -156,9 +157,18 @@ __global__ __launch_bounds__(UAES_WG) void k_chain_serial(uaesk_rk rk, uaesk_tab
                                                           const unsigned char *in,
                                                           unsigned char *out, u64 len)
 {
-    if (OP == CH_CBC_DEC_CTS) fill_dec_tables(tb.td0); else fill_enc_tables(tb.te0);
-    if (threadIdx.x != 0) return;
-    const LaneConst lc = make_lane_const();
+    /* encrypt-direction chains: ONE wave, all 64 lanes run the chain redundantly (a quad shares
+     * each block encryption), lane 0 stores.  The two-block CTS decrypt keeps the one-lane
+     * inverse cipher on the full tables (launched with 1024 threads to fill them).          */
+    LaneConst lc;
+    if (OP == CH_CBC_DEC_CTS) {
+        fill_dec_tables(tb.td0);
+        if (threadIdx.x != 0) return;
+        lc = make_lane_const();
+    } else {
+        quad_fill_tables(tb.te0, rk);
+        lc = quad_lane_const();
+    }
     if (iv_dev) iv4 = *iv_dev;
     Blk iv = { { iv4.x, iv4.y, iv4.z, iv4.w } };
 
@@ -220,6 +230,73 @@ __global__ __launch_bounds__(UAES_WG) void k_chain_serial(uaesk_rk rk, uaesk_tab
 }
 
 /* ------------------------------------------------------------------------ */
+/* batches of independent chains: one lane per message                         */
+/* ------------------------------------------------------------------------ */
+/* A chain is serial, a batch of chains is not: nmsg messages of msg_blocks whole blocks each
+ * (message m at byte m * msg_blocks * 16, its IV at ivs + 16 m), every lane walks one of them
+ * through the full tables.  MAC = false: AES_CBC_encrypt of every message (:697-744; a
+ * message of two or more blocks ends in the CS3 swap of its last two ciphertext blocks, as a
+ * single call on it does).  MAC = true: AES_CMAC of every message (:1108-1118), msg_bytes
+ * need not be a multiple of 16; macs receive 16 bytes each.                               */
+template <int NR, bool MAC>
+__global__ __launch_bounds__(UAES_WG) void k_chain_batch(uaesk_rk rk, uaesk_tables tb, const uint4 *__restrict__ ivs,
+                                                         u64 nmsg, u64 msg_bytes,
+                                                         const unsigned char *in, unsigned char *out)
+{
+    fill_enc_tables(tb.te0);
+    const LaneConst lc = make_lane_const();
+    const u64 nb = msg_bytes / 16;
+    Blk k1 = { { 0, 0, 0, 0 } }, k2 = k1;
+    if (MAC) {                                               /* subkeys K1 = 2L, K2 = 4L (getSubkeys :593-605) */
+        u32 s[1][4] = { { 0, 0, 0, 0 } };
+        enc_blocks<NR, 1>(s, rk, lc);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            u64 hi = ((u64)bswap32(s[0][0]) << 32) | bswap32(s[0][1]), lo = ((u64)bswap32(s[0][2]) << 32) | bswap32(s[0][3]);
+            const u64 carry = hi >> 63;
+            hi = (hi << 1) | (lo >> 63);
+            lo = (lo << 1) ^ (carry ? 0x87ull : 0ull);
+            s[0][0] = bswap32((u32)(hi >> 32)); s[0][1] = bswap32((u32)hi);
+            s[0][2] = bswap32((u32)(lo >> 32)); s[0][3] = bswap32((u32)lo);
+            Blk &k = q ? k2 : k1;
+            k.w[0] = s[0][0]; k.w[1] = s[0][1]; k.w[2] = s[0][2]; k.w[3] = s[0][3];
+        }
+    }
+    for (u64 m = (u64)blockIdx.x * UAES_WG + threadIdx.x; m < nmsg; m += (u64)gridDim.x * UAES_WG) {
+        const unsigned char *src = in + m * msg_bytes;
+        u32 s[1][4] = { { 0, 0, 0, 0 } };
+        if (!MAC) {
+            const uint4 iv = ivs[m];
+            s[0][0] = iv.x; s[0][1] = iv.y; s[0][2] = iv.z; s[0][3] = iv.w;
+            uint4 *dst = (uint4 *)(out + m * msg_bytes);
+            uint4 prev = iv;
+            for (u64 i = 0; i < nb; ++i) {
+                const uint4 x = ((const uint4 *)src)[i];
+                s[0][0] ^= x.x; s[0][1] ^= x.y; s[0][2] ^= x.z; s[0][3] ^= x.w;
+                enc_blocks<NR, 1>(s, rk, lc);
+                const uint4 c = make_uint4(s[0][0], s[0][1], s[0][2], s[0][3]);
+                if (nb > 1 && i == nb - 1) { dst[i - 1] = c; dst[i] = prev; }      /* CS3: the last two swap (:706, :738-742) */
+                else if (nb == 1 || i < nb - 2) dst[i] = c;
+                prev = c;
+            }
+        } else {
+            const u32 last = msg_bytes ? (u32)((msg_bytes - 1) % 16) + 1 : 0;     /* size of the last block */
+            const u64 full = (msg_bytes - last) / 16;
+            for (u64 i = 0; i < full; ++i) {
+                const Blk x = ldb(src + 16 * i, 16);
+                s[0][0] ^= x.w[0]; s[0][1] ^= x.w[1]; s[0][2] ^= x.w[2]; s[0][3] ^= x.w[3];
+                enc_blocks<NR, 1>(s, rk, lc);
+            }
+            Blk l = ldb(src + 16 * full, last);
+            if (last < 16) { l.w[last >> 2] ^= 0x80u << (8 * (last & 3)); xb(l, k2); } else xb(l, k1);
+            s[0][0] ^= l.w[0]; s[0][1] ^= l.w[1]; s[0][2] ^= l.w[2]; s[0][3] ^= l.w[3];
+            enc_blocks<NR, 1>(s, rk, lc);
+            ((uint4 *)out)[m] = make_uint4(s[0][0], s[0][1], s[0][2], s[0][3]);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------ */
 /* launchers                                                                  */
 /* ------------------------------------------------------------------------ */
 #define DISPATCH_NR(nr, CALL)                         \
@@ -266,12 +343,39 @@ template <int NR, int OP>
 static int launch_serial(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *k, uint4 iv,
                          const void *in, void *out, u64 len, const uint4 *iv_dev = nullptr)
 {
-    const unsigned lds = OP == CH_CBC_DEC_CTS ? UAES_LDS_DEC : UAES_LDS_ENC;
+    const unsigned lds = OP == CH_CBC_DEC_CTS ? UAES_LDS_DEC : UAES_LDS_QUAD;
+    const unsigned threads = OP == CH_CBC_DEC_CTS ? UAES_WG : 64u;
     hipError_t e = hipFuncSetAttribute((const void *)k_chain_serial<NR, OP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((k_chain_serial<NR, OP>), dim3(1), dim3(UAES_WG), lds, st, *k, *tb, iv, iv_dev,
+    hipLaunchKernelGGL((k_chain_serial<NR, OP>), dim3(1), dim3(threads), lds, st, *k, *tb, iv, iv_dev,
                        (const unsigned char *)in, (unsigned char *)out, len);
     return (int)hipGetLastError();
+}
+
+template <int NR, bool MAC>
+static int launch_batch(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *k, const void *ivs,
+                        u64 nmsg, u64 msg_bytes, const void *in, void *out)
+{
+    hipError_t e = hipFuncSetAttribute((const void *)k_chain_batch<NR, MAC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)UAES_LDS_ENC);
+    if (e != hipSuccess) return (int)e;
+    u64 want = (nmsg + UAES_WG - 1) / UAES_WG;
+    const unsigned grid = (unsigned)(want < cu_count() ? (want ? want : 1) : cu_count());
+    hipLaunchKernelGGL((k_chain_batch<NR, MAC>), dim3(grid), dim3(UAES_WG), UAES_LDS_ENC, st, *k, *tb,
+                       (const uint4 *)ivs, nmsg, msg_bytes, (const unsigned char *)in, (unsigned char *)out);
+    return (int)hipGetLastError();
+}
+
+/* mac == 0: CBC encrypt of nmsg messages of msg_bytes (a multiple of 16, >= 16) each, IVs at ivs (device);
+ * mac != 0: CMAC of nmsg messages of msg_bytes each into out (16 bytes per message)          */
+extern "C" int uaesk_chain_batch(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek, int mac,
+                                 const void *ivs, size_t nmsg, size_t msg_bytes, const void *in, void *out)
+{
+    if (nmsg == 0) return 0;
+    if (!mac && (msg_bytes < 16 || msg_bytes % 16)) return (int)hipErrorInvalidValue;
+    if (mac) { DISPATCH_NR(nr, return (launch_batch<NR, true>(S(stream), tb, ek, nullptr, nmsg, msg_bytes, in, out))); }
+    else     { DISPATCH_NR(nr, return (launch_batch<NR, false>(S(stream), tb, ek, ivs, nmsg, msg_bytes, in, out))); }
+    return 0;
 }
 
 /* mode: 0 CBC encrypt, 1 CBC decrypt, 2 CFB encrypt, 3 CFB decrypt, 4 OFB.

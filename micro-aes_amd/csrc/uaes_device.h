@@ -127,6 +127,12 @@ int uaesk_feedback(void *stream, const uaesk_tables *tb, int nr,
                    const uaesk_rk *ek, const uaesk_rk *dk, int mode, const uint8_t *iv16,
                    const void *in, size_t len, void *out);
 
+/* Batches of independent serial chains, one lane per message (all device pointers).
+ * mac == 0: AES_CBC_encrypt (CS3) of nmsg messages of msg_bytes (multiple of 16) each, message m
+ * at in + m*msg_bytes with IV ivs[m]; mac != 0: AES_CMAC of each message into out + 16 m.    */
+int uaesk_chain_batch(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek, int mac,
+                      const void *ivs, size_t nmsg, size_t msg_bytes, const void *in, void *out);
+
 /* OCB (AES_OCB_encrypt/decrypt, micro_aes.c:1693-1811): 12-byte nonce (host), 16-byte
  * tag at out+len (encrypt) / read at in+len (decrypt, *status = 0 / 0x1A; the text
  * is written either way, as in the reference).  dk = equivalent-inverse keys.  */

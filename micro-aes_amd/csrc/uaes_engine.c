@@ -1068,6 +1068,53 @@ int uaes_ofb_xcrypt(int keybits, const uint8_t *key, const uint8_t *iVec,
 }
 
 /* ------------------------------------------------------------------------ */
+/* batches of independent chains (one GPU lane per message)                     */
+/* ------------------------------------------------------------------------ */
+static int batch_common(int keybits, const uint8_t *key, int mac, const uint8_t *ivs, size_t nmsg,
+                        size_t msg_bytes, const void *in, void *out)
+{
+    context *c;
+    keysched ks;
+    io_plan io;
+    const void *d_ivs = NULL;
+    int rc;
+    const size_t total = nmsg * msg_bytes, out_len = mac ? nmsg * 16 : total;
+    if ((rc = expand_key(&ks, key, keybits)) != 0) return rc;
+    if (!mac && (msg_bytes < 16 || msg_bytes % 16))
+        return fail(UAES_E_ARG, "batched CBC: every message must be a whole number of blocks (got %zu bytes)", msg_bytes);
+    if (msg_bytes && nmsg > (size_t)-1 / msg_bytes) return fail(UAES_E_ARG, "batch size overflows");
+    if (nmsg == 0) return 0;
+    if ((total && !in) || !out || (!mac && !ivs)) return fail(UAES_E_ARG, "NULL pointer");
+    if ((rc = get_context(&c)) != 0) return rc;
+    LOCKED_BEGIN(c);
+    do {
+        if (!mac && (rc = stage_aad(c, ivs, nmsg * 16, &d_ivs)) != 0) break;     /* host IVs -> device */
+        if (!mac && (((uintptr_t)d_ivs) & 15u)) { rc = fail(UAES_E_ARG, "device IV array must be 16-byte aligned"); break; }
+        if ((rc = plan_io(c, in, total, out, out_len, &io)) != 0) break;
+        if (mac && io.dout == io.din && io.copy_back) {          /* MACs must not overwrite unread messages */
+            if (grow(&c->stage[1], &c->stage_cap[1], out_len + 64)) { rc = UAES_E_HIP; break; }
+            io.dout = c->stage[1];
+        }
+        int k = uaesk_chain_batch(NULL, &c->tb, ks.nr, &ks.ek, mac, d_ivs, nmsg, msg_bytes, io.din, io.dout);
+        if (k) { rc = fail(UAES_E_HIP, "batch launch: %s", hipGetErrorString((hipError_t)k)); break; }
+        rc = finish_io(&io, out_len);
+    } while (0);
+    LOCKED_END(c, rc);
+}
+
+int uaes_cbc_encrypt_batch(int keybits, const uint8_t *key, const uint8_t *ivs, size_t nmsg,
+                           size_t msg_bytes, const void *pntxt, void *crtxt)
+{
+    return batch_common(keybits, key, 0, ivs, nmsg, msg_bytes, pntxt, crtxt);
+}
+
+int uaes_cmac_batch(int keybits, const uint8_t *key, size_t nmsg, size_t msg_bytes,
+                    const void *data, uint8_t *macs)
+{
+    return batch_common(keybits, key, 1, NULL, nmsg, msg_bytes, data, macs);
+}
+
+/* ------------------------------------------------------------------------ */
 /* GCM-SIV (RFC 8452; micro_aes.c:1418-1516)          */
 /* ------------------------------------------------------------------------ */
 /* Host orchestration only: every AES block (key derivation, tag encryption, the

@@ -7,11 +7,10 @@
  *   k_ccm_tag  <- CCMtag :1222-1256 (used by AES_CCM_encrypt/decrypt :1268-1314;
  *                 the CTR half is k_ctr with the CCM/GCM pre-increment)
  *
- * A CBC-MAC is a strictly serial chain (M <- Enc(M ^ X_i)), so there is nothing
- * to spread over lanes: one lane of one workgroup walks the message through the
- * same LDS-resident T-tables as the block-parallel kernels (~1.5 us per block).
- * These kernels exist for completeness of the drop-in API -- all cipher work
- * stays on the GPU -- not for throughput.
+ * A CBC-MAC is a strictly serial chain (M <- Enc(M ^ X_i)): what counts is the latency
+ * of one block.  One wave walks the message; the four lanes of a quad share each block
+ * encryption (quad_encrypt, uaes_aes.hip.h: one output column per lane, DPP exchange).
+ * Independent messages belong in the batched entry points (uaes_chain.hip), one lane each.
  */
 #include <hip/hip_runtime.h>
 #include <string.h>
@@ -38,12 +37,12 @@ __device__ __forceinline__ Blk ld_block(const unsigned char *p, u64 avail)
     return b;
 }
 
+/* one block, shared by the four lanes of a quad (quad_encrypt, uaes_aes.hip.h); every lane of
+ * the wave holds the same block before and after                                          */
 template <int NR>
 __device__ __forceinline__ void enc1(Blk &b, const uaesk_rk &rk, const LaneConst &lc)
 {
-    u32 s[1][4] = { { b.w[0], b.w[1], b.w[2], b.w[3] } };
-    enc_blocks<NR, 1>(s, rk, lc);
-    b.w[0] = s[0][0]; b.w[1] = s[0][1]; b.w[2] = s[0][2]; b.w[3] = s[0][3];
+    quad_encrypt<NR>(b.w, rk, lc);
 }
 
 /* big-endian doubling in GF(2^128) (doubleBblock): <<1, carry -> ^0x87 in the last byte */
@@ -67,6 +66,7 @@ __device__ __forceinline__ void xor_blk(Blk &a, const Blk &b)
 
 __device__ __forceinline__ void st_bytes(unsigned char *dst, const Blk &b)
 {
+    if (threadIdx.x != 0) return;                  /* every lane holds the same block: one stores */
     for (u32 i = 0; i < 16; ++i) dst[i] = (unsigned char)(b.w[i >> 2] >> (8 * (i & 3)));
 }
 
@@ -83,13 +83,12 @@ __device__ __forceinline__ void cbcmac_absorb(Blk &m, const unsigned char *p, u6
 }
 
 template <int NR>
-__global__ __launch_bounds__(UAES_WG) void k_cmac(uaesk_rk rk, uaesk_tables tb,
+__global__ __launch_bounds__(64) void k_cmac(uaesk_rk rk, uaesk_tables tb,
                                                   const unsigned char *__restrict__ data, u64 len,
                                                   unsigned char *__restrict__ mac)
 {
-    fill_enc_tables(tb.te0);
-    if (threadIdx.x != 0) return;
-    const LaneConst lc = make_lane_const();
+    quad_fill_tables(tb.te0, rk);                /* one wave: all lanes run the chain, a quad per block */
+    const LaneConst lc = quad_lane_const();
     Blk k1 = { { 0, 0, 0, 0 } };
     enc1<NR>(k1, rk, lc);                        /* L = Enc(0)                   */
     k1 = dbl_be(k1);                             /* K1 = 2L                      */
@@ -111,17 +110,16 @@ __global__ __launch_bounds__(UAES_WG) void k_cmac(uaesk_rk rk, uaesk_tables tb,
 
 /* mode 0: write the tag to tag_io; mode 1: compare with tag_io, *status = 0 / 0x1A */
 template <int NR>
-__global__ __launch_bounds__(UAES_WG) void k_ccm_tag(uaesk_rk rk, uaesk_tables tb, uint4 iv4,
+__global__ __launch_bounds__(64) void k_ccm_tag(uaesk_rk rk, uaesk_tables tb, uint4 iv4,
                                                      const unsigned char *__restrict__ aad, u64 aad_len,
                                                      const unsigned char *__restrict__ pt, u64 pt_len,
                                                      int mode, unsigned char *tag_io, int *status)
 {
-    fill_enc_tables(tb.te0);
-    if (threadIdx.x != 0) return;
-    const LaneConst lc = make_lane_const();
+    quad_fill_tables(tb.te0, rk);                /* one wave: all lanes run the chain, a quad per block */
+    const LaneConst lc = quad_lane_const();
     const Blk iv = { { iv4.x, iv4.y, iv4.z, iv4.w } };
     unsigned char b0[16], a[16];
-    st_bytes(b0, iv);
+    for (u32 i = 0; i < 16; ++i) b0[i] = (unsigned char)(iv.w[i >> 2] >> (8 * (i & 3)));
     b0[0] |= (16 - 2) << 2;                               /* CCM_TAG_LEN = 16 (:1230)          */
     {
         u64 n = pt_len;                                   /* xorBEint(M, ptextLen, LAST)      */
@@ -161,7 +159,7 @@ __global__ __launch_bounds__(UAES_WG) void k_ccm_tag(uaesk_rk rk, uaesk_tables t
     xor_blk(m, e);
     if (mode == 0) {
         st_bytes(tag_io, m);
-    } else {
+    } else if (threadIdx.x == 0) {
         u32 diff = 0;
         for (u32 i = 0; i < 16; ++i) diff |= (u32)tag_io[i] ^ ((m.w[i >> 2] >> (8 * (i & 3))) & 0xffu);
         *status = diff ? 0x1A : 0;
@@ -180,9 +178,9 @@ template <int NR>
 static int launch_cmac(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek,
                        const void *data, size_t len, void *mac)
 {
-    hipError_t e = hipFuncSetAttribute((const void *)k_cmac<NR>, hipFuncAttributeMaxDynamicSharedMemorySize, UAES_LDS_ENC);
+    hipError_t e = hipFuncSetAttribute((const void *)k_cmac<NR>, hipFuncAttributeMaxDynamicSharedMemorySize, UAES_LDS_QUAD);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((k_cmac<NR>), dim3(1), dim3(UAES_WG), UAES_LDS_ENC, st, *ek, *tb,
+    hipLaunchKernelGGL((k_cmac<NR>), dim3(1), dim3(64), UAES_LDS_QUAD, st, *ek, *tb,
                        (const unsigned char *)data, (u64)len, (unsigned char *)mac);
     return (int)hipGetLastError();
 }
@@ -199,9 +197,9 @@ static int launch_ccm_tag(hipStream_t st, const uaesk_tables *tb, const uaesk_rk
                           const void *aad, size_t aad_len, const void *pt, size_t pt_len,
                           int mode, void *tag_io, int *status)
 {
-    hipError_t e = hipFuncSetAttribute((const void *)k_ccm_tag<NR>, hipFuncAttributeMaxDynamicSharedMemorySize, UAES_LDS_ENC);
+    hipError_t e = hipFuncSetAttribute((const void *)k_ccm_tag<NR>, hipFuncAttributeMaxDynamicSharedMemorySize, UAES_LDS_QUAD);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((k_ccm_tag<NR>), dim3(1), dim3(UAES_WG), UAES_LDS_ENC, st, *ek, *tb, iv,
+    hipLaunchKernelGGL((k_ccm_tag<NR>), dim3(1), dim3(64), UAES_LDS_QUAD, st, *ek, *tb, iv,
                        (const unsigned char *)aad, (u64)aad_len, (const unsigned char *)pt, (u64)pt_len,
                        mode, (unsigned char *)tag_io, status);
     return (int)hipGetLastError();

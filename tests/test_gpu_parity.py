@@ -474,6 +474,30 @@ def test_feedback_modes_vs_oracle(orc, bits):
     assert uaes.AES_CFB_encrypt(key, iv, b"") == b"" and uaes.AES_OFB_encrypt(key, iv, b"abc") == orc.ofb(key, iv, b"abc")
 
 
+@pytest.mark.parametrize("bits", [128, 192, 256])
+def test_batched_chains_equal_the_single_calls(orc, bits):
+    """uaes_cbc_encrypt_batch / uaes_cmac_batch: N independent messages, one GPU lane each, must give
+    exactly what N single calls give (AES_CBC_encrypt with its CS3 swap, AES_CMAC) -- checked against
+    the oracle, for one block, two blocks, many blocks, and more messages than one workgroup holds"""
+    rnd = random.Random(61 + bits)
+    key = rnd.randbytes(bits // 8)
+    for nmsg, size in ((1, 16), (3, 32), (5, 48), (1500, 16), (1030, 208), (7, 4096)):
+        msgs = [rnd.randbytes(size) for _ in range(nmsg)]
+        ivs = [rnd.randbytes(16) for _ in range(nmsg)]
+        got = uaes.cbc_encrypt_batch(key, ivs, msgs)
+        for i in list(range(min(nmsg, 6))) + [nmsg - 1, nmsg // 2]:
+            assert got[i] == orc.cbc(key, ivs[i], msgs[i], True)[1], (nmsg, size, i)
+        if nmsg <= 5:
+            assert got == [uaes.AES_CBC_encrypt(key, iv, m)[1] for iv, m in zip(ivs, msgs)]
+    for nmsg, size in ((1, 0), (4, 1), (3, 16), (5, 17), (1200, 33), (1030, 200), (6, 4096 + 5)):
+        msgs = [rnd.randbytes(size) for _ in range(nmsg)]
+        got = uaes.cmac_batch(key, msgs)
+        for i in list(range(min(nmsg, 6))) + [nmsg - 1, nmsg // 2]:
+            assert got[i] == orc.cmac(key, msgs[i]), (nmsg, size, i)
+    L = uaes.engine()
+    assert L.uaes_cbc_encrypt_batch(bits, key, bytes(16), 1, 24, bytes(24), (C.c_uint8 * 24)()) == -2
+
+
 def test_ghash_kernel_levels(orc):
     """every level plan of the GHASH kernels: direct, one bulk level, two bulk levels"""
     rnd = random.Random(77)
