@@ -230,6 +230,11 @@ typedef struct {
     size_t          aad_cap;
     void           *pin[2];         /* pinned bounce buffers for short host texts (in, out) */
     int             pin_busy;
+    struct {                        /* slice pipeline for long host texts: one entry per worker thread */
+        void  *stream;
+        void  *dbuf;                /* device slice                                            */
+    } pipe[16];
+    int             pipe_busy;      /* a pipelined call owns pipe[] (c->mu is dropped while its workers run) */
     int            *d_status;
     pthread_mutex_t mu;
 } context;
@@ -441,6 +446,135 @@ static int finish_io(io_plan *io, size_t out_len)
     return 0;
 }
 
+/* ------------------------------------------------------------------------ */
+/* long host texts: slices in flight on several streams                        */
+/* ------------------------------------------------------------------------ */
+/* The reference's callers pass HOST buffers.  One big hipMemcpy in, the kernel, one big
+ * hipMemcpy out use the PCIe link in one direction at a time (25 GiB/s for a 1 GiB CTR call
+ * of which the kernel is 0.65 ms).  For the modes whose blocks are independent (ECB, CTR, XTS
+ * data units) a long text is cut into slices and PIPE_WORKERS host threads each take the
+ * next slice: copy in, kernel, copy out on the worker's own stream and device slice, so the
+ * two DMA directions and the staging copies of different slices overlap: 33 GiB/s with four
+ * workers (profiles/r02_host_path_rate.log; 1.29x -- the link gives ~36 GB/s each way when both
+ * directions run; staging through our own pinned buffers measured slower, 26-29 GiB/s, the
+ * runtime's pageable path copies faster than memcpy() from worker threads does).  The workers
+ * touch only c->pipe[w] and read-only context data.                                        */
+#define PIPE_MIN      ((size_t)32 << 20)          /* shorter texts: the plain path            */
+#define PIPE_MAXW     16
+
+typedef int (*pipe_launch_fn)(void *arg, void *stream, const void *d_in, void *d_out, size_t off, size_t len);
+
+typedef struct {
+    context       *c;
+    int            device, worker;
+    const char    *in;
+    char          *out;
+    size_t         total, slice, out_extra;       /* out_extra: bytes the LAST slice writes beyond its input size */
+    size_t        *next;                          /* shared: offset of the next slice to take  */
+    pthread_mutex_t *next_mu;
+    pipe_launch_fn fn;
+    void          *arg;
+    int            rc;
+    char           err[200];
+} pipe_job;
+
+static int pipe_workers(void)
+{
+    static int w = 0;
+    if (!w) {
+        const char *e = getenv("UAES_PIPE_WORKERS");
+        w = e ? atoi(e) : 4;
+        if (w < 1) w = 1;
+        if (w > PIPE_MAXW) w = PIPE_MAXW;
+    }
+    return w;
+}
+
+static size_t pipe_slice_bytes(void)
+{
+    static size_t sl = 0;
+    if (!sl) {
+        const char *e = getenv("UAES_PIPE_SLICE_MIB");
+        sl = (size_t)(e ? atoi(e) : 16) << 20;
+        if (sl < ((size_t)1 << 20)) sl = (size_t)1 << 20;
+    }
+    return sl;
+}
+
+#define PFAIL(j, ...) do { (j)->rc = UAES_E_HIP; snprintf((j)->err, sizeof (j)->err, __VA_ARGS__); return NULL; } while (0)
+
+static void *pipe_worker(void *p)
+{
+    pipe_job *j = (pipe_job *)p;
+    context *c = j->c;
+    hipError_t e = hipSetDevice(j->device);
+    if (e != hipSuccess) PFAIL(j, "hipSetDevice: %s", hipGetErrorString(e));
+    hipStream_t st = (hipStream_t)c->pipe[j->worker].stream;
+    char *d = (char *)c->pipe[j->worker].dbuf;
+    for (;;) {
+        size_t off, len, olen;
+        pthread_mutex_lock(j->next_mu);
+        off = *j->next;
+        len = j->total - off < j->slice ? j->total - off : j->slice;
+        *j->next = off + len;
+        pthread_mutex_unlock(j->next_mu);
+        if (len == 0) return NULL;
+        olen = len + (off + len == j->total ? j->out_extra : 0);
+        e = hipMemcpyAsync(d, j->in + off, len, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) PFAIL(j, "slice copy in: %s", hipGetErrorString(e));
+        int k = j->fn(j->arg, st, d, d, off, len);
+        if (k) PFAIL(j, "slice launch: %s", hipGetErrorString((hipError_t)k));
+        e = hipMemcpyAsync(j->out + off, d, olen, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) PFAIL(j, "slice copy out: %s", hipGetErrorString(e));
+    }
+}
+
+/* returns 1 if the call qualifies (both buffers plain host memory, long enough), and then *rc is its result */
+static int run_pipelined(context *c, const void *in, void *out, size_t total, size_t unit, size_t out_extra,
+                         pipe_launch_fn fn, void *arg, int *rc)
+{
+    pipe_job jobs[PIPE_MAXW];
+    pthread_t th[PIPE_MAXW];
+    pthread_mutex_t next_mu = PTHREAD_MUTEX_INITIALIZER;
+    size_t next = 0, slice = pipe_slice_bytes();
+    int w, started = 0, nw = pipe_workers(), dev = 0;
+    if (total < PIPE_MIN || nw < 2 || is_device_ptr(in) || is_device_ptr(out)) return 0;
+    if (unit > slice) return 0;
+    slice -= slice % unit;
+    if (slice * 2 > total) return 0;
+    if ((size_t)nw > (total + slice - 1) / slice) nw = (int)((total + slice - 1) / slice);
+    *rc = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { *rc = fail(UAES_E_HIP, "hipGetDevice failed"); return 1; }
+    while (c->pipe_busy) pthread_cond_wait(&c->cv, &c->mu);
+    for (w = 0; w < nw && *rc == 0; ++w) {
+        if (!c->pipe[w].stream && hipStreamCreateWithFlags((hipStream_t *)&c->pipe[w].stream, hipStreamNonBlocking) != hipSuccess)
+            *rc = fail(UAES_E_HIP, "pipeline stream creation failed");
+        if (*rc == 0 && !c->pipe[w].dbuf && hipMalloc(&c->pipe[w].dbuf, pipe_slice_bytes() + 64) != hipSuccess)
+            *rc = fail(UAES_E_HIP, "pipeline slice allocation failed");
+    }
+    if (*rc) return 1;
+    /* the workers take c->mu themselves when they need per-stream scratch (XTS): mark pipe[] as
+     * taken and let go of the lock while they run                                          */
+    c->pipe_busy = 1;
+    pthread_mutex_unlock(&c->mu);
+    memset(jobs, 0, sizeof jobs);
+    for (w = 0; w < nw; ++w) {
+        jobs[w].c = c; jobs[w].device = dev; jobs[w].worker = w;
+        jobs[w].in = (const char *)in; jobs[w].out = (char *)out; jobs[w].total = total; jobs[w].slice = slice;
+        jobs[w].out_extra = out_extra; jobs[w].next = &next; jobs[w].next_mu = &next_mu; jobs[w].fn = fn; jobs[w].arg = arg;
+        if (pthread_create(&th[w], NULL, pipe_worker, &jobs[w]) != 0) { *rc = fail(UAES_E_HIP, "pthread_create failed"); break; }
+        ++started;
+    }
+    for (w = 0; w < started; ++w) pthread_join(th[w], NULL);
+    pthread_mutex_lock(&c->mu);
+    c->pipe_busy = 0;
+    pthread_cond_broadcast(&c->cv);
+    for (w = 0; w < started && *rc == 0; ++w)
+        if (jobs[w].rc) *rc = fail(jobs[w].rc, "%s", jobs[w].err);
+    return 1;
+}
+
 /* a decrypt-then-verify mode found a bad tag: hand the text over as the reference's default
  * build does, or (uaes_set_wipe_on_auth_failure) hand over zeros instead               */
 static int finish_io_unauthenticated(io_plan *io, size_t out_len)
@@ -523,6 +657,16 @@ int uaes_selftest(void)
 /* ------------------------------------------------------------------------ */
 /* ECB                                                                        */
 /* ------------------------------------------------------------------------ */
+typedef struct { context *c; keysched *ks; int decrypt, padding; size_t total; } ecb_pipe_arg;
+
+static int ecb_pipe_launch(void *arg, void *stream, const void *d_in, void *d_out, size_t off, size_t len)
+{
+    ecb_pipe_arg *a = (ecb_pipe_arg *)arg;
+    const int last = off + len == a->total;
+    return uaesk_ecb(stream, &a->c->tb, a->ks->nr, a->decrypt ? &a->ks->dk : &a->ks->ek, a->decrypt, d_in, d_out,
+                     len / 16, (a->decrypt || !last) ? 0 : (unsigned)(len % 16), (last && !a->decrypt) ? (unsigned)a->padding : 0);
+}
+
 static int ecb_common(int keybits, const uint8_t *key, int decrypt, int padding,
                       const void *in, size_t len, void *out)
 {
@@ -539,6 +683,9 @@ static int ecb_common(int keybits, const uint8_t *key, int decrypt, int padding,
     if ((rc = get_context(&c)) != 0) return rc;
     LOCKED_BEGIN(c);
     do {
+        ecb_pipe_arg pa;
+        pa.c = c; pa.ks = &ks; pa.decrypt = decrypt; pa.padding = padding; pa.total = len;
+        if (!(decrypt && rem) && run_pipelined(c, in, out, len, 16, out_len - len, ecb_pipe_launch, &pa, &rc)) break;
         if ((rc = plan_io(c, in, len, out, out_len, &io)) != 0) break;
         if (decrypt && rem && io.dout != io.din) {
             /* ragged decrypt: the reference copies the tail through (:664) */
@@ -620,6 +767,16 @@ int uaes_ctr_xcrypt_at_dev(int keybits, const uint8_t *key, const uint8_t ctr0[1
     return 0;
 }
 
+typedef struct { context *c; keysched *ks; uaesk_ctr *ctr; } ctr_pipe_arg;
+
+static int ctr_pipe_launch(void *arg, void *stream, const void *d_in, void *d_out, size_t off, size_t len)
+{
+    ctr_pipe_arg *a = (ctr_pipe_arg *)arg;
+    uaesk_ctr sl = *a->ctr;
+    sl.v0 = (a->ctr->v0 + off / 16) & 0x00FFFFFFFFFFFFFFull;     /* the slice's counter: the 56-bit add of incBlock */
+    return uaesk_ctr_xcrypt(stream, &a->c->tb, a->ks->nr, &a->ks->ek, &sl, d_in, d_out, len, NULL);
+}
+
 int uaes_ctr_xcrypt_at(int keybits, const uint8_t *key, const uint8_t ctr0[16],
                        uint64_t block_offset, const void *in, size_t len, void *out)
 {
@@ -636,6 +793,9 @@ int uaes_ctr_xcrypt_at(int keybits, const uint8_t *key, const uint8_t ctr0[16],
     make_ctr(&ctr, ctr0, block_offset);
     LOCKED_BEGIN(c);
     do {
+        ctr_pipe_arg pa;
+        pa.c = c; pa.ks = &ks; pa.ctr = &ctr;
+        if (run_pipelined(c, in, out, len, 16, 0, ctr_pipe_launch, &pa, &rc)) break;
         if ((rc = plan_io(c, in, len, out, len, &io)) != 0) break;
         int k = uaesk_ctr_xcrypt(NULL, &c->tb, ks.nr, &ks.ek, &ctr, io.din, io.dout, len, NULL);
         if (k) { rc = fail(UAES_E_HIP, "ctr launch: %s", hipGetErrorString((hipError_t)k)); break; }
@@ -684,6 +844,16 @@ static int xts_run(context *c, void *stream, keysched *k1, keysched *k2, int enc
     return 0;
 }
 
+typedef struct { context *c; keysched *k1, *k2; int encrypt; uint64_t first_sector; size_t sector_bytes; } xts_pipe_arg;
+
+static int xts_pipe_launch(void *arg, void *stream, const void *d_in, void *d_out, size_t off, size_t len)
+{
+    xts_pipe_arg *a = (xts_pipe_arg *)arg;
+    const int rc = xts_run(a->c, stream, a->k1, a->k2, a->encrypt, NULL, a->first_sector + off / a->sector_bytes,
+                           a->sector_bytes, len / a->sector_bytes, d_in, d_out, 2);
+    return rc ? (int)hipErrorUnknown : 0;
+}
+
 static int xts_common(int keybits, const uint8_t *keys, const uint8_t *tweak, int raw_tweak,
                       uint64_t first_sector, size_t sector_bytes, size_t nsectors,
                       const void *in, void *out, int encrypt)
@@ -701,6 +871,9 @@ static int xts_common(int keybits, const uint8_t *keys, const uint8_t *tweak, in
     if ((rc = get_context(&c)) != 0) return rc;
     LOCKED_BEGIN(c);
     do {
+        xts_pipe_arg pa;
+        pa.c = c; pa.k1 = &k1; pa.k2 = &k2; pa.encrypt = encrypt; pa.first_sector = first_sector; pa.sector_bytes = sector_bytes;
+        if (!raw_tweak && nsectors > 1 && run_pipelined(c, in, out, total, sector_bytes, 0, xts_pipe_launch, &pa, &rc)) break;
         if ((rc = plan_io(c, in, total, out, total, &io)) != 0) break;
         rc = xts_run(c, NULL, &k1, &k2, encrypt, raw_tweak ? (tweak ? tweak : zero) : NULL,
                      first_sector, sector_bytes, nsectors, io.din, io.dout, 0);

@@ -295,3 +295,58 @@ def test_xts_units_of_ragged_size_on_device_pointers(orc, sector_bytes, nsectors
     uaes.xts_sectors_dev(keys, 1 << 33, sector_bytes, nsectors, dst, dst, encrypt=False)
     torch.cuda.synchronize()
     assert bytes(dst[:total].cpu().numpy()) == data
+
+
+def test_long_host_texts_go_through_the_slice_pipeline(orc):
+    """Host buffers of 32 MiB and more are cut into 16 MiB slices that four worker threads move
+    through the GPU concurrently (CTR with per-slice counter offsets, ECB with the ragged/padded
+    tail in the last slice, XTS by whole data units); results must equal the oracle's / the
+    one-piece device path's, out of place and in place, also from two calling threads at once."""
+    import hashlib
+    import torch
+    L = uaes.engine()
+    rnd = random.Random(808)
+    key, keys, iv = rnd.randbytes(24), rnd.randbytes(64), rnd.randbytes(12)
+    n = (40 << 20) + 21
+    data = orc.splitmix(5, (n + 7) // 8 * 8)[:n]
+    src = (C.c_uint8 * n).from_buffer_copy(data)
+    out = (C.c_uint8 * (n + 32))()
+    sha = lambda b: hashlib.sha256(b).digest()
+    # CTR, a start counter that carries out of 32 bits inside the text
+    ctr0 = iv[:9] + bytes.fromhex("00ffffffff00") + b"\xf0"
+    assert L.uaes_ctr_xcrypt_at(192, key, ctr0, 5, src, n, out) == 0
+    assert sha(bytes(out)[:n]) == sha(orc.ctr_xcrypt_at(key, ctr0, 5, data))
+    # ECB: ragged tail (zero padded) and PKCS#7
+    for padding in (0, 1):
+        want = orc.ecb_encrypt(key, data, padding=padding)
+        assert L.uaes_ecb_encrypt_padded(192, key, padding, src, n, out) == 0
+        assert sha(bytes(out)[: len(want)]) == sha(want)
+    whole = n // 16 * 16
+    back = (C.c_uint8 * whole)()
+    assert L.uaes_ecb_decrypt(192, key, out, whole, back) == 0 and bytes(back) == data[:whole]
+    # XTS data units of 4 KiB + 16 (slices are whole units), in place
+    sb, ns = 4096 + 16, 9000
+    buf = (C.c_uint8 * (sb * ns)).from_buffer_copy(orc.splitmix(6, sb * ns))
+    plain = bytes(buf)
+    assert L.uaes_xts_sectors(256, keys, 1 << 40, sb, ns, buf, buf, 1) == 0
+    dsrc = torch.frombuffer(bytearray(plain), dtype=torch.uint8).to("cuda:0")
+    ddst = torch.empty_like(dsrc)
+    uaes.xts_sectors_dev(keys, 1 << 40, sb, ns, dsrc, ddst)
+    torch.cuda.synchronize()
+    assert sha(bytes(buf)) == sha(ddst.cpu().numpy().tobytes())
+    assert bytes(buf)[-2 * sb:] == orc.xts_sectors(keys, (1 << 40) + ns - 2, sb, plain[-2 * sb:], True)[1]
+    assert L.uaes_xts_sectors(256, keys, 1 << 40, sb, ns, buf, buf, 0) == 0 and bytes(buf) == plain
+    # two threads at once (the second waits for the pipeline, or takes it first)
+    res = {}
+
+    def call(tag, off):
+        o = (C.c_uint8 * n)()
+        res[tag] = (L.uaes_ctr_xcrypt_at(192, key, ctr0, off, src, n, o), sha(bytes(o)))
+
+    th = [threading.Thread(target=call, args=("a", 5)), threading.Thread(target=call, args=("b", 6))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert res["a"] == (0, sha(orc.ctr_xcrypt_at(key, ctr0, 5, data)))
+    assert res["b"] == (0, sha(orc.ctr_xcrypt_at(key, ctr0, 6, data)))
