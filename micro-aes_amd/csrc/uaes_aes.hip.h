@@ -418,14 +418,15 @@ __device__ __forceinline__ void dec_blocks(u32 (&s)[U][4], const uaesk_rk &dk, c
  * Round keys live in LDS after the table region (lane c needs word 4r + c of round r).   */
 #define UAES_LDS_QUAD  (UAES_LDS_ENC + 256u)          /* tables + 60 key words */
 
-__device__ __forceinline__ void quad_fill_tables(const u32 *__restrict__ t0, const uaesk_rk &rk)
+__device__ __forceinline__ void quad_fill_tables(const u32 *__restrict__ t0, const uaesk_rk &rk,
+                                                 u32 key_base = UAES_LDS_ENC)
 {
     for (u32 i = threadIdx.x; i < 1024u; i += blockDim.x) {
         const u32 x = i & 255u, k = i >> 8;
         const u32 v = rotl32(t0[x], 8u * k);
         *(uint4 *)(uaes_lds + x * 256u + (k & 1u) * 128u + (k >> 1) * 65536u) = make_uint4(v, v, v, v);
     }
-    for (u32 i = threadIdx.x; i < 60u; i += blockDim.x) ((u32 *)(uaes_lds + UAES_LDS_ENC))[i] = rk.w[i];
+    for (u32 i = threadIdx.x; i < 60u; i += blockDim.x) ((u32 *)(uaes_lds + key_base))[i] = rk.w[i];
     __syncthreads();
 }
 
@@ -448,10 +449,11 @@ __device__ __forceinline__ u32 quad_perm(u32 v)
 
 /* t = the block (replicated in the quad's four lanes) -> its encryption, replicated again */
 template <int NR>
-__device__ __forceinline__ void quad_encrypt(u32 (&t)[4], const uaesk_rk &rk, const LaneConst &lc)
+__device__ __forceinline__ void quad_encrypt(u32 (&t)[4], const uaesk_rk &rk, const LaneConst &lc,
+                                             u32 key_base = UAES_LDS_ENC)
 {
     const u32 c = threadIdx.x & 3u;
-    const u32 kaddr = UAES_LDS_ENC + 4u * c;                    /* + 16 r: this lane's word of round key r */
+    const u32 kaddr = key_base + 4u * c;                        /* + 16 r: this lane's word of round key r */
 #pragma unroll
     for (int j = 0; j < 4; ++j) t[j] ^= rk.w[j];
     /* rotated view: w[k] = column (c + k) mod 4 */

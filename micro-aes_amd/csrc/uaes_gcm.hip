@@ -275,6 +275,11 @@ __global__ __launch_bounds__(GH_T) void k_ghash_final(GSrc src, u64 nv, const un
     for (u32 i = threadIdx.x; i < 2048u; i += GH_T) TC[i] = g4[i];
     __syncthreads();
 
+    /* The sequence is front-padded with zero blocks to steps * 1024; a level's leading rows that
+     * hold only padding are skipped (their accumulators stay zero), and so is the multiplication
+     * of a still-zero accumulator: a short message (the per-call floor) costs a handful of
+     * dependent table multiplications instead of 16 + 16 + 4 + steps, and the tables of the
+     * levels it never multiplies in need not have been built (launch_setup: maxlog).        */
     const u64 steps = (nv + GH_T - 1) / GH_T;
     const u64 pad = steps * GH_T - nv;
     uint4 acc = make_uint4(0, 0, 0, 0);
@@ -282,25 +287,30 @@ __global__ __launch_bounds__(GH_T) void k_ghash_final(GSrc src, u64 nv, const un
         const u64 u = k * GH_T + threadIdx.x;
         uint4 x = make_uint4(0, 0, 0, 0);
         if (u >= pad) x = load_vblock(src, u - pad);
-        acc = x4(tabmul4(TC, acc), x);
+        acc = k ? x4(tabmul4(TC, acc), x) : x;
     }
     buf[threadIdx.x] = acc;
     __syncthreads();
+    const u32 live = nv < GH_T ? (u32)nv : GH_T;               /* non-padding entries at the end of buf[0..1024) */
     if (threadIdx.x < 64) {
-        acc = make_uint4(0, 0, 0, 0);
-        for (u32 k = 0; k < 16; ++k) acc = x4(tabmul4(TD, acc), buf[k * 64 + threadIdx.x]);
+        const u32 k0 = 16u - (live + 63u) / 64u;               /* first row with a live entry */
+        acc = buf[k0 * 64 + threadIdx.x];
+        for (u32 k = k0 + 1; k < 16; ++k) acc = x4(tabmul4(TD, acc), buf[k * 64 + threadIdx.x]);
         buf[1024 + threadIdx.x] = acc;
     }
     __syncthreads();
+    const u32 live2 = live < 64u ? live : 64u;
     if (threadIdx.x < 4) {
-        acc = make_uint4(0, 0, 0, 0);
-        for (u32 k = 0; k < 16; ++k) acc = x4(tabmul4(TE, acc), buf[1024 + k * 4 + threadIdx.x]);
+        const u32 k0 = 16u - (live2 + 3u) / 4u;
+        acc = buf[1024 + k0 * 4 + threadIdx.x];
+        for (u32 k = k0 + 1; k < 16; ++k) acc = x4(tabmul4(TE, acc), buf[1024 + k * 4 + threadIdx.x]);
         buf[1088 + threadIdx.x] = acc;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
+        const u32 live3 = live2 < 4u ? live2 : 4u;
         acc = make_uint4(0, 0, 0, 0);
-        for (u32 k = 0; k < 4; ++k) acc = tabmul4(TF, x4(acc, buf[1088 + k]));
+        for (u32 k = 4u - live3; k < 4; ++k) acc = tabmul4(TF, x4(acc, buf[1088 + k]));
         if (mode != 2) acc = x4(acc, *(const uint4 *)(scratch + GS_EJ0));
         const u32 w[4] = { acc.x, acc.y, acc.z, acc.w };
         if (mode == 1) {
@@ -343,21 +353,24 @@ template <int NR>
 __global__ __launch_bounds__(UAES_WG) void k_gcm_setup(uaesk_rk ek, uaesk_tables tb, uint4 j0,
                                                        unsigned char *__restrict__ scratch,
                                                        u32 logA, u32 needB, u32 h_given, uint4 hval, u32 want_pow64,
-                                                       u32 logF)
+                                                       u32 logF, u32 maxlog)
 {
     Gf *shPow = (Gf *)(uaes_lds + UAES_LDS_ENC);          /* up to 21 powers   */
     Gf *shGen = shPow + 32;                                /* 7 x 128 generators */
     uint4 *gH = (uint4 *)(scratch + GS_H);
 
     if (!h_given) {
-        fill_enc_tables(tb.te0);
-        const LaneConst lc = make_lane_const();
-        if (threadIdx.x < 2) {
-            u32 s[1][4] = { { 0, 0, 0, 0 } };
-            if (threadIdx.x == 1) { s[0][0] = j0.x; s[0][1] = j0.y; s[0][2] = j0.z; s[0][3] = j0.w; }
-            enc_blocks<NR, 1>(s, ek, lc);
-            gH[threadIdx.x] = make_uint4(s[0][0], s[0][1], s[0][2], s[0][3]);
-            if (threadIdx.x == 0) shPow[0] = gf_from_words(s[0][0], s[0][1], s[0][2], s[0][3]);
+        /* H = Enc(0) and Enc(J0): two blocks, a quad of lanes each (quad_encrypt: 4 KiB of table
+         * stores instead of 128 KiB, ~2x shorter latency than one lane per block)               */
+        const u32 kb = UAES_LDS_ENC + 15104u;                  /* behind shPow / shGen */
+        quad_fill_tables(tb.te0, ek, kb);
+        const LaneConst lc = quad_lane_const();
+        if (threadIdx.x < 64) {                                /* wave 0: quad 0 -> H, the other quads -> Enc(J0) */
+            u32 s[4] = { 0, 0, 0, 0 };
+            if (threadIdx.x >= 4) { s[0] = j0.x; s[1] = j0.y; s[2] = j0.z; s[3] = j0.w; }
+            quad_encrypt<NR>(s, ek, lc, kb);
+            if (threadIdx.x == 0 || threadIdx.x == 4) gH[threadIdx.x >> 2] = make_uint4(s[0], s[1], s[2], s[3]);
+            if (threadIdx.x == 0) shPow[0] = gf_from_words(s[0], s[1], s[2], s[3]);
         }
     } else if (threadIdx.x == 0) {
         gH[0] = hval;
@@ -369,7 +382,7 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_setup(uaesk_rk ek, uaesk_tables
     if (threadIdx.x < 64) {                    /* squaring chain, wave 0 */
         Gf p = shPow[0];
         uint4 *g64 = (uint4 *)(scratch + GS_POW64);
-        const u32 last = want_pow64 ? 63u : (logF > GH_MAXLOG ? logF : GH_MAXLOG);
+        const u32 last = want_pow64 ? 63u : maxlog;          /* the highest power any requested table needs */
         for (u32 k = 0; k <= last; ++k) {
             if (k) p = wave_gfmul(p, p, threadIdx.x);
             if (threadIdx.x == 0) {
@@ -431,7 +444,7 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_setup(uaesk_rk ek, uaesk_tables
             dst[p * 16 + v] = make_uint4(w[0], w[1], w[2], w[3]);
         }
     }
-    if (threadIdx.x <= GH_MAXLOG) {
+    if (threadIdx.x <= (want_pow64 ? GH_MAXLOG : (maxlog < GH_MAXLOG ? maxlog : GH_MAXLOG))) {
         u32 w[4];
         gf_to_words(shPow[threadIdx.x], w);
         ((uint4 *)(scratch + GS_POW))[threadIdx.x] = make_uint4(w[0], w[1], w[2], w[3]);
@@ -560,11 +573,12 @@ static int launch_fused(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *
 struct GPlan {
     u32 logA;       /* 0 = no bulk level */
     u32 needB;
+    u64 nv;         /* blocks the plan was made for */
 };
 
 static GPlan plan_for(u64 nv)
 {
-    GPlan p = { 0, 0 };
+    GPlan p = { 0, 0, nv };
     if (nv <= GH_DIRECT) return p;
     u32 lg = GH_LOGB;
     while (lg < GH_MAXLOG && ((u64)64 << lg) < nv) ++lg;     /* ~64+ steps per lane */
@@ -611,8 +625,14 @@ static int launch_setup(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *
 {
     hipError_t e = hipFuncSetAttribute((const void *)k_gcm_setup<NR>, hipFuncAttributeMaxDynamicSharedMemorySize, SETUP_LDS);
     if (e != hipSuccess) return (int)e;
+    /* powers actually needed: the bulk tables, and of the last-levels tables H^1024 / H^64 / H^4 / H
+     * only those a message of nv blocks reaches (k_ghash_final skips the empty levels)       */
+    u32 maxlog = pl.nv > 1024 ? 10u : pl.nv > 64 ? 6u : pl.nv > 4 ? 2u : 0u;
+    if (pl.logA > maxlog) maxlog = pl.logA;
+    if (pl.needB && GH_LOGB > maxlog) maxlog = GH_LOGB;
+    if (logF > maxlog) maxlog = logF;
     hipLaunchKernelGGL((k_gcm_setup<NR>), dim3(1), dim3(UAES_WG), SETUP_LDS, st, *ek, *tb, j0, scratch,
-                       pl.logA, pl.needB, h_given, hval, want_pow64, logF);
+                       pl.logA, pl.needB, h_given, hval, want_pow64, logF, maxlog);
     return (int)hipGetLastError();
 }
 
