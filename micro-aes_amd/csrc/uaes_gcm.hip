@@ -59,8 +59,10 @@
 #define GS_SMALL    (GS_PART + 64u)                 /* everything the streamed / sharded paths need */
 #define GF_MAXLOG   20u                             /* fused encrypt: lanes of the whole grid, 2048 per workgroup */
 #define GS_TAB8_F   GS_SMALL                        /* H^(2048 * workgroups), 64 KiB (fused encrypt) */
-#define GS_ACCF     (GS_TAB8_F + 65536u)            /* its per-lane accumulators, up to 2^20 x 16    */
-#define GS_TOTAL    (GS_ACCF + (16u << GF_MAXLOG))
+#define GS_YLO      (GS_TAB8_F + 65536u)            /* Y^0..Y^15, Y = H^2048 (workgroup weights)     */
+#define GS_ZHI      (GS_YLO + 256u)                 /* Z^0..Z^15, Z = Y^16                           */
+#define GS_T        (GS_ZHI + 256u)                 /* XOR of the workgroups' weighted partial hashes */
+#define GS_TOTAL    (GS_T + 64u)
 
 static inline hipStream_t S(void *s) { return (hipStream_t)s; }
 
@@ -218,6 +220,35 @@ __device__ __forceinline__ uint4 tabmul4(const uint4 *T, uint4 a)
     return make_uint4(z[0], z[1], z[2], z[3]);
 }
 
+/* The same product shared by the four lanes of a quad: in a dependent chain (the last levels)
+ * what counts is the latency of one multiplication, and one lane alone issues 32 lookups, their
+ * addresses and a 31-term XOR per dword.  Lane c of the quad takes word c of `a` (8 nibbles),
+ * the quad XORs its four partial products with two DPP exchanges per dword; every lane returns
+ * the full product.  `a` must be the same in the four lanes.                              */
+__device__ __forceinline__ uint4 tabmul4q(const uint4 *T, uint4 a)
+{
+    const u32 c = threadIdx.x & 3u;
+    const u32 w = c == 0 ? a.x : c == 1 ? a.y : c == 2 ? a.z : a.w;
+    const u32 base = (u32)(uintptr_t)(__attribute__((address_space(3))) const uint4 *)T + c * 2048u;   /* j = 4c + k */
+    u32x4 e[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const u32 b = w >> (8 * k);
+        e[2 * k] = *(lds_cu128 *)(uintptr_t)((b & 0xf0u) + (base + k * 512u));
+        e[2 * k + 1] = *(lds_cu128 *)(uintptr_t)(((b & 0x0fu) << 4) + (base + k * 512u + 256u));
+    }
+    u32 z[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        u32 t = xor3(xor3(e[0][d], e[1][d], e[2][d]), e[3][d], e[4][d]);
+        t = xor3(t, e[5][d], e[6][d]) ^ e[7][d];
+        t ^= (u32)__builtin_amdgcn_mov_dpp((int)t, 0xB1, 0xf, 0xf, true);      /* quad_perm [1,0,3,2] */
+        t ^= (u32)__builtin_amdgcn_mov_dpp((int)t, 0x4E, 0xf, 0xf, true);      /* quad_perm [2,3,0,1] */
+        z[d] = t;
+    }
+    return make_uint4(z[0], z[1], z[2], z[3]);
+}
+
 /* ------------------------------------------------------------------------ */
 /* bulk level: stride S = gridDim.x * 256                                     */
 /* ------------------------------------------------------------------------ */
@@ -291,26 +322,30 @@ __global__ __launch_bounds__(GH_T) void k_ghash_final(GSrc src, u64 nv, const un
     }
     buf[threadIdx.x] = acc;
     __syncthreads();
+    /* the last levels are dependent chains: a quad of lanes per accumulator (tabmul4q) */
     const u32 live = nv < GH_T ? (u32)nv : GH_T;               /* non-padding entries at the end of buf[0..1024) */
-    if (threadIdx.x < 64) {
+    const u32 qi = threadIdx.x >> 2;                           /* accumulator this quad works on */
+    if (threadIdx.x < 256) {
         const u32 k0 = 16u - (live + 63u) / 64u;               /* first row with a live entry */
-        acc = buf[k0 * 64 + threadIdx.x];
-        for (u32 k = k0 + 1; k < 16; ++k) acc = x4(tabmul4(TD, acc), buf[k * 64 + threadIdx.x]);
-        buf[1024 + threadIdx.x] = acc;
+        acc = buf[k0 * 64 + qi];
+        for (u32 k = k0 + 1; k < 16; ++k) acc = x4(tabmul4q(TD, acc), buf[k * 64 + qi]);
+        if ((threadIdx.x & 3u) == 0) buf[1024 + qi] = acc;
     }
     __syncthreads();
     const u32 live2 = live < 64u ? live : 64u;
-    if (threadIdx.x < 4) {
+    if (threadIdx.x < 16) {
         const u32 k0 = 16u - (live2 + 3u) / 4u;
-        acc = buf[1024 + k0 * 4 + threadIdx.x];
-        for (u32 k = k0 + 1; k < 16; ++k) acc = x4(tabmul4(TE, acc), buf[1024 + k * 4 + threadIdx.x]);
-        buf[1088 + threadIdx.x] = acc;
+        acc = buf[1024 + k0 * 4 + qi];
+        for (u32 k = k0 + 1; k < 16; ++k) acc = x4(tabmul4q(TE, acc), buf[1024 + k * 4 + qi]);
+        if ((threadIdx.x & 3u) == 0) buf[1088 + qi] = acc;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < 4) {
         const u32 live3 = live2 < 4u ? live2 : 4u;
         acc = make_uint4(0, 0, 0, 0);
-        for (u32 k = 4u - live3; k < 4; ++k) acc = tabmul4(TF, x4(acc, buf[1088 + k]));
+        for (u32 k = 4u - live3; k < 4; ++k) acc = tabmul4q(TF, x4(acc, buf[1088 + k]));
+    }
+    if (threadIdx.x == 0) {
         if (mode != 2) acc = x4(acc, *(const uint4 *)(scratch + GS_EJ0));
         const u32 w[4] = { acc.x, acc.y, acc.z, acc.w };
         if (mode == 1) {
@@ -444,6 +479,34 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_setup(uaesk_rk ek, uaesk_tables
             dst[p * 16 + v] = make_uint4(w[0], w[1], w[2], w[3]);
         }
     }
+    if (logF) {
+        /* weights of the fused kernel's workgroups: Y^k and Z^k = Y^(16k), k < 16 (Y = H^2048), by
+         * doubling rounds -- round i computes powers 2^i + 1 .. 2^(i+1) from the ones below, one
+         * wave per product, the Y and Z families side by side                                   */
+        Gf *shY = (Gf *)(uaes_lds + UAES_LDS_ENC + 15360u);       /* [0..15] Y^k, [16..31] Z^k */
+        const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+        if (threadIdx.x < 2) {
+            const Gf one = { 0x8000000000000000ull, 0 };
+            shY[16 * threadIdx.x] = one;
+            shY[16 * threadIdx.x + 1] = shPow[threadIdx.x ? 15 : 11];
+        }
+        __syncthreads();
+        for (u32 half = 1; half < 16; half <<= 1) {                /* powers half+1 .. 2*half (capped at 15) */
+            const u32 fam = wave >> 3, i = (wave & 7u) + 1;        /* product number i of this family */
+            const u32 k = half + i;
+            if (i <= half && k <= 15u) {
+                const Gf pr = wave_gfmul(shY[16 * fam + half], shY[16 * fam + i], lane);
+                if (lane == 0) shY[16 * fam + k] = pr;
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x < 32) {
+            u32 w[4];
+            gf_to_words(shY[threadIdx.x], w);
+            ((uint4 *)(scratch + GS_YLO))[threadIdx.x] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        if (threadIdx.x == 32) *(uint4 *)(scratch + GS_T) = make_uint4(0, 0, 0, 0);
+    }
     if (threadIdx.x <= (want_pow64 ? GH_MAXLOG : (maxlog < GH_MAXLOG ? maxlog : GH_MAXLOG))) {
         u32 w[4];
         gf_to_words(shPow[threadIdx.x], w);
@@ -458,21 +521,29 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_setup(uaesk_rk ek, uaesk_tables
  * algorithmic HBM traffic).  Here every lane folds its ciphertext blocks into its own
  * GHASH accumulators while they are still in registers:
  *
- *   the interleaved geometry of ctr_shared_loop puts block (b, it, q, u, p) at  j + S it,
- *   j = 2048 b + 256 (q + 4u) + p,  S = 2048 * workgroups  -- the strided-Horner layout of
- *   the GHASH levels -- so  acc_j <- acc_j * H^S ^ C  per block (tabmul8_xor, the 64 KiB
- *   byte table of H^S in LDS next to the 64 KiB split-halves AES tables), and the middle
- *   of the message is represented by its S accumulators, acc_0..acc_{S-1}, as S blocks.
+ *   the striped geometry of ctr_shared_loop puts block (b, it, q, u, p) at  j + S it,
+ *   j = 2048 b + 256 (q + 4u) + p,  S = 2048 * workgroups  -- a strided Horner layout -- so
+ *   acc_j <- acc_j * H^S ^ C  per block (tabmul8_xor_half: the 64 KiB byte table of H^S in LDS
+ *   next to the 64 KiB split-halves AES tables).
  *
- * Message layout: [AAD blocks][head: ciphertext blocks up to the first group boundary of
- * the counter, < 256][middle: `iters` whole rounds of S blocks][tail blocks + ragged
- * bytes][length block].  The nfront = AAD + head blocks in front of the middle are the
- * INITIAL values of the last nfront accumulators (they sit exactly one stride before those
- * lanes' first blocks); a head block is encrypted by the lane that absorbs it.  The tail is
- * encrypted in the prologue (spread over all workgroups) and hashed, behind the S
- * accumulators, by the ordinary levels: GHASH([acc_0..acc_{S-1}][tail][lengths]).
+ * When its stripes are done a workgroup reduces its 2048 accumulators to ONE block
+ *   R_b = sum_q acc_q * H^(2047 - q)        (nibble tables H^1024, H^64, H^4, H loaded over the
+ *                                            AES tables: 1 + 16 + 16 + 4 dependent multiplies)
+ * which stands for all the blocks the workgroup encrypted, as a polynomial that ends with its
+ * last stripe.  k_b = stripes dealt after that stripe (0..workgroups-1; workgroups may differ
+ * by one stripe), so the workgroup's share of the hash, taken to the end of the striped
+ * region, is R_b * Y^(k_b), Y = H^2048 = Ylo[k_b & 15] * Zhi[k_b >> 4] (two wave-cooperative
+ * products); the shares are XORed into one 16-byte block T in device memory.
  *
- * LDS: [0, 64K) GHASH table, [64K, 128K) AES tables, then the U-buffer.             */
+ * Message layout: [AAD blocks][head: ciphertext blocks up to the first group boundary of the
+ * counter, < 256][striped region][tail: < 2048 blocks + ragged bytes][length block].  The
+ * nfront = AAD + head blocks are the INITIAL values of the last nfront accumulators (they sit
+ * exactly one stride before those lanes' first blocks); a head block is encrypted by the lane
+ * that absorbs it.  The tail is encrypted in the prologue; the tag is
+ * GHASH([T][tail][lengths]) ^ Enc(J0), one short k_ghash_final.
+ *
+ * LDS: [0, 64K) GHASH table, [64K, 128K) AES tables (later: nibble tables + reduction
+ * buffer), then the U-buffer.                                                            */
 #define GF_LDS_AES    65536u
 #define GF_LDS_BUF    131072u
 #define GF_LDS_TOTAL  (GF_LDS_BUF + 2u * CTRS_CHUNK * 32u)
@@ -514,14 +585,17 @@ struct GhFold {
     }
 };
 
+__device__ __forceinline__ Gf gf_from4(uint4 v) { return gf_from_words(v.x, v.y, v.z, v.w); }
+
 template <int NR>
 __global__ __launch_bounds__(UAES_WG) void k_gcm_enc_fused(uaesk_rk rk, uaesk_tables tb, uaesk_ctr ctr,
                                                            const uint4 *in, uint4 *out,
-                                                           u64 g_lo, u64 iters, u64 h1, u64 nfull, u32 rem,
+                                                           u64 g_lo, u64 stripes, u64 h1, u64 nfull, u32 rem,
                                                            GSrc front, u64 nfront,
-                                                           const uint4 *__restrict__ tab8, uint4 *__restrict__ accs)
+                                                           unsigned char *__restrict__ scratch)
 {
     uint4 *T = (uint4 *)uaes_lds;                  /* LDS address 0 (absolute addressing in tabmul8_xor) */
+    const uint4 *tab8 = (const uint4 *)(scratch + GS_TAB8_F);
     for (u32 i = threadIdx.x; i < 4096u; i += UAES_WG) T[i] = tab8[i];
     fill_tables64(tb.te0, GF_LDS_AES);             /* ends with a barrier */
     const LaneConst2 lc = make_lane_const2(GF_LDS_AES);
@@ -535,35 +609,79 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_enc_fused(uaesk_rk rk, uaesk_ta
     const u32 p = ((wave & 3u) << 6) | lane, quad = wave >> 2;
     const u64 S = 2048ull * gridDim.x;
     const u64 ablk = (front.aad_len + 15) >> 4;
-    u64 j[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        j[u] = 2048ull * blockIdx.x + 256u * (quad + 4u * u) + p;
+        const u64 j = 2048ull * blockIdx.x + 256u * (quad + 4u * u) + p;
         fold.acc[u] = make_uint4(0, 0, 0, 0);
-        if (j[u] >= S - nfront) {                  /* a block in front of the middle: AAD, or a head block */
-            const u64 f = j[u] - (S - nfront);
+        if (j >= S - nfront) {                     /* a block in front of the striped region: AAD, or a head block */
+            const u64 f = j - (S - nfront);
             fold.acc[u] = f < ablk ? load_vblock_fwd(front, f) : ctr_one_block<NR>(rk, ctr, in, out, f - ablk, lc);
         }
     }
     CtrGeo geo;
     geo.first = g_lo;
-    geo.iters = iters;
+    geo.iters = stripes / gridDim.x + (blockIdx.x < stripes % gridDim.x ? 1 : 0);
     ctr_shared_loop<NR>(rk, ctr, in, out, geo, GF_LDS_BUF, lc, fold);
-    accs[j[0]] = fold.acc[0];
-    accs[j[1]] = fold.acc[1];
+
+    /* ---- the workgroup's 2048 accumulators -> R_b -> weighted share into T ---- */
+    __syncthreads();                               /* every wave is done with the AES tables */
+    uint4 *TC = (uint4 *)(uaes_lds + GF_LDS_AES);  /* 4 x 512 entries: H^1024, H^64, H^4, H */
+    uint4 *TD = TC + 512, *TE = TD + 512, *TF = TE + 512;
+    uint4 *buf = TF + 512;                         /* 1024 + 64 + 4 + 1 */
+    {
+        const uint4 *g4 = (const uint4 *)(scratch + GS_TAB4_C);
+        for (u32 i = threadIdx.x; i < 2048u; i += UAES_WG) TC[i] = g4[i];
+    }
+    __syncthreads();
+    /* lane slot q' = 256 quad + p holds accumulators q' and q' + 1024 */
+    buf[(quad << 8) | p] = x4(tabmul4(TC, fold.acc[0]), fold.acc[1]);
+    __syncthreads();
+    uint4 acc;
+    const u32 qi = threadIdx.x >> 2;                           /* a quad of lanes per accumulator (tabmul4q) */
+    if (threadIdx.x < 256) {
+        acc = buf[qi];
+        for (u32 k = 1; k < 16; ++k) acc = x4(tabmul4q(TD, acc), buf[k * 64 + qi]);
+        if ((threadIdx.x & 3u) == 0) buf[1024 + qi] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        acc = buf[1024 + qi];
+        for (u32 k = 1; k < 16; ++k) acc = x4(tabmul4q(TE, acc), buf[1024 + k * 4 + qi]);
+        if ((threadIdx.x & 3u) == 0) buf[1088 + qi] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        acc = buf[1088];
+        for (u32 k = 1; k < 4; ++k) acc = x4(tabmul4q(TF, acc), buf[1088 + k]);      /* last term: H^0 */
+        if (threadIdx.x == 0) buf[1092] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {                        /* wave 0: R_b * Ylo[k & 15] * Zhi[k >> 4] */
+        const u64 last = (u64)blockIdx.x + (u64)gridDim.x * (geo.iters - 1);        /* this workgroup's last stripe */
+        const u32 k = (u32)(stripes - 1 - last);
+        const uint4 *yl = (const uint4 *)(scratch + GS_YLO), *zh = (const uint4 *)(scratch + GS_ZHI);
+        Gf w = wave_gfmul(gf_from4(yl[k & 15u]), gf_from4(zh[k >> 4]), threadIdx.x);
+        w = wave_gfmul(gf_from4(buf[1092]), w, threadIdx.x);
+        if (threadIdx.x == 0) {
+            u32 ww[4];
+            gf_to_words(w, ww);
+            unsigned *t = (unsigned *)(scratch + GS_T);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) atomicXor(t + i, ww[i]);
+        }
+    }
 }
 
 template <int NR>
 static int launch_fused(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek, const uaesk_ctr *c,
-                        const void *in, void *out, unsigned grid, u64 g_lo, u64 iters, u64 h1, u64 nfull, u32 rem,
+                        const void *in, void *out, unsigned grid, u64 g_lo, u64 stripes, u64 h1, u64 nfull, u32 rem,
                         const GSrc &front, u64 nfront, unsigned char *sc)
 {
     hipError_t e = hipFuncSetAttribute((const void *)k_gcm_enc_fused<NR>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        GF_LDS_TOTAL);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL((k_gcm_enc_fused<NR>), dim3(grid), dim3(UAES_WG), GF_LDS_TOTAL, st, *ek, *tb, *c,
-                       (const uint4 *)in, (uint4 *)out, g_lo, iters, h1, nfull, rem, front, nfront,
-                       (const uint4 *)(sc + GS_TAB8_F), (uint4 *)(sc + GS_ACCF));
+                       (const uint4 *)in, (uint4 *)out, g_lo, stripes, h1, nfull, rem, front, nfront, sc);
     return (int)hipGetLastError();
 }
 
@@ -669,9 +787,9 @@ extern "C" int uaesk_gcm(void *stream, const uaesk_tables *tb, int nr, const uae
     const uint4 z = make_uint4(0, 0, 0, 0);
 
     /* Encrypt, long text: CTR and GHASH in one pass (k_gcm_enc_fused).  Needs a power-of-two
-     * number of lanes in the grid (S = 2048 * CUs: 2^19 on MI355X), at least two whole rounds of
-     * S blocks, and the AAD + head blocks to fit in front of one round.  Decrypt authenticates
-     * BEFORE it writes (N7), so it keeps the two-pass order.                              */
+     * number of lanes in the grid (S = 2048 * CUs: 2^19 on MI355X), at least one 2048-block stripe
+     * per workgroup, and the AAD + head blocks to fit in front of one round.  Decrypt
+     * authenticates BEFORE it writes (N7), so it keeps the two-pass order.                */
     if (!decrypt) {
         int cus = 0;
         if (uaesk_device_info(&cus, nullptr) != 0) cus = 0;
@@ -680,16 +798,17 @@ extern "C" int uaesk_gcm(void *stream, const uaesk_tables *tb, int nr, const uae
         while (((u64)1 << logF) < Sl) ++logF;
         const u64 nfull = len / 16, ablk = (aad_len + 15) >> 4;
         const u32 c0 = (u32)c.v0 & 0xffu;
-        const u64 h0 = (256u - c0) & 255u;
-        if (Sl && ((u64)1 << logF) == Sl && logF <= GF_MAXLOG && nfull >= h0 + 2 * Sl && ablk + h0 <= Sl) {
-            const u64 iters = (nfull - h0) / Sl, h1 = h0 + iters * Sl;
-            GSrc fin;                                   /* [accumulators][tail][lengths] */
-            fin.aad = sc + GS_ACCF; fin.aad_len = Sl * 16;
+        const u64 h0 = (256u - c0) & 255u, g_lo = c0 ? 1 : 0;
+        const u64 groups = (c0 + nfull) / 256, n8 = groups > g_lo ? (groups - g_lo) / 8 : 0;
+        if (Sl && ((u64)1 << logF) == Sl && logF <= GF_MAXLOG && n8 >= (u64)cus && ablk + h0 <= Sl) {
+            const u64 h1 = h0 + 2048 * n8;
+            GSrc fin;                                   /* [T][tail][lengths] */
+            fin.aad = sc + GS_T; fin.aad_len = 16;
             fin.ct = (const unsigned char *)out + h1 * 16; fin.ct_len = len - h1 * 16;
             fin.has_len = 1; fin.len_aad = aad_len; fin.len_ct = len; fin.rev = 0;
-            const u64 nvf = Sl + ((fin.ct_len + 15) >> 4) + 1;
+            const u64 nvf = 1 + ((fin.ct_len + 15) >> 4) + 1;
             const GPlan plf = plan_for(nvf);
-            GSrc front = msg;                           /* [AAD][head] in front of the middle */
+            GSrc front = msg;                           /* [AAD][head] in front of the striped region */
             front.ct_len = h0 * 16; front.has_len = 0;
             switch (nr) {
             case 10: rc = launch_setup<10>(st, tb, ek, j0, sc, plf, 0, z, 0, logF); break;
@@ -698,11 +817,10 @@ extern "C" int uaesk_gcm(void *stream, const uaesk_tables *tb, int nr, const uae
             default: return (int)hipErrorInvalidValue;
             }
             if (rc) return rc;
-            const u64 g_lo = c0 ? 1 : 0;
             switch (nr) {
-            case 10: rc = launch_fused<10>(st, tb, ek, &c, in, out, (unsigned)cus, g_lo, iters, h1, nfull, (u32)(len % 16), front, ablk + h0, sc); break;
-            case 12: rc = launch_fused<12>(st, tb, ek, &c, in, out, (unsigned)cus, g_lo, iters, h1, nfull, (u32)(len % 16), front, ablk + h0, sc); break;
-            default: rc = launch_fused<14>(st, tb, ek, &c, in, out, (unsigned)cus, g_lo, iters, h1, nfull, (u32)(len % 16), front, ablk + h0, sc); break;
+            case 10: rc = launch_fused<10>(st, tb, ek, &c, in, out, (unsigned)cus, g_lo, n8, h1, nfull, (u32)(len % 16), front, ablk + h0, sc); break;
+            case 12: rc = launch_fused<12>(st, tb, ek, &c, in, out, (unsigned)cus, g_lo, n8, h1, nfull, (u32)(len % 16), front, ablk + h0, sc); break;
+            default: rc = launch_fused<14>(st, tb, ek, &c, in, out, (unsigned)cus, g_lo, n8, h1, nfull, (u32)(len % 16), front, ablk + h0, sc); break;
             }
             if (rc) return rc;
             return run_ghash_levels(st, fin, nvf, plf, sc, 0, (unsigned char *)out + len, nullptr);

@@ -612,15 +612,17 @@ def test_C3_xts256_sectors_device_resident(orc, golden_dir):
 @pytest.mark.parametrize("bits", [128, 192, 256])
 def test_gcm_fused_encrypt_pass(orc, bits):
     """Long GCM encryptions take the one-pass kernel (CTR + GHASH of the ciphertext in registers,
-    k_gcm_enc_fused): sizes around its thresholds (two rounds of 2^19 blocks + the head), ragged
-    tails, AAD of every shape (it becomes initial accumulator values), against the oracle and
-    against the two-pass decrypt (which re-hashes the ciphertext with the separate GHASH levels)."""
+    k_gcm_enc_fused): sizes around its threshold (one 32 KiB stripe per workgroup + the head),
+    stripe counts that do not divide by the grid (workgroups then differ by one stripe and weight
+    their shares differently), ragged tails, AAD of every shape (it becomes initial accumulator
+    values), against the oracle and against the two-pass decrypt (which re-hashes the ciphertext
+    with the separate GHASH levels)."""
     import torch
     rnd = random.Random(900 + bits)
     key, nonce = rnd.randbytes(bits // 8), rnd.randbytes(12)
     S16 = 16 << 19                                     # one round of the grid in bytes (8 MiB)
-    cases = [(2 * S16 + 254 * 16, 0), (2 * S16 + 254 * 16 - 16, 0), (2 * S16 + 254 * 16 + 16, 5), (3 * S16 + 12345, 13),
-             (2 * S16 + 5000, 16), (5 * S16 - 1, 4096 + 7), (2 * S16 + S16 // 2, 1 << 20)]
+    cases = [(S16 + 254 * 16, 0), (S16 + 254 * 16 - 16, 0), (S16 + 254 * 16 + 16, 5), (S16 + 5 * 32768 + 4064 + 7, 13),
+             (2 * S16 + 5000, 16), (3 * S16 - 1, 4096 + 7), (2 * S16 + S16 // 2, 1 << 20), (5 * S16 + 12345, 0)]
     for i, (n, alen) in enumerate(cases):
         pt = orc.splitmix(1000 + i, (n + 7) // 8 * 8)[:n]
         aad = rnd.randbytes(alen)
