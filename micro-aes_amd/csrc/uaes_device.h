@@ -25,6 +25,11 @@ typedef struct {
 typedef struct {
     const uint32_t *te0;   /* 256 words: bytes {2S,S,S,3S}[x]              */
     const uint32_t *td0;   /* 256 words: bytes {14Si,9Si,13Si,11Si}[x] (their XOR is Si[x]) */
+    /* GHASH: x -> x^(2^k) in GF(2^128) is GF(2)-linear with a matrix that depends on the field
+     * only.  frob[(k-1)*256 + 2p .. +1] = the (hi, lo) input mask of output bit p (p < 64: bit p of
+     * the big-endian high half, else bit p-64 of the low half), k = 1..63.  May be NULL (the
+     * setup kernel then squares k times).                                                     */
+    const uint64_t *frob;
 } uaesk_tables;
 
 /* 56-bit big-endian counter description (reference: incBlock with index 15
@@ -100,12 +105,12 @@ int uaesk_gcm_stream_tag(void *stream, void *scratch, int compare, void *tag_io,
  * POLYVAL(H, X) = rev(GHASH(mulX(rev(H)), rev(X_i)...)); hg_host must already be
  * mulX_GHASH(ByteReverse(H)); pv_out16 receives the RAW GHASH value (the caller
  * byte-reverses it).  Length block = LE64(aad bits) || LE64(pt bits).        */
-int uaesk_polyval(void *stream, const uint8_t *hg_host,
+int uaesk_polyval(void *stream, const uaesk_tables *tb, const uint8_t *hg_host,
                   const void *aad, size_t aad_len, const void *pt, size_t pt_len,
                   void *scratch, void *pv_out16);
 
 /* GHASH only: gh = GHASH_H(aad, ct) with H given (device), for tests.      */
-int uaesk_ghash(void *stream, const uint8_t *H_host,
+int uaesk_ghash(void *stream, const uaesk_tables *tb, const uint8_t *H_host,
                 const void *aad, size_t aad_len, const void *ct, size_t ct_len,
                 void *scratch, void *gh_out16);
 

@@ -93,6 +93,47 @@ static pthread_once_t tables_once = PTHREAD_ONCE_INIT;
 
 static uint8_t xtime(uint8_t a) { return (uint8_t)((a << 1) ^ ((a >> 7) * 0x1b)); }
 
+/* Frobenius matrices of GHASH's field (uaesk_tables.frob): rows of x -> x^(2^k), k = 1..63.
+ * Element = (hi, lo), coefficient of x^q at bit 127-q (hi bit 63 = x^0); times x = shift right,
+ * the bit falling off re-enters as 0xE1 << 120 (SP 800-38D; mulGF128, micro_aes.c:476-493).   */
+#define FROB_K 63
+static uint64_t h_frob[FROB_K * 256];
+
+static void gf128_mul(const uint64_t a[2], const uint64_t b[2], uint64_t z[2])
+{
+    uint64_t vh = b[0], vl = b[1], zh = 0, zl = 0;
+    int q;
+    for (q = 0; q < 128; ++q) {
+        const uint64_t bit = q < 64 ? (a[0] >> (63 - q)) & 1 : (a[1] >> (127 - q)) & 1;
+        const uint64_t m = 0 - bit, carry = vl & 1;
+        zh ^= vh & m;
+        zl ^= vl & m;
+        vl = (vl >> 1) | (vh << 63);
+        vh = (vh >> 1) ^ (carry ? 0xE100000000000000ull : 0);
+    }
+    z[0] = zh; z[1] = zl;
+}
+
+static void build_frobenius(void)
+{
+    static uint64_t col[128][2];           /* image of basis bit j (position j: < 64 = hi bit j, else lo bit j-64) */
+    int j, k, p;
+    for (j = 0; j < 128; ++j) { col[j][0] = j < 64 ? 1ull << j : 0; col[j][1] = j < 64 ? 0 : 1ull << (j - 64); }
+    for (k = 1; k <= FROB_K; ++k) {
+        uint64_t *rows = h_frob + (size_t)(k - 1) * 256;
+        for (j = 0; j < 128; ++j) {
+            uint64_t sq[2];
+            gf128_mul(col[j], col[j], sq);
+            col[j][0] = sq[0]; col[j][1] = sq[1];
+        }
+        memset(rows, 0, 256 * sizeof *rows);
+        for (j = 0; j < 128; ++j)
+            for (p = 0; p < 128; ++p)
+                if ((p < 64 ? col[j][0] >> p : col[j][1] >> (p - 64)) & 1)
+                    rows[2 * p + (j >= 64)] |= 1ull << (j & 63);
+    }
+}
+
 static void build_host_tables(void)
 {
     uint8_t alog[256], logt[256];
@@ -123,6 +164,7 @@ static void build_host_tables(void)
         h_te0[i] = (uint32_t)s2 | ((uint32_t)s << 8) | ((uint32_t)s << 16) | ((uint32_t)s3 << 24);
         h_td0[i] = (uint32_t)ve | ((uint32_t)v9 << 8) | ((uint32_t)vd << 16) | ((uint32_t)vb << 24);
     }
+    build_frobenius();
 }
 
 /* ------------------------------------------------------------------------ */
@@ -257,15 +299,17 @@ static int get_context(context **out)
         if (!c->ready) {
             hipError_t err;
             pthread_once(&tables_once, build_host_tables);
-            err = hipMalloc(&c->d_tables, 3 * 1024 + 64);
+            err = hipMalloc(&c->d_tables, 4096 + sizeof h_frob);
             if (err == hipSuccess) err = hipMemcpy(c->d_tables, h_te0, 1024, hipMemcpyHostToDevice);
             if (err == hipSuccess) err = hipMemcpy((char *)c->d_tables + 1024, h_td0, 1024, hipMemcpyHostToDevice);
+            if (err == hipSuccess) err = hipMemcpy((char *)c->d_tables + 4096, h_frob, sizeof h_frob, hipMemcpyHostToDevice);
             if (err != hipSuccess) {
                 pthread_mutex_unlock(&g_init_mu);
                 return fail(UAES_E_HIP, "context setup failed: %s", hipGetErrorString(err));
             }
             c->tb.te0 = (const uint32_t *)c->d_tables;
             c->tb.td0 = (const uint32_t *)((char *)c->d_tables + 1024);
+            c->tb.frob = (const uint64_t *)((char *)c->d_tables + 4096);
             c->d_status = (int *)((char *)c->d_tables + 3072);
             pthread_mutex_init(&c->mu, NULL);
             pthread_cond_init(&c->cv, NULL);
@@ -1090,7 +1134,7 @@ int uaes_ghash(const uint8_t H[16], const void *aData, size_t aDataLen,
         if ((rc = gcm_scratch(c)) != 0) break;
         if ((rc = stage_aad(c, aData, aDataLen, &d_aad)) != 0) break;
         if ((rc = plan_io(c, crtxt, crtxtLen, NULL, 0, &io)) != 0) break;
-        int k = uaesk_ghash(NULL, H, d_aad, aDataLen, io.din, crtxtLen, c->scratch, c->d_status + 4);
+        int k = uaesk_ghash(NULL, &c->tb, H, d_aad, aDataLen, io.din, crtxtLen, c->scratch, c->d_status + 4);
         if (k) { rc = fail(UAES_E_HIP, "ghash launch: %s", hipGetErrorString((hipError_t)k)); break; }
         hipError_t e = hipMemcpy(gh, c->d_status + 4, 16, hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = fail(UAES_E_HIP, "ghash run: %s", hipGetErrorString(e));
@@ -1348,7 +1392,7 @@ static int gcmsiv_tag(context *c, const sivkeys *k, const uint8_t *nonce,
     uint8_t s[16];
     int i;
     uint8_t *slot = (uint8_t *)(c->d_status + 4);
-    KCHK(uaesk_polyval(NULL, k->hg, d_aad, aad_len, d_pt, len, c->scratch, slot));
+    KCHK(uaesk_polyval(NULL, &c->tb, k->hg, d_aad, aad_len, d_pt, len, c->scratch, slot));
     HIPCHK(hipMemcpy(s, slot, 16, hipMemcpyDeviceToHost));
     rev16_bytes(s);
     for (i = 0; i < 12; ++i) s[i] ^= nonce[i];

@@ -414,10 +414,38 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_setup(uaesk_rk ek, uaesk_tables
     }
     __syncthreads();
 
-    if (threadIdx.x < 64) {                    /* squaring chain, wave 0 */
+    const u32 last = want_pow64 ? 63u : maxlog;              /* the highest power any requested table needs */
+    if (tb.frob) {
+        /* H^(2^k) = F^k H: squaring is the Frobenius map, linear over GF(2) with a matrix that depends on
+         * the field only, so every power is ONE bit-matrix product with a constant (two parities per
+         * lane, two ballots per wave) instead of k dependent multiplications; the waves take different k */
+        uint4 *g64 = (uint4 *)(scratch + GS_POW64);
+        const Gf h = shPow[0];
+        const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+        if (threadIdx.x == 0 && want_pow64) {
+            u32 w[4];
+            gf_to_words(h, w);
+            g64[0] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        for (u32 k = wave + 1; k <= last; k += UAES_WG / 64) {
+            const uint64_t *rows = tb.frob + (u64)(k - 1) * 256u;
+            const u32 b0 = (u32)(__popcll(rows[2 * lane] & h.hi) + __popcll(rows[2 * lane + 1] & h.lo)) & 1u;
+            const u32 b1 = (u32)(__popcll(rows[128 + 2 * lane] & h.hi) + __popcll(rows[128 + 2 * lane + 1] & h.lo)) & 1u;
+            Gf p;
+            p.hi = __ballot(b0);
+            p.lo = __ballot(b1);
+            if (lane == 0) {
+                if (k <= GF_MAXLOG) shPow[k] = p;
+                if (want_pow64) {
+                    u32 w[4];
+                    gf_to_words(p, w);
+                    g64[k] = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+            }
+        }
+    } else if (threadIdx.x < 64) {             /* no matrices: squaring chain, wave 0 */
         Gf p = shPow[0];
         uint4 *g64 = (uint4 *)(scratch + GS_POW64);
-        const u32 last = want_pow64 ? 63u : maxlog;          /* the highest power any requested table needs */
         for (u32 k = 0; k <= last; ++k) {
             if (k) p = wave_gfmul(p, p, threadIdx.x);
             if (threadIdx.x == 0) {
@@ -846,7 +874,7 @@ extern "C" int uaesk_gcm(void *stream, const uaesk_tables *tb, int nr, const uae
     return uaesk_ctr_xcrypt(stream, tb, nr, ek, &c, in, out, len, status);
 }
 
-extern "C" int uaesk_ghash(void *stream, const uint8_t *H_host,
+extern "C" int uaesk_ghash(void *stream, const uaesk_tables *tb, const uint8_t *H_host,
                            const void *aad, size_t aad_len, const void *ct, size_t ct_len,
                            void *scratch, void *gh_out16)
 {
@@ -861,9 +889,8 @@ extern "C" int uaesk_ghash(void *stream, const uint8_t *H_host,
     uint4 h;
     memcpy(&h, H_host, 16);
     uaesk_rk dummy_rk;
-    uaesk_tables dummy_tb = { nullptr, nullptr };
     memset(&dummy_rk, 0, sizeof dummy_rk);
-    int rc = launch_setup<10>(st, &dummy_tb, &dummy_rk, make_uint4(0, 0, 0, 0), sc, pl, 1, h);
+    int rc = launch_setup<10>(st, tb, &dummy_rk, make_uint4(0, 0, 0, 0), sc, pl, 1, h);
     if (rc) return rc;
     return run_ghash_levels(st, msg, nv, pl, sc, 2, (unsigned char *)gh_out16, nullptr);
 }
@@ -1050,7 +1077,7 @@ extern "C" int uaesk_gcm_stream_tag(void *stream, void *scratch, int compare, vo
     return (int)hipGetLastError();
 }
 
-extern "C" int uaesk_polyval(void *stream, const uint8_t *hg_host,
+extern "C" int uaesk_polyval(void *stream, const uaesk_tables *tb, const uint8_t *hg_host,
                              const void *aad, size_t aad_len, const void *pt, size_t pt_len,
                              void *scratch, void *pv_out16)
 {
@@ -1065,9 +1092,8 @@ extern "C" int uaesk_polyval(void *stream, const uint8_t *hg_host,
     uint4 h;
     memcpy(&h, hg_host, 16);
     uaesk_rk dummy_rk;
-    uaesk_tables dummy_tb = { nullptr, nullptr };
     memset(&dummy_rk, 0, sizeof dummy_rk);
-    int rc = launch_setup<10>(st, &dummy_tb, &dummy_rk, make_uint4(0, 0, 0, 0), sc, pl, 1, h);
+    int rc = launch_setup<10>(st, tb, &dummy_rk, make_uint4(0, 0, 0, 0), sc, pl, 1, h);
     if (rc) return rc;
     return run_ghash_levels(st, msg, nv, pl, sc, 2, (unsigned char *)pv_out16, nullptr);
 }
