@@ -63,7 +63,9 @@ enum constant_parameters_of_modes
     CTR_IV_LENGTH   = 12,
     CCM_NONCE_LEN   = 11,
     CCM_TAG_LEN     = 16,
+#ifndef GCM_NONCE_LEN      /* micro_aes.h:108; a caller built with -DGCM_NONCE_LEN=n gets J0 = GHASH(nonce) (see below) */
     GCM_NONCE_LEN   = 12,
+#endif
     GCM_TAG_LEN     = 16,
     OCB_NONCE_LEN   = 12,
     OCB_TAG_LEN     = 16,
@@ -116,6 +118,19 @@ void AES_GCM_encrypt(const uint8_t *key, const uint8_t *nonce,
 char AES_GCM_decrypt(const uint8_t *key, const uint8_t *nonce,
                      const void *aData, const size_t aDataLen,
                      const void *crtxt, const size_t crtxtLen, void *pntxt);
+/* GCM_NONCE_LEN is a compile-time constant of the CALLER's build in the reference; with any value
+ * but 12 GCMsetup derives J0 = GHASH(nonce) (micro_aes.c:1145-1149).  Every library exports the
+ * general entry points and a caller built with -DGCM_NONCE_LEN=n is bound to them:              */
+void AES_GCM_encrypt_ivlen(const size_t nonceLen, const uint8_t *key, const uint8_t *nonce,
+                           const void *aData, const size_t aDataLen,
+                           const void *pntxt, const size_t ptextLen, void *crtxt);
+char AES_GCM_decrypt_ivlen(const size_t nonceLen, const uint8_t *key, const uint8_t *nonce,
+                           const void *aData, const size_t aDataLen,
+                           const void *crtxt, const size_t crtxtLen, void *pntxt);
+#ifdef GCM_NONCE_LEN
+#define AES_GCM_encrypt(k, n, a, al, p, pl, c) AES_GCM_encrypt_ivlen(GCM_NONCE_LEN, k, n, a, al, p, pl, c)
+#define AES_GCM_decrypt(k, n, a, al, c, cl, p) AES_GCM_decrypt_ivlen(GCM_NONCE_LEN, k, n, a, al, c, cl, p)
+#endif
 
 char AES_CBC_encrypt(const uint8_t *key, const uint8_t iVec[16],
                      const void *pntxt, const size_t ptextLen, void *crtxt);

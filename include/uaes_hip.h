@@ -135,6 +135,16 @@ int uaes_gcm_encrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
 int uaes_gcm_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
                      const void *aData, size_t aDataLen,
                      const void *crtxt, size_t crtxtLen, void *pntxt);
+/* The same with a nonce of any length >= 1 -- the reference's compile-time GCM_NONCE_LEN
+ * (micro_aes.h:108): 12 is the default above; otherwise J0 = GHASH_H(nonce) (GCMsetup,
+ * micro_aes.c:1145-1149), and the keystream steps it with the reference's 56-bit incBlock.
+ * J0 is computed on the GPU and read back (16 bytes), so these are synchronous calls.      */
+int uaes_gcm_encrypt_iv(int keybits, const uint8_t *key, const uint8_t *nonce, size_t nonceLen,
+                        const void *aData, size_t aDataLen,
+                        const void *pntxt, size_t ptextLen, void *crtxt);
+int uaes_gcm_decrypt_iv(int keybits, const uint8_t *key, const uint8_t *nonce, size_t nonceLen,
+                        const void *aData, size_t aDataLen,
+                        const void *crtxt, size_t crtxtLen, void *pntxt);
 /* GHASH_H(aData, crtxt) of micro_aes.c:1127-1137 with an explicit H (test
  * hook for the carry-less-multiply kernels); gh receives 16 bytes.           */
 int uaes_ghash(const uint8_t H[16], const void *aData, size_t aDataLen,

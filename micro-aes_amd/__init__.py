@@ -36,7 +36,7 @@ EXPORTS = [
     "uaes_set_wipe_on_auth_failure",
     "uaes_ecb_encrypt", "uaes_ecb_encrypt_padded", "uaes_ecb_decrypt", "uaes_ctr_xcrypt", "uaes_ctr_xcrypt_at",
     "uaes_xts_encrypt", "uaes_xts_decrypt", "uaes_xts_sectors",
-    "uaes_gcm_encrypt", "uaes_gcm_decrypt", "uaes_ghash",
+    "uaes_gcm_encrypt", "uaes_gcm_decrypt", "uaes_gcm_encrypt_iv", "uaes_gcm_decrypt_iv", "uaes_ghash",
     "uaes_cmac", "uaes_ccm_encrypt", "uaes_ccm_decrypt", "uaes_gcmsiv_encrypt", "uaes_gcmsiv_decrypt",
     "uaes_ocb_encrypt", "uaes_ocb_decrypt", "uaes_ocb_dev",
     "uaes_mgpu_ctr_xcrypt_at", "uaes_mgpu_xts_sectors",
@@ -49,6 +49,7 @@ COMPAT_EXPORTS = [
     "AES_ECB_encrypt", "AES_ECB_encrypt_pkcs7", "AES_ECB_encrypt_iso7816", "AES_ECB_decrypt",
     "AES_CTR_encrypt", "AES_CTR_decrypt", "uaes_compat_set_failure_handler",
     "AES_XTS_encrypt", "AES_XTS_decrypt", "AES_GCM_encrypt", "AES_GCM_decrypt",
+    "AES_GCM_encrypt_ivlen", "AES_GCM_decrypt_ivlen",
     "AES_CCM_encrypt", "AES_CCM_decrypt", "AES_CMAC", "GCM_SIV_encrypt", "GCM_SIV_decrypt",
     "AES_OCB_encrypt", "AES_OCB_decrypt",
     "AES_CBC_encrypt", "AES_CBC_decrypt", "AES_CFB_encrypt", "AES_CFB_decrypt", "AES_OFB_encrypt", "AES_OFB_decrypt",
@@ -109,6 +110,8 @@ def engine():
     L.uaes_xts_sectors.argtypes = [i, vp, u64, sz, sz, vp, vp, i]
     for n in ("uaes_gcm_encrypt", "uaes_gcm_decrypt"):
         getattr(L, n).argtypes = [i, vp, vp, vp, sz, vp, sz, vp]
+    for n in ("uaes_gcm_encrypt_iv", "uaes_gcm_decrypt_iv"):
+        getattr(L, n).argtypes = [i, vp, vp, sz, vp, sz, vp, sz, vp]
     L.uaes_ghash.argtypes = [vp, vp, sz, vp, sz, vp]
     L.uaes_cmac.argtypes = [i, vp, vp, sz, vp]
     for n in ("uaes_cbc_encrypt", "uaes_cbc_decrypt", "uaes_cfb_encrypt", "uaes_cfb_decrypt", "uaes_ofb_xcrypt"):
@@ -238,10 +241,13 @@ def xts_sectors(keys, first_sector, sector_bytes, data, encrypt=True):
 
 
 def AES_GCM_encrypt(key, nonce, aData, pntxt):
-    """micro_aes.c:1164.  Returns ciphertext || 16-byte tag."""
+    """micro_aes.c:1164.  Returns ciphertext || 16-byte tag.  len(nonce) is the reference's
+    GCM_NONCE_LEN: 12 by default, any other length >= 1 derives J0 = GHASH(nonce) (:1145-1149)."""
+    if len(nonce) < 1:
+        raise ValueError("empty nonce")
     o = _out(len(pntxt) + 16)
-    _check(engine().uaes_gcm_encrypt(_bits(key), _in(key), _fixed(nonce, 12, "nonce"), _in(aData), len(aData),
-                                     _in(pntxt), len(pntxt), o), "AES_GCM_encrypt")
+    _check(engine().uaes_gcm_encrypt_iv(_bits(key), _in(key), _in(nonce), len(nonce), _in(aData), len(aData),
+                                        _in(pntxt), len(pntxt), o), "AES_GCM_encrypt")
     return bytes(o)[: len(pntxt) + 16]
 
 
@@ -250,8 +256,10 @@ def AES_GCM_decrypt(key, nonce, aData, crtxt_and_tag, prefill=0):
     (prefilled) buffer when authentication fails."""
     n = len(crtxt_and_tag) - 16
     o = _out(n, prefill)
-    rc = _check(engine().uaes_gcm_decrypt(_bits(key), _in(key), _fixed(nonce, 12, "nonce"), _in(aData), len(aData),
-                                          _in(crtxt_and_tag), n, o), "AES_GCM_decrypt")
+    if len(nonce) < 1:
+        raise ValueError("empty nonce")
+    rc = _check(engine().uaes_gcm_decrypt_iv(_bits(key), _in(key), _in(nonce), len(nonce), _in(aData), len(aData),
+                                             _in(crtxt_and_tag), n, o), "AES_GCM_decrypt")
     return rc, bytes(o)[:n]
 
 

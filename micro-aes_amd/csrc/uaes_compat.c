@@ -94,6 +94,23 @@ char AES_XTS_decrypt(const uint8_t *keys, const uint8_t *tweak,
     return soft("AES_XTS_decrypt", uaes_xts_decrypt(KB, keys, tweak, crtxt, crtxtLen, pntxt), M_DECRYPTION_ERROR);
 }
 
+#undef AES_GCM_encrypt
+#undef AES_GCM_decrypt
+void AES_GCM_encrypt_ivlen(const size_t nonceLen, const uint8_t *key, const uint8_t *nonce,
+                           const void *aData, const size_t aDataLen,
+                           const void *pntxt, const size_t ptextLen, void *crtxt)
+{
+    must("AES_GCM_encrypt", uaes_gcm_encrypt_iv(KB, key, nonce, nonceLen, aData, aDataLen, pntxt, ptextLen, crtxt));
+}
+
+char AES_GCM_decrypt_ivlen(const size_t nonceLen, const uint8_t *key, const uint8_t *nonce,
+                           const void *aData, const size_t aDataLen,
+                           const void *crtxt, const size_t crtxtLen, void *pntxt)
+{
+    return soft("AES_GCM_decrypt", uaes_gcm_decrypt_iv(KB, key, nonce, nonceLen, aData, aDataLen, crtxt, crtxtLen, pntxt),
+                M_DECRYPTION_ERROR);
+}
+
 void AES_GCM_encrypt(const uint8_t *key, const uint8_t *nonce,
                      const void *aData, const size_t aDataLen,
                      const void *pntxt, const size_t ptextLen, void *crtxt)

@@ -71,14 +71,18 @@ int uaesk_xts(void *stream, const uaesk_tables *tb, int nr,
               size_t sector_bytes, size_t nsectors,
               const void *in, void *out, void *scratch);
 
-/* GCM.  All pointers are device pointers except nonce12 (host).
+/* GCM.  All pointers are device pointers except j0_16 (host): the initial counter block J0 =
+ * nonce || 00000001 for a 12-byte nonce, else the 16 bytes uaesk_gcm_j0 computed (GHASH of the
+ * nonce, micro_aes.c:1145-1149).
  * scratch must hold uaesk_gcm_scratch_bytes().  encrypt: CTR then GHASH, tag
  * written at out+len.  decrypt: GHASH over in[0..len), compare with the tag
  * at in+len, *status = 0 / 0x1A, CTR gated on *status.                     */
 size_t uaesk_gcm_scratch_bytes(void);
 size_t uaesk_gcm_stream_scratch_bytes(void);     /* what the streamed API needs (no fused-pass buffers) */
+int uaesk_gcm_j0(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek,
+                 const void *d_iv, size_t iv_len, void *scratch, void *j0_out16);
 int uaesk_gcm(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek,
-              int decrypt, const uint8_t *nonce12,
+              int decrypt, const uint8_t *j0_16,
               const void *aad, size_t aad_len,
               const void *in, size_t len, void *out,
               void *scratch, int *status);

@@ -1000,14 +1000,37 @@ static int stage_aad(context *c, const void *aad, size_t aad_len, const void **d
     return 0;
 }
 
-int uaes_gcm_encrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
-                     const void *aData, size_t aDataLen,
-                     const void *pntxt, size_t ptextLen, void *crtxt)
+/* J0 (GCMsetup, micro_aes.c:1140-1152): nonce || 00000001 for the default 12-byte nonce; for any
+ * other length GHASH_H(nonce) computed on the GPU and read back (16 bytes; the counter arithmetic of
+ * every kernel is a launch argument).  Caller holds c->mu and has c->scratch.                    */
+static void j0_of_nonce12(const uint8_t *nonce, uint8_t j0[16])
+{
+    memcpy(j0, nonce, 12);
+    j0[12] = j0[13] = j0[14] = 0;
+    j0[15] = 1;
+}
+
+static int gcm_j0(context *c, keysched *ks, const uint8_t *nonce, size_t nonce_len, uint8_t j0[16])
+{
+    const void *d_iv;
+    int rc;
+    if (nonce_len == 12) { j0_of_nonce12(nonce, j0); return 0; }
+    if (nonce_len == 0) return fail(UAES_E_ARG, "empty GCM nonce");
+    if ((rc = stage_aad(c, nonce, nonce_len, &d_iv)) != 0) return rc;
+    KCHK(uaesk_gcm_j0(NULL, &c->tb, ks->nr, &ks->ek, d_iv, nonce_len, c->scratch, c->d_status + 4));
+    HIPCHK(hipMemcpy(j0, c->d_status + 4, 16, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int uaes_gcm_encrypt_iv(int keybits, const uint8_t *key, const uint8_t *nonce, size_t nonceLen,
+                        const void *aData, size_t aDataLen,
+                        const void *pntxt, size_t ptextLen, void *crtxt)
 {
     context *c;
     keysched ks;
     io_plan io;
     const void *d_aad;
+    uint8_t j0[16];
     int rc;
     if ((rc = expand_key(&ks, key, keybits)) != 0) return rc;
     if (!nonce || !crtxt || (ptextLen && !pntxt)) return fail(UAES_E_ARG, "NULL pointer");
@@ -1015,9 +1038,10 @@ int uaes_gcm_encrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
     LOCKED_BEGIN(c);
     do {
         if ((rc = gcm_scratch(c)) != 0) break;
+        if ((rc = gcm_j0(c, &ks, nonce, nonceLen, j0)) != 0) break;
         if ((rc = stage_aad(c, aData, aDataLen, &d_aad)) != 0) break;
         if ((rc = plan_io(c, pntxt, ptextLen, crtxt, ptextLen + 16, &io)) != 0) break;
-        int k = uaesk_gcm(NULL, &c->tb, ks.nr, &ks.ek, 0, nonce, d_aad, aDataLen,
+        int k = uaesk_gcm(NULL, &c->tb, ks.nr, &ks.ek, 0, j0, d_aad, aDataLen,
                           io.din, ptextLen, io.dout, c->scratch, NULL);
         if (k) { rc = fail(UAES_E_HIP, "gcm launch: %s", hipGetErrorString((hipError_t)k)); break; }
         rc = finish_io(&io, ptextLen + 16);
@@ -1025,14 +1049,22 @@ int uaes_gcm_encrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
     LOCKED_END(c, rc);
 }
 
-int uaes_gcm_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
+int uaes_gcm_encrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
                      const void *aData, size_t aDataLen,
-                     const void *crtxt, size_t crtxtLen, void *pntxt)
+                     const void *pntxt, size_t ptextLen, void *crtxt)
+{
+    return uaes_gcm_encrypt_iv(keybits, key, nonce, 12, aData, aDataLen, pntxt, ptextLen, crtxt);
+}
+
+int uaes_gcm_decrypt_iv(int keybits, const uint8_t *key, const uint8_t *nonce, size_t nonceLen,
+                        const void *aData, size_t aDataLen,
+                        const void *crtxt, size_t crtxtLen, void *pntxt)
 {
     context *c;
     keysched ks;
     io_plan io;
     const void *d_aad;
+    uint8_t j0[16];
     int rc, status = -1;
     if ((rc = expand_key(&ks, key, keybits)) != 0) return rc;
     if (!nonce || !crtxt || (crtxtLen && !pntxt)) return fail(UAES_E_ARG, "NULL pointer");
@@ -1040,6 +1072,7 @@ int uaes_gcm_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
     LOCKED_BEGIN(c);
     do {
         if ((rc = gcm_scratch(c)) != 0) break;
+        if ((rc = gcm_j0(c, &ks, nonce, nonceLen, j0)) != 0) break;
         if ((rc = stage_aad(c, aData, aDataLen, &d_aad)) != 0) break;
         /* input is CT || tag; output is crtxtLen bytes */
         if ((rc = plan_io(c, crtxt, crtxtLen + 16, pntxt, crtxtLen, &io)) != 0) break;
@@ -1049,7 +1082,7 @@ int uaes_gcm_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
             if (grow(&c->stage[1], &c->stage_cap[1], crtxtLen + 64)) { rc = UAES_E_HIP; break; }
             io.dout = c->stage[1];
         }
-        int k = uaesk_gcm(NULL, &c->tb, ks.nr, &ks.ek, 1, nonce, d_aad, aDataLen,
+        int k = uaesk_gcm(NULL, &c->tb, ks.nr, &ks.ek, 1, j0, d_aad, aDataLen,
                           io.din, crtxtLen, io.dout, c->scratch, c->d_status);
         if (k) { rc = fail(UAES_E_HIP, "gcm launch: %s", hipGetErrorString((hipError_t)k)); break; }
         hipError_t e = hipMemcpy(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost);
@@ -1060,6 +1093,13 @@ int uaes_gcm_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
     LOCKED_END(c, rc);
 }
 
+int uaes_gcm_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
+                     const void *aData, size_t aDataLen,
+                     const void *crtxt, size_t crtxtLen, void *pntxt)
+{
+    return uaes_gcm_decrypt_iv(keybits, key, nonce, 12, aData, aDataLen, crtxt, crtxtLen, pntxt);
+}
+
 int uaes_gcm_encrypt_dev(int keybits, const uint8_t *key, const uint8_t *nonce,
                          const void *d_aad, size_t aad_len,
                          const void *d_in, size_t len, void *d_out, void *stream)
@@ -1067,13 +1107,15 @@ int uaes_gcm_encrypt_dev(int keybits, const uint8_t *key, const uint8_t *nonce,
     context *c;
     keysched ks;
     void *scr;
+    uint8_t j0[16];
     int rc, slot;
     if ((rc = expand_key(&ks, key, keybits)) != 0) return rc;
     if (!nonce || !d_out) return fail(UAES_E_ARG, "NULL pointer");
     if ((rc = dev_ptrs_ok(d_in, d_out, len)) != 0) return rc;
     if ((rc = get_context(&c)) != 0) return rc;
     if ((rc = gcm_scratch_locked(c, stream, &scr, &slot)) != 0) return rc;
-    KCHK_PINNED(c, slot, uaesk_gcm(stream, &c->tb, ks.nr, &ks.ek, 0, nonce, d_aad, aad_len, d_in, len, d_out,
+    j0_of_nonce12(nonce, j0);
+    KCHK_PINNED(c, slot, uaesk_gcm(stream, &c->tb, ks.nr, &ks.ek, 0, j0, d_aad, aad_len, d_in, len, d_out,
                                    scr, NULL));
     return 0;
 }
@@ -1086,6 +1128,7 @@ int uaes_gcm_decrypt_dev(int keybits, const uint8_t *key, const uint8_t *nonce,
     context *c;
     keysched ks;
     void *scr;
+    uint8_t j0[16];
     int rc, slot;
     if ((rc = expand_key(&ks, key, keybits)) != 0) return rc;
     if (!nonce || !d_in) return fail(UAES_E_ARG, "NULL pointer");
@@ -1093,7 +1136,8 @@ int uaes_gcm_decrypt_dev(int keybits, const uint8_t *key, const uint8_t *nonce,
     if (!d_status) return fail(UAES_E_ARG, "NULL d_status");
     if ((rc = get_context(&c)) != 0) return rc;
     if ((rc = gcm_scratch_locked(c, stream, &scr, &slot)) != 0) return rc;
-    KCHK_PINNED(c, slot, uaesk_gcm(stream, &c->tb, ks.nr, &ks.ek, 1, nonce, d_aad, aad_len, d_in, len, d_out,
+    j0_of_nonce12(nonce, j0);
+    KCHK_PINNED(c, slot, uaesk_gcm(stream, &c->tb, ks.nr, &ks.ek, 1, j0, d_aad, aad_len, d_in, len, d_out,
                                    scr, d_status));
     return 0;
 }

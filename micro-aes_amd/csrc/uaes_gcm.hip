@@ -782,19 +782,45 @@ static int launch_setup(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *
     return (int)hipGetLastError();
 }
 
+/* J0 of a nonce whose length is not 12 bytes (GCMsetup's first branch, micro_aes.c:1145-1149):
+ * gHash(H, no AAD, nonce) = GHASH(nonce zero padded || [0]_64 || [8 len]_64), raw, to j0_out16
+ * (device).  d_iv = the nonce in device memory.                                            */
+extern "C" int uaesk_gcm_j0(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek,
+                            const void *d_iv, size_t iv_len, void *scratch, void *j0_out16)
+{
+    hipStream_t st = S(stream);
+    unsigned char *sc = (unsigned char *)scratch;
+    GSrc msg;
+    msg.aad = nullptr; msg.aad_len = 0;
+    msg.ct = (const unsigned char *)d_iv; msg.ct_len = iv_len;
+    msg.has_len = 1; msg.len_aad = 0; msg.len_ct = iv_len; msg.rev = 0;
+    const u64 nv = ((iv_len + 15) >> 4) + 1;
+    const GPlan pl = plan_for(nv);
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    int rc;
+    switch (nr) {
+    case 10: rc = launch_setup<10>(st, tb, ek, z, sc, pl, 0, z); break;
+    case 12: rc = launch_setup<12>(st, tb, ek, z, sc, pl, 0, z); break;
+    case 14: rc = launch_setup<14>(st, tb, ek, z, sc, pl, 0, z); break;
+    default: return (int)hipErrorInvalidValue;
+    }
+    if (rc) return rc;
+    return run_ghash_levels(st, msg, nv, pl, sc, 2, (unsigned char *)j0_out16, nullptr);
+}
+
 extern "C" int uaesk_gcm(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek,
-                         int decrypt, const uint8_t *nonce12,
+                         int decrypt, const uint8_t *j0_16,
                          const void *aad, size_t aad_len,
                          const void *in, size_t len, void *out,
                          void *scratch, int *status)
 {
     hipStream_t st = S(stream);
     unsigned char *sc = (unsigned char *)scratch;
-    /* J0 = nonce || 00000001 (GCMsetup, micro_aes.c:1150-1151) */
+    /* J0 = nonce || 00000001 for the 12-byte nonce (GCMsetup, micro_aes.c:1150-1151), or
+     * GHASH(nonce) (uaesk_gcm_j0); the host layer passes the 16 bytes                     */
     uint4 j0;
     unsigned char j0b[16];
-    memcpy(j0b, nonce12, 12);
-    j0b[12] = j0b[13] = j0b[14] = 0; j0b[15] = 1;
+    memcpy(j0b, j0_16, 16);
     memcpy(&j0, j0b, 16);
     /* keystream counter starts at J0 + 1 (pre-increment, N4); the reference's
      * incBlock carries through bytes 15..9, so this is a 56-bit counter      */
@@ -803,7 +829,11 @@ extern "C" int uaesk_gcm(void *stream, const uaesk_tables *tb, int nr, const uae
     memcpy(&c.w0, j0b, 4);
     memcpy(&c.w1, j0b + 4, 4);
     c.b8 = j0b[8];
-    c.v0 = ((uint64_t)j0b[9] << 48) | ((uint64_t)j0b[10] << 40) | ((uint64_t)j0b[11] << 32) | 2u;
+    {
+        uint64_t v = 0;
+        for (int i = 9; i < 16; ++i) v = (v << 8) | j0b[i];
+        c.v0 = (v + 1) & 0x00FFFFFFFFFFFFFFull;
+    }
 
     GSrc msg;
     msg.aad = (const unsigned char *)aad; msg.aad_len = aad_len;

@@ -45,6 +45,8 @@ class Oracle:
         L = self.L = C.CDLL(path)
         sz, i, vp, u64 = C.c_size_t, C.c_int, C.c_void_p, C.c_uint64
         L.orc_ecb_encrypt.argtypes = [i, vp, vp, sz, vp]; L.orc_ecb_encrypt.restype = None
+        L.orc_gcm_encrypt_iv.argtypes = [i, vp, vp, sz, vp, sz, vp, sz, vp]; L.orc_gcm_encrypt_iv.restype = None
+        L.orc_gcm_decrypt_iv.argtypes = [i, vp, vp, sz, vp, sz, vp, sz, vp]; L.orc_gcm_decrypt_iv.restype = C.c_char
         L.orc_ecb_encrypt_padded.argtypes = [i, vp, i, vp, sz, vp]; L.orc_ecb_encrypt_padded.restype = None
         L.orc_ecb_decrypt.argtypes = [i, vp, vp, sz, vp]; L.orc_ecb_decrypt.restype = C.c_char
         L.orc_ctr_encrypt.argtypes = [i, vp, vp, vp, sz, vp]; L.orc_ctr_encrypt.restype = None
@@ -117,16 +119,17 @@ class Oracle:
         return ord(rc), bytes(o)[: len(data)]
 
     def gcm_encrypt(self, key, nonce, aad, pt):
+        """len(nonce) plays the role of the reference's GCM_NONCE_LEN (12 = default build)"""
         o = _out(len(pt) + 16)
-        self.L.orc_gcm_encrypt(len(key) * 8, _buf(key), _buf(nonce), _buf(aad), len(aad),
-                               _buf(pt), len(pt), o)
+        self.L.orc_gcm_encrypt_iv(len(key) * 8, _buf(key), _buf(nonce), len(nonce), _buf(aad), len(aad),
+                                  _buf(pt), len(pt), o)
         return bytes(o)[: len(pt) + 16]
 
     def gcm_decrypt(self, key, nonce, aad, ct_and_tag, prefill=0xCC):
         n = len(ct_and_tag) - 16
         o = (C.c_uint8 * max(n, 1))(*([prefill] * max(n, 1)))
-        rc = self.L.orc_gcm_decrypt(len(key) * 8, _buf(key), _buf(nonce), _buf(aad), len(aad),
-                                    _buf(ct_and_tag), n, o)
+        rc = self.L.orc_gcm_decrypt_iv(len(key) * 8, _buf(key), _buf(nonce), len(nonce), _buf(aad), len(aad),
+                                       _buf(ct_and_tag), n, o)
         return ord(rc), bytes(o)[:n]
 
     def cbc(self, key, iv, data, encrypt=True, prefill=0xCC):
@@ -219,18 +222,21 @@ class Reference:
     PAD_SUFFIX = {0: "", 1: "_pkcs7", 2: "_iso7816"}
 
     @classmethod
-    def path(cls, bits, padding=0):
-        return os.path.join(HERE, "_ref", "libmicroaes_ref_%d%s.so" % (bits, cls.PAD_SUFFIX[padding]))
+    def path(cls, bits, padding=0, gcm_nonce_len=12):
+        iv = "" if gcm_nonce_len == 12 else "_gcmiv%d" % gcm_nonce_len
+        return os.path.join(HERE, "_ref", "libmicroaes_ref_%d%s%s.so" % (bits, cls.PAD_SUFFIX[padding], iv))
 
     @classmethod
-    def available(cls, bits=128, padding=0):
-        return os.path.exists(cls.path(bits, padding))
+    def available(cls, bits=128, padding=0, gcm_nonce_len=12):
+        return os.path.exists(cls.path(bits, padding, gcm_nonce_len))
 
-    def __init__(self, bits, padding=0):
-        """padding: a build with AES_PADDING (micro_aes.h:79) patched to 1 / 2 (oracle/Makefile)"""
+    def __init__(self, bits, padding=0, gcm_nonce_len=12):
+        """padding / gcm_nonce_len: builds with AES_PADDING (micro_aes.h:79) / GCM_NONCE_LEN (:108)
+        patched (oracle/Makefile)"""
         self.bits = bits
         self.padding = padding
-        L = self.L = C.CDLL(self.path(bits, padding))
+        self.gcm_nonce_len = gcm_nonce_len
+        L = self.L = C.CDLL(self.path(bits, padding, gcm_nonce_len))
         sz, vp = C.c_size_t, C.c_void_p
         L.AES_ECB_encrypt.argtypes = [vp, vp, sz, vp]; L.AES_ECB_encrypt.restype = None
         L.AES_ECB_decrypt.argtypes = [vp, vp, sz, vp]; L.AES_ECB_decrypt.restype = C.c_char

@@ -402,24 +402,34 @@ void orc_ghash(const uint8_t H[16], const void *aad, size_t aad_len,
     ghash_absorb(H, lens, 16, gh);
 }
 
-static void gcm_setup(orc_key *ks, int keybits, const uint8_t *key,
-                      const uint8_t *nonce, uint8_t H[16], uint8_t J0[16])
+/* nonce_len = the reference's compile-time GCM_NONCE_LEN (micro_aes.h:108).  12 is the
+ * default; any other length takes GCMsetup's first branch (:1145-1149): the initial
+ * counter block is gHash(H, no AAD, the nonce) -- i.e. GHASH of the zero-padded nonce and
+ * the length block [0]_64 || [8 * nonce_len]_64, as SP 800-38D prescribes -- and the
+ * keystream then steps it with the SAME 56-bit incBlock as before (N2), not with inc32.   */
+static void gcm_setup_iv(orc_key *ks, int keybits, const uint8_t *key,
+                         const uint8_t *nonce, size_t nonce_len, uint8_t H[16], uint8_t J0[16])
 {
     orc_setkey(ks, key, keybits);
     memset(H, 0, 16);
     orc_encrypt_block(ks, H, H);               /* :1144                       */
+    if (nonce_len != 12) {
+        memset(J0, 0, 16);
+        orc_ghash(H, NULL, 0, nonce, nonce_len, J0);     /* :1147 */
+        return;
+    }
     memcpy(J0, nonce, 12);                     /* GCM_NONCE_LEN == 12, :1150  */
     J0[12] = J0[13] = J0[14] = 0;
     J0[15] = 1;
 }
 
-void orc_gcm_encrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
-                     const void *aad, size_t aad_len,
-                     const void *pt, size_t len, void *ct_and_tag)
+void orc_gcm_encrypt_iv(int keybits, const uint8_t *key, const uint8_t *nonce, size_t nonce_len,
+                        const void *aad, size_t aad_len,
+                        const void *pt, size_t len, void *ct_and_tag)
 {
     orc_key ks;
     uint8_t H[16], J0[16], c[16], G[16] = { 0 }, *out = (uint8_t *)ct_and_tag;
-    gcm_setup(&ks, keybits, key, nonce, H, J0);
+    gcm_setup_iv(&ks, keybits, key, nonce, nonce_len, H, J0);
     memcpy(c, J0, 16);
     ctr56_add(c, 1);                           /* N4: pre-increment, :939-941 */
     ctr_stream(&ks, c, (const uint8_t *)pt, len, out);
@@ -429,14 +439,21 @@ void orc_gcm_encrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
     memcpy(out + len, G, 16);
 }
 
-char orc_gcm_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
+void orc_gcm_encrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
                      const void *aad, size_t aad_len,
-                     const void *ct_and_tag, size_t len, void *pt)
+                     const void *pt, size_t len, void *ct_and_tag)
+{
+    orc_gcm_encrypt_iv(keybits, key, nonce, 12, aad, aad_len, pt, len, ct_and_tag);
+}
+
+char orc_gcm_decrypt_iv(int keybits, const uint8_t *key, const uint8_t *nonce, size_t nonce_len,
+                        const void *aad, size_t aad_len,
+                        const void *ct_and_tag, size_t len, void *pt)
 {
     orc_key ks;
     uint8_t H[16], J0[16], E[16], c[16], G[16] = { 0 };
     const uint8_t *in = (const uint8_t *)ct_and_tag;
-    gcm_setup(&ks, keybits, key, nonce, H, J0);
+    gcm_setup_iv(&ks, keybits, key, nonce, nonce_len, H, J0);
     orc_ghash(H, aad, aad_len, in, len, G);    /* N7: authenticate first      */
     orc_encrypt_block(&ks, J0, E);
     xor16(G, E);
@@ -445,6 +462,13 @@ char orc_gcm_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
     ctr56_add(c, 1);
     ctr_stream(&ks, c, in, len, (uint8_t *)pt);
     return ORC_OK;
+}
+
+char orc_gcm_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
+                     const void *aad, size_t aad_len,
+                     const void *ct_and_tag, size_t len, void *pt)
+{
+    return orc_gcm_decrypt_iv(keybits, key, nonce, 12, aad, aad_len, ct_and_tag, len, pt);
 }
 
 /* ------------------------------------------------------------------------ */

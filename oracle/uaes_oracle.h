@@ -86,6 +86,13 @@ void orc_gf128_mul(const uint8_t x[16], uint8_t y[16]);
 void orc_ghash(const uint8_t H[16], const void *aad, size_t aad_len,
                const void *ct, size_t ct_len, uint8_t gh[16]);
 /* micro_aes.c:1164-1212.  12-byte nonce, 16-byte tag appended at ct+len */
+/* nonce_len: the reference's compile-time GCM_NONCE_LEN; != 12 -> J0 = GHASH(nonce), micro_aes.c:1145-1149 */
+void orc_gcm_encrypt_iv(int keybits, const uint8_t *key, const uint8_t *nonce, size_t nonce_len,
+                        const void *aad, size_t aad_len,
+                        const void *pt, size_t len, void *ct_and_tag);
+char orc_gcm_decrypt_iv(int keybits, const uint8_t *key, const uint8_t *nonce, size_t nonce_len,
+                        const void *aad, size_t aad_len,
+                        const void *ct_and_tag, size_t len, void *pt);
 void orc_gcm_encrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
                      const void *aad, size_t aad_len,
                      const void *pt, size_t len, void *ct_and_tag);

@@ -19,7 +19,7 @@ import os
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def gcm_cases(keybits):
+def gcm_cases(keybits, iv_bytes=12):
     path = os.path.join(GOLDEN, "GcmEncryptExtIV%d.rsp" % keybits)
     hdr, cur, cases = {}, None, []
     with open(path) as f:
@@ -36,7 +36,7 @@ def gcm_cases(keybits):
                 elif cur is not None:
                     cur[k] = bytes.fromhex(v)
                     if k == "Tag":
-                        if (len(cur["Key"]) * 8 == keybits and len(cur["IV"]) == 12
+                        if (len(cur["Key"]) * 8 == keybits and len(cur["IV"]) == iv_bytes
                                 and len(cur["Tag"]) >= 16):
                             cases.append(cur)
                         cur = None

@@ -130,7 +130,8 @@ def test_python_wrappers_reject_wrong_sized_nonces():
     k = bytes(16)
     for call in (lambda: uaes.AES_CTR_encrypt(k, bytes(11), b"x"), lambda: uaes.AES_CTR_encrypt(k, bytes(16), b"x"),
                  lambda: uaes.ctr_xcrypt_at(k, bytes(12), 0, b"x"), lambda: uaes.AES_XTS_encrypt(bytes(32), bytes(8), bytes(16)),
-                 lambda: uaes.AES_GCM_encrypt(k, bytes(16), b"", b"x"), lambda: uaes.AES_GCM_decrypt(k, bytes(8), b"", bytes(17)),
+                 lambda: uaes.AES_GCM_encrypt(k, b"", b"", b"x"), lambda: uaes.AES_GCM_decrypt(k, b"", b"", bytes(17)),
+                 lambda: uaes.gcm_encrypt_dev(k, bytes(16), None, None, 0, None),
                  lambda: uaes.AES_CCM_encrypt(k, bytes(12), b"", b"x"), lambda: uaes.AES_OCB_encrypt(k, bytes(15), b"", b"x"),
                  lambda: uaes.GCM_SIV_encrypt(k, bytes(13), b"", b"x"), lambda: uaes.AES_CBC_encrypt(k, bytes(12), bytes(16)),
                  lambda: uaes.GcmStream(k, bytes(16)), lambda: uaes.ghash(bytes(15), b"", b"x"),

@@ -32,6 +32,25 @@ def test_reference_harness_runs_on_the_hip_library(bits, tmp_path, golden_dir):
     assert got == EXPECT[bits], r.stdout
 
 
+@pytest.mark.parametrize("exe,bits,want", [
+    ("harness_hip_128_gcmiv1", 128, {"CMAC": 96, "GCM": 375, "CCM": 10, "OCB": 16, "GCM-SIV": 102, "XTS": 800}),
+    ("harness_hip_256_gcmiv128", 256, {"CMAC": 96, "GCM": 375, "CCM": 10, "XTS": 600})])
+def test_reference_harness_with_other_gcm_nonce_lengths(exe, bits, want, tmp_path, golden_dir):
+    """the unchanged harness built with -DGCM_NONCE_LEN=1 / 128 picks the [IVlen = 8] / [IVlen = 1024]
+    sections of the NIST GCM files (aes_testvectors_GCM.h:86) and must pass all 375 on the HIP library"""
+    path = os.path.join(REF, exe)
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/%s was not built" % exe)
+    for f in os.listdir(golden_dir):
+        if f.endswith((".rsp", ".tv")):
+            os.symlink(os.path.join(golden_dir, f), tmp_path / f)
+    r = subprocess.run([path], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = dict((m, int(n)) for m, n in re.findall(
+        r"Verifying vectors: AES%d-([\w-]+)\s+Nmber of tests:\s*(\d+), All Passed!" % bits, r.stdout))
+    assert got == want, r.stdout
+
+
 @pytest.mark.parametrize("bits", [128, 192, 256])
 def test_reference_main_c_runs_on_the_hip_library(bits):
     exe = os.path.join(REF, "main_hip_%d" % bits)

@@ -78,6 +78,41 @@ def test_gcm_rsp_through_compat_api(bits):
         assert ord(rc) == 0 and bytes(pt)[:n] == c["PT"], c["Count"]
 
 
+@pytest.mark.parametrize("bits", [128, 192, 256])
+@pytest.mark.parametrize("iv_bytes", [1, 128])
+def test_gcm_rsp_other_nonce_lengths_through_compat_api(bits, iv_bytes):
+    """GCM_NONCE_LEN != 12 (J0 = GHASH(nonce), micro_aes.c:1145-1149): the NIST [IVlen = 8] and
+    [IVlen = 1024] sections through the entry points a caller built with -DGCM_NONCE_LEN=n binds to"""
+    cases = gcm_cases(bits, iv_bytes)
+    assert len(cases) == 375
+    L = Compat(bits)
+    for c in cases[::3]:
+        n = len(c["PT"])
+        out = L.buf(n + 16)
+        L.L.AES_GCM_encrypt_ivlen(C.c_size_t(iv_bytes), c["Key"], c["IV"], c["AAD"], C.c_size_t(len(c["AAD"])),
+                                  c["PT"], C.c_size_t(n), out)
+        assert bytes(out)[: n + 16] == c["CT"] + c["Tag"], c["Count"]
+        pt = L.buf(n)
+        L.L.AES_GCM_decrypt_ivlen.restype = C.c_char
+        rc = L.L.AES_GCM_decrypt_ivlen(C.c_size_t(iv_bytes), c["Key"], c["IV"], c["AAD"], C.c_size_t(len(c["AAD"])),
+                                       c["CT"] + c["Tag"], C.c_size_t(n), pt)
+        assert ord(rc) == 0 and bytes(pt)[:n] == c["PT"], c["Count"]
+
+
+def test_gcm_nonce_lengths_vs_oracle(orc):
+    """nonces of 1..128 bytes over sizes up to the one-pass kernel's range; a flipped nonce bit fails"""
+    rnd = random.Random(2024)
+    for nl, n in ((1, 100), (8, 0), (11, 4096), (13, 70001), (16, (9 << 20) + 5), (60, 1 << 20), (128, 333)):
+        bits = rnd.choice([128, 192, 256])
+        key, nonce, aad = rnd.randbytes(bits // 8), rnd.randbytes(nl), rnd.randbytes(rnd.choice([0, 7, 40]))
+        data = orc.splitmix(nl, (n + 7) // 8 * 8)[:n]
+        ct = uaes.AES_GCM_encrypt(key, nonce, aad, data)
+        assert ct == orc.gcm_encrypt(key, nonce, aad, data), (nl, n)
+        assert uaes.AES_GCM_decrypt(key, nonce, aad, ct) == (0, data)
+        bad = bytes([nonce[0] ^ 1]) + nonce[1:]
+        assert uaes.AES_GCM_decrypt(key, bad, aad, ct, prefill=0xCC) == (0x1A, b"\xcc" * n)
+
+
 @pytest.mark.parametrize("bits,count", [(128, 800), (256, 600)])
 def test_xts_rsp_through_compat_api(bits, count):
     cases = xts_cases(bits)

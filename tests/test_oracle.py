@@ -54,6 +54,37 @@ def test_gcm_rsp(orc, bits):
         assert rc == 0 and pt == c["PT"]
 
 
+@pytest.mark.parametrize("bits", [128, 192, 256])
+@pytest.mark.parametrize("iv_bytes", [1, 128])
+def test_gcm_rsp_other_nonce_lengths(orc, bits, iv_bytes):
+    """the [IVlen = 8] and [IVlen = 1024] sections of the NIST files, which reference builds with
+    GCM_NONCE_LEN = 1 / 128 run (aes_testvectors_GCM.h:86): J0 = GHASH(nonce), micro_aes.c:1145-1149"""
+    cases = gcm_cases(bits, iv_bytes)
+    assert len(cases) == 375
+    for c in cases:
+        out = orc.gcm_encrypt(c["Key"], c["IV"], c["AAD"], c["PT"])
+        assert out == c["CT"] + c["Tag"], c["Count"]
+        rc, pt = orc.gcm_decrypt(c["Key"], c["IV"], c["AAD"], c["CT"] + c["Tag"])
+        assert rc == 0 and pt == c["PT"]
+
+
+@pytest.mark.parametrize("bits,iv_bytes", [(128, 1), (256, 128)])
+def test_gcm_nonce_length_builds_of_the_reference(orc, bits, iv_bytes):
+    """oracle == the reference compiled with GCM_NONCE_LEN patched (oracle/Makefile), random inputs:
+    the counter derived from GHASH(nonce) keeps stepping with the 56-bit incBlock (N2)"""
+    if not Reference.available(bits, gcm_nonce_len=iv_bytes):
+        pytest.skip("oracle/_ref not built here")
+    ref = Reference(bits, gcm_nonce_len=iv_bytes)
+    rnd = random.Random(12 + iv_bytes)
+    for _ in range(60):
+        n = rnd.choice([0, 1, 16, 17, 100, 255, 4096, 70001])
+        key, nonce, data = rnd.randbytes(bits // 8), rnd.randbytes(iv_bytes), rnd.randbytes(n)
+        aad = rnd.randbytes(rnd.choice([0, 5, 16, 33]))
+        ct = ref.gcm_encrypt(key, nonce, aad, data)
+        assert orc.gcm_encrypt(key, nonce, aad, data) == ct
+        assert orc.gcm_decrypt(key, nonce, aad, ct) == ref.gcm_decrypt(key, nonce, aad, ct) == (0, data)
+
+
 @pytest.mark.parametrize("bits", [128, 256])
 def test_xts_rsp(orc, bits):
     cases = xts_cases(bits)
