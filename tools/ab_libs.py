@@ -29,7 +29,11 @@ fns = {
     "xts": lambda: uaes.xts_sectors_dev(keys2, 0, 4096, n // 4096, src, dst, stream=st),
     "gcm": lambda: uaes.gcm_encrypt_dev(key, nonce, None, src, n, dst, stream=st),
     "ocb": lambda: uaes.ocb_dev(key, nonce, None, src, n, dst, stream=st),
+    "gcm-dec": lambda: uaes.gcm_decrypt_dev(key, nonce, None, dst, n, src, status, stream=st),
 }
+if %(wl)r == "gcm-dec":
+    uaes.gcm_encrypt_dev(key, nonce, None, src, n, dst, stream=st)
+    torch.cuda.synchronize()
 fn = fns[%(wl)r]
 reps = max(100, 300 * 64 // %(mib)d)
 for _ in range(reps // 2): fn()
