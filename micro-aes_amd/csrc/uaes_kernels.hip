@@ -280,6 +280,7 @@ __global__ __launch_bounds__(UAES_WG) void k_xts(uaesk_rk k1, uaesk_tables tb,
                                                  u64 nsectors, u64 chunks_per_sector,
                                                  u64 main_blocks,      /* whole blocks handled here, per unit */
                                                  u64 sector_bytes,
+                                                 u64 step_q, u64 step_r,   /* (waves of the grid) / and % chunks_per_sector */
                                                  const unsigned char *in,
                                                  unsigned char *out)
 {
@@ -291,13 +292,17 @@ __global__ __launch_bounds__(UAES_WG) void k_xts(uaesk_rk k1, uaesk_tables tb,
     const u64 nwaves = (u64)gridDim.x * (blockDim.x >> 6);
     const u64 nchunks = nsectors * chunks_per_sector;
 
-    /* state of the chunk being fetched */
+    /* (unit, chunk inside the unit) of the chunk being fetched: one division here, then stepped by the
+     * grid's wave count as (step_q, step_r) -- a 64-bit division per chunk cost ~8 % of the loop     */
+    u64 sctn = wave / chunks_per_sector, withn = wave - sctn * chunks_per_sector;
     uint4 dn[UAES_U], tbn = make_uint4(0, 0, 0, 0);
     u32 cntn = 0;
     u64 offn = 0;                                    /* byte offset of the chunk's first block */
     auto fetch = [&](u64 ch) {
-        const u64 sct = ch / chunks_per_sector;
-        const u64 first = (ch - sct * chunks_per_sector) * XTS_CHUNK;
+        const u64 sct = sctn;
+        const u64 first = withn * XTS_CHUNK;
+        sctn += step_q; withn += step_r;             /* the next chunk of this wave */
+        if (withn >= chunks_per_sector) { withn -= chunks_per_sector; ++sctn; }
         const u64 left = main_blocks - first;
         cntn = left < XTS_CHUNK ? (u32)left : XTS_CHUNK;
         offn = sct * sector_bytes + first * 16;
@@ -327,28 +332,29 @@ __global__ __launch_bounds__(UAES_WG) void k_xts(uaesk_rk k1, uaesk_tables tb,
         t.lo = tb4.x | ((u64)tb4.y << 32);
         t.hi = tb4.z | ((u64)tb4.w << 32);
         t = tw_mul_pow(t, lane);
-        u32 s[UAES_U][4], tw[UAES_U][4];
-#pragma unroll
-        for (int u = 0; u < UAES_U; ++u) {
-            tw[u][0] = (u32)t.lo; tw[u][1] = (u32)(t.lo >> 32);
-            tw[u][2] = (u32)t.hi; tw[u][3] = (u32)(t.hi >> 32);
-            s[u][0] = d[u].x ^ tw[u][0]; s[u][1] = d[u].y ^ tw[u][1];
-            s[u][2] = d[u].z ^ tw[u][2]; s[u][3] = d[u].w ^ tw[u][3];
-            t = tw_mul_pow64(t);
-        }
-        if (DEC) {
-            dec_blocks<NR, UAES_U>(s, k1, lc);
-        } else {
-            enc_blocks_skewed<NR>(s[0], s[1], k1, lc);
-            enc_blocks_skewed<NR>(s[2], s[3], k1, lc);
-        }
         unsigned char *dst = out + off;
+        /* two skewed pairs one after the other: only one pair's states and tweaks are live at a time
+         * (all four at once spilled 8-18 registers)                                                  */
 #pragma unroll
-        for (int u = 0; u < UAES_U; ++u) {
-            const u32 j = lane + 64u * u;
-            if (j < cnt)
-                store16<ALIGNED>(dst + 16u * j, make_uint4(s[u][0] ^ tw[u][0], s[u][1] ^ tw[u][1],
-                                                           s[u][2] ^ tw[u][2], s[u][3] ^ tw[u][3]));
+        for (int pr = 0; pr < UAES_U; pr += 2) {
+            u32 s[2][4], tw[2][4];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                tw[u][0] = (u32)t.lo; tw[u][1] = (u32)(t.lo >> 32);
+                tw[u][2] = (u32)t.hi; tw[u][3] = (u32)(t.hi >> 32);
+                s[u][0] = d[pr + u].x ^ tw[u][0]; s[u][1] = d[pr + u].y ^ tw[u][1];
+                s[u][2] = d[pr + u].z ^ tw[u][2]; s[u][3] = d[pr + u].w ^ tw[u][3];
+                t = tw_mul_pow64(t);
+            }
+            if (DEC) dec_blocks_skewed<NR>(s[0], s[1], k1, lc);
+            else enc_blocks_skewed<NR>(s[0], s[1], k1, lc);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const u32 j = lane + 64u * (pr + u);
+                if (j < cnt)
+                    store16<ALIGNED>(dst + 16u * j, make_uint4(s[u][0] ^ tw[u][0], s[u][1] ^ tw[u][1],
+                                                               s[u][2] ^ tw[u][2], s[u][3] ^ tw[u][3]));
+            }
         }
         ch = nxt;
     }
@@ -684,13 +690,15 @@ static int launch_xts(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *k1
          * so below half a GPU's worth of chunks the workgroups shrink to 4 waves              */
         const unsigned wg = grid_for(nchunks, UAES_WG / 64) * 2 <= grid_for(~0ull, 1) ? 256u : UAES_WG;
         /* every block address is a multiple of 16 unless units of ragged size follow one another */
+        const unsigned xgrid = grid_for(nchunks, wg / 64);
+        const u64 nwaves = (u64)xgrid * (wg / 64), step_q = nwaves / cps, step_r = nwaves % cps;
         if (sector_bytes % 16 == 0 || nsectors == 1)
-            hipLaunchKernelGGL((k_xts<NR, DEC, true>), dim3(grid_for(nchunks, wg / 64)), dim3(wg), lds, st,
-                               *k1, *tb, (const uint4 *)scratch, (u64)nsectors, cps, mb, (u64)sector_bytes,
+            hipLaunchKernelGGL((k_xts<NR, DEC, true>), dim3(xgrid), dim3(wg), lds, st,
+                               *k1, *tb, (const uint4 *)scratch, (u64)nsectors, cps, mb, (u64)sector_bytes, step_q, step_r,
                                (const unsigned char *)in, (unsigned char *)out);
         else
-            hipLaunchKernelGGL((k_xts<NR, DEC, false>), dim3(grid_for(nchunks, wg / 64)), dim3(wg), lds, st,
-                               *k1, *tb, (const uint4 *)scratch, (u64)nsectors, cps, mb, (u64)sector_bytes,
+            hipLaunchKernelGGL((k_xts<NR, DEC, false>), dim3(xgrid), dim3(wg), lds, st,
+                               *k1, *tb, (const uint4 *)scratch, (u64)nsectors, cps, mb, (u64)sector_bytes, step_q, step_r,
                                (const unsigned char *)in, (unsigned char *)out);
     }
     if (r) {
