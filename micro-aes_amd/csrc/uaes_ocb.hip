@@ -173,7 +173,9 @@ __global__ __launch_bounds__(UAES_WG) void k_ocb(uaesk_rk rk, uaesk_tables tb,
     const B16 off0 = uniform(b16(scr[OCB_ROW_OFF0]));
     const B16 l5 = uniform(lds_row(2u + 5u)), l6 = uniform(lds_row(2u + 6u)), l7 = uniform(lds_row(2u + 7u));
 
-    auto chunk_of = [&](u64 k) { return ((k / run) * nwaves + wave) * run + (k % run); };
+    /* run is a power of two: shifts and masks, not the 64-bit divisions `k / run`, `k % run` compile to */
+    const u32 lrun = (u32)__builtin_ctz(run), mrun = run - 1u;
+    auto chunk_of = [&](u64 k) { return ((((k >> lrun) * nwaves + wave) << lrun)) + (k & mrun); };
     /* live positions inside chunk c: [lo, hi] (index 0 does not exist, indices end at nblocks) */
     auto span = [&](u64 c, u32 &lo, u32 &hi) {
         lo = c == 0 ? 1u : 0u;
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(UAES_WG) void k_ocb(uaesk_rk rk, uaesk_tables tb,
     u64 k = 0, c = chunk_of(0);
     if (c < nchunks) fetch(c);
     while (c < nchunks) {
-        if ((k % run) == 0) {                         /* first chunk of a run */
+        if ((k & mrun) == 0) {                        /* first chunk of a run */
             cm = off0;
             bx(cm, ocb_gray_sum(c ^ (c >> 1), 8));
             if (c & 1) bx(cm, l7);
