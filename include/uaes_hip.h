@@ -273,6 +273,29 @@ int uaes_ocb_dev(int keybits, const uint8_t *key, const uint8_t *nonce, int decr
                  const void *d_aad, size_t aad_len,
                  const void *d_in, size_t len, void *d_out, int *d_status, void *stream);
 
+/* ---- GCM key context -----------------------------------------------------------
+ * The reference redoes GCMsetup in every call (micro_aes.c:1140-1152) and so do the one-shot
+ * functions above: key schedule, H = Enc(0), the GHASH multiplication tables of H (a 20 us
+ * kernel).  A caller that sends many messages under one key builds them ONCE:
+ *   uaes_gcm_key_new    key schedule + every key-dependent table, on the current device
+ *   uaes_gcm_key_encrypt / _decrypt        = uaes_gcm_encrypt / _decrypt, bit for bit (12-byte
+ *                                            nonce; host or device pointers; synchronous)
+ *   uaes_gcm_key_encrypt_dev / _decrypt_dev  enqueue on a stream
+ * Per message only Enc(J0) is computed (a one-wave kernel).  The context holds per-message
+ * state too: ONE call at a time per context (calls on one stream are ordered; use one context
+ * per stream for concurrency).  uaes_gcm_key_free wipes the tables.                          */
+typedef struct uaes_gcm_key uaes_gcm_key;
+int  uaes_gcm_key_new(uaes_gcm_key **out, int keybits, const uint8_t *key);
+void uaes_gcm_key_free(uaes_gcm_key *k);
+int  uaes_gcm_key_encrypt(uaes_gcm_key *k, const uint8_t *nonce, const void *aData, size_t aDataLen,
+                          const void *pntxt, size_t ptextLen, void *crtxt);
+int  uaes_gcm_key_decrypt(uaes_gcm_key *k, const uint8_t *nonce, const void *aData, size_t aDataLen,
+                          const void *crtxt, size_t crtxtLen, void *pntxt);
+int  uaes_gcm_key_encrypt_dev(uaes_gcm_key *k, const uint8_t *nonce, const void *d_aad, size_t aad_len,
+                              const void *d_in, size_t len, void *d_out, void *stream);
+int  uaes_gcm_key_decrypt_dev(uaes_gcm_key *k, const uint8_t *nonce, const void *d_aad, size_t aad_len,
+                              const void *d_in, size_t len, void *d_out, int *d_status, void *stream);
+
 /* ---- one process, several GPUs -------------------------------------------------
  * The text is cut into aligned slices, one per device; one host thread per device
  * runs the single-device call on its slice with the counter / sector offset

@@ -40,6 +40,8 @@ EXPORTS = [
     "uaes_cmac", "uaes_ccm_encrypt", "uaes_ccm_decrypt", "uaes_gcmsiv_encrypt", "uaes_gcmsiv_decrypt",
     "uaes_ocb_encrypt", "uaes_ocb_decrypt", "uaes_ocb_dev",
     "uaes_mgpu_ctr_xcrypt_at", "uaes_mgpu_xts_sectors",
+    "uaes_gcm_key_new", "uaes_gcm_key_free", "uaes_gcm_key_encrypt", "uaes_gcm_key_decrypt",
+    "uaes_gcm_key_encrypt_dev", "uaes_gcm_key_decrypt_dev",
     "uaes_gcm_stream_begin", "uaes_gcm_stream_update", "uaes_gcm_stream_finish", "uaes_gcm_stream_abort",
     "uaes_cbc_encrypt_batch", "uaes_cmac_batch", "uaes_cbc_encrypt", "uaes_cbc_decrypt", "uaes_cfb_encrypt", "uaes_cfb_decrypt", "uaes_ofb_xcrypt",
     "uaes_ecb_dev", "uaes_ctr_xcrypt_at_dev", "uaes_xts_sectors_dev",
@@ -121,6 +123,13 @@ def engine():
         getattr(L, n).argtypes = [i, vp, vp, vp, sz, vp, sz, vp]
     L.uaes_mgpu_ctr_xcrypt_at.argtypes = [i, C.POINTER(C.c_int), i, vp, vp, u64, vp, sz, vp]
     L.uaes_mgpu_xts_sectors.argtypes = [i, C.POINTER(C.c_int), i, vp, u64, sz, sz, vp, vp, i]
+    L.uaes_gcm_key_new.argtypes = [C.POINTER(vp), i, vp]
+    L.uaes_gcm_key_free.argtypes = [vp]
+    L.uaes_gcm_key_free.restype = None
+    L.uaes_gcm_key_encrypt.argtypes = [vp, vp, vp, sz, vp, sz, vp]
+    L.uaes_gcm_key_decrypt.argtypes = [vp, vp, vp, sz, vp, sz, vp]
+    L.uaes_gcm_key_encrypt_dev.argtypes = [vp, vp, vp, sz, vp, sz, vp, vp]
+    L.uaes_gcm_key_decrypt_dev.argtypes = [vp, vp, vp, sz, vp, sz, vp, vp, vp]
     L.uaes_gcm_stream_begin.argtypes = [C.POINTER(vp), i, vp, vp, vp, sz, i]
     L.uaes_gcm_stream_update.argtypes = [vp, vp, sz, vp]
     L.uaes_gcm_stream_finish.argtypes = [vp, vp]
@@ -135,7 +144,7 @@ def engine():
     L.uaes_gcm_partial_dev.argtypes = [i, vp, vp, vp, u64, vp, sz, u64, u64, vp, vp]
     L.uaes_expand_key.argtypes = [i, vp, vp, vp]
     for n in EXPORTS:
-        if n not in ("uaes_last_error", "uaes_version"):
+        if n not in ("uaes_last_error", "uaes_version", "uaes_gcm_key_free", "uaes_gcm_stream_abort"):
             getattr(L, n).restype = i
     _lib = L
     return L
@@ -383,6 +392,45 @@ def AES_OCB_decrypt(key, nonce, aData, crtxt_and_tag, prefill=0):
     rc = _check(engine().uaes_ocb_decrypt(_bits(key), _in(key), _fixed(nonce, 12, "nonce"), _in(aData), len(aData),
                                           _in(crtxt_and_tag), n, o), "AES_OCB_decrypt")
     return rc, bytes(o)[:n]
+
+
+class GcmKey:
+    """GCM key context (uaes_gcm_key_*): the key's GHASH tables are built once; encrypt / decrypt then equal
+    AES_GCM_encrypt / AES_GCM_decrypt bit for bit.  One call at a time per object."""
+
+    def __init__(self, key):
+        self._h = C.c_void_p()
+        _check(engine().uaes_gcm_key_new(C.byref(self._h), _bits(key), _in(key)), "uaes_gcm_key_new")
+
+    def encrypt(self, nonce, aData, pntxt):
+        o = _out(len(pntxt) + 16)
+        _check(engine().uaes_gcm_key_encrypt(self._h, _fixed(nonce, 12, "nonce"), _in(aData), len(aData),
+                                             _in(pntxt), len(pntxt), o), "uaes_gcm_key_encrypt")
+        return bytes(o)[: len(pntxt) + 16]
+
+    def decrypt(self, nonce, aData, crtxt_and_tag, prefill=0):
+        n = len(crtxt_and_tag) - 16
+        o = _out(n, prefill)
+        rc = _check(engine().uaes_gcm_key_decrypt(self._h, _fixed(nonce, 12, "nonce"), _in(aData), len(aData),
+                                                  _in(crtxt_and_tag), n, o), "uaes_gcm_key_decrypt")
+        return rc, bytes(o)[:n]
+
+    def encrypt_dev(self, nonce, aad, src, nbytes, dst, stream=None):
+        _check(engine().uaes_gcm_key_encrypt_dev(self._h, _fixed(nonce, 12, "nonce"), _ptr(aad),
+                                                 0 if aad is None else aad.numel(), _ptr(src), nbytes, _ptr(dst),
+                                                 _stream(stream)), "uaes_gcm_key_encrypt_dev")
+
+    def decrypt_dev(self, nonce, aad, src, nbytes, dst, status, stream=None):
+        _check(engine().uaes_gcm_key_decrypt_dev(self._h, _fixed(nonce, 12, "nonce"), _ptr(aad),
+                                                 0 if aad is None else aad.numel(), _ptr(src), nbytes, _ptr(dst),
+                                                 _ptr(status), _stream(stream)), "uaes_gcm_key_decrypt_dev")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            engine().uaes_gcm_key_free(self._h)
+            self._h = None
+
+    __del__ = close
 
 
 class GcmStream:

@@ -87,6 +87,16 @@ int uaesk_gcm(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek,
               const void *in, size_t len, void *out,
               void *scratch, int *status);
 
+/* Key context: uaesk_gcm_key_tables fills a scratch buffer (uaesk_gcm_scratch_bytes()) with every table
+ * that depends on the key only; uaesk_gcm_keyed is uaesk_gcm on such a buffer -- per message it computes
+ * just Enc(J0), unless the text needs a size-dependent bulk table.  One call at a time per buffer.  */
+int uaesk_gcm_key_tables(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek, void *key_scratch);
+int uaesk_gcm_keyed(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek,
+                    int decrypt, const uint8_t *j0_16,
+                    const void *aad, size_t aad_len,
+                    const void *in, size_t len, void *out,
+                    void *key_scratch, int *status);
+
 /* Sharded GCM: the weighted partial GHASH of one 16-byte-aligned ciphertext
  * shard (first shard: + AAD and Enc(J0); last shard: + length block).  The tag
  * of the whole message is the XOR of all shards' 16-byte results.           */

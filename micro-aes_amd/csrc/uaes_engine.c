@@ -1142,6 +1142,147 @@ int uaes_gcm_decrypt_dev(int keybits, const uint8_t *key, const uint8_t *nonce,
     return 0;
 }
 
+/* ------------------------------------------------------------------------ */
+/* GCM key context: the tables of a key built once                             */
+/* ------------------------------------------------------------------------ */
+struct uaes_gcm_key {
+    keysched ks;
+    int      device;
+    void    *scratch;               /* uaesk_gcm_scratch_bytes(): the key's tables + per-message state */
+};
+
+int uaes_gcm_key_new(uaes_gcm_key **out, int keybits, const uint8_t *key)
+{
+    context *c;
+    uaes_gcm_key *k;
+    int rc;
+    if (!out) return fail(UAES_E_ARG, "NULL pointer");
+    *out = NULL;
+    if ((k = (uaes_gcm_key *)calloc(1, sizeof *k)) == NULL) return fail(UAES_E_HIP, "out of host memory");
+    if ((rc = expand_key(&k->ks, key, keybits)) != 0 || (rc = get_context(&c)) != 0) { free(k); return rc; }
+    if (hipGetDevice(&k->device) != hipSuccess || hipMalloc(&k->scratch, uaesk_gcm_scratch_bytes()) != hipSuccess) {
+        free(k);
+        return fail(UAES_E_HIP, "key context allocation failed");
+    }
+    LOCKED_BEGIN(c);
+    rc = 0;
+    {
+        int kk = uaesk_gcm_key_tables(NULL, &c->tb, k->ks.nr, &k->ks.ek, k->scratch);
+        if (kk) rc = fail(UAES_E_HIP, "key table launch: %s", hipGetErrorString((hipError_t)kk));
+        else if (hipStreamSynchronize(NULL) != hipSuccess) rc = fail(UAES_E_HIP, "key table build failed");
+    }
+    pthread_mutex_unlock(&c->mu);
+    if (rc) { (void)hipFree(k->scratch); memset(k, 0, sizeof *k); free(k); return rc; }
+    *out = k;
+    return 0;
+}
+
+void uaes_gcm_key_free(uaes_gcm_key *k)
+{
+    if (!k) return;
+    if (k->scratch) {
+        (void)hipDeviceSynchronize();
+        (void)hipMemset(k->scratch, 0, uaesk_gcm_scratch_bytes());    /* H and its tables are key material */
+        (void)hipFree(k->scratch);
+    }
+    memset(k, 0, sizeof *k);
+    free(k);
+}
+
+static int key_device_ok(const uaes_gcm_key *k)
+{
+    int dev = -1;
+    if (!k) return fail(UAES_E_ARG, "NULL key context");
+    if (hipGetDevice(&dev) != hipSuccess || dev != k->device)
+        return fail(UAES_E_ARG, "the key context belongs to device %d, the calling thread is bound to %d", k->device, dev);
+    return 0;
+}
+
+int uaes_gcm_key_encrypt(uaes_gcm_key *k, const uint8_t *nonce, const void *aData, size_t aDataLen,
+                         const void *pntxt, size_t ptextLen, void *crtxt)
+{
+    context *c;
+    io_plan io;
+    const void *d_aad;
+    uint8_t j0[16];
+    int rc;
+    if ((rc = key_device_ok(k)) != 0) return rc;
+    if (!nonce || !crtxt || (ptextLen && !pntxt)) return fail(UAES_E_ARG, "NULL pointer");
+    if ((rc = get_context(&c)) != 0) return rc;
+    j0_of_nonce12(nonce, j0);
+    LOCKED_BEGIN(c);
+    do {
+        if ((rc = stage_aad(c, aData, aDataLen, &d_aad)) != 0) break;
+        if ((rc = plan_io(c, pntxt, ptextLen, crtxt, ptextLen + 16, &io)) != 0) break;
+        int kk = uaesk_gcm_keyed(NULL, &c->tb, k->ks.nr, &k->ks.ek, 0, j0, d_aad, aDataLen,
+                                 io.din, ptextLen, io.dout, k->scratch, NULL);
+        if (kk) { rc = fail(UAES_E_HIP, "gcm launch: %s", hipGetErrorString((hipError_t)kk)); break; }
+        rc = finish_io(&io, ptextLen + 16);
+    } while (0);
+    LOCKED_END(c, rc);
+}
+
+int uaes_gcm_key_decrypt(uaes_gcm_key *k, const uint8_t *nonce, const void *aData, size_t aDataLen,
+                         const void *crtxt, size_t crtxtLen, void *pntxt)
+{
+    context *c;
+    io_plan io;
+    const void *d_aad;
+    uint8_t j0[16];
+    int rc, status = -1;
+    if ((rc = key_device_ok(k)) != 0) return rc;
+    if (!nonce || !crtxt || (crtxtLen && !pntxt)) return fail(UAES_E_ARG, "NULL pointer");
+    if ((rc = get_context(&c)) != 0) return rc;
+    j0_of_nonce12(nonce, j0);
+    LOCKED_BEGIN(c);
+    do {
+        if ((rc = stage_aad(c, aData, aDataLen, &d_aad)) != 0) break;
+        if ((rc = plan_io(c, crtxt, crtxtLen + 16, pntxt, crtxtLen, &io)) != 0) break;
+        if (io.dout == io.din && io.copy_back) {      /* host -> host: keep the caller's buffer untouched on 0x1A */
+            if (grow(&c->stage[1], &c->stage_cap[1], crtxtLen + 64)) { rc = UAES_E_HIP; break; }
+            io.dout = c->stage[1];
+        }
+        int kk = uaesk_gcm_keyed(NULL, &c->tb, k->ks.nr, &k->ks.ek, 1, j0, d_aad, aDataLen,
+                                 io.din, crtxtLen, io.dout, k->scratch, c->d_status);
+        if (kk) { rc = fail(UAES_E_HIP, "gcm launch: %s", hipGetErrorString((hipError_t)kk)); break; }
+        hipError_t e = hipMemcpy(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { rc = fail(UAES_E_HIP, "gcm run: %s", hipGetErrorString(e)); break; }
+        if (status != 0) { rc = UAES_E_AUTHENTICATION; break; }  /* N7: pntxt untouched */
+        rc = finish_io(&io, crtxtLen);
+    } while (0);
+    LOCKED_END(c, rc);
+}
+
+int uaes_gcm_key_encrypt_dev(uaes_gcm_key *k, const uint8_t *nonce, const void *d_aad, size_t aad_len,
+                             const void *d_in, size_t len, void *d_out, void *stream)
+{
+    context *c;
+    uint8_t j0[16];
+    int rc;
+    if ((rc = key_device_ok(k)) != 0) return rc;
+    if (!nonce || !d_out) return fail(UAES_E_ARG, "NULL pointer");
+    if ((rc = dev_ptrs_ok(d_in, d_out, len)) != 0) return rc;
+    if ((rc = get_context(&c)) != 0) return rc;
+    j0_of_nonce12(nonce, j0);
+    KCHK(uaesk_gcm_keyed(stream, &c->tb, k->ks.nr, &k->ks.ek, 0, j0, d_aad, aad_len, d_in, len, d_out, k->scratch, NULL));
+    return 0;
+}
+
+int uaes_gcm_key_decrypt_dev(uaes_gcm_key *k, const uint8_t *nonce, const void *d_aad, size_t aad_len,
+                             const void *d_in, size_t len, void *d_out, int *d_status, void *stream)
+{
+    context *c;
+    uint8_t j0[16];
+    int rc;
+    if ((rc = key_device_ok(k)) != 0) return rc;
+    if (!nonce || !d_in || !d_status) return fail(UAES_E_ARG, "NULL pointer");
+    if ((rc = dev_ptrs_ok(d_in, d_out, len)) != 0) return rc;
+    if ((rc = get_context(&c)) != 0) return rc;
+    j0_of_nonce12(nonce, j0);
+    KCHK(uaesk_gcm_keyed(stream, &c->tb, k->ks.nr, &k->ks.ek, 1, j0, d_aad, aad_len, d_in, len, d_out, k->scratch, d_status));
+    return 0;
+}
+
 int uaes_gcm_partial_dev(int keybits, const uint8_t *key, const uint8_t *nonce,
                          const void *d_aad, uint64_t total_aad_len,
                          const void *d_ct_shard, size_t shard_len, uint64_t shard_offset,

@@ -714,6 +714,33 @@ static int launch_fused(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *
 }
 
 /* ------------------------------------------------------------------------ */
+/* key context: what is left of the setup when the tables of a key are kept    */
+/* ------------------------------------------------------------------------ */
+/* Enc(J0) -> GS_EJ0 and T <- 0: the only per-message inputs of the tag besides the text.  One wave,
+ * a quad per block (quad_encrypt), 4 KiB of table stores.                                       */
+template <int NR>
+__global__ __launch_bounds__(64) void k_gcm_ej0(uaesk_rk ek, uaesk_tables tb, uint4 j0, unsigned char *__restrict__ scratch)
+{
+    quad_fill_tables(tb.te0, ek);
+    const LaneConst lc = quad_lane_const();
+    u32 s[4] = { j0.x, j0.y, j0.z, j0.w };
+    quad_encrypt<NR>(s, ek, lc);
+    if (threadIdx.x == 0) {
+        *(uint4 *)(scratch + GS_EJ0) = make_uint4(s[0], s[1], s[2], s[3]);
+        *(uint4 *)(scratch + GS_T) = make_uint4(0, 0, 0, 0);
+    }
+}
+
+template <int NR>
+static int launch_ej0(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek, uint4 j0, unsigned char *sc)
+{
+    hipError_t e = hipFuncSetAttribute((const void *)k_gcm_ej0<NR>, hipFuncAttributeMaxDynamicSharedMemorySize, UAES_LDS_QUAD);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((k_gcm_ej0<NR>), dim3(1), dim3(64), UAES_LDS_QUAD, st, *ek, *tb, j0, sc);
+    return (int)hipGetLastError();
+}
+
+/* ------------------------------------------------------------------------ */
 /* host-side drivers                                                          */
 /* ------------------------------------------------------------------------ */
 struct GPlan {
@@ -808,11 +835,14 @@ extern "C" int uaesk_gcm_j0(void *stream, const uaesk_tables *tb, int nr, const 
     return run_ghash_levels(st, msg, nv, pl, sc, 2, (unsigned char *)j0_out16, nullptr);
 }
 
-extern "C" int uaesk_gcm(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek,
-                         int decrypt, const uint8_t *j0_16,
-                         const void *aad, size_t aad_len,
-                         const void *in, size_t len, void *out,
-                         void *scratch, int *status)
+/* keyed != 0: `scratch` belongs to a key context whose tables (nibble tables, H^S table, Y/Z powers, all
+ * H^(2^k)) uaesk_gcm_key_tables built; then only Enc(J0) is computed per message unless the text needs
+ * a size-dependent bulk table (two-pass texts over 512 KiB), for which the full setup runs as usual. */
+static int gcm_body(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek,
+                    int decrypt, const uint8_t *j0_16,
+                    const void *aad, size_t aad_len,
+                    const void *in, size_t len, void *out,
+                    void *scratch, int *status, int keyed)
 {
     hipStream_t st = S(stream);
     unsigned char *sc = (unsigned char *)scratch;
@@ -868,11 +898,20 @@ extern "C" int uaesk_gcm(void *stream, const uaesk_tables *tb, int nr, const uae
             const GPlan plf = plan_for(nvf);
             GSrc front = msg;                           /* [AAD][head] in front of the striped region */
             front.ct_len = h0 * 16; front.has_len = 0;
-            switch (nr) {
-            case 10: rc = launch_setup<10>(st, tb, ek, j0, sc, plf, 0, z, 0, logF); break;
-            case 12: rc = launch_setup<12>(st, tb, ek, j0, sc, plf, 0, z, 0, logF); break;
-            case 14: rc = launch_setup<14>(st, tb, ek, j0, sc, plf, 0, z, 0, logF); break;
-            default: return (int)hipErrorInvalidValue;
+            if (keyed) {
+                switch (nr) {
+                case 10: rc = launch_ej0<10>(st, tb, ek, j0, sc); break;
+                case 12: rc = launch_ej0<12>(st, tb, ek, j0, sc); break;
+                case 14: rc = launch_ej0<14>(st, tb, ek, j0, sc); break;
+                default: return (int)hipErrorInvalidValue;
+                }
+            } else {
+                switch (nr) {
+                case 10: rc = launch_setup<10>(st, tb, ek, j0, sc, plf, 0, z, 0, logF); break;
+                case 12: rc = launch_setup<12>(st, tb, ek, j0, sc, plf, 0, z, 0, logF); break;
+                case 14: rc = launch_setup<14>(st, tb, ek, j0, sc, plf, 0, z, 0, logF); break;
+                default: return (int)hipErrorInvalidValue;
+                }
             }
             if (rc) return rc;
             switch (nr) {
@@ -886,11 +925,31 @@ extern "C" int uaesk_gcm(void *stream, const uaesk_tables *tb, int nr, const uae
     }
 
     const GPlan pl = plan_for(nv);
-    switch (nr) {
-    case 10: rc = launch_setup<10>(st, tb, ek, j0, sc, pl, 0, z); break;
-    case 12: rc = launch_setup<12>(st, tb, ek, j0, sc, pl, 0, z); break;
-    case 14: rc = launch_setup<14>(st, tb, ek, j0, sc, pl, 0, z); break;
-    default: return (int)hipErrorInvalidValue;
+    if (keyed && pl.logA == 0) {               /* every table this text needs is in the key context */
+        switch (nr) {
+        case 10: rc = launch_ej0<10>(st, tb, ek, j0, sc); break;
+        case 12: rc = launch_ej0<12>(st, tb, ek, j0, sc); break;
+        case 14: rc = launch_ej0<14>(st, tb, ek, j0, sc); break;
+        default: return (int)hipErrorInvalidValue;
+        }
+    } else {
+        /* (a key context keeps its tables: the full setup rewrites them with the same values) */
+        const u32 all = keyed ? 1u : 0u;
+        u32 logFk = 0;
+        if (keyed) {
+            int cus = 0;
+            if (uaesk_device_info(&cus, nullptr) == 0 && cus > 0) {
+                const u64 Sl = 2048ull * (u64)cus;
+                while (((u64)1 << logFk) < Sl) ++logFk;
+                if (((u64)1 << logFk) != Sl || logFk > GF_MAXLOG) logFk = 0;
+            }
+        }
+        switch (nr) {
+        case 10: rc = launch_setup<10>(st, tb, ek, j0, sc, pl, 0, z, all, logFk); break;
+        case 12: rc = launch_setup<12>(st, tb, ek, j0, sc, pl, 0, z, all, logFk); break;
+        case 14: rc = launch_setup<14>(st, tb, ek, j0, sc, pl, 0, z, all, logFk); break;
+        default: return (int)hipErrorInvalidValue;
+        }
     }
     if (rc) return rc;
 
@@ -902,6 +961,46 @@ extern "C" int uaesk_gcm(void *stream, const uaesk_tables *tb, int nr, const uae
     rc = run_ghash_levels(st, msg, nv, pl, sc, 1, (unsigned char *)in + len, status);
     if (rc) return rc;
     return uaesk_ctr_xcrypt(stream, tb, nr, ek, &c, in, out, len, status);
+}
+
+extern "C" int uaesk_gcm(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek,
+                         int decrypt, const uint8_t *j0_16,
+                         const void *aad, size_t aad_len,
+                         const void *in, size_t len, void *out,
+                         void *scratch, int *status)
+{
+    return gcm_body(stream, tb, nr, ek, decrypt, j0_16, aad, aad_len, in, len, out, scratch, status, 0);
+}
+
+extern "C" int uaesk_gcm_keyed(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek,
+                               int decrypt, const uint8_t *j0_16,
+                               const void *aad, size_t aad_len,
+                               const void *in, size_t len, void *out,
+                               void *key_scratch, int *status)
+{
+    return gcm_body(stream, tb, nr, ek, decrypt, j0_16, aad, aad_len, in, len, out, key_scratch, status, 1);
+}
+
+/* everything of the GCM setup that depends on the key only, into a key context's scratch */
+extern "C" int uaesk_gcm_key_tables(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek, void *key_scratch)
+{
+    hipStream_t st = S(stream);
+    unsigned char *sc = (unsigned char *)key_scratch;
+    GPlan pl = plan_for(2048);                 /* no bulk table; the nibble tables of all four last levels */
+    int cus = 0;
+    u32 logF = 0;
+    if (uaesk_device_info(&cus, nullptr) == 0 && cus > 0) {
+        const u64 Sl = 2048ull * (u64)cus;
+        while (((u64)1 << logF) < Sl) ++logF;
+        if (((u64)1 << logF) != Sl || logF > GF_MAXLOG) logF = 0;
+    }
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    switch (nr) {
+    case 10: return launch_setup<10>(st, tb, ek, z, sc, pl, 0, z, 1, logF);
+    case 12: return launch_setup<12>(st, tb, ek, z, sc, pl, 0, z, 1, logF);
+    case 14: return launch_setup<14>(st, tb, ek, z, sc, pl, 0, z, 1, logF);
+    default: return (int)hipErrorInvalidValue;
+    }
 }
 
 extern "C" int uaesk_ghash(void *stream, const uaesk_tables *tb, const uint8_t *H_host,

@@ -686,6 +686,40 @@ def test_gcm_fused_encrypt_pass(orc, bits):
         assert bytes(big[: n + 16].cpu().numpy()) == got
 
 
+@pytest.mark.parametrize("bits", [128, 192, 256])
+def test_gcm_key_context_equals_the_one_shot_calls(orc, bits):
+    """uaes_gcm_key_*: the key's tables are built once, every message then costs Enc(J0) + the data kernels.
+    Messages of every path (last levels only, two-pass bulk with its size-dependent table, one-pass kernel),
+    interleaved under ONE context, must equal the one-shot calls and the oracle; device-pointer variants too."""
+    import torch
+    rnd = random.Random(77 + bits)
+    key = rnd.randbytes(bits // 8)
+    k = uaes.GcmKey(key)
+    for n in (0, 1, 16, 4096, 70001, 600 << 10, 33, (9 << 20) + 7, 255, 3 << 20, 100):
+        nonce, aad = rnd.randbytes(12), rnd.randbytes(rnd.choice([0, 5, 16, 100]))
+        data = orc.splitmix(n + 1, (n + 7) // 8 * 8)[:n]
+        ct = k.encrypt(nonce, aad, data)
+        assert ct == uaes.AES_GCM_encrypt(key, nonce, aad, data), n
+        if n <= 70001:
+            assert ct == orc.gcm_encrypt(key, nonce, aad, data), n
+        assert k.decrypt(nonce, aad, ct) == (0, data), n
+        bad = bytearray(ct)
+        bad[rnd.randrange(len(bad))] ^= 0x10
+        assert k.decrypt(nonce, aad, bytes(bad), prefill=0xCC) == (0x1A, b"\xcc" * n), n
+    n = 1 << 20
+    src = torch.randint(0, 256, (n,), dtype=torch.uint8, device="cuda:0")
+    one, two = torch.zeros(n + 16, dtype=torch.uint8, device="cuda:0"), torch.zeros(n + 16, dtype=torch.uint8, device="cuda:0")
+    nonce = rnd.randbytes(12)
+    k.encrypt_dev(nonce, None, src, n, one)
+    uaes.gcm_encrypt_dev(key, nonce, None, src, n, two)
+    status = torch.full((1,), -1, dtype=torch.int32, device="cuda:0")
+    back = torch.zeros(n, dtype=torch.uint8, device="cuda:0")
+    k.decrypt_dev(nonce, None, one, n, back, status)
+    torch.cuda.synchronize()
+    assert torch.equal(one, two) and int(status.item()) == 0 and torch.equal(back, src)
+    k.close()
+
+
 def test_C4_gcm128_1GiB_device_resident(orc, golden_dir):
     """BASELINE configs[3]: tag and digest of CT||tag for the 1 GiB message."""
     import torch

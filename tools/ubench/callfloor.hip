@@ -39,8 +39,11 @@ int main()
     printf("empty kernel + hipStreamSynchronize(own stream):    %6.2f us\n", us_per_call([&] { hipLaunchKernelGGL(k_empty, dim3(1), dim3(64), 0, st, nullptr); (void)hipStreamSynchronize(st); }));
     printf("empty kernel launch only (async, amortised):        %6.2f us\n", us_per_call([&] { hipLaunchKernelGGL(k_empty, dim3(1), dim3(64), 0, st, nullptr); }, 20000));
     (void)hipStreamSynchronize(st);
+    uaes_gcm_key *gk = nullptr;
+    if (uaes_gcm_key_new(&gk, 128, key)) { fprintf(stderr, "%s\n", uaes_last_error()); return 1; }
     for (size_t n : { (size_t)16, (size_t)4096, (size_t)65536 }) {
         printf("-- %zu bytes --\n", n);
+        printf("uaes_gcm_key_encrypt_dev + sync (key context): %6.2f us\n", us_per_call([&] { uaes_gcm_key_encrypt_dev(gk, nonce, nullptr, 0, din, n, dout, st); (void)hipStreamSynchronize(st); }));
         printf("uaes_ecb_dev + sync:            %6.2f us\n", us_per_call([&] { uaes_ecb_dev(128, key, 0, din, n, dout, st); (void)hipStreamSynchronize(st); }));
         printf("uaes_ctr_xcrypt_at_dev + sync:  %6.2f us\n", us_per_call([&] { uaes_ctr_xcrypt_at_dev(128, key, ctr0, 0, din, n, dout, st); (void)hipStreamSynchronize(st); }));
         printf("uaes_gcm_encrypt_dev + sync:    %6.2f us\n", us_per_call([&] { uaes_gcm_encrypt_dev(128, key, nonce, nullptr, 0, din, n, dout, st); (void)hipStreamSynchronize(st); }));
@@ -61,5 +64,6 @@ int main()
         (void)hipEventRecord(e1, st); (void)hipStreamSynchronize(st); (void)hipEventElapsedTime(&ms, e0, e1);
         printf("GCM back-to-back on one stream:  %6.2f us per call (device side incl. launch gaps)\n", ms * 1e3 / 200);
     }
+    uaes_gcm_key_free(gk);
     return 0;
 }
