@@ -59,9 +59,16 @@ const char *uaes_version(void);
  * WITH the unauthenticated text in place (SABOTAGE is a no-op, micro_aes.c:1306-1312,
  * :1500-1511, :1803-1810) and that is this library's default too, so results are
  * bit-identical.  on != 0 selects the reference's INCREASE_SECURITY behaviour instead: the
- * buffer is zeroed.  Process-wide; returns the previous setting.  (GCM never releases
- * unauthenticated text; the *_dev calls report through d_status and leave the decision to
- * the caller.)                                                                          */
+ * buffer is zeroed.  Process-wide; returns the previous setting.  (The *_dev calls of those
+ * three modes report through d_status and leave the decision to the caller.)
+ * GCM never releases unauthenticated text (N7).  By default it therefore reads a ciphertext in
+ * device memory twice (GHASH, tag check, then CTR: 1.5x the traffic).  With the switch on, a
+ * long GCM decrypt into the caller's device buffer runs CTR and GHASH in ONE pass and, when the
+ * tag turns out wrong, zeroes what it wrote before it reports 0x1A / a non-zero *d_status --
+ * the caller has said a wiped buffer is acceptable, and after the call (or, for the *_dev
+ * calls, after the stream has run) the buffer never holds unauthenticated plaintext.
+ * Host-memory callers get the one-pass kernel regardless: their plaintext is produced in a
+ * private staging buffer that is copied out only after the tag has been verified.          */
 int         uaes_set_wipe_on_auth_failure(int on);
 /* The *_dev calls keep a device scratch buffer (GHASH tables, XTS chunk tweaks) per
  * hipStream_t they have been used with (8 per device; beyond that the least recently

@@ -116,9 +116,12 @@ __device__ __forceinline__ u64 ctr_geo_group0(const CtrGeo &g, u64 it)
     return g.first + 8ull * ((u64)blockIdx.x + (u64)gridDim.x * it);
 }
 
-/* FOLD: functor called once per iteration with the two ciphertext blocks of this lane
- * (u = 0, 1), in stream order per lane; `void operator()(uint4 c0, uint4 c1)`.       */
+/* FOLD: functor called once per iteration with two blocks of this lane (u = 0, 1), in stream
+ * order per lane; `void operator()(uint4 b0, uint4 b1)`.  FOLD::of_input selects which side of the
+ * XOR it sees: the blocks just written (encrypting GCM hashes its output) or the blocks just
+ * read (decrypting GCM hashes its input).                                            */
 struct CtrNoFold {
+    static constexpr bool of_input = false;
     __device__ __forceinline__ void operator()(const uint4 &, const uint4 &) const {}
 };
 
@@ -215,9 +218,10 @@ __device__ __forceinline__ void ctr_shared_loop(const uaesk_rk &rk, const uaesk_
         for (int u = 0; u < 2; ++u) {
             ct[u] = make_uint4(d_cur[u].x ^ s[u][0], d_cur[u].y ^ s[u][1], d_cur[u].z ^ s[u][2], d_cur[u].w ^ s[u][3]);
             (out + (((g0 + 4u * u) << 8) - c0))[lane_blk] = ct[u];
-            d_cur[u] = d_nxt[u];
         }
-        fold(ct[0], ct[1]);
+        if (FOLD::of_input) fold(d_cur[0], d_cur[1]); else fold(ct[0], ct[1]);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) d_cur[u] = d_nxt[u];
         ++it;
         if ((it & 7) == 0) parity ^= 1u;
     }

@@ -81,6 +81,9 @@ size_t uaesk_gcm_scratch_bytes(void);
 size_t uaesk_gcm_stream_scratch_bytes(void);     /* what the streamed API needs (no fused-pass buffers) */
 int uaesk_gcm_j0(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek,
                  const void *d_iv, size_t iv_len, void *scratch, void *j0_out16);
+/* decrypt: 0 = encrypt; 1 = decrypt, nothing written unless the tag matches (two passes over the text);
+ * 2 = decrypt, long texts in one pass: `out` is written before the tag is known and zeroed if it
+ * turns out wrong (for callers that accept a wiped buffer, or whose `out` is private staging) */
 int uaesk_gcm(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek,
               int decrypt, const uint8_t *j0_16,
               const void *aad, size_t aad_len,

@@ -72,6 +72,9 @@ int uaes_set_wipe_on_auth_failure(int on)
 }
 
 static int wipe_on_auth_failure(void) { return __atomic_load_n(&g_wipe_on_auth_failure, __ATOMIC_ACQUIRE); }
+/* GCM decrypt into the caller's device buffer: two passes (tag first, N7) unless the caller has
+ * accepted a zeroed output on failure, which lets CTR and GHASH share one pass (uaesk_gcm, mode 2) */
+static int gcm_decrypt_mode(void) { return wipe_on_auth_failure() ? 2 : 1; }
 
 /* tag comparison whose run time does not depend on where the tags differ */
 static int tags_differ(const uint8_t *a, const uint8_t *b, size_t n)
@@ -1082,7 +1085,8 @@ int uaes_gcm_decrypt_iv(int keybits, const uint8_t *key, const uint8_t *nonce, s
             if (grow(&c->stage[1], &c->stage_cap[1], crtxtLen + 64)) { rc = UAES_E_HIP; break; }
             io.dout = c->stage[1];
         }
-        int k = uaesk_gcm(NULL, &c->tb, ks.nr, &ks.ek, 1, j0, d_aad, aDataLen,
+        /* a private staging buffer may be written before the tag is known: one pass */
+        int k = uaesk_gcm(NULL, &c->tb, ks.nr, &ks.ek, io.copy_back ? 2 : gcm_decrypt_mode(), j0, d_aad, aDataLen,
                           io.din, crtxtLen, io.dout, c->scratch, c->d_status);
         if (k) { rc = fail(UAES_E_HIP, "gcm launch: %s", hipGetErrorString((hipError_t)k)); break; }
         hipError_t e = hipMemcpy(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost);
@@ -1137,7 +1141,7 @@ int uaes_gcm_decrypt_dev(int keybits, const uint8_t *key, const uint8_t *nonce,
     if ((rc = get_context(&c)) != 0) return rc;
     if ((rc = gcm_scratch_locked(c, stream, &scr, &slot)) != 0) return rc;
     j0_of_nonce12(nonce, j0);
-    KCHK_PINNED(c, slot, uaesk_gcm(stream, &c->tb, ks.nr, &ks.ek, 1, j0, d_aad, aad_len, d_in, len, d_out,
+    KCHK_PINNED(c, slot, uaesk_gcm(stream, &c->tb, ks.nr, &ks.ek, gcm_decrypt_mode(), j0, d_aad, aad_len, d_in, len, d_out,
                                    scr, d_status));
     return 0;
 }
@@ -1242,7 +1246,7 @@ int uaes_gcm_key_decrypt(uaes_gcm_key *k, const uint8_t *nonce, const void *aDat
             if (grow(&c->stage[1], &c->stage_cap[1], crtxtLen + 64)) { rc = UAES_E_HIP; break; }
             io.dout = c->stage[1];
         }
-        int kk = uaesk_gcm_keyed(NULL, &c->tb, k->ks.nr, &k->ks.ek, 1, j0, d_aad, aDataLen,
+        int kk = uaesk_gcm_keyed(NULL, &c->tb, k->ks.nr, &k->ks.ek, io.copy_back ? 2 : gcm_decrypt_mode(), j0, d_aad, aDataLen,
                                  io.din, crtxtLen, io.dout, k->scratch, c->d_status);
         if (kk) { rc = fail(UAES_E_HIP, "gcm launch: %s", hipGetErrorString((hipError_t)kk)); break; }
         hipError_t e = hipMemcpy(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost);
@@ -1279,7 +1283,7 @@ int uaes_gcm_key_decrypt_dev(uaes_gcm_key *k, const uint8_t *nonce, const void *
     if ((rc = dev_ptrs_ok(d_in, d_out, len)) != 0) return rc;
     if ((rc = get_context(&c)) != 0) return rc;
     j0_of_nonce12(nonce, j0);
-    KCHK(uaesk_gcm_keyed(stream, &c->tb, k->ks.nr, &k->ks.ek, 1, j0, d_aad, aad_len, d_in, len, d_out, k->scratch, d_status));
+    KCHK(uaesk_gcm_keyed(stream, &c->tb, k->ks.nr, &k->ks.ek, gcm_decrypt_mode(), j0, d_aad, aad_len, d_in, len, d_out, k->scratch, d_status));
     return 0;
 }
 

@@ -602,7 +602,9 @@ __device__ __forceinline__ uint4 tabmul8_xor_half(uint4 a, uint4 x, const GhLane
     return make_uint4(z[0], z[1], z[2], z[3]);
 }
 
+template <bool DEC>
 struct GhFold {
+    static constexpr bool of_input = DEC;
     uint4 acc[2];
     GhLane gl;
     __device__ __forceinline__ void operator()(const uint4 &c0, const uint4 &c1)
@@ -615,23 +617,35 @@ struct GhFold {
 
 __device__ __forceinline__ Gf gf_from4(uint4 v) { return gf_from_words(v.x, v.y, v.z, v.w); }
 
-template <int NR>
-__global__ __launch_bounds__(UAES_WG) void k_gcm_enc_fused(uaesk_rk rk, uaesk_tables tb, uaesk_ctr ctr,
+#ifdef UAES_GF_TIMING                               /* diagnostic build: phase stamps of workgroup 0 (100 MHz clock) */
+#define GF_STAMP(i) do { if (threadIdx.x == 0) gf_ts[i] = wall_clock64(); } while (0)
+#else
+#define GF_STAMP(i) do { } while (0)
+#endif
+
+template <int NR, bool DEC>
+__global__ __launch_bounds__(UAES_WG) void k_gcm_fused(uaesk_rk rk, uaesk_tables tb, uaesk_ctr ctr,
                                                            const uint4 *in, uint4 *out,
                                                            u64 g_lo, u64 stripes, u64 h1, u64 nfull, u32 rem,
                                                            GSrc front, u64 nfront,
                                                            unsigned char *__restrict__ scratch)
 {
+#ifdef UAES_GF_TIMING
+    u64 gf_ts[12];
+#endif
+    GF_STAMP(0);
     uint4 *T = (uint4 *)uaes_lds;                  /* LDS address 0 (absolute addressing in tabmul8_xor) */
     const uint4 *tab8 = (const uint4 *)(scratch + GS_TAB8_F);
     for (u32 i = threadIdx.x; i < 4096u; i += UAES_WG) T[i] = tab8[i];
     fill_tables64(tb.te0, GF_LDS_AES);             /* ends with a barrier */
+    GF_STAMP(1);
     const LaneConst2 lc = make_lane_const2(GF_LDS_AES);
-    GhFold fold;
+    GhFold<DEC> fold;
     fold.gl = gh_lane_setup();
 
     /* tail blocks [h1, nfull) and the ragged bytes */
     ctr_edge_blocks<NR>(rk, ctr, in, out, 0, h1, nfull, rem, lc);
+    GF_STAMP(2);
 
     const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const u32 p = ((wave & 3u) << 6) | lane, quad = wave >> 2;
@@ -643,13 +657,21 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_enc_fused(uaesk_rk rk, uaesk_ta
         fold.acc[u] = make_uint4(0, 0, 0, 0);
         if (j >= S - nfront) {                     /* a block in front of the striped region: AAD, or a head block */
             const u64 f = j - (S - nfront);
-            fold.acc[u] = f < ablk ? load_vblock_fwd(front, f) : ctr_one_block<NR>(rk, ctr, in, out, f - ablk, lc);
+            if (f < ablk) {
+                fold.acc[u] = load_vblock_fwd(front, f);
+            } else {                               /* GHASH takes the ciphertext: the block read when decrypting */
+                const uint4 d = in[f - ablk];
+                const uint4 c = ctr_one_block<NR>(rk, ctr, in, out, f - ablk, lc);
+                fold.acc[u] = DEC ? d : c;
+            }
         }
     }
+    GF_STAMP(3);
     CtrGeo geo;
     geo.first = g_lo;
     geo.iters = stripes / gridDim.x + (blockIdx.x < stripes % gridDim.x ? 1 : 0);
     ctr_shared_loop<NR>(rk, ctr, in, out, geo, GF_LDS_BUF, lc, fold);
+    GF_STAMP(4);
 
     /* ---- the workgroup's 2048 accumulators -> R_b -> weighted share into T ---- */
     __syncthreads();                               /* every wave is done with the AES tables */
@@ -661,9 +683,11 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_enc_fused(uaesk_rk rk, uaesk_ta
         for (u32 i = threadIdx.x; i < 2048u; i += UAES_WG) TC[i] = g4[i];
     }
     __syncthreads();
+    GF_STAMP(5);
     /* lane slot q' = 256 quad + p holds accumulators q' and q' + 1024 */
     buf[(quad << 8) | p] = x4(tabmul4(TC, fold.acc[0]), fold.acc[1]);
     __syncthreads();
+    GF_STAMP(6);
     uint4 acc;
     const u32 qi = threadIdx.x >> 2;                           /* a quad of lanes per accumulator (tabmul4q) */
     if (threadIdx.x < 256) {
@@ -672,18 +696,21 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_enc_fused(uaesk_rk rk, uaesk_ta
         if ((threadIdx.x & 3u) == 0) buf[1024 + qi] = acc;
     }
     __syncthreads();
+    GF_STAMP(7);
     if (threadIdx.x < 16) {
         acc = buf[1024 + qi];
         for (u32 k = 1; k < 16; ++k) acc = x4(tabmul4q(TE, acc), buf[1024 + k * 4 + qi]);
         if ((threadIdx.x & 3u) == 0) buf[1088 + qi] = acc;
     }
     __syncthreads();
+    GF_STAMP(8);
     if (threadIdx.x < 4) {
         acc = buf[1088];
         for (u32 k = 1; k < 4; ++k) acc = x4(tabmul4q(TF, acc), buf[1088 + k]);      /* last term: H^0 */
         if (threadIdx.x == 0) buf[1092] = acc;
     }
     __syncthreads();
+    GF_STAMP(9);
     if (threadIdx.x < 64) {                        /* wave 0: R_b * Ylo[k & 15] * Zhi[k >> 4] */
         const u64 last = (u64)blockIdx.x + (u64)gridDim.x * (geo.iters - 1);        /* this workgroup's last stripe */
         const u32 k = (u32)(stripes - 1 - last);
@@ -698,19 +725,56 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_enc_fused(uaesk_rk rk, uaesk_ta
             for (int i = 0; i < 4; ++i) atomicXor(t + i, ww[i]);
         }
     }
+#ifdef UAES_GF_TIMING
+    GF_STAMP(10);
+    if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))
+        printf("wg %u iters %llu: fill %llu edge %llu head %llu loop %llu tc %llu s1 %llu s2 %llu s3 %llu s4 %llu weight %llu (x10 ns), start %llu\n",
+               blockIdx.x, (unsigned long long)geo.iters,
+               (unsigned long long)(gf_ts[1] - gf_ts[0]), (unsigned long long)(gf_ts[2] - gf_ts[1]), (unsigned long long)(gf_ts[3] - gf_ts[2]),
+               (unsigned long long)(gf_ts[4] - gf_ts[3]), (unsigned long long)(gf_ts[5] - gf_ts[4]), (unsigned long long)(gf_ts[6] - gf_ts[5]),
+               (unsigned long long)(gf_ts[7] - gf_ts[6]), (unsigned long long)(gf_ts[8] - gf_ts[7]), (unsigned long long)(gf_ts[9] - gf_ts[8]),
+               (unsigned long long)(gf_ts[10] - gf_ts[9]), (unsigned long long)gf_ts[0]);
+#endif
 }
 
-template <int NR>
+template <int NR, bool DEC>
 static int launch_fused(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek, const uaesk_ctr *c,
                         const void *in, void *out, unsigned grid, u64 g_lo, u64 stripes, u64 h1, u64 nfull, u32 rem,
                         const GSrc &front, u64 nfront, unsigned char *sc)
 {
-    hipError_t e = hipFuncSetAttribute((const void *)k_gcm_enc_fused<NR>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute((const void *)k_gcm_fused<NR, DEC>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        GF_LDS_TOTAL);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((k_gcm_enc_fused<NR>), dim3(grid), dim3(UAES_WG), GF_LDS_TOTAL, st, *ek, *tb, *c,
+    hipLaunchKernelGGL((k_gcm_fused<NR, DEC>), dim3(grid), dim3(UAES_WG), GF_LDS_TOTAL, st, *ek, *tb, *c,
                        (const uint4 *)in, (uint4 *)out, g_lo, stripes, h1, nfull, rem, front, nfront, sc);
     return (int)hipGetLastError();
+}
+
+template <bool DEC>
+static int launch_fused_nr(int nr, hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek, const uaesk_ctr *c,
+                           const void *in, void *out, unsigned grid, u64 g_lo, u64 stripes, u64 h1, u64 nfull, u32 rem,
+                           const GSrc &front, u64 nfront, unsigned char *sc)
+{
+    switch (nr) {
+    case 10: return launch_fused<10, DEC>(st, tb, ek, c, in, out, grid, g_lo, stripes, h1, nfull, rem, front, nfront, sc);
+    case 12: return launch_fused<12, DEC>(st, tb, ek, c, in, out, grid, g_lo, stripes, h1, nfull, rem, front, nfront, sc);
+    case 14: return launch_fused<14, DEC>(st, tb, ek, c, in, out, grid, g_lo, stripes, h1, nfull, rem, front, nfront, sc);
+    default: return (int)hipErrorInvalidValue;
+    }
+}
+
+/* one-pass decrypt, failed authentication: the plaintext written before the tag was known is zeroed */
+__global__ __launch_bounds__(1024) void k_wipe_if_failed(const int *__restrict__ status, unsigned char *out, u64 len)
+{
+    if (*status == 0) return;
+    const u64 n16 = len >> 4, stride = (u64)gridDim.x * blockDim.x;
+    const u64 tid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (((uintptr_t)out & 15u) == 0) {
+        for (u64 i = tid; i < n16; i += stride) ((uint4 *)out)[i] = make_uint4(0, 0, 0, 0);
+        for (u64 i = (n16 << 4) + tid; i < len; i += stride) out[i] = 0;
+    } else {
+        for (u64 i = tid; i < len; i += stride) out[i] = 0;
+    }
 }
 
 /* ------------------------------------------------------------------------ */
@@ -874,11 +938,15 @@ static int gcm_body(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk
     int rc;
     const uint4 z = make_uint4(0, 0, 0, 0);
 
-    /* Encrypt, long text: CTR and GHASH in one pass (k_gcm_enc_fused).  Needs a power-of-two
-     * number of lanes in the grid (S = 2048 * CUs: 2^19 on MI355X), at least one 2048-block stripe
-     * per workgroup, and the AAD + head blocks to fit in front of one round.  Decrypt
-     * authenticates BEFORE it writes (N7), so it keeps the two-pass order.                */
-    if (!decrypt) {
+    /* Long text: CTR and GHASH in one pass (k_gcm_fused).  Needs a power-of-two number of lanes in
+     * the grid (S = 2048 * CUs: 2^19 on MI355X), at least one 2048-block stripe per workgroup, and
+     * the AAD + head blocks to fit in front of one round.
+     * Decrypt authenticates BEFORE it writes (N7), so by default it keeps the two-pass order;
+     * decrypt == 2 (the caller accepts a zeroed output on failure, or the output is a private staging
+     * buffer) runs one pass as well: the striped region is decrypted while its ciphertext is hashed,
+     * the tag is checked over [T][tail][lengths] with the tail still ciphertext, then the tail is
+     * decrypted (gated on the status) and, on a mismatch, everything written is zeroed.    */
+    if (decrypt != 1) {
         int cus = 0;
         if (uaesk_device_info(&cus, nullptr) != 0) cus = 0;
         const u64 Sl = 2048ull * (u64)(cus > 0 ? cus : 0);
@@ -892,7 +960,7 @@ static int gcm_body(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk
             const u64 h1 = h0 + 2048 * n8;
             GSrc fin;                                   /* [T][tail][lengths] */
             fin.aad = sc + GS_T; fin.aad_len = 16;
-            fin.ct = (const unsigned char *)out + h1 * 16; fin.ct_len = len - h1 * 16;
+            fin.ct = (const unsigned char *)(decrypt ? in : out) + h1 * 16; fin.ct_len = len - h1 * 16;
             fin.has_len = 1; fin.len_aad = aad_len; fin.len_ct = len; fin.rev = 0;
             const u64 nvf = 1 + ((fin.ct_len + 15) >> 4) + 1;
             const GPlan plf = plan_for(nvf);
@@ -914,13 +982,28 @@ static int gcm_body(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk
                 }
             }
             if (rc) return rc;
-            switch (nr) {
-            case 10: rc = launch_fused<10>(st, tb, ek, &c, in, out, (unsigned)cus, g_lo, n8, h1, nfull, (u32)(len % 16), front, ablk + h0, sc); break;
-            case 12: rc = launch_fused<12>(st, tb, ek, &c, in, out, (unsigned)cus, g_lo, n8, h1, nfull, (u32)(len % 16), front, ablk + h0, sc); break;
-            default: rc = launch_fused<14>(st, tb, ek, &c, in, out, (unsigned)cus, g_lo, n8, h1, nfull, (u32)(len % 16), front, ablk + h0, sc); break;
+            if (!decrypt) {
+                rc = launch_fused_nr<false>(nr, st, tb, ek, &c, in, out, (unsigned)cus, g_lo, n8, h1, nfull,
+                                            (u32)(len % 16), front, ablk + h0, sc);
+                if (rc) return rc;
+                return run_ghash_levels(st, fin, nvf, plf, sc, 0, (unsigned char *)out + len, nullptr);
             }
+            /* the fused kernel leaves the tail alone (h1 = nfull, no ragged bytes) */
+            rc = launch_fused_nr<true>(nr, st, tb, ek, &c, in, out, (unsigned)cus, g_lo, n8, nfull, nfull, 0,
+                                       front, ablk + h0, sc);
             if (rc) return rc;
-            return run_ghash_levels(st, fin, nvf, plf, sc, 0, (unsigned char *)out + len, nullptr);
+            rc = run_ghash_levels(st, fin, nvf, plf, sc, 1, (unsigned char *)in + len, status);
+            if (rc) return rc;
+            if (len > h1 * 16) {
+                uaesk_ctr ct = c;
+                ct.v0 = (c.v0 + h1) & 0x00FFFFFFFFFFFFFFull;
+                rc = uaesk_ctr_xcrypt(stream, tb, nr, ek, &ct, (const unsigned char *)in + h1 * 16,
+                                      (unsigned char *)out + h1 * 16, len - h1 * 16, status);
+                if (rc) return rc;
+            }
+            hipLaunchKernelGGL(k_wipe_if_failed, dim3((unsigned)cus * 2u), dim3(1024), 0, st, status,
+                               (unsigned char *)out, (u64)len);
+            return (int)hipGetLastError();
         }
     }
 

@@ -687,6 +687,89 @@ def test_gcm_fused_encrypt_pass(orc, bits):
 
 
 @pytest.mark.parametrize("bits", [128, 192, 256])
+def test_gcm_one_pass_decrypt(orc, bits):
+    """uaes_set_wipe_on_auth_failure(1): a long GCM decrypt into the caller's device buffer runs CTR and
+    GHASH in one pass (k_gcm_fused<NR, true>: the lane hashes the ciphertext block it has just read, the
+    tail is decrypted after the tag check).  Good tags: plaintext identical to the two-pass result, out of
+    place and in place, AAD of every shape, ragged tails, key context too.  Bad tag / bad AAD / a flipped
+    bit anywhere (head, striped region, tail): non-zero status and an all-zero output.  Host buffers take
+    the one-pass kernel regardless of the switch and leave the caller's buffer untouched on 0x1A."""
+    import torch
+    L = uaes.engine()
+    rnd = random.Random(4200 + bits)
+    key, nonce = rnd.randbytes(bits // 8), rnd.randbytes(12)
+    S16 = 16 << 19
+    cases = [(S16 + 254 * 16, 0), (S16 + 254 * 16 + 16, 5), (S16 + 5 * 32768 + 4064 + 7, 13),
+             (2 * S16 + 5000, 16), (3 * S16 - 1, 4096 + 7), (5 * S16 + 12345, 0)]
+    k = uaes.GcmKey(key)
+    try:
+        assert L.uaes_set_wipe_on_auth_failure(1) == 0
+        for i, (n, alen) in enumerate(cases):
+            pt = orc.splitmix(2000 + i, (n + 7) // 8 * 8)[:n]
+            aad = rnd.randbytes(alen)
+            src = torch.frombuffer(bytearray(pt + bytes(16)), dtype=torch.uint8).to("cuda:0")
+            ct = torch.zeros(n + 16, dtype=torch.uint8, device="cuda:0")
+            a = torch.frombuffer(bytearray(aad), dtype=torch.uint8).to("cuda:0") if alen else None
+            uaes.gcm_encrypt_dev(key, nonce, a, src, n, ct)
+            status = torch.full((1,), -1, dtype=torch.int32, device="cuda:0")
+            back = torch.full((n + 32,), 0xCC, dtype=torch.uint8, device="cuda:0")
+            uaes.gcm_decrypt_dev(key, nonce, a, ct, n, back, status)
+            torch.cuda.synchronize()
+            assert int(status.item()) == 0 and torch.equal(back[:n], src[:n]), (n, alen)
+            assert int((back[n:] != 0xCC).sum()) == 0                     # nothing written past the text
+            # key context, in place (CT || tag becomes PT || tag)
+            work = ct.clone()
+            status.fill_(-1)
+            k.decrypt_dev(nonce, a, work, n, work, status)
+            torch.cuda.synchronize()
+            assert int(status.item()) == 0 and torch.equal(work[:n], src[:n]) and torch.equal(work[n:], ct[n:])
+            # forgeries: a bit of the head, of the striped region, of the tail, of the tag; a bit of the AAD
+            spots = [3, 255 * 16 + 1, n // 2, n - 1, n + 5]
+            for j, pos in enumerate(spots if i < 2 or bits == 128 else spots[2:4]):
+                bad = ct.clone()
+                bad[pos] ^= 0x40
+                status.fill_(-1)
+                back.fill_(0xCC)
+                uaes.gcm_decrypt_dev(key, nonce, a, bad, n, back, status)
+                torch.cuda.synchronize()
+                assert int(status.item()) != 0 and int(back[:n].sum()) == 0, (n, alen, pos)
+                assert int((back[n:] != 0xCC).sum()) == 0
+            if alen:
+                a2 = a.clone()
+                a2[alen // 2] ^= 1
+                status.fill_(-1)
+                work = ct.clone()
+                uaes.gcm_decrypt_dev(key, nonce, a2, work, n, work, status)        # in place: the ciphertext is gone
+                torch.cuda.synchronize()
+                assert int(status.item()) != 0 and int(work[:n].sum()) == 0 and torch.equal(work[n:], ct[n:])
+        assert L.uaes_set_wipe_on_auth_failure(0) == 1
+        # default switch: device buffers untouched on a forgery (two passes) ...
+        n = S16 + 70000
+        pt = orc.splitmix(77, n)
+        full = uaes.AES_GCM_encrypt(key, nonce, b"hdr", pt)
+        bad = bytearray(full)
+        bad[n // 3] ^= 2
+        d_bad = torch.frombuffer(bad, dtype=torch.uint8).to("cuda:0")
+        d_hdr = torch.frombuffer(bytearray(b"hdr"), dtype=torch.uint8).to("cuda:0")
+        status = torch.full((1,), -1, dtype=torch.int32, device="cuda:0")
+        back = torch.full((n,), 0xCC, dtype=torch.uint8, device="cuda:0")
+        uaes.gcm_decrypt_dev(key, nonce, d_hdr, d_bad, n, back, status)
+        torch.cuda.synchronize()
+        assert int(status.item()) != 0 and int((back != 0xCC).sum()) == 0
+        # ... and host buffers (one pass in private staging) likewise, both switch settings
+        for sw in (0, 1):
+            L.uaes_set_wipe_on_auth_failure(sw)
+            assert uaes.AES_GCM_decrypt(key, nonce, b"hdr", full) == (0, pt)
+            rc, text = uaes.AES_GCM_decrypt(key, nonce, b"hdr", bytes(bad), prefill=0xCC)
+            assert rc == 0x1A and text == b"\xcc" * n
+            assert k.decrypt(nonce, b"hdr", full) == (0, pt)
+            assert k.decrypt(nonce, b"hdr", bytes(bad), prefill=0xCC) == (0x1A, b"\xcc" * n)
+    finally:
+        L.uaes_set_wipe_on_auth_failure(0)
+        k.close()
+
+
+@pytest.mark.parametrize("bits", [128, 192, 256])
 def test_gcm_key_context_equals_the_one_shot_calls(orc, bits):
     """uaes_gcm_key_*: the key's tables are built once, every message then costs Enc(J0) + the data kernels.
     Messages of every path (last levels only, two-pass bulk with its size-dependent table, one-pass kernel),
