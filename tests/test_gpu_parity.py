@@ -647,7 +647,7 @@ def test_C3_xts256_sectors_device_resident(orc, golden_dir):
 @pytest.mark.parametrize("bits", [128, 192, 256])
 def test_gcm_fused_encrypt_pass(orc, bits):
     """Long GCM encryptions take the one-pass kernel (CTR + GHASH of the ciphertext in registers,
-    k_gcm_enc_fused): sizes around its threshold (one 32 KiB stripe per workgroup + the head),
+    k_gcm_fused): sizes around its threshold (one 32 KiB stripe per workgroup + the head),
     stripe counts that do not divide by the grid (workgroups then differ by one stripe and weight
     their shares differently), ragged tails, AAD of every shape (it becomes initial accumulator
     values), against the oracle and against the two-pass decrypt (which re-hashes the ciphertext
