@@ -334,19 +334,33 @@ __device__ __forceinline__ void enc_blocks(u32 (&s)[U][4], const uaesk_rk &rk, c
  * lock-step version drains them to zero every ~12 lookups).                 */
 /* RKV: round keys FIRST..NR as an array indexed from 0 (may live in VGPRs: a
  * v_bitop3_b32 with an SGPR operand issues ~1.5 cycles slower than all-VGPR) */
-template <int NR, int FIRST, typename RKV, bool DEC = false, typename LC = LaneConst>
+template <int NR, int FIRST, typename RKV, bool DEC = false, typename LC = LaneConst, int PHI = 1>
 __device__ __forceinline__ void enc_rounds_skewed(u32 (&sa)[4], u32 (&sb)[4], const RKV &rkv, const LC &lc)
 {
 #define rkp(r) (&rkv.w[4 * ((r) - FIRST)])
+    /* Wave priority: a wave that is issuing a round's lookups (16 address computations + 16
+     * ds_read) runs at priority 1, a wave that is combining results at 0.  Every SIMD holds
+     * 4 waves; with equal priorities the oldest wave wins the VALU whatever it is about to do,
+     * and the LDS pipe -- the scarcer resource -- idles while combines run.  Measured on 1 GiB,
+     * interleaved A/B (profiles/r02_wave_priority_ab.log): CTR +3.0 %, ECB +2.1 %, ECB decrypt
+     * +6.5 %, XTS-256 +3.6 %, GCM +1.4 %, neutral for OCB and CBC/CFB decrypt.  Priority 2 or 3
+     * instead of 1 does the same for those and costs OCB / CBC / CFB decrypt 3-5 %.
+     * PHI = the priority of the issue phase (the fused GCM kernel uses 2 and runs its GHASH
+     * lookups at 1, between the two: +0.9 % over 1/0 with the GHASH lookups at 0).          */
+#define XPRIO(n) __builtin_amdgcn_s_setprio((n) ? PHI : 0)
     u32 ta[16], tb[16];
     issue16<false, DEC>(sa, ta, lc);
 #pragma unroll
     for (int r = FIRST; r < NR; ++r) {
         __builtin_amdgcn_sched_barrier(0);
+        XPRIO(1);
         issue16<false, DEC>(sb, tb, lc);
+        XPRIO(0);
         __builtin_amdgcn_sched_barrier(0);
         combine16<false, DEC>(ta, rkp(r), sa, lc, (r & 1) != 0);
+        XPRIO(1);
         if (r + 1 < NR) issue16<false, DEC>(sa, ta, lc); else issue16<true, DEC>(sa, ta, lc);
+        XPRIO(0);
         __builtin_amdgcn_sched_barrier(0);
         combine16<false, DEC>(tb, rkp(r), sb, lc, (r & 1) != 0);
     }
@@ -357,6 +371,7 @@ __device__ __forceinline__ void enc_rounds_skewed(u32 (&sa)[4], u32 (&sb)[4], co
     __builtin_amdgcn_sched_barrier(0);
     combine16<true, DEC>(tb, rkp(NR), sb, lc, false);
 #undef rkp
+#undef XPRIO
 }
 
 /* full cipher on two blocks, skewed (state = plaintext words on entry) */

@@ -122,6 +122,7 @@ __device__ __forceinline__ u64 ctr_geo_group0(const CtrGeo &g, u64 it)
  * read (decrypting GCM hashes its input).                                            */
 struct CtrNoFold {
     static constexpr bool of_input = false;
+    static constexpr int round_prio = 1;       /* wave priority while a round's lookups are issued */
     __device__ __forceinline__ void operator()(const uint4 &, const uint4 &) const {}
 };
 
@@ -212,7 +213,7 @@ __device__ __forceinline__ void ctr_shared_loop(const uaesk_rk &rk, const uaesk_
 #undef TL
             s[u][0] = L0 ^ uu.x; s[u][1] = L1 ^ uu.y; s[u][2] = L2 ^ uu.z; s[u][3] = L3 ^ uu.w;
         }
-        enc_rounds_skewed<NR, 3>(s[0], s[1], rkv, lc);
+        enc_rounds_skewed<NR, 3, decltype(rkv), false, LC, FOLD::round_prio>(s[0], s[1], rkv, lc);
         uint4 ct[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {

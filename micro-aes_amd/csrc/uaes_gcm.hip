@@ -586,12 +586,14 @@ __device__ __forceinline__ uint4 tabmul8_xor_half(uint4 a, uint4 x, const GhLane
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         u32x4 e[8];
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int t = 8 * h + i;
             const u32 sel = 0x0c0c0000u | ((4u + (t & 3)) << 8) | (u32)(t & 3);
             e[i] = *(lds_cu128 *)(uintptr_t)__builtin_amdgcn_perm(r[t >> 2], gl.so[t >> 2], sel);
         }
+        __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
 #pragma unroll
@@ -605,6 +607,7 @@ __device__ __forceinline__ uint4 tabmul8_xor_half(uint4 a, uint4 x, const GhLane
 template <bool DEC>
 struct GhFold {
     static constexpr bool of_input = DEC;
+    static constexpr int round_prio = 2;       /* cipher lookups 2 > GHASH lookups 1 > XOR work 0 */
     uint4 acc[2];
     GhLane gl;
     __device__ __forceinline__ void operator()(const uint4 &c0, const uint4 &c1)

@@ -12,7 +12,7 @@ import subprocess
 import sys
 
 CHILD = r'''
-import sys, time
+import sys, time, ctypes as C
 sys.path.insert(0, %(root)r)
 import torch, micro_aes_amd as uaes
 uaes.lib_path.__defaults__ = (%(lib)r,)
@@ -30,7 +30,13 @@ fns = {
     "gcm": lambda: uaes.gcm_encrypt_dev(key, nonce, None, src, n, dst, stream=st),
     "ocb": lambda: uaes.ocb_dev(key, nonce, None, src, n, dst, stream=st),
     "gcm-dec": lambda: uaes.gcm_decrypt_dev(key, nonce, None, dst, n, src, status, stream=st),
+    "ocb-dec": lambda: uaes.ocb_dev(key, nonce, None, dst, n, src, decrypt=True, status=status, stream=st),
+    "cbc-dec": lambda: uaes.engine().uaes_cbc_decrypt(128, key, bytes(16), C.c_void_p(src.data_ptr()), n, C.c_void_p(dst.data_ptr())),
+    "cfb-dec": lambda: uaes.engine().uaes_cfb_decrypt(128, key, bytes(16), C.c_void_p(src.data_ptr()), n, C.c_void_p(dst.data_ptr())),
 }
+if %(wl)r == "ocb-dec":
+    uaes.ocb_dev(key, nonce, None, src, n, dst, stream=st)
+    torch.cuda.synchronize()
 if %(wl)r == "gcm-dec":
     uaes.gcm_encrypt_dev(key, nonce, None, src, n, dst, stream=st)
     torch.cuda.synchronize()
@@ -44,10 +50,12 @@ print("%%-28s %%-8s %%5d MiB  %%.4f ms  %%8.1f GiB/s" %% (%(lib)r, %(wl)r, %(mib
 '''
 
 if __name__ == "__main__":
+    # two libraries, or a comma-separated list in the first argument and "-" as the second
     a, b, wl = sys.argv[1], sys.argv[2], sys.argv[3]
     mib = int(sys.argv[4]) if len(sys.argv) > 4 else 1024
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for lib in (a, b, a, b, a, b):
+    libs = a.split(",") if b == "-" else [a, b]
+    for lib in libs * 3:
         code = CHILD % dict(root=root, lib=lib, wl=wl, mib=mib)
         out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
         print((out.stdout.strip().splitlines() or [out.stderr.strip()[-300:]])[-1])
