@@ -334,7 +334,7 @@ __device__ __forceinline__ void enc_blocks(u32 (&s)[U][4], const uaesk_rk &rk, c
  * lock-step version drains them to zero every ~12 lookups).                 */
 /* RKV: round keys FIRST..NR as an array indexed from 0 (may live in VGPRs: a
  * v_bitop3_b32 with an SGPR operand issues ~1.5 cycles slower than all-VGPR) */
-template <int NR, int FIRST, typename RKV, bool DEC = false, typename LC = LaneConst, int PHI = 1>
+template <int NR, int FIRST, typename RKV, bool DEC = false, typename LC = LaneConst, int PHI = 1, int PLO = 0>
 __device__ __forceinline__ void enc_rounds_skewed(u32 (&sa)[4], u32 (&sb)[4], const RKV &rkv, const LC &lc)
 {
 #define rkp(r) (&rkv.w[4 * ((r) - FIRST)])
@@ -347,7 +347,7 @@ __device__ __forceinline__ void enc_rounds_skewed(u32 (&sa)[4], u32 (&sb)[4], co
      * instead of 1 does the same for those and costs OCB / CBC / CFB decrypt 3-5 %.
      * PHI = the priority of the issue phase (the fused GCM kernel uses 2 and runs its GHASH
      * lookups at 1, between the two: +0.9 % over 1/0 with the GHASH lookups at 0).          */
-#define XPRIO(n) __builtin_amdgcn_s_setprio((n) ? PHI : 0)
+#define XPRIO(n) __builtin_amdgcn_s_setprio((n) ? PHI : PLO)
     u32 ta[16], tb[16];
     issue16<false, DEC>(sa, ta, lc);
 #pragma unroll

@@ -153,6 +153,10 @@ __device__ __forceinline__ void ctr_shared_loop(const uaesk_rk &rk, const uaesk_
     /* Block index of (it, u, lane) = ((group0(it) + 4u) << 8) - c0 [uniform] + lane_blk [per lane].
      * The plaintext of iteration it+1 is requested before the rounds of iteration it, so
      * HBM latency hides under ~260 table lookups.                                       */
+#ifdef UAES_CTR_TIMING
+    u64 ctr_tm_wait = 0;
+    const u64 ctr_tm_start = wall_clock64();
+#endif
     u64 it = 0;
     uint4 d_cur[2], d_nxt[2];
     if (it < geo.iters) {
@@ -184,7 +188,11 @@ __device__ __forceinline__ void ctr_shared_loop(const uaesk_rk &rk, const uaesk_
                 buf[(parity * CTRS_CHUNK + gi) * 2 + 0] = make_uint4(u0, u1, u2, u3);
                 buf[(parity * CTRS_CHUNK + gi) * 2 + 1] = make_uint4(A, 0, 0, 0);
             }
+#ifdef UAES_CTR_TIMING
+            { const u64 t0 = wall_clock64(); __syncthreads(); ctr_tm_wait += wall_clock64() - t0; }
+#else
             __syncthreads();
+#endif
         }
 
         /* request the next iteration's plaintext (clamped to this workgroup's last one) */
@@ -226,6 +234,11 @@ __device__ __forceinline__ void ctr_shared_loop(const uaesk_rk &rk, const uaesk_
         ++it;
         if ((it & 7) == 0) parity ^= 1u;
     }
+#ifdef UAES_CTR_TIMING
+    if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 100))
+        printf("wg %u wave %2u: loop %llu barrier-wait %llu (x10 ns)\n", blockIdx.x, wave,
+               (unsigned long long)(wall_clock64() - ctr_tm_start), (unsigned long long)ctr_tm_wait);
+#endif
 }
 
 #endif
