@@ -270,8 +270,9 @@ def test_fuzz_gcm_one_pass_sizes(orc):
     """8-70 MiB GCM encryptions take the one-pass kernel: random sizes (stripe counts that do not
     divide by the grid, ragged tails), random AAD up to 2 MiB, device buffers in and out of place.
     Ciphertext == the CTR path from J0+1 (itself pinned to the oracle), the tag is accepted by the
-    two-pass decrypt (separate GHASH levels) and rejected after a bit flip; the shortest case of a run
-    is also checked against the oracle end to end."""
+    two-pass decrypt (separate GHASH levels) and by the one-pass decrypt, and rejected by both after a
+    bit flip (output untouched / zeroed); the shortest case of a run is also checked against the oracle
+    end to end."""
     import torch
     rnd = random.Random(606 + 1000003 * int(os.environ.get("UAES_FUZZ_SEED", "0")))
     cases = sorted((rnd.randrange(8 << 20, 70 << 20) + rnd.choice([0, 0, 1, 15, 16, 4064, 4080]) for _ in range(6)))
@@ -297,10 +298,31 @@ def test_fuzz_gcm_one_pass_sizes(orc):
         uaes.gcm_decrypt_dev(key, nonce, a, dst, n, back, status)
         torch.cuda.synchronize()
         assert int(status.item()) == 0 and torch.equal(back, src[:n]), info
-        dst[rnd.randrange(n + 16)] ^= 1 << rnd.randrange(8)
+        # the one-pass decrypt (allowed once the caller accepts a wiped buffer on failure): same plaintext,
+        # out of place and in place
+        L = uaes.engine()
+        try:
+            L.uaes_set_wipe_on_auth_failure(1)
+            back.fill_(0x5A)
+            status.fill_(-1)
+            uaes.gcm_decrypt_dev(key, nonce, a, dst, n, back, status)
+            torch.cuda.synchronize()
+            assert int(status.item()) == 0 and torch.equal(back, src[:n]), info
+            work = dst[: n + 16].clone()
+            uaes.gcm_decrypt_dev(key, nonce, a, work, n, work, status)
+            torch.cuda.synchronize()
+            assert int(status.item()) == 0 and torch.equal(work[:n], src[:n]) and torch.equal(work[n:], dst[n:n + 16]), info
+            dst[rnd.randrange(n + 16)] ^= 1 << rnd.randrange(8)
+            back.fill_(0x5A)
+            uaes.gcm_decrypt_dev(key, nonce, a, dst, n, back, status)
+            torch.cuda.synchronize()
+            assert int(status.item()) == 0x1A and int(back.sum()) == 0, info         # forged: zeroed
+        finally:
+            L.uaes_set_wipe_on_auth_failure(0)
+        back.fill_(0x5A)
         uaes.gcm_decrypt_dev(key, nonce, a, dst, n, back, status)
         torch.cuda.synchronize()
-        assert int(status.item()) == 0x1A, info
+        assert int(status.item()) == 0x1A and int((back != 0x5A).sum()) == 0, info    # forged, default: untouched
         if i == 0:
             pt = bytes(src[:n].cpu().numpy())
             got = uaes.AES_GCM_encrypt(key, nonce, aad, pt)
