@@ -287,6 +287,39 @@ __global__ __launch_bounds__(GH_PT) void k_ghash_pass(GSrc src, u64 nv, const ui
     accs[j] = acc;
 }
 
+/* The last levels shared by k_ghash_final and k_gcm_small: 1024 accumulators (one per thread, the
+ * last `live` of them are not padding) -> 64 -> 4 -> 1 with the nibble tables of H^64, H^4, H.
+ * Dependent chains: a quad of lanes per accumulator (tabmul4q).  The result is valid in thread 0.
+ * buf: 1024 + 64 + 4 entries of LDS.                                                            */
+__device__ __forceinline__ uint4 gh_last_levels(uint4 *buf, const uint4 *TD, const uint4 *TE, const uint4 *TF,
+                                                uint4 acc, u32 live)
+{
+    buf[threadIdx.x] = acc;
+    __syncthreads();
+    const u32 qi = threadIdx.x >> 2;                           /* accumulator this quad works on */
+    if (threadIdx.x < 256) {
+        const u32 k0 = 16u - (live + 63u) / 64u;               /* first row with a live entry */
+        acc = buf[k0 * 64 + qi];
+        for (u32 k = k0 + 1; k < 16; ++k) acc = x4(tabmul4q(TD, acc), buf[k * 64 + qi]);
+        if ((threadIdx.x & 3u) == 0) buf[1024 + qi] = acc;
+    }
+    __syncthreads();
+    const u32 live2 = live < 64u ? live : 64u;
+    if (threadIdx.x < 16) {
+        const u32 k0 = 16u - (live2 + 3u) / 4u;
+        acc = buf[1024 + k0 * 4 + qi];
+        for (u32 k = k0 + 1; k < 16; ++k) acc = x4(tabmul4q(TE, acc), buf[1024 + k * 4 + qi]);
+        if ((threadIdx.x & 3u) == 0) buf[1088 + qi] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const u32 live3 = live2 < 4u ? live2 : 4u;
+        acc = make_uint4(0, 0, 0, 0);
+        for (u32 k = 4u - live3; k < 4; ++k) acc = tabmul4q(TF, x4(acc, buf[1088 + k]));
+    }
+    return acc;
+}
+
 /* ------------------------------------------------------------------------ */
 /* last levels (strides 256, 16, 1) + tag handling; one workgroup             */
 /* ------------------------------------------------------------------------ */
@@ -320,31 +353,8 @@ __global__ __launch_bounds__(GH_T) void k_ghash_final(GSrc src, u64 nv, const un
         if (u >= pad) x = load_vblock(src, u - pad);
         acc = k ? x4(tabmul4(TC, acc), x) : x;
     }
-    buf[threadIdx.x] = acc;
-    __syncthreads();
-    /* the last levels are dependent chains: a quad of lanes per accumulator (tabmul4q) */
     const u32 live = nv < GH_T ? (u32)nv : GH_T;               /* non-padding entries at the end of buf[0..1024) */
-    const u32 qi = threadIdx.x >> 2;                           /* accumulator this quad works on */
-    if (threadIdx.x < 256) {
-        const u32 k0 = 16u - (live + 63u) / 64u;               /* first row with a live entry */
-        acc = buf[k0 * 64 + qi];
-        for (u32 k = k0 + 1; k < 16; ++k) acc = x4(tabmul4q(TD, acc), buf[k * 64 + qi]);
-        if ((threadIdx.x & 3u) == 0) buf[1024 + qi] = acc;
-    }
-    __syncthreads();
-    const u32 live2 = live < 64u ? live : 64u;
-    if (threadIdx.x < 16) {
-        const u32 k0 = 16u - (live2 + 3u) / 4u;
-        acc = buf[1024 + k0 * 4 + qi];
-        for (u32 k = k0 + 1; k < 16; ++k) acc = x4(tabmul4q(TE, acc), buf[1024 + k * 4 + qi]);
-        if ((threadIdx.x & 3u) == 0) buf[1088 + qi] = acc;
-    }
-    __syncthreads();
-    if (threadIdx.x < 4) {
-        const u32 live3 = live2 < 4u ? live2 : 4u;
-        acc = make_uint4(0, 0, 0, 0);
-        for (u32 k = 4u - live3; k < 4; ++k) acc = tabmul4q(TF, x4(acc, buf[1088 + k]));
-    }
+    acc = gh_last_levels(buf, TD, TE, TF, acc, live);
     if (threadIdx.x == 0) {
         if (mode != 2) acc = x4(acc, *(const uint4 *)(scratch + GS_EJ0));
         const u32 w[4] = { acc.x, acc.y, acc.z, acc.w };
@@ -808,6 +818,147 @@ static int launch_ej0(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek
 }
 
 /* ------------------------------------------------------------------------ */
+/* short messages: the whole of GCM in one workgroup                           */
+/* ------------------------------------------------------------------------ */
+/* AAD blocks + text blocks + the length block <= 2047 (a 16 KiB TLS record, a 4 KiB page, a packet):
+ * CTR, GHASH and the tag in ONE launch of one 1024-thread workgroup instead of three launches
+ * (Enc(J0) / CTR / last GHASH levels) -- per call that is what counts (profiles/r02_call_latency.log).
+ * The GHASH input sequence is front-padded to 1024 or 2048 positions; thread t owns positions t and
+ * t + 1024.  A thread whose position is a text block computes that block's keystream itself, so the
+ * ciphertext it hashes is the one it has in registers; thread 0's first position is always padding and
+ * computes Enc(J0) in that slot (every thread runs the same two block encryptions: no divergence
+ * around the rounds).  Decrypt hashes the ciphertext it READS, keeps the plaintext in registers, and
+ * writes it only after the tag has matched (N7, micro_aes.c:1200-1208) -- in the same launch.
+ * Needs the nibble tables of H^1024 / H^64 / H^4 / H in `scratch` (k_gcm_setup, or a key context).
+ * LDS: [0, 64K) the split-halves AES tables, then the four nibble tables and the reduction buffer.   */
+#define GSM_MAXNV      2047u
+#define GSM_LDS_TAB    65536u
+#define GSM_LDS_TOTAL  (GSM_LDS_TAB + (4u * 512u + 1024u + 64u + 4u + 4u) * 16u)
+
+template <int NR, bool DEC>
+__global__ __launch_bounds__(GH_T) void k_gcm_small(uaesk_rk rk, uaesk_tables tb, uaesk_ctr ctr, uint4 j0,
+                                                    GSrc src, const uint4 *in, uint4 *out,
+                                                    const unsigned char *__restrict__ scratch,
+                                                    unsigned char *tag_io, int *status)
+{
+    uint4 *TC = (uint4 *)(uaes_lds + GSM_LDS_TAB);            /* 4 x 512 entries: H^1024, H^64, H^4, H */
+    uint4 *TD = TC + 512, *TE = TD + 512, *TF = TE + 512;
+    uint4 *buf = TF + 512;                                    /* 1024 + 64 + 4, then Enc(J0), verdict */
+    {
+        const uint4 *g4 = (const uint4 *)(scratch + GS_TAB4_C);
+        for (u32 i = threadIdx.x; i < 2048u; i += GH_T) TC[i] = g4[i];
+    }
+    fill_tables64(tb.te0, 0);                                 /* ends with a barrier */
+    const LaneConst2 lc = make_lane_const2(0);
+
+    const u64 len = src.ct_len;
+    const u64 ablk = (src.aad_len + 15) >> 4, cblk = (len + 15) >> 4, nv = ablk + cblk + 1;
+    const u32 steps = nv >= GH_T ? 2u : 1u;                   /* pad >= 1 either way (nv <= 2047) */
+    const u64 pad = (u64)steps * GH_T - nv;
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    uint4 hold[2];                                            /* decrypt: plaintext waiting for the verdict */
+    u64 hold_i[2];
+    u32 hold_n[2] = { 0, 0 };                                 /* bytes of it (0 = none) */
+    for (u32 k = 0; k < steps; ++k) {
+        const u64 u = (u64)k * GH_T + threadIdx.x;
+        const bool live = u >= pad;
+        const u64 v = live ? u - pad : 0;
+        const bool is_text = live && v >= ablk && v < ablk + cblk;
+        const bool is_j0 = k == 0 && threadIdx.x == 0;        /* position 0 is padding */
+        const u64 i = is_text ? v - ablk : 0;
+        u32 s1[1][4];
+        ctr_words(ctr, i, s1[0]);
+        if (is_j0) { s1[0][0] = j0.x; s1[0][1] = j0.y; s1[0][2] = j0.z; s1[0][3] = j0.w; }
+        enc_blocks<NR, 1>(s1, rk, lc);
+        if (is_j0) buf[1092] = make_uint4(s1[0][0], s1[0][1], s1[0][2], s1[0][3]);
+        uint4 x = make_uint4(0, 0, 0, 0);
+        if (is_text) {
+            const u64 avail = len - 16 * i;
+            const u32 nb = avail < 16 ? (u32)avail : 16u;
+            const uint4 d = nb == 16 ? in[i] : load_bytes_padded((const unsigned char *)(in + i), nb);
+            u32 o[4] = { d.x ^ s1[0][0], d.y ^ s1[0][1], d.z ^ s1[0][2], d.w ^ s1[0][3] };
+            if (nb < 16) {                                    /* the keystream beyond the text is not part of it (N3) */
+#pragma unroll
+                for (u32 w = 0; w < 4; ++w) {
+                    const u32 keep = nb >= 4 * w + 4 ? 0xffffffffu : nb <= 4 * w ? 0u : (1u << (8 * (nb - 4 * w))) - 1u;
+                    o[w] &= keep;
+                }
+            }
+            const uint4 ov = make_uint4(o[0], o[1], o[2], o[3]);
+            x = DEC ? d : ov;                                 /* GHASH takes the ciphertext, zero padded (N6) */
+            if (DEC) {
+                hold[k] = ov; hold_i[k] = i; hold_n[k] = nb;
+            } else if (nb == 16) {
+                out[i] = ov;
+            } else {
+                unsigned char *dst = (unsigned char *)(out + i);
+                for (u32 b = 0; b < nb; ++b) dst[b] = (unsigned char)(o[b >> 2] >> (8 * (b & 3)));
+            }
+        } else if (live) {
+            GSrc rest = src;                                  /* AAD blocks and the length block */
+            rest.ct_len = 0;
+            x = load_vblock_fwd(rest, v < ablk ? v : ablk);
+        }
+        acc = k ? x4(tabmul4(TC, acc), x) : x;
+    }
+    const u32 live_n = steps == 1 ? (u32)nv : GH_T;
+    acc = gh_last_levels(buf, TD, TE, TF, acc, live_n);
+    if (threadIdx.x == 0) {
+        acc = x4(acc, buf[1092]);
+        const u32 w[4] = { acc.x, acc.y, acc.z, acc.w };
+        if (DEC) {
+            u32 diff = 0;
+            for (u32 b = 0; b < 16; ++b) diff |= (u32)tag_io[b] ^ ((w[b >> 2] >> (8 * (b & 3))) & 0xffu);
+            *status = diff ? 0x1A : 0;
+            buf[1093] = make_uint4(diff, 0, 0, 0);
+        } else {
+            for (u32 b = 0; b < 16; ++b) tag_io[b] = (unsigned char)(w[b >> 2] >> (8 * (b & 3)));
+        }
+    }
+    if (DEC) {
+        __syncthreads();
+        if (buf[1093].x == 0) {
+#pragma unroll
+            for (u32 k = 0; k < 2; ++k) {
+                if (hold_n[k] == 16) {
+                    out[hold_i[k]] = hold[k];
+                } else if (hold_n[k]) {
+                    const u32 o[4] = { hold[k].x, hold[k].y, hold[k].z, hold[k].w };
+                    unsigned char *dst = (unsigned char *)(out + hold_i[k]);
+                    for (u32 b = 0; b < hold_n[k]; ++b) dst[b] = (unsigned char)(o[b >> 2] >> (8 * (b & 3)));
+                }
+            }
+        }
+    }
+}
+
+template <int NR, bool DEC>
+static int launch_small(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek, const uaesk_ctr *c, uint4 j0,
+                        const GSrc &src, const void *in, void *out, const unsigned char *sc,
+                        unsigned char *tag_io, int *status)
+{
+    hipError_t e = hipFuncSetAttribute((const void *)k_gcm_small<NR, DEC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       GSM_LDS_TOTAL);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((k_gcm_small<NR, DEC>), dim3(1), dim3(GH_T), GSM_LDS_TOTAL, st, *ek, *tb, *c, j0, src,
+                       (const uint4 *)in, (uint4 *)out, sc, tag_io, status);
+    return (int)hipGetLastError();
+}
+
+template <bool DEC>
+static int launch_small_nr(int nr, hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek, const uaesk_ctr *c,
+                           uint4 j0, const GSrc &src, const void *in, void *out, const unsigned char *sc,
+                           unsigned char *tag_io, int *status)
+{
+    switch (nr) {
+    case 10: return launch_small<10, DEC>(st, tb, ek, c, j0, src, in, out, sc, tag_io, status);
+    case 12: return launch_small<12, DEC>(st, tb, ek, c, j0, src, in, out, sc, tag_io, status);
+    case 14: return launch_small<14, DEC>(st, tb, ek, c, j0, src, in, out, sc, tag_io, status);
+    default: return (int)hipErrorInvalidValue;
+    }
+}
+
+/* ------------------------------------------------------------------------ */
 /* host-side drivers                                                          */
 /* ------------------------------------------------------------------------ */
 struct GPlan {
@@ -1011,6 +1162,22 @@ static int gcm_body(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk
     }
 
     const GPlan pl = plan_for(nv);
+    if (nv <= GSM_MAXNV) {                     /* short message: one workgroup does all of it (k_gcm_small) */
+        if (!keyed) {                          /* the nibble tables of this key; a key context has them */
+            switch (nr) {
+            case 10: rc = launch_setup<10>(st, tb, ek, j0, sc, pl, 0, z); break;
+            case 12: rc = launch_setup<12>(st, tb, ek, j0, sc, pl, 0, z); break;
+            case 14: rc = launch_setup<14>(st, tb, ek, j0, sc, pl, 0, z); break;
+            default: return (int)hipErrorInvalidValue;
+            }
+            if (rc) return rc;
+        }
+        GSrc sm = msg;
+        sm.ct = (const unsigned char *)in;     /* the kernel reads the text itself */
+        if (decrypt)
+            return launch_small_nr<true>(nr, st, tb, ek, &c, j0, sm, in, out, sc, (unsigned char *)in + len, status);
+        return launch_small_nr<false>(nr, st, tb, ek, &c, j0, sm, in, out, sc, (unsigned char *)out + len, nullptr);
+    }
     if (keyed && pl.logA == 0) {               /* every table this text needs is in the key context */
         switch (nr) {
         case 10: rc = launch_ej0<10>(st, tb, ek, j0, sc); break;

@@ -687,6 +687,56 @@ def test_gcm_fused_encrypt_pass(orc, bits):
 
 
 @pytest.mark.parametrize("bits", [128, 192, 256])
+def test_gcm_single_launch_sizes(orc, bits):
+    """Messages of at most 2047 GHASH blocks (AAD + text + the length block) run as ONE workgroup that does
+    CTR, GHASH and the tag (k_gcm_small): the boundaries of its two 1024-position steps, ragged texts, AAD
+    of every shape and alignment, both directions, in place, key context, device pointers; forgeries leave
+    the output untouched (N7) although the plaintext was computed in the same launch."""
+    import torch
+    rnd = random.Random(5100 + bits)
+    key = rnd.randbytes(bits // 8)
+    k = uaes.GcmKey(key)
+    # (text bytes, AAD bytes): nv = ceil(a/16) + ceil(n/16) + 1
+    shapes = [(0, 0), (1, 0), (0, 1), (15, 17), (16, 16), (1021 * 16, 0), (1022 * 16, 0), (1022 * 16, 1), (1022 * 16 + 1, 0),
+              (1023 * 16, 0), (1023 * 16 - 5, 16), (1024 * 16, 0), (1500 * 16 + 3, 300), (16 * 16, 2029 * 16),
+              (2045 * 16, 0), (2045 * 16, 16), (2046 * 16 - 1, 0), (2046 * 16, 0), (0, 2046 * 16), (2046 * 16, 1), (2047 * 16, 0),
+              (16384, 13), (4096, 0)]
+    for n, alen in shapes:
+        nonce = rnd.randbytes(12)
+        data, aad = rnd.randbytes(n), rnd.randbytes(alen)
+        want = orc.gcm_encrypt(key, nonce, aad, data)
+        assert uaes.AES_GCM_encrypt(key, nonce, aad, data) == want, (n, alen)
+        assert k.encrypt(nonce, aad, data) == want, (n, alen)
+        assert uaes.AES_GCM_decrypt(key, nonce, aad, want) == (0, data), (n, alen)
+        assert k.decrypt(nonce, aad, want) == (0, data), (n, alen)
+        bad = bytearray(want)
+        bad[rnd.randrange(len(bad))] ^= 1 << rnd.randrange(8)
+        assert uaes.AES_GCM_decrypt(key, nonce, aad, bytes(bad), prefill=0xCC) == (0x1A, b"\xcc" * n), (n, alen)
+        if alen:
+            bad_aad = bytearray(aad)
+            bad_aad[rnd.randrange(alen)] ^= 0x80
+            assert k.decrypt(nonce, bytes(bad_aad), want, prefill=0xCC) == (0x1A, b"\xcc" * n), (n, alen)
+        # device pointers: out of place with guard bytes, then decrypt in place
+        src = torch.frombuffer(bytearray(data + bytes(16)), dtype=torch.uint8).to("cuda:0")
+        dst = torch.full((n + 48,), 0xA5, dtype=torch.uint8, device="cuda:0")
+        a = torch.frombuffer(bytearray(aad + bytes(3)), dtype=torch.uint8).to("cuda:0")[:alen] if alen else None
+        uaes.gcm_encrypt_dev(key, nonce, a, src, n, dst)
+        torch.cuda.synchronize()
+        assert bytes(dst[: n + 16].cpu().numpy()) == want and int((dst[n + 16:] != 0xA5).sum()) == 0, (n, alen)
+        status = torch.full((1,), -1, dtype=torch.int32, device="cuda:0")
+        work = dst[: n + 16].clone()
+        uaes.gcm_decrypt_dev(key, nonce, a, work, n, work, status)
+        torch.cuda.synchronize()
+        assert int(status.item()) == 0 and bytes(work.cpu().numpy()) == data + want[n:], (n, alen)
+        forged = torch.frombuffer(bad, dtype=torch.uint8).to("cuda:0")
+        back = torch.full((n + 16,), 0xCC, dtype=torch.uint8, device="cuda:0")
+        k.decrypt_dev(nonce, a, forged, n, back, status)
+        torch.cuda.synchronize()
+        assert int(status.item()) == 0x1A and int((back != 0xCC).sum()) == 0, (n, alen)
+    k.close()
+
+
+@pytest.mark.parametrize("bits", [128, 192, 256])
 def test_gcm_one_pass_decrypt(orc, bits):
     """uaes_set_wipe_on_auth_failure(1): a long GCM decrypt into the caller's device buffer runs CTR and
     GHASH in one pass (k_gcm_fused<NR, true>: the lane hashes the ciphertext block it has just read, the

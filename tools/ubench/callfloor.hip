@@ -41,9 +41,11 @@ int main()
     (void)hipStreamSynchronize(st);
     uaes_gcm_key *gk = nullptr;
     if (uaes_gcm_key_new(&gk, 128, key)) { fprintf(stderr, "%s\n", uaes_last_error()); return 1; }
-    for (size_t n : { (size_t)16, (size_t)4096, (size_t)65536 }) {
+    for (size_t n : { (size_t)16, (size_t)4096, (size_t)16384, (size_t)65536 }) {
         printf("-- %zu bytes --\n", n);
         printf("uaes_gcm_key_encrypt_dev + sync (key context): %6.2f us\n", us_per_call([&] { uaes_gcm_key_encrypt_dev(gk, nonce, nullptr, 0, din, n, dout, st); (void)hipStreamSynchronize(st); }));
+        printf("uaes_gcm_key_decrypt_dev + sync (key context): %6.2f us\n", us_per_call([&] { uaes_gcm_key_decrypt_dev(gk, nonce, nullptr, 0, dout, n, din, dstat, st); (void)hipStreamSynchronize(st); }));
+        (void)hipMemset(din, 1, 1 << 20);
         printf("uaes_ecb_dev + sync:            %6.2f us\n", us_per_call([&] { uaes_ecb_dev(128, key, 0, din, n, dout, st); (void)hipStreamSynchronize(st); }));
         printf("uaes_ctr_xcrypt_at_dev + sync:  %6.2f us\n", us_per_call([&] { uaes_ctr_xcrypt_at_dev(128, key, ctr0, 0, din, n, dout, st); (void)hipStreamSynchronize(st); }));
         printf("uaes_gcm_encrypt_dev + sync:    %6.2f us\n", us_per_call([&] { uaes_gcm_encrypt_dev(128, key, nonce, nullptr, 0, din, n, dout, st); (void)hipStreamSynchronize(st); }));
