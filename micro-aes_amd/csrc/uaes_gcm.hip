@@ -45,11 +45,9 @@
 #define GS_H        0u
 #define GS_EJ0      16u
 #define GS_POW      64u                         /* 18 x 16                    */
-#define GS_TAB4_C   1024u                       /* H^1024, 8 KiB nibble table */
-#define GS_TAB4_D   (GS_TAB4_C + 8192u)         /* H^64                       */
-#define GS_TAB4_E   (GS_TAB4_D + 8192u)         /* H^4                        */
-#define GS_TAB4_F   (GS_TAB4_E + 8192u)         /* H                          */
-#define GS_TAB8_A   36864u                      /* H^(2^logA), 64 KiB         */
+#define GS_TAB4     1024u                       /* six 8 KiB nibble tables: H^1024, H^256, H^64, H^16, H^4, H */
+#define GT_NTAB     6u
+#define GS_TAB8_A   (GS_TAB4 + GT_NTAB * 8192u) /* H^(2^logA), 64 KiB         */
 #define GS_TAB8_B   (GS_TAB8_A + 65536u)        /* H^(2^14), 64 KiB           */
 #define GS_ACC1     (GS_TAB8_B + 65536u)        /* 2^17 x 16 = 2 MiB          */
 #define GS_ACC2     (GS_ACC1 + (16u << GH_MAXLOG))
@@ -287,35 +285,50 @@ __global__ __launch_bounds__(GH_PT) void k_ghash_pass(GSrc src, u64 nv, const ui
     accs[j] = acc;
 }
 
-/* The last levels shared by k_ghash_final and k_gcm_small: 1024 accumulators (one per thread, the
- * last `live` of them are not padding) -> 64 -> 4 -> 1 with the nibble tables of H^64, H^4, H.
- * Dependent chains: a quad of lanes per accumulator (tabmul4q).  The result is valid in thread 0.
- * buf: 1024 + 64 + 4 entries of LDS.                                                            */
-__device__ __forceinline__ uint4 gh_last_levels(uint4 *buf, const uint4 *TD, const uint4 *TE, const uint4 *TF,
-                                                uint4 acc, u32 live)
+/* The last levels, shared by k_ghash_final, k_gcm_small and the fused kernel's epilogue: 1024
+ * accumulators (one per thread; the last `live` of them are not padding) -> 256 -> 64 -> 16 -> 4 -> 1,
+ * radix 4: level l folds rows k = 0..3 of its input (row k = entries [k m, (k+1) m)) with the nibble
+ * table of H^m,  out_j = ((in_j H^m ^ in_{m+j}) H^m ^ in_{2m+j}) H^m ^ in_{3m+j}.  These are DEPENDENT
+ * multiplications of one wave each (~270 ns: ~80 dependent VALU instructions), so their number is what
+ * a short call pays: 3+3+3+3+4 = 16 here against 15+15+4 = 34 with the radix-16 levels of round 1
+ * (k_ghash_final 12 -> 7 us).  A quad of lanes shares each product (tabmul4q).  Leading rows that hold
+ * only padding are skipped.  GHASH_LAST: the last level multiplies AFTER adding (every block of a GHASH
+ * carries at least one factor H); otherwise the result is sum in_q H^(1023-q) (a workgroup's share).
+ * T: the six nibble tables (T[0..512) = H^1024 is not used here).  buf: GT_BUF entries.  The result is
+ * valid in thread 0.                                                                              */
+#define GT_BUF  (1024u + 256u + 64u + 16u + 4u + 4u)
+
+template <bool GHASH_LAST>
+__device__ __forceinline__ uint4 gh_tree(uint4 *buf, const uint4 *T, uint4 acc, u32 live)
 {
     buf[threadIdx.x] = acc;
     __syncthreads();
     const u32 qi = threadIdx.x >> 2;                           /* accumulator this quad works on */
-    if (threadIdx.x < 256) {
-        const u32 k0 = 16u - (live + 63u) / 64u;               /* first row with a live entry */
-        acc = buf[k0 * 64 + qi];
-        for (u32 k = k0 + 1; k < 16; ++k) acc = x4(tabmul4q(TD, acc), buf[k * 64 + qi]);
-        if ((threadIdx.x & 3u) == 0) buf[1024 + qi] = acc;
+    u32 n = 1024u, off = 0;
+#pragma unroll
+    for (u32 lvl = 1; lvl <= 4; ++lvl) {                       /* tables H^256, H^64, H^16, H^4 */
+        const u32 m = n >> 2;
+        const uint4 *Tl = T + 512u * lvl;
+        if (threadIdx.x < n) {
+            const u32 k0 = 4u - (live + m - 1u) / m;           /* first row with a live entry */
+            acc = buf[off + k0 * m + qi];
+            for (u32 k = k0 + 1; k < 4; ++k) acc = x4(tabmul4q(Tl, acc), buf[off + k * m + qi]);
+            if ((threadIdx.x & 3u) == 0) buf[off + n + qi] = acc;
+        }
+        __syncthreads();
+        off += n;
+        n = m;
+        live = live < m ? live : m;
     }
-    __syncthreads();
-    const u32 live2 = live < 64u ? live : 64u;
-    if (threadIdx.x < 16) {
-        const u32 k0 = 16u - (live2 + 3u) / 4u;
-        acc = buf[1024 + k0 * 4 + qi];
-        for (u32 k = k0 + 1; k < 16; ++k) acc = x4(tabmul4q(TE, acc), buf[1024 + k * 4 + qi]);
-        if ((threadIdx.x & 3u) == 0) buf[1088 + qi] = acc;
-    }
-    __syncthreads();
     if (threadIdx.x < 4) {
-        const u32 live3 = live2 < 4u ? live2 : 4u;
-        acc = make_uint4(0, 0, 0, 0);
-        for (u32 k = 4u - live3; k < 4; ++k) acc = tabmul4q(TF, x4(acc, buf[1088 + k]));
+        const uint4 *TF = T + 512u * 5u;
+        if (GHASH_LAST) {
+            acc = make_uint4(0, 0, 0, 0);
+            for (u32 k = 4u - live; k < 4; ++k) acc = tabmul4q(TF, x4(acc, buf[off + k]));
+        } else {
+            acc = buf[off + 4u - live];
+            for (u32 k = 5u - live; k < 4; ++k) acc = x4(tabmul4q(TF, acc), buf[off + k]);
+        }
     }
     return acc;
 }
@@ -326,23 +339,22 @@ __device__ __forceinline__ uint4 gh_last_levels(uint4 *buf, const uint4 *TD, con
 /* mode 0: write tag = GHASH ^ EJ0 to tag_io (encrypt)
  * mode 1: compare with the 16 bytes at tag_io, *status = 0 / 0x1A (decrypt)
  * mode 2: write the raw GHASH value to tag_io (tests)
- * Levels inside the workgroup: stride 1024 -> 64 -> 4 -> 1 (nibble tables).   */
-#define GHF_LDS ((4u * 512u + 1024u + 64u + 4u) * 16u)
+ * Levels inside the workgroup: stride 1024, then the radix-4 tree (gh_tree).    */
+#define GHF_LDS ((GT_NTAB * 512u + GT_BUF) * 16u)
 
 __global__ __launch_bounds__(GH_T) void k_ghash_final(GSrc src, u64 nv, const unsigned char *__restrict__ scratch,
                                                       int mode, unsigned char *tag_io, int *status)
 {
-    uint4 *TC = (uint4 *)uaes_lds;            /* 4 x 512 entries: H^1024, H^64, H^4, H */
-    uint4 *TD = TC + 512, *TE = TD + 512, *TF = TE + 512;
-    uint4 *buf = TF + 512;                    /* 1024 + 64 + 4 */
-    const uint4 *g4 = (const uint4 *)(scratch + GS_TAB4_C);
-    for (u32 i = threadIdx.x; i < 2048u; i += GH_T) TC[i] = g4[i];
+    uint4 *TC = (uint4 *)uaes_lds;            /* the six nibble tables; TC[0..512) = H^1024 */
+    uint4 *buf = TC + GT_NTAB * 512u;
+    const uint4 *g4 = (const uint4 *)(scratch + GS_TAB4);
+    for (u32 i = threadIdx.x; i < GT_NTAB * 512u; i += GH_T) TC[i] = g4[i];
     __syncthreads();
 
     /* The sequence is front-padded with zero blocks to steps * 1024; a level's leading rows that
      * hold only padding are skipped (their accumulators stay zero), and so is the multiplication
      * of a still-zero accumulator: a short message (the per-call floor) costs a handful of
-     * dependent table multiplications instead of 16 + 16 + 4 + steps, and the tables of the
+     * dependent table multiplications instead of 3 + 3 + 3 + 3 + 4 + steps, and the tables of the
      * levels it never multiplies in need not have been built (launch_setup: maxlog).        */
     const u64 steps = (nv + GH_T - 1) / GH_T;
     const u64 pad = steps * GH_T - nv;
@@ -354,7 +366,7 @@ __global__ __launch_bounds__(GH_T) void k_ghash_final(GSrc src, u64 nv, const un
         acc = k ? x4(tabmul4(TC, acc), x) : x;
     }
     const u32 live = nv < GH_T ? (u32)nv : GH_T;               /* non-padding entries at the end of buf[0..1024) */
-    acc = gh_last_levels(buf, TD, TE, TF, acc, live);
+    acc = gh_tree<true>(buf, TC, acc, live);
     if (threadIdx.x == 0) {
         if (mode != 2) acc = x4(acc, *(const uint4 *)(scratch + GS_EJ0));
         const u32 w[4] = { acc.x, acc.y, acc.z, acc.w };
@@ -389,7 +401,7 @@ __device__ __forceinline__ Gf wave_gfmul(Gf x, Gf y, u32 lane)
     return z;
 }
 
-#define SETUP_LDS   (UAES_LDS_ENC + 16384u)
+#define SETUP_LDS   (UAES_LDS_ENC + 24576u)
 
 /* logA: log2 of the bulk stride (12..17), 0 = no bulk level.  needB: build the
  * H^4096 table.  h_given: skip AES, use hval as H and 0 as Enc(J0) (tests).
@@ -401,13 +413,13 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_setup(uaesk_rk ek, uaesk_tables
                                                        u32 logF, u32 maxlog)
 {
     Gf *shPow = (Gf *)(uaes_lds + UAES_LDS_ENC);          /* up to 21 powers   */
-    Gf *shGen = shPow + 32;                                /* 7 x 128 generators */
+    Gf *shGen = shPow + 32;                                /* 9 x 128 generators: 18 KiB */
     uint4 *gH = (uint4 *)(scratch + GS_H);
 
     if (!h_given) {
         /* H = Enc(0) and Enc(J0): two blocks, a quad of lanes each (quad_encrypt: 4 KiB of table
          * stores instead of 128 KiB, ~2x shorter latency than one lane per block)               */
-        const u32 kb = UAES_LDS_ENC + 15104u;                  /* behind shPow / shGen */
+        const u32 kb = UAES_LDS_ENC + 19200u;                  /* behind shPow / shGen */
         quad_fill_tables(tb.te0, ek, kb);
         const LaneConst lc = quad_lane_const();
         if (threadIdx.x < 64) {                                /* wave 0: quad 0 -> H, the other quads -> Enc(J0) */
@@ -470,11 +482,12 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_setup(uaesk_rk ek, uaesk_tables
     }
     __syncthreads();
 
-    /* generators M*x^q of the tables: A (2^logA), B (2^14), C (2^10), D (2^6), E (2^2), F (2^0), fused (2^logF) */
-    const u32 logs[7] = { logA, GH_LOGB, 10u, 6u, 2u, 0u, logF };
-    if (threadIdx.x < 896) {
-        const u32 t = threadIdx.x >> 7, q = threadIdx.x & 127u;
-        shGen[threadIdx.x] = gf_mul_xq128(shPow[logs[t]], q);
+    /* generators M*x^q of the tables: A (2^logA), B (2^14), the six nibble tables (2^10, 2^8, 2^6, 2^4, 2^2,
+     * 2^0), fused (2^logF)                                                                              */
+    const u32 logs[9] = { logA, GH_LOGB, 10u, 8u, 6u, 4u, 2u, 0u, logF };
+    for (u32 idx = threadIdx.x; idx < 9u * 128u; idx += UAES_WG) {
+        const u32 t = idx >> 7, q = idx & 127u;
+        shGen[idx] = gf_mul_xq128(shPow[logs[t]], q);
     }
     __syncthreads();
 
@@ -482,7 +495,7 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_setup(uaesk_rk ek, uaesk_tables
     for (u32 t = 0; t < 3; ++t) {
         if ((t == 0 && !logA) || (t == 1 && !needB) || (t == 2 && !logF)) continue;
         uint4 *dst = (uint4 *)(scratch + (t == 0 ? GS_TAB8_A : t == 1 ? GS_TAB8_B : GS_TAB8_F));
-        const Gf *gen = shGen + 128 * (t == 2 ? 6 : t);
+        const Gf *gen = shGen + 128 * (t == 2 ? 8 : t);
         const u32 v = threadIdx.x & 255u;
 #pragma unroll
         for (u32 jj = 0; jj < 4; ++jj) {
@@ -502,8 +515,8 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_setup(uaesk_rk ek, uaesk_tables
     /* nibble-indexed tables: entry (p, v) = sum_i bit(v, 3-i) * gen[4p+i] */
     if (threadIdx.x < 512) {
         const u32 p = threadIdx.x >> 4, v = threadIdx.x & 15u;
-        for (u32 t = 0; t < 4; ++t) {
-            uint4 *dst = (uint4 *)(scratch + GS_TAB4_C + 8192u * t);
+        for (u32 t = 0; t < GT_NTAB; ++t) {
+            uint4 *dst = (uint4 *)(scratch + GS_TAB4 + 8192u * t);
             const Gf *gen = shGen + 128 * (2 + t);
             Gf e = { 0, 0 };
 #pragma unroll
@@ -521,7 +534,7 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_setup(uaesk_rk ek, uaesk_tables
         /* weights of the fused kernel's workgroups: Y^k and Z^k = Y^(16k), k < 16 (Y = H^2048), by
          * doubling rounds -- round i computes powers 2^i + 1 .. 2^(i+1) from the ones below, one
          * wave per product, the Y and Z families side by side                                   */
-        Gf *shY = (Gf *)(uaes_lds + UAES_LDS_ENC + 15360u);       /* [0..15] Y^k, [16..31] Z^k */
+        Gf *shY = (Gf *)(uaes_lds + UAES_LDS_ENC + 19456u);       /* [0..15] Y^k, [16..31] Z^k */
         const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
         if (threadIdx.x < 2) {
             const Gf one = { 0x8000000000000000ull, 0 };
@@ -688,40 +701,17 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_fused(uaesk_rk rk, uaesk_tables
 
     /* ---- the workgroup's 2048 accumulators -> R_b -> weighted share into T ---- */
     __syncthreads();                               /* every wave is done with the AES tables */
-    uint4 *TC = (uint4 *)(uaes_lds + GF_LDS_AES);  /* 4 x 512 entries: H^1024, H^64, H^4, H */
-    uint4 *TD = TC + 512, *TE = TD + 512, *TF = TE + 512;
-    uint4 *buf = TF + 512;                         /* 1024 + 64 + 4 + 1 */
+    uint4 *TC = (uint4 *)(uaes_lds + GF_LDS_AES);  /* the six nibble tables, over the AES tables */
+    uint4 *buf = (uint4 *)uaes_lds;                /* GT_BUF entries, over the GHASH table (every wave is past its last fold) */
     {
-        const uint4 *g4 = (const uint4 *)(scratch + GS_TAB4_C);
-        for (u32 i = threadIdx.x; i < 2048u; i += UAES_WG) TC[i] = g4[i];
+        const uint4 *g4 = (const uint4 *)(scratch + GS_TAB4);
+        for (u32 i = threadIdx.x; i < GT_NTAB * 512u; i += UAES_WG) TC[i] = g4[i];
     }
     __syncthreads();
     GF_STAMP(5);
-    /* lane slot q' = 256 quad + p holds accumulators q' and q' + 1024 */
-    buf[(quad << 8) | p] = x4(tabmul4(TC, fold.acc[0]), fold.acc[1]);
-    __syncthreads();
-    GF_STAMP(6);
-    uint4 acc;
-    const u32 qi = threadIdx.x >> 2;                           /* a quad of lanes per accumulator (tabmul4q) */
-    if (threadIdx.x < 256) {
-        acc = buf[qi];
-        for (u32 k = 1; k < 16; ++k) acc = x4(tabmul4q(TD, acc), buf[k * 64 + qi]);
-        if ((threadIdx.x & 3u) == 0) buf[1024 + qi] = acc;
-    }
-    __syncthreads();
-    GF_STAMP(7);
-    if (threadIdx.x < 16) {
-        acc = buf[1024 + qi];
-        for (u32 k = 1; k < 16; ++k) acc = x4(tabmul4q(TE, acc), buf[1024 + k * 4 + qi]);
-        if ((threadIdx.x & 3u) == 0) buf[1088 + qi] = acc;
-    }
-    __syncthreads();
-    GF_STAMP(8);
-    if (threadIdx.x < 4) {
-        acc = buf[1088];
-        for (u32 k = 1; k < 4; ++k) acc = x4(tabmul4q(TF, acc), buf[1088 + k]);      /* last term: H^0 */
-        if (threadIdx.x == 0) buf[1092] = acc;
-    }
+    /* thread q' = 256 quad + p holds accumulators q' and q' + 1024; then the radix-4 tree, last term H^0 */
+    uint4 acc = gh_tree<false>(buf, TC, x4(tabmul4(TC, fold.acc[0]), fold.acc[1]), 1024u);
+    if (threadIdx.x == 0) buf[GT_BUF - 1] = acc;
     __syncthreads();
     GF_STAMP(9);
     if (threadIdx.x < 64) {                        /* wave 0: R_b * Ylo[k & 15] * Zhi[k >> 4] */
@@ -729,7 +719,7 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_fused(uaesk_rk rk, uaesk_tables
         const u32 k = (u32)(stripes - 1 - last);
         const uint4 *yl = (const uint4 *)(scratch + GS_YLO), *zh = (const uint4 *)(scratch + GS_ZHI);
         Gf w = wave_gfmul(gf_from4(yl[k & 15u]), gf_from4(zh[k >> 4]), threadIdx.x);
-        w = wave_gfmul(gf_from4(buf[1092]), w, threadIdx.x);
+        w = wave_gfmul(gf_from4(buf[GT_BUF - 1]), w, threadIdx.x);
         if (threadIdx.x == 0) {
             u32 ww[4];
             gf_to_words(w, ww);
@@ -741,11 +731,10 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_fused(uaesk_rk rk, uaesk_tables
 #ifdef UAES_GF_TIMING
     GF_STAMP(10);
     if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))
-        printf("wg %u iters %llu: fill %llu edge %llu head %llu loop %llu tc %llu s1 %llu s2 %llu s3 %llu s4 %llu weight %llu (x10 ns), start %llu\n",
+        printf("wg %u iters %llu: fill %llu edge %llu head %llu loop %llu tc %llu tree %llu weight %llu (x10 ns), start %llu\n",
                blockIdx.x, (unsigned long long)geo.iters,
                (unsigned long long)(gf_ts[1] - gf_ts[0]), (unsigned long long)(gf_ts[2] - gf_ts[1]), (unsigned long long)(gf_ts[3] - gf_ts[2]),
-               (unsigned long long)(gf_ts[4] - gf_ts[3]), (unsigned long long)(gf_ts[5] - gf_ts[4]), (unsigned long long)(gf_ts[6] - gf_ts[5]),
-               (unsigned long long)(gf_ts[7] - gf_ts[6]), (unsigned long long)(gf_ts[8] - gf_ts[7]), (unsigned long long)(gf_ts[9] - gf_ts[8]),
+               (unsigned long long)(gf_ts[4] - gf_ts[3]), (unsigned long long)(gf_ts[5] - gf_ts[4]), (unsigned long long)(gf_ts[9] - gf_ts[5]),
                (unsigned long long)(gf_ts[10] - gf_ts[9]), (unsigned long long)gf_ts[0]);
 #endif
 }
@@ -829,11 +818,11 @@ static int launch_ej0(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek
  * computes Enc(J0) in that slot (every thread runs the same two block encryptions: no divergence
  * around the rounds).  Decrypt hashes the ciphertext it READS, keeps the plaintext in registers, and
  * writes it only after the tag has matched (N7, micro_aes.c:1200-1208) -- in the same launch.
- * Needs the nibble tables of H^1024 / H^64 / H^4 / H in `scratch` (k_gcm_setup, or a key context).
- * LDS: [0, 64K) the split-halves AES tables, then the four nibble tables and the reduction buffer.   */
+ * Needs the six nibble tables (H^1024 .. H) in `scratch` (k_gcm_setup, or a key context).
+ * LDS: [0, 64K) the split-halves AES tables, then the six nibble tables and the reduction buffer.    */
 #define GSM_MAXNV      2047u
 #define GSM_LDS_TAB    65536u
-#define GSM_LDS_TOTAL  (GSM_LDS_TAB + (4u * 512u + 1024u + 64u + 4u + 4u) * 16u)
+#define GSM_LDS_TOTAL  (GSM_LDS_TAB + (GT_NTAB * 512u + GT_BUF) * 16u)
 
 template <int NR, bool DEC>
 __global__ __launch_bounds__(GH_T) void k_gcm_small(uaesk_rk rk, uaesk_tables tb, uaesk_ctr ctr, uint4 j0,
@@ -841,12 +830,11 @@ __global__ __launch_bounds__(GH_T) void k_gcm_small(uaesk_rk rk, uaesk_tables tb
                                                     const unsigned char *__restrict__ scratch,
                                                     unsigned char *tag_io, int *status)
 {
-    uint4 *TC = (uint4 *)(uaes_lds + GSM_LDS_TAB);            /* 4 x 512 entries: H^1024, H^64, H^4, H */
-    uint4 *TD = TC + 512, *TE = TD + 512, *TF = TE + 512;
-    uint4 *buf = TF + 512;                                    /* 1024 + 64 + 4, then Enc(J0), verdict */
+    uint4 *TC = (uint4 *)(uaes_lds + GSM_LDS_TAB);            /* the six nibble tables; TC[0..512) = H^1024 */
+    uint4 *buf = TC + GT_NTAB * 512u;                         /* GT_BUF entries (the last two: Enc(J0), verdict) */
     {
-        const uint4 *g4 = (const uint4 *)(scratch + GS_TAB4_C);
-        for (u32 i = threadIdx.x; i < 2048u; i += GH_T) TC[i] = g4[i];
+        const uint4 *g4 = (const uint4 *)(scratch + GS_TAB4);
+        for (u32 i = threadIdx.x; i < GT_NTAB * 512u; i += GH_T) TC[i] = g4[i];
     }
     fill_tables64(tb.te0, 0);                                 /* ends with a barrier */
     const LaneConst2 lc = make_lane_const2(0);
@@ -870,7 +858,7 @@ __global__ __launch_bounds__(GH_T) void k_gcm_small(uaesk_rk rk, uaesk_tables tb
         ctr_words(ctr, i, s1[0]);
         if (is_j0) { s1[0][0] = j0.x; s1[0][1] = j0.y; s1[0][2] = j0.z; s1[0][3] = j0.w; }
         enc_blocks<NR, 1>(s1, rk, lc);
-        if (is_j0) buf[1092] = make_uint4(s1[0][0], s1[0][1], s1[0][2], s1[0][3]);
+        if (is_j0) buf[GT_BUF - 2] = make_uint4(s1[0][0], s1[0][1], s1[0][2], s1[0][3]);
         uint4 x = make_uint4(0, 0, 0, 0);
         if (is_text) {
             const u64 avail = len - 16 * i;
@@ -902,22 +890,22 @@ __global__ __launch_bounds__(GH_T) void k_gcm_small(uaesk_rk rk, uaesk_tables tb
         acc = k ? x4(tabmul4(TC, acc), x) : x;
     }
     const u32 live_n = steps == 1 ? (u32)nv : GH_T;
-    acc = gh_last_levels(buf, TD, TE, TF, acc, live_n);
+    acc = gh_tree<true>(buf, TC, acc, live_n);
     if (threadIdx.x == 0) {
-        acc = x4(acc, buf[1092]);
+        acc = x4(acc, buf[GT_BUF - 2]);
         const u32 w[4] = { acc.x, acc.y, acc.z, acc.w };
         if (DEC) {
             u32 diff = 0;
             for (u32 b = 0; b < 16; ++b) diff |= (u32)tag_io[b] ^ ((w[b >> 2] >> (8 * (b & 3))) & 0xffu);
             *status = diff ? 0x1A : 0;
-            buf[1093] = make_uint4(diff, 0, 0, 0);
+            buf[GT_BUF - 1] = make_uint4(diff, 0, 0, 0);
         } else {
             for (u32 b = 0; b < 16; ++b) tag_io[b] = (unsigned char)(w[b >> 2] >> (8 * (b & 3)));
         }
     }
     if (DEC) {
         __syncthreads();
-        if (buf[1093].x == 0) {
+        if (buf[GT_BUF - 1].x == 0) {
 #pragma unroll
             for (u32 k = 0; k < 2; ++k) {
                 if (hold_n[k] == 16) {
@@ -1001,6 +989,8 @@ static int run_ghash_levels(hipStream_t st, const GSrc &msg, u64 nv, const GPlan
             n = sB;
         }
     }
+    e = hipFuncSetAttribute((const void *)k_ghash_final, hipFuncAttributeMaxDynamicSharedMemorySize, GHF_LDS);
+    if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(k_ghash_final, dim3(1), dim3(GH_T), GHF_LDS, st,
                        cur, n, (const unsigned char *)scratch, mode, tag_io, status);
     return (int)hipGetLastError();
@@ -1018,7 +1008,7 @@ static int launch_setup(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *
     if (e != hipSuccess) return (int)e;
     /* powers actually needed: the bulk tables, and of the last-levels tables H^1024 / H^64 / H^4 / H
      * only those a message of nv blocks reaches (k_ghash_final skips the empty levels)       */
-    u32 maxlog = pl.nv > 1024 ? 10u : pl.nv > 64 ? 6u : pl.nv > 4 ? 2u : 0u;
+    u32 maxlog = pl.nv > 1024 ? 10u : pl.nv > 256 ? 8u : pl.nv > 64 ? 6u : pl.nv > 16 ? 4u : pl.nv > 4 ? 2u : 0u;
     if (pl.logA > maxlog) maxlog = pl.logA;
     if (pl.needB && GH_LOGB > maxlog) maxlog = GH_LOGB;
     if (logF > maxlog) maxlog = logF;
