@@ -412,6 +412,13 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_setup(uaesk_rk ek, uaesk_tables
                                                        u32 logA, u32 needB, u32 h_given, uint4 hval, u32 want_pow64,
                                                        u32 logF, u32 maxlog)
 {
+#ifdef UAES_GF_TIMING
+    u64 st_ts[8];
+#define ST_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0) st_ts[i] = wall_clock64(); } while (0)
+#else
+#define ST_STAMP(i) do { } while (0)
+#endif
+    ST_STAMP(0);
     Gf *shPow = (Gf *)(uaes_lds + UAES_LDS_ENC);          /* up to 21 powers   */
     Gf *shGen = shPow + 32;                                /* 9 x 128 generators: 18 KiB */
     uint4 *gH = (uint4 *)(scratch + GS_H);
@@ -436,6 +443,7 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_setup(uaesk_rk ek, uaesk_tables
     }
     __syncthreads();
 
+    ST_STAMP(1);
     const u32 last = want_pow64 ? 63u : maxlog;              /* the highest power any requested table needs */
     if (tb.frob) {
         /* H^(2^k) = F^k H: squaring is the Frobenius map, linear over GF(2) with a matrix that depends on
@@ -482,6 +490,7 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_setup(uaesk_rk ek, uaesk_tables
     }
     __syncthreads();
 
+    ST_STAMP(2);
     /* generators M*x^q of the tables: A (2^logA), B (2^14), the six nibble tables (2^10, 2^8, 2^6, 2^4, 2^2,
      * 2^0), fused (2^logF)                                                                              */
     const u32 logs[9] = { logA, GH_LOGB, 10u, 8u, 6u, 4u, 2u, 0u, logF };
@@ -491,6 +500,7 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_setup(uaesk_rk ek, uaesk_tables
     }
     __syncthreads();
 
+    ST_STAMP(3);
     /* byte-indexed tables: entry (j, v) = sum_i bit(v, 7-i) * gen[8j+i] */
     for (u32 t = 0; t < 3; ++t) {
         if ((t == 0 && !logA) || (t == 1 && !needB) || (t == 2 && !logF)) continue;
@@ -512,6 +522,7 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_setup(uaesk_rk ek, uaesk_tables
             dst[v * 16 + j] = make_uint4(w[0], w[1], w[2], w[3]);      /* row v, slot j */
         }
     }
+    ST_STAMP(4);
     /* nibble-indexed tables: entry (p, v) = sum_i bit(v, 3-i) * gen[4p+i] */
     if (threadIdx.x < 512) {
         const u32 p = threadIdx.x >> 4, v = threadIdx.x & 15u;
@@ -530,6 +541,7 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_setup(uaesk_rk ek, uaesk_tables
             dst[p * 16 + v] = make_uint4(w[0], w[1], w[2], w[3]);
         }
     }
+    ST_STAMP(5);
     if (logF) {
         /* weights of the fused kernel's workgroups: Y^k and Z^k = Y^(16k), k < 16 (Y = H^2048), by
          * doubling rounds -- round i computes powers 2^i + 1 .. 2^(i+1) from the ones below, one
@@ -558,11 +570,21 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_setup(uaesk_rk ek, uaesk_tables
         }
         if (threadIdx.x == 32) *(uint4 *)(scratch + GS_T) = make_uint4(0, 0, 0, 0);
     }
+    ST_STAMP(6);
     if (threadIdx.x <= (want_pow64 ? GH_MAXLOG : (maxlog < GH_MAXLOG ? maxlog : GH_MAXLOG))) {
         u32 w[4];
         gf_to_words(shPow[threadIdx.x], w);
         ((uint4 *)(scratch + GS_POW))[threadIdx.x] = make_uint4(w[0], w[1], w[2], w[3]);
     }
+#ifdef UAES_GF_TIMING
+    ST_STAMP(7);
+    if (threadIdx.x == 0)
+        printf("setup: aes %llu powers %llu gens %llu byte-tables %llu nibble-tables %llu yz %llu store %llu (x10 ns)\n",
+               (unsigned long long)(st_ts[1] - st_ts[0]), (unsigned long long)(st_ts[2] - st_ts[1]), (unsigned long long)(st_ts[3] - st_ts[2]),
+               (unsigned long long)(st_ts[4] - st_ts[3]), (unsigned long long)(st_ts[5] - st_ts[4]), (unsigned long long)(st_ts[6] - st_ts[5]),
+               (unsigned long long)(st_ts[7] - st_ts[6]));
+#endif
+#undef ST_STAMP
 }
 
 /* ------------------------------------------------------------------------ */
