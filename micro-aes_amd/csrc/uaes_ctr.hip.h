@@ -149,6 +149,8 @@ __device__ __forceinline__ void ctr_shared_loop(const uaesk_rk &rk, const uaesk_
     u32 a_cur = 0, L0 = 0, L1 = 0, L2 = 0, L3 = 0;
     bool have_l = false;
     u32 parity = 0;
+    u32 chunk_a = 0;                                        /* A of the current chunk if all its groups share it */
+    bool chunk_same = false;
 
     /* Block index of (it, u, lane) = ((group0(it) + 4u) << 8) - c0 [uniform] + lane_blk [per lane].
      * The plaintext of iteration it+1 is requested before the rounds of iteration it, so
@@ -185,14 +187,20 @@ __device__ __forceinline__ void ctr_shared_loop(const uaesk_rk &rk, const uaesk_
                 const u32 u1 = xor3(TL(0, 0, c1), TL(1, 1, c2), TL(2, 2, c3)) ^ rk.w[9];
                 const u32 u2 = xor3(TL(0, 0, c2), TL(1, 1, c3), TL(3, 3, c1)) ^ rk.w[10];
                 const u32 u3 = xor3(TL(0, 0, c3), TL(2, 2, c1), TL(3, 3, c2)) ^ rk.w[11];
+                /* A(G) moves only when counter bits 40..47 do: a chunk in which all 64 groups share it says so
+                 * in the first group's slot, and the consumers then skip the per-block read of A           */
+                const u32 same = __ballot(A != (u32)__builtin_amdgcn_readfirstlane((int)A)) == 0 ? 1u : 0u;
                 buf[(parity * CTRS_CHUNK + gi) * 2 + 0] = make_uint4(u0, u1, u2, u3);
-                buf[(parity * CTRS_CHUNK + gi) * 2 + 1] = make_uint4(A, 0, 0, 0);
+                buf[(parity * CTRS_CHUNK + gi) * 2 + 1] = make_uint4(A, same, 0, 0);
             }
 #ifdef UAES_CTR_TIMING
             { const u64 t0 = wall_clock64(); __syncthreads(); ctr_tm_wait += wall_clock64() - t0; }
 #else
             __syncthreads();
 #endif
+            const uint4 hdr = buf[(parity * CTRS_CHUNK) * 2 + 1];
+            chunk_a = (u32)__builtin_amdgcn_readfirstlane((int)hdr.x);
+            chunk_same = __builtin_amdgcn_readfirstlane((int)hdr.y) != 0;
         }
 
         /* request the next iteration's plaintext (clamped to this workgroup's last one) */
@@ -208,7 +216,7 @@ __device__ __forceinline__ void ctr_shared_loop(const uaesk_rk &rk, const uaesk_
         for (int u = 0; u < 2; ++u) {
             const u32 gl = 8u * ((u32)it & 7u) + quad + 4u * u;            /* slot in the U-buffer */
             const uint4 uu = buf[(parity * CTRS_CHUNK + gl) * 2 + 0];
-            const u32 A = buf[(parity * CTRS_CHUNK + gl) * 2 + 1].x;
+            const u32 A = chunk_same ? chunk_a : (u32)__builtin_amdgcn_readfirstlane((int)buf[(parity * CTRS_CHUNK + gl) * 2 + 1].x);
             if (!have_l || A != a_cur) {                                   /* wave-uniform; ~never after the first time */
                 const u32 col0 = A ^ TL(3, 3, x15);
                 L0 = TL(0, 0, col0);
