@@ -360,6 +360,85 @@ __global__ __launch_bounds__(UAES_WG) void k_xts(uaesk_rk k1, uaesk_tables tb,
     }
 }
 
+/* ONE short data unit (<= 4 chunks = 16 KiB: the reference API's call shape, a sector per call,
+ * micro_aes.c:1066-1093): T0 = Enc_key2(tweak) is computed HERE instead of by the k_xts_tweaks pre-pass, so a
+ * call is one launch (4 KiB: 28.3 -> 22.5 us).  Wave 0 encrypts the tweak through an unreplicated 1 KiB copy of Te0
+ * behind the cipher tables (all lanes read the same entry: a broadcast, no conflicts; the decrypt direction has no
+ * Te tables in LDS); then one block per lane.  The chunk tweaks T0 * alpha^(256 c) are also written to chunk_tw
+ * for k_xts_cts.                                                                                              */
+#define XTS_SMALL_CHUNKS 4u          /* 1024 blocks: one per lane; longer units spread better over many CUs */
+#define XTS_SMALL_LDS    (UAES_LDS_ENC + 1024u + 16u)
+
+template <int NR>
+__device__ __forceinline__ void plain_encrypt(const u32 *te0, const uaesk_rk &rk, u32 (&s)[4])
+{
+#pragma unroll
+    for (int c = 0; c < 4; ++c) s[c] ^= rk.w[c];
+    for (int r = 1; r < NR; ++r) {
+        u32 t[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            t[c] = te0[s[c] & 0xffu] ^ rotl32(te0[(s[(c + 1) & 3] >> 8) & 0xffu], 8) ^
+                   rotl32(te0[(s[(c + 2) & 3] >> 16) & 0xffu], 16) ^ rotl32(te0[s[(c + 3) & 3] >> 24], 24) ^ rk.w[4 * r + c];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s[c] = t[c];
+    }
+    u32 t[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)                     /* S[x] = byte 1 of Te0[x] */
+        t[c] = (((te0[s[c] & 0xffu] >> 8) & 0xffu) | (te0[(s[(c + 1) & 3] >> 8) & 0xffu] & 0xff00u) |
+                ((te0[(s[(c + 2) & 3] >> 16) & 0xffu] & 0xff00u) << 8) | ((te0[s[(c + 3) & 3] >> 24] & 0xff00u) << 16)) ^
+               rk.w[4 * NR + c];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) s[c] = t[c];
+}
+
+template <int NR, bool DEC>
+__global__ __launch_bounds__(UAES_WG) void k_xts_small(uaesk_rk k1, uaesk_rk k2, uaesk_tables tb,
+                                                       uint4 raw_tweak, u32 use_raw, u64 sector_id,
+                                                       uint4 *__restrict__ chunk_tw, u64 chunks,
+                                                       u64 main_blocks, const unsigned char *in, unsigned char *out)
+{
+    u32 *te_plain = (u32 *)(uaes_lds + UAES_LDS_ENC);
+    uint4 *t0_slot = (uint4 *)(uaes_lds + UAES_LDS_ENC + 1024u);
+    if (threadIdx.x < 256) te_plain[threadIdx.x] = tb.te0[threadIdx.x];
+    if (DEC) fill_dec_tables(tb.td0); else fill_enc_tables(tb.te0);       /* ends with a barrier */
+    const LaneConst lc = make_lane_const();
+    const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (wave == 0) {
+        u32 s[4];
+        if (use_raw) { s[0] = raw_tweak.x; s[1] = raw_tweak.y; s[2] = raw_tweak.z; s[3] = raw_tweak.w; }
+        else { s[0] = (u32)sector_id; s[1] = (u32)(sector_id >> 32); s[2] = 0; s[3] = 0; }   /* copyLint, micro_aes.c:399-404 */
+        plain_encrypt<NR>(te_plain, k2, s);
+        if (lane == 0) *t0_slot = make_uint4(s[0], s[1], s[2], s[3]);
+    }
+    __syncthreads();
+    const uint4 t4 = *t0_slot;
+    Tw t;
+    t.lo = t4.x | ((u64)t4.y << 32);
+    t.hi = t4.z | ((u64)t4.w << 32);
+    /* thread i takes blocks i, i + 1024, ...: one block per lane spreads a 4 KiB unit over four waves (the
+     * latency of ONE block encryption instead of four in a row); 64-block run w + 16 u of the unit has the
+     * base tweak T0 * alpha^(64 (w + 16 u))                                                            */
+    for (u32 q = 0; q < wave; ++q) t = tw_mul_pow64(t);
+    for (u32 u = 0; u < 4; ++u) {
+        const u32 run = wave + 16u * u;                                  /* 64-block run of the unit */
+        if ((run & 3u) == 0 && (run >> 2) < chunks && lane == 0)        /* chunk tweaks for k_xts_cts */
+            chunk_tw[run >> 2] = make_uint4((u32)t.lo, (u32)(t.lo >> 32), (u32)t.hi, (u32)(t.hi >> 32));
+        const u64 blk = 64ull * run + lane;
+        if (64ull * run >= main_blocks) break;                           /* wave-uniform */
+        const Tw tl = tw_mul_pow(t, lane);
+        const u32 tw[4] = { (u32)tl.lo, (u32)(tl.lo >> 32), (u32)tl.hi, (u32)(tl.hi >> 32) };
+        const u64 bc = blk < main_blocks ? blk : main_blocks - 1;        /* clamped: no branch around the rounds */
+        const uint4 d = load16<true>(in + 16u * bc);
+        u32 s[1][4] = { { d.x ^ tw[0], d.y ^ tw[1], d.z ^ tw[2], d.w ^ tw[3] } };
+        if (DEC) dec_blocks<NR, 1>(s, k1, lc); else enc_blocks<NR, 1>(s, k1, lc);
+        if (blk < main_blocks)
+            store16<true>(out + 16u * blk, make_uint4(s[0][0] ^ tw[0], s[0][1] ^ tw[1], s[0][2] ^ tw[2], s[0][3] ^ tw[3]));
+        for (u32 q = 0; q < 16; ++q) t = tw_mul_pow64(t);               /* the next run of this wave */
+    }
+}
+
 /* ciphertext stealing (micro_aes.c:1037-1053): one thread per data unit handles
  * the last whole block m and the r-byte tail.  All inputs are read before any
  * output is written, so in == out is fine.                                  */
@@ -676,6 +755,18 @@ static int launch_xts(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *k1
 
     uint4 raw = make_uint4(0, 0, 0, 0);
     if (tweak16) memcpy(&raw, tweak16, 16);
+    if (nsectors == 1 && mb > 0 && cps <= XTS_SMALL_CHUNKS) {         /* one short unit: one launch (k_xts_small) */
+        e = set_lds((k_xts_small<NR, DEC>), XTS_SMALL_LDS);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((k_xts_small<NR, DEC>), dim3(1), dim3(UAES_WG), XTS_SMALL_LDS, st, *k1, *k2, *tb, raw,
+                           (u32)(tweak16 != nullptr), first_sector, (uint4 *)scratch, cps, mb,
+                           (const unsigned char *)in, (unsigned char *)out);
+        if (r)
+            hipLaunchKernelGGL((k_xts_cts<NR, DEC>), dim3(1), dim3(UAES_WG), lds, st,
+                               *k1, *tb, (const uint4 *)scratch, (u64)1, cps, mb, r, (u64)sector_bytes,
+                               (const unsigned char *)in, (unsigned char *)out);
+        return (int)hipGetLastError();
+    }
     const bool serial = cps <= XTS_SERIAL_CPS;
     if (!serial && ((cps + 63) / 64) >> XTS_POW_N) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL((k_xts_tweaks<NR>), dim3(grid_for(nsectors, UAES_WG)), dim3(UAES_WG), UAES_LDS_ENC, st,

@@ -416,7 +416,10 @@ def test_ecb_padding_modes(orc, golden_dir):
 @pytest.mark.parametrize("bits", [128, 192, 256])
 def test_xts_vs_oracle(orc, bits):
     rnd = random.Random(bits + 1)
-    for n in [16, 17, 31, 32, 33, 100, 4096, 4097, 4111, 4112, 65536, 65536 + 1, (1 << 20) + 5]:
+    # one unit per call: up to 16 KiB is ONE launch (k_xts_small computes Enc_key2(tweak) itself), longer units
+    # take the tweak pre-pass; sizes on both sides of its 64-block runs, 256-block chunks and its upper limit
+    for n in [16, 17, 31, 32, 33, 100, 1008, 1024, 1025, 1040, 4080, 4096, 4097, 4111, 4112, 8192 + 16, 16368, 16384 - 1,
+              16384, 16384 + 1, 16384 + 15, 16384 + 16, 16384 + 17, 65536, 65536 + 1, (1 << 20) + 5]:
         keys, tw = rnd.randbytes(bits // 4), rnd.randbytes(16)
         data = orc.splitmix(n, n)
         rc, ct = uaes.AES_XTS_encrypt(keys, tw, data)
@@ -425,7 +428,8 @@ def test_xts_vs_oracle(orc, bits):
     keys = rnd.randbytes(bits // 4)
     assert uaes.AES_XTS_encrypt(keys, None, b"Q" * 48) == uaes.AES_XTS_encrypt(keys, bytes(16), b"Q" * 48)
     # batched data units, including ciphertext stealing in every unit
-    for sector, count, first in [(4096, 33, 0), (512, 100, (1 << 40) + 7), (528, 9, 5), (16, 70, 1), (25, 40, 2)]:
+    for sector, count, first in [(4096, 33, 0), (512, 100, (1 << 40) + 7), (528, 9, 5), (16, 70, 1), (25, 40, 2),
+                                 (4096, 1, (1 << 63) + 12345), (4100, 1, 77), (16384, 1, 3)]:      # one unit by sector id
         vol = orc.splitmix(sector, sector * count)
         rc, ct = uaes.xts_sectors(keys, first, sector, vol, True)
         assert (rc, ct) == orc.xts_sectors(keys, first, sector, vol, True)
