@@ -121,14 +121,11 @@ __device__ __forceinline__ void wave_xor_reduce(u32 (&v)[4])
 /* ------------------------------------------------------------------------ */
 /* per-call setup: L table, Offset_0, cleared checksum                         */
 /* ------------------------------------------------------------------------ */
+/* thread 0 only */
 template <int NR>
-__global__ __launch_bounds__(UAES_WG) void k_ocb_setup(uaesk_rk ek, uaesk_tables tb,
-                                                       uint4 nonce_block, u32 bottom, u32 nrows,
-                                                       uint4 *__restrict__ scr)
+__device__ __forceinline__ void ocb_setup_body(const uaesk_rk &ek, const LaneConst &lc, uint4 nonce_block, u32 bottom,
+                                               u32 nrows, uint4 *__restrict__ scr)
 {
-    fill_enc_tables(tb.te0);
-    const LaneConst lc = make_lane_const();
-    if (threadIdx.x != 0) return;
     B16 l = { { 0, 0, 0, 0 } };
     ocb_enc1<NR>(l, ek, lc);                          /* L_* = Enc(0)                  */
     for (u32 j = 0; j < nrows; ++j) {                 /* L_$, L_0, L_1, ... by doubling: only as far as
@@ -147,19 +144,27 @@ __global__ __launch_bounds__(UAES_WG) void k_ocb_setup(uaesk_rk ek, uaesk_tables
                                    bswap32((u32)(olo >> 32)), bswap32((u32)olo));
 }
 
+template <int NR>
+__global__ __launch_bounds__(UAES_WG) void k_ocb_setup(uaesk_rk ek, uaesk_tables tb,
+                                                       uint4 nonce_block, u32 bottom, u32 nrows,
+                                                       uint4 *__restrict__ scr)
+{
+    fill_enc_tables(tb.te0);
+    const LaneConst lc = make_lane_const();
+    if (threadIdx.x == 0) ocb_setup_body<NR>(ek, lc, nonce_block, bottom, nrows, scr);
+}
+
 /* ------------------------------------------------------------------------ */
 /* the block loop                                                              */
 /* ------------------------------------------------------------------------ */
+/* the caller has put the L table (ocb_tables_to_lds) and the cipher tables of the direction into LDS */
 template <int NR, bool DEC>
-__global__ __launch_bounds__(UAES_WG) void k_ocb(uaesk_rk rk, uaesk_tables tb,
-                                                 uint4 *__restrict__ scr, u64 nblocks, u32 run,
-                                                 const uint4 *in, uint4 *out)
+__device__ __forceinline__ void ocb_main_body(const uaesk_rk &rk, const LaneConst &lc,
+                                              uint4 *__restrict__ scr, u64 nblocks, u32 run,
+                                              const uint4 *in, uint4 *out)
 {
     /* run (a power of two <= OCB_RUN_MAX) = consecutive chunks per wave; short texts use
      * short runs so that every CU gets work                                        */
-    ocb_tables_to_lds(scr);
-    if (DEC) fill_dec_tables(tb.td0); else fill_enc_tables(tb.te0);
-    const LaneConst lc = make_lane_const();
     const u32 lane = threadIdx.x & 63u;
     /* launched with 16 waves per workgroup, or 4 for short texts (more CUs, see launch_ocb) */
     const u64 wave = (u64)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -273,6 +278,17 @@ __global__ __launch_bounds__(UAES_WG) void k_ocb(uaesk_rk rk, uaesk_tables tb,
     if (threadIdx.x == 0) scr[OCB_ROW_PART + blockIdx.x] = *(const uint4 *)(uaes_lds + OCB_LDS_ACC);
 }
 
+template <int NR, bool DEC>
+__global__ __launch_bounds__(UAES_WG) void k_ocb(uaesk_rk rk, uaesk_tables tb,
+                                                 uint4 *__restrict__ scr, u64 nblocks, u32 run,
+                                                 const uint4 *in, uint4 *out)
+{
+    ocb_tables_to_lds(scr);
+    if (DEC) fill_dec_tables(tb.td0); else fill_enc_tables(tb.te0);
+    const LaneConst lc = make_lane_const();
+    ocb_main_body<NR, DEC>(rk, lc, scr, nblocks, run, in, out);
+}
+
 /* ------------------------------------------------------------------------ */
 /* tails, PMAC of the associated data, tag                                     */
 /* ------------------------------------------------------------------------ */
@@ -284,16 +300,14 @@ __device__ __forceinline__ B16 ocb_load_bytes(const unsigned char *p, u32 n)
     return b;
 }
 
+/* the caller has put the L table with cleared accumulators (ocb_tables_to_lds) and the ENCRYPTION tables into LDS */
 template <int NR>
-__global__ __launch_bounds__(UAES_WG) void k_ocb_final(uaesk_rk ek, uaesk_tables tb,
-                                                       uint4 *__restrict__ scr, u32 nparts, int decrypt,
-                                                       const unsigned char *__restrict__ aad, u64 aad_len,
-                                                       const unsigned char *in, unsigned char *out, u64 len,
-                                                       int *status)
+__device__ __forceinline__ void ocb_final_body(const uaesk_rk &ek, const LaneConst &lc,
+                                               uint4 *__restrict__ scr, u32 nparts, int decrypt,
+                                               const unsigned char *__restrict__ aad, u64 aad_len,
+                                               const unsigned char *in, unsigned char *out, u64 len,
+                                               int *status)
 {
-    ocb_tables_to_lds(scr);
-    fill_enc_tables(tb.te0);
-    const LaneConst lc = make_lane_const();
 
     /* HASH(K, A): Sum ^= Enc(A_i ^ Offset_i), Offset from zero (:1749-1754); all threads */
     u32 h[4] = { 0, 0, 0, 0 };
@@ -359,6 +373,103 @@ __global__ __launch_bounds__(UAES_WG) void k_ocb_final(uaesk_rk ek, uaesk_tables
     }
 }
 
+template <int NR>
+__global__ __launch_bounds__(UAES_WG) void k_ocb_final(uaesk_rk ek, uaesk_tables tb,
+                                                       uint4 *__restrict__ scr, u32 nparts, int decrypt,
+                                                       const unsigned char *__restrict__ aad, u64 aad_len,
+                                                       const unsigned char *in, unsigned char *out, u64 len,
+                                                       int *status)
+{
+    ocb_tables_to_lds(scr);
+    fill_enc_tables(tb.te0);
+    const LaneConst lc = make_lane_const();
+    ocb_final_body<NR>(ek, lc, scr, nparts, decrypt, aad, aad_len, in, out, len, status);
+}
+
+/* Short messages (<= 1024 whole blocks, <= 64 KiB of associated data): setup, block loop and tag in ONE launch of
+ * one workgroup -- the three phases run one after the other with the scratch rows handed over in global memory
+ * behind workgroup barriers; decryption swaps the cipher tables between the phases (setup and tag use Enc).
+ * 4 KiB call: 38.5 -> 30 us (what is left is serial: tables, L_* / K_top / tag encryptions by one lane).                                                                            */
+#define OCB_SMALL_BLOCKS 1024u
+#define OCB_SMALL_AAD    65536u
+
+template <int NR, bool DEC>
+__global__ __launch_bounds__(UAES_WG) void k_ocb_small(uaesk_rk ek, uaesk_rk dk, uaesk_tables tb,
+                                                       uint4 nonce_block, u32 bottom, u32 nrows,
+                                                       uint4 *scr,
+                                                       const unsigned char *__restrict__ aad, u64 aad_len,
+                                                       const unsigned char *in, unsigned char *out, u64 len,
+                                                       int *status)
+{
+#ifdef UAES_OCB_TIMING
+    u64 ts[6];
+#define OT(i) do { if (threadIdx.x == 0) ts[i] = wall_clock64(); } while (0)
+#else
+#define OT(i) do { } while (0)
+#endif
+    OT(0);
+    fill_enc_tables(tb.te0);
+    const LaneConst lc = make_lane_const();
+    OT(1);
+    if (threadIdx.x == 0) ocb_setup_body<NR>(ek, lc, nonce_block, bottom, nrows, scr);
+    __threadfence();
+    __syncthreads();
+    OT(2);
+    const u64 nblocks = len >> 4;
+    u32 nparts = 0;
+    if (nblocks) {
+        ocb_tables_to_lds(scr);
+        if (DEC) fill_dec_tables(tb.td0); else __syncthreads();
+        /* one block per lane (block i = thread + 1, Offset_i = Offset_0 ^ the L_j of gray(i)): a 4 KiB text runs on
+         * four waves with the latency of ONE block encryption; ocb_main_body's wave-per-256-blocks layout would
+         * put it on a single wave, four blocks in a row                                                       */
+        {
+            const u64 i = (u64)threadIdx.x + 1;
+            const bool live = i <= nblocks;
+            const u64 ic = live ? i : nblocks;                 /* clamped: no branch around the rounds */
+            B16 off = b16(scr[OCB_ROW_OFF0]);
+            bx(off, ocb_delta(ic));
+            const uint4 d = ((const uint4 *)in)[ic - 1];
+            const u32 lv = live ? 0xffffffffu : 0u;
+            u32 sum[4] = { 0, 0, 0, 0 };
+            u32 s1[1][4] = { { d.x ^ off.w[0], d.y ^ off.w[1], d.z ^ off.w[2], d.w ^ off.w[3] } };
+            if (!DEC) { sum[0] = d.x & lv; sum[1] = d.y & lv; sum[2] = d.z & lv; sum[3] = d.w & lv; }
+            if (DEC) dec_blocks<NR, 1>(s1, dk, lc); else enc_blocks<NR, 1>(s1, ek, lc);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s1[0][q] ^= off.w[q];
+            if (DEC) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sum[q] = s1[0][q] & lv;
+            }
+            if (live) ((uint4 *)out)[i - 1] = make_uint4(s1[0][0], s1[0][1], s1[0][2], s1[0][3]);
+            wave_xor_reduce(sum);
+            if ((threadIdx.x & 63u) == 0) {
+                u32 *acc = (u32 *)(uaes_lds + OCB_LDS_ACC);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) atomicXor(acc + q, sum[q]);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) scr[OCB_ROW_PART] = *(const uint4 *)(uaes_lds + OCB_LDS_ACC);
+        }
+        nparts = 1;
+        __threadfence();
+        __syncthreads();
+    }
+    OT(3);
+    ocb_tables_to_lds(scr);
+    if (DEC && nblocks) fill_enc_tables(tb.te0); else __syncthreads();
+    OT(4);
+    ocb_final_body<NR>(ek, lc, scr, nparts, DEC ? 1 : 0, aad, aad_len, in, out, len, status);
+#ifdef UAES_OCB_TIMING
+    OT(5);
+    if (threadIdx.x == 0)
+        printf("ocb small: fill %llu setup %llu main %llu tables %llu final %llu (x10 ns)\n", (unsigned long long)(ts[1] - ts[0]),
+               (unsigned long long)(ts[2] - ts[1]), (unsigned long long)(ts[3] - ts[2]), (unsigned long long)(ts[4] - ts[3]),
+               (unsigned long long)(ts[5] - ts[4]));
+#endif
+#undef OT
+}
+
 /* ------------------------------------------------------------------------ */
 /* launcher                                                                    */
 /* ------------------------------------------------------------------------ */
@@ -389,6 +500,19 @@ static int launch_ocb(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek
     u32 bits = 0;
     while (span) { ++bits; span >>= 1; }
     const u32 nrows = 2u + bits + 2u < OCB_NL ? 2u + bits + 2u : OCB_NL;
+    if ((len >> 4) <= OCB_SMALL_BLOCKS && aad_len <= OCB_SMALL_AAD) {         /* short message: one launch */
+        const void *ks = decrypt ? (const void *)k_ocb_small<NR, true> : (const void *)k_ocb_small<NR, false>;
+        if ((e = want_lds(ks)) != hipSuccess) return (int)e;
+        if (decrypt)
+            hipLaunchKernelGGL((k_ocb_small<NR, true>), dim3(1), dim3(UAES_WG), OCB_LDS, st, *ek, *dk, *tb, nb, bottom, nrows,
+                               scr, (const unsigned char *)aad, (u64)aad_len, (const unsigned char *)in,
+                               (unsigned char *)out, (u64)len, status);
+        else
+            hipLaunchKernelGGL((k_ocb_small<NR, false>), dim3(1), dim3(UAES_WG), OCB_LDS, st, *ek, *ek, *tb, nb, bottom, nrows,
+                               scr, (const unsigned char *)aad, (u64)aad_len, (const unsigned char *)in,
+                               (unsigned char *)out, (u64)len, status);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL((k_ocb_setup<NR>), dim3(1), dim3(UAES_WG), OCB_LDS, st, *ek, *tb, nb, bottom, nrows, scr);
     const u64 nblocks = len >> 4;
     u32 nparts = 0;

@@ -244,11 +244,12 @@ def test_ocb_openssl_vectors():
 def test_ocb_vs_oracle(orc, bits):
     """chunk (256-block) and run (16-chunk) edges of the Gray-code offsets, ragged tails, long AAD"""
     rnd = random.Random(bits + 7)
-    sizes = [0, 1, 15, 16, 17, 255 * 16, 256 * 16, 256 * 16 + 5, 4095 * 16, 4096 * 16, 4097 * 16 + 3,
-             (1 << 20) + 16, (3 << 20) + 7, (16 << 20) - 16]
+    # up to 1024 whole blocks and 64 KiB of AAD a call is ONE launch (k_ocb_small); both sides of that limit
+    sizes = [0, 1, 15, 16, 17, 63 * 16, 64 * 16 + 1, 255 * 16, 256 * 16, 256 * 16 + 5, 1023 * 16 + 15, 1024 * 16, 1024 * 16 + 15,
+             1025 * 16, 4095 * 16, 4096 * 16, 4097 * 16 + 3, (1 << 20) + 16, (3 << 20) + 7, (16 << 20) - 16]
     for n in sizes:
         key, nonce = rnd.randbytes(bits // 8), rnd.randbytes(11) + bytes([rnd.randrange(256)])
-        aad = rnd.randbytes(rnd.choice([0, 1, 16, 20, 4097, 70000]))
+        aad = rnd.randbytes(rnd.choice([0, 1, 16, 20, 4097, 65536, 65537, 70000]))
         data = orc.splitmix(n + 9, n)
         ct = uaes.AES_OCB_encrypt(key, nonce, aad, data)
         assert ct == orc.ocb_encrypt(key, nonce, aad, data), n
