@@ -828,6 +828,49 @@ static int launch_ej0(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek
     return (int)hipGetLastError();
 }
 
+/* The six nibble tables of a key made INSIDE a kernel, from H in buf[GT_BUF - 3] (k_gcm_small, one-shot calls:
+ * no k_gcm_setup launch in front).  Same arithmetic as k_gcm_setup: H^(2^k) = F^k H by the constant Frobenius
+ * matrices (one wave per power), the 128 generators M x^q of every table, then entry (p, v) = the XOR of the
+ * generators the nibble v selects.  buf is scratch here (the reduction buffer is not in use yet).  All 1024
+ * threads call it; ends with a barrier.                                                                    */
+__device__ __forceinline__ void gcm_build_nibble_tables(uint4 *TC, uint4 *buf, const uint64_t *__restrict__ frob)
+{
+    Gf *shPow = (Gf *)buf;                         /* 6 powers                  */
+    Gf *shGen = (Gf *)(buf + 16);                  /* 6 x 128 generators: 12 KiB */
+    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    if (wave < GT_NTAB) {
+        const u32 k = 10u - 2u * wave;             /* table t holds H^(2^(10 - 2t)) */
+        const Gf h = gf_from4(buf[GT_BUF - 3]);
+        Gf pw = h;
+        if (k) {
+            const uint64_t *rows = frob + (u64)(k - 1) * 256u;
+            const u32 b0 = (u32)(__popcll(rows[2 * lane] & h.hi) + __popcll(rows[2 * lane + 1] & h.lo)) & 1u;
+            const u32 b1 = (u32)(__popcll(rows[128 + 2 * lane] & h.hi) + __popcll(rows[128 + 2 * lane + 1] & h.lo)) & 1u;
+            pw.hi = __ballot(b0);
+            pw.lo = __ballot(b1);
+        }
+        if (lane == 0) shPow[wave] = pw;
+    }
+    __syncthreads();
+    for (u32 idx = threadIdx.x; idx < GT_NTAB * 128u; idx += GH_T) shGen[idx] = gf_mul_xq128(shPow[idx >> 7], idx & 127u);
+    __syncthreads();
+    for (u32 e = threadIdx.x; e < GT_NTAB * 512u; e += GH_T) {
+        const u32 t = e >> 9, p = (e >> 4) & 31u, v = e & 15u;
+        const Gf *gen = shGen + 128u * t;
+        Gf x = { 0, 0 };
+#pragma unroll
+        for (u32 i = 0; i < 4; ++i) {
+            const u64 m = 0 - (u64)((v >> (3 - i)) & 1u);
+            x.hi ^= gen[4 * p + i].hi & m;
+            x.lo ^= gen[4 * p + i].lo & m;
+        }
+        u32 w[4];
+        gf_to_words(x, w);
+        TC[e] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    __syncthreads();
+}
+
 /* ------------------------------------------------------------------------ */
 /* short messages: the whole of GCM in one workgroup                           */
 /* ------------------------------------------------------------------------ */
@@ -840,9 +883,9 @@ static int launch_ej0(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek
  * computes Enc(J0) in that slot (every thread runs the same two block encryptions: no divergence
  * around the rounds).  Decrypt hashes the ciphertext it READS, keeps the plaintext in registers, and
  * writes it only after the tag has matched (N7, micro_aes.c:1200-1208) -- in the same launch.
- * Needs the six nibble tables (H^1024 .. H) in `scratch` (k_gcm_setup, or a key context).
+ * The six nibble tables (H^1024 .. H) come from `scratch` (a key context, k_gcm_setup) or are made here.
  * LDS: [0, 64K) the split-halves AES tables, then the six nibble tables and the reduction buffer.    */
-#define GSM_MAXNV      2047u
+#define GSM_MAXNV      2046u           /* two padding positions in front: Enc(J0) and (one-shot calls) H = Enc(0) */
 #define GSM_LDS_TAB    65536u
 #define GSM_LDS_TOTAL  (GSM_LDS_TAB + (GT_NTAB * 512u + GT_BUF) * 16u)
 
@@ -850,11 +893,13 @@ template <int NR, bool DEC>
 __global__ __launch_bounds__(GH_T) void k_gcm_small(uaesk_rk rk, uaesk_tables tb, uaesk_ctr ctr, uint4 j0,
                                                     GSrc src, const uint4 *in, uint4 *out,
                                                     const unsigned char *__restrict__ scratch,
-                                                    unsigned char *tag_io, int *status)
+                                                    unsigned char *tag_io, int *status, u32 build)
 {
+    /* build != 0: a one-shot call -- the key's nibble tables are not in `scratch`, they are made here from
+     * H = Enc(0), which thread 1's padding slot computes (gcm_build_nibble_tables)                        */
     uint4 *TC = (uint4 *)(uaes_lds + GSM_LDS_TAB);            /* the six nibble tables; TC[0..512) = H^1024 */
-    uint4 *buf = TC + GT_NTAB * 512u;                         /* GT_BUF entries (the last two: Enc(J0), verdict) */
-    {
+    uint4 *buf = TC + GT_NTAB * 512u;                         /* GT_BUF entries (the last three: H, Enc(J0), verdict) */
+    if (!build) {
         const uint4 *g4 = (const uint4 *)(scratch + GS_TAB4);
         for (u32 i = threadIdx.x; i < GT_NTAB * 512u; i += GH_T) TC[i] = g4[i];
     }
@@ -863,9 +908,9 @@ __global__ __launch_bounds__(GH_T) void k_gcm_small(uaesk_rk rk, uaesk_tables tb
 
     const u64 len = src.ct_len;
     const u64 ablk = (src.aad_len + 15) >> 4, cblk = (len + 15) >> 4, nv = ablk + cblk + 1;
-    const u32 steps = nv >= GH_T ? 2u : 1u;                   /* pad >= 1 either way (nv <= 2047) */
+    const u32 steps = nv + 2 > GH_T ? 2u : 1u;                /* pad >= 2 either way (nv <= 2046) */
     const u64 pad = (u64)steps * GH_T - nv;
-    uint4 acc = make_uint4(0, 0, 0, 0);
+    uint4 xk[2] = { make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0) };
     uint4 hold[2];                                            /* decrypt: plaintext waiting for the verdict */
     u64 hold_i[2];
     u32 hold_n[2] = { 0, 0 };                                 /* bytes of it (0 = none) */
@@ -874,13 +919,16 @@ __global__ __launch_bounds__(GH_T) void k_gcm_small(uaesk_rk rk, uaesk_tables tb
         const bool live = u >= pad;
         const u64 v = live ? u - pad : 0;
         const bool is_text = live && v >= ablk && v < ablk + cblk;
-        const bool is_j0 = k == 0 && threadIdx.x == 0;        /* position 0 is padding */
+        const bool is_j0 = k == 0 && threadIdx.x == 0;        /* positions 0 and 1 are padding */
+        const bool is_h = k == 0 && threadIdx.x == 1;
         const u64 i = is_text ? v - ablk : 0;
         u32 s1[1][4];
         ctr_words(ctr, i, s1[0]);
         if (is_j0) { s1[0][0] = j0.x; s1[0][1] = j0.y; s1[0][2] = j0.z; s1[0][3] = j0.w; }
+        if (is_h) { s1[0][0] = 0; s1[0][1] = 0; s1[0][2] = 0; s1[0][3] = 0; }
         enc_blocks<NR, 1>(s1, rk, lc);
         if (is_j0) buf[GT_BUF - 2] = make_uint4(s1[0][0], s1[0][1], s1[0][2], s1[0][3]);
+        if (is_h) buf[GT_BUF - 3] = make_uint4(s1[0][0], s1[0][1], s1[0][2], s1[0][3]);
         uint4 x = make_uint4(0, 0, 0, 0);
         if (is_text) {
             const u64 avail = len - 16 * i;
@@ -909,8 +957,14 @@ __global__ __launch_bounds__(GH_T) void k_gcm_small(uaesk_rk rk, uaesk_tables tb
             rest.ct_len = 0;
             x = load_vblock_fwd(rest, v < ablk ? v : ablk);
         }
-        acc = k ? x4(tabmul4(TC, acc), x) : x;
+        xk[k] = x;
     }
+    if (build) {
+        __syncthreads();                                      /* H is in its slot */
+        gcm_build_nibble_tables(TC, buf, tb.frob);
+    }
+    uint4 acc = xk[0];
+    if (steps == 2) acc = x4(tabmul4(TC, acc), xk[1]);
     const u32 live_n = steps == 1 ? (u32)nv : GH_T;
     acc = gh_tree<true>(buf, TC, acc, live_n);
     if (threadIdx.x == 0) {
@@ -945,25 +999,25 @@ __global__ __launch_bounds__(GH_T) void k_gcm_small(uaesk_rk rk, uaesk_tables tb
 template <int NR, bool DEC>
 static int launch_small(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek, const uaesk_ctr *c, uint4 j0,
                         const GSrc &src, const void *in, void *out, const unsigned char *sc,
-                        unsigned char *tag_io, int *status)
+                        unsigned char *tag_io, int *status, u32 build)
 {
     hipError_t e = hipFuncSetAttribute((const void *)k_gcm_small<NR, DEC>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        GSM_LDS_TOTAL);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL((k_gcm_small<NR, DEC>), dim3(1), dim3(GH_T), GSM_LDS_TOTAL, st, *ek, *tb, *c, j0, src,
-                       (const uint4 *)in, (uint4 *)out, sc, tag_io, status);
+                       (const uint4 *)in, (uint4 *)out, sc, tag_io, status, build);
     return (int)hipGetLastError();
 }
 
 template <bool DEC>
 static int launch_small_nr(int nr, hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek, const uaesk_ctr *c,
                            uint4 j0, const GSrc &src, const void *in, void *out, const unsigned char *sc,
-                           unsigned char *tag_io, int *status)
+                           unsigned char *tag_io, int *status, u32 build)
 {
     switch (nr) {
-    case 10: return launch_small<10, DEC>(st, tb, ek, c, j0, src, in, out, sc, tag_io, status);
-    case 12: return launch_small<12, DEC>(st, tb, ek, c, j0, src, in, out, sc, tag_io, status);
-    case 14: return launch_small<14, DEC>(st, tb, ek, c, j0, src, in, out, sc, tag_io, status);
+    case 10: return launch_small<10, DEC>(st, tb, ek, c, j0, src, in, out, sc, tag_io, status, build);
+    case 12: return launch_small<12, DEC>(st, tb, ek, c, j0, src, in, out, sc, tag_io, status, build);
+    case 14: return launch_small<14, DEC>(st, tb, ek, c, j0, src, in, out, sc, tag_io, status, build);
     default: return (int)hipErrorInvalidValue;
     }
 }
@@ -1175,7 +1229,10 @@ static int gcm_body(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk
 
     const GPlan pl = plan_for(nv);
     if (nv <= GSM_MAXNV) {                     /* short message: one workgroup does all of it (k_gcm_small) */
-        if (!keyed) {                          /* the nibble tables of this key; a key context has them */
+        /* the nibble tables of this key: a key context has them; a one-shot call makes them inside the same
+         * launch (needs the Frobenius matrices), else k_gcm_setup runs first                              */
+        const u32 build = (!keyed && tb->frob) ? 1u : 0u;
+        if (!keyed && !build) {
             switch (nr) {
             case 10: rc = launch_setup<10>(st, tb, ek, j0, sc, pl, 0, z); break;
             case 12: rc = launch_setup<12>(st, tb, ek, j0, sc, pl, 0, z); break;
@@ -1187,8 +1244,8 @@ static int gcm_body(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk
         GSrc sm = msg;
         sm.ct = (const unsigned char *)in;     /* the kernel reads the text itself */
         if (decrypt)
-            return launch_small_nr<true>(nr, st, tb, ek, &c, j0, sm, in, out, sc, (unsigned char *)in + len, status);
-        return launch_small_nr<false>(nr, st, tb, ek, &c, j0, sm, in, out, sc, (unsigned char *)out + len, nullptr);
+            return launch_small_nr<true>(nr, st, tb, ek, &c, j0, sm, in, out, sc, (unsigned char *)in + len, status, build);
+        return launch_small_nr<false>(nr, st, tb, ek, &c, j0, sm, in, out, sc, (unsigned char *)out + len, nullptr, build);
     }
     if (keyed && pl.logA == 0) {               /* every table this text needs is in the key context */
         switch (nr) {
