@@ -126,6 +126,11 @@ int uaesk_polyval(void *stream, const uaesk_tables *tb, const uint8_t *hg_host,
                   const void *aad, size_t aad_len, const void *pt, size_t pt_len,
                   void *scratch, void *pv_out16);
 
+/* short GCM-SIV message in one launch; -1 = not applicable (too long): take the general path */
+int uaesk_gcmsiv_small(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek, int decrypt,
+                       const uint8_t *hg16, const uint8_t *nonce12,
+                       const void *aad, size_t aad_len, const void *in, size_t len, void *out, int *status);
+
 /* GHASH only: gh = GHASH_H(aad, ct) with H given (device), for tests.      */
 int uaesk_ghash(void *stream, const uaesk_tables *tb, const uint8_t *H_host,
                 const void *aad, size_t aad_len, const void *ct, size_t ct_len,

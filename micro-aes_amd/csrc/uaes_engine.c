@@ -1563,9 +1563,21 @@ static int gcmsiv_derive(context *c, int keybits, const uint8_t *key, const uint
         memcpy(blocks + 16 * i + 4, nonce, 12);
     }
     if (grow(&c->aad_stage, &c->aad_cap, 256)) return UAES_E_HIP;
-    HIPCHK(hipMemcpy(c->aad_stage, blocks, (size_t)(16 * n), hipMemcpyHostToDevice));
-    KCHK(uaesk_ecb(NULL, &c->tb, master.nr, &master.ek, 0, c->aad_stage, c->aad_stage, (size_t)n, 0, 0));
-    HIPCHK(hipMemcpy(blocks, c->aad_stage, (size_t)(16 * n), hipMemcpyDeviceToHost));
+    if (pinned_ready(c)) {
+        /* through the pinned bounce buffers: two asynchronous copies around the kernel and ONE synchronisation
+         * (pageable hipMemcpy in, kernel, pageable hipMemcpy out synchronise three times: ~30 us -> ~18 us) */
+        if (c->pin_busy) { HIPCHK(hipStreamSynchronize(NULL)); c->pin_busy = 0; }
+        memcpy(c->pin[0], blocks, (size_t)(16 * n));
+        HIPCHK(hipMemcpyAsync(c->aad_stage, c->pin[0], (size_t)(16 * n), hipMemcpyHostToDevice, NULL));
+        KCHK(uaesk_ecb(NULL, &c->tb, master.nr, &master.ek, 0, c->aad_stage, c->aad_stage, (size_t)n, 0, 0));
+        HIPCHK(hipMemcpyAsync(c->pin[1], c->aad_stage, (size_t)(16 * n), hipMemcpyDeviceToHost, NULL));
+        HIPCHK(hipStreamSynchronize(NULL));
+        memcpy(blocks, c->pin[1], (size_t)(16 * n));
+    } else {
+        HIPCHK(hipMemcpy(c->aad_stage, blocks, (size_t)(16 * n), hipMemcpyHostToDevice));
+        KCHK(uaesk_ecb(NULL, &c->tb, master.nr, &master.ek, 0, c->aad_stage, c->aad_stage, (size_t)n, 0, 0));
+        HIPCHK(hipMemcpy(blocks, c->aad_stage, (size_t)(16 * n), hipMemcpyDeviceToHost));
+    }
     for (i = 0; i < n; ++i) memcpy(derived + 8 * i, blocks + 16 * i, 8);
     memcpy(out->hg, derived, 16);
     rev16_bytes(out->hg);
@@ -1625,6 +1637,12 @@ int uaes_gcmsiv_encrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
         /* aad_stage was used for the derivation blocks: stage the AAD after it */
         if ((rc = stage_aad(c, aData, aDataLen, &d_aad)) != 0) break;
         if ((rc = plan_io(c, pntxt, ptextLen, crtxt, ptextLen + 16, &io)) != 0) break;
+        {   /* a short message is one launch (k_siv_small): POLYVAL, tag and keystream in one workgroup */
+            int ks = uaesk_gcmsiv_small(NULL, &c->tb, k.enc.nr, &k.enc.ek, 0, k.hg, nonce, d_aad, aDataLen,
+                                        io.din, ptextLen, io.dout, NULL);
+            if (ks > 0) { rc = fail(UAES_E_HIP, "gcm-siv launch: %s", hipGetErrorString((hipError_t)ks)); break; }
+            if (ks == 0) { rc = finish_io(&io, ptextLen + 16); break; }
+        }
         if ((rc = gcmsiv_tag(c, &k, nonce, d_aad, aDataLen, io.din, ptextLen, tag)) != 0) break;
         gcmsiv_ctr(&ctr, tag);
         int kk = uaesk_ctr_xcrypt(NULL, &c->tb, k.enc.nr, &k.enc.ek, &ctr, io.din, io.dout, ptextLen, NULL);
@@ -1659,6 +1677,21 @@ int uaes_gcmsiv_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
         if ((rc = gcmsiv_derive(c, keybits, key, nonce, &k)) != 0) break;
         if ((rc = stage_aad(c, aData, aDataLen, &d_aad)) != 0) break;
         if ((rc = plan_io(c, crtxt, crtxtLen + 16, pntxt, crtxtLen, &io)) != 0) break;
+        {   /* a short message is one launch (k_siv_small) */
+            int ks = uaesk_gcmsiv_small(NULL, &c->tb, k.enc.nr, &k.enc.ek, 1, k.hg, nonce, d_aad, aDataLen,
+                                        io.din, crtxtLen, io.dout, c->d_status);
+            if (ks > 0) { rc = fail(UAES_E_HIP, "gcm-siv launch: %s", hipGetErrorString((hipError_t)ks)); break; }
+            if (ks == 0) {
+                int status = -1;
+                if (hipMemcpy(&status, c->d_status, sizeof status, hipMemcpyDeviceToHost) != hipSuccess) {
+                    rc = fail(UAES_E_HIP, "gcm-siv run failed");
+                    break;
+                }
+                if ((rc = status ? finish_io_unauthenticated(&io, crtxtLen) : finish_io(&io, crtxtLen)) != 0) break;
+                rc = status ? UAES_E_AUTHENTICATION : 0;
+                break;
+            }
+        }
         if (hipMemcpy(tag_in, (const char *)io.din + crtxtLen, 16, hipMemcpyDeviceToHost) != hipSuccess) {
             rc = fail(UAES_E_HIP, "tag read failed");
             break;

@@ -165,17 +165,22 @@ def test_gcmsiv_acvp_vectors():
 @pytest.mark.parametrize("bits", [128, 192, 256])
 def test_gcmsiv_vs_oracle(orc, bits):
     rnd = random.Random(bits + 6)
-    for n in [0, 1, 16, 17, 100, 4096, 65536 + 3, (1 << 20) + 16]:
+    # up to 2046 POLYVAL blocks (AAD + text + lengths) a message is ONE launch (k_siv_small); the explicit
+    # (text, AAD) shapes sit on both sides of its two 1024-position steps and of its upper limit
+    shapes = [(n, None) for n in [0, 1, 16, 17, 100, 4096, 65536 + 3, (1 << 20) + 16]] + \
+             [(1020 * 16, 16), (1021 * 16, 0), (1021 * 16 + 1, 0), (1022 * 16 - 3, 5), (2044 * 16, 16), (2045 * 16, 0),
+              (2045 * 16 + 1, 0), (2046 * 16, 0), (100, 2040 * 16), (16, 2046 * 16), (16384, 13)]
+    for n, alen in shapes:
         key, nonce = rnd.randbytes(bits // 8), rnd.randbytes(12)
-        aad = rnd.randbytes(rnd.choice([0, 1, 16, 20, 4097]))
+        aad = rnd.randbytes(rnd.choice([0, 1, 16, 20, 4097]) if alen is None else alen)
         data = orc.splitmix(n + 2, n)
         ct = uaes.GCM_SIV_encrypt(key, nonce, aad, data)
-        assert ct == orc.gcmsiv_encrypt(key, nonce, aad, data), n
+        assert ct == orc.gcmsiv_encrypt(key, nonce, aad, data), (n, len(aad))
         assert uaes.GCM_SIV_decrypt(key, nonce, aad, ct) == (0, data)
         bad = bytearray(ct)
         bad[0 if n else -1] ^= 0x01
-        rc, _ = uaes.GCM_SIV_decrypt(key, nonce, aad, bytes(bad))
-        assert rc == 0x1A
+        rc, txt = uaes.GCM_SIV_decrypt(key, nonce, aad, bytes(bad))
+        assert (rc, txt) == orc.gcmsiv_decrypt(key, nonce, aad, bytes(bad)) and rc == 0x1A    # text released, as the reference does
 
 
 @pytest.mark.parametrize("bits", [128, 256])
