@@ -26,58 +26,6 @@
 static inline hipStream_t S(void *s) { return (hipStream_t)s; }
 
 /* ------------------------------------------------------------------------ */
-/* parallel decrypt directions                                                */
-/* ------------------------------------------------------------------------ */
-/* CFB=false: CBC decrypt of blocks [0, n): out_i = Dec(in_i) ^ prev_i
- * CFB=true : CFB decrypt of blocks [0, n): out_i = Enc(prev_i) ^ in_i, plus
- *            `rem` tail bytes out = Enc(prev_n)[0..rem) ^ in   (mixThenXor, :816)
- * prev_0 = iv, prev_i = in_{i-1}.                                            */
-template <int NR, bool CFB, int U>                 /* U blocks per lane: 4 for bulk texts, 1 for short ones */
-__global__ __launch_bounds__(UAES_WG) void k_fb_dec(uaesk_rk rk, uaesk_tables tb, uint4 iv,
-                                                    const uint4 *__restrict__ in, uint4 *__restrict__ out,
-                                                    u64 n, u32 rem)
-{
-    if (CFB) fill_enc_tables(tb.te0); else fill_dec_tables(tb.td0);
-    const LaneConst lc = make_lane_const();
-    const u64 stride = (u64)gridDim.x * UAES_WG * U;
-    for (u64 base = (u64)blockIdx.x * UAES_WG * U; base < n; base += stride) {
-        u32 s[U][4];
-        uint4 x[U], prev[U];
-        u64 idx[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            idx[u] = base + (u64)u * UAES_WG + threadIdx.x;
-            const u64 i = idx[u] < n ? idx[u] : n - 1;
-            x[u] = in[i];
-            prev[u] = i ? in[i - 1] : iv;
-            const uint4 src = CFB ? prev[u] : x[u];
-            s[u][0] = src.x; s[u][1] = src.y; s[u][2] = src.z; s[u][3] = src.w;
-        }
-        if (!CFB) {
-            dec_blocks<NR, U>(s, rk, lc);
-        } else if (U == 4) {                       /* two pairs, each half a round out of phase */
-            enc_blocks_skewed<NR>(s[0], s[1], rk, lc);
-            enc_blocks_skewed<NR>(s[2 % U], s[3 % U], rk, lc);
-        } else {
-            enc_blocks<NR, U>(s, rk, lc);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint4 m = CFB ? x[u] : prev[u];
-            if (idx[u] < n) out[idx[u]] = make_uint4(s[u][0] ^ m.x, s[u][1] ^ m.y, s[u][2] ^ m.z, s[u][3] ^ m.w);
-        }
-    }
-    if (CFB && rem && blockIdx.x == 0 && threadIdx.x == 0) {
-        const uint4 p = n ? in[n - 1] : iv;
-        u32 s1[1][4] = { { p.x, p.y, p.z, p.w } };
-        enc_blocks<NR, 1>(s1, rk, lc);
-        const unsigned char *src = (const unsigned char *)(in + n);
-        unsigned char *dst = (unsigned char *)(out + n);
-        for (u32 i = 0; i < rem; ++i) dst[i] = src[i] ^ (unsigned char)(s1[0][i >> 2] >> (8 * (i & 3)));
-    }
-}
-
-/* ------------------------------------------------------------------------ */
 /* serial directions: one wave, a quad of lanes per block encryption          */
 /* ------------------------------------------------------------------------ */
 struct Blk {
@@ -142,6 +90,83 @@ __device__ __forceinline__ Blk splice(const Blk &a, const Blk &b, u32 r)
         o.w[w] = v;
     }
     return o;
+}
+
+/* the last two blocks {X full, Z r bytes} of AES_CBC_decrypt (:770-778); rk = decryption keys, iv = the block
+ * before X; one lane on the full inverse tables                                                              */
+template <int NR>
+__device__ __forceinline__ void cbc_dec_cts_pair(const uaesk_rk &rk, const LaneConst &lc, const Blk &iv,
+                                                 const unsigned char *in, unsigned char *out, u32 r)
+{
+    const Blk x = ldb(in, 16), z = ldb(in + 16, r);
+    Blk y = x;
+    decb<NR>(y, rk, lc);                              /* Y = Dec(X) */
+    Blk p2 = y;
+    xb(p2, z);                                        /* P2 = Y ^ Z (first r bytes) */
+    Blk c = splice(z, y, r);                          /* Z | tail of Y */
+    decb<NR>(c, rk, lc);
+    xb(c, iv);
+    stb(out, c, 16);
+    stb(out + 16, p2, r);
+}
+
+/* ------------------------------------------------------------------------ */
+/* parallel decrypt directions                                                */
+/* ------------------------------------------------------------------------ */
+/* CFB=false: CBC decrypt of blocks [0, n): out_i = Dec(in_i) ^ prev_i
+ * CFB=true : CFB decrypt of blocks [0, n): out_i = Enc(prev_i) ^ in_i, plus
+ *            `rem` tail bytes out = Enc(prev_n)[0..rem) ^ in   (mixThenXor, :816)
+ * prev_0 = iv, prev_i = in_{i-1}.  CBC with cts_r != 0: blocks n and n+1 are the stolen pair.   */
+template <int NR, bool CFB, int U>                 /* U blocks per lane: 4 for bulk texts, 1 for short ones */
+__global__ __launch_bounds__(UAES_WG) void k_fb_dec(uaesk_rk rk, uaesk_tables tb, uint4 iv,
+                                                    const uint4 *__restrict__ in, uint4 *__restrict__ out,
+                                                    u64 n, u32 rem, u32 cts_r)
+{
+    if (CFB) fill_enc_tables(tb.te0); else fill_dec_tables(tb.td0);
+    const LaneConst lc = make_lane_const();
+    const u64 stride = (u64)gridDim.x * UAES_WG * U;
+    for (u64 base = (u64)blockIdx.x * UAES_WG * U; base < n; base += stride) {
+        u32 s[U][4];
+        uint4 x[U], prev[U];
+        u64 idx[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            idx[u] = base + (u64)u * UAES_WG + threadIdx.x;
+            const u64 i = idx[u] < n ? idx[u] : n - 1;
+            x[u] = in[i];
+            prev[u] = i ? in[i - 1] : iv;
+            const uint4 src = CFB ? prev[u] : x[u];
+            s[u][0] = src.x; s[u][1] = src.y; s[u][2] = src.z; s[u][3] = src.w;
+        }
+        if (!CFB) {
+            dec_blocks<NR, U>(s, rk, lc);
+        } else if (U == 4) {                       /* two pairs, each half a round out of phase */
+            enc_blocks_skewed<NR>(s[0], s[1], rk, lc);
+            enc_blocks_skewed<NR>(s[2 % U], s[3 % U], rk, lc);
+        } else {
+            enc_blocks<NR, U>(s, rk, lc);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint4 m = CFB ? x[u] : prev[u];
+            if (idx[u] < n) out[idx[u]] = make_uint4(s[u][0] ^ m.x, s[u][1] ^ m.y, s[u][2] ^ m.z, s[u][3] ^ m.w);
+        }
+    }
+    /* CBC: the last two blocks {X full, Z cts_r bytes} behind the n parallel ones (AES_CBC_decrypt :770-778), one
+     * lane of the same launch; the block before X is C_{n-1} or the IV                                       */
+    if (!CFB && cts_r && blockIdx.x == 0 && threadIdx.x == 0) {
+        const uint4 pv = n ? in[n - 1] : iv;
+        const Blk ivb = { { pv.x, pv.y, pv.z, pv.w } };
+        cbc_dec_cts_pair<NR>(rk, lc, ivb, (const unsigned char *)(in + n), (unsigned char *)(out + n), cts_r);
+    }
+    if (CFB && rem && blockIdx.x == 0 && threadIdx.x == 0) {
+        const uint4 p = n ? in[n - 1] : iv;
+        u32 s1[1][4] = { { p.x, p.y, p.z, p.w } };
+        enc_blocks<NR, 1>(s1, rk, lc);
+        const unsigned char *src = (const unsigned char *)(in + n);
+        unsigned char *dst = (unsigned char *)(out + n);
+        for (u32 i = 0; i < rem; ++i) dst[i] = src[i] ^ (unsigned char)(s1[0][i >> 2] >> (8 * (i & 3)));
+    }
 }
 
 enum { CH_CBC_ENC = 0, CH_CFB_ENC = 1, CH_OFB = 2, CH_CBC_DEC_CTS = 3 };
@@ -215,17 +240,7 @@ __global__ __launch_bounds__(UAES_WG) void k_chain_serial(uaesk_rk rk, uaesk_tab
             stb(out + 16 * i, b, take);
         }
     } else {                                              /* CH_CBC_DEC_CTS; rk = decryption keys */
-        const u32 r = (u32)len;                           /* size of Z, 1..16 */
-        const Blk x = ldb(in, 16), z = ldb(in + 16, r);
-        Blk y = x;
-        decb<NR>(y, rk, lc);                              /* Y = Dec(X) */
-        Blk p2 = y;
-        xb(p2, z);                                        /* P2 = Y ^ Z (first r bytes) */
-        Blk c = splice(z, y, r);                          /* Z | tail of Y */
-        decb<NR>(c, rk, lc);
-        xb(c, iv);
-        stb(out, c, 16);
-        stb(out + 16, p2, r);
+        cbc_dec_cts_pair<NR>(rk, lc, iv, in, out, (u32)len);
     }
 }
 
@@ -316,7 +331,7 @@ static unsigned cu_count()
 
 template <int NR, bool CFB, int U>
 static int launch_fb_dec_u(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *k, uint4 iv,
-                           const void *in, void *out, u64 n, u32 rem)
+                           const void *in, void *out, u64 n, u32 rem, u32 cts_r)
 {
     const unsigned lds = CFB ? UAES_LDS_ENC : UAES_LDS_DEC;
     hipError_t e = hipFuncSetAttribute((const void *)k_fb_dec<NR, CFB, U>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -325,18 +340,18 @@ static int launch_fb_dec_u(hipStream_t st, const uaesk_tables *tb, const uaesk_r
     if (!want) want = 1;
     const unsigned grid = (unsigned)(want < cu_count() ? want : cu_count());
     hipLaunchKernelGGL((k_fb_dec<NR, CFB, U>), dim3(grid), dim3(UAES_WG), lds, st, *k, *tb, iv,
-                       (const uint4 *)in, (uint4 *)out, n, rem);
+                       (const uint4 *)in, (uint4 *)out, n, rem, cts_r);
     return (int)hipGetLastError();
 }
 
 /* short texts take one block per lane so that up to four times as many CUs take part */
 template <int NR, bool CFB>
 static int launch_fb_dec(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *k, uint4 iv,
-                         const void *in, void *out, u64 n, u32 rem)
+                         const void *in, void *out, u64 n, u32 rem, u32 cts_r = 0)
 {
     const u64 wgs4 = (n + (u64)UAES_WG * UAES_U - 1) / ((u64)UAES_WG * UAES_U);
-    if (wgs4 * 2 <= cu_count()) return launch_fb_dec_u<NR, CFB, 1>(st, tb, k, iv, in, out, n, rem);
-    return launch_fb_dec_u<NR, CFB, UAES_U>(st, tb, k, iv, in, out, n, rem);
+    if (wgs4 * 2 <= cu_count()) return launch_fb_dec_u<NR, CFB, 1>(st, tb, k, iv, in, out, n, rem, cts_r);
+    return launch_fb_dec_u<NR, CFB, UAES_U>(st, tb, k, iv, in, out, n, rem, cts_r);
 }
 
 template <int NR, int OP>
@@ -399,13 +414,8 @@ extern "C" int uaesk_feedback(void *stream, const uaesk_tables *tb, int nr,
         u32 r = (u32)(len % 16);
         if (n > 1 && !r) { --n; r = 16; }                 /* CS3 (:756) */
         if (r) --n;                                       /* hold the last two blocks (:764) */
-        int rc = 0;
-        if (n) { DISPATCH_NR(nr, rc = (launch_fb_dec<NR, false>(st, tb, dk, iv, in, out, n, 0))); }
-        if (rc || !r) return rc;
-        /* the block before X is the IV or C_{n-1}, which lives in device memory */
-        const uint4 *prev = n ? (const uint4 *)((const char *)in + 16 * (n - 1)) : nullptr;
-        DISPATCH_NR(nr, return (launch_serial<NR, CH_CBC_DEC_CTS>(st, tb, dk, iv, (const char *)in + 16 * n,
-                                                                 (char *)out + 16 * n, r, prev)));
+        /* the n parallel blocks and the stolen pair behind them in ONE launch (k_fb_dec: one lane takes the pair) */
+        DISPATCH_NR(nr, return (launch_fb_dec<NR, false>(st, tb, dk, iv, in, out, n, 0, r)));
     } break;
     default: return (int)hipErrorInvalidValue;
     }
