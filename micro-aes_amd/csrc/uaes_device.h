@@ -127,8 +127,8 @@ int uaesk_polyval(void *stream, const uaesk_tables *tb, const uint8_t *hg_host,
                   void *scratch, void *pv_out16);
 
 /* short GCM-SIV message in one launch; -1 = not applicable (too long): take the general path */
-int uaesk_gcmsiv_small(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek, int decrypt,
-                       const uint8_t *hg16, const uint8_t *nonce12,
+int uaesk_gcmsiv_small(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *master_ek, int decrypt,
+                       const uint8_t *nonce12,
                        const void *aad, size_t aad_len, const void *in, size_t len, void *out, int *status);
 
 /* GHASH only: gh = GHASH_H(aad, ct) with H given (device), for tests.      */

@@ -1633,16 +1633,22 @@ int uaes_gcmsiv_encrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
     LOCKED_BEGIN(c);
     do {
         if ((rc = gcm_scratch(c)) != 0) break;
-        if ((rc = gcmsiv_derive(c, keybits, key, nonce, &k)) != 0) break;
-        /* aad_stage was used for the derivation blocks: stage the AAD after it */
         if ((rc = stage_aad(c, aData, aDataLen, &d_aad)) != 0) break;
         if ((rc = plan_io(c, pntxt, ptextLen, crtxt, ptextLen + 16, &io)) != 0) break;
-        {   /* a short message is one launch (k_siv_small): POLYVAL, tag and keystream in one workgroup */
-            int ks = uaesk_gcmsiv_small(NULL, &c->tb, k.enc.nr, &k.enc.ek, 0, k.hg, nonce, d_aad, aDataLen,
+        {   /* a short message is ONE launch (k_siv_small): key derivation, POLYVAL, tag and keystream in one
+             * workgroup; the host only expands the master key */
+            keysched master;
+            if ((rc = expand_key(&master, key, keybits)) != 0) break;
+            int ks = uaesk_gcmsiv_small(NULL, &c->tb, master.nr, &master.ek, 0, nonce, d_aad, aDataLen,
                                         io.din, ptextLen, io.dout, NULL);
+            memset(&master, 0, sizeof master);
             if (ks > 0) { rc = fail(UAES_E_HIP, "gcm-siv launch: %s", hipGetErrorString((hipError_t)ks)); break; }
             if (ks == 0) { rc = finish_io(&io, ptextLen + 16); break; }
         }
+        /* the general path derives the keys with the ECB kernel; it borrows aad_stage for the derivation blocks,
+         * so the AAD is staged again behind it */
+        if ((rc = gcmsiv_derive(c, keybits, key, nonce, &k)) != 0) break;
+        if ((rc = stage_aad(c, aData, aDataLen, &d_aad)) != 0) break;
         if ((rc = gcmsiv_tag(c, &k, nonce, d_aad, aDataLen, io.din, ptextLen, tag)) != 0) break;
         gcmsiv_ctr(&ctr, tag);
         int kk = uaesk_ctr_xcrypt(NULL, &c->tb, k.enc.nr, &k.enc.ek, &ctr, io.din, io.dout, ptextLen, NULL);
@@ -1674,12 +1680,14 @@ int uaes_gcmsiv_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
     LOCKED_BEGIN(c);
     do {
         if ((rc = gcm_scratch(c)) != 0) break;
-        if ((rc = gcmsiv_derive(c, keybits, key, nonce, &k)) != 0) break;
         if ((rc = stage_aad(c, aData, aDataLen, &d_aad)) != 0) break;
         if ((rc = plan_io(c, crtxt, crtxtLen + 16, pntxt, crtxtLen, &io)) != 0) break;
-        {   /* a short message is one launch (k_siv_small) */
-            int ks = uaesk_gcmsiv_small(NULL, &c->tb, k.enc.nr, &k.enc.ek, 1, k.hg, nonce, d_aad, aDataLen,
+        {   /* a short message is ONE launch (k_siv_small), key derivation included */
+            keysched master;
+            if ((rc = expand_key(&master, key, keybits)) != 0) break;
+            int ks = uaesk_gcmsiv_small(NULL, &c->tb, master.nr, &master.ek, 1, nonce, d_aad, aDataLen,
                                         io.din, crtxtLen, io.dout, c->d_status);
+            memset(&master, 0, sizeof master);
             if (ks > 0) { rc = fail(UAES_E_HIP, "gcm-siv launch: %s", hipGetErrorString((hipError_t)ks)); break; }
             if (ks == 0) {
                 int status = -1;
@@ -1692,6 +1700,8 @@ int uaes_gcmsiv_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
                 break;
             }
         }
+        if ((rc = gcmsiv_derive(c, keybits, key, nonce, &k)) != 0) break;
+        if ((rc = stage_aad(c, aData, aDataLen, &d_aad)) != 0) break;
         if (hipMemcpy(tag_in, (const char *)io.din + crtxtLen, 16, hipMemcpyDeviceToHost) != hipSuccess) {
             rc = fail(UAES_E_HIP, "tag read failed");
             break;

@@ -1032,19 +1032,64 @@ static int launch_small_nr(int nr, hipStream_t st, const uaesk_tables *tb, const
  * text positions.  Decrypt: keystream from the RECEIVED tag first, the plaintext is written (the reference
  * releases it before it authenticates, :1500-1511), then the same POLYVAL and the comparison.  The key's
  * nibble tables are made in the kernel (gcm_build_nibble_tables; the message-authentication key is per NONCE
- * here, so there is nothing to keep).  One launch instead of key-derivation ECB + POLYVAL setup / levels +
- * tag ECB + CTR with two host round trips in between: a 4 KiB call 100 -> ~50 us (the key derivation keeps
- * its own ECB launch and read-back: the derived schedule travels as a kernel argument).                     */
+ * here, so there is nothing to keep), and so are the per-nonce keys themselves (derive_keys under the master
+ * key + KeyExpansion of the derived key).  One launch instead of key-derivation ECB + POLYVAL setup / levels +
+ * tag ECB + CTR with three host round trips in between: a 4 KiB call 100 -> 30 us.                        */
+#define SIV_LDS_KEYS   GSM_LDS_TOTAL                    /* 8 derived + 60 schedule words, then a plain copy of Te0 */
+#define SIV_LDS_TE     (SIV_LDS_KEYS + 512u)
+#define SIV_LDS_TOTAL  (SIV_LDS_TE + 1024u)
+
 template <int NR, bool DEC>
-__global__ __launch_bounds__(GH_T) void k_siv_small(uaesk_rk rk, uaesk_tables tb, uint4 hg, uint4 nonce,
+__global__ __launch_bounds__(GH_T) void k_siv_small(uaesk_rk mk, uaesk_tables tb, uint4 nonce,
                                                     GSrc src, const uint4 *in, uint4 *out,
                                                     unsigned char *tag_io, int *status)
 {
     uint4 *TC = (uint4 *)(uaes_lds + GSM_LDS_TAB);
     uint4 *buf = TC + GT_NTAB * 512u;
-    if (threadIdx.x == 0) buf[GT_BUF - 3] = hg;
+    u32 *drv = (u32 *)(uaes_lds + SIV_LDS_KEYS);              /* [0..11] derived words, [16..75] the schedule */
+    u32 *ekl = drv + 16;
+    u32 *te_plain = (u32 *)(uaes_lds + SIV_LDS_TE);
+    if (threadIdx.x < 256) te_plain[threadIdx.x] = tb.te0[threadIdx.x];
     fill_tables64(tb.te0, 0);                                 /* ends with a barrier */
     const LaneConst2 lc = make_lane_const2(0);
+
+    /* derive_keys (RFC 8452 sec. 4; GCM_SIV_init, micro_aes.c:1421-1450) in the kernel: blocks LE32(i) || nonce
+     * under the MASTER key, i < 2 + keybits/64, one lane each; their low halves are the message-authentication
+     * key (blocks 0, 1) and the message-encryption key (blocks 2..), whose schedule thread 0 expands here
+     * (KeyExpansion :144-178; S[x] = byte 1 of Te0[x]).  The host only expands the master key.            */
+    constexpr u32 NK = NR - 6, NB = 2 + NK / 2;
+    if (threadIdx.x < 64) {
+        u32 s1[1][4] = { { threadIdx.x, nonce.x, nonce.y, nonce.z } };
+        enc_blocks<NR, 1>(s1, mk, lc);
+        if (threadIdx.x < NB) { drv[2 * threadIdx.x] = s1[0][0]; drv[2 * threadIdx.x + 1] = s1[0][1]; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint4 auth = make_uint4(drv[0], drv[1], drv[2], drv[3]);
+        u32 hw[4];
+        gf_to_words(gf_mul_xk(gf_from4(rev16(auth)), 1), hw);    /* POLYVAL key in GHASH form: mulX(rev(H)) */
+        buf[GT_BUF - 3] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+        auto subword = [&](u32 w) -> u32 {
+            return ((te_plain[w & 0xffu] >> 8) & 0xffu) | (te_plain[(w >> 8) & 0xffu] & 0xff00u) |
+                   ((te_plain[(w >> 16) & 0xffu] & 0xff00u) << 8) | ((te_plain[w >> 24] & 0xff00u) << 16);
+        };
+        for (u32 i = 0; i < NK; ++i) ekl[i] = drv[4 + i];
+        u32 rcon = 1;
+        for (u32 i = NK; i < 4u * (NR + 1); ++i) {
+            u32 t = ekl[i - 1];
+            if (i % NK == 0) {
+                t = subword((t >> 8) | (t << 24)) ^ rcon;         /* RotWord on LE words */
+                rcon = ((rcon << 1) ^ ((rcon >> 7) * 0x1bu)) & 0xffu;
+            } else if (NK == 8 && i % NK == 4) {
+                t = subword(t);
+            }
+            ekl[i] = ekl[i - NK] ^ t;
+        }
+    }
+    __syncthreads();
+    uaesk_rk rk;
+#pragma unroll
+    for (int i = 0; i < 4 * (NR + 1); ++i) rk.w[i] = (u32)__builtin_amdgcn_readfirstlane((int)ekl[i]);
     gcm_build_nibble_tables(TC, buf, tb.frob);
 
     const u64 len = src.ct_len;
@@ -1667,12 +1712,12 @@ extern "C" int uaesk_polyval(void *stream, const uaesk_tables *tb, const uint8_t
     return run_ghash_levels(st, msg, nv, pl, sc, 2, (unsigned char *)pv_out16, nullptr);
 }
 
-/* GCM-SIV of a short message in one launch (k_siv_small).  hg16 = the POLYVAL key in GHASH form (host), ek = the
- * schedule of the derived message-encryption key.  encrypt: tag written at out + len; decrypt: tag read at
- * in + len, *status = 0 / 0x1A, the plaintext is written either way.  Returns -1 if the message is too long for
- * this path (or the Frobenius matrices are missing): the caller then takes the general path.                  */
-extern "C" int uaesk_gcmsiv_small(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek, int decrypt,
-                                  const uint8_t *hg16, const uint8_t *nonce12,
+/* GCM-SIV of a short message in one launch (k_siv_small), key derivation included: mk = the schedule of the MASTER
+ * key.  encrypt: tag written at out + len; decrypt: tag read at in + len, *status = 0 / 0x1A, the plaintext is
+ * written either way.  Returns -1 if the message is too long for this path (or the Frobenius matrices are
+ * missing): the caller then derives the keys itself and takes the general path.                              */
+extern "C" int uaesk_gcmsiv_small(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *mk, int decrypt,
+                                  const uint8_t *nonce12,
                                   const void *aad, size_t aad_len, const void *in, size_t len, void *out, int *status)
 {
     const u64 nv = ((aad_len + 15) >> 4) + ((len + 15) >> 4) + 1;
@@ -1681,17 +1726,16 @@ extern "C" int uaesk_gcmsiv_small(void *stream, const uaesk_tables *tb, int nr, 
     src.aad = (const unsigned char *)aad; src.aad_len = aad_len;
     src.ct = (const unsigned char *)in; src.ct_len = len;
     src.has_len = 1; src.len_aad = aad_len; src.len_ct = len; src.rev = 1;
-    uint4 hg, nn = make_uint4(0, 0, 0, 0);
-    memcpy(&hg, hg16, 16);
+    uint4 nn = make_uint4(0, 0, 0, 0);
     memcpy(&nn, nonce12, 12);
     hipStream_t st = S(stream);
     hipError_t e;
 #define SIV_LAUNCH(NRV, D)                                                                                          \
     do {                                                                                                            \
         e = hipFuncSetAttribute((const void *)k_siv_small<NRV, D>, hipFuncAttributeMaxDynamicSharedMemorySize,      \
-                                GSM_LDS_TOTAL);                                                                     \
+                                SIV_LDS_TOTAL);                                                                     \
         if (e != hipSuccess) return (int)e;                                                                         \
-        hipLaunchKernelGGL((k_siv_small<NRV, D>), dim3(1), dim3(GH_T), GSM_LDS_TOTAL, st, *ek, *tb, hg, nn, src,    \
+        hipLaunchKernelGGL((k_siv_small<NRV, D>), dim3(1), dim3(GH_T), SIV_LDS_TOTAL, st, *mk, *tb, nn, src,        \
                            (const uint4 *)in, (uint4 *)out,                                                         \
                            (D) ? (unsigned char *)in + len : (unsigned char *)out + len, status);                   \
     } while (0)
