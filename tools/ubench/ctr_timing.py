@@ -1,7 +1,7 @@
 """Diagnostic: per-wave loop time and time spent at the U-buffer barrier in k_ctr_shared2
 (library built with -DUAES_CTR_TIMING as lib/libuaes_hip_T.so):
 
-    cd micro-aes_amd/csrc && make XFLAGS=-DUAES_CTR_TIMING && cp ../lib/libuaes_hip.so ../lib/libuaes_hip_T.so
+    cd micro-aes_amd/csrc && touch uaes_*.hip && make XFLAGS=-DUAES_CTR_TIMING && cp ../lib/libuaes_hip.so ../lib/libuaes_hip_T.so
     touch uaes_*.hip && make                       # back to the product build
 """
 import os

@@ -1,6 +1,6 @@
 """Diagnostic: phase stamps printed by the k_gcm_setup / k_gcm_fused kernels of a TIMING build of the library.
 
-    cd micro-aes_amd/csrc && make XFLAGS=-DUAES_GF_TIMING && cp ../lib/libuaes_hip.so ../lib/libuaes_hip_T.so
+    cd micro-aes_amd/csrc && touch uaes_*.hip && make XFLAGS=-DUAES_GF_TIMING && cp ../lib/libuaes_hip.so ../lib/libuaes_hip_T.so
     touch uaes_*.hip && make                       # back to the product build
     gpurun -- 'python tools/ubench/gf_timing.py'
 """
