@@ -416,6 +416,34 @@ __device__ __forceinline__ void dec_blocks(u32 (&s)[U][4], const uaesk_rk &dk, c
     rounds_from<NR, U, 1, true>(s, dk, lc);
 }
 
+/* ---- one block through an UNREPLICATED 1 KiB copy of Te0 (anywhere in LDS) ---------------------------
+ * For the odd single block a kernel needs before its bulk work (XTS: Enc_key2(tweak); GCM: H = Enc(0), Enc(J0))
+ * when the replicated cipher tables are not there (decrypt direction, GHASH-only kernels): all lanes of a wave
+ * that run it read the same entries -- broadcasts, no bank conflicts -- and Te1..Te3 are rotations.          */
+template <int NR>
+__device__ __forceinline__ void plain_encrypt(const u32 *te0, const uaesk_rk &rk, u32 (&s)[4])
+{
+#pragma unroll
+    for (int c = 0; c < 4; ++c) s[c] ^= rk.w[c];
+    for (int r = 1; r < NR; ++r) {
+        u32 t[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            t[c] = te0[s[c] & 0xffu] ^ rotl32(te0[(s[(c + 1) & 3] >> 8) & 0xffu], 8) ^
+                   rotl32(te0[(s[(c + 2) & 3] >> 16) & 0xffu], 16) ^ rotl32(te0[s[(c + 3) & 3] >> 24], 24) ^ rk.w[4 * r + c];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s[c] = t[c];
+    }
+    u32 t[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)                     /* S[x] = byte 1 of Te0[x] */
+        t[c] = (((te0[s[c] & 0xffu] >> 8) & 0xffu) | (te0[(s[(c + 1) & 3] >> 8) & 0xffu] & 0xff00u) |
+                ((te0[(s[(c + 2) & 3] >> 16) & 0xffu] & 0xff00u) << 8) | ((te0[s[(c + 3) & 3] >> 24] & 0xff00u) << 16)) ^
+               rk.w[4 * NR + c];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) s[c] = t[c];
+}
+
 /* ---- one block at a time, four lanes per block (the serial chains) ---------------- */
 /* CBC/CFB encryption, OFB and the CBC-MACs are chains: block i+1 cannot start before block i
  * is done, so what counts is the LATENCY of one block.  One lane alone issues 16 address

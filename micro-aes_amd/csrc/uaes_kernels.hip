@@ -369,30 +369,6 @@ __global__ __launch_bounds__(UAES_WG) void k_xts(uaesk_rk k1, uaesk_tables tb,
 #define XTS_SMALL_CHUNKS 4u          /* 1024 blocks: one per lane; longer units spread better over many CUs */
 #define XTS_SMALL_LDS    (UAES_LDS_ENC + 1024u + 16u)
 
-template <int NR>
-__device__ __forceinline__ void plain_encrypt(const u32 *te0, const uaesk_rk &rk, u32 (&s)[4])
-{
-#pragma unroll
-    for (int c = 0; c < 4; ++c) s[c] ^= rk.w[c];
-    for (int r = 1; r < NR; ++r) {
-        u32 t[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-            t[c] = te0[s[c] & 0xffu] ^ rotl32(te0[(s[(c + 1) & 3] >> 8) & 0xffu], 8) ^
-                   rotl32(te0[(s[(c + 2) & 3] >> 16) & 0xffu], 16) ^ rotl32(te0[s[(c + 3) & 3] >> 24], 24) ^ rk.w[4 * r + c];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) s[c] = t[c];
-    }
-    u32 t[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c)                     /* S[x] = byte 1 of Te0[x] */
-        t[c] = (((te0[s[c] & 0xffu] >> 8) & 0xffu) | (te0[(s[(c + 1) & 3] >> 8) & 0xffu] & 0xff00u) |
-                ((te0[(s[(c + 2) & 3] >> 16) & 0xffu] & 0xff00u) << 8) | ((te0[s[(c + 3) & 3] >> 24] & 0xff00u) << 16)) ^
-               rk.w[4 * NR + c];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) s[c] = t[c];
-}
-
 template <int NR, bool DEC>
 __global__ __launch_bounds__(UAES_WG) void k_xts_small(uaesk_rk k1, uaesk_rk k2, uaesk_tables tb,
                                                        uint4 raw_tweak, u32 use_raw, u64 sector_id,
