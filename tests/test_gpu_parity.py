@@ -747,6 +747,65 @@ def test_gcm_single_launch_sizes(orc, bits):
 
 
 @pytest.mark.parametrize("bits", [128, 192, 256])
+def test_gcm_chunk_and_combine_kernels(orc, bits):
+    """Texts between the single-workgroup kernel and the striped one-pass kernel (2047 GHASH blocks .. 16 MiB;
+    32 MiB for a decrypt that authenticates first) run as k_gcm_chunks + k_gcm_combine: chunk counts 1 / 2 / 3 /
+    255..257 / 511..513 / 1023..1025, front padding of every size, AAD that spans chunks, ragged texts; encrypt
+    against the oracle (tag always, whole text for the small ones), both decrypt orders, forgeries, in place,
+    key context."""
+    import torch
+    L = uaes.engine()
+    rnd = random.Random(6100 + bits)
+    key = rnd.randbytes(bits // 8)
+    k = uaes.GcmKey(key)
+    B = 16
+    shapes = [(2046 * B, 0), (2047 * B, 0), (2047 * B + 1, 0), (4095 * B, 0), (4095 * B - 7, 32), (100, 4094 * B), (6000 * B + 3, 5000),
+              (255 * 2048 * B - B, 0), (256 * 2048 * B - B, 0), (256 * 2048 * B, 0), (256 * 2048 * B + B, 13)]
+    if bits == 128:
+        shapes += [(512 * 2048 * B - B, 0), (512 * 2048 * B, 16), (1024 * 2048 * B - B, 0), (1024 * 2048 * B, 0)]
+    try:
+        for n, alen in shapes:
+            nonce, aad = rnd.randbytes(12), rnd.randbytes(alen)
+            pt = orc.splitmix(n % 977 + 3, (n + 7) // 8 * 8)[:n]
+            want = orc.gcm_encrypt(key, nonce, aad, pt)
+            src = torch.frombuffer(bytearray(pt + bytes(16)), dtype=torch.uint8).to("cuda:0")
+            dst = torch.full((n + 48,), 0xA5, dtype=torch.uint8, device="cuda:0")
+            a = torch.frombuffer(bytearray(aad + bytes(3)), dtype=torch.uint8).to("cuda:0")[:alen] if alen else None
+            uaes.gcm_encrypt_dev(key, nonce, a, src, n, dst)
+            torch.cuda.synchronize()
+            got = bytes(dst[: n + 16].cpu().numpy())
+            assert got[-16:] == want[-16:], (n, alen)
+            assert hashlib.sha256(got).digest() == hashlib.sha256(want).digest(), (n, alen)
+            assert int((dst[n + 16:] != 0xA5).sum()) == 0
+            two = torch.full((n + 32,), 0xA5, dtype=torch.uint8, device="cuda:0")
+            k.encrypt_dev(nonce, a, src, n, two)
+            torch.cuda.synchronize()
+            assert torch.equal(two[: n + 16], dst[: n + 16]), (n, alen)
+            status = torch.full((1,), -1, dtype=torch.int32, device="cuda:0")
+            for sw in (0, 1):                                            # tag first / one pass
+                L.uaes_set_wipe_on_auth_failure(sw)
+                back = torch.full((n + 16,), 0xCC, dtype=torch.uint8, device="cuda:0")
+                uaes.gcm_decrypt_dev(key, nonce, a, dst, n, back, status)
+                torch.cuda.synchronize()
+                assert int(status.item()) == 0 and torch.equal(back[:n], src[:n]) and int((back[n:] != 0xCC).sum()) == 0, (n, alen, sw)
+                bad = dst[: n + 16].clone()
+                bad[rnd.randrange(n + 16)] ^= 4
+                back.fill_(0xCC)
+                k.decrypt_dev(nonce, a, bad, n, back, status)
+                torch.cuda.synchronize()
+                assert int(status.item()) == 0x1A, (n, alen, sw)
+                assert int((back[:n] != (0 if sw else 0xCC)).sum()) == 0 and int((back[n:] != 0xCC).sum()) == 0, (n, alen, sw)
+            L.uaes_set_wipe_on_auth_failure(0)
+            work = dst[: n + 16].clone()                                  # in place
+            uaes.gcm_decrypt_dev(key, nonce, a, work, n, work, status)
+            torch.cuda.synchronize()
+            assert int(status.item()) == 0 and torch.equal(work[:n], src[:n])
+    finally:
+        L.uaes_set_wipe_on_auth_failure(0)
+        k.close()
+
+
+@pytest.mark.parametrize("bits", [128, 192, 256])
 def test_gcm_one_pass_decrypt(orc, bits):
     """uaes_set_wipe_on_auth_failure(1): a long GCM decrypt into the caller's device buffer runs CTR and
     GHASH in one pass (k_gcm_fused<NR, true>: the lane hashes the ciphertext block it has just read, the
