@@ -8,6 +8,7 @@ the optional ciphertext all-gather is timed separately and never part of
 `value`).  A "step" is one full pass of the hot path over the resident buffer.
 
     python bench.py                       # 1 GPU, defaults
+    python bench.py --gpus N              # launches its own N ranks (torch.distributed.run, free port)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \\
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -157,6 +158,23 @@ def cpu_baseline(workload):
     return res
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, one per GPU, exactly as
+    the documented command does (torch.distributed.run, rendezvous on 127.0.0.1, a free port), relay their
+    output and exit with their status."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -174,6 +192,9 @@ def main():
     ap.add_argument("--single-device", action="store_true", help="all ranks use cuda:0 (dry run only)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a.gpus)
+
     import torch
     import micro_aes_amd as uaes
 
@@ -181,10 +202,12 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("launch with torch.distributed.run --nproc-per-node %d" % a.gpus)
+        sys.exit("--gpus %d but the launcher started %d rank(s)" % (a.gpus, world))
     if a.single_device:
         local = 0
+    elif local >= torch.cuda.device_count():
+        sys.exit("rank %d wants cuda:%d but only %d device(s) are visible (--single-device is the 1-GPU dry run)"
+                 % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -307,8 +330,11 @@ def main():
     if not a.no_verify:
         with open(os.path.join(ROOT, "tests", "golden", "digests.json")) as f:
             gold = json.load(f)
-        if a.workload == "ctr" and n == GIB and rank == 0:
-            verify = sha_of(dst[:n]) == gold["C2_ctr128_1GiB_seed2"]["sha256"]
+        if a.workload == "ctr" and n == GIB and rank < 8:
+            # every rank checks its WHOLE shard against the reference's digest of that shard of the 8 GiB
+            # stream (PRESET_COUNTER build, tests/golden/make_fixtures.py --big); shard 0 = C2
+            verify = sha_of(dst[:n]) == gold["C5_shard_%d" % rank]["sha256"]
+            assert gold["C5_shard_0"]["sha256"] == gold["C2_ctr128_1GiB_seed2"]["sha256"]
         elif a.workload == "gcm" and n == GIB and rank == 0:
             verify = bytes(dst[n:].cpu().numpy()).hex() == gold["C4_gcm128_1GiB_seed4"]["tag"]
         elif a.workload == "xts" and n == 4 * GIB and rank == 0:
@@ -340,11 +366,19 @@ def main():
             dist.all_reduce(v, op=dist.ReduceOp.MIN)
             verify = bool(v.item())
 
+    kern_ms = sum(per_step_ms) / len(per_step_ms)
+    kern_all = [kern_ms]
+    if dist:
+        t = torch.zeros(world, dtype=torch.float64, device=cdev)
+        t[rank] = kern_ms
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        kern_all = [float(x) for x in t.tolist()]
+
     if rank == 0:
         total_gib = world * n * a.steps / GIB
-        kern_ms = sum(per_step_ms) / len(per_step_ms)
-        algo_bytes = 2.0 * n                       # read n + write n per launch
-        achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
+        algo_bytes = 2.0 * n                       # read n + write n per launch, per GPU
+        per_gpu = [algo_bytes / (k * 1e-3) / 1e9 for k in kern_all]
+        achieved = per_gpu[0]
         # HBM bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE need their own
         # runs under the profiler, tools/profile.sh); this run cannot measure them itself, so the
         # line names where the figure was taken from.
@@ -380,6 +414,14 @@ def main():
                          "measured_copy_ceiling_gbs": None if copy_gbs is None else round(copy_gbs, 1)},
             "verified": verify,
         }
+        if world > 1:
+            # roofline above = rank 0's kernel; here every GPU's, and the node aggregate against N x peak
+            line["roofline"]["per_gpu_achieved"] = [round(x, 1) for x in per_gpu]
+            line["roofline"]["per_gpu_frac"] = [round(x / HBM_PEAK_GBS, 4) for x in per_gpu]
+            line["roofline"]["aggregate"] = {"achieved": round(sum(per_gpu), 1), "peak": HBM_PEAK_GBS * world,
+                                             "frac": round(sum(per_gpu) / (HBM_PEAK_GBS * world), 4)}
+            line["verified_shards"] = "every rank hashed its whole shard against the reference's digest" \
+                if (a.workload == "ctr" and n == GIB and not a.no_verify) else "head of every shard against the oracle"
         if gather_ms is not None:
             line["gather_ms"] = round(gather_ms, 3)
         if gathered_ok is not None:

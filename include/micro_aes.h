@@ -55,7 +55,9 @@
 #define AES_PADDING     0   /* built with -DAES_PADDING=1|2 gets that ECB padding (see below)   */
 #endif
 #define DECRYPTION      1
-#define PRESET_COUNTER  0   /* CTR takes a 12-byte IV; see uaes_ctr_xcrypt_at */
+#ifndef PRESET_COUNTER       /* micro_aes.h:100 -- a caller built with -DPRESET_COUNTER=1 hands AES_CTR_* the    */
+#define PRESET_COUNTER  0   /* whole 16-byte counter block instead of a 12-byte IV (micro_aes.c:965-966)     */
+#endif
 
 enum constant_parameters_of_modes
 {
@@ -106,6 +108,18 @@ void AES_CTR_encrypt(const uint8_t *key, const uint8_t *iv,
                      const void *pntxt, const size_t ptextLen, void *crtxt);
 void AES_CTR_decrypt(const uint8_t *key, const uint8_t *iv,
                      const void *crtxt, const size_t crtxtLen, void *pntxt);
+/* PRESET_COUNTER is a compile-time switch of the CALLER's build in the reference: `iv` is then the
+ * pre-initialised 16-byte counter block (bytes 9..15 = the 56-bit big-endian counter of incBlock,
+ * micro_aes.c:421-427) -- the form in which a shard of a longer stream is encrypted.  Every library
+ * exports both forms; a caller built with -DPRESET_COUNTER=1 is bound to these:                 */
+void AES_CTR_encrypt_preset(const uint8_t *key, const uint8_t *counter16,
+                            const void *pntxt, const size_t ptextLen, void *crtxt);
+void AES_CTR_decrypt_preset(const uint8_t *key, const uint8_t *counter16,
+                            const void *crtxt, const size_t crtxtLen, void *pntxt);
+#if PRESET_COUNTER
+#define AES_CTR_encrypt AES_CTR_encrypt_preset
+#define AES_CTR_decrypt AES_CTR_decrypt_preset
+#endif
 
 char AES_XTS_encrypt(const uint8_t *keys, const uint8_t *tweak,
                      const void *pntxt, const size_t ptextLen, void *crtxt);
@@ -128,8 +142,29 @@ char AES_GCM_decrypt_ivlen(const size_t nonceLen, const uint8_t *key, const uint
                            const void *aData, const size_t aDataLen,
                            const void *crtxt, const size_t crtxtLen, void *pntxt);
 #ifdef GCM_NONCE_LEN
-#define AES_GCM_encrypt(k, n, a, al, p, pl, c) AES_GCM_encrypt_ivlen(GCM_NONCE_LEN, k, n, a, al, p, pl, c)
-#define AES_GCM_decrypt(k, n, a, al, c, cl, p) AES_GCM_decrypt_ivlen(GCM_NONCE_LEN, k, n, a, al, c, cl, p)
+/* real functions behind OBJECT-like macros, so that `&AES_GCM_encrypt` or a dispatch-table entry binds to
+ * the nonce length of this build as well as a direct call does                                         */
+#if defined(__cplusplus) || (defined(__STDC_VERSION__) && __STDC_VERSION__ >= 199901L)
+#define UAES_STATIC_INLINE static inline
+#elif defined(__GNUC__)
+#define UAES_STATIC_INLINE static __inline__ __attribute__((unused))
+#else
+#define UAES_STATIC_INLINE static
+#endif
+UAES_STATIC_INLINE void AES_GCM_encrypt_nl(const uint8_t *key, const uint8_t *nonce,
+                                           const void *aData, const size_t aDataLen,
+                                           const void *pntxt, const size_t ptextLen, void *crtxt)
+{
+    AES_GCM_encrypt_ivlen(GCM_NONCE_LEN, key, nonce, aData, aDataLen, pntxt, ptextLen, crtxt);
+}
+UAES_STATIC_INLINE char AES_GCM_decrypt_nl(const uint8_t *key, const uint8_t *nonce,
+                                           const void *aData, const size_t aDataLen,
+                                           const void *crtxt, const size_t crtxtLen, void *pntxt)
+{
+    return AES_GCM_decrypt_ivlen(GCM_NONCE_LEN, key, nonce, aData, aDataLen, crtxt, crtxtLen, pntxt);
+}
+#define AES_GCM_encrypt AES_GCM_encrypt_nl
+#define AES_GCM_decrypt AES_GCM_decrypt_nl
 #endif
 
 char AES_CBC_encrypt(const uint8_t *key, const uint8_t iVec[16],

@@ -49,7 +49,8 @@ EXPORTS = [
 ]
 COMPAT_EXPORTS = [
     "AES_ECB_encrypt", "AES_ECB_encrypt_pkcs7", "AES_ECB_encrypt_iso7816", "AES_ECB_decrypt",
-    "AES_CTR_encrypt", "AES_CTR_decrypt", "uaes_compat_set_failure_handler",
+    "AES_CTR_encrypt", "AES_CTR_decrypt", "AES_CTR_encrypt_preset", "AES_CTR_decrypt_preset",
+    "uaes_compat_set_failure_handler",
     "AES_XTS_encrypt", "AES_XTS_decrypt", "AES_GCM_encrypt", "AES_GCM_decrypt",
     "AES_GCM_encrypt_ivlen", "AES_GCM_decrypt_ivlen",
     "AES_CCM_encrypt", "AES_CCM_decrypt", "AES_CMAC", "GCM_SIV_encrypt", "GCM_SIV_decrypt",

@@ -70,6 +70,22 @@ char AES_ECB_decrypt(const uint8_t *key, const void *crtxt, const size_t crtxtLe
     return soft("AES_ECB_decrypt", uaes_ecb_decrypt(KB, key, crtxt, crtxtLen, pntxt), M_DECRYPTION_ERROR);
 }
 
+/* PRESET_COUNTER (micro_aes.h:100, micro_aes.c:965-966) is likewise the caller's compile-time choice:
+ * both forms are exported and include/micro_aes.h binds AES_CTR_* to the one the caller's build names. */
+#undef AES_CTR_encrypt
+#undef AES_CTR_decrypt
+void AES_CTR_encrypt_preset(const uint8_t *key, const uint8_t *counter16,
+                            const void *pntxt, const size_t ptextLen, void *crtxt)
+{
+    must("AES_CTR_encrypt", uaes_ctr_xcrypt_at(KB, key, counter16, 0, pntxt, ptextLen, crtxt));
+}
+
+void AES_CTR_decrypt_preset(const uint8_t *key, const uint8_t *counter16,
+                            const void *crtxt, const size_t crtxtLen, void *pntxt)
+{
+    must("AES_CTR_decrypt", uaes_ctr_xcrypt_at(KB, key, counter16, 0, crtxt, crtxtLen, pntxt));
+}
+
 void AES_CTR_encrypt(const uint8_t *key, const uint8_t *iv,
                      const void *pntxt, const size_t ptextLen, void *crtxt)
 {

@@ -222,21 +222,24 @@ class Reference:
     PAD_SUFFIX = {0: "", 1: "_pkcs7", 2: "_iso7816"}
 
     @classmethod
-    def path(cls, bits, padding=0, gcm_nonce_len=12):
+    def path(cls, bits, padding=0, gcm_nonce_len=12, preset_counter=False):
         iv = "" if gcm_nonce_len == 12 else "_gcmiv%d" % gcm_nonce_len
-        return os.path.join(HERE, "_ref", "libmicroaes_ref_%d%s%s.so" % (bits, cls.PAD_SUFFIX[padding], iv))
+        pc = "_presetctr" if preset_counter else ""
+        return os.path.join(HERE, "_ref", "libmicroaes_ref_%d%s%s%s.so" % (bits, cls.PAD_SUFFIX[padding], iv, pc))
 
     @classmethod
-    def available(cls, bits=128, padding=0, gcm_nonce_len=12):
-        return os.path.exists(cls.path(bits, padding, gcm_nonce_len))
+    def available(cls, bits=128, padding=0, gcm_nonce_len=12, preset_counter=False):
+        return os.path.exists(cls.path(bits, padding, gcm_nonce_len, preset_counter))
 
-    def __init__(self, bits, padding=0, gcm_nonce_len=12):
-        """padding / gcm_nonce_len: builds with AES_PADDING (micro_aes.h:79) / GCM_NONCE_LEN (:108)
-        patched (oracle/Makefile)"""
+    def __init__(self, bits, padding=0, gcm_nonce_len=12, preset_counter=False):
+        """padding / gcm_nonce_len / preset_counter: builds with AES_PADDING (micro_aes.h:79) /
+        GCM_NONCE_LEN (:108) / PRESET_COUNTER (:100) patched (oracle/Makefile).  With preset_counter the
+        `iv` of ctr_encrypt is the full 16-byte counter block (micro_aes.c:965-966)."""
         self.bits = bits
         self.padding = padding
         self.gcm_nonce_len = gcm_nonce_len
-        L = self.L = C.CDLL(self.path(bits, padding, gcm_nonce_len))
+        self.preset_counter = preset_counter
+        L = self.L = C.CDLL(self.path(bits, padding, gcm_nonce_len, preset_counter))
         sz, vp = C.c_size_t, C.c_void_p
         L.AES_ECB_encrypt.argtypes = [vp, vp, sz, vp]; L.AES_ECB_encrypt.restype = None
         L.AES_ECB_decrypt.argtypes = [vp, vp, sz, vp]; L.AES_ECB_decrypt.restype = C.c_char

@@ -312,6 +312,18 @@ def digests(orc, big):
     d["C5_ctr128_8GiB_seed2"] = dict(
         sha256="5066df5498cacd8b639f3e4fcaed7f6a64c28460702890d4939ab49e66717c46",
         source="SURVEY.md 8d (compiled reference)")
+    # C5 per shard: GPU g of BASELINE configs[4] owns bytes [g GiB, (g+1) GiB) of the 8 GiB stream and starts at
+    # counter offset g * 2^26.  Computed with the REFERENCE built with PRESET_COUNTER 1
+    # (micro_aes.h:100, micro_aes.c:965-966: the caller passes the whole counter block), see c5_shards();
+    # kept from the last --big run otherwise
+    try:
+        with open(os.path.join(HERE, "digests.json")) as f:
+            old = json.load(f)
+    except Exception:
+        old = {}
+    for g in range(8):
+        if "C5_shard_%d" % g in old:
+            d["C5_shard_%d" % g] = old["C5_shard_%d" % g]
     for k, v in d.items():
         if "survey" in v:
             assert v["sha256" if "sha256" in v else "sha256_ct_tag"] == v["survey"], k
@@ -327,8 +339,53 @@ def digests(orc, big):
         assert sha(ct) == d["C2_ctr128_1GiB_seed2"]["sha256"]
         assert ct[-32:].hex() == d["C2_ctr128_1GiB_seed2"]["tail"]
         d["C2_ctr128_1GiB_seed2"]["recomputed"] = True
-        del h, step, tail
+        del h, step, tail, pt, ct
+        d.update(c5_shards(orc, d))
     return d
+
+
+def c5_shards(orc, d):
+    """SHA-256 of each of the eight 1 GiB shards of the C5 stream, by the reference's own AES_CTR_encrypt
+    (PRESET_COUNTER build, counter block = iv || BE32(1 + g * 2^26)), eight forked processes; the
+    concatenation is checked against the survey's digest of the whole 8 GiB stream."""
+    import numpy as np
+    import ctypes as C
+    ref = Reference(128, preset_counter=True)
+    key16 = bytes(range(16))
+    nonce = bytes(range(0xF0, 0xFC))
+    n = 1 << 30
+    tmp = "/tmp/uaes_c5_shards"
+    os.makedirs(tmp, exist_ok=True)
+    pids = []
+    for g in range(8):
+        pid = os.fork()
+        if pid == 0:
+            buf = np.empty(n, dtype=np.uint8)
+            orc.splitmix_into(2, buf, word0=g * (n // 8))
+            out = np.empty(n, dtype=np.uint8)
+            ctr = nonce + (1 + g * (n // 16)).to_bytes(4, "big")
+            ref.L.AES_CTR_encrypt(key16, ctr, C.c_void_p(buf.ctypes.data), n, C.c_void_p(out.ctypes.data))
+            out.tofile(os.path.join(tmp, "shard%d.bin" % g))
+            os._exit(0)
+        pids.append(pid)
+    for pid in pids:
+        assert os.waitpid(pid, 0)[1] == 0
+    res, whole = {}, hashlib.sha256()
+    for g in range(8):
+        h = hashlib.sha256()
+        with open(os.path.join(tmp, "shard%d.bin" % g), "rb") as f:
+            while True:
+                b = f.read(1 << 26)
+                if not b:
+                    break
+                h.update(b)
+                whole.update(b)
+        os.remove(os.path.join(tmp, "shard%d.bin" % g))
+        res["C5_shard_%d" % g] = dict(sha256=h.hexdigest(), counter_offset=g * (n // 16),
+                                      source="compiled reference, PRESET_COUNTER 1 (make_fixtures.py --big)")
+    assert whole.hexdigest() == d["C5_ctr128_8GiB_seed2"]["sha256"], "shards do not concatenate to the C5 stream"
+    assert res["C5_shard_0"]["sha256"] == d["C2_ctr128_1GiB_seed2"]["sha256"]
+    return res
 
 
 def ecb_padding_vectors(orc):

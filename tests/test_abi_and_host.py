@@ -17,6 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_functions(header):
     text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"UAES_STATIC_INLINE[^{;]*\{.*?\n\}", "", text, flags=re.S)      # header-only wrappers are not exports
     return sorted(set(re.findall(r"\b((?:uaes|AES|GCM_SIV)_[A-Za-z0-9_]+)\s*\(", text)))
 
 
@@ -49,6 +50,28 @@ def test_compat_header_compiles_as_c89_and_matches_reference_constants(tmp_path)
                         "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
         out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
         assert [int(x) for x in out] == [kl, 12, 16, 12, 1, 1, 0x1A, 0x1D, 0x1E]
+
+
+def test_compat_header_binds_function_pointers_under_the_callers_switches(tmp_path):
+    """-DGCM_NONCE_LEN=n / -DPRESET_COUNTER=1 / -DAES_PADDING=1 are compile-time switches of the CALLER's
+    build (micro_aes.h:79,100,108).  The header must bind a function POINTER -- not only a direct call --
+    to the matching entry point: object-like macros, never function-like ones; and stay C89-clean."""
+    src = tmp_path / "p.c"
+    src.write_text('#include "micro_aes.h"\n'
+                   'typedef void (*gcm_fn)(const uint8_t*, const uint8_t*, const void*, const size_t, const void*, const size_t, void*);\n'
+                   'typedef void (*ctr_fn)(const uint8_t*, const uint8_t*, const void*, const size_t, void*);\n'
+                   'typedef void (*ecb_fn)(const uint8_t*, const void*, const size_t, void*);\n'
+                   'gcm_fn table_g[1] = { AES_GCM_encrypt };\n'
+                   'ctr_fn table_c[2] = { AES_CTR_encrypt, AES_CTR_decrypt };\n'
+                   'ecb_fn table_e[1] = { AES_ECB_encrypt };\n'
+                   'int main(void) { return (table_g[0] && table_c[0] && table_e[0] && GCM_NONCE_LEN == 7) ? 0 : 1; }\n')
+    obj = tmp_path / "p.o"
+    subprocess.run(["gcc", "-std=c89", "-pedantic", "-Wall", "-Werror", "-DGCM_NONCE_LEN=7", "-DPRESET_COUNTER=1",
+                    "-DAES_PADDING=1", "-I", os.path.join(ROOT, "include"), "-c", str(src), "-o", str(obj)], check=True)
+    syms = subprocess.run(["nm", "-u", str(obj)], check=True, capture_output=True, text=True).stdout
+    assert "AES_GCM_encrypt_ivlen" in syms and "AES_CTR_encrypt_preset" in syms and "AES_CTR_decrypt_preset" in syms
+    assert "AES_ECB_encrypt_pkcs7" in syms
+    assert not re.search(r"\bAES_GCM_encrypt$|\bAES_CTR_encrypt$|\bAES_ECB_encrypt$", syms, flags=re.M)
 
 
 @pytest.mark.parametrize("bits", [128, 192, 256])

@@ -67,9 +67,13 @@ def test_C5_ctr128_8GiB_as_eight_shards(golden_dir):
         src = bench.splitmix_device(torch, 2, GIB, g * (GIB // 8), dev)
         uaes.ctr_xcrypt_dev(key, ctr0, g * (GIB // 16), src, dst)
         torch.cuda.synchronize()
+        # each shard against the reference's own digest of it (PRESET_COUNTER build, make_fixtures.py --big;
+        # shard 0 is C2) -- what every rank of `bench.py --gpus N` checks
+        hs = hashlib.sha256()
+        _update(hs, dst)
+        assert hs.hexdigest() == _digests(golden_dir)["C5_shard_%d" % g]["sha256"], g
         if g == 0:
-            assert hashlib.sha256(dst.cpu().numpy().tobytes()).hexdigest() == \
-                _digests(golden_dir)["C2_ctr128_1GiB_seed2"]["sha256"]
+            assert hs.hexdigest() == _digests(golden_dir)["C2_ctr128_1GiB_seed2"]["sha256"]
         _update(h, dst)
         del src
     assert h.hexdigest() == _digests(golden_dir)["C5_ctr128_8GiB_seed2"]["sha256"]
@@ -103,3 +107,38 @@ def test_bench_two_rank_dry_run(workload):
     assert line["verified"] is True
     assert line["value"] > 0 and line["config"]["parallelism"] == "shard2"
     assert "cpu_baseline" not in line            # rank 0 at N=1 only
+
+
+def _one_json_line(r):
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_self_launch_verifies_every_shard():
+    """`python bench.py --gpus 2` with NO launcher -- the shape of the driver's N=1 command: bench.py starts
+    its own two ranks (torch.distributed.run, free port).  Dry run on this box's one GPU (gloo,
+    --single-device) at the full 1 GiB per rank, so that EVERY rank hashes its whole shard against the
+    reference's digest of that shard of the C5 stream (PRESET_COUNTER build of the reference)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--backend", "gloo", "--single-device", "--settle-ms", "0"]
+    line = _one_json_line(subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900))
+    assert line["n_gpus"] == 2 and line["verified"] is True
+    assert line["verified_shards"].startswith("every rank hashed its whole shard")
+    assert len(line["roofline"]["per_gpu_achieved"]) == 2
+    agg = line["roofline"]["aggregate"]
+    assert agg["peak"] == 16000.0 and abs(agg["achieved"] - sum(line["roofline"]["per_gpu_achieved"])) < 1.0
+
+
+def test_bench_two_ranks_rccl():
+    """the real thing on a multi-GPU box: two ranks, two devices, RCCL (nccl backend with device_id), the
+    ciphertext all-gather included"""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs: this box has %d" % torch.cuda.device_count())
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--gather"]
+    line = _one_json_line(subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900))
+    assert line["n_gpus"] == 2 and line["verified"] is True and line["gather_ms"] > 0

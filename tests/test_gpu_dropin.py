@@ -76,3 +76,15 @@ def test_reference_main_c_aes192_pkcs7_check_runs_on_the_hip_library():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "FAILED" not in r.stdout, r.stdout + r.stderr
     assert re.findall(r"AES-192 (\w+) \w+: PASSED!", r.stdout) == ["ECB", "ECB"], r.stdout
+
+
+def test_reference_main_c_preset_counter_runs_on_the_hip_library():
+    """main.c built with -DPRESET_COUNTER=1 (micro_aes.h:100) passes its 16-byte iVec to AES_CTR_* as the
+    whole counter block and checks its own known answer for that case (main.c:45-47); include/micro_aes.h
+    then binds AES_CTR_* to the *_preset entry points (uaes_ctr_xcrypt_at with block offset 0)"""
+    exe = os.path.join(REF, "main_hip_128_presetctr")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/main_hip_128_presetctr was not built")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "FAILED" not in r.stdout, r.stdout + r.stderr
+    assert re.findall(r"AES-128 (CTR) \w+: PASSED!", r.stdout) == ["CTR", "CTR"], r.stdout

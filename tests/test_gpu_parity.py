@@ -501,6 +501,35 @@ def test_sharded_gcm_partials(orc, total, world, alen):
     assert tag == want[-16:]
 
 
+def test_sharded_gcm_partials_on_distinct_devices(orc):
+    """the same exchange with every shard on ITS OWN GPU (per-device contexts and scratch, shares gathered
+    through the host): needs a multi-GPU box"""
+    import torch
+    import micro_aes_amd.sharding as sh
+    world = torch.cuda.device_count()
+    if world < 2:
+        pytest.skip("needs 2 GPUs: this box has %d" % world)
+    rnd = random.Random(77)
+    total, alen = (24 << 20) + 16 * 3 + 5, 19
+    key, nonce, aad = rnd.randbytes(16), rnd.randbytes(12), rnd.randbytes(alen)
+    data = orc.splitmix(total + 3, total)
+    want = uaes.AES_GCM_encrypt(key, nonce, aad, data)
+    shares, pieces = [], []
+    for rank in range(world):
+        dev = torch.device("cuda", rank)
+        with torch.cuda.device(dev):
+            d_aad = torch.frombuffer(bytearray(aad), dtype=torch.uint8).to(dev)
+            start, n, _ = sh.gcm_shard_roles(total, rank, world)
+            src = torch.frombuffer(bytearray(data[start:start + n] + bytes(16)), dtype=torch.uint8).to(dev)
+            dst = torch.zeros_like(src)
+            tag = sh.gcm_encrypt_sharded(key, nonce, d_aad, alen, total, src, dst, rank, world,
+                                         gather=lambda share: shares.append(share) or list(shares))
+            torch.cuda.synchronize(dev)
+            pieces.append(bytes(dst[:n].cpu().numpy()))
+    assert b"".join(pieces) == want[:-16]
+    assert tag == want[-16:]
+
+
 @pytest.mark.parametrize("bits", [128, 192, 256])
 def test_feedback_modes_vs_oracle(orc, bits):
     """CBC (CS3) / CFB decrypt are block-parallel kernels: check them on large inputs too"""
@@ -630,8 +659,8 @@ def test_ctr_split_between_shared_round_and_generic_kernels(orc, mib, extra, low
 
 
 def test_C3_xts256_sectors_device_resident(orc, golden_dir):
-    """BASELINE configs[2] at 2^18 sectors (1 GiB; the 2^20 digest is checked by
-    bench.py --workload xts): first sectors against the goldens, round trip, and
+    """BASELINE configs[2] at 2^18 sectors (1 GiB; the full 2^20-sector digest is checked by
+    tests/test_gpu_baseline_full.py): first sectors against the goldens, round trip, and
     equality with per-range calls."""
     import torch
     d = load(golden_dir, "digests.json")

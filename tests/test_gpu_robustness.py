@@ -3,6 +3,7 @@
 host/device pointers, concurrent host threads (the reference is not re-entrant,
 micro_aes.c:72 -- this library must be), and streams > 4 GiB (64-bit indexing)."""
 import ctypes as C
+import hashlib
 import random
 import threading
 
@@ -166,34 +167,68 @@ def test_dev_api_rejects_misaligned_pointers():
         uaes.ocb_dev(key, bytes(12), None, t[8:8 + 1024], 1024, t[2048:])
 
 
-def test_single_process_multi_gpu_entry_points(orc):
-    """uaes_mgpu_*: slices of one text on several devices from one process.  On a 1-GPU box the device
-    list names device 0 three times, which still exercises the slicing, the counter / sector offsets and
-    the per-device worker threads; the result must be the single-call result."""
+def _mgpu_device_lists():
+    """device lists for the uaes_mgpu_* tests: {0,0,0} always (slicing, offsets and worker threads on one
+    device), and every visible device once plus a doubled list when the box has more than one GPU"""
+    import torch
+    n = torch.cuda.device_count()
+    lists = [[0, 0, 0]]
+    if n >= 2:
+        lists += [list(range(n)), list(range(n - 1, -1, -1)) + [0]]
+    return lists
+
+
+def _check_mgpu(orc, devlist):
     L = uaes.engine()
-    rnd = random.Random(99)
+    rnd = random.Random(99 + len(devlist))
     key, keys = rnd.randbytes(32), rnd.randbytes(64)
     ctr0 = rnd.randbytes(12) + b"\xff\xff\xff\xf0"
-    devs = (C.c_int * 3)(0, 0, 0)
+    nd = len(devlist)
+    devs = (C.c_int * nd)(*devlist)
     for n in (0, 5, 16, 47, 100003, (3 << 20) + 9):
         data = orc.splitmix(n + 1, n)
         out = (C.c_uint8 * max(n, 1))()
-        assert L.uaes_mgpu_ctr_xcrypt_at(3, devs, 256, key, ctr0, 7, data, n, out) == 0
+        assert L.uaes_mgpu_ctr_xcrypt_at(nd, devs, 256, key, ctr0, 7, data, n, out) == 0
         assert bytes(out)[:n] == orc.ctr_xcrypt_at(key, ctr0, 7, data), n
         assert L.uaes_mgpu_ctr_xcrypt_at(1, None, 256, key, ctr0, 7, data, n, out) == 0
         assert bytes(out)[:n] == orc.ctr_xcrypt_at(key, ctr0, 7, data), n
     for sb, ns in ((512, 1), (512, 2), (4096 + 17, 7), (16, 100)):
         data = orc.splitmix(sb + ns, sb * ns)
         out = (C.c_uint8 * (sb * ns))()
-        assert L.uaes_mgpu_xts_sectors(3, devs, 256, keys, (1 << 40) + 5, sb, ns, data, out, 1) == 0
+        assert L.uaes_mgpu_xts_sectors(nd, devs, 256, keys, (1 << 40) + 5, sb, ns, data, out, 1) == 0
         rc, want = orc.xts_sectors(keys, (1 << 40) + 5, sb, data, True)
         assert rc == 0 and bytes(out) == want, (sb, ns)
         back = (C.c_uint8 * (sb * ns))()
-        assert L.uaes_mgpu_xts_sectors(3, devs, 256, keys, (1 << 40) + 5, sb, ns, out, back, 0) == 0
+        assert L.uaes_mgpu_xts_sectors(nd, devs, 256, keys, (1 << 40) + 5, sb, ns, out, back, 0) == 0
         assert bytes(back) == data
-    bad = (C.c_int * 1)(9)
-    assert L.uaes_mgpu_ctr_xcrypt_at(1, bad, 128, key, ctr0, 0, b"x" * 16, 16, out) == -2       # UAES_E_ARG
+    # a long host text: every device takes its slice through the pipelined host path
+    n = (96 << 20) + 16 * 5
+    data = orc.splitmix(12345, n)
+    out = (C.c_uint8 * n)()
+    assert L.uaes_mgpu_ctr_xcrypt_at(nd, devs, 128, key[:16], ctr0, 3, data, n, out) == 0
+    assert hashlib.sha256(bytes(out)).digest() == hashlib.sha256(orc.ctr_xcrypt_at(key[:16], ctr0, 3, data)).digest()
+
+
+def test_single_process_multi_gpu_entry_points(orc):
+    """uaes_mgpu_*: slices of one text on several devices from one process.  The device list {0,0,0}
+    exercises the slicing, the counter / sector offsets and the per-device worker threads on any box;
+    the result must be the single-call result."""
+    L = uaes.engine()
+    _check_mgpu(orc, [0, 0, 0])
+    bad = (C.c_int * 1)(99)
+    out = (C.c_uint8 * 16)()
+    assert L.uaes_mgpu_ctr_xcrypt_at(1, bad, 128, bytes(16), bytes(16), 0, b"x" * 16, 16, out) == -2       # UAES_E_ARG
     assert b"not one of" in L.uaes_last_error()
+
+
+def test_single_process_multi_gpu_on_distinct_devices(orc):
+    """the same on DISTINCT devices (per-device contexts, hipSetDevice per worker thread, no peer access
+    between them): every visible GPU once, and a list that visits them in reverse and device 0 twice"""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs: this box has %d" % torch.cuda.device_count())
+    for devlist in _mgpu_device_lists()[1:]:
+        _check_mgpu(orc, devlist)
 
 
 def test_more_streams_than_scratch_slots_from_several_threads(orc):

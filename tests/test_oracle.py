@@ -370,3 +370,38 @@ def test_against_compiled_reference_random(orc, bits):
         bad = bytearray(cc); bad[-1] ^= 2
         assert orc.ccm_decrypt(key, iv[:11], aad2, bytes(bad)) == ref.ccm_decrypt(key, iv[:11], aad2, bytes(bad))
         assert orc.ccm_decrypt(key, iv[:11], aad2, bytes(bad))[0] == 0x1A
+
+
+def test_preset_counter_build_of_the_reference(orc, golden_dir):
+    """the oracle's positioned CTR (orc_ctr_xcrypt_at: full 16-byte counter block + block offset) against
+    the reference built with PRESET_COUNTER 1 (micro_aes.h:100, micro_aes.c:965-966), including counters
+    that carry through bytes 9..15 and wrap mod 2^56 (N2), and main.c's own known answer (main.c:45-47)"""
+    if not Reference.available(128, preset_counter=True):
+        pytest.skip("oracle/_ref not built here")
+    ref = Reference(128, preset_counter=True)
+    rnd = random.Random(4242)
+    for _ in range(120):
+        n = rnd.choice([0, 1, 15, 16, 17, 100, 4096, 4097, 70001])
+        key, data = rnd.randbytes(16), rnd.randbytes(n)
+        ctr = bytearray(rnd.randbytes(16))
+        if rnd.random() < 0.5:                                   # near a carry / the 56-bit wrap
+            for i in range(rnd.choice([10, 12, 15]) - 8, 8):
+                ctr[8 + i] = 0xFF
+            ctr[15] = rnd.choice([0xFD, 0xFE, 0xFF])
+        ctr = bytes(ctr)
+        want = ref.ctr_encrypt(key, ctr, data)
+        assert orc.ctr_xcrypt_at(key, ctr, 0, data) == want
+        k = rnd.randrange(0, n // 16 + 1)                        # the same stream entered k blocks later
+        assert orc.ctr_xcrypt_at(key, ctr, k, data[16 * k:]) == want[16 * k:]
+    key = bytes.fromhex("279fb74a7572135e8f9b8ef6d1eee003")         # main.c:16-18, :45-47, :167-173
+    iv = bytes.fromhex("8EA2B7CA516745BFEAfc49904b496089")
+    pt = bytes.fromhex("c9f775baafa36c25cd610d3c75a482eadda97ca4864cdfe06eaf70a0ec0d7191"
+                       "d55027cf8f900214e634412583ff0b478EA2B7CA516745BFEA")
+    kat = bytes.fromhex("edab3105e673bc9eb9102539a9f457bcf2e2606dfa3f93c5c51b910a89cddb67"
+                        "191a118531ea042797626c9bfd370426fdf3f59158bf7d4d43")
+    assert ref.ctr_encrypt(key, iv, pt) == kat == orc.ctr_xcrypt_at(key, iv, 0, pt)
+    # and the C5 shard digests were made with this build: shard 0 must be C2
+    with open(os.path.join(golden_dir, "digests.json")) as f:
+        d = json.load(f)
+    assert d["C5_shard_0"]["sha256"] == d["C2_ctr128_1GiB_seed2"]["sha256"]
+    assert all("C5_shard_%d" % g in d for g in range(8))

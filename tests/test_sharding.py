@@ -168,3 +168,32 @@ def test_sharded_gcm_math(orc, total, world):
         pieces.append(bytes(dst))
     assert b"".join(pieces) == want[:-16]
     assert tag == want[-16:]            # after the last rank every share has been collected
+
+
+def test_bench_self_launch_command(monkeypatch):
+    """`python bench.py --gpus N` without a launcher starts its own N ranks the way the documented
+    torch.distributed.run command does (rendezvous on 127.0.0.1, a free port, the same arguments)."""
+    import subprocess
+    import sys
+    import types
+    import bench
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return types.SimpleNamespace(returncode=7)
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "5"])
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7                                     # the ranks' status is ours
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "5"] and cmd[-5].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
