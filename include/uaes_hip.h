@@ -10,7 +10,9 @@
  *     the compile-time macro AES___ (micro_aes.h:17).  include/micro_aes.h
  *     restores the macro API on top of these functions;
  *   - no global state: the reference keeps one static RoundKey
- *     (micro_aes.c:72) and is not re-entrant; this library is thread-safe;
+ *     (micro_aes.c:72) and is not re-entrant; this library is thread-safe AND concurrent:
+ *     every host thread runs its synchronous calls on its own HIP stream with its own staging,
+ *     so calls from different threads overlap on the GPU (no lock is held while it works);
  *   - data pointers may be HOST or DEVICE (HIP) pointers.  Host buffers are
  *     staged through device memory; device buffers are used in place.
  *     Keys, IVs, nonces and tweaks are always host pointers (<= 64 bytes);
@@ -47,6 +49,12 @@ extern "C" {
 /* Initialise the engine on the calling thread's current HIP device (idempotent;
  * every other call does this lazily).                                        */
 int         uaes_init(void);
+/* Give back everything the library holds on every device: the per-thread lanes of the synchronous
+ * API (stream, staging, pinned bounce buffers, scratch), the slice pipeline's streams and buffers,
+ * the per-stream scratch of the *_dev API and the tables.  Waits for the devices' outstanding work.
+ * No other call may be in flight; the next call after it sets the library up again.  Key contexts
+ * and GCM streams are the caller's objects and are not touched.                               */
+int         uaes_shutdown(void);
 /* Run the on-device primitive self test (FIPS-197 C.1 both directions, byte
  * permute semantics, tweak arithmetic).  0 = pass, >0 = failure bitmask.     */
 int         uaes_selftest(void);
@@ -250,6 +258,10 @@ int  uaes_gcm_stream_update(uaes_gcm_stream *s, const void *in, size_t len, void
 /* encrypting stream: tag <- the 16-byte tag; decrypting stream: tag = the received tag */
 int  uaes_gcm_stream_finish(uaes_gcm_stream *s, uint8_t tag[16]);
 void uaes_gcm_stream_abort(uaes_gcm_stream *s);
+
+/* A synchronous call that is handed DEVICE memory first waits for the work the caller may have in
+ * flight on the default stream (hipStreamSynchronize(NULL)), then runs on the calling thread's own
+ * stream and returns when it is done -- the ordering a default-stream launch used to give.        */
 
 /* ---- asynchronous, device-resident variants -----------------------------
  * All data pointers are device pointers, 16-byte aligned; `stream` is a

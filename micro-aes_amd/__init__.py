@@ -32,7 +32,7 @@ M_DECRYPTION_ERROR = 0x1D
 M_ENCRYPTION_ERROR = 0x1E
 
 EXPORTS = [
-    "uaes_init", "uaes_selftest", "uaes_last_error", "uaes_version", "uaes_expand_key", "uaes_stream_release",
+    "uaes_init", "uaes_shutdown", "uaes_selftest", "uaes_last_error", "uaes_version", "uaes_expand_key", "uaes_stream_release",
     "uaes_set_wipe_on_auth_failure",
     "uaes_ecb_encrypt", "uaes_ecb_encrypt_padded", "uaes_ecb_decrypt", "uaes_ctr_xcrypt", "uaes_ctr_xcrypt_at",
     "uaes_xts_encrypt", "uaes_xts_decrypt", "uaes_xts_sectors",

@@ -385,3 +385,62 @@ def test_long_host_texts_go_through_the_slice_pipeline(orc):
         t.join()
     assert res["a"] == (0, sha(orc.ctr_xcrypt_at(key, ctr0, 5, data)))
     assert res["b"] == (0, sha(orc.ctr_xcrypt_at(key, ctr0, 6, data)))
+
+
+def test_lanes_of_short_lived_threads_and_shutdown(orc):
+    """Every host thread gets its own lane (stream, staging, pinned buffers, scratch) for the synchronous
+    API; a lane goes away with its thread, and uaes_shutdown() returns everything on every device, after
+    which the next call sets the library up again -- results unchanged throughout."""
+    L = uaes.engine()
+    key, iv = bytes(range(16)), bytes(range(12))
+    data = orc.splitmix(5, 70001)
+    want_ctr = orc.ctr_encrypt(key, iv, data)
+    want_gcm = orc.gcm_encrypt(key, iv, b"hdr", data)
+    errs = []
+
+    def work():
+        try:
+            for _ in range(3):
+                assert uaes.AES_CTR_encrypt(key, iv, data) == want_ctr
+                assert uaes.AES_GCM_encrypt(key, iv, b"hdr", data) == want_gcm
+                assert uaes.AES_GCM_decrypt(key, iv, b"hdr", want_gcm) == (0, data)
+        except Exception as e:               # noqa: BLE001
+            errs.append(repr(e))
+
+    for _ in range(6):                       # 48 threads come and go
+        ts = [threading.Thread(target=work) for _ in range(8)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+    assert not errs, errs[:3]
+    assert L.uaes_shutdown() == 0
+    assert uaes.AES_CTR_encrypt(key, iv, data) == want_ctr          # this thread's emptied lane is rebuilt
+    ts = [threading.Thread(target=work) for _ in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs[:3]
+    assert L.uaes_shutdown() == 0 and L.uaes_shutdown() == 0       # idempotent
+    assert uaes.AES_XTS_encrypt(bytes(range(32)), bytes(16), data) == orc.xts(bytes(range(32)), bytes(16), data, True, prefill=0)
+
+
+def test_sync_api_orders_after_the_callers_default_stream_work(orc):
+    """a synchronous call handed DEVICE memory runs on the thread's own (non-blocking) stream; it must
+    still see what the caller queued on the default stream just before"""
+    import torch
+    key, ctr0 = bytes(range(16)), bytes(range(12)) + b"\0\0\0\1"
+    n = 64 << 20
+    Lh = uaes.engine()
+    for rep in range(5):
+        a = torch.zeros(n, dtype=torch.uint8, device="cuda:0")
+        for _ in range(4):                   # a queue of default-stream work ending in the fill we need
+            a.add_(1)
+        a.fill_(rep + 1)
+        out = torch.empty_like(a)
+        assert Lh.uaes_ctr_xcrypt_at(128, key, ctr0, 0, C.c_void_p(a.data_ptr()), n, C.c_void_p(out.data_ptr())) == 0
+        got = bytes(out[:4096].cpu().numpy())
+        assert got == orc.ctr_xcrypt_at(key, ctr0, 0, bytes([rep + 1]) * 4096)
+        tail = bytes(out[n - 4096:].cpu().numpy())
+        assert tail == orc.ctr_xcrypt_at(key, ctr0, (n - 4096) // 16, bytes([rep + 1]) * 4096)
