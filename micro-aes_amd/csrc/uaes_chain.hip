@@ -32,6 +32,23 @@ struct Blk {
     u32 w[4];
 };
 
+/* byte i of a block held in four registers, without indexing the registers by a run-time value (that
+ * would put the block in scratch memory and give the whole kernel a private segment)             */
+__device__ __forceinline__ u32 blk_byte(const u32 w0, const u32 w1, const u32 w2, const u32 w3, u32 i)
+{
+    const u32 w = i < 8 ? (i < 4 ? w0 : w1) : (i < 12 ? w2 : w3);
+    return (w >> (8 * (i & 3))) & 0xffu;
+}
+
+__device__ __forceinline__ void blk_or_byte(Blk &b, u32 i, u32 v)
+{
+    const u32 x = v << (8 * (i & 3)), q = i >> 2;
+    b.w[0] |= q == 0 ? x : 0;
+    b.w[1] |= q == 1 ? x : 0;
+    b.w[2] |= q == 2 ? x : 0;
+    b.w[3] |= q == 3 ? x : 0;
+}
+
 __device__ __forceinline__ Blk ldb(const unsigned char *p, u32 nbytes)        /* zero padded */
 {
     Blk b = { { 0, 0, 0, 0 } };
@@ -40,7 +57,7 @@ __device__ __forceinline__ Blk ldb(const unsigned char *p, u32 nbytes)        /*
         b.w[0] = v.x; b.w[1] = v.y; b.w[2] = v.z; b.w[3] = v.w;
         return b;
     }
-    for (u32 i = 0; i < (nbytes < 16 ? nbytes : 16u); ++i) b.w[i >> 2] |= (u32)p[i] << (8 * (i & 3));
+    for (u32 i = 0; i < (nbytes < 16 ? nbytes : 16u); ++i) blk_or_byte(b, i, (u32)p[i]);
     return b;
 }
 
@@ -51,7 +68,7 @@ __device__ __forceinline__ void stb(unsigned char *p, const Blk &b, u32 nbytes)
         *(uint4 *)p = make_uint4(b.w[0], b.w[1], b.w[2], b.w[3]);
         return;
     }
-    for (u32 i = 0; i < (nbytes < 16 ? nbytes : 16u); ++i) p[i] = (unsigned char)(b.w[i >> 2] >> (8 * (i & 3)));
+    for (u32 i = 0; i < (nbytes < 16 ? nbytes : 16u); ++i) p[i] = (unsigned char)blk_byte(b.w[0], b.w[1], b.w[2], b.w[3], i);
 }
 
 __device__ __forceinline__ void xb(Blk &a, const Blk &b)
@@ -165,7 +182,7 @@ __global__ __launch_bounds__(UAES_WG) void k_fb_dec(uaesk_rk rk, uaesk_tables tb
         enc_blocks<NR, 1>(s1, rk, lc);
         const unsigned char *src = (const unsigned char *)(in + n);
         unsigned char *dst = (unsigned char *)(out + n);
-        for (u32 i = 0; i < rem; ++i) dst[i] = src[i] ^ (unsigned char)(s1[0][i >> 2] >> (8 * (i & 3)));
+        for (u32 i = 0; i < rem; ++i) dst[i] = src[i] ^ (unsigned char)blk_byte(s1[0][0], s1[0][1], s1[0][2], s1[0][3], i);
     }
 }
 
@@ -303,7 +320,7 @@ __global__ __launch_bounds__(UAES_WG) void k_chain_batch(uaesk_rk rk, uaesk_tabl
                 enc_blocks<NR, 1>(s, rk, lc);
             }
             Blk l = ldb(src + 16 * full, last);
-            if (last < 16) { l.w[last >> 2] ^= 0x80u << (8 * (last & 3)); xb(l, k2); } else xb(l, k1);
+            if (last < 16) { blk_or_byte(l, last, 0x80u); xb(l, k2); } else xb(l, k1);   /* the byte there is padding: 0 */
             s[0][0] ^= l.w[0]; s[0][1] ^= l.w[1]; s[0][2] ^= l.w[2]; s[0][3] ^= l.w[3];
             enc_blocks<NR, 1>(s, rk, lc);
             ((uint4 *)out)[m] = make_uint4(s[0][0], s[0][1], s[0][2], s[0][3]);

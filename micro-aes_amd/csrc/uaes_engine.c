@@ -416,6 +416,7 @@ typedef struct lane {
     void       *aad_stage;
     size_t      aad_cap;
     void       *pin[2];             /* pinned bounce buffers for short host texts (in, out)       */
+    void       *pinx;               /* 4 KiB of pinned memory for small values exchanged mid-call */
     int        *d_status;           /* device: status word, and a 16-byte result slot at +4 ints  */
     struct lane *next;              /* context's list                                             */
 } lane;
@@ -432,6 +433,7 @@ static void lane_free_resources(lane *L)
         if (L->stage[i]) (void)hipFree(L->stage[i]);
         if (L->pin[i]) (void)hipHostFree(L->pin[i]);
     }
+    if (L->pinx) (void)hipHostFree(L->pinx);
     if (L->scratch) {                             /* GHASH tables of H are key material */
         (void)hipMemset(L->scratch, 0, L->scratch_cap);
         (void)hipFree(L->scratch);
@@ -441,7 +443,7 @@ static void lane_free_resources(lane *L)
     if (L->stream) (void)hipStreamDestroy((hipStream_t)L->stream);
     (void)hipGetLastError();
     L->stream = NULL; L->stage[0] = L->stage[1] = NULL; L->stage_cap[0] = L->stage_cap[1] = 0;
-    L->pin[0] = L->pin[1] = NULL; L->scratch = NULL; L->scratch_cap = 0;
+    L->pin[0] = L->pin[1] = NULL; L->pinx = NULL; L->scratch = NULL; L->scratch_cap = 0;
     L->aad_stage = NULL; L->aad_cap = 0; L->d_status = NULL;
 }
 
@@ -566,8 +568,26 @@ typedef struct {
 
 /* Short host texts travel through pinned bounce buffers with asynchronous copies on the
  * lane's stream, so a call synchronises once instead of three times (pageable hipMemcpy
- * in, kernel, pageable hipMemcpy out): ~45 -> ~28 us for a 4 KiB call.                 */
-#define PIN_BYTES ((size_t)256 << 10)
+ * in, kernel, pageable hipMemcpy out): ~45 -> ~28 us for a 4 KiB call.  Shorter ones still
+ * (zero_copy_max()) are not copied at all: the pinned buffers are mapped into the GPU's address
+ * space, so the kernel reads the text from pin[0] and writes the result to pin[1] across the
+ * link itself -- one submission per call instead of three (copy, kernel, copy).          */
+static int env_int(const char *name, int dflt, int lo, int hi);
+
+static size_t pin_bytes(void)
+{
+    static size_t z = 0;
+    if (!z) z = (size_t)env_int("UAES_PIN_KIB", 1024, 16, 65536) << 10;
+    return z;
+}
+#define PIN_BYTES pin_bytes()
+
+static size_t zero_copy_max(void)
+{
+    static size_t z = (size_t)-1;
+    if (z == (size_t)-1) z = (size_t)env_int("UAES_ZEROCOPY_MAX_KIB", 1024, 0, (int)(PIN_BYTES >> 10)) << 10;
+    return z;
+}
 
 static int pinned_ready(lane *L)
 {
@@ -578,6 +598,11 @@ static int pinned_ready(lane *L)
             L->pin[i] = NULL;
             return 0;                             /* no pinned memory: the pageable path still works */
         }
+    if (!L->pinx && hipHostMalloc(&L->pinx, 4096, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        L->pinx = NULL;
+        return 0;
+    }
     return 1;
 }
 
@@ -596,6 +621,11 @@ static int plan_io(lane *L, const void *in, size_t in_len, void *out, size_t out
     if (in_dev || out_dev) { int rc = wait_for_callers_device_work(); if (rc) return rc; }
     /* every call ends with the lane's stream drained (finish_io / lane_fetch, and the error paths
      * below the API boundary go through lane_abandon), so the bounce buffers are free here      */
+    if (!in_dev && !out_dev && in_len <= zero_copy_max() && out_cap <= zero_copy_max() && pinned_ready(L)) {
+        if (in_len) { memcpy(L->pin[0], in, in_len); io->din = L->pin[0]; }
+        if (out_cap) io->dout = L->pin[1];        /* finish_io hands it over from there */
+        return 0;
+    }
     if (!in_ok) {
         const size_t need = (in_len > out_cap ? in_len : out_cap) + 64;
         if (grow_on(st, &L->stage[0], &L->stage_cap[0], need)) return UAES_E_HIP;
@@ -618,6 +648,11 @@ static int finish_io(io_plan *io, size_t out_len)
 {
     lane *L = io->L;
     hipStream_t st = (hipStream_t)L->stream;
+    if (io->dout && io->dout == L->pin[1]) {      /* the kernel wrote the mapped pinned buffer itself */
+        HIPCHK(hipStreamSynchronize(st));
+        if (out_len) memcpy(io->user_out, L->pin[1], out_len);
+        return 0;
+    }
     if (io->copy_back && out_len && out_len <= PIN_BYTES && io->out_is_host && pinned_ready(L)) {
         HIPCHK(hipMemcpyAsync(L->pin[1], io->dout, out_len, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
@@ -1773,12 +1808,14 @@ static int gcmsiv_derive(lane *L, int keybits, const uint8_t *key, const uint8_t
      * buffers when there are any (pageable hipMemcpy in, kernel, pageable hipMemcpy out synchronise
      * three times: ~30 us -> ~18 us) */
     if (pinned_ready(L)) {
-        memcpy(L->pin[0], blocks, (size_t)(16 * n));
-        HIPCHK(hipMemcpyAsync(L->aad_stage, L->pin[0], (size_t)(16 * n), hipMemcpyHostToDevice, st));
+        /* pinx, not pin[0] / pin[1]: those may hold this call's text (the copy in may still be running) */
+        uint8_t *px = (uint8_t *)L->pinx;
+        memcpy(px, blocks, (size_t)(16 * n));
+        HIPCHK(hipMemcpyAsync(L->aad_stage, px, (size_t)(16 * n), hipMemcpyHostToDevice, st));
         KCHK(uaesk_ecb(st, &c->tb, master.nr, &master.ek, 0, L->aad_stage, L->aad_stage, (size_t)n, 0, 0));
-        HIPCHK(hipMemcpyAsync(L->pin[1], L->aad_stage, (size_t)(16 * n), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(px + 128, L->aad_stage, (size_t)(16 * n), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        memcpy(blocks, L->pin[1], (size_t)(16 * n));
+        memcpy(blocks, px + 128, (size_t)(16 * n));
     } else {
         HIPCHK(hipMemcpyAsync(L->aad_stage, blocks, (size_t)(16 * n), hipMemcpyHostToDevice, st));
         KCHK(uaesk_ecb(st, &c->tb, master.nr, &master.ek, 0, L->aad_stage, L->aad_stage, (size_t)n, 0, 0));

@@ -75,8 +75,8 @@ __global__ __launch_bounds__(UAES_WG) void k_ecb(uaesk_rk rk, uaesk_tables tb,
         unsigned char pad[16];
         const unsigned char fillv = padding == 1 ? (unsigned char)(16u - rem) : 0;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) pad[i] = (u32)i < rem ? src[i] : fillv;
-        if (padding == 2) pad[rem] = 0x80;
+        for (int i = 0; i < 16; ++i)               /* static indices only: no private segment for the bulk kernel */
+            pad[i] = (u32)i < rem ? src[i] : (padding == 2 && (u32)i == rem) ? (unsigned char)0x80 : fillv;
         u32 s1[1][4];
 #pragma unroll
         for (int w = 0; w < 4; ++w)

@@ -6,6 +6,7 @@ import ctypes as C
 import os
 import re
 import subprocess
+import sys
 
 import pytest
 
@@ -174,3 +175,25 @@ def test_product_does_not_touch_the_oracle():
                 assert "pyoracle" not in text and "liboracle" not in text and "uaes_oracle" not in text, f
     out = subprocess.run(["ldd", uaes.lib_path()], capture_output=True, text=True).stdout
     assert "oracle" not in out
+
+
+def test_bulk_kernels_have_no_private_segment_and_only_gfx950_code():
+    """every grid-wide kernel of the library must run out of registers and LDS alone: a private
+    (scratch) segment -- e.g. from a register array indexed by a run-time value in a one-thread tail
+    case -- makes every wave of the launch set up scratch.  Read from the code objects' metadata
+    (tools/kernel_resources.py); the same pass checks that only gfx950 code objects are shipped."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources
+    ks = kernel_resources.kernels()
+    assert len(ks) > 100
+    bulk = re.compile(r"\bk_(ecb|ctr|ctr_shared2|xts|xts_tweaks|xts_expand|xts_cts|fb_dec|chain_batch|gcm_fused|"
+                      r"ghash_pass|gcm_chunks|ocb|wipe_if_failed)\b")
+    seen = set()
+    for k in ks:
+        m = bulk.search(k["name"])
+        if not m:
+            continue
+        seen.add(m.group(1))
+        assert k["scratch"] == 0 and k["vgpr_spill"] == 0, (k["name"][:80], k["scratch"], k["vgpr_spill"])
+        assert k["vgpr"] <= 128, (k["name"][:80], k["vgpr"])          # 4 waves per SIMD at least
+    assert {"ecb", "ctr", "ctr_shared2", "xts", "fb_dec", "chain_batch", "gcm_fused", "ghash_pass", "gcm_chunks", "ocb"} <= seen
