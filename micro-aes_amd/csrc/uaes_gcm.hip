@@ -1550,19 +1550,23 @@ static int gcm_body(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk
             /* the fused kernel leaves the tail alone (h1 = nfull, no ragged bytes) */
             rc = launch_fused_nr<true>(nr, st, tb, ek, &c, in, out, (unsigned)cus, g_lo, n8, nfull, nfull, 0,
                                        front, ablk + h0, sc);
-            if (rc) return rc;
+            if (rc) return rc;                          /* nothing has been written yet */
+            /* from here on `out` holds plaintext nobody has authenticated: if anything below cannot be
+             * enqueued, the conditional wipe would never run -- wipe unconditionally instead (N7) */
             rc = run_ghash_levels(st, fin, nvf, plf, sc, 1, (unsigned char *)in + len, status);
-            if (rc) return rc;
-            if (len > h1 * 16) {
+            if (!rc && len > h1 * 16) {
                 uaesk_ctr ct = c;
                 ct.v0 = (c.v0 + h1) & 0x00FFFFFFFFFFFFFFull;
                 rc = uaesk_ctr_xcrypt(stream, tb, nr, ek, &ct, (const unsigned char *)in + h1 * 16,
                                       (unsigned char *)out + h1 * 16, len - h1 * 16, status);
-                if (rc) return rc;
             }
-            hipLaunchKernelGGL(k_wipe_if_failed, dim3((unsigned)cus * 2u), dim3(1024), 0, st, status,
-                               (unsigned char *)out, (u64)len);
-            return (int)hipGetLastError();
+            if (!rc) {
+                hipLaunchKernelGGL(k_wipe_if_failed, dim3((unsigned)cus * 2u), dim3(1024), 0, st, status,
+                                   (unsigned char *)out, (u64)len);
+                rc = (int)hipGetLastError();
+            }
+            if (rc) (void)hipMemsetAsync(out, 0, len, st);
+            return rc;
         }
     }
 
@@ -1602,12 +1606,15 @@ static int gcm_body(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk
         case 14: rc = launch_medium<14>(st, tb, ek, &c, j0, sm, in, out, sc, W, build, decrypt, tagp, status); break;
         default: return (int)hipErrorInvalidValue;
         }
+        if (rc && decrypt == 2) (void)hipMemsetAsync(out, 0, len, st);   /* the chunk kernel may have been enqueued: see above */
         if (rc || !decrypt) return rc;
         if (decrypt == 1) return uaesk_ctr_xcrypt(stream, tb, nr, ek, &c, in, out, len, status);
         int cus = 0;
         if (uaesk_device_info(&cus, nullptr) != 0 || cus <= 0) cus = 64;
         hipLaunchKernelGGL(k_wipe_if_failed, dim3((unsigned)cus * 2u), dim3(1024), 0, st, status, (unsigned char *)out, (u64)len);
-        return (int)hipGetLastError();
+        rc = (int)hipGetLastError();
+        if (rc) (void)hipMemsetAsync(out, 0, len, st);
+        return rc;
     }
     if (keyed && pl.logA == 0) {               /* every table this text needs is in the key context */
         switch (nr) {
