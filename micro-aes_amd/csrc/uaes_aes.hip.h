@@ -250,6 +250,15 @@ __device__ __forceinline__ void issue16(const u32 (&s)[4], u32 (&t)[16], const L
             t[4 * c + 2] = tlook<0, 2>(cc, lc); t[4 * c + 3] = tlook<0, 3>(d, lc);
         }
     }
+#ifdef UAES_ISSUE_INTERLEAVE
+    /* experiment: force (address, ds_read) pairs instead of the compiler's 16 address
+     * computations followed by 16 reads; UAES_ISSUE_INTERLEAVE = VALU and DS instructions per group     */
+#pragma unroll
+    for (int i = 0; i < 16 / UAES_ISSUE_INTERLEAVE; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x002, UAES_ISSUE_INTERLEAVE, 0);   /* VALU    */
+        __builtin_amdgcn_sched_group_barrier(0x100, UAES_ISSUE_INTERLEAVE, 0);   /* DS read */
+    }
+#endif
 }
 
 /* Si[x0] | Si[x1] << 16 (bytes 1 and 3 are junk) from the Td0 words of x0 and x1:
