@@ -529,4 +529,176 @@ __device__ __forceinline__ void quad_encrypt(u32 (&t)[4], const uaesk_rk &rk, co
     t[0] = quad_perm<0x00>(n); t[1] = quad_perm<0x55>(n); t[2] = quad_perm<0xAA>(n); t[3] = quad_perm<0xFF>(n);
 }
 
+
+/* ---- one block at a time, SIXTEEN lanes per block (the serial chains, round 3) ------------
+ * quad_encrypt above issues 14 instructions per round from one wave (key word, 4 addresses, 4 lookups,
+ * 2 XORs, 3 DPP moves) and a lone wave issues one instruction every ~8 cycles: 170 cycles per round of which
+ * only ~50 are the LDS round trip.  Here lane i of every 16-lane DPP row owns state byte i (column i/4, row
+ * i%4): a round is ONE lookup per lane and four VALU instructions,
+ *     t = T_r[byte]                             lane (c,r) looks its byte up in the table of its row
+ *     y = t ^ row_ror:11(t);  z = y ^ row_ror:6(y)
+ *                                               lane 4c' now holds t[4c'] ^ t[4c'+5] ^ t[4c'+10] ^ t[4c'+15] (mod 16):
+ *                                               rows 0..3 of columns c', c'+1, c'+2, c'+3 = ShiftRows + MixColumns
+ *                                               of output column c' (the other lanes hold sums nobody needs)
+ *     w = key[c] ^ quad_perm:[0,0,0,0](z)       the column word, in all four lanes of quad c
+ *     address = v_perm(w, lane constant)        byte r of the word -> bits 8..15
+ * so the chain is  ds_read -> 3 DPP XORs -> v_perm -> ds_read.  The four rows of the wave run the same block
+ * redundantly (identical addresses broadcast).  Between blocks the state stays a COLUMN WORD per lane; the
+ * chains XOR the next text column in (one more instruction) without ever assembling a 16-byte block.
+ *
+ * Tables: entry x at x*256; bytes 0..63 = (Te0,Te1,Te2,Te3)[x] four times (slot i = lane i of the row reads
+ * T_(i%4): bank i), bytes 64..127 = (Te2,Te3,Te0,Te1)[x] four times (last round: S[x] sits in byte r of
+ * Te_(r+2), bank 16+i).  32 KiB of stores; the round keys follow at 64 KiB.                          */
+#define UAES_LDS_ROW   (65536u + 256u)
+
+template <int NR>
+struct RowLane {
+    u32 tmain, tlast;     /* address byte 0 for the main / last-round table                         */
+    u32 sel;              /* v_perm selector: byte r of the column word -> bits 8..15                */
+    u32 lsel;             /* v_perm selector keeping byte r of the last-round lookup, zeros elsewhere */
+    u32 c;                /* this lane's column                                                      */
+    u32 kc[NR + 1];       /* this lane's column of every round key                                   */
+};
+
+__device__ __forceinline__ void row_fill_tables(const u32 *__restrict__ te0, const uaesk_rk &rk)
+{
+    for (u32 x = threadIdx.x; x < 256u; x += blockDim.x) {
+        const u32 t0 = te0[x], t1 = rotl32(t0, 8), t2 = rotl32(t0, 16), t3 = rotl32(t0, 24);
+        const uint4 m = make_uint4(t0, t1, t2, t3), l = make_uint4(t2, t3, t0, t1);
+        uint4 *d = (uint4 *)(uaes_lds + x * 256u);
+        d[0] = m; d[1] = m; d[2] = m; d[3] = m;
+        d[4] = l; d[5] = l; d[6] = l; d[7] = l;
+    }
+    for (u32 i = threadIdx.x; i < 60u; i += blockDim.x) ((u32 *)(uaes_lds + 65536u))[i] = rk.w[i];
+    __syncthreads();
+}
+
+template <int NR>
+__device__ __forceinline__ RowLane<NR> row_lane()
+{
+    RowLane<NR> L;
+    const u32 i = threadIdx.x & 15u, r = i & 3u;
+    L.c = i >> 2;
+    L.tmain = 4u * i;
+    L.tlast = 64u + 4u * i;
+    L.sel = 0x0c020000u | ((4u + r) << 8);
+    L.lsel = (0x0c0c0c0cu & ~(0xffu << (8u * r))) | ((4u + r) << (8u * r));
+#pragma unroll
+    for (int j = 0; j <= NR; ++j) L.kc[j] = lds_word(65536u + 16u * (u32)j + 4u * L.c);
+    return L;
+}
+
+template <int CTRL>
+__device__ __forceinline__ u32 row_dpp(u32 v)
+{
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+
+/* w = this lane's column word of the block (no round key applied) -> the same of its encryption */
+template <int NR>
+__device__ __forceinline__ u32 row_encrypt(u32 w, const RowLane<NR> &L)
+{
+    w ^= L.kc[0];
+    u32 addr = __builtin_amdgcn_perm(w, L.tmain, L.sel);
+#pragma unroll
+    for (int r = 1; r <= NR; ++r) {
+        u32 t = lds_word(addr);
+        if (r == NR) t = __builtin_amdgcn_perm(t, 0u, L.lsel);
+        const u32 y = t ^ row_dpp<0x12B>(t);          /* row_ror:11 = take lane i+5  */
+        const u32 z = y ^ row_dpp<0x126>(y);          /* row_ror:6  = take lane i+10 */
+        w = L.kc[r] ^ row_dpp<0x00>(z);               /* quad_perm:[0,0,0,0]         */
+        if (r < NR) addr = __builtin_amdgcn_perm(w, r + 1 < NR ? L.tmain : L.tlast, L.sel);
+    }
+    return w;
+}
+
+/* the column word of lane column c from a block every lane holds / back to such a block */
+__device__ __forceinline__ u32 row_pick(const u32 (&b)[4], u32 c)
+{
+    return c == 0 ? b[0] : c == 1 ? b[1] : c == 2 ? b[2] : b[3];
+}
+
+__device__ __forceinline__ void row_spread(u32 w, u32 (&b)[4])
+{
+    b[0] = (u32)__builtin_amdgcn_readlane((int)w, 0);  b[1] = (u32)__builtin_amdgcn_readlane((int)w, 4);
+    b[2] = (u32)__builtin_amdgcn_readlane((int)w, 8);  b[3] = (u32)__builtin_amdgcn_readlane((int)w, 12);
+}
+
+/* this lane's column word of the 16 bytes at p, zero padded after `avail` bytes */
+__device__ __forceinline__ u32 row_load(const unsigned char *p, u64 avail, u32 c)
+{
+    if (avail >= 16 && (((uintptr_t)p) & 3u) == 0) return ((const u32 *)p)[c];
+    u32 v = 0;
+#pragma unroll
+    for (u32 k = 0; k < 4; ++k)
+        if (4u * c + k < avail) v |= (u32)p[4u * c + k] << (8u * k);
+    return v;
+}
+
+/* the first nbytes of the block whose column words the lanes hold -> p (lanes 0, 4, 8, 12 store) */
+__device__ __forceinline__ void row_store(unsigned char *p, u32 w, u32 nbytes)
+{
+    if (threadIdx.x >= 16u || (threadIdx.x & 3u)) return;
+    const u32 c = threadIdx.x >> 2;
+    if (nbytes >= 16 && (((uintptr_t)p) & 3u) == 0) { ((u32 *)p)[c] = w; return; }
+#pragma unroll
+    for (u32 k = 0; k < 4; ++k)
+        if (4u * c + k < nbytes) p[4u * c + k] = (unsigned char)(w >> (8u * k));
+}
+
+/* full blocks inside the chain loops: the alignment is decided once per message (A4 = both pointers
+ * 4-byte aligned), so that the loop body is straight-line code -- a load behind a branch makes the
+ * compiler wait for it (s_waitcnt vmcnt(0)) right where it was issued, and the chain then pays the
+ * memory latency of every block.  With A4 every lane stores its column word (the four lanes of a
+ * quad and the four rows write the same dword with the same value): no exec masking in the loop.   */
+template <bool A4>
+__device__ __forceinline__ u32 row_load_full(const unsigned char *p, u32 c)
+{
+    if (A4) return ((const u32 *)p)[c];
+    const unsigned char *q = p + 4u * c;
+    return (u32)q[0] | ((u32)q[1] << 8) | ((u32)q[2] << 16) | ((u32)q[3] << 24);
+}
+
+template <bool A4>
+__device__ __forceinline__ void row_store_full(unsigned char *p, u32 w, u32 c)
+{
+    if (A4) { ((u32 *)p)[c] = w; return; }
+    unsigned char *q = p + 4u * c;
+    q[0] = (unsigned char)w; q[1] = (unsigned char)(w >> 8); q[2] = (unsigned char)(w >> 16); q[3] = (unsigned char)(w >> 24);
+}
+
+/* f(i, x): the full 16-byte blocks i = 0..nblk-1 at p as column words x.  The text is requested a whole
+ * chunk of ROW_CH blocks ahead: the loads of chunk k+1 are issued before the chain walks chunk k and are
+ * first touched when it is done (~16 us later), so whatever s_waitcnt vmcnt the compiler places inside a
+ * chunk finds them complete -- with a four-block register ring it waited for the newest load in the middle
+ * of every fourth block (a register copy the allocator put there) and the chain paid the memory latency.
+ * Indices past the end are clamped, not branched around.                                              */
+#define ROW_CH 16
+template <bool A4, typename F>
+__device__ __forceinline__ void row_walk(const unsigned char *p, u64 nblk, u32 c, F f)
+{
+    if (nblk == 0) return;
+    const u64 last = nblk - 1;
+    u32 cur[ROW_CH], nxt[ROW_CH];
+#pragma unroll
+    for (u32 j = 0; j < ROW_CH; ++j) cur[j] = row_load_full<A4>(p + 16u * (j < last ? j : last), c);
+    for (u64 i = 0; i < nblk; i += ROW_CH) {
+#pragma unroll
+        for (u32 j = 0; j < ROW_CH; ++j) {
+            const u64 nx = i + ROW_CH + j;
+            nxt[j] = row_load_full<A4>(p + 16u * (nx < last ? nx : last), c);
+        }
+        if (i + ROW_CH <= nblk) {
+#pragma unroll
+            for (u32 j = 0; j < ROW_CH; ++j) f(i + j, cur[j]);
+        } else {
+#pragma unroll
+            for (u32 j = 0; j < ROW_CH; ++j)
+                if (i + j < nblk) f(i + j, cur[j]);
+        }
+#pragma unroll
+        for (u32 j = 0; j < ROW_CH; ++j) cur[j] = nxt[j];
+    }
+}
+
 #endif

@@ -18,6 +18,7 @@
  * in == out (the reference itself works in place, serially).
  */
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <string.h>
 #include "uaes_aes.hip.h"
 #include "uaes_device.h"
@@ -199,66 +200,64 @@ __global__ __launch_bounds__(UAES_WG) void k_chain_serial(uaesk_rk rk, uaesk_tab
                                                           const unsigned char *in,
                                                           unsigned char *out, u64 len)
 {
-    /* encrypt-direction chains: ONE wave, all 64 lanes run the chain redundantly (a quad shares
-     * each block encryption), lane 0 stores.  The two-block CTS decrypt keeps the one-lane
-     * inverse cipher on the full tables (launched with 1024 threads to fill them).          */
-    LaneConst lc;
+    /* encrypt-direction chains: ONE wave; the sixteen lanes of a DPP row share each block encryption
+     * (row_encrypt, uaes_aes.hip.h: one state byte and one lookup per lane and round), the four rows run
+     * redundantly, the chain value stays a column word per lane and lanes 0/4/8/12 store.  The two-block CTS
+     * decrypt keeps the one-lane inverse cipher on the full tables (launched with 1024 threads to fill them). */
     if (OP == CH_CBC_DEC_CTS) {
         fill_dec_tables(tb.td0);
         if (threadIdx.x != 0) return;
-        lc = make_lane_const();
-    } else {
-        quad_fill_tables(tb.te0, rk);
-        lc = quad_lane_const();
+        const LaneConst lc = make_lane_const();
+        if (iv_dev) iv4 = *iv_dev;
+        const Blk iv = { { iv4.x, iv4.y, iv4.z, iv4.w } };
+        cbc_dec_cts_pair<NR>(rk, lc, iv, in, out, (u32)len);      /* rk = decryption keys */
+        return;
     }
+    row_fill_tables(tb.te0, rk);
+    const RowLane<NR> L = row_lane<NR>();
     if (iv_dev) iv4 = *iv_dev;
-    Blk iv = { { iv4.x, iv4.y, iv4.z, iv4.w } };
+    const u32 ivw[4] = { iv4.x, iv4.y, iv4.z, iv4.w };
+    u32 m = row_pick(ivw, L.c);                               /* the chain value: this lane's column */
 
-    if (OP == CH_CBC_ENC) {
-        u64 n = len / 16;
-        u32 r = (u32)(len % 16);
-        if (n > 1 && !r) { --n; r = 16; }                 /* CS3: always swap the last two (:706) */
-        for (u64 i = 0; i < n; ++i) {
-            Blk b = ldb(in + 16 * i, 16);
-            xb(b, iv);
-            encb<NR>(b, rk, lc);
-            stb(out + 16 * i, b, 16);
-            iv = b;
+    const bool a4 = ((((uintptr_t)in) | ((uintptr_t)out)) & 3u) == 0;
+    auto body = [&](auto A4T) {
+        constexpr bool A4 = decltype(A4T)::value;
+        if (OP == CH_CBC_ENC) {
+            u64 n = len / 16;
+            u32 r = (u32)(len % 16);
+            if (n > 1 && !r) { --n; r = 16; }                 /* CS3: always swap the last two (:706) */
+            /* the last (short or swapped) chunk, zero padded; read before anything is written (in place) */
+            const u32 l0 = r ? row_load(in + 16 * n, r, L.c) : 0u;
+            row_walk<A4>(in, n, L.c, [&](u64 i, u32 x) {
+                m = row_encrypt<NR>(m ^ x, L);
+                row_store_full<A4>(out + 16 * i, m, L.c);
+            });
+            if (r) {                                          /* m == C_{n-1} here */
+                row_store(out + 16 * n, m, r);                /* its place takes the head of C_{n-1} ("stolen") */
+                m = row_encrypt<NR>(m ^ l0, L);
+                row_store(out + 16 * (n - 1), m, 16);
+            }
+        } else if (OP == CH_CFB_ENC) {
+            const u64 n = len / 16;
+            const u32 r = (u32)(len % 16);
+            const u32 l0 = r ? row_load(in + 16 * n, r, L.c) : 0u;
+            row_walk<A4>(in, n, L.c, [&](u64 i, u32 x) {
+                m = row_encrypt<NR>(m, L) ^ x;                /* C_i = Enc(C_{i-1}) ^ P_i = next feedback */
+                row_store_full<A4>(out + 16 * i, m, L.c);
+            });
+            if (r) row_store(out + 16 * n, row_encrypt<NR>(m, L) ^ l0, r);
+        } else {                                              /* CH_OFB */
+            const u64 n = len / 16;
+            const u32 r = (u32)(len % 16);
+            const u32 l0 = r ? row_load(in + 16 * n, r, L.c) : 0u;
+            row_walk<A4>(in, n, L.c, [&](u64 i, u32 x) {
+                m = row_encrypt<NR>(m, L);                    /* O_i = Enc(O_{i-1}) */
+                row_store_full<A4>(out + 16 * i, m ^ x, L.c);
+            });
+            if (r) row_store(out + 16 * n, row_encrypt<NR>(m, L) ^ l0, r);
         }
-        if (r) {                                          /* iv == C_{n-1} here */
-            Blk l = ldb(in + 16 * n, r);                  /* the last (short or swapped) chunk, zero padded */
-            stb(out + 16 * n, iv, r);                     /* its place takes the head of C_{n-1} ("stolen") */
-            xb(l, iv);
-            encb<NR>(l, rk, lc);
-            stb(out + 16 * (n - 1), l, 16);
-        }
-    } else if (OP == CH_CFB_ENC) {
-        const u64 n = len / 16;
-        const u32 r = (u32)(len % 16);
-        for (u64 i = 0; i < n; ++i) {
-            encb<NR>(iv, rk, lc);
-            const Blk b = ldb(in + 16 * i, 16);
-            xb(iv, b);                                    /* C_i = Enc(C_{i-1}) ^ P_i = next feedback */
-            stb(out + 16 * i, iv, 16);
-        }
-        if (r) {
-            encb<NR>(iv, rk, lc);
-            const Blk b = ldb(in + 16 * n, r);
-            xb(iv, b);
-            stb(out + 16 * n, iv, r);
-        }
-    } else if (OP == CH_OFB) {
-        const u64 n = (len + 15) / 16;
-        for (u64 i = 0; i < n; ++i) {
-            const u32 take = (len - 16 * i) < 16 ? (u32)(len - 16 * i) : 16u;
-            encb<NR>(iv, rk, lc);                          /* O_i = Enc(O_{i-1}) */
-            Blk b = ldb(in + 16 * i, take);
-            xb(b, iv);
-            stb(out + 16 * i, b, take);
-        }
-    } else {                                              /* CH_CBC_DEC_CTS; rk = decryption keys */
-        cbc_dec_cts_pair<NR>(rk, lc, iv, in, out, (u32)len);
-    }
+    };
+    if (a4) body(std::true_type{}); else body(std::false_type{});
 }
 
 /* ------------------------------------------------------------------------ */
@@ -375,7 +374,7 @@ template <int NR, int OP>
 static int launch_serial(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *k, uint4 iv,
                          const void *in, void *out, u64 len, const uint4 *iv_dev = nullptr)
 {
-    const unsigned lds = OP == CH_CBC_DEC_CTS ? UAES_LDS_DEC : UAES_LDS_QUAD;
+    const unsigned lds = OP == CH_CBC_DEC_CTS ? UAES_LDS_DEC : UAES_LDS_ROW;
     const unsigned threads = OP == CH_CBC_DEC_CTS ? UAES_WG : 64u;
     hipError_t e = hipFuncSetAttribute((const void *)k_chain_serial<NR, OP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;

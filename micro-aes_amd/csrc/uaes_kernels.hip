@@ -514,6 +514,15 @@ __global__ __launch_bounds__(UAES_WG) void k_selftest(uaesk_rk ek, uaesk_rk dk, 
     for (u32 i = 0; i < 64; ++i) a = tw_mul_pow(a, 1);
     b = tw_mul_pow64(t);
     if (a.lo != b.lo || a.hi != b.hi) bad |= 128;
+    /* sixteen lanes per block (row_encrypt: DPP row_ror / quad_perm directions, table slots) */
+    __syncthreads();
+    row_fill_tables(tb.te0, ek);
+    {
+        const RowLane<10> L = row_lane<10>();
+        const u32 pt[4] = { 0x33221100u, 0x77665544u, 0xbbaa9988u, 0xffeeddccu };
+        const u32 ct[4] = { 0xd8e0c469u, 0x30047b6au, 0x80b7cdd8u, 0x5ac5b470u };
+        if (row_encrypt<10>(row_pick(pt, L.c), L) != row_pick(ct, L.c)) bad |= 2048;
+    }
     if (bad) atomicOr(result, bad);
 }
 

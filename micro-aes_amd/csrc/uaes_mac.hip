@@ -8,8 +8,8 @@
  *                 the CTR half is k_ctr with the CCM/GCM pre-increment)
  *
  * A CBC-MAC is a strictly serial chain (M <- Enc(M ^ X_i)): what counts is the latency
- * of one block.  One wave walks the message; the four lanes of a quad share each block
- * encryption (quad_encrypt, uaes_aes.hip.h: one output column per lane, DPP exchange).
+ * of one block.  One wave walks the message; the sixteen lanes of a DPP row share each block
+ * encryption (row_encrypt, uaes_aes.hip.h: one state byte per lane, DPP reduction).
  * Independent messages belong in the batched entry points (uaes_chain.hip), one lane each.
  */
 #include <hip/hip_runtime.h>
@@ -37,14 +37,6 @@ __device__ __forceinline__ Blk ld_block(const unsigned char *p, u64 avail)
     return b;
 }
 
-/* one block, shared by the four lanes of a quad (quad_encrypt, uaes_aes.hip.h); every lane of
- * the wave holds the same block before and after                                          */
-template <int NR>
-__device__ __forceinline__ void enc1(Blk &b, const uaesk_rk &rk, const LaneConst &lc)
-{
-    quad_encrypt<NR>(b.w, rk, lc);
-}
-
 /* big-endian doubling in GF(2^128) (doubleBblock): <<1, carry -> ^0x87 in the last byte */
 __device__ __forceinline__ Blk dbl_be(Blk b)
 {
@@ -70,16 +62,23 @@ __device__ __forceinline__ void st_bytes(unsigned char *dst, const Blk &b)
     for (u32 i = 0; i < 16; ++i) dst[i] = (unsigned char)(b.w[i >> 2] >> (8 * (i & 3)));
 }
 
-/* M <- Enc(M ^ X_i) over the zero-padded 16-byte blocks of [p, p+len)   (xMac :551-570) */
+/* M <- Enc(M ^ X_i) over the zero-padded 16-byte blocks of [p, p+len)   (xMac :551-570);
+ * m = this lane's column word of M (row_encrypt, uaes_aes.hip.h: sixteen lanes per block) */
 template <int NR>
-__device__ __forceinline__ void cbcmac_absorb(Blk &m, const unsigned char *p, u64 len,
-                                              const uaesk_rk &rk, const LaneConst &lc)
+__device__ __forceinline__ void cbcmac_absorb(u32 &m, const unsigned char *p, u64 len, const RowLane<NR> &L)
 {
-    for (u64 off = 0; off < len; off += 16) {
-        const Blk x = ld_block(p + off, len - off);
-        xor_blk(m, x);
-        enc1<NR>(m, rk, lc);
-    }
+    if ((((uintptr_t)p) & 3u) == 0)
+        row_walk<true>(p, len / 16, L.c, [&](u64, u32 x) { m = row_encrypt<NR>(m ^ x, L); });
+    else
+        row_walk<false>(p, len / 16, L.c, [&](u64, u32 x) { m = row_encrypt<NR>(m ^ x, L); });
+    if (len % 16) m = row_encrypt<NR>(m ^ row_load(p + (len & ~(u64)15), len % 16, L.c), L);
+}
+
+/* a block every lane holds -> its encryption, likewise (the few odd blocks of a MAC: L, B0, Enc(iv)) */
+template <int NR>
+__device__ __forceinline__ void enc1(Blk &b, const RowLane<NR> &L)
+{
+    row_spread(row_encrypt<NR>(row_pick(b.w, L.c), L), b.w);
 }
 
 template <int NR>
@@ -87,15 +86,15 @@ __global__ __launch_bounds__(64) void k_cmac(uaesk_rk rk, uaesk_tables tb,
                                                   const unsigned char *__restrict__ data, u64 len,
                                                   unsigned char *__restrict__ mac)
 {
-    quad_fill_tables(tb.te0, rk);                /* one wave: all lanes run the chain, a quad per block */
-    const LaneConst lc = quad_lane_const();
+    row_fill_tables(tb.te0, rk);                 /* one wave: sixteen lanes per block, four rows redundantly */
+    const RowLane<NR> L = row_lane<NR>();
     Blk k1 = { { 0, 0, 0, 0 } };
-    enc1<NR>(k1, rk, lc);                        /* L = Enc(0)                   */
+    enc1<NR>(k1, L);                             /* L = Enc(0)                   */
     k1 = dbl_be(k1);                             /* K1 = 2L                      */
     const Blk k2 = dbl_be(k1);                   /* K2 = 4L                      */
     const u32 s = len ? (u32)((len - 1) % 16) + 1 : 0;      /* size of the last block */
-    Blk m = { { 0, 0, 0, 0 } };
-    cbcmac_absorb<NR>(m, data, len - s, rk, lc);
+    u32 m = 0;
+    cbcmac_absorb<NR>(m, data, len - s, L);
     Blk last = ld_block(data + (len - s), s);
     if (s < 16) {
         last.w[s >> 2] ^= 0x80u << (8 * (s & 3));            /* 10* padding, then K2 */
@@ -103,9 +102,8 @@ __global__ __launch_bounds__(64) void k_cmac(uaesk_rk rk, uaesk_tables tb,
     } else {
         xor_blk(last, k1);
     }
-    xor_blk(m, last);
-    enc1<NR>(m, rk, lc);
-    st_bytes(mac, m);
+    m = row_encrypt<NR>(m ^ row_pick(last.w, L.c), L);
+    row_store(mac, m, 16);
 }
 
 /* mode 0: write the tag to tag_io; mode 1: compare with tag_io, *status = 0 / 0x1A */
@@ -115,8 +113,8 @@ __global__ __launch_bounds__(64) void k_ccm_tag(uaesk_rk rk, uaesk_tables tb, ui
                                                      const unsigned char *__restrict__ pt, u64 pt_len,
                                                      int mode, unsigned char *tag_io, int *status)
 {
-    quad_fill_tables(tb.te0, rk);                /* one wave: all lanes run the chain, a quad per block */
-    const LaneConst lc = quad_lane_const();
+    row_fill_tables(tb.te0, rk);                 /* one wave: sixteen lanes per block, four rows redundantly */
+    const RowLane<NR> L = row_lane<NR>();
     const Blk iv = { { iv4.x, iv4.y, iv4.z, iv4.w } };
     unsigned char b0[16], a[16];
     for (u32 i = 0; i < 16; ++i) b0[i] = (unsigned char)(iv.w[i >> 2] >> (8 * (i & 3)));
@@ -128,11 +126,11 @@ __global__ __launch_bounds__(64) void k_ccm_tag(uaesk_rk rk, uaesk_tables tb, ui
     }
     for (int i = 0; i < 16; ++i) a[i] = 0;
     u64 s = 0;
-    Blk m;
+    Blk mb;
     if (aad_len) {
         b0[0] |= 0x40;
-        m = ld_block(b0, 16);
-        enc1<NR>(m, rk, lc);
+        mb = ld_block(b0, 16);
+        enc1<NR>(mb, L);
         int p = 1;
         if (aad_len > 0xFEFFull) { p += 4; a[0] = 0xFF; a[1] = 0xFE; }
         {
@@ -145,24 +143,26 @@ __global__ __launch_bounds__(64) void k_ccm_tag(uaesk_rk rk, uaesk_tables tb, ui
         const u64 take = aad_len < s ? aad_len : s;
         for (u64 i = 0; i < take; ++i) a[p + i] = aad[i];
     } else {
-        m = ld_block(b0, 16);
+        mb = ld_block(b0, 16);
     }
     {
         const Blk ab = ld_block(a, 16);                   /* xMac(A, 16): also encrypts B0 when there is no AAD */
-        xor_blk(m, ab);
-        enc1<NR>(m, rk, lc);
+        xor_blk(mb, ab);
     }
-    if (aad_len > s) cbcmac_absorb<NR>(m, aad + s, aad_len - s, rk, lc);
-    cbcmac_absorb<NR>(m, pt, pt_len, rk, lc);
-    Blk e = iv;
-    enc1<NR>(e, rk, lc);                                  /* tag = Enc(iv) ^ CBC-MAC           */
-    xor_blk(m, e);
+    u32 m = row_encrypt<NR>(row_pick(mb.w, L.c), L);
+    if (aad_len > s) cbcmac_absorb<NR>(m, aad + s, aad_len - s, L);
+    cbcmac_absorb<NR>(m, pt, pt_len, L);
+    m ^= row_encrypt<NR>(row_pick(iv.w, L.c), L);         /* tag = Enc(iv) ^ CBC-MAC           */
     if (mode == 0) {
-        st_bytes(tag_io, m);
-    } else if (threadIdx.x == 0) {
-        u32 diff = 0;
-        for (u32 i = 0; i < 16; ++i) diff |= (u32)tag_io[i] ^ ((m.w[i >> 2] >> (8 * (i & 3))) & 0xffu);
-        *status = diff ? 0x1A : 0;
+        row_store(tag_io, m, 16);
+    } else {
+        Blk t;
+        row_spread(m, t.w);
+        if (threadIdx.x == 0) {
+            u32 diff = 0;
+            for (u32 i = 0; i < 16; ++i) diff |= (u32)tag_io[i] ^ ((t.w[i >> 2] >> (8 * (i & 3))) & 0xffu);
+            *status = diff ? 0x1A : 0;
+        }
     }
 }
 
@@ -178,9 +178,9 @@ template <int NR>
 static int launch_cmac(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek,
                        const void *data, size_t len, void *mac)
 {
-    hipError_t e = hipFuncSetAttribute((const void *)k_cmac<NR>, hipFuncAttributeMaxDynamicSharedMemorySize, UAES_LDS_QUAD);
+    hipError_t e = hipFuncSetAttribute((const void *)k_cmac<NR>, hipFuncAttributeMaxDynamicSharedMemorySize, UAES_LDS_ROW);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((k_cmac<NR>), dim3(1), dim3(64), UAES_LDS_QUAD, st, *ek, *tb,
+    hipLaunchKernelGGL((k_cmac<NR>), dim3(1), dim3(64), UAES_LDS_ROW, st, *ek, *tb,
                        (const unsigned char *)data, (u64)len, (unsigned char *)mac);
     return (int)hipGetLastError();
 }
@@ -197,9 +197,9 @@ static int launch_ccm_tag(hipStream_t st, const uaesk_tables *tb, const uaesk_rk
                           const void *aad, size_t aad_len, const void *pt, size_t pt_len,
                           int mode, void *tag_io, int *status)
 {
-    hipError_t e = hipFuncSetAttribute((const void *)k_ccm_tag<NR>, hipFuncAttributeMaxDynamicSharedMemorySize, UAES_LDS_QUAD);
+    hipError_t e = hipFuncSetAttribute((const void *)k_ccm_tag<NR>, hipFuncAttributeMaxDynamicSharedMemorySize, UAES_LDS_ROW);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((k_ccm_tag<NR>), dim3(1), dim3(64), UAES_LDS_QUAD, st, *ek, *tb, iv,
+    hipLaunchKernelGGL((k_ccm_tag<NR>), dim3(1), dim3(64), UAES_LDS_ROW, st, *ek, *tb, iv,
                        (const unsigned char *)aad, (u64)aad_len, (const unsigned char *)pt, (u64)pt_len,
                        mode, (unsigned char *)tag_io, status);
     return (int)hipGetLastError();
