@@ -59,18 +59,32 @@
 #define PRESET_COUNTER  0   /* whole 16-byte counter block instead of a 12-byte IV (micro_aes.c:965-966)     */
 #endif
 
+/* The reference fixes these lengths as enum constants that a user edits in its header (micro_aes.h:103-116).  Here a
+ * caller built with -DCCM_NONCE_LEN=n (7..13), -DCCM_TAG_LEN=n (even, 4..16), -DGCM_NONCE_LEN=n (>= 1),
+ * -DGCM_TAG_LEN=n (1..16), -DOCB_NONCE_LEN=n (1..15) or -DOCB_TAG_LEN=n (1..16) gets that build: the macro stands in
+ * for the enum constant and the AES_CCM_* / AES_GCM_* / AES_OCB_* names bind to the general entry points below.    */
 enum constant_parameters_of_modes
 {
     CTR_START_VALUE = 1,
     CTR_IV_LENGTH   = 12,
+#ifndef CCM_NONCE_LEN
     CCM_NONCE_LEN   = 11,
+#endif
+#ifndef CCM_TAG_LEN
     CCM_TAG_LEN     = 16,
-#ifndef GCM_NONCE_LEN      /* micro_aes.h:108; a caller built with -DGCM_NONCE_LEN=n gets J0 = GHASH(nonce) (see below) */
+#endif
+#ifndef GCM_NONCE_LEN      /* micro_aes.h:108; any value but 12: J0 = GHASH(nonce) (micro_aes.c:1145-1149) */
     GCM_NONCE_LEN   = 12,
 #endif
+#ifndef GCM_TAG_LEN
     GCM_TAG_LEN     = 16,
+#endif
+#ifndef OCB_NONCE_LEN
     OCB_NONCE_LEN   = 12,
+#endif
+#ifndef OCB_TAG_LEN
     OCB_TAG_LEN     = 16,
+#endif
     SIVGCM_NONCE_LEN = 12,
     SIVGCM_TAG_LEN  = 16,
 #if AES___ == 256 || AES___ == 192
@@ -79,6 +93,10 @@ enum constant_parameters_of_modes
     AES_KEYLENGTH   = 16
 #endif
 };
+typedef char uaes_ccm_lengths_ok[(CCM_NONCE_LEN >= 7 && CCM_NONCE_LEN <= 13 && CCM_TAG_LEN >= 4 && CCM_TAG_LEN <= 16 &&
+                                  CCM_TAG_LEN % 2 == 0) ? 1 : -1];
+typedef char uaes_gcm_lengths_ok[(GCM_NONCE_LEN >= 1 && GCM_TAG_LEN >= 1 && GCM_TAG_LEN <= 16) ? 1 : -1];
+typedef char uaes_ocb_lengths_ok[(OCB_NONCE_LEN >= 1 && OCB_NONCE_LEN <= 15 && OCB_TAG_LEN >= 1 && OCB_TAG_LEN <= 16) ? 1 : -1];
 
 #include <stddef.h>
 #include <stdint.h>
@@ -132,18 +150,26 @@ void AES_GCM_encrypt(const uint8_t *key, const uint8_t *nonce,
 char AES_GCM_decrypt(const uint8_t *key, const uint8_t *nonce,
                      const void *aData, const size_t aDataLen,
                      const void *crtxt, const size_t crtxtLen, void *pntxt);
-/* GCM_NONCE_LEN is a compile-time constant of the CALLER's build in the reference; with any value
- * but 12 GCMsetup derives J0 = GHASH(nonce) (micro_aes.c:1145-1149).  Every library exports the
- * general entry points and a caller built with -DGCM_NONCE_LEN=n is bound to them:              */
+/* GCM_NONCE_LEN / GCM_TAG_LEN are compile-time constants of the CALLER's build in the reference; with any nonce
+ * length but 12 GCMsetup derives J0 = GHASH(nonce) (micro_aes.c:1145-1149), and GCM_TAG_LEN bytes of the tag are
+ * appended / compared (:1178, :1204).  Every library exports the general entry points and a caller built with
+ * -DGCM_NONCE_LEN=n and / or -DGCM_TAG_LEN=n is bound to them:                                                */
+void AES_GCM_encrypt_lens(const size_t nonceLen, const size_t tagLen, const uint8_t *key, const uint8_t *nonce,
+                          const void *aData, const size_t aDataLen,
+                          const void *pntxt, const size_t ptextLen, void *crtxt);
+char AES_GCM_decrypt_lens(const size_t nonceLen, const size_t tagLen, const uint8_t *key, const uint8_t *nonce,
+                          const void *aData, const size_t aDataLen,
+                          const void *crtxt, const size_t crtxtLen, void *pntxt);
+/* (the round-2 names: the same with a 16-byte tag) */
 void AES_GCM_encrypt_ivlen(const size_t nonceLen, const uint8_t *key, const uint8_t *nonce,
                            const void *aData, const size_t aDataLen,
                            const void *pntxt, const size_t ptextLen, void *crtxt);
 char AES_GCM_decrypt_ivlen(const size_t nonceLen, const uint8_t *key, const uint8_t *nonce,
                            const void *aData, const size_t aDataLen,
                            const void *crtxt, const size_t crtxtLen, void *pntxt);
-#ifdef GCM_NONCE_LEN
+
 /* real functions behind OBJECT-like macros, so that `&AES_GCM_encrypt` or a dispatch-table entry binds to
- * the nonce length of this build as well as a direct call does                                         */
+ * the lengths of this build as well as a direct call does                                              */
 #if defined(__cplusplus) || (defined(__STDC_VERSION__) && __STDC_VERSION__ >= 199901L)
 #define UAES_STATIC_INLINE static inline
 #elif defined(__GNUC__)
@@ -151,17 +177,18 @@ char AES_GCM_decrypt_ivlen(const size_t nonceLen, const uint8_t *key, const uint
 #else
 #define UAES_STATIC_INLINE static
 #endif
+#if defined(GCM_NONCE_LEN) || defined(GCM_TAG_LEN)
 UAES_STATIC_INLINE void AES_GCM_encrypt_nl(const uint8_t *key, const uint8_t *nonce,
                                            const void *aData, const size_t aDataLen,
                                            const void *pntxt, const size_t ptextLen, void *crtxt)
 {
-    AES_GCM_encrypt_ivlen(GCM_NONCE_LEN, key, nonce, aData, aDataLen, pntxt, ptextLen, crtxt);
+    AES_GCM_encrypt_lens(GCM_NONCE_LEN, GCM_TAG_LEN, key, nonce, aData, aDataLen, pntxt, ptextLen, crtxt);
 }
 UAES_STATIC_INLINE char AES_GCM_decrypt_nl(const uint8_t *key, const uint8_t *nonce,
                                            const void *aData, const size_t aDataLen,
                                            const void *crtxt, const size_t crtxtLen, void *pntxt)
 {
-    return AES_GCM_decrypt_ivlen(GCM_NONCE_LEN, key, nonce, aData, aDataLen, crtxt, crtxtLen, pntxt);
+    return AES_GCM_decrypt_lens(GCM_NONCE_LEN, GCM_TAG_LEN, key, nonce, aData, aDataLen, crtxt, crtxtLen, pntxt);
 }
 #define AES_GCM_encrypt AES_GCM_encrypt_nl
 #define AES_GCM_decrypt AES_GCM_decrypt_nl
@@ -189,12 +216,60 @@ char AES_CCM_decrypt(const uint8_t *key, const uint8_t *nonce,
                      const void *aData, const size_t aDataLen,
                      const void *crtxt, const size_t crtxtLen, void *pntxt);
 
+/* CCM_NONCE_LEN (7..13) / CCM_TAG_LEN (even, 4..16), micro_aes.h:103-104: iv = { 14 - N, nonce, 0.. } (:1273), the
+ * flags byte carries (T - 2) << 2 (:1229), T bytes of tag are appended / compared (:1281, :1308)                 */
+void AES_CCM_encrypt_lens(const size_t nonceLen, const size_t tagLen, const uint8_t *key, const uint8_t *nonce,
+                          const void *aData, const size_t aDataLen,
+                          const void *pntxt, const size_t ptextLen, void *crtxt);
+char AES_CCM_decrypt_lens(const size_t nonceLen, const size_t tagLen, const uint8_t *key, const uint8_t *nonce,
+                          const void *aData, const size_t aDataLen,
+                          const void *crtxt, const size_t crtxtLen, void *pntxt);
+#if defined(CCM_NONCE_LEN) || defined(CCM_TAG_LEN)
+UAES_STATIC_INLINE void AES_CCM_encrypt_nl(const uint8_t *key, const uint8_t *nonce,
+                                           const void *aData, const size_t aDataLen,
+                                           const void *pntxt, const size_t ptextLen, void *crtxt)
+{
+    AES_CCM_encrypt_lens(CCM_NONCE_LEN, CCM_TAG_LEN, key, nonce, aData, aDataLen, pntxt, ptextLen, crtxt);
+}
+UAES_STATIC_INLINE char AES_CCM_decrypt_nl(const uint8_t *key, const uint8_t *nonce,
+                                           const void *aData, const size_t aDataLen,
+                                           const void *crtxt, const size_t crtxtLen, void *pntxt)
+{
+    return AES_CCM_decrypt_lens(CCM_NONCE_LEN, CCM_TAG_LEN, key, nonce, aData, aDataLen, crtxt, crtxtLen, pntxt);
+}
+#define AES_CCM_encrypt AES_CCM_encrypt_nl
+#define AES_CCM_decrypt AES_CCM_decrypt_nl
+#endif
+
 void AES_OCB_encrypt(const uint8_t *key, const uint8_t *nonce,
                      const void *aData, const size_t aDataLen,
                      const void *pntxt, const size_t ptextLen, void *crtxt);
 char AES_OCB_decrypt(const uint8_t *key, const uint8_t *nonce,
                      const void *aData, const size_t aDataLen,
                      const void *crtxt, const size_t crtxtLen, void *pntxt);
+/* OCB_NONCE_LEN (1..15) / OCB_TAG_LEN (1..16), micro_aes.h:115-116: the nonce block of OCB_cipher (:1703-1709) */
+void AES_OCB_encrypt_lens(const size_t nonceLen, const size_t tagLen, const uint8_t *key, const uint8_t *nonce,
+                          const void *aData, const size_t aDataLen,
+                          const void *pntxt, const size_t ptextLen, void *crtxt);
+char AES_OCB_decrypt_lens(const size_t nonceLen, const size_t tagLen, const uint8_t *key, const uint8_t *nonce,
+                          const void *aData, const size_t aDataLen,
+                          const void *crtxt, const size_t crtxtLen, void *pntxt);
+#if defined(OCB_NONCE_LEN) || defined(OCB_TAG_LEN)
+UAES_STATIC_INLINE void AES_OCB_encrypt_nl(const uint8_t *key, const uint8_t *nonce,
+                                           const void *aData, const size_t aDataLen,
+                                           const void *pntxt, const size_t ptextLen, void *crtxt)
+{
+    AES_OCB_encrypt_lens(OCB_NONCE_LEN, OCB_TAG_LEN, key, nonce, aData, aDataLen, pntxt, ptextLen, crtxt);
+}
+UAES_STATIC_INLINE char AES_OCB_decrypt_nl(const uint8_t *key, const uint8_t *nonce,
+                                           const void *aData, const size_t aDataLen,
+                                           const void *crtxt, const size_t crtxtLen, void *pntxt)
+{
+    return AES_OCB_decrypt_lens(OCB_NONCE_LEN, OCB_TAG_LEN, key, nonce, aData, aDataLen, crtxt, crtxtLen, pntxt);
+}
+#define AES_OCB_encrypt AES_OCB_encrypt_nl
+#define AES_OCB_decrypt AES_OCB_decrypt_nl
+#endif
 
 void GCM_SIV_encrypt(const uint8_t *key, const uint8_t *nonce,
                      const void *aData, const size_t aDataLen,

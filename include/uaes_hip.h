@@ -160,6 +160,15 @@ int uaes_gcm_encrypt_iv(int keybits, const uint8_t *key, const uint8_t *nonce, s
 int uaes_gcm_decrypt_iv(int keybits, const uint8_t *key, const uint8_t *nonce, size_t nonceLen,
                         const void *aData, size_t aDataLen,
                         const void *crtxt, size_t crtxtLen, void *pntxt);
+/* ... and with the reference's compile-time GCM_TAG_LEN (micro_aes.h:109) as tagLen = 1..16: tagLen bytes of the
+ * tag are appended at crtxt + ptextLen / compared (micro_aes.c:1178, :1204).  A truncated tag is compared on the
+ * host (constant time) after the device has produced the full one; nothing is decrypted before that (N7).    */
+int uaes_gcm_encrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, size_t nonceLen, size_t tagLen,
+                        const void *aData, size_t aDataLen,
+                        const void *pntxt, size_t ptextLen, void *crtxt);
+int uaes_gcm_decrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, size_t nonceLen, size_t tagLen,
+                        const void *aData, size_t aDataLen,
+                        const void *crtxt, size_t crtxtLen, void *pntxt);
 /* GHASH_H(aData, crtxt) of micro_aes.c:1127-1137 with an explicit H (test
  * hook for the carry-less-multiply kernels); gh receives 16 bytes.           */
 int uaes_ghash(const uint8_t H[16], const void *aData, size_t aDataLen,
@@ -168,7 +177,7 @@ int uaes_ghash(const uint8_t H[16], const void *aData, size_t aDataLen,
 /* ---- CMAC: replaces AES_CMAC ----------------------------------------------
  * micro_aes.h (CMAC section), micro_aes.c:1108-1118.  A CBC-MAC chain is serial:
  * one GPU lane walks it (kept on the device so that no cipher code runs on the
- * host); throughput is ~10 MB/s, meant for the short messages MACs are used on. */
+ * host); ~36 MiB/s for one message (latency-bound); uaes_cmac_batch for many.          */
 int uaes_cmac(int keybits, const uint8_t *key,
               const void *data, size_t dataSize, uint8_t mac[16]);
 
@@ -184,14 +193,22 @@ int uaes_ccm_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
                      const void *aData, size_t aDataLen,
                      const void *crtxt, size_t crtxtLen, void *pntxt);
 
+/* The same with the reference's compile-time CCM_NONCE_LEN (7..13) and CCM_TAG_LEN (even, 4..16), micro_aes.h:103-104 */
+int uaes_ccm_encrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, size_t nonceLen, size_t tagLen,
+                        const void *aData, size_t aDataLen,
+                        const void *pntxt, size_t ptextLen, void *crtxt);
+int uaes_ccm_decrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, size_t nonceLen, size_t tagLen,
+                        const void *aData, size_t aDataLen,
+                        const void *crtxt, size_t crtxtLen, void *pntxt);
+
 /* ---- CBC / CFB / OFB: replace AES_CBC_*, AES_CFB_*, AES_OFB_* -------------
  * micro_aes.c:697-782 (CBC with CS3 ciphertext stealing, CTS 1: the last two
  * blocks are always swapped, len < 16 -> UAES_E_DATALENGTH), :799-845 (CFB),
  * :861-893 (OFB; decrypt is the same function).  iVec = 16 bytes.  The
  * decrypt directions of CBC and CFB are block-parallel kernels; the encrypt
- * directions and OFB are serial chains: one wave walks the chain, the four lanes of a
- * quad share each block encryption (~0.8 us per block, latency-bound: a single stream
- * is slower than the reference's CPU loop -- use the *_batch calls below when there
+ * directions and OFB are serial chains: one wave walks the chain, the sixteen lanes of a
+ * DPP row share each block encryption (~0.42 us per AES-128 block, 36 MiB/s, latency-bound: a single
+ * stream reaches 0.8x of the reference's CPU loop -- use the *_batch calls below when there
  * are many independent messages).                                                */
 int uaes_cbc_encrypt(int keybits, const uint8_t *key, const uint8_t *iVec,
                      const void *pntxt, size_t ptextLen, void *crtxt);
@@ -240,6 +257,14 @@ int uaes_ocb_encrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
 int uaes_ocb_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
                      const void *aData, size_t aDataLen,
                      const void *crtxt, size_t crtxtLen, void *pntxt);
+
+/* The same with the reference's compile-time OCB_NONCE_LEN (1..15) and OCB_TAG_LEN (1..16), micro_aes.h:115-116 */
+int uaes_ocb_encrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, size_t nonceLen, size_t tagLen,
+                        const void *aData, size_t aDataLen,
+                        const void *pntxt, size_t ptextLen, void *crtxt);
+int uaes_ocb_decrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, size_t nonceLen, size_t tagLen,
+                        const void *aData, size_t aDataLen,
+                        const void *crtxt, size_t crtxtLen, void *pntxt);
 
 /* ---- streamed GCM: one message fed in pieces -----------------
  * For texts larger than device (or host) memory: state = key schedule, block

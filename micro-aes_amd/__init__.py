@@ -37,6 +37,8 @@ EXPORTS = [
     "uaes_ecb_encrypt", "uaes_ecb_encrypt_padded", "uaes_ecb_decrypt", "uaes_ctr_xcrypt", "uaes_ctr_xcrypt_at",
     "uaes_xts_encrypt", "uaes_xts_decrypt", "uaes_xts_sectors",
     "uaes_gcm_encrypt", "uaes_gcm_decrypt", "uaes_gcm_encrypt_iv", "uaes_gcm_decrypt_iv", "uaes_ghash",
+    "uaes_gcm_encrypt_ex", "uaes_gcm_decrypt_ex", "uaes_ccm_encrypt_ex", "uaes_ccm_decrypt_ex",
+    "uaes_ocb_encrypt_ex", "uaes_ocb_decrypt_ex",
     "uaes_cmac", "uaes_ccm_encrypt", "uaes_ccm_decrypt", "uaes_gcmsiv_encrypt", "uaes_gcmsiv_decrypt",
     "uaes_ocb_encrypt", "uaes_ocb_decrypt", "uaes_ocb_dev",
     "uaes_mgpu_ctr_xcrypt_at", "uaes_mgpu_xts_sectors",
@@ -52,7 +54,8 @@ COMPAT_EXPORTS = [
     "AES_CTR_encrypt", "AES_CTR_decrypt", "AES_CTR_encrypt_preset", "AES_CTR_decrypt_preset",
     "uaes_compat_set_failure_handler",
     "AES_XTS_encrypt", "AES_XTS_decrypt", "AES_GCM_encrypt", "AES_GCM_decrypt",
-    "AES_GCM_encrypt_ivlen", "AES_GCM_decrypt_ivlen",
+    "AES_GCM_encrypt_ivlen", "AES_GCM_decrypt_ivlen", "AES_GCM_encrypt_lens", "AES_GCM_decrypt_lens",
+    "AES_CCM_encrypt_lens", "AES_CCM_decrypt_lens", "AES_OCB_encrypt_lens", "AES_OCB_decrypt_lens",
     "AES_CCM_encrypt", "AES_CCM_decrypt", "AES_CMAC", "GCM_SIV_encrypt", "GCM_SIV_decrypt",
     "AES_OCB_encrypt", "AES_OCB_decrypt",
     "AES_CBC_encrypt", "AES_CBC_decrypt", "AES_CFB_encrypt", "AES_CFB_decrypt", "AES_OFB_encrypt", "AES_OFB_decrypt",
@@ -115,6 +118,9 @@ def engine():
         getattr(L, n).argtypes = [i, vp, vp, vp, sz, vp, sz, vp]
     for n in ("uaes_gcm_encrypt_iv", "uaes_gcm_decrypt_iv"):
         getattr(L, n).argtypes = [i, vp, vp, sz, vp, sz, vp, sz, vp]
+    for n in ("uaes_gcm_encrypt_ex", "uaes_gcm_decrypt_ex", "uaes_ccm_encrypt_ex", "uaes_ccm_decrypt_ex",
+              "uaes_ocb_encrypt_ex", "uaes_ocb_decrypt_ex"):
+        getattr(L, n).argtypes = [i, vp, vp, sz, sz, vp, sz, vp, sz, vp]
     L.uaes_ghash.argtypes = [vp, vp, sz, vp, sz, vp]
     L.uaes_cmac.argtypes = [i, vp, vp, sz, vp]
     for n in ("uaes_cbc_encrypt", "uaes_cbc_decrypt", "uaes_cfb_encrypt", "uaes_cfb_decrypt", "uaes_ofb_xcrypt"):
@@ -250,25 +256,33 @@ def xts_sectors(keys, first_sector, sector_bytes, data, encrypt=True):
     return rc, bytes(o)[: len(data)]
 
 
-def AES_GCM_encrypt(key, nonce, aData, pntxt):
-    """micro_aes.c:1164.  Returns ciphertext || 16-byte tag.  len(nonce) is the reference's
-    GCM_NONCE_LEN: 12 by default, any other length >= 1 derives J0 = GHASH(nonce) (:1145-1149)."""
+def _taglen(tag_len, lo, hi, even, what):
+    if not (lo <= tag_len <= hi) or (even and tag_len % 2):
+        raise ValueError("%s tag length %d (%s%d..%d)" % (what, tag_len, "even, " if even else "", lo, hi))
+    return tag_len
+
+
+def AES_GCM_encrypt(key, nonce, aData, pntxt, tag_len=16):
+    """micro_aes.c:1164.  Returns ciphertext || tag.  len(nonce) / tag_len are the reference's GCM_NONCE_LEN /
+    GCM_TAG_LEN: 12 / 16 by default, any other nonce length >= 1 derives J0 = GHASH(nonce) (:1145-1149)."""
     if len(nonce) < 1:
         raise ValueError("empty nonce")
+    _taglen(tag_len, 1, 16, False, "GCM")
     o = _out(len(pntxt) + 16)
-    _check(engine().uaes_gcm_encrypt_iv(_bits(key), _in(key), _in(nonce), len(nonce), _in(aData), len(aData),
+    _check(engine().uaes_gcm_encrypt_ex(_bits(key), _in(key), _in(nonce), len(nonce), tag_len, _in(aData), len(aData),
                                         _in(pntxt), len(pntxt), o), "AES_GCM_encrypt")
-    return bytes(o)[: len(pntxt) + 16]
+    return bytes(o)[: len(pntxt) + tag_len]
 
 
-def AES_GCM_decrypt(key, nonce, aData, crtxt_and_tag, prefill=0):
+def AES_GCM_decrypt(key, nonce, aData, crtxt_and_tag, prefill=0, tag_len=16):
     """micro_aes.c:1192.  Returns (code, plaintext); code 0x1A and an untouched
     (prefilled) buffer when authentication fails."""
-    n = len(crtxt_and_tag) - 16
+    _taglen(tag_len, 1, 16, False, "GCM")
+    n = len(crtxt_and_tag) - tag_len
     o = _out(n, prefill)
     if len(nonce) < 1:
         raise ValueError("empty nonce")
-    rc = _check(engine().uaes_gcm_decrypt_iv(_bits(key), _in(key), _in(nonce), len(nonce), _in(aData), len(aData),
+    rc = _check(engine().uaes_gcm_decrypt_ex(_bits(key), _in(key), _in(nonce), len(nonce), tag_len, _in(aData), len(aData),
                                              _in(crtxt_and_tag), n, o), "AES_GCM_decrypt")
     return rc, bytes(o)[:n]
 
@@ -343,21 +357,30 @@ def AES_CMAC(key, data):
     return bytes(o)
 
 
-def AES_CCM_encrypt(key, nonce, aData, pntxt):
-    """micro_aes.c:1268.  11-byte nonce; returns ciphertext || 16-byte tag."""
+def _ccm_nonce(nonce):
+    if not 7 <= len(nonce) <= 13:
+        raise ValueError("CCM nonce of %d bytes (7..13)" % len(nonce))
+    return _in(nonce)
+
+
+def AES_CCM_encrypt(key, nonce, aData, pntxt, tag_len=16):
+    """micro_aes.c:1268.  len(nonce) / tag_len are the reference's CCM_NONCE_LEN (7..13; 11 by default) and
+    CCM_TAG_LEN (even, 4..16); returns ciphertext || tag."""
+    _taglen(tag_len, 4, 16, True, "CCM")
     o = _out(len(pntxt) + 16)
-    _check(engine().uaes_ccm_encrypt(_bits(key), _in(key), _fixed(nonce, 11, "CCM nonce"), _in(aData), len(aData),
-                                     _in(pntxt), len(pntxt), o), "AES_CCM_encrypt")
-    return bytes(o)[: len(pntxt) + 16]
+    _check(engine().uaes_ccm_encrypt_ex(_bits(key), _in(key), _ccm_nonce(nonce), len(nonce), tag_len, _in(aData), len(aData),
+                                        _in(pntxt), len(pntxt), o), "AES_CCM_encrypt")
+    return bytes(o)[: len(pntxt) + tag_len]
 
 
-def AES_CCM_decrypt(key, nonce, aData, crtxt_and_tag, prefill=0):
+def AES_CCM_decrypt(key, nonce, aData, crtxt_and_tag, prefill=0, tag_len=16):
     """micro_aes.c:1294.  Returns (code, text); like the reference the decrypted
     text is returned even when the code is 0x1A."""
-    n = len(crtxt_and_tag) - 16
+    _taglen(tag_len, 4, 16, True, "CCM")
+    n = len(crtxt_and_tag) - tag_len
     o = _out(n, prefill)
-    rc = _check(engine().uaes_ccm_decrypt(_bits(key), _in(key), _fixed(nonce, 11, "CCM nonce"), _in(aData), len(aData),
-                                          _in(crtxt_and_tag), n, o), "AES_CCM_decrypt")
+    rc = _check(engine().uaes_ccm_decrypt_ex(_bits(key), _in(key), _ccm_nonce(nonce), len(nonce), tag_len, _in(aData),
+                                             len(aData), _in(crtxt_and_tag), n, o), "AES_CCM_decrypt")
     return rc, bytes(o)[:n]
 
 
@@ -378,20 +401,29 @@ def GCM_SIV_decrypt(key, nonce, aData, crtxt_and_tag, prefill=0):
     return rc, bytes(o)[:n]
 
 
-def AES_OCB_encrypt(key, nonce, aData, pntxt):
-    """micro_aes.c:1774 (RFC 7253, 12-byte nonce).  Returns ciphertext || 16-byte tag."""
+def _ocb_nonce(nonce):
+    if not 1 <= len(nonce) <= 15:
+        raise ValueError("OCB nonce of %d bytes (1..15)" % len(nonce))
+    return _in(nonce)
+
+
+def AES_OCB_encrypt(key, nonce, aData, pntxt, tag_len=16):
+    """micro_aes.c:1774 (RFC 7253).  len(nonce) / tag_len are the reference's OCB_NONCE_LEN (1..15; 12 by default)
+    and OCB_TAG_LEN (1..16).  Returns ciphertext || tag."""
+    _taglen(tag_len, 1, 16, False, "OCB")
     o = _out(len(pntxt) + 16)
-    _check(engine().uaes_ocb_encrypt(_bits(key), _in(key), _fixed(nonce, 12, "nonce"), _in(aData), len(aData),
-                                     _in(pntxt), len(pntxt), o), "AES_OCB_encrypt")
-    return bytes(o)[: len(pntxt) + 16]
+    _check(engine().uaes_ocb_encrypt_ex(_bits(key), _in(key), _ocb_nonce(nonce), len(nonce), tag_len, _in(aData), len(aData),
+                                        _in(pntxt), len(pntxt), o), "AES_OCB_encrypt")
+    return bytes(o)[: len(pntxt) + tag_len]
 
 
-def AES_OCB_decrypt(key, nonce, aData, crtxt_and_tag, prefill=0):
+def AES_OCB_decrypt(key, nonce, aData, crtxt_and_tag, prefill=0, tag_len=16):
     """micro_aes.c:1797.  Returns (code, text); the text is written even on 0x1A."""
-    n = len(crtxt_and_tag) - 16
+    _taglen(tag_len, 1, 16, False, "OCB")
+    n = len(crtxt_and_tag) - tag_len
     o = _out(n, prefill)
-    rc = _check(engine().uaes_ocb_decrypt(_bits(key), _in(key), _fixed(nonce, 12, "nonce"), _in(aData), len(aData),
-                                          _in(crtxt_and_tag), n, o), "AES_OCB_decrypt")
+    rc = _check(engine().uaes_ocb_decrypt_ex(_bits(key), _in(key), _ocb_nonce(nonce), len(nonce), tag_len, _in(aData),
+                                             len(aData), _in(crtxt_and_tag), n, o), "AES_OCB_decrypt")
     return rc, bytes(o)[:n]
 
 

@@ -112,6 +112,21 @@ char AES_XTS_decrypt(const uint8_t *keys, const uint8_t *tweak,
 
 #undef AES_GCM_encrypt
 #undef AES_GCM_decrypt
+void AES_GCM_encrypt_lens(const size_t nonceLen, const size_t tagLen, const uint8_t *key, const uint8_t *nonce,
+                          const void *aData, const size_t aDataLen,
+                          const void *pntxt, const size_t ptextLen, void *crtxt)
+{
+    must("AES_GCM_encrypt", uaes_gcm_encrypt_ex(KB, key, nonce, nonceLen, tagLen, aData, aDataLen, pntxt, ptextLen, crtxt));
+}
+
+char AES_GCM_decrypt_lens(const size_t nonceLen, const size_t tagLen, const uint8_t *key, const uint8_t *nonce,
+                          const void *aData, const size_t aDataLen,
+                          const void *crtxt, const size_t crtxtLen, void *pntxt)
+{
+    return soft("AES_GCM_decrypt", uaes_gcm_decrypt_ex(KB, key, nonce, nonceLen, tagLen, aData, aDataLen, crtxt, crtxtLen, pntxt),
+                M_DECRYPTION_ERROR);
+}
+
 void AES_GCM_encrypt_ivlen(const size_t nonceLen, const uint8_t *key, const uint8_t *nonce,
                            const void *aData, const size_t aDataLen,
                            const void *pntxt, const size_t ptextLen, void *crtxt)
@@ -139,6 +154,23 @@ char AES_GCM_decrypt(const uint8_t *key, const uint8_t *nonce,
                      const void *crtxt, const size_t crtxtLen, void *pntxt)
 {
     return soft("AES_GCM_decrypt", uaes_gcm_decrypt(KB, key, nonce, aData, aDataLen, crtxt, crtxtLen, pntxt),
+                M_DECRYPTION_ERROR);
+}
+
+#undef AES_CCM_encrypt
+#undef AES_CCM_decrypt
+void AES_CCM_encrypt_lens(const size_t nonceLen, const size_t tagLen, const uint8_t *key, const uint8_t *nonce,
+                          const void *aData, const size_t aDataLen,
+                          const void *pntxt, const size_t ptextLen, void *crtxt)
+{
+    must("AES_CCM_encrypt", uaes_ccm_encrypt_ex(KB, key, nonce, nonceLen, tagLen, aData, aDataLen, pntxt, ptextLen, crtxt));
+}
+
+char AES_CCM_decrypt_lens(const size_t nonceLen, const size_t tagLen, const uint8_t *key, const uint8_t *nonce,
+                          const void *aData, const size_t aDataLen,
+                          const void *crtxt, const size_t crtxtLen, void *pntxt)
+{
+    return soft("AES_CCM_decrypt", uaes_ccm_decrypt_ex(KB, key, nonce, nonceLen, tagLen, aData, aDataLen, crtxt, crtxtLen, pntxt),
                 M_DECRYPTION_ERROR);
 }
 
@@ -210,6 +242,23 @@ char GCM_SIV_decrypt(const uint8_t *key, const uint8_t *nonce,
                      const void *crtxt, const size_t crtxtLen, void *pntxt)
 {
     return soft("GCM_SIV_decrypt", uaes_gcmsiv_decrypt(KB, key, nonce, aData, aDataLen, crtxt, crtxtLen, pntxt),
+                M_DECRYPTION_ERROR);
+}
+
+#undef AES_OCB_encrypt
+#undef AES_OCB_decrypt
+void AES_OCB_encrypt_lens(const size_t nonceLen, const size_t tagLen, const uint8_t *key, const uint8_t *nonce,
+                          const void *aData, const size_t aDataLen,
+                          const void *pntxt, const size_t ptextLen, void *crtxt)
+{
+    must("AES_OCB_encrypt", uaes_ocb_encrypt_ex(KB, key, nonce, nonceLen, tagLen, aData, aDataLen, pntxt, ptextLen, crtxt));
+}
+
+char AES_OCB_decrypt_lens(const size_t nonceLen, const size_t tagLen, const uint8_t *key, const uint8_t *nonce,
+                          const void *aData, const size_t aDataLen,
+                          const void *crtxt, const size_t crtxtLen, void *pntxt)
+{
+    return soft("AES_OCB_decrypt", uaes_ocb_decrypt_ex(KB, key, nonce, nonceLen, tagLen, aData, aDataLen, crtxt, crtxtLen, pntxt),
                 M_DECRYPTION_ERROR);
 }
 

@@ -90,6 +90,11 @@ int uaesk_gcm(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek,
               const void *in, size_t len, void *out,
               void *scratch, int *status);
 
+/* decrypt == 3 (uaesk_gcm only): just the tag of (aad, `in` as ciphertext), 16 bytes written at `status`; the
+ * host layer compares a truncated tag (GCM_TAG_LEN < 16) itself and then calls uaesk_gcm_ctr for the text */
+int uaesk_gcm_ctr(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek,
+                  const uint8_t *j0_16, const void *in, size_t len, void *out);
+
 /* Key context: uaesk_gcm_key_tables fills a scratch buffer (uaesk_gcm_scratch_bytes()) with every table
  * that depends on the key only; uaesk_gcm_keyed is uaesk_gcm on such a buffer -- per message it computes
  * just Enc(J0), unless the text needs a size-dependent bulk table.  One call at a time per buffer.  */
@@ -140,10 +145,10 @@ int uaesk_ghash(void *stream, const uaesk_tables *tb, const uint8_t *H_host,
 int uaesk_cmac(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek,
                const void *data, size_t len, void *mac16);
 
-/* CCM (AES_CCM_encrypt/decrypt, micro_aes.c:1268-1314), 11-byte nonce (host),
- * 16-byte tag at out+len / in+len; decrypt writes *status = 0 / 0x1A.        */
+/* CCM (AES_CCM_encrypt/decrypt, micro_aes.c:1268-1314), nonce (host) of nonce_len = 7..13 bytes,
+ * tag_len (even, 4..16) bytes of tag at out+len / in+len; decrypt writes *status = 0 / 0x1A.   */
 int uaesk_ccm(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek,
-              int decrypt, const uint8_t *nonce11,
+              int decrypt, const uint8_t *nonce, size_t nonce_len, size_t tag_len,
               const void *aad, size_t aad_len,
               const void *in, size_t len, void *out, int *status);
 
@@ -160,12 +165,13 @@ int uaesk_feedback(void *stream, const uaesk_tables *tb, int nr,
 int uaesk_chain_batch(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek, int mac,
                       const void *ivs, size_t nmsg, size_t msg_bytes, const void *in, void *out);
 
-/* OCB (AES_OCB_encrypt/decrypt, micro_aes.c:1693-1811): 12-byte nonce (host), 16-byte
- * tag at out+len (encrypt) / read at in+len (decrypt, *status = 0 / 0x1A; the text
+/* OCB (AES_OCB_encrypt/decrypt, micro_aes.c:1693-1811): nonce (host) of nonce_len = 1..15 bytes, tag_len
+ * (1..16) bytes of tag at out+len (encrypt) / read at in+len (decrypt, *status = 0 / 0x1A; the text
  * is written either way, as in the reference).  dk = equivalent-inverse keys.  */
 size_t uaesk_ocb_scratch_bytes(void);
 int uaesk_ocb(void *stream, const uaesk_tables *tb, int nr,
-              const uaesk_rk *ek, const uaesk_rk *dk, int decrypt, const uint8_t *nonce12,
+              const uaesk_rk *ek, const uaesk_rk *dk, int decrypt, const uint8_t *nonce,
+              size_t nonce_len, size_t tag_len,
               const void *aad, size_t aad_len, const void *in, size_t len, void *out,
               void *scratch, int *status);
 

@@ -1260,7 +1260,10 @@ static int gcm_j0(lane *L, keysched *ks, const uint8_t *nonce, size_t nonce_len,
     return lane_fetch(L, j0, L->d_status + 4, 16);
 }
 
-int uaes_gcm_encrypt_iv(int keybits, const uint8_t *key, const uint8_t *nonce, size_t nonceLen,
+/* nonceLen / tagLen = the reference's compile-time GCM_NONCE_LEN / GCM_TAG_LEN (micro_aes.h:108-109).  The kernels
+ * always produce the 16-byte tag behind the text; a shorter tag is the host layer's business: the text goes
+ * through a buffer with room for sixteen bytes and ptextLen + tagLen bytes are handed over (:1178).         */
+int uaes_gcm_encrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, size_t nonceLen, size_t tagLen,
                         const void *aData, size_t aDataLen,
                         const void *pntxt, size_t ptextLen, void *crtxt)
 {
@@ -1273,18 +1276,32 @@ int uaes_gcm_encrypt_iv(int keybits, const uint8_t *key, const uint8_t *nonce, s
     int rc;
     if ((rc = expand_key(&ks, key, keybits)) != 0) return rc;
     if (!nonce || !crtxt || (ptextLen && !pntxt)) return fail(UAES_E_ARG, "NULL pointer");
+    if (tagLen < 1 || tagLen > 16) return fail(UAES_E_ARG, "GCM tag length %zu (1..16)", tagLen);
     if ((rc = enter(&c, &L)) != 0) return rc;
     do {
         if ((rc = gcm_scratch(L)) != 0) break;
         if ((rc = gcm_j0(L, &ks, nonce, nonceLen, j0)) != 0) break;
         if ((rc = stage_aad(L, aData, aDataLen, &d_aad)) != 0) break;
-        if ((rc = plan_io(L, pntxt, ptextLen, crtxt, ptextLen + 16, &io)) != 0) break;
+        if ((rc = plan_io(L, pntxt, ptextLen, crtxt, ptextLen + tagLen, &io)) != 0) break;
+        if (tagLen < 16 && io.dout == crtxt) {
+            /* the caller's own device buffer ends tagLen bytes behind the text: run into staging, copy back */
+            if (grow_on(L->stream, &L->stage[1], &L->stage_cap[1], ptextLen + 64)) { rc = UAES_E_HIP; break; }
+            io.dout = L->stage[1];
+            io.copy_back = 1;
+        }
         int k = uaesk_gcm(L->stream, &c->tb, ks.nr, &ks.ek, 0, j0, d_aad, aDataLen,
                           io.din, ptextLen, io.dout, L->scratch, NULL);
         if (k) { rc = fail(UAES_E_HIP, "gcm launch: %s", hipGetErrorString((hipError_t)k)); break; }
-        rc = finish_io(&io, ptextLen + 16);
+        rc = finish_io(&io, ptextLen + tagLen);
     } while (0);
     DONE(L, rc);
+}
+
+int uaes_gcm_encrypt_iv(int keybits, const uint8_t *key, const uint8_t *nonce, size_t nonceLen,
+                        const void *aData, size_t aDataLen,
+                        const void *pntxt, size_t ptextLen, void *crtxt)
+{
+    return uaes_gcm_encrypt_ex(keybits, key, nonce, nonceLen, 16, aData, aDataLen, pntxt, ptextLen, crtxt);
 }
 
 int uaes_gcm_encrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
@@ -1294,7 +1311,7 @@ int uaes_gcm_encrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
     return uaes_gcm_encrypt_iv(keybits, key, nonce, 12, aData, aDataLen, pntxt, ptextLen, crtxt);
 }
 
-int uaes_gcm_decrypt_iv(int keybits, const uint8_t *key, const uint8_t *nonce, size_t nonceLen,
+int uaes_gcm_decrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, size_t nonceLen, size_t tagLen,
                         const void *aData, size_t aDataLen,
                         const void *crtxt, size_t crtxtLen, void *pntxt)
 {
@@ -1307,13 +1324,37 @@ int uaes_gcm_decrypt_iv(int keybits, const uint8_t *key, const uint8_t *nonce, s
     int rc, status = -1;
     if ((rc = expand_key(&ks, key, keybits)) != 0) return rc;
     if (!nonce || !crtxt || (crtxtLen && !pntxt)) return fail(UAES_E_ARG, "NULL pointer");
+    if (tagLen < 1 || tagLen > 16) return fail(UAES_E_ARG, "GCM tag length %zu (1..16)", tagLen);
     if ((rc = enter(&c, &L)) != 0) return rc;
     do {
         if ((rc = gcm_scratch(L)) != 0) break;
         if ((rc = gcm_j0(L, &ks, nonce, nonceLen, j0)) != 0) break;
         if ((rc = stage_aad(L, aData, aDataLen, &d_aad)) != 0) break;
         /* input is CT || tag; output is crtxtLen bytes */
-        if ((rc = plan_io(L, crtxt, crtxtLen + 16, pntxt, crtxtLen, &io)) != 0) break;
+        if ((rc = plan_io(L, crtxt, crtxtLen + tagLen, pntxt, crtxtLen, &io)) != 0) break;
+        if (tagLen < 16) {
+            /* a truncated tag (GCM_TAG_LEN < 16, :1204) is compared here: the device computes the full tag of the
+             * ciphertext (nothing is decrypted), its first tagLen bytes are checked against the ones behind the
+             * text in constant time, and only then does the CTR pass write the caller's buffer (N7)          */
+            uint8_t full[16], given[16];
+            int k = uaesk_gcm(L->stream, &c->tb, ks.nr, &ks.ek, 3, j0, d_aad, aDataLen,
+                              io.din, crtxtLen, NULL, L->scratch, L->d_status + 4);
+            if (k) { rc = fail(UAES_E_HIP, "gcm launch: %s", hipGetErrorString((hipError_t)k)); break; }
+            if ((rc = lane_fetch(L, full, L->d_status + 4, 16)) != 0) break;
+            if (is_device_ptr(io.din)) {
+                if (hipMemcpy(given, (const char *)io.din + crtxtLen, tagLen, hipMemcpyDeviceToHost) != hipSuccess) {
+                    rc = fail(UAES_E_HIP, "reading the tag back failed");
+                    break;
+                }
+            } else {
+                memcpy(given, (const char *)io.din + crtxtLen, tagLen);     /* the mapped pinned window */
+            }
+            if (tags_differ(full, given, tagLen)) { rc = UAES_E_AUTHENTICATION; break; }
+            k = uaesk_gcm_ctr(L->stream, &c->tb, ks.nr, &ks.ek, j0, io.din, crtxtLen, io.dout);
+            if (k) { rc = fail(UAES_E_HIP, "gcm launch: %s", hipGetErrorString((hipError_t)k)); break; }
+            rc = finish_io(&io, crtxtLen);
+            break;
+        }
         if (io.dout == io.din && io.copy_back) {
             /* host -> host: decrypt into the second staging buffer so that a
              * failed authentication can leave the caller's buffer untouched   */
@@ -1329,6 +1370,13 @@ int uaes_gcm_decrypt_iv(int keybits, const uint8_t *key, const uint8_t *nonce, s
         rc = finish_io(&io, crtxtLen);
     } while (0);
     DONE(L, rc);
+}
+
+int uaes_gcm_decrypt_iv(int keybits, const uint8_t *key, const uint8_t *nonce, size_t nonceLen,
+                        const void *aData, size_t aDataLen,
+                        const void *crtxt, size_t crtxtLen, void *pntxt)
+{
+    return uaes_gcm_decrypt_ex(keybits, key, nonce, nonceLen, 16, aData, aDataLen, crtxt, crtxtLen, pntxt);
 }
 
 int uaes_gcm_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
@@ -1594,9 +1642,17 @@ int uaes_cmac(int keybits, const uint8_t *key, const void *data, size_t dataSize
     DONE(L, rc);
 }
 
-int uaes_ccm_encrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
-                     const void *aData, size_t aDataLen,
-                     const void *pntxt, size_t ptextLen, void *crtxt)
+static int ccm_lens_ok(size_t nonceLen, size_t tagLen)
+{
+    if (nonceLen < 7 || nonceLen > 13) return fail(UAES_E_ARG, "CCM nonce length %zu (7..13)", nonceLen);
+    if (tagLen < 4 || tagLen > 16 || (tagLen & 1)) return fail(UAES_E_ARG, "CCM tag length %zu (even, 4..16)", tagLen);
+    return 0;
+}
+
+/* nonceLen / tagLen = the reference's compile-time CCM_NONCE_LEN / CCM_TAG_LEN (micro_aes.h:103-104) */
+int uaes_ccm_encrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, size_t nonceLen, size_t tagLen,
+                        const void *aData, size_t aDataLen,
+                        const void *pntxt, size_t ptextLen, void *crtxt)
 {
     context *c;
     lane *L;
@@ -1606,21 +1662,29 @@ int uaes_ccm_encrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
     int rc;
     if ((rc = expand_key(&ks, key, keybits)) != 0) return rc;
     if (!nonce || !crtxt || (ptextLen && !pntxt)) return fail(UAES_E_ARG, "NULL pointer");
+    if ((rc = ccm_lens_ok(nonceLen, tagLen)) != 0) return rc;
     if ((rc = enter(&c, &L)) != 0) return rc;
     do {
         if ((rc = stage_aad(L, aData, aDataLen, &d_aad)) != 0) break;
-        if ((rc = plan_io(L, pntxt, ptextLen, crtxt, ptextLen + 16, &io)) != 0) break;
-        int k = uaesk_ccm(L->stream, &c->tb, ks.nr, &ks.ek, 0, nonce, d_aad, aDataLen,
+        if ((rc = plan_io(L, pntxt, ptextLen, crtxt, ptextLen + tagLen, &io)) != 0) break;
+        int k = uaesk_ccm(L->stream, &c->tb, ks.nr, &ks.ek, 0, nonce, nonceLen, tagLen, d_aad, aDataLen,
                           io.din, ptextLen, io.dout, NULL);
         if (k) { rc = fail(UAES_E_HIP, "ccm launch: %s", hipGetErrorString((hipError_t)k)); break; }
-        rc = finish_io(&io, ptextLen + 16);
+        rc = finish_io(&io, ptextLen + tagLen);
     } while (0);
     DONE(L, rc);
 }
 
-int uaes_ccm_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
+int uaes_ccm_encrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
                      const void *aData, size_t aDataLen,
-                     const void *crtxt, size_t crtxtLen, void *pntxt)
+                     const void *pntxt, size_t ptextLen, void *crtxt)
+{
+    return uaes_ccm_encrypt_ex(keybits, key, nonce, 11, 16, aData, aDataLen, pntxt, ptextLen, crtxt);
+}
+
+int uaes_ccm_decrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, size_t nonceLen, size_t tagLen,
+                        const void *aData, size_t aDataLen,
+                        const void *crtxt, size_t crtxtLen, void *pntxt)
 {
     context *c;
     lane *L;
@@ -1630,11 +1694,12 @@ int uaes_ccm_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
     int rc, status = -1;
     if ((rc = expand_key(&ks, key, keybits)) != 0) return rc;
     if (!nonce || !crtxt || (crtxtLen && !pntxt)) return fail(UAES_E_ARG, "NULL pointer");
+    if ((rc = ccm_lens_ok(nonceLen, tagLen)) != 0) return rc;
     if ((rc = enter(&c, &L)) != 0) return rc;
     do {
         if ((rc = stage_aad(L, aData, aDataLen, &d_aad)) != 0) break;
-        if ((rc = plan_io(L, crtxt, crtxtLen + 16, pntxt, crtxtLen, &io)) != 0) break;
-        int k = uaesk_ccm(L->stream, &c->tb, ks.nr, &ks.ek, 1, nonce, d_aad, aDataLen,
+        if ((rc = plan_io(L, crtxt, crtxtLen + tagLen, pntxt, crtxtLen, &io)) != 0) break;
+        int k = uaesk_ccm(L->stream, &c->tb, ks.nr, &ks.ek, 1, nonce, nonceLen, tagLen, d_aad, aDataLen,
                           io.din, crtxtLen, io.dout, L->d_status);
         if (k) { rc = fail(UAES_E_HIP, "ccm launch: %s", hipGetErrorString((hipError_t)k)); break; }
         if ((rc = lane_fetch(L, &status, L->d_status, sizeof status)) != 0) break;
@@ -1644,6 +1709,13 @@ int uaes_ccm_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
         rc = status ? UAES_E_AUTHENTICATION : 0;
     } while (0);
     DONE(L, rc);
+}
+
+int uaes_ccm_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
+                     const void *aData, size_t aDataLen,
+                     const void *crtxt, size_t crtxtLen, void *pntxt)
+{
+    return uaes_ccm_decrypt_ex(keybits, key, nonce, 11, 16, aData, aDataLen, crtxt, crtxtLen, pntxt);
 }
 
 /* ------------------------------------------------------------------------ */
@@ -1963,7 +2035,8 @@ int uaes_gcmsiv_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
 /* ------------------------------------------------------------------------ */
 /* OCB (RFC 7253; AES_OCB_encrypt / AES_OCB_decrypt, micro_aes.c:1774-1811)     */
 /* ------------------------------------------------------------------------ */
-static int ocb_common(int keybits, const uint8_t *key, const uint8_t *nonce, int decrypt,
+/* nonceLen / tagLen = the reference's compile-time OCB_NONCE_LEN (1..15) / OCB_TAG_LEN (1..16), micro_aes.h:115-116 */
+static int ocb_common(int keybits, const uint8_t *key, const uint8_t *nonce, size_t nonceLen, size_t tagLen, int decrypt,
                       const void *aData, size_t aDataLen, const void *in, size_t len, void *out)
 {
     context *c;
@@ -1975,12 +2048,14 @@ static int ocb_common(int keybits, const uint8_t *key, const uint8_t *nonce, int
     if ((rc = expand_key(&ks, key, keybits)) != 0) return rc;
     if (!nonce || (!decrypt && !out) || (len && (!in || !out)) || (decrypt && !in))
         return fail(UAES_E_ARG, "NULL pointer");
+    if (nonceLen < 1 || nonceLen > 15) return fail(UAES_E_ARG, "OCB nonce length %zu (1..15)", nonceLen);
+    if (tagLen < 1 || tagLen > 16) return fail(UAES_E_ARG, "OCB tag length %zu (1..16)", tagLen);
     if ((rc = enter(&c, &L)) != 0) return rc;
     do {
         if ((rc = gcm_scratch(L)) != 0) break;        /* >= uaesk_ocb_scratch_bytes() */
         if ((rc = stage_aad(L, aData, aDataLen, &d_aad)) != 0) break;
-        if ((rc = plan_io(L, in, len + (decrypt ? 16 : 0), out, len + (decrypt ? 0 : 16), &io)) != 0) break;
-        int k = uaesk_ocb(L->stream, &c->tb, ks.nr, &ks.ek, &ks.dk, decrypt, nonce, d_aad, aDataLen,
+        if ((rc = plan_io(L, in, len + (decrypt ? tagLen : 0), out, len + (decrypt ? 0 : tagLen), &io)) != 0) break;
+        int k = uaesk_ocb(L->stream, &c->tb, ks.nr, &ks.ek, &ks.dk, decrypt, nonce, nonceLen, tagLen, d_aad, aDataLen,
                           io.din, len, io.dout, L->scratch, L->d_status);
         if (k) { rc = fail(UAES_E_HIP, "ocb launch: %s", hipGetErrorString((hipError_t)k)); break; }
         if (decrypt) {
@@ -1988,7 +2063,7 @@ static int ocb_common(int keybits, const uint8_t *key, const uint8_t *nonce, int
         }
         /* decrypt: the text stays on a bad tag, as in the reference, unless wiping is switched on */
         if ((rc = (decrypt && status != 0) ? finish_io_unauthenticated(&io, len)
-                                           : finish_io(&io, len + (decrypt ? 0 : 16))) != 0) break;
+                                           : finish_io(&io, len + (decrypt ? 0 : tagLen))) != 0) break;
         if (decrypt && status != 0) rc = UAES_E_AUTHENTICATION;
     } while (0);
     DONE(L, rc);
@@ -1998,14 +2073,28 @@ int uaes_ocb_encrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
                      const void *aData, size_t aDataLen,
                      const void *pntxt, size_t ptextLen, void *crtxt)
 {
-    return ocb_common(keybits, key, nonce, 0, aData, aDataLen, pntxt, ptextLen, crtxt);
+    return ocb_common(keybits, key, nonce, 12, 16, 0, aData, aDataLen, pntxt, ptextLen, crtxt);
+}
+
+int uaes_ocb_encrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, size_t nonceLen, size_t tagLen,
+                        const void *aData, size_t aDataLen,
+                        const void *pntxt, size_t ptextLen, void *crtxt)
+{
+    return ocb_common(keybits, key, nonce, nonceLen, tagLen, 0, aData, aDataLen, pntxt, ptextLen, crtxt);
+}
+
+int uaes_ocb_decrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, size_t nonceLen, size_t tagLen,
+                        const void *aData, size_t aDataLen,
+                        const void *crtxt, size_t crtxtLen, void *pntxt)
+{
+    return ocb_common(keybits, key, nonce, nonceLen, tagLen, 1, aData, aDataLen, crtxt, crtxtLen, pntxt);
 }
 
 int uaes_ocb_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
                      const void *aData, size_t aDataLen,
                      const void *crtxt, size_t crtxtLen, void *pntxt)
 {
-    return ocb_common(keybits, key, nonce, 1, aData, aDataLen, crtxt, crtxtLen, pntxt);
+    return ocb_common(keybits, key, nonce, 12, 16, 1, aData, aDataLen, crtxt, crtxtLen, pntxt);
 }
 
 int uaes_ocb_dev(int keybits, const uint8_t *key, const uint8_t *nonce, int decrypt,
@@ -2022,7 +2111,7 @@ int uaes_ocb_dev(int keybits, const uint8_t *key, const uint8_t *nonce, int decr
     if (decrypt && !d_status) return fail(UAES_E_ARG, "NULL d_status");
     if ((rc = get_context(&c)) != 0) return rc;
     if ((rc = gcm_scratch_locked(c, stream, &scr, &slot)) != 0) return rc;
-    KCHK_PINNED(c, slot, uaesk_ocb(stream, &c->tb, ks.nr, &ks.ek, &ks.dk, decrypt, nonce, d_aad, aad_len, d_in, len,
+    KCHK_PINNED(c, slot, uaesk_ocb(stream, &c->tb, ks.nr, &ks.ek, &ks.dk, decrypt, nonce, 12, 16, d_aad, aad_len, d_in, len,
                                    d_out, scr, d_status));
     return 0;
 }

@@ -1504,7 +1504,7 @@ static int gcm_body(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk
      * buffer) runs one pass as well: the striped region is decrypted while its ciphertext is hashed,
      * the tag is checked over [T][tail][lengths] with the tail still ciphertext, then the tail is
      * decrypted (gated on the status) and, on a mismatch, everything written is zeroed.    */
-    if (decrypt != 1) {
+    if (decrypt != 1 && decrypt != 3) {
         int cus = 0;
         if (uaesk_device_info(&cus, nullptr) != 0) cus = 0;
         const u64 Sl = 2048ull * (u64)(cus > 0 ? cus : 0);
@@ -1571,7 +1571,7 @@ static int gcm_body(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk
     }
 
     const GPlan pl = plan_for(nv);
-    if (nv <= GSM_MAXNV) {                     /* short message: one workgroup does all of it (k_gcm_small) */
+    if (nv <= GSM_MAXNV && decrypt != 3) {     /* short message: one workgroup does all of it (k_gcm_small) */
         /* the nibble tables of this key: a key context has them; a one-shot call makes them inside the same
          * launch (needs the Frobenius matrices), else k_gcm_setup runs first                              */
         const u32 build = (!keyed && tb->frob) ? 1u : 0u;
@@ -1592,7 +1592,7 @@ static int gcm_body(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk
     }
     /* (a decrypt that must authenticate first has no one-pass alternative: the chunk kernels serve it as far as
      * the combine kernel reaches, 32 MiB: 16 MiB 93 -> 69 us) */
-    if (nv <= 2048ull * (decrypt == 1 ? GMC_MAXW : medium_pref_w()) && tb->frob) {
+    if (decrypt != 3 && nv <= 2048ull * (decrypt == 1 ? GMC_MAXW : medium_pref_w()) && tb->frob) {
         /* a medium-sized text: chunk kernel + combine kernel (k_gcm_chunks, k_gcm_combine), tables made in the
          * kernels for a one-shot call.  Decrypt mode 1 hashes first and lets the gated CTR kernel write; mode 2
          * decrypts in the chunk kernel and zeroes the output if the tag turns out wrong.                       */
@@ -1644,6 +1644,11 @@ static int gcm_body(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk
     }
     if (rc) return rc;
 
+    /* decrypt == 3: only the tag of (aad, `in` as ciphertext), 16 bytes written at `status`; nothing is decrypted.
+     * The host layer compares a TRUNCATED tag (GCM_TAG_LEN < 16, micro_aes.c:1204) itself and then runs
+     * uaesk_gcm_ctr -- the fused kernels compare all sixteen bytes on the device.                        */
+    if (decrypt == 3) return run_ghash_levels(st, msg, nv, pl, sc, 0, (unsigned char *)status, nullptr);
+
     if (!decrypt) {
         rc = uaesk_ctr_xcrypt(stream, tb, nr, ek, &c, in, out, len, nullptr);
         if (rc) return rc;
@@ -1661,6 +1666,21 @@ extern "C" int uaesk_gcm(void *stream, const uaesk_tables *tb, int nr, const uae
                          void *scratch, int *status)
 {
     return gcm_body(stream, tb, nr, ek, decrypt, j0_16, aad, aad_len, in, len, out, scratch, status, 0);
+}
+
+/* the CTR half alone: in -> out under the keystream that starts at J0 + 1 (CTR_cipher mode CCM_GCM, :938-940) */
+extern "C" int uaesk_gcm_ctr(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek,
+                             const uint8_t *j0_16, const void *in, size_t len, void *out)
+{
+    uaesk_ctr c;
+    memset(&c, 0, sizeof c);
+    memcpy(&c.w0, j0_16, 4);
+    memcpy(&c.w1, j0_16 + 4, 4);
+    c.b8 = j0_16[8];
+    uint64_t v = 0;
+    for (int i = 9; i < 16; ++i) v = (v << 8) | j0_16[i];
+    c.v0 = (v + 1) & 0x00FFFFFFFFFFFFFFull;
+    return uaesk_ctr_xcrypt(stream, tb, nr, ek, &c, in, out, len, nullptr);
 }
 
 extern "C" int uaesk_gcm_keyed(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek,

@@ -106,19 +106,20 @@ __global__ __launch_bounds__(64) void k_cmac(uaesk_rk rk, uaesk_tables tb,
     row_store(mac, m, 16);
 }
 
-/* mode 0: write the tag to tag_io; mode 1: compare with tag_io, *status = 0 / 0x1A */
+/* mode 0: write the first tag_len bytes of the tag to tag_io; mode 1: compare them with tag_io, *status = 0 / 0x1A
+ * (tag_len = the reference's CCM_TAG_LEN, micro_aes.h:104: even, 4..16)                                       */
 template <int NR>
 __global__ __launch_bounds__(64) void k_ccm_tag(uaesk_rk rk, uaesk_tables tb, uint4 iv4,
                                                      const unsigned char *__restrict__ aad, u64 aad_len,
                                                      const unsigned char *__restrict__ pt, u64 pt_len,
-                                                     int mode, unsigned char *tag_io, int *status)
+                                                     int mode, unsigned char *tag_io, int *status, u32 tag_len)
 {
     row_fill_tables(tb.te0, rk);                 /* one wave: sixteen lanes per block, four rows redundantly */
     const RowLane<NR> L = row_lane<NR>();
     const Blk iv = { { iv4.x, iv4.y, iv4.z, iv4.w } };
     unsigned char b0[16], a[16];
     for (u32 i = 0; i < 16; ++i) b0[i] = (unsigned char)(iv.w[i >> 2] >> (8 * (i & 3)));
-    b0[0] |= (16 - 2) << 2;                               /* CCM_TAG_LEN = 16 (:1230)          */
+    b0[0] |= (unsigned char)((tag_len - 2) << 2);         /* (CCM_TAG_LEN - 2) << 2, :1229    */
     {
         u64 n = pt_len;                                   /* xorBEint(M, ptextLen, LAST)      */
         int pos = 15;
@@ -154,13 +155,13 @@ __global__ __launch_bounds__(64) void k_ccm_tag(uaesk_rk rk, uaesk_tables tb, ui
     cbcmac_absorb<NR>(m, pt, pt_len, L);
     m ^= row_encrypt<NR>(row_pick(iv.w, L.c), L);         /* tag = Enc(iv) ^ CBC-MAC           */
     if (mode == 0) {
-        row_store(tag_io, m, 16);
+        row_store(tag_io, m, tag_len);
     } else {
         Blk t;
         row_spread(m, t.w);
         if (threadIdx.x == 0) {
             u32 diff = 0;
-            for (u32 i = 0; i < 16; ++i) diff |= (u32)tag_io[i] ^ ((t.w[i >> 2] >> (8 * (i & 3))) & 0xffu);
+            for (u32 i = 0; i < tag_len; ++i) diff |= (u32)tag_io[i] ^ ((t.w[i >> 2] >> (8 * (i & 3))) & 0xffu);
             *status = diff ? 0x1A : 0;
         }
     }
@@ -195,28 +196,32 @@ extern "C" int uaesk_cmac(void *stream, const uaesk_tables *tb, int nr, const ua
 template <int NR>
 static int launch_ccm_tag(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek, uint4 iv,
                           const void *aad, size_t aad_len, const void *pt, size_t pt_len,
-                          int mode, void *tag_io, int *status)
+                          int mode, void *tag_io, int *status, u32 tag_len)
 {
     hipError_t e = hipFuncSetAttribute((const void *)k_ccm_tag<NR>, hipFuncAttributeMaxDynamicSharedMemorySize, UAES_LDS_ROW);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL((k_ccm_tag<NR>), dim3(1), dim3(64), UAES_LDS_ROW, st, *ek, *tb, iv,
                        (const unsigned char *)aad, (u64)aad_len, (const unsigned char *)pt, (u64)pt_len,
-                       mode, (unsigned char *)tag_io, status);
+                       mode, (unsigned char *)tag_io, status, tag_len);
     return (int)hipGetLastError();
 }
 
-/* nonce11 is a host pointer; everything else device memory.  encrypt: tag over
+/* nonce is a host pointer; everything else device memory.  encrypt: tag over
  * `in` (the plaintext) written at out+len, then CTR in -> out.  decrypt: CTR
  * in -> out first, then the tag over the decrypted text is compared with the
- * 16 bytes at in+len: like the reference (:1304-1312, SABOTAGE is a no-op in
- * its default build) the plaintext stays written even when *status = 0x1A.   */
+ * tag_len bytes at in+len: like the reference (:1304-1312, SABOTAGE is a no-op in
+ * its default build) the plaintext stays written even when *status = 0x1A.
+ * nonce_len / tag_len = the reference's CCM_NONCE_LEN (7..13) / CCM_TAG_LEN (even, 4..16).  Whatever the
+ * nonce length, the keystream counter is the 56-bit big-endian integer in bytes 9..15 (incBlock, :421-427).  */
 extern "C" int uaesk_ccm(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek,
-                         int decrypt, const uint8_t *nonce11,
+                         int decrypt, const uint8_t *nonce, size_t nonce_len, size_t tag_len,
                          const void *aad, size_t aad_len,
                          const void *in, size_t len, void *out, int *status)
 {
-    unsigned char ivb[16] = { 14 - 11 };                 /* iv = { 14 - CCM_NONCE_LEN, nonce, 0... } (:1273) */
-    memcpy(ivb + 1, nonce11, 11);
+    if (nonce_len < 7 || nonce_len > 13 || tag_len < 4 || tag_len > 16 || (tag_len & 1)) return (int)hipErrorInvalidValue;
+    unsigned char ivb[16] = { 0 };
+    ivb[0] = (unsigned char)(14 - nonce_len);            /* iv = { 14 - CCM_NONCE_LEN, nonce, 0... } (:1273) */
+    memcpy(ivb + 1, nonce, nonce_len);
     uint4 iv;
     memcpy(&iv, ivb, 16);
     uaesk_ctr c;
@@ -224,17 +229,22 @@ extern "C" int uaesk_ccm(void *stream, const uaesk_tables *tb, int nr, const uae
     memcpy(&c.w0, ivb, 4);
     memcpy(&c.w1, ivb + 4, 4);
     c.b8 = ivb[8];
-    c.v0 = ((uint64_t)ivb[9] << 48) | ((uint64_t)ivb[10] << 40) | ((uint64_t)ivb[11] << 32) | 1u;   /* pre-increment */
+    {
+        uint64_t v = 0;
+        for (int i = 9; i < 16; ++i) v = (v << 8) | ivb[i];
+        c.v0 = (v + 1) & 0x00FFFFFFFFFFFFFFull;          /* pre-increment */
+    }
+    const u32 tl = (u32)tag_len;
     int rc;
     if (!decrypt) {
         DISPATCH_NR(nr, rc = (launch_ccm_tag<NR>(S(stream), tb, ek, iv, aad, aad_len, in, len, 0,
-                                                 (unsigned char *)out + len, nullptr)));
+                                                 (unsigned char *)out + len, nullptr, tl)));
         if (rc) return rc;
         return uaesk_ctr_xcrypt(stream, tb, nr, ek, &c, in, out, len, nullptr);
     }
     rc = uaesk_ctr_xcrypt(stream, tb, nr, ek, &c, in, out, len, nullptr);
     if (rc) return rc;
     DISPATCH_NR(nr, rc = (launch_ccm_tag<NR>(S(stream), tb, ek, iv, aad, aad_len, out, len, 1,
-                                             (unsigned char *)in + len, status)));
+                                             (unsigned char *)in + len, status, tl)));
     return rc;
 }

@@ -306,7 +306,7 @@ __device__ __forceinline__ void ocb_final_body(const uaesk_rk &ek, const LaneCon
                                                uint4 *__restrict__ scr, u32 nparts, int decrypt,
                                                const unsigned char *__restrict__ aad, u64 aad_len,
                                                const unsigned char *in, unsigned char *out, u64 len,
-                                               int *status)
+                                               int *status, u32 tag_len)
 {
 
     /* HASH(K, A): Sum ^= Enc(A_i ^ Offset_i), Offset from zero (:1749-1754); all threads */
@@ -364,11 +364,11 @@ __device__ __forceinline__ void ocb_final_body(const uaesk_rk &ek, const LaneCon
     bx(ck, lds_row(1));                               /* ^ L_$ */
     ocb_enc1<NR>(ck, ek, lc);
     bx(ck, b16(*(const uint4 *)(uaes_lds + OCB_LDS_ACC)));
-    if (!decrypt) {
-        for (u32 i = 0; i < 16; ++i) out[len + i] = (unsigned char)(ck.w[i >> 2] >> (8 * (i & 3)));
+    if (!decrypt) {                                   /* the first OCB_TAG_LEN bytes (:1783 / :1807) */
+        for (u32 i = 0; i < tag_len; ++i) out[len + i] = (unsigned char)(ck.w[i >> 2] >> (8 * (i & 3)));
     } else {
         u32 diff = 0;
-        for (u32 i = 0; i < 16; ++i) diff |= (u32)in[len + i] ^ ((ck.w[i >> 2] >> (8 * (i & 3))) & 0xffu);
+        for (u32 i = 0; i < tag_len; ++i) diff |= (u32)in[len + i] ^ ((ck.w[i >> 2] >> (8 * (i & 3))) & 0xffu);
         *status = diff ? 0x1A : 0;
     }
 }
@@ -378,12 +378,12 @@ __global__ __launch_bounds__(UAES_WG) void k_ocb_final(uaesk_rk ek, uaesk_tables
                                                        uint4 *__restrict__ scr, u32 nparts, int decrypt,
                                                        const unsigned char *__restrict__ aad, u64 aad_len,
                                                        const unsigned char *in, unsigned char *out, u64 len,
-                                                       int *status)
+                                                       int *status, u32 tag_len)
 {
     ocb_tables_to_lds(scr);
     fill_enc_tables(tb.te0);
     const LaneConst lc = make_lane_const();
-    ocb_final_body<NR>(ek, lc, scr, nparts, decrypt, aad, aad_len, in, out, len, status);
+    ocb_final_body<NR>(ek, lc, scr, nparts, decrypt, aad, aad_len, in, out, len, status, tag_len);
 }
 
 /* Short messages (<= 1024 whole blocks, <= 64 KiB of associated data): setup, block loop and tag in ONE launch of
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(UAES_WG) void k_ocb_small(uaesk_rk ek, uaesk_rk dk,
                                                        uint4 *scr,
                                                        const unsigned char *__restrict__ aad, u64 aad_len,
                                                        const unsigned char *in, unsigned char *out, u64 len,
-                                                       int *status)
+                                                       int *status, u32 tag_len)
 {
 #ifdef UAES_OCB_TIMING
     u64 ts[6];
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(UAES_WG) void k_ocb_small(uaesk_rk ek, uaesk_rk dk,
     ocb_tables_to_lds(scr);
     if (DEC && nblocks) fill_enc_tables(tb.te0); else __syncthreads();
     OT(4);
-    ocb_final_body<NR>(ek, lc, scr, nparts, DEC ? 1 : 0, aad, aad_len, in, out, len, status);
+    ocb_final_body<NR>(ek, lc, scr, nparts, DEC ? 1 : 0, aad, aad_len, in, out, len, status, tag_len);
 #ifdef UAES_OCB_TIMING
     OT(5);
     if (threadIdx.x == 0)
@@ -487,7 +487,7 @@ static hipError_t want_lds(const void *kern)
 
 template <int NR>
 static int launch_ocb(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek, const uaesk_rk *dk,
-                      int decrypt, uint4 nb, u32 bottom, const void *aad, size_t aad_len,
+                      int decrypt, uint4 nb, u32 bottom, u32 tag_len, const void *aad, size_t aad_len,
                       const void *in, size_t len, void *out, void *scratch, int *status)
 {
     uint4 *scr = (uint4 *)scratch;
@@ -506,11 +506,11 @@ static int launch_ocb(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek
         if (decrypt)
             hipLaunchKernelGGL((k_ocb_small<NR, true>), dim3(1), dim3(UAES_WG), OCB_LDS, st, *ek, *dk, *tb, nb, bottom, nrows,
                                scr, (const unsigned char *)aad, (u64)aad_len, (const unsigned char *)in,
-                               (unsigned char *)out, (u64)len, status);
+                               (unsigned char *)out, (u64)len, status, tag_len);
         else
             hipLaunchKernelGGL((k_ocb_small<NR, false>), dim3(1), dim3(UAES_WG), OCB_LDS, st, *ek, *ek, *tb, nb, bottom, nrows,
                                scr, (const unsigned char *)aad, (u64)aad_len, (const unsigned char *)in,
-                               (unsigned char *)out, (u64)len, status);
+                               (unsigned char *)out, (u64)len, status, tag_len);
         return (int)hipGetLastError();
     }
     hipLaunchKernelGGL((k_ocb_setup<NR>), dim3(1), dim3(UAES_WG), OCB_LDS, st, *ek, *tb, nb, bottom, nrows, scr);
@@ -537,32 +537,37 @@ static int launch_ocb(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek
     }
     hipLaunchKernelGGL((k_ocb_final<NR>), dim3(1), dim3(UAES_WG), OCB_LDS, st, *ek, *tb, scr, nparts, decrypt,
                        (const unsigned char *)aad, (u64)aad_len, (const unsigned char *)in, (unsigned char *)out,
-                       (u64)len, status);
+                       (u64)len, status, tag_len);
     return (int)hipGetLastError();
 }
 
 extern "C" size_t uaesk_ocb_scratch_bytes(void) { return 16u * (OCB_ROW_PART + OCB_MAX_WGS); }
 
-/* nonce12 is a host pointer; everything else device memory (in/out 16-byte aligned).
- * encrypt: tag written at out+len.  decrypt: tag read at in+len, *status = 0 / 0x1A,
- * the text is written either way (as in the reference, :1804-1809).             */
+/* nonce is a host pointer; everything else device memory (in/out 16-byte aligned).
+ * encrypt: tag_len bytes of tag written at out+len.  decrypt: tag read at in+len, *status = 0 / 0x1A,
+ * the text is written either way (as in the reference, :1804-1809).
+ * nonce_len / tag_len = the reference's OCB_NONCE_LEN (1..15) / OCB_TAG_LEN (1..16), micro_aes.h:115-116 */
 extern "C" int uaesk_ocb(void *stream, const uaesk_tables *tb, int nr,
-                         const uaesk_rk *ek, const uaesk_rk *dk, int decrypt, const uint8_t *nonce12,
+                         const uaesk_rk *ek, const uaesk_rk *dk, int decrypt, const uint8_t *nonce,
+                         size_t nonce_len, size_t tag_len,
                          const void *aad, size_t aad_len, const void *in, size_t len, void *out,
                          void *scratch, int *status)
 {
+    if (nonce_len < 1 || nonce_len > 15 || tag_len < 1 || tag_len > 16) return (int)hipErrorInvalidValue;
     uint8_t kt[16];
     memset(kt, 0, sizeof kt);
-    memcpy(kt + 4, nonce12, 12);
-    kt[3] |= 1;                                       /* :1710 (tag length 128 encodes as 0 in the top 7 bits) */
+    memcpy(kt + 16 - nonce_len, nonce, nonce_len);    /* :1706 */
+    kt[0] |= (uint8_t)(tag_len << 4);                 /* :1707 (tag length 128 encodes as 0 in the top 7 bits) */
+    kt[15 - nonce_len] |= 1;                          /* :1708 */
     const u32 bottom = kt[15] & 63u;
     kt[15] &= 0xC0;
     uint4 nb;
     memcpy(&nb, kt, 16);
+    const u32 tl = (u32)tag_len;
     switch (nr) {
-    case 10: return launch_ocb<10>(S(stream), tb, ek, dk, decrypt, nb, bottom, aad, aad_len, in, len, out, scratch, status);
-    case 12: return launch_ocb<12>(S(stream), tb, ek, dk, decrypt, nb, bottom, aad, aad_len, in, len, out, scratch, status);
-    case 14: return launch_ocb<14>(S(stream), tb, ek, dk, decrypt, nb, bottom, aad, aad_len, in, len, out, scratch, status);
+    case 10: return launch_ocb<10>(S(stream), tb, ek, dk, decrypt, nb, bottom, tl, aad, aad_len, in, len, out, scratch, status);
+    case 12: return launch_ocb<12>(S(stream), tb, ek, dk, decrypt, nb, bottom, tl, aad, aad_len, in, len, out, scratch, status);
+    case 14: return launch_ocb<14>(S(stream), tb, ek, dk, decrypt, nb, bottom, tl, aad, aad_len, in, len, out, scratch, status);
     default: return (int)hipErrorInvalidValue;
     }
 }

@@ -47,6 +47,9 @@ class Oracle:
         L.orc_ecb_encrypt.argtypes = [i, vp, vp, sz, vp]; L.orc_ecb_encrypt.restype = None
         L.orc_gcm_encrypt_iv.argtypes = [i, vp, vp, sz, vp, sz, vp, sz, vp]; L.orc_gcm_encrypt_iv.restype = None
         L.orc_gcm_decrypt_iv.argtypes = [i, vp, vp, sz, vp, sz, vp, sz, vp]; L.orc_gcm_decrypt_iv.restype = C.c_char
+        for m in ("gcm", "ccm", "ocb"):
+            f = getattr(L, "orc_%s_encrypt_ex" % m); f.argtypes = [i, vp, vp, sz, sz, vp, sz, vp, sz, vp]; f.restype = None
+            f = getattr(L, "orc_%s_decrypt_ex" % m); f.argtypes = [i, vp, vp, sz, sz, vp, sz, vp, sz, vp]; f.restype = C.c_char
         L.orc_ecb_encrypt_padded.argtypes = [i, vp, i, vp, sz, vp]; L.orc_ecb_encrypt_padded.restype = None
         L.orc_ecb_decrypt.argtypes = [i, vp, vp, sz, vp]; L.orc_ecb_decrypt.restype = C.c_char
         L.orc_ctr_encrypt.argtypes = [i, vp, vp, vp, sz, vp]; L.orc_ctr_encrypt.restype = None
@@ -118,17 +121,17 @@ class Oracle:
                                     _buf(data), o, 1 if encrypt else 0)
         return ord(rc), bytes(o)[: len(data)]
 
-    def gcm_encrypt(self, key, nonce, aad, pt):
-        """len(nonce) plays the role of the reference's GCM_NONCE_LEN (12 = default build)"""
+    def gcm_encrypt(self, key, nonce, aad, pt, tag_len=16):
+        """len(nonce) / tag_len play the role of the reference's GCM_NONCE_LEN / GCM_TAG_LEN (12 / 16 = default build)"""
         o = _out(len(pt) + 16)
-        self.L.orc_gcm_encrypt_iv(len(key) * 8, _buf(key), _buf(nonce), len(nonce), _buf(aad), len(aad),
+        self.L.orc_gcm_encrypt_ex(len(key) * 8, _buf(key), _buf(nonce), len(nonce), tag_len, _buf(aad), len(aad),
                                   _buf(pt), len(pt), o)
-        return bytes(o)[: len(pt) + 16]
+        return bytes(o)[: len(pt) + tag_len]
 
-    def gcm_decrypt(self, key, nonce, aad, ct_and_tag, prefill=0xCC):
-        n = len(ct_and_tag) - 16
+    def gcm_decrypt(self, key, nonce, aad, ct_and_tag, prefill=0xCC, tag_len=16):
+        n = len(ct_and_tag) - tag_len
         o = (C.c_uint8 * max(n, 1))(*([prefill] * max(n, 1)))
-        rc = self.L.orc_gcm_decrypt_iv(len(key) * 8, _buf(key), _buf(nonce), len(nonce), _buf(aad), len(aad),
+        rc = self.L.orc_gcm_decrypt_ex(len(key) * 8, _buf(key), _buf(nonce), len(nonce), tag_len, _buf(aad), len(aad),
                                        _buf(ct_and_tag), n, o)
         return ord(rc), bytes(o)[:n]
 
@@ -153,17 +156,18 @@ class Oracle:
         self.L.orc_cmac(len(key) * 8, _buf(key), _buf(data), len(data), o)
         return bytes(o)
 
-    def ccm_encrypt(self, key, nonce, aad, pt):
+    def ccm_encrypt(self, key, nonce, aad, pt, tag_len=16):
+        """len(nonce) / tag_len = CCM_NONCE_LEN (7..13) / CCM_TAG_LEN (even, 4..16)"""
         o = _out(len(pt) + 16)
-        self.L.orc_ccm_encrypt(len(key) * 8, _buf(key), _buf(nonce), _buf(aad), len(aad),
-                               _buf(pt), len(pt), o)
-        return bytes(o)[: len(pt) + 16]
+        self.L.orc_ccm_encrypt_ex(len(key) * 8, _buf(key), _buf(nonce), len(nonce), tag_len, _buf(aad), len(aad),
+                                  _buf(pt), len(pt), o)
+        return bytes(o)[: len(pt) + tag_len]
 
-    def ccm_decrypt(self, key, nonce, aad, ct_and_tag, prefill=0xCC):
-        n = len(ct_and_tag) - 16
+    def ccm_decrypt(self, key, nonce, aad, ct_and_tag, prefill=0xCC, tag_len=16):
+        n = len(ct_and_tag) - tag_len
         o = (C.c_uint8 * max(n, 1))(*([prefill] * max(n, 1)))
-        rc = self.L.orc_ccm_decrypt(len(key) * 8, _buf(key), _buf(nonce), _buf(aad), len(aad),
-                                    _buf(ct_and_tag), n, o)
+        rc = self.L.orc_ccm_decrypt_ex(len(key) * 8, _buf(key), _buf(nonce), len(nonce), tag_len, _buf(aad), len(aad),
+                                       _buf(ct_and_tag), n, o)
         return ord(rc), bytes(o)[:n]
 
     def gcmsiv_encrypt(self, key, nonce, aad, pt):
@@ -179,17 +183,18 @@ class Oracle:
                                        _buf(ct_and_tag), n, o)
         return ord(rc), bytes(o)[:n]
 
-    def ocb_encrypt(self, key, nonce, aad, pt):
+    def ocb_encrypt(self, key, nonce, aad, pt, tag_len=16):
+        """len(nonce) / tag_len = OCB_NONCE_LEN (1..15) / OCB_TAG_LEN (1..16)"""
         o = _out(len(pt) + 16)
-        self.L.orc_ocb_encrypt(len(key) * 8, _buf(key), _buf(nonce), _buf(aad), len(aad),
-                               _buf(pt), len(pt), o)
-        return bytes(o)[: len(pt) + 16]
+        self.L.orc_ocb_encrypt_ex(len(key) * 8, _buf(key), _buf(nonce), len(nonce), tag_len, _buf(aad), len(aad),
+                                  _buf(pt), len(pt), o)
+        return bytes(o)[: len(pt) + tag_len]
 
-    def ocb_decrypt(self, key, nonce, aad, ct_and_tag, prefill=0xCC):
-        n = len(ct_and_tag) - 16
+    def ocb_decrypt(self, key, nonce, aad, ct_and_tag, prefill=0xCC, tag_len=16):
+        n = len(ct_and_tag) - tag_len
         o = (C.c_uint8 * max(n, 1))(*([prefill] * max(n, 1)))
-        rc = self.L.orc_ocb_decrypt(len(key) * 8, _buf(key), _buf(nonce), _buf(aad), len(aad),
-                                    _buf(ct_and_tag), n, o)
+        rc = self.L.orc_ocb_decrypt_ex(len(key) * 8, _buf(key), _buf(nonce), len(nonce), tag_len, _buf(aad), len(aad),
+                                       _buf(ct_and_tag), n, o)
         return ord(rc), bytes(o)[:n]
 
     def gf128_mul(self, x, y):
@@ -221,17 +226,22 @@ class Reference:
 
     PAD_SUFFIX = {0: "", 1: "_pkcs7", 2: "_iso7816"}
 
+    # builds with the other compile-time length constants patched (oracle/Makefile, micro_aes.h:103-116):
+    # name -> (key bits, CCM_NONCE_LEN, CCM_TAG_LEN, GCM_TAG_LEN, OCB_NONCE_LEN, OCB_TAG_LEN)
+    LENS = {"A": (128, 13, 4, 12, 15, 8), "B": (256, 7, 10, 4, 7, 12)}
+
     @classmethod
-    def path(cls, bits, padding=0, gcm_nonce_len=12, preset_counter=False):
+    def path(cls, bits, padding=0, gcm_nonce_len=12, preset_counter=False, lens=None):
         iv = "" if gcm_nonce_len == 12 else "_gcmiv%d" % gcm_nonce_len
         pc = "_presetctr" if preset_counter else ""
-        return os.path.join(HERE, "_ref", "libmicroaes_ref_%d%s%s%s.so" % (bits, cls.PAD_SUFFIX[padding], iv, pc))
+        ln = "_lens%s" % lens if lens else ""
+        return os.path.join(HERE, "_ref", "libmicroaes_ref_%d%s%s%s%s.so" % (bits, cls.PAD_SUFFIX[padding], iv, pc, ln))
 
     @classmethod
-    def available(cls, bits=128, padding=0, gcm_nonce_len=12, preset_counter=False):
-        return os.path.exists(cls.path(bits, padding, gcm_nonce_len, preset_counter))
+    def available(cls, bits=128, padding=0, gcm_nonce_len=12, preset_counter=False, lens=None):
+        return os.path.exists(cls.path(bits, padding, gcm_nonce_len, preset_counter, lens))
 
-    def __init__(self, bits, padding=0, gcm_nonce_len=12, preset_counter=False):
+    def __init__(self, bits, padding=0, gcm_nonce_len=12, preset_counter=False, lens=None):
         """padding / gcm_nonce_len / preset_counter: builds with AES_PADDING (micro_aes.h:79) /
         GCM_NONCE_LEN (:108) / PRESET_COUNTER (:100) patched (oracle/Makefile).  With preset_counter the
         `iv` of ctr_encrypt is the full 16-byte counter block (micro_aes.c:965-966)."""
@@ -239,7 +249,11 @@ class Reference:
         self.padding = padding
         self.gcm_nonce_len = gcm_nonce_len
         self.preset_counter = preset_counter
-        L = self.L = C.CDLL(self.path(bits, padding, gcm_nonce_len, preset_counter))
+        self.ccm_nonce, self.ccm_tag, self.gcm_tag, self.ocb_nonce, self.ocb_tag = 11, 16, 16, 12, 16
+        if lens:
+            assert self.LENS[lens][0] == bits
+            self.ccm_nonce, self.ccm_tag, self.gcm_tag, self.ocb_nonce, self.ocb_tag = self.LENS[lens][1:]
+        L = self.L = C.CDLL(self.path(bits, padding, gcm_nonce_len, preset_counter, lens))
         sz, vp = C.c_size_t, C.c_void_p
         L.AES_ECB_encrypt.argtypes = [vp, vp, sz, vp]; L.AES_ECB_encrypt.restype = None
         L.AES_ECB_decrypt.argtypes = [vp, vp, sz, vp]; L.AES_ECB_decrypt.restype = C.c_char
@@ -263,13 +277,15 @@ class Reference:
 
     def ocb_encrypt(self, key, nonce, aad, pt):
         self._chk(key)
+        assert len(nonce) == self.ocb_nonce
         o = _out(len(pt) + 16)
         self.L.AES_OCB_encrypt(_buf(key), _buf(nonce), _buf(aad), len(aad), _buf(pt), len(pt), o)
-        return bytes(o)[: len(pt) + 16]
+        return bytes(o)[: len(pt) + self.ocb_tag]
 
     def ocb_decrypt(self, key, nonce, aad, ct_and_tag, prefill=0xCC):
         self._chk(key)
-        n = len(ct_and_tag) - 16
+        assert len(nonce) == self.ocb_nonce
+        n = len(ct_and_tag) - self.ocb_tag
         o = (C.c_uint8 * max(n, 1))(*([prefill] * max(n, 1)))
         rc = self.L.AES_OCB_decrypt(_buf(key), _buf(nonce), _buf(aad), len(aad), _buf(ct_and_tag), n, o)
         return ord(rc), bytes(o)[:n]
@@ -314,13 +330,15 @@ class Reference:
 
     def ccm_encrypt(self, key, nonce, aad, pt):
         self._chk(key)
+        assert len(nonce) == self.ccm_nonce
         o = _out(len(pt) + 16)
         self.L.AES_CCM_encrypt(_buf(key), _buf(nonce), _buf(aad), len(aad), _buf(pt), len(pt), o)
-        return bytes(o)[: len(pt) + 16]
+        return bytes(o)[: len(pt) + self.ccm_tag]
 
     def ccm_decrypt(self, key, nonce, aad, ct_and_tag, prefill=0xCC):
         self._chk(key)
-        n = len(ct_and_tag) - 16
+        assert len(nonce) == self.ccm_nonce
+        n = len(ct_and_tag) - self.ccm_tag
         o = (C.c_uint8 * max(n, 1))(*([prefill] * max(n, 1)))
         rc = self.L.AES_CCM_decrypt(_buf(key), _buf(nonce), _buf(aad), len(aad), _buf(ct_and_tag), n, o)
         return ord(rc), bytes(o)[:n]
@@ -358,11 +376,11 @@ class Reference:
         self._chk(key)
         o = _out(len(pt) + 16)
         self.L.AES_GCM_encrypt(_buf(key), _buf(nonce), _buf(aad), len(aad), _buf(pt), len(pt), o)
-        return bytes(o)[: len(pt) + 16]
+        return bytes(o)[: len(pt) + self.gcm_tag]
 
     def gcm_decrypt(self, key, nonce, aad, ct_and_tag, prefill=0xCC):
         self._chk(key)
-        n = len(ct_and_tag) - 16
+        n = len(ct_and_tag) - self.gcm_tag
         o = (C.c_uint8 * max(n, 1))(*([prefill] * max(n, 1)))
         rc = self.L.AES_GCM_decrypt(_buf(key), _buf(nonce), _buf(aad), len(aad),
                                     _buf(ct_and_tag), n, o)

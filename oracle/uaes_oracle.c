@@ -423,7 +423,9 @@ static void gcm_setup_iv(orc_key *ks, int keybits, const uint8_t *key,
     J0[15] = 1;
 }
 
-void orc_gcm_encrypt_iv(int keybits, const uint8_t *key, const uint8_t *nonce, size_t nonce_len,
+/* tag_len = the reference's compile-time GCM_TAG_LEN (micro_aes.h:109): the first tag_len bytes of the
+ * tag are written (:1178) / compared (:1204)                                                        */
+void orc_gcm_encrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, size_t nonce_len, size_t tag_len,
                         const void *aad, size_t aad_len,
                         const void *pt, size_t len, void *ct_and_tag)
 {
@@ -436,7 +438,14 @@ void orc_gcm_encrypt_iv(int keybits, const uint8_t *key, const uint8_t *nonce, s
     orc_encrypt_block(&ks, J0, J0);            /* tag mask, :1173             */
     orc_ghash(H, aad, aad_len, out, len, G);
     xor16(G, J0);
-    memcpy(out + len, G, 16);
+    memcpy(out + len, G, tag_len);
+}
+
+void orc_gcm_encrypt_iv(int keybits, const uint8_t *key, const uint8_t *nonce, size_t nonce_len,
+                        const void *aad, size_t aad_len,
+                        const void *pt, size_t len, void *ct_and_tag)
+{
+    orc_gcm_encrypt_ex(keybits, key, nonce, nonce_len, 16, aad, aad_len, pt, len, ct_and_tag);
 }
 
 void orc_gcm_encrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
@@ -446,7 +455,7 @@ void orc_gcm_encrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
     orc_gcm_encrypt_iv(keybits, key, nonce, 12, aad, aad_len, pt, len, ct_and_tag);
 }
 
-char orc_gcm_decrypt_iv(int keybits, const uint8_t *key, const uint8_t *nonce, size_t nonce_len,
+char orc_gcm_decrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, size_t nonce_len, size_t tag_len,
                         const void *aad, size_t aad_len,
                         const void *ct_and_tag, size_t len, void *pt)
 {
@@ -457,11 +466,18 @@ char orc_gcm_decrypt_iv(int keybits, const uint8_t *key, const uint8_t *nonce, s
     orc_ghash(H, aad, aad_len, in, len, G);    /* N7: authenticate first      */
     orc_encrypt_block(&ks, J0, E);
     xor16(G, E);
-    if (memcmp(G, in + len, 16)) return ORC_E_AUTH;   /* pt left untouched    */
+    if (memcmp(G, in + len, tag_len)) return ORC_E_AUTH;   /* pt left untouched */
     memcpy(c, J0, 16);
     ctr56_add(c, 1);
     ctr_stream(&ks, c, in, len, (uint8_t *)pt);
     return ORC_OK;
+}
+
+char orc_gcm_decrypt_iv(int keybits, const uint8_t *key, const uint8_t *nonce, size_t nonce_len,
+                        const void *aad, size_t aad_len,
+                        const void *ct_and_tag, size_t len, void *pt)
+{
+    return orc_gcm_decrypt_ex(keybits, key, nonce, nonce_len, 16, aad, aad_len, ct_and_tag, len, pt);
 }
 
 char orc_gcm_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
@@ -625,14 +641,14 @@ static void be_xor(uint8_t *buf, size_t num, int pos)          /* xorBEint :410 
     do buf[pos--] ^= (uint8_t)num; while (num >>= 8);
 }
 
-static void ccm_tag(const orc_key *ks, const uint8_t iv[16], const uint8_t *aad, size_t alen,
+static void ccm_tag(const orc_key *ks, const uint8_t iv[16], size_t tag_len, const uint8_t *aad, size_t alen,
                     const uint8_t *pt, size_t plen, uint8_t m[16])
 {
     uint8_t a[16] = { 0 }, e[16];
     size_t s = 0;
     int p = 1;
     memcpy(m, iv, 16);
-    m[0] |= (16 - 2) << 2;
+    m[0] |= (uint8_t)((tag_len - 2) << 2);     /* :1229 */
     be_xor(m, plen, 15);
     if (alen) {
         m[0] |= 0x40;
@@ -650,42 +666,59 @@ static void ccm_tag(const orc_key *ks, const uint8_t iv[16], const uint8_t *aad,
     xor16(m, e);
 }
 
-static void ccm_iv(const uint8_t *nonce, uint8_t iv[16])
+static void ccm_iv(const uint8_t *nonce, size_t nonce_len, uint8_t iv[16])
 {
     memset(iv, 0, 16);
-    iv[0] = 14 - 11;
-    memcpy(iv + 1, nonce, 11);
+    iv[0] = (uint8_t)(14 - nonce_len);        /* :1273 */
+    memcpy(iv + 1, nonce, nonce_len);
+}
+
+/* nonce_len / tag_len = the reference's compile-time CCM_NONCE_LEN (7..13) and CCM_TAG_LEN (even, 4..16),
+ * micro_aes.h:103-104.  Whatever the nonce length, the keystream counter is stepped by the same 56-bit
+ * incBlock (bytes 15..9, N2) and the text length is XORed in from byte 15 downwards (xorBEint, :1230).  */
+void orc_ccm_encrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, size_t nonce_len, size_t tag_len,
+                        const void *aad, size_t aad_len,
+                        const void *pt, size_t len, void *ct_and_tag)
+{
+    orc_key ks;
+    uint8_t iv[16], c[16], tag[16], *out = (uint8_t *)ct_and_tag;
+    if (orc_setkey(&ks, key, keybits)) return;
+    ccm_iv(nonce, nonce_len, iv);
+    ccm_tag(&ks, iv, tag_len, (const uint8_t *)aad, aad_len, (const uint8_t *)pt, len, tag);
+    memcpy(c, iv, 16);
+    ctr56_add(c, 1);
+    ctr_stream(&ks, c, (const uint8_t *)pt, len, out);
+    memcpy(out + len, tag, tag_len);
 }
 
 void orc_ccm_encrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
                      const void *aad, size_t aad_len,
                      const void *pt, size_t len, void *ct_and_tag)
 {
+    orc_ccm_encrypt_ex(keybits, key, nonce, 11, 16, aad, aad_len, pt, len, ct_and_tag);
+}
+
+char orc_ccm_decrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, size_t nonce_len, size_t tag_len,
+                        const void *aad, size_t aad_len,
+                        const void *ct_and_tag, size_t len, void *pt)
+{
     orc_key ks;
-    uint8_t iv[16], c[16], tag[16], *out = (uint8_t *)ct_and_tag;
-    if (orc_setkey(&ks, key, keybits)) return;
-    ccm_iv(nonce, iv);
-    ccm_tag(&ks, iv, (const uint8_t *)aad, aad_len, (const uint8_t *)pt, len, tag);
+    uint8_t iv[16], c[16], tag[16];
+    const uint8_t *in = (const uint8_t *)ct_and_tag;
+    if (orc_setkey(&ks, key, keybits)) return ORC_E_DECRYPT;
+    ccm_iv(nonce, nonce_len, iv);
     memcpy(c, iv, 16);
     ctr56_add(c, 1);
-    ctr_stream(&ks, c, (const uint8_t *)pt, len, out);
-    memcpy(out + len, tag, 16);
+    ctr_stream(&ks, c, in, len, (uint8_t *)pt);        /* decrypt first (:1304) */
+    ccm_tag(&ks, iv, tag_len, (const uint8_t *)aad, aad_len, (const uint8_t *)pt, len, tag);
+    return memcmp(tag, in + len, tag_len) ? ORC_E_AUTH : ORC_OK;    /* text stays (SABOTAGE no-op) */
 }
 
 char orc_ccm_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
                      const void *aad, size_t aad_len,
                      const void *ct_and_tag, size_t len, void *pt)
 {
-    orc_key ks;
-    uint8_t iv[16], c[16], tag[16];
-    const uint8_t *in = (const uint8_t *)ct_and_tag;
-    if (orc_setkey(&ks, key, keybits)) return ORC_E_DECRYPT;
-    ccm_iv(nonce, iv);
-    memcpy(c, iv, 16);
-    ctr56_add(c, 1);
-    ctr_stream(&ks, c, in, len, (uint8_t *)pt);        /* decrypt first (:1304) */
-    ccm_tag(&ks, iv, (const uint8_t *)aad, aad_len, (const uint8_t *)pt, len, tag);
-    return memcmp(tag, in + len, 16) ? ORC_E_AUTH : ORC_OK;    /* text stays (SABOTAGE no-op) */
+    return orc_ccm_decrypt_ex(keybits, key, nonce, 11, 16, aad, aad_len, ct_and_tag, len, pt);
 }
 
 /* ------------------------------------------------------------------------ */
@@ -828,13 +861,14 @@ static int ntz64(uint64_t i) { int n = 0; while (!(i & 1)) { i >>= 1; ++n; } ret
 
 /* Offset_0 from the nonce: Ktop = Enc(0^7 1-padded nonce with the low 6 bits cleared),
  * Stretch = Ktop || (Ktop[0..7] ^ Ktop[1..8]), Offset_0 = Stretch[bottom .. bottom+127] */
-static void ocb_offset0(const ocb_ctx *o, const uint8_t *nonce, uint8_t off[16])
+static void ocb_offset0(const ocb_ctx *o, const uint8_t *nonce, size_t nonce_len, size_t tag_len, uint8_t off[16])
 {
     uint8_t kt[24];
-    int i, bottom = nonce[11] & 63, sh = bottom & 7, by = bottom >> 3;
+    int i, bottom = nonce[nonce_len - 1] & 63, sh = bottom & 7, by = bottom >> 3;     /* :1703 */
     memset(kt, 0, sizeof kt);
-    memcpy(kt + 4, nonce, 12);
-    kt[3] |= 1;                               /* taglen 128 mod 128 = 0 in the top 7 bits */
+    memcpy(kt + 16 - nonce_len, nonce, nonce_len);                                    /* :1706 */
+    kt[0] |= (uint8_t)(tag_len << 4);         /* :1707, taglen 128 mod 128 = 0 in the top 7 bits */
+    kt[15 - nonce_len] |= 1;                  /* :1708 */
     kt[15] &= 0xC0;
     orc_encrypt_block(&o->k, kt, kt);
     for (i = 0; i < 8; ++i) kt[16 + i] = (uint8_t)(kt[i] ^ kt[i + 1]);
@@ -863,14 +897,14 @@ static void ocb_hash(const ocb_ctx *o, const uint8_t *a, size_t alen, uint8_t su
     }
 }
 
-static void ocb_crypt(const ocb_ctx *o, const uint8_t *nonce, int decrypt,
+static void ocb_crypt(const ocb_ctx *o, const uint8_t *nonce, size_t nonce_len, size_t tag_len, int decrypt,
                       const uint8_t *aad, size_t alen, const uint8_t *in, size_t len,
                       uint8_t *out, uint8_t tag[16])
 {
     uint8_t off[16], sum[16] = { 0 }, t[16], h[16];
     uint64_t i, m = len / 16;
     size_t r = len % 16, k;
-    ocb_offset0(o, nonce, off);
+    ocb_offset0(o, nonce, nonce_len, tag_len, off);
     for (i = 1; i <= m; ++i, in += 16, out += 16) {
         xor16(off, o->L[ntz64(i)]);
         memcpy(t, in, 16);
@@ -898,29 +932,47 @@ static void ocb_crypt(const ocb_ctx *o, const uint8_t *nonce, int decrypt,
     xor16(tag, h);
 }
 
-void orc_ocb_encrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
-                     const void *aad, size_t aad_len,
-                     const void *pt, size_t len, void *ct_and_tag)
+/* nonce_len / tag_len = the reference's compile-time OCB_NONCE_LEN (1..15) and OCB_TAG_LEN (1..16),
+ * micro_aes.h:115-116                                                                             */
+void orc_ocb_encrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, size_t nonce_len, size_t tag_len,
+                        const void *aad, size_t aad_len,
+                        const void *pt, size_t len, void *ct_and_tag)
 {
     ocb_ctx o;
     uint8_t tag[16];
     ocb_setup(&o, keybits, key);
-    ocb_crypt(&o, nonce, 0, (const uint8_t *)aad, aad_len, (const uint8_t *)pt, len, (uint8_t *)ct_and_tag, tag);
-    memcpy((uint8_t *)ct_and_tag + len, tag, 16);
+    ocb_crypt(&o, nonce, nonce_len, tag_len, 0, (const uint8_t *)aad, aad_len, (const uint8_t *)pt, len,
+              (uint8_t *)ct_and_tag, tag);
+    memcpy((uint8_t *)ct_and_tag + len, tag, tag_len);
+}
+
+void orc_ocb_encrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
+                     const void *aad, size_t aad_len,
+                     const void *pt, size_t len, void *ct_and_tag)
+{
+    orc_ocb_encrypt_ex(keybits, key, nonce, 12, 16, aad, aad_len, pt, len, ct_and_tag);
 }
 
 /* like the reference, the text is decrypted before the tag is known to be good and stays
  * in pt on a mismatch (SABOTAGE is a no-op, :382)                                      */
+char orc_ocb_decrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, size_t nonce_len, size_t tag_len,
+                        const void *aad, size_t aad_len,
+                        const void *ct_and_tag, size_t len, void *pt)
+{
+    ocb_ctx o;
+    uint8_t tag[16], given[16];
+    memcpy(given, (const uint8_t *)ct_and_tag + len, tag_len);
+    ocb_setup(&o, keybits, key);
+    ocb_crypt(&o, nonce, nonce_len, tag_len, 1, (const uint8_t *)aad, aad_len, (const uint8_t *)ct_and_tag, len,
+              (uint8_t *)pt, tag);
+    return memcmp(tag, given, tag_len) ? ORC_E_AUTH : ORC_OK;
+}
+
 char orc_ocb_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
                      const void *aad, size_t aad_len,
                      const void *ct_and_tag, size_t len, void *pt)
 {
-    ocb_ctx o;
-    uint8_t tag[16], given[16];
-    memcpy(given, (const uint8_t *)ct_and_tag + len, 16);
-    ocb_setup(&o, keybits, key);
-    ocb_crypt(&o, nonce, 1, (const uint8_t *)aad, aad_len, (const uint8_t *)ct_and_tag, len, (uint8_t *)pt, tag);
-    return memcmp(tag, given, 16) ? ORC_E_AUTH : ORC_OK;
+    return orc_ocb_decrypt_ex(keybits, key, nonce, 12, 16, aad, aad_len, ct_and_tag, len, pt);
 }
 
 /* ------------------------------------------------------------------------ */

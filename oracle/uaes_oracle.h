@@ -93,6 +93,13 @@ void orc_gcm_encrypt_iv(int keybits, const uint8_t *key, const uint8_t *nonce, s
 char orc_gcm_decrypt_iv(int keybits, const uint8_t *key, const uint8_t *nonce, size_t nonce_len,
                         const void *aad, size_t aad_len,
                         const void *ct_and_tag, size_t len, void *pt);
+/* tag_len: the reference's compile-time GCM_TAG_LEN (micro_aes.h:109): tag_len bytes appended / compared */
+void orc_gcm_encrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, size_t nonce_len, size_t tag_len,
+                        const void *aad, size_t aad_len,
+                        const void *pt, size_t len, void *ct_and_tag);
+char orc_gcm_decrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, size_t nonce_len, size_t tag_len,
+                        const void *aad, size_t aad_len,
+                        const void *ct_and_tag, size_t len, void *pt);
 void orc_gcm_encrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
                      const void *aad, size_t aad_len,
                      const void *pt, size_t len, void *ct_and_tag);
@@ -122,6 +129,14 @@ char orc_ccm_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
                      const void *aad, size_t aad_len,
                      const void *ct_and_tag, size_t len, void *pt);
 
+/* nonce_len / tag_len: the reference's compile-time CCM_NONCE_LEN (7..13) / CCM_TAG_LEN (even, 4..16), micro_aes.h:103-104 */
+void orc_ccm_encrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, size_t nonce_len, size_t tag_len,
+                        const void *aad, size_t aad_len,
+                        const void *pt, size_t len, void *ct_and_tag);
+char orc_ccm_decrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, size_t nonce_len, size_t tag_len,
+                        const void *aad, size_t aad_len,
+                        const void *ct_and_tag, size_t len, void *pt);
+
 /* micro_aes.c:1473-1515 GCM_SIV_encrypt/decrypt (RFC 8452); 12-byte nonce */
 void orc_gcmsiv_encrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
                         const void *aad, size_t aad_len,
@@ -137,6 +152,14 @@ void orc_ocb_encrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
 char orc_ocb_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
                      const void *aad, size_t aad_len,
                      const void *ct_and_tag, size_t len, void *pt);
+
+/* nonce_len / tag_len: the reference's compile-time OCB_NONCE_LEN (1..15) / OCB_TAG_LEN (1..16), micro_aes.h:115-116 */
+void orc_ocb_encrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, size_t nonce_len, size_t tag_len,
+                        const void *aad, size_t aad_len,
+                        const void *pt, size_t len, void *ct_and_tag);
+char orc_ocb_decrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, size_t nonce_len, size_t tag_len,
+                        const void *aad, size_t aad_len,
+                        const void *ct_and_tag, size_t len, void *pt);
 
 /* SURVEY.md section 8d synthetic input: 64-bit LE word w of the stream is
  * splitmix64(seed + (w+1)*0x9E3779B97F4A7C15); fills [word0, word0+nwords) */

@@ -88,7 +88,9 @@ def cmac_cases(keybits):
     return cases
 
 
-def ccm_cases(keybits):
+def ccm_cases(keybits, nonce_len=11):
+    """VNT<bits>.rsp: the [Nlen = nonce_len] section (the reference's harness takes the one that equals its
+    CCM_NONCE_LEN, aes_testvectors_CCM.h:84; every section has 16-byte tags)"""
     path = os.path.join(GOLDEN, "VNT%d.rsp" % keybits)
     cases, key, cur = [], None, {}
     with open(path) as f:
@@ -105,7 +107,7 @@ def ccm_cases(keybits):
                 cur[k] = bytes.fromhex(v)
             elif k == "CT" and "Payload" in cur:
                 cur[k] = bytes.fromhex(v)
-                if (len(cur["Key"]) * 8 == keybits and len(cur["Nonce"]) == 11
+                if (len(cur["Key"]) * 8 == keybits and len(cur["Nonce"]) == nonce_len
                         and len(cur["CT"]) - 16 == len(cur["Payload"])):
                     cases.append(cur)
                 cur = {}
@@ -133,15 +135,15 @@ def gcmsiv_cases(keybits):
     return cases
 
 
-def ocb_cases(keybits):
-    """OCB_AES128.tv (OpenSSL evp format), filter of testvectors/aes_testvectors_OCB.h:86-88: key of
-    AES_KEYLENGTH bytes, 12-byte nonce, 16-byte tag (the last Tag line of a stanza wins)"""
+def ocb_cases(keybits, nonce_len=12, tag_len=16):
+    """OCB_AES128.tv (OpenSSL evp format), filter of testvectors/aes_testvectors_OCB.h:86-90: key of
+    AES_KEYLENGTH bytes, OCB_NONCE_LEN-byte nonce, OCB_TAG_LEN-byte tag (the last Tag line of a stanza wins)"""
     path = os.path.join(GOLDEN, "OCB_AES128.tv")
     cases, cur = [], {}
 
     def flush():
         if {"Key", "IV", "Tag", "Plaintext", "Ciphertext"} <= set(cur) and "Result" not in cur:
-            if len(cur["Key"]) * 8 == keybits and len(cur["IV"]) == 12 and len(cur["Tag"]) == 16:
+            if len(cur["Key"]) * 8 == keybits and len(cur["IV"]) == nonce_len and len(cur["Tag"]) == tag_len:
                 cases.append(dict(key=cur["Key"], iv=cur["IV"], aad=cur.get("AAD", b""), pt=cur["Plaintext"],
                                   ct=cur["Ciphertext"] + cur["Tag"]))
     with open(path) as f:

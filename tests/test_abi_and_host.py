@@ -54,25 +54,32 @@ def test_compat_header_compiles_as_c89_and_matches_reference_constants(tmp_path)
 
 
 def test_compat_header_binds_function_pointers_under_the_callers_switches(tmp_path):
-    """-DGCM_NONCE_LEN=n / -DPRESET_COUNTER=1 / -DAES_PADDING=1 are compile-time switches of the CALLER's
-    build (micro_aes.h:79,100,108).  The header must bind a function POINTER -- not only a direct call --
+    """-DGCM_NONCE_LEN=n / -DPRESET_COUNTER=1 / -DAES_PADDING=1 and the other length constants (-DGCM_TAG_LEN,
+    -DCCM_NONCE_LEN, -DCCM_TAG_LEN, -DOCB_NONCE_LEN, -DOCB_TAG_LEN) are compile-time switches of the CALLER's
+    build (micro_aes.h:79,100,103-116).  The header must bind a function POINTER -- not only a direct call --
     to the matching entry point: object-like macros, never function-like ones; and stay C89-clean."""
     src = tmp_path / "p.c"
     src.write_text('#include "micro_aes.h"\n'
                    'typedef void (*gcm_fn)(const uint8_t*, const uint8_t*, const void*, const size_t, const void*, const size_t, void*);\n'
                    'typedef void (*ctr_fn)(const uint8_t*, const uint8_t*, const void*, const size_t, void*);\n'
                    'typedef void (*ecb_fn)(const uint8_t*, const void*, const size_t, void*);\n'
-                   'gcm_fn table_g[1] = { AES_GCM_encrypt };\n'
+                   'gcm_fn table_g[3] = { AES_GCM_encrypt, AES_CCM_encrypt, AES_OCB_encrypt };\n'
                    'ctr_fn table_c[2] = { AES_CTR_encrypt, AES_CTR_decrypt };\n'
                    'ecb_fn table_e[1] = { AES_ECB_encrypt };\n'
-                   'int main(void) { return (table_g[0] && table_c[0] && table_e[0] && GCM_NONCE_LEN == 7) ? 0 : 1; }\n')
+                   'int main(void) { return (table_g[0] && table_c[0] && table_e[0] && GCM_NONCE_LEN == 7 && GCM_TAG_LEN == 16\n'
+                   '                         && CCM_NONCE_LEN == 13 && CCM_TAG_LEN == 8 && OCB_NONCE_LEN == 12 && OCB_TAG_LEN == 12) ? 0 : 1; }\n')
     obj = tmp_path / "p.o"
     subprocess.run(["gcc", "-std=c89", "-pedantic", "-Wall", "-Werror", "-DGCM_NONCE_LEN=7", "-DPRESET_COUNTER=1",
-                    "-DAES_PADDING=1", "-I", os.path.join(ROOT, "include"), "-c", str(src), "-o", str(obj)], check=True)
+                    "-DAES_PADDING=1", "-DCCM_NONCE_LEN=13", "-DCCM_TAG_LEN=8", "-DOCB_TAG_LEN=12", "-I", os.path.join(ROOT, "include"), "-c", str(src), "-o", str(obj)], check=True)
     syms = subprocess.run(["nm", "-u", str(obj)], check=True, capture_output=True, text=True).stdout
-    assert "AES_GCM_encrypt_ivlen" in syms and "AES_CTR_encrypt_preset" in syms and "AES_CTR_decrypt_preset" in syms
-    assert "AES_ECB_encrypt_pkcs7" in syms
-    assert not re.search(r"\bAES_GCM_encrypt$|\bAES_CTR_encrypt$|\bAES_ECB_encrypt$", syms, flags=re.M)
+    assert "AES_GCM_encrypt_lens" in syms and "AES_CTR_encrypt_preset" in syms and "AES_CTR_decrypt_preset" in syms
+    assert "AES_ECB_encrypt_pkcs7" in syms and "AES_CCM_encrypt_lens" in syms and "AES_OCB_encrypt_lens" in syms
+    assert not re.search(r"\bAES_GCM_encrypt$|\bAES_CTR_encrypt$|\bAES_ECB_encrypt$|\bAES_CCM_encrypt$|\bAES_OCB_encrypt$",
+                         syms, flags=re.M)
+    # a length outside the mode's range does not compile
+    bad = subprocess.run(["gcc", "-std=c89", "-DCCM_TAG_LEN=5", "-I", os.path.join(ROOT, "include"), "-c", str(src), "-o", str(obj)],
+                         capture_output=True, text=True)
+    assert bad.returncode != 0 and "uaes_ccm_lengths_ok" in bad.stderr
 
 
 @pytest.mark.parametrize("bits", [128, 192, 256])
@@ -156,7 +163,10 @@ def test_python_wrappers_reject_wrong_sized_nonces():
                  lambda: uaes.ctr_xcrypt_at(k, bytes(12), 0, b"x"), lambda: uaes.AES_XTS_encrypt(bytes(32), bytes(8), bytes(16)),
                  lambda: uaes.AES_GCM_encrypt(k, b"", b"", b"x"), lambda: uaes.AES_GCM_decrypt(k, b"", b"", bytes(17)),
                  lambda: uaes.gcm_encrypt_dev(k, bytes(16), None, None, 0, None),
-                 lambda: uaes.AES_CCM_encrypt(k, bytes(12), b"", b"x"), lambda: uaes.AES_OCB_encrypt(k, bytes(15), b"", b"x"),
+                 lambda: uaes.AES_CCM_encrypt(k, bytes(6), b"", b"x"), lambda: uaes.AES_CCM_encrypt(k, bytes(14), b"", b"x"),
+                 lambda: uaes.AES_CCM_encrypt(k, bytes(11), b"", b"x", tag_len=5), lambda: uaes.AES_CCM_decrypt(k, bytes(11), b"", bytes(9), tag_len=2),
+                 lambda: uaes.AES_OCB_encrypt(k, bytes(16), b"", b"x"), lambda: uaes.AES_OCB_encrypt(k, b"", b"", b"x"),
+                 lambda: uaes.AES_OCB_encrypt(k, bytes(12), b"", b"x", tag_len=17), lambda: uaes.AES_GCM_encrypt(k, bytes(12), b"", b"x", tag_len=0),
                  lambda: uaes.GCM_SIV_encrypt(k, bytes(13), b"", b"x"), lambda: uaes.AES_CBC_encrypt(k, bytes(12), bytes(16)),
                  lambda: uaes.GcmStream(k, bytes(16)), lambda: uaes.ghash(bytes(15), b"", b"x"),
                  lambda: uaes.AES_ECB_encrypt(k, b"x", padding=3)):

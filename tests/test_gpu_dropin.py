@@ -51,6 +51,27 @@ def test_reference_harness_with_other_gcm_nonce_lengths(exe, bits, want, tmp_pat
     assert got == want, r.stdout
 
 
+@pytest.mark.parametrize("exe,bits,want", [
+    ("harness_hip_128_lens1", 128, {"CMAC": 96, "GCM": 375, "CCM": 10, "OCB": 7, "GCM-SIV": 102, "XTS": 800}),
+    ("harness_hip_256_lens2", 256, {"CMAC": 96, "GCM": 375, "CCM": 10, "XTS": 600})])
+def test_reference_harness_with_other_length_constants(exe, bits, want, tmp_path, golden_dir):
+    """the unchanged harness built with -DCCM_NONCE_LEN=13 -DGCM_TAG_LEN=12 -DOCB_TAG_LEN=12 (AES-128) and
+    -DCCM_NONCE_LEN=7 -DGCM_TAG_LEN=4 (AES-256) against include/micro_aes.h: it then runs the [Nlen = 13] / [Nlen = 7]
+    sections of the VNT files, compares 12 / 4 bytes of every GCM tag and takes the seven 12-byte-tag OCB stanzas (one of them an expected failure)
+    (aes_testvectors_CCM.h:84, _GCM.h:24,86, _OCB.h:90) -- all on the HIP library"""
+    path = os.path.join(REF, exe)
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/%s was not built" % exe)
+    for f in os.listdir(golden_dir):
+        if f.endswith((".rsp", ".tv")):
+            os.symlink(os.path.join(golden_dir, f), tmp_path / f)
+    r = subprocess.run([path], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = dict((m, int(n)) for m, n in re.findall(
+        r"Verifying vectors: AES%d-([\w-]+)\s+Nmber of tests:\s*(\d+), All Passed!" % bits, r.stdout))
+    assert got == want, r.stdout
+
+
 @pytest.mark.parametrize("bits", [128, 192, 256])
 def test_reference_main_c_runs_on_the_hip_library(bits):
     exe = os.path.join(REF, "main_hip_%d" % bits)

@@ -154,6 +154,125 @@ def test_ccm_rsp_through_compat_api(bits):
         assert ord(rc) == 0 and bytes(pt)[:n] == c["Payload"]
 
 
+class CompatLens(Compat):
+    """the general entry points a caller built with -DCCM_NONCE_LEN / -DGCM_TAG_LEN / ... is bound to"""
+
+    def __init__(self, bits):
+        super().__init__(bits)
+        sz, vp = C.c_size_t, C.c_void_p
+        for m in ("GCM", "CCM", "OCB"):
+            f = getattr(self.L, "AES_%s_encrypt_lens" % m); f.argtypes = [sz, sz, vp, vp, vp, sz, vp, sz, vp]; f.restype = None
+            f = getattr(self.L, "AES_%s_decrypt_lens" % m); f.argtypes = [sz, sz, vp, vp, vp, sz, vp, sz, vp]; f.restype = C.c_char
+
+    def enc(self, mode, key, nonce, tl, aad, pt):
+        out = self.buf(len(pt) + 16)
+        getattr(self.L, "AES_%s_encrypt_lens" % mode)(len(nonce), tl, key, nonce, aad, len(aad), pt, len(pt), out)
+        assert bytes(out)[len(pt) + tl:] == b"\xCC" * (16 - tl) or tl == 16      # nothing behind the tag
+        return bytes(out)[: len(pt) + tl]
+
+    def dec(self, mode, key, nonce, tl, aad, ct):
+        n = len(ct) - tl
+        out = self.buf(n)
+        rc = getattr(self.L, "AES_%s_decrypt_lens" % mode)(len(nonce), tl, key, nonce, aad, len(aad), ct, n, out)
+        return ord(rc), bytes(out)[:n]
+
+
+@pytest.mark.parametrize("bits", [128, 192, 256])
+def test_ccm_rsp_every_nonce_length_through_compat_api(bits):
+    """all seven [Nlen = 7..13] sections of the NIST VNT files (the reference's harness runs the one that equals
+    its CCM_NONCE_LEN) through the entry point a -DCCM_NONCE_LEN=n caller is bound to"""
+    L, total = CompatLens(bits), 0
+    for nlen in range(7, 14):
+        for c in ccm_cases(bits, nlen):
+            assert L.enc("CCM", c["Key"], c["Nonce"], 16, c["Adata"], c["Payload"]) == c["CT"], (nlen, c["Count"])
+            assert L.dec("CCM", c["Key"], c["Nonce"], 16, c["Adata"], c["CT"]) == (0, c["Payload"])
+            total += 1
+    assert total == 70
+
+
+def test_ocb_vectors_with_other_lengths_through_compat_api():
+    L = CompatLens(128)
+    for nlen, tlen, count in ((12, 12, 6), (15, 16, 1), (12, 16, 16)):
+        cases = ocb_cases(128, nlen, tlen)
+        assert len(cases) == count
+        for c in cases:
+            assert L.enc("OCB", c["key"], c["iv"], tlen, c["aad"], c["pt"]) == c["ct"]
+            assert L.dec("OCB", c["key"], c["iv"], tlen, c["aad"], c["ct"]) == (0, c["pt"])
+    K, N = bytes.fromhex("0F0E0D0C0B0A09080706050403020100"), bytes.fromhex("BBAA9988776655443322110D")
+    A = P = bytes(range(40))
+    Cx = bytes.fromhex("1792A4E31E0755FB03E31B22116E6C2DDF9EFD6E33D536F1A0124B0A55BAE884ED93481529C76B6A"
+                       "D0C515F4D1CDD4FDAC4F02AA")                                  # RFC 7253 appendix A, TAGLEN 96
+    assert L.enc("OCB", K, N, 12, A, P) == Cx and L.dec("OCB", K, N, 12, A, Cx) == (0, P)
+
+
+def test_length_constant_golden_vectors(golden_dir):
+    """outputs of the reference built with the length constants patched (tests/golden/lens_vectors.json)"""
+    with open(os.path.join(golden_dir, "lens_vectors.json")) as f:
+        fx = json.load(f)
+    for name, v in sorted(fx.items()):
+        L = CompatLens(v["bits"])
+        for c in v["cases"]:
+            key, aad, pt = (bytes.fromhex(c[k]) for k in ("key", "aad", "pt"))
+            for mode, tl in (("GCM", v["gcm_tag"]), ("CCM", v["ccm_tag"]), ("OCB", v["ocb_tag"])):
+                nonce, want = bytes.fromhex(c[mode.lower()]["nonce"]), bytes.fromhex(c[mode.lower()]["out"])
+                assert L.enc(mode, key, nonce, tl, aad, pt) == want, (name, mode, len(pt))
+                assert L.dec(mode, key, nonce, tl, aad, want) == (0, pt), (name, mode, len(pt))
+
+
+@pytest.mark.parametrize("bits", [128, 256])
+def test_nonce_and_tag_lengths_vs_oracle(orc, bits):
+    """every legal length of the three modes on texts that reach the one-launch, chunked and bulk GCM paths;
+    a forged truncated tag leaves a GCM output untouched (N7) and returns 0x1A everywhere"""
+    rnd = random.Random(bits)
+    key = rnd.randbytes(bits // 8)
+    sizes = [0, 1, 16, 33, 4096, 70001, (1 << 20) + 5]
+    for mode, nonces, tags in (("gcm", (12, 1, 60), (1, 4, 8, 12, 13, 15, 16)),
+                               ("ccm", range(7, 14), (4, 6, 8, 10, 12, 14, 16)),
+                               ("ocb", (1, 7, 12, 15), (1, 8, 12, 15, 16))):
+        enc, dec = getattr(uaes, "AES_%s_encrypt" % mode.upper()), getattr(uaes, "AES_%s_decrypt" % mode.upper())
+        oenc = getattr(orc, "%s_encrypt" % mode)
+        for i, tl in enumerate(tags):
+            for j, nl in enumerate(nonces):
+                n = sizes[(i + 2 * j) % len(sizes)]
+                if mode != "gcm" and n > 70001:
+                    n = 4096                                    # the CBC-MAC of CCM is a serial chain
+                nonce, aad, pt = rnd.randbytes(nl), rnd.randbytes(rnd.choice([0, 9, 32, 300])), rnd.randbytes(n)
+                want = oenc(key, nonce, aad, pt, tag_len=tl)
+                assert enc(key, nonce, aad, pt, tag_len=tl) == want, (mode, nl, tl, n)
+                assert dec(key, nonce, aad, want, tag_len=tl) == (0, pt), (mode, nl, tl, n)
+                bad = want[:-1] + bytes([want[-1] ^ 1])
+                rc, out = dec(key, nonce, aad, bad, prefill=0xA5, tag_len=tl)
+                assert rc == 0x1A, (mode, nl, tl, n)
+                if mode == "gcm":
+                    assert out == b"\xA5" * n
+
+
+def test_truncated_gcm_tag_with_device_buffers(orc):
+    """a caller's device buffer ends GCM_TAG_LEN bytes behind the text: nothing may be written past it"""
+    import torch
+    key, nonce, aad = bytes(range(16)), bytes(range(12)), b"header"
+    L = uaes.engine()
+    for n in (100, 5000, 1 << 20):
+        pt = bytes((i * 7 + 3) & 0xFF for i in range(n))
+        src = torch.frombuffer(bytearray(pt), dtype=torch.uint8).cuda()
+        for tl in (4, 12):
+            dst = torch.full((n + 32,), 0xEE, dtype=torch.uint8, device="cuda")
+            assert L.uaes_gcm_encrypt_ex(128, key, nonce, 12, tl, aad, len(aad), C.c_void_p(src.data_ptr()), n,
+                                         C.c_void_p(dst.data_ptr())) == 0
+            got = bytes(dst.cpu().numpy())
+            assert got[: n + tl] == orc.gcm_encrypt(key, nonce, aad, pt, tag_len=tl)
+            assert got[n + tl:] == b"\xEE" * (32 - tl)
+            back = torch.full((n + 16,), 0x77, dtype=torch.uint8, device="cuda")
+            assert L.uaes_gcm_decrypt_ex(128, key, nonce, 12, tl, aad, len(aad), C.c_void_p(dst.data_ptr()), n,
+                                         C.c_void_p(back.data_ptr())) == 0
+            assert bytes(back.cpu().numpy()) == pt + b"\x77" * 16
+            dst[n + tl - 1] ^= 1
+            back.fill_(0x77)
+            assert L.uaes_gcm_decrypt_ex(128, key, nonce, 12, tl, aad, len(aad), C.c_void_p(dst.data_ptr()), n,
+                                         C.c_void_p(back.data_ptr())) == 0x1A
+            assert bytes(back.cpu().numpy()) == b"\x77" * (n + 16)
+
+
 def test_gcmsiv_acvp_vectors():
     cases = gcmsiv_cases(128)
     assert len(cases) == 102

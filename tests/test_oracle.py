@@ -113,6 +113,83 @@ def test_ccm_rsp(orc, bits):
         assert orc.ccm_decrypt(c["Key"], c["Nonce"], c["Adata"], c["CT"]) == (0, c["Payload"])
 
 
+@pytest.mark.parametrize("bits", [128, 192, 256])
+def test_ccm_rsp_every_nonce_length(orc, bits):
+    """the reference's harness takes the [Nlen = CCM_NONCE_LEN] section of VNT*.rsp; with the nonce length a
+    parameter every section (Nlen = 7..13, 10 vectors each) pins the restatement"""
+    total = 0
+    for nlen in range(7, 14):
+        cases = ccm_cases(bits, nlen)
+        assert len(cases) == 10
+        for c in cases:
+            assert orc.ccm_encrypt(c["Key"], c["Nonce"], c["Adata"], c["Payload"]) == c["CT"], (nlen, c["Count"])
+            assert orc.ccm_decrypt(c["Key"], c["Nonce"], c["Adata"], c["CT"]) == (0, c["Payload"])
+            total += 1
+    assert total == 70
+
+
+def test_ocb_vectors_with_other_lengths(orc):
+    """the OpenSSL file's 12-byte-tag stanzas and its 15-byte-nonce stanza (what a reference build with
+    OCB_TAG_LEN 12 / OCB_NONCE_LEN 15 runs), and RFC 7253 appendix A's 96-bit-tag sample"""
+    for nlen, tlen, count in ((12, 12, 6), (15, 16, 1)):
+        cases = ocb_cases(128, nlen, tlen)
+        assert len(cases) == count
+        for c in cases:
+            assert orc.ocb_encrypt(c["key"], c["iv"], c["aad"], c["pt"], tag_len=tlen) == c["ct"]
+            assert orc.ocb_decrypt(c["key"], c["iv"], c["aad"], c["ct"], tag_len=tlen) == (0, c["pt"])
+    K, N = bytes.fromhex("0F0E0D0C0B0A09080706050403020100"), bytes.fromhex("BBAA9988776655443322110D")
+    A = P = bytes(range(40))
+    Cx = bytes.fromhex("1792A4E31E0755FB03E31B22116E6C2DDF9EFD6E33D536F1A0124B0A55BAE884ED93481529C76B6A"
+                       "D0C515F4D1CDD4FDAC4F02AA")
+    assert orc.ocb_encrypt(K, N, A, P, tag_len=12) == Cx
+    assert orc.ocb_decrypt(K, N, A, Cx, tag_len=12) == (0, P)
+
+
+def test_gcm_truncated_tags_are_prefixes(orc):
+    """GCM_TAG_LEN = t appends the first t bytes of the 16-byte tag (:1178): every NIST vector, t = 4, 12, 15"""
+    for c in gcm_cases(128)[::5]:
+        for t in (4, 12, 15):
+            assert orc.gcm_encrypt(c["Key"], c["IV"], c["AAD"], c["PT"], tag_len=t) == c["CT"] + c["Tag"][:t]
+            assert orc.gcm_decrypt(c["Key"], c["IV"], c["AAD"], c["CT"] + c["Tag"][:t], tag_len=t) == (0, c["PT"])
+
+
+def test_length_constant_builds_of_the_reference_golden(orc, golden_dir):
+    """tests/golden/lens_vectors.json: outputs of the reference built with CCM_NONCE_LEN / CCM_TAG_LEN /
+    GCM_TAG_LEN / OCB_NONCE_LEN / OCB_TAG_LEN patched (make_lens_fixtures.py)"""
+    fx = load(golden_dir, "lens_vectors.json")
+    assert sorted(fx) == ["A", "B"]
+    for name, v in fx.items():
+        for c in v["cases"]:
+            key, aad, pt = (bytes.fromhex(c[k]) for k in ("key", "aad", "pt"))
+            for mode, tl, enc, dec in (("gcm", v["gcm_tag"], orc.gcm_encrypt, orc.gcm_decrypt),
+                                       ("ccm", v["ccm_tag"], orc.ccm_encrypt, orc.ccm_decrypt),
+                                       ("ocb", v["ocb_tag"], orc.ocb_encrypt, orc.ocb_decrypt)):
+                nonce, want = bytes.fromhex(c[mode]["nonce"]), bytes.fromhex(c[mode]["out"])
+                assert len(want) == len(pt) + tl
+                assert enc(key, nonce, aad, pt, tag_len=tl) == want, (name, mode, len(pt))
+                assert dec(key, nonce, aad, want, tag_len=tl) == (0, pt)
+
+
+@pytest.mark.parametrize("name", ["A", "B"])
+def test_length_constant_builds_of_the_reference_random(orc, name):
+    bits = Reference.LENS[name][0]
+    if not Reference.available(bits, lens=name):
+        pytest.skip("oracle/_ref/libmicroaes_ref_%d_lens%s.so not built" % (bits, name))
+    ref, rnd = Reference(bits, lens=name), random.Random(77)
+    for trial in range(40):
+        key, pt = rnd.randbytes(bits // 8), rnd.randbytes(rnd.choice([0, 1, 15, 16, 17, 64, 100, 1000]))
+        aad = rnd.randbytes(rnd.choice([0, 5, 16, 40, 70000 if trial == 3 else 20]))
+        for nlen, tl, oe, od, re_, rd in ((12, ref.gcm_tag, orc.gcm_encrypt, orc.gcm_decrypt, ref.gcm_encrypt, ref.gcm_decrypt),
+                                          (ref.ccm_nonce, ref.ccm_tag, orc.ccm_encrypt, orc.ccm_decrypt, ref.ccm_encrypt, ref.ccm_decrypt),
+                                          (ref.ocb_nonce, ref.ocb_tag, orc.ocb_encrypt, orc.ocb_decrypt, ref.ocb_encrypt, ref.ocb_decrypt)):
+            nonce = rnd.randbytes(nlen)
+            ct = re_(key, nonce, aad, pt)
+            assert oe(key, nonce, aad, pt, tag_len=tl) == ct
+            assert od(key, nonce, aad, ct, tag_len=tl) == rd(key, nonce, aad, ct) == (0, pt)
+            bad = ct[:-1] + bytes([ct[-1] ^ 0x40])
+            assert od(key, nonce, aad, bad, tag_len=tl) == rd(key, nonce, aad, bad)
+
+
 def test_gcmsiv_acvp(orc):
     cases = gcmsiv_cases(128)
     assert len(cases) == 102 and not gcmsiv_cases(256)
