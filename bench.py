@@ -92,6 +92,55 @@ def usable_cores():
     return max(1, min(n, 128))
 
 
+def measure_traffic(workload, nbytes):
+    """HBM bytes per step from the PMC counters, measured live: two SEPARATE rocprofv3 passes (--pmc FETCH_SIZE,
+    --pmc WRITE_SIZE; kernel trace only, as MI355X_MICROARCH.md prescribes) over a short child run of this very
+    command (3 steps + 1 warm-up, no settling, no CPU leg).  Per step = the counters of every kernel of the engine
+    (names k_*) summed over the child's launches / its 4 steps.  FETCH_SIZE is in KiB and on gfx950 reports half of a
+    wide coalesced read stream, so bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.  Returns (bytes, note) or
+    (None, why not)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
+        return None, "rocprofv3 not found"
+    steps, warm = 3, 1
+    kib = {}
+    tmp = tempfile.mkdtemp(prefix="uaes_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, ctr)
+            cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", out, "-o", "pmc", "--",
+                   sys.executable, os.path.abspath(__file__), "--gpus", "1", "--workload", workload, "--bytes", str(nbytes),
+                   "--steps", str(steps), "--warmup", str(warm), "--settle-ms", "0", "--no-cpu", "--no-verify",
+                   "--no-traffic"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, "rocprofv3 --pmc %s pass failed (rc %d)" % (ctr, r.returncode)
+            total = 0.0
+            for f in files:
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        name = row.get("Kernel_Name", "")
+                        if row.get("Counter_Name") == ctr and (name.startswith("k_") or name.startswith("void k_")):
+                            total += float(row.get("Counter_Value", 0))
+            kib[ctr] = total / (steps + warm)
+    except Exception as e:                      # a profiler problem must not cost the bench line
+        return None, "PMC pass: %s" % e
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    traffic = int((2.0 * kib["FETCH_SIZE"] + kib["WRITE_SIZE"]) * 1024)
+    return traffic, ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE as two "
+                     "separate passes over a 4-step child run; (2 x %.0f + %.0f) KiB per step" % (kib["FETCH_SIZE"], kib["WRITE_SIZE"]))
+
+
 def cpu_baseline(workload):
     """Reference CPU path on this host: 1 core (the reference is single-threaded
     and non re-entrant, micro_aes.c:72) and, via fork, all cores."""
@@ -186,6 +235,7 @@ def main():
                     help="extra untimed warm-up until the clocks have settled (0 = only --warmup steps)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 PMC passes behind roofline.traffic")
     ap.add_argument("--gather", action="store_true", help="also time the RCCL ciphertext all-gather")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --single-device: dry-run the multi-rank code path on a 1-GPU box")
@@ -379,18 +429,21 @@ def main():
         algo_bytes = 2.0 * n                       # read n + write n per launch, per GPU
         per_gpu = [algo_bytes / (k * 1e-3) / 1e9 for k in kern_all]
         achieved = per_gpu[0]
-        # HBM bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE need their own
-        # runs under the profiler, tools/profile.sh); this run cannot measure them itself, so the
-        # line names where the figure was taken from.
+        # HBM bytes per step: measured live by two rocprofv3 PMC passes over a short child run (N = 1 only, like the
+        # CPU leg); where that is not possible the figure recorded under profiles/ is quoted and labelled as such.
         traffic, traffic_source = None, None
-        try:
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                t = json.load(f).get(a.workload)
-            if t and t["bytes_per_gpu"] == n:
-                traffic = t["traffic_bytes"]
-                traffic_source = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, recorded in %s (not measured in this run)" % t["source"]
-        except Exception:
-            pass
+        if world == 1 and not a.no_traffic:
+            traffic, traffic_source = measure_traffic(a.workload, n)
+        if traffic is None:
+            why = traffic_source
+            try:
+                with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                    t = json.load(f).get(a.workload)
+                if t and t["bytes_per_gpu"] == n:
+                    traffic = t["traffic_bytes"]
+                    traffic_source = "recorded in %s (not measured in this run%s)" % (t["source"], ": " + why if why else "")
+            except Exception:
+                pass
         names = {"ctr": "AES-128-CTR", "ecb": "AES-128-ECB", "xts": "AES-256-XTS 4 KiB sectors", "gcm": "AES-128-GCM",
                  "cbc-dec": "AES-128-CBC decrypt", "cfb-dec": "AES-128-CFB decrypt",
                  "ocb": "AES-128-OCB", "ocb-dec": "AES-128-OCB decrypt"}

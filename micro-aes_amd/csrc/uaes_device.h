@@ -175,6 +175,10 @@ int uaesk_ocb(void *stream, const uaesk_tables *tb, int nr,
               const void *aad, size_t aad_len, const void *in, size_t len, void *out,
               void *scratch, int *status);
 
+/* Completion ticket of a synchronous call: a one-wave kernel behind the call's kernels copies nbytes (a multiple
+ * of 4, <= 64) from d_src to pinned_dst and then stores seq to *pinned_flag with system-scope release.   */
+int uaesk_ticket(void *stream, void *pinned_flag, unsigned seq, const void *d_src, void *pinned_dst, unsigned nbytes);
+
 /* Device self-test of the primitives; writes a bitmask of failures.        */
 int uaesk_selftest(void *stream, const uaesk_tables *tb, const uaesk_rk *ek128,
                    const uaesk_rk *dk128, unsigned *d_result);

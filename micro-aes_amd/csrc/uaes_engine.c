@@ -17,6 +17,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "../../include/uaes_hip.h"
 #include "uaes_device.h"
@@ -416,7 +417,9 @@ typedef struct lane {
     void       *aad_stage;
     size_t      aad_cap;
     void       *pin[2];             /* pinned bounce buffers for short host texts (in, out)       */
-    void       *pinx;               /* 4 KiB of pinned memory for small values exchanged mid-call */
+    void       *pinx;               /* 4 KiB of pinned memory for small values exchanged mid-call;
+                                     * its last 128 bytes: the completion ticket (lane_sync)       */
+    uint32_t    seq;                /* number of the last ticket issued                            */
     int        *d_status;           /* device: status word, and a 16-byte result slot at +4 ints  */
     struct lane *next;              /* context's list                                             */
 } lane;
@@ -520,17 +523,77 @@ static int lane_scratch(lane *L, size_t need)
     return grow_on(L->stream, &L->scratch, &L->scratch_cap, need);
 }
 
+static int pinned_ready(lane *L);
+static int env_int(const char *name, int dflt, int lo, int hi);
+
+/* ---- waiting for the lane's stream ------------------------------------------------------------
+ * hipStreamSynchronize costs ~11 us for an empty kernel and all host threads together get ~0.31 M of them per
+ * second out of the runtime (tools/ubench/threadfloor.hip).  A synchronous call therefore ends with a TICKET: a
+ * one-wave kernel behind the call's kernels stores the lane's next sequence number into pinned memory and the host
+ * spins on that word (8.9 us, 0.6 M calls/s at 8 threads); the same kernel carries the few result bytes a call
+ * reads back (status word, tag, MAC), which saves the hipMemcpyAsync command as well.  A call that is still running
+ * after TICKET_SPIN_US (a long text, a hung or faulted kernel) goes into hipStreamSynchronize after all, which also
+ * is where a device error surfaces.  UAES_TICKET=0 switches the mechanism off.                          */
+#define TICKET_OFF      (4096 - 128)             /* byte offset of the ticket word in pinx   */
+#define TICKET_DATA_OFF (4096 - 64)              /* 64 bytes of fetched result behind it     */
+#define TICKET_SPIN_US  200
+
+static int ticket_enabled(void)
+{
+    static int on = -1;
+    if (on < 0) on = env_int("UAES_TICKET", 1, 0, 1);
+    return on;
+}
+
+static int64_t now_us(void)
+{
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return (int64_t)t.tv_sec * 1000000 + t.tv_nsec / 1000;
+}
+
+/* wait until everything queued on the lane's stream is done; n > 0: also bring n bytes (<= 64, a multiple of 4)
+ * from device memory `dev` to `host`                                                                        */
+static int lane_wait_fetch(lane *L, void *host, const void *dev, size_t n)
+{
+    hipStream_t st = (hipStream_t)L->stream;
+    if (ticket_enabled() && n <= 64 && (n & 3u) == 0 && (((uintptr_t)dev) & 3u) == 0 && pinned_ready(L)) {
+        volatile uint32_t *flag = (volatile uint32_t *)((char *)L->pinx + TICKET_OFF);
+        void *data = (char *)L->pinx + TICKET_DATA_OFF;
+        const uint32_t seq = ++L->seq ? L->seq : ++L->seq;          /* never 0: the page starts zeroed */
+        int k = uaesk_ticket(L->stream, (void *)flag, seq, dev, data, (unsigned)n);
+        if (k == 0) {
+            const int64_t t0 = now_us();
+            unsigned spins = 0;
+            for (;;) {
+                if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) {
+                    if (n) memcpy(host, data, n);
+                    return 0;
+                }
+                __builtin_ia32_pause();
+                if ((++spins & 255u) == 0 && now_us() - t0 > TICKET_SPIN_US) break;
+            }
+            HIPCHK(hipStreamSynchronize(st));                 /* a long call: sleep in the runtime instead */
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) return fail(UAES_E_HIP, "completion ticket lost");
+            if (n) memcpy(host, data, n);
+            return 0;
+        }
+        (void)hipGetLastError();                              /* could not launch it: the plain way */
+    }
+    if (n) HIPCHK(hipMemcpyAsync(host, dev, n, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return 0;
+}
+
 static int lane_sync(lane *L)
 {
-    HIPCHK(hipStreamSynchronize((hipStream_t)L->stream));
-    return 0;
+    return lane_wait_fetch(L, NULL, NULL, 0);
 }
 
 /* 4 .. 16 bytes of result (status word, tag, MAC) from the lane's device slot to the host */
 static int lane_fetch(lane *L, void *host, const void *dev, size_t n)
 {
-    HIPCHK(hipMemcpyAsync(host, dev, n, hipMemcpyDeviceToHost, (hipStream_t)L->stream));
-    return lane_sync(L);
+    return lane_wait_fetch(L, host, dev, n);
 }
 
 static int is_device_ptr(const void *p)
@@ -648,8 +711,9 @@ static int finish_io(io_plan *io, size_t out_len)
 {
     lane *L = io->L;
     hipStream_t st = (hipStream_t)L->stream;
+    int rc;
     if (io->dout && io->dout == L->pin[1]) {      /* the kernel wrote the mapped pinned buffer itself */
-        HIPCHK(hipStreamSynchronize(st));
+        if ((rc = lane_sync(L)) != 0) return rc;
         if (out_len) memcpy(io->user_out, L->pin[1], out_len);
         return 0;
     }
@@ -659,10 +723,12 @@ static int finish_io(io_plan *io, size_t out_len)
         memcpy(io->user_out, L->pin[1], out_len);
         return 0;
     }
-    if (io->copy_back && out_len)
+    if (io->copy_back && out_len) {
         HIPCHK(hipMemcpyAsync(io->user_out, io->dout, out_len, hipMemcpyDefault, st));
-    HIPCHK(hipStreamSynchronize(st));
-    return 0;
+        HIPCHK(hipStreamSynchronize(st));
+        return 0;
+    }
+    return lane_sync(L);
 }
 
 /* a call bails out with work possibly queued on the lane: nothing of it may still be running

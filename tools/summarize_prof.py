@@ -27,6 +27,23 @@ for f in find("kt/**/*kernel_stats.csv"):
                 short(row.get("Name", "")), row.get("Calls"), row.get("AverageNs"), row.get("MinNs"),
                 row.get("MaxNs"), row.get("Percentage")))
 
+# Steady state: the clocks need tens of milliseconds of load to settle and bench.py keeps warming up (untimed) until
+# they have, so the AVERAGE over all launches of a run still contains the ramp and exceeds the driver's ms_per_step.
+# The last 20 launches of each kernel are the timed steps of the profiled command: report their mean beside it.
+print("\n== kernel-trace, steady state: the LAST 20 launches of each kernel (= the timed steps) ==")
+for f in find("kt/**/*kernel_trace.csv"):
+    durs = defaultdict(list)
+    with open(f) as fh:
+        rows = sorted(csv.DictReader(fh), key=lambda r: int(r["Start_Timestamp"]))
+    for row in rows:
+        durs[short(row.get("Kernel_Name", ""))].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+    for k, d in sorted(durs.items(), key=lambda kv: -sum(kv[1])):
+        if "at::" in k or "elementwise" in k or "Cijk" in k or len(d) < 4:
+            continue
+        last = d[-20:]
+        print("%-72s launches=%-5d avg_all_ns=%-10.0f steady_avg_ns=%-10.0f steady_min_ns=%-10d steady_max_ns=%d" % (
+            k, len(d), sum(d) / len(d), sum(last) / len(last), min(last), max(last)))
+
 for sub in ("pmc_sq", "pmc_sq2", "pmc_rd", "pmc_wr"):
     files = find(sub + "/**/*counter_collection.csv")
     if not files:
