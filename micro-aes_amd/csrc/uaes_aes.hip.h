@@ -52,6 +52,42 @@ __device__ __forceinline__ u32 lds_word(u32 byte_addr)
     return *(lds_cu32 *)(uintptr_t)byte_addr;
 }
 
+/* ---- completion ticket riding on a kernel (uaes_device.h: uaesk_done) ----------------------------------------
+ * EVERY thread of EVERY workgroup must call this as its last action: the workgroup meets, thread 0 releases the
+ * workgroup's stores to system scope and counts the workgroup in, and the last one to arrive releases the ticket
+ * number to the pinned host word (the classic last-block pattern; one workgroup: no counting).               */
+uaesk_done uaesk_ticket_take();                     /* the calling host thread's armed ticket (cleared), uaes_kernels.hip */
+void uaesk_ticket_unused();
+
+/* a multi-launch routine takes the ticket at its entry, so that the single-launch building blocks it calls do not
+ * pick it up in the middle of the sequence, and hands it to the one path that is a single launch (use()); if no
+ * such path was taken the host layer is told so (uaesk_ticket_disarm() = 1) and sends k_ticket itself          */
+struct TicketScope {
+    uaesk_done d;
+    bool used;
+    TicketScope() : d(uaesk_ticket_take()), used(false) {}
+    ~TicketScope() { if (d.flag && !used) uaesk_ticket_unused(); }
+    const uaesk_done &use() { used = true; return d; }
+};
+
+__device__ __forceinline__ void ticket_release(const uaesk_done &d)
+{
+    if (!d.flag) return;                             /* kernel argument: uniform */
+    __syncthreads();                                 /* workgroup-scope release / acquire: the workgroup's stores
+                                                      * happen-before what thread 0 does next                      */
+    if (threadIdx.x != 0) return;
+    __threadfence_system();                          /* ONE system-scope release per workgroup (cumulative), not
+                                                      * one per thread: sixteen waves fencing cost more than the
+                                                      * second launch this saves                                   */
+    if (gridDim.x > 1) {
+        const unsigned arrived = __hip_atomic_fetch_add(d.count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (arrived != gridDim.x - 1u) return;
+        __hip_atomic_store(d.count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     /* for the next launch */
+        __threadfence_system();
+    }
+    __hip_atomic_store(d.flag, d.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 /* three-input boolean ops in one VALU instruction (v_bitop3_b32, gfx950) */
 __device__ __forceinline__ u32 xor3(u32 a, u32 b, u32 c)
 {

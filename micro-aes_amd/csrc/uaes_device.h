@@ -175,6 +175,19 @@ int uaesk_ocb(void *stream, const uaesk_tables *tb, int nr,
               const void *aad, size_t aad_len, const void *in, size_t len, void *out,
               void *scratch, int *status);
 
+/* A ticket can also ride on the call's ONLY kernel (saves the second launch: 8.9 -> 7 us for an empty kernel,
+ * tools/ubench/threadfloor.hip).  The host layer arms one for the calling thread right before a kernel-level call
+ * whose last launch may take it (ECB, generic CTR, a one-launch XTS unit, a one-launch GCM encryption); the launcher
+ * that does take it makes the kernel release `seq` to *flag when its last workgroup is done (d_count: a zeroed
+ * device word for that count).  uaesk_ticket_disarm() = 1 if nobody took it (the host then sends k_ticket).   */
+typedef struct {
+    unsigned *flag;                 /* pinned host word the host spins on; NULL = no ticket */
+    unsigned *count;                /* device word, zero between launches                    */
+    unsigned  seq;
+} uaesk_done;
+void uaesk_ticket_arm(void *pinned_flag, void *d_count, unsigned seq);
+int  uaesk_ticket_disarm(void);
+
 /* Completion ticket of a synchronous call: a one-wave kernel behind the call's kernels copies nbytes (a multiple
  * of 4, <= 64) from d_src to pinned_dst and then stores seq to *pinned_flag with system-scope release.   */
 int uaesk_ticket(void *stream, void *pinned_flag, unsigned seq, const void *d_src, void *pinned_dst, unsigned nbytes);

@@ -420,6 +420,7 @@ typedef struct lane {
     void       *pinx;               /* 4 KiB of pinned memory for small values exchanged mid-call;
                                      * its last 128 bytes: the completion ticket (lane_sync)       */
     uint32_t    seq;                /* number of the last ticket issued                            */
+    uint32_t    armed;              /* != 0: the call's only kernel carries this ticket itself     */
     int        *d_status;           /* device: status word, and a 16-byte result slot at +4 ints  */
     struct lane *next;              /* context's list                                             */
 } lane;
@@ -499,7 +500,8 @@ static int get_lane(context *c, lane **out)
     }
     if (!L->stream) {                             /* new, or emptied by uaes_shutdown() */
         hipError_t e = hipStreamCreateWithFlags((hipStream_t *)&L->stream, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipMalloc((void **)&L->d_status, 64);
+        if (e == hipSuccess) e = hipMalloc((void **)&L->d_status, 128);      /* [16]: workgroup count of a riding ticket */
+        if (e == hipSuccess) e = hipMemset(L->d_status, 0, 128);
         if (e != hipSuccess) {
             if (L->stream) (void)hipStreamDestroy((hipStream_t)L->stream);
             L->stream = NULL;
@@ -552,29 +554,61 @@ static int64_t now_us(void)
     return (int64_t)t.tv_sec * 1000000 + t.tv_nsec / 1000;
 }
 
+static volatile uint32_t *ticket_word(lane *L) { return (volatile uint32_t *)((char *)L->pinx + TICKET_OFF); }
+
+static uint32_t ticket_next(lane *L)
+{
+    if (++L->seq == 0) ++L->seq;                              /* never 0: the page starts zeroed */
+    return L->seq;
+}
+
+/* spin on the lane's ticket word until it shows seq; a call that takes longer sleeps in the runtime */
+static int ticket_wait(lane *L, uint32_t seq)
+{
+    volatile uint32_t *flag = ticket_word(L);
+    const int64_t t0 = now_us();
+    unsigned spins = 0;
+    for (;;) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return 0;
+        __builtin_ia32_pause();
+        if ((++spins & 255u) == 0 && now_us() - t0 > TICKET_SPIN_US) break;
+    }
+    HIPCHK(hipStreamSynchronize((hipStream_t)L->stream));
+    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) return fail(UAES_E_HIP, "completion ticket lost");
+    return 0;
+}
+
+/* Right before a kernel-level call whose only (or last) launch may carry the ticket itself (uaes_device.h:
+ * uaesk_ticket_arm) -- ECB, the generic CTR kernel, a one-launch XTS unit, a one-launch GCM encryption -- and right
+ * after it: L->armed != 0 then says that the kernel releases that number and no ticket kernel is needed.       */
+static void ticket_arm(lane *L)
+{
+    L->armed = 0;
+    if (!ticket_enabled() || !pinned_ready(L)) return;
+    L->armed = ticket_next(L);
+    uaesk_ticket_arm((void *)ticket_word(L), L->d_status + 16, L->armed);
+}
+
+static void ticket_armed_launch_done(lane *L)
+{
+    if (uaesk_ticket_disarm()) L->armed = 0;                  /* nobody took it */
+}
+
 /* wait until everything queued on the lane's stream is done; n > 0: also bring n bytes (<= 64, a multiple of 4)
  * from device memory `dev` to `host`                                                                        */
 static int lane_wait_fetch(lane *L, void *host, const void *dev, size_t n)
 {
     hipStream_t st = (hipStream_t)L->stream;
+    const uint32_t armed = L->armed;
+    L->armed = 0;
+    if (armed && n == 0) return ticket_wait(L, armed);        /* the call's kernel releases it itself */
     if (ticket_enabled() && n <= 64 && (n & 3u) == 0 && (((uintptr_t)dev) & 3u) == 0 && pinned_ready(L)) {
-        volatile uint32_t *flag = (volatile uint32_t *)((char *)L->pinx + TICKET_OFF);
         void *data = (char *)L->pinx + TICKET_DATA_OFF;
-        const uint32_t seq = ++L->seq ? L->seq : ++L->seq;          /* never 0: the page starts zeroed */
-        int k = uaesk_ticket(L->stream, (void *)flag, seq, dev, data, (unsigned)n);
+        const uint32_t seq = ticket_next(L);
+        int k = uaesk_ticket(L->stream, (void *)ticket_word(L), seq, dev, data, (unsigned)n);
         if (k == 0) {
-            const int64_t t0 = now_us();
-            unsigned spins = 0;
-            for (;;) {
-                if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) {
-                    if (n) memcpy(host, data, n);
-                    return 0;
-                }
-                __builtin_ia32_pause();
-                if ((++spins & 255u) == 0 && now_us() - t0 > TICKET_SPIN_US) break;
-            }
-            HIPCHK(hipStreamSynchronize(st));                 /* a long call: sleep in the runtime instead */
-            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) return fail(UAES_E_HIP, "completion ticket lost");
+            int rc = ticket_wait(L, seq);
+            if (rc) return rc;
             if (n) memcpy(host, data, n);
             return 0;
         }
@@ -718,12 +752,14 @@ static int finish_io(io_plan *io, size_t out_len)
         return 0;
     }
     if (io->copy_back && out_len && out_len <= PIN_BYTES && io->out_is_host && pinned_ready(L)) {
+        L->armed = 0;                             /* a copy follows the kernel: the stream is drained the plain way */
         HIPCHK(hipMemcpyAsync(L->pin[1], io->dout, out_len, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         memcpy(io->user_out, L->pin[1], out_len);
         return 0;
     }
     if (io->copy_back && out_len) {
+        L->armed = 0;
         HIPCHK(hipMemcpyAsync(io->user_out, io->dout, out_len, hipMemcpyDefault, st));
         HIPCHK(hipStreamSynchronize(st));
         return 0;
@@ -735,6 +771,8 @@ static int finish_io(io_plan *io, size_t out_len)
  * (or reading the bounce buffers) when the next call of this thread starts                    */
 static int lane_abandon(lane *L, int rc)
 {
+    if (L) L->armed = 0;
+    (void)uaesk_ticket_disarm();
     if (L && L->stream) (void)hipStreamSynchronize((hipStream_t)L->stream);
     return rc;
 }
@@ -1035,8 +1073,10 @@ static int ecb_common(int keybits, const uint8_t *key, int decrypt, int padding,
                 break;
             }
         }
+        ticket_arm(L);
         int k = uaesk_ecb(L->stream, &c->tb, ks.nr, decrypt ? &ks.dk : &ks.ek, decrypt,
                           io.din, io.dout, nfull, decrypt ? 0 : (unsigned)rem, decrypt ? 0 : (unsigned)padding);
+        ticket_armed_launch_done(L);
         if (k) { rc = fail(UAES_E_HIP, "ecb launch: %s", hipGetErrorString((hipError_t)k)); break; }
         if ((rc = finish_io(&io, out_len)) != 0) break;
         rc = (decrypt && rem) ? UAES_E_DECRYPTION : 0;           /* :679 */
@@ -1138,7 +1178,9 @@ int uaes_ctr_xcrypt_at(int keybits, const uint8_t *key, const uint8_t ctr0[16],
         pa.c = c; pa.ks = &ks; pa.ctr = &ctr;
         if (run_pipelined(c, in, out, len, 16, 0, ctr_pipe_launch, &pa, &rc)) return rc;
         if ((rc = plan_io(L, in, len, out, len, &io)) != 0) break;
+        ticket_arm(L);
         int k = uaesk_ctr_xcrypt(L->stream, &c->tb, ks.nr, &ks.ek, &ctr, io.din, io.dout, len, NULL);
+        ticket_armed_launch_done(L);
         if (k) { rc = fail(UAES_E_HIP, "ctr launch: %s", hipGetErrorString((hipError_t)k)); break; }
         rc = finish_io(&io, len);
     } while (0);
@@ -1223,8 +1265,10 @@ static int xts_common(int keybits, const uint8_t *keys, const uint8_t *tweak, in
         if (!raw_tweak && nsectors > 1 && run_pipelined(c, in, out, total, sector_bytes, 0, xts_pipe_launch, &pa, &rc)) return rc;
         if ((rc = lane_scratch(L, uaesk_xts_scratch_bytes(sector_bytes, nsectors))) != 0) break;
         if ((rc = plan_io(L, in, total, out, total, &io)) != 0) break;
+        ticket_arm(L);
         rc = xts_run(c, L->stream, &k1, &k2, encrypt, raw_tweak ? (tweak ? tweak : zero) : NULL,
                      first_sector, sector_bytes, nsectors, io.din, io.dout, L->scratch);
+        ticket_armed_launch_done(L);
         if (rc) break;
         rc = finish_io(&io, total);
     } while (0);
@@ -1355,8 +1399,10 @@ int uaes_gcm_encrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, s
             io.dout = L->stage[1];
             io.copy_back = 1;
         }
+        ticket_arm(L);
         int k = uaesk_gcm(L->stream, &c->tb, ks.nr, &ks.ek, 0, j0, d_aad, aDataLen,
                           io.din, ptextLen, io.dout, L->scratch, NULL);
+        ticket_armed_launch_done(L);
         if (k) { rc = fail(UAES_E_HIP, "gcm launch: %s", hipGetErrorString((hipError_t)k)); break; }
         rc = finish_io(&io, ptextLen + tagLen);
     } while (0);

@@ -907,7 +907,7 @@ template <int NR, bool DEC>
 __global__ __launch_bounds__(GH_T) void k_gcm_small(uaesk_rk rk, uaesk_tables tb, uaesk_ctr ctr, uint4 j0,
                                                     GSrc src, const uint4 *in, uint4 *out,
                                                     const unsigned char *__restrict__ scratch,
-                                                    unsigned char *tag_io, int *status, u32 build)
+                                                    unsigned char *tag_io, int *status, u32 build, uaesk_done done)
 {
     /* build != 0: a one-shot call -- the key's nibble tables are not in `scratch`, they are made here from
      * H = Enc(0), which thread 1's padding slot computes (gcm_build_nibble_tables)                        */
@@ -1008,30 +1008,31 @@ __global__ __launch_bounds__(GH_T) void k_gcm_small(uaesk_rk rk, uaesk_tables tb
             }
         }
     }
+    ticket_release(done);
 }
 
 template <int NR, bool DEC>
 static int launch_small(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek, const uaesk_ctr *c, uint4 j0,
                         const GSrc &src, const void *in, void *out, const unsigned char *sc,
-                        unsigned char *tag_io, int *status, u32 build)
+                        unsigned char *tag_io, int *status, u32 build, const uaesk_done &done)
 {
     hipError_t e = hipFuncSetAttribute((const void *)k_gcm_small<NR, DEC>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        GSM_LDS_TOTAL);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL((k_gcm_small<NR, DEC>), dim3(1), dim3(GH_T), GSM_LDS_TOTAL, st, *ek, *tb, *c, j0, src,
-                       (const uint4 *)in, (uint4 *)out, sc, tag_io, status, build);
+                       (const uint4 *)in, (uint4 *)out, sc, tag_io, status, build, done);
     return (int)hipGetLastError();
 }
 
 template <bool DEC>
 static int launch_small_nr(int nr, hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek, const uaesk_ctr *c,
                            uint4 j0, const GSrc &src, const void *in, void *out, const unsigned char *sc,
-                           unsigned char *tag_io, int *status, u32 build)
+                           unsigned char *tag_io, int *status, u32 build, const uaesk_done &done)
 {
     switch (nr) {
-    case 10: return launch_small<10, DEC>(st, tb, ek, c, j0, src, in, out, sc, tag_io, status, build);
-    case 12: return launch_small<12, DEC>(st, tb, ek, c, j0, src, in, out, sc, tag_io, status, build);
-    case 14: return launch_small<14, DEC>(st, tb, ek, c, j0, src, in, out, sc, tag_io, status, build);
+    case 10: return launch_small<10, DEC>(st, tb, ek, c, j0, src, in, out, sc, tag_io, status, build, done);
+    case 12: return launch_small<12, DEC>(st, tb, ek, c, j0, src, in, out, sc, tag_io, status, build, done);
+    case 14: return launch_small<14, DEC>(st, tb, ek, c, j0, src, in, out, sc, tag_io, status, build, done);
     default: return (int)hipErrorInvalidValue;
     }
 }
@@ -1468,6 +1469,10 @@ static int gcm_body(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk
 {
     hipStream_t st = S(stream);
     unsigned char *sc = (unsigned char *)scratch;
+    /* an armed completion ticket (uaes_device.h) may ride on a ONE-launch encryption only; taking it here also
+     * keeps the building blocks below (uaesk_ctr_xcrypt) from picking it up in the middle of a longer sequence */
+    TicketScope ticket;
+    const uaesk_done no_ticket = { nullptr, nullptr, 0 };
     /* J0 = nonce || 00000001 for the 12-byte nonce (GCMsetup, micro_aes.c:1150-1151), or
      * GHASH(nonce) (uaesk_gcm_j0); the host layer passes the 16 bytes                     */
     uint4 j0;
@@ -1586,9 +1591,9 @@ static int gcm_body(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk
         }
         GSrc sm = msg;
         sm.ct = (const unsigned char *)in;     /* the kernel reads the text itself */
-        if (decrypt)
-            return launch_small_nr<true>(nr, st, tb, ek, &c, j0, sm, in, out, sc, (unsigned char *)in + len, status, build);
-        return launch_small_nr<false>(nr, st, tb, ek, &c, j0, sm, in, out, sc, (unsigned char *)out + len, nullptr, build);
+        if (decrypt)                               /* (its status word still has to travel: the host sends k_ticket) */
+            return launch_small_nr<true>(nr, st, tb, ek, &c, j0, sm, in, out, sc, (unsigned char *)in + len, status, build, no_ticket);
+        return launch_small_nr<false>(nr, st, tb, ek, &c, j0, sm, in, out, sc, (unsigned char *)out + len, nullptr, build, ticket.use());
     }
     /* (a decrypt that must authenticate first has no one-pass alternative: the chunk kernels serve it as far as
      * the combine kernel reaches, 32 MiB: 16 MiB 93 -> 69 us) */

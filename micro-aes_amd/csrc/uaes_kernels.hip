@@ -35,7 +35,7 @@ static inline hipStream_t S(void *s) { return (hipStream_t)s; }
 template <int NR, bool DEC, int U>
 __global__ __launch_bounds__(UAES_WG) void k_ecb(uaesk_rk rk, uaesk_tables tb,
                                                  const uint4 *in, uint4 *out,
-                                                 u64 nfull, u32 rem, u32 padding)
+                                                 u64 nfull, u32 rem, u32 padding, uaesk_done done)
 {
     if (DEC) fill_dec_tables(tb.td0); else fill_enc_tables(tb.te0);
     const LaneConst lc = make_lane_const();
@@ -84,6 +84,7 @@ __global__ __launch_bounds__(UAES_WG) void k_ecb(uaesk_rk rk, uaesk_tables tb,
         enc_blocks<NR, 1>(s1, rk, lc);
         out[nfull] = make_uint4(s1[0][0], s1[0][1], s1[0][2], s1[0][3]);
     }
+    ticket_release(done);
 }
 
 /* ------------------------------------------------------------------------ */
@@ -93,9 +94,9 @@ __global__ __launch_bounds__(UAES_WG) void k_ecb(uaesk_rk rk, uaesk_tables tb,
 template <int NR, int U>
 __global__ __launch_bounds__(UAES_WG, 4) void k_ctr(uaesk_rk rk, uaesk_tables tb, uaesk_ctr ctr,
                                                  const uint4 *in, uint4 *out,
-                                                 u64 nfull, u32 rem, const int *__restrict__ gate)
+                                                 u64 nfull, u32 rem, const int *__restrict__ gate, uaesk_done done)
 {
-    if (gate && *gate != 0) return;            /* GCM decrypt: tag mismatch -> untouched */
+    if (gate && *gate != 0) { ticket_release(done); return; }      /* GCM decrypt: tag mismatch -> untouched */
     fill_enc_tables(tb.te0);
     const LaneConst lc = make_lane_const();
     const u64 stride = (u64)gridDim.x * UAES_WG * U;
@@ -125,6 +126,7 @@ __global__ __launch_bounds__(UAES_WG, 4) void k_ctr(uaesk_rk rk, uaesk_tables tb
 
     /* reference N3: len%16 tail bytes use Enc(ctr_final) (mixThenXor, :949) */
     if (rem && blockIdx.x == 0 && threadIdx.x == 0) ctr_byte_tail<NR>(rk, ctr, in, out, nfull, rem, lc);
+    ticket_release(done);
 }
 
 #define CTRS_BUF   (UAES_LDS_ENC)            /* 2 x 64 x 32 B after the tables */
@@ -373,7 +375,8 @@ template <int NR, bool DEC>
 __global__ __launch_bounds__(UAES_WG) void k_xts_small(uaesk_rk k1, uaesk_rk k2, uaesk_tables tb,
                                                        uint4 raw_tweak, u32 use_raw, u64 sector_id,
                                                        uint4 *__restrict__ chunk_tw, u64 chunks,
-                                                       u64 main_blocks, const unsigned char *in, unsigned char *out)
+                                                       u64 main_blocks, const unsigned char *in, unsigned char *out,
+                                                       uaesk_done done)
 {
     u32 *te_plain = (u32 *)(uaes_lds + UAES_LDS_ENC);
     uint4 *t0_slot = (uint4 *)(uaes_lds + UAES_LDS_ENC + 1024u);
@@ -413,6 +416,7 @@ __global__ __launch_bounds__(UAES_WG) void k_xts_small(uaesk_rk k1, uaesk_rk k2,
             store16<true>(out + 16u * blk, make_uint4(s[0][0] ^ tw[0], s[0][1] ^ tw[1], s[0][2] ^ tw[2], s[0][3] ^ tw[3]));
         for (u32 q = 0; q < 16; ++q) t = tw_mul_pow64(t);               /* the next run of this wave */
     }
+    ticket_release(done);
 }
 
 /* ciphertext stealing (micro_aes.c:1037-1053): one thread per data unit handles
@@ -601,12 +605,13 @@ static int launch_ecb(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ke
     if (e == hipSuccess) e = set_lds(k_ecb<NR, DEC, 1>, lds);
     if (e != hipSuccess) return (int)e;
     const u64 items = nfull + ((rem || padding) ? 1 : 0);
+    const uaesk_done done = uaesk_ticket_take();              /* the call's only kernel: it carries the ticket */
     if (short_text(items))
         hipLaunchKernelGGL((k_ecb<NR, DEC, 1>), dim3(grid_for(items, UAES_WG)), dim3(UAES_WG), lds, st, *keys, *tb,
-                           (const uint4 *)in, (uint4 *)out, (u64)nfull, (u32)rem, (u32)padding);
+                           (const uint4 *)in, (uint4 *)out, (u64)nfull, (u32)rem, (u32)padding, done);
     else
         hipLaunchKernelGGL((k_ecb<NR, DEC, UAES_U>), dim3(grid_for(items, (u64)UAES_WG * UAES_U)), dim3(UAES_WG), lds, st,
-                           *keys, *tb, (const uint4 *)in, (uint4 *)out, (u64)nfull, (u32)rem, (u32)padding);
+                           *keys, *tb, (const uint4 *)in, (uint4 *)out, (u64)nfull, (u32)rem, (u32)padding, done);
     return (int)hipGetLastError();
 }
 
@@ -631,8 +636,12 @@ static int launch_ctr_u(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *
     const u64 nfull = len / 16;
     const u32 rem = (u32)(len % 16);
     const unsigned grid = grid_for(nfull + (rem ? 1 : 0), (u64)UAES_WG * U);
+    /* an armed ticket rides on an ungated launch only (the gated one is the second half of a GCM decryption,
+     * which never arms) */
+    uaesk_done done = { nullptr, nullptr, 0 };
+    if (!gate) done = uaesk_ticket_take();
     hipLaunchKernelGGL((k_ctr<NR, U>), dim3(grid), dim3(UAES_WG), lds, st, *ek, *tb, *ctr,
-                       (const uint4 *)in, (uint4 *)out, nfull, rem, gate);
+                       (const uint4 *)in, (uint4 *)out, nfull, rem, gate, done);
     return (int)hipGetLastError();
 }
 
@@ -743,9 +752,11 @@ static int launch_xts(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *k1
     if (nsectors == 1 && mb > 0 && cps <= XTS_SMALL_CHUNKS) {         /* one short unit: one launch (k_xts_small) */
         e = set_lds((k_xts_small<NR, DEC>), XTS_SMALL_LDS);
         if (e != hipSuccess) return (int)e;
+        uaesk_done done = { nullptr, nullptr, 0 };
+        if (!r) done = uaesk_ticket_take();                   /* no stealing kernel behind it: it carries the ticket */
         hipLaunchKernelGGL((k_xts_small<NR, DEC>), dim3(1), dim3(UAES_WG), XTS_SMALL_LDS, st, *k1, *k2, *tb, raw,
                            (u32)(tweak16 != nullptr), first_sector, (uint4 *)scratch, cps, mb,
-                           (const unsigned char *)in, (unsigned char *)out);
+                           (const unsigned char *)in, (unsigned char *)out, done);
         if (r)
             hipLaunchKernelGGL((k_xts_cts<NR, DEC>), dim3(1), dim3(UAES_WG), lds, st,
                                *k1, *tb, (const uint4 *)scratch, (u64)1, cps, mb, r, (u64)sector_bytes,
@@ -806,6 +817,33 @@ extern "C" int uaesk_xts(void *stream, const uaesk_tables *tb, int nr,
  * spins on that word instead of entering hipStreamSynchronize (tools/ubench/threadfloor.hip: an empty kernel +
  * hipStreamSynchronize costs 11 us and tops out at 0.31 M calls/s over all host threads; kernel + ticket kernel
  * 8.9 us and 0.6 M calls/s at 8 threads).  Stream order puts it behind the kernels' end-of-kernel release.  */
+static thread_local uaesk_done g_armed = { nullptr, nullptr, 0 };
+
+extern "C" void uaesk_ticket_arm(void *pinned_flag, void *d_count, unsigned seq)
+{
+    g_armed.flag = (unsigned *)pinned_flag; g_armed.count = (unsigned *)d_count; g_armed.seq = seq;
+}
+
+static thread_local int g_unused = 0;
+
+extern "C" int uaesk_ticket_disarm(void)
+{
+    const int still = g_armed.flag != nullptr || g_unused;
+    g_armed.flag = nullptr;
+    g_unused = 0;
+    return still;
+}
+
+/* a launcher took the ticket (so that its building blocks would not) and then found no kernel to put it on */
+void uaesk_ticket_unused() { g_unused = 1; }
+
+uaesk_done uaesk_ticket_take()
+{
+    const uaesk_done d = g_armed;
+    g_armed.flag = nullptr;
+    return d;
+}
+
 __global__ __launch_bounds__(64) void k_ticket(unsigned *flag, unsigned seq, const unsigned *src, unsigned *dst, unsigned nwords)
 {
     if (threadIdx.x < nwords) dst[threadIdx.x] = src[threadIdx.x];
