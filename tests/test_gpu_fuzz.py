@@ -237,6 +237,46 @@ def test_fuzz_feedback_and_macs(orc):
     run_cases(404, 80, body)
 
 
+def test_fuzz_nonce_and_tag_lengths(orc):
+    """GCM / CCM / OCB with the reference's other compile-time lengths (micro_aes.h:103-116) as run-time arguments:
+    random legal nonce and tag lengths, host or device buffers at odd offsets, in place or not; nothing is written
+    behind the (possibly truncated) tag, a forged tag gives 0x1A and -- for GCM -- an untouched output (N7)"""
+    L = uaes.engine()
+
+    def body(rnd, i):
+        bits = rnd.choice([128, 192, 256])
+        key = rnd.randbytes(bits // 8)
+        mode = rnd.choice(["gcm", "ccm", "ocb"])
+        if mode == "gcm":
+            nl, tl, cap = rnd.choice([12, 12, 1, 8, 13, 60]), rnd.randrange(1, 17), 3 << 20
+        elif mode == "ccm":
+            nl, tl, cap = rnd.randrange(7, 14), 2 * rnd.randrange(2, 9), 24 << 10       # the MAC is a serial chain
+        else:
+            nl, tl, cap = rnd.randrange(1, 16), rnd.randrange(1, 17), 300 << 10
+        n = pick_size(rnd, cap)
+        nonce, aad = rnd.randbytes(nl), rnd.randbytes(rnd.choice([0, 0, 1, 16, 33, 700]))
+        pt = orc.splitmix(9000 + i, n)
+        want = getattr(orc, mode + "_encrypt")(key, nonce, aad, pt, tag_len=tl)
+        enc, dec = getattr(L, "uaes_%s_encrypt_ex" % mode), getattr(L, "uaes_%s_decrypt_ex" % mode)
+        b = Buffers(rnd, pt, n + tl)
+        info = (mode, bits, nl, tl, n, len(aad), b.describe())
+        assert enc(bits, key, nonce, nl, tl, aad, len(aad), b.pin, n, b.pout) == 0, info
+        got, guard_ok = b.result()
+        assert got == want and guard_ok, info
+        b = Buffers(rnd, want, n)
+        assert dec(bits, key, nonce, nl, tl, aad, len(aad), b.pin, n, b.pout) == 0, info
+        got, guard_ok = b.result()
+        assert got == pt and guard_ok, info
+        bad = bytearray(want)
+        bad[n + rnd.randrange(tl)] ^= 1 << rnd.randrange(8)
+        b = Buffers(rnd, bytes(bad), n)
+        assert dec(bits, key, nonce, nl, tl, aad, len(aad), b.pin, n, b.pout) == 0x1A, info
+        if mode == "gcm" and not b.alias:
+            assert all(x == b.guard for x in b.result()[0]), info
+
+    run_cases(606, 120, body)
+
+
 def test_fuzz_ctr_large_sizes_piecewise(orc):
     """60-200 MiB texts (several rounds of 256 KiB chunks plus thin last rounds): one call equals
     three calls over random 16-byte-aligned cuts with the block offset advanced, and the first and

@@ -4,6 +4,7 @@ host/device pointers, concurrent host threads (the reference is not re-entrant,
 micro_aes.c:72 -- this library must be), and streams > 4 GiB (64-bit indexing)."""
 import ctypes as C
 import hashlib
+import os
 import random
 import threading
 
@@ -91,6 +92,50 @@ def test_concurrent_host_threads(orc):
     for t in threads:
         t.join()
     assert not errors
+
+
+def test_completion_tickets_and_the_plain_wait_agree(orc):
+    """a synchronous call ends with a completion ticket: carried by the call's only kernel (ECB,
+    short CTR, a one-launch XTS unit, a one-launch GCM encryption), by the ticket kernel behind a multi-launch call,
+    or -- a call that runs longer than the spin window -- by hipStreamSynchronize after all.  All three, and the
+    build with UAES_TICKET=0, must hand over the same bytes; many short calls from many threads exercise the
+    per-lane sequence numbers"""
+    import subprocess
+    import sys
+    code = r'''
+import sys, hashlib, threading
+sys.path.insert(0, %r)
+import micro_aes_amd as uaes
+from oracle.pyoracle import Oracle
+orc = Oracle()
+key, iv, n12 = bytes(range(16)), bytes(range(16, 28)), bytes(range(12))
+h = hashlib.sha256()
+for n in (16, 4096, 65536, 300000, 3 << 20):                  # one launch .. the spin window is exceeded
+    d = orc.splitmix(77, n)
+    for out in (uaes.AES_ECB_encrypt(key, d), uaes.AES_CTR_encrypt(key, iv, d), uaes.AES_GCM_encrypt(key, n12, b"a", d),
+                uaes.AES_XTS_encrypt(bytes(range(32)), bytes(16), d)[1], uaes.AES_OCB_encrypt(key, n12, b"", d),
+                uaes.AES_GCM_decrypt(key, n12, b"a", uaes.AES_GCM_encrypt(key, n12, b"a", d))[1]):
+        h.update(out)
+    if n <= 65536:
+        h.update(uaes.AES_CMAC(key, d)); h.update(uaes.AES_CBC_encrypt(key, bytes(16), d)[1])
+bad = []
+def work(t):
+    d = orc.splitmix(t, 4096 + 16 * t)
+    want = orc.ctr_encrypt(key, iv, d), orc.gcm_encrypt(key, n12, b"", d)
+    for _ in range(300):
+        if uaes.AES_CTR_encrypt(key, iv, d) != want[0] or uaes.AES_GCM_encrypt(key, n12, b"", d) != want[1]:
+            bad.append(t)
+ts = [threading.Thread(target=work, args=(t,)) for t in range(8)]
+[t.start() for t in ts]; [t.join() for t in ts]
+print(h.hexdigest(), len(bad))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for ticket in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, UAES_TICKET=ticket), capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.split()[-2:])
+    assert outs[0] == outs[1] and outs[0][1] == "0", outs
 
 
 def test_ctr_stream_larger_than_4GiB(orc):
