@@ -463,7 +463,11 @@ class GcmKey:
             engine().uaes_gcm_key_free(self._h)
             self._h = None
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # interpreter shutdown: the module globals may be gone already
+            pass
 
 
 class GcmStream:

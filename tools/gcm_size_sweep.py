@@ -12,7 +12,8 @@ import micro_aes_amd as uaes
 key, nonce = bytes(range(16)), bytes(range(12))
 ctr0 = nonce + b"\0\0\0\1"
 st = torch.cuda.current_stream()
-print("%9s  %-18s %-18s %-18s" % ("KiB", "ctr", "gcm encrypt", "gcm decrypt"))
+gk = uaes.GcmKey(key)
+print("%9s  %-18s %-18s %-18s %-18s %-18s" % ("KiB", "ctr", "gcm encrypt", "gcm decrypt", "keyed encrypt", "keyed decrypt"))
 for kib in (4, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 65536):
     n = kib << 10
     src = torch.randint(0, 256, (n,), dtype=torch.uint8, device="cuda")
@@ -23,7 +24,9 @@ for kib in (4, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 65536):
     row = []
     for fn in (lambda: uaes.ctr_xcrypt_dev(key, ctr0, 0, src, back, nbytes=n, stream=st),
                lambda: uaes.gcm_encrypt_dev(key, nonce, None, src, n, dst, stream=st),
-               lambda: uaes.gcm_decrypt_dev(key, nonce, None, dst, n, back, status, stream=st)):
+               lambda: uaes.gcm_decrypt_dev(key, nonce, None, dst, n, back, status, stream=st),
+               lambda: gk.encrypt_dev(nonce, None, src, n, dst, stream=st),
+               lambda: gk.decrypt_dev(nonce, None, dst, n, back, status, stream=st)):
         reps = 300 if kib <= 8192 else 100
         for _ in range(reps // 2):
             fn()
