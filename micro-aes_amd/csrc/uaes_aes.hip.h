@@ -73,6 +73,10 @@ struct TicketScope {
 __device__ __forceinline__ void ticket_release(const uaesk_done &d)
 {
     if (!d.flag) return;                             /* kernel argument: uniform */
+    /* every wave first waits until its own stores have been acknowledged (in the usual, non-tgsplit mode a
+     * workgroup-scope release does not have to: the waves of a workgroup share their CU's L1 path, so the barrier
+     * alone would let thread 0's fence run while another wave's stores are still on their way to L2 / the fabric) */
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                 /* workgroup-scope release / acquire: the workgroup's stores
                                                       * happen-before what thread 0 does next                      */
     if (threadIdx.x != 0) return;
