@@ -69,15 +69,17 @@ const char *uaes_version(void);
  * bit-identical.  on != 0 selects the reference's INCREASE_SECURITY behaviour instead: the
  * buffer is zeroed.  Process-wide; returns the previous setting.  (The *_dev calls of those
  * three modes report through d_status and leave the decision to the caller.)
- * GCM never releases unauthenticated text (N7).  By default it therefore reads a ciphertext in
- * device memory twice (GHASH, tag check, then CTR: 1.5x the traffic).  With the switch on, a
- * long GCM decrypt into the caller's device buffer runs CTR and GHASH in ONE pass and, when the
- * tag turns out wrong, zeroes what it wrote before it reports 0x1A / a non-zero *d_status --
- * the caller has said a wiped buffer is acceptable, and after the call (or, for the *_dev
- * calls, after the stream has run) the buffer never holds unauthenticated plaintext.
- * Host-memory callers get the one-pass kernel regardless: their plaintext is produced in a
- * private staging buffer that is copied out only after the tag has been verified.          */
+ * GCM never releases unauthenticated text (N7) and is not affected by this switch.               */
 int         uaes_set_wipe_on_auth_failure(int on);
+/* GCM decryption into a caller's DEVICE buffer reads the ciphertext twice by default (GHASH, tag check, then
+ * CTR: 1.5x the traffic), because nothing may be written before the tag is known (N7, micro_aes.c:1204-1210).
+ * on != 0: a long text is decrypted and hashed in ONE pass (8 % faster at 1 GiB) and, when the tag turns out
+ * wrong, everything written is zeroed before 0x1A / a non-zero *d_status is reported -- between the launch and that
+ * moment the buffer holds unauthenticated plaintext, which other streams could observe: that is what the caller
+ * accepts by switching this on.  Process-wide; returns the previous setting.  Host-memory callers get the one-pass
+ * kernel regardless: their plaintext is produced in a private staging buffer that is copied out only after the
+ * tag has been verified.                                                                                   */
+int         uaes_set_gcm_one_pass_decrypt(int on);
 /* The *_dev calls keep a device scratch buffer (GHASH tables, XTS chunk tweaks) per
  * hipStream_t they have been used with (8 per device; beyond that the least recently
  * used one is recycled after a device-wide drain).  Call this when a stream will not

@@ -75,7 +75,18 @@ int uaes_set_wipe_on_auth_failure(int on)
 static int wipe_on_auth_failure(void) { return __atomic_load_n(&g_wipe_on_auth_failure, __ATOMIC_ACQUIRE); }
 /* GCM decrypt into the caller's device buffer: two passes (tag first, N7) unless the caller has
  * accepted a zeroed output on failure, which lets CTR and GHASH share one pass (uaesk_gcm, mode 2) */
-static int gcm_decrypt_mode(void) { return wipe_on_auth_failure() ? 2 : 1; }
+/* GCM decryption into a caller's DEVICE buffer: two passes (GHASH, tag check, then CTR -- nothing is written
+ * before the tag is known, N7) unless the caller has asked for the one-pass order BY NAME: the text is then written
+ * while it is hashed and zeroed if the tag turns out wrong.  (Round 2 hung this on the wipe switch above, whose name
+ * promises more safety, not less: ADVICE r02.)                                                              */
+static int g_gcm_one_pass = 0;
+
+int uaes_set_gcm_one_pass_decrypt(int on)
+{
+    return __atomic_exchange_n(&g_gcm_one_pass, on != 0, __ATOMIC_ACQ_REL);
+}
+
+static int gcm_decrypt_mode(void) { return __atomic_load_n(&g_gcm_one_pass, __ATOMIC_ACQUIRE) ? 2 : 1; }
 
 /* tag comparison whose run time does not depend on where the tags differ */
 static int tags_differ(const uint8_t *a, const uint8_t *b, size_t n)

@@ -338,11 +338,11 @@ def test_fuzz_gcm_one_pass_sizes(orc):
         uaes.gcm_decrypt_dev(key, nonce, a, dst, n, back, status)
         torch.cuda.synchronize()
         assert int(status.item()) == 0 and torch.equal(back, src[:n]), info
-        # the one-pass decrypt (allowed once the caller accepts a wiped buffer on failure): same plaintext,
+        # the one-pass decrypt (uaes_set_gcm_one_pass_decrypt: the caller accepts a wiped buffer on failure): same plaintext,
         # out of place and in place
         L = uaes.engine()
         try:
-            L.uaes_set_wipe_on_auth_failure(1)
+            L.uaes_set_gcm_one_pass_decrypt(1)
             back.fill_(0x5A)
             status.fill_(-1)
             uaes.gcm_decrypt_dev(key, nonce, a, dst, n, back, status)
@@ -358,7 +358,7 @@ def test_fuzz_gcm_one_pass_sizes(orc):
             torch.cuda.synchronize()
             assert int(status.item()) == 0x1A and int(back.sum()) == 0, info         # forged: zeroed
         finally:
-            L.uaes_set_wipe_on_auth_failure(0)
+            L.uaes_set_gcm_one_pass_decrypt(0)
         back.fill_(0x5A)
         uaes.gcm_decrypt_dev(key, nonce, a, dst, n, back, status)
         torch.cuda.synchronize()

@@ -931,7 +931,7 @@ def test_gcm_chunk_and_combine_kernels(orc, bits):
             assert torch.equal(two[: n + 16], dst[: n + 16]), (n, alen)
             status = torch.full((1,), -1, dtype=torch.int32, device="cuda:0")
             for sw in (0, 1):                                            # tag first / one pass
-                L.uaes_set_wipe_on_auth_failure(sw)
+                L.uaes_set_gcm_one_pass_decrypt(sw)
                 back = torch.full((n + 16,), 0xCC, dtype=torch.uint8, device="cuda:0")
                 uaes.gcm_decrypt_dev(key, nonce, a, dst, n, back, status)
                 torch.cuda.synchronize()
@@ -943,19 +943,19 @@ def test_gcm_chunk_and_combine_kernels(orc, bits):
                 torch.cuda.synchronize()
                 assert int(status.item()) == 0x1A, (n, alen, sw)
                 assert int((back[:n] != (0 if sw else 0xCC)).sum()) == 0 and int((back[n:] != 0xCC).sum()) == 0, (n, alen, sw)
-            L.uaes_set_wipe_on_auth_failure(0)
+            L.uaes_set_gcm_one_pass_decrypt(0)
             work = dst[: n + 16].clone()                                  # in place
             uaes.gcm_decrypt_dev(key, nonce, a, work, n, work, status)
             torch.cuda.synchronize()
             assert int(status.item()) == 0 and torch.equal(work[:n], src[:n])
     finally:
-        L.uaes_set_wipe_on_auth_failure(0)
+        L.uaes_set_gcm_one_pass_decrypt(0)
         k.close()
 
 
 @pytest.mark.parametrize("bits", [128, 192, 256])
 def test_gcm_one_pass_decrypt(orc, bits):
-    """uaes_set_wipe_on_auth_failure(1): a long GCM decrypt into the caller's device buffer runs CTR and
+    """uaes_set_gcm_one_pass_decrypt(1): a long GCM decrypt into the caller's device buffer runs CTR and
     GHASH in one pass (k_gcm_fused<NR, true>: the lane hashes the ciphertext block it has just read, the
     tail is decrypted after the tag check).  Good tags: plaintext identical to the two-pass result, out of
     place and in place, AAD of every shape, ragged tails, key context too.  Bad tag / bad AAD / a flipped
@@ -970,7 +970,7 @@ def test_gcm_one_pass_decrypt(orc, bits):
              (2 * S16 + 5000, 16), (3 * S16 - 1, 4096 + 7), (5 * S16 + 12345, 0)]
     k = uaes.GcmKey(key)
     try:
-        assert L.uaes_set_wipe_on_auth_failure(1) == 0
+        assert L.uaes_set_gcm_one_pass_decrypt(1) == 0
         for i, (n, alen) in enumerate(cases):
             pt = orc.splitmix(2000 + i, (n + 7) // 8 * 8)[:n]
             aad = rnd.randbytes(alen)
@@ -1009,7 +1009,7 @@ def test_gcm_one_pass_decrypt(orc, bits):
                 uaes.gcm_decrypt_dev(key, nonce, a2, work, n, work, status)        # in place: the ciphertext is gone
                 torch.cuda.synchronize()
                 assert int(status.item()) != 0 and int(work[:n].sum()) == 0 and torch.equal(work[n:], ct[n:])
-        assert L.uaes_set_wipe_on_auth_failure(0) == 1
+        assert L.uaes_set_gcm_one_pass_decrypt(0) == 1
         # default switch: device buffers untouched on a forgery (two passes) ...
         n = S16 + 70000
         pt = orc.splitmix(77, n)
@@ -1025,14 +1025,14 @@ def test_gcm_one_pass_decrypt(orc, bits):
         assert int(status.item()) != 0 and int((back != 0xCC).sum()) == 0
         # ... and host buffers (one pass in private staging) likewise, both switch settings
         for sw in (0, 1):
-            L.uaes_set_wipe_on_auth_failure(sw)
+            L.uaes_set_gcm_one_pass_decrypt(sw)
             assert uaes.AES_GCM_decrypt(key, nonce, b"hdr", full) == (0, pt)
             rc, text = uaes.AES_GCM_decrypt(key, nonce, b"hdr", bytes(bad), prefill=0xCC)
             assert rc == 0x1A and text == b"\xcc" * n
             assert k.decrypt(nonce, b"hdr", full) == (0, pt)
             assert k.decrypt(nonce, b"hdr", bytes(bad), prefill=0xCC) == (0x1A, b"\xcc" * n)
     finally:
-        L.uaes_set_wipe_on_auth_failure(0)
+        L.uaes_set_gcm_one_pass_decrypt(0)
         k.close()
 
 

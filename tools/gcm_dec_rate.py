@@ -1,5 +1,5 @@
 """GCM decrypt of a device-resident message: the default two-pass order (tag first, N7) against the
-one-pass kernel that uaes_set_wipe_on_auth_failure(1) allows.  Interleaved rounds, hipEvent timing."""
+one-pass kernel that uaes_set_gcm_one_pass_decrypt(1) allows.  Interleaved rounds, hipEvent timing."""
 import os
 import sys
 
@@ -23,7 +23,7 @@ def main():
         for rnd in range(3):
             for name, sw, keyed in (("two-pass", 0, False), ("one-pass", 1, False), ("one-pass keyed", 1, True),
                                     ("encrypt", 0, False)):
-                L.uaes_set_wipe_on_auth_failure(sw)
+                L.uaes_set_gcm_one_pass_decrypt(sw)
                 reps = max(5, min(200, (8 << 30) // n))
 
                 def call():
@@ -46,7 +46,7 @@ def main():
                 res.setdefault(name, []).append(ms)
                 if name != "encrypt":
                     assert int(status.item()) == 0 and torch.equal(out, src)
-        L.uaes_set_wipe_on_auth_failure(0)
+        L.uaes_set_gcm_one_pass_decrypt(0)
         k.close()
         print("%5d MiB  " % (n >> 20) + "  ".join("%s %.4f ms %6.1f GiB/s" % (nm, min(v), n / 2**30 / (min(v) * 1e-3))
                                                    for nm, v in res.items()), flush=True)
