@@ -641,6 +641,25 @@ static int lane_fetch(lane *L, void *host, const void *dev, size_t n)
     return lane_wait_fetch(L, host, dev, n);
 }
 
+/* Where a synchronous call's kernels put their status word (0 / 0x1A): a word of the lane's pinned page when there
+ * is one -- the host then reads it as soon as the stream has drained, no copy command, and a one-launch decryption can
+ * carry the completion ticket itself -- else the lane's device slot.                                            */
+static int *lane_status(lane *L)
+{
+    if (ticket_enabled() && pinned_ready(L)) return (int *)((char *)L->pinx + TICKET_OFF + 16);
+    return L->d_status;
+}
+
+/* wait for the lane, then the status word its kernels wrote through `where` (= lane_status(L)) */
+static int lane_read_status(lane *L, int *where, int *status)
+{
+    int rc;
+    if (where == L->d_status) return lane_fetch(L, status, L->d_status, sizeof *status);
+    if ((rc = lane_sync(L)) != 0) return rc;
+    *status = *(volatile int *)where;
+    return 0;
+}
+
 static int is_device_ptr(const void *p)
 {
     hipPointerAttribute_t a;
@@ -671,6 +690,7 @@ typedef struct {
     size_t      out_len;
     int         copy_back;
     int         out_is_host;
+    int         drained;            /* the caller has just waited for the lane (status fetch) and queued nothing since */
     lane       *L;
 } io_plan;
 
@@ -721,6 +741,7 @@ static int plan_io(lane *L, const void *in, size_t in_len, void *out, size_t out
     const int out_ok = out_cap == 0 || (out_dev && (((uintptr_t)out) & 15u) == 0);
     hipStream_t st = (hipStream_t)L->stream;
     io->user_out = out;
+    io->drained = 0;
     io->copy_back = !out_ok;
     io->out_is_host = !out_dev;
     io->din = in;
@@ -758,7 +779,7 @@ static int finish_io(io_plan *io, size_t out_len)
     hipStream_t st = (hipStream_t)L->stream;
     int rc;
     if (io->dout && io->dout == L->pin[1]) {      /* the kernel wrote the mapped pinned buffer itself */
-        if ((rc = lane_sync(L)) != 0) return rc;
+        if (!io->drained && (rc = lane_sync(L)) != 0) return rc;
         if (out_len) memcpy(io->user_out, L->pin[1], out_len);
         return 0;
     }
@@ -775,7 +796,7 @@ static int finish_io(io_plan *io, size_t out_len)
         HIPCHK(hipStreamSynchronize(st));
         return 0;
     }
-    return lane_sync(L);
+    return io->drained ? 0 : lane_sync(L);
 }
 
 /* a call bails out with work possibly queued on the lane: nothing of it may still be running
@@ -1485,11 +1506,16 @@ int uaes_gcm_decrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, s
             io.dout = L->stage[1];
         }
         /* a private staging buffer may be written before the tag is known: one pass */
-        int k = uaesk_gcm(L->stream, &c->tb, ks.nr, &ks.ek, io.copy_back ? 2 : gcm_decrypt_mode(), j0, d_aad, aDataLen,
-                          io.din, crtxtLen, io.dout, L->scratch, L->d_status);
+        int *st_where = lane_status(L);
+        if (st_where != L->d_status) { *(volatile int *)st_where = -1; ticket_arm(L); }   /* host-visible status: a
+                                                     * one-launch decryption may carry the completion ticket itself */
+        int k = uaesk_gcm(L->stream, &c->tb, ks.nr, &ks.ek, io.copy_back || io.dout == L->pin[1] ? 2 : gcm_decrypt_mode(),
+                          j0, d_aad, aDataLen, io.din, crtxtLen, io.dout, L->scratch, st_where);
+        ticket_armed_launch_done(L);
         if (k) { rc = fail(UAES_E_HIP, "gcm launch: %s", hipGetErrorString((hipError_t)k)); break; }
-        if ((rc = lane_fetch(L, &status, L->d_status, sizeof status)) != 0) break;
+        if ((rc = lane_read_status(L, st_where, &status)) != 0) break;
         if (status != 0) { rc = UAES_E_AUTHENTICATION; break; }  /* N7: pntxt untouched */
+        io.drained = 1;
         rc = finish_io(&io, crtxtLen);
     } while (0);
     DONE(L, rc);
@@ -1632,8 +1658,10 @@ int uaes_gcm_key_encrypt(uaes_gcm_key *k, const uint8_t *nonce, const void *aDat
     do {
         if ((rc = stage_aad(L, aData, aDataLen, &d_aad)) != 0) break;
         if ((rc = plan_io(L, pntxt, ptextLen, crtxt, ptextLen + 16, &io)) != 0) break;
+        ticket_arm(L);
         int kk = uaesk_gcm_keyed(L->stream, &c->tb, k->ks.nr, &k->ks.ek, 0, j0, d_aad, aDataLen,
                                  io.din, ptextLen, io.dout, k->scratch, NULL);
+        ticket_armed_launch_done(L);
         if (kk) { rc = fail(UAES_E_HIP, "gcm launch: %s", hipGetErrorString((hipError_t)kk)); break; }
         rc = finish_io(&io, ptextLen + 16);
     } while (0);
@@ -1660,11 +1688,16 @@ int uaes_gcm_key_decrypt(uaes_gcm_key *k, const uint8_t *nonce, const void *aDat
             if (grow_on(L->stream, &L->stage[1], &L->stage_cap[1], crtxtLen + 64)) { rc = UAES_E_HIP; break; }
             io.dout = L->stage[1];
         }
-        int kk = uaesk_gcm_keyed(L->stream, &c->tb, k->ks.nr, &k->ks.ek, io.copy_back ? 2 : gcm_decrypt_mode(), j0, d_aad, aDataLen,
-                                 io.din, crtxtLen, io.dout, k->scratch, L->d_status);
+        int *st_where = lane_status(L);
+        if (st_where != L->d_status) { *(volatile int *)st_where = -1; ticket_arm(L); }
+        int kk = uaesk_gcm_keyed(L->stream, &c->tb, k->ks.nr, &k->ks.ek,
+                                 io.copy_back || io.dout == L->pin[1] ? 2 : gcm_decrypt_mode(), j0, d_aad, aDataLen,
+                                 io.din, crtxtLen, io.dout, k->scratch, st_where);
+        ticket_armed_launch_done(L);
         if (kk) { rc = fail(UAES_E_HIP, "gcm launch: %s", hipGetErrorString((hipError_t)kk)); break; }
-        if ((rc = lane_fetch(L, &status, L->d_status, sizeof status)) != 0) break;
+        if ((rc = lane_read_status(L, st_where, &status)) != 0) break;
         if (status != 0) { rc = UAES_E_AUTHENTICATION; break; }  /* N7: pntxt untouched */
+        io.drained = 1;
         rc = finish_io(&io, crtxtLen);
     } while (0);
     DONE(L, rc);
@@ -2178,11 +2211,18 @@ static int ocb_common(int keybits, const uint8_t *key, const uint8_t *nonce, siz
         if ((rc = gcm_scratch(L)) != 0) break;        /* >= uaesk_ocb_scratch_bytes() */
         if ((rc = stage_aad(L, aData, aDataLen, &d_aad)) != 0) break;
         if ((rc = plan_io(L, in, len + (decrypt ? tagLen : 0), out, len + (decrypt ? 0 : tagLen), &io)) != 0) break;
+        int *st_where = lane_status(L);
+        if (!decrypt || st_where != L->d_status) {            /* a one-launch call may carry the completion ticket */
+            if (decrypt) *(volatile int *)st_where = -1;
+            ticket_arm(L);
+        }
         int k = uaesk_ocb(L->stream, &c->tb, ks.nr, &ks.ek, &ks.dk, decrypt, nonce, nonceLen, tagLen, d_aad, aDataLen,
-                          io.din, len, io.dout, L->scratch, L->d_status);
+                          io.din, len, io.dout, L->scratch, st_where);
+        ticket_armed_launch_done(L);
         if (k) { rc = fail(UAES_E_HIP, "ocb launch: %s", hipGetErrorString((hipError_t)k)); break; }
         if (decrypt) {
-            if ((rc = lane_fetch(L, &status, L->d_status, sizeof status)) != 0) break;
+            if ((rc = lane_read_status(L, st_where, &status)) != 0) break;
+            io.drained = 1;
         }
         /* decrypt: the text stays on a bad tag, as in the reference, unless wiping is switched on */
         if ((rc = (decrypt && status != 0) ? finish_io_unauthenticated(&io, len)

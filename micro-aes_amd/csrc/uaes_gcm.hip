@@ -1472,7 +1472,6 @@ static int gcm_body(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk
     /* an armed completion ticket (uaes_device.h) may ride on a ONE-launch encryption only; taking it here also
      * keeps the building blocks below (uaesk_ctr_xcrypt) from picking it up in the middle of a longer sequence */
     TicketScope ticket;
-    const uaesk_done no_ticket = { nullptr, nullptr, 0 };
     /* J0 = nonce || 00000001 for the 12-byte nonce (GCMsetup, micro_aes.c:1150-1151), or
      * GHASH(nonce) (uaesk_gcm_j0); the host layer passes the 16 bytes                     */
     uint4 j0;
@@ -1591,8 +1590,8 @@ static int gcm_body(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk
         }
         GSrc sm = msg;
         sm.ct = (const unsigned char *)in;     /* the kernel reads the text itself */
-        if (decrypt)                               /* (its status word still has to travel: the host sends k_ticket) */
-            return launch_small_nr<true>(nr, st, tb, ek, &c, j0, sm, in, out, sc, (unsigned char *)in + len, status, build, no_ticket);
+        if (decrypt)                               /* (the host layer arms a ticket only with a host-visible status word) */
+            return launch_small_nr<true>(nr, st, tb, ek, &c, j0, sm, in, out, sc, (unsigned char *)in + len, status, build, ticket.use());
         return launch_small_nr<false>(nr, st, tb, ek, &c, j0, sm, in, out, sc, (unsigned char *)out + len, nullptr, build, ticket.use());
     }
     /* (a decrypt that must authenticate first has no one-pass alternative: the chunk kernels serve it as far as

@@ -341,35 +341,37 @@ __device__ __forceinline__ void ocb_final_body(const uaesk_rk &ek, const LaneCon
         for (int q = 0; q < 4; ++q) { atomicXor(acc + q, h[q]); atomicXor(acc + 4 + q, cs[q]); }
     }
     __syncthreads();
-    if (threadIdx.x != 0) return;
-
-    const u64 n = len >> 4;
-    const u32 r = (u32)(len & 15u);
-    B16 d = b16(scr[OCB_ROW_OFF0]);
-    bx(d, ocb_delta(n));                              /* Offset_m */
-    B16 ck = b16(*(const uint4 *)(uaes_lds + OCB_LDS_ACC + 16u));
-    if (r) {                                          /* :1736-1741 */
-        bx(d, lds_row(0));                            /* Offset_* = Offset_m ^ L_* */
-        B16 pad = d;
-        ocb_enc1<NR>(pad, ek, lc);
-        for (u32 i = 0; i < r; ++i) {
-            const u32 x = in[16 * n + i];
-            const u32 y = x ^ ((pad.w[i >> 2] >> (8 * (i & 3))) & 0xffu);
-            ck.w[i >> 2] ^= (decrypt ? y : x) << (8 * (i & 3));
-            out[16 * n + i] = (unsigned char)y;
+    /* the rest is one thread's work; the others fall through to the end of the kernel (a completion ticket
+     * riding on k_ocb_small needs every thread there, ticket_release)                                   */
+    if (threadIdx.x == 0) {
+        const u64 n = len >> 4;
+        const u32 r = (u32)(len & 15u);
+        B16 d = b16(scr[OCB_ROW_OFF0]);
+        bx(d, ocb_delta(n));                              /* Offset_m */
+        B16 ck = b16(*(const uint4 *)(uaes_lds + OCB_LDS_ACC + 16u));
+        if (r) {                                          /* :1736-1741 */
+            bx(d, lds_row(0));                            /* Offset_* = Offset_m ^ L_* */
+            B16 pad = d;
+            ocb_enc1<NR>(pad, ek, lc);
+            for (u32 i = 0; i < r; ++i) {
+                const u32 x = in[16 * n + i];
+                const u32 y = x ^ ((pad.w[i >> 2] >> (8 * (i & 3))) & 0xffu);
+                ck.w[i >> 2] ^= (decrypt ? y : x) << (8 * (i & 3));
+                out[16 * n + i] = (unsigned char)y;
+            }
+            ck.w[r >> 2] ^= 0x80u << (8 * (r & 3));
         }
-        ck.w[r >> 2] ^= 0x80u << (8 * (r & 3));
-    }
-    bx(ck, d);
-    bx(ck, lds_row(1));                               /* ^ L_$ */
-    ocb_enc1<NR>(ck, ek, lc);
-    bx(ck, b16(*(const uint4 *)(uaes_lds + OCB_LDS_ACC)));
-    if (!decrypt) {                                   /* the first OCB_TAG_LEN bytes (:1783 / :1807) */
-        for (u32 i = 0; i < tag_len; ++i) out[len + i] = (unsigned char)(ck.w[i >> 2] >> (8 * (i & 3)));
-    } else {
-        u32 diff = 0;
-        for (u32 i = 0; i < tag_len; ++i) diff |= (u32)in[len + i] ^ ((ck.w[i >> 2] >> (8 * (i & 3))) & 0xffu);
-        *status = diff ? 0x1A : 0;
+        bx(ck, d);
+        bx(ck, lds_row(1));                               /* ^ L_$ */
+        ocb_enc1<NR>(ck, ek, lc);
+        bx(ck, b16(*(const uint4 *)(uaes_lds + OCB_LDS_ACC)));
+        if (!decrypt) {                                   /* the first OCB_TAG_LEN bytes (:1783 / :1807) */
+            for (u32 i = 0; i < tag_len; ++i) out[len + i] = (unsigned char)(ck.w[i >> 2] >> (8 * (i & 3)));
+        } else {
+            u32 diff = 0;
+            for (u32 i = 0; i < tag_len; ++i) diff |= (u32)in[len + i] ^ ((ck.w[i >> 2] >> (8 * (i & 3))) & 0xffu);
+            *status = diff ? 0x1A : 0;
+        }
     }
 }
 
@@ -399,7 +401,7 @@ __global__ __launch_bounds__(UAES_WG) void k_ocb_small(uaesk_rk ek, uaesk_rk dk,
                                                        uint4 *scr,
                                                        const unsigned char *__restrict__ aad, u64 aad_len,
                                                        const unsigned char *in, unsigned char *out, u64 len,
-                                                       int *status, u32 tag_len)
+                                                       int *status, u32 tag_len, uaesk_done done)
 {
 #ifdef UAES_OCB_TIMING
     u64 ts[6];
@@ -468,6 +470,7 @@ __global__ __launch_bounds__(UAES_WG) void k_ocb_small(uaesk_rk ek, uaesk_rk dk,
                (unsigned long long)(ts[5] - ts[4]));
 #endif
 #undef OT
+    ticket_release(done);
 }
 
 /* ------------------------------------------------------------------------ */
@@ -501,16 +504,19 @@ static int launch_ocb(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek
     while (span) { ++bits; span >>= 1; }
     const u32 nrows = 2u + bits + 2u < OCB_NL ? 2u + bits + 2u : OCB_NL;
     if ((len >> 4) <= OCB_SMALL_BLOCKS && aad_len <= OCB_SMALL_AAD) {         /* short message: one launch */
+        /* ... which can carry the call's completion ticket (a decryption's status word must then be host-visible:
+         * the host layer arms a ticket only when it passes a pinned status pointer) */
+        const uaesk_done done = uaesk_ticket_take();
         const void *ks = decrypt ? (const void *)k_ocb_small<NR, true> : (const void *)k_ocb_small<NR, false>;
         if ((e = want_lds(ks)) != hipSuccess) return (int)e;
         if (decrypt)
             hipLaunchKernelGGL((k_ocb_small<NR, true>), dim3(1), dim3(UAES_WG), OCB_LDS, st, *ek, *dk, *tb, nb, bottom, nrows,
                                scr, (const unsigned char *)aad, (u64)aad_len, (const unsigned char *)in,
-                               (unsigned char *)out, (u64)len, status, tag_len);
+                               (unsigned char *)out, (u64)len, status, tag_len, done);
         else
             hipLaunchKernelGGL((k_ocb_small<NR, false>), dim3(1), dim3(UAES_WG), OCB_LDS, st, *ek, *ek, *tb, nb, bottom, nrows,
                                scr, (const unsigned char *)aad, (u64)aad_len, (const unsigned char *)in,
-                               (unsigned char *)out, (u64)len, status, tag_len);
+                               (unsigned char *)out, (u64)len, status, tag_len, done);
         return (int)hipGetLastError();
     }
     hipLaunchKernelGGL((k_ocb_setup<NR>), dim3(1), dim3(UAES_WG), OCB_LDS, st, *ek, *tb, nb, bottom, nrows, scr);
