@@ -58,6 +58,10 @@ int         uaes_shutdown(void);
 /* Run the on-device primitive self test (FIPS-197 C.1 both directions, byte
  * permute semantics, tweak arithmetic).  0 = pass, >0 = failure bitmask.     */
 int         uaes_selftest(void);
+/* Measurement aid: one wave on `stream` spins for spin_us microseconds of the constant 100 MHz counter and writes
+ * { shader cycles elapsed, 100 MHz ticks elapsed } (two uint64) to d_out16 -- the shader clock the chip really runs
+ * at while other streams load it (bench.py reports it beside the roofline).  Enqueue only.                    */
+int         uaes_clock_probe_dev(void *d_out16, unsigned spin_us, void *stream);
 /* Thread-local description of the last negative return value.               */
 const char *uaes_last_error(void);
 /* "uaes-hip <version> gfx950"                                               */

@@ -33,7 +33,7 @@ M_ENCRYPTION_ERROR = 0x1E
 
 EXPORTS = [
     "uaes_init", "uaes_shutdown", "uaes_selftest", "uaes_last_error", "uaes_version", "uaes_expand_key", "uaes_stream_release",
-    "uaes_set_wipe_on_auth_failure", "uaes_set_gcm_one_pass_decrypt",
+    "uaes_set_wipe_on_auth_failure", "uaes_set_gcm_one_pass_decrypt", "uaes_clock_probe_dev",
     "uaes_ecb_encrypt", "uaes_ecb_encrypt_padded", "uaes_ecb_decrypt", "uaes_ctr_xcrypt", "uaes_ctr_xcrypt_at",
     "uaes_xts_encrypt", "uaes_xts_decrypt", "uaes_xts_sectors",
     "uaes_gcm_encrypt", "uaes_gcm_decrypt", "uaes_gcm_encrypt_iv", "uaes_gcm_decrypt_iv", "uaes_ghash",
@@ -106,6 +106,7 @@ def engine():
     for n in ("uaes_ecb_encrypt", "uaes_ecb_decrypt"):
         getattr(L, n).argtypes = [i, vp, vp, sz, vp]
     L.uaes_stream_release.argtypes = [vp]
+    L.uaes_clock_probe_dev.argtypes = [vp, C.c_uint, vp]
     L.uaes_cbc_encrypt_batch.argtypes = [i, vp, vp, sz, sz, vp, vp]
     L.uaes_cmac_batch.argtypes = [i, vp, sz, sz, vp, vp]
     L.uaes_ecb_encrypt_padded.argtypes = [i, vp, i, vp, sz, vp]

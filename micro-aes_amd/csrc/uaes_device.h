@@ -192,6 +192,10 @@ int  uaesk_ticket_disarm(void);
  * of 4, <= 64) from d_src to pinned_dst and then stores seq to *pinned_flag with system-scope release.   */
 int uaesk_ticket(void *stream, void *pinned_flag, unsigned seq, const void *d_src, void *pinned_dst, unsigned nbytes);
 
+/* measurement: one wave spins for ticks_100mhz periods of the constant 100 MHz counter and writes
+ * { shader cycles, reference ticks } (two 64-bit words) to d_out16                               */
+int uaesk_clock_probe(void *stream, void *d_out16, unsigned long long ticks_100mhz);
+
 /* Device self-test of the primitives; writes a bitmask of failures.        */
 int uaesk_selftest(void *stream, const uaesk_tables *tb, const uaesk_rk *ek128,
                    const uaesk_rk *dk128, unsigned *d_result);

@@ -1041,6 +1041,17 @@ int uaes_shutdown(void)
     return rc;
 }
 
+/* enqueue the shader-clock probe (uaes_device.h) on `stream`: d_out16 receives { shader cycles, 100 MHz ticks } */
+int uaes_clock_probe_dev(void *d_out16, unsigned spin_us, void *stream)
+{
+    context *c;
+    int rc;
+    if (!d_out16) return fail(UAES_E_ARG, "NULL pointer");
+    if ((rc = get_context(&c)) != 0) return rc;
+    KCHK(uaesk_clock_probe(stream, d_out16, 100ull * spin_us));
+    return 0;
+}
+
 int uaes_selftest(void)
 {
     context *c;

@@ -635,6 +635,26 @@ __device__ __forceinline__ uint4 tabmul8_xor_half(uint4 a, uint4 x, const GhLane
     u32 r[4];
     gh_rotate(a, gl.g, r);
     u32 z[4] = { x.x, x.y, x.z, x.w };
+#ifdef UAES_GHASH_FULL
+    /* experiment: all sixteen lookups of the product in flight at once (64 registers of table entries) */
+    {
+        u32x4 e[16];
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const u32 sel = 0x0c0c0000u | ((4u + (t & 3)) << 8) | (u32)(t & 3);
+            e[t] = *(lds_cu128 *)(uintptr_t)__builtin_amdgcn_perm(r[t >> 2], gl.so[t >> 2], sel);
+        }
+        __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) z[w] = xor3(z[w], e[i][w], e[i + 1][w]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        return make_uint4(z[0], z[1], z[2], z[3]);
+    }
+#endif
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         u32x4 e[8];

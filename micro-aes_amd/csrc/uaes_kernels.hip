@@ -664,7 +664,12 @@ static int launch_ctr_shared(hipStream_t st, const uaesk_tables *tb, const uaesk
 {
     const u64 nfull = len / 16;
     const u32 c0 = (u32)ctr->v0 & 0xffu;
-    const unsigned grid = grid_for(~0ull, 1);
+    unsigned grid = grid_for(~0ull, 1);
+    {   /* measurement only (energy per block): UAES_CTR_GRID = number of workgroups (= CUs used) */
+        static int want = -1;
+        if (want < 0) { const char *e = getenv("UAES_CTR_GRID"); want = e ? atoi(e) : 0; }
+        if (want > 0 && (unsigned)want < grid) grid = (unsigned)want;
+    }
     const u64 g_lo = c0 ? 1 : 0, groups = (c0 + nfull) / 256;
     const u64 n8 = groups > g_lo ? (groups - g_lo) / 8 : 0;
     if (n8 * 2 < (u64)grid * 3) return launch_ctr_v<NR, 4>(st, tb, ek, ctr, in, out, len, gate);
@@ -857,6 +862,32 @@ extern "C" int uaesk_ticket(void *stream, void *pinned_flag, unsigned seq, const
     if (nbytes > 64u || (nbytes & 3u)) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(k_ticket, dim3(1), dim3(64), 0, S(stream), (unsigned *)pinned_flag, seq, (const unsigned *)d_src,
                        (unsigned *)pinned_dst, nbytes / 4u);
+    return (int)hipGetLastError();
+}
+
+/* ------------------------------------------------------------------------ */
+/* shader clock probe (measurement only)                                        */
+/* ------------------------------------------------------------------------ */
+/* One wave spins for `ticks` periods of the 100 MHz reference counter (s_memrealtime) and reports how many shader
+ * cycles (s_memtime) went by: the clock the chip actually runs at while other streams keep it busy.  bench.py
+ * launches it on a second stream beside the measured workload (under the 1.4 kW cap a cipher
+ * kernel settles near 2.1 GHz, not at the 2.4 GHz the device properties quote).                              */
+__global__ __launch_bounds__(64) void k_clock_probe(unsigned long long *out, unsigned long long ticks)
+{
+    const unsigned long long r0 = wall_clock64();
+    const unsigned long long c0 = __builtin_readcyclecounter();
+    unsigned long long r1 = r0;
+    while (r1 - r0 < ticks) {
+        __builtin_amdgcn_s_sleep(32);
+        r1 = wall_clock64();
+    }
+    const unsigned long long c1 = __builtin_readcyclecounter();
+    if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = r1 - r0; }
+}
+
+extern "C" int uaesk_clock_probe(void *stream, void *d_out16, unsigned long long ticks_100mhz)
+{
+    hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, S(stream), (unsigned long long *)d_out16, ticks_100mhz);
     return (int)hipGetLastError();
 }
 
