@@ -119,7 +119,7 @@ def measure_traffic(workload, nbytes):
             cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", out, "-o", "pmc", "--",
                    sys.executable, os.path.abspath(__file__), "--gpus", "1", "--workload", workload, "--bytes", str(nbytes),
                    "--steps", str(steps), "--warmup", str(warm), "--settle-ms", "0", "--no-cpu", "--no-verify",
-                   "--no-traffic"]
+                   "--no-traffic", "--no-clock-probe"]
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=150)
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
@@ -236,6 +236,8 @@ def main():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 PMC passes behind roofline.traffic")
+    ap.add_argument("--no-clock-probe", action="store_true",
+                    help="skip the untimed shader-clock sample behind roofline.lds_ceiling (it queues extra steps)")
     ap.add_argument("--gather", action="store_true", help="also time the RCCL ciphertext all-gather")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --single-device: dry-run the multi-rank code path on a 1-GPU box")
@@ -344,6 +346,8 @@ def main():
     # running (the device properties quote 2.4 GHz; at the 1.4 kW cap a cipher kernel settles near 2.1 GHz).
     sclk_mhz = None
     try:
+        if a.no_clock_probe:
+            raise RuntimeError("skipped")
         probe_out = torch.zeros(2, dtype=torch.int64, device=dev)
         side = torch.cuda.Stream(device=dev)
         # the allocation and the stream above let the GPU idle for a moment and its clocks jump up; the power manager
