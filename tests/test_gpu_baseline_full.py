@@ -132,6 +132,25 @@ def test_bench_self_launch_verifies_every_shard():
     assert agg["peak"] == 16000.0 and abs(agg["achieved"] - sum(line["roofline"]["per_gpu_achieved"])) < 1.0
 
 
+def test_bench_line_measures_its_own_traffic_and_clock():
+    """the N = 1 line as the driver reads it: `roofline.traffic` from the two rocprofv3 PMC passes the run makes over a
+    child of itself -- the algorithmic bytes plus no more than a few per cent (it once counted the clock sample's
+    extra steps) -- and `roofline.lds_ceiling` from the shader clock sampled under the load"""
+    import shutil
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--no-cpu"]
+    line = _one_json_line(subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900))
+    roof = line["roofline"]
+    assert line["n_gpus"] == 1 and line["verified"] is True and roof["algorithmic_bytes"] == 2 << 30
+    assert 0.3 < roof["frac"] < 0.6 and abs(roof["achieved"] / roof["peak"] - roof["frac"]) < 1e-3
+    if shutil.which("rocprofv3") or os.path.exists("/opt/rocm/bin/rocprofv3"):
+        assert roof["traffic_source"].startswith("measured in this run"), roof["traffic_source"]
+        assert 1.0 <= roof["traffic"] / roof["algorithmic_bytes"] < 1.05, roof
+    lc = roof["lds_ceiling"]
+    assert lc and lc["lookups_per_block"] == 128 and 1500 < lc["sclk_mhz_under_load"] < 2500
+    assert 0.6 < lc["frac_of_ceiling"] < 1.0, lc
+
+
 def test_bench_two_ranks_rccl():
     """the real thing on a multi-GPU box: two ranks, two devices, RCCL (nccl backend with device_id), the
     ciphertext all-gather included"""
