@@ -726,10 +726,13 @@ static int pinned_ready(lane *L)
             L->pin[i] = NULL;
             return 0;                             /* no pinned memory: the pageable path still works */
         }
-    if (!L->pinx && hipHostMalloc(&L->pinx, 4096, hipHostMallocDefault) != hipSuccess) {
-        (void)hipGetLastError();
-        L->pinx = NULL;
-        return 0;
+    if (!L->pinx) {
+        if (hipHostMalloc(&L->pinx, 4096, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            L->pinx = NULL;
+            return 0;
+        }
+        memset(L->pinx, 0, 4096);                 /* the ticket word must not hold a stale sequence number */
     }
     return 1;
 }
