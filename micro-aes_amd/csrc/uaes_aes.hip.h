@@ -218,6 +218,10 @@ __device__ __forceinline__ u32 tlook(u32 w, const LaneConst &lc)
 }
 
 /* ---- table construction (once per workgroup) --------------------------- */
+/* 16-byte stores are serviced eight lanes at a time and those eight must fall into different banks, so the
+ * eight lanes of a service group write the eight 16-byte pieces of ONE entry (128 contiguous bytes) instead of
+ * one entry each (256 bytes apart = the same four banks, an 8-way conflict: 3.3 us for the 128 KiB instead of
+ * 0.7, tools/ubench/fillbench.hip -- and every launch of every kernel pays it before its first lookup).      */
 __device__ __forceinline__ void store_replicas(u32 byte_addr, u32 v)
 {
     uint4 vv = make_uint4(v, v, v, v);
@@ -229,23 +233,22 @@ __device__ __forceinline__ void store_replicas(u32 byte_addr, u32 v)
 /* Te_k[x] = rotl(Te0[x], 8k); Te0 bytes = {2S,S,S,3S} */
 __device__ __forceinline__ void fill_enc_tables(const u32 *__restrict__ te0)
 {
-    for (u32 i = threadIdx.x; i < 1024u; i += blockDim.x) {
-        const u32 x = i & 255u, k = i >> 8;
-        store_replicas(x * 256u + (k & 1u) * 128u + (k >> 1) * 65536u, rotl32(te0[x], 8u * k));
+    for (u32 j = threadIdx.x; j < 8192u; j += blockDim.x) {
+        const u32 r = j & 7u, e = j >> 3, x = e & 255u, k = e >> 8;
+        const u32 v = rotl32(te0[x], 8u * k);
+        *(uint4 *)(uaes_lds + x * 256u + (k & 1u) * 128u + (k >> 1) * 65536u + 16u * r) = make_uint4(v, v, v, v);
     }
     __syncthreads();
 }
 
-/* 64 KiB layout: 16 replicas (64 B) per entry */
+/* 64 KiB layout: 16 replicas (64 B) per entry, the four tables of an x side by side in one 256-byte row
+ * (Te0 | Te2 | Te1 | Te3): sixteen lanes write the row's sixteen 16-byte pieces                          */
 __device__ __forceinline__ void fill_tables64(const u32 *__restrict__ t0, u32 base = 0)
 {
-    for (u32 i = threadIdx.x; i < 1024u; i += blockDim.x) {
-        const u32 x = i & 255u, k = i >> 8;
+    for (u32 j = threadIdx.x; j < 4096u; j += blockDim.x) {
+        const u32 p = j & 15u, x = j >> 4, q = p >> 2, k = (q >> 1) | ((q & 1u) << 1);
         const u32 v = rotl32(t0[x], 8u * k);
-        const uint4 vv = make_uint4(v, v, v, v);
-        uint4 *dst = (uint4 *)(uaes_lds + base + x * 256u + (k & 1u) * 128u + (k >> 1) * 64u);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dst[r] = vv;
+        *(uint4 *)(uaes_lds + base + x * 256u + 16u * p) = make_uint4(v, v, v, v);
     }
     __syncthreads();
 }
@@ -602,12 +605,11 @@ struct RowLane {
 
 __device__ __forceinline__ void row_fill_tables(const u32 *__restrict__ te0, const uaesk_rk &rk)
 {
-    for (u32 x = threadIdx.x; x < 256u; x += blockDim.x) {
+    /* eight lanes per entry: the 128 bytes of an entry are eight 16-byte pieces (bank-conflict-free stores) */
+    for (u32 j = threadIdx.x; j < 2048u; j += blockDim.x) {
+        const u32 q = j & 7u, x = j >> 3;
         const u32 t0 = te0[x], t1 = rotl32(t0, 8), t2 = rotl32(t0, 16), t3 = rotl32(t0, 24);
-        const uint4 m = make_uint4(t0, t1, t2, t3), l = make_uint4(t2, t3, t0, t1);
-        uint4 *d = (uint4 *)(uaes_lds + x * 256u);
-        d[0] = m; d[1] = m; d[2] = m; d[3] = m;
-        d[4] = l; d[5] = l; d[6] = l; d[7] = l;
+        *(uint4 *)(uaes_lds + x * 256u + 16u * q) = q < 4u ? make_uint4(t0, t1, t2, t3) : make_uint4(t2, t3, t0, t1);
     }
     for (u32 i = threadIdx.x; i < 60u; i += blockDim.x) ((u32 *)(uaes_lds + 65536u))[i] = rk.w[i];
     __syncthreads();

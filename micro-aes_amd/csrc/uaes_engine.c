@@ -625,7 +625,7 @@ static int lane_wait_fetch(lane *L, void *host, const void *dev, size_t n)
         }
         (void)hipGetLastError();                              /* could not launch it: the plain way */
     }
-    if (n) HIPCHK(hipMemcpyAsync(host, dev, n, hipMemcpyDeviceToHost, st));
+    if (n) HIPCHK(hipMemcpyAsync(host, dev, n, hipMemcpyDefault, st));   /* dev may lie in the mapped pinned window */
     HIPCHK(hipStreamSynchronize(st));
     return 0;
 }
