@@ -14,7 +14,8 @@ ctr0 = nonce + b"\0\0\0\1"
 st = torch.cuda.current_stream()
 gk = uaes.GcmKey(key)
 print("%9s  %-18s %-18s %-18s %-18s %-18s" % ("KiB", "ctr", "gcm encrypt", "gcm decrypt", "keyed encrypt", "keyed decrypt"))
-for kib in (4, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 65536):
+SIZES = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else (4, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 65536)
+for kib in SIZES:
     n = kib << 10
     src = torch.randint(0, 256, (n,), dtype=torch.uint8, device="cuda")
     dst = torch.empty(n + 16, dtype=torch.uint8, device="cuda")
