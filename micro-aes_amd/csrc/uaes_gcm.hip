@@ -931,6 +931,13 @@ __global__ __launch_bounds__(GH_T) void k_gcm_small(uaesk_rk rk, uaesk_tables tb
 {
     /* build != 0: a one-shot call -- the key's nibble tables are not in `scratch`, they are made here from
      * H = Enc(0), which thread 1's padding slot computes (gcm_build_nibble_tables)                        */
+#ifdef UAES_GSM_TIMING                                        /* diagnostic build: phase stamps (100 MHz clock) */
+    u64 sm_ts[6];
+#define SM_STAMP(i) do { if (threadIdx.x == 0) sm_ts[i] = wall_clock64(); } while (0)
+#else
+#define SM_STAMP(i) do { } while (0)
+#endif
+    SM_STAMP(0);
     uint4 *TC = (uint4 *)(uaes_lds + GSM_LDS_TAB);            /* the six nibble tables; TC[0..512) = H^1024 */
     uint4 *buf = TC + GT_NTAB * 512u;                         /* GT_BUF entries (the last three: H, Enc(J0), verdict) */
     if (!build) {
@@ -938,6 +945,7 @@ __global__ __launch_bounds__(GH_T) void k_gcm_small(uaesk_rk rk, uaesk_tables tb
         for (u32 i = threadIdx.x; i < GT_NTAB * 512u; i += GH_T) TC[i] = g4[i];
     }
     fill_tables64(tb.te0, 0);                                 /* ends with a barrier */
+    SM_STAMP(1);
     const LaneConst2 lc = make_lane_const2(0);
 
     const u64 len = src.ct_len;
@@ -960,7 +968,9 @@ __global__ __launch_bounds__(GH_T) void k_gcm_small(uaesk_rk rk, uaesk_tables tb
         ctr_words(ctr, i, s1[0]);
         if (is_j0) { s1[0][0] = j0.x; s1[0][1] = j0.y; s1[0][2] = j0.z; s1[0][3] = j0.w; }
         if (is_h) { s1[0][0] = 0; s1[0][1] = 0; s1[0][2] = 0; s1[0][3] = 0; }
-        enc_blocks<NR, 1>(s1, rk, lc);
+        /* a wave whose sixty-four positions are all padding, AAD or the length block has nothing to encrypt: a 4 KiB
+         * text occupies five of the sixteen waves, and the LDS is what the block phase waits for (wave-uniform) */
+        if (__builtin_amdgcn_ballot_w64(is_text || is_j0 || is_h) != 0) enc_blocks<NR, 1>(s1, rk, lc);
         if (is_j0) buf[GT_BUF - 2] = make_uint4(s1[0][0], s1[0][1], s1[0][2], s1[0][3]);
         if (is_h) buf[GT_BUF - 3] = make_uint4(s1[0][0], s1[0][1], s1[0][2], s1[0][3]);
         uint4 x = make_uint4(0, 0, 0, 0);
@@ -993,14 +1003,17 @@ __global__ __launch_bounds__(GH_T) void k_gcm_small(uaesk_rk rk, uaesk_tables tb
         }
         xk[k] = x;
     }
+    SM_STAMP(2);
     if (build) {
         __syncthreads();                                      /* H is in its slot */
         gcm_build_nibble_tables(TC, buf, tb.frob);
     }
+    SM_STAMP(3);
     uint4 acc = xk[0];
     if (steps == 2) acc = x4(tabmul4(TC, acc), xk[1]);
     const u32 live_n = steps == 1 ? (u32)nv : GH_T;
     acc = gh_tree<true>(buf, TC, acc, live_n);
+    SM_STAMP(4);
     if (threadIdx.x == 0) {
         acc = x4(acc, buf[GT_BUF - 2]);
         const u32 w[4] = { acc.x, acc.y, acc.z, acc.w };
@@ -1028,6 +1041,14 @@ __global__ __launch_bounds__(GH_T) void k_gcm_small(uaesk_rk rk, uaesk_tables tb
             }
         }
     }
+#ifdef UAES_GSM_TIMING
+    SM_STAMP(5);
+    if (threadIdx.x == 0)
+        printf("gcm small (nv %llu, build %u): tables %llu blocks %llu build %llu tree %llu tag+out %llu (x10 ns)\n",
+               (unsigned long long)nv, build, (unsigned long long)(sm_ts[1] - sm_ts[0]), (unsigned long long)(sm_ts[2] - sm_ts[1]),
+               (unsigned long long)(sm_ts[3] - sm_ts[2]), (unsigned long long)(sm_ts[4] - sm_ts[3]), (unsigned long long)(sm_ts[5] - sm_ts[4]));
+#endif
+#undef SM_STAMP
     ticket_release(done);
 }
 
