@@ -143,4 +143,55 @@ UAES_HD Tw tw_mul_pow64(Tw t)
     return r;
 }
 
+/* t * alpha^(256 l), 0 <= l <= 63: lane l of a wave that expands a data unit's chunk tweaks needs exactly this
+ * (a chunk is 256 blocks).  Walking there by alpha^64 steps costs 4 l of them -- 252 for the last lane, and the wave
+ * waits for that lane.  alpha^(256 2^s) mod P is SPARSE for small s (squaring in GF(2)[x] keeps the number of terms
+ * until the exponents pass 128):
+ *   s = 0: x^14+x^4+x^2+1   1: x^28+x^8+x^4+1   2: x^56+x^16+x^8+1   3: x^112+x^32+x^16+1
+ *   s = 4: x^103+x^98+x^97+x^96+x^64+x^32+1     5: fourteen terms (listed below)
+ * so the product is six conditional sums of 4, 4, 4, 4, 7 and 14 shifted copies: 37 shifts instead of up to 252
+ * (checked against repeated doubling in tests/test_gf_helpers.py).                                          */
+UAES_HD Tw tw_xor(Tw a, Tw b)
+{
+    Tw r;
+    r.lo = a.lo ^ b.lo;
+    r.hi = a.hi ^ b.hi;
+    return r;
+}
+
+UAES_HD Tw tw_mul_a256(Tw t, uint32_t l)
+{
+#define TW_STEP(bit, EXPR)                                          \
+    {                                                               \
+        const Tw n_ = (EXPR);                                       \
+        const uint64_t m_ = 0 - (uint64_t)((l >> (bit)) & 1u);      \
+        t.lo ^= (t.lo ^ n_.lo) & m_;                                \
+        t.hi ^= (t.hi ^ n_.hi) & m_;                                \
+    }
+    TW_STEP(0, tw_xor(tw_xor(t, tw_mul_pow(t, 2)), tw_xor(tw_mul_pow(t, 4), tw_mul_pow(t, 14))))
+    TW_STEP(1, tw_xor(tw_xor(t, tw_mul_pow(t, 4)), tw_xor(tw_mul_pow(t, 8), tw_mul_pow(t, 28))))
+    TW_STEP(2, tw_xor(tw_xor(t, tw_mul_pow(t, 8)), tw_xor(tw_mul_pow(t, 16), tw_mul_pow(t, 56))))
+    {
+        const Tw h = tw_mul_pow64(t);                                                    /* t * x^64 */
+        TW_STEP(3, tw_xor(tw_xor(t, tw_mul_pow(t, 16)), tw_xor(tw_mul_pow(t, 32), tw_mul_pow(h, 48))))
+    }
+    {
+        const Tw h = tw_mul_pow64(t);
+        const Tw h32 = tw_mul_pow(h, 32);                                                /* t * x^96 */
+        TW_STEP(4, tw_xor(tw_xor(tw_xor(t, tw_mul_pow(t, 32)), tw_xor(h, h32)),
+                          tw_xor(tw_xor(tw_mul_pow(h32, 1), tw_mul_pow(h32, 2)), tw_mul_pow(h32, 7))))
+    }
+    {
+        /* x^1+x^2+x^7 + x^65+x^67+x^69+x^70+x^71+x^73+x^75+x^78+x^79+x^80+x^85 */
+        const Tw h = tw_mul_pow(tw_mul_pow64(t), 1);                                     /* t * x^65 */
+        Tw a = tw_xor(tw_xor(tw_mul_pow(t, 1), tw_mul_pow(t, 2)), tw_mul_pow(t, 7));
+        a = tw_xor(a, tw_xor(tw_xor(h, tw_mul_pow(h, 2)), tw_xor(tw_mul_pow(h, 4), tw_mul_pow(h, 5))));
+        a = tw_xor(a, tw_xor(tw_xor(tw_mul_pow(h, 6), tw_mul_pow(h, 8)), tw_xor(tw_mul_pow(h, 10), tw_mul_pow(h, 13))));
+        a = tw_xor(a, tw_xor(tw_xor(tw_mul_pow(h, 14), tw_mul_pow(h, 15)), tw_mul_pow(h, 20)));
+        TW_STEP(5, a)
+    }
+#undef TW_STEP
+    return t;
+}
+
 #endif

@@ -239,7 +239,7 @@ __global__ __launch_bounds__(UAES_WG) void k_xts_expand(XtsPow pw, u64 nsectors,
         t.hi = t0.z | ((u64)t0.w << 32);
         for (u32 i = 0; i < XTS_POW_N; ++i)
             if ((r >> i) & 1) t = wave_tw_mul(t, pw.lo[i], pw.hi[i], lane);       /* wave-uniform */
-        for (u32 q = 0; q < 4 * lane; ++q) t = tw_mul_pow64(t);                   /* * alpha^(256 lane) */
+        t = tw_mul_a256(t, lane);                                                 /* * alpha^(256 lane): uaes_gf.h */
         const u64 c = r * 64 + lane;
         if (c != 0 && c < chunks_per_sector)
             chunk_tw[sct * chunks_per_sector + c] =

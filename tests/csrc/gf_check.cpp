@@ -106,6 +106,15 @@ void gfc_last(const uint8_t *T4, const uint8_t *blocks, uint64_t n, uint8_t out[
     memcpy(out, acc, 16);
 }
 
+// t * alpha^(256 l), l < 64 (the chunk tweak of lane l: tw_mul_a256)
+void gfc_tw_a256(const uint8_t t[16], uint32_t l, uint8_t out[16])
+{
+    Tw a;
+    memcpy(&a.lo, t, 8); memcpy(&a.hi, t + 8, 8);
+    Tw r = tw_mul_a256(a, l);
+    memcpy(out, &r.lo, 8); memcpy(out + 8, &r.hi, 8);
+}
+
 // XTS tweak helpers: t * alpha^k (k < 64) and t * alpha^64, 16-byte LE blocks
 void gfc_tw_pow(const uint8_t t[16], uint32_t k, uint8_t out[16])
 {

@@ -97,3 +97,23 @@ def test_xts_tweak_shifts(gfc, orc):
             gfc.gfc_tw_pow(buf(t), k, o)
             assert bytes(o) == cur, k
             cur = double(cur)
+
+
+def test_xts_chunk_tweak_by_sparse_powers(gfc):
+    """tw_mul_a256(t, l) = t * alpha^(256 l) for every lane l = 0..63 (six conditional products by the sparse
+    residues of alpha^(256 2^s)) against 256 l doublings"""
+    rnd = random.Random(11)
+
+    def double(v):
+        v <<= 1
+        return (v & ((1 << 128) - 1)) ^ 0x87 if v >> 128 else v
+
+    for _ in range(6):
+        t = rnd.randbytes(16)
+        cur = int.from_bytes(t, "little")
+        for l in range(64):
+            o = (C.c_uint8 * 16)()
+            gfc.gfc_tw_a256(buf(t), l, o)
+            assert int.from_bytes(bytes(o), "little") == cur, l
+            for _ in range(256):
+                cur = double(cur)
