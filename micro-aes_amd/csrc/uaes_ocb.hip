@@ -394,11 +394,13 @@ __global__ __launch_bounds__(UAES_WG) void k_ocb_final(uaesk_rk ek, uaesk_tables
  * 4 KiB call: 38.5 -> 30 us (what is left is serial: tables, L_* / K_top / tag encryptions by one lane).                                                                            */
 #define OCB_SMALL_BLOCKS 1024u
 #define OCB_SMALL_AAD    65536u
+#define OCB_SMALL_SCR    ((OCB_LDS + 63u) & ~63u)                 /* 66 rows of hand-over scratch behind the accumulators */
+#define OCB_SMALL_LDS    (OCB_SMALL_SCR + 16u * (OCB_ROW_PART + 1u))
 
 template <int NR, bool DEC>
 __global__ __launch_bounds__(UAES_WG) void k_ocb_small(uaesk_rk ek, uaesk_rk dk, uaesk_tables tb,
                                                        uint4 nonce_block, u32 bottom, u32 nrows,
-                                                       uint4 *scr,
+                                                       uint4 *scr_dev,
                                                        const unsigned char *__restrict__ aad, u64 aad_len,
                                                        const unsigned char *in, unsigned char *out, u64 len,
                                                        int *status, u32 tag_len, uaesk_done done)
@@ -410,6 +412,11 @@ __global__ __launch_bounds__(UAES_WG) void k_ocb_small(uaesk_rk ek, uaesk_rk dk,
 #define OT(i) do { } while (0)
 #endif
     OT(0);
+    /* one workgroup: the rows the phases hand over (L table, Offset_0, the checksum share) stay in LDS -- through the
+     * device scratch of the multi-workgroup path every hand-over was a store, a fence and a load from memory, ~2 us
+     * each, three times per call (-DUAES_OCB_TIMING)                                                          */
+    (void)scr_dev;
+    uint4 *const scr = (uint4 *)(uaes_lds + OCB_SMALL_SCR);
     fill_enc_tables(tb.te0);
     const LaneConst lc = make_lane_const();
     OT(1);
@@ -508,13 +515,13 @@ static int launch_ocb(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek
          * the host layer arms a ticket only when it passes a pinned status pointer) */
         const uaesk_done done = uaesk_ticket_take();
         const void *ks = decrypt ? (const void *)k_ocb_small<NR, true> : (const void *)k_ocb_small<NR, false>;
-        if ((e = want_lds(ks)) != hipSuccess) return (int)e;
+        if ((e = hipFuncSetAttribute(ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OCB_SMALL_LDS)) != hipSuccess) return (int)e;
         if (decrypt)
-            hipLaunchKernelGGL((k_ocb_small<NR, true>), dim3(1), dim3(UAES_WG), OCB_LDS, st, *ek, *dk, *tb, nb, bottom, nrows,
+            hipLaunchKernelGGL((k_ocb_small<NR, true>), dim3(1), dim3(UAES_WG), OCB_SMALL_LDS, st, *ek, *dk, *tb, nb, bottom, nrows,
                                scr, (const unsigned char *)aad, (u64)aad_len, (const unsigned char *)in,
                                (unsigned char *)out, (u64)len, status, tag_len, done);
         else
-            hipLaunchKernelGGL((k_ocb_small<NR, false>), dim3(1), dim3(UAES_WG), OCB_LDS, st, *ek, *ek, *tb, nb, bottom, nrows,
+            hipLaunchKernelGGL((k_ocb_small<NR, false>), dim3(1), dim3(UAES_WG), OCB_SMALL_LDS, st, *ek, *ek, *tb, nb, bottom, nrows,
                                scr, (const unsigned char *)aad, (u64)aad_len, (const unsigned char *)in,
                                (unsigned char *)out, (u64)len, status, tag_len, done);
         return (int)hipGetLastError();
