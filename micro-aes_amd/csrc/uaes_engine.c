@@ -1050,6 +1050,7 @@ int uaes_clock_probe_dev(void *d_out16, unsigned spin_us, void *stream)
     context *c;
     int rc;
     if (!d_out16) return fail(UAES_E_ARG, "NULL pointer");
+    if (spin_us > 1000000u) spin_us = 1000000u;                /* a wave that spins: never longer than a second */
     if ((rc = get_context(&c)) != 0) return rc;
     KCHK(uaesk_clock_probe(stream, d_out16, 100ull * spin_us));
     return 0;
