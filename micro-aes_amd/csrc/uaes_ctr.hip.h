@@ -209,6 +209,11 @@ __device__ __forceinline__ void ctr_shared_loop(const uaesk_rk &rk, const uaesk_
             const u64 gn = ctr_geo_group0(geo, it + 1 < geo.iters ? it + 1 : it);
 #pragma unroll
             for (int u = 0; u < 2; ++u) d_nxt[u] = (in + (((gn + 4u * u) << 8) - c0))[lane_blk];
+#ifdef UAES_CTR_NOLOAD                   /* timing-only build (wrong results): what do the text loads cost in cycles? */
+            (void)gn;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) d_nxt[u] = make_uint4(lane, wave, (u32)it, u);
+#endif
         }
 
         u32 s[2][4];
@@ -234,6 +239,9 @@ __device__ __forceinline__ void ctr_shared_loop(const uaesk_rk &rk, const uaesk_
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             ct[u] = make_uint4(d_cur[u].x ^ s[u][0], d_cur[u].y ^ s[u][1], d_cur[u].z ^ s[u][2], d_cur[u].w ^ s[u][3]);
+#ifdef UAES_CTR_NOSTORE                  /* timing-only build: keep the value alive, store (almost) never */
+            if (ct[u].x == 0x12345678u && ct[u].y == 0x9abcdef0u && ct[u].z == it)
+#endif
             (out + (((g0 + 4u * u) << 8) - c0))[lane_blk] = ct[u];
         }
         if (FOLD::of_input) fold(d_cur[0], d_cur[1]); else fold(ct[0], ct[1]);
