@@ -346,6 +346,35 @@ int  uaes_gcm_key_encrypt_dev(uaes_gcm_key *k, const uint8_t *nonce, const void 
 int  uaes_gcm_key_decrypt_dev(uaes_gcm_key *k, const uint8_t *nonce, const void *d_aad, size_t aad_len,
                               const void *d_in, size_t len, void *d_out, int *d_status, void *stream);
 
+/* Many short messages under one key context in ONE launch (the GCM counterpart of uaes_xts_encrypt_sectors;
+ * the reference has a message per call, AES_GCM_encrypt micro_aes.c:1164-1179, and a call costs ~12 us on a GPU
+ * whatever its size).  Record r: rec_len bytes at in + r * in_stride, 12-byte nonce nonces + 12 r, AAD
+ * aad + r * aad_stride (aad_stride 0: the same aad_len bytes for every record).
+ *   encrypt: out + r * out_stride receives ciphertext || 16-byte tag   (out_stride >= rec_len + 16)
+ *   decrypt: the record is ciphertext || tag (in_stride >= rec_len + 16), out + r * out_stride receives the
+ *            plaintext of every record whose tag matches; the others are left untouched (N7), verdicts[r]
+ *            (may be NULL) = 0 / 0x1A, and the call returns UAES_E_AUTHENTICATION if any record failed.
+ * Byte for byte what uaes_gcm_key_encrypt / _decrypt give record by record.  Strides are multiples of 16,
+ * in / out 16-byte aligned (device flavour), rec_len <= uaes_gcm_record_max(aad_len) (32 KiB - 48 without AAD).
+ * The *_dev flavour takes device pointers for everything, enqueues on `stream`, and reports through
+ * d_verdicts / *d_status (zeroed by the call, 0x1A ORed in); any number of record calls may share one context. */
+size_t uaes_gcm_record_max(size_t aad_len);
+int  uaes_gcm_key_encrypt_records(uaes_gcm_key *k, size_t nrec, const uint8_t *nonces,
+                                  const void *aad, size_t aad_len, size_t aad_stride,
+                                  const void *in, size_t rec_len, size_t in_stride, void *out, size_t out_stride);
+int  uaes_gcm_key_decrypt_records(uaes_gcm_key *k, size_t nrec, const uint8_t *nonces,
+                                  const void *aad, size_t aad_len, size_t aad_stride,
+                                  const void *in, size_t rec_len, size_t in_stride, void *out, size_t out_stride,
+                                  uint8_t *verdicts);
+int  uaes_gcm_key_encrypt_records_dev(uaes_gcm_key *k, size_t nrec, const uint8_t *d_nonces,
+                                      const void *d_aad, size_t aad_len, size_t aad_stride,
+                                      const void *d_in, size_t rec_len, size_t in_stride,
+                                      void *d_out, size_t out_stride, void *stream);
+int  uaes_gcm_key_decrypt_records_dev(uaes_gcm_key *k, size_t nrec, const uint8_t *d_nonces,
+                                      const void *d_aad, size_t aad_len, size_t aad_stride,
+                                      const void *d_in, size_t rec_len, size_t in_stride,
+                                      void *d_out, size_t out_stride, uint8_t *d_verdicts, int *d_status, void *stream);
+
 /* ---- one process, several GPUs -------------------------------------------------
  * The text is cut into aligned slices, one per device; one host thread per device
  * runs the single-device call on its slice with the counter / sector offset

@@ -44,6 +44,8 @@ EXPORTS = [
     "uaes_mgpu_ctr_xcrypt_at", "uaes_mgpu_xts_sectors",
     "uaes_gcm_key_new", "uaes_gcm_key_free", "uaes_gcm_key_encrypt", "uaes_gcm_key_decrypt",
     "uaes_gcm_key_encrypt_dev", "uaes_gcm_key_decrypt_dev",
+    "uaes_gcm_record_max", "uaes_gcm_key_encrypt_records", "uaes_gcm_key_decrypt_records",
+    "uaes_gcm_key_encrypt_records_dev", "uaes_gcm_key_decrypt_records_dev",
     "uaes_gcm_stream_begin", "uaes_gcm_stream_update", "uaes_gcm_stream_finish", "uaes_gcm_stream_abort",
     "uaes_cbc_encrypt_batch", "uaes_cmac_batch", "uaes_cbc_encrypt", "uaes_cbc_decrypt", "uaes_cfb_encrypt", "uaes_cfb_decrypt", "uaes_ofb_xcrypt",
     "uaes_ecb_dev", "uaes_ctr_xcrypt_at_dev", "uaes_xts_sectors_dev",
@@ -138,6 +140,12 @@ def engine():
     L.uaes_gcm_key_decrypt.argtypes = [vp, vp, vp, sz, vp, sz, vp]
     L.uaes_gcm_key_encrypt_dev.argtypes = [vp, vp, vp, sz, vp, sz, vp, vp]
     L.uaes_gcm_key_decrypt_dev.argtypes = [vp, vp, vp, sz, vp, sz, vp, vp, vp]
+    L.uaes_gcm_record_max.argtypes = [sz]
+    L.uaes_gcm_record_max.restype = sz
+    L.uaes_gcm_key_encrypt_records.argtypes = [vp, sz, vp, vp, sz, sz, vp, sz, sz, vp, sz]
+    L.uaes_gcm_key_decrypt_records.argtypes = [vp, sz, vp, vp, sz, sz, vp, sz, sz, vp, sz, vp]
+    L.uaes_gcm_key_encrypt_records_dev.argtypes = [vp, sz, vp, vp, sz, sz, vp, sz, sz, vp, sz, vp]
+    L.uaes_gcm_key_decrypt_records_dev.argtypes = [vp, sz, vp, vp, sz, sz, vp, sz, sz, vp, sz, vp, vp, vp]
     L.uaes_gcm_stream_begin.argtypes = [C.POINTER(vp), i, vp, vp, vp, sz, i]
     L.uaes_gcm_stream_update.argtypes = [vp, vp, sz, vp]
     L.uaes_gcm_stream_finish.argtypes = [vp, vp]
@@ -175,6 +183,13 @@ def _fixed(b, n, what):
     if len(b) != n:
         raise ValueError("%s must be exactly %d bytes (got %d)" % (what, n, len(b)))
     return (C.c_uint8 * n).from_buffer_copy(b)
+
+
+def _fixed_bytes(b, n):
+    b = bytes(b)
+    if len(b) != n:
+        raise ValueError("expected exactly %d bytes (got %d)" % (n, len(b)))
+    return b
 
 
 def _out(n, fill=0):
@@ -458,6 +473,75 @@ class GcmKey:
         _check(engine().uaes_gcm_key_decrypt_dev(self._h, _fixed(nonce, 12, "nonce"), _ptr(aad),
                                                  0 if aad is None else aad.numel(), _ptr(src), nbytes, _ptr(dst),
                                                  _ptr(status), _stream(stream)), "uaes_gcm_key_decrypt_dev")
+
+    @staticmethod
+    def record_max(aad_len=0):
+        """longest record (bytes) the record calls take with aad_len bytes of AAD per record"""
+        return int(engine().uaes_gcm_record_max(aad_len))
+
+    def encrypt_records(self, nonces, aads, records, stride=None):
+        """Many equally long messages in one launch (uaes_gcm_key_encrypt_records).  nonces: list of 12-byte
+        values; aads: one bytes object for all records or a list of equally long ones; records: list of equally
+        long plaintexts.  Returns the list of ciphertext || tag, each equal to encrypt() of that record."""
+        n = len(records)
+        if n == 0:
+            return []
+        rec_len = len(records[0])
+        if any(len(r) != rec_len for r in records) or len(nonces) != n:
+            raise ValueError("records must be equally long and have one nonce each")
+        stride = stride or (rec_len + 16 + 15) // 16 * 16
+        aad, aad_len, aad_stride = self._pack_aads(aads, n)
+        src = bytearray(stride * n)
+        for r, rec in enumerate(records):
+            src[r * stride: r * stride + rec_len] = rec
+        dst = _out(stride * n)
+        _check(engine().uaes_gcm_key_encrypt_records(self._h, n, _in(b"".join(_fixed_bytes(x, 12) for x in nonces)),
+                                                     _in(aad), aad_len, aad_stride, _in(bytes(src)), rec_len, stride,
+                                                     dst, stride), "uaes_gcm_key_encrypt_records")
+        b = bytes(dst)
+        return [b[r * stride: r * stride + rec_len + 16] for r in range(n)]
+
+    def decrypt_records(self, nonces, aads, records, prefill=0, stride=None):
+        """records: list of equally long ciphertext || tag.  Returns (code, verdicts, texts): code 0 or 0x1A (some
+        record failed), verdicts[r] 0 / 0x1A, texts[r] the plaintext -- `prefill` bytes where the tag was wrong (N7)."""
+        n = len(records)
+        if n == 0:
+            return 0, [], []
+        rec_len = len(records[0]) - 16
+        if rec_len < 0 or any(len(r) != rec_len + 16 for r in records) or len(nonces) != n:
+            raise ValueError("records must be equally long (text || tag) and have one nonce each")
+        stride = stride or (rec_len + 16 + 15) // 16 * 16
+        aad, aad_len, aad_stride = self._pack_aads(aads, n)
+        src = bytearray(stride * n)
+        for r, rec in enumerate(records):
+            src[r * stride: r * stride + rec_len + 16] = rec
+        dst = _out(stride * n, prefill)
+        ver = _out(n, 0x55)
+        rc = _check(engine().uaes_gcm_key_decrypt_records(self._h, n, _in(b"".join(_fixed_bytes(x, 12) for x in nonces)),
+                                                          _in(aad), aad_len, aad_stride, _in(bytes(src)), rec_len, stride,
+                                                          dst, stride, ver), "uaes_gcm_key_decrypt_records")
+        b = bytes(dst)
+        return rc, list(bytes(ver)), [b[r * stride: r * stride + rec_len] for r in range(n)]
+
+    @staticmethod
+    def _pack_aads(aads, n):
+        if isinstance(aads, (bytes, bytearray)):
+            return bytes(aads), len(aads), 0
+        if len(aads) != n or any(len(a) != len(aads[0]) for a in aads):
+            raise ValueError("one equally long AAD per record (or one bytes object for all)")
+        return b"".join(aads), len(aads[0]), len(aads[0])
+
+    def encrypt_records_dev(self, nrec, nonces, aad, aad_len, aad_stride, src, rec_len, in_stride, dst, out_stride, stream=None):
+        """device tensors (uint8): nonces 12 * nrec bytes; enqueues on `stream`"""
+        _check(engine().uaes_gcm_key_encrypt_records_dev(self._h, nrec, _ptr(nonces), _ptr(aad), aad_len, aad_stride, _ptr(src),
+                                                         rec_len, in_stride, _ptr(dst), out_stride, _stream(stream)),
+               "uaes_gcm_key_encrypt_records_dev")
+
+    def decrypt_records_dev(self, nrec, nonces, aad, aad_len, aad_stride, src, rec_len, in_stride, dst, out_stride,
+                            verdicts, status, stream=None):
+        _check(engine().uaes_gcm_key_decrypt_records_dev(self._h, nrec, _ptr(nonces), _ptr(aad), aad_len, aad_stride, _ptr(src),
+                                                         rec_len, in_stride, _ptr(dst), out_stride, _ptr(verdicts), _ptr(status),
+                                                         _stream(stream)), "uaes_gcm_key_decrypt_records_dev")
 
     def close(self):
         if getattr(self, "_h", None):

@@ -350,7 +350,7 @@ static int launch_fb_dec_u(hipStream_t st, const uaesk_tables *tb, const uaesk_r
                            const void *in, void *out, u64 n, u32 rem, u32 cts_r)
 {
     const unsigned lds = CFB ? UAES_LDS_ENC : UAES_LDS_DEC;
-    hipError_t e = hipFuncSetAttribute((const void *)k_fb_dec<NR, CFB, U>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = uaesk_want_lds((const void *)k_fb_dec<NR, CFB, U>, (unsigned)(lds));
     if (e != hipSuccess) return (int)e;
     u64 want = (n + (u64)UAES_WG * U - 1) / ((u64)UAES_WG * U);
     if (!want) want = 1;
@@ -376,7 +376,7 @@ static int launch_serial(hipStream_t st, const uaesk_tables *tb, const uaesk_rk 
 {
     const unsigned lds = OP == CH_CBC_DEC_CTS ? UAES_LDS_DEC : UAES_LDS_ROW;
     const unsigned threads = OP == CH_CBC_DEC_CTS ? UAES_WG : 64u;
-    hipError_t e = hipFuncSetAttribute((const void *)k_chain_serial<NR, OP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = uaesk_want_lds((const void *)k_chain_serial<NR, OP>, (unsigned)(lds));
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL((k_chain_serial<NR, OP>), dim3(1), dim3(threads), lds, st, *k, *tb, iv, iv_dev,
                        (const unsigned char *)in, (unsigned char *)out, len);
@@ -387,8 +387,7 @@ template <int NR, bool MAC>
 static int launch_batch(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *k, const void *ivs,
                         u64 nmsg, u64 msg_bytes, const void *in, void *out)
 {
-    hipError_t e = hipFuncSetAttribute((const void *)k_chain_batch<NR, MAC>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)UAES_LDS_ENC);
+    hipError_t e = uaesk_want_lds((const void *)k_chain_batch<NR, MAC>, (unsigned)(UAES_LDS_ENC));
     if (e != hipSuccess) return (int)e;
     u64 want = (nmsg + UAES_WG - 1) / UAES_WG;
     const unsigned grid = (unsigned)(want < cu_count() ? (want ? want : 1) : cu_count());

@@ -105,6 +105,18 @@ int uaesk_gcm_keyed(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk
                     const void *in, size_t len, void *out,
                     void *key_scratch, int *status);
 
+/* Many short messages under one key context in one launch (k_gcm_records): record r = rec_len bytes at
+ * in + r * in_stride under nonce nonces12 + 12 r with the AAD at aad + r * aad_stride (stride 0: shared);
+ * encrypt writes text || tag at out + r * out_stride; decrypt reads text || tag, writes the text of the records
+ * whose tag matches, verdicts[r] = 0 / 0x1A (may be NULL) and ORs 0x1A into *status (zero it first).
+ * in, out and the strides are multiples of 16; rec_len <= uaesk_gcm_record_max(aad_len).  Reads the key
+ * context's tables only: any number of these calls may share one context.                               */
+size_t uaesk_gcm_record_max(size_t aad_len);
+int uaesk_gcm_records(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek, int decrypt,
+                      const void *nonces12, const void *aad, size_t aad_len, size_t aad_stride,
+                      const void *in, size_t rec_len, size_t in_stride, void *out, size_t out_stride,
+                      size_t nrec, const void *key_scratch, unsigned char *verdicts, int *status);
+
 /* Sharded GCM: the weighted partial GHASH of one 16-byte-aligned ciphertext
  * shard (first shard: + AAD and Enc(J0); last shard: + length block).  The tag
  * of the whole message is the XOR of all shards' 16-byte results.           */

@@ -1748,6 +1748,174 @@ int uaes_gcm_key_decrypt_dev(uaes_gcm_key *k, const uint8_t *nonce, const void *
     return 0;
 }
 
+/* ---- many short messages under one key context in one launch (uaesk_gcm_records) -------------------------
+ * The reference has one message per call (AES_GCM_encrypt, micro_aes.c:1164-1179); a call costs ~12 us on this
+ * engine whatever the size, so record streams (TLS records, packets, pages) come as one call: record r is rec_len
+ * bytes at in + r * in_stride under the 12-byte nonce nonces + 12 r, with the AAD at aad + r * aad_stride (stride
+ * 0: one AAD for all).  Each record's result is exactly what uaes_gcm_key_encrypt / _decrypt give for it.  */
+size_t uaes_gcm_record_max(size_t aad_len)
+{
+    return uaesk_gcm_record_max(aad_len);
+}
+
+static int records_args_ok(size_t nrec, const void *nonces, const void *aad, size_t aad_len,
+                           const void *in, size_t rec_len, size_t in_stride, size_t in_min,
+                           const void *out, size_t out_stride, size_t out_min)
+{
+    if (!nrec) return 0;
+    if (!nonces || !in || !out || (aad_len && !aad)) return fail(UAES_E_ARG, "NULL pointer");
+    if (rec_len > uaesk_gcm_record_max(aad_len))
+        return fail(UAES_E_ARG, "a record of %zu bytes with %zu bytes of AAD is too long for the record call (%zu)",
+                    rec_len, aad_len, uaesk_gcm_record_max(aad_len));
+    if ((in_stride | out_stride) & 15u) return fail(UAES_E_ARG, "record strides must be multiples of 16");
+    if (in_stride < in_min || out_stride < out_min) return fail(UAES_E_ARG, "record stride shorter than a record");
+    if (nrec > (size_t)1 << 40) return fail(UAES_E_ARG, "too many records");
+    return 0;
+}
+
+int uaes_gcm_key_encrypt_records_dev(uaes_gcm_key *k, size_t nrec, const uint8_t *d_nonces,
+                                     const void *d_aad, size_t aad_len, size_t aad_stride,
+                                     const void *d_in, size_t rec_len, size_t in_stride,
+                                     void *d_out, size_t out_stride, void *stream)
+{
+    context *c;
+    int rc;
+    if ((rc = key_device_ok(k)) != 0) return rc;
+    if ((rc = records_args_ok(nrec, d_nonces, d_aad, aad_len, d_in, rec_len, in_stride, rec_len,
+                              d_out, out_stride, rec_len + 16)) != 0) return rc;
+    if ((rc = dev_ptrs_ok(d_in, d_out, 1)) != 0) return rc;
+    if ((rc = get_context(&c)) != 0) return rc;
+    KCHK(uaesk_gcm_records(stream, &c->tb, k->ks.nr, &k->ks.ek, 0, d_nonces, d_aad, aad_len, aad_stride,
+                           d_in, rec_len, in_stride, d_out, out_stride, nrec, k->scratch, NULL, NULL));
+    return 0;
+}
+
+int uaes_gcm_key_decrypt_records_dev(uaes_gcm_key *k, size_t nrec, const uint8_t *d_nonces,
+                                     const void *d_aad, size_t aad_len, size_t aad_stride,
+                                     const void *d_in, size_t rec_len, size_t in_stride,
+                                     void *d_out, size_t out_stride, uint8_t *d_verdicts, int *d_status, void *stream)
+{
+    context *c;
+    int rc;
+    if ((rc = key_device_ok(k)) != 0) return rc;
+    if (!d_status) return fail(UAES_E_ARG, "NULL d_status");
+    if ((rc = records_args_ok(nrec, d_nonces, d_aad, aad_len, d_in, rec_len, in_stride, rec_len + 16,
+                              d_out, out_stride, rec_len)) != 0) return rc;
+    if ((rc = dev_ptrs_ok(d_in, d_out, 1)) != 0) return rc;
+    if ((rc = get_context(&c)) != 0) return rc;
+    HIPCHK(hipMemsetAsync(d_status, 0, sizeof(int), (hipStream_t)stream));
+    KCHK(uaesk_gcm_records(stream, &c->tb, k->ks.nr, &k->ks.ek, 1, d_nonces, d_aad, aad_len, aad_stride,
+                           d_in, rec_len, in_stride, d_out, out_stride, nrec, k->scratch, d_verdicts, d_status));
+    return 0;
+}
+
+/* host (or device) pointers, synchronous: nonces and AAD go through the lane's AAD staging, the texts through its
+ * two text stagings; only the records' own bytes are written to the caller's output (the gaps of a strided layout,
+ * and on decryption the records whose tag is wrong -- N7 -- keep what they held) */
+static int records_sync(uaes_gcm_key *k, int decrypt, size_t nrec, const uint8_t *nonces,
+                        const void *aad, size_t aad_len, size_t aad_stride,
+                        const void *in, size_t rec_len, size_t in_stride,
+                        void *out, size_t out_stride, uint8_t *verdicts)
+{
+    context *c;
+    lane *L;
+    int rc;
+    const size_t in_rec = rec_len + (decrypt ? 16 : 0), out_rec = rec_len + (decrypt ? 0 : 16);
+    if ((rc = key_device_ok(k)) != 0) return rc;
+    if ((rc = records_args_ok(nrec, nonces, aad, aad_len, in, rec_len, in_stride, in_rec, out, out_stride, out_rec)) != 0)
+        return rc;
+    if (!nrec) return 0;
+    if (aad_len && aad_stride && aad_stride < aad_len) return fail(UAES_E_ARG, "AAD stride shorter than the AAD");
+    if ((rc = enter(&c, &L)) != 0) return rc;
+    do {
+        hipStream_t st = (hipStream_t)L->stream;
+        const size_t non_span = (12 * nrec + 15) & ~(size_t)15;
+        const size_t aad_span = aad_len ? (aad_stride ? (nrec - 1) * aad_stride + aad_len : aad_len) : 0;
+        const size_t in_span = (nrec - 1) * in_stride + in_rec, out_span = (nrec - 1) * out_stride + out_rec;
+        const size_t ver_off = (out_span + 15) & ~(size_t)15;
+        const int in_place = in == out && in_stride == out_stride;
+        unsigned char *d_meta, *d_out, *d_ver;
+        const unsigned char *d_in;
+        int status = 0;
+        if (is_device_ptr(nonces) || is_device_ptr(aad) || is_device_ptr(in) || is_device_ptr(out))
+            if ((rc = wait_for_callers_device_work()) != 0) break;
+        if (grow_on(st, &L->aad_stage, &L->aad_cap, non_span + aad_span + 16)) { rc = UAES_E_HIP; break; }
+        d_meta = (unsigned char *)L->aad_stage;
+        if (hipMemcpyAsync(d_meta, nonces, 12 * nrec, hipMemcpyDefault, st) != hipSuccess ||
+            (aad_span && hipMemcpyAsync(d_meta + non_span, aad, aad_span, hipMemcpyDefault, st) != hipSuccess)) {
+            rc = fail(UAES_E_HIP, "staging the nonces failed");
+            break;
+        }
+        if (grow_on(st, &L->stage[0], &L->stage_cap[0], in_span + 64)) { rc = UAES_E_HIP; break; }
+        if (hipMemcpyAsync(L->stage[0], in, in_span, hipMemcpyDefault, st) != hipSuccess) {
+            rc = fail(UAES_E_HIP, "staging the records failed");
+            break;
+        }
+        d_in = (const unsigned char *)L->stage[0];
+        /* the output staging also holds the verdict bytes behind the records */
+        if (in_place && !decrypt) {
+            d_out = (unsigned char *)L->stage[0];             /* sized in_span + 64: the last tag fits */
+            d_ver = NULL;
+        } else {
+            if (grow_on(st, &L->stage[1], &L->stage_cap[1], ver_off + nrec + 64)) { rc = UAES_E_HIP; break; }
+            d_out = (unsigned char *)L->stage[1];
+            d_ver = d_out + ver_off;
+        }
+        if (decrypt && hipMemsetAsync(L->d_status, 0, sizeof(int), st) != hipSuccess) { rc = fail(UAES_E_HIP, "memset failed"); break; }
+        {
+            int kk = uaesk_gcm_records(L->stream, &c->tb, k->ks.nr, &k->ks.ek, decrypt, d_meta,
+                                       aad_span ? d_meta + non_span : NULL, aad_len, aad_stride, d_in, rec_len, in_stride,
+                                       d_out, out_stride, nrec, k->scratch, decrypt ? d_ver : NULL, decrypt ? L->d_status : NULL);
+            if (kk) { rc = fail(UAES_E_HIP, "gcm records launch: %s", hipGetErrorString((hipError_t)kk)); break; }
+        }
+        if (decrypt) {
+            if ((rc = lane_fetch(L, &status, L->d_status, sizeof status)) != 0) break;
+            if (verdicts || status) {
+                uint8_t *v = verdicts;
+                if (!v && (v = (uint8_t *)malloc(nrec)) == NULL) { rc = fail(UAES_E_HIP, "out of host memory"); break; }
+                if (hipMemcpyAsync(v, d_ver, nrec, hipMemcpyDefault, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+                    if (v != verdicts) free(v);
+                    rc = fail(UAES_E_HIP, "verdict copy failed");
+                    break;
+                }
+                if (status) {                                 /* the good records one by one (N7 for the others) */
+                    size_t r;
+                    for (r = 0; r < nrec && rc == 0; ++r)
+                        if (v[r] == 0 && rec_len &&
+                            hipMemcpyAsync((char *)out + r * out_stride, d_out + r * out_stride, rec_len, hipMemcpyDefault, st) != hipSuccess)
+                            rc = fail(UAES_E_HIP, "copy back failed");
+                    if (v != verdicts) free(v);
+                    if (rc == 0 && hipStreamSynchronize(st) != hipSuccess) rc = fail(UAES_E_HIP, "copy back failed");
+                    if (rc == 0) rc = UAES_E_AUTHENTICATION;
+                    break;
+                }
+                if (v != verdicts) free(v);
+            }
+        }
+        if (out_rec && hipMemcpy2DAsync(out, out_stride, d_out, out_stride, out_rec, nrec, hipMemcpyDefault, st) != hipSuccess) {
+            rc = fail(UAES_E_HIP, "copy back failed");
+            break;
+        }
+        if (hipStreamSynchronize(st) != hipSuccess) rc = fail(UAES_E_HIP, "gcm records failed");
+    } while (0);
+    DONE(L, rc);
+}
+
+int uaes_gcm_key_encrypt_records(uaes_gcm_key *k, size_t nrec, const uint8_t *nonces,
+                                 const void *aad, size_t aad_len, size_t aad_stride,
+                                 const void *in, size_t rec_len, size_t in_stride, void *out, size_t out_stride)
+{
+    return records_sync(k, 0, nrec, nonces, aad, aad_len, aad_stride, in, rec_len, in_stride, out, out_stride, NULL);
+}
+
+int uaes_gcm_key_decrypt_records(uaes_gcm_key *k, size_t nrec, const uint8_t *nonces,
+                                 const void *aad, size_t aad_len, size_t aad_stride,
+                                 const void *in, size_t rec_len, size_t in_stride, void *out, size_t out_stride,
+                                 uint8_t *verdicts)
+{
+    return records_sync(k, 1, nrec, nonces, aad, aad_len, aad_stride, in, rec_len, in_stride, out, out_stride, verdicts);
+}
+
 int uaes_gcm_partial_dev(int keybits, const uint8_t *key, const uint8_t *nonce,
                          const void *d_aad, uint64_t total_aad_len,
                          const void *d_ct_shard, size_t shard_len, uint64_t shard_offset,

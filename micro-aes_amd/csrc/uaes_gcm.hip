@@ -193,28 +193,59 @@ __device__ __forceinline__ uint4 tabmul8_xor(uint4 a, uint4 x, const GhLane &gl)
     return make_uint4(z[0], z[1], z[2], z[3]);
 }
 
-/* a * M through the nibble-indexed table of M (512 entries of 16 B, anywhere in LDS) */
-__device__ __forceinline__ uint4 tabmul4(const uint4 *T, uint4 a)
+/* ---- nibble-indexed tables: a * M = the XOR of 32 entries, one per nibble of a --------------------------------
+ * Layout of one table (512 entries of 16 B = 8 KiB, anywhere in LDS): ROW v (512 B) holds the entries of nibble
+ * VALUE v for the 32 nibble positions -- entry index nib_entry(p, v) = 32 v + slot(p), slot = j for the high
+ * nibble of byte j (p = 2j), 16 + j for its low nibble (p = 2j + 1).  As with the byte tables above, the 16-byte
+ * slot of an LDS address is (addr / 16) mod 16 and a ds_read_b128 serves 16 lanes at a time: the data-dependent
+ * part of the address (the row) is free, the lanes of a service group only must not share a slot, so every lane
+ * walks the bytes of its block in an order rotated by its position in the group and the sixteen lanes read
+ * sixteen different positions at every step.  (Round 2's [position][value] layout put the VALUE into the slot:
+ * random, ~2.9x serialisation of every multiplication.)                                                      */
+__device__ __forceinline__ u32 nib_entry(u32 p, u32 v)
 {
-    const u32 w[4] = { a.x, a.y, a.z, a.w };
+    return v * 32u + (p >> 1) + ((p & 1u) << 4);
+}
+
+/* position of the lane inside its ds_read_b128 service group (gh_lane_setup) */
+__device__ __forceinline__ u32 b128_group_pos(u32 tid = threadIdx.x)
+{
+    const u32 l = tid & 31u;
+    const u64 pack_lo = 0x7654765432103210ull;     /* lanes 0..15  */
+    const u64 pack_hi = 0xfedcfedcba98ba98ull;     /* lanes 16..31 */
+    return (u32)(((l & 16u) ? pack_hi : pack_lo) >> (4 * (l & 15u))) & 15u;
+}
+
+/* a * M, every lane its own product */
+/* (tid: a kernel that loops hands in an opaque copy of threadIdx.x, or the sixteen per-step slot constants are
+ * hoisted out of its loop and spilled) */
+__device__ __forceinline__ uint4 tabmul4(const uint4 *T, uint4 a, u32 tid = threadIdx.x)
+{
+    const u32 g = b128_group_pos(tid);
+    u32 r[4];
+    gh_rotate(a, g, r);                                        /* byte k of r = byte (k + g) mod 16 of a */
     const u32 base = (u32)(uintptr_t)(__attribute__((address_space(3))) const uint4 *)T;
-    u32x4 e[32];
+    /* two halves of sixteen lookups, the second not started before the first is folded: 64 instead of 128 registers
+     * of entries in flight (a caller with live state around the product would spill it otherwise) */
+    u32 z[4] = { 0, 0, 0, 0 };
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        /* entry (2j, hi nibble) at j*512 + hi*16; entry (2j+1, lo nibble) at j*512 + 256 + lo*16 */
-        const u32 b = w[j >> 2] >> (8 * (j & 3));
-        const u32 ahi = (b & 0xf0u) + (base + j * 512u);
-        const u32 alo = ((b & 0x0fu) << 4) + (base + j * 512u + 256u);
-        e[2 * j] = *(lds_cu128 *)(uintptr_t)ahi;
-        e[2 * j + 1] = *(lds_cu128 *)(uintptr_t)alo;
-    }
-    u32 z[4];
+    for (int h = 0; h < 2; ++h) {
+        u32x4 e[16];
 #pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        u32 t = xor3(e[0][d], e[1][d], e[2][d]);
+        for (int q = 0; q < 8; ++q) {
+            const int k = 8 * h + q;
+            const u32 c = base + (((g + (u32)k) & 15u) << 4);  /* slot of byte (k + g) mod 16 */
+            e[2 * q] = *(lds_cu128 *)(uintptr_t)(c + (__builtin_amdgcn_ubfe(r[k >> 2], 8u * (k & 3) + 4u, 4u) << 9));
+            e[2 * q + 1] = *(lds_cu128 *)(uintptr_t)(c + 256u + (__builtin_amdgcn_ubfe(r[k >> 2], 8u * (k & 3), 4u) << 9));
+        }
 #pragma unroll
-        for (int k = 3; k < 31; k += 2) t = xor3(t, e[k][d], e[k + 1][d]);
-        z[d] = t ^ e[31][d];
+        for (int d = 0; d < 4; ++d) {
+            u32 t = xor3(z[d], e[0][d], e[1][d]);
+#pragma unroll
+            for (int k = 2; k < 16; k += 2) t = xor3(t, e[k][d], e[k + 1][d]);
+            z[d] = t;
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
     return make_uint4(z[0], z[1], z[2], z[3]);
 }
@@ -223,18 +254,21 @@ __device__ __forceinline__ uint4 tabmul4(const uint4 *T, uint4 a)
  * what counts is the latency of one multiplication, and one lane alone issues 32 lookups, their
  * addresses and a 31-term XOR per dword.  Lane c of the quad takes word c of `a` (8 nibbles),
  * the quad XORs its four partial products with two DPP exchanges per dword; every lane returns
- * the full product.  `a` must be the same in the four lanes.                              */
-__device__ __forceinline__ uint4 tabmul4q(const uint4 *T, uint4 a)
+ * the full product.  `a` must be the same in the four lanes.  A service group is four whole quads:
+ * quad number qd of the group starts its four bytes at byte qd, so that at every step the sixteen lanes
+ * are at sixteen different bytes.                                                              */
+__device__ __forceinline__ uint4 tabmul4q(const uint4 *T, uint4 a, u32 tid = threadIdx.x)
 {
-    const u32 c = threadIdx.x & 3u;
+    const u32 c = tid & 3u, qd = b128_group_pos(tid) >> 2;
     const u32 w = c == 0 ? a.x : c == 1 ? a.y : c == 2 ? a.z : a.w;
-    const u32 base = (u32)(uintptr_t)(__attribute__((address_space(3))) const uint4 *)T + c * 2048u;   /* j = 4c + k */
+    const u32 wr = __builtin_amdgcn_alignbit(w, w, 8u * qd);                /* byte s of wr = byte (s + qd) mod 4 of w */
+    const u32 base = (u32)(uintptr_t)(__attribute__((address_space(3))) const uint4 *)T + c * 64u;   /* byte j = 4c + kk */
     u32x4 e[8];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const u32 b = w >> (8 * k);
-        e[2 * k] = *(lds_cu128 *)(uintptr_t)((b & 0xf0u) + (base + k * 512u));
-        e[2 * k + 1] = *(lds_cu128 *)(uintptr_t)(((b & 0x0fu) << 4) + (base + k * 512u + 256u));
+    for (int s = 0; s < 4; ++s) {
+        const u32 ca = base + ((((u32)s + qd) & 3u) << 4);
+        e[2 * s] = *(lds_cu128 *)(uintptr_t)(ca + (__builtin_amdgcn_ubfe(wr, 8u * s + 4u, 4u) << 9));
+        e[2 * s + 1] = *(lds_cu128 *)(uintptr_t)(ca + 256u + (__builtin_amdgcn_ubfe(wr, 8u * s, 4u) << 9));
     }
     u32 z[4];
 #pragma unroll
@@ -545,7 +579,7 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_setup(uaesk_rk ek, uaesk_tables
             }
             u32 w[4];
             gf_to_words(e, w);
-            dst[p * 16 + v] = make_uint4(w[0], w[1], w[2], w[3]);
+            dst[nib_entry(p, v)] = make_uint4(w[0], w[1], w[2], w[3]);
         }
     }
     ST_STAMP(5);
@@ -793,8 +827,7 @@ static int launch_fused(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *
                         const void *in, void *out, unsigned grid, u64 g_lo, u64 stripes, u64 h1, u64 nfull, u32 rem,
                         const GSrc &front, u64 nfront, unsigned char *sc)
 {
-    hipError_t e = hipFuncSetAttribute((const void *)k_gcm_fused<NR, DEC>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       GF_LDS_TOTAL);
+    hipError_t e = uaesk_want_lds((const void *)k_gcm_fused<NR, DEC>, (unsigned)(GF_LDS_TOTAL));
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL((k_gcm_fused<NR, DEC>), dim3(grid), dim3(UAES_WG), GF_LDS_TOTAL, st, *ek, *tb, *c,
                        (const uint4 *)in, (uint4 *)out, g_lo, stripes, h1, nfull, rem, front, nfront, sc);
@@ -849,7 +882,7 @@ __global__ __launch_bounds__(64) void k_gcm_ej0(uaesk_rk ek, uaesk_tables tb, ui
 template <int NR>
 static int launch_ej0(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek, uint4 j0, unsigned char *sc)
 {
-    hipError_t e = hipFuncSetAttribute((const void *)k_gcm_ej0<NR>, hipFuncAttributeMaxDynamicSharedMemorySize, UAES_LDS_QUAD);
+    hipError_t e = uaesk_want_lds((const void *)k_gcm_ej0<NR>, (unsigned)(UAES_LDS_QUAD));
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL((k_gcm_ej0<NR>), dim3(1), dim3(64), UAES_LDS_QUAD, st, *ek, *tb, j0, sc);
     return (int)hipGetLastError();
@@ -898,7 +931,7 @@ __device__ __forceinline__ void gcm_build_nibble_tables(uint4 *TC, uint4 *buf, c
         }
         u32 w[4];
         gf_to_words(x, w);
-        TC[e] = make_uint4(w[0], w[1], w[2], w[3]);
+        TC[512u * t + nib_entry(p, v)] = make_uint4(w[0], w[1], w[2], w[3]);
     }
     __syncthreads();
 }
@@ -956,7 +989,9 @@ __global__ __launch_bounds__(GH_T) void k_gcm_small(uaesk_rk rk, uaesk_tables tb
     uint4 hold[2];                                            /* decrypt: plaintext waiting for the verdict */
     u64 hold_i[2];
     u32 hold_n[2] = { 0, 0 };                                 /* bytes of it (0 = none) */
-    for (u32 k = 0; k < steps; ++k) {
+#pragma unroll                                                /* constant indices: the per-step arrays stay in registers */
+    for (u32 k = 0; k < 2; ++k) {
+        if (k >= steps) break;
         const u64 u = (u64)k * GH_T + threadIdx.x;
         const bool live = u >= pad;
         const u64 v = live ? u - pad : 0;
@@ -1057,8 +1092,7 @@ static int launch_small(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *
                         const GSrc &src, const void *in, void *out, const unsigned char *sc,
                         unsigned char *tag_io, int *status, u32 build, const uaesk_done &done)
 {
-    hipError_t e = hipFuncSetAttribute((const void *)k_gcm_small<NR, DEC>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       GSM_LDS_TOTAL);
+    hipError_t e = uaesk_want_lds((const void *)k_gcm_small<NR, DEC>, (unsigned)(GSM_LDS_TOTAL));
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL((k_gcm_small<NR, DEC>), dim3(1), dim3(GH_T), GSM_LDS_TOTAL, st, *ek, *tb, *c, j0, src,
                        (const uint4 *)in, (uint4 *)out, sc, tag_io, status, build, done);
@@ -1074,6 +1108,307 @@ static int launch_small_nr(int nr, hipStream_t st, const uaesk_tables *tb, const
     case 10: return launch_small<10, DEC>(st, tb, ek, c, j0, src, in, out, sc, tag_io, status, build, done);
     case 12: return launch_small<12, DEC>(st, tb, ek, c, j0, src, in, out, sc, tag_io, status, build, done);
     case 14: return launch_small<14, DEC>(st, tb, ek, c, j0, src, in, out, sc, tag_io, status, build, done);
+    default: return (int)hipErrorInvalidValue;
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* many short messages under one key: one launch, 1 / 4 / 16 records per workgroup at a time */
+/* ------------------------------------------------------------------------ */
+/* The GCM counterpart of the XTS sector call ("necessary extensions": a message per API call is
+ * 12 us whatever its size, so a stream of TLS records or packets has to arrive as ONE call to run at the
+ * GPU's rate).  Record r has its own 12-byte nonce, its own (or the shared) AAD, `rec_len` bytes of text at
+ * in + r * in_stride; its output is text || 16-byte tag at out + r * out_stride (decrypt: input is
+ * text || tag, output the text -- untouched when the tag is wrong, N7 -- and verdicts[r] = 0 / 0x1A).
+ *
+ * A workgroup is k_gcm_small's body in a loop: the AES tables and the key's nibble tables are brought into LDS
+ * once per workgroup, not once per record.  One record's hash is a chain of DEPENDENT multiplications (the radix-4
+ * tree: ~0.3 us per level whatever the width), so a short record leaves the workgroup idle: the 1024 threads are
+ * therefore cut into G = 1, 4 or 16 groups of S = 1024, 256 or 64 threads, a record per group -- S is the smallest
+ * of the three with room for the record's GHASH positions + one slot for Enc(J0) at two positions per thread --
+ * and the G trees run side by
+ * side as ONE tree whose first (1024-wide) level is already the groups' own first level (gh_tree_groups).  */
+#define GREC_SLOTS     (GT_BUF)                 /* 16 Enc(J0) slots, 16 verdict slots behind the tree buffer */
+#define GREC_LDS_TOTAL (GSM_LDS_TOTAL + 32u * 16u)
+
+/* gh_tree for 4^(5-lg) independent groups of S = 4^lg consecutive entries each (lg = 5, 4, 3); every group's last
+ * `live` entries are not padding.  Group g's hash comes back in the four threads 4g .. 4g+3.            */
+__device__ __forceinline__ uint4 gh_tree_groups(uint4 *buf, const uint4 *T, uint4 acc, u32 live, u32 lg, u32 tid)
+{
+    buf[tid] = acc;
+    __syncthreads();
+    const u32 o = tid >> 2;                            /* the accumulator this quad makes at every level */
+    u32 n = 1024u, off = 0;
+#pragma unroll
+    for (u32 lvl = 1; lvl <= 4; ++lvl) {                       /* tables H^256, H^64, H^16, H^4: m = 4^(5 - lvl) */
+        if (lvl + lg < 6u) continue;                           /* the groups are shorter than 4 m (uniform) */
+        const u32 m = 1u << (2u * (5u - lvl));
+        const uint4 *Tl = T + 512u * lvl;
+        if (tid < n) {
+            const u32 g = o >> (2u * (5u - lvl)), ql = o & (m - 1u);
+            const uint4 *row = buf + off + g * 4u * m + ql;
+            const u32 k0 = 4u - (live + m - 1u) / m;           /* first row with a live entry */
+            acc = row[k0 * m];
+            for (u32 k = k0 + 1; k < 4; ++k) acc = x4(tabmul4q(Tl, acc, tid), row[k * m]);
+            if ((tid & 3u) == 0) buf[off + n + o] = acc;
+        }
+        __syncthreads();
+        off += n;
+        n >>= 2;
+        live = live < m ? live : m;
+    }
+    if (tid < n) {                                     /* n = 4 G: a quad per group, GHASH's last level */
+        const uint4 *TF = T + 512u * 5u;
+        const uint4 *row = buf + off + 4u * o;
+        acc = make_uint4(0, 0, 0, 0);
+        for (u32 k = 4u - live; k < 4; ++k) acc = tabmul4q(TF, x4(acc, row[k]), tid);
+    }
+    return acc;
+}
+
+template <int NR, bool DEC>
+__global__ __launch_bounds__(GH_T) void k_gcm_records(uaesk_rk rk, uaesk_tables tb, const unsigned char *__restrict__ nonces,
+                                                      const unsigned char *aad, u64 aad_len, u64 aad_stride,
+                                                      const unsigned char *in, u64 rec_len, u64 in_stride,
+                                                      unsigned char *out, u64 out_stride, u64 nrec, u32 lg,
+                                                      const unsigned char *__restrict__ scratch,
+                                                      unsigned char *verdicts, int *status)
+{
+    uint4 *TC = (uint4 *)(uaes_lds + GSM_LDS_TAB);
+    uint4 *buf = TC + GT_NTAB * 512u;
+    uint4 *slots = buf + GREC_SLOTS;
+    {
+        const uint4 *g4 = (const uint4 *)(scratch + GS_TAB4);
+        for (u32 i = threadIdx.x; i < GT_NTAB * 512u; i += GH_T) TC[i] = g4[i];
+    }
+    fill_tables64(tb.te0, 0);                                 /* ends with a barrier */
+    const LaneConst2 lc = make_lane_const2(0);
+    const u64 ablk = (aad_len + 15) >> 4, cblk = (rec_len + 15) >> 4, nv = ablk + cblk + 1;
+    const u32 G = GH_T >> (2u * lg);                          /* groups = records per turn */
+    const u32 grp = threadIdx.x >> (2u * lg);
+    /* the nonce of the group's record in the turn that starts at `base` (three little-endian words); fetched one turn
+     * ahead, as are a turn's texts before its block encryptions: nothing else hides a load's latency here */
+    const bool nonce_words = (((uintptr_t)nonces) & 3u) == 0;
+    auto load_nonce = [&](u64 base, u32 (&nw)[3]) {
+        const u64 r = base + grp;
+        const unsigned char *np = nonces + 12 * (r < nrec ? r : 0);
+        if (nonce_words) {
+            nw[0] = ((const u32 *)np)[0]; nw[1] = ((const u32 *)np)[1]; nw[2] = ((const u32 *)np)[2];
+        } else {
+#pragma unroll
+            for (u32 q = 0; q < 3; ++q)
+                nw[q] = (u32)np[4 * q] | (u32)np[4 * q + 1] << 8 | (u32)np[4 * q + 2] << 16 | (u32)np[4 * q + 3] << 24;
+        }
+    };
+    u32 nw[3];
+    load_nonce((u64)blockIdx.x * G, nw);
+#ifdef UAES_GREC_TIMING                                       /* diagnostic build: phase stamps of one turn (100 MHz clock) */
+    u64 rc_ts[6];
+#define RC_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0) rc_ts[i] = wall_clock64(); } while (0)
+#else
+#define RC_STAMP(i) do { } while (0)
+#endif
+    for (u64 base = (u64)blockIdx.x * G; base < nrec; base += (u64)gridDim.x * G) {
+        RC_STAMP(0);
+        /* everything the rounds derive from the lane constants (the odd rounds' per-lane key words above all) is made
+         * again in every turn: held across the turn it is forty registers that end up in scratch memory */
+        LaneConst2 lcv = lc;
+        u32 tid = threadIdx.x, lgv = lg;
+        asm volatile("" : "+v"(lcv.hmask), "+v"(lcv.t[0]), "+v"(lcv.t[1]), "+v"(lcv.t[2]), "+v"(lcv.t[3]), "+v"(tid), "+s"(lgv));
+        const u32 S = 1u << (2u * lgv), t = tid & (S - 1u);    /* group size, position in the group */
+        const u32 steps = nv + 1 > S ? 2u : 1u;               /* positions per thread (launch_records: nv + 1 <= 2 S) */
+        const u64 pad = (u64)steps * S - nv;                  /* >= 1: the group's position 0 is Enc(J0)'s */
+        const u32 live_n = steps == 1 ? (u32)nv : S;
+        const u64 r = base + grp;
+        const bool have = r < nrec;                           /* the last turn may leave groups without a record */
+        const u64 rr = have ? r : 0;
+        const uint4 *rin = (const uint4 *)(in + rr * in_stride);
+        uint4 *rout = (uint4 *)(out + rr * out_stride);
+        GSrc rest;                                            /* AAD blocks and the length block */
+        rest.aad = aad + rr * aad_stride;
+        rest.aad_len = aad_len;
+        rest.ct = nullptr;
+        rest.ct_len = 0;
+        rest.has_len = 1;
+        rest.len_aad = aad_len;
+        rest.len_ct = rec_len;
+        rest.rev = 0;
+        uint4 xk[2] = { make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0) };   /* the position's GHASH input; first the text read */
+        bool is_text[2] = { false, false };
+        u32 ti[2] = { 0, 0 }, tn[2] = { 0, 0 };                /* text block index, bytes in it */
+#pragma unroll                                                /* constant indices: the per-step arrays stay in registers */
+        for (u32 k = 0; k < 2; ++k) {
+            if (k >= steps) break;
+            const u64 u = (u64)k * S + t;
+            const bool live = have && u >= pad;
+            const u64 v = live ? u - pad : 0;
+            is_text[k] = live && v >= ablk && v < ablk + cblk;
+            if (is_text[k]) {
+                ti[k] = (u32)(v - ablk);
+                const u64 avail = rec_len - 16ull * ti[k];
+                tn[k] = avail < 16 ? (u32)avail : 16u;
+                xk[k] = tn[k] == 16 ? rin[ti[k]] : load_bytes_padded((const unsigned char *)(rin + ti[k]), tn[k]);
+            } else if (live) {
+                xk[k] = load_vblock_fwd(rest, v < ablk ? v : ablk);
+            }
+        }
+        /* J0 = nonce || 00 00 00 01 (GCMsetup, micro_aes.c:1140-1152); text block i takes J0 + 1 + i (N4) */
+        uaesk_ctr ctr;
+        ctr.w0 = nw[0];
+        ctr.w1 = nw[1];
+        ctr.w2 = 0; ctr.w3 = 0;
+        ctr.b8 = nw[2] & 0xffu;
+        const u32 n911 = bswap32(nw[2]) & 0x00ffffffu;        /* nonce bytes 9, 10, 11: the top of the 56-bit counter */
+        ctr.v0 = ((u64)n911 << 32) + 2u;
+        ctr.le32 = 0;
+        const u32 j0w2 = nw[2];
+        load_nonce(base + (u64)gridDim.x * G, nw);            /* the next turn's */
+        RC_STAMP(1);
+        uint4 hold[2];
+#pragma unroll                                                /* constant indices: the per-step arrays stay in registers */
+        for (u32 k = 0; k < 2; ++k) {
+            if (k >= steps) break;
+            const bool is_j0 = have && k == 0 && t == 0;      /* the group's position 0 is padding: Enc(J0) rides there */
+            u32 s1[1][4];
+            ctr_words(ctr, ti[k], s1[0]);
+            if (is_j0) {                                      /* words 0-1 are the nonce's already */
+                s1[0][2] = j0w2;
+                s1[0][3] = 0x01000000u;
+            }
+            if (__builtin_amdgcn_ballot_w64(is_text[k] || is_j0) != 0) enc_blocks<NR, 1>(s1, rk, lcv);
+            if (is_j0) slots[grp] = make_uint4(s1[0][0], s1[0][1], s1[0][2], s1[0][3]);
+            if (is_text[k]) {
+                const uint4 d = xk[k];
+                const u32 nb = tn[k];
+                u32 o[4] = { d.x ^ s1[0][0], d.y ^ s1[0][1], d.z ^ s1[0][2], d.w ^ s1[0][3] };
+                if (nb < 16) {
+#pragma unroll
+                    for (u32 w = 0; w < 4; ++w) {
+                        const u32 keep = nb >= 4 * w + 4 ? 0xffffffffu : nb <= 4 * w ? 0u : (1u << (8 * (nb - 4 * w))) - 1u;
+                        o[w] &= keep;
+                    }
+                }
+                const uint4 ov = make_uint4(o[0], o[1], o[2], o[3]);
+                if (DEC) {
+                    hold[k] = ov;                             /* GHASH takes the ciphertext read (xk[k] stays) */
+                } else {
+                    xk[k] = ov;
+                    if (nb == 16) {
+                        rout[ti[k]] = ov;
+                    } else {
+                        unsigned char *dst = (unsigned char *)(rout + ti[k]);
+                        for (u32 b = 0; b < nb; ++b) dst[b] = (unsigned char)(o[b >> 2] >> (8 * (b & 3)));
+                    }
+                }
+            }
+        }
+        RC_STAMP(2);
+        uint4 acc = xk[0];
+        if (steps == 2) acc = x4(tabmul4(TC + 512u * (5u - lgv), acc, tid), xk[1]);   /* by H^S: tables H^1024, H^256, H^64 */
+        RC_STAMP(3);
+        acc = gh_tree_groups(buf, TC, acc, live_n, lgv, tid);       /* group q's hash: threads 4q .. 4q+3 */
+        RC_STAMP(4);
+        const u32 q = tid >> 2;
+        if ((tid & 3u) == 0 && q < G && base + q < nrec) {
+            const u64 rq = base + q;
+            acc = x4(acc, slots[q]);
+            const u32 w[4] = { acc.x, acc.y, acc.z, acc.w };
+            if (DEC) {
+                const unsigned char *tag = in + rq * in_stride + rec_len;
+                u32 diff = 0;
+                for (u32 b = 0; b < 16; ++b) diff |= (u32)tag[b] ^ ((w[b >> 2] >> (8 * (b & 3))) & 0xffu);
+                if (verdicts) verdicts[rq] = diff ? 0x1A : 0;
+                if (diff) atomicOr(status, 0x1A);
+                slots[16 + q] = make_uint4(diff, 0, 0, 0);
+            } else {
+                unsigned char *tag = out + rq * out_stride + rec_len;
+                for (u32 b = 0; b < 16; ++b) tag[b] = (unsigned char)(w[b >> 2] >> (8 * (b & 3)));
+            }
+        }
+        if (DEC) {
+            __syncthreads();
+            if (have && slots[16 + grp].x == 0) {
+#pragma unroll
+                for (u32 k = 0; k < 2; ++k) {
+                    if (!is_text[k]) continue;
+                    if (tn[k] == 16) {
+                        rout[ti[k]] = hold[k];
+                    } else {
+                        const u32 o[4] = { hold[k].x, hold[k].y, hold[k].z, hold[k].w };
+                        unsigned char *dst = (unsigned char *)(rout + ti[k]);
+                        for (u32 b = 0; b < tn[k]; ++b) dst[b] = (unsigned char)(o[b >> 2] >> (8 * (b & 3)));
+                    }
+                }
+            }
+        }
+        __syncthreads();                                      /* the Enc(J0) and verdict slots are rewritten by the next turn */
+#ifdef UAES_GREC_TIMING
+        RC_STAMP(5);
+        if (threadIdx.x == 0 && blockIdx.x == 0 && base == 2ull * gridDim.x * G)
+            printf("gcm records turn (nv %llu, %u groups): loads %llu blocks %llu multiply %llu tree %llu tag+out %llu (x10 ns)\n",
+                   (unsigned long long)nv, G, (unsigned long long)(rc_ts[1] - rc_ts[0]), (unsigned long long)(rc_ts[2] - rc_ts[1]),
+                   (unsigned long long)(rc_ts[3] - rc_ts[2]), (unsigned long long)(rc_ts[4] - rc_ts[3]), (unsigned long long)(rc_ts[5] - rc_ts[4]));
+#endif
+    }
+#undef RC_STAMP
+}
+
+template <int NR>
+static int launch_records(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek, int decrypt, const void *nonces,
+                          const void *aad, size_t aad_len, size_t aad_stride, const void *in, size_t rec_len,
+                          size_t in_stride, void *out, size_t out_stride, size_t nrec, const void *sc,
+                          unsigned char *verdicts, int *status)
+{
+    int cus = 0;
+    uaesk_device_info(&cus, nullptr);
+    const u64 nv = (aad_len + 15) / 16 + (rec_len + 15) / 16 + 1;
+    const u32 lg = nv + 1 <= 128 ? 3u : nv + 1 <= 512 ? 4u : 5u;   /* one or two positions per thread */
+    const u64 turns = (nrec + (GH_T >> (2 * lg)) - 1) / (GH_T >> (2 * lg));
+    const u64 cap = cus > 0 ? (u64)cus : 256u;
+    const unsigned grid = (unsigned)(turns < cap ? turns : cap);
+    hipError_t e;
+    if (decrypt) {
+        e = uaesk_want_lds((const void *)k_gcm_records<NR, true>, (unsigned)GREC_LDS_TOTAL);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((k_gcm_records<NR, true>), dim3(grid), dim3(GH_T), GREC_LDS_TOTAL, st, *ek, *tb,
+                           (const unsigned char *)nonces, (const unsigned char *)aad, (u64)aad_len, (u64)aad_stride,
+                           (const unsigned char *)in, (u64)rec_len, (u64)in_stride, (unsigned char *)out, (u64)out_stride,
+                           (u64)nrec, lg, (const unsigned char *)sc, verdicts, status);
+    } else {
+        e = uaesk_want_lds((const void *)k_gcm_records<NR, false>, (unsigned)GREC_LDS_TOTAL);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((k_gcm_records<NR, false>), dim3(grid), dim3(GH_T), GREC_LDS_TOTAL, st, *ek, *tb,
+                           (const unsigned char *)nonces, (const unsigned char *)aad, (u64)aad_len, (u64)aad_stride,
+                           (const unsigned char *)in, (u64)rec_len, (u64)in_stride, (unsigned char *)out, (u64)out_stride,
+                           (u64)nrec, lg, (const unsigned char *)sc, verdicts, status);
+    }
+    return (int)hipGetLastError();
+}
+
+/* records of up to uaesk_gcm_record_max(aad_len) bytes; texts and strides 16-byte aligned; decrypt: *status must be
+ * zero when the kernel starts (it ORs 0x1A in), verdicts may be NULL */
+extern "C" size_t uaesk_gcm_record_max(size_t aad_len)
+{
+    const size_t ablk = (aad_len + 15) / 16;
+    return ablk + 2 > GSM_MAXNV ? 0 : (GSM_MAXNV - 1 - ablk) * 16;
+}
+
+extern "C" int uaesk_gcm_records(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek, int decrypt,
+                                 const void *nonces12, const void *aad, size_t aad_len, size_t aad_stride,
+                                 const void *in, size_t rec_len, size_t in_stride, void *out, size_t out_stride,
+                                 size_t nrec, const void *key_scratch, unsigned char *verdicts, int *status)
+{
+    if (!nrec) return 0;
+    if (((aad_len + 15) / 16) + ((rec_len + 15) / 16) + 1 > GSM_MAXNV) return (int)hipErrorInvalidValue;
+    if ((((uintptr_t)in | (uintptr_t)out | in_stride | out_stride) & 15u) != 0) return (int)hipErrorInvalidValue;
+    if (decrypt && !status) return (int)hipErrorInvalidValue;
+    switch (nr) {
+    case 10: return launch_records<10>(S(stream), tb, ek, decrypt, nonces12, aad, aad_len, aad_stride, in, rec_len, in_stride,
+                                       out, out_stride, nrec, key_scratch, verdicts, status);
+    case 12: return launch_records<12>(S(stream), tb, ek, decrypt, nonces12, aad, aad_len, aad_stride, in, rec_len, in_stride,
+                                       out, out_stride, nrec, key_scratch, verdicts, status);
+    case 14: return launch_records<14>(S(stream), tb, ek, decrypt, nonces12, aad, aad_len, aad_stride, in, rec_len, in_stride,
+                                       out, out_stride, nrec, key_scratch, verdicts, status);
     default: return (int)hipErrorInvalidValue;
     }
 }
@@ -1210,14 +1545,14 @@ static int launch_medium(hipStream_t st, const uaesk_tables *tb, const uaesk_rk 
     hipError_t e;
 #define GMC_LAUNCH(M)                                                                                               \
     do {                                                                                                            \
-        e = hipFuncSetAttribute((const void *)k_gcm_chunks<NR, M>, hipFuncAttributeMaxDynamicSharedMemorySize, GSM_LDS_TOTAL); \
+        e = uaesk_want_lds((const void *)k_gcm_chunks<NR, M>, (unsigned)(GSM_LDS_TOTAL)); \
         if (e != hipSuccess) return (int)e;                                                                         \
         hipLaunchKernelGGL((k_gcm_chunks<NR, M>), dim3(W), dim3(GH_T), GSM_LDS_TOTAL, st, *ek, *tb, *c, src,          \
                            (const uint4 *)in, (uint4 *)out, (const unsigned char *)sc, partial, build);            \
     } while (0)
     if (decrypt == 0) GMC_LAUNCH(0); else if (decrypt == 1) GMC_LAUNCH(1); else GMC_LAUNCH(2);
 #undef GMC_LAUNCH
-    e = hipFuncSetAttribute((const void *)k_gcm_combine<NR>, hipFuncAttributeMaxDynamicSharedMemorySize, GHFB_LDS);
+    e = uaesk_want_lds((const void *)k_gcm_combine<NR>, (unsigned)(GHFB_LDS));
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL((k_gcm_combine<NR>), dim3(1), dim3(GH_T), GHFB_LDS, st, *ek, *tb, j0, (const uint4 *)partial, W,
                        (const unsigned char *)sc, build, decrypt ? 1 : 0, tag_io, status);
@@ -1334,7 +1669,9 @@ __global__ __launch_bounds__(GH_T) void k_siv_small(uaesk_rk mk, uaesk_tables tb
 
     /* POLYVAL input of this thread's positions (decrypt: produced by decrypting them) */
     uint4 xk[2] = { make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0) };
-    for (u32 k = 0; k < steps; ++k) {
+#pragma unroll                                                /* constant indices: the per-step arrays stay in registers */
+    for (u32 k = 0; k < 2; ++k) {
+        if (k >= steps) break;
         const u64 u = (u64)k * GH_T + threadIdx.x;
         if (u < pad) continue;
         const u64 v = u - pad;
@@ -1377,7 +1714,9 @@ __global__ __launch_bounds__(GH_T) void k_siv_small(uaesk_rk mk, uaesk_tables tb
         return;
     }
     ctr.w0 = t1[0][0]; ctr.w1 = t1[0][1]; ctr.w2 = t1[0][2]; ctr.w3 = t1[0][3] | 0x80000000u;
-    for (u32 k = 0; k < steps; ++k) {
+#pragma unroll                                                /* constant indices: the per-step arrays stay in registers */
+    for (u32 k = 0; k < 2; ++k) {
+        if (k >= steps) break;
         const u64 u = (u64)k * GH_T + threadIdx.x;
         if (u < pad) continue;
         const u64 v = u - pad;
@@ -1414,7 +1753,7 @@ static int run_ghash_levels(hipStream_t st, const GSrc &msg, u64 nv, const GPlan
     u64 n = nv;
     hipError_t e;
     if (pl.logA) {
-        e = hipFuncSetAttribute((const void *)k_ghash_pass, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        e = uaesk_want_lds((const void *)k_ghash_pass, (unsigned)(65536));
         if (e != hipSuccess) return (int)e;
         const u64 sA = (u64)1 << pl.logA;
         hipLaunchKernelGGL(k_ghash_pass, dim3((unsigned)(sA / GH_PT)), dim3(GH_PT), 65536, st,
@@ -1430,7 +1769,7 @@ static int run_ghash_levels(hipStream_t st, const GSrc &msg, u64 nv, const GPlan
             n = sB;
         }
     }
-    e = hipFuncSetAttribute((const void *)k_ghash_final, hipFuncAttributeMaxDynamicSharedMemorySize, GHF_LDS);
+    e = uaesk_want_lds((const void *)k_ghash_final, (unsigned)(GHF_LDS));
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(k_ghash_final, dim3(1), dim3(GH_T), GHF_LDS, st,
                        cur, n, (const unsigned char *)scratch, mode, tag_io, status);
@@ -1445,7 +1784,7 @@ static int launch_setup(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *
                         unsigned char *scratch, const GPlan &pl, u32 h_given, uint4 hval, u32 want_pow64 = 0,
                         u32 logF = 0)
 {
-    hipError_t e = hipFuncSetAttribute((const void *)k_gcm_setup<NR>, hipFuncAttributeMaxDynamicSharedMemorySize, SETUP_LDS);
+    hipError_t e = uaesk_want_lds((const void *)k_gcm_setup<NR>, (unsigned)(SETUP_LDS));
     if (e != hipSuccess) return (int)e;
     /* powers actually needed: the bulk tables, and of the last-levels tables H^1024 / H^64 / H^4 / H
      * only those a message of nv blocks reaches (k_ghash_final skips the empty levels)       */
@@ -2003,8 +2342,7 @@ extern "C" int uaesk_gcmsiv_small(void *stream, const uaesk_tables *tb, int nr, 
     hipError_t e;
 #define SIV_LAUNCH(NRV, D)                                                                                          \
     do {                                                                                                            \
-        e = hipFuncSetAttribute((const void *)k_siv_small<NRV, D>, hipFuncAttributeMaxDynamicSharedMemorySize,      \
-                                SIV_LDS_TOTAL);                                                                     \
+        e = uaesk_want_lds((const void *)k_siv_small<NRV, D>, (unsigned)(SIV_LDS_TOTAL));                           \
         if (e != hipSuccess) return (int)e;                                                                         \
         hipLaunchKernelGGL((k_siv_small<NRV, D>), dim3(1), dim3(GH_T), SIV_LDS_TOTAL, st, *mk, *tb, nn, src,        \
                            (const uint4 *)in, (uint4 *)out,                                                         \

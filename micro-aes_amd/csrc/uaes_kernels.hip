@@ -558,18 +558,24 @@ static unsigned grid_for(u64 work_items, u64 per_wg)
     return (unsigned)(want < cap ? want : cap);
 }
 
-/* > 64 KiB of dynamic LDS needs the attribute; set it once per (kernel, device).
- * Keyed by the kernel's address: instantiations share C++ types, so a per-type
- * static would be wrong.  A racing first call merely sets the attribute twice. */
-static hipError_t set_lds_ptr(const void *kern, unsigned bytes)
+/* > 64 KiB of dynamic LDS needs the attribute; set it once per (kernel, device): hipFuncSetAttribute takes
+ * a runtime-wide lock, which the host threads of the synchronous API would otherwise meet on every call.
+ * Keyed by the kernel's address (instantiations share C++ types, so a per-type static would be wrong),
+ * open addressing on a few address bits.  A racing first call merely sets the attribute twice; a full
+ * neighbourhood falls back to setting it every time. */
+hipError_t uaesk_want_lds(const void *kern, unsigned bytes)
 {
-    static const void *seen[16][64];
+    enum { SLOTS = 512, PROBE = 16 };
+    static const void *volatile seen[16][SLOTS];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    const unsigned h = (unsigned)(((uintptr_t)kern >> 3) * 2654435761u) >> 16;
     int free_slot = -1;
-    for (int i = 0; i < 64; ++i) {
-        if (seen[dev][i] == kern) return hipSuccess;
-        if (!seen[dev][i]) { free_slot = i; break; }
+    for (int i = 0; i < PROBE; ++i) {
+        const unsigned s = (h + i) % SLOTS;
+        const void *v = seen[dev][s];
+        if (v == kern) return hipSuccess;
+        if (!v) { free_slot = (int)s; break; }
     }
     hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e == hipSuccess && free_slot >= 0) seen[dev][free_slot] = kern;
@@ -579,7 +585,7 @@ static hipError_t set_lds_ptr(const void *kern, unsigned bytes)
 template <typename K>
 static hipError_t set_lds(K kern, unsigned bytes)
 {
-    return set_lds_ptr((const void *)kern, bytes);
+    return uaesk_want_lds((const void *)kern, bytes);
 }
 
 #define DISPATCH_NR(nr, CALL)                         \

@@ -179,7 +179,7 @@ template <int NR>
 static int launch_cmac(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek,
                        const void *data, size_t len, void *mac)
 {
-    hipError_t e = hipFuncSetAttribute((const void *)k_cmac<NR>, hipFuncAttributeMaxDynamicSharedMemorySize, UAES_LDS_ROW);
+    hipError_t e = uaesk_want_lds((const void *)k_cmac<NR>, (unsigned)(UAES_LDS_ROW));
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL((k_cmac<NR>), dim3(1), dim3(64), UAES_LDS_ROW, st, *ek, *tb,
                        (const unsigned char *)data, (u64)len, (unsigned char *)mac);
@@ -198,7 +198,7 @@ static int launch_ccm_tag(hipStream_t st, const uaesk_tables *tb, const uaesk_rk
                           const void *aad, size_t aad_len, const void *pt, size_t pt_len,
                           int mode, void *tag_io, int *status, u32 tag_len)
 {
-    hipError_t e = hipFuncSetAttribute((const void *)k_ccm_tag<NR>, hipFuncAttributeMaxDynamicSharedMemorySize, UAES_LDS_ROW);
+    hipError_t e = uaesk_want_lds((const void *)k_ccm_tag<NR>, (unsigned)(UAES_LDS_ROW));
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL((k_ccm_tag<NR>), dim3(1), dim3(64), UAES_LDS_ROW, st, *ek, *tb, iv,
                        (const unsigned char *)aad, (u64)aad_len, (const unsigned char *)pt, (u64)pt_len,

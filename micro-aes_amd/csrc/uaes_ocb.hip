@@ -492,7 +492,7 @@ static unsigned cu_count()
 
 static hipError_t want_lds(const void *kern)
 {
-    return hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OCB_LDS);
+    return uaesk_want_lds(kern, (unsigned)(OCB_LDS));
 }
 
 template <int NR>
@@ -515,7 +515,7 @@ static int launch_ocb(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek
          * the host layer arms a ticket only when it passes a pinned status pointer) */
         const uaesk_done done = uaesk_ticket_take();
         const void *ks = decrypt ? (const void *)k_ocb_small<NR, true> : (const void *)k_ocb_small<NR, false>;
-        if ((e = hipFuncSetAttribute(ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OCB_SMALL_LDS)) != hipSuccess) return (int)e;
+        if ((e = uaesk_want_lds(ks, (unsigned)OCB_SMALL_LDS)) != hipSuccess) return (int)e;
         if (decrypt)
             hipLaunchKernelGGL((k_ocb_small<NR, true>), dim3(1), dim3(UAES_WG), OCB_SMALL_LDS, st, *ek, *dk, *tb, nb, bottom, nrows,
                                scr, (const unsigned char *)aad, (u64)aad_len, (const unsigned char *)in,

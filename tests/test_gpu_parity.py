@@ -1070,6 +1070,121 @@ def test_gcm_key_context_equals_the_one_shot_calls(orc, bits):
     k.close()
 
 
+@pytest.mark.parametrize("bits", [128, 192, 256])
+def test_gcm_record_calls_equal_a_call_per_record(orc, bits):
+    """uaes_gcm_key_{en,de}crypt_records: many equally long messages in one launch, each with its own nonce (and
+    its own or the shared AAD).  Every record must equal the oracle's AES_GCM_encrypt of that record alone; on
+    decryption the records with a wrong tag keep what the output held (N7), the others come out, verdicts say which.
+    The shapes walk the kernel's six arrangements: 16 / 4 / 1 records per workgroup turn, one or two GHASH positions
+    per thread, and their boundaries (63/64, 127/128, 255/256, 511/512, 1023/1024 positions + the Enc(J0) slot)."""
+    rnd = random.Random(4100 + bits)
+    key = rnd.randbytes(bits // 8)
+    k = uaes.GcmKey(key)
+    assert k.record_max(0) == (2046 - 1) * 16 and k.record_max(33) == (2046 - 1 - 3) * 16
+    try:
+        shapes = [(1, 0, 0), (3, 1, 0), (5, 16, 13), (300, 1500, 13), (7, 4096, 0), (600, 100, 5), (2, 16368, 0),
+                  (3, k.record_max(40), 40), (9, 16383, 16), (260, 33, 100), (4, 32720, 0), (5, 10000, 20), (11, 3000, 7),
+                  (70, 1000, 0), (33, 2016, 0), (17, 8160, 0)]
+        for nrec, rec_len, aad_len in shapes:
+            nonces = [rnd.randbytes(12) for _ in range(nrec)]
+            recs = [rnd.randbytes(rec_len) for _ in range(nrec)]
+            for per_record_aad in (False, True):
+                aads = [rnd.randbytes(aad_len) for _ in range(nrec)] if per_record_aad else rnd.randbytes(aad_len)
+                aad_of = (lambda r: aads[r]) if per_record_aad else (lambda r: aads)
+                want = [orc.gcm_encrypt(key, nonces[r], aad_of(r), recs[r]) for r in range(nrec)]
+                got = k.encrypt_records(nonces, aads, recs)
+                assert got == want, (nrec, rec_len, aad_len, per_record_aad)
+                rc, ver, texts = k.decrypt_records(nonces, aads, got, prefill=0xCC)
+                assert rc == 0 and ver == [0] * nrec and texts == recs
+                # spoil some records: in the text, in the tag, (with AAD) by handing over another record's nonce
+                bad = sorted(rnd.sample(range(nrec), min(nrec, 1 + nrec // 7)))
+                spoiled = list(got)
+                for r in bad:
+                    b = bytearray(spoiled[r])
+                    b[rnd.randrange(len(b))] ^= 1 << rnd.randrange(8)
+                    spoiled[r] = bytes(b)
+                rc, ver, texts = k.decrypt_records(nonces, aads, spoiled, prefill=0xCC)
+                assert rc == 0x1A
+                assert ver == [0x1A if r in bad else 0 for r in range(nrec)]
+                for r in range(nrec):
+                    assert texts[r] == (b"\xcc" * rec_len if r in bad else recs[r]), (nrec, rec_len, r)
+                if aad_len == 0:
+                    break
+        # a strided layout: the gaps between the records are not written
+        nrec, rec_len, stride = 37, 1000, 2048
+        nonces = [rnd.randbytes(12) for _ in range(nrec)]
+        recs = [rnd.randbytes(rec_len) for _ in range(nrec)]
+        got = k.encrypt_records(nonces, b"hdr", recs, stride=stride)
+        assert got == [orc.gcm_encrypt(key, nonces[r], b"hdr", recs[r]) for r in range(nrec)]
+        L = uaes.engine()
+        src = bytearray(stride * nrec)
+        for r in range(nrec):
+            src[r * stride: r * stride + rec_len + 16] = got[r]
+        dst = (C.c_uint8 * (stride * nrec))()
+        C.memset(dst, 0xEE, stride * nrec)
+        ver = (C.c_uint8 * nrec)()
+        rc = L.uaes_gcm_key_decrypt_records(k._h, nrec, (C.c_uint8 * (12 * nrec)).from_buffer_copy(b"".join(nonces)),
+                                            (C.c_uint8 * 3).from_buffer_copy(b"hdr"), 3, 0,
+                                            (C.c_uint8 * len(src)).from_buffer_copy(bytes(src)), rec_len, stride, dst, stride, ver)
+        assert rc == 0
+        b = bytes(dst)
+        for r in range(nrec):
+            assert b[r * stride: r * stride + rec_len] == recs[r]
+            assert b[r * stride + rec_len: (r + 1) * stride] == b"\xee" * (stride - rec_len)
+        # argument checks
+        assert L.uaes_gcm_key_encrypt_records(k._h, 1, dst, None, 0, 0, dst, k.record_max(0) + 1, 65536, dst, 65536) == -2
+        assert L.uaes_gcm_key_encrypt_records(k._h, 2, dst, None, 0, 0, dst, 100, 120, dst, 128) == -2     # stride % 16
+        assert L.uaes_gcm_key_encrypt_records(k._h, 2, dst, None, 0, 0, dst, 100, 112, dst, 112) == -2     # no room for the tag
+        assert L.uaes_gcm_key_encrypt_records(k._h, 0, None, None, 0, 0, None, 100, 112, None, 128) == 0
+    finally:
+        k.close()
+
+
+def test_gcm_record_calls_on_device_buffers(orc):
+    """the *_dev flavour: device pointers for nonces, AAD, records; many more records than workgroups; in place;
+    two record calls sharing one key context on two streams"""
+    import torch
+    rnd = random.Random(4200)
+    key = rnd.randbytes(16)
+    k = uaes.GcmKey(key)
+    try:
+        nrec, rec_len, stride, aad_len = 3000, 1440, 1472, 13
+        nonces = torch.randint(0, 256, (nrec * 12 + 1,), dtype=torch.uint8, device="cuda:0")[1:]     # not word aligned
+        aad = torch.randint(0, 256, (nrec * 16,), dtype=torch.uint8, device="cuda:0")
+        buf = torch.randint(0, 256, (nrec * stride,), dtype=torch.uint8, device="cuda:0")
+        plain = buf.clone()
+        out2 = torch.zeros_like(buf)
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        torch.cuda.synchronize()
+        aligned = nonces.clone()
+        k.encrypt_records_dev(nrec, aligned, aad, aad_len, 16, plain, rec_len, stride, out2, stride, stream=s2)
+        k.encrypt_records_dev(nrec, nonces, aad, aad_len, 16, buf, rec_len, stride, buf, stride, stream=s1)   # in place
+        torch.cuda.synchronize()
+        nb, ab, ob, pb = (bytes(t.cpu().numpy()) for t in (nonces, aad, buf, plain))
+        o2 = bytes(out2.cpu().numpy())
+        for r in list(range(0, nrec, 97)) + [nrec - 1]:
+            want = orc.gcm_encrypt(key, nb[12 * r: 12 * r + 12], ab[16 * r: 16 * r + aad_len], pb[r * stride: r * stride + rec_len])
+            assert ob[r * stride: r * stride + rec_len + 16] == want, r
+            assert o2[r * stride: r * stride + rec_len + 16] == want, r
+            assert ob[r * stride + rec_len + 16: (r + 1) * stride] == pb[r * stride + rec_len + 16: (r + 1) * stride]
+        back = torch.full_like(buf, 0xCC)
+        ver = torch.full((nrec,), 0x55, dtype=torch.uint8, device="cuda:0")
+        status = torch.full((1,), -1, dtype=torch.int32, device="cuda:0")
+        buf[5 * stride + 7] ^= 1
+        buf[2999 * stride + rec_len + 15] ^= 0x80
+        k.decrypt_records_dev(nrec, nonces, aad, aad_len, 16, buf, rec_len, stride, back, stride, ver, status)
+        torch.cuda.synchronize()
+        assert int(status.item()) == 0x1A
+        v = ver.cpu().numpy()
+        assert set(np.nonzero(v)[0].tolist()) == {5, 2999} and int(v[5]) == 0x1A
+        bb = bytes(back.cpu().numpy())
+        for r in range(nrec):
+            want = b"\xcc" * rec_len if r in (5, 2999) else pb[r * stride: r * stride + rec_len]
+            assert bb[r * stride: r * stride + rec_len] == want, r
+    finally:
+        k.close()
+
+
 def test_C4_gcm128_1GiB_device_resident(orc, golden_dir):
     """BASELINE configs[3]: tag and digest of CT||tag for the 1 GiB message."""
     import torch
