@@ -33,7 +33,10 @@ __device__ __forceinline__ Blk ld_block(const unsigned char *p, u64 avail)
         return b;
     }
     const u32 n = avail < 16 ? (u32)avail : 16u;
-    for (u32 i = 0; i < n; ++i) b.w[i >> 2] |= (u32)p[i] << (8 * (i & 3));
+#pragma unroll                                                /* constant word indices: b stays in registers (a run-time
+                                                                 index puts it into scratch memory, a round trip per access) */
+    for (u32 i = 0; i < 16; ++i)
+        if (i < n) b.w[i >> 2] |= (u32)p[i] << (8 * (i & 3));
     return b;
 }
 
@@ -97,7 +100,9 @@ __global__ __launch_bounds__(64) void k_cmac(uaesk_rk rk, uaesk_tables tb,
     cbcmac_absorb<NR>(m, data, len - s, L);
     Blk last = ld_block(data + (len - s), s);
     if (s < 16) {
-        last.w[s >> 2] ^= 0x80u << (8 * (s & 3));            /* 10* padding, then K2 */
+#pragma unroll
+        for (u32 q = 0; q < 4; ++q)                           /* 10* padding, then K2 */
+            last.w[q] ^= q == (s >> 2) ? 0x80u << (8 * (s & 3)) : 0u;
         xor_blk(last, k2);
     } else {
         xor_blk(last, k1);
@@ -117,39 +122,33 @@ __global__ __launch_bounds__(64) void k_ccm_tag(uaesk_rk rk, uaesk_tables tb, ui
     row_fill_tables(tb.te0, rk);                 /* one wave: sixteen lanes per block, four rows redundantly */
     const RowLane<NR> L = row_lane<NR>();
     const Blk iv = { { iv4.x, iv4.y, iv4.z, iv4.w } };
-    unsigned char b0[16], a[16];
-    for (u32 i = 0; i < 16; ++i) b0[i] = (unsigned char)(iv.w[i >> 2] >> (8 * (i & 3)));
-    b0[0] |= (unsigned char)((tag_len - 2) << 2);         /* (CCM_TAG_LEN - 2) << 2, :1229    */
-    {
-        u64 n = pt_len;                                   /* xorBEint(M, ptextLen, LAST)      */
-        int pos = 15;
-        do { b0[pos--] ^= (unsigned char)n; } while (n >>= 8);
-    }
-    for (int i = 0; i < 16; ++i) a[i] = 0;
+    /* B0 and the first AAD block are put together in words (byte arrays indexed at run time live in scratch memory) */
+    Blk mb = iv;
+    mb.w[0] |= (tag_len - 2) << 2;                        /* (CCM_TAG_LEN - 2) << 2 into byte 0, :1229 */
+    mb.w[2] ^= bswap32((u32)((u64)pt_len >> 32));         /* xorBEint(M, ptextLen, LAST): big-endian, ending at byte 15 */
+    mb.w[3] ^= bswap32((u32)pt_len);
+    Blk ab = { { 0, 0, 0, 0 } };
     u64 s = 0;
-    Blk mb;
     if (aad_len) {
-        b0[0] |= 0x40;
-        mb = ld_block(b0, 16);
+        mb.w[0] |= 0x40u;
         enc1<NR>(mb, L);
-        int p = 1;
-        if (aad_len > 0xFEFFull) { p += 4; a[0] = 0xFF; a[1] = 0xFE; }
-        {
-            u64 n = aad_len;                              /* xorBEint(A, aDataLen, p)          */
-            int pos = p;
-            do { a[pos--] ^= (unsigned char)n; } while (n >>= 8);
+        /* the length of the AAD in front of it: two bytes, or ff fe + four (the reference's p = 1 / 5, :1236-1241;
+         * xorBEint keeps going while bits are left, so a length of 2^32 and more spills into the ff fe bytes) */
+        const u32 hdr = aad_len > 0xFEFFull ? 6u : 2u;
+        if (hdr == 6) {
+            ab.w[0] = (0xFFu ^ ((u32)(aad_len >> 40) & 0xffu)) | (0xFEu ^ ((u32)(aad_len >> 32) & 0xffu)) << 8 |
+                      ((u32)(aad_len >> 24) & 0xffu) << 16 | ((u32)(aad_len >> 16) & 0xffu) << 24;
+            ab.w[1] = ((u32)(aad_len >> 8) & 0xffu) | ((u32)aad_len & 0xffu) << 8;
+        } else {
+            ab.w[0] = ((u32)(aad_len >> 8) & 0xffu) | ((u32)aad_len & 0xffu) << 8;
         }
-        ++p;
-        s = 16 - p;
-        const u64 take = aad_len < s ? aad_len : s;
-        for (u64 i = 0; i < take; ++i) a[p + i] = aad[i];
-    } else {
-        mb = ld_block(b0, 16);
+        s = 16 - hdr;
+        const u32 take = aad_len < s ? (u32)aad_len : (u32)s;
+#pragma unroll
+        for (u32 i = 2; i < 16; ++i)
+            if (i >= hdr && i - hdr < take) ab.w[i >> 2] |= (u32)aad[i - hdr] << (8 * (i & 3));
     }
-    {
-        const Blk ab = ld_block(a, 16);                   /* xMac(A, 16): also encrypts B0 when there is no AAD */
-        xor_blk(mb, ab);
-    }
+    xor_blk(mb, ab);                                      /* xMac(A, 16): also encrypts B0 when there is no AAD */
     u32 m = row_encrypt<NR>(row_pick(mb.w, L.c), L);
     if (aad_len > s) cbcmac_absorb<NR>(m, aad + s, aad_len - s, L);
     cbcmac_absorb<NR>(m, pt, pt_len, L);
@@ -161,7 +160,9 @@ __global__ __launch_bounds__(64) void k_ccm_tag(uaesk_rk rk, uaesk_tables tb, ui
         row_spread(m, t.w);
         if (threadIdx.x == 0) {
             u32 diff = 0;
-            for (u32 i = 0; i < tag_len; ++i) diff |= (u32)tag_io[i] ^ ((t.w[i >> 2] >> (8 * (i & 3))) & 0xffu);
+#pragma unroll
+            for (u32 i = 0; i < 16; ++i)
+                if (i < tag_len) diff |= (u32)tag_io[i] ^ ((t.w[i >> 2] >> (8 * (i & 3))) & 0xffu);
             *status = diff ? 0x1A : 0;
         }
     }

@@ -296,8 +296,25 @@ __device__ __forceinline__ B16 ocb_load_bytes(const unsigned char *p, u32 n)
 {
     B16 b = { { 0, 0, 0, 0 } };
     if (n == 16 && (((uintptr_t)p) & 15u) == 0) return b16(*(const uint4 *)p);
-    for (u32 i = 0; i < n; ++i) b.w[i >> 2] |= (u32)p[i] << (8 * (i & 3));
+#pragma unroll                                                /* constant word indices: a block indexed at run time lives
+                                                                 in scratch memory, a round trip to it per access */
+    for (u32 i = 0; i < 16; ++i)
+        if (i < n) b.w[i >> 2] |= (u32)p[i] << (8 * (i & 3));
     return b;
+}
+
+/* byte `pos` (0..15, run time) of a block in registers: ^= v, and its value */
+__device__ __forceinline__ void b16_xor_byte(B16 &b, u32 pos, u32 v)
+{
+#pragma unroll
+    for (u32 q = 0; q < 4; ++q) b.w[q] ^= q == (pos >> 2) ? v << (8 * (pos & 3)) : 0u;
+}
+
+__device__ __forceinline__ u32 b16_byte(const B16 &b, u32 pos)
+{
+    const u32 q = pos >> 2;
+    const u32 w = q == 0 ? b.w[0] : q == 1 ? b.w[1] : q == 2 ? b.w[2] : b.w[3];
+    return (w >> (8 * (pos & 3))) & 0xffu;
 }
 
 /* the caller has put the L table with cleared accumulators (ocb_tables_to_lds) and the ENCRYPTION tables into LDS */
@@ -321,7 +338,7 @@ __device__ __forceinline__ void ocb_final_body(const uaesk_rk &ek, const LaneCon
     if (threadIdx.x == 0 && (aad_len & 15u)) {        /* A_* || 1 || 0.., Offset_* = Offset_m ^ L_* (:1755-1760) */
         const u32 r = (u32)(aad_len & 15u);
         B16 b = ocb_load_bytes(aad + 16 * na, r);
-        b.w[r >> 2] ^= 0x80u << (8 * (r & 3));
+        b16_xor_byte(b, r, 0x80u);
         bx(b, ocb_delta(na));
         bx(b, lds_row(0));
         ocb_enc1<NR>(b, ek, lc);
@@ -355,21 +372,25 @@ __device__ __forceinline__ void ocb_final_body(const uaesk_rk &ek, const LaneCon
             ocb_enc1<NR>(pad, ek, lc);
             for (u32 i = 0; i < r; ++i) {
                 const u32 x = in[16 * n + i];
-                const u32 y = x ^ ((pad.w[i >> 2] >> (8 * (i & 3))) & 0xffu);
-                ck.w[i >> 2] ^= (decrypt ? y : x) << (8 * (i & 3));
+                const u32 y = x ^ b16_byte(pad, i);
+                b16_xor_byte(ck, i, decrypt ? y : x);
                 out[16 * n + i] = (unsigned char)y;
             }
-            ck.w[r >> 2] ^= 0x80u << (8 * (r & 3));
+            b16_xor_byte(ck, r, 0x80u);
         }
         bx(ck, d);
         bx(ck, lds_row(1));                               /* ^ L_$ */
         ocb_enc1<NR>(ck, ek, lc);
         bx(ck, b16(*(const uint4 *)(uaes_lds + OCB_LDS_ACC)));
         if (!decrypt) {                                   /* the first OCB_TAG_LEN bytes (:1783 / :1807) */
-            for (u32 i = 0; i < tag_len; ++i) out[len + i] = (unsigned char)(ck.w[i >> 2] >> (8 * (i & 3)));
+#pragma unroll
+            for (u32 i = 0; i < 16; ++i)
+                if (i < tag_len) out[len + i] = (unsigned char)(ck.w[i >> 2] >> (8 * (i & 3)));
         } else {
             u32 diff = 0;
-            for (u32 i = 0; i < tag_len; ++i) diff |= (u32)in[len + i] ^ ((ck.w[i >> 2] >> (8 * (i & 3))) & 0xffu);
+#pragma unroll
+            for (u32 i = 0; i < 16; ++i)
+                if (i < tag_len) diff |= (u32)in[len + i] ^ ((ck.w[i >> 2] >> (8 * (i & 3))) & 0xffu);
             *status = diff ? 0x1A : 0;
         }
     }

@@ -207,3 +207,12 @@ def test_bulk_kernels_have_no_private_segment_and_only_gfx950_code():
         assert k["scratch"] == 0 and k["vgpr_spill"] == 0, (k["name"][:80], k["scratch"], k["vgpr_spill"])
         assert k["vgpr"] <= 128, (k["name"][:80], k["vgpr"])          # 4 waves per SIMD at least
     assert {"ecb", "ctr", "ctr_shared2", "xts", "fb_dec", "chain_batch", "gcm_fused", "ghash_pass", "gcm_chunks", "ocb"} <= seen
+    # the one-workgroup kernels of the short calls as well: a scratch access is a round trip to memory in the middle
+    # of a latency-bound chain (round 3: k_gcm_small, k_siv_small, k_cmac, k_ccm_tag, k_ocb_small / _final had
+    # step arrays and byte buffers indexed at run time there).  The one exception is the decrypting record kernel,
+    # which keeps four registers of held plaintext across its hash.
+    for k in ks:
+        if re.search(r"\bk_gcm_records<\d+, true>", k["name"]):
+            assert k["scratch"] <= 32 and k["vgpr_spill"] <= 8, (k["name"][:80], k["scratch"], k["vgpr_spill"])
+        else:
+            assert k["scratch"] == 0 and k["vgpr_spill"] == 0, (k["name"][:80], k["scratch"], k["vgpr_spill"])
