@@ -61,7 +61,10 @@
 #define GS_YLO      (GS_TAB8_F + 65536u)            /* Y^0..Y^15, Y = H^2048 (workgroup weights)     */
 #define GS_ZHI      (GS_YLO + 256u)                 /* Z^0..Z^15, Z = Y^16                           */
 #define GS_T        (GS_ZHI + 256u)                 /* XOR of the workgroups' weighted partial hashes */
-#define GS_TOTAL    (GS_T + 64u)
+#define GS_YTAB     (GS_T + 64u)                    /* key contexts: the combine kernel's nibble tables of Y^256 .. Y, 40 KiB
+                                                       each for Y = H^1024 and Y = H^2048 (k_gcm_ytables)                */
+#define GS_YTAB_SET (5u * 8192u)
+#define GS_TOTAL    (GS_YTAB + 2u * GS_YTAB_SET)
 
 static inline hipStream_t S(void *s) { return (hipStream_t)s; }
 
@@ -898,13 +901,13 @@ static int launch_ej0(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek
  *               H^(2^11), and table 1 holds Y^256 = H^(2^19): the same radix-4 tree over the partial hashes of
  *               2048-block chunks (k_gcm_combine); table 0 is not made.                                        */
 template <bool YPOW = false>
-__device__ __forceinline__ void gcm_build_nibble_tables(uint4 *TC, uint4 *buf, const uint64_t *__restrict__ frob)
+__device__ __forceinline__ void gcm_build_nibble_tables(uint4 *TC, uint4 *buf, const uint64_t *__restrict__ frob, u32 ylog = 11)
 {
     Gf *shPow = (Gf *)buf;                         /* 6 powers                  */
     Gf *shGen = (Gf *)(buf + 16);                  /* 6 x 128 generators: 12 KiB */
     const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     if (wave < GT_NTAB && !(YPOW && wave < 1)) {
-        const u32 k = YPOW ? 21u - 2u * wave : 10u - 2u * wave;
+        const u32 k = YPOW ? ylog + 10u - 2u * wave : 10u - 2u * wave;   /* Y = H^(2^ylog): chunks of 2048 or 1024 positions */
         const Gf h = gf_from4(buf[GT_BUF - 3]);
         Gf pw = h;
         if (k) {
@@ -1431,7 +1434,8 @@ extern "C" int uaesk_gcm_records(void *stream, const uaesk_tables *tb, int nr, c
 template <int NR, int MODE>
 __global__ __launch_bounds__(GH_T) void k_gcm_chunks(uaesk_rk rk, uaesk_tables tb, uaesk_ctr ctr,
                                                      GSrc src, const uint4 *in, uint4 *out,
-                                                     const unsigned char *__restrict__ scratch, uint4 *partial, u32 build)
+                                                     const unsigned char *__restrict__ scratch, uint4 *partial, u32 build,
+                                                     u32 steps)
 {
     uint4 *TC = (uint4 *)(uaes_lds + GSM_LDS_TAB);
     uint4 *buf = TC + GT_NTAB * 512u;
@@ -1450,13 +1454,15 @@ __global__ __launch_bounds__(GH_T) void k_gcm_chunks(uaesk_rk rk, uaesk_tables t
     }
     const u64 len = src.ct_len;
     const u64 ablk = (src.aad_len + 15) >> 4, cblk = (len + 15) >> 4, nv = ablk + cblk + 1;
-    const u64 pad = 2048ull * gridDim.x - nv;                 /* zero positions in front of the sequence */
+    const u64 chunk = (u64)steps * GH_T;                      /* positions per workgroup: one or two per thread */
+    const u64 pad = chunk * gridDim.x - nv;                   /* zero positions in front of the sequence */
     GSrc rest = src;                                          /* AAD blocks and the length block */
     rest.ct_len = 0;
-    uint4 xk[2];
+    uint4 xk[2] = { make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0) };
 #pragma unroll
     for (u32 k = 0; k < 2; ++k) {
-        const u64 P = 2048ull * blockIdx.x + (u64)k * GH_T + threadIdx.x;
+        if (k >= steps) break;
+        const u64 P = chunk * blockIdx.x + (u64)k * GH_T + threadIdx.x;
         const bool live = P >= pad;
         const u64 v = live ? P - pad : 0;
         const bool is_text = live && v >= ablk && v < ablk + cblk;
@@ -1492,7 +1498,8 @@ __global__ __launch_bounds__(GH_T) void k_gcm_chunks(uaesk_rk rk, uaesk_tables t
         }
         xk[k] = x;
     }
-    uint4 acc = x4(tabmul4(TC, xk[0]), xk[1]);
+    uint4 acc = xk[0];
+    if (steps == 2) acc = x4(tabmul4(TC, acc), xk[1]);
     acc = gh_tree<true>(buf, TC, acc, GH_T);
     if (threadIdx.x == 0) partial[blockIdx.x] = acc;
 }
@@ -1501,7 +1508,8 @@ __global__ __launch_bounds__(GH_T) void k_gcm_chunks(uaesk_rk rk, uaesk_tables t
 template <int NR>
 __global__ __launch_bounds__(GH_T) void k_gcm_combine(uaesk_rk ek, uaesk_tables tb, uint4 j0, const uint4 *partial, u32 W,
                                                       const unsigned char *__restrict__ scratch, u32 build,
-                                                      int mode, unsigned char *tag_io, int *status)
+                                                      int mode, unsigned char *tag_io, int *status, u32 ylog,
+                                                      unsigned char *wipe_out, u64 wipe_len)
 {
     uint4 *TC = (uint4 *)uaes_lds;
     uint4 *buf = TC + GT_NTAB * 512u;
@@ -1518,7 +1526,13 @@ __global__ __launch_bounds__(GH_T) void k_gcm_combine(uaesk_rk ek, uaesk_tables 
     }
     __syncthreads();
     const uint4 ej0 = buf[GT_BUF - 2];
-    gcm_build_nibble_tables<true>(TC, buf, tb.frob);          /* Y^256, Y^64, Y^16, Y^4, Y in tables 1..5 */
+    if (build) {
+        gcm_build_nibble_tables<true>(TC, buf, tb.frob, ylog);    /* Y^256, Y^64, Y^16, Y^4, Y in tables 1..5 */
+    } else {                                                      /* a key context holds them (k_gcm_ytables) */
+        const uint4 *gy = (const uint4 *)(scratch + GS_YTAB + (ylog - 10u) * GS_YTAB_SET);
+        for (u32 i = threadIdx.x; i < 5u * 512u; i += GH_T) TC[512u + i] = gy[i];
+        __syncthreads();
+    }
     /* the W partial hashes are the LAST W of 1024 entries (up to 256 of them the 1024 -> 256 level only copies) */
     uint4 acc = make_uint4(0, 0, 0, 0);
     if (threadIdx.x >= GH_T - W) acc = partial[threadIdx.x - (GH_T - W)];
@@ -1530,15 +1544,42 @@ __global__ __launch_bounds__(GH_T) void k_gcm_combine(uaesk_rk ek, uaesk_tables 
             u32 diff = 0;
             for (u32 i = 0; i < 16; ++i) diff |= (u32)tag_io[i] ^ ((w[i >> 2] >> (8 * (i & 3))) & 0xffu);
             *status = diff ? 0x1A : 0;
+            buf[GT_BUF - 1] = make_uint4(diff, 0, 0, 0);
         } else {
             for (u32 i = 0; i < 16; ++i) tag_io[i] = (unsigned char)(w[i >> 2] >> (8 * (i & 3)));
         }
     }
+    /* one-pass decryption (the chunk kernel has written the plaintext already): a wrong tag takes it back HERE, by
+     * this one workgroup -- slow for megabytes, but only a forgery pays it, and every good message saves the launch
+     * of a wipe kernel behind this one */
+    if (wipe_out) {
+        __syncthreads();
+        if (buf[GT_BUF - 1].x != 0) {
+            const u64 head = wipe_len < 16 ? wipe_len : (16 - ((uintptr_t)wipe_out & 15u)) & 15u;
+            for (u64 i = threadIdx.x; i < head; i += GH_T) wipe_out[i] = 0;
+            uint4 *v = (uint4 *)(wipe_out + head);
+            const u64 nv16 = (wipe_len - head) >> 4;
+            for (u64 i = threadIdx.x; i < nv16; i += GH_T) v[i] = make_uint4(0, 0, 0, 0);
+            for (u64 i = head + (nv16 << 4) + threadIdx.x; i < wipe_len; i += GH_T) wipe_out[i] = 0;
+        }
+    }
+}
+
+/* key context: the two table sets k_gcm_combine would otherwise make in every call (workgroup 0: Y = H^1024, 1: H^2048) */
+__global__ __launch_bounds__(GH_T) void k_gcm_ytables(uaesk_tables tb, unsigned char *__restrict__ scratch)
+{
+    uint4 *TC = (uint4 *)uaes_lds;
+    uint4 *buf = TC + GT_NTAB * 512u;
+    if (threadIdx.x == 0) buf[GT_BUF - 3] = *(const uint4 *)(scratch + GS_H);
+    __syncthreads();
+    gcm_build_nibble_tables<true>(TC, buf, tb.frob, 10u + blockIdx.x);
+    uint4 *gy = (uint4 *)(scratch + GS_YTAB + blockIdx.x * GS_YTAB_SET);
+    for (u32 i = threadIdx.x; i < 5u * 512u; i += GH_T) gy[i] = TC[512u + i];
 }
 
 template <int NR>
 static int launch_medium(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek, const uaesk_ctr *c, uint4 j0,
-                         const GSrc &src, const void *in, void *out, unsigned char *sc, u32 W, u32 build, int decrypt,
+                         const GSrc &src, const void *in, void *out, unsigned char *sc, u32 W, u32 steps, u32 build, int decrypt,
                          unsigned char *tag_io, int *status)
 {
     uint4 *partial = (uint4 *)(sc + GS_ACC1);
@@ -1548,14 +1589,15 @@ static int launch_medium(hipStream_t st, const uaesk_tables *tb, const uaesk_rk 
         e = uaesk_want_lds((const void *)k_gcm_chunks<NR, M>, (unsigned)(GSM_LDS_TOTAL)); \
         if (e != hipSuccess) return (int)e;                                                                         \
         hipLaunchKernelGGL((k_gcm_chunks<NR, M>), dim3(W), dim3(GH_T), GSM_LDS_TOTAL, st, *ek, *tb, *c, src,          \
-                           (const uint4 *)in, (uint4 *)out, (const unsigned char *)sc, partial, build);            \
+                           (const uint4 *)in, (uint4 *)out, (const unsigned char *)sc, partial, build, steps);     \
     } while (0)
     if (decrypt == 0) GMC_LAUNCH(0); else if (decrypt == 1) GMC_LAUNCH(1); else GMC_LAUNCH(2);
 #undef GMC_LAUNCH
     e = uaesk_want_lds((const void *)k_gcm_combine<NR>, (unsigned)(GHFB_LDS));
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL((k_gcm_combine<NR>), dim3(1), dim3(GH_T), GHFB_LDS, st, *ek, *tb, j0, (const uint4 *)partial, W,
-                       (const unsigned char *)sc, build, decrypt ? 1 : 0, tag_io, status);
+                       (const unsigned char *)sc, build, decrypt ? 1 : 0, tag_io, status, steps == 2 ? 11u : 10u,
+                       decrypt == 2 ? (unsigned char *)out : nullptr, (u64)src.ct_len);
     return (int)hipGetLastError();
 }
 
@@ -1980,25 +2022,25 @@ static int gcm_body(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk
         /* a medium-sized text: chunk kernel + combine kernel (k_gcm_chunks, k_gcm_combine), tables made in the
          * kernels for a one-shot call.  Decrypt mode 1 hashes first and lets the gated CTR kernel write; mode 2
          * decrypts in the chunk kernel and zeroes the output if the tag turns out wrong.                       */
-        const u32 W = (u32)((nv + 2047) / 2048), build = keyed ? 0u : 1u;
+        /* one position per thread while that still gives every workgroup its own CU (up to 4 MiB on 256 CUs): the
+         * chunk kernel then runs one pass of block encryptions and no stride multiplication (1 MiB 24.7 -> ?? us) */
+        int cus_m = 0;
+        if (uaesk_device_info(&cus_m, nullptr) != 0 || cus_m <= 0) cus_m = 64;
+        const u32 steps = (nv + 1023) / 1024 <= (u64)cus_m ? 1u : 2u;
+        const u32 W = (u32)((nv + 1024ull * steps - 1) / (1024ull * steps)), build = keyed ? 0u : 1u;
         GSrc sm = msg;
         sm.ct = (const unsigned char *)in;
         unsigned char *tagp = decrypt ? (unsigned char *)in + len : (unsigned char *)out + len;
         switch (nr) {
-        case 10: rc = launch_medium<10>(st, tb, ek, &c, j0, sm, in, out, sc, W, build, decrypt, tagp, status); break;
-        case 12: rc = launch_medium<12>(st, tb, ek, &c, j0, sm, in, out, sc, W, build, decrypt, tagp, status); break;
-        case 14: rc = launch_medium<14>(st, tb, ek, &c, j0, sm, in, out, sc, W, build, decrypt, tagp, status); break;
+        case 10: rc = launch_medium<10>(st, tb, ek, &c, j0, sm, in, out, sc, W, steps, build, decrypt, tagp, status); break;
+        case 12: rc = launch_medium<12>(st, tb, ek, &c, j0, sm, in, out, sc, W, steps, build, decrypt, tagp, status); break;
+        case 14: rc = launch_medium<14>(st, tb, ek, &c, j0, sm, in, out, sc, W, steps, build, decrypt, tagp, status); break;
         default: return (int)hipErrorInvalidValue;
         }
         if (rc && decrypt == 2) (void)hipMemsetAsync(out, 0, len, st);   /* the chunk kernel may have been enqueued: see above */
         if (rc || !decrypt) return rc;
         if (decrypt == 1) return uaesk_ctr_xcrypt(stream, tb, nr, ek, &c, in, out, len, status);
-        int cus = 0;
-        if (uaesk_device_info(&cus, nullptr) != 0 || cus <= 0) cus = 64;
-        hipLaunchKernelGGL(k_wipe_if_failed, dim3((unsigned)cus * 2u), dim3(1024), 0, st, status, (unsigned char *)out, (u64)len);
-        rc = (int)hipGetLastError();
-        if (rc) (void)hipMemsetAsync(out, 0, len, st);
-        return rc;
+        return rc;                             /* mode 2: the combine kernel takes a forgery's plaintext back itself */
     }
     if (keyed && pl.logA == 0) {               /* every table this text needs is in the key context */
         switch (nr) {
@@ -2090,12 +2132,18 @@ extern "C" int uaesk_gcm_key_tables(void *stream, const uaesk_tables *tb, int nr
         if (((u64)1 << logF) != Sl || logF > GF_MAXLOG) logF = 0;
     }
     const uint4 z = make_uint4(0, 0, 0, 0);
+    int rc;
     switch (nr) {
-    case 10: return launch_setup<10>(st, tb, ek, z, sc, pl, 0, z, 1, logF);
-    case 12: return launch_setup<12>(st, tb, ek, z, sc, pl, 0, z, 1, logF);
-    case 14: return launch_setup<14>(st, tb, ek, z, sc, pl, 0, z, 1, logF);
+    case 10: rc = launch_setup<10>(st, tb, ek, z, sc, pl, 0, z, 1, logF); break;
+    case 12: rc = launch_setup<12>(st, tb, ek, z, sc, pl, 0, z, 1, logF); break;
+    case 14: rc = launch_setup<14>(st, tb, ek, z, sc, pl, 0, z, 1, logF); break;
     default: return (int)hipErrorInvalidValue;
     }
+    if (rc || !tb->frob) return rc;            /* (without the Frobenius matrices the chunk + combine path is not taken) */
+    hipError_t e = uaesk_want_lds((const void *)k_gcm_ytables, (unsigned)GHF_LDS);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k_gcm_ytables, dim3(2), dim3(GH_T), GHF_LDS, st, *tb, sc);
+    return (int)hipGetLastError();
 }
 
 extern "C" int uaesk_ghash(void *stream, const uaesk_tables *tb, const uint8_t *H_host,
