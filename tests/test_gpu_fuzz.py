@@ -368,3 +368,77 @@ def test_fuzz_gcm_one_pass_sizes(orc):
             got = uaes.AES_GCM_encrypt(key, nonce, aad, pt)
             want = orc.gcm_encrypt(key, nonce, aad, pt)
             assert got[-16:] == want[-16:] and got[:4096] == want[:4096] and got[-4096:] == want[-4096:], info
+
+
+def test_fuzz_gcm_record_calls(orc):
+    """uaes_gcm_key_{en,de}crypt_records against the oracle's AES_GCM_encrypt of every record by itself: random record
+    counts (more and fewer than one workgroup turn holds), record and AAD lengths across the kernel's arrangements,
+    shared or per-record AAD, strides with gaps, host or device buffers, in place; forged records keep the output's
+    guard bytes (N7) while their neighbours decrypt."""
+    import torch
+
+    def body(rnd, i):
+        bits = rnd.choice([128, 192, 256])
+        key = rnd.randbytes(bits // 8)
+        k = uaes.GcmKey(key)
+        try:
+            aad_len = rnd.choice([0, 0, 5, 13, 16, 17, rnd.randrange(0, 200)])
+            cap = k.record_max(aad_len)
+            rec_len = rnd.choice([rnd.randrange(0, 64), rnd.randrange(0, 1100), rnd.randrange(900, 2100), rnd.randrange(2000, 4200),
+                                  rnd.randrange(4000, 8300), rnd.randrange(8000, 16500), rnd.randrange(16000, cap + 1), cap,
+                                  16 * rnd.randrange(0, 64)])
+            nrec = rnd.choice([1, 2, rnd.randrange(1, 40), rnd.randrange(1, 40), rnd.randrange(200, 700)])
+            if rec_len > 9000:
+                nrec = min(nrec, 24)                        # the oracle takes ~1 ms per 16 KiB
+            stride = (rec_len + 16 + 15) // 16 * 16 + 16 * rnd.choice([0, 0, 1, 3, 16])
+            per_record_aad = aad_len > 0 and rnd.random() < 0.5
+            aad_stride = (aad_len + rnd.choice([0, 1, 7])) if per_record_aad else 0
+            nonces = rnd.randbytes(12 * nrec)
+            aad = rnd.randbytes(aad_stride * (nrec - 1) + aad_len if per_record_aad else aad_len)
+            plain = bytearray(rnd.randbytes(stride * nrec))
+            info = dict(seed_case=i, bits=bits, nrec=nrec, rec_len=rec_len, aad_len=aad_len, stride=stride, aad_stride=aad_stride)
+            want = [orc.gcm_encrypt(key, nonces[12 * r: 12 * r + 12], aad[aad_stride * r: aad_stride * r + aad_len],
+                                    bytes(plain[stride * r: stride * r + rec_len])) for r in range(nrec)]
+            L = uaes.engine()
+            u8 = lambda b: (C.c_uint8 * max(len(b), 1)).from_buffer_copy(bytes(b) if len(b) else b"\0")
+            on_device = rnd.random() < 0.5
+            if on_device:
+                dev = lambda b: torch.frombuffer(bytearray(b) if len(b) else bytearray(1), dtype=torch.uint8).to("cuda:0")
+                tn, ta, tp = dev(nonces), dev(aad), dev(plain)
+                out = tp if rnd.random() < 0.4 else torch.full((stride * nrec,), 0xA5, dtype=torch.uint8, device="cuda:0")
+                k.encrypt_records_dev(nrec, tn, ta if aad_len else None, aad_len, aad_stride, tp, rec_len, stride, out, stride)
+                torch.cuda.synchronize()
+                got = bytes(out.cpu().numpy())
+            else:
+                ob = (C.c_uint8 * (stride * nrec))()
+                C.memset(ob, 0xA5, stride * nrec)
+                rc = L.uaes_gcm_key_encrypt_records(k._h, nrec, u8(nonces), u8(aad) if aad_len else None, aad_len, aad_stride,
+                                                    u8(plain), rec_len, stride, ob, stride)
+                assert rc == 0, info
+                got = bytes(ob)
+            for r in range(nrec):
+                assert got[stride * r: stride * r + rec_len + 16] == want[r], (info, r)
+            # decrypt with some records forged
+            forged = set(rnd.sample(range(nrec), rnd.choice([0, 0, 1, min(nrec, 3)])))
+            ct = bytearray(stride * nrec)
+            for r in range(nrec):
+                rec = bytearray(want[r])
+                if r in forged:
+                    rec[rnd.randrange(len(rec))] ^= 1 << rnd.randrange(8)
+                ct[stride * r: stride * r + rec_len + 16] = rec
+            ob = (C.c_uint8 * (stride * nrec))()
+            C.memset(ob, 0xA5, stride * nrec)
+            ver = (C.c_uint8 * nrec)()
+            rc = L.uaes_gcm_key_decrypt_records(k._h, nrec, u8(nonces), u8(aad) if aad_len else None, aad_len, aad_stride,
+                                                u8(ct), rec_len, stride, ob, stride, ver)
+            assert rc == (0x1A if forged else 0), info
+            back = bytes(ob)
+            for r in range(nrec):
+                assert ver[r] == (0x1A if r in forged else 0), (info, r)
+                keep = b"\xa5" * rec_len if r in forged else bytes(plain[stride * r: stride * r + rec_len])
+                assert back[stride * r: stride * r + rec_len] == keep, (info, r)
+                assert back[stride * r + rec_len: stride * (r + 1)] == b"\xa5" * (stride - rec_len), (info, r)
+        finally:
+            k.close()
+
+    run_cases(909, 14, body)
