@@ -232,13 +232,20 @@ __device__ __forceinline__ void store_replicas(u32 byte_addr, u32 v)
 }
 
 /* Te_k[x] = rotl(Te0[x], 8k); Te0 bytes = {2S,S,S,3S} */
-__device__ __forceinline__ void fill_enc_tables(const u32 *__restrict__ te0)
+/* the share j = first, first + step, ... of the 8192 pieces (no barrier: a kernel whose first wave has something
+ * else to do meanwhile -- k_xts_small's tweak encryption -- lets the others fill) */
+__device__ __forceinline__ void fill_enc_tables_share(const u32 *__restrict__ te0, u32 first, u32 step)
 {
-    for (u32 j = threadIdx.x; j < 8192u; j += blockDim.x) {
+    for (u32 j = first; j < 8192u; j += step) {
         const u32 r = j & 7u, e = j >> 3, x = e & 255u, k = e >> 8;
         const u32 v = rotl32(te0[x], 8u * k);
         *(uint4 *)(uaes_lds + x * 256u + (k & 1u) * 128u + (k >> 1) * 65536u + 16u * r) = make_uint4(v, v, v, v);
     }
+}
+
+__device__ __forceinline__ void fill_enc_tables(const u32 *__restrict__ te0)
+{
+    fill_enc_tables_share(te0, threadIdx.x, blockDim.x);
     __syncthreads();
 }
 

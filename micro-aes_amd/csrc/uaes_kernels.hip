@@ -37,18 +37,27 @@ __global__ __launch_bounds__(UAES_WG) void k_ecb(uaesk_rk rk, uaesk_tables tb,
                                                  const uint4 *in, uint4 *out,
                                                  u64 nfull, u32 rem, u32 padding, uaesk_done done)
 {
+    /* the first pass's text is requested before the tables are made (see k_ctr) */
+    const u64 first = (u64)blockIdx.x * UAES_WG * U;
+    uint4 d0[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const u64 i0 = first + (u64)u * UAES_WG + threadIdx.x;
+        d0[u] = make_uint4(0, 0, 0, 0);
+        if (i0 < nfull) d0[u] = in[i0];
+    }
     if (DEC) fill_dec_tables(tb.td0); else fill_enc_tables(tb.te0);
     const LaneConst lc = make_lane_const();
     const u64 stride = (u64)gridDim.x * UAES_WG * U;
 
-    for (u64 base = (u64)blockIdx.x * UAES_WG * U; base < nfull; base += stride) {
+    for (u64 base = first; base < nfull; base += stride) {
         u32 s[U][4];
         u64 idx[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             idx[u] = base + (u64)u * UAES_WG + threadIdx.x;
-            uint4 d = make_uint4(0, 0, 0, 0);
-            if (idx[u] < nfull) d = in[idx[u]];
+            uint4 d = d0[u];
+            if (base != first && idx[u] < nfull) d = in[idx[u]];
             s[u][0] = d.x; s[u][1] = d.y; s[u][2] = d.z; s[u][3] = d.w;
         }
         if (DEC) {
@@ -97,19 +106,30 @@ __global__ __launch_bounds__(UAES_WG, 4) void k_ctr(uaesk_rk rk, uaesk_tables tb
                                                  u64 nfull, u32 rem, const int *__restrict__ gate, uaesk_done done)
 {
     if (gate && *gate != 0) { ticket_release(done); return; }      /* GCM decrypt: tag mismatch -> untouched */
+    /* the first pass's text is requested BEFORE the tables are made: a short call is this one pass, and the load
+     * (from the host's pinned window, across the link, for a host caller) then runs beside the 0.7 us of table stores
+     * instead of after them */
+    const u64 first = (u64)blockIdx.x * UAES_WG * U;
+    uint4 d0[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const u64 i0 = first + (u64)u * UAES_WG + threadIdx.x;
+        d0[u] = make_uint4(0, 0, 0, 0);
+        if (i0 < nfull) d0[u] = in[i0];
+    }
     fill_enc_tables(tb.te0);
     const LaneConst lc = make_lane_const();
     const u64 stride = (u64)gridDim.x * UAES_WG * U;
 
-    for (u64 base = (u64)blockIdx.x * UAES_WG * U; base < nfull; base += stride) {
+    for (u64 base = first; base < nfull; base += stride) {
         u32 s[U][4];
         uint4 d[U];
         u64 idx[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             idx[u] = base + (u64)u * UAES_WG + threadIdx.x;
-            d[u] = make_uint4(0, 0, 0, 0);
-            if (idx[u] < nfull) d[u] = in[idx[u]];
+            d[u] = d0[u];
+            if (base != first && idx[u] < nfull) d[u] = in[idx[u]];
             ctr_words(ctr, idx[u], s[u]);
         }
         if (U == 4) {                              /* two pairs, each half a round out of phase (as k_ecb) */
@@ -362,13 +382,17 @@ __global__ __launch_bounds__(UAES_WG) void k_xts(uaesk_rk k1, uaesk_tables tb,
     }
 }
 
-/* ONE short data unit (<= 4 chunks = 16 KiB: the reference API's call shape, a sector per call,
- * micro_aes.c:1066-1093): T0 = Enc_key2(tweak) is computed HERE instead of by the k_xts_tweaks pre-pass, so a
- * call is one launch (4 KiB: 28.3 -> 22.5 us).  Wave 0 encrypts the tweak through an unreplicated 1 KiB copy of Te0
- * behind the cipher tables (all lanes read the same entry: a broadcast, no conflicts; the decrypt direction has no
- * Te tables in LDS); then one block per lane.  The chunk tweaks T0 * alpha^(256 c) are also written to chunk_tw
- * for k_xts_cts.                                                                                              */
-#define XTS_SMALL_CHUNKS 4u          /* 1024 blocks: one per lane; longer units spread better over many CUs */
+/* ONE data unit of up to 64 chunks = 256 KiB (the reference API's call shape, a unit per call, micro_aes.c:1066-1093):
+ * T0 = Enc_key2(tweak) is computed HERE, by every workgroup for itself, instead of by the k_xts_tweaks pre-pass, so a
+ * call is one launch (4 KiB: 28.3 -> 22.5 us in round 2; 64 KiB 24 -> ?? us in round 3 when the kernel learnt to run
+ * on several workgroups, 1 MiB 20 -> ?? us).  Wave 0 encrypts the tweak through an unreplicated 1 KiB copy of Te0 behind the cipher
+ * tables (all lanes read the same entry: a broadcast, no conflicts; the decrypt direction has no Te tables in LDS)
+ * while the other waves fill the tables; then one block per lane: wave w of the grid takes the 64-block runs
+ * w, w + waves, ... of the unit, run q = 4c + k has the base tweak T0 * alpha^(256 c) * alpha^(64 k) (c = 64 g + l:
+ * k_xts_expand's arithmetic, a wave-wide product per set bit of g and the sparse shifts of tw_mul_a256 for l).  The chunk
+ * tweaks T0 * alpha^(256 c) are also written to chunk_tw for k_xts_cts.                                       */
+#define XTS_SMALL_CHUNKS 1024u       /* 4 MiB: every wave of 256 CUs still has one run; longer units take the pre-pass
+                                        and the bulk kernel (four blocks per lane, skewed pairs) */
 #define XTS_SMALL_LDS    (UAES_LDS_ENC + 1024u + 16u)
 
 template <int NR, bool DEC>
@@ -376,45 +400,55 @@ __global__ __launch_bounds__(UAES_WG) void k_xts_small(uaesk_rk k1, uaesk_rk k2,
                                                        uint4 raw_tweak, u32 use_raw, u64 sector_id,
                                                        uint4 *__restrict__ chunk_tw, u64 chunks,
                                                        u64 main_blocks, const unsigned char *in, unsigned char *out,
-                                                       uaesk_done done)
+                                                       uaesk_done done, XtsPow pw)
 {
     u32 *te_plain = (u32 *)(uaes_lds + UAES_LDS_ENC);
     uint4 *t0_slot = (uint4 *)(uaes_lds + UAES_LDS_ENC + 1024u);
-    if (threadIdx.x < 256) te_plain[threadIdx.x] = tb.te0[threadIdx.x];
-    if (DEC) fill_dec_tables(tb.td0); else fill_enc_tables(tb.te0);       /* ends with a barrier */
-    const LaneConst lc = make_lane_const();
     const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    if (wave == 0) {
+    const u32 run0 = blockIdx.x * (UAES_WG / 64u) + wave;            /* this wave's first run: its text is requested now */
+    uint4 d0 = make_uint4(0, 0, 0, 0);
+    if (64ull * run0 < main_blocks) {
+        const u64 b0 = 64ull * run0 + lane;
+        d0 = load16<true>(in + 16u * (b0 < main_blocks ? b0 : main_blocks - 1));
+    }
+    if (threadIdx.x >= blockDim.x - 256u) te_plain[threadIdx.x - (blockDim.x - 256u)] = tb.te0[threadIdx.x - (blockDim.x - 256u)];
+    __syncthreads();
+    if (wave == 0) {                                          /* the tweak's encryption, while the other waves fill the tables */
         u32 s[4];
         if (use_raw) { s[0] = raw_tweak.x; s[1] = raw_tweak.y; s[2] = raw_tweak.z; s[3] = raw_tweak.w; }
         else { s[0] = (u32)sector_id; s[1] = (u32)(sector_id >> 32); s[2] = 0; s[3] = 0; }   /* copyLint, micro_aes.c:399-404 */
         plain_encrypt<NR>(te_plain, k2, s);
         if (lane == 0) *t0_slot = make_uint4(s[0], s[1], s[2], s[3]);
+    } else {
+        fill_enc_tables_share(DEC ? tb.td0 : tb.te0, threadIdx.x - 64u, blockDim.x - 64u);
     }
+    const LaneConst lc = make_lane_const();
     __syncthreads();
     const uint4 t4 = *t0_slot;
-    Tw t;
-    t.lo = t4.x | ((u64)t4.y << 32);
-    t.hi = t4.z | ((u64)t4.w << 32);
-    /* thread i takes blocks i, i + 1024, ...: one block per lane spreads a 4 KiB unit over four waves (the
-     * latency of ONE block encryption instead of four in a row); 64-block run w + 16 u of the unit has the
-     * base tweak T0 * alpha^(64 (w + 16 u))                                                            */
-    for (u32 q = 0; q < wave; ++q) t = tw_mul_pow64(t);
-    for (u32 u = 0; u < 4; ++u) {
-        const u32 run = wave + 16u * u;                                  /* 64-block run of the unit */
-        if ((run & 3u) == 0 && (run >> 2) < chunks && lane == 0)        /* chunk tweaks for k_xts_cts */
-            chunk_tw[run >> 2] = make_uint4((u32)t.lo, (u32)(t.lo >> 32), (u32)t.hi, (u32)(t.hi >> 32));
+    Tw t0;
+    t0.lo = t4.x | ((u64)t4.y << 32);
+    t0.hi = t4.z | ((u64)t4.w << 32);
+    const u32 waves = gridDim.x * (UAES_WG / 64u);
+    const u64 runs = (main_blocks + 63) >> 6, heads = 4 * chunks;         /* runs with blocks / runs that may head a chunk */
+    for (u32 run = run0; run < runs || run < heads; run += waves) {       /* wave-uniform */
+        const u32 c = (u32)__builtin_amdgcn_readfirstlane((int)(run >> 2)), k = run & 3u;
+        Tw t = t0;
+        for (u32 i = 0; (c >> 6) >> i; ++i)                               /* chunk 64 g + l: alpha^(2^14 g) by the wave, */
+            if (((c >> 6) >> i) & 1) t = wave_tw_mul(t, pw.lo[i], pw.hi[i], lane);
+        if (c & 63u) t = tw_mul_a256(t, c & 63u);                          /* alpha^(256 l) by sparse shifts (uaes_gf.h)   */
+        for (u32 q = 0; q < k; ++q) t = tw_mul_pow64(t);
+        if (k == 0 && c < chunks && lane == 0)                          /* chunk tweaks for k_xts_cts */
+            chunk_tw[c] = make_uint4((u32)t.lo, (u32)(t.lo >> 32), (u32)t.hi, (u32)(t.hi >> 32));
+        if (run >= runs) continue;
         const u64 blk = 64ull * run + lane;
-        if (64ull * run >= main_blocks) break;                           /* wave-uniform */
         const Tw tl = tw_mul_pow(t, lane);
         const u32 tw[4] = { (u32)tl.lo, (u32)(tl.lo >> 32), (u32)tl.hi, (u32)(tl.hi >> 32) };
         const u64 bc = blk < main_blocks ? blk : main_blocks - 1;        /* clamped: no branch around the rounds */
-        const uint4 d = load16<true>(in + 16u * bc);
+        const uint4 d = run == run0 ? d0 : load16<true>(in + 16u * bc);
         u32 s[1][4] = { { d.x ^ tw[0], d.y ^ tw[1], d.z ^ tw[2], d.w ^ tw[3] } };
         if (DEC) dec_blocks<NR, 1>(s, k1, lc); else enc_blocks<NR, 1>(s, k1, lc);
         if (blk < main_blocks)
             store16<true>(out + 16u * blk, make_uint4(s[0][0] ^ tw[0], s[0][1] ^ tw[1], s[0][2] ^ tw[2], s[0][3] ^ tw[3]));
-        for (u32 q = 0; q < 16; ++q) t = tw_mul_pow64(t);               /* the next run of this wave */
     }
     ticket_release(done);
 }
@@ -765,9 +799,13 @@ static int launch_xts(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *k1
         if (e != hipSuccess) return (int)e;
         uaesk_done done = { nullptr, nullptr, 0 };
         if (!r) done = uaesk_ticket_take();                   /* no stealing kernel behind it: it carries the ticket */
-        hipLaunchKernelGGL((k_xts_small<NR, DEC>), dim3(1), dim3(UAES_WG), XTS_SMALL_LDS, st, *k1, *k2, *tb, raw,
+        /* a workgroup per 1024 blocks (one per lane), as many as half the CUs: a 64 KiB unit runs on four CUs at the
+         * latency of one block */
+        const u64 runs = (mb + 63) / 64;
+        const unsigned sgrid = grid_for(runs, UAES_WG / 64);
+        hipLaunchKernelGGL((k_xts_small<NR, DEC>), dim3(sgrid), dim3(UAES_WG), XTS_SMALL_LDS, st, *k1, *k2, *tb, raw,
                            (u32)(tweak16 != nullptr), first_sector, (uint4 *)scratch, cps, mb,
-                           (const unsigned char *)in, (unsigned char *)out, done);
+                           (const unsigned char *)in, (unsigned char *)out, done, *xts_pow_table());
         if (r)
             hipLaunchKernelGGL((k_xts_cts<NR, DEC>), dim3(1), dim3(UAES_WG), lds, st,
                                *k1, *tb, (const uint4 *)scratch, (u64)1, cps, mb, r, (u64)sector_bytes,
