@@ -976,6 +976,34 @@ __global__ __launch_bounds__(GH_T) void k_gcm_small(uaesk_rk rk, uaesk_tables tb
     SM_STAMP(0);
     uint4 *TC = (uint4 *)(uaes_lds + GSM_LDS_TAB);            /* the six nibble tables; TC[0..512) = H^1024 */
     uint4 *buf = TC + GT_NTAB * 512u;                         /* GT_BUF entries (the last three: H, Enc(J0), verdict) */
+    const u64 len = src.ct_len;
+    const u64 ablk = (src.aad_len + 15) >> 4, cblk = (len + 15) >> 4, nv = ablk + cblk + 1;
+    const u32 steps = nv + 2 > GH_T ? 2u : 1u;                /* pad >= 2 either way (nv <= 2046) */
+    const u64 pad = (u64)steps * GH_T - nv;
+    /* what this thread's positions READ (text, AAD, lengths) is requested before the tables are made: the loads -- across
+     * the link, for a host caller's pinned window -- then run beside 1.5-2 us of table stores instead of after them */
+    uint4 xk[2] = { make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0) };
+    bool is_text[2] = { false, false };
+    u64 ti[2] = { 0, 0 };
+    u32 tn[2] = { 0, 0 };
+#pragma unroll                                                /* constant indices: the per-step arrays stay in registers */
+    for (u32 k = 0; k < 2; ++k) {
+        if (k >= steps) break;
+        const u64 u = (u64)k * GH_T + threadIdx.x;
+        const bool live = u >= pad;
+        const u64 v = live ? u - pad : 0;
+        is_text[k] = live && v >= ablk && v < ablk + cblk;
+        if (is_text[k]) {
+            ti[k] = v - ablk;
+            const u64 avail = len - 16 * ti[k];
+            tn[k] = avail < 16 ? (u32)avail : 16u;
+            xk[k] = tn[k] == 16 ? in[ti[k]] : load_bytes_padded((const unsigned char *)(in + ti[k]), tn[k]);
+        } else if (live) {
+            GSrc rest = src;                                  /* AAD blocks and the length block */
+            rest.ct_len = 0;
+            xk[k] = load_vblock_fwd(rest, v < ablk ? v : ablk);
+        }
+    }
     if (!build) {
         const uint4 *g4 = (const uint4 *)(scratch + GS_TAB4);
         for (u32 i = threadIdx.x; i < GT_NTAB * 512u; i += GH_T) TC[i] = g4[i];
@@ -984,38 +1012,24 @@ __global__ __launch_bounds__(GH_T) void k_gcm_small(uaesk_rk rk, uaesk_tables tb
     SM_STAMP(1);
     const LaneConst2 lc = make_lane_const2(0);
 
-    const u64 len = src.ct_len;
-    const u64 ablk = (src.aad_len + 15) >> 4, cblk = (len + 15) >> 4, nv = ablk + cblk + 1;
-    const u32 steps = nv + 2 > GH_T ? 2u : 1u;                /* pad >= 2 either way (nv <= 2046) */
-    const u64 pad = (u64)steps * GH_T - nv;
-    uint4 xk[2] = { make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0) };
     uint4 hold[2];                                            /* decrypt: plaintext waiting for the verdict */
-    u64 hold_i[2];
-    u32 hold_n[2] = { 0, 0 };                                 /* bytes of it (0 = none) */
 #pragma unroll                                                /* constant indices: the per-step arrays stay in registers */
     for (u32 k = 0; k < 2; ++k) {
         if (k >= steps) break;
-        const u64 u = (u64)k * GH_T + threadIdx.x;
-        const bool live = u >= pad;
-        const u64 v = live ? u - pad : 0;
-        const bool is_text = live && v >= ablk && v < ablk + cblk;
         const bool is_j0 = k == 0 && threadIdx.x == 0;        /* positions 0 and 1 are padding */
         const bool is_h = k == 0 && threadIdx.x == 1;
-        const u64 i = is_text ? v - ablk : 0;
         u32 s1[1][4];
-        ctr_words(ctr, i, s1[0]);
+        ctr_words(ctr, ti[k], s1[0]);
         if (is_j0) { s1[0][0] = j0.x; s1[0][1] = j0.y; s1[0][2] = j0.z; s1[0][3] = j0.w; }
         if (is_h) { s1[0][0] = 0; s1[0][1] = 0; s1[0][2] = 0; s1[0][3] = 0; }
         /* a wave whose sixty-four positions are all padding, AAD or the length block has nothing to encrypt: a 4 KiB
          * text occupies five of the sixteen waves, and the LDS is what the block phase waits for (wave-uniform) */
-        if (__builtin_amdgcn_ballot_w64(is_text || is_j0 || is_h) != 0) enc_blocks<NR, 1>(s1, rk, lc);
+        if (__builtin_amdgcn_ballot_w64(is_text[k] || is_j0 || is_h) != 0) enc_blocks<NR, 1>(s1, rk, lc);
         if (is_j0) buf[GT_BUF - 2] = make_uint4(s1[0][0], s1[0][1], s1[0][2], s1[0][3]);
         if (is_h) buf[GT_BUF - 3] = make_uint4(s1[0][0], s1[0][1], s1[0][2], s1[0][3]);
-        uint4 x = make_uint4(0, 0, 0, 0);
-        if (is_text) {
-            const u64 avail = len - 16 * i;
-            const u32 nb = avail < 16 ? (u32)avail : 16u;
-            const uint4 d = nb == 16 ? in[i] : load_bytes_padded((const unsigned char *)(in + i), nb);
+        if (is_text[k]) {
+            const uint4 d = xk[k];
+            const u32 nb = tn[k];
             u32 o[4] = { d.x ^ s1[0][0], d.y ^ s1[0][1], d.z ^ s1[0][2], d.w ^ s1[0][3] };
             if (nb < 16) {                                    /* the keystream beyond the text is not part of it (N3) */
 #pragma unroll
@@ -1025,21 +1039,18 @@ __global__ __launch_bounds__(GH_T) void k_gcm_small(uaesk_rk rk, uaesk_tables tb
                 }
             }
             const uint4 ov = make_uint4(o[0], o[1], o[2], o[3]);
-            x = DEC ? d : ov;                                 /* GHASH takes the ciphertext, zero padded (N6) */
             if (DEC) {
-                hold[k] = ov; hold_i[k] = i; hold_n[k] = nb;
-            } else if (nb == 16) {
-                out[i] = ov;
+                hold[k] = ov;                                 /* GHASH takes the ciphertext read, zero padded (N6): xk[k] stays */
             } else {
-                unsigned char *dst = (unsigned char *)(out + i);
-                for (u32 b = 0; b < nb; ++b) dst[b] = (unsigned char)(o[b >> 2] >> (8 * (b & 3)));
+                xk[k] = ov;
+                if (nb == 16) {
+                    out[ti[k]] = ov;
+                } else {
+                    unsigned char *dst = (unsigned char *)(out + ti[k]);
+                    for (u32 b = 0; b < nb; ++b) dst[b] = (unsigned char)(o[b >> 2] >> (8 * (b & 3)));
+                }
             }
-        } else if (live) {
-            GSrc rest = src;                                  /* AAD blocks and the length block */
-            rest.ct_len = 0;
-            x = load_vblock_fwd(rest, v < ablk ? v : ablk);
         }
-        xk[k] = x;
     }
     SM_STAMP(2);
     if (build) {
@@ -1069,12 +1080,13 @@ __global__ __launch_bounds__(GH_T) void k_gcm_small(uaesk_rk rk, uaesk_tables tb
         if (buf[GT_BUF - 1].x == 0) {
 #pragma unroll
             for (u32 k = 0; k < 2; ++k) {
-                if (hold_n[k] == 16) {
-                    out[hold_i[k]] = hold[k];
-                } else if (hold_n[k]) {
+                if (!is_text[k]) continue;
+                if (tn[k] == 16) {
+                    out[ti[k]] = hold[k];
+                } else {
                     const u32 o[4] = { hold[k].x, hold[k].y, hold[k].z, hold[k].w };
-                    unsigned char *dst = (unsigned char *)(out + hold_i[k]);
-                    for (u32 b = 0; b < hold_n[k]; ++b) dst[b] = (unsigned char)(o[b >> 2] >> (8 * (b & 3)));
+                    unsigned char *dst = (unsigned char *)(out + ti[k]);
+                    for (u32 b = 0; b < tn[k]; ++b) dst[b] = (unsigned char)(o[b >> 2] >> (8 * (b & 3)));
                 }
             }
         }
