@@ -904,7 +904,7 @@ template <bool YPOW = false>
 __device__ __forceinline__ void gcm_build_nibble_tables(uint4 *TC, uint4 *buf, const uint64_t *__restrict__ frob, u32 ylog = 11)
 {
     Gf *shPow = (Gf *)buf;                         /* 6 powers                  */
-    Gf *shGen = (Gf *)(buf + 16);                  /* 6 x 128 generators: 12 KiB */
+    Gf *shGen = (Gf *)(buf + 16);                  /* 6 x 128 generators, one slot of skew per eight: 13.5 KiB */
     const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     if (wave < GT_NTAB && !(YPOW && wave < 1)) {
         const u32 k = YPOW ? ylog + 10u - 2u * wave : 10u - 2u * wave;   /* Y = H^(2^ylog): chunks of 2048 or 1024 positions */
@@ -920,21 +920,27 @@ __device__ __forceinline__ void gcm_build_nibble_tables(uint4 *TC, uint4 *buf, c
         if (lane == 0) shPow[wave] = pw;
     }
     __syncthreads();
-    for (u32 idx = threadIdx.x; idx < GT_NTAB * 128u; idx += GH_T) shGen[idx] = gf_mul_xq128(shPow[idx >> 7], idx & 127u);
+    /* (generator g sits at slot g + g / 8: the lanes of the loop below read generators eight apart, 128 bytes, which
+     * without the skew are two bank sets for sixteen lanes) */
+    for (u32 idx = threadIdx.x; idx < GT_NTAB * 128u; idx += GH_T) shGen[idx + (idx >> 3)] = gf_mul_xq128(shPow[idx >> 7], idx & 127u);
     __syncthreads();
     for (u32 e = threadIdx.x; e < GT_NTAB * 512u; e += GH_T) {
-        const u32 t = e >> 9, p = (e >> 4) & 31u, v = e & 15u;
-        const Gf *gen = shGen + 128u * t;
+        /* e IS the entry's place in its table (nib_entry: 32 v + slot): neighbouring lanes store neighbouring 16-byte
+         * slots.  (Counting e = 16 p + v instead put the eight lanes of a store group 512 bytes apart: an 8-way bank
+         * conflict on every one of the 3072 stores, ~2 us of the 4.5 us this function took.) */
+        const u32 t = e >> 9, v = (e >> 5) & 15u, sl = e & 31u, p = sl < 16u ? 2u * sl : 2u * (sl - 16u) + 1u;
+        const u32 g0 = 128u * t + 4u * p;                     /* four generators, never across a multiple of eight */
+        const Gf *gen = shGen + g0 + (g0 >> 3);
         Gf x = { 0, 0 };
 #pragma unroll
         for (u32 i = 0; i < 4; ++i) {
             const u64 m = 0 - (u64)((v >> (3 - i)) & 1u);
-            x.hi ^= gen[4 * p + i].hi & m;
-            x.lo ^= gen[4 * p + i].lo & m;
+            x.hi ^= gen[i].hi & m;
+            x.lo ^= gen[i].lo & m;
         }
         u32 w[4];
         gf_to_words(x, w);
-        TC[512u * t + nib_entry(p, v)] = make_uint4(w[0], w[1], w[2], w[3]);
+        TC[e] = make_uint4(w[0], w[1], w[2], w[3]);           /* = TC[512 t + nib_entry(p, v)] */
     }
     __syncthreads();
 }
