@@ -307,7 +307,10 @@ def test_xts_long_data_units(orc, bits):
     """one data unit of many 256-block chunks (the reference API is one unit per call): the chunk
     tweaks come from the parallel expansion, not from walking the unit"""
     rnd = random.Random(bits + 9)
-    for n in [9 * 4096, 64 * 4096, 65 * 4096 + 16, (1 << 20) + 33, (4 << 20) + 4096 * 63 + 17, 16 << 20]:
+    # (a unit of up to 1024 chunks = 4 MiB is ONE launch, k_xts_small on many workgroups: both sides of that line, of the
+    # 64-chunk range of the sparse-shift product and of a workgroup's 1024 blocks, whole and with a stolen tail)
+    for n in [9 * 4096, 64 * 4096, 65 * 4096 + 16, 16384 - 16, 16384 + 16, 256 * 1024 - 16, 256 * 1024, 256 * 1024 + 16 + 5,
+              (1 << 20) + 33, (4 << 20) - 16, 4 << 20, (4 << 20) + 3, (4 << 20) + 16, (4 << 20) + 4096 * 63 + 17, 16 << 20]:
         keys, tweak = rnd.randbytes(bits // 4), rnd.randbytes(16)
         data = orc.splitmix(n + 13, n)
         rc, ct = uaes.AES_XTS_encrypt(keys, tweak, data)
