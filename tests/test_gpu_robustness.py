@@ -94,6 +94,40 @@ def test_concurrent_host_threads(orc):
     assert not errors
 
 
+def test_record_calls_from_several_threads_share_one_key_context(orc):
+    """uaes_gcm_key_*_records only READS the context's tables: six host threads run record calls of different shapes on
+    ONE context at the same time (each on its own lane: stream, stagings), every record against the oracle"""
+    rnd = random.Random(61)
+    key = rnd.randbytes(16)
+    k = uaes.GcmKey(key)
+    jobs = []
+    for t in range(6):
+        nrec, rec_len = [(40, 100), (9, 5000), (300, 48), (3, 20000), (64, 1440), (17, 4096)][t]
+        nonces = [rnd.randbytes(12) for _ in range(nrec)]
+        recs = [rnd.randbytes(rec_len) for _ in range(nrec)]
+        aad = rnd.randbytes(t * 3)
+        jobs.append((nonces, aad, recs, [orc.gcm_encrypt(key, nonces[r], aad, recs[r]) for r in range(nrec)]))
+    errors = []
+
+    def work(job):
+        nonces, aad, recs, want = job
+        for _ in range(4):
+            got = k.encrypt_records(nonces, aad, recs)
+            if got != want:
+                errors.append("encrypt")
+            rc, ver, back = k.decrypt_records(nonces, aad, got)
+            if rc != 0 or any(ver) or back != recs:
+                errors.append("decrypt")
+
+    threads = [threading.Thread(target=work, args=(j,)) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    k.close()
+    assert not errors
+
+
 def test_completion_tickets_and_the_plain_wait_agree(orc):
     """a synchronous call ends with a completion ticket: carried by the call's only kernel (ECB,
     short CTR, a one-launch XTS unit, a one-launch GCM encryption), by the ticket kernel behind a multi-launch call,
