@@ -1769,7 +1769,8 @@ static int records_args_ok(size_t nrec, const void *nonces, const void *aad, siz
                     rec_len, aad_len, uaesk_gcm_record_max(aad_len));
     if ((in_stride | out_stride) & 15u) return fail(UAES_E_ARG, "record strides must be multiples of 16");
     if (in_stride < in_min || out_stride < out_min) return fail(UAES_E_ARG, "record stride shorter than a record");
-    if (nrec > (size_t)1 << 40) return fail(UAES_E_ARG, "too many records");
+    if (nrec > (size_t)1 << 40 || in_stride > (size_t)1 << 22 || out_stride > (size_t)1 << 22)
+        return fail(UAES_E_ARG, "too many records / record stride too long");     /* spans stay far below 2^64 */
     return 0;
 }
 
