@@ -233,33 +233,34 @@ __device__ __forceinline__ void store_replicas(u32 byte_addr, u32 v)
 
 /* Te_k[x] = rotl(Te0[x], 8k); Te0 bytes = {2S,S,S,3S} */
 /* the share j = first, first + step, ... of the 8192 pieces (no barrier: a kernel whose first wave has something
- * else to do meanwhile -- k_xts_small's tweak encryption -- lets the others fill) */
+ * else to do meanwhile -- k_xts_small's tweak encryption -- lets the others fill).  Eight pieces at a time: their eight
+ * table words are requested before the first is used -- a loop that loads, rotates and stores piece by piece waits for
+ * every load where it is issued, one cache round trip per piece (32 in a row for the 256-thread workgroups of the
+ * short XTS / OCB launches: ~4 us before the first block) */
 __device__ __forceinline__ void fill_enc_tables_share(const u32 *__restrict__ te0, u32 first, u32 step)
 {
-    for (u32 j = first; j < 8192u; j += step) {
-        const u32 r = j & 7u, e = j >> 3, x = e & 255u, k = e >> 8;
-        const u32 v = rotl32(te0[x], 8u * k);
-        *(uint4 *)(uaes_lds + x * 256u + (k & 1u) * 128u + (k >> 1) * 65536u + 16u * r) = make_uint4(v, v, v, v);
+    for (u32 j0 = first; j0 < 8192u; j0 += 8u * step) {
+        u32 t[8];
+#pragma unroll
+        for (u32 k = 0; k < 8; ++k) {
+            const u32 j = j0 + k * step;
+            t[k] = te0[((j < 8192u ? j : 0u) >> 3) & 255u];
+        }
+#pragma unroll
+        for (u32 k = 0; k < 8; ++k) {
+            const u32 j = j0 + k * step;
+            if (j < 8192u) {
+                const u32 r = j & 7u, e = j >> 3, x = e & 255u, kk = e >> 8;
+                const u32 v = rotl32(t[k], 8u * kk);
+                *(uint4 *)(uaes_lds + x * 256u + (kk & 1u) * 128u + (kk >> 1) * 65536u + 16u * r) = make_uint4(v, v, v, v);
+            }
+        }
     }
 }
 
 __device__ __forceinline__ void fill_enc_tables(const u32 *__restrict__ te0)
 {
-    if (blockDim.x == 1024u) {
-        /* the usual shape: eight pieces per thread -- all eight table words are requested before the first is used
-         * (one trip to the cache instead of eight in a row: the loop below waits for every load where it is issued) */
-        u32 t[8];
-#pragma unroll
-        for (u32 k = 0; k < 8; ++k) t[k] = te0[((threadIdx.x + 1024u * k) >> 3) & 255u];
-#pragma unroll
-        for (u32 k = 0; k < 8; ++k) {
-            const u32 j = threadIdx.x + 1024u * k, r = j & 7u, e = j >> 3, x = e & 255u, kk = e >> 8;
-            const u32 v = rotl32(t[k], 8u * kk);
-            *(uint4 *)(uaes_lds + x * 256u + (kk & 1u) * 128u + (kk >> 1) * 65536u + 16u * r) = make_uint4(v, v, v, v);
-        }
-    } else {
-        fill_enc_tables_share(te0, threadIdx.x, blockDim.x);
-    }
+    fill_enc_tables_share(te0, threadIdx.x, blockDim.x);
     __syncthreads();
 }
 
@@ -267,21 +268,21 @@ __device__ __forceinline__ void fill_enc_tables(const u32 *__restrict__ te0)
  * (Te0 | Te2 | Te1 | Te3): sixteen lanes write the row's sixteen 16-byte pieces                          */
 __device__ __forceinline__ void fill_tables64(const u32 *__restrict__ t0, u32 base = 0)
 {
-    if (blockDim.x == 1024u) {                     /* four pieces per thread, their table words requested together */
+    for (u32 j0 = threadIdx.x; j0 < 4096u; j0 += 4u * blockDim.x) {       /* four pieces at a time, their table words first */
         u32 t[4];
 #pragma unroll
-        for (u32 k = 0; k < 4; ++k) t[k] = t0[(threadIdx.x + 1024u * k) >> 4];
+        for (u32 k = 0; k < 4; ++k) {
+            const u32 j = j0 + k * blockDim.x;
+            t[k] = t0[(j < 4096u ? j : 0u) >> 4];
+        }
 #pragma unroll
         for (u32 k = 0; k < 4; ++k) {
-            const u32 j = threadIdx.x + 1024u * k, p = j & 15u, x = j >> 4, q = p >> 2, kk = (q >> 1) | ((q & 1u) << 1);
-            const u32 v = rotl32(t[k], 8u * kk);
-            *(uint4 *)(uaes_lds + base + x * 256u + 16u * p) = make_uint4(v, v, v, v);
-        }
-    } else {
-        for (u32 j = threadIdx.x; j < 4096u; j += blockDim.x) {
-            const u32 p = j & 15u, x = j >> 4, q = p >> 2, k = (q >> 1) | ((q & 1u) << 1);
-            const u32 v = rotl32(t0[x], 8u * k);
-            *(uint4 *)(uaes_lds + base + x * 256u + 16u * p) = make_uint4(v, v, v, v);
+            const u32 j = j0 + k * blockDim.x;
+            if (j < 4096u) {
+                const u32 p = j & 15u, x = j >> 4, q = p >> 2, kk = (q >> 1) | ((q & 1u) << 1);
+                const u32 v = rotl32(t[k], 8u * kk);
+                *(uint4 *)(uaes_lds + base + x * 256u + 16u * p) = make_uint4(v, v, v, v);
+            }
         }
     }
     __syncthreads();
@@ -639,24 +640,24 @@ struct RowLane {
 
 __device__ __forceinline__ void row_fill_tables(const u32 *__restrict__ te0, const uaesk_rk &rk)
 {
-    /* eight lanes per entry: the 128 bytes of an entry are eight 16-byte pieces (bank-conflict-free stores) */
-    if (blockDim.x == 64u) {
-        /* the chain kernels' one wave: 32 pieces per lane, and a loop that loads a table word, rotates and stores it
-         * waits for 32 cache round trips in a row (~4 us of a 7 us CMAC call) -- all 32 words are requested first */
-        u32 t[32];
+    /* eight lanes per entry: the 128 bytes of an entry are eight 16-byte pieces (bank-conflict-free stores).
+     * The chain kernels' one wave has 32 pieces per lane, and a loop that loads a table word, rotates and stores it
+     * waits for 32 cache round trips in a row (~4 us of a 7 us CMAC call): sixteen words are requested at a time */
+    for (u32 j0 = threadIdx.x; j0 < 2048u; j0 += 16u * blockDim.x) {
+        u32 t[16];
 #pragma unroll
-        for (u32 k = 0; k < 32; ++k) t[k] = te0[(threadIdx.x >> 3) + 8u * k];
-#pragma unroll
-        for (u32 k = 0; k < 32; ++k) {
-            const u32 q = threadIdx.x & 7u, x = (threadIdx.x >> 3) + 8u * k;
-            const u32 t0 = t[k], t1 = rotl32(t0, 8), t2 = rotl32(t0, 16), t3 = rotl32(t0, 24);
-            *(uint4 *)(uaes_lds + x * 256u + 16u * q) = q < 4u ? make_uint4(t0, t1, t2, t3) : make_uint4(t2, t3, t0, t1);
+        for (u32 k = 0; k < 16; ++k) {
+            const u32 j = j0 + k * blockDim.x;
+            t[k] = te0[(j < 2048u ? j : 0u) >> 3];
         }
-    } else {
-        for (u32 j = threadIdx.x; j < 2048u; j += blockDim.x) {
-            const u32 q = j & 7u, x = j >> 3;
-            const u32 t0 = te0[x], t1 = rotl32(t0, 8), t2 = rotl32(t0, 16), t3 = rotl32(t0, 24);
-            *(uint4 *)(uaes_lds + x * 256u + 16u * q) = q < 4u ? make_uint4(t0, t1, t2, t3) : make_uint4(t2, t3, t0, t1);
+#pragma unroll
+        for (u32 k = 0; k < 16; ++k) {
+            const u32 j = j0 + k * blockDim.x;
+            if (j < 2048u) {
+                const u32 q = j & 7u, x = j >> 3;
+                const u32 t0 = t[k], t1 = rotl32(t0, 8), t2 = rotl32(t0, 16), t3 = rotl32(t0, 24);
+                *(uint4 *)(uaes_lds + x * 256u + 16u * q) = q < 4u ? make_uint4(t0, t1, t2, t3) : make_uint4(t2, t3, t0, t1);
+            }
         }
     }
     for (u32 i = threadIdx.x; i < 60u; i += blockDim.x) ((u32 *)(uaes_lds + 65536u))[i] = rk.w[i];
