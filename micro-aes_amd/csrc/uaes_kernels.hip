@@ -400,55 +400,76 @@ __global__ __launch_bounds__(UAES_WG) void k_xts_small(uaesk_rk k1, uaesk_rk k2,
                                                        uint4 raw_tweak, u32 use_raw, u64 sector_id,
                                                        uint4 *__restrict__ chunk_tw, u64 chunks,
                                                        u64 main_blocks, const unsigned char *in, unsigned char *out,
-                                                       uaesk_done done, XtsPow pw)
+                                                       uaesk_done done, XtsPow pw, u64 nsectors, u64 sector_bytes)
 {
+    /* nsectors == 1: the one unit described above.  nsectors > 1 (units of a multiple of 16 bytes, tweak = the unit's
+     * number: a 64 KiB write to a disk of 4 KiB sectors): the same kernel with one more level -- run R of the call is
+     * run R % rps of unit R / rps, and every WAVE encrypts the tweak of the unit its run lies in by itself (no
+     * k_xts_tweaks pre-pass for a call of a few hundred units either) */
     u32 *te_plain = (u32 *)(uaes_lds + UAES_LDS_ENC);
     uint4 *t0_slot = (uint4 *)(uaes_lds + UAES_LDS_ENC + 1024u);
     const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const u32 run0 = blockIdx.x * (UAES_WG / 64u) + wave;            /* this wave's first run: its text is requested now */
+    const u64 runs_per_unit = (main_blocks + 63) >> 6, heads = 4 * chunks;   /* runs with blocks / runs that may head a chunk */
+    const u64 rps = nsectors > 1 ? runs_per_unit : (runs_per_unit > heads ? runs_per_unit : heads);
+    const u64 total = rps * nsectors;
+    const u64 run0 = (u64)blockIdx.x * (UAES_WG / 64u) + wave;       /* this wave's first run: its text is requested now */
     uint4 d0 = make_uint4(0, 0, 0, 0);
-    if (64ull * run0 < main_blocks) {
-        const u64 b0 = 64ull * run0 + lane;
-        d0 = load16<true>(in + 16u * (b0 < main_blocks ? b0 : main_blocks - 1));
+    if (run0 < total) {
+        const u64 u0 = run0 / rps, r0 = run0 - u0 * rps;
+        if (64ull * r0 < main_blocks) {
+            const u64 b0 = 64ull * r0 + lane;
+            d0 = load16<true>(in + u0 * sector_bytes + 16u * (b0 < main_blocks ? b0 : main_blocks - 1));
+        }
     }
     if (threadIdx.x >= blockDim.x - 256u) te_plain[threadIdx.x - (blockDim.x - 256u)] = tb.te0[threadIdx.x - (blockDim.x - 256u)];
     __syncthreads();
-    if (wave == 0) {                                          /* the tweak's encryption, while the other waves fill the tables */
+    if (wave == 0 && nsectors == 1) {                         /* the tweak's encryption, while the other waves fill the tables */
         u32 s[4];
         if (use_raw) { s[0] = raw_tweak.x; s[1] = raw_tweak.y; s[2] = raw_tweak.z; s[3] = raw_tweak.w; }
         else { s[0] = (u32)sector_id; s[1] = (u32)(sector_id >> 32); s[2] = 0; s[3] = 0; }   /* copyLint, micro_aes.c:399-404 */
         plain_encrypt<NR>(te_plain, k2, s);
         if (lane == 0) *t0_slot = make_uint4(s[0], s[1], s[2], s[3]);
-    } else {
+    } else if (nsectors == 1) {
         fill_enc_tables_share(DEC ? tb.td0 : tb.te0, threadIdx.x - 64u, blockDim.x - 64u);
+    } else {
+        fill_enc_tables_share(DEC ? tb.td0 : tb.te0, threadIdx.x, blockDim.x);
     }
     const LaneConst lc = make_lane_const();
     __syncthreads();
-    const uint4 t4 = *t0_slot;
-    Tw t0;
-    t0.lo = t4.x | ((u64)t4.y << 32);
-    t0.hi = t4.z | ((u64)t4.w << 32);
-    const u32 waves = gridDim.x * (UAES_WG / 64u);
-    const u64 runs = (main_blocks + 63) >> 6, heads = 4 * chunks;         /* runs with blocks / runs that may head a chunk */
-    for (u32 run = run0; run < runs || run < heads; run += waves) {       /* wave-uniform */
-        const u32 c = (u32)__builtin_amdgcn_readfirstlane((int)(run >> 2)), k = run & 3u;
-        Tw t = t0;
+    const u64 waves = (u64)gridDim.x * (UAES_WG / 64u);
+    for (u64 run = run0; run < total; run += waves) {                     /* wave-uniform */
+        const u64 unit = run / rps, ru = run - unit * rps;
+        Tw t;
+        if (nsectors == 1) {
+            const uint4 t4 = *t0_slot;
+            t.lo = t4.x | ((u64)t4.y << 32);
+            t.hi = t4.z | ((u64)t4.w << 32);
+        } else {                                                          /* T0 of this run's unit, by this wave */
+            const u64 sid = sector_id + unit;
+            u32 s[4] = { (u32)sid, (u32)(sid >> 32), 0, 0 };
+            plain_encrypt<NR>(te_plain, k2, s);
+            t.lo = s[0] | ((u64)s[1] << 32);
+            t.hi = s[2] | ((u64)s[3] << 32);
+        }
+        const u32 c = (u32)__builtin_amdgcn_readfirstlane((int)(ru >> 2)), k = (u32)ru & 3u;
         for (u32 i = 0; (c >> 6) >> i; ++i)                               /* chunk 64 g + l: alpha^(2^14 g) by the wave, */
             if (((c >> 6) >> i) & 1) t = wave_tw_mul(t, pw.lo[i], pw.hi[i], lane);
         if (c & 63u) t = tw_mul_a256(t, c & 63u);                          /* alpha^(256 l) by sparse shifts (uaes_gf.h)   */
         for (u32 q = 0; q < k; ++q) t = tw_mul_pow64(t);
-        if (k == 0 && c < chunks && lane == 0)                          /* chunk tweaks for k_xts_cts */
+        if (nsectors == 1 && k == 0 && c < chunks && lane == 0)          /* chunk tweaks for k_xts_cts */
             chunk_tw[c] = make_uint4((u32)t.lo, (u32)(t.lo >> 32), (u32)t.hi, (u32)(t.hi >> 32));
-        if (run >= runs) continue;
-        const u64 blk = 64ull * run + lane;
+        if (64ull * ru >= main_blocks) continue;
+        const u64 blk = 64ull * ru + lane;
         const Tw tl = tw_mul_pow(t, lane);
         const u32 tw[4] = { (u32)tl.lo, (u32)(tl.lo >> 32), (u32)tl.hi, (u32)(tl.hi >> 32) };
         const u64 bc = blk < main_blocks ? blk : main_blocks - 1;        /* clamped: no branch around the rounds */
-        const uint4 d = run == run0 ? d0 : load16<true>(in + 16u * bc);
+        const unsigned char *src = in + unit * sector_bytes;
+        const uint4 d = run == run0 ? d0 : load16<true>(src + 16u * bc);
         u32 s[1][4] = { { d.x ^ tw[0], d.y ^ tw[1], d.z ^ tw[2], d.w ^ tw[3] } };
         if (DEC) dec_blocks<NR, 1>(s, k1, lc); else enc_blocks<NR, 1>(s, k1, lc);
         if (blk < main_blocks)
-            store16<true>(out + 16u * blk, make_uint4(s[0][0] ^ tw[0], s[0][1] ^ tw[1], s[0][2] ^ tw[2], s[0][3] ^ tw[3]));
+            store16<true>(out + unit * sector_bytes + 16u * blk,
+                          make_uint4(s[0][0] ^ tw[0], s[0][1] ^ tw[1], s[0][2] ^ tw[2], s[0][3] ^ tw[3]));
     }
     ticket_release(done);
 }
@@ -794,18 +815,23 @@ static int launch_xts(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *k1
 
     uint4 raw = make_uint4(0, 0, 0, 0);
     if (tweak16) memcpy(&raw, tweak16, 16);
-    if (nsectors == 1 && mb > 0 && cps <= XTS_SMALL_CHUNKS) {         /* one short unit: one launch (k_xts_small) */
+    /* one unit of up to 4 MiB, or up to 4 MiB of whole-block units numbered from first_sector: one launch (k_xts_small) */
+    const bool one_unit = nsectors == 1 && mb > 0 && cps <= XTS_SMALL_CHUNKS;
+    const bool few_units = nsectors > 1 && !tweak16 && r == 0 && mb > 0 &&
+                           (u64)nsectors * ((mb + 63) / 64) <= 4ull * XTS_SMALL_CHUNKS;
+    if (one_unit || few_units) {
         e = set_lds((k_xts_small<NR, DEC>), XTS_SMALL_LDS);
         if (e != hipSuccess) return (int)e;
         uaesk_done done = { nullptr, nullptr, 0 };
         if (!r) done = uaesk_ticket_take();                   /* no stealing kernel behind it: it carries the ticket */
         /* a workgroup per 1024 blocks (one per lane), as many as half the CUs: a 64 KiB unit runs on four CUs at the
          * latency of one block */
-        const u64 runs = (mb + 63) / 64;
+        const u64 runs = (u64)nsectors * ((mb + 63) / 64);
         const unsigned sgrid = grid_for(runs, UAES_WG / 64);
         hipLaunchKernelGGL((k_xts_small<NR, DEC>), dim3(sgrid), dim3(UAES_WG), XTS_SMALL_LDS, st, *k1, *k2, *tb, raw,
                            (u32)(tweak16 != nullptr), first_sector, (uint4 *)scratch, cps, mb,
-                           (const unsigned char *)in, (unsigned char *)out, done, *xts_pow_table());
+                           (const unsigned char *)in, (unsigned char *)out, done, *xts_pow_table(), (u64)nsectors,
+                           (u64)sector_bytes);
         if (r)
             hipLaunchKernelGGL((k_xts_cts<NR, DEC>), dim3(1), dim3(UAES_WG), lds, st,
                                *k1, *tb, (const uint4 *)scratch, (u64)1, cps, mb, r, (u64)sector_bytes,

@@ -556,8 +556,12 @@ def test_xts_vs_oracle(orc, bits):
     keys = rnd.randbytes(bits // 4)
     assert uaes.AES_XTS_encrypt(keys, None, b"Q" * 48) == uaes.AES_XTS_encrypt(keys, bytes(16), b"Q" * 48)
     # batched data units, including ciphertext stealing in every unit
+    # (up to 4 MiB of whole-block units is ONE launch in which every wave encrypts its unit's tweak itself; beyond
+    # that, and for ragged units, the tweak pre-pass: both, on both sides of the limit)
     for sector, count, first in [(4096, 33, 0), (512, 100, (1 << 40) + 7), (528, 9, 5), (16, 70, 1), (25, 40, 2),
-                                 (4096, 1, (1 << 63) + 12345), (4100, 1, 77), (16384, 1, 3)]:      # one unit by sector id
+                                 (4096, 1, (1 << 63) + 12345), (4100, 1, 77), (16384, 1, 3),       # one unit by sector id
+                                 (4096, 1024, (1 << 32) - 5), (4096, 1025, 9), (48, 1300, 0), (1024 + 16, 61, 3),
+                                 (65536, 2, 0xFFFFFFFFFFFFFFFE), (1 << 20, 5, 11), (32, 2, 0)]:
         vol = orc.splitmix(sector, sector * count)
         rc, ct = uaes.xts_sectors(keys, first, sector, vol, True)
         assert (rc, ct) == orc.xts_sectors(keys, first, sector, vol, True)
