@@ -395,7 +395,9 @@ __global__ __launch_bounds__(UAES_WG) void k_xts(uaesk_rk k1, uaesk_tables tb,
                                         and the bulk kernel (four blocks per lane, skewed pairs) */
 #define XTS_SMALL_LDS    (UAES_LDS_ENC + 1024u + 16u)
 
-template <int NR, bool DEC>
+/* MULTI: several units per call (a compile-time split: with both shapes in one kernel the tweak key stays live in the
+ * loop beside the data key and the power table, and 85 scalar registers spill into the hot path of the one-unit call) */
+template <int NR, bool DEC, bool MULTI>
 __global__ __launch_bounds__(UAES_WG) void k_xts_small(uaesk_rk k1, uaesk_rk k2, uaesk_tables tb,
                                                        uint4 raw_tweak, u32 use_raw, u64 sector_id,
                                                        uint4 *__restrict__ chunk_tw, u64 chunks,
@@ -409,38 +411,40 @@ __global__ __launch_bounds__(UAES_WG) void k_xts_small(uaesk_rk k1, uaesk_rk k2,
     u32 *te_plain = (u32 *)(uaes_lds + UAES_LDS_ENC);
     uint4 *t0_slot = (uint4 *)(uaes_lds + UAES_LDS_ENC + 1024u);
     const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const u64 runs_per_unit = (main_blocks + 63) >> 6, heads = 4 * chunks;   /* runs with blocks / runs that may head a chunk */
-    const u64 rps = nsectors > 1 ? runs_per_unit : (runs_per_unit > heads ? runs_per_unit : heads);
-    const u64 total = rps * nsectors;
-    const u64 run0 = (u64)blockIdx.x * (UAES_WG / 64u) + wave;       /* this wave's first run: its text is requested now */
+    /* (run counts fit 32 bits by far -- launch_xts: at most 4 * XTS_SMALL_CHUNKS runs with blocks -- and one unit needs
+     * no division at all: a 64-bit division is ~1.5 us of a lone wave) */
+    const u32 runs_per_unit = (u32)((main_blocks + 63) >> 6), heads = (u32)(4 * chunks);   /* runs with blocks / runs that may head a chunk */
+    const u32 rps = MULTI ? runs_per_unit : (runs_per_unit > heads ? runs_per_unit : heads);
+    const u32 total = rps * (u32)nsectors;
+    const u32 run0 = blockIdx.x * (UAES_WG / 64u) + wave;             /* this wave's first run: its text is requested now */
     uint4 d0 = make_uint4(0, 0, 0, 0);
     if (run0 < total) {
-        const u64 u0 = run0 / rps, r0 = run0 - u0 * rps;
+        const u32 u0 = MULTI ? run0 / rps : 0u, r0 = run0 - u0 * rps;
         if (64ull * r0 < main_blocks) {
             const u64 b0 = 64ull * r0 + lane;
-            d0 = load16<true>(in + u0 * sector_bytes + 16u * (b0 < main_blocks ? b0 : main_blocks - 1));
+            d0 = load16<true>(in + (u64)u0 * sector_bytes + 16u * (b0 < main_blocks ? b0 : main_blocks - 1));
         }
     }
     if (threadIdx.x >= blockDim.x - 256u) te_plain[threadIdx.x - (blockDim.x - 256u)] = tb.te0[threadIdx.x - (blockDim.x - 256u)];
     __syncthreads();
-    if (wave == 0 && nsectors == 1) {                         /* the tweak's encryption, while the other waves fill the tables */
+    if (wave == 0 && !MULTI) {                         /* the tweak's encryption, while the other waves fill the tables */
         u32 s[4];
         if (use_raw) { s[0] = raw_tweak.x; s[1] = raw_tweak.y; s[2] = raw_tweak.z; s[3] = raw_tweak.w; }
         else { s[0] = (u32)sector_id; s[1] = (u32)(sector_id >> 32); s[2] = 0; s[3] = 0; }   /* copyLint, micro_aes.c:399-404 */
         plain_encrypt<NR>(te_plain, k2, s);
         if (lane == 0) *t0_slot = make_uint4(s[0], s[1], s[2], s[3]);
-    } else if (nsectors == 1) {
+    } else if (!MULTI) {
         fill_enc_tables_share(DEC ? tb.td0 : tb.te0, threadIdx.x - 64u, blockDim.x - 64u);
     } else {
         fill_enc_tables_share(DEC ? tb.td0 : tb.te0, threadIdx.x, blockDim.x);
     }
     const LaneConst lc = make_lane_const();
     __syncthreads();
-    const u64 waves = (u64)gridDim.x * (UAES_WG / 64u);
-    for (u64 run = run0; run < total; run += waves) {                     /* wave-uniform */
-        const u64 unit = run / rps, ru = run - unit * rps;
+    const u32 waves = gridDim.x * (UAES_WG / 64u);
+    for (u32 run = run0; run < total; run += waves) {                     /* wave-uniform */
+        const u32 unit = MULTI ? run / rps : 0u, ru = run - unit * rps;
         Tw t;
-        if (nsectors == 1) {
+        if (!MULTI) {
             const uint4 t4 = *t0_slot;
             t.lo = t4.x | ((u64)t4.y << 32);
             t.hi = t4.z | ((u64)t4.w << 32);
@@ -451,24 +455,24 @@ __global__ __launch_bounds__(UAES_WG) void k_xts_small(uaesk_rk k1, uaesk_rk k2,
             t.lo = s[0] | ((u64)s[1] << 32);
             t.hi = s[2] | ((u64)s[3] << 32);
         }
-        const u32 c = (u32)__builtin_amdgcn_readfirstlane((int)(ru >> 2)), k = (u32)ru & 3u;
+        const u32 c = (u32)__builtin_amdgcn_readfirstlane((int)(ru >> 2)), k = ru & 3u;
         for (u32 i = 0; (c >> 6) >> i; ++i)                               /* chunk 64 g + l: alpha^(2^14 g) by the wave, */
             if (((c >> 6) >> i) & 1) t = wave_tw_mul(t, pw.lo[i], pw.hi[i], lane);
         if (c & 63u) t = tw_mul_a256(t, c & 63u);                          /* alpha^(256 l) by sparse shifts (uaes_gf.h)   */
         for (u32 q = 0; q < k; ++q) t = tw_mul_pow64(t);
-        if (nsectors == 1 && k == 0 && c < chunks && lane == 0)          /* chunk tweaks for k_xts_cts */
+        if (!MULTI && k == 0 && c < chunks && lane == 0)          /* chunk tweaks for k_xts_cts */
             chunk_tw[c] = make_uint4((u32)t.lo, (u32)(t.lo >> 32), (u32)t.hi, (u32)(t.hi >> 32));
         if (64ull * ru >= main_blocks) continue;
         const u64 blk = 64ull * ru + lane;
         const Tw tl = tw_mul_pow(t, lane);
         const u32 tw[4] = { (u32)tl.lo, (u32)(tl.lo >> 32), (u32)tl.hi, (u32)(tl.hi >> 32) };
         const u64 bc = blk < main_blocks ? blk : main_blocks - 1;        /* clamped: no branch around the rounds */
-        const unsigned char *src = in + unit * sector_bytes;
+        const unsigned char *src = in + (u64)unit * sector_bytes;
         const uint4 d = run == run0 ? d0 : load16<true>(src + 16u * bc);
         u32 s[1][4] = { { d.x ^ tw[0], d.y ^ tw[1], d.z ^ tw[2], d.w ^ tw[3] } };
         if (DEC) dec_blocks<NR, 1>(s, k1, lc); else enc_blocks<NR, 1>(s, k1, lc);
         if (blk < main_blocks)
-            store16<true>(out + unit * sector_bytes + 16u * blk,
+            store16<true>(out + (u64)unit * sector_bytes + 16u * blk,
                           make_uint4(s[0][0] ^ tw[0], s[0][1] ^ tw[1], s[0][2] ^ tw[2], s[0][3] ^ tw[3]));
     }
     ticket_release(done);
@@ -820,7 +824,7 @@ static int launch_xts(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *k1
     const bool few_units = nsectors > 1 && !tweak16 && r == 0 && mb > 0 &&
                            (u64)nsectors * ((mb + 63) / 64) <= 4ull * XTS_SMALL_CHUNKS;
     if (one_unit || few_units) {
-        e = set_lds((k_xts_small<NR, DEC>), XTS_SMALL_LDS);
+        e = few_units ? set_lds((k_xts_small<NR, DEC, true>), XTS_SMALL_LDS) : set_lds((k_xts_small<NR, DEC, false>), XTS_SMALL_LDS);
         if (e != hipSuccess) return (int)e;
         uaesk_done done = { nullptr, nullptr, 0 };
         if (!r) done = uaesk_ticket_take();                   /* no stealing kernel behind it: it carries the ticket */
@@ -828,10 +832,16 @@ static int launch_xts(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *k1
          * latency of one block */
         const u64 runs = (u64)nsectors * ((mb + 63) / 64);
         const unsigned sgrid = grid_for(runs, UAES_WG / 64);
-        hipLaunchKernelGGL((k_xts_small<NR, DEC>), dim3(sgrid), dim3(UAES_WG), XTS_SMALL_LDS, st, *k1, *k2, *tb, raw,
-                           (u32)(tweak16 != nullptr), first_sector, (uint4 *)scratch, cps, mb,
-                           (const unsigned char *)in, (unsigned char *)out, done, *xts_pow_table(), (u64)nsectors,
-                           (u64)sector_bytes);
+        if (few_units)
+            hipLaunchKernelGGL((k_xts_small<NR, DEC, true>), dim3(sgrid), dim3(UAES_WG), XTS_SMALL_LDS, st, *k1, *k2, *tb, raw,
+                               0u, first_sector, (uint4 *)scratch, cps, mb,
+                               (const unsigned char *)in, (unsigned char *)out, done, *xts_pow_table(), (u64)nsectors,
+                               (u64)sector_bytes);
+        else
+            hipLaunchKernelGGL((k_xts_small<NR, DEC, false>), dim3(sgrid), dim3(UAES_WG), XTS_SMALL_LDS, st, *k1, *k2, *tb, raw,
+                               (u32)(tweak16 != nullptr), first_sector, (uint4 *)scratch, cps, mb,
+                               (const unsigned char *)in, (unsigned char *)out, done, *xts_pow_table(), (u64)1,
+                               (u64)sector_bytes);
         if (r)
             hipLaunchKernelGGL((k_xts_cts<NR, DEC>), dim3(1), dim3(UAES_WG), lds, st,
                                *k1, *tb, (const uint4 *)scratch, (u64)1, cps, mb, r, (u64)sector_bytes,
