@@ -1532,6 +1532,10 @@ __global__ __launch_bounds__(GH_T) void k_gcm_combine(uaesk_rk ek, uaesk_tables 
     uint4 *TC = (uint4 *)uaes_lds;
     uint4 *buf = TC + GT_NTAB * 512u;
     u32 *te_plain = (u32 *)(uaes_lds + GHF_LDS);
+    /* the W partial hashes are the LAST W of 1024 entries (up to 256 of them the 1024 -> 256 level only copies);
+     * requested first: they travel while the tables are made */
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    if (threadIdx.x >= GH_T - W) acc = partial[threadIdx.x - (GH_T - W)];
     if (threadIdx.x < 256) te_plain[threadIdx.x] = tb.te0[threadIdx.x];
     __syncthreads();
     const u32 wave = threadIdx.x >> 6;
@@ -1539,21 +1543,17 @@ __global__ __launch_bounds__(GH_T) void k_gcm_combine(uaesk_rk ek, uaesk_tables 
         u32 s1[4] = { 0, 0, 0, 0 };
         if (wave) { s1[0] = j0.x; s1[1] = j0.y; s1[2] = j0.z; s1[3] = j0.w; }
         if (wave || build) plain_encrypt<NR>(te_plain, ek, s1);
-        else { const uint4 h = *(const uint4 *)(scratch + GS_H); s1[0] = h.x; s1[1] = h.y; s1[2] = h.z; s1[3] = h.w; }
         if ((threadIdx.x & 63u) == 0) buf[GT_BUF - 3 + wave] = make_uint4(s1[0], s1[1], s1[2], s1[3]);
+    }
+    if (!build) {                                             /* a key context holds the tables (k_gcm_ytables): waves 2..15
+                                                                 bring them in while wave 1 encrypts J0 */
+        const uint4 *gy = (const uint4 *)(scratch + GS_YTAB + (ylog - 10u) * GS_YTAB_SET);
+        if (threadIdx.x >= 128u)
+            for (u32 i = threadIdx.x - 128u; i < 5u * 512u; i += GH_T - 128u) TC[512u + i] = gy[i];
     }
     __syncthreads();
     const uint4 ej0 = buf[GT_BUF - 2];
-    if (build) {
-        gcm_build_nibble_tables<true>(TC, buf, tb.frob, ylog);    /* Y^256, Y^64, Y^16, Y^4, Y in tables 1..5 */
-    } else {                                                      /* a key context holds them (k_gcm_ytables) */
-        const uint4 *gy = (const uint4 *)(scratch + GS_YTAB + (ylog - 10u) * GS_YTAB_SET);
-        for (u32 i = threadIdx.x; i < 5u * 512u; i += GH_T) TC[512u + i] = gy[i];
-        __syncthreads();
-    }
-    /* the W partial hashes are the LAST W of 1024 entries (up to 256 of them the 1024 -> 256 level only copies) */
-    uint4 acc = make_uint4(0, 0, 0, 0);
-    if (threadIdx.x >= GH_T - W) acc = partial[threadIdx.x - (GH_T - W)];
+    if (build) gcm_build_nibble_tables<true>(TC, buf, tb.frob, ylog);    /* Y^256, Y^64, Y^16, Y^4, Y in tables 1..5 */
     acc = gh_tree<false>(buf, TC, acc, W);
     if (threadIdx.x == 0) {
         acc = x4(acc, ej0);
