@@ -1670,18 +1670,25 @@ __global__ __launch_bounds__(GH_T) void k_siv_small(uaesk_rk mk, uaesk_tables tb
             return ((te_plain[w & 0xffu] >> 8) & 0xffu) | (te_plain[(w >> 8) & 0xffu] & 0xff00u) |
                    ((te_plain[(w >> 16) & 0xffu] & 0xff00u) << 8) | ((te_plain[w >> 24] & 0xff00u) << 16);
         };
-        for (u32 i = 0; i < NK; ++i) ekl[i] = drv[4 + i];
+        /* the schedule grows in REGISTERS (fully unrolled: constant indices) and goes to LDS at the end: with ekl[] as
+         * the working array every word waited for an LDS store and two loads, ~200 cycles x 40..52 words = 3.7 us */
+        u32 w[4 * (NR + 1)];
+#pragma unroll
+        for (u32 i = 0; i < NK; ++i) w[i] = drv[4 + i];
         u32 rcon = 1;
+#pragma unroll
         for (u32 i = NK; i < 4u * (NR + 1); ++i) {
-            u32 t = ekl[i - 1];
+            u32 t = w[i - 1];
             if (i % NK == 0) {
                 t = subword((t >> 8) | (t << 24)) ^ rcon;         /* RotWord on LE words */
                 rcon = ((rcon << 1) ^ ((rcon >> 7) * 0x1bu)) & 0xffu;
             } else if (NK == 8 && i % NK == 4) {
                 t = subword(t);
             }
-            ekl[i] = ekl[i - NK] ^ t;
+            w[i] = w[i - NK] ^ t;
         }
+#pragma unroll
+        for (u32 i = 0; i < 4u * (NR + 1); ++i) ekl[i] = w[i];
     }
     __syncthreads();
     uaesk_rk rk;
