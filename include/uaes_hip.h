@@ -374,6 +374,26 @@ int  uaes_gcm_key_decrypt_records_dev(uaes_gcm_key *k, size_t nrec, const uint8_
                                       const void *d_aad, size_t aad_len, size_t aad_stride,
                                       const void *d_in, size_t rec_len, size_t in_stride,
                                       void *d_out, size_t out_stride, uint8_t *d_verdicts, int *d_status, void *stream);
+/* ... with records of DIFFERENT lengths in slots of one size (packet buffers): record r is lens[r] <= max_len bytes at
+ * the start of slot r (uint32 lengths; the device flavour clamps a longer one to max_len), its tag follows its own text;
+ * strides >= max_len (+ 16 where the tag is).  The other bytes of a slot's first max_len + 16 output bytes are
+ * unspecified afterwards.  The arrangement of the launch is the one the longest record needs.                   */
+int  uaes_gcm_key_encrypt_records_v(uaes_gcm_key *k, size_t nrec, const uint8_t *nonces,
+                                    const void *aad, size_t aad_len, size_t aad_stride,
+                                    const void *in, const uint32_t *lens, size_t max_len, size_t in_stride,
+                                    void *out, size_t out_stride);
+int  uaes_gcm_key_decrypt_records_v(uaes_gcm_key *k, size_t nrec, const uint8_t *nonces,
+                                    const void *aad, size_t aad_len, size_t aad_stride,
+                                    const void *in, const uint32_t *lens, size_t max_len, size_t in_stride,
+                                    void *out, size_t out_stride, uint8_t *verdicts);
+int  uaes_gcm_key_encrypt_records_v_dev(uaes_gcm_key *k, size_t nrec, const uint8_t *d_nonces,
+                                        const void *d_aad, size_t aad_len, size_t aad_stride,
+                                        const void *d_in, const uint32_t *d_lens, size_t max_len, size_t in_stride,
+                                        void *d_out, size_t out_stride, void *stream);
+int  uaes_gcm_key_decrypt_records_v_dev(uaes_gcm_key *k, size_t nrec, const uint8_t *d_nonces,
+                                        const void *d_aad, size_t aad_len, size_t aad_stride,
+                                        const void *d_in, const uint32_t *d_lens, size_t max_len, size_t in_stride,
+                                        void *d_out, size_t out_stride, uint8_t *d_verdicts, int *d_status, void *stream);
 
 /* ---- one process, several GPUs -------------------------------------------------
  * The text is cut into aligned slices, one per device; one host thread per device

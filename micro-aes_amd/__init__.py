@@ -46,6 +46,8 @@ EXPORTS = [
     "uaes_gcm_key_encrypt_dev", "uaes_gcm_key_decrypt_dev",
     "uaes_gcm_record_max", "uaes_gcm_key_encrypt_records", "uaes_gcm_key_decrypt_records",
     "uaes_gcm_key_encrypt_records_dev", "uaes_gcm_key_decrypt_records_dev",
+    "uaes_gcm_key_encrypt_records_v", "uaes_gcm_key_decrypt_records_v",
+    "uaes_gcm_key_encrypt_records_v_dev", "uaes_gcm_key_decrypt_records_v_dev",
     "uaes_gcm_stream_begin", "uaes_gcm_stream_update", "uaes_gcm_stream_finish", "uaes_gcm_stream_abort",
     "uaes_cbc_encrypt_batch", "uaes_cmac_batch", "uaes_cbc_encrypt", "uaes_cbc_decrypt", "uaes_cfb_encrypt", "uaes_cfb_decrypt", "uaes_ofb_xcrypt",
     "uaes_ecb_dev", "uaes_ctr_xcrypt_at_dev", "uaes_xts_sectors_dev",
@@ -146,6 +148,10 @@ def engine():
     L.uaes_gcm_key_decrypt_records.argtypes = [vp, sz, vp, vp, sz, sz, vp, sz, sz, vp, sz, vp]
     L.uaes_gcm_key_encrypt_records_dev.argtypes = [vp, sz, vp, vp, sz, sz, vp, sz, sz, vp, sz, vp]
     L.uaes_gcm_key_decrypt_records_dev.argtypes = [vp, sz, vp, vp, sz, sz, vp, sz, sz, vp, sz, vp, vp, vp]
+    L.uaes_gcm_key_encrypt_records_v.argtypes = [vp, sz, vp, vp, sz, sz, vp, vp, sz, sz, vp, sz]
+    L.uaes_gcm_key_decrypt_records_v.argtypes = [vp, sz, vp, vp, sz, sz, vp, vp, sz, sz, vp, sz, vp]
+    L.uaes_gcm_key_encrypt_records_v_dev.argtypes = [vp, sz, vp, vp, sz, sz, vp, vp, sz, sz, vp, sz, vp]
+    L.uaes_gcm_key_decrypt_records_v_dev.argtypes = [vp, sz, vp, vp, sz, sz, vp, vp, sz, sz, vp, sz, vp, vp, vp]
     L.uaes_gcm_stream_begin.argtypes = [C.POINTER(vp), i, vp, vp, vp, sz, i]
     L.uaes_gcm_stream_update.argtypes = [vp, vp, sz, vp]
     L.uaes_gcm_stream_finish.argtypes = [vp, vp]
@@ -522,6 +528,47 @@ class GcmKey:
                                                           dst, stride, ver), "uaes_gcm_key_decrypt_records")
         b = bytes(dst)
         return rc, list(bytes(ver)), [b[r * stride: r * stride + rec_len] for r in range(n)]
+
+    def encrypt_records_v(self, nonces, aads, records, max_len=None, stride=None):
+        """records of DIFFERENT lengths in equal slots (uaes_gcm_key_encrypt_records_v).  Returns the list of
+        ciphertext || tag, each equal to encrypt() of that record."""
+        n = len(records)
+        if n == 0:
+            return []
+        max_len = max(len(r) for r in records) if max_len is None else max_len
+        stride = stride or (max_len + 16 + 15) // 16 * 16
+        aad, aad_len, aad_stride = self._pack_aads(aads, n)
+        src = bytearray(stride * n)
+        for r, rec in enumerate(records):
+            src[r * stride: r * stride + len(rec)] = rec
+        lens = (C.c_uint32 * n)(*[len(r) for r in records])
+        dst = _out(stride * n)
+        _check(engine().uaes_gcm_key_encrypt_records_v(self._h, n, _in(b"".join(_fixed_bytes(x, 12) for x in nonces)),
+                                                       _in(aad), aad_len, aad_stride, _in(bytes(src)), lens, max_len, stride,
+                                                       dst, stride), "uaes_gcm_key_encrypt_records_v")
+        b = bytes(dst)
+        return [b[r * stride: r * stride + len(records[r]) + 16] for r in range(n)]
+
+    def decrypt_records_v(self, nonces, aads, records, prefill=0, max_len=None, stride=None):
+        """records: list of ciphertext || tag of different lengths.  Returns (code, verdicts, texts)."""
+        n = len(records)
+        if n == 0:
+            return 0, [], []
+        tl = [len(r) - 16 for r in records]
+        max_len = max(tl) if max_len is None else max_len
+        stride = stride or (max_len + 16 + 15) // 16 * 16
+        aad, aad_len, aad_stride = self._pack_aads(aads, n)
+        src = bytearray(stride * n)
+        for r, rec in enumerate(records):
+            src[r * stride: r * stride + len(rec)] = rec
+        lens = (C.c_uint32 * n)(*tl)
+        dst = _out(stride * n, prefill)
+        ver = _out(n, 0x55)
+        rc = _check(engine().uaes_gcm_key_decrypt_records_v(self._h, n, _in(b"".join(_fixed_bytes(x, 12) for x in nonces)),
+                                                            _in(aad), aad_len, aad_stride, _in(bytes(src)), lens, max_len, stride,
+                                                            dst, stride, ver), "uaes_gcm_key_decrypt_records_v")
+        b = bytes(dst)
+        return rc, list(bytes(ver)), [b[r * stride: r * stride + tl[r]] for r in range(n)]
 
     @staticmethod
     def _pack_aads(aads, n):

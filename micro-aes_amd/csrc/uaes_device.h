@@ -115,7 +115,8 @@ size_t uaesk_gcm_record_max(size_t aad_len);
 int uaesk_gcm_records(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek, int decrypt,
                       const void *nonces12, const void *aad, size_t aad_len, size_t aad_stride,
                       const void *in, size_t rec_len, size_t in_stride, void *out, size_t out_stride,
-                      size_t nrec, const void *key_scratch, unsigned char *verdicts, int *status);
+                      size_t nrec, const void *key_scratch, unsigned char *verdicts, int *status,
+                      const void *lens /* NULL: every record rec_len bytes; else uint32 lens[nrec], record r = min(lens[r], rec_len) bytes */);
 
 /* Sharded GCM: the weighted partial GHASH of one 16-byte-aligned ciphertext
  * shard (first shard: + AAD and Enc(J0); last shard: + length block).  The tag

@@ -1774,10 +1774,10 @@ static int records_args_ok(size_t nrec, const void *nonces, const void *aad, siz
     return 0;
 }
 
-int uaes_gcm_key_encrypt_records_dev(uaes_gcm_key *k, size_t nrec, const uint8_t *d_nonces,
-                                     const void *d_aad, size_t aad_len, size_t aad_stride,
-                                     const void *d_in, size_t rec_len, size_t in_stride,
-                                     void *d_out, size_t out_stride, void *stream)
+static int records_enc_dev(uaes_gcm_key *k, size_t nrec, const uint8_t *d_nonces,
+                           const void *d_aad, size_t aad_len, size_t aad_stride,
+                           const void *d_in, const uint32_t *d_lens, size_t rec_len, size_t in_stride,
+                           void *d_out, size_t out_stride, void *stream)
 {
     context *c;
     int rc;
@@ -1787,14 +1787,31 @@ int uaes_gcm_key_encrypt_records_dev(uaes_gcm_key *k, size_t nrec, const uint8_t
     if ((rc = dev_ptrs_ok(d_in, d_out, 1)) != 0) return rc;
     if ((rc = get_context(&c)) != 0) return rc;
     KCHK(uaesk_gcm_records(stream, &c->tb, k->ks.nr, &k->ks.ek, 0, d_nonces, d_aad, aad_len, aad_stride,
-                           d_in, rec_len, in_stride, d_out, out_stride, nrec, k->scratch, NULL, NULL));
+                           d_in, rec_len, in_stride, d_out, out_stride, nrec, k->scratch, NULL, NULL, d_lens));
     return 0;
 }
 
-int uaes_gcm_key_decrypt_records_dev(uaes_gcm_key *k, size_t nrec, const uint8_t *d_nonces,
+int uaes_gcm_key_encrypt_records_dev(uaes_gcm_key *k, size_t nrec, const uint8_t *d_nonces,
                                      const void *d_aad, size_t aad_len, size_t aad_stride,
                                      const void *d_in, size_t rec_len, size_t in_stride,
-                                     void *d_out, size_t out_stride, uint8_t *d_verdicts, int *d_status, void *stream)
+                                     void *d_out, size_t out_stride, void *stream)
+{
+    return records_enc_dev(k, nrec, d_nonces, d_aad, aad_len, aad_stride, d_in, NULL, rec_len, in_stride, d_out, out_stride, stream);
+}
+
+int uaes_gcm_key_encrypt_records_v_dev(uaes_gcm_key *k, size_t nrec, const uint8_t *d_nonces,
+                                       const void *d_aad, size_t aad_len, size_t aad_stride,
+                                       const void *d_in, const uint32_t *d_lens, size_t max_len, size_t in_stride,
+                                       void *d_out, size_t out_stride, void *stream)
+{
+    if (nrec && !d_lens) return fail(UAES_E_ARG, "NULL lengths");
+    return records_enc_dev(k, nrec, d_nonces, d_aad, aad_len, aad_stride, d_in, d_lens, max_len, in_stride, d_out, out_stride, stream);
+}
+
+static int records_dec_dev(uaes_gcm_key *k, size_t nrec, const uint8_t *d_nonces,
+                           const void *d_aad, size_t aad_len, size_t aad_stride,
+                           const void *d_in, const uint32_t *d_lens, size_t rec_len, size_t in_stride,
+                           void *d_out, size_t out_stride, uint8_t *d_verdicts, int *d_status, void *stream)
 {
     context *c;
     int rc;
@@ -1806,8 +1823,27 @@ int uaes_gcm_key_decrypt_records_dev(uaes_gcm_key *k, size_t nrec, const uint8_t
     if ((rc = get_context(&c)) != 0) return rc;
     HIPCHK(hipMemsetAsync(d_status, 0, sizeof(int), (hipStream_t)stream));
     KCHK(uaesk_gcm_records(stream, &c->tb, k->ks.nr, &k->ks.ek, 1, d_nonces, d_aad, aad_len, aad_stride,
-                           d_in, rec_len, in_stride, d_out, out_stride, nrec, k->scratch, d_verdicts, d_status));
+                           d_in, rec_len, in_stride, d_out, out_stride, nrec, k->scratch, d_verdicts, d_status, d_lens));
     return 0;
+}
+
+int uaes_gcm_key_decrypt_records_dev(uaes_gcm_key *k, size_t nrec, const uint8_t *d_nonces,
+                                     const void *d_aad, size_t aad_len, size_t aad_stride,
+                                     const void *d_in, size_t rec_len, size_t in_stride,
+                                     void *d_out, size_t out_stride, uint8_t *d_verdicts, int *d_status, void *stream)
+{
+    return records_dec_dev(k, nrec, d_nonces, d_aad, aad_len, aad_stride, d_in, NULL, rec_len, in_stride, d_out, out_stride,
+                           d_verdicts, d_status, stream);
+}
+
+int uaes_gcm_key_decrypt_records_v_dev(uaes_gcm_key *k, size_t nrec, const uint8_t *d_nonces,
+                                       const void *d_aad, size_t aad_len, size_t aad_stride,
+                                       const void *d_in, const uint32_t *d_lens, size_t max_len, size_t in_stride,
+                                       void *d_out, size_t out_stride, uint8_t *d_verdicts, int *d_status, void *stream)
+{
+    if (nrec && !d_lens) return fail(UAES_E_ARG, "NULL lengths");
+    return records_dec_dev(k, nrec, d_nonces, d_aad, aad_len, aad_stride, d_in, d_lens, max_len, in_stride, d_out, out_stride,
+                           d_verdicts, d_status, stream);
 }
 
 /* host (or device) pointers, synchronous: nonces and AAD go through the lane's AAD staging, the texts through its
@@ -1815,7 +1851,7 @@ int uaes_gcm_key_decrypt_records_dev(uaes_gcm_key *k, size_t nrec, const uint8_t
  * and on decryption the records whose tag is wrong -- N7 -- keep what they held) */
 static int records_sync(uaes_gcm_key *k, int decrypt, size_t nrec, const uint8_t *nonces,
                         const void *aad, size_t aad_len, size_t aad_stride,
-                        const void *in, size_t rec_len, size_t in_stride,
+                        const void *in, const uint32_t *lens, size_t rec_len, size_t in_stride,
                         void *out, size_t out_stride, uint8_t *verdicts)
 {
     context *c;
@@ -1832,18 +1868,25 @@ static int records_sync(uaes_gcm_key *k, int decrypt, size_t nrec, const uint8_t
         hipStream_t st = (hipStream_t)L->stream;
         const size_t non_span = (12 * nrec + 15) & ~(size_t)15;
         const size_t aad_span = aad_len ? (aad_stride ? (nrec - 1) * aad_stride + aad_len : aad_len) : 0;
+        const size_t lens_off = non_span + ((aad_span + 15) & ~(size_t)15), lens_span = lens ? 4 * nrec : 0;
         const size_t in_span = (nrec - 1) * in_stride + in_rec, out_span = (nrec - 1) * out_stride + out_rec;
         const size_t ver_off = (out_span + 15) & ~(size_t)15;
         const int in_place = in == out && in_stride == out_stride;
         unsigned char *d_meta, *d_out, *d_ver;
         const unsigned char *d_in;
         int status = 0;
-        if (is_device_ptr(nonces) || is_device_ptr(aad) || is_device_ptr(in) || is_device_ptr(out))
+        if (is_device_ptr(nonces) || is_device_ptr(aad) || is_device_ptr(in) || is_device_ptr(out) || is_device_ptr(lens))
             if ((rc = wait_for_callers_device_work()) != 0) break;
-        if (grow_on(st, &L->aad_stage, &L->aad_cap, non_span + aad_span + 16)) { rc = UAES_E_HIP; break; }
+        if (lens && !is_device_ptr(lens)) {                   /* (the kernel clamps; a host array can be checked here) */
+            size_t r;
+            for (r = 0; r < nrec && lens[r] <= rec_len; ++r) { }
+            if (r < nrec) { rc = fail(UAES_E_ARG, "record %zu is %u bytes, longer than max_len %zu", r, lens[r], rec_len); break; }
+        }
+        if (grow_on(st, &L->aad_stage, &L->aad_cap, lens_off + lens_span + 16)) { rc = UAES_E_HIP; break; }
         d_meta = (unsigned char *)L->aad_stage;
         if (hipMemcpyAsync(d_meta, nonces, 12 * nrec, hipMemcpyDefault, st) != hipSuccess ||
-            (aad_span && hipMemcpyAsync(d_meta + non_span, aad, aad_span, hipMemcpyDefault, st) != hipSuccess)) {
+            (aad_span && hipMemcpyAsync(d_meta + non_span, aad, aad_span, hipMemcpyDefault, st) != hipSuccess) ||
+            (lens_span && hipMemcpyAsync(d_meta + lens_off, lens, lens_span, hipMemcpyDefault, st) != hipSuccess)) {
             rc = fail(UAES_E_HIP, "staging the nonces failed");
             break;
         }
@@ -1866,7 +1909,8 @@ static int records_sync(uaes_gcm_key *k, int decrypt, size_t nrec, const uint8_t
         {
             int kk = uaesk_gcm_records(L->stream, &c->tb, k->ks.nr, &k->ks.ek, decrypt, d_meta,
                                        aad_span ? d_meta + non_span : NULL, aad_len, aad_stride, d_in, rec_len, in_stride,
-                                       d_out, out_stride, nrec, k->scratch, decrypt ? d_ver : NULL, decrypt ? L->d_status : NULL);
+                                       d_out, out_stride, nrec, k->scratch, decrypt ? d_ver : NULL, decrypt ? L->d_status : NULL,
+                                       lens ? d_meta + lens_off : NULL);
             if (kk) { rc = fail(UAES_E_HIP, "gcm records launch: %s", hipGetErrorString((hipError_t)kk)); break; }
         }
         if (decrypt) {
@@ -1883,7 +1927,8 @@ static int records_sync(uaes_gcm_key *k, int decrypt, size_t nrec, const uint8_t
                     size_t r;
                     for (r = 0; r < nrec && rc == 0; ++r)
                         if (v[r] == 0 && rec_len &&
-                            hipMemcpyAsync((char *)out + r * out_stride, d_out + r * out_stride, rec_len, hipMemcpyDefault, st) != hipSuccess)
+                            hipMemcpyAsync((char *)out + r * out_stride, d_out + r * out_stride,
+                                           lens && !is_device_ptr(lens) ? lens[r] : rec_len, hipMemcpyDefault, st) != hipSuccess)
                             rc = fail(UAES_E_HIP, "copy back failed");
                     if (v != verdicts) free(v);
                     if (rc == 0 && hipStreamSynchronize(st) != hipSuccess) rc = fail(UAES_E_HIP, "copy back failed");
@@ -1906,7 +1951,7 @@ int uaes_gcm_key_encrypt_records(uaes_gcm_key *k, size_t nrec, const uint8_t *no
                                  const void *aad, size_t aad_len, size_t aad_stride,
                                  const void *in, size_t rec_len, size_t in_stride, void *out, size_t out_stride)
 {
-    return records_sync(k, 0, nrec, nonces, aad, aad_len, aad_stride, in, rec_len, in_stride, out, out_stride, NULL);
+    return records_sync(k, 0, nrec, nonces, aad, aad_len, aad_stride, in, NULL, rec_len, in_stride, out, out_stride, NULL);
 }
 
 int uaes_gcm_key_decrypt_records(uaes_gcm_key *k, size_t nrec, const uint8_t *nonces,
@@ -1914,7 +1959,28 @@ int uaes_gcm_key_decrypt_records(uaes_gcm_key *k, size_t nrec, const uint8_t *no
                                  const void *in, size_t rec_len, size_t in_stride, void *out, size_t out_stride,
                                  uint8_t *verdicts)
 {
-    return records_sync(k, 1, nrec, nonces, aad, aad_len, aad_stride, in, rec_len, in_stride, out, out_stride, verdicts);
+    return records_sync(k, 1, nrec, nonces, aad, aad_len, aad_stride, in, NULL, rec_len, in_stride, out, out_stride, verdicts);
+}
+
+/* records of DIFFERENT lengths in slots of one size (packet buffers): record r is lens[r] <= max_len bytes at the start of
+ * its slot, its tag follows its own text.  What else of a slot's first max_len + 16 output bytes holds afterwards is
+ * unspecified (the synchronous flavour copies whole slots back). */
+int uaes_gcm_key_encrypt_records_v(uaes_gcm_key *k, size_t nrec, const uint8_t *nonces,
+                                   const void *aad, size_t aad_len, size_t aad_stride,
+                                   const void *in, const uint32_t *lens, size_t max_len, size_t in_stride,
+                                   void *out, size_t out_stride)
+{
+    if (nrec && !lens) return fail(UAES_E_ARG, "NULL lengths");
+    return records_sync(k, 0, nrec, nonces, aad, aad_len, aad_stride, in, lens, max_len, in_stride, out, out_stride, NULL);
+}
+
+int uaes_gcm_key_decrypt_records_v(uaes_gcm_key *k, size_t nrec, const uint8_t *nonces,
+                                   const void *aad, size_t aad_len, size_t aad_stride,
+                                   const void *in, const uint32_t *lens, size_t max_len, size_t in_stride,
+                                   void *out, size_t out_stride, uint8_t *verdicts)
+{
+    if (nrec && !lens) return fail(UAES_E_ARG, "NULL lengths");
+    return records_sync(k, 1, nrec, nonces, aad, aad_len, aad_stride, in, lens, max_len, in_stride, out, out_stride, verdicts);
 }
 
 int uaes_gcm_partial_dev(int keybits, const uint8_t *key, const uint8_t *nonce,

@@ -442,3 +442,46 @@ def test_fuzz_gcm_record_calls(orc):
             k.close()
 
     run_cases(909, 14, body)
+
+
+def test_fuzz_gcm_record_calls_of_different_lengths(orc):
+    """uaes_gcm_key_{en,de}crypt_records_v: random slot sizes, random lengths per record (zero and the maximum among them),
+    shared or per-record AAD, some records forged -- every record against the oracle's call of that record alone"""
+    def body(rnd, i):
+        bits = rnd.choice([128, 192, 256])
+        key = rnd.randbytes(bits // 8)
+        k = uaes.GcmKey(key)
+        try:
+            aad_len = rnd.choice([0, 0, 5, 13, 16, rnd.randrange(0, 100)])
+            cap = k.record_max(aad_len)
+            max_len = rnd.choice([rnd.randrange(0, 64), rnd.randrange(0, 1100), rnd.randrange(900, 2100), rnd.randrange(2000, 8300),
+                                  rnd.randrange(8000, cap + 1), cap])
+            nrec = rnd.choice([1, 2, rnd.randrange(1, 40), rnd.randrange(100, 400)])
+            if max_len > 6000:
+                nrec = min(nrec, 20)
+            lens = [rnd.choice([0, max_len, rnd.randrange(0, max_len + 1)]) for _ in range(nrec)]
+            per_record_aad = aad_len > 0 and rnd.random() < 0.5
+            nonces = [rnd.randbytes(12) for _ in range(nrec)]
+            aads = [rnd.randbytes(aad_len) for _ in range(nrec)] if per_record_aad else rnd.randbytes(aad_len)
+            aad_of = (lambda r: aads[r]) if per_record_aad else (lambda r: aads)
+            recs = [rnd.randbytes(n) for n in lens]
+            info = dict(seed_case=i, bits=bits, nrec=nrec, max_len=max_len, aad_len=aad_len, per_record_aad=per_record_aad)
+            want = [orc.gcm_encrypt(key, nonces[r], aad_of(r), recs[r]) for r in range(nrec)]
+            stride = (max_len + 16 + 15) // 16 * 16 + 16 * rnd.choice([0, 0, 2])
+            got = k.encrypt_records_v(nonces, aads, recs, max_len=max_len, stride=stride)
+            assert got == want, info
+            forged = set(rnd.sample(range(nrec), rnd.choice([0, 1, min(nrec, 3)])))
+            spoiled = list(got)
+            for r in forged:
+                b = bytearray(spoiled[r])
+                b[rnd.randrange(len(b))] ^= 1 << rnd.randrange(8)
+                spoiled[r] = bytes(b)
+            rc, ver, texts = k.decrypt_records_v(nonces, aads, spoiled, prefill=0xC3, max_len=max_len, stride=stride)
+            assert rc == (0x1A if forged else 0), info
+            for r in range(nrec):
+                assert ver[r] == (0x1A if r in forged else 0), (info, r)
+                assert texts[r] == (b"\xc3" * lens[r] if r in forged else recs[r]), (info, r)
+        finally:
+            k.close()
+
+    run_cases(1010, 12, body)

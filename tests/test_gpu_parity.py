@@ -1149,6 +1149,59 @@ def test_gcm_record_calls_equal_a_call_per_record(orc, bits):
         k.close()
 
 
+@pytest.mark.parametrize("bits", [128, 256])
+def test_gcm_record_calls_with_records_of_different_lengths(orc, bits):
+    """uaes_gcm_key_{en,de}crypt_records_v: packet buffers -- equal slots, every record its own length (zero included),
+    the launch arranged for the longest.  Every record against the oracle's call of that record alone, in each of the
+    kernel's arrangements; forged records are reported one by one and keep the output's prefill."""
+    import torch
+    rnd = random.Random(4300 + bits)
+    key = rnd.randbytes(bits // 8)
+    k = uaes.GcmKey(key)
+    try:
+        for nrec, max_len, aad_len in [(1, 0, 0), (40, 60, 13), (100, 1000, 0), (37, 1500, 5), (19, 4096, 13), (11, 9000, 0),
+                                       (5, 20000, 16), (260, 300, 20), (3, k.record_max(0), 0)]:
+            lens = [rnd.choice([0, 1, max_len, max_len // 2, rnd.randrange(0, max_len + 1)]) for _ in range(nrec)]
+            lens[rnd.randrange(nrec)] = max_len
+            nonces = [rnd.randbytes(12) for _ in range(nrec)]
+            recs = [rnd.randbytes(n) for n in lens]
+            aad = rnd.randbytes(aad_len)
+            want = [orc.gcm_encrypt(key, nonces[r], aad, recs[r]) for r in range(nrec)]
+            got = k.encrypt_records_v(nonces, aad, recs, max_len=max_len)
+            assert got == want, (nrec, max_len, aad_len)
+            rc, ver, texts = k.decrypt_records_v(nonces, aad, got, prefill=0xCC, max_len=max_len)
+            assert rc == 0 and ver == [0] * nrec and texts == recs
+            bad = sorted(rnd.sample(range(nrec), min(nrec, 1 + nrec // 9)))
+            spoiled = list(got)
+            for r in bad:
+                b = bytearray(spoiled[r])
+                b[rnd.randrange(len(b))] ^= 1 << rnd.randrange(8)
+                spoiled[r] = bytes(b)
+            rc, ver, texts = k.decrypt_records_v(nonces, aad, spoiled, prefill=0xCC, max_len=max_len)
+            assert rc == 0x1A and ver == [0x1A if r in bad else 0 for r in range(nrec)]
+            for r in range(nrec):
+                assert texts[r] == (b"\xcc" * lens[r] if r in bad else recs[r]), (nrec, max_len, r)
+        # device flavour: lengths on the device, one of them longer than max_len (clamped, not overrun)
+        nrec, max_len, stride = 500, 1440, 1472
+        lens = [rnd.randrange(0, max_len + 1) for _ in range(nrec)]
+        lens[7] = max_len + 999
+        d_lens = torch.tensor(lens, dtype=torch.int32, device="cuda:0")
+        nonces = torch.randint(0, 256, (nrec * 12,), dtype=torch.uint8, device="cuda:0")
+        src = torch.randint(0, 256, (nrec * stride,), dtype=torch.uint8, device="cuda:0")
+        dst = torch.full((nrec * stride,), 0xA5, dtype=torch.uint8, device="cuda:0")
+        L = uaes.engine()
+        st = torch.cuda.current_stream().cuda_stream
+        assert L.uaes_gcm_key_encrypt_records_v_dev(k._h, nrec, nonces.data_ptr(), None, 0, 0, src.data_ptr(), d_lens.data_ptr(),
+                                                    max_len, stride, dst.data_ptr(), stride, st) == 0
+        torch.cuda.synchronize()
+        nb, sb, ob = (bytes(t.cpu().numpy()) for t in (nonces, src, dst))
+        for r in range(nrec):
+            n = min(lens[r], max_len)
+            assert ob[r * stride: r * stride + n + 16] == orc.gcm_encrypt(key, nb[12 * r: 12 * r + 12], b"", sb[r * stride: r * stride + n]), r
+    finally:
+        k.close()
+
+
 def test_gcm_record_calls_on_device_buffers(orc):
     """the *_dev flavour: device pointers for nonces, AAD, records; many more records than workgroups; in place;
     two record calls sharing one key context on two streams"""
