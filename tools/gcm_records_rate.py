@@ -60,3 +60,32 @@ for rec_len in (64, 256, 1440, 4096, 16384, 32704):
     dt = (time.perf_counter() - t0) / calls
     row.append("%7.3f M/s %8.2f GiB/s" % (1 / dt / 1e6, rec_len / dt / 2**30))
     print("%8d %9d | %s" % (rec_len, nrec, " | ".join(row)), flush=True)
+
+# packet buffers: records of different lengths (uniform in 40..1500 bytes) in 1536-byte slots, one call
+nrec, max_len, stride = 1 << 18, 1500, 1536
+L = uaes.engine()
+lens = torch.randint(40, max_len + 1, (nrec,), dtype=torch.int32, device="cuda")
+nonces = torch.randint(0, 256, (nrec * 12,), dtype=torch.uint8, device="cuda")
+aad = torch.randint(0, 256, (16,), dtype=torch.uint8, device="cuda")
+src = torch.randint(0, 256, (nrec * stride,), dtype=torch.uint8, device="cuda")
+dst = torch.zeros(nrec * stride, dtype=torch.uint8, device="cuda")
+sp = st.cuda_stream
+call = lambda: L.uaes_gcm_key_encrypt_records_v_dev(gk._h, nrec, nonces.data_ptr(), aad.data_ptr(), AAD, 0, src.data_ptr(),
+                                                    lens.data_ptr(), max_len, stride, dst.data_ptr(), stride, sp)
+for _ in range(3):
+    assert call() == 0
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(10):
+    call()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / 10
+total = int(lens.sum().item())
+print("mixed 40..1500-byte records in 1536-byte slots, %d records: %.3f ms  %.2f M records/s  %.1f GiB/s of text"
+      % (nrec, dt * 1e3, nrec / dt / 1e6, total / dt / 2**30))
+r = 12345
+n = int(lens[r].item())
+one = torch.zeros(n + 16, dtype=torch.uint8, device="cuda")
+gk.encrypt_dev(bytes(nonces[12 * r: 12 * r + 12].cpu().numpy()), aad[:AAD].clone(), src[r * stride: r * stride + n], n, one, stream=st)
+torch.cuda.synchronize()
+assert torch.equal(one, dst[r * stride: r * stride + n + 16])
