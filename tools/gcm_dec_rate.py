@@ -12,7 +12,8 @@ import micro_aes_amd as uaes  # noqa: E402
 def main():
     L = uaes.engine()
     key, nonce = bytes(range(16)), bytes(range(0xF0, 0xFC))
-    for n in (16 << 20, 64 << 20, 256 << 20, 1 << 30):
+    sizes = [int(a) << 20 for a in sys.argv[1:]] or [16 << 20, 64 << 20, 256 << 20, 1 << 30]
+    for n in sizes:
         src = torch.randint(0, 256, (n,), dtype=torch.uint8, device="cuda:0")
         ct = torch.zeros(n + 16, dtype=torch.uint8, device="cuda:0")
         out = torch.zeros(n, dtype=torch.uint8, device="cuda:0")
