@@ -41,7 +41,9 @@
 #define CBC      1          /* feedback modes: decrypt of CBC/CFB is block-   */
 #define CFB      1          /* parallel, the rest one GPU lane (uaes_chain.hip) */
 #define OFB      1
-#define CTS      1          /* CBC ciphertext stealing, CS3 (micro_aes.h:57)  */
+#ifndef CTS                  /* micro_aes.h:56 -- CBC ciphertext stealing (CS3).  A caller built with -DCTS=0 gets   */
+#define CTS      1          /* the reference's other CBC: last chunk padded (AES_PADDING), whole-block decrypt   */
+#endif
 #define KWA      0
 #define FPE      0
 #define EAX      0
@@ -65,8 +67,12 @@
  * for the enum constant and the AES_CCM_* / AES_GCM_* / AES_OCB_* names bind to the general entry points below.    */
 enum constant_parameters_of_modes
 {
-    CTR_START_VALUE = 1,
+#ifndef CTR_START_VALUE    /* micro_aes.h:98-99; -DCTR_START_VALUE=n / -DCTR_IV_LENGTH=n (<= 16) bind AES_CTR_* to  */
+    CTR_START_VALUE = 1,   /* the general entry point below (micro_aes.c:968-971)                                */
+#endif
+#ifndef CTR_IV_LENGTH
     CTR_IV_LENGTH   = 12,
+#endif
 #ifndef CCM_NONCE_LEN
     CCM_NONCE_LEN   = 11,
 #endif
@@ -95,6 +101,7 @@ enum constant_parameters_of_modes
 };
 typedef char uaes_ccm_lengths_ok[(CCM_NONCE_LEN >= 7 && CCM_NONCE_LEN <= 13 && CCM_TAG_LEN >= 4 && CCM_TAG_LEN <= 16 &&
                                   CCM_TAG_LEN % 2 == 0) ? 1 : -1];
+typedef char uaes_ctr_lengths_ok[(CTR_IV_LENGTH >= 0 && CTR_IV_LENGTH <= 16) ? 1 : -1];
 typedef char uaes_gcm_lengths_ok[(GCM_NONCE_LEN >= 1 && GCM_TAG_LEN >= 1 && GCM_TAG_LEN <= 16) ? 1 : -1];
 typedef char uaes_ocb_lengths_ok[(OCB_NONCE_LEN >= 1 && OCB_NONCE_LEN <= 15 && OCB_TAG_LEN >= 1 && OCB_TAG_LEN <= 16) ? 1 : -1];
 
@@ -104,6 +111,16 @@ typedef char uaes_ocb_lengths_ok[(OCB_NONCE_LEN >= 1 && OCB_NONCE_LEN <= 15 && O
 
 #ifdef __cplusplus
 extern "C" {
+#endif
+
+/* real functions behind OBJECT-like macros, so that `&AES_GCM_encrypt` / `&AES_CTR_encrypt` or a dispatch-table entry binds to
+ * the lengths of this build as well as a direct call does                                              */
+#if defined(__cplusplus) || (defined(__STDC_VERSION__) && __STDC_VERSION__ >= 199901L)
+#define UAES_STATIC_INLINE static inline
+#elif defined(__GNUC__)
+#define UAES_STATIC_INLINE static __inline__ __attribute__((unused))
+#else
+#define UAES_STATIC_INLINE static
 #endif
 
 void AES_ECB_encrypt(const uint8_t *key,
@@ -134,9 +151,21 @@ void AES_CTR_encrypt_preset(const uint8_t *key, const uint8_t *counter16,
                             const void *pntxt, const size_t ptextLen, void *crtxt);
 void AES_CTR_decrypt_preset(const uint8_t *key, const uint8_t *counter16,
                             const void *crtxt, const size_t crtxtLen, void *pntxt);
+/* CTR_IV_LENGTH / CTR_START_VALUE other than 12 / 1 (micro_aes.h:98-99): counter block = iv[0..CTR_IV_LENGTH) ||
+ * zeros with CTR_START_VALUE XORed in big-endian at its end (micro_aes.c:968-971).  Decrypt = encrypt (:986-990). */
+void AES_CTR_encrypt_iv(const size_t ivLen, const size_t startValue, const uint8_t *key, const uint8_t *iv,
+                        const void *pntxt, const size_t ptextLen, void *crtxt);
 #if PRESET_COUNTER
 #define AES_CTR_encrypt AES_CTR_encrypt_preset
 #define AES_CTR_decrypt AES_CTR_decrypt_preset
+#elif defined(CTR_IV_LENGTH) || defined(CTR_START_VALUE)
+UAES_STATIC_INLINE void AES_CTR_encrypt_nl(const uint8_t *key, const uint8_t *iv,
+                                        const void *pntxt, const size_t ptextLen, void *crtxt)
+{
+    AES_CTR_encrypt_iv(CTR_IV_LENGTH, CTR_START_VALUE, key, iv, pntxt, ptextLen, crtxt);
+}
+#define AES_CTR_encrypt AES_CTR_encrypt_nl
+#define AES_CTR_decrypt AES_CTR_encrypt_nl
 #endif
 
 char AES_XTS_encrypt(const uint8_t *keys, const uint8_t *tweak,
@@ -168,15 +197,6 @@ char AES_GCM_decrypt_ivlen(const size_t nonceLen, const uint8_t *key, const uint
                            const void *aData, const size_t aDataLen,
                            const void *crtxt, const size_t crtxtLen, void *pntxt);
 
-/* real functions behind OBJECT-like macros, so that `&AES_GCM_encrypt` or a dispatch-table entry binds to
- * the lengths of this build as well as a direct call does                                              */
-#if defined(__cplusplus) || (defined(__STDC_VERSION__) && __STDC_VERSION__ >= 199901L)
-#define UAES_STATIC_INLINE static inline
-#elif defined(__GNUC__)
-#define UAES_STATIC_INLINE static __inline__ __attribute__((unused))
-#else
-#define UAES_STATIC_INLINE static
-#endif
 #if defined(GCM_NONCE_LEN) || defined(GCM_TAG_LEN)
 UAES_STATIC_INLINE void AES_GCM_encrypt_nl(const uint8_t *key, const uint8_t *nonce,
                                            const void *aData, const size_t aDataLen,
@@ -198,6 +218,28 @@ char AES_CBC_encrypt(const uint8_t *key, const uint8_t iVec[16],
                      const void *pntxt, const size_t ptextLen, void *crtxt);
 char AES_CBC_decrypt(const uint8_t *key, const uint8_t iVec[16],
                      const void *crtxt, const size_t crtxtLen, void *pntxt);
+/* CTS 0 (micro_aes.h:56): no stealing -- AES_CBC_encrypt pads its last chunk with padBlock like ECB (micro_aes.c:
+ * 727-733; zeros behind a partial chunk, or PKCS#7 / ISO 7816-4 which always append: crtxt then holds
+ * (ptextLen / 16 + 1) * 16 bytes), any length is accepted (:704-708), and AES_CBC_decrypt wants whole blocks
+ * (:761, M_DATALENGTH_ERROR otherwise) and leaves the padding in place.  Every library exports both families:    */
+char AES_CBC_encrypt_nocts(const uint8_t *key, const uint8_t iVec[16],
+                           const void *pntxt, const size_t ptextLen, void *crtxt);
+char AES_CBC_encrypt_nocts_pkcs7(const uint8_t *key, const uint8_t iVec[16],
+                                 const void *pntxt, const size_t ptextLen, void *crtxt);
+char AES_CBC_encrypt_nocts_iso7816(const uint8_t *key, const uint8_t iVec[16],
+                                   const void *pntxt, const size_t ptextLen, void *crtxt);
+char AES_CBC_decrypt_nocts(const uint8_t *key, const uint8_t iVec[16],
+                           const void *crtxt, const size_t crtxtLen, void *pntxt);
+#if !CTS
+#if AES_PADDING == 1
+#define AES_CBC_encrypt AES_CBC_encrypt_nocts_pkcs7
+#elif AES_PADDING == 2
+#define AES_CBC_encrypt AES_CBC_encrypt_nocts_iso7816
+#else
+#define AES_CBC_encrypt AES_CBC_encrypt_nocts
+#endif
+#define AES_CBC_decrypt AES_CBC_decrypt_nocts
+#endif
 
 void AES_CFB_encrypt(const uint8_t *key, const uint8_t iVec[16],
                      const void *pntxt, const size_t ptextLen, void *crtxt);

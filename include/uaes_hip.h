@@ -121,6 +121,10 @@ int uaes_ecb_encrypt_padded(int keybits, const uint8_t *key, int padding,
  * micro_aes.c:421-427).  Decrypt is the same function.                      */
 int uaes_ctr_xcrypt(int keybits, const uint8_t *key, const uint8_t *iv,
                     const void *in, size_t len, void *out);
+/* the same of a reference build with other CTR_IV_LENGTH / CTR_START_VALUE (micro_aes.h:98-99): counter block =
+ * iv[0..ivLen) || zeros, startValue XORed in big-endian ending at byte 15 (micro_aes.c:968-971); ivLen <= 16     */
+int uaes_ctr_xcrypt_iv(int keybits, const uint8_t *key, const uint8_t *iv, size_t ivLen, uint64_t startValue,
+                       const void *in, size_t len, void *out);
 /* Sharding extension: full 16-byte initial counter block (what the reference
  * builds internally, or takes directly when PRESET_COUNTER is 1,
  * micro_aes.h:100) plus a block offset added with the same 56-bit carry.
@@ -220,6 +224,14 @@ int uaes_cbc_encrypt(int keybits, const uint8_t *key, const uint8_t *iVec,
                      const void *pntxt, size_t ptextLen, void *crtxt);
 int uaes_cbc_decrypt(int keybits, const uint8_t *key, const uint8_t *iVec,
                      const void *crtxt, size_t crtxtLen, void *pntxt);
+/* CBC as a reference build with CTS 0 does it (micro_aes.h:56; micro_aes.c:704-733, :753-761): no stealing, no
+ * minimum length; the last chunk is padded like ECB's -- padding = AES_PADDING: 0 zeros behind a partial chunk,
+ * 1 PKCS#7 / 2 ISO 7816-4 always append -- so crtxt receives 16 * (ptextLen / 16 + (ptextLen % 16 || padding))
+ * bytes; decryption wants whole blocks (else UAES_E_DATALENGTH), is block-parallel, and leaves the padding.    */
+int uaes_cbc_encrypt_padded(int keybits, const uint8_t *key, const uint8_t *iVec, int padding,
+                            const void *pntxt, size_t ptextLen, void *crtxt);
+int uaes_cbc_decrypt_blocks(int keybits, const uint8_t *key, const uint8_t *iVec,
+                            const void *crtxt, size_t crtxtLen, void *pntxt);
 int uaes_cfb_encrypt(int keybits, const uint8_t *key, const uint8_t *iVec,
                      const void *pntxt, size_t ptextLen, void *crtxt);
 int uaes_cfb_decrypt(int keybits, const uint8_t *key, const uint8_t *iVec,

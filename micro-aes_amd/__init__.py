@@ -34,7 +34,7 @@ M_ENCRYPTION_ERROR = 0x1E
 EXPORTS = [
     "uaes_init", "uaes_shutdown", "uaes_selftest", "uaes_last_error", "uaes_version", "uaes_expand_key", "uaes_stream_release",
     "uaes_set_wipe_on_auth_failure", "uaes_set_gcm_one_pass_decrypt", "uaes_clock_probe_dev",
-    "uaes_ecb_encrypt", "uaes_ecb_encrypt_padded", "uaes_ecb_decrypt", "uaes_ctr_xcrypt", "uaes_ctr_xcrypt_at",
+    "uaes_ecb_encrypt", "uaes_ecb_encrypt_padded", "uaes_ecb_decrypt", "uaes_ctr_xcrypt", "uaes_ctr_xcrypt_iv", "uaes_ctr_xcrypt_at",
     "uaes_xts_encrypt", "uaes_xts_decrypt", "uaes_xts_sectors",
     "uaes_gcm_encrypt", "uaes_gcm_decrypt", "uaes_gcm_encrypt_iv", "uaes_gcm_decrypt_iv", "uaes_ghash",
     "uaes_gcm_encrypt_ex", "uaes_gcm_decrypt_ex", "uaes_ccm_encrypt_ex", "uaes_ccm_decrypt_ex",
@@ -49,13 +49,14 @@ EXPORTS = [
     "uaes_gcm_key_encrypt_records_v", "uaes_gcm_key_decrypt_records_v",
     "uaes_gcm_key_encrypt_records_v_dev", "uaes_gcm_key_decrypt_records_v_dev",
     "uaes_gcm_stream_begin", "uaes_gcm_stream_update", "uaes_gcm_stream_finish", "uaes_gcm_stream_abort",
-    "uaes_cbc_encrypt_batch", "uaes_cmac_batch", "uaes_cbc_encrypt", "uaes_cbc_decrypt", "uaes_cfb_encrypt", "uaes_cfb_decrypt", "uaes_ofb_xcrypt",
+    "uaes_cbc_encrypt_batch", "uaes_cmac_batch", "uaes_cbc_encrypt", "uaes_cbc_decrypt", "uaes_cbc_encrypt_padded", "uaes_cbc_decrypt_blocks", "uaes_cfb_encrypt", "uaes_cfb_decrypt", "uaes_ofb_xcrypt",
     "uaes_ecb_dev", "uaes_ctr_xcrypt_at_dev", "uaes_xts_sectors_dev",
     "uaes_gcm_encrypt_dev", "uaes_gcm_decrypt_dev", "uaes_gcm_partial_dev",
 ]
 COMPAT_EXPORTS = [
     "AES_ECB_encrypt", "AES_ECB_encrypt_pkcs7", "AES_ECB_encrypt_iso7816", "AES_ECB_decrypt",
-    "AES_CTR_encrypt", "AES_CTR_decrypt", "AES_CTR_encrypt_preset", "AES_CTR_decrypt_preset",
+    "AES_CTR_encrypt", "AES_CTR_decrypt", "AES_CTR_encrypt_preset", "AES_CTR_decrypt_preset", "AES_CTR_encrypt_iv",
+    "AES_CBC_encrypt_nocts", "AES_CBC_encrypt_nocts_pkcs7", "AES_CBC_encrypt_nocts_iso7816", "AES_CBC_decrypt_nocts",
     "uaes_compat_set_failure_handler",
     "AES_XTS_encrypt", "AES_XTS_decrypt", "AES_GCM_encrypt", "AES_GCM_decrypt",
     "AES_GCM_encrypt_ivlen", "AES_GCM_decrypt_ivlen", "AES_GCM_encrypt_lens", "AES_GCM_decrypt_lens",
@@ -116,6 +117,9 @@ def engine():
     L.uaes_ecb_encrypt_padded.argtypes = [i, vp, i, vp, sz, vp]
     L.uaes_ctr_xcrypt.argtypes = [i, vp, vp, vp, sz, vp]
     L.uaes_ctr_xcrypt_at.argtypes = [i, vp, vp, u64, vp, sz, vp]
+    L.uaes_ctr_xcrypt_iv.argtypes = [i, vp, vp, sz, u64, vp, sz, vp]
+    L.uaes_cbc_encrypt_padded.argtypes = [i, vp, vp, i, vp, sz, vp]
+    L.uaes_cbc_decrypt_blocks.argtypes = [i, vp, vp, vp, sz, vp]
     for n in ("uaes_xts_encrypt", "uaes_xts_decrypt"):
         getattr(L, n).argtypes = [i, vp, vp, vp, sz, vp]
     L.uaes_xts_sectors.argtypes = [i, vp, u64, sz, sz, vp, vp, i]
@@ -128,7 +132,7 @@ def engine():
         getattr(L, n).argtypes = [i, vp, vp, sz, sz, vp, sz, vp, sz, vp]
     L.uaes_ghash.argtypes = [vp, vp, sz, vp, sz, vp]
     L.uaes_cmac.argtypes = [i, vp, vp, sz, vp]
-    for n in ("uaes_cbc_encrypt", "uaes_cbc_decrypt", "uaes_cfb_encrypt", "uaes_cfb_decrypt", "uaes_ofb_xcrypt"):
+    for n in ("uaes_cbc_encrypt", "uaes_cbc_decrypt", "uaes_cbc_decrypt_blocks", "uaes_cfb_encrypt", "uaes_cfb_decrypt", "uaes_ofb_xcrypt"):
         getattr(L, n).argtypes = [i, vp, vp, vp, sz, vp]
     for n in ("uaes_ccm_encrypt", "uaes_ccm_decrypt", "uaes_gcmsiv_encrypt", "uaes_gcmsiv_decrypt",
               "uaes_ocb_encrypt", "uaes_ocb_decrypt"):
@@ -234,10 +238,17 @@ def AES_ECB_decrypt(key, crtxt):
     return rc, bytes(o)[: len(crtxt)]
 
 
-def AES_CTR_encrypt(key, iv, pntxt):
-    """micro_aes.c:962.  iv: 12 bytes; counter block = iv || 00000001."""
+def AES_CTR_encrypt(key, iv, pntxt, iv_length=12, start_value=1):
+    """micro_aes.c:962.  iv: 12 bytes; counter block = iv || 00000001.  iv_length / start_value = the reference's
+    compile-time CTR_IV_LENGTH (<= 16) / CTR_START_VALUE (micro_aes.h:98-99; 12 / 1 = the default build)."""
     o = _out(len(pntxt))
-    _check(engine().uaes_ctr_xcrypt(_bits(key), _in(key), _fixed(iv, 12, "iv"), _in(pntxt), len(pntxt), o), "AES_CTR_encrypt")
+    if not 0 <= iv_length <= 16 or not 0 <= start_value < 1 << 64:
+        raise ValueError("iv_length: 0..16; start_value: a 64-bit unsigned integer")
+    if iv_length == 12 and start_value == 1:
+        _check(engine().uaes_ctr_xcrypt(_bits(key), _in(key), _fixed(iv, 12, "iv"), _in(pntxt), len(pntxt), o), "AES_CTR_encrypt")
+    else:
+        _check(engine().uaes_ctr_xcrypt_iv(_bits(key), _in(key), _fixed(iv, iv_length, "iv"), iv_length, start_value,
+                                           _in(pntxt), len(pntxt), o), "AES_CTR_encrypt")
     return bytes(o)[: len(pntxt)]
 
 
@@ -315,14 +326,24 @@ def _fb(fn, name, key, iVec, data, prefill=0):
     return rc, bytes(o)[: len(data)]
 
 
-def AES_CBC_encrypt(key, iVec, pntxt, prefill=0):
-    """micro_aes.c:697 (CS3 ciphertext stealing).  Returns (code, ciphertext); code 1 if len < 16."""
-    return _fb(engine().uaes_cbc_encrypt, "AES_CBC_encrypt", key, iVec, pntxt, prefill)
+def AES_CBC_encrypt(key, iVec, pntxt, prefill=0, cts=True, padding=0):
+    """micro_aes.c:697 (CS3 ciphertext stealing).  Returns (code, ciphertext); code 1 if len < 16.
+    cts=False: a build with CTS 0 (micro_aes.h:56) -- no stealing, any length, the last chunk padded like ECB's
+    with padding = AES_PADDING (micro_aes.c:727-733): 16 * (len // 16 + (len % 16 or padding != 0)) bytes."""
+    if cts:
+        return _fb(engine().uaes_cbc_encrypt, "AES_CBC_encrypt", key, iVec, pntxt, prefill)
+    if padding not in (0, 1, 2):
+        raise ValueError("padding must be 0, 1 or 2")
+    n = len(pntxt) // 16 * 16 + (16 if (len(pntxt) % 16 or padding) else 0)
+    o = _out(n, prefill)
+    rc = _check(engine().uaes_cbc_encrypt_padded(_bits(key), _in(key), _fixed(iVec, 16, "iVec"), padding,
+                                                 _in(pntxt), len(pntxt), o), "AES_CBC_encrypt")
+    return rc, bytes(o)[:n]
 
 
-def AES_CBC_decrypt(key, iVec, crtxt, prefill=0):
-    """micro_aes.c:746."""
-    return _fb(engine().uaes_cbc_decrypt, "AES_CBC_decrypt", key, iVec, crtxt, prefill)
+def AES_CBC_decrypt(key, iVec, crtxt, prefill=0, cts=True):
+    """micro_aes.c:746.  cts=False: the CTS 0 build -- whole blocks only (code 1 otherwise, :761), padding left in place."""
+    return _fb(engine().uaes_cbc_decrypt if cts else engine().uaes_cbc_decrypt_blocks, "AES_CBC_decrypt", key, iVec, crtxt, prefill)
 
 
 def cbc_encrypt_batch(key, ivs, messages):

@@ -187,18 +187,21 @@ __global__ __launch_bounds__(UAES_WG) void k_fb_dec(uaesk_rk rk, uaesk_tables tb
     }
 }
 
-enum { CH_CBC_ENC = 0, CH_CFB_ENC = 1, CH_OFB = 2, CH_CBC_DEC_CTS = 3 };
+enum { CH_CBC_ENC = 0, CH_CFB_ENC = 1, CH_OFB = 2, CH_CBC_DEC_CTS = 3, CH_CBC_ENC_PAD = 4 };
 
 /* OP = CH_CBC_ENC     whole message, CS3 ciphertext stealing (AES_CBC_encrypt :697-744); len >= 16
  *      CH_CFB_ENC     whole message (:799-817 mode 1)
  *      CH_OFB         whole message (:861-886)
  *      CH_CBC_DEC_CTS the last two blocks {X full, Z r bytes} of AES_CBC_decrypt (:770-778):
- *                     in/out point at X; iv = the block before X (or the IV)          */
+ *                     in/out point at X; iv = the block before X (or the IV)
+ *      CH_CBC_ENC_PAD whole message of a build with CTS 0 (:704-733): no stealing, the last chunk padded by
+ *                     padBlock (:610-621) with aux = AES_PADDING (0: zeros behind a partial chunk only; 1 PKCS#7 and
+ *                     2 ISO 7816-4 always append); any len, writes 16 * (len / 16 + (len % 16 || aux)) bytes       */
 template <int NR, int OP>
 __global__ __launch_bounds__(UAES_WG) void k_chain_serial(uaesk_rk rk, uaesk_tables tb, uint4 iv4,
                                                           const uint4 *__restrict__ iv_dev,   /* overrides iv4 if set */
                                                           const unsigned char *in,
-                                                          unsigned char *out, u64 len)
+                                                          unsigned char *out, u64 len, u32 aux)
 {
     /* encrypt-direction chains: ONE wave; the sixteen lanes of a DPP row share each block encryption
      * (row_encrypt, uaes_aes.hip.h: one state byte and one lookup per lane and round), the four rows run
@@ -237,6 +240,22 @@ __global__ __launch_bounds__(UAES_WG) void k_chain_serial(uaesk_rk rk, uaesk_tab
                 m = row_encrypt<NR>(m ^ l0, L);
                 row_store(out + 16 * (n - 1), m, 16);
             }
+        } else if (OP == CH_CBC_ENC_PAD) {
+            const u64 n = len / 16;
+            const u32 r = (u32)(len % 16);
+            /* the padded last chunk as this lane's column word: text bytes below r, then the padding */
+            u32 l0 = r ? row_load(in + 16 * n, r, L.c) : 0u;
+#pragma unroll
+            for (u32 k = 0; k < 4; ++k) {
+                const u32 i = 4u * L.c + k;
+                const u32 pb = aux == 1 ? 16u - r : (aux == 2 && i == r ? 0x80u : 0u);
+                if (i >= r) l0 |= pb << (8u * k);
+            }
+            row_walk<A4>(in, n, L.c, [&](u64 i, u32 x) {
+                m = row_encrypt<NR>(m ^ x, L);
+                row_store_full<A4>(out + 16 * i, m, L.c);
+            });
+            if (r || aux) row_store(out + 16 * n, row_encrypt<NR>(m ^ l0, L), 16);
         } else if (OP == CH_CFB_ENC) {
             const u64 n = len / 16;
             const u32 r = (u32)(len % 16);
@@ -372,14 +391,14 @@ static int launch_fb_dec(hipStream_t st, const uaesk_tables *tb, const uaesk_rk 
 
 template <int NR, int OP>
 static int launch_serial(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *k, uint4 iv,
-                         const void *in, void *out, u64 len, const uint4 *iv_dev = nullptr)
+                         const void *in, void *out, u64 len, const uint4 *iv_dev = nullptr, u32 aux = 0)
 {
     const unsigned lds = OP == CH_CBC_DEC_CTS ? UAES_LDS_DEC : UAES_LDS_ROW;
     const unsigned threads = OP == CH_CBC_DEC_CTS ? UAES_WG : 64u;
     hipError_t e = uaesk_want_lds((const void *)k_chain_serial<NR, OP>, (unsigned)(lds));
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL((k_chain_serial<NR, OP>), dim3(1), dim3(threads), lds, st, *k, *tb, iv, iv_dev,
-                       (const unsigned char *)in, (unsigned char *)out, len);
+                       (const unsigned char *)in, (unsigned char *)out, len, aux);
     return (int)hipGetLastError();
 }
 
@@ -408,9 +427,10 @@ extern "C" int uaesk_chain_batch(void *stream, const uaesk_tables *tb, int nr, c
     return 0;
 }
 
-/* mode: 0 CBC encrypt, 1 CBC decrypt, 2 CFB encrypt, 3 CFB decrypt, 4 OFB.
+/* mode: 0 CBC encrypt, 1 CBC decrypt, 2 CFB encrypt, 3 CFB decrypt, 4 OFB;
+ *       5 + p: CBC encrypt of a build with CTS 0 and AES_PADDING p (0..2), 8: its CBC decrypt (whole blocks).
  * ek / dk: encryption / equivalent-inverse keys; iv16: host pointer.
- * Parallel directions (1, 3) require in != out.  CBC needs len >= 16.        */
+ * Parallel directions (1, 3, 8) require in != out.  CBC with stealing (0, 1) needs len >= 16.        */
 extern "C" int uaesk_feedback(void *stream, const uaesk_tables *tb, int nr,
                               const uaesk_rk *ek, const uaesk_rk *dk, int mode, const uint8_t *iv16,
                               const void *in, size_t len, void *out)
@@ -418,8 +438,13 @@ extern "C" int uaesk_feedback(void *stream, const uaesk_tables *tb, int nr,
     hipStream_t st = S(stream);
     uint4 iv;
     memcpy(&iv, iv16, 16);
-    if (len == 0) return 0;
+    if (len == 0 && mode != 6 && mode != 7) return 0;
     switch (mode) {
+    case 5: case 6: case 7:
+        DISPATCH_NR(nr, return (launch_serial<NR, CH_CBC_ENC_PAD>(st, tb, ek, iv, in, out, len, nullptr, (u32)(mode - 5)))); break;
+    case 8:
+        if (len % 16) return (int)hipErrorInvalidValue;
+        DISPATCH_NR(nr, return (launch_fb_dec<NR, false>(st, tb, dk, iv, in, out, len / 16, 0, 0))); break;
     case 0: DISPATCH_NR(nr, return (launch_serial<NR, CH_CBC_ENC>(st, tb, ek, iv, in, out, len))); break;
     case 2: DISPATCH_NR(nr, return (launch_serial<NR, CH_CFB_ENC>(st, tb, ek, iv, in, out, len))); break;
     case 4: DISPATCH_NR(nr, return (launch_serial<NR, CH_OFB>(st, tb, ek, iv, in, out, len))); break;

@@ -86,6 +86,14 @@ void AES_CTR_decrypt_preset(const uint8_t *key, const uint8_t *counter16,
     must("AES_CTR_decrypt", uaes_ctr_xcrypt_at(KB, key, counter16, 0, crtxt, crtxtLen, pntxt));
 }
 
+/* CTR_IV_LENGTH / CTR_START_VALUE (micro_aes.h:98-99, micro_aes.c:968-971) are the caller's compile-time
+ * constants as well: one general entry point, to which include/micro_aes.h binds a build that defines them */
+void AES_CTR_encrypt_iv(const size_t ivLen, const size_t startValue, const uint8_t *key, const uint8_t *iv,
+                        const void *pntxt, const size_t ptextLen, void *crtxt)
+{
+    must("AES_CTR_encrypt", uaes_ctr_xcrypt_iv(KB, key, iv, ivLen, startValue, pntxt, ptextLen, crtxt));
+}
+
 void AES_CTR_encrypt(const uint8_t *key, const uint8_t *iv,
                      const void *pntxt, const size_t ptextLen, void *crtxt)
 {
@@ -192,6 +200,35 @@ char AES_CCM_decrypt(const uint8_t *key, const uint8_t *nonce,
 void AES_CMAC(const uint8_t *key, const void *data, const size_t dataSize, uint8_t mac[16])
 {
     must("AES_CMAC", uaes_cmac(KB, key, data, dataSize, mac));
+}
+
+/* CTS (micro_aes.h:56) is the caller's compile-time choice too: with CTS 0 the reference's CBC pads its last
+ * chunk like ECB (AES_PADDING) instead of stealing (micro_aes.c:704-733) and its decryption wants whole blocks
+ * (:761).  Every library exports both families; include/micro_aes.h binds AES_CBC_* to the caller's.      */
+#undef AES_CBC_encrypt
+#undef AES_CBC_decrypt
+char AES_CBC_encrypt_nocts(const uint8_t *key, const uint8_t iVec[16],
+                           const void *pntxt, const size_t ptextLen, void *crtxt)
+{
+    return soft("AES_CBC_encrypt", uaes_cbc_encrypt_padded(KB, key, iVec, 0, pntxt, ptextLen, crtxt), M_ENCRYPTION_ERROR);
+}
+
+char AES_CBC_encrypt_nocts_pkcs7(const uint8_t *key, const uint8_t iVec[16],
+                                 const void *pntxt, const size_t ptextLen, void *crtxt)
+{
+    return soft("AES_CBC_encrypt", uaes_cbc_encrypt_padded(KB, key, iVec, 1, pntxt, ptextLen, crtxt), M_ENCRYPTION_ERROR);
+}
+
+char AES_CBC_encrypt_nocts_iso7816(const uint8_t *key, const uint8_t iVec[16],
+                                   const void *pntxt, const size_t ptextLen, void *crtxt)
+{
+    return soft("AES_CBC_encrypt", uaes_cbc_encrypt_padded(KB, key, iVec, 2, pntxt, ptextLen, crtxt), M_ENCRYPTION_ERROR);
+}
+
+char AES_CBC_decrypt_nocts(const uint8_t *key, const uint8_t iVec[16],
+                           const void *crtxt, const size_t crtxtLen, void *pntxt)
+{
+    return soft("AES_CBC_decrypt", uaes_cbc_decrypt_blocks(KB, key, iVec, crtxt, crtxtLen, pntxt), M_DECRYPTION_ERROR);
 }
 
 char AES_CBC_encrypt(const uint8_t *key, const uint8_t iVec[16],

@@ -1234,14 +1234,26 @@ int uaes_ctr_xcrypt_at(int keybits, const uint8_t *key, const uint8_t ctr0[16],
     DONE(L, rc);
 }
 
+/* ivLen / startValue = the reference's compile-time CTR_IV_LENGTH / CTR_START_VALUE (micro_aes.h:98-99): the counter
+ * block is the IV's first ivLen bytes with zeros behind them, and the start value XORed in as a big-endian integer
+ * that ends at byte 15 (micro_aes.c:968-971, xorBEint :410-415)                                                   */
+int uaes_ctr_xcrypt_iv(int keybits, const uint8_t *key, const uint8_t *iv, size_t ivLen, uint64_t startValue,
+                       const void *in, size_t len, void *out)
+{
+    uint8_t ctr0[16] = { 0 };
+    int pos = 15;
+    if (!iv && ivLen) return fail(UAES_E_ARG, "NULL iv");
+    if (ivLen > 16) return fail(UAES_E_ARG, "CTR IV length %zu (at most 16)", ivLen);
+    if (ivLen) memcpy(ctr0, iv, ivLen);
+    do ctr0[pos--] ^= (uint8_t)startValue; while ((startValue >>= 8) != 0);
+    return uaes_ctr_xcrypt_at(keybits, key, ctr0, 0, in, len, out);
+}
+
 int uaes_ctr_xcrypt(int keybits, const uint8_t *key, const uint8_t *iv,
                     const void *in, size_t len, void *out)
 {
-    uint8_t ctr0[16] = { 0 };
     if (!iv) return fail(UAES_E_ARG, "NULL iv");
-    memcpy(ctr0, iv, 12);                        /* CTR_IV_LENGTH, micro_aes.c:968-971 */
-    ctr0[15] ^= 1;                               /* CTR_START_VALUE                    */
-    return uaes_ctr_xcrypt_at(keybits, key, ctr0, 0, in, len, out);
+    return uaes_ctr_xcrypt_iv(keybits, key, iv, 12, 1, in, len, out);      /* CTR_IV_LENGTH 12, CTR_START_VALUE 1 */
 }
 
 /* ------------------------------------------------------------------------ */
@@ -2128,7 +2140,8 @@ int uaes_ccm_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
 /* ------------------------------------------------------------------------ */
 /* CBC / CFB / OFB                                   */
 /* ------------------------------------------------------------------------ */
-/* mode: 0 CBC enc, 1 CBC dec, 2 CFB enc, 3 CFB dec, 4 OFB */
+/* mode: 0 CBC enc, 1 CBC dec, 2 CFB enc, 3 CFB dec, 4 OFB; the CBC of a reference build with CTS 0 (micro_aes.h:56):
+ * 5 + p CBC enc that pads its last chunk with AES_PADDING p (micro_aes.c:727-733), 8 CBC dec of whole blocks (:761) */
 static int feedback_common(int keybits, const uint8_t *key, const uint8_t *iVec, int mode,
                            const void *in, size_t len, void *out)
 {
@@ -2137,15 +2150,21 @@ static int feedback_common(int keybits, const uint8_t *key, const uint8_t *iVec,
     keysched ks;
     io_plan io;
     int rc;
+    size_t out_len = len;
     if ((rc = expand_key(&ks, key, keybits)) != 0) return rc;
     if (!iVec) return fail(UAES_E_ARG, "NULL iVec");
     if (mode <= 1 && len < 16) return UAES_E_DATALENGTH;          /* CTS: data size >= BLOCKSIZE (:708, :758) */
-    if (len == 0) return 0;
-    if (!in || !out) return fail(UAES_E_ARG, "NULL data pointer");
+    if (mode == 8 && len % 16) return UAES_E_DATALENGTH;          /* no CTS: whole blocks (:761)              */
+    if (mode >= 5 && mode <= 7) {
+        if (len > (size_t)-1 - 16) return fail(UAES_E_ARG, "length overflows");
+        out_len = len - len % 16 + ((len % 16 || mode > 5) ? 16 : 0);       /* padBlock (:610-621)            */
+    }
+    if (out_len == 0) return 0;
+    if ((len && !in) || !out) return fail(UAES_E_ARG, "NULL data pointer");
     if ((rc = enter(&c, &L)) != 0) return rc;
     do {
-        if ((rc = plan_io(L, in, len, out, len, &io)) != 0) break;
-        if ((mode == 1 || mode == 3) && io.din == io.dout) {
+        if ((rc = plan_io(L, in, len, out, out_len, &io)) != 0) break;
+        if ((mode == 1 || mode == 3 || mode == 8) && io.din == io.dout) {
             /* the parallel directions read C_{i-1} from the input: give them a private copy */
             if (grow_on(L->stream, &L->stage[1], &L->stage_cap[1], len + 64)) { rc = UAES_E_HIP; break; }
             if (hipMemcpyAsync(L->stage[1], io.din, len, hipMemcpyDeviceToDevice, (hipStream_t)L->stream) != hipSuccess) {
@@ -2156,9 +2175,26 @@ static int feedback_common(int keybits, const uint8_t *key, const uint8_t *iVec,
         }
         int k = uaesk_feedback(L->stream, &c->tb, ks.nr, &ks.ek, &ks.dk, mode, iVec, io.din, len, io.dout);
         if (k) { rc = fail(UAES_E_HIP, "feedback-mode launch: %s", hipGetErrorString((hipError_t)k)); break; }
-        rc = finish_io(&io, len);
+        rc = finish_io(&io, out_len);
     } while (0);
     DONE(L, rc);
+}
+
+/* CBC as a reference build with CTS 0 does it (micro_aes.h:56, micro_aes.c:704-733, :753-761): no ciphertext stealing
+ * and no minimum length; the last chunk is padded like ECB's (padding = AES_PADDING: 0 zeros behind a partial chunk,
+ * 1 PKCS#7 / 2 ISO 7816-4 always append), so crtxt receives 16 * (ptextLen / 16 + (ptextLen % 16 || padding)) bytes;
+ * decryption wants whole blocks (else UAES_E_DATALENGTH) and leaves the padding in place                         */
+int uaes_cbc_encrypt_padded(int keybits, const uint8_t *key, const uint8_t *iVec, int padding,
+                            const void *pntxt, size_t ptextLen, void *crtxt)
+{
+    if (padding < 0 || padding > 2) return fail(UAES_E_ARG, "padding %d (0 zeros, 1 PKCS#7, 2 ISO/IEC 7816-4)", padding);
+    return feedback_common(keybits, key, iVec, 5 + padding, pntxt, ptextLen, crtxt);
+}
+
+int uaes_cbc_decrypt_blocks(int keybits, const uint8_t *key, const uint8_t *iVec,
+                            const void *crtxt, size_t crtxtLen, void *pntxt)
+{
+    return feedback_common(keybits, key, iVec, 8, crtxt, crtxtLen, pntxt);
 }
 
 int uaes_cbc_encrypt(int keybits, const uint8_t *key, const uint8_t *iVec,

@@ -54,6 +54,9 @@ class Oracle:
         L.orc_ecb_decrypt.argtypes = [i, vp, vp, sz, vp]; L.orc_ecb_decrypt.restype = C.c_char
         L.orc_ctr_encrypt.argtypes = [i, vp, vp, vp, sz, vp]; L.orc_ctr_encrypt.restype = None
         L.orc_ctr_xcrypt_at.argtypes = [i, vp, vp, u64, vp, sz, vp]; L.orc_ctr_xcrypt_at.restype = None
+        L.orc_ctr_encrypt_iv.argtypes = [i, vp, vp, sz, u64, vp, sz, vp]; L.orc_ctr_encrypt_iv.restype = None
+        L.orc_cbc_encrypt_nocts.argtypes = [i, vp, vp, i, vp, sz, vp, C.POINTER(sz)]; L.orc_cbc_encrypt_nocts.restype = C.c_char
+        L.orc_cbc_decrypt_nocts.argtypes = [i, vp, vp, vp, sz, vp]; L.orc_cbc_decrypt_nocts.restype = C.c_char
         for f in (L.orc_xts_encrypt, L.orc_xts_decrypt):
             f.argtypes = [i, vp, vp, vp, sz, vp]; f.restype = C.c_char
         L.orc_xts_sectors.argtypes = [i, vp, u64, sz, sz, vp, vp, i]; L.orc_xts_sectors.restype = C.c_char
@@ -102,6 +105,12 @@ class Oracle:
         self.L.orc_ctr_encrypt(len(key) * 8, _buf(key), _buf(iv), _buf(data), len(data), o)
         return bytes(o)[: len(data)]
 
+    def ctr_encrypt_iv(self, key, iv, start, data):
+        """a build with CTR_IV_LENGTH = len(iv) (<= 16) and CTR_START_VALUE = start (micro_aes.h:98-99)"""
+        o = _out(len(data))
+        self.L.orc_ctr_encrypt_iv(len(key) * 8, _buf(key), _buf(iv), len(iv), start, _buf(data), len(data), o)
+        return bytes(o)[: len(data)]
+
     def ctr_xcrypt_at(self, key, ctr0, block_offset, data):
         o = _out(len(data))
         self.L.orc_ctr_xcrypt_at(len(key) * 8, _buf(key), _buf(ctr0), block_offset,
@@ -139,6 +148,18 @@ class Oracle:
         o = (C.c_uint8 * max(len(data), 1))(*([prefill] * max(len(data), 1)))
         f = self.L.orc_cbc_encrypt if encrypt else self.L.orc_cbc_decrypt
         rc = f(len(key) * 8, _buf(key), _buf(iv), _buf(data), len(data), o)
+        return ord(rc), bytes(o)[: len(data)]
+
+    def cbc_nocts(self, key, iv, data, encrypt=True, padding=0, prefill=0xCC):
+        """CBC of a build with CTS 0: encrypt pads like ECB (padding = AES_PADDING) and returns the padded
+        length's worth; decrypt wants whole blocks (else 0x1D... the reference's M_DATALENGTH_ERROR = 1)"""
+        cap = len(data) + 16
+        o = (C.c_uint8 * cap)(*([prefill] * cap))
+        if encrypt:
+            n = C.c_size_t(0)
+            rc = self.L.orc_cbc_encrypt_nocts(len(key) * 8, _buf(key), _buf(iv), padding, _buf(data), len(data), o, C.byref(n))
+            return ord(rc), bytes(o)[: n.value]
+        rc = self.L.orc_cbc_decrypt_nocts(len(key) * 8, _buf(key), _buf(iv), _buf(data), len(data), o)
         return ord(rc), bytes(o)[: len(data)]
 
     def cfb(self, key, iv, data, encrypt=True):
@@ -230,18 +251,35 @@ class Reference:
     # name -> (key bits, CCM_NONCE_LEN, CCM_TAG_LEN, GCM_TAG_LEN, OCB_NONCE_LEN, OCB_TAG_LEN)
     LENS = {"A": (128, 13, 4, 12, 15, 8), "B": (256, 7, 10, 4, 7, 12)}
 
+    # builds with CTS 0 (micro_aes.h:56; CBC pads like ECB then, AES_PADDING as given) and with other
+    # CTR_IV_LENGTH / CTR_START_VALUE (micro_aes.h:98-99); oracle/Makefile has the same tables:
+    # name -> (key bits, AES_PADDING)  /  name -> (key bits, CTR_IV_LENGTH, CTR_START_VALUE)
+    NOCTS = {"nocts": (128, 0), "nocts_pkcs7": (256, 1), "nocts_iso7816": (192, 2)}
+    CTRV = {"ctrA": (128, 8, 0x01A2B3C4), "ctrB": (256, 16, 2)}
+
     @classmethod
-    def path(cls, bits, padding=0, gcm_nonce_len=12, preset_counter=False, lens=None):
+    def path(cls, bits, padding=0, gcm_nonce_len=12, preset_counter=False, lens=None, variant=None):
+        if variant:
+            return os.path.join(HERE, "_ref", "libmicroaes_ref_%d_%s.so" % (bits, variant))
         iv = "" if gcm_nonce_len == 12 else "_gcmiv%d" % gcm_nonce_len
         pc = "_presetctr" if preset_counter else ""
         ln = "_lens%s" % lens if lens else ""
         return os.path.join(HERE, "_ref", "libmicroaes_ref_%d%s%s%s%s.so" % (bits, cls.PAD_SUFFIX[padding], iv, pc, ln))
 
     @classmethod
-    def available(cls, bits=128, padding=0, gcm_nonce_len=12, preset_counter=False, lens=None):
-        return os.path.exists(cls.path(bits, padding, gcm_nonce_len, preset_counter, lens))
+    def available(cls, bits=128, padding=0, gcm_nonce_len=12, preset_counter=False, lens=None, variant=None):
+        return os.path.exists(cls.path(bits, padding, gcm_nonce_len, preset_counter, lens, variant))
 
-    def __init__(self, bits, padding=0, gcm_nonce_len=12, preset_counter=False, lens=None):
+    @classmethod
+    def of_variant(cls, variant):
+        """the build named in NOCTS / CTRV, or None if it did not travel"""
+        bits = (cls.NOCTS.get(variant) or cls.CTRV[variant])[0]
+        if not cls.available(bits, variant=variant):
+            return None
+        r = cls(bits, padding=cls.NOCTS[variant][1] if variant in cls.NOCTS else 0, variant=variant)
+        return r
+
+    def __init__(self, bits, padding=0, gcm_nonce_len=12, preset_counter=False, lens=None, variant=None):
         """padding / gcm_nonce_len / preset_counter: builds with AES_PADDING (micro_aes.h:79) /
         GCM_NONCE_LEN (:108) / PRESET_COUNTER (:100) patched (oracle/Makefile).  With preset_counter the
         `iv` of ctr_encrypt is the full 16-byte counter block (micro_aes.c:965-966)."""
@@ -253,7 +291,9 @@ class Reference:
         if lens:
             assert self.LENS[lens][0] == bits
             self.ccm_nonce, self.ccm_tag, self.gcm_tag, self.ocb_nonce, self.ocb_tag = self.LENS[lens][1:]
-        L = self.L = C.CDLL(self.path(bits, padding, gcm_nonce_len, preset_counter, lens))
+        self.variant = variant
+        self.ctr_iv_len, self.ctr_start = (self.CTRV[variant][1:] if variant in self.CTRV else (12, 1))
+        L = self.L = C.CDLL(self.path(bits, padding, gcm_nonce_len, preset_counter, lens, variant))
         sz, vp = C.c_size_t, C.c_void_p
         L.AES_ECB_encrypt.argtypes = [vp, vp, sz, vp]; L.AES_ECB_encrypt.restype = None
         L.AES_ECB_decrypt.argtypes = [vp, vp, sz, vp]; L.AES_ECB_decrypt.restype = C.c_char
@@ -309,6 +349,18 @@ class Reference:
         f = self.L.AES_CBC_encrypt if encrypt else self.L.AES_CBC_decrypt
         rc = f(_buf(key), _buf(iv), _buf(data), len(data), o)
         return ord(rc), bytes(o)[: len(data)]
+
+    def cbc_nocts(self, key, iv, data, encrypt=True, prefill=0xCC):
+        """only on a CTS 0 build (variant in NOCTS): AES_CBC_encrypt pads (micro_aes.c:727-733)"""
+        self._chk(key)
+        assert self.variant in self.NOCTS
+        r = len(data) % 16
+        n = len(data) if not encrypt else (len(data) - r + (16 if (r or self.padding) else 0))
+        cap = len(data) + 16
+        o = (C.c_uint8 * cap)(*([prefill] * cap))
+        f = self.L.AES_CBC_encrypt if encrypt else self.L.AES_CBC_decrypt
+        rc = f(_buf(key), _buf(iv), _buf(data), len(data), o)
+        return ord(rc), bytes(o)[:n]
 
     def cfb(self, key, iv, data, encrypt=True):
         self._chk(key)

@@ -257,13 +257,23 @@ void orc_ctr_xcrypt_at(int keybits, const uint8_t *key, const uint8_t ctr0[16],
     ctr_stream(&ks, c, (const uint8_t *)in, len, (uint8_t *)out);
 }
 
+/* a build with other CTR_IV_LENGTH / CTR_START_VALUE (micro_aes.h:98-99): the counter block is
+ * the IV's first iv_len bytes, zeros behind them, and the start value XORed in as a big-endian
+ * integer ending at byte 15 (xorBEint :410-415: at least one byte, then while bytes remain)     */
+void orc_ctr_encrypt_iv(int keybits, const uint8_t *key, const uint8_t *iv, size_t iv_len, uint64_t start,
+                        const void *in, size_t len, void *out)
+{
+    uint8_t c[16] = { 0 };
+    int pos = 15;
+    memcpy(c, iv, iv_len > 16 ? 16 : iv_len);  /* CTR_IV_LENGTH, :968-971     */
+    do c[pos--] ^= (uint8_t)start; while ((start >>= 8) != 0);
+    orc_ctr_xcrypt_at(keybits, key, c, 0, in, len, out);
+}
+
 void orc_ctr_encrypt(int keybits, const uint8_t *key, const uint8_t *iv,
                      const void *in, size_t len, void *out)
 {
-    uint8_t c[16] = { 0 };
-    memcpy(c, iv, 12);                         /* CTR_IV_LENGTH, :968-971     */
-    c[15] ^= 1;                                /* CTR_START_VALUE = 1         */
-    orc_ctr_xcrypt_at(keybits, key, c, 0, in, len, out);
+    orc_ctr_encrypt_iv(keybits, key, iv, 12, 1, in, len, out);   /* CTR_IV_LENGTH 12, CTR_START_VALUE 1 */
 }
 
 /* ------------------------------------------------------------------------ */
@@ -548,6 +558,58 @@ char orc_cbc_decrypt(int keybits, const uint8_t *key, const uint8_t iv[16],
         orc_decrypt_block(&ks, c, c);
         xor16(c, prev);
         memcpy(y + 16 * n, c, 16);
+    }
+    return ORC_OK;
+}
+
+/* CBC of a reference build with CTS 0 (micro_aes.c:704-708, :727-733, :753-761): no stealing; the
+ * last chunk is padded like ECB's (padBlock :610-621: zeros only if it is partial; PKCS#7 and
+ * ISO 7816-4 ALWAYS append, so ct holds (len / 16 + 1) * 16 bytes then), no minimum length;
+ * decryption wants whole blocks (:761) and does not strip the padding.  *out_len = bytes written. */
+char orc_cbc_encrypt_nocts(int keybits, const uint8_t *key, const uint8_t iv[16], int padding,
+                           const void *pt, size_t len, void *ct, size_t *out_len)
+{
+    orc_key ks;
+    const uint8_t *x = (const uint8_t *)pt;
+    uint8_t *y = (uint8_t *)ct, chain[16];
+    const size_t n = len / 16, r = len % 16;
+    size_t i;
+    if (orc_setkey(&ks, key, keybits)) return ORC_E_ENCRYPT;
+    memcpy(chain, iv, 16);
+    for (i = 0; i < n; ++i) {
+        uint8_t b[16];
+        memcpy(b, x + 16 * i, 16);
+        xor16(b, chain);
+        orc_encrypt_block(&ks, b, chain);
+        memcpy(y + 16 * i, chain, 16);
+    }
+    if (r || padding) {
+        uint8_t last[16] = { 0 };
+        if (r) memcpy(last, x + 16 * n, r);
+        if (padding == 1) memset(last + r, (int)(16 - r), 16 - r);
+        else if (padding == 2) last[r] = 0x80;
+        xor16(last, chain);
+        orc_encrypt_block(&ks, last, y + 16 * n);
+    }
+    if (out_len) *out_len = 16 * (n + ((r || padding) ? 1 : 0));
+    return ORC_OK;
+}
+
+char orc_cbc_decrypt_nocts(int keybits, const uint8_t *key, const uint8_t iv[16],
+                           const void *ct, size_t len, void *pt)
+{
+    orc_key ks;
+    const uint8_t *x = (const uint8_t *)ct;
+    uint8_t *y = (uint8_t *)pt, prev[16], cur[16];
+    size_t i;
+    if (len % 16) return ORC_E_DATALENGTH;
+    if (orc_setkey(&ks, key, keybits)) return ORC_E_DECRYPT;
+    memcpy(prev, iv, 16);
+    for (i = 0; i < len / 16; ++i) {
+        memcpy(cur, x + 16 * i, 16);
+        orc_decrypt_block(&ks, cur, y + 16 * i);
+        xor16(y + 16 * i, prev);
+        memcpy(prev, cur, 16);
     }
     return ORC_OK;
 }

@@ -63,6 +63,9 @@ char orc_ecb_decrypt(int keybits, const uint8_t *key,
 /* micro_aes.c:962-990.  iv = 12 bytes; counter = iv || 00000001 (N2, N3) */
 void orc_ctr_encrypt(int keybits, const uint8_t *key, const uint8_t *iv,
                      const void *in, size_t len, void *out);
+/* CTR_IV_LENGTH = iv_len (<= 16), CTR_START_VALUE = start (micro_aes.h:98-99, micro_aes.c:968-971) */
+void orc_ctr_encrypt_iv(int keybits, const uint8_t *key, const uint8_t *iv, size_t iv_len, uint64_t start,
+                        const void *in, size_t len, void *out);
 /* extension used by sharded CTR: 16-byte initial counter block plus a block
  * offset that is added with the reference's 56-bit big-endian carry (N2)   */
 void orc_ctr_xcrypt_at(int keybits, const uint8_t *key, const uint8_t ctr0[16],
@@ -112,6 +115,11 @@ char orc_cbc_encrypt(int keybits, const uint8_t *key, const uint8_t iv[16],
                      const void *pt, size_t len, void *ct);
 char orc_cbc_decrypt(int keybits, const uint8_t *key, const uint8_t iv[16],
                      const void *ct, size_t len, void *pt);
+/* the same of a reference build with CTS 0 (micro_aes.c:704-733, :753-761); padding = AES_PADDING */
+char orc_cbc_encrypt_nocts(int keybits, const uint8_t *key, const uint8_t iv[16], int padding,
+                           const void *pt, size_t len, void *ct, size_t *out_len);
+char orc_cbc_decrypt_nocts(int keybits, const uint8_t *key, const uint8_t iv[16],
+                           const void *ct, size_t len, void *pt);
 /* micro_aes.c:799-845 CFB (encrypt != 0 / decrypt), :861-893 OFB */
 void orc_cfb(int keybits, const uint8_t *key, const uint8_t iv[16], int encrypt,
              const void *in, size_t len, void *out);

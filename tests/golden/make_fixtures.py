@@ -24,6 +24,9 @@ source text):
   for ECB/CTR/XTS/GCM at 128/192/256 bits, plus error-path behaviour (N1,N5,N7).
 * ``ecb_padding_vectors.json`` -- AES_ECB_encrypt of reference builds with AES_PADDING 1 / 2
   (micro_aes.h:79) on seeded inputs, and the main.c AES-192 PKCS#7 known answer (main.c:86,139).
+* ``build_variant_vectors.json`` -- AES_CBC_* of reference builds with CTS 0 (micro_aes.h:56) and each AES_PADDING,
+  AES_CTR_encrypt of builds with other CTR_IV_LENGTH / CTR_START_VALUE (micro_aes.h:98-99), and main.c's CTS 0
+  known answer (main.c:36-40); ``--variants`` rewrites only this file.
 * ``digests.json`` -- SHA-256 digests of the reference's output on the
   BASELINE.json workloads.  Cheap ones are recomputed
   here; the multi-GiB ones are recomputed only with --big (minutes of CPU).
@@ -412,7 +415,51 @@ def ecb_padding_vectors(orc):
     return vecs
 
 
+def build_variant_vectors(orc):
+    """AES_CBC_* of reference builds with CTS 0 and each AES_PADDING (micro_aes.h:56,79; micro_aes.c:704-733,
+    :753-761) and AES_CTR_encrypt of builds with other CTR_IV_LENGTH / CTR_START_VALUE (micro_aes.h:98-99), on
+    seeded inputs, plus main.c's own CTS 0 known answer (main.c:36-40, :149)"""
+    rng = random.Random(0x6e6f6374)
+    cbc, ctr = [], []
+    ref = Reference.of_variant("nocts")
+    key, iv, pt = bytes.fromhex(MAIN_KEY)[:16], bytes.fromhex(MAIN_IV), bytes.fromhex(MAIN_PT)
+    main_c = ("65c48fdf9fbd626128f2d8bac3f7125175e7f4821fda026370011632779d7403"
+              "7E9E2D298E154BC42Dc7a9bc419b915dc119ef461ac4e1bc8a7e36bf92b3b3d1").lower()
+    rc, out = ref.cbc_nocts(key, iv, pt, True)
+    assert rc == 0 and out.hex() == main_c                            # main.c:30-40,147-149 with CTS 0
+    cbc.append(dict(name="main.c:149 CBC AES-128 CTS 0", variant="nocts", keybits=128, padding=0, key=key.hex(),
+                    iv=iv.hex(), pt=pt.hex(), out={"hex": main_c}))
+    for v, (bits, padding) in Reference.NOCTS.items():
+        ref = Reference.of_variant(v)
+        for n in [0, 1, 15, 16, 17, 31, 32, 33, 48, 255, 256, 4095, 4096, 4097, 65541]:
+            seed = rng.getrandbits(32)
+            k, ivv = rng.randbytes(bits // 8), rng.randbytes(16)
+            data = splitmix(orc, seed, n)
+            rc, out = ref.cbc_nocts(k, ivv, data, True)
+            assert rc == 0
+            rcd, back = ref.cbc_nocts(k, ivv, out, False)
+            assert rcd == 0 and back[:n] == data
+            cbc.append(dict(variant=v, keybits=bits, padding=padding, len=n, seed=seed, key=k.hex(), iv=ivv.hex(),
+                            out=enc_out(out), ragged_decrypt_rc=ref.cbc_nocts(k, ivv, data, False)[0] if n % 16 else 0))
+    for v, (bits, ivl, start) in Reference.CTRV.items():
+        ref = Reference.of_variant(v)
+        for n in [0, 1, 15, 16, 17, 33, 255, 4096, 4097, 65541]:
+            seed = rng.getrandbits(32)
+            k, ivv = rng.randbytes(bits // 8), rng.randbytes(ivl)
+            if n == 4097:
+                ivv = ivv[:9] + b"\xff" * (ivl - 9) if ivl > 9 else ivv      # counter bytes about to carry
+            ctr.append(dict(variant=v, keybits=bits, iv_length=ivl, start_value=start, len=n, seed=seed, key=k.hex(),
+                            iv=ivv.hex(), out=enc_out(ref.ctr_encrypt(k, ivv, splitmix(orc, seed, n)))))
+    return dict(cbc_nocts=cbc, ctr_iv=ctr)
+
+
 def main():
+    if "--variants" in sys.argv:           # only the build-variant vectors (leaves the other fixtures as they are)
+        build()
+        with open(os.path.join(HERE, "build_variant_vectors.json"), "w") as f:
+            json.dump(build_variant_vectors(Oracle()), f, indent=0)
+        print("build_variant_vectors.json written")
+        return
     big = "--big" in sys.argv
     build()
     orc = Oracle()
@@ -431,6 +478,8 @@ def main():
         json.dump(ref_vectors(orc), f, indent=0)
     with open(os.path.join(HERE, "ecb_padding_vectors.json"), "w") as f:
         json.dump(ecb_padding_vectors(orc), f, indent=0)
+    with open(os.path.join(HERE, "build_variant_vectors.json"), "w") as f:
+        json.dump(build_variant_vectors(orc), f, indent=0)
     with open(os.path.join(HERE, "digests.json"), "w") as f:
         json.dump(digests(orc, big), f, indent=1)
     print("fixtures written to", HERE)

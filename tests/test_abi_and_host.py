@@ -76,6 +76,22 @@ def test_compat_header_binds_function_pointers_under_the_callers_switches(tmp_pa
     assert "AES_ECB_encrypt_pkcs7" in syms and "AES_CCM_encrypt_lens" in syms and "AES_OCB_encrypt_lens" in syms
     assert not re.search(r"\bAES_GCM_encrypt$|\bAES_CTR_encrypt$|\bAES_ECB_encrypt$|\bAES_CCM_encrypt$|\bAES_OCB_encrypt$",
                          syms, flags=re.M)
+    # CTS 0 / other CTR constants bind likewise (micro_aes.h:56, :98-99)
+    src2 = tmp_path / "q.c"
+    src2.write_text('#include "micro_aes.h"\n'
+                    'typedef void (*ctr_fn)(const uint8_t*, const uint8_t*, const void*, const size_t, void*);\n'
+                    'typedef char (*cbc_fn)(const uint8_t*, const uint8_t*, const void*, const size_t, void*);\n'
+                    'ctr_fn table_c[2] = { AES_CTR_encrypt, AES_CTR_decrypt };\n'
+                    'cbc_fn table_b[2] = { AES_CBC_encrypt, AES_CBC_decrypt };\n'
+                    'int main(void) { return (table_c[0] && table_b[0] && CTR_IV_LENGTH == 8 && CTR_START_VALUE == 7 && !CTS) ? 0 : 1; }\n')
+    subprocess.run(["gcc", "-std=c89", "-pedantic", "-Wall", "-Werror", "-DCTS=0", "-DAES_PADDING=2", "-DCTR_IV_LENGTH=8",
+                    "-DCTR_START_VALUE=7", "-I", os.path.join(ROOT, "include"), "-c", str(src2), "-o", str(obj)], check=True)
+    syms2 = subprocess.run(["nm", "-u", str(obj)], check=True, capture_output=True, text=True).stdout
+    assert "AES_CBC_encrypt_nocts_iso7816" in syms2 and "AES_CBC_decrypt_nocts" in syms2 and "AES_CTR_encrypt_iv" in syms2
+    assert not re.search(r"\bAES_CBC_encrypt$|\bAES_CBC_decrypt$|\bAES_CTR_encrypt$", syms2, flags=re.M)
+    bad = subprocess.run(["gcc", "-std=c89", "-DCTR_IV_LENGTH=17", "-I", os.path.join(ROOT, "include"), "-c", str(src2), "-o", str(obj)],
+                         capture_output=True, text=True)
+    assert bad.returncode != 0 and "uaes_ctr_lengths_ok" in bad.stderr
     # a length outside the mode's range does not compile
     bad = subprocess.run(["gcc", "-std=c89", "-DCCM_TAG_LEN=5", "-I", os.path.join(ROOT, "include"), "-c", str(src), "-o", str(obj)],
                          capture_output=True, text=True)

@@ -109,3 +109,15 @@ def test_reference_main_c_preset_counter_runs_on_the_hip_library():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "FAILED" not in r.stdout, r.stdout + r.stderr
     assert re.findall(r"AES-128 (CTR) \w+: PASSED!", r.stdout) == ["CTR", "CTR"], r.stdout
+
+
+def test_reference_main_c_without_cts_runs_on_the_hip_library():
+    """main.c built with -DCTS=0 (micro_aes.h:56) checks CBC against its zero-padded known answer (main.c:36-40,
+    :149-150: the whole padded ciphertext, and decryption of it); include/micro_aes.h then binds AES_CBC_* to the
+    *_nocts entry points (padded last chunk, block-parallel whole-block decryption)"""
+    exe = os.path.join(REF, "main_hip_128_nocts")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/main_hip_128_nocts was not built")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "FAILED" not in r.stdout, r.stdout + r.stderr
+    assert re.findall(r"AES-128 (CBC) \w+: PASSED!", r.stdout) == ["CBC", "CBC"], r.stdout

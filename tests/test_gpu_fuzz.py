@@ -237,6 +237,43 @@ def test_fuzz_feedback_and_macs(orc):
     run_cases(404, 80, body)
 
 
+def test_fuzz_cbc_without_cts_and_ctr_constants(orc):
+    """the CTS 0 build's CBC (padded last chunk, whole-block decrypt) and CTR with other CTR_IV_LENGTH /
+    CTR_START_VALUE, any placement of the buffers (host / device, misaligned, in place)"""
+    L = uaes.engine()
+
+    def body(rnd, i):
+        bits = rnd.choice([128, 192, 256])
+        key, iv = rnd.randbytes(bits // 8), rnd.randbytes(16)
+        n = pick_size(rnd, 24 << 10)
+        padding = rnd.choice([0, 1, 2])
+        data = orc.splitmix(9000 + i, n)
+        rc, want = orc.cbc_nocts(key, iv, data, True, padding=padding)
+        b = Buffers(rnd, data, len(want))
+        info = ("cbc-nocts", bits, n, padding, b.describe())
+        assert rc == 0 and L.uaes_cbc_encrypt_padded(bits, key, iv, padding, b.pin, n, b.pout) == 0, info
+        got, guard_ok = b.result()
+        assert got == want and guard_ok, info
+        b = Buffers(rnd, want, len(want))
+        assert L.uaes_cbc_decrypt_blocks(bits, key, iv, b.pin, len(want), b.pout) == 0, info
+        got, guard_ok = b.result()
+        assert got == orc.cbc_nocts(key, iv, want, False)[1] and got[:n] == data and guard_ok, info
+        if len(want) > 16:                                   # a ragged length is refused, nothing written
+            b = Buffers(rnd, want, len(want))
+            before = b.result()[0]
+            assert L.uaes_cbc_decrypt_blocks(bits, key, iv, b.pin, len(want) - 3, b.pout) == 1, info
+            assert b.result()[0] == before, info
+        ivl, start = rnd.choice([0, 1, 8, 11, 12, 13, 16]), rnd.choice([0, 1, 2, 255, 256, 0xFFFFFFFF, rnd.getrandbits(64)])
+        civ = rnd.randbytes(ivl)
+        b = Buffers(rnd, data, n)
+        info = ("ctr-iv", bits, n, ivl, start, b.describe())
+        assert L.uaes_ctr_xcrypt_iv(bits, key, civ, ivl, start, b.pin, n, b.pout) == 0, info
+        got, guard_ok = b.result()
+        assert got == orc.ctr_encrypt_iv(key, civ, start, data) and guard_ok, info
+
+    run_cases(505, 60, body)
+
+
 def test_fuzz_nonce_and_tag_lengths(orc):
     """GCM / CCM / OCB with the reference's other compile-time lengths (micro_aes.h:103-116) as run-time arguments:
     random legal nonce and tag lengths, host or device buffers at odd offsets, in place or not; nothing is written

@@ -676,6 +676,68 @@ def test_feedback_modes_vs_oracle(orc, bits):
     assert uaes.AES_CFB_encrypt(key, iv, b"") == b"" and uaes.AES_OFB_encrypt(key, iv, b"abc") == orc.ofb(key, iv, b"abc")
 
 
+def test_build_variant_vectors_cbc_without_cts_and_other_ctr_constants(orc, golden_dir):
+    """The reference's other compile-time builds of two in-scope functions, through the C ABI and through the
+    compat libraries' entry points that include/micro_aes.h binds such a caller to:
+    CTS 0 (micro_aes.h:56): AES_CBC_encrypt pads its last chunk like ECB (AES_PADDING 0/1/2, micro_aes.c:727-733),
+    any length; AES_CBC_decrypt wants whole blocks (:761) -- block-parallel here -- and keeps the padding;
+    CTR_IV_LENGTH / CTR_START_VALUE (micro_aes.h:98-99, micro_aes.c:968-971).
+    Against vectors made by reference builds with those switches (incl. main.c's own CTS 0 answer) and the oracle."""
+    vecs = load(golden_dir, "build_variant_vectors.json")
+    for v in vecs["cbc_nocts"]:
+        key, iv = bytes.fromhex(v["key"]), bytes.fromhex(v["iv"])
+        data = bytes.fromhex(v["pt"]) if "pt" in v else orc.splitmix(v["seed"], (v["len"] + 7) // 8 * 8)[: v["len"]]
+        rc, ct = uaes.AES_CBC_encrypt(key, iv, data, cts=False, padding=v["padding"])
+        assert rc == 0
+        check_out(ct, v["out"])
+        rc, back = uaes.AES_CBC_decrypt(key, iv, ct, cts=False)
+        assert rc == 0 and back[: len(data)] == data and back == orc.cbc_nocts(key, iv, ct, False)[1]
+        if len(data) % 16:
+            assert uaes.AES_CBC_decrypt(key, iv, data, prefill=0xCC, cts=False) == (1, b"\xcc" * len(data))
+    for v in vecs["ctr_iv"]:
+        key, iv = bytes.fromhex(v["key"]), bytes.fromhex(v["iv"])
+        data = orc.splitmix(v["seed"], (v["len"] + 7) // 8 * 8)[: v["len"]]
+        check_out(uaes.AES_CTR_encrypt(key, iv, data, iv_length=v["iv_length"], start_value=v["start_value"]), v["out"])
+    rnd = random.Random(0xC750)
+    sym = {0: "AES_CBC_encrypt_nocts", 1: "AES_CBC_encrypt_nocts_pkcs7", 2: "AES_CBC_encrypt_nocts_iso7816"}
+    for bits in (128, 192, 256):
+        lib = C.CDLL(uaes.lib_path("libmicro_aes_hip_%d.so" % bits))
+        lib.AES_CTR_encrypt_iv.argtypes = [C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        lib.AES_CTR_encrypt_iv.restype = None
+        for padding in (0, 1, 2):
+            f = getattr(lib, sym[padding])
+            f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+            f.restype = C.c_char
+            lib.AES_CBC_decrypt_nocts.argtypes = f.argtypes
+            lib.AES_CBC_decrypt_nocts.restype = C.c_char
+            for n in (0, 5, 16, 47, 48, 4096, 4099, 65537, (1 << 20) + 16):
+                key, iv, data = rnd.randbytes(bits // 8), rnd.randbytes(16), rnd.randbytes(n)
+                rc, want = orc.cbc_nocts(key, iv, data, True, padding=padding)
+                assert rc == 0
+                if n <= 65537:                              # the chain itself: 0.42 us per block
+                    assert uaes.AES_CBC_encrypt(key, iv, data, cts=False, padding=padding) == (0, want), (bits, padding, n)
+                    out = (C.c_uint8 * max(len(want), 1))()
+                    assert ord(f(key, iv, data, n, out)) == 0 and bytes(out)[: len(want)] == want
+                # decrypt: the parallel kernel, in place as well
+                assert uaes.AES_CBC_decrypt(key, iv, want, cts=False) == orc.cbc_nocts(key, iv, want, False), (bits, padding, n)
+                if want:
+                    buf = (C.c_uint8 * len(want)).from_buffer_copy(want)
+                    assert ord(lib.AES_CBC_decrypt_nocts(key, iv, buf, len(want), buf)) == 0
+                    assert bytes(buf) == orc.cbc_nocts(key, iv, want, False)[1]
+                    assert ord(lib.AES_CBC_decrypt_nocts(key, iv, buf, len(want) - 1, buf)) == 1      # M_DATALENGTH_ERROR
+        for ivl, start in ((0, 0), (4, 0xFFFFFFFF), (8, 0x01A2B3C4), (12, 1), (15, 0x0102030405060708), (16, 2)):
+            key, iv, data = rnd.randbytes(bits // 8), rnd.randbytes(ivl), rnd.randbytes(rnd.choice([1, 33, 5000]))
+            want = orc.ctr_encrypt_iv(key, iv, start, data)
+            assert uaes.AES_CTR_encrypt(key, iv, data, iv_length=ivl, start_value=start) == want, (bits, ivl, start)
+            out = (C.c_uint8 * len(data))()
+            lib.AES_CTR_encrypt_iv(ivl, start, key, iv, data, len(data), out)
+            assert bytes(out) == want
+    with pytest.raises(ValueError):
+        uaes.AES_CTR_encrypt(bytes(16), bytes(17), b"x", iv_length=17)
+    assert uaes.engine().uaes_ctr_xcrypt_iv(128, bytes(16), bytes(17), 17, 1, b"x", 1, (C.c_uint8 * 1)()) == -2
+    assert uaes.engine().uaes_cbc_encrypt_padded(128, bytes(16), bytes(16), 3, b"x", 1, (C.c_uint8 * 16)()) == -2
+
+
 @pytest.mark.parametrize("bits", [128, 192, 256])
 def test_batched_chains_equal_the_single_calls(orc, bits):
     """uaes_cbc_encrypt_batch / uaes_cmac_batch: N independent messages, one GPU lane each, must give

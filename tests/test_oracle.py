@@ -405,6 +405,51 @@ def test_padded_ecb_against_compiled_reference(orc, bits, padding):
         assert orc.ecb_encrypt(key, data, padding=padding) == ref.ecb_encrypt(key, data)
 
 
+def test_build_variant_vectors(orc, golden_dir):
+    """the oracle's CTS 0 CBC (micro_aes.c:704-733, :753-761) and its CTR with other CTR_IV_LENGTH / CTR_START_VALUE
+    (micro_aes.h:98-99) against vectors made by reference builds with those switches, incl. main.c's CTS 0 answer"""
+    vecs = load(golden_dir, "build_variant_vectors.json")
+    assert any(v.get("name", "").startswith("main.c:149") for v in vecs["cbc_nocts"])
+    for v in vecs["cbc_nocts"]:
+        key, iv = bytes.fromhex(v["key"]), bytes.fromhex(v["iv"])
+        data = bytes.fromhex(v["pt"]) if "pt" in v else orc.splitmix(v["seed"], (v["len"] + 7) // 8 * 8)[: v["len"]]
+        rc, ct = orc.cbc_nocts(key, iv, data, True, padding=v["padding"])
+        assert rc == 0
+        check_out(ct, v["out"])
+        rc, back = orc.cbc_nocts(key, iv, ct, False)
+        assert rc == 0 and back[: len(data)] == data             # the padding stays behind the text
+        if len(data) % 16:
+            assert orc.cbc_nocts(key, iv, data, False)[0] == v.get("ragged_decrypt_rc", 1) == 1
+    for v in vecs["ctr_iv"]:
+        key, iv = bytes.fromhex(v["key"]), bytes.fromhex(v["iv"])
+        data = orc.splitmix(v["seed"], (v["len"] + 7) // 8 * 8)[: v["len"]]
+        assert len(iv) == v["iv_length"]
+        check_out(orc.ctr_encrypt_iv(key, iv, v["start_value"], data), v["out"])
+    # the default build is the (12, 1) member of the same family
+    k, iv, d = bytes(range(16)), bytes(range(12)), bytes(range(100))
+    assert orc.ctr_encrypt_iv(k, iv, 1, d) == orc.ctr_encrypt(k, iv, d)
+
+
+@pytest.mark.parametrize("variant", ["nocts", "nocts_pkcs7", "nocts_iso7816", "ctrA", "ctrB"])
+def test_build_variants_against_compiled_reference(orc, variant):
+    ref = Reference.of_variant(variant)
+    if ref is None:
+        pytest.skip("oracle/_ref/%s not built here" % variant)
+    rnd = random.Random(variant)
+    for _ in range(60):
+        n = rnd.choice([0, 1, 7, 15, 16, 17, 32, 33, 100, 511, 512, 3001])
+        data, key = rnd.randbytes(n), rnd.randbytes(ref.bits // 8)
+        if variant in Reference.NOCTS:
+            iv = rnd.randbytes(16)
+            got, want = orc.cbc_nocts(key, iv, data, True, padding=ref.padding), ref.cbc_nocts(key, iv, data, True)
+            assert got == want and got[0] == 0
+            assert orc.cbc_nocts(key, iv, got[1], False) == ref.cbc_nocts(key, iv, got[1], False)
+            assert orc.cbc_nocts(key, iv, data, False)[0] == ref.cbc_nocts(key, iv, data, False)[0] == (1 if n % 16 else 0)
+        else:
+            iv = rnd.randbytes(ref.ctr_iv_len)
+            assert orc.ctr_encrypt_iv(key, iv, ref.ctr_start, data) == ref.ctr_encrypt(key, iv, data)
+
+
 @pytest.mark.parametrize("bits", [128, 192, 256])
 def test_against_compiled_reference_random(orc, bits):
     """oracle == the real reference on fresh random inputs (skipped if the
