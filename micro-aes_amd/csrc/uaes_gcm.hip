@@ -463,6 +463,10 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_setup(uaesk_rk ek, uaesk_tables
 #define ST_STAMP(i) do { } while (0)
 #endif
     ST_STAMP(0);
+    /* A long one-shot call (logF) is launched on TWO workgroups that both make H and its powers and then split the
+     * rest: workgroup 0 the tables, workgroup 1 the fused kernel's weights (latency-bound dependent products that
+     * would otherwise wait behind the table stores: 10.7 -> ~7.5 us).  Every output has exactly one writer.      */
+    const bool tables_wg = blockIdx.x == 0, weights_wg = blockIdx.x == gridDim.x - 1;
     Gf *shPow = (Gf *)(uaes_lds + UAES_LDS_ENC);          /* up to 21 powers   */
     Gf *shGen = shPow + 32;                                /* 9 x 128 generators: 18 KiB */
     uint4 *gH = (uint4 *)(scratch + GS_H);
@@ -477,18 +481,21 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_setup(uaesk_rk ek, uaesk_tables
             u32 s[4] = { 0, 0, 0, 0 };
             if (threadIdx.x >= 4) { s[0] = j0.x; s[1] = j0.y; s[2] = j0.z; s[3] = j0.w; }
             quad_encrypt<NR>(s, ek, lc, kb);
-            if (threadIdx.x == 0 || threadIdx.x == 4) gH[threadIdx.x >> 2] = make_uint4(s[0], s[1], s[2], s[3]);
+            if (tables_wg && (threadIdx.x == 0 || threadIdx.x == 4)) gH[threadIdx.x >> 2] = make_uint4(s[0], s[1], s[2], s[3]);
             if (threadIdx.x == 0) shPow[0] = gf_from_words(s[0], s[1], s[2], s[3]);
         }
     } else if (threadIdx.x == 0) {
-        gH[0] = hval;
-        gH[1] = make_uint4(0, 0, 0, 0);
+        if (tables_wg) {
+            gH[0] = hval;
+            gH[1] = make_uint4(0, 0, 0, 0);
+        }
         shPow[0] = gf_from_words(hval.x, hval.y, hval.z, hval.w);
     }
     __syncthreads();
 
     ST_STAMP(1);
-    const u32 last = want_pow64 ? 63u : maxlog;              /* the highest power any requested table needs */
+    /* the highest power any requested table needs; the workgroup weights take Y^(2^i), Z^(2^i), i < 4 = H^(2^(11..18)) */
+    const u32 last = want_pow64 ? 63u : (logF && maxlog < 18u ? 18u : maxlog);
     if (tb.frob) {
         /* H^(2^k) = F^k H: squaring is the Frobenius map, linear over GF(2) with a matrix that depends on
          * the field only, so every power is ONE bit-matrix product with a constant (two parities per
@@ -496,7 +503,7 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_setup(uaesk_rk ek, uaesk_tables
         uint4 *g64 = (uint4 *)(scratch + GS_POW64);
         const Gf h = shPow[0];
         const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-        if (threadIdx.x == 0 && want_pow64) {
+        if (threadIdx.x == 0 && want_pow64 && tables_wg) {
             u32 w[4];
             gf_to_words(h, w);
             g64[0] = make_uint4(w[0], w[1], w[2], w[3]);
@@ -510,7 +517,7 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_setup(uaesk_rk ek, uaesk_tables
             p.lo = __ballot(b1);
             if (lane == 0) {
                 if (k <= GF_MAXLOG) shPow[k] = p;
-                if (want_pow64) {
+                if (want_pow64 && tables_wg) {
                     u32 w[4];
                     gf_to_words(p, w);
                     g64[k] = make_uint4(w[0], w[1], w[2], w[3]);
@@ -524,7 +531,7 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_setup(uaesk_rk ek, uaesk_tables
             if (k) p = wave_gfmul(p, p, threadIdx.x);
             if (threadIdx.x == 0) {
                 if (k <= GF_MAXLOG) shPow[k] = p;
-                if (want_pow64) {
+                if (want_pow64 && tables_wg) {
                     u32 w[4];
                     gf_to_words(p, w);
                     g64[k] = make_uint4(w[0], w[1], w[2], w[3]);
@@ -535,6 +542,7 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_setup(uaesk_rk ek, uaesk_tables
     __syncthreads();
 
     ST_STAMP(2);
+    if (tables_wg) {
     /* generators M*x^q of the tables: A (2^logA), B (2^14), the six nibble tables (2^10, 2^8, 2^6, 2^4, 2^2,
      * 2^0), fused (2^logF)                                                                              */
     const u32 logs[9] = { logA, GH_LOGB, 10u, 8u, 6u, 4u, 2u, 0u, logF };
@@ -550,16 +558,22 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_setup(uaesk_rk ek, uaesk_tables
         if ((t == 0 && !logA) || (t == 1 && !needB) || (t == 2 && !logF)) continue;
         uint4 *dst = (uint4 *)(scratch + (t == 0 ? GS_TAB8_A : t == 1 ? GS_TAB8_B : GS_TAB8_F));
         const Gf *gen = shGen + 128 * (t == 2 ? 8 : t);
-        const u32 v = threadIdx.x & 255u;
+        /* entry (v, j) sits at v * 16 + j: a thread keeps its slot j = tid & 15 (eight generators, read once) and
+         * takes rows v = tid / 16 + 64 q, so that a wave stores 1 KiB of consecutive entries per pass -- row by row
+         * (v = tid & 255) every lane wrote into a different 256-byte row, 64 cache lines per store: 2.9 us a table */
+        const u32 j = threadIdx.x & 15u;
+        Gf g[8];
 #pragma unroll
-        for (u32 jj = 0; jj < 4; ++jj) {
-            const u32 j = (threadIdx.x >> 8) * 4 + jj;
+        for (u32 i = 0; i < 8; ++i) g[i] = gen[8 * j + i];
+#pragma unroll
+        for (u32 q = 0; q < 4; ++q) {
+            const u32 v = (threadIdx.x >> 4) + 64u * q;
             Gf e = { 0, 0 };
 #pragma unroll
             for (u32 i = 0; i < 8; ++i) {
                 const u64 m = 0 - (u64)((v >> (7 - i)) & 1u);
-                e.hi ^= gen[8 * j + i].hi & m;
-                e.lo ^= gen[8 * j + i].lo & m;
+                e.hi ^= g[i].hi & m;
+                e.lo ^= g[i].lo & m;
             }
             u32 w[4];
             gf_to_words(e, w);
@@ -585,28 +599,40 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_setup(uaesk_rk ek, uaesk_tables
             dst[nib_entry(p, v)] = make_uint4(w[0], w[1], w[2], w[3]);
         }
     }
+    }                                          /* tables_wg */
     ST_STAMP(5);
-    if (logF) {
-        /* weights of the fused kernel's workgroups: Y^k and Z^k = Y^(16k), k < 16 (Y = H^2048), by
-         * doubling rounds -- round i computes powers 2^i + 1 .. 2^(i+1) from the ones below, one
-         * wave per product, the Y and Z families side by side                                   */
+    if (logF && weights_wg) {
+        /* weights of the fused kernel's workgroups: Y^k and Z^k = Y^(16k), k < 16 (Y = H^2048).  The squarings
+         * Y^(2^i) = H^(2^(11+i)), Z^(2^i) = H^(2^(15+i)) are among the powers made above, so every other exponent
+         * is a product of at most three of them: TWO rounds of independent products (six, then five per family,
+         * one wave each) instead of four doubling rounds (4.2 -> 2.2 us of every one-shot long call)          */
         Gf *shY = (Gf *)(uaes_lds + UAES_LDS_ENC + 19456u);       /* [0..15] Y^k, [16..31] Z^k */
         const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+        const u32 fam = wave >> 3, i = wave & 7u;                  /* product number i of this family */
         if (threadIdx.x < 2) {
             const Gf one = { 0x8000000000000000ull, 0 };
+            const u32 base = threadIdx.x ? 15u : 11u;
             shY[16 * threadIdx.x] = one;
-            shY[16 * threadIdx.x + 1] = shPow[threadIdx.x ? 15 : 11];
+#pragma unroll
+            for (u32 q = 0; q < 4; ++q) shY[16 * threadIdx.x + (1u << q)] = shPow[base + q];
         }
         __syncthreads();
-        for (u32 half = 1; half < 16; half <<= 1) {                /* powers half+1 .. 2*half (capped at 15) */
-            const u32 fam = wave >> 3, i = (wave & 7u) + 1;        /* product number i of this family */
-            const u32 k = half + i;
-            if (i <= half && k <= 15u) {
-                const Gf pr = wave_gfmul(shY[16 * fam + half], shY[16 * fam + i], lane);
-                if (lane == 0) shY[16 * fam + k] = pr;
+        {   /* 3 = 2+1, 5 = 4+1, 6 = 4+2, 9 = 8+1, 10 = 8+2, 12 = 8+4 */
+            const u32 a = i < 1 ? 2u : i < 3 ? 4u : 8u, b = i == 0 || i == 1 || i == 3 ? 1u : (i == 2 || i == 4 ? 2u : 4u);
+            if (i < 6) {
+                const Gf pr = wave_gfmul(shY[16 * fam + a], shY[16 * fam + b], lane);
+                if (lane == 0) shY[16 * fam + a + b] = pr;
             }
-            __syncthreads();
         }
+        __syncthreads();
+        {   /* 7 = 4+3, 11 = 8+3, 13 = 8+5, 14 = 8+6, 15 = 12+3 */
+            const u32 a = i == 0 ? 4u : i < 4 ? 8u : 12u, b = i < 2 || i == 4 ? 3u : (i == 2 ? 5u : 6u);
+            if (i < 5) {
+                const Gf pr = wave_gfmul(shY[16 * fam + a], shY[16 * fam + b], lane);
+                if (lane == 0) shY[16 * fam + a + b] = pr;
+            }
+        }
+        __syncthreads();
         if (threadIdx.x < 32) {
             u32 w[4];
             gf_to_words(shY[threadIdx.x], w);
@@ -615,7 +641,7 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_setup(uaesk_rk ek, uaesk_tables
         if (threadIdx.x == 32) *(uint4 *)(scratch + GS_T) = make_uint4(0, 0, 0, 0);
     }
     ST_STAMP(6);
-    if (threadIdx.x <= (want_pow64 ? GH_MAXLOG : (maxlog < GH_MAXLOG ? maxlog : GH_MAXLOG))) {
+    if (tables_wg && threadIdx.x <= (want_pow64 ? GH_MAXLOG : (maxlog < GH_MAXLOG ? maxlog : GH_MAXLOG))) {
         u32 w[4];
         gf_to_words(shPow[threadIdx.x], w);
         ((uint4 *)(scratch + GS_POW))[threadIdx.x] = make_uint4(w[0], w[1], w[2], w[3]);
@@ -623,7 +649,7 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_setup(uaesk_rk ek, uaesk_tables
 #ifdef UAES_GF_TIMING
     ST_STAMP(7);
     if (threadIdx.x == 0)
-        printf("setup: aes %llu powers %llu gens %llu byte-tables %llu nibble-tables %llu yz %llu store %llu (x10 ns)\n",
+        printf("setup wg %u: aes %llu powers %llu gens %llu byte-tables %llu nibble-tables %llu yz %llu store %llu (x10 ns)\n", blockIdx.x,
                (unsigned long long)(st_ts[1] - st_ts[0]), (unsigned long long)(st_ts[2] - st_ts[1]), (unsigned long long)(st_ts[3] - st_ts[2]),
                (unsigned long long)(st_ts[4] - st_ts[3]), (unsigned long long)(st_ts[5] - st_ts[4]), (unsigned long long)(st_ts[6] - st_ts[5]),
                (unsigned long long)(st_ts[7] - st_ts[6]));
@@ -786,12 +812,16 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_fused(uaesk_rk rk, uaesk_tables
     GF_STAMP(4);
 
     /* ---- the workgroup's 2048 accumulators -> R_b -> weighted share into T ---- */
-    __syncthreads();                               /* every wave is done with the AES tables */
-    uint4 *TC = (uint4 *)(uaes_lds + GF_LDS_AES);  /* the six nibble tables, over the AES tables */
+    /* the six nibble tables go over the AES tables: requested BEFORE the barrier (the loads touch no LDS), stored
+     * behind it -- the cache round trip hides behind the wait for the workgroup's slowest wave               */
+    uint4 *TC = (uint4 *)(uaes_lds + GF_LDS_AES);
     uint4 *buf = (uint4 *)uaes_lds;                /* GT_BUF entries, over the GHASH table (every wave is past its last fold) */
     {
+        static_assert(GT_NTAB * 512u == 3u * UAES_WG, "three table entries per thread");
         const uint4 *g4 = (const uint4 *)(scratch + GS_TAB4);
-        for (u32 i = threadIdx.x; i < GT_NTAB * 512u; i += UAES_WG) TC[i] = g4[i];
+        const uint4 e0 = g4[threadIdx.x], e1 = g4[threadIdx.x + UAES_WG], e2 = g4[threadIdx.x + 2u * UAES_WG];
+        __syncthreads();                           /* every wave is done with the AES tables */
+        TC[threadIdx.x] = e0; TC[threadIdx.x + UAES_WG] = e1; TC[threadIdx.x + 2u * UAES_WG] = e2;
     }
     __syncthreads();
     GF_STAMP(5);
@@ -1879,7 +1909,8 @@ static int launch_setup(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *
     if (pl.logA > maxlog) maxlog = pl.logA;
     if (pl.needB && GH_LOGB > maxlog) maxlog = GH_LOGB;
     if (logF > maxlog) maxlog = logF;
-    hipLaunchKernelGGL((k_gcm_setup<NR>), dim3(1), dim3(UAES_WG), SETUP_LDS, st, *ek, *tb, j0, scratch,
+    /* with the fused kernel's weights to make: a second workgroup for them (k_gcm_setup: tables_wg / weights_wg) */
+    hipLaunchKernelGGL((k_gcm_setup<NR>), dim3(logF ? 2u : 1u), dim3(UAES_WG), SETUP_LDS, st, *ek, *tb, j0, scratch,
                        pl.logA, pl.needB, h_given, hval, want_pow64, logF, maxlog);
     return (int)hipGetLastError();
 }
