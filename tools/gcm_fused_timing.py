@@ -1,5 +1,11 @@
-"""Phase stamps of k_gcm_fused (a library built with -DUAES_GF_TIMING as lib/libuaes_hip_T.so): where a mid-sized
-one-shot GCM call spends its time.  usage: gcm_fused_timing.py <MiB>"""
+"""Phase stamps of k_gcm_setup / k_gcm_fused: where a mid-sized one-shot GCM call spends its time.
+Needs a timing build of the library next to the product one (its kernels printf their stamps, x10 ns):
+
+    make -C micro-aes_amd/csrc XFLAGS=-DUAES_GF_TIMING OBJ=$PWD/micro-aes_amd/csrc/build_T OUT=$PWD/micro-aes_amd/lib_T \
+         $PWD/micro-aes_amd/lib_T/libuaes_hip.so
+    cp micro-aes_amd/lib_T/libuaes_hip.so micro-aes_amd/lib/libuaes_hip_T.so
+    gpurun -- 'python tools/gcm_fused_timing.py 16'        # MiB; results: profiles/r03_gcm_setup_split.log
+"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import micro_aes_amd as uaes
