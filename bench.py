@@ -119,7 +119,7 @@ def measure_traffic(workload, nbytes):
             cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", out, "-o", "pmc", "--",
                    sys.executable, os.path.abspath(__file__), "--gpus", "1", "--workload", workload, "--bytes", str(nbytes),
                    "--steps", str(steps), "--warmup", str(warm), "--settle-ms", "0", "--no-cpu", "--no-verify",
-                   "--no-traffic", "--no-clock-probe"]
+                   "--no-traffic", "--no-clock-probe", "--sustain-s", "0"]
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=150)
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
@@ -148,7 +148,9 @@ def cpu_baseline(workload):
     from oracle.pyoracle import Oracle, Reference
     orc = Oracle()
     use_ref = Reference.available(128)
-    sample = {"ctr": 512 << 20, "ecb": 512 << 20, "xts": 512 << 20, "gcm": 64 << 20}.get(workload, 256 << 20)
+    sample = {"ctr": 512 << 20, "ecb": 512 << 20, "xts": 512 << 20, "gcm": 64 << 20, "cbc-enc": 256 << 20,
+              "cmac": 256 << 20}.get(workload, 256 << 20)
+    mac16 = (ctypes.c_uint8 * 16)()
     buf = np.empty(sample, dtype=np.uint8)
     orc.splitmix_into(2, buf)
     out = np.empty(sample + 16, dtype=np.uint8)
@@ -165,6 +167,8 @@ def cpu_baseline(workload):
               "ocb": lambda n: L.AES_OCB_encrypt(KEY16, NONCE, None, 0, src, n, dst),
               "ocb-dec": lambda n: L.AES_OCB_encrypt(KEY16, NONCE, None, 0, src, n, dst),
               "cbc-dec": lambda n: L.AES_CBC_decrypt(KEY16, bytes(range(16)), src, n, dst),
+              "cbc-enc": lambda n: L.AES_CBC_encrypt(KEY16, bytes(range(16)), src, n, dst),
+              "cmac": lambda n: L.AES_CMAC(KEY16, src, n, mac16),
               "cfb-dec": lambda n: L.AES_CFB_decrypt(KEY16, bytes(range(16)), src, n, dst)}[workload]
     else:
         L = orc.L
@@ -175,6 +179,8 @@ def cpu_baseline(workload):
               "ocb": lambda n: L.orc_ocb_encrypt(128, KEY16, NONCE, None, 0, src, n, dst),
               "ocb-dec": lambda n: L.orc_ocb_encrypt(128, KEY16, NONCE, None, 0, src, n, dst),
               "cbc-dec": lambda n: L.orc_cbc_decrypt(128, KEY16, bytes(range(16)), src, n, dst),
+              "cbc-enc": lambda n: L.orc_cbc_encrypt(128, KEY16, bytes(range(16)), src, n, dst),
+              "cmac": lambda n: L.orc_cmac(128, KEY16, src, n, mac16),
               "cfb-dec": lambda n: L.orc_cfb(128, KEY16, bytes(range(16)), 0, src, n, dst)}[workload]
     t0 = time.perf_counter()
     fn(sample)
@@ -207,6 +213,60 @@ def cpu_baseline(workload):
     return res
 
 
+def setup_collectives(a, torch, rank, world, local, dev):
+    """Control plane of an N-rank run.  `value` needs no data-path collective: a barrier either
+    side of the timed steps and three scalar reductions.  The default process group is therefore gloo over
+    127.0.0.1 -- it cannot fail for reasons that have to do with the GPUs -- and RCCL is brought up NEXT to it
+    as a second group, proven with a 16-byte all-gather under a bounded wait, and used for the barrier, the
+    reductions and the optional ciphertext gather only once EVERY rank has seen it work.  If any rank's RCCL
+    init or probe raises or does not return in time, all ranks agree (over gloo) to stay on gloo: every rank
+    still runs on its own GPU and still verifies its shard, and the line says so in `collective_backend`.
+    Returns (dist, group, device for collective scalars, info for the JSON line)."""
+    import datetime
+    import threading
+    import torch.distributed as dist
+    os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")      # a stuck RCCL probe must not abort the process
+    dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))
+    info = {"collective_backend": "gloo", "control_plane": "gloo over 127.0.0.1"}
+    if a.backend != "nccl":
+        info["collective_backend"] = "gloo (requested with --backend gloo)"
+        return dist, None, torch.device("cpu"), info
+    wait_s = float(os.environ.get("UAES_BENCH_RCCL_WAIT_S", "90"))
+    state = {"ok": False, "err": "no answer within %.0f s" % wait_s, "group": None}
+
+    def bring_up():
+        try:
+            if os.environ.get("UAES_BENCH_FORCE_NCCL_FAIL"):
+                raise RuntimeError("forced by UAES_BENCH_FORCE_NCCL_FAIL")
+            torch.cuda.set_device(local)
+            g = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=max(wait_s * 4, 600)))
+            state["group"] = g
+            mine = torch.full((16,), rank, dtype=torch.uint8, device=dev)
+            allr = torch.empty(16 * world, dtype=torch.uint8, device=dev)
+            dist.all_gather_into_tensor(allr, mine, group=g)
+            torch.cuda.synchronize()
+            want = torch.arange(world, dtype=torch.uint8).repeat_interleave(16)
+            if not torch.equal(allr.cpu(), want):
+                raise RuntimeError("16-byte all-gather returned the wrong bytes")
+            state["ok"], state["err"] = True, None
+        except Exception as e:                                      # noqa: BLE001 -- whatever RCCL throws
+            state["err"] = "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:200] if str(e) else "")
+
+    th = threading.Thread(target=bring_up, daemon=True)
+    th.start()
+    th.join(wait_s)
+    flag = torch.tensor([1 if state["ok"] and not th.is_alive() else 0], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)                      # gloo: every rank learns whether ALL ranks have RCCL
+    if int(flag.item()) == 1:
+        info = {"collective_backend": "nccl (RCCL)", "rccl_ranks": dist.get_world_size(state["group"]),
+                "rccl_probe": "16-byte all_gather_into_tensor ok on every rank", "control_plane": "gloo init, RCCL barrier/reductions"}
+        return dist, state["group"], dev, info
+    why = state["err"] if not state["ok"] else "another rank's RCCL bring-up failed"
+    info["collective_backend"] = "gloo (nccl init failed: %s)" % why
+    info["rccl_stuck_thread"] = th.is_alive()
+    return dist, None, torch.device("cpu"), info
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, one per GPU, exactly as
     the documented command does (torch.distributed.run, rendezvous on 127.0.0.1, a free port), relay their
@@ -229,7 +289,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="ctr", choices=["ctr", "ecb", "xts", "gcm", "ocb", "ocb-dec", "cbc-dec", "cfb-dec"])
+    ap.add_argument("--workload", default="ctr", choices=["ctr", "ecb", "xts", "gcm", "ocb", "ocb-dec", "cbc-dec", "cfb-dec", "cbc-enc", "cmac"])
     ap.add_argument("--bytes", type=int, default=GIB, help="bytes per GPU")
     ap.add_argument("--settle-ms", type=float, default=150.0,
                     help="extra untimed warm-up until the clocks have settled (0 = only --warmup steps)")
@@ -237,8 +297,14 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 PMC passes behind roofline.traffic")
     ap.add_argument("--no-clock-probe", action="store_true",
-                    help="skip the untimed shader-clock sample behind roofline.lds_ceiling (it queues extra steps)")
+                    help="skip the shader-clock sample behind roofline.lds_ceiling (taken in the middle of the sustained run)")
+    ap.add_argument("--sustain-s", type=float, default=2.0,
+                    help="after the K timed steps, seconds of the same step back to back (untimed for `value`) behind "
+                         "`sustained` and roofline.frac_sustained; 0 = skip")
     ap.add_argument("--gather", action="store_true", help="also time the RCCL ciphertext all-gather")
+    ap.add_argument("--c-gather", action="store_true",
+                    help="with --gather: rank 0 also runs uaes_mgpu_ctr_encrypt_gather -- the C host's own encrypt + RCCL "
+                         "gather over all N devices in ONE process (include/uaes_hip.h) -- while the other ranks wait")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --single-device: dry-run the multi-rank code path on a 1-GPU box")
     ap.add_argument("--single-device", action="store_true", help="all ranks use cuda:0 (dry run only)")
@@ -262,17 +328,13 @@ def main():
                  % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist = None
+    dist, cg, cdev, coll_info = None, None, dev, {}
     if world > 1:
-        import torch.distributed as dist
-        if a.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)       # RCCL over xGMI
-        else:
-            dist.init_process_group("gloo")
-    cdev = dev if a.backend == "nccl" else torch.device("cpu")   # where collective scalars live
+        dist, cg, cdev, coll_info = setup_collectives(a, torch, rank, world, local, dev)
+    rccl_up = cg is not None                                     # RCCL over xGMI carries the collectives
 
     n = a.bytes
-    seed = {"ctr": 2, "ecb": 1, "xts": 3, "gcm": 4, "cbc-dec": 5, "cfb-dec": 6, "ocb": 7, "ocb-dec": 7}[a.workload]
+    seed = {"ctr": 2, "ecb": 1, "xts": 3, "gcm": 4, "cbc-dec": 5, "cfb-dec": 6, "ocb": 7, "ocb-dec": 7, "cbc-enc": 5, "cmac": 5}[a.workload]
     # rank g owns bytes [g*n, (g+1)*n) of the world*n stream
     src = splitmix_device(torch, seed, n, rank * (n // 8), dev)
     dst = torch.empty(n + 16, dtype=torch.uint8, device=dev)
@@ -300,6 +362,18 @@ def main():
 
         def step():
             uaes.ocb_dev(KEY16, NONCE, None, ocb_ct, n, dst, decrypt=True, status=ocb_status, stream=st)
+    elif a.workload in ("cbc-enc", "cmac"):
+        # ONE serial chain (north_star: "CBC/CFB/OFB stay single-GPU because the chain is serial"): a latency-bound
+        # single wave, here so that the reference's CPU loop is timed beside it in the same line (use --bytes 4194304)
+        import ctypes as C
+        L = uaes.engine()
+        iv16, mac16 = bytes(range(16)), (C.c_uint8 * 16)()
+
+        def step():
+            if a.workload == "cbc-enc":
+                assert L.uaes_cbc_encrypt(128, KEY16, iv16, C.c_void_p(src.data_ptr()), n, C.c_void_p(dst.data_ptr())) == 0
+            else:
+                assert L.uaes_cmac(128, KEY16, C.c_void_p(src.data_ptr()), n, mac16) == 0
     else:
         # block-parallel decrypt directions of the feedback modes, through the host-pointer C ABI
         # with device pointers (synchronous call: launch + stream sync)
@@ -311,6 +385,13 @@ def main():
         def step():
             assert fn(128, KEY16, iv16, C.c_void_p(src.data_ptr()), n, C.c_void_p(dst.data_ptr())) == 0
 
+    probe_out, side = None, None
+    if not a.no_clock_probe and a.sustain_s > 0:
+        try:
+            probe_out = torch.zeros(2, dtype=torch.int64, device=dev)
+            side = torch.cuda.Stream(device=dev)
+        except Exception:
+            probe_out = None
     for _ in range(a.warmup):
         step()
     # The GPU's clocks take tens of milliseconds of load to settle (a 1 GiB step is ~0.7 ms:
@@ -327,7 +408,7 @@ def main():
             extra += 8
     torch.cuda.synchronize()
     if dist:
-        dist.barrier()
+        dist.barrier(group=cg)
     torch.cuda.synchronize()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     t0 = time.perf_counter()
@@ -337,60 +418,101 @@ def main():
         ev[i + 1].record(st)
     torch.cuda.synchronize()
     if dist:
-        dist.barrier()
+        dist.barrier(group=cg)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     per_step_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(a.steps)]
-    # Untimed, after the measured steps: the shader clock the chip really runs at under this load.  A one-wave probe
-    # on a second stream counts shader cycles against the constant 100 MHz counter for 20 ms while the workload keeps
-    # running (the device properties quote 2.4 GHz; at the 1.4 kW cap a cipher kernel settles near 2.1 GHz).
-    sclk_mhz = None
-    try:
-        if a.no_clock_probe:
-            raise RuntimeError("skipped")
-        probe_out = torch.zeros(2, dtype=torch.int64, device=dev)
-        side = torch.cuda.Stream(device=dev)
-        # the allocation and the stream above let the GPU idle for a moment and its clocks jump up; the power manager
-        # then undershoots for tens of milliseconds (a probe launched right away reads 1.8 GHz where the steady value
-        # is 2.05): settle again first, exactly as before the timed steps
-        w0 = time.perf_counter()
-        while (time.perf_counter() - w0) * 1e3 < max(a.settle_ms, 100.0):
-            for _ in range(8):
-                step()
-            st.synchronize()
-        nprobe = max(8, int(30.0 / max(sum(per_step_ms) / len(per_step_ms), 1e-3)) + 1)
-        for _ in range(8):
+    # Untimed for `value`, after the measured steps: the SUSTAINED rate.  K steps after 150 ms of settling are a
+    # window of ~12 ms; the power manager keeps adjusting for longer than that (1605 GiB/s in the window,
+    # 1512-1524 over 30 000 steps).  So the same step is queued back to back for >= --sustain-s seconds (HIP events on
+    # the launch stream around the whole run) and, in the middle of it, a one-wave probe on a second stream counts shader
+    # cycles against the constant 100 MHz counter for 20 ms: the clock the chip really runs at under this load (the
+    # device properties quote 2.4 GHz; at the 1.4 kW cap a cipher kernel settles near 2.0 GHz).
+    sclk_mhz, sustained = None, None
+    if a.sustain_s > 0:
+        mean_ms = max(sum(per_step_ms) / len(per_step_ms), 1e-3)
+        sus_steps = max(a.steps, int(a.sustain_s * 1e3 / mean_ms) + 1)
+        s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        probe_rc = -1
+        s0.record(st)
+        for i in range(sus_steps):
             step()
-        rc = uaes.engine().uaes_clock_probe_dev(ctypes.c_void_p(probe_out.data_ptr()), 20000, ctypes.c_void_p(side.cuda_stream))
-        for _ in range(nprobe):             # ~30 ms of the same steps, queued back to back, cover the probe's 20 ms
-            step()
+            if i == sus_steps // 2 and probe_out is not None:
+                probe_rc = uaes.engine().uaes_clock_probe_dev(ctypes.c_void_p(probe_out.data_ptr()), 20000,
+                                                              ctypes.c_void_p(side.cuda_stream))
+        s1.record(st)
         torch.cuda.synchronize()
-        cyc, ticks = [int(x) for x in probe_out.tolist()]
-        if rc == 0 and ticks > 0:
-            sclk_mhz = cyc / (ticks / 100.0)
-    except Exception:
-        sclk_mhz = None
+        sus_ms = s0.elapsed_time(s1)
+        if probe_out is not None and probe_rc == 0:
+            cyc, ticks = [int(x) for x in probe_out.tolist()]
+            if ticks > 0:
+                sclk_mhz = cyc / (ticks / 100.0)
+        sustained = {"gib_s": n * sus_steps / GIB / (sus_ms * 1e-3), "seconds": sus_ms * 1e-3, "steps": sus_steps,
+                     "ms_per_step": sus_ms / sus_steps}
     if dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=cg)
         elapsed = float(t.item())
 
     gather_ms, gathered_ok = None, None
-    if dist and a.gather and a.backend == "nccl":
+    if dist and a.gather and rccl_up:
         full = torch.empty(world * n, dtype=torch.uint8, device=dev)
-        dist.all_gather_into_tensor(full, dst[:n])
+        dist.all_gather_into_tensor(full, dst[:n], group=cg)
         torch.cuda.synchronize()
-        dist.barrier()
+        dist.barrier(group=cg)
         g0 = time.perf_counter()
-        dist.all_gather_into_tensor(full, dst[:n])
+        dist.all_gather_into_tensor(full, dst[:n], group=cg)
         torch.cuda.synchronize()
-        dist.barrier()
+        dist.barrier(group=cg)
         gather_ms = (time.perf_counter() - g0) * 1e3
         if rank == 0 and a.workload == "ctr" and n == GIB and world == 8 and not a.no_verify:
             # BASELINE configs[4]: the concatenated 8 GiB stream against the reference's digest (C5)
             with open(os.path.join(ROOT, "tests", "golden", "digests.json")) as f:
                 gathered_ok = sha_of(full) == json.load(f)["C5_ctr128_8GiB_seed2"]["sha256"]
         del full
+
+    # the C host's own gather (north_star: host code in C, RCCL only for the final ciphertext gather): rank 0 alone, one
+    # process over all N devices, fresh shards generated on every device; timed end to end (encrypt + gather), twice
+    c_gather = None
+    if a.gather and a.c_gather and a.workload == "ctr":
+        if rank == 0:
+            try:
+                ndev = 1 if a.single_device else world
+                devs = [0] * world if a.single_device else list(range(world))
+                ins, outs, keep = (ctypes.c_void_p * world)(), (ctypes.c_void_p * world)(), []
+                for g, d in enumerate(devs):
+                    dd = torch.device("cuda", d)
+                    t_in = src if g == 0 else splitmix_device(torch, seed, n, g * (n // 8), dd)
+                    t_out = torch.empty(n, dtype=torch.uint8, device=dd)
+                    keep += [t_in, t_out]
+                    ins[g], outs[g] = t_in.data_ptr(), t_out.data_ptr()
+                full = torch.empty(world * n, dtype=torch.uint8, device=dev)
+                for d in set(devs):
+                    torch.cuda.synchronize(d)
+                times = []
+                for _ in range(2):
+                    g0 = time.perf_counter()
+                    rc = uaes.engine().uaes_mgpu_ctr_encrypt_gather(world, (ctypes.c_int * world)(*devs), 128, KEY16, CTR0, 0,
+                                                                    ins, world * n, outs, 0, ctypes.c_void_p(full.data_ptr()))
+                    for d in set(devs):
+                        torch.cuda.synchronize(d)
+                    times.append((time.perf_counter() - g0) * 1e3)
+                    if rc != 0:
+                        raise RuntimeError(uaes.engine().uaes_last_error().decode())
+                c_gather = {"ms_first": round(times[0], 3), "ms": round(times[1], 3), "devices": ndev,
+                            "gib_s_end_to_end": round(world * n / GIB / (times[1] * 1e-3), 1),
+                            "call": "uaes_mgpu_ctr_encrypt_gather (C host, RCCL send/recv to device 0)"}
+                if not a.no_verify:
+                    if n == GIB and world == 8:
+                        with open(os.path.join(ROOT, "tests", "golden", "digests.json")) as f:
+                            c_gather["stream_digest_ok"] = sha_of(full) == json.load(f)["C5_ctr128_8GiB_seed2"]["sha256"]
+                    else:        # shard 0 of the gathered text is what this rank's own timed step wrote
+                        c_gather["shard0_equals_own_step"] = bool(torch.equal(full[:n], dst[:n]))
+                del full, keep
+            except Exception as e:                          # noqa: BLE001 -- the bench line must survive
+                c_gather = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        if dist:
+            dist.barrier(group=cg)
 
     # measured HBM stream-copy ceiling on this GPU (read n + write n), for context next to the 8 TB/s spec
     copy_gbs = None
@@ -442,18 +564,26 @@ def main():
                 verify = got[: m - 32] == orc.cbc(KEY16, bytes(range(16)), head, False)[1][: m - 32]
             elif a.workload == "cfb-dec":
                 verify = got == orc.cfb(KEY16, bytes(range(16)), head, False)
+            elif a.workload == "cbc-enc":
+                verify = got == orc.cbc(KEY16, bytes(range(16)), head, True)[1][:m]
+            elif a.workload == "cmac":
+                verify = bytes(mac16) == orc.cmac(KEY16, orc.splitmix(seed, n)) if n <= (16 << 20) else None
         if dist:
             v = torch.tensor([1 if verify in (True, None) else 0], device=cdev)
-            dist.all_reduce(v, op=dist.ReduceOp.MIN)
+            dist.all_reduce(v, op=dist.ReduceOp.MIN, group=cg)
             verify = bool(v.item())
 
     kern_ms = sum(per_step_ms) / len(per_step_ms)
     kern_all = [kern_ms]
+    sus_all = [sustained["gib_s"]] if sustained else None
     if dist:
-        t = torch.zeros(world, dtype=torch.float64, device=cdev)
+        t = torch.zeros(2 * world, dtype=torch.float64, device=cdev)
         t[rank] = kern_ms
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        kern_all = [float(x) for x in t.tolist()]
+        t[world + rank] = sustained["gib_s"] if sustained else 0.0
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=cg)
+        kern_all = [float(x) for x in t.tolist()[:world]]
+        if sustained:
+            sus_all = [float(x) for x in t.tolist()[world:]]
 
     if rank == 0:
         total_gib = world * n * a.steps / GIB
@@ -481,7 +611,7 @@ def main():
         # under this very load, so achieved / ceiling is the kernel's distance from its own bound.
         lds_ceiling = None
         lookups = {"ctr": 128, "gcm": 128 + 32, "ecb": 160, "ocb": 160, "ocb-dec": 160, "cbc-dec": 160, "cfb-dec": 160,
-                   "xts": 224}.get(a.workload)
+                   "xts": 224}.get(a.workload)               # the serial chains are latency-bound: no lookup ceiling
         if sclk_mhz and lookups:
             cus = torch.cuda.get_device_properties(0).multi_processor_count
             ceil_gbs = cus * sclk_mhz * 1e6 * 32.0 / lookups * 32.0 / 1e9
@@ -490,6 +620,7 @@ def main():
                            "frac_of_ceiling": round(achieved / ceil_gbs, 4)}
         names = {"ctr": "AES-128-CTR", "ecb": "AES-128-ECB", "xts": "AES-256-XTS 4 KiB sectors", "gcm": "AES-128-GCM",
                  "cbc-dec": "AES-128-CBC decrypt", "cfb-dec": "AES-128-CFB decrypt",
+                 "cbc-enc": "AES-128-CBC encrypt, ONE serial chain", "cmac": "AES-128-CMAC, ONE serial chain",
                  "ocb": "AES-128-OCB", "ocb-dec": "AES-128-OCB decrypt"}
         line = {
             "metric": "GiB/s encrypted (AES-128-CTR, 1 GiB buffer per GPU)" if a.workload == "ctr"
@@ -520,14 +651,27 @@ def main():
                                              "frac": round(sum(per_gpu) / (HBM_PEAK_GBS * world), 4)}
             line["verified_shards"] = "every rank hashed its whole shard against the reference's digest" \
                 if (a.workload == "ctr" and n == GIB and not a.no_verify) else "head of every shard against the oracle"
+        if sustained:
+            # whole-job sustained rate = the sum of the ranks' own back-to-back rates (no collective inside the run)
+            line["sustained"] = {"value": round(sum(sus_all), 2), "unit": "GiB/s", "seconds": round(sustained["seconds"], 3),
+                                 "steps": sustained["steps"], "ms_per_step": round(sustained["ms_per_step"], 4),
+                                 "sclk_mhz": None if sclk_mhz is None else round(sclk_mhz, 0),
+                                 "note": "the same step back to back after the K timed steps; not part of `value`"}
+            line["roofline"]["frac_sustained"] = round(2.0 * n / (sustained["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        line.update(coll_info)
         if gather_ms is not None:
             line["gather_ms"] = round(gather_ms, 3)
         if gathered_ok is not None:
             line["gathered_stream_digest_ok"] = gathered_ok
+        if c_gather is not None:
+            line["c_gather"] = c_gather
         if not a.no_cpu and world == 1:
             line["cpu_baseline"] = cpu_baseline(a.workload)
         print(json.dumps(line))
     if dist:
+        sys.stdout.flush()
+        if coll_info.get("rccl_stuck_thread"):
+            os._exit(0)                         # a thread still inside RCCL: tearing the groups down could hang with it
         dist.destroy_process_group()
 
 

@@ -422,6 +422,20 @@ int uaes_mgpu_xts_sectors(int ndev, const int *devices, int keybits, const uint8
                           uint64_t first_sector, size_t sector_bytes, size_t nsectors,
                           const void *in, void *out, int encrypt);
 
+/* BASELINE configs[4] in one call: the plaintext lies sharded over ndev GPUs (d_in[i] on devices[i] holds the slice
+ * uaes_mgpu_ctr_xcrypt_at would give device i: blocks [B*i/ndev, B*(i+1)/ndev) of the B = ceil(len/16) blocks), every
+ * device encrypts its slice with the counter advanced by its block offset (incBlock's 56-bit add, micro_aes.c:421-427;
+ * CTR_cipher :943-949 -- the reference has no collective), and the ciphertext slices are gathered into
+ * d_full_on_root (len bytes on devices[root]) by RCCL over xGMI: grouped ncclSend / ncclRecv, one per peer, each slice
+ * over its own link.  d_out[i] = device i's own ciphertext shard buffer (required for every device other than the root's;
+ * on the root's device NULL means "encrypt straight into place").  RCCL is loaded with dlopen on first use with ndev > 1 (librccl.so.1,
+ * or $UAES_RCCL_LIB): without it the call fails with UAES_E_HIP and uaes_last_error() says why; ndev = 1 needs no RCCL.
+ * The communicators of the last device list are cached for the life of the process (ncclCommInitAll costs seconds). */
+int uaes_mgpu_ctr_encrypt_gather(int ndev, const int *devices, int keybits, const uint8_t *key,
+                                 const uint8_t ctr0[16], uint64_t block_offset,
+                                 const void *const *d_in, size_t len, void *const *d_out,
+                                 int root, void *d_full_on_root);
+
 /* ---- sharded GCM (multi-GPU) ------------------------------------------------
  * One message, cut into 16-byte aligned ciphertext shards, one per GPU.  Each
  * rank encrypts its shard with uaes_ctr_xcrypt_at_dev(ctr0 = nonce || 00000001,

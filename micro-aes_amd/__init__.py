@@ -41,7 +41,7 @@ EXPORTS = [
     "uaes_ocb_encrypt_ex", "uaes_ocb_decrypt_ex",
     "uaes_cmac", "uaes_ccm_encrypt", "uaes_ccm_decrypt", "uaes_gcmsiv_encrypt", "uaes_gcmsiv_decrypt",
     "uaes_ocb_encrypt", "uaes_ocb_decrypt", "uaes_ocb_dev",
-    "uaes_mgpu_ctr_xcrypt_at", "uaes_mgpu_xts_sectors",
+    "uaes_mgpu_ctr_xcrypt_at", "uaes_mgpu_xts_sectors", "uaes_mgpu_ctr_encrypt_gather",
     "uaes_gcm_key_new", "uaes_gcm_key_free", "uaes_gcm_key_encrypt", "uaes_gcm_key_decrypt",
     "uaes_gcm_key_encrypt_dev", "uaes_gcm_key_decrypt_dev",
     "uaes_gcm_record_max", "uaes_gcm_key_encrypt_records", "uaes_gcm_key_decrypt_records",
@@ -139,6 +139,7 @@ def engine():
         getattr(L, n).argtypes = [i, vp, vp, vp, sz, vp, sz, vp]
     L.uaes_mgpu_ctr_xcrypt_at.argtypes = [i, C.POINTER(C.c_int), i, vp, vp, u64, vp, sz, vp]
     L.uaes_mgpu_xts_sectors.argtypes = [i, C.POINTER(C.c_int), i, vp, u64, sz, sz, vp, vp, i]
+    L.uaes_mgpu_ctr_encrypt_gather.argtypes = [i, C.POINTER(C.c_int), i, vp, vp, u64, C.POINTER(vp), sz, C.POINTER(vp), i, vp]
     L.uaes_gcm_key_new.argtypes = [C.POINTER(vp), i, vp]
     L.uaes_gcm_key_free.argtypes = [vp]
     L.uaes_gcm_key_free.restype = None

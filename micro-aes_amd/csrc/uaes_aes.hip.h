@@ -461,6 +461,11 @@ __device__ __forceinline__ void enc_rounds_skewed(u32 (&sa)[4], u32 (&sb)[4], co
 #undef XPRIO
 }
 
+/* hand-scheduled variants of the same two-block loop (tools/gen_rounds_asm.py), selected at build time */
+#ifdef UAES_ASM_VARIANT
+#include "uaes_rounds_asm.inc.h"
+#endif
+
 /* full cipher on two blocks, skewed (state = plaintext words on entry) */
 struct RkView {
     const u32 *w;

@@ -123,6 +123,7 @@ __device__ __forceinline__ u64 ctr_geo_group0(const CtrGeo &g, u64 it)
 struct CtrNoFold {
     static constexpr bool of_input = false;
     static constexpr int round_prio = 1;       /* wave priority while a round's lookups are issued */
+    static constexpr bool expand2 = true;      /* the loop body twice per trip, text buffers swapped (no register moves) */
     __device__ __forceinline__ void operator()(const uint4 &, const uint4 &) const {}
 };
 
@@ -160,15 +161,26 @@ __device__ __forceinline__ void ctr_shared_loop(const uaesk_rk &rk, const uaesk_
     const u64 ctr_tm_start = wall_clock64();
 #endif
     u64 it = 0;
-    uint4 d_cur[2], d_nxt[2];
+    uint4 d_cur[2];
     if (it < geo.iters) {
         const u64 g0 = ctr_geo_group0(geo, 0);
 #pragma unroll
         for (int u = 0; u < 2; ++u) d_cur[u] = (in + (((g0 + 4u * u) << 8) - c0))[lane_blk];
     }
 
-    while (it < geo.iters) {
-        if ((it & 7) == 0) {
+    /* One iteration = two blocks per lane.  The body is written once and expanded twice per trip with the two text
+     * buffers swapped, so that "next becomes current" is a renaming, not eight register moves; the text addresses are a
+     * wave-uniform 64-bit base (SGPRs, advanced by scalar instructions) plus the lane's constant 32-bit offset, so no
+     * 64-bit vector adds either: the VALU is the second-busiest unit of this kernel.          */
+    const u32 lane_byte = lane_blk * 16u;
+    /* the text of a stripe through a buffer resource whose base is the stripe (four SGPRs, rebuilt by scalar
+     * instructions every iteration) + the lane's constant byte offset + 16 KiB for the second block of the lane */
+    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+#define STRIPE_RSRC(p) __builtin_amdgcn_make_buffer_rsrc( \
+        (void *)(((u64)(u32)__builtin_amdgcn_readfirstlane((int)((u64)(p) >> 32)) << 32) | \
+                 (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(u64)(p))), 0, 0x7fffffff, 0x00020000)
+    auto refill = [&](u64 it) {
+        {
             if (wave == 0) {
                 /* uniform part of rounds 1 and 2 for the 64 groups of iterations it .. it+7:
                  * lane gi handles group group0(it + gi/8) + gi%8                          */
@@ -203,12 +215,18 @@ __device__ __forceinline__ void ctr_shared_loop(const uaesk_rk &rk, const uaesk_
             chunk_same = __builtin_amdgcn_readfirstlane((int)hdr.y) != 0;
         }
 
+    };
+    auto body = [&](u64 it, uint4 (&d_cur)[2], uint4 (&d_nxt)[2]) {
         /* request the next iteration's plaintext (clamped to this workgroup's last one) */
         const u64 g0 = ctr_geo_group0(geo, it);
         {
             const u64 gn = ctr_geo_group0(geo, it + 1 < geo.iters ? it + 1 : it);
+            const __amdgpu_buffer_rsrc_t rin = STRIPE_RSRC(in + ((gn << 8) - c0));
 #pragma unroll
-            for (int u = 0; u < 2; ++u) d_nxt[u] = (in + (((gn + 4u * u) << 8) - c0))[lane_blk];
+            for (int u = 0; u < 2; ++u) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rin, lane_byte, 16384 * u, 0);
+                d_nxt[u] = make_uint4(v.x, v.y, v.z, v.w);
+            }
 #ifdef UAES_CTR_NOLOAD                   /* timing-only build (wrong results): what do the text loads cost in cycles? */
             (void)gn;
 #pragma unroll
@@ -234,22 +252,58 @@ __device__ __forceinline__ void ctr_shared_loop(const uaesk_rk &rk, const uaesk_
 #undef TL
             s[u][0] = L0 ^ uu.x; s[u][1] = L1 ^ uu.y; s[u][2] = L2 ^ uu.z; s[u][3] = L3 ^ uu.w;
         }
+#ifdef UAES_ASM_VARIANT
+        if constexpr (LC::LAY == 0) enc_rounds_asm<NR - 2>(s[0], s[1], rkv.w, lc);
+        else
+#endif
         enc_rounds_skewed<NR, 3, decltype(rkv), false, LC, FOLD::round_prio>(s[0], s[1], rkv, lc);
         uint4 ct[2];
+        const __amdgpu_buffer_rsrc_t rout = STRIPE_RSRC(out + ((g0 << 8) - c0));
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             ct[u] = make_uint4(d_cur[u].x ^ s[u][0], d_cur[u].y ^ s[u][1], d_cur[u].z ^ s[u][2], d_cur[u].w ^ s[u][3]);
 #ifdef UAES_CTR_NOSTORE                  /* timing-only build: keep the value alive, store (almost) never */
             if (ct[u].x == 0x12345678u && ct[u].y == 0x9abcdef0u && ct[u].z == it)
 #endif
-            (out + (((g0 + 4u * u) << 8) - c0))[lane_blk] = ct[u];
+            __builtin_amdgcn_raw_buffer_store_b128((u32x4){ct[u].x, ct[u].y, ct[u].z, ct[u].w}, rout, lane_byte, 16384 * u, 0);
         }
         if (FOLD::of_input) fold(d_cur[0], d_cur[1]); else fold(ct[0], ct[1]);
+    };
+    uint4 d_a[2], d_b[2];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) d_cur[u] = d_nxt[u];
-        ++it;
-        if ((it & 7) == 0) parity ^= 1u;
+    for (int u = 0; u < 2; ++u) d_a[u] = d_cur[u];
+#if defined(UAES_CTR_NO_EXPAND2) || defined(UAES_ASM_VARIANT)
+    /* measurement builds.  The hand-scheduled round blocks (UAES_ASM_VARIANT, tools/gen_rounds_asm.py) are bit-exact
+     * with the body once per trip; with TWO >100-operand asm statements per trip the build's output is wrong and varies
+     * from run to run (profiles/r04_ctr_asm_variants_ab.log, third table) -- not understood, so not allowed.          */
+    constexpr bool twice = false;
+#else
+    constexpr bool twice = FOLD::expand2;
+#endif
+    if constexpr (twice) {
+        while (it + 2 <= geo.iters) {
+            if ((it & 7) == 0) refill(it);
+            body(it, d_a, d_b);
+            body(it + 1, d_b, d_a);
+            it += 2;
+            if ((it & 7) == 0) parity ^= 1u;
+        }
+        if (it < geo.iters) {                               /* an odd count: the last stripe alone */
+            if ((it & 7) == 0) refill(it);
+            body(it, d_a, d_b);
+            ++it;
+        }
+    } else {                                                /* a fold too big to hold twice (GCM: it would spill) */
+        while (it < geo.iters) {
+            if ((it & 7) == 0) refill(it);
+            body(it, d_a, d_b);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) d_a[u] = d_b[u];
+            ++it;
+            if ((it & 7) == 0) parity ^= 1u;
+        }
     }
+#undef STRIPE_RSRC
 #ifdef UAES_CTR_TIMING
     if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 100))
         printf("wg %u wave %2u: loop %llu barrier-wait %llu (x10 ns)\n", blockIdx.x, wave,

@@ -12,6 +12,7 @@
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
 
+#include <dlfcn.h>
 #include <pthread.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -551,11 +552,20 @@ static int env_int(const char *name, int dflt, int lo, int hi);
 #define TICKET_DATA_OFF (4096 - 64)              /* 64 bytes of fetched result behind it     */
 #define TICKET_SPIN_US  200
 
+/* every setting read from the environment, once per process and race-free (the lazily initialised
+ * function-local statics were a benign but real data race between the first calls of two threads) */
+static struct {
+    int    ticket, pipe_workers;
+    size_t pin_bytes, zero_copy_max, pipe_slice;
+} g_env;
+static pthread_once_t g_env_once = PTHREAD_ONCE_INIT;
+static void env_init(void);
+static inline void env_ready(void) { (void)pthread_once(&g_env_once, env_init); }
+
 static int ticket_enabled(void)
 {
-    static int on = -1;
-    if (on < 0) on = env_int("UAES_TICKET", 1, 0, 1);
-    return on;
+    env_ready();
+    return g_env.ticket;
 }
 
 static int64_t now_us(void)
@@ -704,30 +714,42 @@ static int env_int(const char *name, int dflt, int lo, int hi);
 
 static size_t pin_bytes(void)
 {
-    static size_t z = 0;
-    if (!z) z = (size_t)env_int("UAES_PIN_KIB", 1024, 16, 65536) << 10;
-    return z;
+    env_ready();
+    return g_env.pin_bytes;
 }
 #define PIN_BYTES pin_bytes()
 
 static size_t zero_copy_max(void)
 {
-    static size_t z = (size_t)-1;
-    if (z == (size_t)-1) z = (size_t)env_int("UAES_ZEROCOPY_MAX_KIB", 1024, 0, (int)(PIN_BYTES >> 10)) << 10;
-    return z;
+    env_ready();
+    return g_env.zero_copy_max;
+}
+
+/* The ticket word, the fetched result bytes and the zero-copy windows are written by kernels and read by the host
+ * after it has seen a flag change, with no runtime call in between: that needs fine-grained, coherent, GPU-mapped
+ * host memory.  hipHostMallocDefault gives that only as long as nobody sets HIP_HOST_COHERENT=0, so it is asked for
+ * by name; a runtime that refuses the flags gets the default request (and its default behaviour) instead.       */
+static hipError_t pinned_alloc(void **p, size_t bytes)
+{
+    hipError_t e = hipHostMalloc(p, bytes, hipHostMallocCoherent | hipHostMallocMapped);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        e = hipHostMalloc(p, bytes, hipHostMallocDefault);
+    }
+    return e;
 }
 
 static int pinned_ready(lane *L)
 {
     int i;
     for (i = 0; i < 2; ++i)
-        if (!L->pin[i] && hipHostMalloc(&L->pin[i], PIN_BYTES + 64, hipHostMallocDefault) != hipSuccess) {
+        if (!L->pin[i] && pinned_alloc(&L->pin[i], PIN_BYTES + 64) != hipSuccess) {
             (void)hipGetLastError();
             L->pin[i] = NULL;
             return 0;                             /* no pinned memory: the pageable path still works */
         }
     if (!L->pinx) {
-        if (hipHostMalloc(&L->pinx, 4096, hipHostMallocDefault) != hipSuccess) {
+        if (pinned_alloc(&L->pinx, 4096) != hipSuccess) {
             (void)hipGetLastError();
             L->pinx = NULL;
             return 0;
@@ -859,18 +881,25 @@ static int env_int(const char *name, int dflt, int lo, int hi)
     return (int)v;
 }
 
+static void env_init(void)
+{
+    g_env.ticket = env_int("UAES_TICKET", 1, 0, 1);
+    g_env.pin_bytes = (size_t)env_int("UAES_PIN_KIB", 1024, 16, 65536) << 10;
+    g_env.zero_copy_max = (size_t)env_int("UAES_ZEROCOPY_MAX_KIB", 1024, 0, (int)(g_env.pin_bytes >> 10)) << 10;
+    g_env.pipe_workers = env_int("UAES_PIPE_WORKERS", 4, 1, PIPE_MAXW);
+    g_env.pipe_slice = (size_t)env_int("UAES_PIPE_SLICE_MIB", 16, 1, 1024) << 20;
+}
+
 static int pipe_workers(void)
 {
-    static int w = 0;
-    if (!w) w = env_int("UAES_PIPE_WORKERS", 4, 1, PIPE_MAXW);
-    return w;
+    env_ready();
+    return g_env.pipe_workers;
 }
 
 static size_t pipe_slice_bytes(void)
 {
-    static size_t sl = 0;
-    if (!sl) sl = (size_t)env_int("UAES_PIPE_SLICE_MIB", 16, 1, 1024) << 20;
-    return sl;
+    env_ready();
+    return g_env.pipe_slice;
 }
 
 #define PFAIL(j, ...) do { (j)->rc = UAES_E_HIP; snprintf((j)->err, sizeof (j)->err, __VA_ARGS__); return NULL; } while (0)
@@ -1916,6 +1945,10 @@ static int records_sync(uaes_gcm_key *k, int decrypt, size_t nrec, const uint8_t
             if (grow_on(st, &L->stage[1], &L->stage_cap[1], ver_off + nrec + 64)) { rc = UAES_E_HIP; break; }
             d_out = (unsigned char *)L->stage[1];
             d_ver = d_out + ver_off;
+            /* variable-length records: the kernel writes lens[r] (+16) bytes of a slot and whole slots are copied
+             * back, so what lies between must not be whatever an earlier call of this thread left in the staging
+             * buffer (another message's plaintext): the slots' tails come back as zeros */
+            if (lens && hipMemsetAsync(d_out, 0, out_span, st) != hipSuccess) { rc = fail(UAES_E_HIP, "memset failed"); break; }
         }
         if (decrypt && hipMemsetAsync(L->d_status, 0, sizeof(int), st) != hipSuccess) { rc = fail(UAES_E_HIP, "memset failed"); break; }
         {
@@ -1935,13 +1968,26 @@ static int records_sync(uaes_gcm_key *k, int decrypt, size_t nrec, const uint8_t
                     rc = fail(UAES_E_HIP, "verdict copy failed");
                     break;
                 }
-                if (status) {                                 /* the good records one by one (N7 for the others) */
-                    size_t r;
-                    for (r = 0; r < nrec && rc == 0; ++r)
-                        if (v[r] == 0 && rec_len &&
-                            hipMemcpyAsync((char *)out + r * out_stride, d_out + r * out_stride,
-                                           lens && !is_device_ptr(lens) ? lens[r] : rec_len, hipMemcpyDefault, st) != hipSuccess)
+                if (status) {                                 /* the good records (N7 for the others): runs of consecutive
+                                                               * good records go back as one 2-D copy each */
+                    const int host_lens = lens && !is_device_ptr(lens);
+                    size_t r = 0;
+                    while (r < nrec && rc == 0 && rec_len) {
+                        size_t e;
+                        if (v[r]) { ++r; continue; }
+                        if (host_lens) {                       /* exactly lens[r] bytes each: one record per copy */
+                            if (lens[r] && hipMemcpyAsync((char *)out + r * out_stride, d_out + r * out_stride, lens[r],
+                                                          hipMemcpyDefault, st) != hipSuccess)
+                                rc = fail(UAES_E_HIP, "copy back failed");
+                            ++r;
+                            continue;
+                        }
+                        for (e = r + 1; e < nrec && v[e] == 0; ++e) { }
+                        if (hipMemcpy2DAsync((char *)out + r * out_stride, out_stride, d_out + r * out_stride, out_stride,
+                                             rec_len, e - r, hipMemcpyDefault, st) != hipSuccess)
                             rc = fail(UAES_E_HIP, "copy back failed");
+                        r = e;
+                    }
                     if (v != verdicts) free(v);
                     if (rc == 0 && hipStreamSynchronize(st) != hipSuccess) rc = fail(UAES_E_HIP, "copy back failed");
                     if (rc == 0) rc = UAES_E_AUTHENTICATION;
@@ -1976,7 +2022,8 @@ int uaes_gcm_key_decrypt_records(uaes_gcm_key *k, size_t nrec, const uint8_t *no
 
 /* records of DIFFERENT lengths in slots of one size (packet buffers): record r is lens[r] <= max_len bytes at the start of
  * its slot, its tag follows its own text.  What else of a slot's first max_len + 16 output bytes holds afterwards is
- * unspecified (the synchronous flavour copies whole slots back). */
+ * unspecified, but never another call's data: the synchronous flavour copies whole slots back from a staging buffer
+ * whose slots were zeroed before the launch, so the tail of a slot reads as zeros. */
 int uaes_gcm_key_encrypt_records_v(uaes_gcm_key *k, size_t nrec, const uint8_t *nonces,
                                    const void *aad, size_t aad_len, size_t aad_stride,
                                    const void *in, const uint32_t *lens, size_t max_len, size_t in_stride,
@@ -2756,6 +2803,7 @@ static void *mgpu_worker(void *arg)
         snprintf(j->err, sizeof j->err, "hipSetDevice(%d): %s", j->device, hipGetErrorString(e));
         return NULL;
     }
+    if (j->mode == 2) return NULL;                       /* an empty slice */
     j->rc = j->mode == 0
         ? uaes_ctr_xcrypt_at(j->keybits, j->key, j->ctr0, j->offset, j->in, j->len, j->out)
         : uaes_xts_sectors(j->keybits, j->key, j->offset, j->sector_bytes, j->nsectors, j->in, j->out, j->encrypt);
@@ -2763,16 +2811,93 @@ static void *mgpu_worker(void *arg)
     return NULL;
 }
 
+/* One PERSISTENT worker thread per device ordinal, started the first time a multi-GPU call names the device
+ * (threads created per call also created and destroyed their per-thread lane -- a stream, pinned
+ * windows, staging -- per call, milliseconds of hipHostMalloc / hipHostFree for a medium-sized text).  A call hands
+ * every slice to the worker of its device and waits for all of them; slices of one device run one after the other on
+ * that device's worker, slices of different devices side by side.  Calls from several host threads queue up
+ * per worker.  The workers live until the process ends (they hold nothing but their lane).                  */
+typedef struct mgpu_item {
+    mgpu_job *job;
+    int *left;                                   /* jobs of the same call still running (under done_mu) */
+    pthread_mutex_t *done_mu;
+    pthread_cond_t *done_cv;
+    struct mgpu_item *next;
+} mgpu_item;
+
+static struct {
+    pthread_t th;
+    int started;
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+    mgpu_item *head, *tail;
+} g_mgpu[MAX_DEVICES];
+static pthread_mutex_t g_mgpu_start_mu = PTHREAD_MUTEX_INITIALIZER;
+
+static void *mgpu_pool_thread(void *arg)
+{
+    const int d = (int)(intptr_t)arg;
+    for (;;) {
+        mgpu_item *it;
+        pthread_mutex_lock(&g_mgpu[d].mu);
+        while (!g_mgpu[d].head) pthread_cond_wait(&g_mgpu[d].cv, &g_mgpu[d].mu);
+        it = g_mgpu[d].head;
+        g_mgpu[d].head = it->next;
+        if (!g_mgpu[d].head) g_mgpu[d].tail = NULL;
+        pthread_mutex_unlock(&g_mgpu[d].mu);
+        (void)mgpu_worker(it->job);
+        pthread_mutex_lock(it->done_mu);
+        if (--*it->left == 0) pthread_cond_signal(it->done_cv);
+        pthread_mutex_unlock(it->done_mu);
+    }
+    return NULL;
+}
+
+static int mgpu_pool_ensure(int d)
+{
+    int ok = 1;
+    pthread_mutex_lock(&g_mgpu_start_mu);
+    if (!g_mgpu[d].started) {
+        pthread_attr_t at;
+        pthread_mutex_init(&g_mgpu[d].mu, NULL);
+        pthread_cond_init(&g_mgpu[d].cv, NULL);
+        pthread_attr_init(&at);
+        pthread_attr_setdetachstate(&at, PTHREAD_CREATE_DETACHED);
+        ok = pthread_create(&g_mgpu[d].th, &at, mgpu_pool_thread, (void *)(intptr_t)d) == 0;
+        pthread_attr_destroy(&at);
+        g_mgpu[d].started = ok;
+    }
+    pthread_mutex_unlock(&g_mgpu_start_mu);
+    return ok;
+}
+
 static int mgpu_run(mgpu_job *jobs, int n)
 {
-    pthread_t th[MAX_DEVICES];
-    int i, started = 0, rc = 0;
+    mgpu_item items[MAX_DEVICES];
+    pthread_mutex_t done_mu = PTHREAD_MUTEX_INITIALIZER;
+    pthread_cond_t done_cv = PTHREAD_COND_INITIALIZER;
+    int i, left = 0, rc = 0;
+    for (i = 0; i < n; ++i)
+        if (!mgpu_pool_ensure(jobs[i].device)) return fail(UAES_E_HIP, "pthread_create failed");
+    pthread_mutex_lock(&done_mu);
+    left = n;
+    pthread_mutex_unlock(&done_mu);
     for (i = 0; i < n; ++i) {
-        if (pthread_create(&th[i], NULL, mgpu_worker, &jobs[i]) != 0) { rc = fail(UAES_E_HIP, "pthread_create failed"); break; }
-        ++started;
+        const int d = jobs[i].device;
+        items[i].job = &jobs[i]; items[i].left = &left; items[i].done_mu = &done_mu; items[i].done_cv = &done_cv;
+        items[i].next = NULL;
+        pthread_mutex_lock(&g_mgpu[d].mu);
+        if (g_mgpu[d].tail) g_mgpu[d].tail->next = &items[i]; else g_mgpu[d].head = &items[i];
+        g_mgpu[d].tail = &items[i];
+        pthread_cond_signal(&g_mgpu[d].cv);
+        pthread_mutex_unlock(&g_mgpu[d].mu);
     }
-    for (i = 0; i < started; ++i) pthread_join(th[i], NULL);
-    for (i = 0; i < started && rc == 0; ++i)
+    pthread_mutex_lock(&done_mu);
+    while (left) pthread_cond_wait(&done_cv, &done_mu);
+    pthread_mutex_unlock(&done_mu);
+    pthread_mutex_destroy(&done_mu);
+    pthread_cond_destroy(&done_cv);
+    for (i = 0; i < n && rc == 0; ++i)
         if (jobs[i].rc) rc = jobs[i].rc < 0 ? fail(jobs[i].rc, "%s", jobs[i].err) : jobs[i].rc;
     return rc;
 }
@@ -2833,4 +2958,177 @@ int uaes_mgpu_xts_sectors(int ndev, const int *devices, int keybits, const uint8
         ++n;
     }
     return n ? mgpu_run(jobs, n) : 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* CTR over several GPUs with the ciphertext gathered on one of them over xGMI */
+/* (BASELINE configs[4]; north_star: "RCCL over xGMI only for the final         */
+/* ciphertext gather", host code in C).  RCCL is a SOFT dependency: librccl.so  */
+/* is opened with dlopen the first time more than one device takes part, and a  */
+/* box without it gets UAES_E_HIP with the loader's message, not a link error.  */
+/* ------------------------------------------------------------------------ */
+typedef struct { char internal[128]; } rccl_unique_id;
+typedef void *rccl_comm;
+typedef struct {
+    void *handle;
+    int (*CommInitAll)(rccl_comm *comms, int ndev, const int *devlist);
+    int (*CommDestroy)(rccl_comm comm);
+    int (*GroupStart)(void);
+    int (*GroupEnd)(void);
+    int (*Send)(const void *buf, size_t count, int dtype, int peer, rccl_comm comm, hipStream_t st);
+    int (*Recv)(void *buf, size_t count, int dtype, int peer, rccl_comm comm, hipStream_t st);
+    const char *(*GetErrorString)(int rc);
+    int tried;
+    char err[256];
+} rccl_api;
+#define RCCL_UINT8 1                                      /* ncclUint8 (nccl.h: ncclInt8 = 0, ncclUint8 = 1) */
+
+static rccl_api g_rccl;
+static pthread_mutex_t g_rccl_mu = PTHREAD_MUTEX_INITIALIZER;
+
+/* the communicators of ONE device list are kept for the life of the process: ncclCommInitAll costs seconds */
+static struct {
+    int ndev, devs[MAX_DEVICES], ready;
+    rccl_comm comm[MAX_DEVICES];
+    hipStream_t stream[MAX_DEVICES];
+} g_gather;
+
+static int rccl_load(void)
+{
+    static const char *names[] = { NULL, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so" };
+    size_t i;
+    if (g_rccl.handle) return 0;
+    if (g_rccl.tried) return fail(UAES_E_HIP, "RCCL is not available: %s", g_rccl.err);
+    g_rccl.tried = 1;
+    names[0] = getenv("UAES_RCCL_LIB");
+    for (i = 0; i < sizeof names / sizeof names[0] && !g_rccl.handle; ++i) {
+        if (!names[i] || !*names[i]) continue;
+        g_rccl.handle = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+        if (!g_rccl.handle) snprintf(g_rccl.err, sizeof g_rccl.err, "%s", dlerror());
+        if (i == 0 && !g_rccl.handle) break;              /* an explicit UAES_RCCL_LIB that does not load is an error, not a hint */
+    }
+    if (!g_rccl.handle) return fail(UAES_E_HIP, "RCCL is not available: %s", g_rccl.err);
+#define RCCL_SYM(field, name) \
+    do { *(void **)&g_rccl.field = dlsym(g_rccl.handle, name); \
+         if (!g_rccl.field) { snprintf(g_rccl.err, sizeof g_rccl.err, "%s not found in librccl", name); \
+                              dlclose(g_rccl.handle); g_rccl.handle = NULL; return fail(UAES_E_HIP, "RCCL is not available: %s", g_rccl.err); } } while (0)
+    RCCL_SYM(CommInitAll, "ncclCommInitAll"); RCCL_SYM(CommDestroy, "ncclCommDestroy");
+    RCCL_SYM(GroupStart, "ncclGroupStart");   RCCL_SYM(GroupEnd, "ncclGroupEnd");
+    RCCL_SYM(Send, "ncclSend");               RCCL_SYM(Recv, "ncclRecv");
+    RCCL_SYM(GetErrorString, "ncclGetErrorString");
+#undef RCCL_SYM
+    return 0;
+}
+
+static int rccl_fail(const char *what, int rc)
+{
+    return fail(UAES_E_HIP, "%s: %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "RCCL error");
+}
+
+/* communicators + one stream per device for this device list (mutex held) */
+static int gather_setup(int ndev, const int *dev)
+{
+    int i, rc, prev = -1;
+    if (g_gather.ready && g_gather.ndev == ndev && memcmp(g_gather.devs, dev, (size_t)ndev * sizeof *dev) == 0) return 0;
+    (void)hipGetDevice(&prev);
+    if (g_gather.ready) {                                  /* another device list: start over */
+        for (i = 0; i < g_gather.ndev; ++i) {
+            (void)g_rccl.CommDestroy(g_gather.comm[i]);
+            if (hipSetDevice(g_gather.devs[i]) == hipSuccess) (void)hipStreamDestroy(g_gather.stream[i]);
+        }
+        g_gather.ready = 0;
+    }
+    for (i = 0; i < ndev; ++i)
+        if (hipSetDevice(dev[i]) != hipSuccess || hipStreamCreateWithFlags(&g_gather.stream[i], hipStreamNonBlocking) != hipSuccess) {
+            while (--i >= 0) if (hipSetDevice(dev[i]) == hipSuccess) (void)hipStreamDestroy(g_gather.stream[i]);
+            if (prev >= 0) (void)hipSetDevice(prev);
+            return fail(UAES_E_HIP, "stream creation for the gather failed");
+        }
+    rc = g_rccl.CommInitAll(g_gather.comm, ndev, dev);
+    if (prev >= 0) (void)hipSetDevice(prev);
+    if (rc != 0) {
+        for (i = 0; i < ndev; ++i) if (hipSetDevice(dev[i]) == hipSuccess) (void)hipStreamDestroy(g_gather.stream[i]);
+        if (prev >= 0) (void)hipSetDevice(prev);
+        return rccl_fail("ncclCommInitAll", rc);
+    }
+    memcpy(g_gather.devs, dev, (size_t)ndev * sizeof *dev);
+    g_gather.ndev = ndev;
+    g_gather.ready = 1;
+    return 0;
+}
+
+int uaes_mgpu_ctr_encrypt_gather(int ndev, const int *devices, int keybits, const uint8_t *key,
+                                 const uint8_t ctr0[16], uint64_t block_offset,
+                                 const void *const *d_in, size_t len, void *const *d_out,
+                                 int root, void *d_full_on_root)
+{
+    mgpu_job jobs[MAX_DEVICES];
+    size_t lo[MAX_DEVICES], hi[MAX_DEVICES];
+    int dev[MAX_DEVICES], i, rc, prev = -1;
+    const size_t blocks = (len + 15) / 16;
+    if (!key || !ctr0 || (len && (!d_in || !d_full_on_root))) return fail(UAES_E_ARG, "NULL pointer");
+    if ((rc = mgpu_devices(ndev, devices, dev)) != 0) return rc;
+    if (root < 0 || root >= ndev) return fail(UAES_E_ARG, "root %d is not one of the %d devices", root, ndev);
+    if (!len) return 0;
+    memset(jobs, 0, sizeof jobs);
+    for (i = 0; i < ndev; ++i) {
+        const size_t b0 = blocks * (size_t)i / (size_t)ndev, b1 = blocks * (size_t)(i + 1) / (size_t)ndev;
+        lo[i] = b0 * 16; hi[i] = b1 * 16 < len ? b1 * 16 : len;
+        if (hi[i] < lo[i]) hi[i] = lo[i];
+        if (hi[i] > lo[i] && !d_in[i]) return fail(UAES_E_ARG, "no input shard for device %d", dev[i]);
+        if (hi[i] > lo[i] && dev[i] != dev[root] && (!d_out || !d_out[i])) return fail(UAES_E_ARG, "no output shard for device %d", dev[i]);
+        jobs[i].device = dev[i]; jobs[i].keybits = keybits; jobs[i].key = key; jobs[i].mode = hi[i] > lo[i] ? 0 : 2;
+        memcpy(jobs[i].ctr0, ctr0, 16);
+        jobs[i].offset = block_offset + b0;
+        jobs[i].in = d_in[i];
+        /* a slice on the root's device is encrypted straight into its place in the gathered text unless the caller
+         * also wants it in a shard buffer of its own */
+        jobs[i].out = (dev[i] == dev[root] && !(d_out && d_out[i])) ? (void *)((char *)d_full_on_root + lo[i]) : d_out[i];
+        jobs[i].len = hi[i] - lo[i];
+    }
+    if ((rc = mgpu_run(jobs, ndev)) != 0) return rc;
+    (void)hipGetDevice(&prev);
+    {
+        /* slices that live on the root's own device (its own, and those of a device list that names the device more
+         * than once) are device-to-device copies; the others travel by RCCL, one send / receive pair each */
+        int uniq[MAX_DEVICES], rank_of[MAX_DEVICES], nu = 0, remote = 0, u;
+        for (i = 0; i < ndev; ++i) {
+            for (u = 0; u < nu && uniq[u] != dev[i]; ++u) { }
+            if (u == nu) uniq[nu++] = dev[i];
+            rank_of[i] = u;
+            if (dev[i] != dev[root] && hi[i] > lo[i]) ++remote;
+        }
+        if (hipSetDevice(dev[root]) != hipSuccess) rc = fail(UAES_E_HIP, "hipSetDevice(%d) failed", dev[root]);
+        for (i = 0; i < ndev && rc == 0; ++i) {
+            if (dev[i] != dev[root] || hi[i] == lo[i] || jobs[i].out == (void *)((char *)d_full_on_root + lo[i])) continue;
+            if (hipMemcpy((char *)d_full_on_root + lo[i], jobs[i].out, hi[i] - lo[i], hipMemcpyDeviceToDevice) != hipSuccess)
+                rc = fail(UAES_E_HIP, "copying a local slice into place failed: %s", hipGetErrorString(hipGetLastError()));
+        }
+        if (rc == 0 && remote) {
+            int g, started = 0;
+            pthread_mutex_lock(&g_rccl_mu);
+            rc = rccl_load();
+            if (rc == 0) rc = gather_setup(nu, uniq);
+            if (rc == 0 && (g = g_rccl.GroupStart()) != 0) rc = rccl_fail("ncclGroupStart", g);
+            if (rc == 0) {
+                started = 1;
+                for (i = 0; i < ndev && rc == 0; ++i) {
+                    if (dev[i] == dev[root] || hi[i] == lo[i]) continue;
+                    if ((g = g_rccl.Send(jobs[i].out, hi[i] - lo[i], RCCL_UINT8, rank_of[root], g_gather.comm[rank_of[i]],
+                                         g_gather.stream[rank_of[i]])) != 0)
+                        rc = rccl_fail("ncclSend", g);
+                    else if ((g = g_rccl.Recv((char *)d_full_on_root + lo[i], hi[i] - lo[i], RCCL_UINT8, rank_of[i],
+                                              g_gather.comm[rank_of[root]], g_gather.stream[rank_of[root]])) != 0)
+                        rc = rccl_fail("ncclRecv", g);
+                }
+            }
+            if (started && (g = g_rccl.GroupEnd()) != 0 && rc == 0) rc = rccl_fail("ncclGroupEnd", g);
+            for (u = 0; u < nu && rc == 0; ++u)
+                if (hipSetDevice(uniq[u]) != hipSuccess || hipStreamSynchronize(g_gather.stream[u]) != hipSuccess)
+                    rc = fail(UAES_E_HIP, "the gather did not complete on device %d: %s", uniq[u], hipGetErrorString(hipGetLastError()));
+            pthread_mutex_unlock(&g_rccl_mu);
+        }
+    }
+    if (prev >= 0) (void)hipSetDevice(prev);
+    return rc;
 }

@@ -743,6 +743,7 @@ template <bool DEC>
 struct GhFold {
     static constexpr bool of_input = DEC;
     static constexpr int round_prio = 2;       /* cipher lookups 2 > GHASH lookups 1 > XOR work 0 */
+    static constexpr bool expand2 = false;     /* the loop body once per trip: twice would spill (128 VGPRs are all in use) */
     uint4 acc[2];
     GhLane gl;
     __device__ __forceinline__ void operator()(const uint4 &c0, const uint4 &c1)

@@ -96,7 +96,7 @@ def test_bench_two_rank_dry_run(workload):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--backend", "gloo", "--single-device", "--bytes", str(64 << 20), "--settle-ms", "0",
+           "--backend", "gloo", "--single-device", "--bytes", str(64 << 20), "--settle-ms", "0", "--sustain-s", "0.2",
            "--workload", workload]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -123,7 +123,7 @@ def test_bench_self_launch_verifies_every_shard():
     reference's digest of that shard of the C5 stream (PRESET_COUNTER build of the reference)."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--backend", "gloo", "--single-device", "--settle-ms", "0"]
+           "--backend", "gloo", "--single-device", "--settle-ms", "0", "--sustain-s", "0.5"]
     line = _one_json_line(subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900))
     assert line["n_gpus"] == 2 and line["verified"] is True
     assert line["verified_shards"].startswith("every rank hashed its whole shard")
@@ -149,6 +149,14 @@ def test_bench_line_measures_its_own_traffic_and_clock():
     lc = roof["lds_ceiling"]
     assert lc and lc["lookups_per_block"] == 128 and 1500 < lc["sclk_mhz_under_load"] < 2500
     assert 0.6 < lc["frac_of_ceiling"] < 1.0, lc
+    # the sustained rate (>= 2 s of the same step back to back) rides next to `value`; the 12 ms window
+    # behind `value` may catch the clocks a little high, never the other way round by more than noise
+    sus = line["sustained"]
+    assert sus["seconds"] >= 1.9 and sus["steps"] >= 1000 and sus["unit"] == "GiB/s"
+    assert sus["value"] <= line["value"] * 1.02, (sus, line["value"])
+    assert sus["value"] >= line["value"] * 0.85, (sus, line["value"])
+    assert abs(roof["frac_sustained"] - 2.0 * (1 << 30) / (sus["ms_per_step"] * 1e-3) / 1e9 / roof["peak"]) < 1e-3
+    assert sus["sclk_mhz"] == lc["sclk_mhz_under_load"]
 
 
 def test_bench_two_ranks_rccl():
@@ -161,3 +169,32 @@ def test_bench_two_ranks_rccl():
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--gather"]
     line = _one_json_line(subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900))
     assert line["n_gpus"] == 2 and line["verified"] is True and line["gather_ms"] > 0
+
+
+def test_bench_two_ranks_survive_an_rccl_failure():
+    """`bench.py --gpus 2` with the default nccl backend, both ranks on this box's one GPU and the RCCL
+    bring-up forced to fail on every rank (UAES_BENCH_FORCE_NCCL_FAIL): the run must fall back to gloo for the control
+    plane, still time and verify both shards, and say what happened in `collective_backend`."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(UAES_BENCH_FORCE_NCCL_FAIL="1", UAES_BENCH_RCCL_WAIT_S="30")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--single-device", "--bytes", str(64 << 20), "--settle-ms", "0", "--sustain-s", "0.2", "--gather", "--c-gather"]
+    line = _one_json_line(subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900))
+    assert line["n_gpus"] == 2 and line["verified"] is True and line["value"] > 0
+    assert line["collective_backend"].startswith("gloo (nccl init failed: RuntimeError: forced by"), line["collective_backend"]
+    assert "gather_ms" not in line                       # the torch.distributed gather is RCCL-only
+    # the C host's gather needs no RCCL when every shard sits on the root's device: it ran, and shard 0 is the step's output
+    assert line["c_gather"].get("shard0_equals_own_step") is True, line["c_gather"]
+    assert line["sustained"]["value"] > 0
+
+
+def test_bench_two_ranks_real_rccl_bring_up_on_one_device():
+    """the same WITHOUT forcing: two ranks really ask RCCL for a communicator on the same device.  Whatever RCCL does
+    with that (it refuses duplicate devices), the bench line must come out verified, on RCCL or on the gloo fallback."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(UAES_BENCH_RCCL_WAIT_S="60")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--single-device", "--bytes", str(64 << 20), "--settle-ms", "0", "--sustain-s", "0.2"]
+    line = _one_json_line(subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900))
+    assert line["n_gpus"] == 2 and line["verified"] is True
+    assert line["collective_backend"].startswith(("gloo (nccl init failed", "nccl (RCCL)")), line["collective_backend"]

@@ -1411,3 +1411,49 @@ def test_gmac_of_a_bulk_text(orc):
             assert L.uaes_gcm_encrypt(128, key, nonce, C.c_void_p(t.data_ptr() + off), n, None, 0, tag) == 0
             assert bytes(tag) == want, (n, off)
             assert L.uaes_gcm_decrypt(128, key, nonce, C.c_void_p(t.data_ptr() + off), n, tag, 0, None) == 0
+
+
+def test_gcm_records_v_slot_tails_hold_no_earlier_message(orc):
+    """the synchronous variable-length record calls copy whole slots back from a per-thread staging buffer
+    that is reused across calls.  The bytes of a slot behind lens[r] (+ tag) must not be an EARLIER call's text: after a
+    call with long, recognisable records, a call with short ones must return slots whose tails are zeros, in both
+    directions (decrypt: only the text is defined, the rest of the slot's max_len bytes)."""
+    import ctypes as C
+    L = uaes.engine()
+    key = bytes(range(16))
+    k = uaes.GcmKey(key)
+    try:
+        nrec, max_len, stride = 64, 1024, 1024 + 16
+        marker = b"\xA5SECRET\x5A" * 128
+        long_recs = [marker[:max_len] for _ in range(nrec)]
+        nonces = [bytes([r]) * 12 for r in range(nrec)]
+        ct_long = k.encrypt_records_v(nonces, b"", long_recs, max_len=max_len, stride=stride)
+        rc, ver, texts = k.decrypt_records_v(nonces, b"", ct_long, max_len=max_len, stride=stride)      # plaintext now sits in the staging
+        assert rc == 0 and texts == long_recs
+        short = [bytes([r]) * (r % 7) for r in range(nrec)]
+        lens = (C.c_uint32 * nrec)(*[len(s) for s in short])
+        src = bytearray(stride * nrec)
+        for r, s in enumerate(short):
+            src[r * stride: r * stride + len(s)] = s
+        dst = (C.c_ubyte * (stride * nrec))(*([0xEE] * (stride * nrec)))
+        nb = b"".join(nonces)
+        assert L.uaes_gcm_key_encrypt_records_v(k._h, nrec, nb, None, 0, 0, bytes(src), lens, max_len, stride, dst, stride) == 0
+        out = bytes(dst)
+        for r, s in enumerate(short):
+            slot = out[r * stride: (r + 1) * stride]
+            assert slot[: len(s) + 16] == orc.gcm_encrypt(key, nonces[r], b"", s)
+            assert slot[len(s) + 16: max_len + 16] == bytes(max_len - len(s)), "slot %d leaks staging bytes" % r
+        # decrypt direction: the ciphertexts just made, text slots of max_len bytes
+        cts = bytearray(stride * nrec)
+        for r, s in enumerate(short):
+            cts[r * stride: r * stride + len(s) + 16] = out[r * stride: r * stride + len(s) + 16]
+        dst2 = (C.c_ubyte * (stride * nrec))(*([0xEE] * (stride * nrec)))
+        ver = (C.c_ubyte * nrec)()
+        assert L.uaes_gcm_key_decrypt_records_v(k._h, nrec, nb, None, 0, 0, bytes(cts), lens, max_len, stride, dst2, stride, ver) == 0
+        out2 = bytes(dst2)
+        for r, s in enumerate(short):
+            assert out2[r * stride: r * stride + len(s)] == s
+            assert marker[:8] not in out2[r * stride: r * stride + max_len], "slot %d leaks an earlier plaintext" % r
+            assert out2[r * stride + len(s): r * stride + max_len] == bytes(max_len - len(s))
+    finally:
+        k.close()

@@ -523,3 +523,57 @@ def test_sync_api_orders_after_the_callers_default_stream_work(orc):
         assert got == orc.ctr_xcrypt_at(key, ctr0, 0, bytes([rep + 1]) * 4096)
         tail = bytes(out[n - 4096:].cpu().numpy())
         assert tail == orc.ctr_xcrypt_at(key, ctr0, (n - 4096) // 16, bytes([rep + 1]) * 4096)
+
+
+def _gather_check(orc, devlist, root, n, with_own_buffers):
+    """uaes_mgpu_ctr_encrypt_gather on device-resident shards: the gathered text is the single-call result"""
+    import torch
+    L = uaes.engine()
+    nd = len(devlist)
+    key, ctr0 = bytes(range(32)), bytes(range(12)) + b"\xff\xff\xff\xfe"
+    data = orc.splitmix(n + 3, n)
+    blocks = (n + 15) // 16
+    ins, outs, keep = (C.c_void_p * nd)(), (C.c_void_p * nd)(), []
+    for i, d in enumerate(devlist):
+        lo, hi = min(n, 16 * (blocks * i // nd)), min(n, 16 * (blocks * (i + 1) // nd))
+        t = torch.frombuffer(bytearray(data[lo:hi] or b"\0"), dtype=torch.uint8).to("cuda:%d" % d)
+        o = torch.full((max(hi - lo, 1),), 0xEE, dtype=torch.uint8, device="cuda:%d" % d)
+        keep += [t, o]
+        ins[i] = t.data_ptr()
+        outs[i] = o.data_ptr() if (with_own_buffers or d != devlist[root]) else None
+    full = torch.full((max(n, 1) + 32,), 0xDD, dtype=torch.uint8, device="cuda:%d" % devlist[root])
+    devs = (C.c_int * nd)(*devlist)
+    rc = L.uaes_mgpu_ctr_encrypt_gather(nd, devs, 256, key, ctr0, 9, ins, n, outs, root, full.data_ptr())
+    assert rc == 0, L.uaes_last_error()
+    for d in set(devlist):
+        torch.cuda.synchronize(d)
+    got = bytes(full.cpu().numpy())
+    assert got[:n] == orc.ctr_xcrypt_at(key, ctr0, 9, data), (devlist, root, n)
+    assert got[n:] == b"\xdd" * 32
+
+
+def test_mgpu_ctr_encrypt_gather_on_one_device(orc):
+    """the C-host gather call (BASELINE configs[4] in one call) where every slice lives on the root's device: no RCCL
+    involved, the gather degenerates to in-place encryption or device-to-device copies.  Also: a device list that is
+    not visible, a root outside the list, and -- when a second device is missing -- that nothing tried to load RCCL."""
+    L = uaes.engine()
+    for n in (0, 5, 16, 1000, (2 << 20) + 7):
+        _gather_check(orc, [0], 0, n, False)
+        _gather_check(orc, [0, 0, 0], 1, n, False)
+        _gather_check(orc, [0, 0, 0], 2, n, True)
+    one = (C.c_void_p * 1)(1)
+    assert L.uaes_mgpu_ctr_encrypt_gather(1, (C.c_int * 1)(0), 128, bytes(16), bytes(16), 0, one, 16, one, 3, 1) == -2
+    assert b"root" in L.uaes_last_error()
+    assert L.uaes_mgpu_ctr_encrypt_gather(1, (C.c_int * 1)(77), 128, bytes(16), bytes(16), 0, one, 16, one, 0, 1) == -2
+
+
+def test_mgpu_ctr_encrypt_gather_rccl(orc):
+    """the real thing: slices on distinct devices, gathered on the root by RCCL send / receive over xGMI"""
+    import torch
+    nd = torch.cuda.device_count()
+    if nd < 2:
+        pytest.skip("needs 2 GPUs: this box has %d" % nd)
+    for n in (16 * nd, 100003, (64 << 20) + 5):
+        _gather_check(orc, list(range(nd)), 0, n, True)
+        _gather_check(orc, list(range(nd - 1, -1, -1)), nd - 1, n, True)
+        _gather_check(orc, [0, 1, 0, 1], 3, n, True)

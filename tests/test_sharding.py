@@ -197,3 +197,44 @@ def test_bench_self_launch_command(monkeypatch):
     assert 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
     assert cmd[-4:] == ["--gpus", "4", "--steps", "5"] and cmd[-5].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def _collectives_worker(rank, world, port, q):
+    """bench.setup_collectives without a GPU: the RCCL bring-up cannot work here (no device), so every rank must
+    agree on the gloo fallback -- with the reason in `collective_backend` -- and the group handed back must work"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      UAES_BENCH_RCCL_WAIT_S="20")
+    if rank == 1:
+        os.environ["UAES_BENCH_FORCE_NCCL_FAIL"] = "1"        # ONE rank failing must be enough for all to fall back
+    import types
+    import torch
+    import bench
+    a = types.SimpleNamespace(backend="nccl")
+    dist, group, cdev, info = bench.setup_collectives(a, torch, rank, world, 0, torch.device("cpu"))
+    t = torch.tensor([rank + 1.0], device=cdev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    dist.barrier(group=group)
+    q.put((rank, group is None, str(cdev), info["collective_backend"], float(t.item())))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_bench_collectives_fall_back_to_gloo_when_rccl_does_not_come_up():
+    """the first real N > 1 run must not be lost to an RCCL problem.  Two gloo ranks on the CPU: rank 1's
+    bring-up is forced to fail, rank 0's fails for real (no GPU here); both must report the gloo fallback and the
+    control plane (barrier + reductions) must work on what setup_collectives returned."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_collectives_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, is_default_group, cdev, backend, total in got:
+        assert is_default_group and cdev == "cpu" and total == 3.0
+        assert backend.startswith("gloo (nccl init failed: "), backend
+    assert "forced by UAES_BENCH_FORCE_NCCL_FAIL" in got[1][3]

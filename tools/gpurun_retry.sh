@@ -1,0 +1,10 @@
+#!/bin/bash
+# tools/gpurun_retry.sh <timeout-seconds> '<command>' -- gpurun, retried while the pod has no free GPU slot (exit 3)
+T=$1; shift
+for i in $(seq 1 40); do
+    /usr/local/graft/bin/gpurun --timeout "$T" -- "$@"
+    rc=$?
+    [ $rc -ne 3 ] && exit $rc
+    sleep 45
+done
+exit 3

@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Registers, LDS and private-segment (scratch) size of every kernel in libuaes_hip.so, read from the
 code objects' metadata notes (llvm-objdump --offloading + llvm-readelf --notes; needs no GPU).
-Usage: kernel_resources.py [--scratch-only]"""
+Usage: kernel_resources.py [--scratch-only]
+       kernel_resources.py --disasm <kernel-name-substring> ... [--out DIR]
+           the hot loop of each kernel (the backward-branch loop holding the most ds_read_b32) from llvm-objdump -d of
+           the shipped code object: instruction counts per loop trip by opcode and the listing itself, so that DESIGN.md's
+           "VALU + LDS instructions per block" can be re-derived from a tracked file (profiles/r04_isa/)."""
 import os
 import re
 import shutil
@@ -36,7 +40,101 @@ def kernels(lib=None):
     return out
 
 
+def code_objects(lib=None):
+    """(temporary directory, [paths of the gfx950 code objects]) extracted from the library"""
+    lib = lib or os.path.join(ROOT, "micro-aes_amd", "lib", "libuaes_hip.so")
+    tmp = tempfile.mkdtemp(prefix="uaes_co_")
+    so = os.path.join(tmp, "lib.so")
+    shutil.copy(lib, so)
+    subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", so], check=True, capture_output=True)
+    return tmp, [os.path.join(tmp, f) for f in sorted(os.listdir(tmp)) if "amdgcn" in f]
+
+
+def disassemble(lib=None):
+    """{demangled kernel name: [(address, mnemonic, operands)]} for every kernel of the library"""
+    tmp, cos = code_objects(lib)
+    out = {}
+    try:
+        for co in cos:
+            txt = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", co], check=True,
+                                 capture_output=True, text=True).stdout
+            cur = None
+            for line in txt.splitlines():
+                m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+                if m:
+                    name = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip()
+                    cur = out.setdefault(name, [])
+                    continue
+                m = re.match(r"^\s+(\S+)\s*(.*?)\s*//\s*([0-9A-Fa-f]+):", line)
+                if m and cur is not None:
+                    cur.append((int(m.group(3), 16), m.group(1), m.group(2)))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
+def hot_loop(insts):
+    """the backward-branch loop with the most ds_read_b32: (start index, end index) into insts"""
+    addr_ix = {a: i for i, (a, _, _) in enumerate(insts)}
+    best, best_n = None, -1
+    for i, (a, op, args) in enumerate(insts):
+        if not op.startswith("s_cbranch"):
+            continue
+        m2 = re.match(r"^(\d+)", args.strip())              # the simm16, printed unsigned: target = pc + 4 + 4 * simm16
+        tgt = None
+        if m2:
+            off = int(m2.group(1))
+            tgt = a + 4 + 4 * (off - 65536 if off >= 32768 else off)
+        if tgt is None or tgt not in addr_ix or tgt >= a:
+            continue
+        j = addr_ix[tgt]
+        n = sum(1 for (_, o, _) in insts[j:i + 1] if o == "ds_read_b32")
+        if n > best_n:
+            best, best_n = (j, i), n
+    return best
+
+
+def loop_report(name, insts):
+    lp = hot_loop(insts)
+    if lp is None:
+        return "%s: no backward branch found\n" % name
+    body = insts[lp[0]:lp[1] + 1]
+    counts = {}
+    for _, op, _ in body:
+        counts[op] = counts.get(op, 0) + 1
+    valu = sum(n for o, n in counts.items() if o.startswith("v_"))
+    lds = sum(n for o, n in counts.items() if o.startswith("ds_"))
+    lines = ["# %s" % name, "# hot loop: %d instructions, %d VALU, %d DS, %d SALU/other per trip" %
+             (len(body), valu, lds, len(body) - valu - lds),
+             "# by opcode: " + ", ".join("%s %d" % (o, n) for o, n in sorted(counts.items(), key=lambda x: -x[1]))]
+    lines += ["  %06x  %-24s %s" % (a, op, args) for a, op, args in body]
+    return "\n".join(lines) + "\n", counts
+
+
 if __name__ == "__main__":
+    if "--disasm" in sys.argv:
+        args = sys.argv[sys.argv.index("--disasm") + 1:]
+        out_dir = None
+        if "--out" in args:
+            out_dir = args[args.index("--out") + 1]
+            args = args[:args.index("--out")]
+            os.makedirs(out_dir, exist_ok=True)
+        dis = disassemble()
+        for want in args:
+            for name, insts in sorted(dis.items()):
+                if want not in name:
+                    continue
+                rep = loop_report(name, insts)
+                text = rep if isinstance(rep, str) else rep[0]
+                if out_dir:
+                    fn = re.sub(r"[^A-Za-z0-9_]+", "_", name.split("(")[0]).strip("_") + ".hotloop.txt"
+                    with open(os.path.join(out_dir, fn), "w") as f:
+                        f.write(text)
+                    print(text.splitlines()[0], "->", fn)
+                    print("\n".join(text.splitlines()[1:3]))
+                else:
+                    print(text)
+        sys.exit(0)
     ks = kernels()
     for k in sorted(ks, key=lambda k: k["name"]):
         if "--scratch-only" in sys.argv and not (k["scratch"] or k["vgpr_spill"]):
