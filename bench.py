@@ -565,7 +565,8 @@ def main():
             elif a.workload == "cfb-dec":
                 verify = got == orc.cfb(KEY16, bytes(range(16)), head, False)
             elif a.workload == "cbc-enc":
-                verify = got == orc.cbc(KEY16, bytes(range(16)), head, True)[1][:m]
+                # CS3 stealing swaps the LAST two blocks of a message: the head of a longer message matches up to there
+                verify = got[: m - 32] == orc.cbc(KEY16, bytes(range(16)), head, True)[1][: m - 32]
             elif a.workload == "cmac":
                 verify = bytes(mac16) == orc.cmac(KEY16, orc.splitmix(seed, n)) if n <= (16 << 20) else None
         if dist:

@@ -309,52 +309,69 @@ __global__ __launch_bounds__(UAES_WG) void k_xts(uaesk_rk k1, uaesk_tables tb,
     if (DEC) fill_dec_tables(tb.td0); else fill_enc_tables(tb.te0);
     const LaneConst lc = make_lane_const();
     const u32 lane = threadIdx.x & 63u;
-    /* launched with 16 waves per workgroup, or 4 for short texts (more CUs, see launch_xts) */
-    const u64 wave = (u64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    /* launched with 16 waves per workgroup, or 4 for short texts (more CUs, see launch_xts).  The wave's number is made
+     * a SCALAR explicitly: everything that positions a chunk (unit, chunk in the unit, byte offset, block count) then
+     * lives in SGPRs and is stepped by scalar instructions -- as vector arithmetic it was ~20 VALU instructions per
+     * chunk in a kernel whose VALU is as busy as its LDS.                                        */
+    const u64 wave = (u64)blockIdx.x * (blockDim.x >> 6) + (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const u64 nwaves = (u64)gridDim.x * (blockDim.x >> 6);
     const u64 nchunks = nsectors * chunks_per_sector;
+    const u32 lane16 = lane * 16u;
+    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 
     /* (unit, chunk inside the unit) of the chunk being fetched: one division here, then stepped by the
      * grid's wave count as (step_q, step_r) -- a 64-bit division per chunk cost ~8 % of the loop     */
     u64 sctn = wave / chunks_per_sector, withn = wave - sctn * chunks_per_sector;
-    uint4 dn[UAES_U], tbn = make_uint4(0, 0, 0, 0);
-    u32 cntn = 0;
-    u64 offn = 0;                                    /* byte offset of the chunk's first block */
-    auto fetch = [&](u64 ch) {
+    struct Fetched {
+        uint4 d[UAES_U], tb;
+        u32 cnt;
+        u64 off;                                     /* byte offset of the chunk's first block */
+    };
+    auto fetch = [&](u64 ch, Fetched &f) {
         const u64 sct = sctn;
         const u64 first = withn * XTS_CHUNK;
         sctn += step_q; withn += step_r;             /* the next chunk of this wave */
         if (withn >= chunks_per_sector) { withn -= chunks_per_sector; ++sctn; }
         const u64 left = main_blocks - first;
-        cntn = left < XTS_CHUNK ? (u32)left : XTS_CHUNK;
-        offn = sct * sector_bytes + first * 16;
-        tbn = chunk_tw[ch];
-        const unsigned char *src = in + offn;
+        f.cnt = left < XTS_CHUNK ? (u32)left : XTS_CHUNK;
+        f.off = sct * sector_bytes + first * 16;
+        f.tb = chunk_tw[ch];
+        const unsigned char *src = in + f.off;
+        if (ALIGNED) {
+            /* a buffer resource over exactly the chunk's blocks: base in SGPRs, the lane's constant offset, and the
+             * range check returns zeros for the blocks a short last chunk does not have (no clamping, no branch) */
+            const u64 b = (u64)src;
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
+                (void *)(((u64)(u32)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) |
+                         (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)b)),
+                0, (int)(f.cnt * 16u), 0x00020000);
 #pragma unroll
-        for (int u = 0; u < UAES_U; ++u) {
-            const u32 j = lane + 64u * u;
-            const u32 jc = j < cntn ? j : (cntn ? cntn - 1 : 0);     /* clamped: no branch before the load */
-            dn[u] = cntn ? load16<ALIGNED>(src + 16u * jc) : make_uint4(0, 0, 0, 0);
+            for (int u = 0; u < UAES_U; ++u) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, lane16 + 1024u * u, 0, 0);
+                f.d[u] = make_uint4(v.x, v.y, v.z, v.w);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < UAES_U; ++u) {
+                const u32 j = lane + 64u * u;
+                const u32 jc = j < f.cnt ? j : (f.cnt ? f.cnt - 1 : 0);     /* clamped: no branch before the load */
+                f.d[u] = f.cnt ? load16<ALIGNED>(src + 16u * jc) : make_uint4(0, 0, 0, 0);
+            }
         }
     };
 
-    u64 ch = wave;
-    if (ch < nchunks) fetch(ch);
-    while (ch < nchunks) {
-        uint4 d[UAES_U];
-#pragma unroll
-        for (int u = 0; u < UAES_U; ++u) d[u] = dn[u];
-        const uint4 tb4 = tbn;
-        const u32 cnt = cntn;
-        const u64 off = offn;
+    /* one chunk: request the wave's next one into `nx`, then whiten, encrypt and store `cur`.  Expanded twice per loop
+     * trip with the two buffers swapped: "next becomes current" is a renaming, not twenty register moves.  (Stores go
+     * through plain global pointers: uaes_ctr.hip.h explains why not through a buffer resource.)               */
+    auto body = [&](u64 ch, const Fetched &cur, Fetched &nx) {
         const u64 nxt = ch + nwaves;
-        if (nxt < nchunks) fetch(nxt);
+        if (nxt < nchunks) fetch(nxt, nx);
 
         Tw t;
-        t.lo = tb4.x | ((u64)tb4.y << 32);
-        t.hi = tb4.z | ((u64)tb4.w << 32);
+        t.lo = cur.tb.x | ((u64)cur.tb.y << 32);
+        t.hi = cur.tb.z | ((u64)cur.tb.w << 32);
         t = tw_mul_pow(t, lane);
-        unsigned char *dst = out + off;
+        unsigned char *dst = out + cur.off;
         /* two skewed pairs one after the other: only one pair's states and tweaks are live at a time
          * (all four at once spilled 8-18 registers)                                                  */
 #pragma unroll
@@ -364,8 +381,8 @@ __global__ __launch_bounds__(UAES_WG) void k_xts(uaesk_rk k1, uaesk_tables tb,
             for (int u = 0; u < 2; ++u) {
                 tw[u][0] = (u32)t.lo; tw[u][1] = (u32)(t.lo >> 32);
                 tw[u][2] = (u32)t.hi; tw[u][3] = (u32)(t.hi >> 32);
-                s[u][0] = d[pr + u].x ^ tw[u][0]; s[u][1] = d[pr + u].y ^ tw[u][1];
-                s[u][2] = d[pr + u].z ^ tw[u][2]; s[u][3] = d[pr + u].w ^ tw[u][3];
+                s[u][0] = cur.d[pr + u].x ^ tw[u][0]; s[u][1] = cur.d[pr + u].y ^ tw[u][1];
+                s[u][2] = cur.d[pr + u].z ^ tw[u][2]; s[u][3] = cur.d[pr + u].w ^ tw[u][3];
                 t = tw_mul_pow64(t);
             }
             if (DEC) dec_blocks_skewed<NR>(s[0], s[1], k1, lc);
@@ -373,12 +390,22 @@ __global__ __launch_bounds__(UAES_WG) void k_xts(uaesk_rk k1, uaesk_tables tb,
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const u32 j = lane + 64u * (pr + u);
-                if (j < cnt)
+                if (j < cur.cnt)
                     store16<ALIGNED>(dst + 16u * j, make_uint4(s[u][0] ^ tw[u][0], s[u][1] ^ tw[u][1],
                                                                s[u][2] ^ tw[u][2], s[u][3] ^ tw[u][3]));
             }
         }
-        ch = nxt;
+    };
+
+    Fetched fa, fb;
+    u64 ch = wave;
+    if (ch < nchunks) fetch(ch, fa);
+    while (ch < nchunks) {
+        body(ch, fa, fb);
+        ch += nwaves;
+        if (ch >= nchunks) break;
+        body(ch, fb, fa);
+        ch += nwaves;
     }
 }
 

@@ -232,3 +232,37 @@ def test_bulk_kernels_have_no_private_segment_and_only_gfx950_code():
             assert k["scratch"] <= 32 and k["vgpr_spill"] <= 8, (k["name"][:80], k["scratch"], k["vgpr_spill"])
         else:
             assert k["scratch"] == 0 and k["vgpr_spill"] == 0, (k["name"][:80], k["scratch"], k["vgpr_spill"])
+
+
+def test_ctr_hot_loop_instruction_budget():
+    """DESIGN section 4 prices AES-128-CTR in instructions per block: 128 table lookups and about 210 VALU operations.
+    Re-derived here from the SHIPPED code object (llvm-objdump of libuaes_hip.so, tools/kernel_resources.py --disasm),
+    so that a compiler upgrade or an innocent edit cannot add instructions to the loop unnoticed.  One trip of the hot
+    loop of k_ctr_shared2<10> = the body twice = 4 blocks per lane: 2 x 2 x 8 rounds x 16 lookups, plus the 40 lookups
+    of the wave-0 refill of the U-buffer that sit inside the loop (executed once per 8 trips by one wave only)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources
+    dis = kernel_resources.disassemble()
+    names = [n for n in dis if n.startswith("void k_ctr_shared2<10>")]
+    assert len(names) == 1
+    text, counts = kernel_resources.loop_report(names[0], dis[names[0]])
+    refill = 40
+    assert counts["ds_read_b32"] == 2 * 2 * 8 * 16 + refill, counts["ds_read_b32"]
+    valu = sum(n for op, n in counts.items() if op.startswith("v_"))
+    # per block: 7 rounds x 24 + the last round's 16 + 12 + 4 (round-3 entry) + 4 (text xor) = 204; the static count
+    # also holds the refill's ~60 and the loop's bookkeeping
+    assert valu <= 4 * 204 + 110, valu
+    assert counts.get("buffer_load_dwordx4", 0) + counts.get("global_load_dwordx4", 0) == 4
+    assert counts.get("v_mov_b64_e32", 0) == 0            # the text buffers are renamed, not moved
+    # sixteen lookups per round and block: between two s_setprio 1 there must be exactly 16 ds_read_b32
+    ops = [l.split()[1] for l in text.splitlines() if l.startswith("  ")]
+    args = [l.split()[2] if len(l.split()) > 2 else "" for l in text.splitlines() if l.startswith("  ")]
+    bursts, cur, on = [], 0, False
+    for op, a in zip(ops, args):
+        if op == "s_setprio":
+            if on and a == "0":
+                bursts.append(cur)
+            on, cur = a == "1", 0
+        elif op == "ds_read_b32" and on:
+            cur += 1
+    assert bursts and set(bursts) == {16}, sorted(set(bursts))

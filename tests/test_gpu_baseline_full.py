@@ -153,7 +153,7 @@ def test_bench_line_measures_its_own_traffic_and_clock():
     # behind `value` may catch the clocks a little high, never the other way round by more than noise
     sus = line["sustained"]
     assert sus["seconds"] >= 1.9 and sus["steps"] >= 1000 and sus["unit"] == "GiB/s"
-    assert sus["value"] <= line["value"] * 1.02, (sus, line["value"])
+    assert sus["value"] <= line["value"] * 1.04, (sus, line["value"])      # (measured: 0.99 .. 1.014 of the window's rate)
     assert sus["value"] >= line["value"] * 0.85, (sus, line["value"])
     assert abs(roof["frac_sustained"] - 2.0 * (1 << 30) / (sus["ms_per_step"] * 1e-3) / 1e9 / roof["peak"]) < 1e-3
     assert sus["sclk_mhz"] == lc["sclk_mhz_under_load"]

@@ -549,7 +549,7 @@ def _gather_check(orc, devlist, root, n, with_own_buffers):
         torch.cuda.synchronize(d)
     got = bytes(full.cpu().numpy())
     assert got[:n] == orc.ctr_xcrypt_at(key, ctr0, 9, data), (devlist, root, n)
-    assert got[n:] == b"\xdd" * 32
+    assert got[n:n + 32] == b"\xdd" * 32
 
 
 def test_mgpu_ctr_encrypt_gather_on_one_device(orc):

@@ -76,22 +76,28 @@ def disassemble(lib=None):
 def hot_loop(insts):
     """the backward-branch loop with the most ds_read_b32: (start index, end index) into insts"""
     addr_ix = {a: i for i, (a, _, _) in enumerate(insts)}
-    best, best_n = None, -1
+    loops = []
     for i, (a, op, args) in enumerate(insts):
         if not op.startswith("s_cbranch"):
             continue
         m2 = re.match(r"^(\d+)", args.strip())              # the simm16, printed unsigned: target = pc + 4 + 4 * simm16
-        tgt = None
-        if m2:
-            off = int(m2.group(1))
-            tgt = a + 4 + 4 * (off - 65536 if off >= 32768 else off)
-        if tgt is None or tgt not in addr_ix or tgt >= a:
+        if not m2:
+            continue
+        off = int(m2.group(1))
+        tgt = a + 4 + 4 * (off - 65536 if off >= 32768 else off)
+        if tgt not in addr_ix or tgt >= a:
             continue
         j = addr_ix[tgt]
-        n = sum(1 for (_, o, _) in insts[j:i + 1] if o == "ds_read_b32")
-        if n > best_n:
-            best, best_n = (j, i), n
-    return best
+        loops.append((i - j + 1, sum(1 for (_, o, _) in insts[j:i + 1] if o == "ds_read_b32"), j, i))
+    if not loops:
+        return None
+    # the loop with the most lookups that is not merely the shell around another one: skip a loop if one strictly inside
+    # it holds more than 55 % of its lookups
+    for size, n, j, i in sorted(loops, key=lambda l: (-l[1], l[0])):
+        inner = [l for l in loops if l[2] >= j and l[3] <= i and (l[2], l[3]) != (j, i)]
+        if not any(l[1] > 0.55 * n for l in inner):
+            return (j, i)
+    return None
 
 
 def loop_report(name, insts):
