@@ -50,15 +50,34 @@ __global__ __launch_bounds__(UAES_WG) void k_ecb(uaesk_rk rk, uaesk_tables tb,
     const LaneConst lc = make_lane_const();
     const u64 stride = (u64)gridDim.x * UAES_WG * U;
 
+    const u32 lane16 = threadIdx.x * 16u;
+    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
     for (u64 base = first; base < nfull; base += stride) {
         u32 s[U][4];
         u64 idx[U];
+        /* a tile that lies completely inside the text (all but the last one of the launch) needs no bounds checks, and
+         * its address is a wave-uniform base + the thread's constant offset: loads through a buffer resource (SGPR base,
+         * one VGPR offset), no compares, no exec masking, no 64-bit vector adds -- ~9 VALU instructions per block less */
+        const bool whole = base + (u64)UAES_WG * U <= nfull;
+        if (whole && base != first) {
+            const u64 b = (u64)(in + base);
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
+                (void *)(((u64)(u32)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) |
+                         (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)b)), 0, (int)(UAES_WG * U * 16u), 0x00020000);
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            idx[u] = base + (u64)u * UAES_WG + threadIdx.x;
-            uint4 d = d0[u];
-            if (base != first && idx[u] < nfull) d = in[idx[u]];
-            s[u][0] = d.x; s[u][1] = d.y; s[u][2] = d.z; s[u][3] = d.w;
+            for (int u = 0; u < U; ++u) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, lane16, (int)(UAES_WG * 16u) * u, 0);
+                idx[u] = base + (u64)u * UAES_WG + threadIdx.x;
+                s[u][0] = v.x; s[u][1] = v.y; s[u][2] = v.z; s[u][3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                idx[u] = base + (u64)u * UAES_WG + threadIdx.x;
+                uint4 d = d0[u];
+                if (base != first && idx[u] < nfull) d = in[idx[u]];
+                s[u][0] = d.x; s[u][1] = d.y; s[u][2] = d.z; s[u][3] = d.w;
+            }
         }
         if (DEC) {
             dec_blocks<NR, U>(s, rk, lc);
@@ -68,9 +87,15 @@ __global__ __launch_bounds__(UAES_WG) void k_ecb(uaesk_rk rk, uaesk_tables tb,
         } else {
             enc_blocks<NR, U>(s, rk, lc);
         }
+        if (whole) {
+            uint4 *o = out + base + threadIdx.x;              /* (global stores: uaes_ctr.hip.h says why not buffer stores) */
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (idx[u] < nfull) out[idx[u]] = make_uint4(s[u][0], s[u][1], s[u][2], s[u][3]);
+            for (int u = 0; u < U; ++u) o[(u32)u * UAES_WG] = make_uint4(s[u][0], s[u][1], s[u][2], s[u][3]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (idx[u] < nfull) out[idx[u]] = make_uint4(s[u][0], s[u][1], s[u][2], s[u][3]);
+        }
     }
 
     /* reference N1: a trailing partial block is zero padded and ENCRYPTED into
