@@ -197,6 +197,45 @@ def a2r2():
     return out
 kernel("P_a2r2_kv", a2r2() * 2, 48, 32)
 
+# ---- F: an all-full-rate round?  Two state words per column with the index bytes at positions 1 and 3 (8-byte table
+# entries, ds_read_b64): byte extraction = and-or (position 1) or v_lshrrev 16 + and-or (position 3), no v_perm at all;
+# the price is twice the combines.  Per block-round: 8 shifts + 16 and-or + 16 xor3 = 40 full-rate VALU + 16 ds_read_b64.
+def rd64(i):
+    return f"ds_read_b64 v[{T0 + 2 * (i % 8)}:{T0 + 2 * (i % 8) + 1}], v{A0 + i % NCH}"
+
+
+def fast_round(order, slow=0):
+    addr = []
+    for i in range(16):
+        if i % 2:
+            addr += [valu("lshr16", i), valu("andor_vvv", i)]
+        else:
+            addr += [valu("andor_vvv", i)]
+    xors = [valu("bitop_vvv", i) for i in range(16)]
+    if slow:                                         # a few half-rate instructions sprinkled in
+        for k in range(slow):
+            xors[(5 * k + 2) % 16] = valu("perm_vvs", 5 * k + 2)
+    reads = [rd64(i) for i in range(16)]
+    if order == "valu":
+        return addr + xors
+    if order == "grouped":
+        return addr + reads + xors
+    if order == "a4r4":
+        out = []
+        for c in range(4):
+            out += addr[6 * c:6 * c + 6] + reads[4 * c:4 * c + 4] + xors[4 * c:4 * c + 4]
+        return out
+    raise ValueError(order)
+
+
+kernel("F_fast40_valu", fast_round("valu") * 2, 80, 0)
+kernel("F_fast40_valu_2slow", fast_round("valu", 2) * 2, 80, 0, "2 of 40 are v_perm")
+kernel("F_fast40_valu_4slow", fast_round("valu", 4) * 2, 80, 0, "4 of 40 are v_perm")
+kernel("F_reads64_only", [rd64(i) for i in range(16)] * 2, 0, 32)
+kernel("F_fast40_b64_grouped", fast_round("grouped") * 2, 80, 32)
+kernel("F_fast40_b64_a4r4", fast_round("a4r4") * 2, 80, 32)
+kernel("F_fast40_b64_grouped_2slow", fast_round("grouped", 2) * 2, 80, 32)
+
 HDR = r'''// GENERATED by tools/ubench/gen_issuebench.py -- do not edit.  Diagnostic, not part of the product.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -228,7 +267,7 @@ __global__ __launch_bounds__(1024) void k_%(name)s(u32 iters, u64 *cycles, u32 *
         "s_cbranch_scc1 L_%(name)s_%%=\n"
         "s_waitcnt lgkmcnt(0)\n"
 %(fold)s
-        : [out] "=v"(out) : [slot] "v"(slot), [iters] "s"(iters) : CLOB);
+        : [out] "=v"(out) : [slot] "v"(slot), [slot8] "v"(slot * 2u), [iters] "s"(iters) : CLOB);
     const u64 t1 = __builtin_readcyclecounter();
     if (out == 0x12345678u) sink[0] = out;
     if ((threadIdx.x & 63u) == 0) cycles[blockIdx.x * 16 + (threadIdx.x >> 6)] = t1 - t0;
@@ -253,8 +292,9 @@ def emit():
     for i in range(NCH):
         fold.append(f"v_xor_b32_e32 %[out], %[out], v{T0 + i}")
         fold.append(f"v_xor_b32_e32 %[out], %[out], v{B0 + i}")
+    init64 = [l.replace("%[slot]", "%[slot8]") if l.startswith("v_add_u32_e32 v%d" % A0) or any(l.startswith("v_add_u32_e32 v%d," % (A0 + i)) for i in range(NCH)) else l for l in init]
     for k in KERNELS:
-        src.append(KERN % dict(name=k["name"], init=q(init), body=q(k["body"]), fold=q(fold)))
+        src.append(KERN % dict(name=k["name"], init=q(init64 if k["name"].startswith("F_") else init), body=q(k["body"]), fold=q(fold)))
     # functional test W: address bits above the LDS size
     src.append(r'''
 __global__ void k_W_wrap(u32 *res)
