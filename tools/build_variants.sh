@@ -5,6 +5,8 @@
 #     tools/build_variants.sh base= v2=-DUAES_ASM_VARIANT=2
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
+# the hand-scheduled round blocks are generated, not tracked
+case "$*" in *UAES_ASM_VARIANT*) python3 "$ROOT/tools/gen_rounds_asm.py" > /dev/null;; esac
 pids=()
 for spec in "$@"; do
     name=${spec%%=*}; flags=${spec#*=}

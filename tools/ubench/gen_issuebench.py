@@ -12,6 +12,11 @@ Groups:
   A  the AES block-round mix in several orders, SGPR or VGPR round keys
   D  ds_read2_b32 / ds_read_u8_d16 in place of ds_read_b32
   W  functional: does the LDS ignore address bits above 17?
+  P  does the half-rate / full-rate split survive mixing?
+  F  an all-full-rate round (8-byte table entries, no v_perm)
+
+    python tools/ubench/gen_issuebench.py && hipcc --offload-arch=gfx950 -O2 -o tools/ubench/issuebench tools/ubench/issuebench.hip
+    gpurun -- 'tools/ubench/issuebench [name filter]'          # neither the .hip nor the binary is tracked
 """
 import os
 
