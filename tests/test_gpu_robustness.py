@@ -577,3 +577,36 @@ def test_mgpu_ctr_encrypt_gather_rccl(orc):
         _gather_check(orc, list(range(nd)), 0, n, True)
         _gather_check(orc, list(range(nd - 1, -1, -1)), nd - 1, n, True)
         _gather_check(orc, [0, 1, 0, 1], 3, n, True)
+
+
+def test_mgpu_calls_from_several_host_threads_share_the_persistent_workers(orc):
+    """the per-device workers of uaes_mgpu_* now live for the life of the process and calls queue up per
+    worker.  Six host threads call at once with device lists that all name device 0 several times: every call must
+    get its own result (jobs of different calls interleave on the one worker), repeatedly."""
+    import threading
+    L = uaes.engine()
+    key, ctr0 = bytes(range(16)), bytes(range(12)) + b"\0\0\0\7"
+    errs = []
+
+    def worker(t):
+        try:
+            rnd = random.Random(500 + t)
+            for rep in range(6):
+                n = rnd.choice([0, 16, 1000, 70001, (1 << 20) + 3])
+                data = orc.splitmix(1000 * t + rep, n)
+                nd = rnd.choice([1, 2, 3, 5])
+                devs = (C.c_int * nd)(*([0] * nd))
+                out = (C.c_uint8 * max(n, 1))()
+                rc = L.uaes_mgpu_ctr_xcrypt_at(nd, devs, 128, key, ctr0, t, data, n, out)
+                assert rc == 0, L.uaes_last_error()
+                assert bytes(out)[:n] == orc.ctr_xcrypt_at(key, ctr0, t, data), (t, rep, n, nd)
+        except Exception as e:                      # noqa: BLE001
+            errs.append(repr(e))
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(6)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join(300)
+    assert not errs, errs
+    assert all(not th.is_alive() for th in ths)
