@@ -17,7 +17,14 @@ the 8 TB/s HBM peak with ALGORITHMIC bytes (32 B per 16-byte block: read the
 plaintext, write the ciphertext); `cpu_baseline` times the
 compiled REFERENCE (oracle/_ref, or the oracle restatement if that did not
 travel) on this box's host cores on a bounded sample of the same workload.
-Other workloads (--workload ecb|xts|gcm|ocb|...) are for profiling, not the bench line.
+Other workloads (--workload ecb|xts|gcm|ocb|...) are for profiling, not the bench line; `cbc-enc` / `cmac` time ONE
+serial chain with the reference's CPU loop beside it.
+
+After the K timed steps the same step runs back to back for --sustain-s seconds (default 2): `sustained` and
+`roofline.frac_sustained` ride next to `value`, never inside it.  With --gpus N the control plane is gloo; RCCL is
+brought up beside it, proven with a 16-byte all-gather and used only if every rank saw it work -- otherwise the run
+finishes on gloo and says so in `collective_backend` (setup_collectives).  --gather times the RCCL all-gather of the
+ciphertext, --c-gather additionally the C host's own uaes_mgpu_ctr_encrypt_gather on rank 0.
 """
 import argparse
 import ctypes
