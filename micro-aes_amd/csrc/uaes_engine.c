@@ -1033,10 +1033,13 @@ int uaes_init(void)
     return get_context(&c);
 }
 
+static void gather_teardown(void);                 /* the cached RCCL communicators and streams of uaes_mgpu_ctr_encrypt_gather */
+
 int uaes_shutdown(void)
 {
     int d, i, prev = -1, rc = 0;
     if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; }
+    gather_teardown();
     pthread_mutex_lock(&g_init_mu);
     for (d = 0; d < MAX_DEVICES; ++d) {
         context *c = &g_ctx[d];
@@ -3018,6 +3021,22 @@ static int rccl_load(void)
     RCCL_SYM(GetErrorString, "ncclGetErrorString");
 #undef RCCL_SYM
     return 0;
+}
+
+static void gather_teardown(void)
+{
+    int i, prev = -1;
+    pthread_mutex_lock(&g_rccl_mu);
+    if (g_gather.ready) {
+        (void)hipGetDevice(&prev);
+        for (i = 0; i < g_gather.ndev; ++i) {
+            (void)g_rccl.CommDestroy(g_gather.comm[i]);
+            if (hipSetDevice(g_gather.devs[i]) == hipSuccess) (void)hipStreamDestroy(g_gather.stream[i]);
+        }
+        g_gather.ready = 0;
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    pthread_mutex_unlock(&g_rccl_mu);
 }
 
 static int rccl_fail(const char *what, int rc)
