@@ -788,8 +788,17 @@ static int launch_ctr_shared(hipStream_t st, const uaesk_tables *tb, const uaesk
         if (want > 0 && (unsigned)want < grid) grid = (unsigned)want;
     }
     const u64 g_lo = c0 ? 1 : 0, groups = (c0 + nfull) / 256;
-    const u64 n8 = groups > g_lo ? (groups - g_lo) / 8 : 0;
+    u64 n8 = groups > g_lo ? (groups - g_lo) / 8 : 0;
     if (n8 * 2 < (u64)grid * 3) return launch_ctr_v<NR, 4>(st, tb, ek, ctr, in, out, len, gate);
+    {   /* A last round of stripes that covers only part of the grid leaves the other workgroups idle for a whole stripe
+         * (20 MiB = 640 stripes on 256 workgroups: 2.5 rounds cost 3).  Below `pct` % of the grid those stripes are
+         * handed to the kernel's edge path instead -- one block per thread through the plain rounds, spread evenly over
+         * ALL workgroups: 160 lookups per block instead of 128, but nobody waits (UAES_CTR_TAIL_PCT, 0 = off). */
+        static int pct = -1;
+        if (pct < 0) { const char *e = getenv("UAES_CTR_TAIL_PCT"); pct = e ? atoi(e) : 80; if (pct < 0 || pct > 100) pct = 80; }
+        const u64 r = n8 % grid;
+        if (r && n8 > grid && r * 100 < (u64)grid * (u64)pct) n8 -= r;
+    }
     hipError_t e = set_lds(k_ctr_shared2<NR>, UAES_LDS_CTRS);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL((k_ctr_shared2<NR>), dim3(grid), dim3(UAES_WG), UAES_LDS_CTRS, st, *ek, *tb, *ctr,
