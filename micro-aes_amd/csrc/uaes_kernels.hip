@@ -789,7 +789,11 @@ static int launch_ctr_shared(hipStream_t st, const uaesk_tables *tb, const uaesk
     }
     const u64 g_lo = c0 ? 1 : 0, groups = (c0 + nfull) / 256;
     u64 n8 = groups > g_lo ? (groups - g_lo) / 8 : 0;
-    if (n8 * 2 < (u64)grid * 3) return launch_ctr_v<NR, 4>(st, tb, ek, ctr, in, out, len, gate);
+    {   /* below `half_rounds` / 2 rounds of stripes the generic kernel spreads better (UAES_CTR_MIN_HALF_ROUNDS, measurement) */
+        static int half_rounds = -1;
+        if (half_rounds < 0) { const char *e = getenv("UAES_CTR_MIN_HALF_ROUNDS"); half_rounds = e ? atoi(e) : 2; if (half_rounds < 2) half_rounds = 2; }
+        if (n8 * 2 < (u64)grid * (u64)half_rounds) return launch_ctr_v<NR, 4>(st, tb, ek, ctr, in, out, len, gate);
+    }
     {   /* A last round of stripes that covers only part of the grid leaves the other workgroups idle for a whole stripe
          * (20 MiB = 640 stripes on 256 workgroups: 2.5 rounds cost 3).  Below `pct` % of the grid those stripes are
          * handed to the kernel's edge path instead -- one block per thread through the plain rounds, spread evenly over

@@ -1457,3 +1457,26 @@ def test_gcm_records_v_slot_tails_hold_no_earlier_message(orc):
             assert out2[r * stride + len(s): r * stride + max_len] == bytes(max_len - len(s))
     finally:
         k.close()
+
+
+@pytest.mark.parametrize("bits", [128, 256])
+def test_ctr_partial_last_round_of_stripes(orc, bits):
+    """k_ctr_shared2 deals 32 KiB stripes round-robin over the workgroups; a last round that covers only part of the grid is
+    handed to the kernel's edge path (one block per thread, plain rounds) when it is below UAES_CTR_TAIL_PCT of the grid.
+    Sizes on both sides of that rule -- 2.5 rounds, 2 rounds + one stripe, 3 rounds - one stripe, an exact multiple -- with
+    ragged ends and a counter that carries, against the oracle."""
+    import torch
+    key = bytes(range(bits // 8))
+    ctr0 = bytes(range(12)) + b"\xff\xff\xff\x80"
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    stripe = 32 << 10
+    for n in (cus * stripe * 5 // 2 + 5, 2 * cus * stripe + stripe + 16 * 3, 3 * cus * stripe - stripe - 7, 2 * cus * stripe,
+              cus * stripe * 3 // 2 + 4096):
+        data = orc.splitmix(n & 0xffff, n)
+        src = torch.frombuffer(bytearray(data), dtype=torch.uint8).to("cuda:0")
+        dst = torch.full((n + 64,), 0xEE, dtype=torch.uint8, device="cuda:0")
+        uaes.ctr_xcrypt_dev(key, ctr0, 77, src, dst, nbytes=n)
+        torch.cuda.synchronize()
+        got = bytes(dst.cpu().numpy())
+        assert hashlib.sha256(got[:n]).digest() == hashlib.sha256(orc.ctr_xcrypt_at(key, ctr0, 77, data)).digest(), (bits, n)
+        assert got[n:] == b"\xee" * 64

@@ -9,7 +9,7 @@ big = torch.randint(0, 256, (1 << 28,), dtype=torch.uint8, device="cuda"); dst =
 for _ in range(400): uaes.ctr_xcrypt_dev(key, ctr0, 0, big, dst, nbytes=1 << 28, stream=st)
 torch.cuda.synchronize()
 row = []
-for mib in (12, 14, 18, 20, 22, 28, 36, 40, 44, 52, 56, 60, 68, 72, 100, 136):
+for mib in (6, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 24):
     n = mib << 20
     reps = 400
     for _ in range(50): uaes.ctr_xcrypt_dev(key, ctr0, 0, big, dst, nbytes=n, stream=st)
@@ -20,6 +20,6 @@ for mib in (12, 14, 18, 20, 22, 28, 36, 40, 44, 52, 56, 60, 68, 72, 100, 136):
 print(" ".join(row))
 '''
 for rnd in range(2):
-    for pct in (0, 80, 90, 100):
-        r = subprocess.run([sys.executable, "-c", CH], env=dict(os.environ, UAES_CTR_TAIL_PCT=str(pct)), capture_output=True, text=True)
-        print("pct %2d  " % pct + (r.stdout.strip().splitlines() or [r.stderr[-300:]])[-1], flush=True)
+    for hr in (3, 2):
+        r = subprocess.run([sys.executable, "-c", CH], env=dict(os.environ, UAES_CTR_MIN_HALF_ROUNDS=str(hr)), capture_output=True, text=True)
+        print("min half rounds %d  " % hr + (r.stdout.strip().splitlines() or [r.stderr[-300:]])[-1], flush=True)
