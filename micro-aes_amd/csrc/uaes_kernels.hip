@@ -35,7 +35,8 @@ static inline hipStream_t S(void *s) { return (hipStream_t)s; }
 template <int NR, bool DEC, int U>
 __global__ __launch_bounds__(UAES_WG) void k_ecb(uaesk_rk rk, uaesk_tables tb,
                                                  const uint4 *in, uint4 *out,
-                                                 u64 nfull, u32 rem, u32 padding, uaesk_done done)
+                                                 u64 nfull, u32 rem, u32 padding, uaesk_done done,
+                                                 u64 tail_from)        /* blocks from here on: one per thread (== nfull: none) */
 {
     /* the first pass's text is requested before the tables are made (see k_ctr) */
     const u64 first = (u64)blockIdx.x * UAES_WG * U;
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(UAES_WG) void k_ecb(uaesk_rk rk, uaesk_tables tb,
 
     const u32 lane16 = threadIdx.x * 16u;
     typedef u32 u32x4 __attribute__((ext_vector_type(4)));
-    for (u64 base = first; base < nfull; base += stride) {
+    for (u64 base = first; base < tail_from; base += stride) {
         u32 s[U][4];
         u64 idx[U];
         /* a tile that lies completely inside the text (all but the last one of the launch) needs no bounds checks, and
@@ -95,6 +96,18 @@ __global__ __launch_bounds__(UAES_WG) void k_ecb(uaesk_rk rk, uaesk_tables tb,
 #pragma unroll
             for (int u = 0; u < U; ++u)
                 if (idx[u] < nfull) out[idx[u]] = make_uint4(s[u][0], s[u][1], s[u][2], s[u][3]);
+        }
+    }
+
+    /* A last round of tiles that covers only part of the grid would leave the other workgroups idle for a whole tile
+     * (20 MiB = 320 tiles of 64 KiB on 256 workgroups: 1.25 rounds cost 2): the host hands such a remainder over as
+     * [tail_from, nfull), one block per thread over ALL workgroups (as the CTR kernel's edge path).      */
+    if (U > 1) {
+        for (u64 i = tail_from + (u64)blockIdx.x * UAES_WG + threadIdx.x; i < nfull; i += (u64)gridDim.x * UAES_WG) {
+            const uint4 d = in[i];
+            u32 s1[1][4] = { { d.x, d.y, d.z, d.w } };
+            if (DEC) dec_blocks<NR, 1>(s1, rk, lc); else enc_blocks<NR, 1>(s1, rk, lc);
+            out[i] = make_uint4(s1[0][0], s1[0][1], s1[0][2], s1[0][3]);
         }
     }
 
@@ -329,7 +342,8 @@ __global__ __launch_bounds__(UAES_WG) void k_xts(uaesk_rk k1, uaesk_tables tb,
                                                  u64 sector_bytes,
                                                  u64 step_q, u64 step_r,   /* (waves of the grid) / and % chunks_per_sector */
                                                  const unsigned char *in,
-                                                 unsigned char *out)
+                                                 unsigned char *out,
+                                                 u64 nmain)            /* chunks [nmain, all) go by quarters (== all: none) */
 {
     if (DEC) fill_dec_tables(tb.td0); else fill_enc_tables(tb.te0);
     const LaneConst lc = make_lane_const();
@@ -340,7 +354,7 @@ __global__ __launch_bounds__(UAES_WG) void k_xts(uaesk_rk k1, uaesk_tables tb,
      * chunk in a kernel whose VALU is as busy as its LDS.                                        */
     const u64 wave = (u64)blockIdx.x * (blockDim.x >> 6) + (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const u64 nwaves = (u64)gridDim.x * (blockDim.x >> 6);
-    const u64 nchunks = nsectors * chunks_per_sector;
+    const u64 nchunks = nmain;                         /* the main loop's share; the rest follows behind it */
     const u32 lane16 = lane * 16u;
     typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 
@@ -431,6 +445,34 @@ __global__ __launch_bounds__(UAES_WG) void k_xts(uaesk_rk k1, uaesk_tables tb,
         if (ch >= nchunks) break;
         body(ch, fb, fa);
         ch += nwaves;
+    }
+
+    /* A last round of chunks that covers only part of the grid's waves would leave the others idle for a whole chunk
+     * (a round is 4096 waves x 4 KiB = 16 MiB: 18 MiB ran at 0.75 of the 16 MiB rate).  The host hands such a remainder
+     * over as chunks [nmain, all); here they go by QUARTERS -- 64 blocks, one per lane -- over four times as many waves.
+     * Quarter k of a chunk starts at its tweak * alpha^(64 k).                                                       */
+    const u64 all = nsectors * chunks_per_sector;
+    for (u64 q = wave; q < 4 * (all - nmain); q += nwaves) {
+        const u64 c = nmain + (q >> 2);
+        const u32 k = (u32)q & 3u;
+        const u64 sct = c / chunks_per_sector, first = (c - sct * chunks_per_sector) * XTS_CHUNK;
+        const u64 left = main_blocks - first;
+        const u32 cnt = left < XTS_CHUNK ? (u32)left : XTS_CHUNK;
+        const u32 j = 64u * k + lane;
+        const uint4 tb4 = chunk_tw[c];
+        Tw t;
+        t.lo = tb4.x | ((u64)tb4.y << 32);
+        t.hi = tb4.z | ((u64)tb4.w << 32);
+        for (u32 i = 0; i < k; ++i) t = tw_mul_pow64(t);
+        t = tw_mul_pow(t, lane);
+        if (j < cnt) {
+            const u64 off = sct * sector_bytes + (first + j) * 16;
+            const uint4 d = load16<ALIGNED>(in + off);
+            const u32 tw[4] = { (u32)t.lo, (u32)(t.lo >> 32), (u32)t.hi, (u32)(t.hi >> 32) };
+            u32 s1[1][4] = { { d.x ^ tw[0], d.y ^ tw[1], d.z ^ tw[2], d.w ^ tw[3] } };
+            if (DEC) dec_blocks<NR, 1>(s1, k1, lc); else enc_blocks<NR, 1>(s1, k1, lc);
+            store16<ALIGNED>(out + off, make_uint4(s1[0][0] ^ tw[0], s1[0][1] ^ tw[1], s1[0][2] ^ tw[2], s1[0][3] ^ tw[3]));
+        }
     }
 }
 
@@ -723,12 +765,18 @@ static int launch_ecb(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ke
     if (e != hipSuccess) return (int)e;
     const u64 items = nfull + ((rem || padding) ? 1 : 0);
     const uaesk_done done = uaesk_ticket_take();              /* the call's only kernel: it carries the ticket */
-    if (short_text(items))
+    if (short_text(items)) {
         hipLaunchKernelGGL((k_ecb<NR, DEC, 1>), dim3(grid_for(items, UAES_WG)), dim3(UAES_WG), lds, st, *keys, *tb,
-                           (const uint4 *)in, (uint4 *)out, (u64)nfull, (u32)rem, (u32)padding, done);
-    else
-        hipLaunchKernelGGL((k_ecb<NR, DEC, UAES_U>), dim3(grid_for(items, (u64)UAES_WG * UAES_U)), dim3(UAES_WG), lds, st,
-                           *keys, *tb, (const uint4 *)in, (uint4 *)out, (u64)nfull, (u32)rem, (u32)padding, done);
+                           (const uint4 *)in, (uint4 *)out, (u64)nfull, (u32)rem, (u32)padding, done, (u64)nfull);
+    } else {
+        const unsigned grid = grid_for(items, (u64)UAES_WG * UAES_U);
+        const u64 tile = (u64)UAES_WG * UAES_U, per_round = tile * grid;
+        const u64 rounds = (u64)nfull / per_round, left = (u64)nfull - rounds * per_round;
+        /* the remainder of the last round as single blocks when it covers less than 80 % of the grid */
+        const u64 tail_from = (rounds && left && left * 100 < per_round * 80) ? rounds * per_round : (u64)nfull;
+        hipLaunchKernelGGL((k_ecb<NR, DEC, UAES_U>), dim3(grid), dim3(UAES_WG), lds, st,
+                           *keys, *tb, (const uint4 *)in, (uint4 *)out, (u64)nfull, (u32)rem, (u32)padding, done, tail_from);
+    }
     return (int)hipGetLastError();
 }
 
@@ -929,14 +977,19 @@ static int launch_xts(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *k1
         /* every block address is a multiple of 16 unless units of ragged size follow one another */
         const unsigned xgrid = grid_for(nchunks, wg / 64);
         const u64 nwaves = (u64)xgrid * (wg / 64), step_q = nwaves / cps, step_r = nwaves % cps;
+        /* the remainder of the last round by quarter chunks when it covers less than 80 % of the waves (k_xts) */
+        static int pct = -1;
+        if (pct < 0) { const char *e = getenv("UAES_XTS_TAIL_PCT"); pct = e ? atoi(e) : 80; if (pct < 0 || pct > 100) pct = 80; }
+        const u64 rounds = nchunks / nwaves, left = nchunks % nwaves;
+        const u64 nmain = (rounds && left && left * 100 < nwaves * (u64)pct) ? rounds * nwaves : nchunks;
         if (sector_bytes % 16 == 0 || nsectors == 1)
             hipLaunchKernelGGL((k_xts<NR, DEC, true>), dim3(xgrid), dim3(wg), lds, st,
                                *k1, *tb, (const uint4 *)scratch, (u64)nsectors, cps, mb, (u64)sector_bytes, step_q, step_r,
-                               (const unsigned char *)in, (unsigned char *)out);
+                               (const unsigned char *)in, (unsigned char *)out, nmain);
         else
             hipLaunchKernelGGL((k_xts<NR, DEC, false>), dim3(xgrid), dim3(wg), lds, st,
                                *k1, *tb, (const uint4 *)scratch, (u64)nsectors, cps, mb, (u64)sector_bytes, step_q, step_r,
-                               (const unsigned char *)in, (unsigned char *)out);
+                               (const unsigned char *)in, (unsigned char *)out, nmain);
     }
     if (r) {
         hipLaunchKernelGGL((k_xts_cts<NR, DEC>), dim3(grid_for(nsectors, UAES_WG)), dim3(UAES_WG), lds, st,

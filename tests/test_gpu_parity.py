@@ -1480,3 +1480,29 @@ def test_ctr_partial_last_round_of_stripes(orc, bits):
         got = bytes(dst.cpu().numpy())
         assert hashlib.sha256(got[:n]).digest() == hashlib.sha256(orc.ctr_xcrypt_at(key, ctr0, 77, data)).digest(), (bits, n)
         assert got[n:] == b"\xee" * 64
+
+
+@pytest.mark.parametrize("sector_bytes,nsectors", [(4096, 4096 + 512), (4096, 2 * 4096 + 1), (512, 8 * 4096 * 2 + 4099), (4096 + 16, 4300),
+                                                   (528, 70001)])
+def test_xts_partial_last_round_of_chunks(orc, sector_bytes, nsectors):
+    """k_xts gives every wave 256-block chunks round-robin; a last round that covers only part of the grid's waves goes by
+    QUARTER chunks (64 blocks, one per lane, tweak * alpha^(64 k)) over four times as many waves.  Volumes just past one
+    and two rounds (a round = 4096 waves x 4 KiB), short chunks at the end of every unit (4112-byte units: 257 blocks = a
+    full chunk + a one-block chunk), both directions, against the oracle."""
+    import torch
+    keys = bytes(range(64))
+    n = sector_bytes * nsectors
+    data = orc.splitmix(nsectors & 0xffff, n)
+    rc, want = orc.xts_sectors(keys, 1 << 33, sector_bytes, data, True)
+    assert rc == 0
+    src = torch.frombuffer(bytearray(data), dtype=torch.uint8).to("cuda:0")
+    dst = torch.full((n + 64,), 0xEE, dtype=torch.uint8, device="cuda:0")
+    uaes.xts_sectors_dev(keys, 1 << 33, sector_bytes, nsectors, src, dst)
+    torch.cuda.synchronize()
+    got = bytes(dst.cpu().numpy())
+    assert hashlib.sha256(got[:n]).digest() == hashlib.sha256(want).digest()
+    assert got[n:] == b"\xee" * 64
+    back = torch.empty(n, dtype=torch.uint8, device="cuda:0")
+    uaes.xts_sectors_dev(keys, 1 << 33, sector_bytes, nsectors, dst, back, encrypt=False)
+    torch.cuda.synchronize()
+    assert torch.equal(back, src)
