@@ -626,6 +626,22 @@ def main():
             lds_ceiling = {"lookups_per_block": lookups, "lookups_per_clk_per_cu": 32, "cus": cus,
                            "sclk_mhz_under_load": round(sclk_mhz, 0), "ceiling_gbs": round(ceil_gbs, 1),
                            "frac_of_ceiling": round(achieved / ceil_gbs, 4)}
+        # Both pipes, in shader clocks per 16-byte block per CU: the LDS serves 32 lookups per
+        # clock, and every VALU instruction of a stream that contains v_perm_b32 costs 4.43 SIMD-cycles
+        # (profiles/r04_issuebench.log); VALU instructions per block = SQ_INSTS_VALU x 64 / blocks of the recorded rocprofv3
+        # PMC pass (profiles/r04_*_rocprof_summary.txt).  The two do not overlap freely (they share the register-file
+        # ports): the dependency-free ceiling of the CTR mix is 4.56 clk per block, not max(valu, lds).
+        pipes = None
+        valu_per_block = {"ctr": 213, "gcm": 297, "xts": 373}.get(a.workload)
+        if sclk_mhz and lookups and valu_per_block and a.workload in ("ctr", "gcm", "xts") and n >= (256 << 20):
+            cus = torch.cuda.get_device_properties(0).multi_processor_count
+            blocks = n / 16.0
+            pipes = {"achieved_clk_per_block_per_cu": round(cus * sclk_mhz * 1e6 * kern_ms * 1e-3 / blocks, 3),
+                     "lds_clk_per_block_per_cu": round(lookups * 2.08 / 64.0, 3),
+                     "valu_clk_per_block_per_cu": round(valu_per_block * 4.43 / 256.0, 3),
+                     "valu_insts_per_block": valu_per_block,
+                     "source": "recorded: SQ_INSTS_VALU of profiles/r04_*_rocprof_summary.txt, 4.43 cycles per VALU "
+                               "instruction and 2.08 clk per ds_read_b32 from profiles/r04_issuebench.log; clock measured in this run"}
         names = {"ctr": "AES-128-CTR", "ecb": "AES-128-ECB", "xts": "AES-256-XTS 4 KiB sectors", "gcm": "AES-128-GCM",
                  "cbc-dec": "AES-128-CBC decrypt", "cfb-dec": "AES-128-CFB decrypt",
                  "cbc-enc": "AES-128-CBC encrypt, ONE serial chain", "cmac": "AES-128-CMAC, ONE serial chain",
@@ -648,7 +664,7 @@ def main():
                          "kernel_ms": round(kern_ms, 4),
                          "kernel_ms_min": round(min(per_step_ms), 4),
                          "measured_copy_ceiling_gbs": None if copy_gbs is None else round(copy_gbs, 1),
-                         "lds_ceiling": lds_ceiling},
+                         "lds_ceiling": lds_ceiling, "pipes": pipes},
             "verified": verify,
         }
         if world > 1:
