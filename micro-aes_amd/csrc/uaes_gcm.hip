@@ -1949,14 +1949,13 @@ extern "C" int uaesk_gcm_j0(void *stream, const uaesk_tables *tb, int nr, const 
  * (whose fixed cost is ~60 us); UAES_GCM_MEDIUM_W overrides it (tools/gcm_size_sweep.py)                  */
 static u32 medium_pref_w(void)
 {
-    static u32 w = 0;
-    if (!w) {
+    static const u32 w = [] {                          /* initialised once, thread-safe */
         const char *e = getenv("UAES_GCM_MEDIUM_W");
         long v = e ? atol(e) : 512;
         if (v < 1) v = 1;
         if (v > (long)GMC_MAXW) v = GMC_MAXW;
-        w = (u32)v;
-    }
+        return (u32)v;
+    }();
     return w;
 }
 

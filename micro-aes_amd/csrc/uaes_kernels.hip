@@ -702,6 +702,14 @@ extern "C" int uaesk_device_info(int *cu_count, int *lds_bytes)
     return 0;
 }
 
+/* an integer from the environment, clamped; callers keep it in a function-local `static const` (initialised once, thread-safe) */
+static int env_int_clamped(const char *name, int dflt, int lo, int hi)
+{
+    const char *e = getenv(name);
+    int v = (e && *e) ? atoi(e) : dflt;
+    return v < lo ? lo : v > hi ? hi : v;
+}
+
 static unsigned grid_for(u64 work_items, u64 per_wg)
 {
     if (g_cus <= 0) uaesk_device_info(nullptr, nullptr);
@@ -831,23 +839,20 @@ static int launch_ctr_shared(hipStream_t st, const uaesk_tables *tb, const uaesk
     const u32 c0 = (u32)ctr->v0 & 0xffu;
     unsigned grid = grid_for(~0ull, 1);
     {   /* measurement only (energy per block): UAES_CTR_GRID = number of workgroups (= CUs used) */
-        static int want = -1;
-        if (want < 0) { const char *e = getenv("UAES_CTR_GRID"); want = e ? atoi(e) : 0; }
+        static const int want = env_int_clamped("UAES_CTR_GRID", 0, 0, 1 << 20);
         if (want > 0 && (unsigned)want < grid) grid = (unsigned)want;
     }
     const u64 g_lo = c0 ? 1 : 0, groups = (c0 + nfull) / 256;
     u64 n8 = groups > g_lo ? (groups - g_lo) / 8 : 0;
     {   /* below `half_rounds` / 2 rounds of stripes the generic kernel spreads better (UAES_CTR_MIN_HALF_ROUNDS, measurement) */
-        static int half_rounds = -1;
-        if (half_rounds < 0) { const char *e = getenv("UAES_CTR_MIN_HALF_ROUNDS"); half_rounds = e ? atoi(e) : 2; if (half_rounds < 2) half_rounds = 2; }
+        static const int half_rounds = env_int_clamped("UAES_CTR_MIN_HALF_ROUNDS", 2, 2, 1 << 20);
         if (n8 * 2 < (u64)grid * (u64)half_rounds) return launch_ctr_v<NR, 4>(st, tb, ek, ctr, in, out, len, gate);
     }
     {   /* A last round of stripes that covers only part of the grid leaves the other workgroups idle for a whole stripe
          * (20 MiB = 640 stripes on 256 workgroups: 2.5 rounds cost 3).  Below `pct` % of the grid those stripes are
          * handed to the kernel's edge path instead -- one block per thread through the plain rounds, spread evenly over
          * ALL workgroups: 160 lookups per block instead of 128, but nobody waits (UAES_CTR_TAIL_PCT, 0 = off). */
-        static int pct = -1;
-        if (pct < 0) { const char *e = getenv("UAES_CTR_TAIL_PCT"); pct = e ? atoi(e) : 80; if (pct < 0 || pct > 100) pct = 80; }
+        static const int pct = env_int_clamped("UAES_CTR_TAIL_PCT", 80, 0, 100);
         const u64 r = n8 % grid;
         if (r && n8 > grid && r * 100 < (u64)grid * (u64)pct) n8 -= r;
     }
@@ -978,8 +983,7 @@ static int launch_xts(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *k1
         const unsigned xgrid = grid_for(nchunks, wg / 64);
         const u64 nwaves = (u64)xgrid * (wg / 64), step_q = nwaves / cps, step_r = nwaves % cps;
         /* the remainder of the last round by quarter chunks when it covers less than 80 % of the waves (k_xts) */
-        static int pct = -1;
-        if (pct < 0) { const char *e = getenv("UAES_XTS_TAIL_PCT"); pct = e ? atoi(e) : 80; if (pct < 0 || pct > 100) pct = 80; }
+        static const int pct = env_int_clamped("UAES_XTS_TAIL_PCT", 80, 0, 100);
         const u64 rounds = nchunks / nwaves, left = nchunks % nwaves;
         const u64 nmain = (rounds && left && left * 100 < nwaves * (u64)pct) ? rounds * nwaves : nchunks;
         if (sector_bytes % 16 == 0 || nsectors == 1)
