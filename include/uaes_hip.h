@@ -422,6 +422,31 @@ int uaes_mgpu_xts_sectors(int ndev, const int *devices, int keybits, const uint8
                           uint64_t first_sector, size_t sector_bytes, size_t nsectors,
                           const void *in, void *out, int encrypt);
 
+/* ECB over several GPUs (AES_ECB_encrypt / AES_ECB_decrypt, micro_aes.c:636-680: any partition of the blocks).  The
+ * whole blocks are dealt out evenly; the last device also takes the ragged tail and the padding (padding = the
+ * reference's AES_PADDING as in uaes_ecb_encrypt_padded), so the bytes written, and decryption's UAES_E_DECRYPTION
+ * for a length that is no multiple of 16, are those of the one-device call.                                     */
+int uaes_mgpu_ecb_encrypt(int ndev, const int *devices, int keybits, const uint8_t *key, int padding,
+                          const void *pntxt, size_t ptextLen, void *crtxt);
+int uaes_mgpu_ecb_decrypt(int ndev, const int *devices, int keybits, const uint8_t *key,
+                          const void *crtxt, size_t crtxtLen, void *pntxt);
+
+/* GCM over several GPUs (AES_GCM_encrypt / AES_GCM_decrypt, micro_aes.c:1164-1212; gHash :1127-1137), the C host's
+ * form of the sharded GCM described further down: device i runs CTR over its 16-byte aligned slice at keystream block
+ * J0 + 1 + slice_start / 16 FUSED with the slice's weighted share of Enc(J0) ^ GHASH (one pass over the text; the
+ * first slice carries aData and Enc(J0), the last one the length block); the host XORs the ndev 16-byte shares -- the
+ * only exchange GCM needs, and it needs no collective in one process.  12-byte nonce, 16-byte tag at crtxt + ptextLen
+ * / read at crtxt + crtxtLen, bit for bit what uaes_gcm_encrypt / _decrypt give on one device.
+ * decrypt keeps N7 across devices: every device hashes its slice of the INPUT, the host compares the tag, and only
+ * then is anything written; a forgery returns UAES_E_AUTHENTICATION with every slice of pntxt untouched.  (Host
+ * buffers: each slice is decrypted inside a private device buffer during the hashing pass and copied out after the
+ * verdict, so the text crosses each device's link once per direction.  Device buffers: two passes, or -- under
+ * uaes_set_gcm_one_pass_decrypt -- one pass and zeroed slices on a forgery.)                                      */
+int uaes_mgpu_gcm_encrypt(int ndev, const int *devices, int keybits, const uint8_t *key, const uint8_t *nonce,
+                          const void *aData, size_t aDataLen, const void *pntxt, size_t ptextLen, void *crtxt);
+int uaes_mgpu_gcm_decrypt(int ndev, const int *devices, int keybits, const uint8_t *key, const uint8_t *nonce,
+                          const void *aData, size_t aDataLen, const void *crtxt, size_t crtxtLen, void *pntxt);
+
 /* BASELINE configs[4] in one call: the plaintext lies sharded over ndev GPUs (d_in[i] on devices[i] holds the slice
  * uaes_mgpu_ctr_xcrypt_at would give device i: blocks [B*i/ndev, B*(i+1)/ndev) of the B = ceil(len/16) blocks), every
  * device encrypts its slice with the counter advanced by its block offset (incBlock's 56-bit add, micro_aes.c:421-427;

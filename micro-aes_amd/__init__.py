@@ -42,6 +42,7 @@ EXPORTS = [
     "uaes_cmac", "uaes_ccm_encrypt", "uaes_ccm_decrypt", "uaes_gcmsiv_encrypt", "uaes_gcmsiv_decrypt",
     "uaes_ocb_encrypt", "uaes_ocb_decrypt", "uaes_ocb_dev",
     "uaes_mgpu_ctr_xcrypt_at", "uaes_mgpu_xts_sectors", "uaes_mgpu_ctr_encrypt_gather",
+    "uaes_mgpu_ecb_encrypt", "uaes_mgpu_ecb_decrypt", "uaes_mgpu_gcm_encrypt", "uaes_mgpu_gcm_decrypt",
     "uaes_gcm_key_new", "uaes_gcm_key_free", "uaes_gcm_key_encrypt", "uaes_gcm_key_decrypt",
     "uaes_gcm_key_encrypt_dev", "uaes_gcm_key_decrypt_dev",
     "uaes_gcm_record_max", "uaes_gcm_key_encrypt_records", "uaes_gcm_key_decrypt_records",
@@ -140,6 +141,10 @@ def engine():
     L.uaes_mgpu_ctr_xcrypt_at.argtypes = [i, C.POINTER(C.c_int), i, vp, vp, u64, vp, sz, vp]
     L.uaes_mgpu_xts_sectors.argtypes = [i, C.POINTER(C.c_int), i, vp, u64, sz, sz, vp, vp, i]
     L.uaes_mgpu_ctr_encrypt_gather.argtypes = [i, C.POINTER(C.c_int), i, vp, vp, u64, C.POINTER(vp), sz, C.POINTER(vp), i, vp]
+    L.uaes_mgpu_ecb_encrypt.argtypes = [i, C.POINTER(C.c_int), i, vp, i, vp, sz, vp]
+    L.uaes_mgpu_ecb_decrypt.argtypes = [i, C.POINTER(C.c_int), i, vp, vp, sz, vp]
+    for n in ("uaes_mgpu_gcm_encrypt", "uaes_mgpu_gcm_decrypt"):
+        getattr(L, n).argtypes = [i, C.POINTER(C.c_int), i, vp, vp, vp, sz, vp, sz, vp]
     L.uaes_gcm_key_new.argtypes = [C.POINTER(vp), i, vp]
     L.uaes_gcm_key_free.argtypes = [vp]
     L.uaes_gcm_key_free.restype = None
@@ -469,6 +474,61 @@ def AES_OCB_decrypt(key, nonce, aData, crtxt_and_tag, prefill=0, tag_len=16):
     rc = _check(engine().uaes_ocb_decrypt_ex(_bits(key), _in(key), _ocb_nonce(nonce), len(nonce), tag_len, _in(aData),
                                              len(aData), _in(crtxt_and_tag), n, o), "AES_OCB_decrypt")
     return rc, bytes(o)[:n]
+
+
+# ---------------------------------------------------------------------------
+# one process, several GPUs (uaes_mgpu_*): `devices` = list of HIP ordinals (an ordinal may repeat)
+# ---------------------------------------------------------------------------
+def _devs(devices):
+    devices = list(devices)
+    return len(devices), (C.c_int * len(devices))(*devices)
+
+
+def _buf(x):
+    """host bytes -> ctypes copy; an int is taken as a raw (device) address"""
+    return C.c_void_p(x) if isinstance(x, int) else _in(x)
+
+
+def mgpu_ecb_encrypt(devices, key, pntxt, padding=0):
+    n, d = _devs(devices)
+    m = (len(pntxt) // 16 + 1) * 16 if padding else (len(pntxt) + 15) // 16 * 16
+    o = _out(m)
+    _check(engine().uaes_mgpu_ecb_encrypt(n, d, _bits(key), _in(key), padding, _in(pntxt), len(pntxt), o), "uaes_mgpu_ecb_encrypt")
+    return bytes(o)[:m]
+
+
+def mgpu_ecb_decrypt(devices, key, crtxt, prefill=0):
+    n, d = _devs(devices)
+    o = _out(len(crtxt), prefill)
+    rc = _check(engine().uaes_mgpu_ecb_decrypt(n, d, _bits(key), _in(key), _in(crtxt), len(crtxt), o), "uaes_mgpu_ecb_decrypt")
+    return rc, bytes(o)[: len(crtxt)]
+
+
+def mgpu_gcm_encrypt(devices, key, nonce, aData, pntxt):
+    """== AES_GCM_encrypt, the text cut into one 16-byte aligned slice per device (uaes_mgpu_gcm_encrypt)."""
+    n, d = _devs(devices)
+    o = _out(len(pntxt) + 16)
+    _check(engine().uaes_mgpu_gcm_encrypt(n, d, _bits(key), _in(key), _fixed(nonce, 12, "nonce"), _in(aData), len(aData),
+                                          _in(pntxt), len(pntxt), o), "uaes_mgpu_gcm_encrypt")
+    return bytes(o)[: len(pntxt) + 16]
+
+
+def mgpu_gcm_decrypt(devices, key, nonce, aData, crtxt_and_tag, prefill=0):
+    """== AES_GCM_decrypt: (code, plaintext); 0x1A and an untouched (prefilled) buffer on a forgery (N7 across devices)."""
+    n, d = _devs(devices)
+    m = len(crtxt_and_tag) - 16
+    o = _out(m, prefill)
+    rc = _check(engine().uaes_mgpu_gcm_decrypt(n, d, _bits(key), _in(key), _fixed(nonce, 12, "nonce"), _in(aData), len(aData),
+                                               _in(crtxt_and_tag), m, o), "uaes_mgpu_gcm_decrypt")
+    return rc, bytes(o)[:m]
+
+
+def mgpu_gcm_dev(devices, key, nonce, aad, src_ptr, nbytes, dst_ptr, decrypt=False):
+    """the same on raw device addresses (ints): encrypt writes nbytes + 16 at dst_ptr; decrypt reads nbytes + 16"""
+    n, d = _devs(devices)
+    fn = engine().uaes_mgpu_gcm_decrypt if decrypt else engine().uaes_mgpu_gcm_encrypt
+    return _check(fn(n, d, _bits(key), _in(key), _fixed(nonce, 12, "nonce"), _in(aad or b""), len(aad or b""),
+                     C.c_void_p(src_ptr), nbytes, C.c_void_p(dst_ptr)), "uaes_mgpu_gcm_*")
 
 
 class GcmKey:

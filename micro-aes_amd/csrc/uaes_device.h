@@ -125,6 +125,14 @@ int uaesk_gcm_partial(void *stream, const uaesk_tables *tb, int nr, const uaesk_
                       const uint8_t *nonce12, const void *aad, uint64_t total_aad_len,
                       const void *ct_shard, size_t shard_len, uint64_t shard_offset,
                       uint64_t total_len, void *scratch, void *partial16);
+/* ... and the shard's CTR pass with it (one process driving several GPUs, uaes_mgpu_gcm_*): mode 0 encrypts
+ * in -> out (keystream from J0 + 1 + shard_offset / 16) and hashes `out`; mode 1 = uaesk_gcm_partial (`out` unused);
+ * mode 2 decrypts in -> out and hashes `in` -- `out` is written before any tag is known, the caller owns N7.
+ * Every shard but the last is a multiple of 16 bytes.  A long shard runs CTR and GHASH in one pass.          */
+int uaesk_gcm_shard(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek, int mode,
+                    const uint8_t *nonce12, const void *aad, uint64_t total_aad_len,
+                    const void *in, size_t shard_len, uint64_t shard_offset,
+                    uint64_t total_len, void *out, void *scratch, void *partial16);
 
 /* Streamed GCM: the running GHASH value stays in `scratch` (one
  * scratch buffer per stream).  absorb kind 0 = AAD (restarts the hash), 1 = a piece of

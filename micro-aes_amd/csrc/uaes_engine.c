@@ -2786,16 +2786,71 @@ void uaes_gcm_stream_abort(uaes_gcm_stream *s)
  * offset advanced -- the per-device contexts make that safe.  With host buffers
  * every device moves its slice over its own PCIe link, which is what scales.  */
 typedef struct {
-    int         device, keybits, mode, encrypt, rc;       /* mode 0 CTR, 1 XTS sectors */
+    int         device, keybits, mode, encrypt, rc;       /* mode 0 CTR, 1 XTS sectors, 2 nothing (an empty slice),
+                                                           * 3 ECB, 4 a GCM shard, 5 what a GCM-decrypt shard does once the
+                                                           * tag has been judged (encrypt = the verdict: 1 good, 0 forged) */
     const uint8_t *key;
     uint8_t     ctr0[16];
-    uint64_t    offset;                                   /* block offset / first sector */
+    uint64_t    offset;                                   /* block offset / first sector / byte offset of a GCM shard */
     size_t      sector_bytes, nsectors;
     const void *in;
     void       *out;
     size_t      len;
+    /* GCM shards */
+    int         gcm_mode, padding;                        /* uaesk_gcm_shard's mode; ECB: the reference's AES_PADDING */
+    const uint8_t *nonce;
+    const void *aad;
+    uint64_t    aad_len, total_len;
+    uint8_t     share[16];
+    void       *hold;                                     /* a decrypting shard's private device copy, kept until the verdict */
     char        err[256];
 } mgpu_job;
+
+static int gcm_shard_sync(int keybits, const uint8_t *key, const uint8_t *nonce, int mode,
+                          const void *aData, uint64_t aDataLen, const void *in, size_t len, uint64_t off,
+                          uint64_t total, void *out, uint8_t share[16]);
+
+/* One device's part of uaes_mgpu_gcm_decrypt BEFORE the tag is known.  Nothing may reach the caller's buffer yet (N7,
+ * micro_aes.c:1200-1208).  Device-reachable, aligned buffers: the shard's ciphertext is hashed where it lies (with
+ * uaes_set_gcm_one_pass_decrypt: decrypted into place in the same pass and zeroed again if the tag turns out wrong).
+ * Host (or misaligned) buffers: the slice goes into a device buffer of this call's own, is decrypted there in one
+ * pass with the hash, and waits for the verdict -- the text crosses the link once each way.                       */
+static int gcm_decrypt_shard_first(mgpu_job *j)
+{
+    const int direct = (j->len == 0) ||
+                       (is_device_ptr(j->in) && is_device_ptr(j->out) && ((((uintptr_t)j->in) | ((uintptr_t)j->out)) & 15u) == 0);
+    if (direct) {
+        j->gcm_mode = (j->len && gcm_decrypt_mode() == 2) ? 2 : 1;
+        return gcm_shard_sync(j->keybits, j->key, j->nonce, j->gcm_mode, j->aad, j->aad_len, j->in, j->len, j->offset,
+                              j->total_len, j->out, j->share);
+    }
+    j->gcm_mode = 2;
+    if (hipMalloc(&j->hold, j->len + 64) != hipSuccess) { j->hold = NULL; return fail(UAES_E_HIP, "no device memory for a %zu-byte shard", j->len); }
+    if (hipMemcpy(j->hold, j->in, j->len, hipMemcpyDefault) != hipSuccess) return fail(UAES_E_HIP, "copying a shard in failed");
+    return gcm_shard_sync(j->keybits, j->key, j->nonce, 2, j->aad, j->aad_len, j->hold, j->len, j->offset,
+                          j->total_len, j->hold, j->share);
+}
+
+/* ... and once the host has XORed the shares and compared the tag */
+static int gcm_decrypt_shard_second(mgpu_job *j)
+{
+    const int good = j->encrypt;
+    int rc = 0;
+    if (j->hold) {
+        if (good && hipMemcpy(j->out, j->hold, j->len, hipMemcpyDefault) != hipSuccess) rc = fail(UAES_E_HIP, "copying a shard out failed");
+        (void)hipMemset(j->hold, 0, j->len);              /* plaintext */
+        if (hipFree(j->hold) != hipSuccess && rc == 0) rc = fail(UAES_E_HIP, "hipFree of a shard buffer failed");
+        j->hold = NULL;
+        return rc;
+    }
+    if (j->len == 0) return 0;
+    if (j->gcm_mode == 2) {                               /* written already: keep it, or take it back */
+        if (!good && hipMemset(j->out, 0, j->len) != hipSuccess) rc = fail(UAES_E_HIP, "wiping an unauthenticated shard failed");
+        return rc;
+    }
+    if (!good) return 0;
+    return uaes_ctr_xcrypt_at(j->keybits, j->key, j->ctr0, 1 + j->offset / 16, j->in, j->len, j->out);
+}
 
 static void *mgpu_worker(void *arg)
 {
@@ -2806,10 +2861,18 @@ static void *mgpu_worker(void *arg)
         snprintf(j->err, sizeof j->err, "hipSetDevice(%d): %s", j->device, hipGetErrorString(e));
         return NULL;
     }
-    if (j->mode == 2) return NULL;                       /* an empty slice */
-    j->rc = j->mode == 0
-        ? uaes_ctr_xcrypt_at(j->keybits, j->key, j->ctr0, j->offset, j->in, j->len, j->out)
-        : uaes_xts_sectors(j->keybits, j->key, j->offset, j->sector_bytes, j->nsectors, j->in, j->out, j->encrypt);
+    switch (j->mode) {
+    case 0: j->rc = uaes_ctr_xcrypt_at(j->keybits, j->key, j->ctr0, j->offset, j->in, j->len, j->out); break;
+    case 1: j->rc = uaes_xts_sectors(j->keybits, j->key, j->offset, j->sector_bytes, j->nsectors, j->in, j->out, j->encrypt); break;
+    case 2: return NULL;                                  /* an empty slice */
+    case 3: j->rc = j->encrypt ? uaes_ecb_encrypt_padded(j->keybits, j->key, j->padding, j->in, j->len, j->out)
+                               : uaes_ecb_decrypt(j->keybits, j->key, j->in, j->len, j->out); break;
+    case 4: j->rc = j->encrypt ? gcm_shard_sync(j->keybits, j->key, j->nonce, 0, j->aad, j->aad_len, j->in, j->len, j->offset,
+                                                j->total_len, j->out, j->share)
+                               : gcm_decrypt_shard_first(j); break;
+    case 5: j->rc = gcm_decrypt_shard_second(j); break;
+    default: j->rc = UAES_E_ARG; snprintf(j->err, sizeof j->err, "unknown job"); return NULL;
+    }
     if (j->rc < 0) snprintf(j->err, sizeof j->err, "device %d: %s", j->device, uaes_last_error());
     return NULL;
 }
@@ -2914,6 +2977,7 @@ static int mgpu_devices(int ndev, const int *devices, int *out)
     for (i = 0; i < ndev; ++i) {
         out[i] = devices ? devices[i] : i;
         if (out[i] < 0 || out[i] >= avail) return fail(UAES_E_ARG, "device %d is not one of the %d visible", out[i], avail);
+        if (out[i] >= MAX_DEVICES) return fail(UAES_E_ARG, "device %d: this library drives ordinals below %d", out[i], MAX_DEVICES);
     }
     return 0;
 }
@@ -2961,6 +3025,159 @@ int uaes_mgpu_xts_sectors(int ndev, const int *devices, int keybits, const uint8
         ++n;
     }
     return n ? mgpu_run(jobs, n) : 0;
+}
+
+/* ECB (AES_ECB_encrypt / AES_ECB_decrypt, micro_aes.c:636-680): any partition of the blocks will do.  The whole
+ * blocks are dealt out evenly; the last slice also takes the ragged tail and the padding (N1, padBlock :610-621), so
+ * what is written -- and a decryption's 0x1D for a length that is no multiple of 16 (:679) -- is the one-device result. */
+static int mgpu_ecb(int ndev, const int *devices, int keybits, const uint8_t *key, int encrypt, int padding,
+                    const void *in, size_t len, void *out)
+{
+    mgpu_job jobs[MAX_DEVICES];
+    int dev[MAX_DEVICES], i, rc, n = 0;
+    const size_t nfull = len / 16;
+    if (!key || (len && (!in || !out)) || (encrypt && padding && !out)) return fail(UAES_E_ARG, "NULL pointer");
+    if (padding < 0 || padding > 2) return fail(UAES_E_ARG, "padding %d (0 zeros, 1 PKCS#7, 2 ISO 7816-4)", padding);
+    if ((rc = mgpu_devices(ndev, devices, dev)) != 0) return rc;
+    memset(jobs, 0, sizeof jobs);
+    for (i = 0; i < ndev; ++i) {
+        const int last = i == ndev - 1;
+        const size_t lo = nfull * (size_t)i / (size_t)ndev * 16, hi = last ? len : nfull * (size_t)(i + 1) / (size_t)ndev * 16;
+        if (hi <= lo && !(last && encrypt && padding)) continue;      /* (PKCS#7 / ISO padding always appends a block) */
+        jobs[n].device = dev[i]; jobs[n].keybits = keybits; jobs[n].key = key; jobs[n].mode = 3;
+        jobs[n].encrypt = encrypt; jobs[n].padding = last ? padding : 0;
+        jobs[n].in = (const char *)in + lo; jobs[n].out = (char *)out + lo; jobs[n].len = hi - lo;
+        ++n;
+    }
+    return n ? mgpu_run(jobs, n) : 0;
+}
+
+int uaes_mgpu_ecb_encrypt(int ndev, const int *devices, int keybits, const uint8_t *key, int padding,
+                          const void *pntxt, size_t ptextLen, void *crtxt)
+{
+    return mgpu_ecb(ndev, devices, keybits, key, 1, padding, pntxt, ptextLen, crtxt);
+}
+
+int uaes_mgpu_ecb_decrypt(int ndev, const int *devices, int keybits, const uint8_t *key,
+                          const void *crtxt, size_t crtxtLen, void *pntxt)
+{
+    return mgpu_ecb(ndev, devices, keybits, key, 0, 0, crtxt, crtxtLen, pntxt);
+}
+
+/* ------------------------------------------------------------------------ */
+/* GCM over several GPUs (CTR shards + one 16-byte exchange)     */
+/* ------------------------------------------------------------------------ */
+/* One shard of a GCM message on the calling thread's current device, synchronously: the CTR pass (mode 0 / 2) fused
+ * with the shard's weighted share of Enc(J0) ^ GHASH (uaesk_gcm_shard); mode 1 hashes only.  in / out host or device. */
+static int gcm_shard_sync(int keybits, const uint8_t *key, const uint8_t *nonce, int mode,
+                          const void *aData, uint64_t aDataLen, const void *in, size_t len, uint64_t off,
+                          uint64_t total, void *out, uint8_t share[16])
+{
+    context *c;
+    lane *L;
+    keysched ks;
+    io_plan io;
+    const void *d_aad = NULL;
+    int rc;
+    if ((rc = expand_key(&ks, key, keybits)) != 0) return rc;
+    if ((rc = enter(&c, &L)) != 0) return rc;
+    do {
+        int k;
+        if ((rc = gcm_scratch(L)) != 0) break;
+        if (off == 0 && (rc = stage_aad(L, aData, (size_t)aDataLen, &d_aad)) != 0) break;
+        if ((rc = plan_io(L, in, len, mode == 1 ? NULL : out, mode == 1 ? 0 : len, &io)) != 0) break;
+        k = uaesk_gcm_shard(L->stream, &c->tb, ks.nr, &ks.ek, mode, nonce, d_aad, aDataLen, io.din, len, off, total,
+                            mode == 1 ? NULL : io.dout, L->scratch, L->d_status + 4);
+        if (k) { rc = fail(UAES_E_HIP, "gcm shard launch: %s", hipGetErrorString((hipError_t)k)); break; }
+        if ((rc = lane_fetch(L, share, L->d_status + 4, 16)) != 0) break;
+        if (mode != 1) { io.drained = 1; rc = finish_io(&io, len); }
+    } while (0);
+    memset(&ks, 0, sizeof ks);
+    DONE(L, rc);
+}
+
+/* the 16 bytes behind a text that may be host or device memory */
+static int tag_store(void *dst, const uint8_t tag[16])
+{
+    if (!is_device_ptr(dst)) { memcpy(dst, tag, 16); return 0; }
+    if (hipMemcpy(dst, tag, 16, hipMemcpyDefault) != hipSuccess) return fail(UAES_E_HIP, "writing the tag failed");
+    return 0;
+}
+
+static int tag_load(uint8_t tag[16], const void *src)
+{
+    if (!is_device_ptr(src)) { memcpy(tag, src, 16); return 0; }
+    if (hipMemcpy(tag, src, 16, hipMemcpyDefault) != hipSuccess) return fail(UAES_E_HIP, "reading the tag failed");
+    return 0;
+}
+
+/* the shards of a len-byte text: 16-byte aligned slices, the first one at offset 0 (it carries the AAD and Enc(J0)),
+ * the last one ending at len (it carries the length block); a text too short for every device leaves some out, and
+ * an EMPTY text still is one shard (its tag is Enc(J0) ^ GHASH(AAD, lengths))                                     */
+static int gcm_shard_jobs(mgpu_job *jobs, int ndev, const int *dev, int keybits, const uint8_t *key, const uint8_t *nonce,
+                          const void *aData, size_t aDataLen, const void *in, size_t len, void *out, int encrypt)
+{
+    const size_t blocks = (len + 15) / 16;
+    int i, n = 0;
+    for (i = 0; i < ndev; ++i) {
+        const size_t b0 = blocks * (size_t)i / (size_t)ndev, b1 = blocks * (size_t)(i + 1) / (size_t)ndev;
+        const size_t lo = b0 * 16, hi = b1 * 16 < len ? b1 * 16 : len;
+        if (hi <= lo && !(len == 0 && i == 0)) continue;
+        memset(&jobs[n], 0, sizeof jobs[n]);
+        jobs[n].device = dev[i]; jobs[n].keybits = keybits; jobs[n].key = key; jobs[n].mode = 4; jobs[n].encrypt = encrypt;
+        jobs[n].nonce = nonce; jobs[n].aad = aData; jobs[n].aad_len = aDataLen; jobs[n].total_len = len;
+        j0_of_nonce12(nonce, jobs[n].ctr0);
+        jobs[n].offset = lo;
+        jobs[n].in = len ? (const char *)in + lo : NULL; jobs[n].out = len ? (char *)out + lo : NULL; jobs[n].len = hi - lo;
+        ++n;
+    }
+    return n;
+}
+
+int uaes_mgpu_gcm_encrypt(int ndev, const int *devices, int keybits, const uint8_t *key, const uint8_t *nonce,
+                          const void *aData, size_t aDataLen, const void *pntxt, size_t ptextLen, void *crtxt)
+{
+    mgpu_job jobs[MAX_DEVICES];
+    uint8_t tag[16] = { 0 };
+    int dev[MAX_DEVICES], i, k, rc, n;
+    if (!key || !nonce || !crtxt || (ptextLen && !pntxt) || (aDataLen && !aData)) return fail(UAES_E_ARG, "NULL pointer");
+    if (keybits != 128 && keybits != 192 && keybits != 256) return fail(UAES_E_ARG, "keybits must be 128, 192 or 256 (got %d)", keybits);
+    if ((rc = mgpu_devices(ndev, devices, dev)) != 0) return rc;
+    n = gcm_shard_jobs(jobs, ndev, dev, keybits, key, nonce, aData, aDataLen, pntxt, ptextLen, crtxt, 1);
+    if ((rc = mgpu_run(jobs, n)) != 0) return rc;
+    for (i = 0; i < n; ++i)
+        for (k = 0; k < 16; ++k) tag[k] ^= jobs[i].share[k];
+    return tag_store((char *)crtxt + ptextLen, tag);
+}
+
+/* N7 across devices (micro_aes.c:1200-1208): every device first produces its share of the tag over the INPUT; the host
+ * XORs them and compares; only then does any device write the caller's buffer.  A forgery returns 0x1A with every
+ * shard untouched (or, for device buffers under uaes_set_gcm_one_pass_decrypt, zeroed -- as the one-device call does). */
+int uaes_mgpu_gcm_decrypt(int ndev, const int *devices, int keybits, const uint8_t *key, const uint8_t *nonce,
+                          const void *aData, size_t aDataLen, const void *crtxt, size_t crtxtLen, void *pntxt)
+{
+    mgpu_job jobs[MAX_DEVICES];
+    uint8_t tag[16] = { 0 }, given[16];
+    int dev[MAX_DEVICES], i, k, rc, rc2, n, good;
+    if (!key || !nonce || !crtxt || (crtxtLen && !pntxt) || (aDataLen && !aData)) return fail(UAES_E_ARG, "NULL pointer");
+    if (keybits != 128 && keybits != 192 && keybits != 256) return fail(UAES_E_ARG, "keybits must be 128, 192 or 256 (got %d)", keybits);
+    if ((rc = mgpu_devices(ndev, devices, dev)) != 0) return rc;
+    if ((rc = tag_load(given, (const char *)crtxt + crtxtLen)) != 0) return rc;
+    n = gcm_shard_jobs(jobs, ndev, dev, keybits, key, nonce, aData, aDataLen, crtxt, crtxtLen, pntxt, 0);
+    rc = mgpu_run(jobs, n);
+    for (i = 0; i < n; ++i)
+        for (k = 0; k < 16; ++k) tag[k] ^= jobs[i].share[k];
+    good = rc == 0 && !tags_differ(tag, given, 16);
+    for (i = 0; i < n; ++i) { jobs[i].mode = 5; jobs[i].encrypt = good; jobs[i].rc = 0; }
+    if (rc != 0) {                                         /* a device failed: the others still give their buffers back */
+        char msg[256];
+        snprintf(msg, sizeof msg, "%s", uaes_last_error());
+        (void)mgpu_run(jobs, n);
+        return rc < 0 ? fail(rc, "%s", msg) : rc;
+    }
+    rc2 = mgpu_run(jobs, n);
+    if (rc2 != 0) return rc2;
+    return good ? 0 : UAES_E_AUTHENTICATION;
 }
 
 /* ------------------------------------------------------------------------ */
@@ -3099,10 +3316,13 @@ int uaes_mgpu_ctr_encrypt_gather(int ndev, const int *devices, int keybits, cons
         jobs[i].device = dev[i]; jobs[i].keybits = keybits; jobs[i].key = key; jobs[i].mode = hi[i] > lo[i] ? 0 : 2;
         memcpy(jobs[i].ctr0, ctr0, 16);
         jobs[i].offset = block_offset + b0;
-        jobs[i].in = d_in[i];
+        jobs[i].in = hi[i] > lo[i] ? d_in[i] : NULL;
         /* a slice on the root's device is encrypted straight into its place in the gathered text unless the caller
          * also wants it in a shard buffer of its own */
-        jobs[i].out = (dev[i] == dev[root] && !(d_out && d_out[i])) ? (void *)((char *)d_full_on_root + lo[i]) : d_out[i];
+        {
+            void *own = d_out ? d_out[i] : NULL;
+            jobs[i].out = (dev[i] == dev[root] && !own) ? (void *)((char *)d_full_on_root + lo[i]) : own;
+        }
         jobs[i].len = hi[i] - lo[i];
     }
     if ((rc = mgpu_run(jobs, ndev)) != 0) return rc;
@@ -3142,8 +3362,10 @@ int uaes_mgpu_ctr_encrypt_gather(int ndev, const int *devices, int keybits, cons
                 }
             }
             if (started && (g = g_rccl.GroupEnd()) != 0 && rc == 0) rc = rccl_fail("ncclGroupEnd", g);
-            for (u = 0; u < nu && rc == 0; ++u)
-                if (hipSetDevice(uniq[u]) != hipSuccess || hipStreamSynchronize(g_gather.stream[u]) != hipSuccess)
+            /* drained whatever happened: after a failed send / receive the ones already enqueued may still be writing
+             * d_full_on_root and reading the shard buffers, and the caller is about to get those back */
+            for (u = 0; u < nu && g_gather.ready; ++u)
+                if ((hipSetDevice(uniq[u]) != hipSuccess || hipStreamSynchronize(g_gather.stream[u]) != hipSuccess) && rc == 0)
                     rc = fail(UAES_E_HIP, "the gather did not complete on device %d: %s", uniq[u], hipGetErrorString(hipGetLastError()));
             pthread_mutex_unlock(&g_rccl_mu);
         }

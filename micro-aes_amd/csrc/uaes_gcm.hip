@@ -2278,17 +2278,25 @@ __global__ __launch_bounds__(64) void k_gcm_weight(const unsigned char *__restri
  * blocks; GHASH = sum X_v * H^(M-v).  A shard owning blocks [lo, hi) computes
  * P = sum X_v * H^(hi-v) with the ordinary levels and weights it by H^(M-hi);
  * the tag is the XOR of all shards' results (Enc(J0) rides on the first).
- * Shards are 16-byte aligned slices of the ciphertext; the first one also
- * carries the AAD, the last one the length block (with the TOTAL lengths).  */
-extern "C" int uaesk_gcm_partial(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek,
-                                 const uint8_t *nonce12, const void *aad, uint64_t total_aad_len,
-                                 const void *ct_shard, size_t shard_len, uint64_t shard_offset,
-                                 uint64_t total_len, void *scratch, void *partial16)
+ * Shards are 16-byte aligned slices of the text; the first one also
+ * carries the AAD, the last one the length block (with the TOTAL lengths).
+ *
+ * mode 0: encrypt the shard (in -> out, keystream block J0 + 1 + shard_offset/16 onwards: the pre-increment of
+ *         CTR_cipher's CCM_GCM flavour, micro_aes.c:938-941, with incBlock's 56-bit carry, :421-427) and hash what
+ *         was written;  mode 1: hash `in` as ciphertext, write nothing (`out` unused);  mode 2: decrypt in -> out
+ *         and hash `in` -- the caller owns the N7 decision (micro_aes.c:1200-1208): `out` is written before any tag
+ *         is known.  A shard long enough for the striped kernel gets CTR and GHASH in one pass (k_gcm_fused, as a
+ *         whole message does); in == out is allowed.                                                            */
+extern "C" int uaesk_gcm_shard(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek, int mode,
+                               const uint8_t *nonce12, const void *aad, uint64_t total_aad_len,
+                               const void *in, size_t shard_len, uint64_t shard_offset,
+                               uint64_t total_len, void *out, void *scratch, void *partial16)
 {
     hipStream_t st = S(stream);
     unsigned char *sc = (unsigned char *)scratch;
-    if (shard_offset % 16 || shard_offset + shard_len > total_len) return (int)hipErrorInvalidValue;
+    if (shard_offset % 16 || shard_offset + shard_len > total_len || mode < 0 || mode > 2) return (int)hipErrorInvalidValue;
     const bool first = shard_offset == 0, last = shard_offset + shard_len == total_len;
+    if (!last && shard_len % 16) return (int)hipErrorInvalidValue;
     const u64 a_blk = (total_aad_len + 15) >> 4, c_blk = (total_len + 15) >> 4;
     const u64 m_total = a_blk + c_blk + 1;
     const u64 lo = first ? 0 : a_blk + shard_offset / 16;
@@ -2300,16 +2308,79 @@ extern "C" int uaesk_gcm_partial(void *stream, const uaesk_tables *tb, int nr, c
     memcpy(j0b, nonce12, 12);
     j0b[12] = j0b[13] = j0b[14] = 0; j0b[15] = 1;
     memcpy(&j0, j0b, 16);
+    uaesk_ctr c;
+    memset(&c, 0, sizeof c);
+    memcpy(&c.w0, j0b, 4);
+    memcpy(&c.w1, j0b + 4, 4);
+    c.b8 = j0b[8];
+    {
+        uint64_t v = 0;                         /* bytes 9..15 of J0: the reference's 56-bit counter (N2) */
+        for (int i = 9; i < 16; ++i) v = (v << 8) | j0b[i];
+        c.v0 = (v + 1 + shard_offset / 16) & 0x00FFFFFFFFFFFFFFull;
+    }
 
     GSrc msg;
     msg.aad = first ? (const unsigned char *)aad : nullptr;
     msg.aad_len = first ? total_aad_len : 0;
-    msg.ct = (const unsigned char *)ct_shard; msg.ct_len = shard_len;
+    msg.ct = (const unsigned char *)(mode == 0 ? out : in); msg.ct_len = shard_len;
     msg.has_len = last ? 1 : 0;
     msg.len_aad = total_aad_len; msg.len_ct = total_len; msg.rev = 0;
-    const GPlan pl = plan_for(nv ? nv : 1);
     const uint4 z = make_uint4(0, 0, 0, 0);
     int rc;
+
+    if (mode != 1) {                            /* CTR and GHASH of a long shard in one pass: gcm_body's conditions */
+        int cus = 0;
+        if (uaesk_device_info(&cus, nullptr) != 0) cus = 0;
+        const u64 Sl = 2048ull * (u64)(cus > 0 ? cus : 0);
+        u32 logF = 0;
+        while (((u64)1 << logF) < Sl) ++logF;
+        const u64 nfull = shard_len / 16, ablk = (msg.aad_len + 15) >> 4;
+        const u32 c0 = (u32)c.v0 & 0xffu;
+        const u64 h0 = (256u - c0) & 255u, g_lo = c0 ? 1 : 0;
+        const u64 groups = (c0 + nfull) / 256, n8 = groups > g_lo ? (groups - g_lo) / 8 : 0;
+        if (Sl && ((u64)1 << logF) == Sl && logF <= GF_MAXLOG && n8 >= (u64)cus && ablk + h0 <= Sl) {
+            const u64 h1 = h0 + 2048 * n8;
+            GSrc fin;                                   /* [T][tail]([lengths] on the last shard) */
+            fin.aad = sc + GS_T; fin.aad_len = 16;
+            fin.ct = msg.ct + h1 * 16; fin.ct_len = shard_len - h1 * 16;
+            fin.has_len = msg.has_len; fin.len_aad = total_aad_len; fin.len_ct = total_len; fin.rev = 0;
+            const u64 nvf = 1 + ((fin.ct_len + 15) >> 4) + (last ? 1 : 0);
+            const GPlan plf = plan_for(nvf);
+            GSrc front = msg;                           /* [AAD][head] in front of the striped region */
+            front.ct_len = h0 * 16; front.has_len = 0;
+            switch (nr) {
+            case 10: rc = launch_setup<10>(st, tb, ek, j0, sc, plf, 0, z, 1, logF); break;
+            case 12: rc = launch_setup<12>(st, tb, ek, j0, sc, plf, 0, z, 1, logF); break;
+            case 14: rc = launch_setup<14>(st, tb, ek, j0, sc, plf, 0, z, 1, logF); break;
+            default: return (int)hipErrorInvalidValue;
+            }
+            if (rc) return rc;
+            if (mode == 0) {
+                rc = launch_fused_nr<false>(nr, st, tb, ek, &c, in, out, (unsigned)cus, g_lo, n8, h1, nfull,
+                                            (u32)(shard_len % 16), front, ablk + h0, sc);
+                if (rc) return rc;
+                rc = run_ghash_levels(st, fin, nvf, plf, sc, 2, sc + GS_PART, nullptr);
+            } else {
+                /* the fused kernel leaves the tail alone: it is hashed as ciphertext first (in may be out) */
+                rc = launch_fused_nr<true>(nr, st, tb, ek, &c, in, out, (unsigned)cus, g_lo, n8, nfull, nfull, 0,
+                                           front, ablk + h0, sc);
+                if (rc) return rc;
+                rc = run_ghash_levels(st, fin, nvf, plf, sc, 2, sc + GS_PART, nullptr);
+                if (!rc && shard_len > h1 * 16) {
+                    uaesk_ctr ct = c;
+                    ct.v0 = (c.v0 + h1) & 0x00FFFFFFFFFFFFFFull;
+                    rc = uaesk_ctr_xcrypt(stream, tb, nr, ek, &ct, (const unsigned char *)in + h1 * 16,
+                                          (unsigned char *)out + h1 * 16, shard_len - h1 * 16, nullptr);
+                }
+            }
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_gcm_weight, dim3(1), dim3(64), 0, st, (const unsigned char *)sc, m_total - hi,
+                               (u32)first, 0u, (unsigned char *)partial16);
+            return (int)hipGetLastError();
+        }
+    }
+
+    const GPlan pl = plan_for(nv ? nv : 1);
     switch (nr) {
     case 10: rc = launch_setup<10>(st, tb, ek, j0, sc, pl, 0, z, 1); break;
     case 12: rc = launch_setup<12>(st, tb, ek, j0, sc, pl, 0, z, 1); break;
@@ -2317,13 +2388,29 @@ extern "C" int uaesk_gcm_partial(void *stream, const uaesk_tables *tb, int nr, c
     default: return (int)hipErrorInvalidValue;
     }
     if (rc) return rc;
+    if (mode == 0 && shard_len) {
+        rc = uaesk_ctr_xcrypt(stream, tb, nr, ek, &c, in, out, shard_len, nullptr);
+        if (rc) return rc;
+    }
     if (nv) {
         rc = run_ghash_levels(st, msg, nv, pl, sc, 2, sc + GS_PART, nullptr);
         if (rc) return rc;
     }
     hipLaunchKernelGGL(k_gcm_weight, dim3(1), dim3(64), 0, st, (const unsigned char *)sc, m_total - hi,
                        (u32)first, (u32)(nv == 0), (unsigned char *)partial16);
-    return (int)hipGetLastError();
+    rc = (int)hipGetLastError();
+    if (!rc && mode == 2 && shard_len)          /* behind the hash: the ciphertext may be overwritten now */
+        rc = uaesk_ctr_xcrypt(stream, tb, nr, ek, &c, in, out, shard_len, nullptr);
+    return rc;
+}
+
+extern "C" int uaesk_gcm_partial(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek,
+                                 const uint8_t *nonce12, const void *aad, uint64_t total_aad_len,
+                                 const void *ct_shard, size_t shard_len, uint64_t shard_offset,
+                                 uint64_t total_len, void *scratch, void *partial16)
+{
+    return uaesk_gcm_shard(stream, tb, nr, ek, 1, nonce12, aad, total_aad_len, ct_shard, shard_len, shard_offset,
+                           total_len, nullptr, scratch, partial16);
 }
 
 

@@ -1,0 +1,194 @@
+"""uaes_mgpu_gcm_encrypt / _decrypt and uaes_mgpu_ecb_*: the multi-GPU split performed by the C host (one process,
+N devices; SURVEY.md 8e, VERDICT r04 row e'').  Reference semantics: AES_GCM_encrypt / _decrypt micro_aes.c:1164-1212
+with gHash :1127-1137 (N4, N6, N7), AES_ECB_encrypt / _decrypt :636-680 (N1).
+
+A device list may name a device more than once, so {0}, {0,0,0} and {0} x 8 exercise the slicing, the per-slice
+counter offsets, the share exchange and the two-phase decryption on the one GPU of the test box; the variants on
+distinct devices skip below two GPUs.  Everything is compared with the oracle, with the single-call result and --
+at BASELINE configs[3]'s full size -- with the compiled reference's tag and digest (tests/golden/digests.json)."""
+import ctypes as C
+import hashlib
+import json
+import os
+import random
+
+import pytest
+
+import micro_aes_amd as uaes
+
+pytestmark = pytest.mark.gpu
+
+GIB = 1 << 30
+DEVLISTS = [[0], [0, 0, 0], [0] * 8]
+
+
+def _distinct_lists():
+    import torch
+    n = torch.cuda.device_count()
+    return [list(range(n)), list(range(n - 1, -1, -1)) + [0]] if n >= 2 else []
+
+
+# lengths around every boundary of the slicing: empty, shorter than the device list, ragged tails, one block per
+# device, a text whose slices take the striped one-pass kernel (>= 256 CUs x 2048 blocks each), ...
+LENS = [0, 1, 15, 16, 17, 47, 48, 127, 128, 129, 1000, 4096 + 5, 100003, (1 << 20) + 16 * 3 + 7]
+
+
+@pytest.mark.parametrize("devlist", DEVLISTS, ids=lambda d: "x".join(map(str, d)))
+def test_mgpu_gcm_matches_oracle_and_single_call(orc, devlist):
+    rnd = random.Random(500 + len(devlist))
+    for bits in (128, 192, 256):
+        key, nonce = rnd.randbytes(bits // 8), rnd.randbytes(12)
+        for n in LENS:
+            for aad in (b"", rnd.randbytes(1 + n % 41)):
+                pt = orc.splitmix(n + 7, n)
+                want = orc.gcm_encrypt(key, nonce, aad, pt)
+                got = uaes.mgpu_gcm_encrypt(devlist, key, nonce, aad, pt)
+                assert got == want, (bits, n, len(aad))
+                assert got == uaes.AES_GCM_encrypt(key, nonce, aad, pt)
+                rc, back = uaes.mgpu_gcm_decrypt(devlist, key, nonce, aad, got, prefill=0xAB)
+                assert rc == 0 and back == pt, (bits, n, len(aad))
+                # N7 across devices: a forged tag, a forged byte in any slice, forged AAD -> 0x1A, nothing written
+                bad = bytearray(got)
+                bad[rnd.randrange(len(bad))] ^= 1 << rnd.randrange(8)
+                rc, back = uaes.mgpu_gcm_decrypt(devlist, key, nonce, aad, bytes(bad), prefill=0xAB)
+                assert rc == uaes.M_AUTHENTICATION_ERROR and back == b"\xab" * n, (bits, n)
+                if aad:
+                    rc, back = uaes.mgpu_gcm_decrypt(devlist, key, nonce, aad[:-1] + bytes([aad[-1] ^ 0x80]), got, prefill=0xAB)
+                    assert rc == uaes.M_AUTHENTICATION_ERROR and back == b"\xab" * n
+
+
+def test_mgpu_gcm_nist_vectors_through_three_slices():
+    """the reference-held GcmEncryptExtIV*.rsp (the 375 cases per key size its own harness runs: 96-bit IV, 128-bit
+    tag, aes_testvectors_GCM.h:86) through uaes_mgpu_gcm_* on {0,0,0}"""
+    from tests.rsp import gcm_cases
+    for bits in (128, 192, 256):
+        cases = gcm_cases(bits)
+        assert len(cases) == 375
+        for v in cases:
+            pt, aad = v.get("PT", b""), v.get("AAD", b"")
+            got = uaes.mgpu_gcm_encrypt([0, 0, 0], v["Key"], v["IV"], aad, pt)
+            assert got == v.get("CT", b"") + v["Tag"][:16], (bits, v["Count"])
+            rc, back = uaes.mgpu_gcm_decrypt([0, 0, 0], v["Key"], v["IV"], aad, got)
+            assert rc == 0 and back == pt
+
+
+def test_mgpu_gcm_in_place_and_device_pointers(orc):
+    import torch
+    key, nonce, aad = bytes(range(32)), bytes(range(12)), b"associated"
+    n = (48 << 20) + 16 * 9 + 3      # {0,0,0}: 16 MiB slices, the striped one-pass kernel; {0} x 8: 6 MiB, the generic path
+    pt = orc.splitmix(77, n)
+    want = orc.gcm_encrypt(key, nonce, aad, pt)
+    # host, in place (the reference memcpy()s in -> out and works there, micro_aes.h:520-526)
+    L = uaes.engine()
+    buf = (C.c_uint8 * (n + 16)).from_buffer_copy(pt + bytes(16))
+    devs = (C.c_int * 3)(0, 0, 0)
+    assert L.uaes_mgpu_gcm_encrypt(3, devs, 256, key, nonce, aad, len(aad), buf, n, buf) == 0
+    assert bytes(buf) == want
+    assert L.uaes_mgpu_gcm_decrypt(3, devs, 256, key, nonce, aad, len(aad), buf, n, buf) == 0
+    assert bytes(buf)[:n] == pt
+    # device memory, out of place and in place; a forgery leaves the device buffer untouched too
+    src = torch.frombuffer(bytearray(pt), dtype=torch.uint8).to("cuda:0")
+    dst = torch.empty(n + 16, dtype=torch.uint8, device="cuda:0")
+    for devlist in ([0], [0, 0, 0], [0] * 8):
+        dst.zero_()
+        uaes.mgpu_gcm_dev(devlist, key, nonce, aad, src.data_ptr(), n, dst.data_ptr())
+        assert bytes(dst.cpu().numpy()) == want, devlist
+        back = torch.full((n,), 0xAB, dtype=torch.uint8, device="cuda:0")
+        assert uaes.mgpu_gcm_dev(devlist, key, nonce, aad, dst.data_ptr(), n, back.data_ptr(), decrypt=True) == 0
+        assert torch.equal(back, src)
+        dst[n // 2] ^= 4
+        back.fill_(0xAB)
+        assert uaes.mgpu_gcm_dev(devlist, key, nonce, aad, dst.data_ptr(), n, back.data_ptr(), decrypt=True) == uaes.M_AUTHENTICATION_ERROR
+        assert int((back != 0xAB).sum()) == 0
+    # one-pass decryption of device buffers: same plaintext; a forgery hands back zeros, never text
+    prev = L.uaes_set_gcm_one_pass_decrypt(1)
+    try:
+        dst.zero_()
+        uaes.mgpu_gcm_dev([0, 0, 0], key, nonce, aad, src.data_ptr(), n, dst.data_ptr())
+        back = torch.full((n,), 0xAB, dtype=torch.uint8, device="cuda:0")
+        assert uaes.mgpu_gcm_dev([0, 0, 0], key, nonce, aad, dst.data_ptr(), n, back.data_ptr(), decrypt=True) == 0
+        assert torch.equal(back, src)
+        dst[5] ^= 1
+        assert uaes.mgpu_gcm_dev([0, 0, 0], key, nonce, aad, dst.data_ptr(), n, back.data_ptr(), decrypt=True) == uaes.M_AUTHENTICATION_ERROR
+        assert int((back != 0).sum()) == 0
+    finally:
+        L.uaes_set_gcm_one_pass_decrypt(prev)
+
+
+def test_mgpu_gcm_C4_1GiB_in_eight_shards_matches_the_reference(golden_dir):
+    """BASELINE configs[3] (AES-128-GCM, 1 GiB, seed 4) cut into 8 slices by the C host: the reference's tag and
+    SHA-256(CT || tag); then N7 at full size -- a forged byte in the LAST slice leaves all eight untouched"""
+    import torch
+    import bench
+    with open(os.path.join(golden_dir, "digests.json")) as f:
+        want = json.load(f)["C4_gcm128_1GiB_seed4"]
+    dev = torch.device("cuda", 0)
+    key, nonce = bytes(range(16)), bytes(range(0xF0, 0xFC))
+    src = bench.splitmix_device(torch, 4, GIB, 0, dev)
+    dst = torch.empty(GIB + 16, dtype=torch.uint8, device=dev)
+    uaes.mgpu_gcm_dev([0] * 8, key, nonce, b"", src.data_ptr(), GIB, dst.data_ptr())
+    assert bytes(dst[GIB:].cpu().numpy()).hex() == want["tag"]
+    h = hashlib.sha256()
+    for o in range(0, GIB + 16, 1 << 28):
+        h.update(dst[o:o + (1 << 28)].cpu().numpy().tobytes())
+    assert h.hexdigest() == want["sha256_ct_tag"]
+    back = torch.full((GIB,), 0x5A, dtype=torch.uint8, device=dev)
+    assert uaes.mgpu_gcm_dev([0] * 8, key, nonce, b"", dst.data_ptr(), GIB, back.data_ptr(), decrypt=True) == 0
+    assert torch.equal(back, src)
+    back.fill_(0x5A)
+    dst[GIB - 3] ^= 0x10
+    assert uaes.mgpu_gcm_dev([0] * 8, key, nonce, b"", dst.data_ptr(), GIB, back.data_ptr(), decrypt=True) == uaes.M_AUTHENTICATION_ERROR
+    assert int((back != 0x5A).sum()) == 0
+
+
+@pytest.mark.parametrize("devlist", DEVLISTS, ids=lambda d: "x".join(map(str, d)))
+def test_mgpu_ecb_matches_oracle(orc, devlist):
+    rnd = random.Random(900 + len(devlist))
+    for bits in (128, 192, 256):
+        key = rnd.randbytes(bits // 8)
+        for n in (0, 1, 16, 20, 47, 48, 16 * 8, 16 * 8 + 5, 4096, 100003, (2 << 20) + 16 * 5 + 9):
+            pt = orc.splitmix(n + 3, n)
+            for padding in (0, 1, 2):
+                want = orc.ecb_encrypt(key, pt, padding)
+                got = uaes.mgpu_ecb_encrypt(devlist, key, pt, padding)
+                assert got == want, (bits, n, padding)
+            ct = orc.ecb_encrypt(key, pt)
+            rc, back = uaes.mgpu_ecb_decrypt(devlist, key, ct)
+            assert rc == 0 and back[:n] == pt
+            if n % 16:                                # N1: floor(len/16) blocks, 0x1D, the ragged tail passed through
+                rc, back = uaes.mgpu_ecb_decrypt(devlist, key, ct[:n])
+                rc1, back1 = uaes.AES_ECB_decrypt(key, ct[:n])
+                assert rc == uaes.M_DECRYPTION_ERROR == rc1 and back == back1
+
+
+def test_mgpu_argument_checks():
+    L = uaes.engine()
+    out = (C.c_uint8 * 64)()
+    bad = (C.c_int * 1)(99)
+    assert L.uaes_mgpu_gcm_encrypt(1, bad, 128, bytes(16), bytes(12), None, 0, b"x" * 16, 16, out) == -2
+    assert L.uaes_mgpu_gcm_encrypt(0, None, 128, bytes(16), bytes(12), None, 0, b"x" * 16, 16, out) == -2
+    assert L.uaes_mgpu_gcm_encrypt(1, None, 100, bytes(16), bytes(12), None, 0, b"x" * 16, 16, out) == -2
+    assert L.uaes_mgpu_gcm_decrypt(1, None, 128, bytes(16), None, None, 0, b"x" * 32, 16, out) == -2
+    assert L.uaes_mgpu_ecb_encrypt(1, None, 128, bytes(16), 3, b"x" * 16, 16, out) == -2
+    assert L.uaes_mgpu_ecb_decrypt(17, None, 128, bytes(16), b"x" * 16, 16, out) == -2
+
+
+def test_mgpu_gcm_and_ecb_on_distinct_devices(orc):
+    lists = _distinct_lists()
+    if not lists:
+        pytest.skip("needs 2 GPUs")
+    rnd = random.Random(4242)
+    key, nonce, aad = rnd.randbytes(16), rnd.randbytes(12), rnd.randbytes(33)
+    for devlist in lists:
+        for n in (0, 5, 100003, (40 << 20) + 11):
+            pt = orc.splitmix(n + 1, n)
+            want = orc.gcm_encrypt(key, nonce, aad, pt)
+            assert uaes.mgpu_gcm_encrypt(devlist, key, nonce, aad, pt) == want
+            rc, back = uaes.mgpu_gcm_decrypt(devlist, key, nonce, aad, want, prefill=0xAB)
+            assert rc == 0 and back == pt
+            if n:
+                bad = bytearray(want)
+                bad[n - 1] ^= 1
+                rc, back = uaes.mgpu_gcm_decrypt(devlist, key, nonce, aad, bytes(bad), prefill=0xAB)
+                assert rc == uaes.M_AUTHENTICATION_ERROR and back == b"\xab" * n
+            assert uaes.mgpu_ecb_encrypt(devlist, key, pt, 1) == orc.ecb_encrypt(key, pt, 1)
