@@ -23,8 +23,15 @@ serial chain with the reference's CPU loop beside it.
 After the K timed steps the same step runs back to back for --sustain-s seconds (default 2): `sustained` and
 `roofline.frac_sustained` ride next to `value`, never inside it.  With --gpus N the control plane is gloo; RCCL is
 brought up beside it, proven with a 16-byte all-gather and used only if every rank saw it work -- otherwise the run
-finishes on gloo and says so in `collective_backend` (setup_collectives).  --gather times the RCCL all-gather of the
-ciphertext, --c-gather additionally the C host's own uaes_mgpu_ctr_encrypt_gather on rank 0.
+finishes on gloo and says so in `collective_backend` (setup_collectives).
+
+With more than one rank the line also carries what SURVEY.md 8e lists beside the encrypt-only rate, all of it AFTER the
+timed steps and never part of `value`: `gather_ms` (the ciphertext all-gather: RCCL over xGMI, or -- when RCCL did not
+come up, e.g. the one-device dry run -- a gloo gather to rank 0), `encrypt_plus_gather_gib_s` (one step + the gather,
+end to end), `gathered_stream_digest_ok` (the concatenated stream against the reference's digests: every 1 GiB shard,
+and the whole 8 GiB C5 stream at N = 8) and `c_gather` (rank 0 alone runs the C host's uaes_mgpu_ctr_encrypt_gather
+over all N devices in ONE process).  Each runs under its own bounded wait and try/except: none of them can cost the
+line.  --no-gather / --no-c-gather switch them off.
 """
 import argparse
 import ctypes
@@ -274,6 +281,184 @@ def setup_collectives(a, torch, rank, world, local, dev):
     return dist, None, torch.device("cpu"), info
 
 
+def resolve_gather_flags(a, world):
+    """--gather / --c-gather default ON as soon as there is more than one rank (SURVEY.md 8e "what to report":
+    encrypt-only, encrypt + gather, bit-exactness of the concatenated stream), OFF for the one-GPU line"""
+    gather = (world > 1) if a.gather is None else bool(a.gather)
+    c_gather = (world > 1 and gather) if a.c_gather is None else bool(a.c_gather)
+    return gather, c_gather and gather
+
+
+def bounded(fn, wait_s):
+    """fn() in a daemon thread, waited for at most wait_s seconds: (result, error text or None, thread still alive).
+    Whatever a collective or the C host throws -- or if it never returns -- the caller gets an answer."""
+    import threading
+    state = {"res": None, "err": "no answer within %.0f s" % wait_s}
+
+    def run():
+        try:
+            state["res"] = fn()
+            state["err"] = None
+        except BaseException as e:                                  # noqa: BLE001
+            msg = str(e).splitlines()[0][:300] if str(e) else ""
+            state["err"] = "%s: %s" % (type(e).__name__, msg)
+
+    th = threading.Thread(target=run, daemon=True)
+    th.start()
+    th.join(wait_s)
+    alive = th.is_alive()
+    return (None if alive else state["res"]), (state["err"] if (alive or state["err"]) else None), alive
+
+
+def check_gathered_stream(torch, full, world, n, workload, seed, no_verify):
+    """rank 0: the concatenated ciphertext against the reference.  CTR at 1 GiB per rank: SHA-256 of every shard
+    against the reference's digest of that shard of the C5 stream and, at N = 8, of the whole 8 GiB stream
+    (BASELINE configs[4], tests/golden/digests.json).  Other sizes / workloads: the head of every shard against the
+    oracle at that shard's offset.  Returns a dict of fields for the line."""
+    if no_verify:
+        return {}
+    if workload == "ctr" and n == GIB and world <= 8:
+        with open(os.path.join(ROOT, "tests", "golden", "digests.json")) as f:
+            gold = json.load(f)
+        whole, ok, step = hashlib.sha256(), True, 1 << 28
+        for g in range(world):
+            h = hashlib.sha256()
+            for o in range(g * n, (g + 1) * n, step):
+                b = full[o:o + step].cpu().numpy().tobytes()
+                h.update(b)
+                whole.update(b)
+            ok = ok and h.hexdigest() == gold["C5_shard_%d" % g]["sha256"]
+        res = {"gathered_stream_digest_ok": ok,
+               "gathered_stream_check": "SHA-256 of each of the %d gathered 1 GiB shards against the reference's digest" % world}
+        if world == 8:
+            res["gathered_stream_digest_ok"] = ok and whole.hexdigest() == gold["C5_ctr128_8GiB_seed2"]["sha256"]
+            res["gathered_stream_check"] += " and of the whole 8 GiB stream against C5_ctr128_8GiB_seed2"
+        return res
+    if workload in ("ctr", "ecb", "xts"):
+        from oracle.pyoracle import Oracle
+        orc = Oracle()
+        m, ok = min(n, 1 << 16), True
+        for g in range(world):
+            head = orc.splitmix(seed, m, word0=g * (n // 8))
+            got = bytes(full[g * n:g * n + m].cpu().numpy())
+            if workload == "ctr":
+                ok = ok and got == orc.ctr_xcrypt_at(KEY16, CTR0, g * (n // 16), head)
+            elif workload == "ecb":
+                ok = ok and got == orc.ecb_encrypt(KEY16, head)
+            else:
+                ok = ok and got == orc.xts_sectors(KEY64, g * (n // 4096), 4096, head, True)[1]
+        return {"gathered_stream_digest_ok": ok,
+                "gathered_stream_check": "head (%d KiB) of each of the %d gathered shards against the oracle" % (m >> 10, world)}
+    return {}
+
+
+def gather_phase(a, torch, dist, cg, rank, world, local, n, dev, dst, step, seed):
+    """After the timed steps: the ciphertext gather, one encrypt + gather end to end, and the check of the
+    concatenated stream.  RCCL (all_gather_into_tensor over xGMI, every rank receives the stream) when it is up; else
+    a gloo gather to rank 0 through host memory in 64 MiB pieces -- the one-device dry run's stand-in, labelled as such.
+    Returns (fields for the line, RCCL still usable)."""
+    wait_s = float(os.environ.get("UAES_BENCH_GATHER_WAIT_S", "300"))
+    rccl = cg is not None
+
+    def run():
+        torch.cuda.set_device(local)
+        if rccl:
+            full = torch.empty(world * n, dtype=torch.uint8, device=dev)
+
+            def gather():
+                dist.all_gather_into_tensor(full, dst[:n], group=cg)
+                torch.cuda.synchronize()
+                dist.barrier(group=cg)
+        else:
+            chunk = min(n, 64 << 20)
+            full = torch.empty(world * n, dtype=torch.uint8, device=dev) if rank == 0 else None
+            host = torch.empty(chunk, dtype=torch.uint8).pin_memory()
+            recv = [torch.empty(chunk, dtype=torch.uint8) for _ in range(world)] if rank == 0 else None
+
+            def gather():
+                for o in range(0, n, chunk):
+                    m = min(chunk, n - o)
+                    host[:m].copy_(dst[o:o + m])
+                    dist.gather(host[:m], gather_list=[r[:m] for r in recv] if rank == 0 else None, dst=0)
+                    if rank == 0:
+                        for g in range(world):
+                            full[g * n + o:g * n + o + m].copy_(recv[g][:m])
+                torch.cuda.synchronize()
+                dist.barrier()
+        gather()                                                 # first use sets the channels up
+        g0 = time.perf_counter()
+        gather()
+        gather_ms = (time.perf_counter() - g0) * 1e3
+        e0 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        gather()
+        e2e_ms = (time.perf_counter() - e0) * 1e3
+        return full, gather_ms, e2e_ms
+
+    res, err, stuck = bounded(run, wait_s)
+    flag = torch.tensor([0 if err else 1], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)                  # gloo: did EVERY rank get through?
+    out = {}
+    if int(flag.item()) != 1:
+        out["gather"] = {"error": err or "another rank's gather failed", "stuck_thread": stuck}
+        # RCCL (if that is what carried it) is no longer trusted by ANY rank; tearing its group down could hang with
+        # a peer's stuck thread, so every rank leaves through os._exit once the line is out
+        return out, False, stuck or rccl
+    full, gather_ms, e2e_ms = res
+    out["gather_ms"] = round(gather_ms, 3)
+    out["gather_backend"] = ("RCCL all_gather_into_tensor over xGMI (every rank receives the whole stream)" if rccl else
+                             "gloo gather to rank 0 through host memory (RCCL not up: dry run, says nothing about xGMI)")
+    out["gather_gib_s"] = round(world * n / GIB / (gather_ms * 1e-3), 2)
+    out["encrypt_plus_gather_ms"] = round(e2e_ms, 3)
+    out["encrypt_plus_gather_gib_s"] = round(world * n / GIB / (e2e_ms * 1e-3), 2)
+    if rank == 0:
+        try:
+            out.update(check_gathered_stream(torch, full, world, n, a.workload, seed, a.no_verify))
+        except Exception as e:                                   # noqa: BLE001
+            out["gathered_stream_check"] = "failed: %s: %s" % (type(e).__name__, str(e)[:200])
+    del full
+    dist.barrier()                                               # gloo: the others wait for rank 0's hashing
+    return out, rccl, False
+
+
+def c_gather_phase(a, torch, uaes, rank, world, n, dev, src, dst, seed):
+    """rank 0 alone: the C host's own encrypt + gather (north_star: host code in C, RCCL only for the final ciphertext
+    gather) -- one process over all N devices, fresh shards generated on every device, timed end to end, twice."""
+    ndev = 1 if a.single_device else world
+    devs = [0] * world if a.single_device else list(range(world))
+    ins, outs, keep = (ctypes.c_void_p * world)(), (ctypes.c_void_p * world)(), []
+    for g, d in enumerate(devs):
+        dd = torch.device("cuda", d)
+        t_in = src if g == 0 else splitmix_device(torch, seed, n, g * (n // 8), dd)
+        t_out = torch.empty(n, dtype=torch.uint8, device=dd)
+        keep += [t_in, t_out]
+        ins[g], outs[g] = t_in.data_ptr(), t_out.data_ptr()
+    full = torch.empty(world * n, dtype=torch.uint8, device=dev)
+    for d in set(devs):
+        torch.cuda.synchronize(d)
+    times = []
+    for _ in range(2):
+        g0 = time.perf_counter()
+        rc = uaes.engine().uaes_mgpu_ctr_encrypt_gather(world, (ctypes.c_int * world)(*devs), 128, KEY16, CTR0, 0,
+                                                        ins, world * n, outs, 0, ctypes.c_void_p(full.data_ptr()))
+        for d in set(devs):
+            torch.cuda.synchronize(d)
+        times.append((time.perf_counter() - g0) * 1e3)
+        if rc != 0:
+            raise RuntimeError(uaes.engine().uaes_last_error().decode())
+    res = {"ms_first": round(times[0], 3), "ms": round(times[1], 3), "devices": ndev,
+           "gib_s_end_to_end": round(world * n / GIB / (times[1] * 1e-3), 1),
+           "call": "uaes_mgpu_ctr_encrypt_gather (C host, RCCL send/recv to device 0)"}
+    if not a.no_verify:
+        chk = check_gathered_stream(torch, full, world, n, "ctr", seed, False)
+        if "gathered_stream_digest_ok" in chk:
+            res["stream_digest_ok"] = chk["gathered_stream_digest_ok"]
+            res["stream_check"] = chk["gathered_stream_check"]
+        res["shard0_equals_own_step"] = bool(torch.equal(full[:n], dst[:n]))
+    return res
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, one per GPU, exactly as
     the documented command does (torch.distributed.run, rendezvous on 127.0.0.1, a free port), relay their
@@ -291,7 +476,7 @@ def self_launch(n):
     sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
-def main():
+def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -308,14 +493,23 @@ def main():
     ap.add_argument("--sustain-s", type=float, default=2.0,
                     help="after the K timed steps, seconds of the same step back to back (untimed for `value`) behind "
                          "`sustained` and roofline.frac_sustained; 0 = skip")
-    ap.add_argument("--gather", action="store_true", help="also time the RCCL ciphertext all-gather")
-    ap.add_argument("--c-gather", action="store_true",
-                    help="with --gather: rank 0 also runs uaes_mgpu_ctr_encrypt_gather -- the C host's own encrypt + RCCL "
-                         "gather over all N devices in ONE process (include/uaes_hip.h) -- while the other ranks wait")
+    ap.add_argument("--gather", dest="gather", action="store_true", default=None,
+                    help="after the timed steps: the ciphertext gather, encrypt + gather end to end and the digest of the "
+                         "concatenated stream (default: ON with more than one rank)")
+    ap.add_argument("--no-gather", dest="gather", action="store_false")
+    ap.add_argument("--c-gather", dest="c_gather", action="store_true", default=None,
+                    help="with the gather: rank 0 also runs uaes_mgpu_ctr_encrypt_gather -- the C host's own encrypt + RCCL "
+                         "gather over all N devices in ONE process (include/uaes_hip.h) -- while the other ranks wait "
+                         "(default: ON with more than one rank)")
+    ap.add_argument("--no-c-gather", dest="c_gather", action="store_false")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --single-device: dry-run the multi-rank code path on a 1-GPU box")
     ap.add_argument("--single-device", action="store_true", help="all ranks use cuda:0 (dry run only)")
-    a = ap.parse_args()
+    return ap
+
+
+def main():
+    a = build_parser().parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(a.gpus)
@@ -461,65 +655,26 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=cg)
         elapsed = float(t.item())
 
-    gather_ms, gathered_ok = None, None
-    if dist and a.gather and rccl_up:
-        full = torch.empty(world * n, dtype=torch.uint8, device=dev)
-        dist.all_gather_into_tensor(full, dst[:n], group=cg)
-        torch.cuda.synchronize()
-        dist.barrier(group=cg)
-        g0 = time.perf_counter()
-        dist.all_gather_into_tensor(full, dst[:n], group=cg)
-        torch.cuda.synchronize()
-        dist.barrier(group=cg)
-        gather_ms = (time.perf_counter() - g0) * 1e3
-        if rank == 0 and a.workload == "ctr" and n == GIB and world == 8 and not a.no_verify:
-            # BASELINE configs[4]: the concatenated 8 GiB stream against the reference's digest (C5)
-            with open(os.path.join(ROOT, "tests", "golden", "digests.json")) as f:
-                gathered_ok = sha_of(full) == json.load(f)["C5_ctr128_8GiB_seed2"]["sha256"]
-        del full
-
-    # the C host's own gather (north_star: host code in C, RCCL only for the final ciphertext gather): rank 0 alone, one
-    # process over all N devices, fresh shards generated on every device; timed end to end (encrypt + gather), twice
-    c_gather = None
-    if a.gather and a.c_gather and a.workload == "ctr":
+    # ---- beside the encrypt-only rate: gather, encrypt + gather, the concatenated stream, the C host's
+    # own gather.  After the timed region, each under a bounded wait; a failure becomes a field of the line.
+    want_gather, want_c_gather = resolve_gather_flags(a, world)
+    gather_info, c_gather, stuck_extra = {}, None, False
+    if dist and want_gather:
+        try:
+            gather_info, still_rccl, stuck_extra = gather_phase(a, torch, dist, cg, rank, world, local, n, dev, dst, step, seed)
+        except Exception as e:                                  # noqa: BLE001 -- the bench line must survive
+            gather_info, still_rccl = {"gather": {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}}, False
+        if cg is not None and not still_rccl and "gather" in gather_info:
+            cg, cdev = None, torch.device("cpu")                # RCCL misbehaved: the remaining reductions go over gloo
+            coll_info["collective_backend"] += "; gloo after the gather failed"
+    if want_gather and want_c_gather and a.workload == "ctr" and world > 1:
         if rank == 0:
-            try:
-                ndev = 1 if a.single_device else world
-                devs = [0] * world if a.single_device else list(range(world))
-                ins, outs, keep = (ctypes.c_void_p * world)(), (ctypes.c_void_p * world)(), []
-                for g, d in enumerate(devs):
-                    dd = torch.device("cuda", d)
-                    t_in = src if g == 0 else splitmix_device(torch, seed, n, g * (n // 8), dd)
-                    t_out = torch.empty(n, dtype=torch.uint8, device=dd)
-                    keep += [t_in, t_out]
-                    ins[g], outs[g] = t_in.data_ptr(), t_out.data_ptr()
-                full = torch.empty(world * n, dtype=torch.uint8, device=dev)
-                for d in set(devs):
-                    torch.cuda.synchronize(d)
-                times = []
-                for _ in range(2):
-                    g0 = time.perf_counter()
-                    rc = uaes.engine().uaes_mgpu_ctr_encrypt_gather(world, (ctypes.c_int * world)(*devs), 128, KEY16, CTR0, 0,
-                                                                    ins, world * n, outs, 0, ctypes.c_void_p(full.data_ptr()))
-                    for d in set(devs):
-                        torch.cuda.synchronize(d)
-                    times.append((time.perf_counter() - g0) * 1e3)
-                    if rc != 0:
-                        raise RuntimeError(uaes.engine().uaes_last_error().decode())
-                c_gather = {"ms_first": round(times[0], 3), "ms": round(times[1], 3), "devices": ndev,
-                            "gib_s_end_to_end": round(world * n / GIB / (times[1] * 1e-3), 1),
-                            "call": "uaes_mgpu_ctr_encrypt_gather (C host, RCCL send/recv to device 0)"}
-                if not a.no_verify:
-                    if n == GIB and world == 8:
-                        with open(os.path.join(ROOT, "tests", "golden", "digests.json")) as f:
-                            c_gather["stream_digest_ok"] = sha_of(full) == json.load(f)["C5_ctr128_8GiB_seed2"]["sha256"]
-                    else:        # shard 0 of the gathered text is what this rank's own timed step wrote
-                        c_gather["shard0_equals_own_step"] = bool(torch.equal(full[:n], dst[:n]))
-                del full, keep
-            except Exception as e:                          # noqa: BLE001 -- the bench line must survive
-                c_gather = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+            res, err, stuck = bounded(lambda: c_gather_phase(a, torch, uaes, rank, world, n, dev, src, dst, seed),
+                                      float(os.environ.get("UAES_BENCH_CGATHER_WAIT_S", "300")))
+            c_gather = res if err is None else {"error": err, "stuck_thread": stuck}
+            stuck_extra = stuck_extra or stuck
         if dist:
-            dist.barrier(group=cg)
+            dist.barrier()                                      # gloo (the default group)
 
     # measured HBM stream-copy ceiling on this GPU (read n + write n), for context next to the 8 TB/s spec
     copy_gbs = None
@@ -683,10 +838,7 @@ def main():
                                  "note": "the same step back to back after the K timed steps; not part of `value`"}
             line["roofline"]["frac_sustained"] = round(2.0 * n / (sustained["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         line.update(coll_info)
-        if gather_ms is not None:
-            line["gather_ms"] = round(gather_ms, 3)
-        if gathered_ok is not None:
-            line["gathered_stream_digest_ok"] = gathered_ok
+        line.update(gather_info)
         if c_gather is not None:
             line["c_gather"] = c_gather
         if not a.no_cpu and world == 1:
@@ -694,7 +846,7 @@ def main():
         print(json.dumps(line))
     if dist:
         sys.stdout.flush()
-        if coll_info.get("rccl_stuck_thread"):
+        if coll_info.get("rccl_stuck_thread") or stuck_extra:
             os._exit(0)                         # a thread still inside RCCL: tearing the groups down could hang with it
         dist.destroy_process_group()
 

@@ -181,11 +181,14 @@ def test_bench_two_ranks_survive_an_rccl_failure():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env.update(UAES_BENCH_FORCE_NCCL_FAIL="1", UAES_BENCH_RCCL_WAIT_S="30")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--single-device", "--bytes", str(64 << 20), "--settle-ms", "0", "--sustain-s", "0.2", "--gather", "--c-gather"]
+           "--single-device", "--bytes", str(64 << 20), "--settle-ms", "0", "--sustain-s", "0.2"]      # gather + C gather: defaults
     line = _one_json_line(subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900))
     assert line["n_gpus"] == 2 and line["verified"] is True and line["value"] > 0
     assert line["collective_backend"].startswith("gloo (nccl init failed: RuntimeError: forced by"), line["collective_backend"]
-    assert "gather_ms" not in line                       # the torch.distributed gather is RCCL-only
+    # without RCCL the ciphertext gather goes to rank 0 over gloo (the dry run's stand-in) and says so; the
+    # concatenated stream is checked shard by shard
+    assert line["gather_ms"] > 0 and line["gather_backend"].startswith("gloo gather to rank 0")
+    assert line["encrypt_plus_gather_gib_s"] > 0 and line["gathered_stream_digest_ok"] is True
     # the C host's gather needs no RCCL when every shard sits on the root's device: it ran, and shard 0 is the step's output
     assert line["c_gather"].get("shard0_equals_own_step") is True, line["c_gather"]
     assert line["sustained"]["value"] > 0
@@ -201,3 +204,19 @@ def test_bench_two_ranks_real_rccl_bring_up_on_one_device():
     line = _one_json_line(subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900))
     assert line["n_gpus"] == 2 and line["verified"] is True
     assert line["collective_backend"].startswith(("gloo (nccl init failed", "nccl (RCCL)")), line["collective_backend"]
+
+
+def test_bench_eight_ranks_flagless_dry_run_reports_everything_8e_lists():
+    """the driver's multi-GPU command carries no flag but --gpus/--steps/--warmup.  Eight ranks on this
+    box's one GPU (--single-device is the only addition): the line must hold the gather, encrypt + gather, the digest of
+    the concatenated 8 GiB stream against the reference's C5 digest, and the C host's own gather with the same digest --
+    RCCL refuses eight ranks on one device, so the collective is the labelled gloo stand-in here."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(UAES_BENCH_RCCL_WAIT_S="60")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--single-device"]
+    line = _one_json_line(subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200))
+    assert line["n_gpus"] == 8 and line["verified"] is True and line["config"]["bytes_per_gpu"] == GIB
+    assert line["gather_ms"] > 0 and line["encrypt_plus_gather_gib_s"] > 0
+    assert line["gathered_stream_digest_ok"] is True and "whole 8 GiB stream" in line["gathered_stream_check"]
+    cg = line["c_gather"]
+    assert cg.get("stream_digest_ok") is True and cg["shard0_equals_own_step"] is True and cg["ms"] > 0, cg

@@ -199,6 +199,32 @@ def test_bench_self_launch_command(monkeypatch):
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
 
 
+def test_bench_reports_the_gather_by_default_with_more_than_one_rank():
+    """the driver's command is `bench.py --gpus N --steps K --warmup W` and nothing else -- with N > 1
+    that alone must produce everything SURVEY.md 8e lists (gather, encrypt + gather, the digest of the concatenated
+    stream, the C host's own gather); the one-GPU line stays as it is; --no-gather / --no-c-gather opt out"""
+    import bench
+    ap = bench.build_parser()
+    a = ap.parse_args(["--gpus", "8", "--steps", "20", "--warmup", "3"])
+    assert a.gather is None and a.c_gather is None
+    assert bench.resolve_gather_flags(a, 8) == (True, True)
+    assert bench.resolve_gather_flags(a, 2) == (True, True)
+    assert bench.resolve_gather_flags(ap.parse_args([]), 1) == (False, False)
+    assert bench.resolve_gather_flags(ap.parse_args(["--gpus", "8", "--no-gather"]), 8) == (False, False)
+    assert bench.resolve_gather_flags(ap.parse_args(["--gpus", "8", "--no-c-gather"]), 8) == (True, False)
+    assert bench.resolve_gather_flags(ap.parse_args(["--gather", "--c-gather"]), 1) == (True, True)
+
+
+def test_bench_bounded_wait_returns_an_answer_whatever_happens():
+    import time
+    import bench
+    assert bench.bounded(lambda: 41 + 1, 5) == (42, None, False)
+    res, err, alive = bench.bounded(lambda: 1 / 0, 5)
+    assert res is None and err.startswith("ZeroDivisionError") and not alive
+    res, err, alive = bench.bounded(lambda: time.sleep(3), 0.2)
+    assert res is None and err.startswith("no answer within") and alive
+
+
 def _collectives_worker(rank, world, port, q):
     """bench.setup_collectives without a GPU: the RCCL bring-up cannot work here (no device), so every rank must
     agree on the gloo fallback -- with the reason in `collective_backend` -- and the group handed back must work"""
