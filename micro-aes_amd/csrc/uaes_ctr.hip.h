@@ -232,11 +232,6 @@ __device__ __forceinline__ void ctr_shared_loop(const uaesk_rk &rk, const uaesk_
                 d_nxt[u] = make_uint4(v.x, v.y, v.z, v.w);
             }
 #endif
-#ifdef UAES_CTR_NOLOAD                   /* timing-only build (wrong results): what do the text loads cost in cycles? */
-            (void)gn;
-#pragma unroll
-            for (int u = 0; u < 2; ++u) d_nxt[u] = make_uint4(lane, wave, (u32)it, u);
-#endif
         }
 
         u32 s[2][4];
@@ -263,32 +258,19 @@ __device__ __forceinline__ void ctr_shared_loop(const uaesk_rk &rk, const uaesk_
 #endif
         enc_rounds_skewed<NR, 3, decltype(rkv), false, LC, FOLD::round_prio>(s[0], s[1], rkv, lc);
         uint4 ct[2];
-#ifdef UAES_CTR_BUFFER_ST                 /* experiment only, see below */
-        const __amdgpu_buffer_rsrc_t rout = STRIPE_RSRC(out + ((g0 << 8) - c0));
-#endif
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             ct[u] = make_uint4(d_cur[u].x ^ s[u][0], d_cur[u].y ^ s[u][1], d_cur[u].z ^ s[u][2], d_cur[u].w ^ s[u][3]);
-#ifdef UAES_CTR_NOSTORE                  /* timing-only build: keep the value alive, store (almost) never */
-            if (ct[u].x == 0x12345678u && ct[u].y == 0x9abcdef0u && ct[u].z == it)
-#endif
-#if !defined(UAES_CTR_BUFFER_ST)
             /* the ciphertext goes out through a plain global pointer, NOT through a buffer resource like the loads:
              * `buffer_store_dwordx4 v[a:a+3], voff, s[rsrc], s_off offen` followed at once by a VALU write to v[a..a+3]
              * stores garbage for some lanes on gfx950 (seen in the one-pass GCM decrypt, whose GHASH selects reuse the
              * registers of the second store: ~1 % of the blocks came out as the selects' zeros, different ones every run,
              * profiles/r04_buffer_store_hazard.log).  The ISA manuals list that hazard -- store data of more than 64 bits,
              * then a VALU write of the data registers: 1 wait state -- with the exception "not if SOFFSET is an SGPR",
-             * and the compiler's hazard recogniser follows them; for global_store it always inserts the wait state. */
+             * and the compiler's hazard recogniser follows them; for global_store it always inserts the wait state.
+             * (The store path that reproduces it, and the timing-only builds without loads / stores, are a patch for the
+             * measuring tools: tools/experiments/ctr_measurement_switches.patch.)                                      */
             (out + (((g0 + 4u * u) << 8) - c0))[lane_blk] = ct[u];
-#else
-            __builtin_amdgcn_raw_buffer_store_b128((u32x4){ct[u].x, ct[u].y, ct[u].z, ct[u].w}, rout, lane_byte, 16384 * u, 0);
-#ifdef UAES_CTR_STORE_NOP
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_nop 1");
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-#endif
         }
         if (FOLD::of_input) fold(d_cur[0], d_cur[1]); else fold(ct[0], ct[1]);
     };
@@ -298,7 +280,9 @@ __device__ __forceinline__ void ctr_shared_loop(const uaesk_rk &rk, const uaesk_
 #if defined(UAES_CTR_NO_EXPAND2) || defined(UAES_ASM_VARIANT)
     /* measurement builds.  The hand-scheduled round blocks (UAES_ASM_VARIANT, tools/gen_rounds_asm.py) are bit-exact
      * with the body once per trip; with TWO >100-operand asm statements per trip the build's output is wrong and varies
-     * from run to run (profiles/r04_ctr_asm_variants_ab.log, third table) -- not understood, so not allowed.          */
+     * from run to run (profiles/r04_ctr_asm_variants_ab.log, third table): the second statement's clobbers land right
+     * behind the first body's 128-bit store, the buffer_store / VALU-write hazard described at the store above
+     *  -- so the asm variants run the body once per trip.                                          */
     constexpr bool twice = false;
 #else
     constexpr bool twice = FOLD::expand2;

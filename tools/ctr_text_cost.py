@@ -2,6 +2,8 @@
 """What do the text loads and stores cost the CTR kernel in CYCLES?  Timing-only builds of the library
 (-DUAES_CTR_NOLOAD, -DUAES_CTR_NOSTORE, both: wrong results by construction) against the product build, with
 UAES_CTR_GRID=128 -- at 128 CUs the chip is not power-capped (2.38 GHz), so time is cycles -- and at the full grid.
+The switches are not in the product source: `git apply tools/experiments/ctr_measurement_switches.patch` first (and
+`git apply -R` it afterwards).
     cd micro-aes_amd/csrc; for v in NOLOAD NOSTORE "NOLOAD -DUAES_CTR_NOSTORE"; do touch uaes_ctr.hip.h; make XFLAGS=-DUAES_CTR_$v; cp ../lib/libuaes_hip.so ../lib/libuaes_hip_<name>.so; done"""
 import os, subprocess, sys
 CHILD = r'''
