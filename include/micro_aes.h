@@ -331,6 +331,13 @@ void AES_CMAC(const uint8_t *key,
 typedef void (*uaes_failure_handler)(const char *fn, int rc, const char *msg);
 uaes_failure_handler uaes_compat_set_failure_handler(uaes_failure_handler h);
 
+/* Not in the reference either: DEVICE pointers are accepted wherever the reference takes a buffer.  A call first waits
+ * for the work the caller may have in flight on the default stream; a caller that produces its data on a stream of
+ * its own (hipStreamNonBlocking streams do not synchronise with the default one) names that stream here, per thread
+ * (a hipStream_t; NULL = the default stream again).  Long HOST buffers can be spread over several GPUs without a
+ * change in the caller: environment variable UAES_DEVICES=all | 0,1,... (include/uaes_hip.h, uaes_set_devices).   */
+void uaes_compat_set_producer_stream(void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -306,6 +306,10 @@ void uaes_gcm_stream_abort(uaes_gcm_stream *s);
  * flight on the default stream (hipStreamSynchronize(NULL)), then runs on the calling thread's own
  * stream and returns when it is done -- the ordering a default-stream launch used to give.        */
 
+/* ... or, when the caller's device data is produced on a stream of its own (one made with hipStreamNonBlocking does
+ * not synchronise with the default stream), for the stream named here.  Thread-local; NULL = the default stream.  */
+int uaes_set_producer_stream(void *stream);
+
 /* ---- asynchronous, device-resident variants -----------------------------
  * All data pointers are device pointers, 16-byte aligned; `stream` is a
  * hipStream_t (NULL = default stream).  The call only enqueues work.  Scratch
@@ -446,6 +450,15 @@ int uaes_mgpu_gcm_encrypt(int ndev, const int *devices, int keybits, const uint8
                           const void *aData, size_t aDataLen, const void *pntxt, size_t ptextLen, void *crtxt);
 int uaes_mgpu_gcm_decrypt(int ndev, const int *devices, int keybits, const uint8_t *key, const uint8_t *nonce,
                           const void *aData, size_t aDataLen, const void *crtxt, size_t crtxtLen, void *pntxt);
+
+/* The same split WITHOUT a change in the caller: with a device list configured -- here, or by the environment
+ * variable UAES_DEVICES=all | 0,1,2,... read at first use -- the synchronous uaes_ecb_* / uaes_ctr_xcrypt* /
+ * uaes_xts_sectors / uaes_gcm_encrypt / uaes_gcm_decrypt calls (and so the AES_* symbols of include/micro_aes.h) hand
+ * a text that lies in HOST memory and is at least min_bytes long (UAES_DEVICES_MIN_MIB, default 64 MiB) to the
+ * uaes_mgpu_* functions above, every device staging its slice over its own PCIe link; the bytes produced are the
+ * one-device call's.  ndev = 0 switches it off (the default), -1 = every visible device, devices NULL = 0..ndev-1,
+ * min_bytes 0 = keep the threshold.  Device-pointer calls and short texts are never split.                       */
+int uaes_set_devices(int ndev, const int *devices, size_t min_bytes);
 
 /* BASELINE configs[4] in one call: the plaintext lies sharded over ndev GPUs (d_in[i] on devices[i] holds the slice
  * uaes_mgpu_ctr_xcrypt_at would give device i: blocks [B*i/ndev, B*(i+1)/ndev) of the B = ceil(len/16) blocks), every

@@ -43,6 +43,7 @@ EXPORTS = [
     "uaes_ocb_encrypt", "uaes_ocb_decrypt", "uaes_ocb_dev",
     "uaes_mgpu_ctr_xcrypt_at", "uaes_mgpu_xts_sectors", "uaes_mgpu_ctr_encrypt_gather",
     "uaes_mgpu_ecb_encrypt", "uaes_mgpu_ecb_decrypt", "uaes_mgpu_gcm_encrypt", "uaes_mgpu_gcm_decrypt",
+    "uaes_set_devices", "uaes_set_producer_stream",
     "uaes_gcm_key_new", "uaes_gcm_key_free", "uaes_gcm_key_encrypt", "uaes_gcm_key_decrypt",
     "uaes_gcm_key_encrypt_dev", "uaes_gcm_key_decrypt_dev",
     "uaes_gcm_record_max", "uaes_gcm_key_encrypt_records", "uaes_gcm_key_decrypt_records",
@@ -58,7 +59,7 @@ COMPAT_EXPORTS = [
     "AES_ECB_encrypt", "AES_ECB_encrypt_pkcs7", "AES_ECB_encrypt_iso7816", "AES_ECB_decrypt",
     "AES_CTR_encrypt", "AES_CTR_decrypt", "AES_CTR_encrypt_preset", "AES_CTR_decrypt_preset", "AES_CTR_encrypt_iv",
     "AES_CBC_encrypt_nocts", "AES_CBC_encrypt_nocts_pkcs7", "AES_CBC_encrypt_nocts_iso7816", "AES_CBC_decrypt_nocts",
-    "uaes_compat_set_failure_handler",
+    "uaes_compat_set_failure_handler", "uaes_compat_set_producer_stream",
     "AES_XTS_encrypt", "AES_XTS_decrypt", "AES_GCM_encrypt", "AES_GCM_decrypt",
     "AES_GCM_encrypt_ivlen", "AES_GCM_decrypt_ivlen", "AES_GCM_encrypt_lens", "AES_GCM_decrypt_lens",
     "AES_CCM_encrypt_lens", "AES_CCM_decrypt_lens", "AES_OCB_encrypt_lens", "AES_OCB_decrypt_lens",
@@ -145,6 +146,8 @@ def engine():
     L.uaes_mgpu_ecb_decrypt.argtypes = [i, C.POINTER(C.c_int), i, vp, vp, sz, vp]
     for n in ("uaes_mgpu_gcm_encrypt", "uaes_mgpu_gcm_decrypt"):
         getattr(L, n).argtypes = [i, C.POINTER(C.c_int), i, vp, vp, vp, sz, vp, sz, vp]
+    L.uaes_set_devices.argtypes = [i, C.POINTER(C.c_int), sz]
+    L.uaes_set_producer_stream.argtypes = [vp]
     L.uaes_gcm_key_new.argtypes = [C.POINTER(vp), i, vp]
     L.uaes_gcm_key_free.argtypes = [vp]
     L.uaes_gcm_key_free.restype = None

@@ -33,6 +33,11 @@ uaes_failure_handler uaes_compat_set_failure_handler(uaes_failure_handler h)
     return old == default_failure ? NULL : old;
 }
 
+void uaes_compat_set_producer_stream(void *stream)
+{
+    (void)uaes_set_producer_stream(stream);
+}
+
 static void must(const char *fn, int rc)
 {
     if (rc == 0) return;

@@ -684,10 +684,91 @@ static int is_device_ptr(const void *p)
 /* A caller that hands the synchronous API DEVICE memory may have produced it with work still in
  * flight on the default stream (or streams that synchronise with it) -- the lane's stream is
  * non-blocking and would not wait for that by itself.                                        */
+static __thread void *tls_producer_stream;      /* uaes_set_producer_stream(): NULL = the default stream */
+
 static int wait_for_callers_device_work(void)
 {
-    HIPCHK(hipStreamSynchronize(NULL));
+    HIPCHK(hipStreamSynchronize((hipStream_t)tls_producer_stream));
     return 0;
+}
+
+/* A caller whose device-resident input is produced on a stream of its own -- one created with hipStreamNonBlocking does
+ * not synchronise with the default stream -- names it here (thread-local): every later synchronous call of this thread
+ * that is handed device memory waits for THAT stream before it reads.  NULL = the default stream again.           */
+int uaes_set_producer_stream(void *stream)
+{
+    tls_producer_stream = stream;
+    return 0;
+}
+
+/* ---- long HOST texts over several GPUs without a change in the caller (UAES_DEVICES / uaes_set_devices) ----------
+ * The reference's callers pass host pointers (micro_aes.h:173-181, :239-249, :256-266, :294-308) and one GPU's PCIe
+ * link carries 25-33 GiB/s of such a text.  With a device list configured, the synchronous
+ * ECB / CTR / XTS-sector / GCM calls hand a host text of at least min_bytes to the uaes_mgpu_* split, every device
+ * staging its slice over its own link; results are bit-identical (the slices carry their counter / sector offsets and
+ * GCM's shares are XORed on the host).  Off by default.  The workers of uaes_mgpu_* call the same entry points for
+ * their slices: they are marked so that a slice is never split again.                                             */
+static struct {
+    int n, devs[MAX_DEVICES];
+    size_t min_bytes;
+    pthread_mutex_t mu;
+} g_auto = { 0, { 0 }, (size_t)64 << 20, PTHREAD_MUTEX_INITIALIZER };
+static __thread int tls_is_mgpu_worker;
+
+int uaes_set_devices(int ndev, const int *devices, size_t min_bytes)
+{
+    int i, avail = 0;
+    if (ndev < -1 || ndev > MAX_DEVICES) return fail(UAES_E_ARG, "ndev must be -1 (all visible), 0 (off) or 1..%d", MAX_DEVICES);
+    if (ndev != 0 && (hipGetDeviceCount(&avail) != hipSuccess || avail <= 0))
+        return fail(UAES_E_HIP, "no usable HIP device; this library has no CPU path");
+    if (ndev == -1) ndev = avail > MAX_DEVICES ? MAX_DEVICES : avail, devices = NULL;
+    for (i = 0; i < ndev; ++i) {
+        const int d = devices ? devices[i] : i;
+        if (d < 0 || d >= avail || d >= MAX_DEVICES) return fail(UAES_E_ARG, "device %d is not one of the %d visible", d, avail);
+    }
+    pthread_mutex_lock(&g_auto.mu);
+    g_auto.n = ndev;
+    for (i = 0; i < ndev; ++i) g_auto.devs[i] = devices ? devices[i] : i;
+    if (min_bytes) g_auto.min_bytes = min_bytes;
+    pthread_mutex_unlock(&g_auto.mu);
+    return 0;
+}
+
+static void auto_devices_from_env(void)          /* once, from env_init() */
+{
+    const char *e = getenv("UAES_DEVICES"), *m = getenv("UAES_DEVICES_MIN_MIB");
+    int devs[MAX_DEVICES], n = 0;
+    if (m && *m) { long v = strtol(m, NULL, 10); if (v >= 0) g_auto.min_bytes = v ? (size_t)v << 20 : 1; }
+    if (!e || !*e) return;
+    if (strcmp(e, "all") == 0) {
+        if (uaes_set_devices(-1, NULL, 0) != 0) fprintf(stderr, "uaes-hip: UAES_DEVICES=all ignored: %s\n", uaes_last_error());
+        return;
+    }
+    while (*e && n < MAX_DEVICES) {
+        char *end = NULL;
+        long v = strtol(e, &end, 10);
+        if (end == e) break;
+        devs[n++] = (int)v;
+        e = end;
+        while (*e == ',' || *e == ' ') ++e;
+    }
+    if (*e || n == 0 || uaes_set_devices(n, devs, 0) != 0)
+        fprintf(stderr, "uaes-hip: UAES_DEVICES ignored (a comma-separated list of visible device ordinals, or \"all\")\n");
+}
+
+/* > 1: split this call over devs[0..n); 0: run it on the current device as always */
+static int auto_devices(const void *in, const void *out, size_t len, int *devs)
+{
+    int n;
+    if (tls_is_mgpu_worker) return 0;
+    env_ready();
+    if (g_auto.n < 2 || len < g_auto.min_bytes) return 0;
+    if (is_device_ptr(in) || is_device_ptr(out)) return 0;
+    pthread_mutex_lock(&g_auto.mu);
+    n = g_auto.n;
+    memcpy(devs, g_auto.devs, sizeof g_auto.devs);
+    pthread_mutex_unlock(&g_auto.mu);
+    return n < 2 ? 0 : n;
 }
 
 /* Resolve (in, out) to device pointers, staging whatever is host memory or
@@ -888,6 +969,7 @@ static void env_init(void)
     g_env.zero_copy_max = (size_t)env_int("UAES_ZEROCOPY_MAX_KIB", 1024, 0, (int)(g_env.pin_bytes >> 10)) << 10;
     g_env.pipe_workers = env_int("UAES_PIPE_WORKERS", 4, 1, PIPE_MAXW);
     g_env.pipe_slice = (size_t)env_int("UAES_PIPE_SLICE_MIB", 16, 1, 1024) << 20;
+    auto_devices_from_env();
 }
 
 static int pipe_workers(void)
@@ -1138,6 +1220,12 @@ static int ecb_common(int keybits, const uint8_t *key, int decrypt, int padding,
     if (padding < 0 || padding > 2) return fail(UAES_E_ARG, "padding must be 0 (zeros), 1 (PKCS#7) or 2 (ISO/IEC 7816-4)");
     if (out_len == 0) return 0;
     if ((len && !in) || !out) return fail(UAES_E_ARG, "NULL data pointer");
+    {
+        int devs[MAX_DEVICES];
+        const int nd = auto_devices(in, out, len, devs);
+        if (nd) return decrypt ? uaes_mgpu_ecb_decrypt(nd, devs, keybits, key, in, len, out)
+                               : uaes_mgpu_ecb_encrypt(nd, devs, keybits, key, padding, in, len, out);
+    }
     if ((rc = enter(&c, &L)) != 0) return rc;
     do {
         ecb_pipe_arg pa;
@@ -1250,6 +1338,11 @@ int uaes_ctr_xcrypt_at(int keybits, const uint8_t *key, const uint8_t ctr0[16],
     if (!ctr0) return fail(UAES_E_ARG, "NULL counter block");
     if (len == 0) return 0;
     if (!in || !out) return fail(UAES_E_ARG, "NULL data pointer");
+    {
+        int devs[MAX_DEVICES];
+        const int nd = auto_devices(in, out, len, devs);
+        if (nd) return uaes_mgpu_ctr_xcrypt_at(nd, devs, keybits, key, ctr0, block_offset, in, len, out);
+    }
     if ((rc = enter(&c, &L)) != 0) return rc;
     make_ctr(&ctr, ctr0, block_offset);
     do {
@@ -1349,6 +1442,11 @@ static int xts_common(int keybits, const uint8_t *keys, const uint8_t *tweak, in
     if (sector_bytes < 16) return UAES_E_DATALENGTH;             /* :1069, untouched */
     if (nsectors == 0) return 0;
     if (!in || !out) return fail(UAES_E_ARG, "NULL data pointer");
+    if (!raw_tweak && nsectors > 1) {
+        int devs[MAX_DEVICES];
+        const int nd = auto_devices(in, out, total, devs);
+        if (nd) return uaes_mgpu_xts_sectors(nd, devs, keybits, keys, first_sector, sector_bytes, nsectors, in, out, encrypt);
+    }
     if ((rc = enter(&c, &L)) != 0) return rc;
     do {
         xts_pipe_arg pa;
@@ -1478,6 +1576,11 @@ int uaes_gcm_encrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, s
     if ((rc = expand_key(&ks, key, keybits)) != 0) return rc;
     if (!nonce || !crtxt || (ptextLen && !pntxt)) return fail(UAES_E_ARG, "NULL pointer");
     if (tagLen < 1 || tagLen > 16) return fail(UAES_E_ARG, "GCM tag length %zu (1..16)", tagLen);
+    if (nonceLen == 12 && tagLen == 16) {
+        int devs[MAX_DEVICES];
+        const int nd = auto_devices(pntxt, crtxt, ptextLen, devs);
+        if (nd) return uaes_mgpu_gcm_encrypt(nd, devs, keybits, key, nonce, aData, aDataLen, pntxt, ptextLen, crtxt);
+    }
     if ((rc = enter(&c, &L)) != 0) return rc;
     do {
         if ((rc = gcm_scratch(L)) != 0) break;
@@ -1528,6 +1631,11 @@ int uaes_gcm_decrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, s
     if ((rc = expand_key(&ks, key, keybits)) != 0) return rc;
     if (!nonce || !crtxt || (crtxtLen && !pntxt)) return fail(UAES_E_ARG, "NULL pointer");
     if (tagLen < 1 || tagLen > 16) return fail(UAES_E_ARG, "GCM tag length %zu (1..16)", tagLen);
+    if (nonceLen == 12 && tagLen == 16) {
+        int devs[MAX_DEVICES];
+        const int nd = auto_devices(crtxt, pntxt, crtxtLen, devs);
+        if (nd) return uaes_mgpu_gcm_decrypt(nd, devs, keybits, key, nonce, aData, aDataLen, crtxt, crtxtLen, pntxt);
+    }
     if ((rc = enter(&c, &L)) != 0) return rc;
     do {
         if ((rc = gcm_scratch(L)) != 0) break;
@@ -2903,6 +3011,7 @@ static pthread_mutex_t g_mgpu_start_mu = PTHREAD_MUTEX_INITIALIZER;
 static void *mgpu_pool_thread(void *arg)
 {
     const int d = (int)(intptr_t)arg;
+    tls_is_mgpu_worker = 1;                          /* a slice is never split again (auto_devices) */
     for (;;) {
         mgpu_item *it;
         pthread_mutex_lock(&g_mgpu[d].mu);

@@ -192,3 +192,115 @@ def test_mgpu_gcm_and_ecb_on_distinct_devices(orc):
                 rc, back = uaes.mgpu_gcm_decrypt(devlist, key, nonce, aad, bytes(bad), prefill=0xAB)
                 assert rc == uaes.M_AUTHENTICATION_ERROR and back == b"\xab" * n
             assert uaes.mgpu_ecb_encrypt(devlist, key, pt, 1) == orc.ecb_encrypt(key, pt, 1)
+
+
+# ---- the same split without a change in the caller: UAES_DEVICES / uaes_set_devices ----
+def _compat(bits):
+    L = C.CDLL(uaes.lib_path("libmicro_aes_hip_%d.so" % bits))
+    for name in ("AES_ECB_decrypt", "AES_GCM_decrypt", "AES_XTS_encrypt"):
+        getattr(L, name).restype = C.c_char
+    return L
+
+
+def test_drop_in_symbols_spread_long_host_buffers_over_the_configured_devices(orc):
+    """uaes_set_devices(3, {0,0,0}): AES_ECB_* / AES_CTR_* / AES_GCM_* (micro_aes.h:173-181, :256-266, :294-308) on a
+    256 MiB HOST text go through uaes_mgpu_* -- bit-identical to the default one-device call -- while device pointers
+    and texts below the threshold stay on the one-device path"""
+    import numpy as np
+    L, K = uaes.engine(), _compat(128)
+    n = (256 << 20) + 16 * 3 + 5
+    key, iv = bytes(range(16)), bytes(range(0xF0, 0xFC))
+    src = np.empty(n, dtype=np.uint8)
+    orc.splitmix_into(2, src[: n // 8 * 8])
+    src[n // 8 * 8:] = 7
+    sp = C.c_void_p(src.ctypes.data)
+
+    def run_all():
+        res = {}
+        out = np.zeros(n + 32, dtype=np.uint8)
+        op = C.c_void_p(out.ctypes.data)
+        K.AES_CTR_encrypt(key, iv, sp, C.c_size_t(n), op)
+        res["ctr"] = hashlib.sha256(out[:n].tobytes()).hexdigest()
+        K.AES_ECB_encrypt(key, sp, C.c_size_t(n), op)
+        res["ecb"] = hashlib.sha256(out[: (n + 15) // 16 * 16].tobytes()).hexdigest()
+        ecb = out[: n // 16 * 16].copy()
+        back = np.zeros(n, dtype=np.uint8)
+        rc = K.AES_ECB_decrypt(key, C.c_void_p(ecb.ctypes.data), C.c_size_t(ecb.size), C.c_void_p(back.ctypes.data))
+        assert ord(rc) == 0 and np.array_equal(back[: ecb.size], src[: ecb.size])
+        K.AES_GCM_encrypt(key, iv, b"hdr", C.c_size_t(3), sp, C.c_size_t(n), op)
+        res["gcm"] = hashlib.sha256(out[: n + 16].tobytes()).hexdigest()
+        back[:] = 0xAB
+        rc = K.AES_GCM_decrypt(key, iv, b"hdr", C.c_size_t(3), op, C.c_size_t(n), C.c_void_p(back.ctypes.data))
+        assert ord(rc) == 0 and np.array_equal(back, src)
+        out[n // 3] ^= 1                                         # N7 through the split: untouched
+        back[:] = 0xAB
+        rc = K.AES_GCM_decrypt(key, iv, b"hdr", C.c_size_t(3), op, C.c_size_t(n), C.c_void_p(back.ctypes.data))
+        assert ord(rc) == uaes.M_AUTHENTICATION_ERROR and int((back != 0xAB).sum()) == 0
+        ns = n // 4096
+        assert L.uaes_xts_sectors(256, bytes(range(64)), 5, 4096, ns, sp, op, 1) == 0
+        res["xts"] = hashlib.sha256(out[: ns * 4096].tobytes()).hexdigest()
+        return res
+
+    base = run_all()
+    assert base["ctr"] == hashlib.sha256(orc.ctr_encrypt(key, iv, src.tobytes())).hexdigest()
+    devs = (C.c_int * 3)(0, 0, 0)
+    assert L.uaes_set_devices(3, devs, 1 << 20) == 0
+    try:
+        assert run_all() == base
+        # short texts and device pointers are not split (and still right)
+        assert uaes.AES_CTR_encrypt(key, iv, b"x" * 100) == orc.ctr_encrypt(key, iv, b"x" * 100)
+    finally:
+        assert L.uaes_set_devices(0, None, 64 << 20) == 0
+    assert L.uaes_set_devices(2, (C.c_int * 2)(0, 99), 0) == -2
+
+
+def test_reference_main_c_with_UAES_DEVICES_in_the_environment():
+    """the reference's own main.c on the HIP library with UAES_DEVICES=0,0,0 and the threshold at one byte: every host
+    call of its known-answer tests -- 57-byte texts -- is cut into three slices, and every verdict stays PASSED"""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "oracle", "_ref", "main_hip_128")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/main_hip_128 was not built")
+    base = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    env = dict(os.environ, UAES_DEVICES="0,0,0", UAES_DEVICES_MIN_MIB="0")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "FAILED" not in r.stdout, r.stdout + r.stderr
+    assert re.findall(r"AES-128 (\w+) \w+: PASSED!", r.stdout) == re.findall(r"AES-128 (\w+) \w+: PASSED!", base.stdout)
+    assert r.stdout.count("PASSED") == base.stdout.count("PASSED") >= 27
+    bad = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=dict(env, UAES_DEVICES="0,x"))
+    assert bad.returncode == 0 and "UAES_DEVICES ignored" in bad.stderr
+
+
+def test_compat_calls_wait_for_a_named_producer_stream(orc):
+    """VERDICT r04 #8c: device-pointer callers whose data is produced on a hipStreamNonBlocking stream (every torch side
+    stream is one) name it with uaes_compat_set_producer_stream; the synchronous call then waits for it instead of for
+    the default stream.  ~50 ms of work is queued in front of the write the cipher must see."""
+    import torch
+    K = _compat(128)
+    K.uaes_compat_set_producer_stream.argtypes = [C.c_void_p]
+    K.uaes_compat_set_producer_stream.restype = None
+    key, iv = bytes(range(16)), bytes(range(0xF0, 0xFC))
+    n = 64 << 20
+    dev = torch.device("cuda", 0)
+    s = torch.cuda.Stream(device=dev)
+    src = torch.zeros(n, dtype=torch.uint8, device=dev)
+    dst = torch.zeros(n, dtype=torch.uint8, device=dev)
+    big = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+    final = torch.frombuffer(bytearray(orc.splitmix(9, n)), dtype=torch.uint8).to(dev)
+    torch.cuda.synchronize()
+    want = hashlib.sha256(orc.ctr_encrypt(key, iv, bytes(final.cpu().numpy()))).hexdigest()
+    K.uaes_compat_set_producer_stream(C.c_void_p(s.cuda_stream))
+    try:
+        for trial in range(3):
+            src.zero_()
+            torch.cuda.synchronize()
+            with torch.cuda.stream(s):
+                for _ in range(40):
+                    big.add_(1)                                 # ~1 ms each: the producer is still busy when the call starts
+                src.copy_(final)
+            K.AES_CTR_encrypt(key, iv, C.c_void_p(src.data_ptr()), C.c_size_t(n), C.c_void_p(dst.data_ptr()))
+            assert hashlib.sha256(dst.cpu().numpy().tobytes()).hexdigest() == want, trial
+    finally:
+        K.uaes_compat_set_producer_stream(None)
