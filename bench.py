@@ -106,13 +106,11 @@ def usable_cores():
     return max(1, min(n, 128))
 
 
-def measure_traffic(workload, nbytes):
-    """HBM bytes per step from the PMC counters, measured live: two SEPARATE rocprofv3 passes (--pmc FETCH_SIZE,
-    --pmc WRITE_SIZE; kernel trace only, as MI355X_MICROARCH.md prescribes) over a short child run of this very
-    command (3 steps + 1 warm-up, no settling, no CPU leg).  Per step = the counters of every kernel of the engine
-    (names k_*) summed over the child's launches / its 4 steps.  FETCH_SIZE is in KiB and on gfx950 reports half of a
-    wide coalesced read stream, so bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.  Returns (bytes, note) or
-    (None, why not)."""
+def measure_counters(workload, nbytes, counters=("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU")):
+    """PMC counters per step, measured live: one SEPARATE rocprofv3 pass per counter (kernel trace only, as
+    MI355X_MICROARCH.md prescribes) over a short child run of this very command (3 steps + 1 warm-up, no settling, no
+    CPU leg).  Per step = the counter of every kernel of the engine (names k_*) summed over the child's launches / its
+    4 steps.  Returns ({counter: value per step}, None) or ({whatever was collected}, why the rest is missing)."""
     import csv
     import glob
     import shutil
@@ -120,15 +118,15 @@ def measure_traffic(workload, nbytes):
     import tempfile
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if not exe:
-        return None, "rocprofv3 not found"
+        return {}, "rocprofv3 not found"
     steps, warm = 3, 1
-    kib = {}
+    got = {}
     tmp = tempfile.mkdtemp(prefix="uaes_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     try:
-        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        for ctr in counters:
             out = os.path.join(tmp, ctr)
             cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", out, "-o", "pmc", "--",
                    sys.executable, os.path.abspath(__file__), "--gpus", "1", "--workload", workload, "--bytes", str(nbytes),
@@ -137,7 +135,7 @@ def measure_traffic(workload, nbytes):
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=150)
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
-                return None, "rocprofv3 --pmc %s pass failed (rc %d)" % (ctr, r.returncode)
+                return got, "rocprofv3 --pmc %s pass failed (rc %d)" % (ctr, r.returncode)
             total = 0.0
             for f in files:
                 with open(f) as fh:
@@ -145,14 +143,39 @@ def measure_traffic(workload, nbytes):
                         name = row.get("Kernel_Name", "")
                         if row.get("Counter_Name") == ctr and (name.startswith("k_") or name.startswith("void k_")):
                             total += float(row.get("Counter_Value", 0))
-            kib[ctr] = total / (steps + warm)
+            got[ctr] = total / (steps + warm)
     except Exception as e:                      # a profiler problem must not cost the bench line
-        return None, "PMC pass: %s" % e
+        return got, "PMC pass: %s" % e
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    traffic = int((2.0 * kib["FETCH_SIZE"] + kib["WRITE_SIZE"]) * 1024)
-    return traffic, ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE as two "
-                     "separate passes over a 4-step child run; (2 x %.0f + %.0f) KiB per step" % (kib["FETCH_SIZE"], kib["WRITE_SIZE"]))
+    return got, None
+
+
+def traffic_of(counters):
+    """HBM bytes per step: FETCH_SIZE and WRITE_SIZE are in KiB and on gfx950 FETCH_SIZE reports half of a wide coalesced
+    read stream (MI355X_MICROARCH.md, HBM), so bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.  (bytes, note) or (None, None)."""
+    if "FETCH_SIZE" not in counters or "WRITE_SIZE" not in counters:
+        return None, None
+    traffic = int((2.0 * counters["FETCH_SIZE"] + counters["WRITE_SIZE"]) * 1024)
+    return traffic, ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE as two separate "
+                     "passes over a 4-step child run; (2 x %.0f + %.0f) KiB per step" % (counters["FETCH_SIZE"], counters["WRITE_SIZE"]))
+
+
+def valu_per_block_of(counters, nbytes, workload, profiles_dir=None):
+    """VALU instructions per 16-byte block = SQ_INSTS_VALU (wave instructions per step) x 64 lanes / blocks per step:
+    from the PMC pass of THIS run when there is one, else the figure tools/profile.sh recorded for this workload and
+    size in profiles/pmc_valu.json -- and then labelled as recorded, with the build it came from.  (value, source)"""
+    if counters.get("SQ_INSTS_VALU"):
+        return round(counters["SQ_INSTS_VALU"] * 64.0 / (nbytes / 16.0), 1), \
+            "measured in this run: rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU over a 4-step child run"
+    try:
+        with open(os.path.join(profiles_dir or os.path.join(ROOT, "profiles"), "pmc_valu.json")) as f:
+            t = json.load(f).get(workload)
+        if t and t["bytes_per_gpu"] == nbytes:
+            return t["valu_insts_per_block"], "recorded in %s (build %s; not measured in this run)" % (t["source"], t.get("build", "?"))
+    except Exception:
+        pass
+    return None, None
 
 
 def cpu_baseline(workload):
@@ -755,9 +778,12 @@ def main():
         achieved = per_gpu[0]
         # HBM bytes per step: measured live by two rocprofv3 PMC passes over a short child run (N = 1 only, like the
         # CPU leg); where that is not possible the figure recorded under profiles/ is quoted and labelled as such.
-        traffic, traffic_source = None, None
+        traffic, traffic_source, counters = None, None, {}
         if world == 1 and not a.no_traffic:
-            traffic, traffic_source = measure_traffic(a.workload, n)
+            counters, why_not = measure_counters(a.workload, n)
+            traffic, traffic_source = traffic_of(counters)
+            if traffic is None:
+                traffic_source = why_not
         if traffic is None:
             why = traffic_source
             try:
@@ -783,11 +809,11 @@ def main():
                            "frac_of_ceiling": round(achieved / ceil_gbs, 4)}
         # Both pipes, in shader clocks per 16-byte block per CU: the LDS serves 32 lookups per
         # clock, and every VALU instruction of a stream that contains v_perm_b32 costs 4.43 SIMD-cycles
-        # (profiles/r04_issuebench.log); VALU instructions per block = SQ_INSTS_VALU x 64 / blocks of the recorded rocprofv3
-        # PMC pass (profiles/r04_*_rocprof_summary.txt).  The two do not overlap freely (they share the register-file
-        # ports): the dependency-free ceiling of the CTR mix is 4.56 clk per block, not max(valu, lds).
+        # (profiles/r04_issuebench.log); VALU instructions per block = SQ_INSTS_VALU x 64 / blocks, from the PMC pass of
+        # THIS run (or, where no pass could run, the recorded figure, labelled).  The two do not overlap freely (they
+        # share the register-file ports): the dependency-free ceiling of the CTR mix is 4.56 clk per block, not max(valu, lds).
         pipes = None
-        valu_per_block = {"ctr": 213, "gcm": 297, "xts": 373}.get(a.workload)
+        valu_per_block, valu_source = valu_per_block_of(counters, n, a.workload)
         if sclk_mhz and lookups and valu_per_block and a.workload in ("ctr", "gcm", "xts") and n >= (256 << 20):
             cus = torch.cuda.get_device_properties(0).multi_processor_count
             blocks = n / 16.0
@@ -795,8 +821,9 @@ def main():
                      "lds_clk_per_block_per_cu": round(lookups * 2.08 / 64.0, 3),
                      "valu_clk_per_block_per_cu": round(valu_per_block * 4.43 / 256.0, 3),
                      "valu_insts_per_block": valu_per_block,
-                     "source": "recorded: SQ_INSTS_VALU of profiles/r04_*_rocprof_summary.txt, 4.43 cycles per VALU "
-                               "instruction and 2.08 clk per ds_read_b32 from profiles/r04_issuebench.log; clock measured in this run"}
+                     "valu_insts_source": valu_source,
+                     "source": "4.43 cycles per VALU instruction and 2.08 clk per ds_read_b32 from profiles/r04_issuebench.log; "
+                               "clock measured in this run"}
         names = {"ctr": "AES-128-CTR", "ecb": "AES-128-ECB", "xts": "AES-256-XTS 4 KiB sectors", "gcm": "AES-128-GCM",
                  "cbc-dec": "AES-128-CBC decrypt", "cfb-dec": "AES-128-CFB decrypt",
                  "cbc-enc": "AES-128-CBC encrypt, ONE serial chain", "cmac": "AES-128-CMAC, ONE serial chain",

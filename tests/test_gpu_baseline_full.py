@@ -150,7 +150,10 @@ def test_bench_line_measures_its_own_traffic_and_clock():
     assert lc and lc["lookups_per_block"] == 128 and 1500 < lc["sclk_mhz_under_load"] < 2500
     assert 0.6 < lc["frac_of_ceiling"] < 1.0, lc
     pp = roof["pipes"]
-    assert pp["valu_insts_per_block"] == 213 and 4.0 < pp["lds_clk_per_block_per_cu"] < 4.3
+    assert 4.0 < pp["lds_clk_per_block_per_cu"] < 4.3
+    if shutil.which("rocprofv3") or os.path.exists("/opt/rocm/bin/rocprofv3"):
+        # measured by the SQ_INSTS_VALU pass of this very run (213 for the round-4 kernel), not a copied constant
+        assert pp["valu_insts_source"].startswith("measured in this run") and 190 < pp["valu_insts_per_block"] < 225, pp
     assert pp["lds_clk_per_block_per_cu"] < pp["achieved_clk_per_block_per_cu"] < 5.2, pp
     # the sustained rate (>= 2 s of the same step back to back) rides next to `value`; the 12 ms window
     # behind `value` may catch the clocks a little high, never the other way round by more than noise
