@@ -14,9 +14,15 @@ Groups:
   W  functional: does the LDS ignore address bits above 17?
   P  does the half-rate / full-rate split survive mixing?
   F  an all-full-rate round (8-byte table entries, no v_perm)
+  E  ENERGY (round 5): the block-round mix in its best order (a4r4, VGPR keys) with the byte-extract instruction swapped
+     -- v_perm_b32 (SGPR / VGPR selector), v_and_or_b32, v_bfe_u32 + v_lshl_or_b32, SDWA, v_alignbyte, v_lshrrev + and-or --
+     to be run with `--sustain S`: every row is launched back to back for S seconds on all 256 CUs so that the power
+     manager settles, and the row reports the SETTLED clock and instructions (block-rounds) per second at that clock.
+     At the 1.4 kW cap throughput is energy per block, not cycles per block.
 
     python tools/ubench/gen_issuebench.py && hipcc --offload-arch=gfx950 -O2 -o tools/ubench/issuebench tools/ubench/issuebench.hip
     gpurun -- 'tools/ubench/issuebench [name filter]'          # neither the .hip nor the binary is tracked
+    gpurun -- 'tools/ubench/issuebench --sustain 1.5 E_'       # settled clock x instructions/s (energy ranking)
 """
 import os
 
@@ -57,8 +63,8 @@ def rd(i):
     return f"ds_read_b32 v{T0 + i % NCH}, v{A0 + i % NCH}"
 
 
-def kernel(name, body, per_trip_valu, per_trip_lds, note=""):
-    KERNELS.append(dict(name=name, body=body, valu=per_trip_valu, lds=per_trip_lds, note=note))
+def kernel(name, body, per_trip_valu, per_trip_lds, note="", rand=False):
+    KERNELS.append(dict(name=name, body=body, valu=per_trip_valu, lds=per_trip_lds, note=note, rand=rand))
 
 
 # ---- R: single opcodes
@@ -241,6 +247,45 @@ kernel("F_fast40_b64_grouped", fast_round("grouped") * 2, 80, 32)
 kernel("F_fast40_b64_a4r4", fast_round("a4r4") * 2, 80, 32)
 kernel("F_fast40_b64_grouped_2slow", fast_round("grouped", 2) * 2, 80, 32)
 
+
+# ---- E: energy.  a4r4 order, VGPR keys; `ext` = the instruction(s) that turn one state byte into an LDS address
+def energy_mix(ext):
+    addr = []
+    for i in range(16):
+        if i % 4 == 1:
+            addr.append([valu("andor_vvv", i)])                 # the byte that already sits in position: and-or today too
+        elif ext == "bfe_or":
+            addr.append([valu("bfe", i), valu("lshl_or", i)])
+        elif ext == "lshr_andor":
+            addr.append([valu("lshr16", i), valu("andor_vvv", i)])
+        else:
+            addr.append([valu(ext, i)])
+    xors = [valu("bitop_vvv", i) for i in range(8)]
+    out, n = [], 0
+    for c in range(4):
+        for a in addr[4 * c:4 * c + 4]:
+            out += a
+            n += len(a)
+        out += [rd(4 * c + j) for j in range(4)] + xors[2 * c:2 * c + 2]
+        n += 2
+    return out, n
+
+
+for ext in ["perm_vvs", "perm_vvv", "and_or", "andor_vvv", "bfe_or", "sdwa_b2", "alignbyte", "lshr_andor"]:
+    body, nv = energy_mix(ext)
+    kernel("E_mix_" + ext, body * 2, 2 * nv, 32, "block-round mix, byte extract = %s" % ext)
+kernel("E_reads_only", [rd(i) for i in range(16)] * 2, 0, 32, "the 16 lookups of a block-round alone")
+for op in ["perm_vvs", "perm_vvv", "and_or", "andor_vvv", "bfe", "lshl_or", "sdwa_b2", "alignbyte", "xor", "bitop_vvv", "bitop_vvs", "lshr16", "mov", "add"]:
+    kernel("E_op_" + op, [valu(op, i) for i in range(64)], 64, 0, "single opcode")
+# the same streams over RANDOM per-lane data (chains, constants and table rows hashed from the thread id): the streams
+# above run on near-constant operands, toggle few wires and never reach the power cap; a cipher's operands are random
+for ext in ["perm_vvs", "perm_vvv", "and_or", "andor_vvv", "bfe_or", "sdwa_b2", "alignbyte", "lshr_andor"]:
+    body, nv = energy_mix(ext)
+    kernel("X_mix_" + ext, body * 2, 2 * nv, 32, "random data; byte extract = %s" % ext, rand=True)
+kernel("X_reads_only", [rd(i) for i in range(16)] * 2, 0, 32, "random rows; the 16 lookups alone", rand=True)
+for op in ["perm_vvs", "and_or", "andor_vvv", "bfe", "sdwa_b2", "xor", "bitop_vvv", "bitop_vvs", "mov"]:
+    kernel("X_op_" + op, [valu(op, i) for i in range(64)], 64, 0, "random data; single opcode", rand=True)
+
 HDR = r'''// GENERATED by tools/ubench/gen_issuebench.py -- do not edit.  Diagnostic, not part of the product.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -272,7 +317,7 @@ __global__ __launch_bounds__(1024) void k_%(name)s(u32 iters, u64 *cycles, u32 *
         "s_cbranch_scc1 L_%(name)s_%%=\n"
         "s_waitcnt lgkmcnt(0)\n"
 %(fold)s
-        : [out] "=v"(out) : [slot] "v"(slot), [slot8] "v"(slot * 2u), [iters] "s"(iters) : CLOB);
+        : [out] "=v"(out) : [slot] "v"(slot), [slot8] "v"(slot * 2u), [iters] "s"(iters), [tid] "v"(threadIdx.x + 1024u * blockIdx.x) : CLOB);
     const u64 t1 = __builtin_readcyclecounter();
     if (out == 0x12345678u) sink[0] = out;
     if ((threadIdx.x & 63u) == 0) cycles[blockIdx.x * 16 + (threadIdx.x >> 6)] = t1 - t0;
@@ -297,9 +342,25 @@ def emit():
     for i in range(NCH):
         fold.append(f"v_xor_b32_e32 %[out], %[out], v{T0 + i}")
         fold.append(f"v_xor_b32_e32 %[out], %[out], v{B0 + i}")
+    # random per-lane data: chain i = hash(tid, i); constants hashed too; table row of address register i = 7 bits of its hash
+    init_rand = []
+    for i in range(NCH):
+        init_rand += [f"s_mov_b32 s40, {hex((0x9E3779B1 * (2 * i + 1) + 0x7F4A7C15 * i) & 0xffffffff | 1)}",
+                      f"v_mul_lo_u32 v{B0 + i}, %[tid], s40",
+                      f"v_lshrrev_b32_e32 v{T0 + i}, 15, v{B0 + i}",
+                      f"v_xor_b32_e32 v{B0 + i}, v{B0 + i}, v{T0 + i}",
+                      f"s_mov_b32 s40, {hex((0x85EBCA6B + 0x27D4EB2F * i) & 0xffffffff | 1)}",
+                      f"v_mul_lo_u32 v{B0 + i}, v{B0 + i}, s40",
+                      f"v_lshrrev_b32_e32 v{T0 + i}, 13, v{B0 + i}",
+                      f"v_xor_b32_e32 v{B0 + i}, v{B0 + i}, v{T0 + i}",
+                      f"v_and_b32_e32 v{A0 + i}, 0x7f00, v{B0 + i}",
+                      f"v_or_b32_e32 v{A0 + i}, v{A0 + i}, %[slot]",
+                      f"v_mov_b32_e32 v{T0 + i}, 0"]
+    init_rand += [f"v_mov_b32_e32 v{C0}, 0x0000ff00", f"v_mov_b32_e32 v{C0 + 1}, 0x0c020500", f"v_mov_b32_e32 v{C0 + 2}, 0x00080008",
+                  f"v_xor_b32_e32 v{C0 + 3}, v{B0}, v{B0 + 7}"]
     init64 = [l.replace("%[slot]", "%[slot8]") if l.startswith("v_add_u32_e32 v%d" % A0) or any(l.startswith("v_add_u32_e32 v%d," % (A0 + i)) for i in range(NCH)) else l for l in init]
     for k in KERNELS:
-        src.append(KERN % dict(name=k["name"], init=q(init64 if k["name"].startswith("F_") else init), body=q(k["body"]), fold=q(fold)))
+        src.append(KERN % dict(name=k["name"], init=q(init_rand if k["rand"] else init64 if k["name"].startswith("F_") else init), body=q(k["body"]), fold=q(fold)))
     # functional test W: address bits above the LDS size
     src.append(r'''
 __global__ void k_W_wrap(u32 *res)
@@ -325,7 +386,12 @@ static Row rows[] = {
 int main(int argc, char **argv)
 {
     const int wgs = 256;
-    const char *only = argc > 1 ? argv[1] : "";
+    double sustain = 0;
+    const char *only = "";
+    for (int i = 1; i < argc; ++i) {
+        if (!strcmp(argv[i], "--sustain") && i + 1 < argc) sustain = atof(argv[++i]);
+        else only = argv[i];
+    }
     u64 *d_cyc; u32 *d_sink;
     (void)hipMalloc(&d_cyc, wgs * 16 * sizeof(u64)); (void)hipMalloc(&d_sink, 4096 * 6 * 4);
     u64 *h = (u64 *)malloc(wgs * 16 * sizeof(u64));
@@ -349,6 +415,39 @@ int main(int argc, char **argv)
         hipLaunchKernelGGL(R.fn, dim3(wgs), dim3(1024), 65536, 0, iters / 8, d_cyc, d_sink);
         (void)hipDeviceSynchronize();
         hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        if (sustain > 0) {
+            /* energy ranking: the same launch back to back until `sustain` seconds have passed (the power manager needs
+             * far longer than one 20 ms launch), then one more launch timed: its clock is the SETTLED clock of this
+             * instruction stream on all 256 CUs, and instructions / its time is what the chip sustains under the cap */
+            hipEvent_t s0, s1; (void)hipEventCreate(&s0); (void)hipEventCreate(&s1);
+            float run_ms = 0;
+            (void)hipEventRecord(s0);
+            int launches = 0;
+            do {
+                for (int k = 0; k < 8; ++k) hipLaunchKernelGGL(R.fn, dim3(wgs), dim3(1024), 65536, 0, iters, d_cyc, d_sink);
+                launches += 8;
+                (void)hipEventRecord(s1); (void)hipEventSynchronize(s1);
+                (void)hipEventElapsedTime(&run_ms, s0, s1);
+            } while (run_ms < sustain * 1e3);
+            const int NL = 6;                                     // the reported figures: mean of six more launches
+            (void)hipEventRecord(e0);
+            for (int k = 0; k < NL; ++k) hipLaunchKernelGGL(R.fn, dim3(wgs), dim3(1024), 65536, 0, iters, d_cyc, d_sink);
+            (void)hipEventRecord(e1); (void)hipDeviceSynchronize();
+            float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+            ms /= NL;
+            (void)hipMemcpy(h, d_cyc, wgs * 16 * sizeof(u64), hipMemcpyDeviceToHost);
+            u64 mx = 0;
+            for (int i = 0; i < wgs * 16; ++i) if (h[i] > mx) mx = h[i];   // (cycles of the last launch)
+            const double trips = 16.0 * iters * wgs;              // wave-trips on the chip
+            const double ghz = (double)mx / (ms * 1e6);
+            printf("%-22s settled %5.3f GHz after %5.2f s (%3d launches) | last launch %7.3f ms", R.name, ghz, run_ms * 1e-3, launches, ms);
+            if (R.valu) printf(" | %7.2f G VALU wave-instr/s", trips * R.valu / (ms * 1e6));
+            if (R.ldsn) printf(" | %7.2f G ds_read wave-instr/s | %7.2f G block-rounds/s", trips * R.ldsn / (ms * 1e6), trips * R.ldsn / 16.0 * 64.0 / (ms * 1e6));
+            if (R.valu && R.ldsn) printf(" | %6.1f SIMD cyc per 16 reads + %d VALU", 4.0 * (double)mx / (16.0 * iters) * 16.0 / R.ldsn, R.valu * 16 / R.ldsn);
+            printf("  %s\n", R.note);
+            fflush(stdout);
+            continue;
+        }
         (void)hipEventRecord(e0);
         hipLaunchKernelGGL(R.fn, dim3(wgs), dim3(1024), 65536, 0, iters, d_cyc, d_sink);
         (void)hipEventRecord(e1); (void)hipDeviceSynchronize();
