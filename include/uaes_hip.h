@@ -21,8 +21,11 @@
  *   - *_dev variants enqueue on a caller-supplied hipStream_t and return
  *     without synchronising: the form bench.py and multi-GPU sharding use.
  *
- * There is NO CPU fallback anywhere in this library: if no HIP device is
- * usable every call fails loudly (UAES_E_HIP, message in uaes_last_error()).
+ * By DEFAULT every call runs on the GPU and there is no CPU fallback: if no HIP
+ * device is usable every call fails loudly (UAES_E_HIP, message in
+ * uaes_last_error()).  A deployer may switch on the engine's own host data path
+ * for short host-pointer calls, single serial chains and GPU-less boxes:
+ * uaes_set_host_policy() below -- opt-in, never silent.
  *
  * Return values: 0 on success; the reference's codes (micro_aes.h:469-476)
  * for the reference's error conditions; negative for engine failures.
@@ -90,6 +93,22 @@ int         uaes_set_gcm_one_pass_decrypt(int on);
  * be used with the library any more -- before or after hipStreamDestroy -- to give
  * its buffer back.  Waits for the device's outstanding work.                       */
 int         uaes_stream_release(void *stream);
+
+/* The engine's own HOST data path (micro-aes_amd/csrc/uaes_host.c: portable table-driven C, re-entrant, bit-identical to
+ * the kernels and parity-tested like them).  OFF by default -- max_bytes 0, chains 0, fallback 0: every call runs on the
+ * GPU and fails loudly without one.  Three independent, process-wide switches for the cases a GPU serves badly:
+ *   max_bytes  calls whose data pointers are HOST memory and whose text is at most this long run on the host: a
+ *              launch costs 12-20 us whatever the size, one host core needs that long for ~1 KiB (GCM ~200 B);
+ *   chains     ONE serial chain in host memory -- CBC / CFB encryption, OFB, CMAC, CCM -- runs on the host whatever
+ *              its length (a chain is a latency-bound single wave on the GPU: 36 MiB/s; uaes_*_batch are the GPU's form);
+ *   fallback   with NO usable HIP device the calls below run on the host instead of returning UAES_E_HIP -- the
+ *              reference's `void` functions cannot report an error.
+ * Covered: every synchronous one-message call of this header -- ECB, CTR, XTS (unit and sectors), GCM (any nonce / tag
+ * length), CBC (CTS and CTS-0 forms), CFB, OFB, CMAC, CCM, GCM-SIV, OCB.  Not covered (always GPU): the *_dev / *_batch
+ * / record / key-context / stream / mgpu calls, uaes_ghash, and any call that is handed a device pointer.
+ * Environment, read at first use: UAES_HOST_MAX=<bytes>, UAES_HOST_CHAINS=1, UAES_HOST_FALLBACK=1.               */
+int uaes_set_host_policy(size_t max_bytes, int chains, int fallback);
+int uaes_get_host_policy(size_t *max_bytes, int *chains, int *fallback);
 
 /* Host-side key schedule (KeyExpansion, micro_aes.c:144-178) as the kernels
  * receive it: (nr+1)*4 little-endian words of encryption round keys and of

@@ -10,7 +10,8 @@ sharding layer drive with ``torch`` tensors' raw pointers.  torch is only
 plumbing here (device memory, streams, torch.distributed).
 
 There is NO fallback: if the shared library is missing or no HIP device is
-usable, importing ``engine()`` / calling any function raises.
+usable, importing ``engine()`` / calling any function raises.  (The engine's own
+host data path, csrc/uaes_host.c, is opt-in: ``host_policy()`` below.)
 
 The directory name carries a hyphen (it is the name the project was given), so
 import it through the alias module at the repo root::
@@ -43,7 +44,7 @@ EXPORTS = [
     "uaes_ocb_encrypt", "uaes_ocb_decrypt", "uaes_ocb_dev",
     "uaes_mgpu_ctr_xcrypt_at", "uaes_mgpu_xts_sectors", "uaes_mgpu_ctr_encrypt_gather",
     "uaes_mgpu_ecb_encrypt", "uaes_mgpu_ecb_decrypt", "uaes_mgpu_gcm_encrypt", "uaes_mgpu_gcm_decrypt",
-    "uaes_set_devices", "uaes_set_producer_stream",
+    "uaes_set_devices", "uaes_set_producer_stream", "uaes_set_host_policy", "uaes_get_host_policy",
     "uaes_gcm_key_new", "uaes_gcm_key_free", "uaes_gcm_key_encrypt", "uaes_gcm_key_decrypt",
     "uaes_gcm_key_encrypt_dev", "uaes_gcm_key_decrypt_dev",
     "uaes_gcm_record_max", "uaes_gcm_key_encrypt_records", "uaes_gcm_key_decrypt_records",
@@ -147,6 +148,8 @@ def engine():
     for n in ("uaes_mgpu_gcm_encrypt", "uaes_mgpu_gcm_decrypt"):
         getattr(L, n).argtypes = [i, C.POINTER(C.c_int), i, vp, vp, vp, sz, vp, sz, vp]
     L.uaes_set_devices.argtypes = [i, C.POINTER(C.c_int), sz]
+    L.uaes_set_host_policy.argtypes = [sz, i, i]
+    L.uaes_get_host_policy.argtypes = [C.POINTER(sz), C.POINTER(i), C.POINTER(i)]
     L.uaes_set_producer_stream.argtypes = [vp]
     L.uaes_gcm_key_new.argtypes = [C.POINTER(vp), i, vp]
     L.uaes_gcm_key_free.argtypes = [vp]
@@ -723,6 +726,19 @@ def ghash(H, aData, crtxt):
 
 def selftest():
     return _check(engine().uaes_selftest(), "uaes_selftest")
+
+
+def host_policy(max_bytes=None, chains=None, fallback=None):
+    """Get / set the opt-in host data path (uaes_set_host_policy).  Returns the policy in force BEFORE the call as
+    (max_bytes, chains, fallback); arguments left None keep their value.  Default (0, 0, 0): GPU always."""
+    mb, ch, fb = C.c_size_t(), C.c_int(), C.c_int()
+    engine().uaes_get_host_policy(C.byref(mb), C.byref(ch), C.byref(fb))
+    prev = (mb.value, ch.value, fb.value)
+    if max_bytes is not None or chains is not None or fallback is not None:
+        engine().uaes_set_host_policy(prev[0] if max_bytes is None else max_bytes,
+                                      prev[1] if chains is None else int(chains),
+                                      prev[2] if fallback is None else int(fallback))
+    return prev
 
 
 # ---------------------------------------------------------------------------

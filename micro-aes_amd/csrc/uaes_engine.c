@@ -22,6 +22,7 @@
 
 #include "../../include/uaes_hip.h"
 #include "uaes_device.h"
+#include "uaes_host.h"
 
 #define UAES_VERSION "uaes-hip 0.1 gfx950"
 #define MAX_DEVICES  16
@@ -181,6 +182,7 @@ static void build_host_tables(void)
         h_td0[i] = (uint32_t)ve | ((uint32_t)v9 << 8) | ((uint32_t)vd << 16) | ((uint32_t)vb << 24);
     }
     build_frobenius();
+    uaesh_tables_init(h_te0, h_td0);               /* the host data path's tables (uaes_host.c): off unless switched on */
 }
 
 /* ------------------------------------------------------------------------ */
@@ -756,6 +758,74 @@ static void auto_devices_from_env(void)          /* once, from env_init() */
         fprintf(stderr, "uaes-hip: UAES_DEVICES ignored (a comma-separated list of visible device ordinals, or \"all\")\n");
 }
 
+/* ---- the engine's own HOST data path (uaes_host.c): OFF unless the deployer switches it on --------------------------
+ * By default every call runs on the GPU and fails loudly without one.  Three independent switches, process-wide:
+ *   max_bytes  host-pointer calls of at most this many bytes run on the host (0 = never): below ~1 KiB (GCM ~200 B) a
+ *              kernel launch costs more than the cipher (profiles/r04_break_even.md);
+ *   chains     ONE serial chain given host pointers -- CBC / CFB encryption, OFB, CMAC, CCM -- runs on the host whatever
+ *              its length: a chain is a latency-bound single wave on the GPU (36 MiB/s);
+ *   fallback   with NO usable HIP device the modes this path implements run on the host instead of failing
+ *              (a `void` function of the reference's API cannot report an error).
+ * Environment, read once: UAES_HOST_MAX (bytes), UAES_HOST_CHAINS=1, UAES_HOST_FALLBACK=1.  Device pointers always go to
+ * the GPU.  The batch / record / key-context / stream / mgpu / *_dev calls have no host path.                      */
+static struct { size_t max_bytes; int chains, fallback, no_device; } g_host = { 0, 0, 0, -1 };
+
+int uaes_set_host_policy(size_t max_bytes, int chains, int fallback)
+{
+    env_ready();                                   /* (so that a later first call does not overwrite this with the environment) */
+    __atomic_store_n(&g_host.max_bytes, max_bytes, __ATOMIC_RELEASE);
+    __atomic_store_n(&g_host.chains, chains != 0, __ATOMIC_RELEASE);
+    __atomic_store_n(&g_host.fallback, fallback != 0, __ATOMIC_RELEASE);
+    return 0;
+}
+
+int uaes_get_host_policy(size_t *max_bytes, int *chains, int *fallback)
+{
+    env_ready();
+    if (max_bytes) *max_bytes = __atomic_load_n(&g_host.max_bytes, __ATOMIC_ACQUIRE);
+    if (chains) *chains = __atomic_load_n(&g_host.chains, __ATOMIC_ACQUIRE);
+    if (fallback) *fallback = __atomic_load_n(&g_host.fallback, __ATOMIC_ACQUIRE);
+    return 0;
+}
+
+static void host_policy_from_env(void)             /* once, from env_init() */
+{
+    const char *m = getenv("UAES_HOST_MAX");
+    if (m && *m) { long long v = strtoll(m, NULL, 10); if (v > 0) g_host.max_bytes = (size_t)v; }
+    g_host.chains = env_int("UAES_HOST_CHAINS", 0, 0, 1);
+    g_host.fallback = env_int("UAES_HOST_FALLBACK", 0, 0, 1);
+}
+
+/* does this call run on the host path?  chain != 0: one serial chain */
+static int host_take(const void *in, const void *out, size_t len, int chain)
+{
+    const size_t mx = __atomic_load_n(&g_host.max_bytes, __ATOMIC_ACQUIRE);
+    const int ch = __atomic_load_n(&g_host.chains, __ATOMIC_ACQUIRE), fb = __atomic_load_n(&g_host.fallback, __ATOMIC_ACQUIRE);
+    if (!mx && !ch && !fb) {
+        env_ready();
+        if (!g_host.max_bytes && !g_host.chains && !g_host.fallback) return 0;      /* the default: GPU, always */
+        return host_take(in, out, len, chain);
+    }
+    if (fb) {
+        if (g_host.no_device < 0) {
+            int n = 0;
+            const int none = hipGetDeviceCount(&n) != hipSuccess || n <= 0;
+            (void)hipGetLastError();
+            __atomic_store_n(&g_host.no_device, none, __ATOMIC_RELEASE);
+        }
+        if (g_host.no_device) return 1;
+    }
+    if (!(chain ? (ch || (mx && len <= mx)) : (mx && len <= mx))) return 0;
+    return !is_device_ptr(in) && !is_device_ptr(out);
+}
+
+static uaesh_key host_key(const keysched *ks)
+{
+    uaesh_key k;
+    k.ek = ks->ek.w; k.dk = ks->dk.w; k.nr = ks->nr;
+    return k;
+}
+
 /* > 1: split this call over devs[0..n); 0: run it on the current device as always */
 static int auto_devices(const void *in, const void *out, size_t len, int *devs)
 {
@@ -970,6 +1040,7 @@ static void env_init(void)
     g_env.pipe_workers = env_int("UAES_PIPE_WORKERS", 4, 1, PIPE_MAXW);
     g_env.pipe_slice = (size_t)env_int("UAES_PIPE_SLICE_MIB", 16, 1, 1024) << 20;
     auto_devices_from_env();
+    host_policy_from_env();
 }
 
 static int pipe_workers(void)
@@ -1220,6 +1291,12 @@ static int ecb_common(int keybits, const uint8_t *key, int decrypt, int padding,
     if (padding < 0 || padding > 2) return fail(UAES_E_ARG, "padding must be 0 (zeros), 1 (PKCS#7) or 2 (ISO/IEC 7816-4)");
     if (out_len == 0) return 0;
     if ((len && !in) || !out) return fail(UAES_E_ARG, "NULL data pointer");
+    if (host_take(in, out, len, 0)) {
+        const uaesh_key hk = host_key(&ks);
+        if (!decrypt) { uaesh_ecb_encrypt(&hk, padding, (const uint8_t *)in, len, (uint8_t *)out); return 0; }
+        uaesh_ecb_decrypt(&hk, (const uint8_t *)in, len, (uint8_t *)out);
+        return rem ? UAES_E_DECRYPTION : 0;
+    }
     {
         int devs[MAX_DEVICES];
         const int nd = auto_devices(in, out, len, devs);
@@ -1338,6 +1415,11 @@ int uaes_ctr_xcrypt_at(int keybits, const uint8_t *key, const uint8_t ctr0[16],
     if (!ctr0) return fail(UAES_E_ARG, "NULL counter block");
     if (len == 0) return 0;
     if (!in || !out) return fail(UAES_E_ARG, "NULL data pointer");
+    if (host_take(in, out, len, 0)) {
+        const uaesh_key hk = host_key(&ks);
+        uaesh_ctr(&hk, ctr0, block_offset, (const uint8_t *)in, len, (uint8_t *)out);
+        return 0;
+    }
     {
         int devs[MAX_DEVICES];
         const int nd = auto_devices(in, out, len, devs);
@@ -1442,6 +1524,12 @@ static int xts_common(int keybits, const uint8_t *keys, const uint8_t *tweak, in
     if (sector_bytes < 16) return UAES_E_DATALENGTH;             /* :1069, untouched */
     if (nsectors == 0) return 0;
     if (!in || !out) return fail(UAES_E_ARG, "NULL data pointer");
+    if (host_take(in, out, total, 0)) {
+        const uaesh_key h1 = host_key(&k1), h2 = host_key(&k2);
+        if (raw_tweak) uaesh_xts_unit(&h1, &h2, encrypt, tweak ? tweak : zero, (const uint8_t *)in, sector_bytes, (uint8_t *)out);
+        else uaesh_xts_sectors(&h1, &h2, encrypt, first_sector, sector_bytes, nsectors, (const uint8_t *)in, (uint8_t *)out);
+        return 0;
+    }
     if (!raw_tweak && nsectors > 1) {
         int devs[MAX_DEVICES];
         const int nd = auto_devices(in, out, total, devs);
@@ -1576,6 +1664,12 @@ int uaes_gcm_encrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, s
     if ((rc = expand_key(&ks, key, keybits)) != 0) return rc;
     if (!nonce || !crtxt || (ptextLen && !pntxt)) return fail(UAES_E_ARG, "NULL pointer");
     if (tagLen < 1 || tagLen > 16) return fail(UAES_E_ARG, "GCM tag length %zu (1..16)", tagLen);
+    if (nonceLen == 0) return fail(UAES_E_ARG, "empty GCM nonce");
+    if (aDataLen && !aData) return fail(UAES_E_ARG, "NULL aData with aDataLen != 0");
+    if (!is_device_ptr(aData) && host_take(pntxt, crtxt, ptextLen, 0)) {
+        const uaesh_key hk = host_key(&ks);
+        return uaesh_gcm(&hk, 0, nonce, nonceLen, tagLen, (const uint8_t *)aData, aDataLen, (const uint8_t *)pntxt, ptextLen, (uint8_t *)crtxt);
+    }
     if (nonceLen == 12 && tagLen == 16) {
         int devs[MAX_DEVICES];
         const int nd = auto_devices(pntxt, crtxt, ptextLen, devs);
@@ -1631,6 +1725,12 @@ int uaes_gcm_decrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, s
     if ((rc = expand_key(&ks, key, keybits)) != 0) return rc;
     if (!nonce || !crtxt || (crtxtLen && !pntxt)) return fail(UAES_E_ARG, "NULL pointer");
     if (tagLen < 1 || tagLen > 16) return fail(UAES_E_ARG, "GCM tag length %zu (1..16)", tagLen);
+    if (nonceLen == 0) return fail(UAES_E_ARG, "empty GCM nonce");
+    if (aDataLen && !aData) return fail(UAES_E_ARG, "NULL aData with aDataLen != 0");
+    if (!is_device_ptr(aData) && host_take(crtxt, pntxt, crtxtLen, 0)) {
+        const uaesh_key hk = host_key(&ks);
+        return uaesh_gcm(&hk, 1, nonce, nonceLen, tagLen, (const uint8_t *)aData, aDataLen, (const uint8_t *)crtxt, crtxtLen, (uint8_t *)pntxt);
+    }
     if (nonceLen == 12 && tagLen == 16) {
         int devs[MAX_DEVICES];
         const int nd = auto_devices(crtxt, pntxt, crtxtLen, devs);
@@ -2208,6 +2308,11 @@ int uaes_cmac(int keybits, const uint8_t *key, const void *data, size_t dataSize
     int rc;
     if ((rc = expand_key(&ks, key, keybits)) != 0) return rc;
     if (!mac || (dataSize && !data)) return fail(UAES_E_ARG, "NULL pointer");
+    if (host_take(data, NULL, dataSize, 1)) {
+        const uaesh_key hk = host_key(&ks);
+        uaesh_cmac(&hk, (const uint8_t *)data, dataSize, mac);
+        return 0;
+    }
     if ((rc = enter(&c, &L)) != 0) return rc;
     do {
         if ((rc = plan_io(L, data, dataSize, NULL, 0, &io)) != 0) break;
@@ -2239,6 +2344,11 @@ int uaes_ccm_encrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, s
     if ((rc = expand_key(&ks, key, keybits)) != 0) return rc;
     if (!nonce || !crtxt || (ptextLen && !pntxt)) return fail(UAES_E_ARG, "NULL pointer");
     if ((rc = ccm_lens_ok(nonceLen, tagLen)) != 0) return rc;
+    if (aDataLen && !aData) return fail(UAES_E_ARG, "NULL aData with aDataLen != 0");
+    if (!is_device_ptr(aData) && host_take(pntxt, crtxt, ptextLen, 1)) {
+        const uaesh_key hk = host_key(&ks);
+        return uaesh_ccm(&hk, 0, nonce, nonceLen, tagLen, (const uint8_t *)aData, aDataLen, (const uint8_t *)pntxt, ptextLen, (uint8_t *)crtxt);
+    }
     if ((rc = enter(&c, &L)) != 0) return rc;
     do {
         if ((rc = stage_aad(L, aData, aDataLen, &d_aad)) != 0) break;
@@ -2271,6 +2381,13 @@ int uaes_ccm_decrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, s
     if ((rc = expand_key(&ks, key, keybits)) != 0) return rc;
     if (!nonce || !crtxt || (crtxtLen && !pntxt)) return fail(UAES_E_ARG, "NULL pointer");
     if ((rc = ccm_lens_ok(nonceLen, tagLen)) != 0) return rc;
+    if (aDataLen && !aData) return fail(UAES_E_ARG, "NULL aData with aDataLen != 0");
+    if (!is_device_ptr(aData) && host_take(crtxt, pntxt, crtxtLen, 1)) {
+        const uaesh_key hk = host_key(&ks);
+        rc = uaesh_ccm(&hk, 1, nonce, nonceLen, tagLen, (const uint8_t *)aData, aDataLen, (const uint8_t *)crtxt, crtxtLen, (uint8_t *)pntxt);
+        if (rc && wipe_on_auth_failure()) memset(pntxt, 0, crtxtLen);       /* (the default leaves the text, as the reference does) */
+        return rc;
+    }
     if ((rc = enter(&c, &L)) != 0) return rc;
     do {
         if ((rc = stage_aad(L, aData, aDataLen, &d_aad)) != 0) break;
@@ -2319,6 +2436,21 @@ static int feedback_common(int keybits, const uint8_t *key, const uint8_t *iVec,
     }
     if (out_len == 0) return 0;
     if ((len && !in) || !out) return fail(UAES_E_ARG, "NULL data pointer");
+    /* the encrypting directions and OFB are ONE serial chain; the decrypting directions of CBC and CFB are block-parallel */
+    if (host_take(in, out, len, !(mode == 1 || mode == 3 || mode == 8))) {
+        const uaesh_key hk = host_key(&ks);
+        const uint8_t *x = (const uint8_t *)in;
+        uint8_t *y = (uint8_t *)out;
+        switch (mode) {
+        case 0: return uaesh_cbc_encrypt(&hk, iVec, 1, 0, x, len, y);
+        case 1: return uaesh_cbc_decrypt(&hk, iVec, 1, x, len, y);
+        case 2: uaesh_cfb(&hk, iVec, 1, x, len, y); return 0;
+        case 3: uaesh_cfb(&hk, iVec, 0, x, len, y); return 0;
+        case 4: uaesh_ofb(&hk, iVec, x, len, y); return 0;
+        case 8: return uaesh_cbc_decrypt(&hk, iVec, 0, x, len, y);
+        default: return uaesh_cbc_encrypt(&hk, iVec, 0, mode - 5, x, len, y);
+        }
+    }
     if ((rc = enter(&c, &L)) != 0) return rc;
     do {
         if ((rc = plan_io(L, in, len, out, out_len, &io)) != 0) break;
@@ -2549,6 +2681,16 @@ int uaes_gcmsiv_encrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
     if (keybits != 128 && keybits != 192 && keybits != 256)
         return fail(UAES_E_ARG, "keybits must be 128, 192 or 256 (got %d)", keybits);
     if (!key || !nonce || !crtxt || (ptextLen && !pntxt)) return fail(UAES_E_ARG, "NULL pointer");
+    if (aDataLen && !aData) return fail(UAES_E_ARG, "NULL aData with aDataLen != 0");
+    if (!is_device_ptr(aData) && host_take(pntxt, crtxt, ptextLen, 0)) {
+        keysched mk;
+        uaesh_key hk;
+        if ((rc = expand_key(&mk, key, keybits)) != 0) return rc;
+        hk = host_key(&mk);
+        rc = uaesh_gcmsiv(&hk, keybits, 0, nonce, (const uint8_t *)aData, aDataLen, (const uint8_t *)pntxt, ptextLen, (uint8_t *)crtxt, uaes_expand_key);
+        memset(&mk, 0, sizeof mk);
+        return rc;
+    }
     if ((rc = enter(&c, &L)) != 0) return rc;
     do {
         if ((rc = gcm_scratch(L)) != 0) break;
@@ -2596,6 +2738,17 @@ int uaes_gcmsiv_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
     if (keybits != 128 && keybits != 192 && keybits != 256)
         return fail(UAES_E_ARG, "keybits must be 128, 192 or 256 (got %d)", keybits);
     if (!key || !nonce || !crtxt || (crtxtLen && !pntxt)) return fail(UAES_E_ARG, "NULL pointer");
+    if (aDataLen && !aData) return fail(UAES_E_ARG, "NULL aData with aDataLen != 0");
+    if (!is_device_ptr(aData) && host_take(crtxt, pntxt, crtxtLen, 0)) {
+        keysched mk;
+        uaesh_key hk;
+        if ((rc = expand_key(&mk, key, keybits)) != 0) return rc;
+        hk = host_key(&mk);
+        rc = uaesh_gcmsiv(&hk, keybits, 1, nonce, (const uint8_t *)aData, aDataLen, (const uint8_t *)crtxt, crtxtLen, (uint8_t *)pntxt, uaes_expand_key);
+        memset(&mk, 0, sizeof mk);
+        if (rc == UAES_E_AUTHENTICATION && wipe_on_auth_failure()) memset(pntxt, 0, crtxtLen);
+        return rc;
+    }
     if ((rc = enter(&c, &L)) != 0) return rc;
     do {
         if ((rc = gcm_scratch(L)) != 0) break;
@@ -2652,6 +2805,14 @@ static int ocb_common(int keybits, const uint8_t *key, const uint8_t *nonce, siz
         return fail(UAES_E_ARG, "NULL pointer");
     if (nonceLen < 1 || nonceLen > 15) return fail(UAES_E_ARG, "OCB nonce length %zu (1..15)", nonceLen);
     if (tagLen < 1 || tagLen > 16) return fail(UAES_E_ARG, "OCB tag length %zu (1..16)", tagLen);
+    if (aDataLen && !aData) return fail(UAES_E_ARG, "NULL aData with aDataLen != 0");
+    if (!is_device_ptr(aData) && host_take(in, out, len, 0)) {
+        const uaesh_key hk = host_key(&ks);
+        rc = uaesh_ocb(&hk, decrypt, nonce, nonceLen, tagLen, (const uint8_t *)aData, aDataLen, (const uint8_t *)in, len, (uint8_t *)out);
+        if (rc < 0) return fail(UAES_E_HIP, "out of host memory");
+        if (rc == UAES_E_AUTHENTICATION && wipe_on_auth_failure()) memset(out, 0, len);
+        return rc;
+    }
     if ((rc = enter(&c, &L)) != 0) return rc;
     do {
         if ((rc = gcm_scratch(L)) != 0) break;        /* >= uaesk_ocb_scratch_bytes() */

@@ -739,12 +739,78 @@ __device__ __forceinline__ uint4 tabmul8_xor_half(uint4 a, uint4 x, const GhLane
     return make_uint4(z[0], z[1], z[2], z[3]);
 }
 
+#ifdef UAES_GHASH_XORWALK
+/* EXPERIMENT (profiles/r05_gcm_rotate_ab.log): walk the sixteen bytes of the accumulator in the order
+ * j = g ^ t instead of (g + t) mod 16.  Still sixteen different slots per service group at every step, but XOR has no
+ * carries: the WORD a lane needs at step t is word (g >> 2) ^ (t >> 2) -- two levels of v_cndmask, as before -- and the
+ * BYTE inside it is (g & 3) ^ (t & 3), which a per-lane v_perm selector picks without the four v_alignbyte of gh_rotate:
+ * 8 instead of 12 VALU per product, at the price of four more VGPRs (the selectors).                                 */
+struct GhLaneX {
+    u32 so[4];          /* byte m of so[q] = slot offset (g ^ (4q + m)) << 4 */
+    u32 sel[4];         /* v_perm selector of step t with t & 3 = m: byte 1 <- data byte (g & 3) ^ m, byte 0 <- so byte m */
+    u32 g;
+};
+
+__device__ __forceinline__ GhLaneX gh_lane_setup_x()
+{
+    const GhLane b = gh_lane_setup();
+    GhLaneX gl;
+    gl.g = b.g;
+#pragma unroll
+    for (u32 q = 0; q < 4; ++q) {
+        u32 v = 0;
+#pragma unroll
+        for (u32 m = 0; m < 4; ++m) v |= ((gl.g ^ (4 * q + m)) << 4) << (8 * m);
+        gl.so[q] = v;
+    }
+#pragma unroll
+    for (u32 m = 0; m < 4; ++m) gl.sel[m] = 0x0c0c0000u | ((4u + ((gl.g & 3u) ^ m)) << 8) | m;
+    return gl;
+}
+
+__device__ __forceinline__ uint4 tabmul8_xor_half_x(uint4 a, uint4 x, const GhLaneX &gl)
+{
+    /* u[q] = word q ^ (g >> 2) of a */
+    const bool w1 = (gl.g & 4u) != 0, w2 = (gl.g & 8u) != 0;
+    const u32 t0 = w1 ? a.y : a.x, t1 = w1 ? a.x : a.y, t2 = w1 ? a.w : a.z, t3 = w1 ? a.z : a.w;
+    const u32 r[4] = { w2 ? t2 : t0, w2 ? t3 : t1, w2 ? t0 : t2, w2 ? t1 : t3 };
+    u32 z[4] = { x.x, x.y, x.z, x.w };
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        u32x4 e[8];
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int t = 8 * h + i;
+            e[i] = *(lds_cu128 *)(uintptr_t)__builtin_amdgcn_perm(r[t >> 2], gl.so[t >> 2], gl.sel[t & 3]);
+        }
+        __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+#pragma unroll
+            for (int i = 0; i < 8; i += 2) z[w] = xor3(z[w], e[i][w], e[i + 1][w]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    return make_uint4(z[0], z[1], z[2], z[3]);
+}
+#endif
+
 template <bool DEC>
 struct GhFold {
     static constexpr bool of_input = DEC;
     static constexpr int round_prio = 2;       /* cipher lookups 2 > GHASH lookups 1 > XOR work 0 */
     static constexpr bool expand2 = false;     /* the loop body once per trip: twice would spill (128 VGPRs are all in use) */
     uint4 acc[2];
+#ifdef UAES_GHASH_XORWALK
+    GhLaneX gl;
+    __device__ __forceinline__ void operator()(const uint4 &c0, const uint4 &c1)
+    {
+        __builtin_amdgcn_sched_barrier(0);
+        acc[0] = tabmul8_xor_half_x(acc[0], c0, gl);
+        acc[1] = tabmul8_xor_half_x(acc[1], c1, gl);
+    }
+#else
     GhLane gl;
     __device__ __forceinline__ void operator()(const uint4 &c0, const uint4 &c1)
     {
@@ -752,6 +818,7 @@ struct GhFold {
         acc[0] = tabmul8_xor_half(acc[0], c0, gl);
         acc[1] = tabmul8_xor_half(acc[1], c1, gl);
     }
+#endif
 };
 
 __device__ __forceinline__ Gf gf_from4(uint4 v) { return gf_from_words(v.x, v.y, v.z, v.w); }
@@ -780,7 +847,11 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_fused(uaesk_rk rk, uaesk_tables
     GF_STAMP(1);
     const LaneConst2 lc = make_lane_const2(GF_LDS_AES);
     GhFold<DEC> fold;
+#ifdef UAES_GHASH_XORWALK
+    fold.gl = gh_lane_setup_x();
+#else
     fold.gl = gh_lane_setup();
+#endif
 
     /* tail blocks [h1, nfull) and the ragged bytes */
     ctr_edge_blocks<NR>(rk, ctr, in, out, 0, h1, nfull, rem, lc);

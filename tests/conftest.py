@@ -27,3 +27,16 @@ def orc():
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(autouse=True)
+def _gpu_tests_run_with_the_host_path_off(request):
+    """The engine's own host data path (csrc/uaes_host.c) is opt-in.  Every `-m gpu` test must find the default policy
+    (0, 0, 0) -- nothing ever runs on the host, a missing GPU fails loudly -- so that no GPU parity test can be passed
+    by host code.  (tests/test_host_path.py forces the host path in CPU tests of its own.)"""
+    if request.node.get_closest_marker("gpu") is not None:
+        import micro_aes_amd as uaes
+        assert uaes.host_policy() == (0, 0, 0), "a GPU parity test must not run with the host data path switched on"
+        for name in ("UAES_HOST_MAX", "UAES_HOST_CHAINS", "UAES_HOST_FALLBACK"):
+            assert not os.environ.get(name), "%s is set: GPU parity tests run with the host path off" % name
+    yield
