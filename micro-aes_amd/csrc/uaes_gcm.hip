@@ -129,35 +129,57 @@ __device__ __forceinline__ uint4 x4(uint4 a, uint4 b)
  * ds_read_b128 is serviced in four 16-lane groups and a 16-byte slot is
  * (addr/16) mod 16 (MI355X_MICROARCH.md, LDS), so a data-dependent row is free
  * but two lanes of a group must not share a SLOT.  Lane l therefore walks the
- * 16 bytes of its block in a rotated order -- byte (g+t) mod 16 at step t, where
- * g = position of the lane inside its service group -- so at every step the 16
+ * 16 bytes of its block in its own order -- byte g ^ t at step t, where g =
+ * position of the lane inside its service group -- so at every step the 16
  * lanes of a group read 16 different tables = 16 different slots.  (A naive
- * [j][v] layout puts the slot at v mod 16: random, ~2.9x serialisation.)     */
+ * [j][v] layout puts the slot at v mod 16: random, ~2.9x serialisation.)
+ *
+ * Why g ^ t and not (g + t) mod 16 (rounds 2-4): XOR has no carries.  The WORD a lane needs at step t is word
+ * (g >> 2) ^ (t >> 2) -- the accumulator's words permuted once per product by two levels of v_cndmask -- and the BYTE
+ * inside it is (g & 3) ^ (t & 3), which the lane's own v_perm selector (a VGPR, one per t & 3) picks: 8 VALU per
+ * product where rotating the block by g bytes took 12 (8 selects + 4 v_alignbyte).  1 GiB GCM 1262 -> 1268 GiB/s
+ * (profiles/r05_gcm_rotate_ab.log, which also says why the other 8 cannot go).                                    */
 struct GhLane {
-    u32 so[4];          /* byte k of so[q] = slot offset ((g + 4q + k) & 15) << 4 */
+    u32 so[4];          /* byte m of so[q] = slot offset (g ^ (4q + m)) << 4 */
+    u32 sel[4];         /* v_perm selector of the steps with t & 3 = m: byte 1 <- data byte (g & 3) ^ m, byte 0 <- so byte m */
     u32 g;
 };
 
-__device__ __forceinline__ GhLane gh_lane_setup()
+/* position of lane (l & 31) inside its ds_read_b128 service group:
+ * groups {0-3,12-15,20-27} and {4-11,16-19,28-31} (and the same +32)      */
+__device__ __forceinline__ u32 b128_group_pos(u32 tid = threadIdx.x)
 {
-    /* position of lane (l & 31) inside its ds_read_b128 service group:
-     * groups {0-3,12-15,20-27} and {4-11,16-19,28-31} (and the same +32)      */
-    const u32 l = threadIdx.x & 31u;
+    const u32 l = tid & 31u;
     const u64 pack_lo = 0x7654765432103210ull;     /* lanes 0..15  */
     const u64 pack_hi = 0xfedcfedcba98ba98ull;     /* lanes 16..31 */
+    return (u32)(((l & 16u) ? pack_hi : pack_lo) >> (4 * (l & 15u))) & 15u;
+}
+
+__device__ __forceinline__ GhLane gh_lane_setup()
+{
     GhLane gl;
-    gl.g = (u32)(((l & 16u) ? pack_hi : pack_lo) >> (4 * (l & 15u))) & 15u;
+    gl.g = b128_group_pos();
 #pragma unroll
     for (u32 q = 0; q < 4; ++q) {
         u32 v = 0;
 #pragma unroll
-        for (u32 k = 0; k < 4; ++k) v |= (((gl.g + 4 * q + k) & 15u) << 4) << (8 * k);
+        for (u32 m = 0; m < 4; ++m) v |= ((gl.g ^ (4 * q + m)) << 4) << (8 * m);
         gl.so[q] = v;
     }
+#pragma unroll
+    for (u32 m = 0; m < 4; ++m) gl.sel[m] = 0x0c0c0000u | ((4u + ((gl.g & 3u) ^ m)) << 8) | m;
     return gl;
 }
 
-/* bytes of a rotated left by g: result byte k = a byte (k + g) mod 16 */
+/* r[q] = word q ^ (g >> 2) of a */
+__device__ __forceinline__ void gh_words(const uint4 a, u32 g, u32 (&r)[4])
+{
+    const bool w1 = (g & 4u) != 0, w2 = (g & 8u) != 0;
+    const u32 t0 = w1 ? a.y : a.x, t1 = w1 ? a.x : a.y, t2 = w1 ? a.w : a.z, t3 = w1 ? a.z : a.w;
+    r[0] = w2 ? t2 : t0; r[1] = w2 ? t3 : t1; r[2] = w2 ? t0 : t2; r[3] = w2 ? t1 : t3;
+}
+
+/* bytes of a rotated left by g: result byte k = a byte (k + g) mod 16 (the nibble-table products below) */
 __device__ __forceinline__ void gh_rotate(const uint4 a, u32 g, u32 (&r)[4])
 {
     const bool w1 = (g & 4u) != 0, w2 = (g & 8u) != 0;
@@ -177,13 +199,12 @@ typedef __attribute__((address_space(3))) const u32x4 lds_cu128;
 __device__ __forceinline__ uint4 tabmul8_xor(uint4 a, uint4 x, const GhLane &gl)
 {
     u32 r[4];
-    gh_rotate(a, gl.g, r);
+    gh_words(a, gl.g, r);
     u32x4 e[16];
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
-        /* address = (byte t of the rotated block) << 8 | slot offset of step t */
-        const u32 sel = 0x0c0c0000u | ((4u + (t & 3)) << 8) | (u32)(t & 3);
-        const u32 addr = __builtin_amdgcn_perm(r[t >> 2], gl.so[t >> 2], sel);
+        /* address = (byte g ^ t of the block) << 8 | slot offset of step t */
+        const u32 addr = __builtin_amdgcn_perm(r[t >> 2], gl.so[t >> 2], gl.sel[t & 3]);
         e[t] = *(lds_cu128 *)(uintptr_t)addr;
     }
     /* 17 inputs per dword -> 8 three-input XORs */
@@ -208,15 +229,6 @@ __device__ __forceinline__ uint4 tabmul8_xor(uint4 a, uint4 x, const GhLane &gl)
 __device__ __forceinline__ u32 nib_entry(u32 p, u32 v)
 {
     return v * 32u + (p >> 1) + ((p & 1u) << 4);
-}
-
-/* position of the lane inside its ds_read_b128 service group (gh_lane_setup) */
-__device__ __forceinline__ u32 b128_group_pos(u32 tid = threadIdx.x)
-{
-    const u32 l = tid & 31u;
-    const u64 pack_lo = 0x7654765432103210ull;     /* lanes 0..15  */
-    const u64 pack_hi = 0xfedcfedcba98ba98ull;     /* lanes 16..31 */
-    return (u32)(((l & 16u) ? pack_hi : pack_lo) >> (4 * (l & 15u))) & 15u;
 }
 
 /* a * M, every lane its own product */
@@ -696,84 +708,7 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_setup(uaesk_rk ek, uaesk_tables
 __device__ __forceinline__ uint4 tabmul8_xor_half(uint4 a, uint4 x, const GhLane &gl)
 {
     u32 r[4];
-    gh_rotate(a, gl.g, r);
-    u32 z[4] = { x.x, x.y, x.z, x.w };
-#ifdef UAES_GHASH_FULL
-    /* experiment: all sixteen lookups of the product in flight at once (64 registers of table entries) */
-    {
-        u32x4 e[16];
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const u32 sel = 0x0c0c0000u | ((4u + (t & 3)) << 8) | (u32)(t & 3);
-            e[t] = *(lds_cu128 *)(uintptr_t)__builtin_amdgcn_perm(r[t >> 2], gl.so[t >> 2], sel);
-        }
-        __builtin_amdgcn_s_setprio(0);
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-#pragma unroll
-            for (int i = 0; i < 16; i += 2) z[w] = xor3(z[w], e[i][w], e[i + 1][w]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        return make_uint4(z[0], z[1], z[2], z[3]);
-    }
-#endif
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        u32x4 e[8];
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int t = 8 * h + i;
-            const u32 sel = 0x0c0c0000u | ((4u + (t & 3)) << 8) | (u32)(t & 3);
-            e[i] = *(lds_cu128 *)(uintptr_t)__builtin_amdgcn_perm(r[t >> 2], gl.so[t >> 2], sel);
-        }
-        __builtin_amdgcn_s_setprio(0);
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-#pragma unroll
-            for (int i = 0; i < 8; i += 2) z[w] = xor3(z[w], e[i][w], e[i + 1][w]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    return make_uint4(z[0], z[1], z[2], z[3]);
-}
-
-#ifdef UAES_GHASH_XORWALK
-/* EXPERIMENT (profiles/r05_gcm_rotate_ab.log): walk the sixteen bytes of the accumulator in the order
- * j = g ^ t instead of (g + t) mod 16.  Still sixteen different slots per service group at every step, but XOR has no
- * carries: the WORD a lane needs at step t is word (g >> 2) ^ (t >> 2) -- two levels of v_cndmask, as before -- and the
- * BYTE inside it is (g & 3) ^ (t & 3), which a per-lane v_perm selector picks without the four v_alignbyte of gh_rotate:
- * 8 instead of 12 VALU per product, at the price of four more VGPRs (the selectors).                                 */
-struct GhLaneX {
-    u32 so[4];          /* byte m of so[q] = slot offset (g ^ (4q + m)) << 4 */
-    u32 sel[4];         /* v_perm selector of step t with t & 3 = m: byte 1 <- data byte (g & 3) ^ m, byte 0 <- so byte m */
-    u32 g;
-};
-
-__device__ __forceinline__ GhLaneX gh_lane_setup_x()
-{
-    const GhLane b = gh_lane_setup();
-    GhLaneX gl;
-    gl.g = b.g;
-#pragma unroll
-    for (u32 q = 0; q < 4; ++q) {
-        u32 v = 0;
-#pragma unroll
-        for (u32 m = 0; m < 4; ++m) v |= ((gl.g ^ (4 * q + m)) << 4) << (8 * m);
-        gl.so[q] = v;
-    }
-#pragma unroll
-    for (u32 m = 0; m < 4; ++m) gl.sel[m] = 0x0c0c0000u | ((4u + ((gl.g & 3u) ^ m)) << 8) | m;
-    return gl;
-}
-
-__device__ __forceinline__ uint4 tabmul8_xor_half_x(uint4 a, uint4 x, const GhLaneX &gl)
-{
-    /* u[q] = word q ^ (g >> 2) of a */
-    const bool w1 = (gl.g & 4u) != 0, w2 = (gl.g & 8u) != 0;
-    const u32 t0 = w1 ? a.y : a.x, t1 = w1 ? a.x : a.y, t2 = w1 ? a.w : a.z, t3 = w1 ? a.z : a.w;
-    const u32 r[4] = { w2 ? t2 : t0, w2 ? t3 : t1, w2 ? t0 : t2, w2 ? t1 : t3 };
+    gh_words(a, gl.g, r);
     u32 z[4] = { x.x, x.y, x.z, x.w };
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -794,7 +729,6 @@ __device__ __forceinline__ uint4 tabmul8_xor_half_x(uint4 a, uint4 x, const GhLa
     }
     return make_uint4(z[0], z[1], z[2], z[3]);
 }
-#endif
 
 template <bool DEC>
 struct GhFold {
@@ -802,15 +736,6 @@ struct GhFold {
     static constexpr int round_prio = 2;       /* cipher lookups 2 > GHASH lookups 1 > XOR work 0 */
     static constexpr bool expand2 = false;     /* the loop body once per trip: twice would spill (128 VGPRs are all in use) */
     uint4 acc[2];
-#ifdef UAES_GHASH_XORWALK
-    GhLaneX gl;
-    __device__ __forceinline__ void operator()(const uint4 &c0, const uint4 &c1)
-    {
-        __builtin_amdgcn_sched_barrier(0);
-        acc[0] = tabmul8_xor_half_x(acc[0], c0, gl);
-        acc[1] = tabmul8_xor_half_x(acc[1], c1, gl);
-    }
-#else
     GhLane gl;
     __device__ __forceinline__ void operator()(const uint4 &c0, const uint4 &c1)
     {
@@ -818,7 +743,6 @@ struct GhFold {
         acc[0] = tabmul8_xor_half(acc[0], c0, gl);
         acc[1] = tabmul8_xor_half(acc[1], c1, gl);
     }
-#endif
 };
 
 __device__ __forceinline__ Gf gf_from4(uint4 v) { return gf_from_words(v.x, v.y, v.z, v.w); }
@@ -847,11 +771,7 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_fused(uaesk_rk rk, uaesk_tables
     GF_STAMP(1);
     const LaneConst2 lc = make_lane_const2(GF_LDS_AES);
     GhFold<DEC> fold;
-#ifdef UAES_GHASH_XORWALK
-    fold.gl = gh_lane_setup_x();
-#else
     fold.gl = gh_lane_setup();
-#endif
 
     /* tail blocks [h1, nfull) and the ragged bytes */
     ctr_edge_blocks<NR>(rk, ctr, in, out, 0, h1, nfull, rem, lc);
