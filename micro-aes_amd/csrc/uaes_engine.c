@@ -1666,7 +1666,7 @@ int uaes_gcm_encrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, s
     if (tagLen < 1 || tagLen > 16) return fail(UAES_E_ARG, "GCM tag length %zu (1..16)", tagLen);
     if (nonceLen == 0) return fail(UAES_E_ARG, "empty GCM nonce");
     if (aDataLen && !aData) return fail(UAES_E_ARG, "NULL aData with aDataLen != 0");
-    if (!is_device_ptr(aData) && host_take(pntxt, crtxt, ptextLen, 0)) {
+    if (host_take(pntxt, crtxt, ptextLen, 0) && !is_device_ptr(aData)) {
         const uaesh_key hk = host_key(&ks);
         return uaesh_gcm(&hk, 0, nonce, nonceLen, tagLen, (const uint8_t *)aData, aDataLen, (const uint8_t *)pntxt, ptextLen, (uint8_t *)crtxt);
     }
@@ -1727,7 +1727,7 @@ int uaes_gcm_decrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, s
     if (tagLen < 1 || tagLen > 16) return fail(UAES_E_ARG, "GCM tag length %zu (1..16)", tagLen);
     if (nonceLen == 0) return fail(UAES_E_ARG, "empty GCM nonce");
     if (aDataLen && !aData) return fail(UAES_E_ARG, "NULL aData with aDataLen != 0");
-    if (!is_device_ptr(aData) && host_take(crtxt, pntxt, crtxtLen, 0)) {
+    if (host_take(crtxt, pntxt, crtxtLen, 0) && !is_device_ptr(aData)) {
         const uaesh_key hk = host_key(&ks);
         return uaesh_gcm(&hk, 1, nonce, nonceLen, tagLen, (const uint8_t *)aData, aDataLen, (const uint8_t *)crtxt, crtxtLen, (uint8_t *)pntxt);
     }
@@ -2345,7 +2345,7 @@ int uaes_ccm_encrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, s
     if (!nonce || !crtxt || (ptextLen && !pntxt)) return fail(UAES_E_ARG, "NULL pointer");
     if ((rc = ccm_lens_ok(nonceLen, tagLen)) != 0) return rc;
     if (aDataLen && !aData) return fail(UAES_E_ARG, "NULL aData with aDataLen != 0");
-    if (!is_device_ptr(aData) && host_take(pntxt, crtxt, ptextLen, 1)) {
+    if (host_take(pntxt, crtxt, ptextLen, 1) && !is_device_ptr(aData)) {
         const uaesh_key hk = host_key(&ks);
         return uaesh_ccm(&hk, 0, nonce, nonceLen, tagLen, (const uint8_t *)aData, aDataLen, (const uint8_t *)pntxt, ptextLen, (uint8_t *)crtxt);
     }
@@ -2382,7 +2382,7 @@ int uaes_ccm_decrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, s
     if (!nonce || !crtxt || (crtxtLen && !pntxt)) return fail(UAES_E_ARG, "NULL pointer");
     if ((rc = ccm_lens_ok(nonceLen, tagLen)) != 0) return rc;
     if (aDataLen && !aData) return fail(UAES_E_ARG, "NULL aData with aDataLen != 0");
-    if (!is_device_ptr(aData) && host_take(crtxt, pntxt, crtxtLen, 1)) {
+    if (host_take(crtxt, pntxt, crtxtLen, 1) && !is_device_ptr(aData)) {
         const uaesh_key hk = host_key(&ks);
         rc = uaesh_ccm(&hk, 1, nonce, nonceLen, tagLen, (const uint8_t *)aData, aDataLen, (const uint8_t *)crtxt, crtxtLen, (uint8_t *)pntxt);
         if (rc && wipe_on_auth_failure()) memset(pntxt, 0, crtxtLen);       /* (the default leaves the text, as the reference does) */
@@ -2682,7 +2682,7 @@ int uaes_gcmsiv_encrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
         return fail(UAES_E_ARG, "keybits must be 128, 192 or 256 (got %d)", keybits);
     if (!key || !nonce || !crtxt || (ptextLen && !pntxt)) return fail(UAES_E_ARG, "NULL pointer");
     if (aDataLen && !aData) return fail(UAES_E_ARG, "NULL aData with aDataLen != 0");
-    if (!is_device_ptr(aData) && host_take(pntxt, crtxt, ptextLen, 0)) {
+    if (host_take(pntxt, crtxt, ptextLen, 0) && !is_device_ptr(aData)) {
         keysched mk;
         uaesh_key hk;
         if ((rc = expand_key(&mk, key, keybits)) != 0) return rc;
@@ -2739,7 +2739,7 @@ int uaes_gcmsiv_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
         return fail(UAES_E_ARG, "keybits must be 128, 192 or 256 (got %d)", keybits);
     if (!key || !nonce || !crtxt || (crtxtLen && !pntxt)) return fail(UAES_E_ARG, "NULL pointer");
     if (aDataLen && !aData) return fail(UAES_E_ARG, "NULL aData with aDataLen != 0");
-    if (!is_device_ptr(aData) && host_take(crtxt, pntxt, crtxtLen, 0)) {
+    if (host_take(crtxt, pntxt, crtxtLen, 0) && !is_device_ptr(aData)) {
         keysched mk;
         uaesh_key hk;
         if ((rc = expand_key(&mk, key, keybits)) != 0) return rc;
@@ -2806,7 +2806,7 @@ static int ocb_common(int keybits, const uint8_t *key, const uint8_t *nonce, siz
     if (nonceLen < 1 || nonceLen > 15) return fail(UAES_E_ARG, "OCB nonce length %zu (1..15)", nonceLen);
     if (tagLen < 1 || tagLen > 16) return fail(UAES_E_ARG, "OCB tag length %zu (1..16)", tagLen);
     if (aDataLen && !aData) return fail(UAES_E_ARG, "NULL aData with aDataLen != 0");
-    if (!is_device_ptr(aData) && host_take(in, out, len, 0)) {
+    if (host_take(in, out, len, 0) && !is_device_ptr(aData)) {
         const uaesh_key hk = host_key(&ks);
         rc = uaesh_ocb(&hk, decrypt, nonce, nonceLen, tagLen, (const uint8_t *)aData, aDataLen, (const uint8_t *)in, len, (uint8_t *)out);
         if (rc < 0) return fail(UAES_E_HIP, "out of host memory");

@@ -1506,3 +1506,32 @@ def test_xts_partial_last_round_of_chunks(orc, sector_bytes, nsectors):
     uaes.xts_sectors_dev(keys, 1 << 33, sector_bytes, nsectors, dst, back, encrypt=False)
     torch.cuda.synchronize()
     assert torch.equal(back, src)
+
+
+@pytest.mark.parametrize("bits", [128, 192, 256])
+def test_ecb_partial_last_round_of_tiles(orc, bits):
+    """k_ecb's remainder path.  One round = 256 workgroups x 64 KiB tiles = 16 MiB; a last round that
+    covers less than 80 % of the grid is handed over as single blocks over all workgroups ([tail_from, nfull)), a fuller
+    one runs as whole tiles through the buffer-resource loads with idle workgroups.  Sizes on both sides of that switch,
+    each with a trailing partial block and every padding mode, both directions, against the oracle (SHA-256)."""
+    import torch
+    L = uaes.engine()
+    tile, rnd_bytes = 64 << 10, 16 << 20
+    key = bytes(range(7, 7 + bits // 8))
+    dev = torch.device("cuda", 0)
+    for n, padding in (((5 * rnd_bytes) // 2 + 5, 0),                  # 2.5 rounds: the remainder as single blocks
+                       (2 * rnd_bytes + tile + 16 * 3 + 11, 1),        # 2 rounds + 1 tile (+ 3 blocks + 11 bytes), PKCS#7
+                       (3 * rnd_bytes - tile + 7, 2),                  # 3 rounds - 1 tile: whole tiles, ISO 7816-4
+                       (2 * rnd_bytes + 13 * tile, 0),                 # no ragged tail, 80 % boundary side A
+                       (2 * rnd_bytes + 204 * tile + 16, 1)):          # just under 80 % of a round: single blocks
+        pt = orc.splitmix(n % 251 + bits, n + 8)[:n]
+        want = orc.ecb_encrypt(key, pt, padding)
+        src = torch.frombuffer(bytearray(pt + bytes(32)), dtype=torch.uint8).to(dev)
+        dst = torch.zeros(len(want) + 32, dtype=torch.uint8, device=dev)
+        assert L.uaes_ecb_encrypt_padded(bits, key, padding, C.c_void_p(src.data_ptr()), n, C.c_void_p(dst.data_ptr())) == 0
+        got = dst.cpu().numpy().tobytes()
+        assert hashlib.sha256(got[: len(want)]).digest() == hashlib.sha256(want).digest(), (bits, n, padding)
+        assert got[len(want):] == bytes(32)                                         # nothing beyond the last block
+        back = torch.zeros(len(want), dtype=torch.uint8, device=dev)
+        assert L.uaes_ecb_decrypt(bits, key, C.c_void_p(dst.data_ptr()), len(want), C.c_void_p(back.data_ptr())) == 0
+        assert back[:n].cpu().numpy().tobytes() == pt, (bits, n, padding)
