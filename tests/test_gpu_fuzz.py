@@ -522,3 +522,136 @@ def test_fuzz_gcm_record_calls_of_different_lengths(orc):
             k.close()
 
     run_cases(1010, 12, body)
+
+
+def test_fuzz_mgpu_split(orc):
+    """uaes_mgpu_{ctr,ecb,gcm,xts}: random device lists over the visible devices (an ordinal may repeat), random
+    buffer placement (host / device, aligned or not, in place), sizes around the slicing boundaries -- the result is the
+    one-call result whatever the list; a forged GCM text leaves the plaintext buffer as it was (N7 across devices)"""
+    import torch
+    L = uaes.engine()
+    ndev_visible = torch.cuda.device_count()
+
+    def body(rnd, i):
+        nd = rnd.choice([1, 2, 3, 5, 8, 16])
+        devlist = [rnd.randrange(ndev_visible) for _ in range(nd)]
+        devs = (C.c_int * nd)(*devlist)
+        bits = rnd.choice([128, 192, 256])
+        key = rnd.randbytes(bits // 8)
+        n = pick_size(rnd, 1 << 20) if rnd.random() < 0.8 else rnd.randrange(0, 16 * nd + 40)
+        data = orc.splitmix(7000 + i, n)
+        which = rnd.choice(["ctr", "ecb", "gcm", "xts"])
+        if which == "ctr":
+            ctr0, off = rnd.randbytes(9) + rnd.choice([bytes(7), b"\xff" * 7, rnd.randbytes(7)]), rnd.choice([0, 3, (1 << 40) + 7])
+            b = Buffers(rnd, data, n)
+            info = ("mgpu-ctr", devlist, bits, n, b.describe())
+            assert L.uaes_mgpu_ctr_xcrypt_at(nd, devs, bits, key, ctr0, off, b.pin, n, b.pout) == 0, info
+            got, guard_ok = b.result()
+            assert got == orc.ctr_xcrypt_at(key, ctr0, off, data) and guard_ok, info
+        elif which == "ecb":
+            padding = rnd.choice([0, 0, 1, 2])
+            want = orc.ecb_encrypt(key, data, padding)
+            b = Buffers(rnd, data, len(want))
+            info = ("mgpu-ecb", devlist, bits, n, padding, b.describe())
+            assert L.uaes_mgpu_ecb_encrypt(nd, devs, bits, key, padding, b.pin, n, b.pout) == 0, info
+            got, guard_ok = b.result()
+            assert got == want and guard_ok, info
+            b = Buffers(rnd, want, len(want))
+            assert L.uaes_mgpu_ecb_decrypt(nd, devs, bits, key, b.pin, len(want), b.pout) == 0, info
+            assert b.result()[0][:n] == data, info
+        elif which == "gcm":
+            nonce, aad = rnd.randbytes(12), rnd.randbytes(rnd.choice([0, 0, 1, 16, 33, 4097]))
+            want = orc.gcm_encrypt(key, nonce, aad, data)
+            b = Buffers(rnd, data, n + 16)
+            info = ("mgpu-gcm", devlist, bits, n, len(aad), b.describe())
+            assert L.uaes_mgpu_gcm_encrypt(nd, devs, bits, key, nonce, aad, len(aad), b.pin, n, b.pout) == 0, info
+            got, guard_ok = b.result()
+            assert got == want and guard_ok, info
+            b = Buffers(rnd, want, n)
+            assert L.uaes_mgpu_gcm_decrypt(nd, devs, bits, key, nonce, aad, len(aad), b.pin, n, b.pout) == 0, info
+            assert b.result()[0] == data, info
+            bad = bytearray(want)
+            bad[rnd.randrange(len(bad))] ^= 1 << rnd.randrange(8)
+            b = Buffers(rnd, bytes(bad), n)
+            assert L.uaes_mgpu_gcm_decrypt(nd, devs, bits, key, nonce, aad, len(aad), b.pin, n, b.pout) == 0x1A, info
+            if not b.alias:
+                assert all(x == b.guard for x in b.result()[0]), info
+        else:
+            keys = rnd.randbytes(bits // 4)
+            sb = rnd.choice([16, 17, 512, 4096, 4099])
+            ns = rnd.randrange(1, 60)
+            first = rnd.choice([0, 1, (1 << 32) - 1, rnd.getrandbits(60)])
+            data = orc.splitmix(7500 + i, sb * ns)
+            b = Buffers(rnd, data, sb * ns)
+            info = ("mgpu-xts", devlist, bits, sb, ns, first, b.describe())
+            assert L.uaes_mgpu_xts_sectors(nd, devs, bits, keys, first, sb, ns, b.pin, b.pout, 1) == 0, info
+            got, guard_ok = b.result()
+            assert got == orc.xts_sectors(keys, first, sb, data, True)[1] and guard_ok, info
+
+    run_cases(707, 120, body)
+
+
+def test_fuzz_kernels_against_the_host_path(orc):
+    """the two product implementations against each other: every one-message mode on random inputs, once on the GPU
+    (default policy) and once on the engine's own host path (forced for the second call and switched off again) -- and
+    both against the oracle.  Also what the opt-in promises: device pointers never take the host path."""
+    import torch
+    L = uaes.engine()
+
+    def both(fn):
+        gpu = fn()
+        prev = uaes.host_policy(1 << 62, 1, 0)
+        try:
+            host = fn()
+        finally:
+            uaes.host_policy(*prev)
+        assert uaes.host_policy() == (0, 0, 0)
+        return gpu, host
+
+    def body(rnd, i):
+        bits = rnd.choice([128, 192, 256])
+        key, iv, nonce = rnd.randbytes(bits // 8), rnd.randbytes(16), rnd.randbytes(12)
+        n = pick_size(rnd, 200000)
+        data, aad = orc.splitmix(9000 + i, n), rnd.randbytes(rnd.choice([0, 1, 16, 40]))
+        info = (bits, n, len(aad))
+        g, h = both(lambda: uaes.AES_CTR_encrypt(key, nonce, data))
+        assert g == h == orc.ctr_encrypt(key, nonce, data), ("ctr",) + info
+        pad = rnd.choice([0, 1, 2])
+        g, h = both(lambda: uaes.AES_ECB_encrypt(key, data, pad))
+        assert g == h == orc.ecb_encrypt(key, data, pad), ("ecb",) + info
+        g, h = both(lambda: uaes.AES_GCM_encrypt(key, nonce, aad, data))
+        assert g == h == orc.gcm_encrypt(key, nonce, aad, data), ("gcm",) + info
+        g2, h2 = both(lambda: uaes.AES_GCM_decrypt(key, nonce, aad, g))
+        assert g2 == h2 == (0, data)
+        g, h = both(lambda: uaes.AES_OCB_encrypt(key, nonce, aad, data))
+        assert g == h == orc.ocb_encrypt(key, nonce, aad, data), ("ocb",) + info
+        g, h = both(lambda: uaes.GCM_SIV_encrypt(key, nonce, aad, data[:30000]))
+        assert g == h == orc.gcmsiv_encrypt(key, nonce, aad, data[:30000]), ("gcmsiv",) + info
+        g, h = both(lambda: uaes.AES_CCM_encrypt(key, nonce[:11], aad, data[:20000]))
+        assert g == h == orc.ccm_encrypt(key, nonce[:11], aad, data[:20000]), ("ccm",) + info
+        g, h = both(lambda: uaes.AES_CMAC(key, data[:20000]))
+        assert g == h == orc.cmac(key, data[:20000]), ("cmac",) + info
+        g, h = both(lambda: uaes.AES_CFB_encrypt(key, iv, data[:20000]))
+        assert g == h == orc.cfb(key, iv, data[:20000], True), ("cfb",) + info
+        g, h = both(lambda: uaes.AES_OFB_encrypt(key, iv, data[:20000]))
+        assert g == h == orc.ofb(key, iv, data[:20000]), ("ofb",) + info
+        if n >= 16:
+            keys = rnd.randbytes(bits // 4)
+            g, h = both(lambda: uaes.AES_XTS_encrypt(keys, iv, data))
+            assert g == h == orc.xts(keys, iv, data, True), ("xts",) + info
+            g, h = both(lambda: uaes.AES_CBC_encrypt(key, iv, data[:20000 + n % 16]))
+            assert g == h and g[1] == orc.cbc(key, iv, data[:20000 + n % 16], True)[1], ("cbc",) + info
+            g, h = both(lambda: uaes.AES_CBC_decrypt(key, iv, g[1]))
+            assert g == h == (0, data[:20000 + n % 16])
+
+    run_cases(909, 40, body)
+    # device pointers stay on the GPU even with the host path switched on: a host routine would fault on them
+    prev = uaes.host_policy(1 << 62, 1, 0)
+    try:
+        t = torch.zeros(4096, dtype=torch.uint8, device="cuda:0")
+        o = torch.zeros(4096 + 16, dtype=torch.uint8, device="cuda:0")
+        assert L.uaes_ctr_xcrypt(128, bytes(16), bytes(12), C.c_void_p(t.data_ptr()), 4096, C.c_void_p(o.data_ptr())) == 0
+        assert bytes(o[:4096].cpu().numpy()) == orc.ctr_encrypt(bytes(16), bytes(12), bytes(4096))
+        assert L.uaes_cmac(128, bytes(16), C.c_void_p(t.data_ptr()), 4096, (C.c_uint8 * 16)()) == 0
+    finally:
+        uaes.host_policy(*prev)
