@@ -508,6 +508,17 @@ int uaes_gcm_partial_dev(int keybits, const uint8_t *key, const uint8_t *nonce,
                          const void *d_ct_shard, size_t shard_len, uint64_t shard_offset,
                          uint64_t total_len, void *d_partial16, void *stream);
 
+/* ... and the shard's CTR pass with it, in ONE pass over the text (what uaes_mgpu_gcm_* run per device): mode 0
+ * encrypts d_in -> d_out (keystream block J0 + 1 + shard_offset / 16 onwards) and hashes d_out; mode 1 = the call
+ * above (d_out unused); mode 2 decrypts d_in -> d_out and hashes d_in -- d_out is written before any tag is known: a
+ * caller that must keep N7 (micro_aes.c:1200-1208) runs mode 1 on every shard first, compares the XOR of the shares
+ * with the tag, and only then decrypts (uaes_ctr_xcrypt_at_dev at block offset 1 + shard_offset / 16).  Every shard
+ * but the last is a multiple of 16 bytes; d_in == d_out is allowed.  Enqueue only.                               */
+int uaes_gcm_shard_dev(int keybits, const uint8_t *key, const uint8_t *nonce, int mode,
+                       const void *d_aad, uint64_t total_aad_len,
+                       const void *d_in, size_t shard_len, uint64_t shard_offset, uint64_t total_len,
+                       void *d_out, void *d_partial16, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

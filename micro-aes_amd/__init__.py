@@ -54,7 +54,7 @@ EXPORTS = [
     "uaes_gcm_stream_begin", "uaes_gcm_stream_update", "uaes_gcm_stream_finish", "uaes_gcm_stream_abort",
     "uaes_cbc_encrypt_batch", "uaes_cmac_batch", "uaes_cbc_encrypt", "uaes_cbc_decrypt", "uaes_cbc_encrypt_padded", "uaes_cbc_decrypt_blocks", "uaes_cfb_encrypt", "uaes_cfb_decrypt", "uaes_ofb_xcrypt",
     "uaes_ecb_dev", "uaes_ctr_xcrypt_at_dev", "uaes_xts_sectors_dev",
-    "uaes_gcm_encrypt_dev", "uaes_gcm_decrypt_dev", "uaes_gcm_partial_dev",
+    "uaes_gcm_encrypt_dev", "uaes_gcm_decrypt_dev", "uaes_gcm_partial_dev", "uaes_gcm_shard_dev",
 ]
 COMPAT_EXPORTS = [
     "AES_ECB_encrypt", "AES_ECB_encrypt_pkcs7", "AES_ECB_encrypt_iso7816", "AES_ECB_decrypt",
@@ -180,6 +180,7 @@ def engine():
     L.uaes_gcm_encrypt_dev.argtypes = [i, vp, vp, vp, sz, vp, sz, vp, vp]
     L.uaes_gcm_decrypt_dev.argtypes = [i, vp, vp, vp, sz, vp, sz, vp, vp, vp]
     L.uaes_gcm_partial_dev.argtypes = [i, vp, vp, vp, u64, vp, sz, u64, u64, vp, vp]
+    L.uaes_gcm_shard_dev.argtypes = [i, vp, vp, i, vp, u64, vp, sz, u64, u64, vp, vp, vp]
     L.uaes_expand_key.argtypes = [i, vp, vp, vp]
     for n in EXPORTS:
         if n not in ("uaes_last_error", "uaes_version", "uaes_gcm_key_free", "uaes_gcm_stream_abort"):
@@ -801,3 +802,11 @@ def gcm_partial_dev(key, nonce, aad, total_aad_len, ct_shard, shard_len, shard_o
     _check(engine().uaes_gcm_partial_dev(_bits(key), _in(key), _fixed(nonce, 12, "nonce"), _ptr(aad), total_aad_len,
                                          _ptr(ct_shard), shard_len, shard_offset, total_len, _ptr(partial),
                                          _stream(stream)), "uaes_gcm_partial_dev")
+
+
+def gcm_shard_dev(key, nonce, mode, aad, total_aad_len, src, shard_len, shard_offset, total_len, dst, partial, stream=None):
+    """This shard's CTR pass (mode 0 encrypt / 2 decrypt; 1 = hash only) fused with its 16-byte share of the tag
+    (uaes_gcm_shard_dev): one pass over the text."""
+    _check(engine().uaes_gcm_shard_dev(_bits(key), _in(key), _fixed(nonce, 12, "nonce"), mode, _ptr(aad), total_aad_len,
+                                       _ptr(src), shard_len, shard_offset, total_len, _ptr(dst), _ptr(partial),
+                                       _stream(stream)), "uaes_gcm_shard_dev")

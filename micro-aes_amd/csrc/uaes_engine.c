@@ -2275,6 +2275,33 @@ int uaes_gcm_partial_dev(int keybits, const uint8_t *key, const uint8_t *nonce,
     return 0;
 }
 
+/* the shard's CTR pass and its share in ONE pass on the caller's stream (uaesk_gcm_shard): what a rank of a
+ * one-process-per-GPU job runs on its slice of one GCM message */
+int uaes_gcm_shard_dev(int keybits, const uint8_t *key, const uint8_t *nonce, int mode,
+                       const void *d_aad, uint64_t total_aad_len,
+                       const void *d_in, size_t shard_len, uint64_t shard_offset, uint64_t total_len,
+                       void *d_out, void *d_partial16, void *stream)
+{
+    context *c;
+    keysched ks;
+    void *scr;
+    int rc, slot;
+    if ((rc = expand_key(&ks, key, keybits)) != 0) return rc;
+    if (!nonce || !d_partial16) return fail(UAES_E_ARG, "NULL pointer");
+    if (mode < 0 || mode > 2) return fail(UAES_E_ARG, "mode %d (0 encrypt, 1 hash only, 2 decrypt)", mode);
+    if ((((uintptr_t)d_in) | ((uintptr_t)(mode == 1 ? NULL : d_out))) & 15u)
+        return fail(UAES_E_ARG, "the shard buffers must be 16-byte aligned");
+    if (shard_len && (!d_in || (mode != 1 && !d_out))) return fail(UAES_E_ARG, "NULL shard buffer");
+    if (shard_offset % 16 || shard_offset + shard_len > total_len || (shard_len % 16 && shard_offset + shard_len != total_len))
+        return fail(UAES_E_ARG, "shard [%llu, +%zu) is not a 16-byte aligned slice of %llu bytes",
+                    (unsigned long long)shard_offset, shard_len, (unsigned long long)total_len);
+    if ((rc = get_context(&c)) != 0) return rc;
+    if ((rc = gcm_scratch_locked(c, stream, &scr, &slot)) != 0) return rc;
+    KCHK_PINNED(c, slot, uaesk_gcm_shard(stream, &c->tb, ks.nr, &ks.ek, mode, nonce, d_aad, total_aad_len,
+                                         d_in, shard_len, shard_offset, total_len, d_out, scr, d_partial16));
+    return 0;
+}
+
 int uaes_ghash(const uint8_t H[16], const void *aData, size_t aDataLen,
                const void *crtxt, size_t crtxtLen, uint8_t gh[16])
 {

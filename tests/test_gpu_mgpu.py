@@ -304,3 +304,57 @@ def test_compat_calls_wait_for_a_named_producer_stream(orc):
             assert hashlib.sha256(dst.cpu().numpy().tobytes()).hexdigest() == want, trial
     finally:
         K.uaes_compat_set_producer_stream(None)
+
+
+def test_gcm_shard_dev_one_pass_per_rank(orc):
+    """uaes_gcm_shard_dev -- what a rank of a one-process-per-GPU job runs on its slice: CTR and the weighted share in
+    ONE pass (mode 0), the hash-only share (mode 1) and the one-pass decrypt (mode 2), for 1..5 shards of texts on both
+    sides of the striped kernel's minimum; the XOR of the shares is the reference's tag; sharding.gcm_encrypt_sharded /
+    gcm_decrypt_sharded drive it with a stand-in exchange"""
+    import torch
+    from micro_aes_amd import sharding as sh
+    dev = torch.device("cuda", 0)
+    key, nonce, aad = bytes(range(5, 21)), bytes(range(12)), b"header bytes"
+    d_aad = torch.frombuffer(bytearray(aad), dtype=torch.uint8).to(dev)
+    for total, world in ((0, 2), (100, 3), ((40 << 20) + 37, 2), ((40 << 20) + 37, 5)):
+        pt = orc.splitmix(total % 97, total + 8)[:total]
+        want = orc.gcm_encrypt(key, nonce, aad, pt)
+        src = torch.frombuffer(bytearray(pt + bytes(16)), dtype=torch.uint8).to(dev)
+        ct = torch.zeros(total + 16, dtype=torch.uint8, device=dev)
+        shares = []
+        for rank in range(world):
+            start, n, takes = sh.gcm_shard_roles(total, rank, world)
+            if not takes:
+                continue
+            p = torch.zeros(16, dtype=torch.uint8, device=dev)
+            uaes.gcm_shard_dev(key, nonce, 0, d_aad if rank == 0 else None, len(aad), src[start:start + n], n, start, total,
+                               ct[start:start + n], p)
+            shares.append(p)
+        torch.cuda.synchronize()
+        tag = bytes(16)
+        for p in shares:
+            tag = bytes(a ^ b for a, b in zip(tag, bytes(p.cpu().numpy())))
+        assert bytes(ct[:total].cpu().numpy()) == want[:-16] and tag == want[-16:], (total, world)
+        # modes 1 and 2 over the ciphertext: the same shares; mode 2 also gives the plaintext back (in place)
+        back = ct.clone()
+        for mode in (1, 2):
+            tag2 = bytes(16)
+            for rank in range(world):
+                start, n, takes = sh.gcm_shard_roles(total, rank, world)
+                if not takes:
+                    continue
+                p = torch.zeros(16, dtype=torch.uint8, device=dev)
+                uaes.gcm_shard_dev(key, nonce, mode, d_aad if rank == 0 else None, len(aad), back[start:start + n], n, start,
+                                   total, back[start:start + n] if mode == 2 else None, p)
+                tag2 = bytes(a ^ b for a, b in zip(tag2, bytes(p.cpu().numpy())))
+            assert tag2 == want[-16:], (total, world, mode)
+        assert bytes(back[:total].cpu().numpy()) == pt
+        # the sharding module on top of it, rank by rank with a stand-in exchange
+        all_shares = [bytes(p.cpu().numpy()) for p in shares]
+        for rank in range(world):
+            start, n, _ = sh.gcm_shard_roles(total, rank, world)
+            dst = torch.zeros(max(n, 16), dtype=torch.uint8, device=dev)
+            t = sh.gcm_encrypt_sharded(key, nonce, d_aad, len(aad), total, src[start:start + n], dst[:n], rank, world,
+                                       gather=lambda share, r=rank: [s if i != r else share for i, s in enumerate(
+                                           all_shares + [bytes(16)] * (world - len(all_shares)))])
+            assert t == want[-16:] and bytes(dst[:n].cpu().numpy()) == want[start:start + n]

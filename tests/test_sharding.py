@@ -170,6 +170,69 @@ def test_sharded_gcm_math(orc, total, world):
     assert tag == want[-16:]            # after the last rank every share has been collected
 
 
+@pytest.mark.parametrize("total,world", [(0, 2), (16, 3), (1000, 3), (100000, 8)])
+def test_sharded_gcm_decrypt_authenticates_before_any_rank_writes(orc, total, world):
+    """gcm_decrypt_sharded with oracle stand-ins: phase 1 = every rank's share over the RECEIVED ciphertext, phase 2 =
+    the CTR pass, only when the XOR of the shares equals the tag; a forgery returns 0x1A on every rank with every
+    local output untouched (N7 across ranks, micro_aes.c:1200-1208)"""
+    import random
+    rnd = random.Random(7 * total + world)
+    key, nonce, aad = rnd.randbytes(16), rnd.randbytes(12), rnd.randbytes(rnd.choice([0, 5, 32]))
+    data = orc.splitmix(total + 3, total)
+    msg = orc.gcm_encrypt(key, nonce, aad, data)
+
+    def cipher(k, c, off, s, d, n):
+        d[:n] = orc.ctr_xcrypt_at(k, c, off, bytes(s[:n]))
+
+    def partial(k, no, a, ta, ct, n, start, tot):
+        return _oracle_partial(orc, k, no, a, ta, bytes(ct[:n]), n, start, tot)
+
+    for forged in (False, True):
+        ct, tag = bytearray(msg[:-16]), bytearray(msg[-16:])
+        if forged:
+            if total and rnd.random() < 0.7:
+                ct[rnd.randrange(total)] ^= 0x20
+            else:
+                tag[3] ^= 1
+        # every rank's share first (what the all-gather would deliver), then every rank's call sees all of them
+        shares = []
+        for rank in range(world):
+            start, n, takes = sh.gcm_shard_roles(total, rank, world)
+            shares.append(partial(key, nonce, aad if rank == 0 else None, len(aad), ct[start:start + n], n, start, total)
+                          if takes else bytes(16))
+        outs = []
+        for rank in range(world):
+            start, n, _ = sh.gcm_shard_roles(total, rank, world)
+            src, dst = bytearray(ct[start:start + n]), bytearray(b"\xAB" * n)
+            rc = sh.gcm_decrypt_sharded(key, nonce, aad, len(aad), total, bytes(tag), src, dst, rank, world,
+                                        cipher=cipher, partial=partial, gather=lambda share: list(shares))
+            assert rc == (0x1A if forged else 0)
+            outs.append(bytes(dst))
+        assert b"".join(outs) == (b"\xAB" * total if forged else data)
+
+
+@pytest.mark.parametrize("total,world", [(0, 2), (5, 3), (16, 2), (4096 + 7, 4), (100000, 8)])
+def test_sharded_ecb(orc, total, world):
+    """ecb_shard_args / ecb_sharded: whole blocks per rank, the rank that holds the end of the text takes the ragged
+    tail (N1: zero padded into a whole block); the concatenation is the one-call result"""
+    key = bytes(range(16))
+    data = orc.splitmix(total + 11, total)
+    want = orc.ecb_encrypt(key, data)
+    out, lasts = b"", 0
+
+    def cipher(k, s, d, n, dec):
+        d[: (n + 15) // 16 * 16] = orc.ecb_encrypt(k, bytes(s[:n]))
+
+    for rank in range(world):
+        start, n, last = sh.ecb_shard_args(total, rank, world)
+        lasts += last
+        assert n % 16 == 0 or last
+        src, dst = bytearray(data[start:start + n]), bytearray((n + 15) // 16 * 16)
+        assert sh.ecb_sharded(key, total, src, dst, rank, world, cipher=cipher) == (start, n)
+        out += bytes(dst)
+    assert out == want and lasts == 1
+
+
 def test_bench_self_launch_command(monkeypatch):
     """`python bench.py --gpus N` without a launcher starts its own N ranks the way the documented
     torch.distributed.run command does (rendezvous on 127.0.0.1, a free port, the same arguments)."""
