@@ -430,6 +430,9 @@ int  uaes_gcm_key_decrypt_records_v_dev(uaes_gcm_key *k, size_t nrec, const uint
                                         const void *d_in, const uint32_t *d_lens, size_t max_len, size_t in_stride,
                                         void *d_out, size_t out_stride, uint8_t *d_verdicts, int *d_status, void *stream);
 
+/* (The uaes_mgpu_* calls below start one worker thread per device ordinal the first time it is named; the workers live
+ * until the process ends -- they hold nothing but their lane -- so a process that has made such a call must not
+ * dlclose() the library.)                                                                                          */
 /* ---- one process, several GPUs -------------------------------------------------
  * The text is cut into aligned slices, one per device; one host thread per device
  * runs the single-device call on its slice with the counter / sector offset

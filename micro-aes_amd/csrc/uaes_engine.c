@@ -1206,7 +1206,10 @@ int uaes_shutdown(void)
         for (L = c->lanes; L; L = L->next) lane_free_resources(L);   /* the structs stay with their threads */
         for (i = 0; i < PIPE_MAXW; ++i) {
             if (c->pipe[i].dbuf) (void)hipFree(c->pipe[i].dbuf);
-            if (c->pipe[i].xscratch) (void)hipFree(c->pipe[i].xscratch);
+            if (c->pipe[i].xscratch) {
+                (void)hipMemset(c->pipe[i].xscratch, 0, c->pipe[i].xscratch_cap);   /* may hold GHASH tables (the GCM pipeline) */
+                (void)hipFree(c->pipe[i].xscratch);
+            }
             if (c->pipe[i].stream) (void)hipStreamDestroy((hipStream_t)c->pipe[i].stream);
             memset(&c->pipe[i], 0, sizeof c->pipe[i]);
         }
@@ -1647,6 +1650,65 @@ static int gcm_j0(lane *L, keysched *ks, const uint8_t *nonce, size_t nonce_len,
     return lane_fetch(L, j0, L->d_status + 4, 16);
 }
 
+/* A long HOST text through AES_GCM_encrypt: one copy in, the kernels, one copy out use the link one direction at a time.
+ * The slice pipeline of ECB / CTR / XTS serves GCM as well since every slice can be a SHARD of the message
+ * (uaesk_gcm_shard: CTR at the slice's counter offset fused with the slice's weighted share of the tag, round 5): the
+ * workers copy a slice in, run the shard pass on their own stream and scratch, fetch its 16-byte share and copy the
+ * slice out; the host XORs the shares into the tag.  Encryption only -- decryption must not release a byte before the
+ * whole text has been authenticated (N7), so it keeps the one staging buffer.                                        */
+typedef struct {
+    context *c; keysched *ks; const uint8_t *nonce; const void *d_aad;
+    uint64_t aad_len, total;
+    size_t slice;
+    uint8_t (*shares)[16];
+} gcm_pipe_arg;
+
+static int gcm_pipe_launch(void *arg, int worker, void *stream, const void *d_in, void *d_out, size_t off, size_t len)
+{
+    gcm_pipe_arg *a = (gcm_pipe_arg *)arg;
+    context *c = a->c;
+    const size_t sb = uaesk_gcm_scratch_bytes();
+    char *scr;
+    int k;
+    if (grow_on(stream, &c->pipe[worker].xscratch, &c->pipe[worker].xscratch_cap, sb + 64)) return -1;
+    scr = (char *)c->pipe[worker].xscratch;
+    k = uaesk_gcm_shard(stream, &c->tb, a->ks->nr, &a->ks->ek, 0, a->nonce, off == 0 ? a->d_aad : NULL, a->aad_len,
+                        d_in, len, off, a->total, d_out, scr, scr + sb);
+    if (k) return k;
+    return (int)hipMemcpyAsync(a->shares[off / a->slice], scr + sb, 16, hipMemcpyDeviceToHost, (hipStream_t)stream);
+}
+
+/* 1 if the call qualified (then *rc is its result) */
+static int gcm_encrypt_pipelined(keysched *ks, const uint8_t *nonce, const void *aData, size_t aDataLen,
+                                 const void *pntxt, size_t ptextLen, void *crtxt, int *rc)
+{
+    context *c;
+    lane *L;
+    gcm_pipe_arg pa;
+    const void *d_aad = NULL;
+    size_t slice = pipe_slice_bytes(), nsl, i;
+    uint8_t tag[16] = { 0 };
+    int k, took;
+    if (ptextLen < PIPE_MIN || pipe_workers() < 2 || is_device_ptr(pntxt) || is_device_ptr(crtxt)) return 0;
+    slice -= slice % 16;
+    if (slice * 2 > ptextLen) return 0;
+    if ((*rc = enter(&c, &L)) != 0) return 1;
+    /* the AAD once, on the caller's lane, complete before the first worker reads it */
+    if ((*rc = stage_aad(L, aData, aDataLen, &d_aad)) != 0 || (*rc = lane_sync(L)) != 0) { *rc = lane_abandon(L, *rc); return 1; }
+    nsl = (ptextLen + slice - 1) / slice;
+    pa.c = c; pa.ks = ks; pa.nonce = nonce; pa.d_aad = d_aad; pa.aad_len = aDataLen; pa.total = ptextLen; pa.slice = slice;
+    pa.shares = (uint8_t (*)[16])calloc(nsl, 16);
+    if (!pa.shares) { *rc = fail(UAES_E_HIP, "out of host memory"); return 1; }
+    took = run_pipelined(c, pntxt, crtxt, ptextLen, 16, 0, gcm_pipe_launch, &pa, rc);
+    if (took && *rc == 0) {
+        for (i = 0; i < nsl; ++i)
+            for (k = 0; k < 16; ++k) tag[k] ^= pa.shares[i][k];
+        memcpy((char *)crtxt + ptextLen, tag, 16);
+    }
+    free(pa.shares);
+    return took;
+}
+
 /* nonceLen / tagLen = the reference's compile-time GCM_NONCE_LEN / GCM_TAG_LEN (micro_aes.h:108-109).  The kernels
  * always produce the 16-byte tag behind the text; a shorter tag is the host layer's business: the text goes
  * through a buffer with room for sixteen bytes and ptextLen + tagLen bytes are handed over (:1178).         */
@@ -1674,6 +1736,7 @@ int uaes_gcm_encrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, s
         int devs[MAX_DEVICES];
         const int nd = auto_devices(pntxt, crtxt, ptextLen, devs);
         if (nd) return uaes_mgpu_gcm_encrypt(nd, devs, keybits, key, nonce, aData, aDataLen, pntxt, ptextLen, crtxt);
+        if (gcm_encrypt_pipelined(&ks, nonce, aData, aDataLen, pntxt, ptextLen, crtxt, &rc)) return rc;
     }
     if ((rc = enter(&c, &L)) != 0) return rc;
     do {

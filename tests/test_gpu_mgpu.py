@@ -358,3 +358,72 @@ def test_gcm_shard_dev_one_pass_per_rank(orc):
                                        gather=lambda share, r=rank: [s if i != r else share for i, s in enumerate(
                                            all_shares + [bytes(16)] * (world - len(all_shares)))])
             assert t == want[-16:] and bytes(dst[:n].cpu().numpy()) == want[start:start + n]
+
+
+def test_mgpu_gcm_calls_from_several_host_threads(orc):
+    """the two phases of uaes_mgpu_gcm_decrypt are two rounds of jobs on the per-device workers, and calls from several
+    host threads interleave there: every call's state (shares, the private device copies of host slices) must be its own"""
+    import threading
+    key, aad = bytes(range(16)), b"thread"
+    errors = []
+
+    def work(t):
+        try:
+            rnd = random.Random(t)
+            for i in range(6):
+                n = rnd.choice([0, 33, 5000, (1 << 20) + 7, (9 << 20) + 16 * t + i])
+                nonce = rnd.randbytes(12)
+                pt = orc.splitmix(100 * t + i, n)
+                devs = [0] * rnd.choice([1, 2, 3, 5])
+                ct = uaes.mgpu_gcm_encrypt(devs, key, nonce, aad, pt)
+                assert ct == orc.gcm_encrypt(key, nonce, aad, pt), (t, i, n)
+                assert uaes.mgpu_gcm_decrypt(devs, key, nonce, aad, ct, prefill=0xAB) == (0, pt), (t, i, n)
+                if n:
+                    bad = bytearray(ct)
+                    bad[rnd.randrange(n)] ^= 2
+                    assert uaes.mgpu_gcm_decrypt(devs, key, nonce, aad, bytes(bad), prefill=0xAB) == (0x1A, b"\xab" * n), (t, i, n)
+        except Exception as e:                                   # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+
+
+def test_long_host_gcm_texts_go_through_the_slice_pipeline(orc):
+    """AES_GCM_encrypt on a long HOST text: the slices of the host pipeline are shards of the message (fused CTR +
+    weighted share per slice, XORed on the host).  Same bytes and tag as the oracle / the device-resident call, with
+    AAD, ragged length, in place; one worker (UAES_PIPE_WORKERS=1 in a child) takes the plain path and agrees"""
+    import subprocess
+    import sys
+    import numpy as np
+    L = uaes.engine()
+    key, nonce, aad = bytes(range(32)), bytes(range(3, 15)), bytes(range(41))
+    for n in ((96 << 20) + 16 * 7 + 9, (32 << 20), (33 << 20) + 1):
+        src = np.empty(n + 16, dtype=np.uint8)
+        orc.splitmix_into(n % 1000, src[: (n + 15) // 8 * 8] if (n + 15) // 8 * 8 <= n + 16 else src[: n // 8 * 8])
+        pt = src[:n].tobytes()
+        want = hashlib.sha256(orc.gcm_encrypt(key, nonce, aad, pt)).hexdigest()
+        out = np.zeros(n + 16, dtype=np.uint8)
+        assert L.uaes_gcm_encrypt(256, key, nonce, aad, len(aad), C.c_void_p(src.ctypes.data), n, C.c_void_p(out.ctypes.data)) == 0
+        assert hashlib.sha256(out.tobytes()).hexdigest() == want, n
+        buf = np.concatenate([src[:n], np.zeros(16, dtype=np.uint8)])
+        assert L.uaes_gcm_encrypt(256, key, nonce, aad, len(aad), C.c_void_p(buf.ctypes.data), n, C.c_void_p(buf.ctypes.data)) == 0
+        assert hashlib.sha256(buf.tobytes()).hexdigest() == want, ("in place", n)
+        back = np.full(n, 0xAB, dtype=np.uint8)
+        assert L.uaes_gcm_decrypt(256, key, nonce, aad, len(aad), C.c_void_p(out.ctypes.data), n, C.c_void_p(back.ctypes.data)) == 0
+        assert back.tobytes() == pt
+    code = ("import sys, hashlib, ctypes as C; sys.path.insert(0, %r); import numpy as np, micro_aes_amd as u; L = u.engine(); "
+            "n = (40 << 20) + 5; src = (np.arange(n, dtype=np.uint32) * 2654435761 >> 7).astype(np.uint8); out = np.zeros(n + 16, dtype=np.uint8); "
+            "assert L.uaes_gcm_encrypt(128, bytes(16), bytes(12), None, 0, C.c_void_p(src.ctypes.data), n, C.c_void_p(out.ctypes.data)) == 0; "
+            "print(hashlib.sha256(out.tobytes()).hexdigest())") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = []
+    for workers in ("1", "4"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, UAES_PIPE_WORKERS=workers))
+        assert r.returncode == 0, r.stderr[-1500:]
+        got.append(r.stdout.split()[-1])
+    assert got[0] == got[1]
