@@ -106,7 +106,9 @@ int         uaes_stream_release(void *stream);
  * Covered: every synchronous one-message call of this header -- ECB, CTR, XTS (unit and sectors), GCM (any nonce / tag
  * length), CBC (CTS and CTS-0 forms), CFB, OFB, CMAC, CCM, GCM-SIV, OCB.  Not covered (always GPU): the *_dev / *_batch
  * / record / key-context / stream / mgpu calls, uaes_ghash, and any call that is handed a device pointer.
- * Environment, read at first use: UAES_HOST_MAX=<bytes>, UAES_HOST_CHAINS=1, UAES_HOST_FALLBACK=1.               */
+ * Environment, read at first use: UAES_HOST_MAX=<bytes>, UAES_HOST_CHAINS=1, UAES_HOST_FALLBACK=1; or
+ * UAES_HOST_POLICY=recommended = (4096, 1, 1), the measured crossover on the builder's hosts (profiles/r05_host_policy.md),
+ * which the three variables then refine.                                                                           */
 int uaes_set_host_policy(size_t max_bytes, int chains, int fallback);
 int uaes_get_host_policy(size_t *max_bytes, int *chains, int *fallback);
 

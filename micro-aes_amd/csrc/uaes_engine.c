@@ -790,10 +790,14 @@ int uaes_get_host_policy(size_t *max_bytes, int *chains, int *fallback)
 
 static void host_policy_from_env(void)             /* once, from env_init() */
 {
-    const char *m = getenv("UAES_HOST_MAX");
-    if (m && *m) { long long v = strtoll(m, NULL, 10); if (v > 0) g_host.max_bytes = (size_t)v; }
-    g_host.chains = env_int("UAES_HOST_CHAINS", 0, 0, 1);
-    g_host.fallback = env_int("UAES_HOST_FALLBACK", 0, 0, 1);
+    const char *m = getenv("UAES_HOST_MAX"), *p = getenv("UAES_HOST_POLICY");
+    /* UAES_HOST_POLICY=recommended: the measured crossover of this host class (profiles/r05_host_policy.md: the host path
+     * is the faster one up to 4 KiB, GCM 2 KiB), single chains on the host, and a GPU-less box served instead of refused;
+     * the individual variables refine it */
+    if (p && strcmp(p, "recommended") == 0) { g_host.max_bytes = 4096; g_host.chains = 1; g_host.fallback = 1; }
+    if (m && *m) { long long v = strtoll(m, NULL, 10); if (v >= 0) g_host.max_bytes = (size_t)v; }
+    g_host.chains = env_int("UAES_HOST_CHAINS", g_host.chains, 0, 1);
+    g_host.fallback = env_int("UAES_HOST_FALLBACK", g_host.fallback, 0, 1);
 }
 
 /* does this call run on the host path?  chain != 0: one serial chain */

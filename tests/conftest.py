@@ -37,6 +37,6 @@ def _gpu_tests_run_with_the_host_path_off(request):
     if request.node.get_closest_marker("gpu") is not None:
         import micro_aes_amd as uaes
         assert uaes.host_policy() == (0, 0, 0), "a GPU parity test must not run with the host data path switched on"
-        for name in ("UAES_HOST_MAX", "UAES_HOST_CHAINS", "UAES_HOST_FALLBACK"):
+        for name in ("UAES_HOST_MAX", "UAES_HOST_CHAINS", "UAES_HOST_FALLBACK", "UAES_HOST_POLICY"):
             assert not os.environ.get(name), "%s is set: GPU parity tests run with the host path off" % name
     yield

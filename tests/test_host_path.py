@@ -67,6 +67,14 @@ def test_host_policy_from_the_environment():
     assert r.stdout.startswith("(4096, 1, 1)")
     from oracle.pyoracle import Oracle
     assert lines[-1] == Oracle().ctr_encrypt(bytes(16), bytes(12), bytes(40)).hex()
+    env = {k: v for k, v in os.environ.items() if not k.startswith("UAES_HOST")}
+    env.update(UAES_HOST_POLICY="recommended", PYTHONPATH=ROOT)
+    r = subprocess.run(["python", "-c", "import micro_aes_amd as u; print(u.host_policy())"], capture_output=True, text=True,
+                       env=env, cwd=ROOT, timeout=300)
+    assert r.stdout.startswith("(4096, 1, 1)"), r.stdout + r.stderr
+    r = subprocess.run(["python", "-c", "import micro_aes_amd as u; print(u.host_policy())"], capture_output=True, text=True,
+                       env=dict(env, UAES_HOST_MAX="0", UAES_HOST_FALLBACK="0"), cwd=ROOT, timeout=300)
+    assert r.stdout.startswith("(0, 1, 0)"), r.stdout + r.stderr
 
 
 # ---- the reference-held vector files and the compiled reference's outputs, through the compat ABI, host path forced ----
