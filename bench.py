@@ -382,6 +382,9 @@ def gather_phase(a, torch, dist, cg, rank, world, local, n, dev, dst, step, seed
     Returns (fields for the line, RCCL still usable)."""
     wait_s = float(os.environ.get("UAES_BENCH_GATHER_WAIT_S", "300"))
     rccl = cg is not None
+    # the stand-in gather runs in a thread: it gets a gloo group of its own, so that the control plane's collectives on
+    # the default group (main thread) can never interleave with a gather that is late or stuck
+    gg = None if rccl else dist.new_group(backend="gloo")
 
     def run():
         torch.cuda.set_device(local)
@@ -402,12 +405,12 @@ def gather_phase(a, torch, dist, cg, rank, world, local, n, dev, dst, step, seed
                 for o in range(0, n, chunk):
                     m = min(chunk, n - o)
                     host[:m].copy_(dst[o:o + m])
-                    dist.gather(host[:m], gather_list=[r[:m] for r in recv] if rank == 0 else None, dst=0)
+                    dist.gather(host[:m], gather_list=[r[:m] for r in recv] if rank == 0 else None, dst=0, group=gg)
                     if rank == 0:
                         for g in range(world):
                             full[g * n + o:g * n + o + m].copy_(recv[g][:m])
                 torch.cuda.synchronize()
-                dist.barrier()
+                dist.barrier(group=gg)
         gather()                                                 # first use sets the channels up
         g0 = time.perf_counter()
         gather()
