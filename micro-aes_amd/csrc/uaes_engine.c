@@ -717,7 +717,7 @@ static struct {
 } g_auto = { 0, { 0 }, (size_t)64 << 20, PTHREAD_MUTEX_INITIALIZER };
 static __thread int tls_is_mgpu_worker;
 
-int uaes_set_devices(int ndev, const int *devices, size_t min_bytes)
+static int set_devices(int ndev, const int *devices, size_t min_bytes)
 {
     int i, avail = 0;
     if (ndev < -1 || ndev > MAX_DEVICES) return fail(UAES_E_ARG, "ndev must be -1 (all visible), 0 (off) or 1..%d", MAX_DEVICES);
@@ -736,6 +736,12 @@ int uaes_set_devices(int ndev, const int *devices, size_t min_bytes)
     return 0;
 }
 
+int uaes_set_devices(int ndev, const int *devices, size_t min_bytes)
+{
+    env_ready();                                   /* (a later first call must not overwrite this with the environment) */
+    return set_devices(ndev, devices, min_bytes);
+}
+
 static void auto_devices_from_env(void)          /* once, from env_init() */
 {
     const char *e = getenv("UAES_DEVICES"), *m = getenv("UAES_DEVICES_MIN_MIB");
@@ -743,7 +749,7 @@ static void auto_devices_from_env(void)          /* once, from env_init() */
     if (m && *m) { long v = strtol(m, NULL, 10); if (v >= 0) g_auto.min_bytes = v ? (size_t)v << 20 : 1; }
     if (!e || !*e) return;
     if (strcmp(e, "all") == 0) {
-        if (uaes_set_devices(-1, NULL, 0) != 0) fprintf(stderr, "uaes-hip: UAES_DEVICES=all ignored: %s\n", uaes_last_error());
+        if (set_devices(-1, NULL, 0) != 0) fprintf(stderr, "uaes-hip: UAES_DEVICES=all ignored: %s\n", uaes_last_error());
         return;
     }
     while (*e && n < MAX_DEVICES) {
@@ -754,7 +760,7 @@ static void auto_devices_from_env(void)          /* once, from env_init() */
         e = end;
         while (*e == ',' || *e == ' ') ++e;
     }
-    if (*e || n == 0 || uaes_set_devices(n, devs, 0) != 0)
+    if (*e || n == 0 || set_devices(n, devs, 0) != 0)
         fprintf(stderr, "uaes-hip: UAES_DEVICES ignored (a comma-separated list of visible device ordinals, or \"all\")\n");
 }
 
