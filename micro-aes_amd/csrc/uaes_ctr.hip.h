@@ -106,6 +106,19 @@ __device__ __forceinline__ void ctr_edge_blocks(const uaesk_rk &rk, const uaesk_
  *
  * U-buffer: the uniform parts of the next 8 iterations (64 groups), double buffered,
  * one s_barrier per 8 iterations.                                                */
+/* A(G) is the same for every group of ONE LAUNCH: it depends on the counter's bits 40..47 only, and the launchers cut
+ * a text at the (one in 2^40 blocks) place where those move -- ctr_stripes_cross_a() below, launch_ctr_shared and the
+ * GCM launchers -- so the lane constants L are made once per kernel and are loop invariants.  (Until round 5 the loop
+ * watched A per block and redefined L under a wave-uniform condition: a loop-carried value with a conditional
+ * definition, which cost eight v_mov per trip and a second copy of the flags in the U-buffer.)                   */
+static inline bool ctr_stripes_cross_a(const uaesk_ctr *c, u64 g_lo, u64 n8)
+{
+    if (!n8) return false;
+    const u64 vbase = c->v0 - (c->v0 & 0xffu);
+    const u64 first = vbase + (g_lo << 8), last = vbase + ((g_lo + 8 * n8) << 8) - 1;     /* (a wrap at 2^56 counts) */
+    return (first >> 40) != (last >> 40);
+}
+
 struct CtrGeo {
     u64 first;          /* g_lo: first group of the striped region                    */
     u64 iters;          /* iterations (stripes) of THIS workgroup                     */
@@ -124,6 +137,7 @@ struct CtrNoFold {
     static constexpr bool of_input = false;
     static constexpr int round_prio = 1;       /* wave priority while a round's lookups are issued */
     static constexpr bool expand2 = true;      /* the loop body twice per trip, text buffers swapped (no register moves) */
+    static constexpr bool text_ahead = true;   /* the text of iteration it + 1 is requested before the rounds of iteration it */
     __device__ __forceinline__ void operator()(const uint4 &, const uint4 &) const {}
 };
 
@@ -147,11 +161,8 @@ __device__ __forceinline__ void ctr_shared_loop(const uaesk_rk &rk, const uaesk_
     struct { u32 w[4 * (NR - 2)]; } rkv;
 #pragma unroll
     for (int i = 0; i < 4 * (NR - 2); ++i) rkv.w[i] = rk.w[12 + i];
-    u32 a_cur = 0, L0 = 0, L1 = 0, L2 = 0, L3 = 0;
-    bool have_l = false;
+    u32 L0 = 0, L1 = 0, L2 = 0, L3 = 0;
     u32 parity = 0;
-    u32 chunk_a = 0;                                        /* A of the current chunk if all its groups share it */
-    bool chunk_same = false;
 
     /* Block index of (it, u, lane) = ((group0(it) + 4u) << 8) - c0 [uniform] + lane_blk [per lane].
      * The plaintext of iteration it+1 is requested before the rounds of iteration it, so
@@ -161,8 +172,8 @@ __device__ __forceinline__ void ctr_shared_loop(const uaesk_rk &rk, const uaesk_
     const u64 ctr_tm_start = wall_clock64();
 #endif
     u64 it = 0;
-    uint4 d_cur[2];
-    if (it < geo.iters) {
+    uint4 d_cur[2] = { make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0) };
+    if (FOLD::text_ahead && it < geo.iters) {
         const u64 g0 = ctr_geo_group0(geo, 0);
 #pragma unroll
         for (int u = 0; u < 2; ++u) d_cur[u] = (in + (((g0 + 4u * u) << 8) - c0))[lane_blk];
@@ -179,6 +190,18 @@ __device__ __forceinline__ void ctr_shared_loop(const uaesk_rk &rk, const uaesk_
 #define STRIPE_RSRC(p) __builtin_amdgcn_make_buffer_rsrc( \
         (void *)(((u64)(u32)__builtin_amdgcn_readfirstlane((int)((u64)(p) >> 32)) << 32) | \
                  (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(u64)(p))), 0, 0x7fffffff, 0x00020000)
+#define TL(k, b, w) tlook_true<k, b>(w, lc)
+    if (geo.iters) {                                        /* the lane constants: A of the launch, then L0..L3 */
+        const u64 v = (vbase + (ctr_geo_group0(geo, 0) << 8)) & 0x00FFFFFFFFFFFFFFull;
+        const u32 s0 = ctr.w0 ^ rk.w[0], s1 = ctr.w1 ^ rk.w[1];
+        const u32 s2 = bswap32((ctr.b8 << 24) | (u32)(v >> 32)) ^ rk.w[2];
+        const u32 A = xor3(TL(0, 0, s0), TL(1, 1, s1), TL(2, 2, s2)) ^ rk.w[4];
+        const u32 col0 = A ^ TL(3, 3, x15);
+        L0 = TL(0, 0, col0);
+        L1 = TL(3, 3, col0);
+        L2 = TL(2, 2, col0);
+        L3 = TL(1, 1, col0);
+    }
     auto refill = [&](u64 it) {
         {
             if (wave == 0) {
@@ -190,8 +213,6 @@ __device__ __forceinline__ void ctr_shared_loop(const uaesk_rk &rk, const uaesk_
                 const u32 s0 = ctr.w0 ^ rk.w[0], s1 = ctr.w1 ^ rk.w[1];
                 const u32 s2 = bswap32((ctr.b8 << 24) | (u32)(v >> 32)) ^ rk.w[2];
                 const u32 s3 = (bswap32((u32)v) ^ rk.w[3]) & 0x00ffffffu;      /* byte 15 excluded */
-#define TL(k, b, w) tlook_true<k, b>(w, lc)
-                const u32 A = xor3(TL(0, 0, s0), TL(1, 1, s1), TL(2, 2, s2)) ^ rk.w[4];
                 const u32 c1 = xor3(xor3(TL(0, 0, s1), TL(1, 1, s2), TL(2, 2, s3)), TL(3, 3, s0), rk.w[5]);
                 const u32 c2 = xor3(xor3(TL(0, 0, s2), TL(1, 1, s3), TL(2, 2, s0)), TL(3, 3, s1), rk.w[6]);
                 const u32 c3 = xor3(xor3(TL(0, 0, s3), TL(1, 1, s0), TL(2, 2, s1)), TL(3, 3, s2), rk.w[7]);
@@ -199,37 +220,33 @@ __device__ __forceinline__ void ctr_shared_loop(const uaesk_rk &rk, const uaesk_
                 const u32 u1 = xor3(TL(0, 0, c1), TL(1, 1, c2), TL(2, 2, c3)) ^ rk.w[9];
                 const u32 u2 = xor3(TL(0, 0, c2), TL(1, 1, c3), TL(3, 3, c1)) ^ rk.w[10];
                 const u32 u3 = xor3(TL(0, 0, c3), TL(2, 2, c1), TL(3, 3, c2)) ^ rk.w[11];
-                /* A(G) moves only when counter bits 40..47 do: a chunk in which all 64 groups share it says so
-                 * in the first group's slot, and the consumers then skip the per-block read of A           */
-                const u32 same = __ballot(A != (u32)__builtin_amdgcn_readfirstlane((int)A)) == 0 ? 1u : 0u;
                 buf[(parity * CTRS_CHUNK + gi) * 2 + 0] = make_uint4(u0, u1, u2, u3);
-                buf[(parity * CTRS_CHUNK + gi) * 2 + 1] = make_uint4(A, same, 0, 0);
             }
 #ifdef UAES_CTR_TIMING
             { const u64 t0 = wall_clock64(); __syncthreads(); ctr_tm_wait += wall_clock64() - t0; }
 #else
             __syncthreads();
 #endif
-            const uint4 hdr = buf[(parity * CTRS_CHUNK) * 2 + 1];
-            chunk_a = (u32)__builtin_amdgcn_readfirstlane((int)hdr.x);
-            chunk_same = __builtin_amdgcn_readfirstlane((int)hdr.y) != 0;
         }
 
     };
     auto body = [&](u64 it, uint4 (&d_cur)[2], uint4 (&d_nxt)[2]) {
-        /* request the next iteration's plaintext (clamped to this workgroup's last one) */
+        /* request the next iteration's plaintext (clamped to this workgroup's last one) -- or, for a fold that cannot
+         * afford a second text buffer (FOLD::text_ahead == false), THIS iteration's: the text is not needed before the
+         * rounds are done, and one iteration (~4.7 us per 2048 blocks of a workgroup) hides the load either way */
         const u64 g0 = ctr_geo_group0(geo, it);
         {
-            const u64 gn = ctr_geo_group0(geo, it + 1 < geo.iters ? it + 1 : it);
+            const u64 gn = FOLD::text_ahead ? ctr_geo_group0(geo, it + 1 < geo.iters ? it + 1 : it) : g0;
+            uint4 (&d_ld)[2] = FOLD::text_ahead ? d_nxt : d_cur;
 #ifdef UAES_CTR_GLOBAL_LD               /* measurement / bisecting build: plain pointers instead of buffer resources */
 #pragma unroll
-            for (int u = 0; u < 2; ++u) d_nxt[u] = (in + (((gn + 4u * u) << 8) - c0))[lane_blk];
+            for (int u = 0; u < 2; ++u) d_ld[u] = (in + (((gn + 4u * u) << 8) - c0))[lane_blk];
 #else
             const __amdgpu_buffer_rsrc_t rin = STRIPE_RSRC(in + ((gn << 8) - c0));
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rin, lane_byte, 16384 * u, 0);
-                d_nxt[u] = make_uint4(v.x, v.y, v.z, v.w);
+                d_ld[u] = make_uint4(v.x, v.y, v.z, v.w);
             }
 #endif
         }
@@ -239,17 +256,6 @@ __device__ __forceinline__ void ctr_shared_loop(const uaesk_rk &rk, const uaesk_
         for (int u = 0; u < 2; ++u) {
             const u32 gl = 8u * ((u32)it & 7u) + quad + 4u * u;            /* slot in the U-buffer */
             const uint4 uu = buf[(parity * CTRS_CHUNK + gl) * 2 + 0];
-            const u32 A = chunk_same ? chunk_a : (u32)__builtin_amdgcn_readfirstlane((int)buf[(parity * CTRS_CHUNK + gl) * 2 + 1].x);
-            if (!have_l || A != a_cur) {                                   /* wave-uniform; ~never after the first time */
-                const u32 col0 = A ^ TL(3, 3, x15);
-                L0 = TL(0, 0, col0);
-                L1 = TL(3, 3, col0);
-                L2 = TL(2, 2, col0);
-                L3 = TL(1, 1, col0);
-                a_cur = A;
-                have_l = true;
-            }
-#undef TL
             s[u][0] = L0 ^ uu.x; s[u][1] = L1 ^ uu.y; s[u][2] = L2 ^ uu.z; s[u][3] = L3 ^ uu.w;
         }
 #ifdef UAES_ASM_VARIANT
@@ -287,29 +293,28 @@ __device__ __forceinline__ void ctr_shared_loop(const uaesk_rk &rk, const uaesk_
 #else
     constexpr bool twice = FOLD::expand2;
 #endif
-    if constexpr (twice) {
-        while (it + 2 <= geo.iters) {
-            if ((it & 7) == 0) refill(it);
-            body(it, d_a, d_b);
-            body(it + 1, d_b, d_a);
-            it += 2;
-            if ((it & 7) == 0) parity ^= 1u;
-        }
-        if (it < geo.iters) {                               /* an odd count: the last stripe alone */
-            if ((it & 7) == 0) refill(it);
-            body(it, d_a, d_b);
-            ++it;
-        }
-    } else {                                                /* a fold too big to hold twice (GCM: it would spill) */
-        while (it < geo.iters) {
-            if ((it & 7) == 0) refill(it);
-            body(it, d_a, d_b);
+    /* chunk by chunk (8 iterations = 64 groups of the U-buffer): refill, then the chunk's iterations */
+    while (it < geo.iters) {
+        const u64 end = it + 8 < geo.iters ? it + 8 : geo.iters;
+        refill(it);
+        if constexpr (twice) {
+            for (; it + 2 <= end; it += 2) {
+                body(it, d_a, d_b);
+                body(it + 1, d_b, d_a);
+            }
+            if (it < end) { body(it, d_a, d_b); ++it; }      /* an odd count: only the launch's last stripe */
+        } else {                                            /* a fold too big to hold twice (GCM: it would spill) */
+            for (; it < end; ++it) {
+                body(it, d_a, d_b);
+                if (FOLD::text_ahead) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) d_a[u] = d_b[u];
-            ++it;
-            if ((it & 7) == 0) parity ^= 1u;
+                    for (int u = 0; u < 2; ++u) d_a[u] = d_b[u];
+                }
+            }
         }
+        parity ^= 1u;
     }
+#undef TL
 #undef STRIPE_RSRC
 #ifdef UAES_CTR_TIMING
     if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 100))

@@ -735,6 +735,12 @@ struct GhFold {
     static constexpr bool of_input = DEC;
     static constexpr int round_prio = 2;       /* cipher lookups 2 > GHASH lookups 1 > XOR work 0 */
     static constexpr bool expand2 = false;     /* the loop body once per trip: twice would spill (128 VGPRs are all in use) */
+#ifdef UAES_GCM_TEXT_AHEAD
+    static constexpr bool text_ahead = true;
+#else
+    static constexpr bool text_ahead = false;  /* one text buffer, loaded at the head of its own iteration: no second buffer,
+                                                  no eight v_mov per trip to rotate it (profiles/r05_gcm_text_ab.log) */
+#endif
     uint4 acc[2];
     GhLane gl;
     __device__ __forceinline__ void operator()(const uint4 &c0, const uint4 &c1)
@@ -2008,6 +2014,7 @@ static int gcm_body(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk
         const u64 h0 = (256u - c0) & 255u, g_lo = c0 ? 1 : 0;
         const u64 groups = (c0 + nfull) / 256, n8 = groups > g_lo ? (groups - g_lo) / 8 : 0;
         if (Sl && ((u64)1 << logF) == Sl && logF <= GF_MAXLOG && n8 >= (u64)cus && ablk + h0 <= Sl &&
+            !ctr_stripes_cross_a(&c, g_lo, n8) &&      /* (one in 2^40 blocks: the two-pass path, whose CTR kernel cuts there) */
             !(tb->frob && nv <= 2048ull * medium_pref_w())) {
             const u64 h1 = h0 + 2048 * n8;
             GSrc fin;                                   /* [T][tail][lengths] */
@@ -2329,7 +2336,8 @@ extern "C" int uaesk_gcm_shard(void *stream, const uaesk_tables *tb, int nr, con
         const u32 c0 = (u32)c.v0 & 0xffu;
         const u64 h0 = (256u - c0) & 255u, g_lo = c0 ? 1 : 0;
         const u64 groups = (c0 + nfull) / 256, n8 = groups > g_lo ? (groups - g_lo) / 8 : 0;
-        if (Sl && ((u64)1 << logF) == Sl && logF <= GF_MAXLOG && n8 >= (u64)cus && ablk + h0 <= Sl) {
+        if (Sl && ((u64)1 << logF) == Sl && logF <= GF_MAXLOG && n8 >= (u64)cus && ablk + h0 <= Sl &&
+            !ctr_stripes_cross_a(&c, g_lo, n8)) {
             const u64 h1 = h0 + 2048 * n8;
             GSrc fin;                                   /* [T][tail]([lengths] on the last shard) */
             fin.aad = sc + GS_T; fin.aad_len = 16;

@@ -856,6 +856,20 @@ static int launch_ctr_shared(hipStream_t st, const uaesk_tables *tb, const uaesk
         const u64 r = n8 % grid;
         if (r && n8 > grid && r * 100 < (u64)grid * (u64)pct) n8 -= r;
     }
+    if (ctr_stripes_cross_a(ctr, g_lo, n8)) {
+        /* the striped kernel makes its lane constants once per launch (uaes_ctr.hip.h): a text in which counter bits
+         * 40..47 move -- once in 2^40 blocks -- is cut there into two launches                                     */
+        const u64 nb = ((u64)1 << 40) - (ctr->v0 & (((u64)1 << 40) - 1));          /* blocks up to the boundary */
+        if (nb > 0 && nb < nfull) {
+            uaesk_ctr second = *ctr;
+            second.v0 = (ctr->v0 + nb) & 0x00FFFFFFFFFFFFFFull;
+            int rc = launch_ctr_shared<NR>(st, tb, ek, ctr, in, out, (size_t)(nb * 16), gate);
+            if (rc) return rc;
+            return launch_ctr_shared<NR>(st, tb, ek, &second, (const unsigned char *)in + nb * 16, (unsigned char *)out + nb * 16,
+                                         len - (size_t)(nb * 16), gate);
+        }
+        return launch_ctr_v<NR, 4>(st, tb, ek, ctr, in, out, len, gate);        /* (cannot happen: the boundary lies inside) */
+    }
     hipError_t e = set_lds(k_ctr_shared2<NR>, UAES_LDS_CTRS);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL((k_ctr_shared2<NR>), dim3(grid), dim3(UAES_WG), UAES_LDS_CTRS, st, *ek, *tb, *ctr,

@@ -427,3 +427,35 @@ def test_long_host_gcm_texts_go_through_the_slice_pipeline(orc):
         assert r.returncode == 0, r.stderr[-1500:]
         got.append(r.stdout.split()[-1])
     assert got[0] == got[1]
+
+
+def test_gcm_shard_whose_counter_bits_40_47_move_takes_the_two_pass_path(orc):
+    """the fused CTR + GHASH pass makes its lane constants once per launch; a shard inside which counter bits 40..47
+    move (only reachable 64 GiB into a message: nonce byte 11 = 0xff and a shard offset just below 2^36 bytes) must fall
+    back to CTR (which cuts there) + the GHASH levels: ciphertext against the oracle's CTR at that offset, share equal
+    to the hash-only share over that ciphertext"""
+    import torch
+    dev = torch.device("cuda", 0)
+    key, nonce = bytes(range(16)), bytes(range(11)) + b"\xff"
+    n = 64 << 20
+    into = (24 << 20) // 16 + 3                                     # the carry: this many blocks into the shard
+    off_blocks = (1 << 32) - 2 - into                               # J0's low 40 bits are ff 00 00 00 01; +1 pre-increment
+    off, total = off_blocks * 16, off_blocks * 16 + n + (5 << 30)
+    pt = orc.splitmix(99, n)
+    src = torch.frombuffer(bytearray(pt), dtype=torch.uint8).to(dev)
+    ct = torch.zeros(n, dtype=torch.uint8, device=dev)
+    p0, p1 = torch.zeros(16, dtype=torch.uint8, device=dev), torch.zeros(16, dtype=torch.uint8, device=dev)
+    uaes.gcm_shard_dev(key, nonce, 0, None, 0, src, n, off, total, ct, p0)
+    uaes.gcm_shard_dev(key, nonce, 1, None, 0, ct, n, off, total, None, p1)
+    torch.cuda.synchronize()
+    want = orc.ctr_xcrypt_at(key, nonce + b"\0\0\0\1", 1 + off_blocks, pt)
+    assert hashlib.sha256(ct.cpu().numpy().tobytes()).digest() == hashlib.sha256(want).digest()
+    assert bytes(p0.cpu().numpy()) == bytes(p1.cpu().numpy())
+    # the shard just BEFORE it (no carry inside) takes the fused pass: same two checks
+    off2 = off - n
+    uaes.gcm_shard_dev(key, nonce, 0, None, 0, src, n, off2, total, ct, p0)
+    uaes.gcm_shard_dev(key, nonce, 1, None, 0, ct, n, off2, total, None, p1)
+    torch.cuda.synchronize()
+    want = orc.ctr_xcrypt_at(key, nonce + b"\0\0\0\1", 1 + off2 // 16, pt)
+    assert hashlib.sha256(ct.cpu().numpy().tobytes()).digest() == hashlib.sha256(want).digest()
+    assert bytes(p0.cpu().numpy()) == bytes(p1.cpu().numpy())

@@ -1535,3 +1535,28 @@ def test_ecb_partial_last_round_of_tiles(orc, bits):
         back = torch.zeros(len(want), dtype=torch.uint8, device=dev)
         assert L.uaes_ecb_decrypt(bits, key, C.c_void_p(dst.data_ptr()), len(want), C.c_void_p(back.data_ptr())) == 0
         assert back[:n].cpu().numpy().tobytes() == pt, (bits, n, padding)
+
+
+@pytest.mark.parametrize("bits", [128, 256])
+def test_ctr_counter_bits_40_47_move_inside_the_striped_region(orc, bits):
+    """The striped CTR kernel makes its lane constants once per launch: they depend on counter bits 40..47, and the
+    launcher cuts a text at the (one in 2^40 blocks) place where those move (ctr_stripes_cross_a, launch_ctr_shared).
+    Counters whose low 40 bits run out 3 / 40 / 70 MiB into a 96 MiB text -- in the head, in the middle of the stripes
+    and near their end -- and the same with the 2^56 wrap, against the oracle (incBlock's carry, micro_aes.c:421-427)."""
+    import torch
+    key = bytes(range(1, 1 + bits // 8))
+    n = (96 << 20) + 16 * 5 + 3
+    data = orc.splitmix(4040, n + 5)[:n]
+    src = torch.frombuffer(bytearray(data + bytes(16)), dtype=torch.uint8).to("cuda:0")
+    dst = torch.empty(n + 16, dtype=torch.uint8, device="cuda:0")
+    for top, into_mib in ((0x12, 3), (0x12, 40), (0xfe, 70), (0xffff, 40), (0xffff, 95)):
+        blocks_left = (into_mib << 20) // 16 + 7                      # the carry happens this many blocks into the text
+        low40 = (1 << 40) - blocks_left
+        v = ((top << 40) | low40) & ((1 << 56) - 1)
+        ctr0 = bytes(range(0xA0, 0xA9)) + v.to_bytes(7, "big")
+        for off in (0, 11):
+            dst.zero_()
+            uaes.ctr_xcrypt_dev(key, ctr0, off, src, dst, nbytes=n)
+            torch.cuda.synchronize()
+            want = orc.ctr_xcrypt_at(key, ctr0, off, data)
+            assert hashlib.sha256(dst[:n].cpu().numpy().tobytes()).digest() == hashlib.sha256(want).digest(), (bits, top, into_mib, off)

@@ -91,11 +91,12 @@ def hot_loop(insts):
         loops.append((i - j + 1, sum(1 for (_, o, _) in insts[j:i + 1] if o == "ds_read_b32"), j, i))
     if not loops:
         return None
-    # the loop with the most lookups that is not merely the shell around another one: skip a loop if one strictly inside
-    # it holds more than 55 % of its lookups
+    # the loop with the most lookups that is not the shell around another one: skip a loop if one strictly inside it
+    # holds a round's worth of lookups itself (the chunk loop of the shared-round CTR kernels wraps the iteration loop,
+    # its refill and the odd last iteration)
     for size, n, j, i in sorted(loops, key=lambda l: (-l[1], l[0])):
         inner = [l for l in loops if l[2] >= j and l[3] <= i and (l[2], l[3]) != (j, i)]
-        if not any(l[1] > 0.55 * n for l in inner):
+        if not any(l[1] >= 64 for l in inner):
             return (j, i)
     return None
 
