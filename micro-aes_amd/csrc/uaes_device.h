@@ -188,13 +188,15 @@ int uaesk_chain_batch(void *stream, const uaesk_tables *tb, int nr, const uaesk_
 
 /* OCB (AES_OCB_encrypt/decrypt, micro_aes.c:1693-1811): nonce (host) of nonce_len = 1..15 bytes, tag_len
  * (1..16) bytes of tag at out+len (encrypt) / read at in+len (decrypt, *status = 0 / 0x1A; the text
- * is written either way, as in the reference).  dk = equivalent-inverse keys.  */
+ * is written either way, as in the reference).  dk = equivalent-inverse keys.  ONE launch; done_word = a device
+ * word that is zero between calls and that nothing else writes (the launch's workgroups count themselves in on it
+ * and the last one to arrive computes the tag and puts the zero back).  */
 size_t uaesk_ocb_scratch_bytes(void);
 int uaesk_ocb(void *stream, const uaesk_tables *tb, int nr,
               const uaesk_rk *ek, const uaesk_rk *dk, int decrypt, const uint8_t *nonce,
               size_t nonce_len, size_t tag_len,
               const void *aad, size_t aad_len, const void *in, size_t len, void *out,
-              void *scratch, int *status);
+              void *scratch, unsigned *done_word, int *status);
 
 /* A ticket can also ride on the call's ONLY kernel (saves the second launch: 8.9 -> 7 us for an empty kernel,
  * tools/ubench/threadfloor.hip).  The host layer arms one for the calling thread right before a kernel-level call

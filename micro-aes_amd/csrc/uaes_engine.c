@@ -354,6 +354,16 @@ static int grow_on(void *stream, void **buf, size_t *cap, size_t need)
     return 0;
 }
 
+/* The last SCRATCH_TAIL bytes of a scratch buffer (lanes, *_dev slots) are words that are ZERO BETWEEN CALLS: the
+ * workgroups of a one-launch call count themselves in on one and the last arrival puts the zero back (uaesk_ocb's
+ * done_word).  Cleared when the buffer is allocated, on the stream that uses it; no kernel's scratch layout
+ * reaches them (every request is made SCRATCH_TAIL bytes larger).                                            */
+#define SCRATCH_TAIL 256u
+static unsigned *scratch_done_word(void *buf, size_t cap)
+{
+    return (unsigned *)((char *)buf + cap - SCRATCH_TAIL);
+}
+
 /* for buffers that several streams may have used (the *_dev scratch slots) */
 static int grow(void **buf, size_t *cap, size_t need)
 {
@@ -385,14 +395,19 @@ static int scratch_pin(context *c, void *stream, size_t need, void **buf, int *s
             HIPCHK(hipDeviceSynchronize());       /* everything already issued on the old stream is done */
             c->slot[k].stream = stream;
         }
-        if (need > c->slot[k].cap && c->slot[k].pins > 0) {
+        if (need + SCRATCH_TAIL > c->slot[k].cap && c->slot[k].pins > 0) {
             pthread_cond_wait(&c->cv, &c->mu);    /* another caller of this stream is about to launch on it */
             continue;
         }
         c->slot[k].used = 1;
         c->slot[k].stream = stream;
         c->slot[k].tick = ++c->tick;
-        if (grow(&c->slot[k].buf, &c->slot[k].cap, need)) return UAES_E_HIP;
+        {
+            const size_t before = c->slot[k].cap;
+            if (grow(&c->slot[k].buf, &c->slot[k].cap, need + SCRATCH_TAIL)) return UAES_E_HIP;
+            if (c->slot[k].cap != before)
+                HIPCHK(hipMemsetAsync(scratch_done_word(c->slot[k].buf, c->slot[k].cap), 0, SCRATCH_TAIL, (hipStream_t)stream));
+        }
         c->slot[k].pins++;
         *buf = c->slot[k].buf;
         *slot_out = k;
@@ -536,7 +551,12 @@ static int enter(context **c, lane **L)
 
 static int lane_scratch(lane *L, size_t need)
 {
-    return grow_on(L->stream, &L->scratch, &L->scratch_cap, need);
+    const size_t before = L->scratch_cap;
+    int rc = grow_on(L->stream, &L->scratch, &L->scratch_cap, need + SCRATCH_TAIL);
+    if (rc) return rc;
+    if (L->scratch_cap != before)
+        HIPCHK(hipMemsetAsync(scratch_done_word(L->scratch, L->scratch_cap), 0, SCRATCH_TAIL, (hipStream_t)L->stream));
+    return 0;
 }
 
 static int pinned_ready(lane *L);
@@ -2924,7 +2944,7 @@ static int ocb_common(int keybits, const uint8_t *key, const uint8_t *nonce, siz
             ticket_arm(L);
         }
         int k = uaesk_ocb(L->stream, &c->tb, ks.nr, &ks.ek, &ks.dk, decrypt, nonce, nonceLen, tagLen, d_aad, aDataLen,
-                          io.din, len, io.dout, L->scratch, st_where);
+                          io.din, len, io.dout, L->scratch, scratch_done_word(L->scratch, L->scratch_cap), st_where);
         ticket_armed_launch_done(L);
         if (k) { rc = fail(UAES_E_HIP, "ocb launch: %s", hipGetErrorString((hipError_t)k)); break; }
         if (decrypt) {
@@ -2982,7 +3002,7 @@ int uaes_ocb_dev(int keybits, const uint8_t *key, const uint8_t *nonce, int decr
     if ((rc = get_context(&c)) != 0) return rc;
     if ((rc = gcm_scratch_locked(c, stream, &scr, &slot)) != 0) return rc;
     KCHK_PINNED(c, slot, uaesk_ocb(stream, &c->tb, ks.nr, &ks.ek, &ks.dk, decrypt, nonce, 12, 16, d_aad, aad_len, d_in, len,
-                                   d_out, scr, d_status));
+                                   d_out, scr, scratch_done_word(scr, c->slot[slot].cap), d_status));
     return 0;
 }
 

@@ -2,11 +2,14 @@
  * uaes_ocb.hip -- OCB (RFC 7253), the remaining block-parallel AEAD of the
  * reference.
  *
- *   k_ocb_setup  <- getSubkeys :593-604 (L_*, L_$, L_0 ...), the nonce part of
- *                   OCB_cipher :1705-1719 (K_top, stretch, Offset_0)
- *   k_ocb        <- the block loop of OCB_cipher :1721-1730 with getDelta :1662-1680
- *   k_ocb_final  <- the partial block :1736-1741, the tag :1743-1744 and the
- *                   PMAC of the associated data :1746-1760
+ *   ocb_setup_lds  <- getSubkeys :593-604 (L_*, L_$, L_0 ...), the nonce part of
+ *                     OCB_cipher :1705-1719 (K_top, stretch, Offset_0)
+ *   ocb_main_body  <- the block loop of OCB_cipher :1721-1730 with getDelta :1662-1680
+ *   ocb_final_body <- the partial block :1736-1741, the tag :1743-1744 and the
+ *                     PMAC of the associated data :1746-1760
+ * ONE launch per call (k_ocb; k_ocb_small for short messages): every workgroup derives the L table and
+ * Offset_0 for itself (two block encryptions side by side + one shift per table row, ~1 us), and the
+ * workgroup that finishes last computes the tag.
  *
  * The reference walks the blocks one by one and recomputes Offset_i from scratch
  * for every i (getDelta doubles L up to 64 times per block).  Here the offsets are
@@ -30,15 +33,19 @@ static inline hipStream_t S(void *s) { return (hipStream_t)s; }
 #define OCB_NL       64u                      /* table rows: 0 L_*, 1 L_$, 2+j L_j      */
 #define OCB_LDS_L    (128u * 1024u)           /* L table in LDS, after the cipher tables */
 #define OCB_LDS_ACC  (OCB_LDS_L + OCB_NL * 16u)
-#define OCB_LDS      (OCB_LDS_ACC + 32u)        /* two 16-byte accumulators */
+#define OCB_LDS_OFF0 (OCB_LDS_ACC + 32u)        /* behind the two 16-byte accumulators: Offset_0 */
+#define OCB_LDS_FLAG (OCB_LDS_OFF0 + 16u)       /* "this workgroup finishes the call" */
+#define OCB_LDS_TE0  (OCB_LDS_FLAG + 16u)        /* decryption: 1 KiB, plain Te0 (EncPlain) */
+#define OCB_LDS      (OCB_LDS_TE0 + 1024u)
 #define OCB_CHUNK    256u                     /* blocks per chunk: one wave x 4 per lane */
 #define OCB_RUN_MAX  16u                      /* most consecutive chunks a wave takes at once */
 #define UAES_U       4                        /* blocks per lane per chunk               */
-/* scratch rows (uint4): [0..63] L table, [64] Offset_0, [65..] one checksum share per
- * workgroup of k_ocb (plain stores: thousands of same-address atomics cost 0.2 ms) */
+/* scratch rows (uint4): [65..] one checksum share per workgroup of k_ocb (plain stores: thousands of
+ * same-address atomics cost 0.2 ms); rows [0..64] are the hand-over rows of k_ocb_small (L table, Offset_0) */
 #define OCB_ROW_OFF0 64u
 #define OCB_ROW_PART 65u
 #define OCB_MAX_WGS  1024u
+#define OCB_PLAIN_AAD (16u * 1024u)            /* decryption: associated data up to here is hashed through the plain Te0 */
 
 struct B16 {
     u32 w[4];
@@ -79,12 +86,34 @@ __device__ __forceinline__ B16 ocb_double(const B16 &b)
     return r;
 }
 
+/* One block encryption, two ways.  EncRep: the replicated tables of the encryption direction are in LDS.
+ * EncPlain: a 1 KiB copy of Te0 at OCB_LDS_TE0 -- what a DECRYPTING kernel uses for the handful of encryptions OCB
+ * needs whatever the direction (L_*, K_top, the pad of a ragged block, the tag, short associated data), instead of
+ * swapping 128 KiB of tables in and out around them.                                                        */
 template <int NR>
-__device__ __forceinline__ void ocb_enc1(B16 &b, const uaesk_rk &rk, const LaneConst &lc)
+struct EncRep {
+    const uaesk_rk &rk;
+    const LaneConst &lc;
+    __device__ __forceinline__ void operator()(B16 &b) const
+    {
+        u32 s[1][4] = { { b.w[0], b.w[1], b.w[2], b.w[3] } };
+        enc_blocks<NR, 1>(s, rk, lc);
+        b.w[0] = s[0][0]; b.w[1] = s[0][1]; b.w[2] = s[0][2]; b.w[3] = s[0][3];
+    }
+};
+
+template <int NR>
+struct EncPlain {
+    const uaesk_rk &rk;
+    __device__ __forceinline__ void operator()(B16 &b) const
+    {
+        plain_encrypt<NR>((const u32 *)(uaes_lds + OCB_LDS_TE0), rk, b.w);
+    }
+};
+
+__device__ __forceinline__ void ocb_fill_plain_te0(const u32 *__restrict__ te0)      /* a barrier must follow */
 {
-    u32 s[1][4] = { { b.w[0], b.w[1], b.w[2], b.w[3] } };
-    enc_blocks<NR, 1>(s, rk, lc);
-    b.w[0] = s[0][0]; b.w[1] = s[0][1]; b.w[2] = s[0][2]; b.w[3] = s[0][3];
+    if (threadIdx.x < 256u) ((u32 *)(uaes_lds + OCB_LDS_TE0))[threadIdx.x] = te0[threadIdx.x];
 }
 
 /* XOR of the L_j selected by the bits of g, j counted from `first` (LDS table) */
@@ -102,11 +131,10 @@ __device__ __forceinline__ B16 ocb_gray_sum(u64 g, u32 first)
 /* Offset_i - Offset_0 for an arbitrary index (the tails; one lane) */
 __device__ __forceinline__ B16 ocb_delta(u64 i) { return ocb_gray_sum(i ^ (i >> 1), 0); }
 
-__device__ __forceinline__ void ocb_tables_to_lds(const uint4 *__restrict__ scr)
+/* the two checksum accumulators of a workgroup */
+__device__ __forceinline__ void ocb_clear_acc()
 {
-    if (threadIdx.x < OCB_NL) ((uint4 *)(uaes_lds + OCB_LDS_L))[threadIdx.x] = scr[threadIdx.x];
-    if (threadIdx.x == OCB_NL || threadIdx.x == OCB_NL + 1)
-        *(uint4 *)(uaes_lds + OCB_LDS_ACC + 16u * (threadIdx.x - OCB_NL)) = make_uint4(0, 0, 0, 0);
+    if (threadIdx.x < 2) *(uint4 *)(uaes_lds + OCB_LDS_ACC + 16u * threadIdx.x) = make_uint4(0, 0, 0, 0);
 }
 
 __device__ __forceinline__ void wave_xor_reduce(u32 (&v)[4])
@@ -121,71 +149,56 @@ __device__ __forceinline__ void wave_xor_reduce(u32 (&v)[4])
 /* ------------------------------------------------------------------------ */
 /* per-call setup: L table, Offset_0, cleared checksum                         */
 /* ------------------------------------------------------------------------ */
-/* thread 0 only */
-template <int NR>
-__device__ __forceinline__ void ocb_setup_body(const uaesk_rk &ek, const LaneConst &lc, uint4 nonce_block, u32 bottom,
-                                               u32 nrows, uint4 *__restrict__ scr)
+/* v * x^r (0 <= r < 64) in GF(2^128) as OCB numbers its bits (the block is a big-endian integer, doubleBblock
+ * :434-443 is r = 1): the r bits shifted out come back multiplied by x^7 + x^2 + x + 1, which stays below x^71 */
+__device__ __forceinline__ B16 ocb_times_x_pow(const B16 &b, u32 r)
 {
-    B16 l = { { 0, 0, 0, 0 } };
-    ocb_enc1<NR>(l, ek, lc);                          /* L_* = Enc(0)                  */
-    for (u32 j = 0; j < nrows; ++j) {                 /* L_$, L_0, L_1, ... by doubling: only as far as
-                                                         the block indices of this call reach */
-        scr[j] = u4(l);
-        l = ocb_double(l);
+    u64 hi = ((u64)bswap32(b.w[0]) << 32) | bswap32(b.w[1]);
+    u64 lo = ((u64)bswap32(b.w[2]) << 32) | bswap32(b.w[3]);
+    if (r) {
+        const u64 o = hi >> (64u - r);
+        hi = (hi << r) | (lo >> (64u - r));
+        lo <<= r;
+        lo ^= o ^ (o << 1) ^ (o << 2) ^ (o << 7);
+        hi ^= (o >> 63) ^ (o >> 62) ^ (o >> 57);
     }
-    B16 kt = b16(nonce_block);
-    ocb_enc1<NR>(kt, ek, lc);                         /* K_top                         */
-    const u64 hi = ((u64)bswap32(kt.w[0]) << 32) | bswap32(kt.w[1]);
-    const u64 lo = ((u64)bswap32(kt.w[2]) << 32) | bswap32(kt.w[3]);
-    const u64 ext = hi ^ ((hi << 8) | (lo >> 56));    /* Stretch = K_top || ext        */
-    const u64 ohi = bottom ? (hi << bottom) | (lo >> (64u - bottom)) : hi;
-    const u64 olo = bottom ? (lo << bottom) | (ext >> (64u - bottom)) : lo;
-    scr[OCB_ROW_OFF0] = make_uint4(bswap32((u32)(ohi >> 32)), bswap32((u32)ohi),
-                                   bswap32((u32)(olo >> 32)), bswap32((u32)olo));
+    B16 v;
+    v.w[0] = bswap32((u32)(hi >> 32)); v.w[1] = bswap32((u32)hi);
+    v.w[2] = bswap32((u32)(lo >> 32)); v.w[3] = bswap32((u32)lo);
+    return v;
 }
 
-/* the same by ONE WAVE with the two encryptions side by side (lane 0: L_* = Enc(0), lane 1: K_top): a lane alone
- * walks its ten rounds at the pace of a lone wave whatever the other lanes do, so the second block is free
- * (k_ocb_small: 3.4 -> ?? us of a 14 us launch).  Call with the whole first wave.                          */
-template <int NR>
-__device__ __forceinline__ void ocb_setup_pair(const uaesk_rk &ek, const LaneConst &lc, uint4 nonce_block, u32 bottom,
-                                               u32 nrows, uint4 *scr)
+/* Call with the whole first wave, what `enc` needs in LDS; a barrier must follow.
+ * Lane 0 encrypts the zero block (L_*), lane 1 the nonce block (K_top) -- a lane alone walks its rounds at the
+ * pace of a lone wave whatever the other lanes do, so the second block is free.  Row r of the table is
+ * L_* x^r (row 0 L_*, 1 L_$, 2 + j L_j; getSubkeys doubles its way up, :593-604): every lane shifts its own row
+ * out of L_* in one step.  Offset_0 = bits bottom .. bottom + 127 of K_top || (K_top ^ K_top << 8)[0..63].  */
+template <typename ENC>
+__device__ __forceinline__ void ocb_setup_lds(const ENC &enc, uint4 nonce_block, u32 bottom)
 {
     B16 b = { { 0, 0, 0, 0 } };
     if (threadIdx.x == 1) b = b16(nonce_block);
-    ocb_enc1<NR>(b, ek, lc);
-    if (threadIdx.x == 0) {
-        B16 l = b;
-        for (u32 j = 0; j < nrows; ++j) {             /* L_$, L_0, L_1, ... by doubling */
-            scr[j] = u4(l);
-            l = ocb_double(l);
-        }
-    } else if (threadIdx.x == 1) {
-        const B16 kt = b;
-        const u64 hi = ((u64)bswap32(kt.w[0]) << 32) | bswap32(kt.w[1]);
-        const u64 lo = ((u64)bswap32(kt.w[2]) << 32) | bswap32(kt.w[3]);
+    enc(b);
+    B16 ls;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ls.w[q] = (u32)__builtin_amdgcn_readfirstlane((int)b.w[q]);
+    ((uint4 *)(uaes_lds + OCB_LDS_L))[threadIdx.x] = u4(ocb_times_x_pow(ls, threadIdx.x));
+    if (threadIdx.x == 1) {
+        const u64 hi = ((u64)bswap32(b.w[0]) << 32) | bswap32(b.w[1]);
+        const u64 lo = ((u64)bswap32(b.w[2]) << 32) | bswap32(b.w[3]);
         const u64 ext = hi ^ ((hi << 8) | (lo >> 56));    /* Stretch = K_top || ext        */
         const u64 ohi = bottom ? (hi << bottom) | (lo >> (64u - bottom)) : hi;
         const u64 olo = bottom ? (lo << bottom) | (ext >> (64u - bottom)) : lo;
-        scr[OCB_ROW_OFF0] = make_uint4(bswap32((u32)(ohi >> 32)), bswap32((u32)ohi),
-                                       bswap32((u32)(olo >> 32)), bswap32((u32)olo));
+        *(uint4 *)(uaes_lds + OCB_LDS_OFF0) = make_uint4(bswap32((u32)(ohi >> 32)), bswap32((u32)ohi),
+                                                         bswap32((u32)(olo >> 32)), bswap32((u32)olo));
     }
-}
-
-template <int NR>
-__global__ __launch_bounds__(UAES_WG) void k_ocb_setup(uaesk_rk ek, uaesk_tables tb,
-                                                       uint4 nonce_block, u32 bottom, u32 nrows,
-                                                       uint4 *__restrict__ scr)
-{
-    fill_enc_tables(tb.te0);
-    const LaneConst lc = make_lane_const();
-    if (threadIdx.x == 0) ocb_setup_body<NR>(ek, lc, nonce_block, bottom, nrows, scr);
+    ocb_clear_acc();
 }
 
 /* ------------------------------------------------------------------------ */
 /* the block loop                                                              */
 /* ------------------------------------------------------------------------ */
-/* the caller has put the L table (ocb_tables_to_lds) and the cipher tables of the direction into LDS */
+/* the caller has put the L table and Offset_0 (ocb_setup_lds) and the cipher tables of the direction into LDS */
 template <int NR, bool DEC>
 __device__ __forceinline__ void ocb_main_body(const uaesk_rk &rk, const LaneConst &lc,
                                               uint4 *__restrict__ scr, u64 nblocks, u32 run,
@@ -203,7 +216,7 @@ __device__ __forceinline__ void ocb_main_body(const uaesk_rk &rk, const LaneCons
      * gray(lane), bit 5 taken as lane bit 5), a part that depends on u only (L_5..L_7) and
      * the chunk part; the last two are wave-uniform and live in scalar registers.        */
     const B16 lm = ocb_gray_sum(lane ^ (lane >> 1), 0);
-    const B16 off0 = uniform(b16(scr[OCB_ROW_OFF0]));
+    const B16 off0 = uniform(b16(*(const uint4 *)(uaes_lds + OCB_LDS_OFF0)));
     const B16 l5 = uniform(lds_row(2u + 5u)), l6 = uniform(lds_row(2u + 6u)), l7 = uniform(lds_row(2u + 7u));
 
     /* run is a power of two: shifts and masks, not the 64-bit divisions `k / run`, `k % run` compile to */
@@ -303,18 +316,21 @@ __device__ __forceinline__ void ocb_main_body(const uaesk_rk &rk, const LaneCons
         for (int q = 0; q < 4; ++q) atomicXor(acc + q, sum[q]);
     }
     __syncthreads();
+#ifdef UAES_OCB_SHARE_FENCE
     if (threadIdx.x == 0) scr[OCB_ROW_PART + blockIdx.x] = *(const uint4 *)(uaes_lds + OCB_LDS_ACC);
-}
-
-template <int NR, bool DEC>
-__global__ __launch_bounds__(UAES_WG) void k_ocb(uaesk_rk rk, uaesk_tables tb,
-                                                 uint4 *__restrict__ scr, u64 nblocks, u32 run,
-                                                 const uint4 *in, uint4 *out)
-{
-    ocb_tables_to_lds(scr);
-    if (DEC) fill_dec_tables(tb.td0); else fill_enc_tables(tb.te0);
-    const LaneConst lc = make_lane_const();
-    ocb_main_body<NR, DEC>(rk, lc, scr, nblocks, run, in, out);
+#else
+    /* the share goes out as four device-scope atomic exchanges whose results have come back before the workgroup
+     * counts itself in (k_ocb): they are performed where every XCD sees them, so the counting needs no release
+     * fence -- which on this part writes back the XCD's whole L2, full of ciphertext that nobody is waiting for */
+    if (threadIdx.x == 0) {
+        u32 *row = (u32 *)(scr + OCB_ROW_PART + blockIdx.x);
+        const u32 *acc = (const u32 *)(uaes_lds + OCB_LDS_ACC);
+        u32 old = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) old |= __hip_atomic_exchange(row + q, acc[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" :: "v"(old) : "memory");
+    }
+#endif
 }
 
 /* ------------------------------------------------------------------------ */
@@ -345,10 +361,11 @@ __device__ __forceinline__ u32 b16_byte(const B16 &b, u32 pos)
     return (w >> (8 * (pos & 3))) & 0xffu;
 }
 
-/* the caller has put the L table with cleared accumulators (ocb_tables_to_lds) and the ENCRYPTION tables into LDS */
-template <int NR>
-__device__ __forceinline__ void ocb_final_body(const uaesk_rk &ek, const LaneConst &lc,
-                                               uint4 *__restrict__ scr, u32 nparts, int decrypt,
+/* the caller has put the L table, Offset_0, CLEARED accumulators (ocb_clear_acc) and what `enc` needs into
+ * LDS; parts = the checksum shares of the nparts workgroups of the block loop (any address space) */
+template <typename ENC>
+__device__ __forceinline__ void ocb_final_body(const ENC &enc,
+                                               const uint4 *parts, u32 nparts, int decrypt,
                                                const unsigned char *__restrict__ aad, u64 aad_len,
                                                const unsigned char *in, unsigned char *out, u64 len,
                                                int *status, u32 tag_len)
@@ -357,10 +374,10 @@ __device__ __forceinline__ void ocb_final_body(const uaesk_rk &ek, const LaneCon
     /* HASH(K, A): Sum ^= Enc(A_i ^ Offset_i), Offset from zero (:1749-1754); all threads */
     u32 h[4] = { 0, 0, 0, 0 };
     const u64 na = aad_len >> 4;
-    for (u64 i = threadIdx.x + 1; i <= na; i += UAES_WG) {
+    for (u64 i = threadIdx.x + 1; i <= na; i += blockDim.x) {
         B16 b = ocb_load_bytes(aad + 16 * (i - 1), 16);
         bx(b, ocb_delta(i));
-        ocb_enc1<NR>(b, ek, lc);
+        enc(b);
         h[0] ^= b.w[0]; h[1] ^= b.w[1]; h[2] ^= b.w[2]; h[3] ^= b.w[3];
     }
     if (threadIdx.x == 0 && (aad_len & 15u)) {        /* A_* || 1 || 0.., Offset_* = Offset_m ^ L_* (:1755-1760) */
@@ -369,15 +386,15 @@ __device__ __forceinline__ void ocb_final_body(const uaesk_rk &ek, const LaneCon
         b16_xor_byte(b, r, 0x80u);
         bx(b, ocb_delta(na));
         bx(b, lds_row(0));
-        ocb_enc1<NR>(b, ek, lc);
+        enc(b);
         h[0] ^= b.w[0]; h[1] ^= b.w[1]; h[2] ^= b.w[2]; h[3] ^= b.w[3];
     }
     wave_xor_reduce(h);
     /* checksum shares of the k_ocb workgroups */
     u32 cs[4] = { 0, 0, 0, 0 };
-    if (threadIdx.x < nparts) {
-        const uint4 v = scr[OCB_ROW_PART + threadIdx.x];
-        cs[0] = v.x; cs[1] = v.y; cs[2] = v.z; cs[3] = v.w;
+    for (u32 i = threadIdx.x; i < nparts; i += blockDim.x) {
+        const uint4 v = parts[i];
+        cs[0] ^= v.x; cs[1] ^= v.y; cs[2] ^= v.z; cs[3] ^= v.w;
     }
     wave_xor_reduce(cs);
     if ((threadIdx.x & 63u) == 0) {
@@ -391,13 +408,13 @@ __device__ __forceinline__ void ocb_final_body(const uaesk_rk &ek, const LaneCon
     if (threadIdx.x == 0) {
         const u64 n = len >> 4;
         const u32 r = (u32)(len & 15u);
-        B16 d = b16(scr[OCB_ROW_OFF0]);
+        B16 d = b16(*(const uint4 *)(uaes_lds + OCB_LDS_OFF0));
         bx(d, ocb_delta(n));                              /* Offset_m */
         B16 ck = b16(*(const uint4 *)(uaes_lds + OCB_LDS_ACC + 16u));
         if (r) {                                          /* :1736-1741 */
             bx(d, lds_row(0));                            /* Offset_* = Offset_m ^ L_* */
             B16 pad = d;
-            ocb_enc1<NR>(pad, ek, lc);
+            enc(pad);
             for (u32 i = 0; i < r; ++i) {
                 const u32 x = in[16 * n + i];
                 const u32 y = x ^ b16_byte(pad, i);
@@ -408,7 +425,7 @@ __device__ __forceinline__ void ocb_final_body(const uaesk_rk &ek, const LaneCon
         }
         bx(ck, d);
         bx(ck, lds_row(1));                               /* ^ L_$ */
-        ocb_enc1<NR>(ck, ek, lc);
+        enc(ck);
         bx(ck, b16(*(const uint4 *)(uaes_lds + OCB_LDS_ACC)));
         if (!decrypt) {                                   /* the first OCB_TAG_LEN bytes (:1783 / :1807) */
 #pragma unroll
@@ -424,32 +441,104 @@ __device__ __forceinline__ void ocb_final_body(const uaesk_rk &ek, const LaneCon
     }
 }
 
-template <int NR>
-__global__ __launch_bounds__(UAES_WG) void k_ocb_final(uaesk_rk ek, uaesk_tables tb,
-                                                       uint4 *__restrict__ scr, u32 nparts, int decrypt,
-                                                       const unsigned char *__restrict__ aad, u64 aad_len,
-                                                       const unsigned char *in, unsigned char *out, u64 len,
-                                                       int *status, u32 tag_len)
+/* One call = one launch.  Every workgroup: encryption tables, L table + Offset_0 (first wave), for decryption
+ * the tables of the other direction, then its runs of chunks.  Its checksum share goes to the scratch row of the
+ * workgroup (plain store, released to the device by thread 0) and the workgroup counts itself in on *done_word;
+ * whoever arrives last acquires the others' shares and finishes the call: PMAC of the associated data, the ragged
+ * block, the tag (decryption: the encryption tables come back first).  *done_word is zero between calls (the last
+ * arrival puts it back; the host layer hands out a word that nothing else writes).  A completion ticket may ride
+ * on the launch (every thread ends in ticket_release).
+ * Against setup / block loop / tag as three launches (round 4): 1 GiB +3 %, 16 MiB 33 -> ?? us.                   */
+struct OcbArgs {
+    uaesk_rk ek, dk;                                  /* dk = ek for encryption */
+    uaesk_tables tb;
+    uint4 nonce_block;
+    uint4 *scr;
+    unsigned *done_word;
+    u64 nblocks, aad_len, len;
+    const unsigned char *aad, *in;
+    unsigned char *out;
+    int *status;
+    u32 bottom, run, tag_len;
+    uaesk_done done;
+};
+
+/* The arguments are read through the kernel-argument pointer where they are used: as plain parameters all of them
+ * are loaded at the entry and what only the last phase needs (pointers, lengths, for decryption a second key
+ * schedule) sits in scalar registers across the block loop, which has none to spare (22 more v_readlane per trip). */
+template <int NR, bool DEC>
+__global__ __launch_bounds__(UAES_WG) void k_ocb(OcbArgs)
 {
-    ocb_tables_to_lds(scr);
-    fill_enc_tables(tb.te0);
+    const OcbArgs *const a = (const OcbArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    if (DEC) {
+        ocb_fill_plain_te0(a->tb.te0);
+        fill_dec_tables(a->tb.td0);
+    } else {
+        fill_enc_tables(a->tb.te0);
+    }
     const LaneConst lc = make_lane_const();
-    ocb_final_body<NR>(ek, lc, scr, nparts, decrypt, aad, aad_len, in, out, len, status, tag_len);
+    if (threadIdx.x < 64) {
+        const uaesk_rk ek = a->ek;
+        if (DEC) ocb_setup_lds(EncPlain<NR>{ ek }, a->nonce_block, a->bottom);
+        else ocb_setup_lds(EncRep<NR>{ ek, lc }, a->nonce_block, a->bottom);
+    }
+    __syncthreads();
+    const u64 nblocks = a->nblocks;
+    if (nblocks) {
+        const uaesk_rk rk = DEC ? a->dk : a->ek;
+        ocb_main_body<NR, DEC>(rk, lc, a->scr, nblocks, a->run, (const uint4 *)a->in, (uint4 *)a->out);
+    }
+    bool last = true;
+    if (gridDim.x > 1) {
+        if (threadIdx.x == 0) {                       /* after ocb_main_body's store of the share, same thread */
+            unsigned *const done_word = a->done_word;
+#ifdef UAES_OCB_SHARE_FENCE
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
+            const unsigned arrived = __hip_atomic_fetch_add(done_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned l = arrived == gridDim.x - 1u ? 1u : 0u;
+            if (l) __hip_atomic_store(done_word, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *(volatile u32 *)(uaes_lds + OCB_LDS_FLAG) = l;
+        }
+        __syncthreads();
+        last = __builtin_amdgcn_readfirstlane((int)*(volatile u32 *)(uaes_lds + OCB_LDS_FLAG)) != 0;
+    }
+    if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        ocb_clear_acc();
+        const uaesk_rk ek = a->ek;
+        const u32 nparts = nblocks ? gridDim.x : 0u;
+        /* decryption: the few encryptions of the tag go through the plain table; associated data beyond a few
+         * blocks per thread is worth bringing the replicated encryption tables back for */
+        if (DEC && a->aad_len > OCB_PLAIN_AAD) {
+            fill_enc_tables(a->tb.te0);
+            ocb_final_body(EncRep<NR>{ ek, lc }, a->scr + OCB_ROW_PART, nparts, 1, a->aad, a->aad_len,
+                           a->in, a->out, a->len, a->status, a->tag_len);
+        } else {
+            __syncthreads();
+            if (DEC)
+                ocb_final_body(EncPlain<NR>{ ek }, a->scr + OCB_ROW_PART, nparts, 1, a->aad, a->aad_len,
+                               a->in, a->out, a->len, a->status, a->tag_len);
+            else
+                ocb_final_body(EncRep<NR>{ ek, lc }, a->scr + OCB_ROW_PART, nparts, 0, a->aad, a->aad_len,
+                               a->in, a->out, a->len, a->status, a->tag_len);
+        }
+    }
+    ticket_release(a->done);
 }
 
-/* Short messages (<= 1024 whole blocks, <= 64 KiB of associated data): setup, block loop and tag in ONE launch of
- * one workgroup -- the three phases run one after the other with the scratch rows handed over in global memory
- * behind workgroup barriers; decryption swaps the cipher tables between the phases (setup and tag use Enc).
+/* Short messages (<= 1024 whole blocks, <= 64 KiB of associated data): ONE workgroup, one block per lane -- the
+ * three phases run one after the other with everything handed over in LDS; decryption swaps the cipher tables
+ * between the phases (setup and tag use Enc).
  * 4 KiB call: 38.5 -> 30 us (what is left is serial: tables, L_* / K_top / tag encryptions by one lane).                                                                            */
 #define OCB_SMALL_BLOCKS 1024u
 #define OCB_SMALL_AAD    65536u
-#define OCB_SMALL_SCR    ((OCB_LDS + 63u) & ~63u)                 /* 66 rows of hand-over scratch behind the accumulators */
-#define OCB_SMALL_LDS    (OCB_SMALL_SCR + 16u * (OCB_ROW_PART + 1u))
+#define OCB_SMALL_SCR    ((OCB_LDS + 63u) & ~63u)                 /* the checksum share, behind the flag */
+#define OCB_SMALL_LDS    (OCB_SMALL_SCR + 16u)
 
 template <int NR, bool DEC>
 __global__ __launch_bounds__(UAES_WG) void k_ocb_small(uaesk_rk ek, uaesk_rk dk, uaesk_tables tb,
-                                                       uint4 nonce_block, u32 bottom, u32 nrows,
-                                                       uint4 *scr_dev,
+                                                       uint4 nonce_block, u32 bottom,
                                                        const unsigned char *__restrict__ aad, u64 aad_len,
                                                        const unsigned char *in, unsigned char *out, u64 len,
                                                        int *status, u32 tag_len, uaesk_done done)
@@ -461,22 +550,25 @@ __global__ __launch_bounds__(UAES_WG) void k_ocb_small(uaesk_rk ek, uaesk_rk dk,
 #define OT(i) do { } while (0)
 #endif
     OT(0);
-    /* one workgroup: the rows the phases hand over (L table, Offset_0, the checksum share) stay in LDS -- through the
-     * device scratch of the multi-workgroup path every hand-over was a store, a fence and a load from memory, ~2 us
-     * each, three times per call (-DUAES_OCB_TIMING)                                                          */
-    (void)scr_dev;
-    uint4 *const scr = (uint4 *)(uaes_lds + OCB_SMALL_SCR);
-    fill_enc_tables(tb.te0);
+    uint4 *const part = (uint4 *)(uaes_lds + OCB_SMALL_SCR);
+    const u64 nblocks = len >> 4;
+    const bool dec_tables = DEC && nblocks;                   /* else: an encrypting launch in all but name */
+    if (dec_tables) {
+        ocb_fill_plain_te0(tb.te0);
+        fill_dec_tables(tb.td0);
+    } else {
+        fill_enc_tables(tb.te0);
+    }
     const LaneConst lc = make_lane_const();
     OT(1);
-    if (threadIdx.x < 64) ocb_setup_pair<NR>(ek, lc, nonce_block, bottom, nrows, scr);
-    __syncthreads();                                          /* (the rows are in LDS: no fence to memory needed) */
+    if (threadIdx.x < 64) {
+        if (dec_tables) ocb_setup_lds(EncPlain<NR>{ ek }, nonce_block, bottom);
+        else ocb_setup_lds(EncRep<NR>{ ek, lc }, nonce_block, bottom);
+    }
+    __syncthreads();
     OT(2);
-    const u64 nblocks = len >> 4;
     u32 nparts = 0;
     if (nblocks) {
-        ocb_tables_to_lds(scr);
-        if (DEC) fill_dec_tables(tb.td0); else __syncthreads();
         /* one block per lane (block i = thread + 1, Offset_i = Offset_0 ^ the L_j of gray(i)): a 4 KiB text runs on
          * four waves with the latency of ONE block encryption; ocb_main_body's wave-per-256-blocks layout would
          * put it on a single wave, four blocks in a row                                                       */
@@ -484,7 +576,7 @@ __global__ __launch_bounds__(UAES_WG) void k_ocb_small(uaesk_rk ek, uaesk_rk dk,
             const u64 i = (u64)threadIdx.x + 1;
             const bool live = i <= nblocks;
             const u64 ic = live ? i : nblocks;                 /* clamped: no branch around the rounds */
-            B16 off = b16(scr[OCB_ROW_OFF0]);
+            B16 off = b16(*(const uint4 *)(uaes_lds + OCB_LDS_OFF0));
             bx(off, ocb_delta(ic));
             const uint4 d = ((const uint4 *)in)[ic - 1];
             const u32 lv = live ? 0xffffffffu : 0u;
@@ -506,16 +598,23 @@ __global__ __launch_bounds__(UAES_WG) void k_ocb_small(uaesk_rk ek, uaesk_rk dk,
                 for (int q = 0; q < 4; ++q) atomicXor(acc + q, sum[q]);
             }
             __syncthreads();
-            if (threadIdx.x == 0) scr[OCB_ROW_PART] = *(const uint4 *)(uaes_lds + OCB_LDS_ACC);
+            if (threadIdx.x == 0) *part = *(const uint4 *)(uaes_lds + OCB_LDS_ACC);
         }
         nparts = 1;
         __syncthreads();
+        ocb_clear_acc();
     }
     OT(3);
-    ocb_tables_to_lds(scr);
-    if (DEC && nblocks) fill_enc_tables(tb.te0); else __syncthreads();
-    OT(4);
-    ocb_final_body<NR>(ek, lc, scr, nparts, DEC ? 1 : 0, aad, aad_len, in, out, len, status, tag_len);
+    if (dec_tables && aad_len > OCB_PLAIN_AAD) {
+        fill_enc_tables(tb.te0);
+        OT(4);
+        ocb_final_body(EncRep<NR>{ ek, lc }, part, nparts, 1, aad, aad_len, in, out, len, status, tag_len);
+    } else {
+        __syncthreads();
+        OT(4);
+        if (dec_tables) ocb_final_body(EncPlain<NR>{ ek }, part, nparts, 1, aad, aad_len, in, out, len, status, tag_len);
+        else ocb_final_body(EncRep<NR>{ ek, lc }, part, nparts, DEC ? 1 : 0, aad, aad_len, in, out, len, status, tag_len);
+    }
 #ifdef UAES_OCB_TIMING
     OT(5);
     if (threadIdx.x == 0)
@@ -545,65 +644,53 @@ static hipError_t want_lds(const void *kern)
 template <int NR>
 static int launch_ocb(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek, const uaesk_rk *dk,
                       int decrypt, uint4 nb, u32 bottom, u32 tag_len, const void *aad, size_t aad_len,
-                      const void *in, size_t len, void *out, void *scratch, int *status)
+                      const void *in, size_t len, void *out, void *scratch, unsigned *done_word, int *status)
 {
     uint4 *scr = (uint4 *)scratch;
-    hipError_t e = want_lds((const void *)k_ocb_setup<NR>);
-    if (e == hipSuccess) e = want_lds((const void *)k_ocb_final<NR>);
-    if (e == hipSuccess) e = want_lds(decrypt ? (const void *)k_ocb<NR, true> : (const void *)k_ocb<NR, false>);
-    if (e != hipSuccess) return (int)e;
-    /* row 2+j holds L_j; block indices below 2^b (text or AAD) reach L_0..L_b; L_0..L_7 always */
-    u64 span = (u64)(len >> 4) | (u64)(aad_len >> 4) | 255u;
-    u32 bits = 0;
-    while (span) { ++bits; span >>= 1; }
-    const u32 nrows = 2u + bits + 2u < OCB_NL ? 2u + bits + 2u : OCB_NL;
-    if ((len >> 4) <= OCB_SMALL_BLOCKS && aad_len <= OCB_SMALL_AAD) {         /* short message: one launch */
-        /* ... which can carry the call's completion ticket (a decryption's status word must then be host-visible:
-         * the host layer arms a ticket only when it passes a pinned status pointer) */
-        const uaesk_done done = uaesk_ticket_take();
+    hipError_t e;
+    /* one launch either way, which can carry the call's completion ticket (a decryption's status word must then
+     * be host-visible: the host layer arms a ticket only when it passes a pinned status pointer) */
+    const uaesk_done done = uaesk_ticket_take();
+    if ((len >> 4) <= OCB_SMALL_BLOCKS && aad_len <= OCB_SMALL_AAD) {         /* short message: one workgroup */
         const void *ks = decrypt ? (const void *)k_ocb_small<NR, true> : (const void *)k_ocb_small<NR, false>;
         if ((e = uaesk_want_lds(ks, (unsigned)OCB_SMALL_LDS)) != hipSuccess) return (int)e;
         if (decrypt)
-            hipLaunchKernelGGL((k_ocb_small<NR, true>), dim3(1), dim3(UAES_WG), OCB_SMALL_LDS, st, *ek, *dk, *tb, nb, bottom, nrows,
-                               scr, (const unsigned char *)aad, (u64)aad_len, (const unsigned char *)in,
+            hipLaunchKernelGGL((k_ocb_small<NR, true>), dim3(1), dim3(UAES_WG), OCB_SMALL_LDS, st, *ek, *dk, *tb, nb, bottom,
+                               (const unsigned char *)aad, (u64)aad_len, (const unsigned char *)in,
                                (unsigned char *)out, (u64)len, status, tag_len, done);
         else
-            hipLaunchKernelGGL((k_ocb_small<NR, false>), dim3(1), dim3(UAES_WG), OCB_SMALL_LDS, st, *ek, *ek, *tb, nb, bottom, nrows,
-                               scr, (const unsigned char *)aad, (u64)aad_len, (const unsigned char *)in,
+            hipLaunchKernelGGL((k_ocb_small<NR, false>), dim3(1), dim3(UAES_WG), OCB_SMALL_LDS, st, *ek, *ek, *tb, nb, bottom,
+                               (const unsigned char *)aad, (u64)aad_len, (const unsigned char *)in,
                                (unsigned char *)out, (u64)len, status, tag_len, done);
         return (int)hipGetLastError();
     }
-    hipLaunchKernelGGL((k_ocb_setup<NR>), dim3(1), dim3(UAES_WG), OCB_LDS, st, *ek, *tb, nb, bottom, nrows, scr);
+    if ((e = want_lds(decrypt ? (const void *)k_ocb<NR, true> : (const void *)k_ocb<NR, false>)) != hipSuccess) return (int)e;
     const u64 nblocks = len >> 4;
-    u32 nparts = 0;
-    if (nblocks) {
-        const u64 nchunks = (nblocks >> 8) + 1;
-        /* at least 8 runs per wave, so that an uneven split costs at most 1/8 */
-        u32 run = OCB_RUN_MAX;
-        while (run > 1 && nchunks / run < 8ull * cu_count() * (UAES_WG / 64)) run >>= 1;
-        const u64 runs = (nchunks + run - 1) / run;
-        /* short texts: 4-wave workgroups, so that the few chunks spread over more CUs */
-        const unsigned wg = (runs + UAES_WG / 64 - 1) / (UAES_WG / 64) * 2 <= cu_count() ? 256u : UAES_WG;
-        u64 grid = (runs + wg / 64 - 1) / (wg / 64);
-        if (grid > cu_count()) grid = cu_count();
-        if (grid > OCB_MAX_WGS) grid = OCB_MAX_WGS;
-        nparts = (u32)grid;
-        if (decrypt)
-            hipLaunchKernelGGL((k_ocb<NR, true>), dim3((unsigned)grid), dim3(wg), OCB_LDS, st, *dk, *tb, scr,
-                               nblocks, run, (const uint4 *)in, (uint4 *)out);
-        else
-            hipLaunchKernelGGL((k_ocb<NR, false>), dim3((unsigned)grid), dim3(wg), OCB_LDS, st, *ek, *tb, scr,
-                               nblocks, run, (const uint4 *)in, (uint4 *)out);
-    }
-    hipLaunchKernelGGL((k_ocb_final<NR>), dim3(1), dim3(UAES_WG), OCB_LDS, st, *ek, *tb, scr, nparts, decrypt,
-                       (const unsigned char *)aad, (u64)aad_len, (const unsigned char *)in, (unsigned char *)out,
-                       (u64)len, status, tag_len);
+    const u64 nchunks = (nblocks >> 8) + 1;
+    /* at least 8 runs per wave, so that an uneven split costs at most 1/8 */
+    u32 run = OCB_RUN_MAX;
+    while (run > 1 && nchunks / run < 8ull * cu_count() * (UAES_WG / 64)) run >>= 1;
+    const u64 runs = (nchunks + run - 1) / run;
+    /* short texts: 4-wave workgroups, so that the few chunks spread over more CUs */
+    const unsigned wg = (runs + UAES_WG / 64 - 1) / (UAES_WG / 64) * 2 <= cu_count() ? 256u : UAES_WG;
+    u64 grid = (runs + wg / 64 - 1) / (wg / 64);
+    if (grid > cu_count()) grid = cu_count();
+    if (grid > OCB_MAX_WGS) grid = OCB_MAX_WGS;
+    if (!nblocks) grid = 1;                                                   /* associated data only */
+    OcbArgs ka;
+    ka.ek = *ek; ka.dk = decrypt ? *dk : *ek; ka.tb = *tb; ka.nonce_block = nb; ka.scr = scr; ka.done_word = done_word;
+    ka.nblocks = nblocks; ka.aad_len = aad_len; ka.len = len; ka.aad = (const unsigned char *)aad;
+    ka.in = (const unsigned char *)in; ka.out = (unsigned char *)out; ka.status = status;
+    ka.bottom = bottom; ka.run = run; ka.tag_len = tag_len; ka.done = done;
+    if (decrypt) hipLaunchKernelGGL((k_ocb<NR, true>), dim3((unsigned)grid), dim3(wg), OCB_LDS, st, ka);
+    else hipLaunchKernelGGL((k_ocb<NR, false>), dim3((unsigned)grid), dim3(wg), OCB_LDS, st, ka);
     return (int)hipGetLastError();
 }
 
 extern "C" size_t uaesk_ocb_scratch_bytes(void) { return 16u * (OCB_ROW_PART + OCB_MAX_WGS); }
 
-/* nonce is a host pointer; everything else device memory (in/out 16-byte aligned).
+/* nonce is a host pointer; everything else device memory (in/out 16-byte aligned).  done_word: a device word that
+ * is zero between calls and that nothing else writes (the workgroups of a launch count themselves in on it).
  * encrypt: tag_len bytes of tag written at out+len.  decrypt: tag read at in+len, *status = 0 / 0x1A,
  * the text is written either way (as in the reference, :1804-1809).
  * nonce_len / tag_len = the reference's OCB_NONCE_LEN (1..15) / OCB_TAG_LEN (1..16), micro_aes.h:115-116 */
@@ -611,7 +698,7 @@ extern "C" int uaesk_ocb(void *stream, const uaesk_tables *tb, int nr,
                          const uaesk_rk *ek, const uaesk_rk *dk, int decrypt, const uint8_t *nonce,
                          size_t nonce_len, size_t tag_len,
                          const void *aad, size_t aad_len, const void *in, size_t len, void *out,
-                         void *scratch, int *status)
+                         void *scratch, unsigned *done_word, int *status)
 {
     if (nonce_len < 1 || nonce_len > 15 || tag_len < 1 || tag_len > 16) return (int)hipErrorInvalidValue;
     uint8_t kt[16];
@@ -625,9 +712,9 @@ extern "C" int uaesk_ocb(void *stream, const uaesk_tables *tb, int nr,
     memcpy(&nb, kt, 16);
     const u32 tl = (u32)tag_len;
     switch (nr) {
-    case 10: return launch_ocb<10>(S(stream), tb, ek, dk, decrypt, nb, bottom, tl, aad, aad_len, in, len, out, scratch, status);
-    case 12: return launch_ocb<12>(S(stream), tb, ek, dk, decrypt, nb, bottom, tl, aad, aad_len, in, len, out, scratch, status);
-    case 14: return launch_ocb<14>(S(stream), tb, ek, dk, decrypt, nb, bottom, tl, aad, aad_len, in, len, out, scratch, status);
+    case 10: return launch_ocb<10>(S(stream), tb, ek, dk, decrypt, nb, bottom, tl, aad, aad_len, in, len, out, scratch, done_word, status);
+    case 12: return launch_ocb<12>(S(stream), tb, ek, dk, decrypt, nb, bottom, tl, aad, aad_len, in, len, out, scratch, done_word, status);
+    case 14: return launch_ocb<14>(S(stream), tb, ek, dk, decrypt, nb, bottom, tl, aad, aad_len, in, len, out, scratch, done_word, status);
     default: return (int)hipErrorInvalidValue;
     }
 }

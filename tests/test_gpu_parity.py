@@ -387,6 +387,45 @@ def test_ocb_vs_oracle(orc, bits):
         assert (rc, txt) == orc.ocb_decrypt(key, nonce, aad, bytes(bad)) and rc == 0x1A
 
 
+@pytest.mark.parametrize("bits", [128, 256])
+def test_ocb_one_launch_paths(orc, bits):
+    """OCB is one launch per call: every workgroup derives the L table and Offset_0 itself and the LAST workgroup to
+    arrive (a counter word that must be back at zero for the next call) hashes the associated data and makes the
+    tag; a decrypting launch encrypts through a plain Te0, or brings the encryption tables back for long
+    associated data.  Text sizes on both sides of the one-workgroup limit x associated data on both sides of the
+    plain-table limit (16 KiB) and of the one-workgroup limit (64 KiB), no text at all, the same lane again and
+    again, host and device pointers (the *_dev scratch slots have their own counter word)."""
+    import torch
+    rnd = random.Random(bits + 77)
+    st = torch.cuda.current_stream()
+    for n in (0, 100, 16 * 1024, 16 * 1025 + 3, (5 << 20) + 1, (40 << 20) + 16):
+        for alen in (0, 15, 16384, 16385, 65536, 65537, 200000):
+            if n > (5 << 20) and alen not in (0, 16385):
+                continue
+            key, nonce = rnd.randbytes(bits // 8), rnd.randbytes(12)
+            aad, data = rnd.randbytes(alen), orc.splitmix(n + alen, n)
+            want = orc.ocb_encrypt(key, nonce, aad, data)
+            ct = uaes.AES_OCB_encrypt(key, nonce, aad, data)
+            assert ct == want, (n, alen)
+            assert uaes.AES_OCB_decrypt(key, nonce, aad, ct) == (0, data), (n, alen)
+            bad = bytearray(ct)
+            bad[-1] ^= 1
+            assert uaes.AES_OCB_decrypt(key, nonce, aad, bytes(bad))[0] == 0x1A
+            if bits == 128 and n % 16 == 0 and n:
+                d_in = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+                d_aad = torch.frombuffer(bytearray(aad), dtype=torch.uint8).cuda() if alen else None
+                d_out = torch.zeros(n + 16, dtype=torch.uint8, device="cuda")
+                status = torch.full((1,), -1, dtype=torch.int32, device="cuda")
+                for _ in range(2):
+                    uaes.ocb_dev(key, nonce, d_aad, d_in, n, d_out, stream=st)
+                torch.cuda.synchronize()
+                assert bytes(d_out.cpu().numpy()) == want, (n, alen)
+                back = torch.zeros(n, dtype=torch.uint8, device="cuda")
+                uaes.ocb_dev(key, nonce, d_aad, d_out, n, back, decrypt=True, status=status, stream=st)
+                torch.cuda.synchronize()
+                assert int(status.item()) == 0 and bytes(back.cpu().numpy()) == data
+
+
 def test_main_c_kats(golden_dir):
     for k in load(golden_dir, "main_kats.json"):
         key, pt, exp = bytes.fromhex(k["key"]), bytes.fromhex(k["pt"]), bytes.fromhex(k["expect"])
