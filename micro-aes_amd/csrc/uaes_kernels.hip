@@ -334,7 +334,17 @@ __device__ __forceinline__ void store16(unsigned char *p, uint4 v)
  * The next chunk's data and tweak are requested before this chunk's rounds;
  * encryption runs the four blocks as two skewed pairs (enc_blocks_skewed).   */
 /* in == out is allowed (every lane reads its blocks before it writes them): no __restrict__ */
-template <int NR, bool DEC, bool ALIGNED>
+/* PACKED (round 5): data units SHORTER than a chunk -- 64 B .. 4080 B, a multiple of 64 bytes; the 512-byte
+ * sector is the classic one.  With a chunk per unit a 512-byte unit filled 32 of a wave's 256 block slots (140 GiB/s
+ * against 1000 for 4 KiB units).  Here the text is one flat run of blocks cut into 256-block chunks whatever the unit
+ * size, and lane l takes the four CONSECUTIVE blocks 4 l .. 4 l + 3 of the chunk: they lie in one unit (a unit is a
+ * multiple of four blocks), so the lane needs one unit tweak T_s (a per-lane load from the pre-pass' table instead of
+ * a wave-uniform one), one shift by the block's position in the unit and three doublings.  Its loads and stores are
+ * 64 bytes apart from its neighbours' instead of 16 (a wave-level access is 4 KiB wide, a quarter of it used, the
+ * four accesses of a chunk use all of it); the memory path has room for that in a kernel that needs 16 + 16 bytes
+ * every eight cycles per CU.  Arguments then: chunks_per_sector = blocks per unit, main_blocks = blocks of the whole
+ * text, (step_q, step_r) = (256 * waves) / and % blocks per unit, magic = ceil(2^24 / blocks per unit).           */
+template <int NR, bool DEC, bool ALIGNED, bool PACKED = false>
 __global__ __launch_bounds__(UAES_WG) void k_xts(uaesk_rk k1, uaesk_tables tb,
                                                  const uint4 *__restrict__ chunk_tw,
                                                  u64 nsectors, u64 chunks_per_sector,
@@ -343,7 +353,8 @@ __global__ __launch_bounds__(UAES_WG) void k_xts(uaesk_rk k1, uaesk_tables tb,
                                                  u64 step_q, u64 step_r,   /* (waves of the grid) / and % chunks_per_sector */
                                                  const unsigned char *in,
                                                  unsigned char *out,
-                                                 u64 nmain)            /* chunks [nmain, all) go by quarters (== all: none) */
+                                                 u64 nmain,            /* chunks [nmain, all) go by quarters (== all: none) */
+                                                 u32 magic)
 {
     if (DEC) fill_dec_tables(tb.td0); else fill_enc_tables(tb.te0);
     const LaneConst lc = make_lane_const();
@@ -360,21 +371,28 @@ __global__ __launch_bounds__(UAES_WG) void k_xts(uaesk_rk k1, uaesk_tables tb,
 
     /* (unit, chunk inside the unit) of the chunk being fetched: one division here, then stepped by the
      * grid's wave count as (step_q, step_r) -- a 64-bit division per chunk cost ~8 % of the loop     */
-    u64 sctn = wave / chunks_per_sector, withn = wave - sctn * chunks_per_sector;
+    /* PACKED: (unit, block inside the unit) of the chunk's first block */
+    u64 sctn = (PACKED ? wave * XTS_CHUNK : wave) / chunks_per_sector;
+    u64 withn = (PACKED ? wave * XTS_CHUNK : wave) - sctn * chunks_per_sector;
     struct Fetched {
         uint4 d[UAES_U], tb;
         u32 cnt;
+        u32 rb;                                      /* PACKED: (unit, position in it) of the chunk's first block */
+        u64 sb;
         u64 off;                                     /* byte offset of the chunk's first block */
     };
+    const u32 lane_off = PACKED ? lane * 64u : lane16, u_off = PACKED ? 16u : 1024u;
     auto fetch = [&](u64 ch, Fetched &f) {
         const u64 sct = sctn;
-        const u64 first = withn * XTS_CHUNK;
+        const u64 first = PACKED ? ch * XTS_CHUNK : withn * XTS_CHUNK;
+        const u32 rb = (u32)withn;
         sctn += step_q; withn += step_r;             /* the next chunk of this wave */
         if (withn >= chunks_per_sector) { withn -= chunks_per_sector; ++sctn; }
         const u64 left = main_blocks - first;
         f.cnt = left < XTS_CHUNK ? (u32)left : XTS_CHUNK;
-        f.off = sct * sector_bytes + first * 16;
-        f.tb = chunk_tw[ch];
+        f.off = PACKED ? first * 16 : sct * sector_bytes + first * 16;
+        if (PACKED) { f.rb = rb; f.sb = sct; }                   /* the lane's unit tweak follows later (fetch_tw) */
+        else f.tb = chunk_tw[ch];
         const unsigned char *src = in + f.off;
         if (ALIGNED) {
             /* a buffer resource over exactly the chunk's blocks: base in SGPRs, the lane's constant offset, and the
@@ -386,7 +404,7 @@ __global__ __launch_bounds__(UAES_WG) void k_xts(uaesk_rk k1, uaesk_tables tb,
                 0, (int)(f.cnt * 16u), 0x00020000);
 #pragma unroll
             for (int u = 0; u < UAES_U; ++u) {
-                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, lane16 + 1024u * u, 0, 0);
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, lane_off + u_off * u, 0, 0);
                 f.d[u] = make_uint4(v.x, v.y, v.z, v.w);
             }
         } else {
@@ -399,6 +417,26 @@ __global__ __launch_bounds__(UAES_WG) void k_xts(uaesk_rk k1, uaesk_tables tb,
         }
     };
 
+    /* PACKED: the unit tweak of the lane's four blocks, a per-lane load (four vector registers where the other
+     * arrangement has four scalars); requested for the NEXT chunk between the two pairs of this one, when the first
+     * pair's text registers are free -- with the text loads at the top the kernel does not fit 128 registers */
+    auto lane_pos = [&](const Fetched &f, u32 &q) {
+        const u32 x = f.rb + 4u * lane;                          /* < 512 */
+        q = (x * magic) >> 24;                                   /* x / blocks per unit */
+        return x - q * (u32)chunks_per_sector;
+    };
+    auto fetch_tw = [&](Fetched &f) {
+        u32 q;
+        (void)lane_pos(f, q);
+        /* a buffer resource over the table from the chunk's first unit on: base in SGPRs, 16 q as the lane's offset,
+         * zeros for lanes past the last unit */
+        const u64 left = nsectors - f.sb;
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(chunk_tw + f.sb), 0, (int)(left < 1024 ? left * 16u : 16384u), 0x00020000);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, q * 16u, 0, 0);
+        f.tb = make_uint4(v.x, v.y, v.z, v.w);
+    };
+
     /* one chunk: request the wave's next one into `nx`, then whiten, encrypt and store `cur`.  Expanded twice per loop
      * trip with the two buffers swapped: "next becomes current" is a renaming, not twenty register moves.  (Stores go
      * through plain global pointers: uaes_ctr.hip.h explains why not through a buffer resource.)               */
@@ -409,7 +447,17 @@ __global__ __launch_bounds__(UAES_WG) void k_xts(uaesk_rk k1, uaesk_tables tb,
         Tw t;
         t.lo = cur.tb.x | ((u64)cur.tb.y << 32);
         t.hi = cur.tb.z | ((u64)cur.tb.w << 32);
-        t = tw_mul_pow(t, lane);
+        if (PACKED) {
+            u32 q;
+            const u32 p0 = lane_pos(cur, q);
+            t = tw_mul_pow(t, p0 & 63u);
+            const Tw t64 = tw_mul_pow64(t);
+            if (p0 & 64u) t = t64;
+            const Tw t128 = tw_mul_pow64(tw_mul_pow64(t));
+            if (p0 & 128u) t = t128;
+        } else {
+            t = tw_mul_pow(t, lane);
+        }
         unsigned char *dst = out + cur.off;
         /* two skewed pairs one after the other: only one pair's states and tweaks are live at a time
          * (all four at once spilled 8-18 registers)                                                  */
@@ -422,23 +470,24 @@ __global__ __launch_bounds__(UAES_WG) void k_xts(uaesk_rk k1, uaesk_tables tb,
                 tw[u][2] = (u32)t.hi; tw[u][3] = (u32)(t.hi >> 32);
                 s[u][0] = cur.d[pr + u].x ^ tw[u][0]; s[u][1] = cur.d[pr + u].y ^ tw[u][1];
                 s[u][2] = cur.d[pr + u].z ^ tw[u][2]; s[u][3] = cur.d[pr + u].w ^ tw[u][3];
-                t = tw_mul_pow64(t);
+                t = PACKED ? tw_mul_pow(t, 1) : tw_mul_pow64(t);
             }
             if (DEC) dec_blocks_skewed<NR>(s[0], s[1], k1, lc);
             else enc_blocks_skewed<NR>(s[0], s[1], k1, lc);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const u32 j = lane + 64u * (pr + u);
+                const u32 j = PACKED ? 4u * lane + (u32)(pr + u) : lane + 64u * (pr + u);
                 if (j < cur.cnt)
                     store16<ALIGNED>(dst + 16u * j, make_uint4(s[u][0] ^ tw[u][0], s[u][1] ^ tw[u][1],
                                                                s[u][2] ^ tw[u][2], s[u][3] ^ tw[u][3]));
             }
         }
+        if (PACKED && nxt < nchunks) fetch_tw(nx);
     };
 
     Fetched fa, fb;
     u64 ch = wave;
-    if (ch < nchunks) fetch(ch, fa);
+    if (ch < nchunks) { fetch(ch, fa); if (PACKED) fetch_tw(fa); }
     while (ch < nchunks) {
         body(ch, fa, fb);
         ch += nwaves;
@@ -451,7 +500,7 @@ __global__ __launch_bounds__(UAES_WG) void k_xts(uaesk_rk k1, uaesk_tables tb,
      * (a round is 4096 waves x 4 KiB = 16 MiB: 18 MiB ran at 0.75 of the 16 MiB rate).  The host hands such a remainder
      * over as chunks [nmain, all); here they go by QUARTERS -- 64 blocks, one per lane -- over four times as many waves.
      * Quarter k of a chunk starts at its tweak * alpha^(64 k).                                                       */
-    const u64 all = nsectors * chunks_per_sector;
+    const u64 all = PACKED ? nmain : nsectors * chunks_per_sector;
     for (u64 q = wave; q < 4 * (all - nmain); q += nwaves) {
         const u64 c = nmain + (q >> 2);
         const u32 k = (u32)q & 3u;
@@ -988,6 +1037,18 @@ static int launch_xts(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *k1
     if (!serial)
         hipLaunchKernelGGL(k_xts_expand, dim3(grid_for((u64)nsectors * ((cps + 63) / 64), UAES_WG / 64)),
                            dim3(UAES_WG), 0, st, *xts_pow_table(), (u64)nsectors, cps, (uint4 *)scratch);
+    /* units shorter than a chunk (whole blocks, a multiple of four): the flat, packed arrangement (k_xts) */
+    if (!tweak16 && r == 0 && mb >= 4 && mb < XTS_CHUNK && mb % 4 == 0 && nsectors > 1) {
+        if ((e = set_lds((k_xts<NR, DEC, true, true>), lds)) != hipSuccess) return (int)e;
+        const u64 total = (u64)nsectors * mb, nchunks = (total + XTS_CHUNK - 1) / XTS_CHUNK;
+        const unsigned wg = grid_for(nchunks, UAES_WG / 64) * 2 <= grid_for(~0ull, 1) ? 256u : UAES_WG;
+        const unsigned xgrid = grid_for(nchunks, wg / 64);
+        const u64 adv = (u64)xgrid * (wg / 64) * XTS_CHUNK;
+        hipLaunchKernelGGL((k_xts<NR, DEC, true, true>), dim3(xgrid), dim3(wg), lds, st,
+                           *k1, *tb, (const uint4 *)scratch, (u64)nsectors, mb, total, (u64)sector_bytes, adv / mb, adv % mb,
+                           (const unsigned char *)in, (unsigned char *)out, nchunks, (u32)(((1u << 24) + mb - 1) / mb));
+        return (int)hipGetLastError();
+    }
     if (mb > 0) {
         const u64 nchunks = (u64)nsectors * ((mb + XTS_CHUNK - 1) / XTS_CHUNK);
         /* one wave per 256-block chunk: a short text on 16-wave workgroups would sit on a few CUs,
@@ -1003,11 +1064,11 @@ static int launch_xts(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *k1
         if (sector_bytes % 16 == 0 || nsectors == 1)
             hipLaunchKernelGGL((k_xts<NR, DEC, true>), dim3(xgrid), dim3(wg), lds, st,
                                *k1, *tb, (const uint4 *)scratch, (u64)nsectors, cps, mb, (u64)sector_bytes, step_q, step_r,
-                               (const unsigned char *)in, (unsigned char *)out, nmain);
+                               (const unsigned char *)in, (unsigned char *)out, nmain, 0u);
         else
             hipLaunchKernelGGL((k_xts<NR, DEC, false>), dim3(xgrid), dim3(wg), lds, st,
                                *k1, *tb, (const uint4 *)scratch, (u64)nsectors, cps, mb, (u64)sector_bytes, step_q, step_r,
-                               (const unsigned char *)in, (unsigned char *)out, nmain);
+                               (const unsigned char *)in, (unsigned char *)out, nmain, 0u);
     }
     if (r) {
         hipLaunchKernelGGL((k_xts_cts<NR, DEC>), dim3(grid_for(nsectors, UAES_WG)), dim3(UAES_WG), lds, st,
