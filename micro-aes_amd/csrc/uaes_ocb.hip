@@ -45,6 +45,8 @@ static inline hipStream_t S(void *s) { return (hipStream_t)s; }
 #define OCB_ROW_OFF0 64u
 #define OCB_ROW_PART 65u
 #define OCB_MAX_WGS  1024u
+#define OCB_ROW_HASH (OCB_ROW_PART + OCB_MAX_WGS)  /* ... and one share of HASH(K, A) per workgroup when the associated data is long */
+#define OCB_HASH_SPREAD 8192u                   /* whole blocks of associated data from which every workgroup hashes a part (below: the finishing workgroup alone) */
 #define OCB_PLAIN_AAD (16u * 1024u)            /* decryption: associated data up to here is hashed through the plain Te0 */
 
 struct B16 {
@@ -199,9 +201,11 @@ __device__ __forceinline__ void ocb_setup_lds(const ENC &enc, uint4 nonce_block,
 /* the block loop                                                              */
 /* ------------------------------------------------------------------------ */
 /* the caller has put the L table and Offset_0 (ocb_setup_lds) and the cipher tables of the direction into LDS */
-template <int NR, bool DEC>
+/* HASH: the same walk over the ASSOCIATED DATA (HASH(K, A), :1749-1754: Sum ^= Enc(A_i ^ Offset_i) with offsets
+ * counted from zero): nothing is written, the sum collects the cipher's outputs.  share = the workgroup's row.    */
+template <int NR, bool DEC, bool HASH = false>
 __device__ __forceinline__ void ocb_main_body(const uaesk_rk &rk, const LaneConst &lc,
-                                              uint4 *__restrict__ scr, u64 nblocks, u32 run,
+                                              uint4 *__restrict__ share, u64 nblocks, u32 run,
                                               const uint4 *in, uint4 *out)
 {
     /* run (a power of two <= OCB_RUN_MAX) = consecutive chunks per wave; short texts use
@@ -216,7 +220,8 @@ __device__ __forceinline__ void ocb_main_body(const uaesk_rk &rk, const LaneCons
      * gray(lane), bit 5 taken as lane bit 5), a part that depends on u only (L_5..L_7) and
      * the chunk part; the last two are wave-uniform and live in scalar registers.        */
     const B16 lm = ocb_gray_sum(lane ^ (lane >> 1), 0);
-    const B16 off0 = uniform(b16(*(const uint4 *)(uaes_lds + OCB_LDS_OFF0)));
+    const B16 zero16 = { { 0, 0, 0, 0 } };
+    const B16 off0 = HASH ? zero16 : uniform(b16(*(const uint4 *)(uaes_lds + OCB_LDS_OFF0)));
     const B16 l5 = uniform(lds_row(2u + 5u)), l6 = uniform(lds_row(2u + 6u)), l7 = uniform(lds_row(2u + 7u));
 
     /* run is a power of two: shifts and masks, not the 64-bit divisions `k / run`, `k % run` compile to */
@@ -278,7 +283,7 @@ __device__ __forceinline__ void ocb_main_body(const uaesk_rk &rk, const LaneCons
         for (int u = 0; u < UAES_U; ++u) {
             s[u][0] = xor3(d[u].x, um[u].w[0], lm.w[0]); s[u][1] = xor3(d[u].y, um[u].w[1], lm.w[1]);
             s[u][2] = xor3(d[u].z, um[u].w[2], lm.w[2]); s[u][3] = xor3(d[u].w, um[u].w[3], lm.w[3]);
-            if (!DEC) {
+            if (!DEC && !HASH) {
                 const u32 lv = live(u);
                 sum[0] ^= d[u].x & lv; sum[1] ^= d[u].y & lv;
                 sum[2] ^= d[u].z & lv; sum[3] ^= d[u].w & lv;
@@ -294,6 +299,11 @@ __device__ __forceinline__ void ocb_main_body(const uaesk_rk &rk, const LaneCons
 #pragma unroll
         for (int u = 0; u < UAES_U; ++u) {
             const u32 lv = live(u);
+            if (HASH) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sum[q] ^= s[u][q] & lv;
+                continue;
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) s[u][q] = xor3(s[u][q], um[u].w[q], lm.w[q]);
             if (DEC) {
@@ -317,13 +327,13 @@ __device__ __forceinline__ void ocb_main_body(const uaesk_rk &rk, const LaneCons
     }
     __syncthreads();
 #ifdef UAES_OCB_SHARE_FENCE
-    if (threadIdx.x == 0) scr[OCB_ROW_PART + blockIdx.x] = *(const uint4 *)(uaes_lds + OCB_LDS_ACC);
+    if (threadIdx.x == 0) *share = *(const uint4 *)(uaes_lds + OCB_LDS_ACC);
 #else
     /* the share goes out as four device-scope atomic exchanges whose results have come back before the workgroup
      * counts itself in (k_ocb): they are performed where every XCD sees them, so the counting needs no release
      * fence -- which on this part writes back the XCD's whole L2, full of ciphertext that nobody is waiting for */
     if (threadIdx.x == 0) {
-        u32 *row = (u32 *)(scr + OCB_ROW_PART + blockIdx.x);
+        u32 *row = (u32 *)share;
         const u32 *acc = (const u32 *)(uaes_lds + OCB_LDS_ACC);
         u32 old = 0;
 #pragma unroll
@@ -362,10 +372,12 @@ __device__ __forceinline__ u32 b16_byte(const B16 &b, u32 pos)
 }
 
 /* the caller has put the L table, Offset_0, CLEARED accumulators (ocb_clear_acc) and what `enc` needs into
- * LDS; parts = the checksum shares of the nparts workgroups of the block loop (any address space) */
+ * LDS; parts = the checksum shares of the nparts workgroups of the block loop (any address space), hparts = their
+ * nhash shares of HASH(K, A) over the first na_done blocks of the associated data (the rest is hashed here) */
 template <typename ENC>
 __device__ __forceinline__ void ocb_final_body(const ENC &enc,
-                                               const uint4 *parts, u32 nparts, int decrypt,
+                                               const uint4 *parts, u32 nparts,
+                                               const uint4 *hparts, u32 nhash, u64 na_done, int decrypt,
                                                const unsigned char *__restrict__ aad, u64 aad_len,
                                                const unsigned char *in, unsigned char *out, u64 len,
                                                int *status, u32 tag_len)
@@ -374,7 +386,11 @@ __device__ __forceinline__ void ocb_final_body(const ENC &enc,
     /* HASH(K, A): Sum ^= Enc(A_i ^ Offset_i), Offset from zero (:1749-1754); all threads */
     u32 h[4] = { 0, 0, 0, 0 };
     const u64 na = aad_len >> 4;
-    for (u64 i = threadIdx.x + 1; i <= na; i += blockDim.x) {
+    for (u32 i = threadIdx.x; i < nhash; i += blockDim.x) {
+        const uint4 v = hparts[i];
+        h[0] ^= v.x; h[1] ^= v.y; h[2] ^= v.z; h[3] ^= v.w;
+    }
+    for (u64 i = na_done + threadIdx.x + 1; i <= na; i += blockDim.x) {
         B16 b = ocb_load_bytes(aad + 16 * (i - 1), 16);
         bx(b, ocb_delta(i));
         enc(b);
@@ -456,10 +472,11 @@ struct OcbArgs {
     uint4 *scr;
     unsigned *done_word;
     u64 nblocks, aad_len, len;
+    u64 hash_blocks;                                  /* whole blocks of associated data hashed by all workgroups (0: by the last one) */
     const unsigned char *aad, *in;
     unsigned char *out;
     int *status;
-    u32 bottom, run, tag_len;
+    u32 bottom, run, run_aad, tag_len;
     uaesk_done done;
 };
 
@@ -486,7 +503,19 @@ __global__ __launch_bounds__(UAES_WG) void k_ocb(OcbArgs)
     const u64 nblocks = a->nblocks;
     if (nblocks) {
         const uaesk_rk rk = DEC ? a->dk : a->ek;
-        ocb_main_body<NR, DEC>(rk, lc, a->scr, nblocks, a->run, (const uint4 *)a->in, (uint4 *)a->out);
+        ocb_main_body<NR, DEC>(rk, lc, a->scr + OCB_ROW_PART + blockIdx.x, nblocks, a->run, (const uint4 *)a->in, (uint4 *)a->out);
+    }
+    /* long associated data: every workgroup hashes its part of it (a decrypting launch swaps the tables first) --
+     * left to the finishing workgroup alone, 32 MiB of it took 7.4 ms */
+    const u64 hash_blocks = a->hash_blocks;
+    const bool enc_tables = !DEC || hash_blocks;      /* the replicated tables of the encryption direction are in LDS */
+    if (hash_blocks) {
+        __syncthreads();
+        ocb_clear_acc();
+        if (DEC) fill_enc_tables(a->tb.te0); else __syncthreads();
+        const uaesk_rk ek = a->ek;
+        ocb_main_body<NR, false, true>(ek, lc, a->scr + OCB_ROW_HASH + blockIdx.x, hash_blocks, a->run_aad,
+                                       (const uint4 *)a->aad, nullptr);
     }
     bool last = true;
     if (gridDim.x > 1) {
@@ -505,23 +534,20 @@ __global__ __launch_bounds__(UAES_WG) void k_ocb(OcbArgs)
     }
     if (last) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __syncthreads();
         ocb_clear_acc();
         const uaesk_rk ek = a->ek;
-        const u32 nparts = nblocks ? gridDim.x : 0u;
+        const u32 nparts = nblocks ? gridDim.x : 0u, nhash = hash_blocks ? gridDim.x : 0u;
         /* decryption: the few encryptions of the tag go through the plain table; associated data beyond a few
          * blocks per thread is worth bringing the replicated encryption tables back for */
-        if (DEC && a->aad_len > OCB_PLAIN_AAD) {
-            fill_enc_tables(a->tb.te0);
-            ocb_final_body(EncRep<NR>{ ek, lc }, a->scr + OCB_ROW_PART, nparts, 1, a->aad, a->aad_len,
-                           a->in, a->out, a->len, a->status, a->tag_len);
+        if (enc_tables || a->aad_len > OCB_PLAIN_AAD) {
+            if (!enc_tables) fill_enc_tables(a->tb.te0); else __syncthreads();
+            ocb_final_body(EncRep<NR>{ ek, lc }, a->scr + OCB_ROW_PART, nparts, a->scr + OCB_ROW_HASH, nhash, hash_blocks,
+                           DEC ? 1 : 0, a->aad, a->aad_len, a->in, a->out, a->len, a->status, a->tag_len);
         } else {
             __syncthreads();
-            if (DEC)
-                ocb_final_body(EncPlain<NR>{ ek }, a->scr + OCB_ROW_PART, nparts, 1, a->aad, a->aad_len,
-                               a->in, a->out, a->len, a->status, a->tag_len);
-            else
-                ocb_final_body(EncRep<NR>{ ek, lc }, a->scr + OCB_ROW_PART, nparts, 0, a->aad, a->aad_len,
-                               a->in, a->out, a->len, a->status, a->tag_len);
+            ocb_final_body(EncPlain<NR>{ ek }, a->scr + OCB_ROW_PART, nparts, a->scr + OCB_ROW_HASH, 0u, 0ull,
+                           1, a->aad, a->aad_len, a->in, a->out, a->len, a->status, a->tag_len);
         }
     }
     ticket_release(a->done);
@@ -608,12 +634,12 @@ __global__ __launch_bounds__(UAES_WG) void k_ocb_small(uaesk_rk ek, uaesk_rk dk,
     if (dec_tables && aad_len > OCB_PLAIN_AAD) {
         fill_enc_tables(tb.te0);
         OT(4);
-        ocb_final_body(EncRep<NR>{ ek, lc }, part, nparts, 1, aad, aad_len, in, out, len, status, tag_len);
+        ocb_final_body(EncRep<NR>{ ek, lc }, part, nparts, part, 0u, 0ull, 1, aad, aad_len, in, out, len, status, tag_len);
     } else {
         __syncthreads();
         OT(4);
-        if (dec_tables) ocb_final_body(EncPlain<NR>{ ek }, part, nparts, 1, aad, aad_len, in, out, len, status, tag_len);
-        else ocb_final_body(EncRep<NR>{ ek, lc }, part, nparts, DEC ? 1 : 0, aad, aad_len, in, out, len, status, tag_len);
+        if (dec_tables) ocb_final_body(EncPlain<NR>{ ek }, part, nparts, part, 0u, 0ull, 1, aad, aad_len, in, out, len, status, tag_len);
+        else ocb_final_body(EncRep<NR>{ ek, lc }, part, nparts, part, 0u, 0ull, DEC ? 1 : 0, aad, aad_len, in, out, len, status, tag_len);
     }
 #ifdef UAES_OCB_TIMING
     OT(5);
@@ -666,20 +692,37 @@ static int launch_ocb(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek
     }
     if ((e = want_lds(decrypt ? (const void *)k_ocb<NR, true> : (const void *)k_ocb<NR, false>)) != hipSuccess) return (int)e;
     const u64 nblocks = len >> 4;
-    const u64 nchunks = (nblocks >> 8) + 1;
-    /* at least 8 runs per wave, so that an uneven split costs at most 1/8 */
-    u32 run = OCB_RUN_MAX;
-    while (run > 1 && nchunks / run < 8ull * cu_count() * (UAES_WG / 64)) run >>= 1;
-    const u64 runs = (nchunks + run - 1) / run;
-    /* short texts: 4-wave workgroups, so that the few chunks spread over more CUs */
-    const unsigned wg = (runs + UAES_WG / 64 - 1) / (UAES_WG / 64) * 2 <= cu_count() ? 256u : UAES_WG;
-    u64 grid = (runs + wg / 64 - 1) / (wg / 64);
+    /* long associated data (whole blocks, 16-byte aligned) is hashed by all workgroups as a second walk */
+    const u64 hblocks = ((u64)(aad_len >> 4) >= OCB_HASH_SPREAD && ((uintptr_t)aad & 15u) == 0) ? (u64)(aad_len >> 4) : 0;
+    unsigned wg = 256u;
+    u64 grid = 1;
+    u32 runs_of[2] = { 1, 1 };
+    const u64 walk[2] = { nblocks, hblocks };
+    for (int w = 0; w < 2; ++w) {
+        if (!walk[w]) continue;
+        const u64 nchunks = (walk[w] >> 8) + 1;
+        /* at least 8 runs per wave, so that an uneven split costs at most 1/8 */
+        u32 run = OCB_RUN_MAX;
+        while (run > 1 && nchunks / run < 8ull * cu_count() * (UAES_WG / 64)) run >>= 1;
+        const u64 runs = (nchunks + run - 1) / run;
+        /* short texts: 4-wave workgroups, so that the few chunks spread over more CUs */
+        const unsigned wgw = (runs + UAES_WG / 64 - 1) / (UAES_WG / 64) * 2 <= cu_count() ? 256u : UAES_WG;
+        runs_of[w] = run;
+        if (wgw > wg) wg = wgw;
+    }
+    for (int w = 0; w < 2; ++w) {
+        if (!walk[w]) continue;
+        const u64 runs = (((walk[w] >> 8) + 1) + runs_of[w] - 1) / runs_of[w];
+        u64 g = (runs + wg / 64 - 1) / (wg / 64);
+        if (g > grid) grid = g;
+    }
     if (grid > cu_count()) grid = cu_count();
     if (grid > OCB_MAX_WGS) grid = OCB_MAX_WGS;
-    if (!nblocks) grid = 1;                                                   /* associated data only */
+    const u32 run = runs_of[0];
     OcbArgs ka;
     ka.ek = *ek; ka.dk = decrypt ? *dk : *ek; ka.tb = *tb; ka.nonce_block = nb; ka.scr = scr; ka.done_word = done_word;
     ka.nblocks = nblocks; ka.aad_len = aad_len; ka.len = len; ka.aad = (const unsigned char *)aad;
+    ka.hash_blocks = hblocks; ka.run_aad = runs_of[1];
     ka.in = (const unsigned char *)in; ka.out = (unsigned char *)out; ka.status = status;
     ka.bottom = bottom; ka.run = run; ka.tag_len = tag_len; ka.done = done;
     if (decrypt) hipLaunchKernelGGL((k_ocb<NR, true>), dim3((unsigned)grid), dim3(wg), OCB_LDS, st, ka);
@@ -687,7 +730,7 @@ static int launch_ocb(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek
     return (int)hipGetLastError();
 }
 
-extern "C" size_t uaesk_ocb_scratch_bytes(void) { return 16u * (OCB_ROW_PART + OCB_MAX_WGS); }
+extern "C" size_t uaesk_ocb_scratch_bytes(void) { return 16u * (OCB_ROW_HASH + OCB_MAX_WGS); }
 
 /* nonce is a host pointer; everything else device memory (in/out 16-byte aligned).  done_word: a device word that
  * is zero between calls and that nothing else writes (the workgroups of a launch count themselves in on it).

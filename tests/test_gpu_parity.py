@@ -398,9 +398,11 @@ def test_ocb_one_launch_paths(orc, bits):
     import torch
     rnd = random.Random(bits + 77)
     st = torch.cuda.current_stream()
+    # (associated data from 8192 whole blocks on is hashed by ALL workgroups as a second walk, the decrypting launch
+    # swapping its tables in between: 131072 bytes and more, with and without a ragged last block, text or none)
     for n in (0, 100, 16 * 1024, 16 * 1025 + 3, (5 << 20) + 1, (40 << 20) + 16):
-        for alen in (0, 15, 16384, 16385, 65536, 65537, 200000):
-            if n > (5 << 20) and alen not in (0, 16385):
+        for alen in (0, 15, 16384, 16385, 65536, 65537, 131071, 131072, 200000, (3 << 20) + 5):
+            if n > (5 << 20) and alen not in (0, 16385, (3 << 20) + 5):
                 continue
             key, nonce = rnd.randbytes(bits // 8), rnd.randbytes(12)
             aad, data = rnd.randbytes(alen), orc.splitmix(n + alen, n)
