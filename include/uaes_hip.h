@@ -260,8 +260,8 @@ int uaes_cfb_decrypt(int keybits, const uint8_t *key, const uint8_t *iVec,
 int uaes_ofb_xcrypt(int keybits, const uint8_t *key, const uint8_t *iVec,
                     const void *in, size_t len, void *out);
 
-/* Batches of INDEPENDENT chains, one GPU lane per message -- where a GPU serves the serial
- * modes well.  nmsg messages of msg_bytes each, stored back to back (message m at
+/* Batches of INDEPENDENT chains, sixteen GPU lanes per message (up to 81 919 messages) or one (above) -- where
+ * a GPU serves the serial modes well.  nmsg messages of msg_bytes each, stored back to back (message m at
  * m * msg_bytes).  uaes_cbc_encrypt_batch: crtxt[m] = AES_CBC_encrypt(key, ivs + 16 m, message
  * m) bit for bit, CS3 swap included; msg_bytes must be a multiple of 16.  uaes_cmac_batch:
  * macs + 16 m = AES_CMAC(key, message m), any msg_bytes.  Data pointers host or device; ivs

@@ -684,6 +684,52 @@ __device__ __forceinline__ RowLane<NR> row_lane()
     return L;
 }
 
+/* The same with the FOUR ROWS OF A WAVE ON FOUR DIFFERENT BLOCKS (batches of independent chains, uaes_chain.hip):
+ * row q of a wave needs banks of its own, so the entry of x (still at x*256) holds (Te0,Te1,Te2,Te3)[x] sixteen
+ * times -- row q reads bytes 64 q .. 64 q + 63, banks 16 q .. 16 q + 15 -- and the last round's
+ * (Te2,Te3,Te0,Te1)[x] sits in a second region 64 KiB up (bit 16 of the address comes from byte 2 of the lane
+ * constant, which the same v_perm selector already copies); the round keys follow at 128 KiB.                 */
+#define UAES_LDS_ROW4  (131072u + 256u)
+
+__device__ __forceinline__ void row4_fill_tables(const u32 *__restrict__ te0, const uaesk_rk &rk)
+{
+    for (u32 j0 = threadIdx.x; j0 < 8192u; j0 += 8u * blockDim.x) {      /* 256 entries x 32 pieces of 16 bytes */
+        u32 t[8];
+#pragma unroll
+        for (u32 k = 0; k < 8; ++k) {
+            const u32 j = j0 + k * blockDim.x;
+            t[k] = te0[(j < 8192u ? j : 0u) >> 5];
+        }
+#pragma unroll
+        for (u32 k = 0; k < 8; ++k) {
+            const u32 j = j0 + k * blockDim.x;
+            if (j < 8192u) {
+                const u32 q = j & 31u, x = j >> 5;
+                const u32 t0 = t[k], t1 = rotl32(t0, 8), t2 = rotl32(t0, 16), t3 = rotl32(t0, 24);
+                *(uint4 *)(uaes_lds + (q >> 4) * 65536u + x * 256u + 16u * (q & 15u)) =
+                    q < 16u ? make_uint4(t0, t1, t2, t3) : make_uint4(t2, t3, t0, t1);
+            }
+        }
+    }
+    for (u32 i = threadIdx.x; i < 60u; i += blockDim.x) ((u32 *)(uaes_lds + 131072u))[i] = rk.w[i];
+    __syncthreads();
+}
+
+template <int NR>
+__device__ __forceinline__ RowLane<NR> row4_lane()
+{
+    RowLane<NR> L;
+    const u32 i = threadIdx.x & 15u, r = i & 3u, q = (threadIdx.x >> 4) & 3u;
+    L.c = i >> 2;
+    L.tmain = 64u * q + 4u * i;
+    L.tlast = 65536u + 64u * q + 4u * i;
+    L.sel = 0x0c020000u | ((4u + r) << 8);
+    L.lsel = (0x0c0c0c0cu & ~(0xffu << (8u * r))) | ((4u + r) << (8u * r));
+#pragma unroll
+    for (int j = 0; j <= NR; ++j) L.kc[j] = lds_word(131072u + 16u * (u32)j + 4u * L.c);
+    return L;
+}
+
 template <int CTRL>
 __device__ __forceinline__ u32 row_dpp(u32 v)
 {

@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include <string.h>
+#include <stdlib.h>
 #include "uaes_aes.hip.h"
 #include "uaes_device.h"
 
@@ -320,7 +321,35 @@ __global__ __launch_bounds__(UAES_WG) void k_chain_batch(uaesk_rk rk, uaesk_tabl
             s[0][0] = iv.x; s[0][1] = iv.y; s[0][2] = iv.z; s[0][3] = iv.w;
             uint4 *dst = (uint4 *)(out + m * msg_bytes);
             uint4 prev = iv;
-            for (u64 i = 0; i < nb; ++i) {
+            /* whole groups of four blocks in front of the last two: the next group's text is requested before this
+             * group's four dependent encryptions start (a lane's loads are 16 bytes from a line of its own: every block
+             * used to wait for memory), and the four results leave together -- 64 contiguous bytes per lane; written
+             * one block per trip, a line was evicted half-written with 2^18 lanes at work (2^18 messages of 1 KiB: 524 ->
+             * 1122 GiB/s) */
+            u64 i0 = 0;
+            if (nb >= 6) {
+                const u64 ngrp = (nb - 2) / 4;
+                uint4 cur[4], nxt[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) cur[j] = ((const uint4 *)src)[j];
+                for (u64 g = 0; g < ngrp; ++g) {
+                    const u64 gn = g + 1 < ngrp ? g + 1 : g;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) nxt[j] = ((const uint4 *)src)[4 * gn + j];
+                    uint4 c[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        s[0][0] ^= cur[j].x; s[0][1] ^= cur[j].y; s[0][2] ^= cur[j].z; s[0][3] ^= cur[j].w;
+                        enc_blocks<NR, 1>(s, rk, lc);
+                        c[j] = make_uint4(s[0][0], s[0][1], s[0][2], s[0][3]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { dst[4 * g + j] = c[j]; cur[j] = nxt[j]; }
+                    prev = c[3];
+                }
+                i0 = 4 * ngrp;
+            }
+            for (u64 i = i0; i < nb; ++i) {
                 const uint4 x = ((const uint4 *)src)[i];
                 s[0][0] ^= x.x; s[0][1] ^= x.y; s[0][2] ^= x.z; s[0][3] ^= x.w;
                 enc_blocks<NR, 1>(s, rk, lc);
@@ -332,7 +361,27 @@ __global__ __launch_bounds__(UAES_WG) void k_chain_batch(uaesk_rk rk, uaesk_tabl
         } else {
             const u32 last = msg_bytes ? (u32)((msg_bytes - 1) % 16) + 1 : 0;     /* size of the last block */
             const u64 full = (msg_bytes - last) / 16;
-            for (u64 i = 0; i < full; ++i) {
+            u64 i0 = 0;
+            if (full >= 4 && (((uintptr_t)src) & 15u) == 0) {          /* groups of four, the next one requested ahead */
+                const u64 ngrp = full / 4;
+                uint4 cur[4], nxt[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) cur[j] = ((const uint4 *)src)[j];
+                for (u64 g = 0; g < ngrp; ++g) {
+                    const u64 gn = g + 1 < ngrp ? g + 1 : g;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) nxt[j] = ((const uint4 *)src)[4 * gn + j];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        s[0][0] ^= cur[j].x; s[0][1] ^= cur[j].y; s[0][2] ^= cur[j].z; s[0][3] ^= cur[j].w;
+                        enc_blocks<NR, 1>(s, rk, lc);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) cur[j] = nxt[j];
+                }
+                i0 = 4 * ngrp;
+            }
+            for (u64 i = i0; i < full; ++i) {
                 const Blk x = ldb(src + 16 * i, 16);
                 s[0][0] ^= x.w[0]; s[0][1] ^= x.w[1]; s[0][2] ^= x.w[2]; s[0][3] ^= x.w[3];
                 enc_blocks<NR, 1>(s, rk, lc);
@@ -342,6 +391,71 @@ __global__ __launch_bounds__(UAES_WG) void k_chain_batch(uaesk_rk rk, uaesk_tabl
             s[0][0] ^= l.w[0]; s[0][1] ^= l.w[1]; s[0][2] ^= l.w[2]; s[0][3] ^= l.w[3];
             enc_blocks<NR, 1>(s, rk, lc);
             ((uint4 *)out)[m] = make_uint4(s[0][0], s[0][1], s[0][2], s[0][3]);
+        }
+    }
+}
+
+/* The same batch with SIXTEEN LANES PER MESSAGE (round 5): a lane per message fills the GPU only from 2^18 messages
+ * on -- 4096 messages of 64 KiB ran on 64 waves, 23 GiB/s, every chain at the 5.8 MiB/s a lane makes of it.  Here
+ * the four DPP rows of a wave walk four messages (row_encrypt: one state byte and one lookup per lane and round;
+ * row4_fill_tables gives every row banks of its own), a chain runs at the pace of the serial-chain kernel and
+ * 16384 messages already occupy every SIMD four waves deep.  Same results byte for byte; launch_batch picks the
+ * arrangement by the number of messages.  Messages and IVs as k_chain_batch; A4: every message 4-byte aligned.  */
+template <int NR, bool MAC, bool A4>
+__global__ __launch_bounds__(UAES_WG) void k_chain_batch_row(uaesk_rk rk, uaesk_tables tb, const uint4 *__restrict__ ivs,
+                                                             u64 nmsg, u64 msg_bytes,
+                                                             const unsigned char *in, unsigned char *out)
+{
+    row4_fill_tables(tb.te0, rk);
+    const RowLane<NR> L = row4_lane<NR>();
+    u32 k1c = 0, k2c = 0;                                     /* this lane's column of the subkeys */
+    if (MAC) {                                                /* K1 = 2L, K2 = 4L, L = Enc(0) (getSubkeys :593-605) */
+        u32 b[4];
+        row_spread(row_encrypt<NR>(0u, L), b);                /* (row 0's copy: all rows hold the same) */
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            u64 hi = ((u64)bswap32(b[0]) << 32) | bswap32(b[1]), lo = ((u64)bswap32(b[2]) << 32) | bswap32(b[3]);
+            const u64 carry = hi >> 63;
+            hi = (hi << 1) | (lo >> 63);
+            lo = (lo << 1) ^ (carry ? 0x87ull : 0ull);
+            b[0] = bswap32((u32)(hi >> 32)); b[1] = bswap32((u32)hi);
+            b[2] = bswap32((u32)(lo >> 32)); b[3] = bswap32((u32)lo);
+            if (q) k2c = row_pick(b, L.c); else k1c = row_pick(b, L.c);
+        }
+    }
+    const u64 rows = blockDim.x >> 4;
+    for (u64 m = (u64)blockIdx.x * rows + (threadIdx.x >> 4); m < nmsg; m += (u64)gridDim.x * rows) {
+        const unsigned char *src = in + m * msg_bytes;
+        if (!MAC) {
+            unsigned char *dst = out + m * msg_bytes;
+            u32 v = ((const u32 *)(ivs + m))[L.c];            /* the chain value: this lane's column */
+            u64 n = msg_bytes / 16;
+            const bool swap = n > 1;                          /* CS3: the last two blocks swap (:706, :738-742) */
+            if (swap) --n;
+            const u32 l0 = swap ? row_load_full<A4>(src + 16 * n, L.c) : 0u;   /* read before anything is written */
+            row_walk<A4>(src, n, L.c, [&](u64 i, u32 x) {
+                v = row_encrypt<NR>(v ^ x, L);
+                row_store_full<A4>(dst + 16 * i, v, L.c);
+            });
+            if (swap) {                                       /* v == C_{n-1} here */
+                row_store_full<A4>(dst + 16 * n, v, L.c);
+                v = row_encrypt<NR>(v ^ l0, L);
+                row_store_full<A4>(dst + 16 * (n - 1), v, L.c);
+            }
+        } else {
+            const u32 last = msg_bytes ? (u32)((msg_bytes - 1) % 16) + 1 : 0;     /* size of the last block */
+            const u64 full = (msg_bytes - last) / 16;
+            u32 v = 0;
+            row_walk<A4>(src, full, L.c, [&](u64, u32 x) { v = row_encrypt<NR>(v ^ x, L); });
+            u32 l = last ? row_load(src + 16 * full, last, L.c) : 0u;
+            if (last < 16) {                                  /* 10* padding, then K2 */
+                if ((last >> 2) == L.c) l |= 0x80u << (8u * (last & 3u));
+                l ^= k2c;
+            } else {
+                l ^= k1c;
+            }
+            v = row_encrypt<NR>(v ^ l, L);
+            ((u32 *)out)[4 * m + L.c] = v;
         }
     }
 }
@@ -362,6 +476,14 @@ static unsigned cu_count()
     static int cus = 0;
     if (!cus) uaesk_device_info(&cus, nullptr);
     return cus > 0 ? (unsigned)cus : 256u;
+}
+
+/* an integer from the environment, clamped; callers keep it in a function-local `static const` */
+static int env_int_clamped(const char *name, int dflt, int lo, int hi)
+{
+    const char *e = getenv(name);
+    int v = (e && *e) ? atoi(e) : dflt;
+    return v < lo ? lo : v > hi ? hi : v;
 }
 
 template <int NR, bool CFB, int U>
@@ -402,10 +524,31 @@ static int launch_serial(hipStream_t st, const uaesk_tables *tb, const uaesk_rk 
     return (int)hipGetLastError();
 }
 
+/* a lane per message from 81 920 messages on (where the two arrangements cross), sixteen lanes below:
+ * tools/batch_rate.py, profiles/r05_batch_rate.log; UAES_BATCH_ROW_MAX moves the switch */
 template <int NR, bool MAC>
 static int launch_batch(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *k, const void *ivs,
                         u64 nmsg, u64 msg_bytes, const void *in, void *out)
 {
+    static const int row_max = env_int_clamped("UAES_BATCH_ROW_MAX", 81919, 0, 1 << 30);
+    if (nmsg <= (u64)row_max) {
+        const bool a4 = ((((uintptr_t)in) | ((uintptr_t)out)) & 3u) == 0 && msg_bytes % 4 == 0;
+        /* 64 messages per 16-wave workgroup; few messages: 4-wave workgroups, so that they spread over the CUs */
+        const unsigned wg = (nmsg + 63) / 64 * 2 <= cu_count() ? 256u : UAES_WG;
+        const u64 want = (nmsg + wg / 16 - 1) / (wg / 16);
+        const unsigned grid = (unsigned)(want < cu_count() ? want : cu_count());
+        hipError_t e;
+        if (a4) {
+            if ((e = uaesk_want_lds((const void *)k_chain_batch_row<NR, MAC, true>, (unsigned)(UAES_LDS_ROW4))) != hipSuccess) return (int)e;
+            hipLaunchKernelGGL((k_chain_batch_row<NR, MAC, true>), dim3(grid), dim3(wg), UAES_LDS_ROW4, st, *k, *tb,
+                               (const uint4 *)ivs, nmsg, msg_bytes, (const unsigned char *)in, (unsigned char *)out);
+        } else {
+            if ((e = uaesk_want_lds((const void *)k_chain_batch_row<NR, MAC, false>, (unsigned)(UAES_LDS_ROW4))) != hipSuccess) return (int)e;
+            hipLaunchKernelGGL((k_chain_batch_row<NR, MAC, false>), dim3(grid), dim3(wg), UAES_LDS_ROW4, st, *k, *tb,
+                               (const uint4 *)ivs, nmsg, msg_bytes, (const unsigned char *)in, (unsigned char *)out);
+        }
+        return (int)hipGetLastError();
+    }
     hipError_t e = uaesk_want_lds((const void *)k_chain_batch<NR, MAC>, (unsigned)(UAES_LDS_ENC));
     if (e != hipSuccess) return (int)e;
     u64 want = (nmsg + UAES_WG - 1) / UAES_WG;

@@ -781,7 +781,7 @@ def test_build_variant_vectors_cbc_without_cts_and_other_ctr_constants(orc, gold
 
 @pytest.mark.parametrize("bits", [128, 192, 256])
 def test_batched_chains_equal_the_single_calls(orc, bits):
-    """uaes_cbc_encrypt_batch / uaes_cmac_batch: N independent messages, one GPU lane each, must give
+    """uaes_cbc_encrypt_batch / uaes_cmac_batch: N independent messages, a DPP row of sixteen lanes or one lane each, must give
     exactly what N single calls give (AES_CBC_encrypt with its CS3 swap, AES_CMAC) -- checked against
     the oracle, for one block, two blocks, many blocks, and more messages than one workgroup holds"""
     rnd = random.Random(61 + bits)
@@ -799,6 +799,24 @@ def test_batched_chains_equal_the_single_calls(orc, bits):
         got = uaes.cmac_batch(key, msgs)
         for i in list(range(min(nmsg, 6))) + [nmsg - 1, nmsg // 2]:
             assert got[i] == orc.cmac(key, msgs[i]), (nmsg, size, i)
+    # up to 81919 messages sixteen lanes walk a message (k_chain_batch_row), from 81920 on one lane does
+    # (k_chain_batch): the same messages through both, every one of them compared, and spot checks against the oracle
+    # (the one-lane arrangement takes whole groups of four blocks in front of the last two: 208 = 13 blocks)
+    for size in (48, 208):
+        nmsg = 90000
+        blob = orc.splitmix(size + bits, nmsg * size)
+        msgs = [blob[i * size:(i + 1) * size] for i in range(nmsg)]
+        ivs = [blob[(i * 7) % (len(blob) - 16):][:16] for i in range(nmsg)]
+        lane, row = uaes.cbc_encrypt_batch(key, ivs, msgs), uaes.cbc_encrypt_batch(key, ivs[:60000], msgs[:60000])
+        assert lane[:60000] == row
+        for i in (0, 1, 59999, 60000, nmsg - 1):
+            assert lane[i] == orc.cbc(key, ivs[i], msgs[i], True)[1]
+        for cut in (3, 0):
+            mm = [m[:size - cut] for m in msgs]
+            lane, row = uaes.cmac_batch(key, mm), uaes.cmac_batch(key, mm[:60000])
+            assert lane[:60000] == row
+            for i in (0, 59999, nmsg - 1):
+                assert lane[i] == orc.cmac(key, mm[i])
     L = uaes.engine()
     assert L.uaes_cbc_encrypt_batch(bits, key, bytes(16), 1, 24, bytes(24), (C.c_uint8 * 24)()) == -2
 
