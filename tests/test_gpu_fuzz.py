@@ -142,6 +142,9 @@ def test_fuzz_xts(orc):
         # batched data units of a random size (ciphertext stealing when ragged)
         sb = rnd.choice([16, 17, 31, 512, 520, 4096, 4099, 65536 + 7])
         ns = rnd.randrange(1, 40 if sb < 5000 else 4)
+        if rnd.random() < 0.2:                       # units shorter than a chunk, beyond the one-launch limit: packed chunks
+            sb = rnd.choice([64, 128, 192, 512, 1024, 1984, 2048, 4032])
+            ns = rnd.randrange(4097, 4600) if sb >= 1024 else rnd.randrange(4097, 12000)
         first = rnd.choice([0, 1, (1 << 32) - 1, rnd.getrandbits(60)])
         data = orc.splitmix(2500 + i, sb * ns)
         b = Buffers(rnd, data, sb * ns)
@@ -166,7 +169,7 @@ def test_fuzz_aead(orc):
         enc, dec, ref, cap = modes[name]
         bits = rnd.choice([128, 192, 256])
         key, nonce = rnd.randbytes(bits // 8), rnd.randbytes(12)
-        aad = rnd.randbytes(rnd.choice([0, 0, 1, 15, 16, 17, 100, 4096, 5000]))
+        aad = rnd.randbytes(rnd.choice([0, 0, 1, 15, 16, 17, 100, 4096, 5000, 16385, 131072 + 5, 262144]))
         n = pick_size(rnd, cap)
         data = orc.splitmix(3000 + i, n)
         want = ref(key, nonce, aad, data)
