@@ -58,6 +58,7 @@ __device__ __forceinline__ u32 lds_word(u32 byte_addr)
  * number to the pinned host word (the classic last-block pattern; one workgroup: no counting).               */
 uaesk_done uaesk_ticket_take();                     /* the calling host thread's armed ticket (cleared), uaes_kernels.hip */
 void uaesk_ticket_unused();
+unsigned *uaesk_done_word_take();                    /* the armed zero-between-calls word (cleared), uaes_kernels.hip */
 hipError_t uaesk_want_lds(const void *kern, unsigned bytes);   /* dynamic-LDS attribute, set once per (kernel, device) */
 
 /* a multi-launch routine takes the ticket at its entry, so that the single-launch building blocks it calls do not

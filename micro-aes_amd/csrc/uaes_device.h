@@ -209,6 +209,9 @@ typedef struct {
     unsigned  seq;
 } uaesk_done;
 void uaesk_ticket_arm(void *pinned_flag, void *d_count, unsigned seq);
+/* a device word that is zero between calls and that nothing else writes, for the calling thread's NEXT kernel-level
+ * call (uaesk_gcm / uaesk_gcm_keyed take it: with it a medium-sized text is one launch); NULL disarms */
+void uaesk_done_word_arm(unsigned *w);
 int  uaesk_ticket_disarm(void);
 
 /* Completion ticket of a synchronous call: a one-wave kernel behind the call's kernels copies nbytes (a multiple

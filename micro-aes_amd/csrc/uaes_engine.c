@@ -1781,8 +1781,10 @@ int uaes_gcm_encrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, s
             io.copy_back = 1;
         }
         ticket_arm(L);
+        uaesk_done_word_arm(scratch_done_word(L->scratch, L->scratch_cap));
         int k = uaesk_gcm(L->stream, &c->tb, ks.nr, &ks.ek, 0, j0, d_aad, aDataLen,
                           io.din, ptextLen, io.dout, L->scratch, NULL);
+        uaesk_done_word_arm(NULL);
         ticket_armed_launch_done(L);
         if (k) { rc = fail(UAES_E_HIP, "gcm launch: %s", hipGetErrorString((hipError_t)k)); break; }
         rc = finish_io(&io, ptextLen + tagLen);
@@ -1869,8 +1871,10 @@ int uaes_gcm_decrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, s
         int *st_where = lane_status(L);
         if (st_where != L->d_status) { *(volatile int *)st_where = -1; ticket_arm(L); }   /* host-visible status: a
                                                      * one-launch decryption may carry the completion ticket itself */
+        uaesk_done_word_arm(scratch_done_word(L->scratch, L->scratch_cap));
         int k = uaesk_gcm(L->stream, &c->tb, ks.nr, &ks.ek, io.copy_back || io.dout == L->pin[1] ? 2 : gcm_decrypt_mode(),
                           j0, d_aad, aDataLen, io.din, crtxtLen, io.dout, L->scratch, st_where);
+        uaesk_done_word_arm(NULL);
         ticket_armed_launch_done(L);
         if (k) { rc = fail(UAES_E_HIP, "gcm launch: %s", hipGetErrorString((hipError_t)k)); break; }
         if ((rc = lane_read_status(L, st_where, &status)) != 0) break;
@@ -1910,8 +1914,10 @@ int uaes_gcm_encrypt_dev(int keybits, const uint8_t *key, const uint8_t *nonce,
     if ((rc = get_context(&c)) != 0) return rc;
     if ((rc = gcm_scratch_locked(c, stream, &scr, &slot)) != 0) return rc;
     j0_of_nonce12(nonce, j0);
-    KCHK_PINNED(c, slot, uaesk_gcm(stream, &c->tb, ks.nr, &ks.ek, 0, j0, d_aad, aad_len, d_in, len, d_out,
-                                   scr, NULL));
+    uaesk_done_word_arm(scratch_done_word(scr, c->slot[slot].cap));
+    rc = uaesk_gcm(stream, &c->tb, ks.nr, &ks.ek, 0, j0, d_aad, aad_len, d_in, len, d_out, scr, NULL);
+    uaesk_done_word_arm(NULL);
+    KCHK_PINNED(c, slot, rc);
     return 0;
 }
 
@@ -1932,8 +1938,10 @@ int uaes_gcm_decrypt_dev(int keybits, const uint8_t *key, const uint8_t *nonce,
     if ((rc = get_context(&c)) != 0) return rc;
     if ((rc = gcm_scratch_locked(c, stream, &scr, &slot)) != 0) return rc;
     j0_of_nonce12(nonce, j0);
-    KCHK_PINNED(c, slot, uaesk_gcm(stream, &c->tb, ks.nr, &ks.ek, gcm_decrypt_mode(), j0, d_aad, aad_len, d_in, len, d_out,
-                                   scr, d_status));
+    uaesk_done_word_arm(scratch_done_word(scr, c->slot[slot].cap));
+    rc = uaesk_gcm(stream, &c->tb, ks.nr, &ks.ek, gcm_decrypt_mode(), j0, d_aad, aad_len, d_in, len, d_out, scr, d_status);
+    uaesk_done_word_arm(NULL);
+    KCHK_PINNED(c, slot, rc);
     return 0;
 }
 
@@ -1943,8 +1951,10 @@ int uaes_gcm_decrypt_dev(int keybits, const uint8_t *key, const uint8_t *nonce,
 struct uaes_gcm_key {
     keysched ks;
     int      device;
-    void    *scratch;               /* uaesk_gcm_scratch_bytes(): the key's tables + per-message state */
+    void    *scratch;               /* uaesk_gcm_scratch_bytes(): the key's tables + per-message state, then SCRATCH_TAIL bytes
+                                     * of zero-between-calls words like the lanes' scratch buffers have */
 };
+#define KEY_DONE_WORD(k) ((unsigned *)((char *)(k)->scratch + uaesk_gcm_scratch_bytes()))
 
 int uaes_gcm_key_new(uaes_gcm_key **out, int keybits, const uint8_t *key)
 {
@@ -1962,10 +1972,12 @@ int uaes_gcm_key_new(uaes_gcm_key **out, int keybits, const uint8_t *key)
         return rc;
     }
     if (hipGetDevice(&k->device) != hipSuccess) rc = fail(UAES_E_HIP, "hipGetDevice failed");
-    else if (hipMalloc(&k->scratch, uaesk_gcm_scratch_bytes()) != hipSuccess) {
+    else if (hipMalloc(&k->scratch, uaesk_gcm_scratch_bytes() + SCRATCH_TAIL) != hipSuccess) {
         k->scratch = NULL;
         rc = fail(UAES_E_HIP, "key context allocation failed (%zu bytes of device memory)", uaesk_gcm_scratch_bytes());
     }
+    if (rc == 0 && hipMemsetAsync(KEY_DONE_WORD(k), 0, SCRATCH_TAIL, (hipStream_t)L->stream) != hipSuccess)
+        rc = fail(UAES_E_HIP, "key context: hipMemsetAsync failed");
     if (rc == 0) {
         int kk = uaesk_gcm_key_tables(L->stream, &c->tb, k->ks.nr, &k->ks.ek, k->scratch);
         if (kk) rc = fail(UAES_E_HIP, "key table launch: %s", hipGetErrorString((hipError_t)kk));
@@ -2019,8 +2031,10 @@ int uaes_gcm_key_encrypt(uaes_gcm_key *k, const uint8_t *nonce, const void *aDat
         if ((rc = stage_aad(L, aData, aDataLen, &d_aad)) != 0) break;
         if ((rc = plan_io(L, pntxt, ptextLen, crtxt, ptextLen + 16, &io)) != 0) break;
         ticket_arm(L);
+        uaesk_done_word_arm(KEY_DONE_WORD(k));
         int kk = uaesk_gcm_keyed(L->stream, &c->tb, k->ks.nr, &k->ks.ek, 0, j0, d_aad, aDataLen,
                                  io.din, ptextLen, io.dout, k->scratch, NULL);
+        uaesk_done_word_arm(NULL);
         ticket_armed_launch_done(L);
         if (kk) { rc = fail(UAES_E_HIP, "gcm launch: %s", hipGetErrorString((hipError_t)kk)); break; }
         rc = finish_io(&io, ptextLen + 16);
@@ -2050,9 +2064,11 @@ int uaes_gcm_key_decrypt(uaes_gcm_key *k, const uint8_t *nonce, const void *aDat
         }
         int *st_where = lane_status(L);
         if (st_where != L->d_status) { *(volatile int *)st_where = -1; ticket_arm(L); }
+        uaesk_done_word_arm(KEY_DONE_WORD(k));
         int kk = uaesk_gcm_keyed(L->stream, &c->tb, k->ks.nr, &k->ks.ek,
                                  io.copy_back || io.dout == L->pin[1] ? 2 : gcm_decrypt_mode(), j0, d_aad, aDataLen,
                                  io.din, crtxtLen, io.dout, k->scratch, st_where);
+        uaesk_done_word_arm(NULL);
         ticket_armed_launch_done(L);
         if (kk) { rc = fail(UAES_E_HIP, "gcm launch: %s", hipGetErrorString((hipError_t)kk)); break; }
         if ((rc = lane_read_status(L, st_where, &status)) != 0) break;
@@ -2074,7 +2090,10 @@ int uaes_gcm_key_encrypt_dev(uaes_gcm_key *k, const uint8_t *nonce, const void *
     if ((rc = dev_ptrs_ok(d_in, d_out, len)) != 0) return rc;
     if ((rc = get_context(&c)) != 0) return rc;
     j0_of_nonce12(nonce, j0);
-    KCHK(uaesk_gcm_keyed(stream, &c->tb, k->ks.nr, &k->ks.ek, 0, j0, d_aad, aad_len, d_in, len, d_out, k->scratch, NULL));
+    uaesk_done_word_arm(KEY_DONE_WORD(k));
+    rc = uaesk_gcm_keyed(stream, &c->tb, k->ks.nr, &k->ks.ek, 0, j0, d_aad, aad_len, d_in, len, d_out, k->scratch, NULL);
+    uaesk_done_word_arm(NULL);
+    KCHK(rc);
     return 0;
 }
 
@@ -2089,7 +2108,10 @@ int uaes_gcm_key_decrypt_dev(uaes_gcm_key *k, const uint8_t *nonce, const void *
     if ((rc = dev_ptrs_ok(d_in, d_out, len)) != 0) return rc;
     if ((rc = get_context(&c)) != 0) return rc;
     j0_of_nonce12(nonce, j0);
-    KCHK(uaesk_gcm_keyed(stream, &c->tb, k->ks.nr, &k->ks.ek, gcm_decrypt_mode(), j0, d_aad, aad_len, d_in, len, d_out, k->scratch, d_status));
+    uaesk_done_word_arm(KEY_DONE_WORD(k));
+    rc = uaesk_gcm_keyed(stream, &c->tb, k->ks.nr, &k->ks.ek, gcm_decrypt_mode(), j0, d_aad, aad_len, d_in, len, d_out, k->scratch, d_status);
+    uaesk_done_word_arm(NULL);
+    KCHK(rc);
     return 0;
 }
 

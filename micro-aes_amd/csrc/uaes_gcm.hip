@@ -1497,12 +1497,42 @@ extern "C" int uaesk_gcm_records(void *stream, const uaesk_tables *tb, int nr, c
  * MODE 0: encrypt; 1: hash the ciphertext only (decrypt, tag first: N7); 2: decrypt while hashing (one pass).  */
 #define GMC_MAXW 1024u          /* the combine kernel folds up to 1024 partial hashes: 32 MiB */
 
-template <int NR, int MODE>
+/* FOLD (round 5): ONE launch -- workgroup 0 is the FINISHER (gcm_combine_body: Enc(J0), the tables of Y, then it waits
+ * for the others on *done_word, folds their hashes and makes the tag), workgroups 1..W hash the chunks.  The finisher's
+ * preparations (6-7 us of a one-shot call) run beside the chunk work instead of behind it, and the launch of a second
+ * kernel goes: 64 KiB 21.8 -> 18.9 us per call, 1 MiB 23.5 -> 21.1, with a key context 17.0 -> 15.3.  Nobody waits for the finisher, so it cannot block progress; it is
+ * dispatched first and sleeps between looks at the counter.  A chunk's hash goes out as four device-scope atomic
+ * exchanges whose results are back before the workgroup counts itself in (uaes_ocb.hip explains why not a release
+ * fence); the last look resets the counter for the next call (a word that is zero between calls, uaes_device.h).   */
+struct GmcFin {
+    uint4 j0;
+    unsigned *done_word;
+    unsigned char *tag_io;
+    int *status;
+    int mode;                                                 /* 0: write the tag, 1: compare it */
+    u32 ylog;
+    uaesk_done done;
+};
+
+template <int NR, bool WAIT>
+__device__ __forceinline__ void gcm_combine_body(const uaesk_rk &ek, const uaesk_tables &tb, uint4 j0, const uint4 *partial, u32 W,
+                                                 const unsigned char *__restrict__ scratch, u32 build,
+                                                 int mode, unsigned char *tag_io, int *status, u32 ylog,
+                                                 unsigned char *wipe_out, u64 wipe_len, unsigned *done_word);
+
+template <int NR, int MODE, bool FOLD = false>
 __global__ __launch_bounds__(GH_T) void k_gcm_chunks(uaesk_rk rk, uaesk_tables tb, uaesk_ctr ctr,
                                                      GSrc src, const uint4 *in, uint4 *out,
                                                      const unsigned char *__restrict__ scratch, uint4 *partial, u32 build,
-                                                     u32 steps)
+                                                     u32 steps, GmcFin fin)
 {
+    if (FOLD && blockIdx.x == 0) {
+        gcm_combine_body<NR, true>(rk, tb, fin.j0, partial, gridDim.x - 1u, scratch, build, fin.mode, fin.tag_io, fin.status,
+                                   fin.ylog, nullptr, 0, fin.done_word);
+        ticket_release(fin.done);
+        return;
+    }
+    const u32 wg = FOLD ? blockIdx.x - 1u : blockIdx.x, nwg = FOLD ? gridDim.x - 1u : gridDim.x;
     uint4 *TC = (uint4 *)(uaes_lds + GSM_LDS_TAB);
     uint4 *buf = TC + GT_NTAB * 512u;
     if (!build) {
@@ -1521,14 +1551,14 @@ __global__ __launch_bounds__(GH_T) void k_gcm_chunks(uaesk_rk rk, uaesk_tables t
     const u64 len = src.ct_len;
     const u64 ablk = (src.aad_len + 15) >> 4, cblk = (len + 15) >> 4, nv = ablk + cblk + 1;
     const u64 chunk = (u64)steps * GH_T;                      /* positions per workgroup: one or two per thread */
-    const u64 pad = chunk * gridDim.x - nv;                   /* zero positions in front of the sequence */
+    const u64 pad = chunk * nwg - nv;                   /* zero positions in front of the sequence */
     GSrc rest = src;                                          /* AAD blocks and the length block */
     rest.ct_len = 0;
     uint4 xk[2] = { make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0) };
 #pragma unroll
     for (u32 k = 0; k < 2; ++k) {
         if (k >= steps) break;
-        const u64 P = chunk * blockIdx.x + (u64)k * GH_T + threadIdx.x;
+        const u64 P = chunk * wg + (u64)k * GH_T + threadIdx.x;
         const bool live = P >= pad;
         const u64 v = live ? P - pad : 0;
         const bool is_text = live && v >= ablk && v < ablk + cblk;
@@ -1567,23 +1597,36 @@ __global__ __launch_bounds__(GH_T) void k_gcm_chunks(uaesk_rk rk, uaesk_tables t
     uint4 acc = xk[0];
     if (steps == 2) acc = x4(tabmul4(TC, acc), xk[1]);
     acc = gh_tree<true>(buf, TC, acc, GH_T);
-    if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+    if (!FOLD) {
+        if (threadIdx.x == 0) partial[wg] = acc;
+        return;
+    }
+    if (threadIdx.x == 0) {
+        u32 *row = (u32 *)(partial + wg);
+        const u32 v[4] = { acc.x, acc.y, acc.z, acc.w };
+        u32 old = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) old |= __hip_atomic_exchange(row + q, v[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" :: "v"(old) : "memory");
+        (void)__hip_atomic_fetch_add(fin.done_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    ticket_release(fin.done);
 }
 
 /* mode 0: tag = sum_w G_w Y^(W-1-w) ^ Enc(J0) written to tag_io; mode 1: compared with the 16 bytes there */
-template <int NR>
-__global__ __launch_bounds__(GH_T) void k_gcm_combine(uaesk_rk ek, uaesk_tables tb, uint4 j0, const uint4 *partial, u32 W,
-                                                      const unsigned char *__restrict__ scratch, u32 build,
-                                                      int mode, unsigned char *tag_io, int *status, u32 ylog,
-                                                      unsigned char *wipe_out, u64 wipe_len)
+template <int NR, bool WAIT>
+__device__ __forceinline__ void gcm_combine_body(const uaesk_rk &ek, const uaesk_tables &tb, uint4 j0, const uint4 *partial, u32 W,
+                                                 const unsigned char *__restrict__ scratch, u32 build,
+                                                 int mode, unsigned char *tag_io, int *status, u32 ylog,
+                                                 unsigned char *wipe_out, u64 wipe_len, unsigned *done_word)
 {
     uint4 *TC = (uint4 *)uaes_lds;
     uint4 *buf = TC + GT_NTAB * 512u;
     u32 *te_plain = (u32 *)(uaes_lds + GHF_LDS);
     /* the W partial hashes are the LAST W of 1024 entries (up to 256 of them the 1024 -> 256 level only copies);
-     * requested first: they travel while the tables are made */
+     * requested first: they travel while the tables are made (WAIT: they do not exist yet) */
     uint4 acc = make_uint4(0, 0, 0, 0);
-    if (threadIdx.x >= GH_T - W) acc = partial[threadIdx.x - (GH_T - W)];
+    if (!WAIT && threadIdx.x >= GH_T - W) acc = partial[threadIdx.x - (GH_T - W)];
     if (threadIdx.x < 256) te_plain[threadIdx.x] = tb.te0[threadIdx.x];
     __syncthreads();
     const u32 wave = threadIdx.x >> 6;
@@ -1602,6 +1645,21 @@ __global__ __launch_bounds__(GH_T) void k_gcm_combine(uaesk_rk ek, uaesk_tables 
     __syncthreads();
     const uint4 ej0 = buf[GT_BUF - 2];
     if (build) gcm_build_nibble_tables<true>(TC, buf, tb.frob, ylog);    /* Y^256, Y^64, Y^16, Y^4, Y in tables 1..5 */
+    if (WAIT) {
+        /* the chunk workgroups count themselves in behind their hashes; a look every few hundred cycles; five seconds
+         * without the last one means a workgroup of this launch never ran: give the error to the runtime, not a hang */
+        if (threadIdx.x == 0) {
+            const u64 t0 = wall_clock64();
+            while (__hip_atomic_load(done_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != W) {
+                __builtin_amdgcn_s_sleep(8);
+                if (wall_clock64() - t0 > 500000000ull) __builtin_trap();
+            }
+            __hip_atomic_store(done_word, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     /* for the next call */
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (threadIdx.x >= GH_T - W) acc = partial[threadIdx.x - (GH_T - W)];
+    }
     acc = gh_tree<false>(buf, TC, acc, W);
     if (threadIdx.x == 0) {
         acc = x4(acc, ej0);
@@ -1631,6 +1689,15 @@ __global__ __launch_bounds__(GH_T) void k_gcm_combine(uaesk_rk ek, uaesk_tables 
     }
 }
 
+template <int NR>
+__global__ __launch_bounds__(GH_T) void k_gcm_combine(uaesk_rk ek, uaesk_tables tb, uint4 j0, const uint4 *partial, u32 W,
+                                                      const unsigned char *__restrict__ scratch, u32 build,
+                                                      int mode, unsigned char *tag_io, int *status, u32 ylog,
+                                                      unsigned char *wipe_out, u64 wipe_len)
+{
+    gcm_combine_body<NR, false>(ek, tb, j0, partial, W, scratch, build, mode, tag_io, status, ylog, wipe_out, wipe_len, nullptr);
+}
+
 /* key context: the two table sets k_gcm_combine would otherwise make in every call (workgroup 0: Y = H^1024, 1: H^2048) */
 __global__ __launch_bounds__(GH_T) void k_gcm_ytables(uaesk_tables tb, unsigned char *__restrict__ scratch)
 {
@@ -1646,18 +1713,34 @@ __global__ __launch_bounds__(GH_T) void k_gcm_ytables(uaesk_tables tb, unsigned 
 template <int NR>
 static int launch_medium(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek, const uaesk_ctr *c, uint4 j0,
                          const GSrc &src, const void *in, void *out, unsigned char *sc, u32 W, u32 steps, u32 build, int decrypt,
-                         unsigned char *tag_io, int *status)
+                         unsigned char *tag_io, int *status, unsigned *done_word, TicketScope &ticket)
 {
     uint4 *partial = (uint4 *)(sc + GS_ACC1);
     hipError_t e;
-#define GMC_LAUNCH(M)                                                                                               \
+    GmcFin fin;
+    memset(&fin, 0, sizeof fin);
+    /* with a counter word from the host layer, encryption and the hash-only pass of a decryption are ONE launch */
+    /* (as long as the finisher's workgroup still finds a CU of its own beside the chunk workgroups' first round) */
+    int cus_f = 0;
+    if (uaesk_device_info(&cus_f, nullptr) != 0) cus_f = 0;
+    const bool fold = done_word != nullptr && decrypt != 2 && (int)W + 1 <= cus_f;
+    if (fold) {
+        fin.j0 = j0; fin.done_word = done_word; fin.tag_io = tag_io; fin.status = status; fin.mode = decrypt ? 1 : 0;
+        fin.ylog = steps == 2 ? 11u : 10u;
+        if (!decrypt) fin.done = ticket.use();
+    }
+#define GMC_LAUNCH(M, F)                                                                                            \
     do {                                                                                                            \
-        e = uaesk_want_lds((const void *)k_gcm_chunks<NR, M>, (unsigned)(GSM_LDS_TOTAL)); \
+        e = uaesk_want_lds((const void *)k_gcm_chunks<NR, M, F>, (unsigned)(GSM_LDS_TOTAL)); \
         if (e != hipSuccess) return (int)e;                                                                         \
-        hipLaunchKernelGGL((k_gcm_chunks<NR, M>), dim3(W), dim3(GH_T), GSM_LDS_TOTAL, st, *ek, *tb, *c, src,          \
-                           (const uint4 *)in, (uint4 *)out, (const unsigned char *)sc, partial, build, steps);     \
+        hipLaunchKernelGGL((k_gcm_chunks<NR, M, F>), dim3(W + (F ? 1u : 0u)), dim3(GH_T), GSM_LDS_TOTAL, st, *ek, *tb, *c, src, \
+                           (const uint4 *)in, (uint4 *)out, (const unsigned char *)sc, partial, build, steps, fin);  \
     } while (0)
-    if (decrypt == 0) GMC_LAUNCH(0); else if (decrypt == 1) GMC_LAUNCH(1); else GMC_LAUNCH(2);
+    if (fold) {
+        if (decrypt == 0) GMC_LAUNCH(0, true); else GMC_LAUNCH(1, true);
+        return (int)hipGetLastError();
+    }
+    if (decrypt == 0) GMC_LAUNCH(0, false); else if (decrypt == 1) GMC_LAUNCH(1, false); else GMC_LAUNCH(2, false);
 #undef GMC_LAUNCH
     e = uaesk_want_lds((const void *)k_gcm_combine<NR>, (unsigned)(GHFB_LDS));
     if (e != hipSuccess) return (int)e;
@@ -1967,6 +2050,8 @@ static int gcm_body(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk
     /* an armed completion ticket (uaes_device.h) may ride on a ONE-launch encryption only; taking it here also
      * keeps the building blocks below (uaesk_ctr_xcrypt) from picking it up in the middle of a longer sequence */
     TicketScope ticket;
+    /* ... and so may the counter word a one-launch arrangement of several workgroups needs (uaesk_done_word_arm) */
+    unsigned *const done_word = uaesk_done_word_take();
     /* J0 = nonce || 00000001 for the 12-byte nonce (GCMsetup, micro_aes.c:1150-1151), or
      * GHASH(nonce) (uaesk_gcm_j0); the host layer passes the 16 bytes                     */
     uint4 j0;
@@ -2106,9 +2191,9 @@ static int gcm_body(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk
         sm.ct = (const unsigned char *)in;
         unsigned char *tagp = decrypt ? (unsigned char *)in + len : (unsigned char *)out + len;
         switch (nr) {
-        case 10: rc = launch_medium<10>(st, tb, ek, &c, j0, sm, in, out, sc, W, steps, build, decrypt, tagp, status); break;
-        case 12: rc = launch_medium<12>(st, tb, ek, &c, j0, sm, in, out, sc, W, steps, build, decrypt, tagp, status); break;
-        case 14: rc = launch_medium<14>(st, tb, ek, &c, j0, sm, in, out, sc, W, steps, build, decrypt, tagp, status); break;
+        case 10: rc = launch_medium<10>(st, tb, ek, &c, j0, sm, in, out, sc, W, steps, build, decrypt, tagp, status, done_word, ticket); break;
+        case 12: rc = launch_medium<12>(st, tb, ek, &c, j0, sm, in, out, sc, W, steps, build, decrypt, tagp, status, done_word, ticket); break;
+        case 14: rc = launch_medium<14>(st, tb, ek, &c, j0, sm, in, out, sc, W, steps, build, decrypt, tagp, status, done_word, ticket); break;
         default: return (int)hipErrorInvalidValue;
         }
         if (rc && decrypt == 2) (void)hipMemsetAsync(out, 0, len, st);   /* the chunk kernel may have been enqueued: see above */

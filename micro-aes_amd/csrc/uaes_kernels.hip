@@ -1108,6 +1108,18 @@ extern "C" void uaesk_ticket_arm(void *pinned_flag, void *d_count, unsigned seq)
 
 static thread_local int g_unused = 0;
 
+/* A word that is ZERO BETWEEN CALLS, for the next kernel-level call of this thread that runs several workgroups in one
+ * launch and lets one of them finish the job (the GCM chunk kernel's finisher): the host layer owns such words (the
+ * tail of its scratch buffers) and arms one right before the call; a routine that can use it takes it at its entry. */
+static thread_local unsigned *g_done_word = nullptr;
+extern "C" void uaesk_done_word_arm(unsigned *w) { g_done_word = w; }
+unsigned *uaesk_done_word_take()
+{
+    unsigned *w = g_done_word;
+    g_done_word = nullptr;
+    return w;
+}
+
 extern "C" int uaesk_ticket_disarm(void)
 {
     const int still = g_armed.flag != nullptr || g_unused;

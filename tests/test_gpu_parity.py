@@ -428,6 +428,41 @@ def test_ocb_one_launch_paths(orc, bits):
                 assert int(status.item()) == 0 and bytes(back.cpu().numpy()) == data
 
 
+def test_gcm_medium_texts_one_launch(orc):
+    """32 KiB .. 8 MiB: the chunk workgroups and a FINISHER workgroup in one launch (k_gcm_chunks<.., FOLD>): the
+    finisher waits on a counter word that must be back at zero for the next call -- the same lane / stream slot / key
+    context again and again, sizes on both sides of the arrangement's limits (one or two positions per thread; as many
+    chunk workgroups as the finisher still leaves a CU for), AAD, encryption and both decryption orders."""
+    import torch
+    rnd = random.Random(4242)
+    key, st = rnd.randbytes(16), torch.cuda.current_stream()
+    gk = uaes.GcmKey(key)
+    for n in (40000, 65536 + 5, (1 << 20) - 16, (4 << 20) - 32, (4 << 20) - 16, (4 << 20), (4 << 20) + 4096, (8 << 20) - 48, (8 << 20) + 1):
+        nonce, aad = rnd.randbytes(12), rnd.randbytes(rnd.choice([0, 20, 4096]))
+        data = orc.splitmix(n, n)
+        want = orc.gcm_encrypt(key, nonce, aad, data)
+        for _ in range(2):
+            assert uaes.AES_GCM_encrypt(key, nonce, aad, data) == want, n
+            assert gk.encrypt(nonce, aad, data) == want, n
+        assert uaes.AES_GCM_decrypt(key, nonce, aad, want) == (0, data), n
+        assert gk.decrypt(nonce, aad, want) == (0, data), n
+        bad = bytearray(want)
+        bad[n // 3] ^= 4
+        assert uaes.AES_GCM_decrypt(key, nonce, aad, bytes(bad))[0] == 0x1A
+        d_in = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+        d_aad = torch.frombuffer(bytearray(aad), dtype=torch.uint8).cuda() if aad else None
+        d_out = torch.zeros(n + 16, dtype=torch.uint8, device="cuda")
+        for _ in range(3):
+            uaes.gcm_encrypt_dev(key, nonce, d_aad, d_in, n, d_out, stream=st)
+        torch.cuda.synchronize()
+        assert bytes(d_out.cpu().numpy()) == want, n
+        back = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        status = torch.full((1,), -1, dtype=torch.int32, device="cuda")
+        uaes.gcm_decrypt_dev(key, nonce, d_aad, d_out, n, back, status, stream=st)
+        torch.cuda.synchronize()
+        assert int(status.item()) == 0 and bytes(back.cpu().numpy()) == data
+
+
 def test_main_c_kats(golden_dir):
     for k in load(golden_dir, "main_kats.json"):
         key, pt, exp = bytes.fromhex(k["key"]), bytes.fromhex(k["pt"]), bytes.fromhex(k["expect"])

@@ -9,6 +9,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import micro_aes_amd as uaes
 
+if os.environ.get("UAES_LIB"):                      # A/B against another build of the library
+    uaes.lib_path.__defaults__ = (os.environ["UAES_LIB"],)
+    print("# " + os.environ["UAES_LIB"])
 key, nonce = bytes(range(16)), bytes(range(12))
 ctr0 = nonce + b"\0\0\0\1"
 st = torch.cuda.current_stream()
