@@ -292,6 +292,9 @@ typedef struct {
         size_t xscratch_cap;
     } pipe[16];
     int             pipe_busy;      /* a pipelined call owns pipe[] (c->mu is dropped while its workers run) */
+    void           *spool[8];       /* wiped scratch buffers of finished GCM streams, for the next uaes_gcm_stream_begin:
+                                     * hipMalloc + hipDeviceSynchronize + hipFree were 230 us of every streamed message */
+    int             nspool;
     struct lane    *lanes;          /* every thread's lane on this device (uaes_shutdown)      */
     pthread_mutex_t mu;             /* slot[], pipe[] ownership, the lane list -- never held while the GPU works */
 } context;
@@ -1243,6 +1246,8 @@ int uaes_shutdown(void)
             if (c->pipe[i].stream) (void)hipStreamDestroy((hipStream_t)c->pipe[i].stream);
             memset(&c->pipe[i], 0, sizeof c->pipe[i]);
         }
+        for (i = 0; i < c->nspool; ++i) (void)hipFree(c->spool[i]);   /* (wiped when they were put there) */
+        c->nspool = 0;
         for (i = 0; i < SCRATCH_SLOTS; ++i) {
             if (c->slot[i].buf) {
                 (void)hipMemset(c->slot[i].buf, 0, c->slot[i].cap);  /* GHASH tables are key material */
@@ -3040,7 +3045,9 @@ struct uaes_gcm_stream {
     void     *scratch;              /* uaesk_gcm_stream_scratch_bytes() + 64: tables, running GHASH, tag, status */
 };
 
-static void *stream_tag_slot(uaes_gcm_stream *s) { return (char *)s->scratch + uaesk_gcm_stream_scratch_bytes(); }
+/* (the whole GCM layout: a long piece takes the one-pass kernel, which needs its tables there) */
+#define STREAM_SCRATCH_BYTES uaesk_gcm_scratch_bytes()
+static void *stream_tag_slot(uaes_gcm_stream *s) { return (char *)s->scratch + STREAM_SCRATCH_BYTES; }
 static int *stream_status_slot(uaes_gcm_stream *s) { return (int *)((char *)stream_tag_slot(s) + 16); }
 
 int uaes_gcm_stream_begin(uaes_gcm_stream **out, int keybits, const uint8_t *key, const uint8_t *nonce,
@@ -3058,8 +3065,11 @@ int uaes_gcm_stream_begin(uaes_gcm_stream **out, int keybits, const uint8_t *key
     memcpy(s->nonce, nonce, 12);
     s->decrypt = decrypt != 0;
     s->aad_len = aDataLen;
+    pthread_mutex_lock(&c->mu);
+    if (c->nspool > 0) s->scratch = c->spool[--c->nspool];
+    pthread_mutex_unlock(&c->mu);
     if (hipGetDevice(&s->device) != hipSuccess ||
-        hipMalloc(&s->scratch, uaesk_gcm_stream_scratch_bytes() + 64) != hipSuccess) {
+        (!s->scratch && hipMalloc(&s->scratch, STREAM_SCRATCH_BYTES + 64) != hipSuccess)) {
         memset(s, 0, sizeof *s);
         free(s);
         return fail(UAES_E_HIP, "stream scratch allocation failed");
@@ -3113,6 +3123,11 @@ static int gcm_stream_update_on_device(uaes_gcm_stream *s, const void *in, size_
     do {
         int k;
         if ((rc = plan_io(L, in, len, outp, len, &io)) != 0) break;
+        /* a long piece: CTR and GHASH in one pass over it (uaesk_gcm_stream_piece; 1 = not taken) */
+        k = uaesk_gcm_stream_piece(L->stream, &c->tb, s->ks.nr, &s->ks.ek, s->nonce, s->decrypt, io.din, len, s->done, io.dout,
+                                   s->scratch, &s->plan_state);
+        if (k == 0) { rc = finish_io(&io, len); break; }
+        if (k != 1) { rc = fail(UAES_E_HIP, "gcm stream launch: %s", hipGetErrorString((hipError_t)k)); break; }
         if (s->decrypt) {                             /* hash the ciphertext before it may be overwritten */
             k = uaesk_gcm_stream_absorb(L->stream, &c->tb, s->ks.nr, &s->ks.ek, s->nonce, 1, io.din, len, 0, 0, s->scratch, &s->plan_state);
             if (!k) k = uaesk_ctr_xcrypt(L->stream, &c->tb, s->ks.nr, &s->ks.ek, &ctr, io.din, io.dout, len, NULL);
@@ -3161,6 +3176,13 @@ int uaes_gcm_stream_finish(uaes_gcm_stream *s, uint8_t tag[16])
         else rc = lane_fetch(L, tag, stream_tag_slot(s), 16);
         if (rc) break;
         if (s->decrypt && status != 0) rc = UAES_E_AUTHENTICATION;
+        /* everything this stream enqueued is done (lane_fetch drained the lane): wipe the scratch (H and its tables are
+         * key material) and keep it for the next stream instead of hipDeviceSynchronize + hipFree */
+        if (hipMemsetAsync(s->scratch, 0, STREAM_SCRATCH_BYTES + 64, st) == hipSuccess && lane_sync(L) == 0) {
+            pthread_mutex_lock(&c->mu);
+            if (c->nspool < (int)(sizeof c->spool / sizeof c->spool[0])) { c->spool[c->nspool++] = s->scratch; s->scratch = NULL; }
+            pthread_mutex_unlock(&c->mu);
+        }
     } while (0);
     if (rc < 0) (void)lane_abandon(L, rc);
     uaes_gcm_stream_abort(s);

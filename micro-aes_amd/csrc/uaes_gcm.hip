@@ -2579,13 +2579,106 @@ extern "C" int uaesk_gcm_stream_absorb(void *stream, const uaesk_tables *tb, int
         default: return (int)hipErrorInvalidValue;
         }
         if (rc) return rc;
-        if (plan_state) *plan_state = 0x80000000u | (pl.needB ? 0x100u : 0u) | pl.logA;
+        if (plan_state) *plan_state = 0x80000000u | (*plan_state & 0x200u) | (pl.needB ? 0x100u : 0u) | pl.logA;   /* (bit 9: the striped
+                                         * kernel's tables, uaesk_gcm_stream_piece -- another setup leaves them alone) */
     }
     if (nv) {
         rc = run_ghash_levels(st, msg, nv, pl, sc, 2, sc + GS_PART, nullptr);
         if (rc) return rc;
     }
     hipLaunchKernelGGL(k_gcm_fold, dim3(1), dim3(64), 0, st, sc, nv, (u32)(kind == 0));
+    return (int)hipGetLastError();
+}
+
+/* One piece of a streamed message, CTR and GHASH in ONE pass when the piece is long enough for the striped kernel
+ * (8 MiB on 256 CUs): what uaesk_gcm_shard does for a slice, with the running value folded (k_gcm_fold) instead of a
+ * weighted share.  Returns 1 if it was not taken (the caller then runs uaesk_ctr_xcrypt + uaesk_gcm_stream_absorb as
+ * before: CTR kernel, GHASH levels, fold -- two passes over the piece, 415 GiB/s for one 256 MiB piece), 0 when the
+ * work is enqueued, else a hipError_t.  done_bytes = text absorbed so far (a multiple of 16); a piece of a length
+ * that is no multiple of 16 is the message's last.  The stream's scratch must hold uaesk_gcm_scratch_bytes().
+ * plan_state bit 9: the striped kernel's tables of this key are in the scratch.                                 */
+extern "C" int uaesk_gcm_stream_piece(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek,
+                                      const uint8_t *nonce12, int decrypt, const void *in, size_t len,
+                                      uint64_t done_bytes, void *out, void *scratch, unsigned *plan_state)
+{
+    hipStream_t st = S(stream);
+    unsigned char *sc = (unsigned char *)scratch;
+    if (done_bytes % 16 || !plan_state) return (int)hipErrorInvalidValue;
+    int cus = 0;
+    if (uaesk_device_info(&cus, nullptr) != 0 || cus <= 0) return 1;
+    uint4 j0;
+    unsigned char j0b[16];
+    memcpy(j0b, nonce12, 12);
+    j0b[12] = j0b[13] = j0b[14] = 0; j0b[15] = 1;
+    memcpy(&j0, j0b, 16);
+    uaesk_ctr c;
+    memset(&c, 0, sizeof c);
+    memcpy(&c.w0, j0b, 4);
+    memcpy(&c.w1, j0b + 4, 4);
+    c.b8 = j0b[8];
+    {
+        uint64_t v = 0;                         /* bytes 9..15 of J0: the reference's 56-bit counter (N2); + 1: pre-increment (N4) */
+        for (int i = 9; i < 16; ++i) v = (v << 8) | j0b[i];
+        c.v0 = (v + 1 + done_bytes / 16) & 0x00FFFFFFFFFFFFFFull;
+    }
+    const u64 Sl = 2048ull * (u64)cus;
+    u32 logF = 0;
+    while (((u64)1 << logF) < Sl) ++logF;
+    const u64 nfull = len / 16;
+    const u32 c0 = (u32)c.v0 & 0xffu;
+    const u64 h0 = (256u - c0) & 255u, g_lo = c0 ? 1 : 0;
+    const u64 groups = (c0 + nfull) / 256, n8 = groups > g_lo ? (groups - g_lo) / 8 : 0;
+    if (!(((u64)1 << logF) == Sl && logF <= GF_MAXLOG && n8 >= (u64)cus && h0 <= Sl && !ctr_stripes_cross_a(&c, g_lo, n8)))
+        return 1;
+    const u64 h1 = h0 + 2048 * n8;
+    GSrc msg;
+    memset(&msg, 0, sizeof msg);
+    msg.ct = (const unsigned char *)(decrypt ? in : out); msg.ct_len = len;
+    GSrc fin;                                                   /* [T][tail] */
+    memset(&fin, 0, sizeof fin);
+    fin.aad = sc + GS_T; fin.aad_len = 16;
+    fin.ct = msg.ct + h1 * 16; fin.ct_len = len - h1 * 16;
+    const u64 nvf = 1 + ((fin.ct_len + 15) >> 4);
+    const GPlan plf = plan_for(nvf);
+    GSrc front = msg;                                           /* [head] in front of the striped region */
+    front.ct_len = h0 * 16;
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    int rc;
+    if ((*plan_state >> 31) && ((*plan_state >> 9) & 1u) && (!plf.logA || (*plan_state & 0xffu) == plf.logA) &&
+        (!plf.needB || ((*plan_state >> 8) & 1u))) {           /* the tables are there: Enc(J0) again and T <- 0 */
+        switch (nr) {
+        case 10: rc = launch_ej0<10>(st, tb, ek, j0, sc); break;
+        case 12: rc = launch_ej0<12>(st, tb, ek, j0, sc); break;
+        case 14: rc = launch_ej0<14>(st, tb, ek, j0, sc); break;
+        default: return (int)hipErrorInvalidValue;
+        }
+    } else {
+        switch (nr) {
+        case 10: rc = launch_setup<10>(st, tb, ek, j0, sc, plf, 0, z, 1, logF); break;
+        case 12: rc = launch_setup<12>(st, tb, ek, j0, sc, plf, 0, z, 1, logF); break;
+        case 14: rc = launch_setup<14>(st, tb, ek, j0, sc, plf, 0, z, 1, logF); break;
+        default: return (int)hipErrorInvalidValue;
+        }
+        if (!rc) *plan_state = 0x80000000u | 0x200u | (plf.needB ? 0x100u : 0u) | plf.logA;
+    }
+    if (rc) return rc;
+    if (!decrypt) {
+        rc = launch_fused_nr<false>(nr, st, tb, ek, &c, in, out, (unsigned)cus, g_lo, n8, h1, nfull, (u32)(len % 16),
+                                    front, h0, sc);
+        if (!rc) rc = run_ghash_levels(st, fin, nvf, plf, sc, 2, sc + GS_PART, nullptr);
+    } else {
+        /* the fused kernel leaves the tail alone: it is hashed as ciphertext first (in may be out) */
+        rc = launch_fused_nr<true>(nr, st, tb, ek, &c, in, out, (unsigned)cus, g_lo, n8, nfull, nfull, 0, front, h0, sc);
+        if (!rc) rc = run_ghash_levels(st, fin, nvf, plf, sc, 2, sc + GS_PART, nullptr);
+        if (!rc && len > h1 * 16) {
+            uaesk_ctr ct = c;
+            ct.v0 = (c.v0 + h1) & 0x00FFFFFFFFFFFFFFull;
+            rc = uaesk_ctr_xcrypt(stream, tb, nr, ek, &ct, (const unsigned char *)in + h1 * 16,
+                                  (unsigned char *)out + h1 * 16, len - h1 * 16, nullptr);
+        }
+    }
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_gcm_fold, dim3(1), dim3(64), 0, st, sc, (u64)((len + 15) >> 4), 0u);
     return (int)hipGetLastError();
 }
 

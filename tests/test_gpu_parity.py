@@ -332,7 +332,10 @@ def test_gcm_stream_equals_one_shot(orc, bits):
     rnd = random.Random(bits + 8)
     for pieces, aad_len in [([16], 0), ([5], 3), ([16, 16, 7], 20), ([4096, 16, 65536, 1], 0),
                             ([(1 << 20) + 16, 48, (600 << 10), 12345], 4097), ([0, 32, 0, 16], 16),
-                            ([40 << 10, 2 << 20, 64, 5 << 20, 2 << 20, 100], 1)]:   # level plans change back and forth
+                            ([40 << 10, 2 << 20, 64, 5 << 20, 2 << 20, 100], 1),    # level plans change back and forth
+                            # pieces long enough for the one-pass kernel (8 MiB on 256 CUs) between short ones: its
+                            # tables are made once per stream, a later short piece's setup must leave them alone
+                            ([9 << 20, 4096, (17 << 20) + 16, 16, (8 << 20) + 5], 33), ([(12 << 20) + 7], 0)]:
         key, nonce, aad = rnd.randbytes(bits // 8), rnd.randbytes(12), rnd.randbytes(aad_len)
         n = sum(pieces)
         data = orc.splitmix(n + 11, n)
