@@ -226,16 +226,26 @@ __global__ __launch_bounds__(UAES_WG, 4) void k_ctr_shared2(uaesk_rk rk, uaesk_t
 /* pre-pass: one thread per data unit.  T0 = Enc_key2(tweak) (:1026-1027),
  * then the tweak at the start of every 256-block chunk of the unit; for units of
  * many chunks (serial != 0 only below XTS_SERIAL_CPS) k_xts_expand does the latter. */
-template <int NR>
+/* PLAIN (round 5): up to 2^16 units -- one-wave workgroups that encrypt through an UNREPLICATED 1 KiB copy of Te0
+ * (plain_encrypt; the lanes' lookups collide in the banks, which costs a wave's 160 lookups a microsecond): filling
+ * 128 KiB of replicated tables for one block per lane was most of this kernel's 8.5 us (8 MiB of 4 KiB sectors:
+ * 27 -> ?? us per call).                                                                                    */
+template <int NR, bool PLAIN = false>
 __global__ __launch_bounds__(UAES_WG) void k_xts_tweaks(uaesk_rk k2, uaesk_tables tb,
                                                         uint4 raw_tweak, u32 use_raw, u64 first_sector,
                                                         u64 nsectors, u64 chunks_per_sector, u32 serial,
                                                         uint4 *__restrict__ chunk_tw)
 {
-    fill_enc_tables(tb.te0);
-    const LaneConst lc = make_lane_const();
-    const u64 stride = (u64)gridDim.x * UAES_WG;
-    for (u64 sct = (u64)blockIdx.x * UAES_WG + threadIdx.x; sct < nsectors; sct += stride) {
+    LaneConst lc;
+    if (PLAIN) {
+        for (u32 i = threadIdx.x; i < 256u; i += blockDim.x) ((u32 *)uaes_lds)[i] = tb.te0[i];
+        __syncthreads();
+    } else {
+        fill_enc_tables(tb.te0);
+        lc = make_lane_const();
+    }
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 sct = (u64)blockIdx.x * blockDim.x + threadIdx.x; sct < nsectors; sct += stride) {
         u32 s[1][4];
         if (use_raw) {
             s[0][0] = raw_tweak.x; s[0][1] = raw_tweak.y; s[0][2] = raw_tweak.z; s[0][3] = raw_tweak.w;
@@ -243,7 +253,7 @@ __global__ __launch_bounds__(UAES_WG) void k_xts_tweaks(uaesk_rk k2, uaesk_table
             const u64 id = first_sector + sct;  /* copyLint, micro_aes.c:399-404 */
             s[0][0] = (u32)id; s[0][1] = (u32)(id >> 32); s[0][2] = 0; s[0][3] = 0;
         }
-        enc_blocks<NR, 1>(s, k2, lc);
+        if (PLAIN) plain_encrypt<NR>((const u32 *)uaes_lds, k2, s[0]); else enc_blocks<NR, 1>(s, k2, lc);
         Tw t;
         t.lo = s[0][0] | ((u64)s[0][1] << 32);
         t.hi = s[0][2] | ((u64)s[0][3] << 32);
@@ -344,18 +354,25 @@ __device__ __forceinline__ void store16(unsigned char *p, uint4 v)
  * four accesses of a chunk use all of it); the memory path has room for that in a kernel that needs 16 + 16 bytes
  * every eight cycles per CU.  Arguments then: chunks_per_sector = blocks per unit, main_blocks = blocks of the whole
  * text, (step_q, step_r) = (256 * waves) / and % blocks per unit, magic = ceil(2^24 / blocks per unit).           */
-template <int NR, bool DEC, bool ALIGNED, bool PACKED = false>
-__global__ __launch_bounds__(UAES_WG) void k_xts(uaesk_rk k1, uaesk_tables tb,
-                                                 const uint4 *__restrict__ chunk_tw,
-                                                 u64 nsectors, u64 chunks_per_sector,
-                                                 u64 main_blocks,      /* whole blocks handled here, per unit */
-                                                 u64 sector_bytes,
-                                                 u64 step_q, u64 step_r,   /* (waves of the grid) / and % chunks_per_sector */
-                                                 const unsigned char *in,
-                                                 unsigned char *out,
-                                                 u64 nmain,            /* chunks [nmain, all) go by quarters (== all: none) */
-                                                 u32 magic)
+/* FOLD (round 5, second half): a chunk per unit and ONE chunk per unit (4 KiB sectors) -- no pre-pass launch: a wave
+ * encrypts the tweaks of its next 64 chunks itself, one per lane (plain_encrypt through a 1 KiB copy of Te0 behind the
+ * cipher tables, key 2 read through the kernel-argument pointer where it is used), keeps them in four vector
+ * registers and takes one out with v_readlane per trip.  Between 4 and 64 MiB a call was bound by the HOST's two
+ * launches (8 and 16 MiB: 26 us per enqueued call either way), not by the GPU.  Used while a wave has at most eight
+ * chunks (128 MiB on 256 CUs); beyond that the pre-pass is the cheaper way to the tweaks.                    */
+template <int NR, bool DEC, bool ALIGNED, bool PACKED, bool FOLD>
+__device__ __forceinline__ void xts_body(const uaesk_rk &k1, const uaesk_tables &tb,
+                                         const uint4 *__restrict__ chunk_tw,
+                                         u64 nsectors, u64 chunks_per_sector,
+                                         u64 main_blocks,      /* whole blocks handled here, per unit */
+                                         u64 sector_bytes,
+                                         u64 step_q, u64 step_r,   /* (waves of the grid) / and % chunks_per_sector */
+                                         const unsigned char *in,
+                                         unsigned char *out,
+                                         u64 nmain,            /* chunks [nmain, all) go by quarters (== all: none) */
+                                         u32 magic, const uaesk_rk *k2p, u64 first_sector)
 {
+    if (FOLD && threadIdx.x < 256u) ((u32 *)(uaes_lds + UAES_LDS_ENC))[threadIdx.x] = tb.te0[threadIdx.x];
     if (DEC) fill_dec_tables(tb.td0); else fill_enc_tables(tb.te0);
     const LaneConst lc = make_lane_const();
     const u32 lane = threadIdx.x & 63u;
@@ -382,7 +399,26 @@ __global__ __launch_bounds__(UAES_WG) void k_xts(uaesk_rk k1, uaesk_tables tb,
         u64 off;                                     /* byte offset of the chunk's first block */
     };
     const u32 lane_off = PACKED ? lane * 64u : lane16, u_off = PACKED ? 16u : 1024u;
+    /* FOLD: the tweaks of this wave's chunks wave + (t0 + lane) * nwaves, t0 = 0, 64, 128 ... (the unit's number is
+     * the chunk's: copyLint, micro_aes.c:399-404, then Enc_key2, :1026-1027) */
+    u32 twl[4] = { 0, 0, 0, 0 };
+    u32 trip = 0;
+    auto tweak_of = [&](u64 ch, u32 (&t)[4]) {
+        const u64 id = first_sector + ch;
+        t[0] = (u32)id; t[1] = (u32)(id >> 32); t[2] = 0; t[3] = 0;
+        plain_encrypt<NR>((const u32 *)(uaes_lds + UAES_LDS_ENC), *k2p, t);
+    };
     auto fetch = [&](u64 ch, Fetched &f) {
+        if (FOLD) {
+            /* (only as many lanes as the wave has chunks -- the host takes this kernel up to eight per wave: sixteen
+             * waves' lookups in the plain table collide in the banks, 64 busy lanes each cost all of a CU's waves
+             * ~14 us per batch, 16 MiB 27 -> 30 us; eight cost ~3) */
+            if (trip == 0 && ch + (u64)lane * nwaves < nsectors) tweak_of(ch + (u64)lane * nwaves, twl);
+            const u32 k = trip;
+            f.tb = make_uint4((u32)__builtin_amdgcn_readlane((int)twl[0], (int)k), (u32)__builtin_amdgcn_readlane((int)twl[1], (int)k),
+                              (u32)__builtin_amdgcn_readlane((int)twl[2], (int)k), (u32)__builtin_amdgcn_readlane((int)twl[3], (int)k));
+            ++trip;
+        }
         const u64 sct = sctn;
         const u64 first = PACKED ? ch * XTS_CHUNK : withn * XTS_CHUNK;
         const u32 rb = (u32)withn;
@@ -392,7 +428,7 @@ __global__ __launch_bounds__(UAES_WG) void k_xts(uaesk_rk k1, uaesk_tables tb,
         f.cnt = left < XTS_CHUNK ? (u32)left : XTS_CHUNK;
         f.off = PACKED ? first * 16 : sct * sector_bytes + first * 16;
         if (PACKED) { f.rb = rb; f.sb = sct; }                   /* the lane's unit tweak follows later (fetch_tw) */
-        else f.tb = chunk_tw[ch];
+        else if (!FOLD) f.tb = chunk_tw[ch];
         const unsigned char *src = in + f.off;
         if (ALIGNED) {
             /* a buffer resource over exactly the chunk's blocks: base in SGPRs, the lane's constant offset, and the
@@ -508,7 +544,14 @@ __global__ __launch_bounds__(UAES_WG) void k_xts(uaesk_rk k1, uaesk_tables tb,
         const u64 left = main_blocks - first;
         const u32 cnt = left < XTS_CHUNK ? (u32)left : XTS_CHUNK;
         const u32 j = 64u * k + lane;
-        const uint4 tb4 = chunk_tw[c];
+        uint4 tb4;
+        if (FOLD) {
+            u32 tq[4];
+            tweak_of(c, tq);                               /* (every lane the same block: broadcast reads) */
+            tb4 = make_uint4(tq[0], tq[1], tq[2], tq[3]);
+        } else {
+            tb4 = chunk_tw[c];
+        }
         Tw t;
         t.lo = tb4.x | ((u64)tb4.y << 32);
         t.hi = tb4.z | ((u64)tb4.w << 32);
@@ -523,6 +566,35 @@ __global__ __launch_bounds__(UAES_WG) void k_xts(uaesk_rk k1, uaesk_tables tb,
             store16<ALIGNED>(out + off, make_uint4(s1[0][0] ^ tw[0], s1[0][1] ^ tw[1], s1[0][2] ^ tw[2], s1[0][3] ^ tw[3]));
         }
     }
+}
+
+template <int NR, bool DEC, bool ALIGNED, bool PACKED = false>
+__global__ __launch_bounds__(UAES_WG) void k_xts(uaesk_rk k1, uaesk_tables tb,
+                                                 const uint4 *__restrict__ chunk_tw,
+                                                 u64 nsectors, u64 chunks_per_sector, u64 main_blocks, u64 sector_bytes,
+                                                 u64 step_q, u64 step_r, const unsigned char *in, unsigned char *out,
+                                                 u64 nmain, u32 magic)
+{
+    xts_body<NR, DEC, ALIGNED, PACKED, false>(k1, tb, chunk_tw, nsectors, chunks_per_sector, main_blocks, sector_bytes,
+                                              step_q, step_r, in, out, nmain, magic, nullptr, 0);
+}
+
+struct XtsFoldArgs {
+    uaesk_rk k1, k2;
+    uaesk_tables tb;
+    u64 nsectors, main_blocks, sector_bytes, step_q, step_r, nmain, first_sector;
+    const unsigned char *in;
+    unsigned char *out;
+};
+
+template <int NR, bool DEC>
+__global__ __launch_bounds__(UAES_WG) void k_xts_fold(XtsFoldArgs)
+{
+    const XtsFoldArgs *const a = (const XtsFoldArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    const uaesk_rk k1 = a->k1;
+    const uaesk_tables tb = a->tb;
+    xts_body<NR, DEC, true, false, true>(k1, tb, nullptr, a->nsectors, 1, a->main_blocks, a->sector_bytes, a->step_q, a->step_r,
+                                         a->in, a->out, a->nmain, 0u, &a->k2, a->first_sector);
 }
 
 /* ONE data unit of up to 64 chunks = 256 KiB (the reference API's call shape, a unit per call, micro_aes.c:1066-1093):
@@ -1029,11 +1101,36 @@ static int launch_xts(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *k1
                                (const unsigned char *)in, (unsigned char *)out);
         return (int)hipGetLastError();
     }
+    /* a chunk per unit, one chunk per unit, whole blocks (4 KiB sectors): the bulk kernel makes its tweaks itself */
+    if (!tweak16 && r == 0 && cps == 1 && mb >= 4 && !(mb < XTS_CHUNK && mb % 4 == 0) && nsectors > 1 &&
+        (u64)nsectors <= 8ull * grid_for(~0ull, 1) * (UAES_WG / 64)) {          /* ... up to eight chunks per wave: 128 MiB */
+        if ((e = set_lds((k_xts_fold<NR, DEC>), lds + 1024u)) != hipSuccess) return (int)e;
+        const u64 nchunks = (u64)nsectors;
+        const unsigned wg = grid_for(nchunks, UAES_WG / 64) * 2 <= grid_for(~0ull, 1) ? 256u : UAES_WG;
+        const unsigned xgrid = grid_for(nchunks, wg / 64);
+        const u64 nwaves = (u64)xgrid * (wg / 64);
+        static const int pct = env_int_clamped("UAES_XTS_TAIL_PCT", 80, 0, 100);
+        const u64 rounds = nchunks / nwaves, left = nchunks % nwaves;
+        XtsFoldArgs ka;
+        ka.k1 = *k1; ka.k2 = *k2; ka.tb = *tb; ka.nsectors = nsectors; ka.main_blocks = mb; ka.sector_bytes = sector_bytes;
+        ka.step_q = nwaves; ka.step_r = 0; ka.first_sector = first_sector;
+        ka.nmain = (rounds && left && left * 100 < nwaves * (u64)pct) ? rounds * nwaves : nchunks;
+        ka.in = (const unsigned char *)in; ka.out = (unsigned char *)out;
+        hipLaunchKernelGGL((k_xts_fold<NR, DEC>), dim3(xgrid), dim3(wg), lds + 1024u, st, ka);
+        return (int)hipGetLastError();
+    }
     const bool serial = cps <= XTS_SERIAL_CPS;
     if (!serial && ((cps + 63) / 64) >> XTS_POW_N) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL((k_xts_tweaks<NR>), dim3(grid_for(nsectors, UAES_WG)), dim3(UAES_WG), UAES_LDS_ENC, st,
-                       *k2, *tb, raw, (u32)(tweak16 != nullptr), first_sector, (u64)nsectors, cps, (u32)serial,
-                       (uint4 *)scratch);
+    if (nsectors <= 65536) {                 /* few units: one-wave workgroups on a plain table (k_xts_tweaks) */
+        if ((e = set_lds((k_xts_tweaks<NR, true>), 1024u)) != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((k_xts_tweaks<NR, true>), dim3((unsigned)((nsectors + 63) / 64)), dim3(64), 1024u, st,
+                           *k2, *tb, raw, (u32)(tweak16 != nullptr), first_sector, (u64)nsectors, cps, (u32)serial,
+                           (uint4 *)scratch);
+    } else {
+        hipLaunchKernelGGL((k_xts_tweaks<NR>), dim3(grid_for(nsectors, UAES_WG)), dim3(UAES_WG), UAES_LDS_ENC, st,
+                           *k2, *tb, raw, (u32)(tweak16 != nullptr), first_sector, (u64)nsectors, cps, (u32)serial,
+                           (uint4 *)scratch);
+    }
     if (!serial)
         hipLaunchKernelGGL(k_xts_expand, dim3(grid_for((u64)nsectors * ((cps + 63) / 64), UAES_WG / 64)),
                            dim3(UAES_WG), 0, st, *xts_pow_table(), (u64)nsectors, cps, (uint4 *)scratch);

@@ -3,7 +3,7 @@ sys.path.insert(0, os.getcwd())
 import torch, micro_aes_amd as uaes
 keys = bytes(range(64))
 print("%9s %8s %10s" % ("total", "unit", "us/call"))
-for total in (65536, 262144, 1 << 20, 2 << 20, 4 << 20, 8 << 20):
+for total in (65536, 1 << 20, 4 << 20, 8 << 20, 16 << 20, 64 << 20):
     src = torch.randint(0, 256, (total,), dtype=torch.uint8, device="cuda")
     dst = torch.empty_like(src)
     for unit in (512, 4096):
