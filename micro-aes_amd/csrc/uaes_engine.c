@@ -2543,7 +2543,7 @@ int uaes_ccm_decrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, s
                           io.din, crtxtLen, io.dout, L->d_status);
         if (k) { rc = fail(UAES_E_HIP, "ccm launch: %s", hipGetErrorString((hipError_t)k)); break; }
         if ((rc = lane_fetch(L, &status, L->d_status, sizeof status)) != 0) break;
-        io.drained = 1;                              /* (a second wait costs another ticket kernel: 25 -> ?? us for 16 bytes) */
+        io.drained = 1;                              /* (a second wait costs another ticket kernel) */
         /* the reference decrypts before it authenticates and (SABOTAGE being a
          * no-op in its default build) leaves the text in place on a mismatch   */
         if ((rc = status ? finish_io_unauthenticated(&io, crtxtLen) : finish_io(&io, crtxtLen)) != 0) break;

@@ -2182,7 +2182,7 @@ static int gcm_body(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk
          * kernels for a one-shot call.  Decrypt mode 1 hashes first and lets the gated CTR kernel write; mode 2
          * decrypts in the chunk kernel and zeroes the output if the tag turns out wrong.                       */
         /* one position per thread while that still gives every workgroup its own CU (up to 4 MiB on 256 CUs): the
-         * chunk kernel then runs one pass of block encryptions and no stride multiplication (1 MiB 24.7 -> ?? us) */
+         * chunk kernel then runs one pass of block encryptions and no stride multiplication (1 MiB 24.7 -> 23.5 us) */
         int cus_m = 0;
         if (uaesk_device_info(&cus_m, nullptr) != 0 || cus_m <= 0) cus_m = 64;
         const u32 steps = (nv + 1023) / 1024 <= (u64)cus_m ? 1u : 2u;

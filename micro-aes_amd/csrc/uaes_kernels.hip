@@ -229,7 +229,7 @@ __global__ __launch_bounds__(UAES_WG, 4) void k_ctr_shared2(uaesk_rk rk, uaesk_t
 /* PLAIN (round 5): up to 2^16 units -- one-wave workgroups that encrypt through an UNREPLICATED 1 KiB copy of Te0
  * (plain_encrypt; the lanes' lookups collide in the banks, which costs a wave's 160 lookups a microsecond): filling
  * 128 KiB of replicated tables for one block per lane was most of this kernel's 8.5 us (8 MiB of 4 KiB sectors:
- * 27 -> ?? us per call).                                                                                    */
+ * the kernel 8.5 -> ~4 us).                                                                                    */
 template <int NR, bool PLAIN = false>
 __global__ __launch_bounds__(UAES_WG) void k_xts_tweaks(uaesk_rk k2, uaesk_tables tb,
                                                         uint4 raw_tweak, u32 use_raw, u64 first_sector,
@@ -599,8 +599,8 @@ __global__ __launch_bounds__(UAES_WG) void k_xts_fold(XtsFoldArgs)
 
 /* ONE data unit of up to 64 chunks = 256 KiB (the reference API's call shape, a unit per call, micro_aes.c:1066-1093):
  * T0 = Enc_key2(tweak) is computed HERE, by every workgroup for itself, instead of by the k_xts_tweaks pre-pass, so a
- * call is one launch (4 KiB: 28.3 -> 22.5 us in round 2; 64 KiB 24 -> ?? us in round 3 when the kernel learnt to run
- * on several workgroups, 1 MiB 20 -> ?? us).  Wave 0 encrypts the tweak through an unreplicated 1 KiB copy of Te0 behind the cipher
+ * call is one launch (4 KiB: 28.3 -> 22.5 us in round 2; 64 KiB 16.2 -> 11.7 us in round 3 when the kernel learnt to run
+ * on several workgroups, 1 MiB 20.3 -> 13.9 us).  Wave 0 encrypts the tweak through an unreplicated 1 KiB copy of Te0 behind the cipher
  * tables (all lanes read the same entry: a broadcast, no conflicts; the decrypt direction has no Te tables in LDS)
  * while the other waves fill the tables; then one block per lane: wave w of the grid takes the 64-block runs
  * w, w + waves, ... of the unit, run q = 4c + k has the base tweak T0 * alpha^(256 c) * alpha^(64 k) (c = 64 g + l:

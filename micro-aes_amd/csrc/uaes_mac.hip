@@ -185,7 +185,7 @@ __device__ __forceinline__ u32 ccm_ctr_word(const uaesk_ctr &ctr, u64 i, u32 c)
 /* The text of a CCM message: CBC-MAC over the PLAINTEXT and CTR over the same blocks, in ONE wave.  row_encrypt runs
  * a block on sixteen lanes and the wave's other three rows used to repeat it; here rows 0 and 2 walk the MAC chain
  * and rows 1 and 3 encrypt the counter block -- the same instructions on different data -- so the CTR half costs no
- * time at all and a CCM call needs no k_ctr launch next to the MAC kernel (16 B: 18.7 -> ?? us, decrypt 30.5 -> ??).
+ * time at all and a CCM call needs no k_ctr launch next to the MAC kernel (16 B: 18.7 -> 13.6 us, decrypt 30.5 -> 16.8).
  * Encrypt: the counter rows store C_i = P_i ^ KS_i.  Decrypt: the chain needs P_i = C_i ^ KS_i before it can go on,
  * so the counter rows run one block ahead and hand the keystream across (swap_rows); the chain rows store P_i. */
 template <int NR, bool DEC, bool A4>

@@ -464,7 +464,7 @@ __device__ __forceinline__ void ocb_final_body(const ENC &enc,
  * block, the tag (decryption: the encryption tables come back first).  *done_word is zero between calls (the last
  * arrival puts it back; the host layer hands out a word that nothing else writes).  A completion ticket may ride
  * on the launch (every thread ends in ticket_release).
- * Against setup / block loop / tag as three launches (round 4): 1 GiB +3 %, 16 MiB 33 -> ?? us.                   */
+ * Against setup / block loop / tag as three launches (round 4): 1 MiB 25.4 -> 17.0 us, 16 MiB 32.3 -> 26.6, 1 GiB +-0. */
 struct OcbArgs {
     uaesk_rk ek, dk;                                  /* dk = ek for encryption */
     uaesk_tables tb;
