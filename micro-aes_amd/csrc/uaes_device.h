@@ -142,11 +142,12 @@ int uaesk_gcm_stream_absorb(void *stream, const uaesk_tables *tb, int nr, const 
                             const uint8_t *nonce12, int kind, const void *data, size_t len,
                             uint64_t total_aad_len, uint64_t total_ct_len, void *scratch,
                             unsigned *plan_state);   /* per stream, starts at 0: which tables scratch holds */
-/* one piece of the text, CTR + GHASH in one pass when it is long enough for the striped kernel: returns 1 when it
- * is not (run uaesk_ctr_xcrypt + uaesk_gcm_stream_absorb instead); the scratch must hold uaesk_gcm_scratch_bytes() */
+/* one piece of the text, CTR + GHASH in one pass: the striped kernel when it is long enough, one launch of chunk
+ * workgroups + finisher from 16 KiB (needs done_word: zero between calls); returns 1 when neither applies (run
+ * uaesk_ctr_xcrypt + uaesk_gcm_stream_absorb instead); the scratch must hold uaesk_gcm_scratch_bytes() */
 int uaesk_gcm_stream_piece(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek,
                            const uint8_t *nonce12, int decrypt, const void *in, size_t len,
-                           uint64_t done_bytes, void *out, void *scratch, unsigned *plan_state);
+                           uint64_t done_bytes, void *out, void *scratch, unsigned *plan_state, unsigned *done_word);
 int uaesk_gcm_stream_tag(void *stream, void *scratch, int compare, void *tag_io, int *status);
 
 /* POLYVAL of RFC 8452 (polyval, micro_aes.c:1421-1432) through the GHASH levels:

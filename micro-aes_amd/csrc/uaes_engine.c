@@ -3049,6 +3049,8 @@ struct uaes_gcm_stream {
 #define STREAM_SCRATCH_BYTES uaesk_gcm_scratch_bytes()
 static void *stream_tag_slot(uaes_gcm_stream *s) { return (char *)s->scratch + STREAM_SCRATCH_BYTES; }
 static int *stream_status_slot(uaes_gcm_stream *s) { return (int *)((char *)stream_tag_slot(s) + 16); }
+/* (a word that is zero between calls, for the one-launch pieces: cleared at begin, put back by their finisher) */
+static unsigned *stream_done_word(uaes_gcm_stream *s) { return (unsigned *)((char *)stream_tag_slot(s) + 32); }
 
 int uaes_gcm_stream_begin(uaes_gcm_stream **out, int keybits, const uint8_t *key, const uint8_t *nonce,
                           const void *aData, size_t aDataLen, int decrypt)
@@ -3077,6 +3079,7 @@ int uaes_gcm_stream_begin(uaes_gcm_stream **out, int keybits, const uint8_t *key
     /* every call on a stream object ends with the calling thread's lane drained, so the pieces may come
      * from different threads (one at a time): the next piece is ordered behind this one by the host  */
     do {
+        if (hipMemsetAsync(stream_tag_slot(s), 0, 64, (hipStream_t)L->stream) != hipSuccess) { rc = fail(UAES_E_HIP, "hipMemsetAsync failed"); break; }
         if ((rc = stage_aad(L, aData, aDataLen, &d_aad)) != 0) break;
         int k = uaesk_gcm_stream_absorb(L->stream, &c->tb, s->ks.nr, &s->ks.ek, s->nonce, 0, d_aad, aDataLen,
                                         0, 0, s->scratch, &s->plan_state);
@@ -3125,7 +3128,7 @@ static int gcm_stream_update_on_device(uaes_gcm_stream *s, const void *in, size_
         if ((rc = plan_io(L, in, len, outp, len, &io)) != 0) break;
         /* a long piece: CTR and GHASH in one pass over it (uaesk_gcm_stream_piece; 1 = not taken) */
         k = uaesk_gcm_stream_piece(L->stream, &c->tb, s->ks.nr, &s->ks.ek, s->nonce, s->decrypt, io.din, len, s->done, io.dout,
-                                   s->scratch, &s->plan_state);
+                                   s->scratch, &s->plan_state, stream_done_word(s));
         if (k == 0) { rc = finish_io(&io, len); break; }
         if (k != 1) { rc = fail(UAES_E_HIP, "gcm stream launch: %s", hipGetErrorString((hipError_t)k)); break; }
         if (s->decrypt) {                             /* hash the ciphertext before it may be overwritten */

@@ -1509,8 +1509,12 @@ struct GmcFin {
     unsigned *done_word;
     unsigned char *tag_io;
     int *status;
-    int mode;                                                 /* 0: write the tag, 1: compare it */
+    int mode;                                                 /* 0: write the tag, 1: compare it, 2: a piece of a streamed
+                                                               * message -- fold its raw hash into the running value */
     u32 ylog;
+    u32 fin_build;                                            /* mode 2: the finisher makes the tables of Y (the chunk
+                                                               * workgroups take theirs from the scratch: `build`) */
+    u64 m;                                                    /* mode 2: blocks of the piece */
     uaesk_done done;
 };
 
@@ -1527,8 +1531,8 @@ __global__ __launch_bounds__(GH_T) void k_gcm_chunks(uaesk_rk rk, uaesk_tables t
                                                      u32 steps, GmcFin fin)
 {
     if (FOLD && blockIdx.x == 0) {
-        gcm_combine_body<NR, true>(rk, tb, fin.j0, partial, gridDim.x - 1u, scratch, build, fin.mode, fin.tag_io, fin.status,
-                                   fin.ylog, nullptr, 0, fin.done_word);
+        gcm_combine_body<NR, true>(rk, tb, fin.j0, partial, gridDim.x - 1u, scratch, fin.mode == 2 ? fin.fin_build : build, fin.mode,
+                                   fin.tag_io, fin.status, fin.ylog, nullptr, fin.m, fin.done_word);
         ticket_release(fin.done);
         return;
     }
@@ -1549,7 +1553,7 @@ __global__ __launch_bounds__(GH_T) void k_gcm_chunks(uaesk_rk rk, uaesk_tables t
         gcm_build_nibble_tables(TC, buf, tb.frob);
     }
     const u64 len = src.ct_len;
-    const u64 ablk = (src.aad_len + 15) >> 4, cblk = (len + 15) >> 4, nv = ablk + cblk + 1;
+    const u64 ablk = (src.aad_len + 15) >> 4, cblk = (len + 15) >> 4, nv = ablk + cblk + (src.has_len ? 1u : 0u);
     const u64 chunk = (u64)steps * GH_T;                      /* positions per workgroup: one or two per thread */
     const u64 pad = chunk * nwg - nv;                   /* zero positions in front of the sequence */
     GSrc rest = src;                                          /* AAD blocks and the length block */
@@ -1633,7 +1637,7 @@ __device__ __forceinline__ void gcm_combine_body(const uaesk_rk &ek, const uaesk
     if (wave < 2) {                                           /* wave 0: H; wave 1: Enc(J0) */
         u32 s1[4] = { 0, 0, 0, 0 };
         if (wave) { s1[0] = j0.x; s1[1] = j0.y; s1[2] = j0.z; s1[3] = j0.w; }
-        if (wave || build) plain_encrypt<NR>(te_plain, ek, s1);
+        if ((wave && mode != 2) || (!wave && build)) plain_encrypt<NR>(te_plain, ek, s1);
         if ((threadIdx.x & 63u) == 0) buf[GT_BUF - 3 + wave] = make_uint4(s1[0], s1[1], s1[2], s1[3]);
     }
     if (!build) {                                             /* a key context holds the tables (k_gcm_ytables): waves 2..15
@@ -1661,6 +1665,30 @@ __device__ __forceinline__ void gcm_combine_body(const uaesk_rk &ek, const uaesk
         if (threadIdx.x >= GH_T - W) acc = partial[threadIdx.x - (GH_T - W)];
     }
     acc = gh_tree<false>(buf, TC, acc, W);
+    if (mode == 2) {
+        /* a streamed piece: Y <- Y * H^m ^ P (k_gcm_fold's arithmetic, wave 0; wipe_len carries m) */
+        if (threadIdx.x == 0) buf[GT_BUF - 1] = acc;
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            unsigned char *sc = (unsigned char *)scratch;
+            const uint4 y4 = *(const uint4 *)(sc + GS_RUN);
+            Gf run = gf_from_words(y4.x, y4.y, y4.z, y4.w);
+            const uint4 *pw = (const uint4 *)(sc + GS_POW64);
+            for (u32 k = 0; k < 64; ++k) {
+                if ((wipe_len >> k) & 1) {                    /* wave-uniform */
+                    const uint4 h = pw[k];
+                    run = wave_gfmul(run, gf_from_words(h.x, h.y, h.z, h.w), threadIdx.x);
+                }
+            }
+            if (threadIdx.x == 0) {
+                u32 w[4];
+                gf_to_words(run, w);
+                const uint4 p4 = buf[GT_BUF - 1];
+                *(uint4 *)(sc + GS_RUN) = make_uint4(w[0] ^ p4.x, w[1] ^ p4.y, w[2] ^ p4.z, w[3] ^ p4.w);
+            }
+        }
+        return;
+    }
     if (threadIdx.x == 0) {
         acc = x4(acc, ej0);
         const u32 w[4] = { acc.x, acc.y, acc.z, acc.w };
@@ -2597,9 +2625,31 @@ extern "C" int uaesk_gcm_stream_absorb(void *stream, const uaesk_tables *tb, int
  * work is enqueued, else a hipError_t.  done_bytes = text absorbed so far (a multiple of 16); a piece of a length
  * that is no multiple of 16 is the message's last.  The stream's scratch must hold uaesk_gcm_scratch_bytes().
  * plan_state bit 9: the striped kernel's tables of this key are in the scratch.                                 */
+template <int NR>
+static int launch_stream_chunks(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek, const uaesk_ctr *c, const GSrc &src,
+                                const void *in, void *out, unsigned char *sc, u32 W, u32 steps, int decrypt, const GmcFin &fin)
+{
+    hipError_t e;
+    uint4 *partial = (uint4 *)(sc + GS_ACC1);
+    if (decrypt) {
+        if ((e = uaesk_want_lds((const void *)k_gcm_chunks<NR, 2, true>, (unsigned)(GSM_LDS_TOTAL))) != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((k_gcm_chunks<NR, 2, true>), dim3(W + 1u), dim3(GH_T), GSM_LDS_TOTAL, st, *ek, *tb, *c, src,
+                           (const uint4 *)in, (uint4 *)out, (const unsigned char *)sc, partial, 0u, steps, fin);
+    } else {
+        if ((e = uaesk_want_lds((const void *)k_gcm_chunks<NR, 0, true>, (unsigned)(GSM_LDS_TOTAL))) != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((k_gcm_chunks<NR, 0, true>), dim3(W + 1u), dim3(GH_T), GSM_LDS_TOTAL, st, *ek, *tb, *c, src,
+                           (const uint4 *)in, (uint4 *)out, (const unsigned char *)sc, partial, 0u, steps, fin);
+    }
+    return (int)hipGetLastError();
+}
+
+/* ... and a piece of 16 KiB .. 8 MiB is ONE launch: the chunk workgroups of the medium-sized one-shot call (k_gcm_chunks,
+ * FOLD) with a finisher that folds the piece's raw hash into the running value (GmcFin.mode 2) -- needs done_word (a
+ * word that is zero between calls) and the key's nibble tables in the scratch (the stream's first absorb made them). */
 extern "C" int uaesk_gcm_stream_piece(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek,
                                       const uint8_t *nonce12, int decrypt, const void *in, size_t len,
-                                      uint64_t done_bytes, void *out, void *scratch, unsigned *plan_state)
+                                      uint64_t done_bytes, void *out, void *scratch, unsigned *plan_state,
+                                      unsigned *done_word)
 {
     hipStream_t st = S(stream);
     unsigned char *sc = (unsigned char *)scratch;
@@ -2628,8 +2678,24 @@ extern "C" int uaesk_gcm_stream_piece(void *stream, const uaesk_tables *tb, int 
     const u32 c0 = (u32)c.v0 & 0xffu;
     const u64 h0 = (256u - c0) & 255u, g_lo = c0 ? 1 : 0;
     const u64 groups = (c0 + nfull) / 256, n8 = groups > g_lo ? (groups - g_lo) / 8 : 0;
-    if (!(((u64)1 << logF) == Sl && logF <= GF_MAXLOG && n8 >= (u64)cus && h0 <= Sl && !ctr_stripes_cross_a(&c, g_lo, n8)))
-        return 1;
+    if (!(((u64)1 << logF) == Sl && logF <= GF_MAXLOG && n8 >= (u64)cus && h0 <= Sl && !ctr_stripes_cross_a(&c, g_lo, n8))) {
+        const u64 nvp = ((u64)len + 15) >> 4;
+        const u32 steps = (nvp + 1023) / 1024 + 1 <= (u64)cus ? 1u : 2u;
+        const u64 W = (nvp + 1024ull * steps - 1) / (1024ull * steps);
+        if (!(done_word && tb->frob && (*plan_state >> 31) && nvp >= 1024 && W + 1 <= (u64)cus)) return 1;
+        GSrc src;
+        memset(&src, 0, sizeof src);
+        src.ct = (const unsigned char *)in; src.ct_len = len;          /* the kernel reads the text itself */
+        GmcFin fin;
+        memset(&fin, 0, sizeof fin);
+        fin.done_word = done_word; fin.mode = 2; fin.ylog = steps == 2 ? 11u : 10u; fin.fin_build = 1; fin.m = nvp;
+        switch (nr) {
+        case 10: return launch_stream_chunks<10>(st, tb, ek, &c, src, in, out, sc, (u32)W, steps, decrypt, fin);
+        case 12: return launch_stream_chunks<12>(st, tb, ek, &c, src, in, out, sc, (u32)W, steps, decrypt, fin);
+        case 14: return launch_stream_chunks<14>(st, tb, ek, &c, src, in, out, sc, (u32)W, steps, decrypt, fin);
+        default: return (int)hipErrorInvalidValue;
+        }
+    }
     const u64 h1 = h0 + 2048 * n8;
     GSrc msg;
     memset(&msg, 0, sizeof msg);
