@@ -454,8 +454,22 @@ typedef struct lane {
     uint32_t    seq;                /* number of the last ticket issued                            */
     uint32_t    armed;              /* != 0: the call's only kernel carries this ticket itself     */
     int        *d_status;           /* device: status word, and a 16-byte result slot at +4 ints  */
+    /* The GCM key this thread used last on this device (lane_gcm_keyed): a caller of the drop-in API sends message
+     * after message under one key, and the reference redoes GCMsetup for each (micro_aes.c:1140-1152).  The eighth
+     * call in a row with the same key builds the key's whole table set in the lane's scratch once (what
+     * uaes_gcm_key_new does), the following ones run as calls on a key context: only Enc(J0) per message.         */
+    uint8_t     gk[32];
+    int         gk_bits;
+    int         gk_state;           /* 0 nothing, n < GK_BUILD_AT: calls in a row under this key, GK_TABLES: its tables are in `scratch` */
     struct lane *next;              /* context's list                                             */
 } lane;
+
+/* anything else that writes the lane's scratch (XTS chunk tweaks, OCB rows, GHASH under a foreign H ...) */
+static void lane_scratch_clobbered(lane *L)
+{
+    L->gk_state = 0;
+    memset(L->gk, 0, sizeof L->gk);
+}
 
 static __thread lane *tls_lane[MAX_DEVICES];
 static pthread_key_t   lane_key;
@@ -474,6 +488,7 @@ static void lane_free_resources(lane *L)
         (void)hipMemset(L->scratch, 0, L->scratch_cap);
         (void)hipFree(L->scratch);
     }
+    lane_scratch_clobbered(L);
     if (L->aad_stage) (void)hipFree(L->aad_stage);
     if (L->d_status) (void)hipFree(L->d_status);
     if (L->stream) (void)hipStreamDestroy((hipStream_t)L->stream);
@@ -557,8 +572,10 @@ static int lane_scratch(lane *L, size_t need)
     const size_t before = L->scratch_cap;
     int rc = grow_on(L->stream, &L->scratch, &L->scratch_cap, need + SCRATCH_TAIL);
     if (rc) return rc;
-    if (L->scratch_cap != before)
+    if (L->scratch_cap != before) {
+        lane_scratch_clobbered(L);
         HIPCHK(hipMemsetAsync(scratch_done_word(L->scratch, L->scratch_cap), 0, SCRATCH_TAIL, (hipStream_t)L->stream));
+    }
     return 0;
 }
 
@@ -580,7 +597,7 @@ static int env_int(const char *name, int dflt, int lo, int hi);
 /* every setting read from the environment, once per process and race-free (the lazily initialised
  * function-local statics were a benign but real data race between the first calls of two threads) */
 static struct {
-    int    ticket, pipe_workers;
+    int    ticket, pipe_workers, gcm_key_cache;
     size_t pin_bytes, zero_copy_max, pipe_slice;
 } g_env;
 static pthread_once_t g_env_once = PTHREAD_ONCE_INIT;
@@ -1068,6 +1085,7 @@ static int env_int(const char *name, int dflt, int lo, int hi)
 static void env_init(void)
 {
     g_env.ticket = env_int("UAES_TICKET", 1, 0, 1);
+    g_env.gcm_key_cache = env_int("UAES_GCM_KEY_CACHE", 1, 0, 1);
     g_env.pin_bytes = (size_t)env_int("UAES_PIN_KIB", 1024, 16, 65536) << 10;
     g_env.zero_copy_max = (size_t)env_int("UAES_ZEROCOPY_MAX_KIB", 1024, 0, (int)(g_env.pin_bytes >> 10)) << 10;
     g_env.pipe_workers = env_int("UAES_PIPE_WORKERS", 4, 1, PIPE_MAXW);
@@ -1578,6 +1596,7 @@ static int xts_common(int keybits, const uint8_t *keys, const uint8_t *tweak, in
         xts_pipe_arg pa;
         pa.c = c; pa.k1 = &k1; pa.k2 = &k2; pa.encrypt = encrypt; pa.first_sector = first_sector; pa.sector_bytes = sector_bytes;
         if (!raw_tweak && nsectors > 1 && run_pipelined(c, in, out, total, sector_bytes, 0, xts_pipe_launch, &pa, &rc)) return rc;
+        lane_scratch_clobbered(L);
         if ((rc = lane_scratch(L, uaesk_xts_scratch_bytes(sector_bytes, nsectors))) != 0) break;
         if ((rc = plan_io(L, in, total, out, total, &io)) != 0) break;
         ticket_arm(L);
@@ -1628,6 +1647,34 @@ int uaes_xts_sectors_dev(int keybits, const uint8_t *keys, uint64_t first_sector
 static int gcm_scratch(lane *L)                  /* synchronous API: the thread's own scratch */
 {
     return lane_scratch(L, uaesk_gcm_scratch_bytes());
+}
+
+/* 1: the tables of `key` are in the lane's scratch (this call may run as a call on a key context, uaesk_gcm_keyed),
+ * 0: they are not (the one-shot path), < 0: error.  Call with the scratch allocated (gcm_scratch).  A call on a key
+ * context is 2-4 us shorter than a one-shot call and the table set costs ~20 us once, so it is built when the EIGHTH
+ * call in a row comes under one key (a sequence that stops there has lost those 20 us, a longer one gains 10-15 %
+ * per call); UAES_GCM_KEY_CACHE=0 switches the cache off.                                                     */
+#define GK_BUILD_AT 8
+#define GK_TABLES   255
+static int lane_gcm_keyed(lane *L, const keysched *ks, const uint8_t *key, int keybits)
+{
+    const size_t kb = (size_t)keybits / 8;
+    if (!g_env.gcm_key_cache || !L->c->tb.frob) return 0;
+    if (L->gk_state && L->gk_bits == keybits && memcmp(L->gk, key, kb) == 0) {
+        if (L->gk_state == GK_TABLES) return 1;
+        if (++L->gk_state < GK_BUILD_AT) return 0;
+        {
+            int k = uaesk_gcm_key_tables(L->stream, &L->c->tb, ks->nr, &ks->ek, L->scratch);
+            if (k) return fail(UAES_E_HIP, "key table launch: %s", hipGetErrorString((hipError_t)k));
+            L->gk_state = GK_TABLES;
+        }
+        return 1;
+    }
+    memset(L->gk, 0, sizeof L->gk);
+    memcpy(L->gk, key, kb);
+    L->gk_bits = keybits;
+    L->gk_state = 1;
+    return 0;
 }
 
 /* the *_dev entry points do not hold the context lock while the GPU works (they only
@@ -1776,6 +1823,12 @@ int uaes_gcm_encrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, s
     if ((rc = enter(&c, &L)) != 0) return rc;
     do {
         if ((rc = gcm_scratch(L)) != 0) break;
+        /* (before anything of this call writes the scratch under its key.  A one-shot setup builds only the tables its
+         * message reaches and leaves the others undefined: with a nonce whose J0 is a GHASH of its own, which runs such
+         * a setup, the call stays one-shot and the cache starts over) */
+        int keyed = nonceLen == 12 ? lane_gcm_keyed(L, &ks, key, keybits) : 0;
+        if (keyed < 0) { rc = keyed; break; }
+        if (nonceLen != 12) lane_scratch_clobbered(L);
         if ((rc = gcm_j0(L, &ks, nonce, nonceLen, j0)) != 0) break;
         if ((rc = stage_aad(L, aData, aDataLen, &d_aad)) != 0) break;
         if ((rc = plan_io(L, pntxt, ptextLen, crtxt, ptextLen + tagLen, &io)) != 0) break;
@@ -1787,8 +1840,10 @@ int uaes_gcm_encrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, s
         }
         ticket_arm(L);
         uaesk_done_word_arm(scratch_done_word(L->scratch, L->scratch_cap));
-        int k = uaesk_gcm(L->stream, &c->tb, ks.nr, &ks.ek, 0, j0, d_aad, aDataLen,
-                          io.din, ptextLen, io.dout, L->scratch, NULL);
+        int k = keyed ? uaesk_gcm_keyed(L->stream, &c->tb, ks.nr, &ks.ek, 0, j0, d_aad, aDataLen,
+                                        io.din, ptextLen, io.dout, L->scratch, NULL)
+                      : uaesk_gcm(L->stream, &c->tb, ks.nr, &ks.ek, 0, j0, d_aad, aDataLen,
+                                  io.din, ptextLen, io.dout, L->scratch, NULL);
         uaesk_done_word_arm(NULL);
         ticket_armed_launch_done(L);
         if (k) { rc = fail(UAES_E_HIP, "gcm launch: %s", hipGetErrorString((hipError_t)k)); break; }
@@ -1839,6 +1894,12 @@ int uaes_gcm_decrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, s
     if ((rc = enter(&c, &L)) != 0) return rc;
     do {
         if ((rc = gcm_scratch(L)) != 0) break;
+        /* (before anything of this call writes the scratch under its key.  A one-shot setup builds only the tables its
+         * message reaches and leaves the others undefined: with a nonce whose J0 is a GHASH of its own, which runs such
+         * a setup, the call stays one-shot and the cache starts over) */
+        int keyed = nonceLen == 12 ? lane_gcm_keyed(L, &ks, key, keybits) : 0;
+        if (keyed < 0) { rc = keyed; break; }
+        if (nonceLen != 12) lane_scratch_clobbered(L);
         if ((rc = gcm_j0(L, &ks, nonce, nonceLen, j0)) != 0) break;
         if ((rc = stage_aad(L, aData, aDataLen, &d_aad)) != 0) break;
         /* input is CT || tag; output is crtxtLen bytes */
@@ -1848,8 +1909,10 @@ int uaes_gcm_decrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, s
              * ciphertext (nothing is decrypted), its first tagLen bytes are checked against the ones behind the
              * text in constant time, and only then does the CTR pass write the caller's buffer (N7)          */
             uint8_t full[16], given[16];
-            int k = uaesk_gcm(L->stream, &c->tb, ks.nr, &ks.ek, 3, j0, d_aad, aDataLen,
-                              io.din, crtxtLen, NULL, L->scratch, L->d_status + 4);
+            int k = keyed ? uaesk_gcm_keyed(L->stream, &c->tb, ks.nr, &ks.ek, 3, j0, d_aad, aDataLen,
+                                            io.din, crtxtLen, NULL, L->scratch, L->d_status + 4)
+                          : uaesk_gcm(L->stream, &c->tb, ks.nr, &ks.ek, 3, j0, d_aad, aDataLen,
+                                      io.din, crtxtLen, NULL, L->scratch, L->d_status + 4);
             if (k) { rc = fail(UAES_E_HIP, "gcm launch: %s", hipGetErrorString((hipError_t)k)); break; }
             if ((rc = lane_fetch(L, full, L->d_status + 4, 16)) != 0) break;
             if (is_device_ptr(io.din)) {
@@ -1877,8 +1940,11 @@ int uaes_gcm_decrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, s
         if (st_where != L->d_status) { *(volatile int *)st_where = -1; ticket_arm(L); }   /* host-visible status: a
                                                      * one-launch decryption may carry the completion ticket itself */
         uaesk_done_word_arm(scratch_done_word(L->scratch, L->scratch_cap));
-        int k = uaesk_gcm(L->stream, &c->tb, ks.nr, &ks.ek, io.copy_back || io.dout == L->pin[1] ? 2 : gcm_decrypt_mode(),
-                          j0, d_aad, aDataLen, io.din, crtxtLen, io.dout, L->scratch, st_where);
+        const int dmode = io.copy_back || io.dout == L->pin[1] ? 2 : gcm_decrypt_mode();
+        int k = keyed ? uaesk_gcm_keyed(L->stream, &c->tb, ks.nr, &ks.ek, dmode, j0, d_aad, aDataLen, io.din, crtxtLen, io.dout,
+                                        L->scratch, st_where)
+                      : uaesk_gcm(L->stream, &c->tb, ks.nr, &ks.ek, dmode, j0, d_aad, aDataLen, io.din, crtxtLen, io.dout,
+                                  L->scratch, st_where);
         uaesk_done_word_arm(NULL);
         ticket_armed_launch_done(L);
         if (k) { rc = fail(UAES_E_HIP, "gcm launch: %s", hipGetErrorString((hipError_t)k)); break; }
@@ -2433,6 +2499,7 @@ int uaes_ghash(const uint8_t H[16], const void *aData, size_t aDataLen,
     if (!H || !gh) return fail(UAES_E_ARG, "NULL pointer");
     if ((rc = enter(&c, &L)) != 0) return rc;
     do {
+        lane_scratch_clobbered(L);
         if ((rc = gcm_scratch(L)) != 0) break;
         if ((rc = stage_aad(L, aData, aDataLen, &d_aad)) != 0) break;
         if ((rc = plan_io(L, crtxt, crtxtLen, NULL, 0, &io)) != 0) break;
@@ -2792,6 +2859,7 @@ static int gcmsiv_tag(lane *L, const sivkeys *k, const uint8_t *nonce,
     uint8_t s[16];
     int i, rc;
     uint8_t *slot = (uint8_t *)(L->d_status + 4);
+    lane_scratch_clobbered(L);
     KCHK(uaesk_polyval(st, &c->tb, k->hg, d_aad, aad_len, d_pt, len, L->scratch, slot));
     if ((rc = lane_fetch(L, s, slot, 16)) != 0) return rc;
     rev16_bytes(s);
@@ -2840,6 +2908,7 @@ int uaes_gcmsiv_encrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
     }
     if ((rc = enter(&c, &L)) != 0) return rc;
     do {
+        lane_scratch_clobbered(L);
         if ((rc = gcm_scratch(L)) != 0) break;
         if ((rc = stage_aad(L, aData, aDataLen, &d_aad)) != 0) break;
         if ((rc = plan_io(L, pntxt, ptextLen, crtxt, ptextLen + 16, &io)) != 0) break;
@@ -2898,6 +2967,7 @@ int uaes_gcmsiv_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
     }
     if ((rc = enter(&c, &L)) != 0) return rc;
     do {
+        lane_scratch_clobbered(L);
         if ((rc = gcm_scratch(L)) != 0) break;
         if ((rc = stage_aad(L, aData, aDataLen, &d_aad)) != 0) break;
         if ((rc = plan_io(L, crtxt, crtxtLen + 16, pntxt, crtxtLen, &io)) != 0) break;
@@ -2962,6 +3032,7 @@ static int ocb_common(int keybits, const uint8_t *key, const uint8_t *nonce, siz
     }
     if ((rc = enter(&c, &L)) != 0) return rc;
     do {
+        lane_scratch_clobbered(L);
         if ((rc = gcm_scratch(L)) != 0) break;        /* >= uaesk_ocb_scratch_bytes() */
         if ((rc = stage_aad(L, aData, aDataLen, &d_aad)) != 0) break;
         if ((rc = plan_io(L, in, len + (decrypt ? tagLen : 0), out, len + (decrypt ? 0 : tagLen), &io)) != 0) break;
@@ -3520,6 +3591,7 @@ static int gcm_shard_sync(int keybits, const uint8_t *key, const uint8_t *nonce,
     if ((rc = enter(&c, &L)) != 0) return rc;
     do {
         int k;
+        lane_scratch_clobbered(L);
         if ((rc = gcm_scratch(L)) != 0) break;
         if (off == 0 && (rc = stage_aad(L, aData, (size_t)aDataLen, &d_aad)) != 0) break;
         if ((rc = plan_io(L, in, len, mode == 1 ? NULL : out, mode == 1 ? 0 : len, &io)) != 0) break;

@@ -466,6 +466,44 @@ def test_gcm_medium_texts_one_launch(orc):
         assert int(status.item()) == 0 and bytes(back.cpu().numpy()) == data
 
 
+def test_gcm_lane_key_cache(orc):
+    """A thread that sends message after message under ONE key through the drop-in calls gets that key's table set
+    built in its lane's scratch at the eighth call in a row and runs as on a key context from then on
+    (lane_gcm_keyed).  Whatever else writes the scratch in between -- XTS chunk tweaks, OCB rows, GHASH under another
+    H, a GCM call under another key, J0 = GHASH(nonce) of another key, the truncated-tag order -- must end that:
+    every result against the oracle, sizes of all three GCM arrangements, before and after each disturbance."""
+    rnd = random.Random(20260930)
+    ka, kb = rnd.randbytes(16), rnd.randbytes(32)
+    sizes = [0, 16, 100, 4096, 70000, (1 << 20) + 3, (9 << 20) + 16]
+
+    def check(key, n, nonce_len=12, tag_len=16, alen=5):
+        nonce, aad, data = rnd.randbytes(nonce_len), rnd.randbytes(alen), orc.splitmix(n + nonce_len, n)
+        want = orc.gcm_encrypt(key, nonce, aad, data, tag_len)
+        assert uaes.AES_GCM_encrypt(key, nonce, aad, data, tag_len=tag_len) == want, (n, nonce_len, tag_len)
+        assert uaes.AES_GCM_decrypt(key, nonce, aad, want, tag_len=tag_len) == (0, data), (n, nonce_len, tag_len)
+        bad = bytearray(want)
+        bad[-1] ^= 2
+        assert uaes.AES_GCM_decrypt(key, nonce, aad, bytes(bad), tag_len=tag_len)[0] == 0x1A
+
+    for i in range(14):                                       # 28 calls in a row under ka: the tables come at the eighth
+        check(ka, sizes[i % len(sizes)])
+    disturbances = [
+        lambda: uaes.xts_sectors(bytes(range(32)), 7, 512, orc.splitmix(1, 512 * 40), True),
+        lambda: uaes.AES_OCB_encrypt(kb[:16], bytes(12), b"", orc.splitmix(2, 70000)),
+        lambda: uaes.ghash(rnd.randbytes(16), b"aad", orc.splitmix(3, 50000)),
+        lambda: check(kb, 70000),                             # another key, once
+        lambda: check(kb, 100, nonce_len=8),                  # ... whose J0 is a GHASH on the lane's scratch
+        lambda: check(kb, 4096, tag_len=12),                  # ... the truncated-tag order (tag first, then CTR)
+        lambda: uaes.GCM_SIV_encrypt(ka, bytes(12), b"", orc.splitmix(4, 30000)),
+    ]
+    for d in disturbances:
+        d()
+        for i in range(10):
+            check(ka, sizes[(i + 3) % len(sizes)])
+    for i in range(10):                                       # other nonce and tag lengths on the cached key
+        check(ka, sizes[i % len(sizes)], nonce_len=rnd.choice([1, 8, 13, 60]), tag_len=rnd.choice([4, 12, 16]))
+
+
 def test_main_c_kats(golden_dir):
     for k in load(golden_dir, "main_kats.json"):
         key, pt, exp = bytes.fromhex(k["key"]), bytes.fromhex(k["pt"]), bytes.fromhex(k["expect"])
