@@ -1497,11 +1497,14 @@ extern "C" int uaesk_gcm_records(void *stream, const uaesk_tables *tb, int nr, c
  * MODE 0: encrypt; 1: hash the ciphertext only (decrypt, tag first: N7); 2: decrypt while hashing (one pass).  */
 #define GMC_MAXW 1024u          /* the combine kernel folds up to 1024 partial hashes: 32 MiB */
 
-/* FOLD (round 5): ONE launch -- workgroup 0 is the FINISHER (gcm_combine_body: Enc(J0), the tables of Y, then it waits
- * for the others on *done_word, folds their hashes and makes the tag), workgroups 1..W hash the chunks.  The finisher's
+/* FOLD (round 5): ONE launch -- the LAST workgroup is the FINISHER (gcm_combine_body: Enc(J0), the tables of Y, then it
+ * waits for the others on *done_word, folds their hashes and makes the tag), workgroups 0..W-1 hash the chunks.  (Last,
+ * not first: workgroups are dispatched in the order of their numbers, so when the finisher runs every chunk workgroup
+ * has its place on the chip already -- a finisher that came first could sit on the only free slot of a crowded or
+ * partitioned device while the ones it waits for cannot start.  On an idle device all W + 1 start together.)  The finisher's
  * preparations (6-7 us of a one-shot call) run beside the chunk work instead of behind it, and the launch of a second
- * kernel goes: 64 KiB 21.8 -> 18.9 us per call, 1 MiB 23.5 -> 21.1, with a key context 17.0 -> 15.3.  Nobody waits for the finisher, so it cannot block progress; it is
- * dispatched first and sleeps between looks at the counter.  A chunk's hash goes out as four device-scope atomic
+ * kernel goes: 64 KiB 21.8 -> 18.9 us per call, 1 MiB 23.5 -> 21.1, with a key context 17.0 -> 15.3.  Nobody waits for the finisher, so it cannot block progress; it
+ * sleeps between looks at the counter.  A chunk's hash goes out as four device-scope atomic
  * exchanges whose results are back before the workgroup counts itself in (uaes_ocb.hip explains why not a release
  * fence); the last look resets the counter for the next call (a word that is zero between calls, uaes_device.h).   */
 struct GmcFin {
@@ -1530,13 +1533,13 @@ __global__ __launch_bounds__(GH_T) void k_gcm_chunks(uaesk_rk rk, uaesk_tables t
                                                      const unsigned char *__restrict__ scratch, uint4 *partial, u32 build,
                                                      u32 steps, GmcFin fin)
 {
-    if (FOLD && blockIdx.x == 0) {
+    if (FOLD && blockIdx.x == gridDim.x - 1u) {
         gcm_combine_body<NR, true>(rk, tb, fin.j0, partial, gridDim.x - 1u, scratch, fin.mode == 2 ? fin.fin_build : build, fin.mode,
                                    fin.tag_io, fin.status, fin.ylog, nullptr, fin.m, fin.done_word);
         ticket_release(fin.done);
         return;
     }
-    const u32 wg = FOLD ? blockIdx.x - 1u : blockIdx.x, nwg = FOLD ? gridDim.x - 1u : gridDim.x;
+    const u32 wg = blockIdx.x, nwg = FOLD ? gridDim.x - 1u : gridDim.x;
     uint4 *TC = (uint4 *)(uaes_lds + GSM_LDS_TAB);
     uint4 *buf = TC + GT_NTAB * 512u;
     if (!build) {
