@@ -25,6 +25,7 @@
  */
 #include <hip/hip_runtime.h>
 #include <string.h>
+#include <type_traits>
 #include "uaes_aes.hip.h"
 #include "uaes_device.h"
 
@@ -224,46 +225,26 @@ __device__ __forceinline__ void ocb_main_body(const uaesk_rk &rk, const LaneCons
     const B16 off0 = HASH ? zero16 : uniform(b16(*(const uint4 *)(uaes_lds + OCB_LDS_OFF0)));
     const B16 l5 = uniform(lds_row(2u + 5u)), l6 = uniform(lds_row(2u + 6u)), l7 = uniform(lds_row(2u + 7u));
 
-    /* run is a power of two: shifts and masks, not the 64-bit divisions `k / run`, `k % run` compile to */
-    const u32 lrun = (u32)__builtin_ctz(run), mrun = run - 1u;
-    auto chunk_of = [&](u64 k) { return ((((k >> lrun) * nwaves + wave) << lrun)) + (k & mrun); };
-    /* live positions inside chunk c: [lo, hi] (index 0 does not exist, indices end at nblocks) */
-    auto span = [&](u64 c, u32 &lo, u32 &hi) {
-        lo = c == 0 ? 1u : 0u;
-        const u64 left = nblocks - c * OCB_CHUNK;
-        hi = left < OCB_CHUNK - 1 ? (u32)left : OCB_CHUNK - 1;
-    };
-
-    uint4 dn[UAES_U];
-    auto fetch = [&](u64 c) {
-        u32 lo, hi;
-        span(c, lo, hi);
-        const unsigned char *base = (const unsigned char *)in + c * (OCB_CHUNK * 16u) - 16;
-#pragma unroll
-        for (int u = 0; u < UAES_U; ++u) {
-            u32 j = 64u * u + lane;
-            j = j < lo ? lo : (j > hi ? hi : j);              /* clamped: no branch before the load */
-            dn[u] = *(const uint4 *)(base + 16u * j);
-        }
-    };
-
     u32 sum[4] = { 0, 0, 0, 0 };
-    B16 cm = off0;                                    /* chunk mask */
-    u64 k = 0, c = chunk_of(0);
-    if (c < nchunks) fetch(c);
-    while (c < nchunks) {
-        if ((k & mrun) == 0) {                        /* first chunk of a run */
-            cm = off0;
-            bx(cm, ocb_gray_sum(c ^ (c >> 1), 8));
-            if (c & 1) bx(cm, l7);
-            cm = uniform(cm);
-        }
-        uint4 d[UAES_U];
-#pragma unroll
-        for (int u = 0; u < UAES_U; ++u) d[u] = dn[u];
-        const u64 cn = chunk_of(k + 1);
-        if (cn < nchunks) fetch(cn);
-
+    /* the chunk mask of chunk c from scratch: the set bits of gray(c) from bit 8 on, and L_7 for bit 0 of c */
+    auto chunk_mask = [&](u64 c) {
+        B16 m = off0;
+        bx(m, ocb_gray_sum(c ^ (c >> 1), 8));
+        if (c & 1) bx(m, l7);
+        return uniform(m);
+    };
+    /* one chunk, text in d[]: whiten, encrypt, whiten, store, checksum.  FULL: all 256 positions exist (every chunk
+     * but the first, whose index 0 does not, and the last) -- no masks on the checksum, no exec-masked stores */
+    auto chunk = [&](auto FULLT, u64 c, const B16 &cm, const uint4 (&d)[UAES_U]) {
+        constexpr bool FULL = decltype(FULLT)::value;
+        const u32 lo = c == 0 ? 1u : 0u;
+        const u64 left = nblocks - c * OCB_CHUNK;
+        const u32 hi = left < OCB_CHUNK - 1 ? (u32)left : OCB_CHUNK - 1;
+        auto live = [&](int u) -> u32 {
+            if (FULL) return 0xffffffffu;
+            const u32 j = 64u * u + lane;
+            return (j >= lo && j <= hi) ? 0xffffffffu : 0u;
+        };
         B16 um[UAES_U];                               /* uniform masks: chunk ^ u part */
 #pragma unroll
         for (int u = 0; u < UAES_U; ++u) {
@@ -272,12 +253,6 @@ __device__ __forceinline__ void ocb_main_body(const uaesk_rk &rk, const LaneCons
             if ((u ^ (u >> 1)) & 1) bx(um[u], l6);
             if (u >> 1) bx(um[u], l7);
         }
-        u32 lo, hi;
-        span(c, lo, hi);
-        auto live = [&](int u) -> u32 {
-            const u32 j = 64u * u + lane;
-            return (j >= lo && j <= hi) ? 0xffffffffu : 0u;
-        };
         u32 s[UAES_U][4];
 #pragma unroll
         for (int u = 0; u < UAES_U; ++u) {
@@ -310,14 +285,67 @@ __device__ __forceinline__ void ocb_main_body(const uaesk_rk &rk, const LaneCons
 #pragma unroll
                 for (int q = 0; q < 4; ++q) sum[q] ^= s[u][q] & lv;
             }
-            if (lv) *(uint4 *)(obase + 16u * (64u * u + lane)) = make_uint4(s[u][0], s[u][1], s[u][2], s[u][3]);
+            if (FULL || lv) *(uint4 *)(obase + 16u * (64u * u + lane)) = make_uint4(s[u][0], s[u][1], s[u][2], s[u][3]);
         }
-        /* next chunk of the run: bit 0 of c flips (L_7), gray(c) gains or loses bit ntz(c+1) */
-        ++k;
-        bx(cm, l7);
-        bx(cm, lds_row(2u + 8u + (u32)__builtin_ctzll(c + 1)));
-        cm = uniform(cm);
-        c = cn;
+    };
+
+    /* The first chunk (index 0 does not exist) and the last (it ends where the text ends) are the only ones that need
+     * masks: they go LAST, to the two waves that are next in the round-robin of the runs, with clamped loads of their
+     * own; the loop runs over whole chunks only -- in one expansion with the masks it was 3 % slower, as a second
+     * expansion inside the loop it did not fit 128 registers, and neither did the edge chunks in front of the loop with
+     * the loop's first text already requested.                                                                      */
+    const u64 nfull = nchunks > 2 ? nchunks - 2 : 0;  /* whole chunks: 1 .. nchunks - 2 */
+    /* run is a power of two: shifts and masks, not the 64-bit divisions `k / run`, `k % run` compile to */
+    const u32 lrun = (u32)__builtin_ctz(run), mrun = run - 1u;
+    auto chunk_of = [&](u64 k) { return ((((k >> lrun) * nwaves + wave) << lrun)) + (k & mrun); };
+    uint4 dn[UAES_U];
+    auto fetch = [&](u64 f) {
+        const unsigned char *base = (const unsigned char *)in + (f + 1) * (OCB_CHUNK * 16u) - 16;
+#pragma unroll
+        for (int u = 0; u < UAES_U; ++u) dn[u] = *(const uint4 *)(base + 16u * (64u * u + lane));
+    };
+    u64 k = 0, f = chunk_of(0);                       /* f counts the whole chunks: chunk c = f + 1 */
+    if (f < nfull) fetch(f);
+    {
+        B16 cm = off0;                                /* chunk mask */
+        while (f < nfull) {
+            const u64 c = f + 1;
+            if ((k & mrun) == 0) cm = chunk_mask(c);  /* first chunk of a run */
+            uint4 d[UAES_U];
+#pragma unroll
+            for (int u = 0; u < UAES_U; ++u) d[u] = dn[u];
+            const u64 fn = chunk_of(k + 1);
+            if (fn < nfull) fetch(fn);
+            chunk(std::true_type{}, c, cm, d);
+            /* next chunk of the run: bit 0 of c flips (L_7), gray(c) gains or loses bit ntz(c+1) */
+            ++k;
+            bx(cm, l7);
+            bx(cm, lds_row(2u + 8u + (u32)__builtin_ctzll(c + 1)));
+            cm = uniform(cm);
+            f = fn;
+        }
+    }
+    {
+        const u64 runs = (nfull + mrun) >> lrun;
+        const u64 e0 = runs % nwaves, e1 = (runs + 1) % nwaves;          /* owners of the first / the last chunk */
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {
+            if (pass == 1 && nchunks < 2) break;
+            if (wave != (pass ? e1 : e0)) continue;
+            const u64 ce = pass ? nchunks - 1 : 0;
+            const u32 lo = ce == 0 ? 1u : 0u;
+            const u64 left = nblocks - ce * OCB_CHUNK;
+            const u32 hi = left < OCB_CHUNK - 1 ? (u32)left : OCB_CHUNK - 1;
+            const unsigned char *base = (const unsigned char *)in + ce * (OCB_CHUNK * 16u) - 16;
+            uint4 d[UAES_U];
+#pragma unroll
+            for (int u = 0; u < UAES_U; ++u) {
+                u32 j = 64u * u + lane;
+                j = j < lo ? lo : (j > hi ? hi : j);          /* clamped: no branch before the load */
+                d[u] = *(const uint4 *)(base + 16u * j);
+            }
+            chunk(std::false_type{}, ce, chunk_mask(ce), d);
+        }
     }
     wave_xor_reduce(sum);
     if (lane == 0) {
