@@ -360,7 +360,9 @@ __device__ __forceinline__ void store16(unsigned char *p, uint4 v)
  * registers and takes one out with v_readlane per trip.  Between 4 and 64 MiB a call was bound by the HOST's two
  * launches (8 and 16 MiB: 26 us per enqueued call either way), not by the GPU.  Used while a wave has at most eight
  * chunks (128 MiB on 256 CUs); beyond that the pre-pass is the cheaper way to the tweaks.                    */
-template <int NR, bool DEC, bool ALIGNED, bool PACKED, bool FOLD>
+/* ALLFULL: the host knows that every chunk has all 256 blocks (units of a multiple of 4 KiB, the C3 shape): no block
+ * count per chunk, no exec-masked stores */
+template <int NR, bool DEC, bool ALIGNED, bool PACKED, bool FOLD, bool ALLFULL = false>
 __device__ __forceinline__ void xts_body(const uaesk_rk &k1, const uaesk_tables &tb,
                                          const uint4 *__restrict__ chunk_tw,
                                          u64 nsectors, u64 chunks_per_sector,
@@ -425,7 +427,7 @@ __device__ __forceinline__ void xts_body(const uaesk_rk &k1, const uaesk_tables 
         sctn += step_q; withn += step_r;             /* the next chunk of this wave */
         if (withn >= chunks_per_sector) { withn -= chunks_per_sector; ++sctn; }
         const u64 left = main_blocks - first;
-        f.cnt = left < XTS_CHUNK ? (u32)left : XTS_CHUNK;
+        f.cnt = ALLFULL ? XTS_CHUNK : (left < XTS_CHUNK ? (u32)left : XTS_CHUNK);
         f.off = PACKED ? first * 16 : sct * sector_bytes + first * 16;
         if (PACKED) { f.rb = rb; f.sb = sct; }                   /* the lane's unit tweak follows later (fetch_tw) */
         else if (!FOLD) f.tb = chunk_tw[ch];
@@ -513,7 +515,7 @@ __device__ __forceinline__ void xts_body(const uaesk_rk &k1, const uaesk_tables 
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const u32 j = PACKED ? 4u * lane + (u32)(pr + u) : lane + 64u * (pr + u);
-                if (j < cur.cnt)
+                if (ALLFULL || j < cur.cnt)
                     store16<ALIGNED>(dst + 16u * j, make_uint4(s[u][0] ^ tw[u][0], s[u][1] ^ tw[u][1],
                                                                s[u][2] ^ tw[u][2], s[u][3] ^ tw[u][3]));
             }
@@ -568,15 +570,15 @@ __device__ __forceinline__ void xts_body(const uaesk_rk &k1, const uaesk_tables 
     }
 }
 
-template <int NR, bool DEC, bool ALIGNED, bool PACKED = false>
+template <int NR, bool DEC, bool ALIGNED, bool PACKED = false, bool ALLFULL = false>
 __global__ __launch_bounds__(UAES_WG) void k_xts(uaesk_rk k1, uaesk_tables tb,
                                                  const uint4 *__restrict__ chunk_tw,
                                                  u64 nsectors, u64 chunks_per_sector, u64 main_blocks, u64 sector_bytes,
                                                  u64 step_q, u64 step_r, const unsigned char *in, unsigned char *out,
                                                  u64 nmain, u32 magic)
 {
-    xts_body<NR, DEC, ALIGNED, PACKED, false>(k1, tb, chunk_tw, nsectors, chunks_per_sector, main_blocks, sector_bytes,
-                                              step_q, step_r, in, out, nmain, magic, nullptr, 0);
+    xts_body<NR, DEC, ALIGNED, PACKED, false, ALLFULL>(k1, tb, chunk_tw, nsectors, chunks_per_sector, main_blocks, sector_bytes,
+                                                       step_q, step_r, in, out, nmain, magic, nullptr, 0);
 }
 
 struct XtsFoldArgs {
@@ -587,13 +589,13 @@ struct XtsFoldArgs {
     unsigned char *out;
 };
 
-template <int NR, bool DEC>
+template <int NR, bool DEC, bool ALLFULL>
 __global__ __launch_bounds__(UAES_WG) void k_xts_fold(XtsFoldArgs)
 {
     const XtsFoldArgs *const a = (const XtsFoldArgs *)__builtin_amdgcn_kernarg_segment_ptr();
     const uaesk_rk k1 = a->k1;
     const uaesk_tables tb = a->tb;
-    xts_body<NR, DEC, true, false, true>(k1, tb, nullptr, a->nsectors, 1, a->main_blocks, a->sector_bytes, a->step_q, a->step_r,
+    xts_body<NR, DEC, true, false, true, ALLFULL>(k1, tb, nullptr, a->nsectors, 1, a->main_blocks, a->sector_bytes, a->step_q, a->step_r,
                                          a->in, a->out, a->nmain, 0u, &a->k2, a->first_sector);
 }
 
@@ -1104,7 +1106,8 @@ static int launch_xts(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *k1
     /* a chunk per unit, one chunk per unit, whole blocks (4 KiB sectors): the bulk kernel makes its tweaks itself */
     if (!tweak16 && r == 0 && cps == 1 && mb >= 4 && !(mb < XTS_CHUNK && mb % 4 == 0) && nsectors > 1 &&
         (u64)nsectors <= 8ull * grid_for(~0ull, 1) * (UAES_WG / 64)) {          /* ... up to eight chunks per wave: 128 MiB */
-        if ((e = set_lds((k_xts_fold<NR, DEC>), lds + 1024u)) != hipSuccess) return (int)e;
+        if ((e = set_lds((k_xts_fold<NR, DEC, true>), lds + 1024u)) != hipSuccess) return (int)e;
+        if ((e = set_lds((k_xts_fold<NR, DEC, false>), lds + 1024u)) != hipSuccess) return (int)e;
         const u64 nchunks = (u64)nsectors;
         const unsigned wg = grid_for(nchunks, UAES_WG / 64) * 2 <= grid_for(~0ull, 1) ? 256u : UAES_WG;
         const unsigned xgrid = grid_for(nchunks, wg / 64);
@@ -1116,7 +1119,8 @@ static int launch_xts(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *k1
         ka.step_q = nwaves; ka.step_r = 0; ka.first_sector = first_sector;
         ka.nmain = (rounds && left && left * 100 < nwaves * (u64)pct) ? rounds * nwaves : nchunks;
         ka.in = (const unsigned char *)in; ka.out = (unsigned char *)out;
-        hipLaunchKernelGGL((k_xts_fold<NR, DEC>), dim3(xgrid), dim3(wg), lds + 1024u, st, ka);
+        if (mb == XTS_CHUNK) hipLaunchKernelGGL((k_xts_fold<NR, DEC, true>), dim3(xgrid), dim3(wg), lds + 1024u, st, ka);
+        else hipLaunchKernelGGL((k_xts_fold<NR, DEC, false>), dim3(xgrid), dim3(wg), lds + 1024u, st, ka);
         return (int)hipGetLastError();
     }
     const bool serial = cps <= XTS_SERIAL_CPS;
@@ -1158,7 +1162,12 @@ static int launch_xts(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *k1
         static const int pct = env_int_clamped("UAES_XTS_TAIL_PCT", 80, 0, 100);
         const u64 rounds = nchunks / nwaves, left = nchunks % nwaves;
         const u64 nmain = (rounds && left && left * 100 < nwaves * (u64)pct) ? rounds * nwaves : nchunks;
-        if (sector_bytes % 16 == 0 || nsectors == 1)
+        if ((sector_bytes % 16 == 0 || nsectors == 1) && mb % XTS_CHUNK == 0) {        /* every chunk whole: k_xts<.., ALLFULL> */
+            if ((e = set_lds((k_xts<NR, DEC, true, false, true>), lds)) != hipSuccess) return (int)e;
+            hipLaunchKernelGGL((k_xts<NR, DEC, true, false, true>), dim3(xgrid), dim3(wg), lds, st,
+                               *k1, *tb, (const uint4 *)scratch, (u64)nsectors, cps, mb, (u64)sector_bytes, step_q, step_r,
+                               (const unsigned char *)in, (unsigned char *)out, nmain, 0u);
+        } else if (sector_bytes % 16 == 0 || nsectors == 1)
             hipLaunchKernelGGL((k_xts<NR, DEC, true>), dim3(xgrid), dim3(wg), lds, st,
                                *k1, *tb, (const uint4 *)scratch, (u64)nsectors, cps, mb, (u64)sector_bytes, step_q, step_r,
                                (const unsigned char *)in, (unsigned char *)out, nmain, 0u);
