@@ -64,5 +64,6 @@ for bits, key in ((128, key16), (256, key32)):
         rate("cmac (1 MiB: serial)", lambda: L.uaes_cmac(bits, key, a, small, mac), small, reps=2)
         rate("cbc enc (1 MiB: serial)", lambda: L.uaes_cbc_encrypt(bits, key, iv16, a, small, b), small, reps=2)
         rate("ofb (1 MiB: serial)", lambda: L.uaes_ofb_xcrypt(bits, key, iv16, a, small, b), small, reps=2)
-        rate("cbc enc batch 4096 x 64 KiB", lambda: L.uaes_cbc_encrypt_batch(bits, key, ad, 4096, 65536, a, b), 4096 * 65536)
-        rate("cmac batch 4096 x 64 KiB", lambda: L.uaes_cmac_batch(bits, key, 4096, 65536, a, b), 4096 * 65536)
+        nb = max(1, n // 65536)                              # (messages of 64 KiB: as many as the buffers hold)
+        rate("cbc enc batch %d x 64 KiB" % nb, lambda: L.uaes_cbc_encrypt_batch(bits, key, ad, nb, 65536, a, b), nb * 65536)
+        rate("cmac batch %d x 64 KiB" % nb, lambda: L.uaes_cmac_batch(bits, key, nb, 65536, a, b), nb * 65536)
