@@ -354,6 +354,24 @@ __device__ __forceinline__ void store16(unsigned char *p, uint4 v)
  * four accesses of a chunk use all of it); the memory path has room for that in a kernel that needs 16 + 16 bytes
  * every eight cycles per CU.  Arguments then: chunks_per_sector = blocks per unit, main_blocks = blocks of the whole
  * text, (step_q, step_r) = (256 * waves) / and % blocks per unit, magic = ceil(2^24 / blocks per unit).           */
+/* k_xts_fold's first wave: the tweaks of the chunks of all wpw waves of the workgroup, eight per wave, into LDS rows
+ * (chunk = wave number + trip * waves of the grid; the unit's number is the chunk's: copyLint, micro_aes.c:399-404,
+ * then Enc_key2, :1026-1027).  Out of line: inlined, its registers are added to the block loop's (14 spilled). */
+template <int NR>
+__device__ __attribute__((noinline)) void xts_fold_tweaks(const u32 *te_plain, uint4 *tw_rows, const uaesk_rk *k2p,
+                                                          u64 first_sector, u64 nsectors, u32 wpw)
+{
+    const u32 lane = threadIdx.x & 63u;
+    const u64 nw = (u64)gridDim.x * wpw;
+    for (u32 idx = lane; idx < 8u * wpw; idx += 64u) {
+        const u64 ch = (u64)blockIdx.x * wpw + (idx >> 3) + (u64)(idx & 7u) * nw;
+        const u64 id = first_sector + (ch < nsectors ? ch : 0);
+        u32 t[4] = { (u32)id, (u32)(id >> 32), 0, 0 };
+        plain_encrypt<NR>(te_plain, *k2p, t);
+        tw_rows[idx] = make_uint4(t[0], t[1], t[2], t[3]);
+    }
+}
+
 /* FOLD (round 5, second half): a chunk per unit and ONE chunk per unit (4 KiB sectors) -- no pre-pass launch: a wave
  * encrypts the tweaks of its next 64 chunks itself, one per lane (plain_encrypt through a 1 KiB copy of Te0 behind the
  * cipher tables, key 2 read through the kernel-argument pointer where it is used), keeps them in four vector
@@ -374,10 +392,26 @@ __device__ __forceinline__ void xts_body(const uaesk_rk &k1, const uaesk_tables 
                                          u64 nmain,            /* chunks [nmain, all) go by quarters (== all: none) */
                                          u32 magic, const uaesk_rk *k2p, u64 first_sector)
 {
-    if (FOLD && threadIdx.x < 256u) ((u32 *)(uaes_lds + UAES_LDS_ENC))[threadIdx.x] = tb.te0[threadIdx.x];
-    if (DEC) fill_dec_tables(tb.td0); else fill_enc_tables(tb.te0);
-    const LaneConst lc = make_lane_const();
     const u32 lane = threadIdx.x & 63u;
+    if (FOLD) {
+        /* the workgroup's first wave encrypts the tweaks of ALL its waves' chunks (up to eight each: the host's limit)
+         * through the plain table -- two blocks per lane at most -- into an LDS row per wave, while the other waves fill
+         * the cipher tables: what every wave did for itself before its first chunk (sixteen waves' dependent lookups in
+         * one unreplicated table) was 5 us of a 16 MiB call's 28 */
+        u32 *te_plain = (u32 *)(uaes_lds + UAES_LDS_ENC);
+        uint4 *tw_rows = (uint4 *)(uaes_lds + UAES_LDS_ENC + 1024u);
+        if (threadIdx.x < 256u) te_plain[threadIdx.x] = tb.te0[threadIdx.x];
+        __syncthreads();
+        const u32 wpw = blockDim.x >> 6;
+        /* (every wave keeps its sixteenth of the fill, the first one comes to it late: taking the first wave out of
+         * the fill -- a run-time step for the others -- cost the block loop 14 registers it does not have) */
+        if (threadIdx.x < 64u) xts_fold_tweaks<NR>(te_plain, tw_rows, k2p, first_sector, nsectors, wpw);
+        fill_enc_tables_share(DEC ? tb.td0 : tb.te0, threadIdx.x, blockDim.x);
+        __syncthreads();
+    } else {
+        if (DEC) fill_dec_tables(tb.td0); else fill_enc_tables(tb.te0);
+    }
+    const LaneConst lc = make_lane_const();
     /* launched with 16 waves per workgroup, or 4 for short texts (more CUs, see launch_xts).  The wave's number is made
      * a SCALAR explicitly: everything that positions a chunk (unit, chunk in the unit, byte offset, block count) then
      * lives in SGPRs and is stepped by scalar instructions -- as vector arithmetic it was ~20 VALU instructions per
@@ -401,10 +435,7 @@ __device__ __forceinline__ void xts_body(const uaesk_rk &k1, const uaesk_tables 
         u64 off;                                     /* byte offset of the chunk's first block */
     };
     const u32 lane_off = PACKED ? lane * 64u : lane16, u_off = PACKED ? 16u : 1024u;
-    /* FOLD: the tweaks of this wave's chunks wave + (t0 + lane) * nwaves, t0 = 0, 64, 128 ... (the unit's number is
-     * the chunk's: copyLint, micro_aes.c:399-404, then Enc_key2, :1026-1027) */
-    u32 twl[4] = { 0, 0, 0, 0 };
-    u32 trip = 0;
+    u32 trip = 0;                                    /* FOLD: this wave's row of tweaks is read trip by trip */
     auto tweak_of = [&](u64 ch, u32 (&t)[4]) {
         const u64 id = first_sector + ch;
         t[0] = (u32)id; t[1] = (u32)(id >> 32); t[2] = 0; t[3] = 0;
@@ -412,13 +443,10 @@ __device__ __forceinline__ void xts_body(const uaesk_rk &k1, const uaesk_tables 
     };
     auto fetch = [&](u64 ch, Fetched &f) {
         if (FOLD) {
-            /* (only as many lanes as the wave has chunks -- the host takes this kernel up to eight per wave: sixteen
-             * waves' lookups in the plain table collide in the banks, 64 busy lanes each cost all of a CU's waves
-             * ~14 us per batch, 16 MiB 27 -> 30 us; eight cost ~3) */
-            if (trip == 0 && ch + (u64)lane * nwaves < nsectors) tweak_of(ch + (u64)lane * nwaves, twl);
-            const u32 k = trip;
-            f.tb = make_uint4((u32)__builtin_amdgcn_readlane((int)twl[0], (int)k), (u32)__builtin_amdgcn_readlane((int)twl[1], (int)k),
-                              (u32)__builtin_amdgcn_readlane((int)twl[2], (int)k), (u32)__builtin_amdgcn_readlane((int)twl[3], (int)k));
+            const uint4 *row = (const uint4 *)(uaes_lds + UAES_LDS_ENC + 1024u) + 8u * (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+            const uint4 t4 = row[trip & 7u];                     /* (wave-uniform: back into scalar registers) */
+            f.tb = make_uint4((u32)__builtin_amdgcn_readfirstlane((int)t4.x), (u32)__builtin_amdgcn_readfirstlane((int)t4.y),
+                              (u32)__builtin_amdgcn_readfirstlane((int)t4.z), (u32)__builtin_amdgcn_readfirstlane((int)t4.w));
             ++trip;
         }
         const u64 sct = sctn;
@@ -1106,8 +1134,8 @@ static int launch_xts(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *k1
     /* a chunk per unit, one chunk per unit, whole blocks (4 KiB sectors): the bulk kernel makes its tweaks itself */
     if (!tweak16 && r == 0 && cps == 1 && mb >= 4 && !(mb < XTS_CHUNK && mb % 4 == 0) && nsectors > 1 &&
         (u64)nsectors <= 8ull * grid_for(~0ull, 1) * (UAES_WG / 64)) {          /* ... up to eight chunks per wave: 128 MiB */
-        if ((e = set_lds((k_xts_fold<NR, DEC, true>), lds + 1024u)) != hipSuccess) return (int)e;
-        if ((e = set_lds((k_xts_fold<NR, DEC, false>), lds + 1024u)) != hipSuccess) return (int)e;
+        if ((e = set_lds((k_xts_fold<NR, DEC, true>), lds + 3072u)) != hipSuccess) return (int)e;
+        if ((e = set_lds((k_xts_fold<NR, DEC, false>), lds + 3072u)) != hipSuccess) return (int)e;
         const u64 nchunks = (u64)nsectors;
         const unsigned wg = grid_for(nchunks, UAES_WG / 64) * 2 <= grid_for(~0ull, 1) ? 256u : UAES_WG;
         const unsigned xgrid = grid_for(nchunks, wg / 64);
@@ -1119,8 +1147,8 @@ static int launch_xts(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *k1
         ka.step_q = nwaves; ka.step_r = 0; ka.first_sector = first_sector;
         ka.nmain = (rounds && left && left * 100 < nwaves * (u64)pct) ? rounds * nwaves : nchunks;
         ka.in = (const unsigned char *)in; ka.out = (unsigned char *)out;
-        if (mb == XTS_CHUNK) hipLaunchKernelGGL((k_xts_fold<NR, DEC, true>), dim3(xgrid), dim3(wg), lds + 1024u, st, ka);
-        else hipLaunchKernelGGL((k_xts_fold<NR, DEC, false>), dim3(xgrid), dim3(wg), lds + 1024u, st, ka);
+        if (mb == XTS_CHUNK) hipLaunchKernelGGL((k_xts_fold<NR, DEC, true>), dim3(xgrid), dim3(wg), lds + 3072u, st, ka);
+        else hipLaunchKernelGGL((k_xts_fold<NR, DEC, false>), dim3(xgrid), dim3(wg), lds + 3072u, st, ka);
         return (int)hipGetLastError();
     }
     const bool serial = cps <= XTS_SERIAL_CPS;
