@@ -593,11 +593,13 @@ static int env_int(const char *name, int dflt, int lo, int hi);
 #define TICKET_OFF      (4096 - 128)             /* byte offset of the ticket word in pinx   */
 #define TICKET_DATA_OFF (4096 - 64)              /* 64 bytes of fetched result behind it     */
 #define TICKET_SPIN_US  200
+#define TICKET_RIDE_MAX_KIB 512                /* profiles/r05_ticket_ride_sweep.log: equal at 256-512 KiB, riding loses 1-8 us from 1 MiB on */
 
 /* every setting read from the environment, once per process and race-free (the lazily initialised
  * function-local statics were a benign but real data race between the first calls of two threads) */
 static struct {
     int    ticket, pipe_workers, gcm_key_cache;
+    size_t ticket_ride_max;         /* longest text whose only kernel carries the completion ticket itself */
     size_t pin_bytes, zero_copy_max, pipe_slice;
 } g_env;
 static pthread_once_t g_env_once = PTHREAD_ONCE_INIT;
@@ -644,10 +646,14 @@ static int ticket_wait(lane *L, uint32_t seq)
 /* Right before a kernel-level call whose only (or last) launch may carry the ticket itself (uaes_device.h:
  * uaesk_ticket_arm) -- ECB, the generic CTR kernel, a one-launch XTS unit, a one-launch GCM encryption -- and right
  * after it: L->armed != 0 then says that the kernel releases that number and no ticket kernel is needed.       */
-static void ticket_arm(lane *L)
+static void ticket_arm(lane *L, size_t text_bytes)
 {
     L->armed = 0;
     if (!ticket_enabled() || !pinned_ready(L)) return;
+    /* A riding ticket ends EVERY workgroup in a system-scope release (ticket_release: the L2 write-back of a grid
+     * that is still writing its text); past a few hundred workgroups that costs more than the second launch it
+     * saves (tools/sync_vs_async.py), so a long text gets k_ticket behind its kernel instead.                   */
+    if (text_bytes > g_env.ticket_ride_max) return;
     L->armed = ticket_next(L);
     uaesk_ticket_arm((void *)ticket_word(L), L->d_status + 16, L->armed);
 }
@@ -1085,6 +1091,7 @@ static int env_int(const char *name, int dflt, int lo, int hi)
 static void env_init(void)
 {
     g_env.ticket = env_int("UAES_TICKET", 1, 0, 1);
+    g_env.ticket_ride_max = (size_t)env_int("UAES_TICKET_RIDE_MAX_KIB", TICKET_RIDE_MAX_KIB, 0, 1 << 30) << 10;
     g_env.gcm_key_cache = env_int("UAES_GCM_KEY_CACHE", 1, 0, 1);
     g_env.pin_bytes = (size_t)env_int("UAES_PIN_KIB", 1024, 16, 65536) << 10;
     g_env.zero_copy_max = (size_t)env_int("UAES_ZEROCOPY_MAX_KIB", 1024, 0, (int)(g_env.pin_bytes >> 10)) << 10;
@@ -1373,7 +1380,7 @@ static int ecb_common(int keybits, const uint8_t *key, int decrypt, int padding,
                 break;
             }
         }
-        ticket_arm(L);
+        ticket_arm(L, len);
         int k = uaesk_ecb(L->stream, &c->tb, ks.nr, decrypt ? &ks.dk : &ks.ek, decrypt,
                           io.din, io.dout, nfull, decrypt ? 0 : (unsigned)rem, decrypt ? 0 : (unsigned)padding);
         ticket_armed_launch_done(L);
@@ -1488,7 +1495,7 @@ int uaes_ctr_xcrypt_at(int keybits, const uint8_t *key, const uint8_t ctr0[16],
         pa.c = c; pa.ks = &ks; pa.ctr = &ctr;
         if (run_pipelined(c, in, out, len, 16, 0, ctr_pipe_launch, &pa, &rc)) return rc;
         if ((rc = plan_io(L, in, len, out, len, &io)) != 0) break;
-        ticket_arm(L);
+        ticket_arm(L, len);
         int k = uaesk_ctr_xcrypt(L->stream, &c->tb, ks.nr, &ks.ek, &ctr, io.din, io.dout, len, NULL);
         ticket_armed_launch_done(L);
         if (k) { rc = fail(UAES_E_HIP, "ctr launch: %s", hipGetErrorString((hipError_t)k)); break; }
@@ -1599,7 +1606,7 @@ static int xts_common(int keybits, const uint8_t *keys, const uint8_t *tweak, in
         lane_scratch_clobbered(L);
         if ((rc = lane_scratch(L, uaesk_xts_scratch_bytes(sector_bytes, nsectors))) != 0) break;
         if ((rc = plan_io(L, in, total, out, total, &io)) != 0) break;
-        ticket_arm(L);
+        ticket_arm(L, total);
         rc = xts_run(c, L->stream, &k1, &k2, encrypt, raw_tweak ? (tweak ? tweak : zero) : NULL,
                      first_sector, sector_bytes, nsectors, io.din, io.dout, L->scratch);
         ticket_armed_launch_done(L);
@@ -1838,7 +1845,7 @@ int uaes_gcm_encrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, s
             io.dout = L->stage[1];
             io.copy_back = 1;
         }
-        ticket_arm(L);
+        ticket_arm(L, ptextLen);
         uaesk_done_word_arm(scratch_done_word(L->scratch, L->scratch_cap));
         int k = keyed ? uaesk_gcm_keyed(L->stream, &c->tb, ks.nr, &ks.ek, 0, j0, d_aad, aDataLen,
                                         io.din, ptextLen, io.dout, L->scratch, NULL)
@@ -1937,7 +1944,7 @@ int uaes_gcm_decrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, s
         }
         /* a private staging buffer may be written before the tag is known: one pass */
         int *st_where = lane_status(L);
-        if (st_where != L->d_status) { *(volatile int *)st_where = -1; ticket_arm(L); }   /* host-visible status: a
+        if (st_where != L->d_status) { *(volatile int *)st_where = -1; ticket_arm(L, crtxtLen); }   /* host-visible status: a
                                                      * one-launch decryption may carry the completion ticket itself */
         uaesk_done_word_arm(scratch_done_word(L->scratch, L->scratch_cap));
         const int dmode = io.copy_back || io.dout == L->pin[1] ? 2 : gcm_decrypt_mode();
@@ -2101,7 +2108,7 @@ int uaes_gcm_key_encrypt(uaes_gcm_key *k, const uint8_t *nonce, const void *aDat
     do {
         if ((rc = stage_aad(L, aData, aDataLen, &d_aad)) != 0) break;
         if ((rc = plan_io(L, pntxt, ptextLen, crtxt, ptextLen + 16, &io)) != 0) break;
-        ticket_arm(L);
+        ticket_arm(L, ptextLen);
         uaesk_done_word_arm(KEY_DONE_WORD(k));
         int kk = uaesk_gcm_keyed(L->stream, &c->tb, k->ks.nr, &k->ks.ek, 0, j0, d_aad, aDataLen,
                                  io.din, ptextLen, io.dout, k->scratch, NULL);
@@ -2134,7 +2141,7 @@ int uaes_gcm_key_decrypt(uaes_gcm_key *k, const uint8_t *nonce, const void *aDat
             io.dout = L->stage[1];
         }
         int *st_where = lane_status(L);
-        if (st_where != L->d_status) { *(volatile int *)st_where = -1; ticket_arm(L); }
+        if (st_where != L->d_status) { *(volatile int *)st_where = -1; ticket_arm(L, crtxtLen); }
         uaesk_done_word_arm(KEY_DONE_WORD(k));
         int kk = uaesk_gcm_keyed(L->stream, &c->tb, k->ks.nr, &k->ks.ek,
                                  io.copy_back || io.dout == L->pin[1] ? 2 : gcm_decrypt_mode(), j0, d_aad, aDataLen,
@@ -3039,7 +3046,7 @@ static int ocb_common(int keybits, const uint8_t *key, const uint8_t *nonce, siz
         int *st_where = lane_status(L);
         if (!decrypt || st_where != L->d_status) {            /* a one-launch call may carry the completion ticket */
             if (decrypt) *(volatile int *)st_where = -1;
-            ticket_arm(L);
+            ticket_arm(L, len);
         }
         int k = uaesk_ocb(L->stream, &c->tb, ks.nr, &ks.ek, &ks.dk, decrypt, nonce, nonceLen, tagLen, d_aad, aDataLen,
                           io.din, len, io.dout, L->scratch, scratch_done_word(L->scratch, L->scratch_cap), st_where);

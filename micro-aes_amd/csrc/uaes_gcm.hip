@@ -62,9 +62,10 @@
 #define GS_ZHI      (GS_YLO + 256u)                 /* Z^0..Z^15, Z = Y^16                           */
 #define GS_T        (GS_ZHI + 256u)                 /* XOR of the workgroups' weighted partial hashes */
 #define GS_YTAB     (GS_T + 64u)                    /* key contexts: the combine kernel's nibble tables of Y^256 .. Y, 40 KiB
-                                                       each for Y = H^1024 and Y = H^2048 (k_gcm_ytables)                */
+                                                       each for Y = H^1024, H^2048 .. H^32768 (k_gcm_ytables)                */
 #define GS_YTAB_SET (5u * 8192u)
-#define GS_TOTAL    (GS_YTAB + 2u * GS_YTAB_SET)
+#define GS_YTAB_SETS 6u                         /* Y = H^1024 .. H^32768 (GMC_MAXLOGSTEPS + 1) */
+#define GS_TOTAL    (GS_YTAB + GS_YTAB_SETS * GS_YTAB_SET)
 
 static inline hipStream_t S(void *s) { return (hipStream_t)s; }
 
@@ -927,15 +928,15 @@ static int launch_ej0(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek
 /* YPOW = false: table t holds H^(2^(10 - 2t)) (the last levels of a sequence of blocks).
  * YPOW = true : table t (t >= 2) holds Y^(4^(5 - t)), Y = H^2048, i.e. H^(2^(21 - 2t)) = H^(2^17), H^(2^15), H^(2^13),
  *               H^(2^11), and table 1 holds Y^256 = H^(2^19): the same radix-4 tree over the partial hashes of
- *               2048-block chunks (k_gcm_combine); table 0 is not made.                                        */
+ *               2048-block chunks (k_gcm_combine); table 0 holds H (the finisher's length-block step).                                        */
 template <bool YPOW = false>
 __device__ __forceinline__ void gcm_build_nibble_tables(uint4 *TC, uint4 *buf, const uint64_t *__restrict__ frob, u32 ylog = 11)
 {
     Gf *shPow = (Gf *)buf;                         /* 6 powers                  */
     Gf *shGen = (Gf *)(buf + 16);                  /* 6 x 128 generators, one slot of skew per eight: 13.5 KiB */
     const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    if (wave < GT_NTAB && !(YPOW && wave < 1)) {
-        const u32 k = YPOW ? ylog + 10u - 2u * wave : 10u - 2u * wave;   /* Y = H^(2^ylog): chunks of 2048 or 1024 positions */
+    if (wave < GT_NTAB) {
+        const u32 k = YPOW ? (wave ? ylog + 10u - 2u * wave : 0u) : 10u - 2u * wave;   /* Y = H^(2^ylog): chunks of 2^ylog positions */
         const Gf h = gf_from4(buf[GT_BUF - 3]);
         Gf pw = h;
         if (k) {
@@ -1518,6 +1519,9 @@ struct GmcFin {
     u32 fin_build;                                            /* mode 2: the finisher makes the tables of Y (the chunk
                                                                * workgroups take theirs from the scratch: `build`) */
     u64 m;                                                    /* mode 2: blocks of the piece */
+    u64 len_aad, len_ct;                                      /* modes 0 / 1: the length block, which the FINISHER absorbs --
+                                                               * (S ^ lengths) H, S the hash of AAD and text the chunks made: a
+                                                               * text of 2^k blocks is 2^k positions, not one more          */
     uaesk_done done;
 };
 
@@ -1525,7 +1529,8 @@ template <int NR, bool WAIT>
 __device__ __forceinline__ void gcm_combine_body(const uaesk_rk &ek, const uaesk_tables &tb, uint4 j0, const uint4 *partial, u32 W,
                                                  const unsigned char *__restrict__ scratch, u32 build,
                                                  int mode, unsigned char *tag_io, int *status, u32 ylog,
-                                                 unsigned char *wipe_out, u64 wipe_len, unsigned *done_word);
+                                                 unsigned char *wipe_out, u64 wipe_len, unsigned *done_word,
+                                                 u64 len_aad, u64 len_ct);
 
 template <int NR, int MODE, bool FOLD = false>
 __global__ __launch_bounds__(GH_T) void k_gcm_chunks(uaesk_rk rk, uaesk_tables tb, uaesk_ctr ctr,
@@ -1535,7 +1540,7 @@ __global__ __launch_bounds__(GH_T) void k_gcm_chunks(uaesk_rk rk, uaesk_tables t
 {
     if (FOLD && blockIdx.x == gridDim.x - 1u) {
         gcm_combine_body<NR, true>(rk, tb, fin.j0, partial, gridDim.x - 1u, scratch, fin.mode == 2 ? fin.fin_build : build, fin.mode,
-                                   fin.tag_io, fin.status, fin.ylog, nullptr, fin.m, fin.done_word);
+                                   fin.tag_io, fin.status, fin.ylog, nullptr, fin.m, fin.done_word, fin.len_aad, fin.len_ct);
         ticket_release(fin.done);
         return;
     }
@@ -1561,10 +1566,11 @@ __global__ __launch_bounds__(GH_T) void k_gcm_chunks(uaesk_rk rk, uaesk_tables t
     const u64 pad = chunk * nwg - nv;                   /* zero positions in front of the sequence */
     GSrc rest = src;                                          /* AAD blocks and the length block */
     rest.ct_len = 0;
-    uint4 xk[2] = { make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0) };
-#pragma unroll
-    for (u32 k = 0; k < 2; ++k) {
-        if (k >= steps) break;
+    /* position k * 1024 + t of the chunk belongs to thread t: Horner over the thread's own positions with H^1024
+     * (table 0), steps = 1, 2, 4 ... so that the chunk length stays a power of two (the finisher's Y = H^chunk is a
+     * Frobenius power) and one round of workgroups covers the text */
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    for (u32 k = 0; k < steps; ++k) {
         const u64 P = chunk * wg + (u64)k * GH_T + threadIdx.x;
         const bool live = P >= pad;
         const u64 v = live ? P - pad : 0;
@@ -1599,10 +1605,8 @@ __global__ __launch_bounds__(GH_T) void k_gcm_chunks(uaesk_rk rk, uaesk_tables t
         } else if (live) {
             x = load_vblock_fwd(rest, v < ablk ? v : ablk);
         }
-        xk[k] = x;
+        acc = k ? x4(tabmul4(TC, acc), x) : x;
     }
-    uint4 acc = xk[0];
-    if (steps == 2) acc = x4(tabmul4(TC, acc), xk[1]);
     acc = gh_tree<true>(buf, TC, acc, GH_T);
     if (!FOLD) {
         if (threadIdx.x == 0) partial[wg] = acc;
@@ -1625,7 +1629,8 @@ template <int NR, bool WAIT>
 __device__ __forceinline__ void gcm_combine_body(const uaesk_rk &ek, const uaesk_tables &tb, uint4 j0, const uint4 *partial, u32 W,
                                                  const unsigned char *__restrict__ scratch, u32 build,
                                                  int mode, unsigned char *tag_io, int *status, u32 ylog,
-                                                 unsigned char *wipe_out, u64 wipe_len, unsigned *done_word)
+                                                 unsigned char *wipe_out, u64 wipe_len, unsigned *done_word,
+                                                 u64 len_aad, u64 len_ct)
 {
     uint4 *TC = (uint4 *)uaes_lds;
     uint4 *buf = TC + GT_NTAB * 512u;
@@ -1646,8 +1651,9 @@ __device__ __forceinline__ void gcm_combine_body(const uaesk_rk &ek, const uaesk
     if (!build) {                                             /* a key context holds the tables (k_gcm_ytables): waves 2..15
                                                                  bring them in while wave 1 encrypts J0 */
         const uint4 *gy = (const uint4 *)(scratch + GS_YTAB + (ylog - 10u) * GS_YTAB_SET);
+        const uint4 *gh = (const uint4 *)(scratch + GS_TAB4 + 5u * 8192u);      /* the key's table of H itself */
         if (threadIdx.x >= 128u)
-            for (u32 i = threadIdx.x - 128u; i < 5u * 512u; i += GH_T - 128u) TC[512u + i] = gy[i];
+            for (u32 i = threadIdx.x - 128u; i < 6u * 512u; i += GH_T - 128u) TC[i] = i < 512u ? gh[i] : gy[i - 512u];
     }
     __syncthreads();
     const uint4 ej0 = buf[GT_BUF - 2];
@@ -1668,6 +1674,12 @@ __device__ __forceinline__ void gcm_combine_body(const uaesk_rk &ek, const uaesk
         if (threadIdx.x >= GH_T - W) acc = partial[threadIdx.x - (GH_T - W)];
     }
     acc = gh_tree<false>(buf, TC, acc, W);
+    if (mode != 2 && threadIdx.x < 4) {                       /* the length block (N6): (S ^ lengths) H, table 0 = H */
+        const u64 abits = len_aad * 8, cbits = len_ct * 8;
+        const uint4 lb = make_uint4(bswap32((u32)(abits >> 32)), bswap32((u32)abits),
+                                    bswap32((u32)(cbits >> 32)), bswap32((u32)cbits));
+        acc = tabmul4q(TC, x4(acc, lb));
+    }
     if (mode == 2) {
         /* a streamed piece: Y <- Y * H^m ^ P (k_gcm_fold's arithmetic, wave 0; wipe_len carries m) */
         if (threadIdx.x == 0) buf[GT_BUF - 1] = acc;
@@ -1724,12 +1736,13 @@ template <int NR>
 __global__ __launch_bounds__(GH_T) void k_gcm_combine(uaesk_rk ek, uaesk_tables tb, uint4 j0, const uint4 *partial, u32 W,
                                                       const unsigned char *__restrict__ scratch, u32 build,
                                                       int mode, unsigned char *tag_io, int *status, u32 ylog,
-                                                      unsigned char *wipe_out, u64 wipe_len)
+                                                      unsigned char *wipe_out, u64 wipe_len, u64 len_aad, u64 len_ct)
 {
-    gcm_combine_body<NR, false>(ek, tb, j0, partial, W, scratch, build, mode, tag_io, status, ylog, wipe_out, wipe_len, nullptr);
+    gcm_combine_body<NR, false>(ek, tb, j0, partial, W, scratch, build, mode, tag_io, status, ylog, wipe_out, wipe_len, nullptr,
+                                len_aad, len_ct);
 }
 
-/* key context: the two table sets k_gcm_combine would otherwise make in every call (workgroup 0: Y = H^1024, 1: H^2048) */
+/* key context: the table sets k_gcm_combine would otherwise make in every call (workgroup i: Y = H^(1024 << i)) */
 __global__ __launch_bounds__(GH_T) void k_gcm_ytables(uaesk_tables tb, unsigned char *__restrict__ scratch)
 {
     uint4 *TC = (uint4 *)uaes_lds;
@@ -1739,6 +1752,13 @@ __global__ __launch_bounds__(GH_T) void k_gcm_ytables(uaesk_tables tb, unsigned 
     gcm_build_nibble_tables<true>(TC, buf, tb.frob, 10u + blockIdx.x);
     uint4 *gy = (uint4 *)(scratch + GS_YTAB + blockIdx.x * GS_YTAB_SET);
     for (u32 i = threadIdx.x; i < 5u * 512u; i += GH_T) gy[i] = TC[512u + i];
+}
+
+static u32 log2_u32(u32 v)
+{
+    u32 lg = 0;
+    while ((1u << lg) < v) ++lg;
+    return lg;
 }
 
 template <int NR>
@@ -1751,13 +1771,14 @@ static int launch_medium(hipStream_t st, const uaesk_tables *tb, const uaesk_rk 
     GmcFin fin;
     memset(&fin, 0, sizeof fin);
     /* with a counter word from the host layer, encryption and the hash-only pass of a decryption are ONE launch */
-    /* (as long as the finisher's workgroup still finds a CU of its own beside the chunk workgroups' first round) */
+    /* (as long as the chunk workgroups are one round; see medium_steps about W = the number of CUs) */
     int cus_f = 0;
     if (uaesk_device_info(&cus_f, nullptr) != 0) cus_f = 0;
-    const bool fold = done_word != nullptr && decrypt != 2 && (int)W + 1 <= cus_f;
+    const bool fold = done_word != nullptr && decrypt != 2 && (int)W <= cus_f;
     if (fold) {
         fin.j0 = j0; fin.done_word = done_word; fin.tag_io = tag_io; fin.status = status; fin.mode = decrypt ? 1 : 0;
-        fin.ylog = steps == 2 ? 11u : 10u;
+        fin.ylog = 10u + log2_u32(steps);
+        fin.len_aad = src.len_aad; fin.len_ct = src.len_ct;
         if (!decrypt) fin.done = ticket.use();
     }
 #define GMC_LAUNCH(M, F)                                                                                            \
@@ -1776,8 +1797,8 @@ static int launch_medium(hipStream_t st, const uaesk_tables *tb, const uaesk_rk 
     e = uaesk_want_lds((const void *)k_gcm_combine<NR>, (unsigned)(GHFB_LDS));
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL((k_gcm_combine<NR>), dim3(1), dim3(GH_T), GHFB_LDS, st, *ek, *tb, j0, (const uint4 *)partial, W,
-                       (const unsigned char *)sc, build, decrypt ? 1 : 0, tag_io, status, steps == 2 ? 11u : 10u,
-                       decrypt == 2 ? (unsigned char *)out : nullptr, (u64)src.ct_len);
+                       (const unsigned char *)sc, build, decrypt ? 1 : 0, tag_io, status, 10u + log2_u32(steps),
+                       decrypt == 2 ? (unsigned char *)out : nullptr, (u64)src.ct_len, (u64)src.len_aad, (u64)src.len_ct);
     return (int)hipGetLastError();
 }
 
@@ -2056,18 +2077,41 @@ extern "C" int uaesk_gcm_j0(void *stream, const uaesk_tables *tb, int nr, const 
 /* keyed != 0: `scratch` belongs to a key context whose tables (nibble tables, H^S table, Y/Z powers, all
  * H^(2^k)) uaesk_gcm_key_tables built; then only Enc(J0) is computed per message unless the text needs
  * a size-dependent bulk table (two-pass texts over 512 KiB), for which the full setup runs as usual. */
-/* up to this many 2048-block chunks the chunk + combine kernels are preferred to the striped one-pass kernel
- * (whose fixed cost is ~60 us); UAES_GCM_MEDIUM_W overrides it (tools/gcm_size_sweep.py)                  */
-static u32 medium_pref_w(void)
+/* Up to this many GHASH positions the chunk workgroups + finisher (k_gcm_chunks) are preferred to the striped one-pass
+ * kernel, whose three launches cost ~35 us whatever the size; UAES_GCM_MEDIUM_MAX_KIB overrides it
+ * (tools/gcm_size_sweep.py).  A workgroup takes 1024 * steps positions, steps a power of two chosen so that ONE round
+ * of workgroups (and the finisher) covers the text: medium_steps().                                              */
+#define GMC_MAXLOGSTEPS 5u                      /* chunks of up to 32 768 positions: 127 MiB on 256 CUs */
+static u64 medium_max_nv(void)
 {
-    static const u32 w = [] {                          /* initialised once, thread-safe */
-        const char *e = getenv("UAES_GCM_MEDIUM_W");
-        long v = e ? atol(e) : 512;
-        if (v < 1) v = 1;
-        if (v > (long)GMC_MAXW) v = GMC_MAXW;
-        return (u32)v;
+    static const u64 w = [] {                          /* initialised once, thread-safe */
+        const char *e = getenv("UAES_GCM_MEDIUM_MAX_KIB");
+        long long v = e ? atoll(e) : 16384;
+        if (v < 16) v = 16;
+        if (v > (1ll << 21)) v = 1ll << 21;
+        return (u64)v * 64u;
     }();
     return w;
+}
+
+/* the smallest power of two of positions per thread with which the W chunk workgroups are one round on `cus` CUs; 0:
+ * the text is too long for that.  (W = cus leaves the finisher -- the LAST workgroup, which nobody waits for -- without
+ * a CU until the first chunk workgroup retires: its 6 us of preparations then come behind the chunk work instead of
+ * beside it, which is still less than twice the positions per thread on half the CUs: the case of every text of
+ * exactly 2^k blocks.)                                                                                              */
+static u32 medium_steps(u64 nv, int cus)
+{
+    if (cus < 2) return 0;
+    for (u32 lg = 0; lg <= GMC_MAXLOGSTEPS; ++lg)
+        if ((nv + (1024ull << lg) - 1) / (1024ull << lg) <= (u64)cus) return 1u << lg;
+    return 0;
+}
+
+static int medium_cus(void)
+{
+    int cus = 0;
+    if (uaesk_device_info(&cus, nullptr) != 0 || cus <= 0) cus = 64;
+    return cus;
 }
 
 static int gcm_body(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek,
@@ -2131,7 +2175,7 @@ static int gcm_body(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk
         const u64 groups = (c0 + nfull) / 256, n8 = groups > g_lo ? (groups - g_lo) / 8 : 0;
         if (Sl && ((u64)1 << logF) == Sl && logF <= GF_MAXLOG && n8 >= (u64)cus && ablk + h0 <= Sl &&
             !ctr_stripes_cross_a(&c, g_lo, n8) &&      /* (one in 2^40 blocks: the two-pass path, whose CTR kernel cuts there) */
-            !(tb->frob && nv <= 2048ull * medium_pref_w())) {
+            !(tb->frob && nv - 1 <= medium_max_nv() && medium_steps(nv - 1, medium_cus()))) {
             const u64 h1 = h0 + 2048 * n8;
             GSrc fin;                                   /* [T][tail][lengths] */
             fin.aad = sc + GS_T; fin.aad_len = 16;
@@ -2206,20 +2250,22 @@ static int gcm_body(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk
             return launch_small_nr<true>(nr, st, tb, ek, &c, j0, sm, in, out, sc, (unsigned char *)in + len, status, build, ticket.use());
         return launch_small_nr<false>(nr, st, tb, ek, &c, j0, sm, in, out, sc, (unsigned char *)out + len, nullptr, build, ticket.use());
     }
-    /* (a decrypt that must authenticate first has no one-pass alternative: the chunk kernels serve it as far as
-     * the combine kernel reaches, 32 MiB: 16 MiB 93 -> 69 us) */
-    if (decrypt != 3 && nv <= 2048ull * (decrypt == 1 ? GMC_MAXW : medium_pref_w()) && tb->frob) {
-        /* a medium-sized text: chunk kernel + combine kernel (k_gcm_chunks, k_gcm_combine), tables made in the
-         * kernels for a one-shot call.  Decrypt mode 1 hashes first and lets the gated CTR kernel write; mode 2
-         * decrypts in the chunk kernel and zeroes the output if the tag turns out wrong.                       */
+    const u32 msteps = medium_steps(nv - 1, medium_cus());     /* (the finisher takes the length block: nv - 1 positions) */
+    /* (a decryption that must authenticate first has no one-pass alternative: the chunk workgroups hash it as far as
+     * one round of them reaches, 128 MiB on 256 CUs: 16 MiB 92 -> 44 us, 64 MiB 107 -> 96) */
+    if (decrypt != 3 && msteps && (decrypt == 1 || nv - 1 <= medium_max_nv()) && tb->frob) {
+        /* a medium-sized text: chunk workgroups + finisher (k_gcm_chunks; two launches with k_gcm_combine where the
+         * one-launch arrangement cannot be used), tables made in the kernels for a one-shot call.  Decrypt mode 1
+         * hashes first and lets the gated CTR kernel write; mode 2 decrypts in the chunk kernel and zeroes the output
+         * if the tag turns out wrong.                                                                             */
         /* one position per thread while that still gives every workgroup its own CU (up to 4 MiB on 256 CUs): the
-         * chunk kernel then runs one pass of block encryptions and no stride multiplication (1 MiB 24.7 -> 23.5 us) */
-        int cus_m = 0;
-        if (uaesk_device_info(&cus_m, nullptr) != 0 || cus_m <= 0) cus_m = 64;
-        const u32 steps = (nv + 1023) / 1024 <= (u64)cus_m ? 1u : 2u;
-        const u32 W = (u32)((nv + 1024ull * steps - 1) / (1024ull * steps)), build = keyed ? 0u : 1u;
+         * chunk kernel then runs one pass of block encryptions and no stride multiplication (1 MiB 24.7 -> 23.5 us);
+         * longer texts double the positions per thread until one round of workgroups covers them                   */
+        const u32 steps = msteps;
+        const u32 W = (u32)((nv - 1 + 1024ull * steps - 1) / (1024ull * steps)), build = keyed ? 0u : 1u;
         GSrc sm = msg;
         sm.ct = (const unsigned char *)in;
+        sm.has_len = 0;
         unsigned char *tagp = decrypt ? (unsigned char *)in + len : (unsigned char *)out + len;
         switch (nr) {
         case 10: rc = launch_medium<10>(st, tb, ek, &c, j0, sm, in, out, sc, W, steps, build, decrypt, tagp, status, done_word, ticket); break;
@@ -2332,7 +2378,7 @@ extern "C" int uaesk_gcm_key_tables(void *stream, const uaesk_tables *tb, int nr
     if (rc || !tb->frob) return rc;            /* (without the Frobenius matrices the chunk + combine path is not taken) */
     hipError_t e = uaesk_want_lds((const void *)k_gcm_ytables, (unsigned)GHF_LDS);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(k_gcm_ytables, dim3(2), dim3(GH_T), GHF_LDS, st, *tb, sc);
+    hipLaunchKernelGGL(k_gcm_ytables, dim3(GS_YTAB_SETS), dim3(GH_T), GHF_LDS, st, *tb, sc);
     return (int)hipGetLastError();
 }
 
@@ -2683,15 +2729,16 @@ extern "C" int uaesk_gcm_stream_piece(void *stream, const uaesk_tables *tb, int 
     const u64 groups = (c0 + nfull) / 256, n8 = groups > g_lo ? (groups - g_lo) / 8 : 0;
     if (!(((u64)1 << logF) == Sl && logF <= GF_MAXLOG && n8 >= (u64)cus && h0 <= Sl && !ctr_stripes_cross_a(&c, g_lo, n8))) {
         const u64 nvp = ((u64)len + 15) >> 4;
-        const u32 steps = (nvp + 1023) / 1024 + 1 <= (u64)cus ? 1u : 2u;
+        const u32 steps = medium_steps(nvp, cus);
+        if (!steps) return 1;
         const u64 W = (nvp + 1024ull * steps - 1) / (1024ull * steps);
-        if (!(done_word && tb->frob && (*plan_state >> 31) && nvp >= 1024 && W + 1 <= (u64)cus)) return 1;
+        if (!(done_word && tb->frob && (*plan_state >> 31) && nvp >= 1024 && W <= (u64)cus)) return 1;
         GSrc src;
         memset(&src, 0, sizeof src);
         src.ct = (const unsigned char *)in; src.ct_len = len;          /* the kernel reads the text itself */
         GmcFin fin;
         memset(&fin, 0, sizeof fin);
-        fin.done_word = done_word; fin.mode = 2; fin.ylog = steps == 2 ? 11u : 10u; fin.fin_build = 1; fin.m = nvp;
+        fin.done_word = done_word; fin.mode = 2; fin.ylog = 10u + log2_u32(steps); fin.fin_build = 1; fin.m = nvp;
         switch (nr) {
         case 10: return launch_stream_chunks<10>(st, tb, ek, &c, src, in, out, sc, (u32)W, steps, decrypt, fin);
         case 12: return launch_stream_chunks<12>(st, tb, ek, &c, src, in, out, sc, (u32)W, steps, decrypt, fin);

@@ -1100,6 +1100,47 @@ def test_gcm_single_launch_sizes(orc, bits):
     k.close()
 
 
+def test_gcm_long_texts_hashed_by_chunk_workgroups(orc):
+    """A decryption that authenticates first (N7) hashes its ciphertext with the chunk workgroups + finisher as far as
+    ONE round of workgroups reaches (1024 * 2^k positions per workgroup, k <= 5: 128 MiB on 256 CUs), and an
+    encryption does up to 16 MiB.  The sizes the oracle finishes in seconds are in test_gcm_chunk_and_combine_kernels;
+    here the longer ones are pinned through the OTHER arrangement: the striped one-pass kernel made the tag (the kernel
+    of the C4 digest test), the chunk workgroups must accept it, reject one flipped bit anywhere and leave the output
+    alone then -- one-shot and key context (its Y tables for chunks of 4096 .. 32768 positions), with and without AAD,
+    2^k blocks exactly (as many chunk workgroups as CUs: the finisher comes late) and ragged."""
+    import torch
+    rnd = random.Random(77001)
+    key, nonce = rnd.randbytes(16), rnd.randbytes(12)
+    k = uaes.GcmKey(key)
+    status = torch.full((1,), -1, dtype=torch.int32, device="cuda:0")
+    try:
+        for n, alen in (((24 << 20) + 5, 0), (32 << 20, 0), ((40 << 20) - 16, 7), (64 << 20, 0), ((64 << 20) + 16, 4096),
+                        ((100 << 20) + 3, 0), (128 << 20, 0), ((128 << 20) - 4096, 33)):
+            src = torch.randint(0, 256, (n,), dtype=torch.uint8, device="cuda:0")
+            a = torch.randint(0, 256, (alen,), dtype=torch.uint8, device="cuda:0") if alen else None
+            ct = torch.empty(n + 16, dtype=torch.uint8, device="cuda:0")
+            uaes.gcm_encrypt_dev(key, nonce, a, src, n, ct)                   # striped one-pass kernel (> 16 MiB)
+            torch.cuda.synchronize()
+            head = 1 << 16                                                     # the first 64 KiB and the tag against the oracle's CTR
+            aad = bytes(a.cpu().numpy()) if alen else b""
+            assert bytes(ct[:head].cpu().numpy()) == orc.gcm_encrypt(key, nonce, aad, bytes(src[:head].cpu().numpy()))[:head]
+            for dec in (lambda *x: uaes.gcm_decrypt_dev(key, nonce, *x), lambda *x: k.decrypt_dev(nonce, *x)):
+                back = torch.full((n + 16,), 0xCC, dtype=torch.uint8, device="cuda:0")
+                dec(a, ct, n, back, status)
+                torch.cuda.synchronize()
+                assert int(status.item()) == 0 and torch.equal(back[:n], src) and int((back[n:] != 0xCC).sum()) == 0, (n, alen)
+                for pos in (0, n // 2 + 1, n - 1, n + 15):
+                    bad = ct.clone()
+                    bad[pos] ^= 0x20
+                    back.fill_(0xCC)
+                    dec(a, bad, n, back, status)
+                    torch.cuda.synchronize()
+                    assert int(status.item()) == 0x1A and int((back != 0xCC).sum()) == 0, (n, alen, pos)
+            del src, ct, back, bad
+    finally:
+        k.close()
+
+
 @pytest.mark.parametrize("bits", [128, 192, 256])
 def test_gcm_chunk_and_combine_kernels(orc, bits):
     """Texts between the single-workgroup kernel and the striped one-pass kernel (2047 GHASH blocks .. 16 MiB;

@@ -164,12 +164,14 @@ ts = [threading.Thread(target=work, args=(t,)) for t in range(8)]
 print(h.hexdigest(), len(bad))
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for ticket in ("1", "0"):
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, UAES_TICKET=ticket), capture_output=True,
+    # (default: the ticket rides up to 512 KiB; never; at every size -- round 4's behaviour; no tickets at all)
+    for extra in ({"UAES_TICKET": "1"}, {"UAES_TICKET_RIDE_MAX_KIB": "0"}, {"UAES_TICKET_RIDE_MAX_KIB": "1073741824"},
+                  {"UAES_TICKET": "0"}):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **extra), capture_output=True,
                            text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(r.stdout.split()[-2:])
-    assert outs[0] == outs[1] and outs[0][1] == "0", outs
+    assert all(o == outs[0] for o in outs) and outs[0][1] == "0", outs
 
 
 def test_ctr_stream_larger_than_4GiB(orc):
