@@ -59,6 +59,10 @@ int uaesk_ecb(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *keys
 int uaesk_ctr_xcrypt(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek,
                      const uaesk_ctr *ctr, const void *in, void *out, size_t len,
                      const int *gate);
+/* the generic CTR kernel with its key schedule and counter description in DEVICE memory (made by an earlier kernel
+ * of the same stream) */
+int uaesk_ctr_xcrypt_ind(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *d_rk,
+                         const uaesk_ctr *d_ctr, const void *in, void *out, size_t len);
 
 /* XTS over nsectors data units of sector_bytes each (>= 16).  Unit i has the
  * tweak block LE128(first_sector+i), or, if tweak16 != NULL (single unit),
@@ -162,6 +166,12 @@ int uaesk_polyval(void *stream, const uaesk_tables *tb, const uint8_t *hg_host,
 int uaesk_gcmsiv_small(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *master_ek, int decrypt,
                        const uint8_t *nonce12,
                        const void *aad, size_t aad_len, const void *in, size_t len, void *out, int *status);
+
+/* GCM-SIV of a message of any length without a host round trip: key derivation, key expansion, tag and counter stay
+ * in `scratch` (uaesk_gcm_scratch_bytes()); *status (decrypt) = 0 / 0x1A, the plaintext is written either way */
+int uaesk_gcmsiv_long(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *master_ek, int decrypt,
+                      const uint8_t *nonce12, const void *aad, size_t aad_len,
+                      const void *in, size_t len, void *out, void *scratch, int *status);
 
 /* GHASH only: gh = GHASH_H(aad, ct) with H given (device), for tests.      */
 int uaesk_ghash(void *stream, const uaesk_tables *tb, const uint8_t *H_host,

@@ -2788,117 +2788,17 @@ int uaes_cmac_batch(int keybits, const uint8_t *key, size_t nmsg, size_t msg_byt
 /* ------------------------------------------------------------------------ */
 /* GCM-SIV (RFC 8452; micro_aes.c:1418-1516)          */
 /* ------------------------------------------------------------------------ */
-/* Host orchestration only: every AES block (key derivation, tag encryption, the
- * LE32 counter stream) and POLYVAL run in kernels.  The host moves 16..96-byte
- * values between the steps and does the RFC's byte reversals / x-multiplication
- * of the POLYVAL key (plain integer bit operations on 16 bytes).             */
-static void rev16_bytes(uint8_t b[16])
-{
-    int i;
-    for (i = 0; i < 8; ++i) { uint8_t t = b[i]; b[i] = b[15 - i]; b[15 - i] = t; }
-}
-
-/* v <- v * x in GHASH's field (right shift of the big-endian block, 0xe1 fold) */
-static void ghash_mulx(uint8_t v[16])
-{
-    int k;
-    const uint8_t lsb = (uint8_t)(v[15] & 1);
-    for (k = 15; k > 0; --k) v[k] = (uint8_t)((v[k] >> 1) | (v[k - 1] << 7));
-    v[0] >>= 1;
-    if (lsb) v[0] ^= 0xe1;
-}
-
-typedef struct {
-    keysched enc;           /* message-encryption key schedule              */
-    uint8_t  hg[16];        /* mulX_GHASH(ByteReverse(message-authentication key)) */
-} sivkeys;
-
-/* GCM_SIVsetup (:1435-1450): blocks LE32(i) || nonce under the main key, the
- * first 8 bytes of each; auth key = first 16 bytes, cipher key = last KEYSIZE */
-static int gcmsiv_derive(lane *L, int keybits, const uint8_t *key, const uint8_t *nonce, sivkeys *out)
-{
-    context *c = L->c;
-    hipStream_t st = (hipStream_t)L->stream;
-    keysched master;
-    uint8_t blocks[6 * 16], derived[6 * 8];
-    const int kbytes = keybits / 8, n = 2 + keybits / 64;
-    int rc, i;
-    if ((rc = expand_key(&master, key, keybits)) != 0) return rc;
-    memset(blocks, 0, sizeof blocks);
-    for (i = 0; i < n; ++i) {
-        blocks[16 * i] = (uint8_t)i;
-        memcpy(blocks + 16 * i + 4, nonce, 12);
-    }
-    if (grow_on(st, &L->aad_stage, &L->aad_cap, 256)) return UAES_E_HIP;
-    /* two asynchronous copies around the kernel and ONE synchronisation; through the pinned bounce
-     * buffers when there are any (pageable hipMemcpy in, kernel, pageable hipMemcpy out synchronise
-     * three times: ~30 us -> ~18 us) */
-    if (pinned_ready(L)) {
-        /* pinx, not pin[0] / pin[1]: those may hold this call's text (the copy in may still be running) */
-        uint8_t *px = (uint8_t *)L->pinx;
-        memcpy(px, blocks, (size_t)(16 * n));
-        HIPCHK(hipMemcpyAsync(L->aad_stage, px, (size_t)(16 * n), hipMemcpyHostToDevice, st));
-        KCHK(uaesk_ecb(st, &c->tb, master.nr, &master.ek, 0, L->aad_stage, L->aad_stage, (size_t)n, 0, 0));
-        HIPCHK(hipMemcpyAsync(px + 128, L->aad_stage, (size_t)(16 * n), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        memcpy(blocks, px + 128, (size_t)(16 * n));
-    } else {
-        HIPCHK(hipMemcpyAsync(L->aad_stage, blocks, (size_t)(16 * n), hipMemcpyHostToDevice, st));
-        KCHK(uaesk_ecb(st, &c->tb, master.nr, &master.ek, 0, L->aad_stage, L->aad_stage, (size_t)n, 0, 0));
-        HIPCHK(hipMemcpyAsync(blocks, L->aad_stage, (size_t)(16 * n), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-    }
-    memset(&master, 0, sizeof master);
-    for (i = 0; i < n; ++i) memcpy(derived + 8 * i, blocks + 16 * i, 8);
-    memcpy(out->hg, derived, 16);
-    rev16_bytes(out->hg);
-    ghash_mulx(out->hg);
-    return expand_key(&out->enc, derived + 8 * n - kbytes, keybits);
-}
-
-/* tag = Enc_k((POLYVAL ^ nonce) with the top bit cleared)   (GCM_SIVtag :1453-1460);
- * d_pt: device plaintext; result in tag[16] (host)                          */
-static int gcmsiv_tag(lane *L, const sivkeys *k, const uint8_t *nonce,
-                      const void *d_aad, size_t aad_len, const void *d_pt, size_t len, uint8_t tag[16])
-{
-    context *c = L->c;
-    hipStream_t st = (hipStream_t)L->stream;
-    uint8_t s[16];
-    int i, rc;
-    uint8_t *slot = (uint8_t *)(L->d_status + 4);
-    lane_scratch_clobbered(L);
-    KCHK(uaesk_polyval(st, &c->tb, k->hg, d_aad, aad_len, d_pt, len, L->scratch, slot));
-    if ((rc = lane_fetch(L, s, slot, 16)) != 0) return rc;
-    rev16_bytes(s);
-    for (i = 0; i < 12; ++i) s[i] ^= nonce[i];
-    s[15] &= 0x7F;
-    HIPCHK(hipMemcpyAsync(slot, s, 16, hipMemcpyHostToDevice, st));
-    KCHK(uaesk_ecb(st, &c->tb, k->enc.nr, &k->enc.ek, 0, slot, slot, 1, 0, 0));
-    return lane_fetch(L, tag, slot, 16);
-}
-
-static void gcmsiv_ctr(uaesk_ctr *ctr, const uint8_t tag[16])
-{
-    memset(ctr, 0, sizeof *ctr);
-    ctr->le32 = 1;
-    memcpy(&ctr->w0, tag, 4);
-    memcpy(&ctr->w1, tag + 4, 4);
-    memcpy(&ctr->w2, tag + 8, 4);
-    memcpy(&ctr->w3, tag + 12, 4);
-    ctr->w3 |= 0x80000000u;                      /* c[LAST] |= 0x80 (:936) */
-}
-
+/* Host orchestration only: the host expands the MASTER key and enqueues; key derivation, the derived key's
+ * expansion, POLYVAL, the tag and the LE32 counter stream run in kernels and their per-nonce values never leave the
+ * device (k_siv_small for a short message, uaesk_gcmsiv_long otherwise).                                       */
 int uaes_gcmsiv_encrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
                         const void *aData, size_t aDataLen,
                         const void *pntxt, size_t ptextLen, void *crtxt)
 {
     context *c;
     lane *L;
-    sivkeys k;
     io_plan io;
     const void *d_aad;
-    uaesk_ctr ctr;
-    uint8_t tag[16];
     int rc;
     if (keybits != 128 && keybits != 192 && keybits != 256)
         return fail(UAES_E_ARG, "keybits must be 128, 192 or 256 (got %d)", keybits);
@@ -2929,17 +2829,16 @@ int uaes_gcmsiv_encrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
             if (ks > 0) { rc = fail(UAES_E_HIP, "gcm-siv launch: %s", hipGetErrorString((hipError_t)ks)); break; }
             if (ks == 0) { rc = finish_io(&io, ptextLen + 16); break; }
         }
-        /* the general path derives the keys with the ECB kernel; it borrows aad_stage for the derivation blocks,
-         * so the AAD is staged again behind it */
-        if ((rc = gcmsiv_derive(L, keybits, key, nonce, &k)) != 0) break;
-        if ((rc = stage_aad(L, aData, aDataLen, &d_aad)) != 0) break;
-        if ((rc = gcmsiv_tag(L, &k, nonce, d_aad, aDataLen, io.din, ptextLen, tag)) != 0) break;
-        gcmsiv_ctr(&ctr, tag);
-        int kk = uaesk_ctr_xcrypt(L->stream, &c->tb, k.enc.nr, &k.enc.ek, &ctr, io.din, io.dout, ptextLen, NULL);
-        if (kk) { rc = fail(UAES_E_HIP, "gcm-siv ctr launch: %s", hipGetErrorString((hipError_t)kk)); break; }
-        if (hipMemcpyAsync((char *)io.dout + ptextLen, tag, 16, hipMemcpyHostToDevice, (hipStream_t)L->stream) != hipSuccess) {
-            rc = fail(UAES_E_HIP, "tag copy failed");
-            break;
+        {   /* a longer one: six or seven launches one behind the other, the per-nonce key, the hash, the tag and the
+             * counter made of it stay on the device (uaesk_gcmsiv_long) -- the host waits once, in finish_io */
+            keysched master;
+            if ((rc = expand_key(&master, key, keybits)) != 0) break;
+            uaesk_done_word_arm(scratch_done_word(L->scratch, L->scratch_cap));
+            int kl = uaesk_gcmsiv_long(L->stream, &c->tb, master.nr, &master.ek, 0, nonce, d_aad, aDataLen,
+                                       io.din, ptextLen, io.dout, L->scratch, NULL);
+            uaesk_done_word_arm(NULL);
+            memset(&master, 0, sizeof master);
+            if (kl) { rc = fail(UAES_E_HIP, "gcm-siv launch: %s", hipGetErrorString((hipError_t)kl)); break; }
         }
         rc = finish_io(&io, ptextLen + 16);
     } while (0);
@@ -2952,11 +2851,8 @@ int uaes_gcmsiv_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
 {
     context *c;
     lane *L;
-    sivkeys k;
     io_plan io;
     const void *d_aad;
-    uaesk_ctr ctr;
-    uint8_t tag_in[16], tag[16];
     int rc;
     if (keybits != 128 && keybits != 192 && keybits != 256)
         return fail(UAES_E_ARG, "keybits must be 128, 192 or 256 (got %d)", keybits);
@@ -2994,18 +2890,22 @@ int uaes_gcmsiv_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
                 break;
             }
         }
-        if ((rc = gcmsiv_derive(L, keybits, key, nonce, &k)) != 0) break;
-        if ((rc = stage_aad(L, aData, aDataLen, &d_aad)) != 0) break;
-        if ((rc = lane_fetch(L, tag_in, (const char *)io.din + crtxtLen, 16)) != 0) break;
-        /* like the reference: decrypt with the RECEIVED tag as counter, then authenticate (:1500-1502) */
-        gcmsiv_ctr(&ctr, tag_in);
-        int kk = uaesk_ctr_xcrypt(L->stream, &c->tb, k.enc.nr, &k.enc.ek, &ctr, io.din, io.dout, crtxtLen, NULL);
-        if (kk) { rc = fail(UAES_E_HIP, "gcm-siv ctr launch: %s", hipGetErrorString((hipError_t)kk)); break; }
-        if ((rc = gcmsiv_tag(L, &k, nonce, d_aad, aDataLen, io.dout, crtxtLen, tag)) != 0) break;
-        {   /* text stays (SABOTAGE is a no-op) unless uaes_set_wipe_on_auth_failure(1) */
-            const int bad = tags_differ(tag, tag_in, 16);
-            if ((rc = bad ? finish_io_unauthenticated(&io, crtxtLen) : finish_io(&io, crtxtLen)) != 0) break;
-            rc = bad ? UAES_E_AUTHENTICATION : 0;
+        {   /* like the reference: decrypt with the RECEIVED tag as counter, then authenticate (:1500-1502) -- all of
+             * it on the device (uaesk_gcmsiv_long); the text stays (SABOTAGE is a no-op) unless
+             * uaes_set_wipe_on_auth_failure(1) */
+            keysched master;
+            int status = -1;
+            if ((rc = expand_key(&master, key, keybits)) != 0) break;
+            uaesk_done_word_arm(scratch_done_word(L->scratch, L->scratch_cap));
+            int kl = uaesk_gcmsiv_long(L->stream, &c->tb, master.nr, &master.ek, 1, nonce, d_aad, aDataLen,
+                                       io.din, crtxtLen, io.dout, L->scratch, L->d_status);
+            uaesk_done_word_arm(NULL);
+            memset(&master, 0, sizeof master);
+            if (kl) { rc = fail(UAES_E_HIP, "gcm-siv launch: %s", hipGetErrorString((hipError_t)kl)); break; }
+            if ((rc = lane_fetch(L, &status, L->d_status, sizeof status)) != 0) break;
+            io.drained = 1;
+            if ((rc = status ? finish_io_unauthenticated(&io, crtxtLen) : finish_io(&io, crtxtLen)) != 0) break;
+            rc = status ? UAES_E_AUTHENTICATION : 0;
         }
     } while (0);
     DONE(L, rc);

@@ -65,7 +65,12 @@
                                                        each for Y = H^1024, H^2048 .. H^32768 (k_gcm_ytables)                */
 #define GS_YTAB_SET (5u * 8192u)
 #define GS_YTAB_SETS 6u                         /* Y = H^1024 .. H^32768 (GMC_MAXLOGSTEPS + 1) */
-#define GS_TOTAL    (GS_YTAB + GS_YTAB_SETS * GS_YTAB_SET)
+#define GS_SIV      (GS_YTAB + GS_YTAB_SETS * GS_YTAB_SET)   /* a long GCM-SIV message's per-nonce values, made and used on the device: */
+#define GS_SIV_RK   GS_SIV                          /*   the message-encryption key's schedule (uaesk_rk, 240 B) */
+#define GS_SIV_HG   (GS_SIV + 256u)                 /*   the POLYVAL key in GHASH form                           */
+#define GS_SIV_PV   (GS_SIV + 272u)                 /*   the raw hash                                            */
+#define GS_SIV_CTR  (GS_SIV + 288u)                 /*   the keystream's counter description (uaesk_ctr)         */
+#define GS_TOTAL    (GS_SIV + 512u)
 
 static inline hipStream_t S(void *s) { return (hipStream_t)s; }
 
@@ -235,6 +240,8 @@ __device__ __forceinline__ u32 nib_entry(u32 p, u32 v)
 /* a * M, every lane its own product */
 /* (tid: a kernel that loops hands in an opaque copy of threadIdx.x, or the sixteen per-step slot constants are
  * hoisted out of its loop and spilled) */
+template <int PARTS = 2>                                       /* 4: eight lookups in flight (32 registers) -- inside a loop
+                                                                * that keeps a cipher's state and keys alive around it */
 __device__ __forceinline__ uint4 tabmul4(const uint4 *T, uint4 a, u32 tid = threadIdx.x)
 {
     const u32 g = b128_group_pos(tid);
@@ -244,12 +251,13 @@ __device__ __forceinline__ uint4 tabmul4(const uint4 *T, uint4 a, u32 tid = thre
     /* two halves of sixteen lookups, the second not started before the first is folded: 64 instead of 128 registers
      * of entries in flight (a caller with live state around the product would spill it otherwise) */
     u32 z[4] = { 0, 0, 0, 0 };
+    constexpr int NQ = 16 / PARTS;                             /* bytes per part */
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        u32x4 e[16];
+    for (int h = 0; h < PARTS; ++h) {
+        u32x4 e[2 * NQ];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int k = 8 * h + q;
+        for (int q = 0; q < NQ; ++q) {
+            const int k = NQ * h + q;
             const u32 c = base + (((g + (u32)k) & 15u) << 4);  /* slot of byte (k + g) mod 16 */
             e[2 * q] = *(lds_cu128 *)(uintptr_t)(c + (__builtin_amdgcn_ubfe(r[k >> 2], 8u * (k & 3) + 4u, 4u) << 9));
             e[2 * q + 1] = *(lds_cu128 *)(uintptr_t)(c + 256u + (__builtin_amdgcn_ubfe(r[k >> 2], 8u * (k & 3), 4u) << 9));
@@ -258,7 +266,7 @@ __device__ __forceinline__ uint4 tabmul4(const uint4 *T, uint4 a, u32 tid = thre
         for (int d = 0; d < 4; ++d) {
             u32 t = xor3(z[d], e[0][d], e[1][d]);
 #pragma unroll
-            for (int k = 2; k < 16; k += 2) t = xor3(t, e[k][d], e[k + 1][d]);
+            for (int k = 2; k < 2 * NQ; k += 2) t = xor3(t, e[k][d], e[k + 1][d]);
             z[d] = t;
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -461,7 +469,7 @@ __device__ __forceinline__ Gf wave_gfmul(Gf x, Gf y, u32 lane)
 #define SETUP_LDS   (UAES_LDS_ENC + 24576u)
 
 /* logA: log2 of the bulk stride (12..17), 0 = no bulk level.  needB: build the
- * H^4096 table.  h_given: skip AES, use hval as H and 0 as Enc(J0) (tests).
+ * H^4096 table.  h_given: skip AES, use hval as H and 0 as Enc(J0) (tests, POLYVAL); 2: H from GS_SIV_HG.
  * logF != 0: also build the table of H^(2^logF) for the fused encrypt kernel.   */
 template <int NR>
 __global__ __launch_bounds__(UAES_WG) void k_gcm_setup(uaesk_rk ek, uaesk_tables tb, uint4 j0,
@@ -498,6 +506,7 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_setup(uaesk_rk ek, uaesk_tables
             if (threadIdx.x == 0) shPow[0] = gf_from_words(s[0], s[1], s[2], s[3]);
         }
     } else if (threadIdx.x == 0) {
+        if (h_given == 2) hval = *(const uint4 *)(scratch + GS_SIV_HG);     /* made by k_siv_prep on this stream */
         if (tables_wg) {
             gH[0] = hval;
             gH[1] = make_uint4(0, 0, 0, 0);
@@ -1554,9 +1563,13 @@ __global__ __launch_bounds__(GH_T) void k_gcm_chunks(uaesk_rk rk, uaesk_tables t
     fill_tables64(tb.te0, 0);                                 /* ends with a barrier */
     const LaneConst2 lc = make_lane_const2(0);
     if (build) {                                              /* H = Enc(0): one uniform pass, thread 0 keeps it */
-        u32 s1[1][4] = { { 0, 0, 0, 0 } };
-        enc_blocks<NR, 1>(s1, rk, lc);
-        if (threadIdx.x == 0) buf[GT_BUF - 3] = make_uint4(s1[0][0], s1[0][1], s1[0][2], s1[0][3]);
+        if (MODE == 1 && src.rev) {                           /* POLYVAL of a long GCM-SIV message: the key k_siv_prep made */
+            if (threadIdx.x == 0) buf[GT_BUF - 3] = *(const uint4 *)(scratch + GS_SIV_HG);
+        } else {
+            u32 s1[1][4] = { { 0, 0, 0, 0 } };
+            enc_blocks<NR, 1>(s1, rk, lc);
+            if (threadIdx.x == 0) buf[GT_BUF - 3] = make_uint4(s1[0][0], s1[0][1], s1[0][2], s1[0][3]);
+        }
         __syncthreads();
         gcm_build_nibble_tables(TC, buf, tb.frob);
     }
@@ -1571,6 +1584,13 @@ __global__ __launch_bounds__(GH_T) void k_gcm_chunks(uaesk_rk rk, uaesk_tables t
      * Frobenius power) and one round of workgroups covers the text */
     uint4 acc = make_uint4(0, 0, 0, 0);
     for (u32 k = 0; k < steps; ++k) {
+        if (k) {                                              /* (first, while little else is live; an opaque copy of the
+                                                               * thread number, or tabmul4's sixteen slot constants are
+                                                               * hoisted out of the loop and spilled) */
+            u32 tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));
+            acc = tabmul4<4>(TC, acc, tid);
+        }
         const u64 P = chunk * wg + (u64)k * GH_T + threadIdx.x;
         const bool live = P >= pad;
         const u64 v = live ? P - pad : 0;
@@ -1586,7 +1606,7 @@ __global__ __launch_bounds__(GH_T) void k_gcm_chunks(uaesk_rk rk, uaesk_tables t
             const u64 avail = len - 16 * i;
             const u32 nb = avail < 16 ? (u32)avail : 16u;
             const uint4 d = nb == 16 ? in[i] : load_bytes_padded((const unsigned char *)(in + i), nb);
-            x = d;
+            x = (MODE == 1 && src.rev) ? rev16(d) : d;
             if (MODE != 1) {
                 u32 o[4] = { d.x ^ s1[0][0], d.y ^ s1[0][1], d.z ^ s1[0][2], d.w ^ s1[0][3] };
                 if (nb < 16) {
@@ -1603,9 +1623,9 @@ __global__ __launch_bounds__(GH_T) void k_gcm_chunks(uaesk_rk rk, uaesk_tables t
                 if (MODE == 0) x = make_uint4(o[0], o[1], o[2], o[3]);   /* GHASH takes the ciphertext */
             }
         } else if (live) {
-            x = load_vblock_fwd(rest, v < ablk ? v : ablk);
+            x = load_vblock(rest, v < ablk ? v : ablk);       /* (byte-reversed for POLYVAL) */
         }
-        acc = k ? x4(tabmul4(TC, acc), x) : x;
+        acc = x4(acc, x);
     }
     acc = gh_tree<true>(buf, TC, acc, GH_T);
     if (!FOLD) {
@@ -1644,8 +1664,12 @@ __device__ __forceinline__ void gcm_combine_body(const uaesk_rk &ek, const uaesk
     const u32 wave = threadIdx.x >> 6;
     if (wave < 2) {                                           /* wave 0: H; wave 1: Enc(J0) */
         u32 s1[4] = { 0, 0, 0, 0 };
-        if (wave) { s1[0] = j0.x; s1[1] = j0.y; s1[2] = j0.z; s1[3] = j0.w; }
-        if ((wave && mode != 2) || (!wave && build)) plain_encrypt<NR>(te_plain, ek, s1);
+        if (mode >= 3) {                                      /* GCM-SIV: the POLYVAL key k_siv_prep made; j0 is the nonce */
+            if (!wave) { const uint4 h = *(const uint4 *)(scratch + GS_SIV_HG); s1[0] = h.x; s1[1] = h.y; s1[2] = h.z; s1[3] = h.w; }
+        } else {
+            if (wave) { s1[0] = j0.x; s1[1] = j0.y; s1[2] = j0.z; s1[3] = j0.w; }
+            if ((wave && mode != 2) || (!wave && build)) plain_encrypt<NR>(te_plain, ek, s1);
+        }
         if ((threadIdx.x & 63u) == 0) buf[GT_BUF - 3 + wave] = make_uint4(s1[0], s1[1], s1[2], s1[3]);
     }
     if (!build) {                                             /* a key context holds the tables (k_gcm_ytables): waves 2..15
@@ -1676,9 +1700,36 @@ __device__ __forceinline__ void gcm_combine_body(const uaesk_rk &ek, const uaesk
     acc = gh_tree<false>(buf, TC, acc, W);
     if (mode != 2 && threadIdx.x < 4) {                       /* the length block (N6): (S ^ lengths) H, table 0 = H */
         const u64 abits = len_aad * 8, cbits = len_ct * 8;
-        const uint4 lb = make_uint4(bswap32((u32)(abits >> 32)), bswap32((u32)abits),
-                                    bswap32((u32)(cbits >> 32)), bswap32((u32)cbits));
+        const uint4 lb = mode >= 3 ? rev16(make_uint4((u32)abits, (u32)(abits >> 32), (u32)cbits, (u32)(cbits >> 32)))
+                                   : make_uint4(bswap32((u32)(abits >> 32)), bswap32((u32)abits),
+                                                bswap32((u32)(cbits >> 32)), bswap32((u32)cbits));
         acc = tabmul4q(TC, x4(acc, lb));
+    }
+    if (mode >= 3) {
+        /* GCM-SIV (3: encrypt, 4: decrypt): tag = Enc_k((POLYVAL ^ nonce) with the top bit cleared) (GCM_SIVtag
+         * :1453-1460) under the schedule k_siv_prep left in the scratch; written behind the text together with the
+         * counter made of it, or compared */
+        if (threadIdx.x == 0) {
+            unsigned char *sc = (unsigned char *)scratch;
+            uaesk_rk rk;
+            const u32 *rkw = (const u32 *)(sc + GS_SIV_RK);
+#pragma unroll
+            for (int i = 0; i < 4 * (NR + 1); ++i) rk.w[i] = rkw[i];
+            const uint4 pv = rev16(acc);
+            u32 s1[4] = { pv.x ^ j0.x, pv.y ^ j0.y, pv.z ^ j0.z, pv.w & 0x7fffffffu };
+            plain_encrypt<NR>(te_plain, rk, s1);
+            if (mode == 4) {
+                u32 diff = 0;
+                for (u32 b = 0; b < 16; ++b) diff |= (u32)tag_io[b] ^ ((s1[b >> 2] >> (8 * (b & 3))) & 0xffu);
+                *status = diff ? 0x1A : 0;
+            } else {
+                for (u32 b = 0; b < 16; ++b) tag_io[b] = (unsigned char)(s1[b >> 2] >> (8 * (b & 3)));
+                uaesk_ctr *c = (uaesk_ctr *)(sc + GS_SIV_CTR);
+                c->w0 = s1[0]; c->w1 = s1[1]; c->w2 = s1[2]; c->w3 = s1[3] | 0x80000000u;
+                c->b8 = 0; c->v0 = 0; c->le32 = 1;
+            }
+        }
+        return;
     }
     if (mode == 2) {
         /* a streamed piece: Y <- Y * H^m ^ P (k_gcm_fold's arithmetic, wave 0; wipe_len carries m) */
@@ -2860,4 +2911,172 @@ extern "C" int uaesk_gcmsiv_small(void *stream, const uaesk_tables *tb, int nr, 
     }
 #undef SIV_LAUNCH
     return (int)hipGetLastError();
+}
+
+/* ------------------------------------------------------------------------ */
+/* long GCM-SIV messages: nothing per-nonce visits the host                    */
+/* ------------------------------------------------------------------------ */
+/* Through round 4 a message too long for k_siv_small took derive_keys by the ECB kernel (read back: the host expanded
+ * the derived key), POLYVAL (read back: the host made the tag's input), the tag by the ECB kernel (read back: the host
+ * made the counter) and CTR -- three round trips, 110 us for 4 MiB.  Now the per-nonce values stay in the scratch:
+ * k_siv_prep derives the keys under the master key and expands the message-encryption key there (GCM_SIV_init,
+ * micro_aes.c:1421-1450; KeyExpansion :144-178) and, for a decryption, turns the received tag into the counter;
+ * POLYVAL's setup reads its key from there (h_given = 2); k_siv_tag makes the tag from the raw hash (:1453-1460)
+ * and writes it behind the text (or compares it) and the counter; the CTR kernel reads schedule and counter from
+ * there (k_ctr_ind).  The launches follow one another on the stream; the host waits once, at the end.            */
+template <int NR>
+__global__ __launch_bounds__(64) void k_siv_prep(uaesk_rk mk, uaesk_tables tb, uint4 nonce,
+                                                 const unsigned char *tag_in, unsigned char *__restrict__ scratch)
+{
+    u32 *te_plain = (u32 *)uaes_lds;                          /* 1 KiB: an unreplicated Te0 */
+    u32 *drv = te_plain + 256;                                /* the derived words */
+    for (u32 i = threadIdx.x; i < 256u; i += 64u) te_plain[i] = tb.te0[i];
+    __syncthreads();
+    constexpr u32 NK = NR - 6, NB = 2 + NK / 2;
+    if (threadIdx.x < NB) {                                   /* block i = LE32(i) || nonce under the MASTER key, its low half */
+        u32 s1[4] = { threadIdx.x, nonce.x, nonce.y, nonce.z };
+        plain_encrypt<NR>(te_plain, mk, s1);
+        drv[2 * threadIdx.x] = s1[0];
+        drv[2 * threadIdx.x + 1] = s1[1];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint4 auth = make_uint4(drv[0], drv[1], drv[2], drv[3]);
+        u32 hw[4];
+        gf_to_words(gf_mul_xk(gf_from4(rev16(auth)), 1), hw);    /* POLYVAL key in GHASH form: mulX(rev(H)) */
+        *(uint4 *)(scratch + GS_SIV_HG) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+        auto subword = [&](u32 w) -> u32 {
+            return ((te_plain[w & 0xffu] >> 8) & 0xffu) | (te_plain[(w >> 8) & 0xffu] & 0xff00u) |
+                   ((te_plain[(w >> 16) & 0xffu] & 0xff00u) << 8) | ((te_plain[w >> 24] & 0xff00u) << 16);
+        };
+        u32 w[4 * (NR + 1)];
+#pragma unroll
+        for (u32 i = 0; i < NK; ++i) w[i] = drv[4 + i];
+        u32 rcon = 1;
+#pragma unroll
+        for (u32 i = NK; i < 4u * (NR + 1); ++i) {
+            u32 t = w[i - 1];
+            if (i % NK == 0) {
+                t = subword((t >> 8) | (t << 24)) ^ rcon;         /* RotWord on LE words */
+                rcon = ((rcon << 1) ^ ((rcon >> 7) * 0x1bu)) & 0xffu;
+            } else if (NK == 8 && i % NK == 4) {
+                t = subword(t);
+            }
+            w[i] = w[i - NK] ^ t;
+        }
+        u32 *rk = (u32 *)(scratch + GS_SIV_RK);
+#pragma unroll
+        for (u32 i = 0; i < 60u; ++i) rk[i] = i < 4u * (NR + 1) ? w[i] : 0u;
+    }
+    if (threadIdx.x == 1 && tag_in) {                         /* decrypt: the received tag is the counter (:1500-1502) */
+        u32 t[4] = { 0, 0, 0, 0 };
+        for (u32 b = 0; b < 16; ++b) t[b >> 2] |= (u32)tag_in[b] << (8 * (b & 3));
+        uaesk_ctr *c = (uaesk_ctr *)(scratch + GS_SIV_CTR);
+        c->w0 = t[0]; c->w1 = t[1]; c->w2 = t[2]; c->w3 = t[3] | 0x80000000u;     /* c[LAST] |= 0x80 (:936) */
+        c->b8 = 0; c->v0 = 0; c->le32 = 1;
+    }
+}
+
+/* tag = Enc_k((POLYVAL ^ nonce) with the top bit cleared) (GCM_SIVtag :1453-1460) from the raw hash in the scratch.
+ * DEC: compared with the 16 bytes at tag_io, *status = 0 / 0x1A; else written there, and the counter made of it. */
+template <int NR, bool DEC>
+__global__ __launch_bounds__(64) void k_siv_tag(uaesk_tables tb, uint4 nonce, unsigned char *__restrict__ scratch,
+                                                unsigned char *tag_io, int *status)
+{
+    u32 *te_plain = (u32 *)uaes_lds;
+    for (u32 i = threadIdx.x; i < 256u; i += 64u) te_plain[i] = tb.te0[i];
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    uaesk_rk rk;
+    const u32 *rkw = (const u32 *)(scratch + GS_SIV_RK);
+#pragma unroll
+    for (int i = 0; i < 4 * (NR + 1); ++i) rk.w[i] = rkw[i];
+    const uint4 pv = rev16(*(const uint4 *)(scratch + GS_SIV_PV));
+    u32 s1[4] = { pv.x ^ nonce.x, pv.y ^ nonce.y, pv.z ^ nonce.z, pv.w & 0x7fffffffu };
+    plain_encrypt<NR>(te_plain, rk, s1);
+    if (DEC) {
+        u32 diff = 0;
+        for (u32 b = 0; b < 16; ++b) diff |= (u32)tag_io[b] ^ ((s1[b >> 2] >> (8 * (b & 3))) & 0xffu);
+        *status = diff ? 0x1A : 0;
+    } else {
+        for (u32 b = 0; b < 16; ++b) tag_io[b] = (unsigned char)(s1[b >> 2] >> (8 * (b & 3)));
+        uaesk_ctr *c = (uaesk_ctr *)(scratch + GS_SIV_CTR);
+        c->w0 = s1[0]; c->w1 = s1[1]; c->w2 = s1[2]; c->w3 = s1[3] | 0x80000000u;
+        c->b8 = 0; c->v0 = 0; c->le32 = 1;
+    }
+}
+
+template <int NR>
+static int siv_long_nr(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *mk, int decrypt, uint4 nn,
+                       const void *aad, size_t aad_len, const void *in, size_t len, void *out, unsigned char *sc, int *status,
+                       unsigned *done_word)
+{
+    const unsigned char *tag_in = decrypt ? (const unsigned char *)in + len : nullptr;
+    hipLaunchKernelGGL((k_siv_prep<NR>), dim3(1), dim3(64), 1024 + 64, st, *mk, *tb, nn, tag_in, sc);
+    int rc = (int)hipGetLastError();
+    if (rc) return rc;
+    const uaesk_rk *d_rk = (const uaesk_rk *)(sc + GS_SIV_RK);
+    const uaesk_ctr *d_ctr = (const uaesk_ctr *)(sc + GS_SIV_CTR);
+    /* decrypt like the reference: the keystream first (the received tag is its counter), then authenticate */
+    if (decrypt && (rc = uaesk_ctr_xcrypt_ind(st, tb, NR, d_rk, d_ctr, in, out, len)) != 0) return rc;
+    GSrc msg;                                                    /* POLYVAL over AAD || plaintext || lengths */
+    msg.aad = (const unsigned char *)aad; msg.aad_len = aad_len;
+    msg.ct = (const unsigned char *)(decrypt ? out : in); msg.ct_len = len;
+    msg.has_len = 1; msg.len_aad = aad_len; msg.len_ct = len; msg.rev = 1;
+    const u64 nv = ((aad_len + 15) >> 4) + ((len + 15) >> 4) + 1;
+    const u32 steps = medium_steps(nv - 1, medium_cus());
+    if (done_word && tb->frob && steps) {
+        /* as far as one round of chunk workgroups reaches (128 MiB on 256 CUs) POLYVAL and the tag are ONE launch:
+         * the hash-only chunk workgroups (byte-reversed blocks, the key from the scratch) and the finisher, which
+         * also makes the tag and the counter (gcm_combine_body, modes 3 / 4) */
+        const u32 W = (u32)((nv - 1 + 1024ull * steps - 1) / (1024ull * steps));
+        GSrc sm = msg;
+        sm.has_len = 0;
+        GmcFin fin;
+        memset(&fin, 0, sizeof fin);
+        fin.j0 = nn; fin.done_word = done_word; fin.mode = decrypt ? 4 : 3; fin.ylog = 10u + log2_u32(steps);
+        fin.tag_io = decrypt ? (unsigned char *)in + len : (unsigned char *)out + len;
+        fin.status = status; fin.len_aad = aad_len; fin.len_ct = len;
+        uaesk_rk dummy;
+        uaesk_ctr cdummy;
+        memset(&dummy, 0, sizeof dummy);
+        memset(&cdummy, 0, sizeof cdummy);
+        hipError_t e = uaesk_want_lds((const void *)k_gcm_chunks<NR, 1, true>, (unsigned)(GSM_LDS_TOTAL));
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((k_gcm_chunks<NR, 1, true>), dim3(W + 1u), dim3(GH_T), GSM_LDS_TOTAL, st, dummy, *tb, cdummy, sm,
+                           (const uint4 *)msg.ct, (uint4 *)nullptr, (const unsigned char *)sc, (uint4 *)(sc + GS_ACC1), 1u, steps, fin);
+        if ((rc = (int)hipGetLastError()) != 0) return rc;
+        if (!decrypt) rc = uaesk_ctr_xcrypt_ind(st, tb, NR, d_rk, d_ctr, in, out, len);
+        return rc;
+    }
+    const GPlan pl = plan_for(nv);
+    uaesk_rk dummy_rk;
+    memset(&dummy_rk, 0, sizeof dummy_rk);
+    if ((rc = launch_setup<10>(st, tb, &dummy_rk, make_uint4(0, 0, 0, 0), sc, pl, 2, make_uint4(0, 0, 0, 0))) != 0) return rc;
+    if ((rc = run_ghash_levels(st, msg, nv, pl, sc, 2, sc + GS_SIV_PV, nullptr)) != 0) return rc;
+    if (decrypt) hipLaunchKernelGGL((k_siv_tag<NR, true>), dim3(1), dim3(64), 1024, st, *tb, nn, sc, (unsigned char *)in + len, status);
+    else         hipLaunchKernelGGL((k_siv_tag<NR, false>), dim3(1), dim3(64), 1024, st, *tb, nn, sc, (unsigned char *)out + len, nullptr);
+    if ((rc = (int)hipGetLastError()) != 0) return rc;
+    if (!decrypt) rc = uaesk_ctr_xcrypt_ind(st, tb, NR, d_rk, d_ctr, in, out, len);
+    return rc;
+}
+
+/* GCM-SIV of a message of any length, six or seven launches and no host round trip (see above).  mk = the schedule
+ * of the MASTER key; encrypt: the tag is written at out + len; decrypt: read at in + len, the plaintext is written
+ * either way (the reference's order) and *status (device or host-visible) = 0 / 0x1A.  in == out is allowed.
+ * With a counter word armed (uaesk_done_word_arm) and up to 128 MiB: three launches (prep, POLYVAL + tag, CTR).  */
+extern "C" int uaesk_gcmsiv_long(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *mk, int decrypt,
+                                 const uint8_t *nonce12, const void *aad, size_t aad_len,
+                                 const void *in, size_t len, void *out, void *scratch, int *status)
+{
+    uint4 nn = make_uint4(0, 0, 0, 0);
+    memcpy(&nn, nonce12, 12);
+    unsigned char *sc = (unsigned char *)scratch;
+    unsigned *done_word = uaesk_done_word_take();               /* armed by the host layer: a word that is zero between calls */
+    switch (nr) {
+    case 10: return siv_long_nr<10>(S(stream), tb, mk, decrypt, nn, aad, aad_len, in, len, out, sc, status, done_word);
+    case 12: return siv_long_nr<12>(S(stream), tb, mk, decrypt, nn, aad, aad_len, in, len, out, sc, status, done_word);
+    case 14: return siv_long_nr<14>(S(stream), tb, mk, decrypt, nn, aad, aad_len, in, len, out, sc, status, done_word);
+    default: return (int)hipErrorInvalidValue;
+    }
 }

@@ -139,9 +139,9 @@ __global__ __launch_bounds__(UAES_WG) void k_ecb(uaesk_rk rk, uaesk_tables tb,
 /* ------------------------------------------------------------------------ */
 /* the generic CTR kernel: work items are single blocks, U = 4 per lane per iteration */
 template <int NR, int U>
-__global__ __launch_bounds__(UAES_WG, 4) void k_ctr(uaesk_rk rk, uaesk_tables tb, uaesk_ctr ctr,
+__device__ __forceinline__ void ctr_generic_body(const uaesk_rk &rk, const uaesk_tables &tb, const uaesk_ctr &ctr,
                                                  const uint4 *in, uint4 *out,
-                                                 u64 nfull, u32 rem, const int *__restrict__ gate, uaesk_done done)
+                                                 u64 nfull, u32 rem, const int *__restrict__ gate, const uaesk_done &done)
 {
     if (gate && *gate != 0) { ticket_release(done); return; }      /* GCM decrypt: tag mismatch -> untouched */
     /* the first pass's text is requested BEFORE the tables are made: a short call is this one pass, and the load
@@ -185,6 +185,41 @@ __global__ __launch_bounds__(UAES_WG, 4) void k_ctr(uaesk_rk rk, uaesk_tables tb
     /* reference N3: len%16 tail bytes use Enc(ctr_final) (mixThenXor, :949) */
     if (rem && blockIdx.x == 0 && threadIdx.x == 0) ctr_byte_tail<NR>(rk, ctr, in, out, nfull, rem, lc);
     ticket_release(done);
+}
+
+template <int NR, int U>
+__global__ __launch_bounds__(UAES_WG, 4) void k_ctr(uaesk_rk rk, uaesk_tables tb, uaesk_ctr ctr,
+                                                 const uint4 *in, uint4 *out,
+                                                 u64 nfull, u32 rem, const int *__restrict__ gate, uaesk_done done)
+{
+    ctr_generic_body<NR, U>(rk, tb, ctr, in, out, nfull, rem, gate, done);
+}
+
+/* the same kernel with its key schedule and counter description in DEVICE memory: what an earlier kernel of the same
+ * stream made them from (a long GCM-SIV message: the per-nonce key and the tag that is the counter never visit the
+ * host, uaesk_gcmsiv_long).  Read at the kernel's entry, before any store: uniform, unclobbered -> scalar loads. */
+template <int NR, int U>
+__global__ __launch_bounds__(UAES_WG, 4) void k_ctr_ind(const uaesk_rk *__restrict__ rkp, uaesk_tables tb,
+                                                     const uaesk_ctr *__restrict__ ctrp,
+                                                     const uint4 *in, uint4 *out, u64 nfull, u32 rem)
+{
+    uaesk_rk rk;
+#pragma unroll
+    for (int i = 0; i < 4 * (NR + 1); ++i) rk.w[i] = (u32)__builtin_amdgcn_readfirstlane((int)rkp->w[i]);
+    uaesk_ctr ctr;
+    ctr.w0 = (u32)__builtin_amdgcn_readfirstlane((int)ctrp->w0);
+    ctr.w1 = (u32)__builtin_amdgcn_readfirstlane((int)ctrp->w1);
+    ctr.w2 = (u32)__builtin_amdgcn_readfirstlane((int)ctrp->w2);
+    ctr.w3 = (u32)__builtin_amdgcn_readfirstlane((int)ctrp->w3);
+    ctr.b8 = (u32)__builtin_amdgcn_readfirstlane((int)ctrp->b8);
+    ctr.le32 = (u32)__builtin_amdgcn_readfirstlane((int)ctrp->le32);
+    {
+        const u32 lo = (u32)__builtin_amdgcn_readfirstlane((int)(u32)ctrp->v0);
+        const u32 hi = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(ctrp->v0 >> 32));
+        ctr.v0 = ((u64)hi << 32) | lo;
+    }
+    const uaesk_done none = { nullptr, nullptr, 0 };
+    ctr_generic_body<NR, U>(rk, tb, ctr, in, out, nfull, rem, nullptr, none);
 }
 
 #define CTRS_BUF   (UAES_LDS_ENC)            /* 2 x 64 x 32 B after the tables */
@@ -1035,6 +1070,31 @@ static int launch_ctr(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek
     if (ctr->le32)                             /* the shared-round kernel assumes the 56-bit BE counter */
         return launch_ctr_v<NR, 4>(st, tb, ek, ctr, in, out, len, gate);
     return launch_ctr_shared<NR>(st, tb, ek, ctr, in, out, len, gate);
+}
+
+template <int NR, int U>
+static int launch_ctr_ind_u(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *d_rk, const uaesk_ctr *d_ctr,
+                            const void *in, void *out, size_t len)
+{
+    const unsigned lds = UAES_LDS_ENC;
+    hipError_t e = set_lds(k_ctr_ind<NR, U>, lds);
+    if (e != hipSuccess) return (int)e;
+    const u64 nfull = len / 16;
+    const u32 rem = (u32)(len % 16);
+    const unsigned grid = grid_for(nfull + (rem ? 1 : 0), (u64)UAES_WG * U);
+    hipLaunchKernelGGL((k_ctr_ind<NR, U>), dim3(grid), dim3(UAES_WG), lds, st, d_rk, *tb, d_ctr,
+                       (const uint4 *)in, (uint4 *)out, nfull, rem);
+    return (int)hipGetLastError();
+}
+
+/* the generic CTR kernel with key schedule and counter description read from device memory (k_ctr_ind) */
+extern "C" int uaesk_ctr_xcrypt_ind(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *d_rk,
+                                    const uaesk_ctr *d_ctr, const void *in, void *out, size_t len)
+{
+    if (len == 0) return 0;
+    if (short_text((len + 15) / 16)) { DISPATCH_NR(nr, return (launch_ctr_ind_u<NR, 1>(S(stream), tb, d_rk, d_ctr, in, out, len))); }
+    else                             { DISPATCH_NR(nr, return (launch_ctr_ind_u<NR, 4>(S(stream), tb, d_rk, d_ctr, in, out, len))); }
+    return 0;
 }
 
 extern "C" int uaesk_ctr_xcrypt(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek,

@@ -302,6 +302,46 @@ def test_gcmsiv_vs_oracle(orc, bits):
         assert (rc, txt) == orc.gcmsiv_decrypt(key, nonce, aad, bytes(bad)) and rc == 0x1A    # text released, as the reference does
 
 
+def test_gcmsiv_long_messages_stay_on_the_device(orc):
+    """A GCM-SIV message too long for the one-workgroup kernel: derive_keys, the derived key's expansion, POLYVAL, the
+    tag and the counter made of it run as kernels one behind the other and never visit the host (uaesk_gcmsiv_long:
+    k_siv_prep, the hash-only chunk workgroups with a finisher that makes the tag -- 1 .. 32 positions per thread, as
+    many workgroups as CUs at 2^k blocks -- and the CTR kernel reading schedule and counter from the scratch; beyond
+    one round of workgroups, 128 MiB, the GHASH levels and k_siv_tag).  Device pointers through the C ABI against the
+    oracle: whole ciphertext and tag, decryption in place, a forgery (0x1A, the text released as the reference does)."""
+    import torch
+    L = uaes.engine()
+    rnd = random.Random(8452)
+    shapes = [(128, (8 << 20) - 16, 0), (128, 8 << 20, 0), (192, (8 << 20) + 16, 33), (256, (16 << 20) + 5, 4096),
+              (128, (40 << 20) - 7, 0), (256, (100 << 20) + 3, 20), (128, 128 << 20, 0), (128, (128 << 20) + 16, 1),
+              (192, 2047 * 16, 0), (128, 3 << 20, 1 << 20)]
+    for bits, n, alen in shapes:
+        key, nonce, aad = rnd.randbytes(bits // 8), rnd.randbytes(12), rnd.randbytes(alen)
+        data = np.empty((n + 7) // 8 * 8, dtype=np.uint8)
+        orc.splitmix_into(n % 1009 + 1, data)
+        data = data[:n]
+        want = orc.gcmsiv_encrypt(key, nonce, aad, bytes(data))
+        src = torch.from_numpy(data.copy()).to("cuda:0")
+        dst = torch.full((n + 32,), 0xA5, dtype=torch.uint8, device="cuda:0")
+        a = torch.frombuffer(bytearray(aad), dtype=torch.uint8).to("cuda:0") if alen else None
+        ap = C.c_void_p(a.data_ptr()) if alen else None
+        for _ in range(2):                                             # (the finisher's counter word must be back at zero)
+            assert L.uaes_gcmsiv_encrypt(bits, key, nonce, ap, alen, C.c_void_p(src.data_ptr()), n, C.c_void_p(dst.data_ptr())) == 0
+        got = bytes(dst[: n + 16].cpu().numpy())
+        assert got[-16:] == want[-16:], (bits, n, alen)
+        assert hashlib.sha256(got).digest() == hashlib.sha256(want).digest(), (bits, n, alen)
+        assert int((dst[n + 16:] != 0xA5).sum()) == 0
+        work = dst[: n + 16].clone()                                   # in place
+        assert L.uaes_gcmsiv_decrypt(bits, key, nonce, ap, alen, C.c_void_p(work.data_ptr()), n, C.c_void_p(work.data_ptr())) == 0
+        assert torch.equal(work[:n], src), (bits, n, alen)
+        bad = dst[: n + 16].clone()
+        bad[rnd.randrange(n)] ^= 0x10
+        back = torch.full((n,), 0xCC, dtype=torch.uint8, device="cuda:0")
+        assert L.uaes_gcmsiv_decrypt(bits, key, nonce, ap, alen, C.c_void_p(bad.data_ptr()), n, C.c_void_p(back.data_ptr())) == 0x1A
+        assert int((back != src).sum()) == 1                           # released: CTR of the forged text under the received tag
+        del src, dst, work, bad, back
+
+
 @pytest.mark.parametrize("bits", [128, 256])
 def test_xts_long_data_units(orc, bits):
     """one data unit of many 256-block chunks (the reference API is one unit per call): the chunk
