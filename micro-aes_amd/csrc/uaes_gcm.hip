@@ -1815,8 +1815,9 @@ static u32 log2_u32(u32 v)
 template <int NR>
 static int launch_medium(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek, const uaesk_ctr *c, uint4 j0,
                          const GSrc &src, const void *in, void *out, unsigned char *sc, u32 W, u32 steps, u32 build, int decrypt,
-                         unsigned char *tag_io, int *status, unsigned *done_word, TicketScope &ticket)
+                         unsigned char *tag_io, int *status, unsigned *done_word, TicketScope &ticket, bool hash_only = false)
 {
+    /* hash_only: an encryption without text (GMAC): the hash-only chunk workgroups, the tag written by the finisher */
     uint4 *partial = (uint4 *)(sc + GS_ACC1);
     hipError_t e;
     GmcFin fin;
@@ -1840,10 +1841,10 @@ static int launch_medium(hipStream_t st, const uaesk_tables *tb, const uaesk_rk 
                            (const uint4 *)in, (uint4 *)out, (const unsigned char *)sc, partial, build, steps, fin);  \
     } while (0)
     if (fold) {
-        if (decrypt == 0) GMC_LAUNCH(0, true); else GMC_LAUNCH(1, true);
+        if (decrypt == 0 && !hash_only) GMC_LAUNCH(0, true); else GMC_LAUNCH(1, true);
         return (int)hipGetLastError();
     }
-    if (decrypt == 0) GMC_LAUNCH(0, false); else if (decrypt == 1) GMC_LAUNCH(1, false); else GMC_LAUNCH(2, false);
+    if (decrypt == 0 && !hash_only) GMC_LAUNCH(0, false); else if (decrypt == 1 || hash_only) GMC_LAUNCH(1, false); else GMC_LAUNCH(2, false);
 #undef GMC_LAUNCH
     e = uaesk_want_lds((const void *)k_gcm_combine<NR>, (unsigned)(GHFB_LDS));
     if (e != hipSuccess) return (int)e;
@@ -2304,7 +2305,8 @@ static int gcm_body(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk
     const u32 msteps = medium_steps(nv - 1, medium_cus());     /* (the finisher takes the length block: nv - 1 positions) */
     /* (a decryption that must authenticate first has no one-pass alternative: the chunk workgroups hash it as far as
      * one round of them reaches, 128 MiB on 256 CUs: 16 MiB 92 -> 44 us, 64 MiB 107 -> 96) */
-    if (decrypt != 3 && msteps && (decrypt == 1 || nv - 1 <= medium_max_nv()) && tb->frob) {
+    const bool gmac = len == 0 && decrypt != 3;               /* nothing to encrypt: hash-only chunks whatever the direction */
+    if (decrypt != 3 && msteps && (decrypt == 1 || gmac || nv - 1 <= medium_max_nv()) && tb->frob) {
         /* a medium-sized text: chunk workgroups + finisher (k_gcm_chunks; two launches with k_gcm_combine where the
          * one-launch arrangement cannot be used), tables made in the kernels for a one-shot call.  Decrypt mode 1
          * hashes first and lets the gated CTR kernel write; mode 2 decrypts in the chunk kernel and zeroes the output
@@ -2317,16 +2319,17 @@ static int gcm_body(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk
         GSrc sm = msg;
         sm.ct = (const unsigned char *)in;
         sm.has_len = 0;
+        const int dmode = (gmac && decrypt == 2) ? 1 : decrypt;     /* (without a text there is nothing a one-pass order could write early) */
         unsigned char *tagp = decrypt ? (unsigned char *)in + len : (unsigned char *)out + len;
         switch (nr) {
-        case 10: rc = launch_medium<10>(st, tb, ek, &c, j0, sm, in, out, sc, W, steps, build, decrypt, tagp, status, done_word, ticket); break;
-        case 12: rc = launch_medium<12>(st, tb, ek, &c, j0, sm, in, out, sc, W, steps, build, decrypt, tagp, status, done_word, ticket); break;
-        case 14: rc = launch_medium<14>(st, tb, ek, &c, j0, sm, in, out, sc, W, steps, build, decrypt, tagp, status, done_word, ticket); break;
+        case 10: rc = launch_medium<10>(st, tb, ek, &c, j0, sm, in, out, sc, W, steps, build, dmode, tagp, status, done_word, ticket, gmac && !decrypt); break;
+        case 12: rc = launch_medium<12>(st, tb, ek, &c, j0, sm, in, out, sc, W, steps, build, dmode, tagp, status, done_word, ticket, gmac && !decrypt); break;
+        case 14: rc = launch_medium<14>(st, tb, ek, &c, j0, sm, in, out, sc, W, steps, build, dmode, tagp, status, done_word, ticket, gmac && !decrypt); break;
         default: return (int)hipErrorInvalidValue;
         }
-        if (rc && decrypt == 2) (void)hipMemsetAsync(out, 0, len, st);   /* the chunk kernel may have been enqueued: see above */
+        if (rc && dmode == 2) (void)hipMemsetAsync(out, 0, len, st);   /* the chunk kernel may have been enqueued: see above */
         if (rc || !decrypt) return rc;
-        if (decrypt == 1) return uaesk_ctr_xcrypt(stream, tb, nr, ek, &c, in, out, len, status);
+        if (dmode == 1) return uaesk_ctr_xcrypt(stream, tb, nr, ek, &c, in, out, len, status);
         return rc;                             /* mode 2: the combine kernel takes a forgery's plaintext back itself */
     }
     if (keyed && pl.logA == 0) {               /* every table this text needs is in the key context */

@@ -1196,8 +1196,9 @@ def test_gcm_chunk_and_combine_kernels(orc, bits):
     B = 16
     shapes = [(2046 * B, 0), (2047 * B, 0), (2047 * B + 1, 0), (4095 * B, 0), (4095 * B - 7, 32), (100, 4094 * B), (6000 * B + 3, 5000),
               (255 * 2048 * B - B, 0), (256 * 2048 * B - B, 0), (256 * 2048 * B, 0), (256 * 2048 * B + B, 13)]
+    shapes += [(0, 2047 * B), (0, (3 << 20) + 5)]             # no text at all (GMAC): hash-only chunk workgroups, both directions
     if bits == 128:
-        shapes += [(512 * 2048 * B - B, 0), (512 * 2048 * B, 16), (1024 * 2048 * B - B, 0), (1024 * 2048 * B, 0)]
+        shapes += [(512 * 2048 * B - B, 0), (512 * 2048 * B, 16), (1024 * 2048 * B - B, 0), (1024 * 2048 * B, 0), (0, 40 << 20)]
     try:
         for n, alen in shapes:
             nonce, aad = rnd.randbytes(12), rnd.randbytes(alen)
