@@ -2138,7 +2138,7 @@ static u64 medium_max_nv(void)
 {
     static const u64 w = [] {                          /* initialised once, thread-safe */
         const char *e = getenv("UAES_GCM_MEDIUM_MAX_KIB");
-        long long v = e ? atoll(e) : 16384;
+        long long v = e ? atoll(e) : 32768;
         if (v < 16) v = 16;
         if (v > (1ll << 21)) v = 1ll << 21;
         return (u64)v * 64u;
