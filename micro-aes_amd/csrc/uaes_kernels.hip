@@ -1163,7 +1163,11 @@ static int launch_xts(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *k1
     uint4 raw = make_uint4(0, 0, 0, 0);
     if (tweak16) memcpy(&raw, tweak16, 16);
     /* one unit of up to 4 MiB, or up to 4 MiB of whole-block units numbered from first_sector: one launch (k_xts_small) */
-    const bool one_unit = nsectors == 1 && mb > 0 && cps <= XTS_SMALL_CHUNKS;
+    /* (UAES_XTS_SMALL_CHUNKS: measurement -- how long a single unit stays on the one-launch kernel, one block per lane
+     * and a run loop, before the pre-pass + expand + bulk kernel's four blocks per lane win: 8 MiB, two runs per wave
+     * -- 5 MiB 27.2 -> 23.8 us, 8 MiB 31.5 -> 28.5, 12 MiB 32.3 against 39.8; profiles/r05_xts_small_limit.log) */
+    static const int small_chunks = env_int_clamped("UAES_XTS_SMALL_CHUNKS", 2 * (int)XTS_SMALL_CHUNKS, 1, 1 << 16);
+    const bool one_unit = nsectors == 1 && mb > 0 && cps <= (u64)small_chunks;
     const bool few_units = nsectors > 1 && !tweak16 && r == 0 && mb > 0 &&
                            (u64)nsectors * ((mb + 63) / 64) <= 4ull * XTS_SMALL_CHUNKS;
     if (one_unit || few_units) {

@@ -14,7 +14,9 @@ if os.environ.get("UAES_LIB"):                      # A/B against another build 
     uaes.lib_path.__defaults__ = (os.environ["UAES_LIB"],)
 keys = bytes(range(32))
 print("%9s  %10s %10s %10s" % ("bytes", "ecb", "xts enc", "xts dec"))
-for n in (16, 4096, 16384, 32768, 65536, 131072, 262144, 262144 + 16, 524288, 1 << 20, 4 << 20, 65536 + 7):
+SIZES = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else \
+    (16, 4096, 16384, 32768, 65536, 131072, 262144, 262144 + 16, 524288, 1 << 20, 4 << 20, 65536 + 7)
+for n in SIZES:
     src = torch.randint(0, 256, (n + 16,), dtype=torch.uint8, device="cuda")
     dst = torch.empty_like(src)
     row = []
