@@ -2781,12 +2781,14 @@ extern "C" int uaesk_gcm_stream_piece(void *stream, const uaesk_tables *tb, int 
     const u32 c0 = (u32)c.v0 & 0xffu;
     const u64 h0 = (256u - c0) & 255u, g_lo = c0 ? 1 : 0;
     const u64 groups = (c0 + nfull) / 256, n8 = groups > g_lo ? (groups - g_lo) / 8 : 0;
-    if (!(((u64)1 << logF) == Sl && logF <= GF_MAXLOG && n8 >= (u64)cus && h0 <= Sl && !ctr_stripes_cross_a(&c, g_lo, n8))) {
-        const u64 nvp = ((u64)len + 15) >> 4;
-        const u32 steps = medium_steps(nvp, cus);
-        if (!steps) return 1;
-        const u64 W = (nvp + 1024ull * steps - 1) / (1024ull * steps);
-        if (!(done_word && tb->frob && (*plan_state >> 31) && nvp >= 1024 && W <= (u64)cus)) return 1;
+    const bool striped = ((u64)1 << logF) == Sl && logF <= GF_MAXLOG && n8 >= (u64)cus && h0 <= Sl && !ctr_stripes_cross_a(&c, g_lo, n8);
+    const u64 nvp = ((u64)len + 15) >> 4;
+    const u32 steps = medium_steps(nvp, cus);
+    const u64 W = steps ? (nvp + 1024ull * steps - 1) / (1024ull * steps) : 0;
+    const bool chunks_ok = steps && done_word && tb->frob && (*plan_state >> 31) && nvp >= 1024 && W <= (u64)cus;
+    /* as for a one-shot call: up to 32 MiB the chunk workgroups beat the striped pass and its launches */
+    if (!striped || (chunks_ok && nvp <= medium_max_nv())) {
+        if (!chunks_ok) return 1;
         GSrc src;
         memset(&src, 0, sizeof src);
         src.ct = (const unsigned char *)in; src.ct_len = len;          /* the kernel reads the text itself */

@@ -16,7 +16,7 @@ src = torch.randint(0, 256, (total,), dtype=torch.uint8, device="cuda")
 dst = torch.empty(total, dtype=torch.uint8, device="cuda")
 tag = (C.c_uint8 * 16)()
 print("%10s %12s %12s" % ("piece", "enc GiB/s", "dec GiB/s"))
-for piece in (64 << 10, 1 << 20, 16 << 20, 64 << 20, total):
+for piece in (64 << 10, 1 << 20, 8 << 20, 16 << 20, 32 << 20, 64 << 20, total):
     row = []
     for dec in (0, 1):
         def run():
