@@ -161,7 +161,7 @@ def test_fuzz_aead(orc):
     modes = {
         "gcm": (L.uaes_gcm_encrypt, L.uaes_gcm_decrypt, orc.gcm_encrypt, 300 << 10),
         "ocb": (L.uaes_ocb_encrypt, L.uaes_ocb_decrypt, orc.ocb_encrypt, 2 << 20),
-        "gcmsiv": (L.uaes_gcmsiv_encrypt, L.uaes_gcmsiv_decrypt, orc.gcmsiv_encrypt, 40 << 10),
+        "gcmsiv": (L.uaes_gcmsiv_encrypt, L.uaes_gcmsiv_decrypt, orc.gcmsiv_encrypt, 600 << 10),     # (long: uaesk_gcmsiv_long)
     }
 
     def body(rnd, i):
