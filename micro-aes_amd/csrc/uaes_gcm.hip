@@ -1560,18 +1560,48 @@ __global__ __launch_bounds__(GH_T) void k_gcm_chunks(uaesk_rk rk, uaesk_tables t
         const uint4 *g4 = (const uint4 *)(scratch + GS_TAB4);
         for (u32 i = threadIdx.x; i < GT_NTAB * 512u; i += GH_T) TC[i] = g4[i];
     }
-    fill_tables64(tb.te0, 0);                                 /* ends with a barrier */
     const LaneConst2 lc = make_lane_const2(0);
-    if (build) {                                              /* H = Enc(0): one uniform pass, thread 0 keeps it */
-        if (MODE == 1 && src.rev) {                           /* POLYVAL of a long GCM-SIV message: the key k_siv_prep made */
-            if (threadIdx.x == 0) buf[GT_BUF - 3] = *(const uint4 *)(scratch + GS_SIV_HG);
+    GhLane gl = gh_lane_setup();
+    if (MODE == 1) {
+        /* hash only (a decryption that authenticates first, GMAC, GCM-SIV's POLYVAL): no cipher tables -- their 64 KiB
+         * hold the BYTE table of H^1024 for the stride products (sixteen ds_read_b128 per product where the nibble
+         * table takes thirty-two: the loop's only LDS traffic, so a step costs half), made from nibble table 0 once
+         * the tables are there: T8[v][j] = T4[2j][v >> 4] ^ T4[2j + 1][v & 15]                                    */
+        if (build) {
+            if (src.rev) {                                    /* POLYVAL of a long GCM-SIV message: the key k_siv_prep made */
+                if (threadIdx.x == 0) buf[GT_BUF - 3] = *(const uint4 *)(scratch + GS_SIV_HG);
+            } else {                                          /* H = Enc(0) through an unreplicated Te0 (the table's place) */
+                u32 *te_plain = (u32 *)uaes_lds;
+                if (threadIdx.x < 256u) te_plain[threadIdx.x] = tb.te0[threadIdx.x];
+                __syncthreads();
+                if (threadIdx.x < 64u) {
+                    u32 s1[4] = { 0, 0, 0, 0 };
+                    plain_encrypt<NR>(te_plain, rk, s1);
+                    if (threadIdx.x == 0) buf[GT_BUF - 3] = make_uint4(s1[0], s1[1], s1[2], s1[3]);
+                }
+            }
+            __syncthreads();
+            gcm_build_nibble_tables(TC, buf, tb.frob);        /* ends with a barrier */
         } else {
+            __syncthreads();                                  /* the key context's tables are in */
+        }
+        if (steps > 1) {
+            uint4 *T8 = (uint4 *)uaes_lds;
+            for (u32 e = threadIdx.x; e < 4096u; e += GH_T) {
+                const u32 v = e >> 4, j = e & 15u;
+                T8[e] = x4(TC[nib_entry(2u * j, v >> 4)], TC[nib_entry(2u * j + 1u, v & 15u)]);
+            }
+            __syncthreads();
+        }
+    } else {
+        fill_tables64(tb.te0, 0);                             /* ends with a barrier */
+        if (build) {                                          /* H = Enc(0): one uniform pass, thread 0 keeps it */
             u32 s1[1][4] = { { 0, 0, 0, 0 } };
             enc_blocks<NR, 1>(s1, rk, lc);
             if (threadIdx.x == 0) buf[GT_BUF - 3] = make_uint4(s1[0][0], s1[0][1], s1[0][2], s1[0][3]);
+            __syncthreads();
+            gcm_build_nibble_tables(TC, buf, tb.frob);
         }
-        __syncthreads();
-        gcm_build_nibble_tables(TC, buf, tb.frob);
     }
     const u64 len = src.ct_len;
     const u64 ablk = (src.aad_len + 15) >> 4, cblk = (len + 15) >> 4, nv = ablk + cblk + (src.has_len ? 1u : 0u);
@@ -1583,8 +1613,39 @@ __global__ __launch_bounds__(GH_T) void k_gcm_chunks(uaesk_rk rk, uaesk_tables t
      * (table 0), steps = 1, 2, 4 ... so that the chunk length stays a power of two (the finisher's Y = H^chunk is a
      * Frobenius power) and one round of workgroups covers the text */
     uint4 acc = make_uint4(0, 0, 0, 0);
-    for (u32 k = 0; k < steps; ++k) {
-        if (k) {                                              /* (first, while little else is live; an opaque copy of the
+    if (MODE == 1) {
+        /* hash only: the step's block is all a step needs from memory, so the blocks of up to four steps are requested
+         * ahead of the dependent products (as k_ghash_pass does) */
+        auto load_x = [&](u32 k) -> uint4 {
+            const u64 P = chunk * wg + (u64)k * GH_T + threadIdx.x;
+            if (P < pad) return make_uint4(0, 0, 0, 0);
+            const u64 v = P - pad;
+            if (v >= ablk && v < ablk + cblk) {
+                const u64 i = v - ablk, avail = len - 16 * i;
+                const uint4 d = avail >= 16 ? in[i] : load_bytes_padded((const unsigned char *)(in + i), (u32)avail);
+                return src.rev ? rev16(d) : d;
+            }
+            return load_vblock(rest, v < ablk ? v : ablk);    /* (byte-reversed for POLYVAL) */
+        };
+        if (steps < 4) {
+            const uint4 x0 = load_x(0);
+            uint4 x1 = make_uint4(0, 0, 0, 0);
+            if (steps == 2) x1 = load_x(1);
+            acc = x0;
+            if (steps == 2) acc = tabmul8_xor(acc, x1, gl);
+        } else {
+            for (u32 k = 0; k < steps; k += 4) {
+                uint4 x[4];
+#pragma unroll
+                for (u32 p = 0; p < 4; ++p) x[p] = load_x(k + p);
+                acc = k ? tabmul8_xor(acc, x[0], gl) : x[0];  /* acc * H^1024 ^ x through the byte table at LDS 0 */
+#pragma unroll
+                for (u32 p = 1; p < 4; ++p) acc = tabmul8_xor(acc, x[p], gl);
+            }
+        }
+    }
+    for (u32 k = 0; MODE != 1 && k < steps; ++k) {
+        if (k) {                                 /* (first, while little else is live; an opaque copy of the
                                                                * thread number, or tabmul4's sixteen slot constants are
                                                                * hoisted out of the loop and spilled) */
             u32 tid = threadIdx.x;
