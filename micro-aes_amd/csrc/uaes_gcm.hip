@@ -2199,12 +2199,23 @@ static u64 medium_max_nv(void)
 {
     static const u64 w = [] {                          /* initialised once, thread-safe */
         const char *e = getenv("UAES_GCM_MEDIUM_MAX_KIB");
-        long long v = e ? atoll(e) : 32768;
+        long long v = e ? atoll(e) : 16384;
         if (v < 16) v = 16;
         if (v > (1ll << 21)) v = 1ll << 21;
         return (u64)v * 64u;
     }();
     return w;
+}
+
+/* Past that size an encryption runs in TWO PHASES as far as one round of chunk workgroups reaches (128 MiB on 256 CUs):
+ * the CTR kernel of the bulk path (shared rounds, 1600 GiB/s), then the hash-only chunk workgroups + finisher over the
+ * ciphertext (byte-table stride products, ~3 TB/s of reads, mostly out of the last-level cache the CTR kernel just
+ * filled) -- two launches against the striped one-pass kernel's three (setup, pass, last levels) with their 35-40 us of
+ * fixed cost: 64 MiB 84 -> 75 us.  UAES_GCM_TWOPHASE=0 switches it off (measurement).                            */
+static bool medium_twophase(void)
+{
+    static const bool on = [] { const char *e = getenv("UAES_GCM_TWOPHASE"); return !(e && e[0] == '0'); }();
+    return on;
 }
 
 /* the smallest power of two of positions per thread with which the W chunk workgroups are one round on `cus` CUs; 0:
@@ -2288,7 +2299,7 @@ static int gcm_body(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk
         const u64 groups = (c0 + nfull) / 256, n8 = groups > g_lo ? (groups - g_lo) / 8 : 0;
         if (Sl && ((u64)1 << logF) == Sl && logF <= GF_MAXLOG && n8 >= (u64)cus && ablk + h0 <= Sl &&
             !ctr_stripes_cross_a(&c, g_lo, n8) &&      /* (one in 2^40 blocks: the two-pass path, whose CTR kernel cuts there) */
-            !(tb->frob && nv - 1 <= medium_max_nv() && medium_steps(nv - 1, medium_cus()))) {
+            !(tb->frob && medium_steps(nv - 1, medium_cus()) && ((!decrypt && medium_twophase()) || nv - 1 <= medium_max_nv()))) {
             const u64 h1 = h0 + 2048 * n8;
             GSrc fin;                                   /* [T][tail][lengths] */
             fin.aad = sc + GS_T; fin.aad_len = 16;
@@ -2367,7 +2378,7 @@ static int gcm_body(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk
     /* (a decryption that must authenticate first has no one-pass alternative: the chunk workgroups hash it as far as
      * one round of them reaches, 128 MiB on 256 CUs: 16 MiB 92 -> 44 us, 64 MiB 107 -> 96) */
     const bool gmac = len == 0 && decrypt != 3;               /* nothing to encrypt: hash-only chunks whatever the direction */
-    if (decrypt != 3 && msteps && (decrypt == 1 || gmac || nv - 1 <= medium_max_nv()) && tb->frob) {
+    if (decrypt != 3 && msteps && (decrypt == 1 || gmac || nv - 1 <= medium_max_nv() || (!decrypt && medium_twophase())) && tb->frob) {
         /* a medium-sized text: chunk workgroups + finisher (k_gcm_chunks; two launches with k_gcm_combine where the
          * one-launch arrangement cannot be used), tables made in the kernels for a one-shot call.  Decrypt mode 1
          * hashes first and lets the gated CTR kernel write; mode 2 decrypts in the chunk kernel and zeroes the output
@@ -2380,12 +2391,23 @@ static int gcm_body(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk
         GSrc sm = msg;
         sm.ct = (const unsigned char *)in;
         sm.has_len = 0;
-        const int dmode = (gmac && decrypt == 2) ? 1 : decrypt;     /* (without a text there is nothing a one-pass order could write early) */
+        /* two phases past medium_max_nv(): an encryption runs the bulk CTR kernel and then hashes its OUTPUT with the
+         * hash-only chunks (a one-pass decryption keeps the striped kernel there: its contract is a ZEROED output on a
+         * forgery, which the tag-first order would leave untouched) */
+        const bool two = !gmac && !decrypt && nv - 1 > medium_max_nv();
+        const int dmode = (gmac && decrypt == 2) ? 1 : decrypt;   /* (without a text there is nothing a one-pass order could write early) */
+        const bool hash_only = (gmac || two) && !decrypt;
+        const void *text = in;
+        if (two && !decrypt) {
+            if ((rc = uaesk_ctr_xcrypt(stream, tb, nr, ek, &c, in, out, len, nullptr)) != 0) return rc;
+            sm.ct = (const unsigned char *)out;
+            text = out;
+        }
         unsigned char *tagp = decrypt ? (unsigned char *)in + len : (unsigned char *)out + len;
         switch (nr) {
-        case 10: rc = launch_medium<10>(st, tb, ek, &c, j0, sm, in, out, sc, W, steps, build, dmode, tagp, status, done_word, ticket, gmac && !decrypt); break;
-        case 12: rc = launch_medium<12>(st, tb, ek, &c, j0, sm, in, out, sc, W, steps, build, dmode, tagp, status, done_word, ticket, gmac && !decrypt); break;
-        case 14: rc = launch_medium<14>(st, tb, ek, &c, j0, sm, in, out, sc, W, steps, build, dmode, tagp, status, done_word, ticket, gmac && !decrypt); break;
+        case 10: rc = launch_medium<10>(st, tb, ek, &c, j0, sm, text, out, sc, W, steps, build, dmode, tagp, status, done_word, ticket, hash_only); break;
+        case 12: rc = launch_medium<12>(st, tb, ek, &c, j0, sm, text, out, sc, W, steps, build, dmode, tagp, status, done_word, ticket, hash_only); break;
+        case 14: rc = launch_medium<14>(st, tb, ek, &c, j0, sm, text, out, sc, W, steps, build, dmode, tagp, status, done_word, ticket, hash_only); break;
         default: return (int)hipErrorInvalidValue;
         }
         if (rc && dmode == 2) (void)hipMemsetAsync(out, 0, len, st);   /* the chunk kernel may have been enqueued: see above */
