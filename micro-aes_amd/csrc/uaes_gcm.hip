@@ -2813,11 +2813,16 @@ extern "C" int uaesk_gcm_stream_absorb(void *stream, const uaesk_tables *tb, int
  * plan_state bit 9: the striped kernel's tables of this key are in the scratch.                                 */
 template <int NR>
 static int launch_stream_chunks(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek, const uaesk_ctr *c, const GSrc &src,
-                                const void *in, void *out, unsigned char *sc, u32 W, u32 steps, int decrypt, const GmcFin &fin)
+                                const void *in, void *out, unsigned char *sc, u32 W, u32 steps, int decrypt, const GmcFin &fin,
+                                bool hash_only = false)
 {
     hipError_t e;
     uint4 *partial = (uint4 *)(sc + GS_ACC1);
-    if (decrypt) {
+    if (hash_only) {                                          /* `in` = the piece's CIPHERTEXT; nothing is written */
+        if ((e = uaesk_want_lds((const void *)k_gcm_chunks<NR, 1, true>, (unsigned)(GSM_LDS_TOTAL))) != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((k_gcm_chunks<NR, 1, true>), dim3(W + 1u), dim3(GH_T), GSM_LDS_TOTAL, st, *ek, *tb, *c, src,
+                           (const uint4 *)in, (uint4 *)out, (const unsigned char *)sc, partial, 0u, steps, fin);
+    } else if (decrypt) {
         if ((e = uaesk_want_lds((const void *)k_gcm_chunks<NR, 2, true>, (unsigned)(GSM_LDS_TOTAL))) != hipSuccess) return (int)e;
         hipLaunchKernelGGL((k_gcm_chunks<NR, 2, true>), dim3(W + 1u), dim3(GH_T), GSM_LDS_TOTAL, st, *ek, *tb, *c, src,
                            (const uint4 *)in, (uint4 *)out, (const unsigned char *)sc, partial, 0u, steps, fin);
@@ -2869,21 +2874,33 @@ extern "C" int uaesk_gcm_stream_piece(void *stream, const uaesk_tables *tb, int 
     const u32 steps = medium_steps(nvp, cus);
     const u64 W = steps ? (nvp + 1024ull * steps - 1) / (1024ull * steps) : 0;
     const bool chunks_ok = steps && done_word && tb->frob && (*plan_state >> 31) && nvp >= 1024 && W <= (u64)cus;
-    /* as for a one-shot call: up to 32 MiB the chunk workgroups beat the striped pass and its launches */
-    if (!striped || (chunks_ok && nvp <= medium_max_nv())) {
+    /* as for a one-shot call: up to 16 MiB the chunk workgroups (CTR and GHASH together) beat the striped pass and its
+     * launches, and from there to the end of their round two phases do -- the bulk CTR kernel and the hash-only chunk
+     * workgroups over the piece's ciphertext (a decryption hashes first: in may be out) */
+    if (!striped || (chunks_ok && (nvp <= medium_max_nv() || medium_twophase()))) {
         if (!chunks_ok) return 1;
+        const bool two = nvp > medium_max_nv() && striped;
         GSrc src;
         memset(&src, 0, sizeof src);
         src.ct = (const unsigned char *)in; src.ct_len = len;          /* the kernel reads the text itself */
         GmcFin fin;
         memset(&fin, 0, sizeof fin);
         fin.done_word = done_word; fin.mode = 2; fin.ylog = 10u + log2_u32(steps); fin.fin_build = 1; fin.m = nvp;
+        const void *text = in;
+        int rc = 0;
+        if (two && !decrypt) {
+            if ((rc = uaesk_ctr_xcrypt(stream, tb, nr, ek, &c, in, out, len, nullptr)) != 0) return rc;
+            src.ct = (const unsigned char *)out;
+            text = out;
+        }
         switch (nr) {
-        case 10: return launch_stream_chunks<10>(st, tb, ek, &c, src, in, out, sc, (u32)W, steps, decrypt, fin);
-        case 12: return launch_stream_chunks<12>(st, tb, ek, &c, src, in, out, sc, (u32)W, steps, decrypt, fin);
-        case 14: return launch_stream_chunks<14>(st, tb, ek, &c, src, in, out, sc, (u32)W, steps, decrypt, fin);
+        case 10: rc = launch_stream_chunks<10>(st, tb, ek, &c, src, text, out, sc, (u32)W, steps, decrypt, fin, two); break;
+        case 12: rc = launch_stream_chunks<12>(st, tb, ek, &c, src, text, out, sc, (u32)W, steps, decrypt, fin, two); break;
+        case 14: rc = launch_stream_chunks<14>(st, tb, ek, &c, src, text, out, sc, (u32)W, steps, decrypt, fin, two); break;
         default: return (int)hipErrorInvalidValue;
         }
+        if (!rc && two && decrypt) rc = uaesk_ctr_xcrypt(stream, tb, nr, ek, &c, in, out, len, nullptr);
+        return rc;
     }
     const u64 h1 = h0 + 2048 * n8;
     GSrc msg;

@@ -375,7 +375,9 @@ def test_gcm_stream_equals_one_shot(orc, bits):
                             ([40 << 10, 2 << 20, 64, 5 << 20, 2 << 20, 100], 1),    # level plans change back and forth
                             # pieces long enough for the one-pass kernel (8 MiB on 256 CUs) between short ones: its
                             # tables are made once per stream, a later short piece's setup must leave them alone
-                            ([9 << 20, 4096, (17 << 20) + 16, 16, (8 << 20) + 5], 33), ([(12 << 20) + 7], 0)]:
+                            ([9 << 20, 4096, (17 << 20) + 16, 16, (8 << 20) + 5], 33), ([(12 << 20) + 7], 0),
+                            # pieces of 16 .. 128 MiB: two phases (bulk CTR kernel + hash-only chunk workgroups), 2^k blocks too
+                            ([16 << 20, (33 << 20) + 48, 32, 32 << 20, (20 << 20) + 9], 5)][: 11 if bits == 128 else 10]:
         key, nonce, aad = rnd.randbytes(bits // 8), rnd.randbytes(12), rnd.randbytes(aad_len)
         n = sum(pieces)
         data = orc.splitmix(n + 11, n)
