@@ -1556,6 +1556,32 @@ __global__ __launch_bounds__(GH_T) void k_gcm_chunks(uaesk_rk rk, uaesk_tables t
     const u32 wg = blockIdx.x, nwg = FOLD ? gridDim.x - 1u : gridDim.x;
     uint4 *TC = (uint4 *)(uaes_lds + GSM_LDS_TAB);
     uint4 *buf = TC + GT_NTAB * 512u;
+    const u64 len = src.ct_len;
+    const u64 ablk = (src.aad_len + 15) >> 4, cblk = (len + 15) >> 4, nv = ablk + cblk + (src.has_len ? 1u : 0u);
+    const u64 chunk = (u64)steps * GH_T;                      /* positions per workgroup: one or two per thread */
+    const u64 pad = chunk * nwg - nv;                   /* zero positions in front of the sequence */
+    GSrc rest = src;                                          /* AAD blocks and the length block */
+    rest.ct_len = 0;
+    /* hash only: the step's block is all a step needs from memory, so the blocks of up to four steps are requested
+     * ahead of the dependent products (as k_ghash_pass does) -- and the first group's HERE, before the tables are made:
+     * they travel beside the 5 us of table building instead of behind it */
+    auto load_x = [&](u32 k) -> uint4 {
+        const u64 P = chunk * wg + (u64)k * GH_T + threadIdx.x;
+        if (P < pad) return make_uint4(0, 0, 0, 0);
+        const u64 v = P - pad;
+        if (v >= ablk && v < ablk + cblk) {
+            const u64 i = v - ablk, avail = len - 16 * i;
+            const uint4 d = avail >= 16 ? in[i] : load_bytes_padded((const unsigned char *)(in + i), (u32)avail);
+            return src.rev ? rev16(d) : d;
+        }
+        return load_vblock(rest, v < ablk ? v : ablk);        /* (byte-reversed for POLYVAL) */
+    };
+    uint4 x0[4] = { make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0) };
+    if (MODE == 1) {
+#pragma unroll
+        for (u32 p = 0; p < 4; ++p)
+            if (p < steps) x0[p] = load_x(p);
+    }
     if (!build) {
         const uint4 *g4 = (const uint4 *)(scratch + GS_TAB4);
         for (u32 i = threadIdx.x; i < GT_NTAB * 512u; i += GH_T) TC[i] = g4[i];
@@ -1603,45 +1629,23 @@ __global__ __launch_bounds__(GH_T) void k_gcm_chunks(uaesk_rk rk, uaesk_tables t
             gcm_build_nibble_tables(TC, buf, tb.frob);
         }
     }
-    const u64 len = src.ct_len;
-    const u64 ablk = (src.aad_len + 15) >> 4, cblk = (len + 15) >> 4, nv = ablk + cblk + (src.has_len ? 1u : 0u);
-    const u64 chunk = (u64)steps * GH_T;                      /* positions per workgroup: one or two per thread */
-    const u64 pad = chunk * nwg - nv;                   /* zero positions in front of the sequence */
-    GSrc rest = src;                                          /* AAD blocks and the length block */
-    rest.ct_len = 0;
     /* position k * 1024 + t of the chunk belongs to thread t: Horner over the thread's own positions with H^1024
      * (table 0), steps = 1, 2, 4 ... so that the chunk length stays a power of two (the finisher's Y = H^chunk is a
      * Frobenius power) and one round of workgroups covers the text */
     uint4 acc = make_uint4(0, 0, 0, 0);
     if (MODE == 1) {
-        /* hash only: the step's block is all a step needs from memory, so the blocks of up to four steps are requested
-         * ahead of the dependent products (as k_ghash_pass does) */
-        auto load_x = [&](u32 k) -> uint4 {
-            const u64 P = chunk * wg + (u64)k * GH_T + threadIdx.x;
-            if (P < pad) return make_uint4(0, 0, 0, 0);
-            const u64 v = P - pad;
-            if (v >= ablk && v < ablk + cblk) {
-                const u64 i = v - ablk, avail = len - 16 * i;
-                const uint4 d = avail >= 16 ? in[i] : load_bytes_padded((const unsigned char *)(in + i), (u32)avail);
-                return src.rev ? rev16(d) : d;
-            }
-            return load_vblock(rest, v < ablk ? v : ablk);    /* (byte-reversed for POLYVAL) */
-        };
-        if (steps < 4) {
-            const uint4 x0 = load_x(0);
-            uint4 x1 = make_uint4(0, 0, 0, 0);
-            if (steps == 2) x1 = load_x(1);
-            acc = x0;
-            if (steps == 2) acc = tabmul8_xor(acc, x1, gl);
-        } else {
-            for (u32 k = 0; k < steps; k += 4) {
-                uint4 x[4];
+        acc = x0[0];
+        if (steps >= 2) acc = tabmul8_xor(acc, x0[1], gl);    /* acc * H^1024 ^ x through the byte table at LDS 0 */
+        if (steps >= 4) {
+            acc = tabmul8_xor(acc, x0[2], gl);
+            acc = tabmul8_xor(acc, x0[3], gl);
+        }
+        for (u32 k = 4; k < steps; k += 4) {
+            uint4 x[4];
 #pragma unroll
-                for (u32 p = 0; p < 4; ++p) x[p] = load_x(k + p);
-                acc = k ? tabmul8_xor(acc, x[0], gl) : x[0];  /* acc * H^1024 ^ x through the byte table at LDS 0 */
+            for (u32 p = 0; p < 4; ++p) x[p] = load_x(k + p);
 #pragma unroll
-                for (u32 p = 1; p < 4; ++p) acc = tabmul8_xor(acc, x[p], gl);
-            }
+            for (u32 p = 0; p < 4; ++p) acc = tabmul8_xor(acc, x[p], gl);
         }
     }
     for (u32 k = 0; MODE != 1 && k < steps; ++k) {
