@@ -2303,7 +2303,7 @@ static int gcm_body(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk
         const u64 groups = (c0 + nfull) / 256, n8 = groups > g_lo ? (groups - g_lo) / 8 : 0;
         if (Sl && ((u64)1 << logF) == Sl && logF <= GF_MAXLOG && n8 >= (u64)cus && ablk + h0 <= Sl &&
             !ctr_stripes_cross_a(&c, g_lo, n8) &&      /* (one in 2^40 blocks: the two-pass path, whose CTR kernel cuts there) */
-            !(tb->frob && medium_steps(nv - 1, medium_cus()) && ((!decrypt && medium_twophase()) || nv - 1 <= medium_max_nv()))) {
+            !(tb->frob && medium_steps(nv - 1, medium_cus()) && (medium_twophase() || nv - 1 <= medium_max_nv()))) {
             const u64 h1 = h0 + 2048 * n8;
             GSrc fin;                                   /* [T][tail][lengths] */
             fin.aad = sc + GS_T; fin.aad_len = 16;
@@ -2382,7 +2382,7 @@ static int gcm_body(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk
     /* (a decryption that must authenticate first has no one-pass alternative: the chunk workgroups hash it as far as
      * one round of them reaches, 128 MiB on 256 CUs: 16 MiB 92 -> 44 us, 64 MiB 107 -> 96) */
     const bool gmac = len == 0 && decrypt != 3;               /* nothing to encrypt: hash-only chunks whatever the direction */
-    if (decrypt != 3 && msteps && (decrypt == 1 || gmac || nv - 1 <= medium_max_nv() || (!decrypt && medium_twophase())) && tb->frob) {
+    if (decrypt != 3 && msteps && (decrypt == 1 || gmac || nv - 1 <= medium_max_nv() || medium_twophase()) && tb->frob) {
         /* a medium-sized text: chunk workgroups + finisher (k_gcm_chunks; two launches with k_gcm_combine where the
          * one-launch arrangement cannot be used), tables made in the kernels for a one-shot call.  Decrypt mode 1
          * hashes first and lets the gated CTR kernel write; mode 2 decrypts in the chunk kernel and zeroes the output
@@ -2396,10 +2396,10 @@ static int gcm_body(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk
         sm.ct = (const unsigned char *)in;
         sm.has_len = 0;
         /* two phases past medium_max_nv(): an encryption runs the bulk CTR kernel and then hashes its OUTPUT with the
-         * hash-only chunks (a one-pass decryption keeps the striped kernel there: its contract is a ZEROED output on a
-         * forgery, which the tag-first order would leave untouched) */
-        const bool two = !gmac && !decrypt && nv - 1 > medium_max_nv();
-        const int dmode = (gmac && decrypt == 2) ? 1 : decrypt;   /* (without a text there is nothing a one-pass order could write early) */
+         * hash-only chunks; a one-pass decryption takes the tag-first order there (the faster one in this range) and
+         * keeps its contract -- a ZEROED output on a forgery -- with the wipe kernel the striped order launches too */
+        const bool two = !gmac && decrypt != 1 && nv - 1 > medium_max_nv();
+        const int dmode = ((gmac || two) && decrypt == 2) ? 1 : decrypt;   /* (without a text there is nothing a one-pass order could write early) */
         const bool hash_only = (gmac || two) && !decrypt;
         const void *text = in;
         if (two && !decrypt) {
@@ -2416,7 +2416,15 @@ static int gcm_body(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk
         }
         if (rc && dmode == 2) (void)hipMemsetAsync(out, 0, len, st);   /* the chunk kernel may have been enqueued: see above */
         if (rc || !decrypt) return rc;
-        if (dmode == 1) return uaesk_ctr_xcrypt(stream, tb, nr, ek, &c, in, out, len, status);
+        if (dmode == 1) {
+            rc = uaesk_ctr_xcrypt(stream, tb, nr, ek, &c, in, out, len, status);
+            if (!rc && two && decrypt == 2) {                    /* the one-pass contract: zeroed on a forgery */
+                hipLaunchKernelGGL(k_wipe_if_failed, dim3((unsigned)medium_cus() * 2u), dim3(1024), 0, st, status,
+                                   (unsigned char *)out, (u64)len);
+                rc = (int)hipGetLastError();
+            }
+            return rc;
+        }
         return rc;                             /* mode 2: the combine kernel takes a forgery's plaintext back itself */
     }
     if (keyed && pl.logA == 0) {               /* every table this text needs is in the key context */
