@@ -62,9 +62,9 @@
 #define GS_ZHI      (GS_YLO + 256u)                 /* Z^0..Z^15, Z = Y^16                           */
 #define GS_T        (GS_ZHI + 256u)                 /* XOR of the workgroups' weighted partial hashes */
 #define GS_YTAB     (GS_T + 64u)                    /* key contexts: the combine kernel's nibble tables of Y^256 .. Y, 40 KiB
-                                                       each for Y = H^1024, H^2048 .. H^32768 (k_gcm_ytables)                */
+                                                       each for Y = H^1024, H^2048 .. H^131072 (k_gcm_ytables)                */
 #define GS_YTAB_SET (5u * 8192u)
-#define GS_YTAB_SETS 6u                         /* Y = H^1024 .. H^32768 (GMC_MAXLOGSTEPS + 1) */
+#define GS_YTAB_SETS 8u                         /* Y = H^1024 .. H^131072 (GMC_MAXLOGSTEPS + 1) */
 #define GS_SIV      (GS_YTAB + GS_YTAB_SETS * GS_YTAB_SET)   /* a long GCM-SIV message's per-nonce values, made and used on the device: */
 #define GS_SIV_RK   GS_SIV                          /*   the message-encryption key's schedule (uaesk_rk, 240 B) */
 #define GS_SIV_HG   (GS_SIV + 256u)                 /*   the POLYVAL key in GHASH form                           */
@@ -2198,7 +2198,19 @@ extern "C" int uaesk_gcm_j0(void *stream, const uaesk_tables *tb, int nr, const 
  * kernel, whose three launches cost ~35 us whatever the size; UAES_GCM_MEDIUM_MAX_KIB overrides it
  * (tools/gcm_size_sweep.py).  A workgroup takes 1024 * steps positions, steps a power of two chosen so that ONE round
  * of workgroups (and the finisher) covers the text: medium_steps().                                              */
-#define GMC_MAXLOGSTEPS 5u                      /* chunks of up to 32 768 positions: 127 MiB on 256 CUs */
+#define GMC_MAXLOGSTEPS 7u                      /* chunks of up to 131 072 positions: 512 MiB on 256 CUs (hash only) */
+#define GMC_TWOPHASE_MAX_NV ((u64)1 << 23)      /* an ENCRYPTION in two phases pays up to 128 MiB: past that the second pass no
+                                                 * longer finds the ciphertext in the last-level cache and the striped one-pass
+                                                 * kernel wins */
+static u32 medium_maxlogsteps(void)             /* UAES_GCM_MAXLOGSTEPS: tests reach the fallbacks with it */
+{
+    static const u32 v = [] {
+        const char *e = getenv("UAES_GCM_MAXLOGSTEPS");
+        long x = e ? atol(e) : (long)GMC_MAXLOGSTEPS;
+        return (u32)(x < 0 ? 0 : x > (long)GMC_MAXLOGSTEPS ? (long)GMC_MAXLOGSTEPS : x);
+    }();
+    return v;
+}
 static u64 medium_max_nv(void)
 {
     static const u64 w = [] {                          /* initialised once, thread-safe */
@@ -2216,10 +2228,10 @@ static u64 medium_max_nv(void)
  * ciphertext (byte-table stride products, ~3 TB/s of reads, mostly out of the last-level cache the CTR kernel just
  * filled) -- two launches against the striped one-pass kernel's three (setup, pass, last levels) with their 35-40 us of
  * fixed cost: 64 MiB 84 -> 75 us.  UAES_GCM_TWOPHASE=0 switches it off (measurement).                            */
-static bool medium_twophase(void)
+static bool medium_twophase(u64 nv)
 {
     static const bool on = [] { const char *e = getenv("UAES_GCM_TWOPHASE"); return !(e && e[0] == '0'); }();
-    return on;
+    return on && nv <= GMC_TWOPHASE_MAX_NV;
 }
 
 /* the smallest power of two of positions per thread with which the W chunk workgroups are one round on `cus` CUs; 0:
@@ -2230,7 +2242,7 @@ static bool medium_twophase(void)
 static u32 medium_steps(u64 nv, int cus)
 {
     if (cus < 2) return 0;
-    for (u32 lg = 0; lg <= GMC_MAXLOGSTEPS; ++lg)
+    for (u32 lg = 0; lg <= medium_maxlogsteps(); ++lg)
         if ((nv + (1024ull << lg) - 1) / (1024ull << lg) <= (u64)cus) return 1u << lg;
     return 0;
 }
@@ -2303,7 +2315,7 @@ static int gcm_body(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk
         const u64 groups = (c0 + nfull) / 256, n8 = groups > g_lo ? (groups - g_lo) / 8 : 0;
         if (Sl && ((u64)1 << logF) == Sl && logF <= GF_MAXLOG && n8 >= (u64)cus && ablk + h0 <= Sl &&
             !ctr_stripes_cross_a(&c, g_lo, n8) &&      /* (one in 2^40 blocks: the two-pass path, whose CTR kernel cuts there) */
-            !(tb->frob && medium_steps(nv - 1, medium_cus()) && (medium_twophase() || nv - 1 <= medium_max_nv()))) {
+            !(tb->frob && medium_steps(nv - 1, medium_cus()) && (medium_twophase(nv - 1) || nv - 1 <= medium_max_nv()))) {
             const u64 h1 = h0 + 2048 * n8;
             GSrc fin;                                   /* [T][tail][lengths] */
             fin.aad = sc + GS_T; fin.aad_len = 16;
@@ -2382,7 +2394,7 @@ static int gcm_body(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk
     /* (a decryption that must authenticate first has no one-pass alternative: the chunk workgroups hash it as far as
      * one round of them reaches, 128 MiB on 256 CUs: 16 MiB 92 -> 44 us, 64 MiB 107 -> 96) */
     const bool gmac = len == 0 && decrypt != 3;               /* nothing to encrypt: hash-only chunks whatever the direction */
-    if (decrypt != 3 && msteps && (decrypt == 1 || gmac || nv - 1 <= medium_max_nv() || medium_twophase()) && tb->frob) {
+    if (decrypt != 3 && msteps && (decrypt == 1 || gmac || nv - 1 <= medium_max_nv() || medium_twophase(nv - 1)) && tb->frob) {
         /* a medium-sized text: chunk workgroups + finisher (k_gcm_chunks; two launches with k_gcm_combine where the
          * one-launch arrangement cannot be used), tables made in the kernels for a one-shot call.  Decrypt mode 1
          * hashes first and lets the gated CTR kernel write; mode 2 decrypts in the chunk kernel and zeroes the output
@@ -2889,7 +2901,7 @@ extern "C" int uaesk_gcm_stream_piece(void *stream, const uaesk_tables *tb, int 
     /* as for a one-shot call: up to 16 MiB the chunk workgroups (CTR and GHASH together) beat the striped pass and its
      * launches, and from there to the end of their round two phases do -- the bulk CTR kernel and the hash-only chunk
      * workgroups over the piece's ciphertext (a decryption hashes first: in may be out) */
-    if (!striped || (chunks_ok && (nvp <= medium_max_nv() || medium_twophase()))) {
+    if (!striped || (chunks_ok && (nvp <= medium_max_nv() || medium_twophase(nvp)))) {
         if (!chunks_ok) return 1;
         const bool two = nvp > medium_max_nv() && striped;
         GSrc src;

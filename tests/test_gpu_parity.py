@@ -302,6 +302,38 @@ def test_gcmsiv_vs_oracle(orc, bits):
         assert (rc, txt) == orc.gcmsiv_decrypt(key, nonce, aad, bytes(bad)) and rc == 0x1A    # text released, as the reference does
 
 
+def test_paths_behind_the_chunk_workgroups_still_hold(orc):
+    """What a text takes when one round of chunk workgroups does not reach it -- GCM's setup / GHASH levels / last levels
+    for a tag-first decryption and a GMAC, the striped kernel for an encryption, GCM-SIV's POLYVAL by the levels with
+    k_siv_tag -- is beyond 512 MiB on an MI355X now.  UAES_GCM_MAXLOGSTEPS=0 (one position per thread: 4 MiB) brings
+    those paths down to sizes the oracle checks in a second."""
+    import subprocess
+    import sys
+    code = r"""
+import sys, hashlib
+sys.path.insert(0, %r)
+import micro_aes_amd as uaes
+from oracle.pyoracle import Oracle
+orc = Oracle()
+key, n12 = bytes(range(32)), bytes(range(12))
+for n, aad in (((6 << 20) + 5, b"abc"), (9 << 20, b""), (0, bytes(5 << 20))):
+    d = orc.splitmix(n + 1, n)
+    want = orc.gcm_encrypt(key, n12, aad, d)
+    assert uaes.AES_GCM_encrypt(key, n12, aad, d) == want, n
+    assert uaes.AES_GCM_decrypt(key, n12, aad, want) == (0, d), n
+    bad = bytearray(want); bad[len(bad) // 2] ^= 1
+    assert uaes.AES_GCM_decrypt(key, n12, aad, bytes(bad))[0] == 0x1A
+    if n:
+        ws = orc.gcmsiv_encrypt(key, n12, aad, d)
+        assert uaes.GCM_SIV_encrypt(key, n12, aad, d) == ws, n
+        assert uaes.GCM_SIV_decrypt(key, n12, aad, ws) == (0, d), n
+print("ok")
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, UAES_GCM_MAXLOGSTEPS="0"), capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.split()[-1] == "ok", r.stderr[-2000:]
+
+
 def test_gcmsiv_long_messages_stay_on_the_device(orc):
     """A GCM-SIV message too long for the one-workgroup kernel: derive_keys, the derived key's expansion, POLYVAL, the
     tag and the counter made of it run as kernels one behind the other and never visit the host (uaesk_gcmsiv_long:
@@ -1144,8 +1176,8 @@ def test_gcm_single_launch_sizes(orc, bits):
 
 def test_gcm_long_texts_hashed_by_chunk_workgroups(orc):
     """A decryption that authenticates first (N7) hashes its ciphertext with the chunk workgroups + finisher as far as
-    ONE round of workgroups reaches (1024 * 2^k positions per workgroup, k <= 5: 128 MiB on 256 CUs), and an
-    encryption does up to 16 MiB.  The sizes the oracle finishes in seconds are in test_gcm_chunk_and_combine_kernels;
+    ONE round of workgroups reaches (1024 * 2^k positions per workgroup, k <= 7: 512 MiB on 256 CUs), and an
+    encryption does up to 16 MiB (two phases up to 128 MiB).  The sizes the oracle finishes in seconds are in test_gcm_chunk_and_combine_kernels;
     here the longer ones are pinned through the OTHER arrangement: the striped one-pass kernel made the tag (the kernel
     of the C4 digest test), the chunk workgroups must accept it, reject one flipped bit anywhere and leave the output
     alone then -- one-shot and key context (its Y tables for chunks of 4096 .. 32768 positions), with and without AAD,
@@ -1157,7 +1189,8 @@ def test_gcm_long_texts_hashed_by_chunk_workgroups(orc):
     status = torch.full((1,), -1, dtype=torch.int32, device="cuda:0")
     try:
         for n, alen in (((24 << 20) + 5, 0), (32 << 20, 0), ((40 << 20) - 16, 7), (64 << 20, 0), ((64 << 20) + 16, 4096),
-                        ((100 << 20) + 3, 0), (128 << 20, 0), ((128 << 20) - 4096, 33)):
+                        ((100 << 20) + 3, 0), (128 << 20, 0), ((128 << 20) - 4096, 33),
+                        ((200 << 20) + 3, 0), (512 << 20, 0)):                  # hash only: 64 and 128 positions per thread
             src = torch.randint(0, 256, (n,), dtype=torch.uint8, device="cuda:0")
             a = torch.randint(0, 256, (alen,), dtype=torch.uint8, device="cuda:0") if alen else None
             ct = torch.empty(n + 16, dtype=torch.uint8, device="cuda:0")
