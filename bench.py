@@ -304,11 +304,13 @@ def setup_collectives(a, torch, rank, world, local, dev):
     return dist, None, torch.device("cpu"), info
 
 
-def resolve_gather_flags(a, world):
+def resolve_gather_flags(a, world, force=False):
     """--gather / --c-gather default ON as soon as there is more than one rank (SURVEY.md 8e "what to report":
-    encrypt-only, encrypt + gather, bit-exactness of the concatenated stream), OFF for the one-GPU line"""
-    gather = (world > 1) if a.gather is None else bool(a.gather)
-    c_gather = (world > 1 and gather) if a.c_gather is None else bool(a.c_gather)
+    encrypt-only, encrypt + gather, bit-exactness of the concatenated stream) or --force-collective asks for the
+    one-rank run of the same code, OFF for the plain one-GPU line"""
+    many = world > 1 or force
+    gather = many if a.gather is None else bool(a.gather)
+    c_gather = (many and gather) if a.c_gather is None else bool(a.c_gather)
     return gather, c_gather and gather
 
 
@@ -433,7 +435,8 @@ def gather_phase(a, torch, dist, cg, rank, world, local, n, dev, dst, step, seed
         return out, False, stuck or rccl
     full, gather_ms, e2e_ms = res
     out["gather_ms"] = round(gather_ms, 3)
-    out["gather_backend"] = ("RCCL all_gather_into_tensor over xGMI (every rank receives the whole stream)" if rccl else
+    out["gather_backend"] = ("RCCL all_gather_into_tensor, ONE rank (--force-collective: the code path, not xGMI)" if rccl and world == 1 else
+                             "RCCL all_gather_into_tensor over xGMI (every rank receives the whole stream)" if rccl else
                              "gloo gather to rank 0 through host memory (RCCL not up: dry run, says nothing about xGMI)")
     out["gather_gib_s"] = round(world * n / GIB / (gather_ms * 1e-3), 2)
     out["encrypt_plus_gather_ms"] = round(e2e_ms, 3)
@@ -464,6 +467,8 @@ def c_gather_phase(a, torch, uaes, rank, world, n, dev, src, dst, seed):
     for d in set(devs):
         torch.cuda.synchronize(d)
     times = []
+    stats0 = (ctypes.c_ulong * 5)()
+    uaes.engine().uaes_debug_gather_stats(stats0)
     for _ in range(2):
         g0 = time.perf_counter()
         rc = uaes.engine().uaes_mgpu_ctr_encrypt_gather(world, (ctypes.c_int * world)(*devs), 128, KEY16, CTR0, 0,
@@ -473,9 +478,15 @@ def c_gather_phase(a, torch, uaes, rank, world, n, dev, src, dst, seed):
         times.append((time.perf_counter() - g0) * 1e3)
         if rc != 0:
             raise RuntimeError(uaes.engine().uaes_last_error().decode())
+    stats1 = (ctypes.c_ulong * 5)()
+    uaes.engine().uaes_debug_gather_stats(stats1)
     res = {"ms_first": round(times[0], 3), "ms": round(times[1], 3), "devices": ndev,
            "gib_s_end_to_end": round(world * n / GIB / (times[1] * 1e-3), 1),
-           "call": "uaes_mgpu_ctr_encrypt_gather (C host, RCCL send/recv to device 0)"}
+           "call": "uaes_mgpu_ctr_encrypt_gather (C host, RCCL send/recv to device 0)",
+           # what RCCL itself was asked to do by the two calls (uaes_debug_gather_stats): 0 sends = every slice was local
+           "rccl_sends": int(stats1[0] - stats0[0]), "rccl_recvs": int(stats1[1] - stats0[1]),
+           "rccl_comm_inits": int(stats1[3] - stats0[3]),
+           "forced_self_send": bool(os.environ.get("UAES_GATHER_FORCE_RCCL"))}
     if not a.no_verify:
         chk = check_gathered_stream(torch, full, world, n, "ctr", seed, False)
         if "gathered_stream_digest_ok" in chk:
@@ -531,6 +542,12 @@ def build_parser():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --single-device: dry-run the multi-rank code path on a 1-GPU box")
     ap.add_argument("--single-device", action="store_true", help="all ranks use cuda:0 (dry run only)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="with --gpus 1: bring the collectives up anyway -- a ONE-rank RCCL process group "
+                         "(init_process_group / new_group(\"nccl\"), world_size 1) carries the barrier, the reductions and "
+                         "the ciphertext all-gather, and the C host's uaes_mgpu_ctr_encrypt_gather sends its slice through "
+                         "ncclSend / ncclRecv to itself (UAES_GATHER_FORCE_RCCL) -- so that a one-GPU box executes the "
+                         "code an 8-GPU run depends on.  Says nothing about xGMI; never part of `value`.")
     return ap
 
 
@@ -556,8 +573,20 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist, cg, cdev, coll_info = None, None, dev, {}
-    if world > 1:
+    force = bool(a.force_collective) and world == 1
+    if force:
+        # a one-rank job has no launcher: give torch.distributed its rendezvous (127.0.0.1, a free port)
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        for k, v in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", str(port))):
+            os.environ.setdefault(k, v)
+        os.environ["UAES_GATHER_FORCE_RCCL"] = "1"          # read by the C host on every gather call
+    if world > 1 or force:
         dist, cg, cdev, coll_info = setup_collectives(a, torch, rank, world, local, dev)
+        if force:
+            coll_info["force_collective"] = "one-rank groups: every collective below ran through RCCL on this one GPU"
     rccl_up = cg is not None                                     # RCCL over xGMI carries the collectives
 
     n = a.bytes
@@ -683,7 +712,7 @@ def main():
 
     # ---- beside the encrypt-only rate: gather, encrypt + gather, the concatenated stream, the C host's
     # own gather.  After the timed region, each under a bounded wait; a failure becomes a field of the line.
-    want_gather, want_c_gather = resolve_gather_flags(a, world)
+    want_gather, want_c_gather = resolve_gather_flags(a, world, force)
     gather_info, c_gather, stuck_extra = {}, None, False
     if dist and want_gather:
         try:
@@ -693,7 +722,7 @@ def main():
         if cg is not None and not still_rccl and "gather" in gather_info:
             cg, cdev = None, torch.device("cpu")                # RCCL misbehaved: the remaining reductions go over gloo
             coll_info["collective_backend"] += "; gloo after the gather failed"
-    if want_gather and want_c_gather and a.workload == "ctr" and world > 1:
+    if want_gather and want_c_gather and a.workload == "ctr" and (world > 1 or force):
         if rank == 0:
             res, err, stuck = bounded(lambda: c_gather_phase(a, torch, uaes, rank, world, n, dev, src, dst, seed),
                                       float(os.environ.get("UAES_BENCH_CGATHER_WAIT_S", "300")))

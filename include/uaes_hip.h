@@ -498,6 +498,18 @@ int uaes_mgpu_ctr_encrypt_gather(int ndev, const int *devices, int keybits, cons
                                  const void *const *d_in, size_t len, void *const *d_out,
                                  int root, void *d_full_on_root);
 
+/* Test hooks of the gather (the one-GPU evidence that the RCCL code runs; tests/test_gpu_robustness.py, bench.py
+ * --force-collective).  Environment, read on every call:
+ *   UAES_GATHER_FORCE_RCCL=1   slices on the root's OWN device that were encrypted into shard buffers (d_out[i] given)
+ *                              also travel by ncclSend / ncclRecv -- rank r to rank r on the cached communicator, which
+ *                              RCCL allows inside a group -- instead of hipMemcpy; ndev = 1 then loads RCCL too.
+ *   UAES_GATHER_FAIL_SEND=k    the k-th ncclSend of the call names a peer the communicator does not have: RCCL itself
+ *                              refuses it with the group open.  The call returns UAES_E_HIP, every gather stream is
+ *                              drained before it returns, and the communicators are aborted and rebuilt on the next call.
+ * out[0..4] = ncclSend calls accepted, ncclRecv calls accepted, groups opened, ncclCommInitAll runs, failed gathers --
+ * since the library was loaded. */
+void uaes_debug_gather_stats(unsigned long out[5]);
+
 /* ---- sharded GCM (multi-GPU) ------------------------------------------------
  * One message, cut into 16-byte aligned ciphertext shards, one per GPU.  Each
  * rank encrypts its shard with uaes_ctr_xcrypt_at_dev(ctr0 = nonce || 00000001,

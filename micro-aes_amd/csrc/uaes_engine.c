@@ -3609,6 +3609,8 @@ typedef struct {
     void *handle;
     int (*CommInitAll)(rccl_comm *comms, int ndev, const int *devlist);
     int (*CommDestroy)(rccl_comm comm);
+    int (*CommAbort)(rccl_comm comm);                     /* optional: NULL when the library has none */
+    int (*CommCount)(const rccl_comm comm, int *count);   /* optional */
     int (*GroupStart)(void);
     int (*GroupEnd)(void);
     int (*Send)(const void *buf, size_t count, int dtype, int peer, rccl_comm comm, hipStream_t st);
@@ -3653,22 +3655,62 @@ static int rccl_load(void)
     RCCL_SYM(Send, "ncclSend");               RCCL_SYM(Recv, "ncclRecv");
     RCCL_SYM(GetErrorString, "ncclGetErrorString");
 #undef RCCL_SYM
+    *(void **)&g_rccl.CommAbort = dlsym(g_rccl.handle, "ncclCommAbort");
+    *(void **)&g_rccl.CommCount = dlsym(g_rccl.handle, "ncclCommCount");
     return 0;
+}
+
+/* Two switches for the test suite and the one-GPU bench line, read on every call (a gather moves megabytes: a getenv
+ * is nothing beside it).  UAES_GATHER_FORCE_RCCL=1: slices that live on the root's own device and were encrypted into
+ * shard buffers of their own also travel by ncclSend / ncclRecv -- rank r to rank r inside the group, which RCCL
+ * allows -- instead of hipMemcpy, so that a box with ONE GPU runs the loader, the hand-declared prototypes,
+ * RCCL_UINT8, the communicator cache and the drain below.  UAES_GATHER_FAIL_SEND=k (k >= 1): the k-th send of the
+ * call is issued with a peer rank that does not exist, so RCCL itself refuses it (ncclInvalidArgument) in the middle
+ * of an open group with k-1 transfers already enqueued. */
+static int gather_force_rccl(void)
+{
+    const char *e = getenv("UAES_GATHER_FORCE_RCCL");
+    return e && *e && *e != '0';
+}
+
+static int gather_fail_send(void)
+{
+    const char *e = getenv("UAES_GATHER_FAIL_SEND");
+    return e && *e ? atoi(e) : 0;
+}
+
+static struct { unsigned long sends, recvs, groups, inits, failures; } g_gather_stats;
+
+/* how often each RCCL entry point has run in this process (tests: "the gather really went through RCCL") */
+void uaes_debug_gather_stats(unsigned long out[5])
+{
+    pthread_mutex_lock(&g_rccl_mu);
+    out[0] = g_gather_stats.sends; out[1] = g_gather_stats.recvs; out[2] = g_gather_stats.groups;
+    out[3] = g_gather_stats.inits; out[4] = g_gather_stats.failures;
+    pthread_mutex_unlock(&g_rccl_mu);
+}
+
+/* forget the communicators and streams of the cached device list (mutex held).  After a failed transfer the
+ * communicators are in a state RCCL does not define: they are aborted (ncclCommAbort, where the library has it)
+ * rather than destroyed, and the next gather builds fresh ones. */
+static void gather_drop_locked(int after_failure)
+{
+    int i, prev = -1;
+    if (!g_gather.ready) return;
+    (void)hipGetDevice(&prev);
+    for (i = 0; i < g_gather.ndev; ++i) {
+        if (after_failure && g_rccl.CommAbort) (void)g_rccl.CommAbort(g_gather.comm[i]);
+        else (void)g_rccl.CommDestroy(g_gather.comm[i]);
+        if (hipSetDevice(g_gather.devs[i]) == hipSuccess) (void)hipStreamDestroy(g_gather.stream[i]);
+    }
+    g_gather.ready = 0;
+    if (prev >= 0) (void)hipSetDevice(prev);
 }
 
 static void gather_teardown(void)
 {
-    int i, prev = -1;
     pthread_mutex_lock(&g_rccl_mu);
-    if (g_gather.ready) {
-        (void)hipGetDevice(&prev);
-        for (i = 0; i < g_gather.ndev; ++i) {
-            (void)g_rccl.CommDestroy(g_gather.comm[i]);
-            if (hipSetDevice(g_gather.devs[i]) == hipSuccess) (void)hipStreamDestroy(g_gather.stream[i]);
-        }
-        g_gather.ready = 0;
-        if (prev >= 0) (void)hipSetDevice(prev);
-    }
+    gather_drop_locked(0);
     pthread_mutex_unlock(&g_rccl_mu);
 }
 
@@ -3683,13 +3725,7 @@ static int gather_setup(int ndev, const int *dev)
     int i, rc, prev = -1;
     if (g_gather.ready && g_gather.ndev == ndev && memcmp(g_gather.devs, dev, (size_t)ndev * sizeof *dev) == 0) return 0;
     (void)hipGetDevice(&prev);
-    if (g_gather.ready) {                                  /* another device list: start over */
-        for (i = 0; i < g_gather.ndev; ++i) {
-            (void)g_rccl.CommDestroy(g_gather.comm[i]);
-            if (hipSetDevice(g_gather.devs[i]) == hipSuccess) (void)hipStreamDestroy(g_gather.stream[i]);
-        }
-        g_gather.ready = 0;
-    }
+    gather_drop_locked(0);                                 /* another device list: start over */
     for (i = 0; i < ndev; ++i)
         if (hipSetDevice(dev[i]) != hipSuccess || hipStreamCreateWithFlags(&g_gather.stream[i], hipStreamNonBlocking) != hipSuccess) {
             while (--i >= 0) if (hipSetDevice(dev[i]) == hipSuccess) (void)hipStreamDestroy(g_gather.stream[i]);
@@ -3702,6 +3738,16 @@ static int gather_setup(int ndev, const int *dev)
         for (i = 0; i < ndev; ++i) if (hipSetDevice(dev[i]) == hipSuccess) (void)hipStreamDestroy(g_gather.stream[i]);
         if (prev >= 0) (void)hipSetDevice(prev);
         return rccl_fail("ncclCommInitAll", rc);
+    }
+    ++g_gather_stats.inits;
+    if (g_rccl.CommCount) {                                /* the hand-declared prototypes against the library: ask it */
+        int cnt = -1;
+        if (g_rccl.CommCount(g_gather.comm[0], &cnt) != 0 || cnt != ndev) {
+            memcpy(g_gather.devs, dev, (size_t)ndev * sizeof *dev);
+            g_gather.ndev = ndev; g_gather.ready = 1;
+            gather_drop_locked(1);
+            return fail(UAES_E_HIP, "ncclCommCount says %d ranks, %d were set up", cnt, ndev);
+        }
     }
     memcpy(g_gather.devs, dev, (size_t)ndev * sizeof *dev);
     g_gather.ndev = ndev;
@@ -3745,36 +3791,45 @@ int uaes_mgpu_ctr_encrypt_gather(int ndev, const int *devices, int keybits, cons
     (void)hipGetDevice(&prev);
     {
         /* slices that live on the root's own device (its own, and those of a device list that names the device more
-         * than once) are device-to-device copies; the others travel by RCCL, one send / receive pair each */
-        int uniq[MAX_DEVICES], rank_of[MAX_DEVICES], nu = 0, remote = 0, u;
+         * than once) are device-to-device copies -- unless UAES_GATHER_FORCE_RCCL sends them through RCCL as well; the
+         * others travel by RCCL, one send / receive pair each */
+        int uniq[MAX_DEVICES], rank_of[MAX_DEVICES], by_rccl[MAX_DEVICES], nu = 0, remote = 0, u;
+        const int force = gather_force_rccl(), fail_at = gather_fail_send();
         for (i = 0; i < ndev; ++i) {
+            const int in_place = jobs[i].out == (void *)((char *)d_full_on_root + lo[i]);
             for (u = 0; u < nu && uniq[u] != dev[i]; ++u) { }
             if (u == nu) uniq[nu++] = dev[i];
             rank_of[i] = u;
-            if (dev[i] != dev[root] && hi[i] > lo[i]) ++remote;
+            by_rccl[i] = hi[i] > lo[i] && !in_place && (dev[i] != dev[root] || force);
+            if (by_rccl[i]) ++remote;
         }
         if (hipSetDevice(dev[root]) != hipSuccess) rc = fail(UAES_E_HIP, "hipSetDevice(%d) failed", dev[root]);
         for (i = 0; i < ndev && rc == 0; ++i) {
-            if (dev[i] != dev[root] || hi[i] == lo[i] || jobs[i].out == (void *)((char *)d_full_on_root + lo[i])) continue;
+            if (dev[i] != dev[root] || hi[i] == lo[i] || by_rccl[i] || jobs[i].out == (void *)((char *)d_full_on_root + lo[i])) continue;
             if (hipMemcpy((char *)d_full_on_root + lo[i], jobs[i].out, hi[i] - lo[i], hipMemcpyDeviceToDevice) != hipSuccess)
                 rc = fail(UAES_E_HIP, "copying a local slice into place failed: %s", hipGetErrorString(hipGetLastError()));
         }
         if (rc == 0 && remote) {
-            int g, started = 0;
+            int g, started = 0, nsend = 0;
             pthread_mutex_lock(&g_rccl_mu);
             rc = rccl_load();
             if (rc == 0) rc = gather_setup(nu, uniq);
             if (rc == 0 && (g = g_rccl.GroupStart()) != 0) rc = rccl_fail("ncclGroupStart", g);
             if (rc == 0) {
                 started = 1;
+                ++g_gather_stats.groups;
                 for (i = 0; i < ndev && rc == 0; ++i) {
-                    if (dev[i] == dev[root] || hi[i] == lo[i]) continue;
-                    if ((g = g_rccl.Send(jobs[i].out, hi[i] - lo[i], RCCL_UINT8, rank_of[root], g_gather.comm[rank_of[i]],
+                    if (!by_rccl[i]) continue;
+                    /* the injected failure: a destination rank the communicator does not have */
+                    const int to = (++nsend == fail_at) ? nu + 7 : rank_of[root];
+                    if ((g = g_rccl.Send(jobs[i].out, hi[i] - lo[i], RCCL_UINT8, to, g_gather.comm[rank_of[i]],
                                          g_gather.stream[rank_of[i]])) != 0)
                         rc = rccl_fail("ncclSend", g);
-                    else if ((g = g_rccl.Recv((char *)d_full_on_root + lo[i], hi[i] - lo[i], RCCL_UINT8, rank_of[i],
+                    else if (++g_gather_stats.sends,
+                             (g = g_rccl.Recv((char *)d_full_on_root + lo[i], hi[i] - lo[i], RCCL_UINT8, rank_of[i],
                                               g_gather.comm[rank_of[root]], g_gather.stream[rank_of[root]])) != 0)
                         rc = rccl_fail("ncclRecv", g);
+                    else ++g_gather_stats.recvs;
                 }
             }
             if (started && (g = g_rccl.GroupEnd()) != 0 && rc == 0) rc = rccl_fail("ncclGroupEnd", g);
@@ -3783,6 +3838,10 @@ int uaes_mgpu_ctr_encrypt_gather(int ndev, const int *devices, int keybits, cons
             for (u = 0; u < nu && g_gather.ready; ++u)
                 if ((hipSetDevice(uniq[u]) != hipSuccess || hipStreamSynchronize(g_gather.stream[u]) != hipSuccess) && rc == 0)
                     rc = fail(UAES_E_HIP, "the gather did not complete on device %d: %s", uniq[u], hipGetErrorString(hipGetLastError()));
+            if (rc != 0) {                                 /* whatever state the group left them in: not reused */
+                ++g_gather_stats.failures;
+                gather_drop_locked(1);
+            }
             pthread_mutex_unlock(&g_rccl_mu);
         }
     }

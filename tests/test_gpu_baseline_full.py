@@ -177,6 +177,26 @@ def test_bench_two_ranks_rccl():
     assert line["n_gpus"] == 2 and line["verified"] is True and line["gather_ms"] > 0
 
 
+def test_bench_one_rank_force_collective_runs_rccl_on_one_gpu():
+    """`bench.py --gpus 1 --force-collective` brings up a ONE-rank RCCL group (torch's "nccl"
+    backend), runs the barrier / reductions / ciphertext all-gather through it and the C host's gather through ncclSend /
+    ncclRecv to itself: on a one-GPU box this is the first and only execution of the code the 8-GPU run depends on.
+    The gathered stream (1 GiB, = C2) must match the reference's digest through BOTH gathers."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                            "UAES_GATHER_FORCE_RCCL", "UAES_GATHER_FAIL_SEND")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--force-collective",
+           "--sustain-s", "0.2", "--no-traffic", "--no-cpu"]
+    line = _one_json_line(subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900))
+    assert line["n_gpus"] == 1 and line["verified"] is True and line["value"] > 0
+    assert line["collective_backend"] == "nccl (RCCL)", line["collective_backend"]
+    assert line["rccl_ranks"] == 1
+    assert line["gather_ms"] > 0 and line["gather_backend"].startswith("RCCL all_gather_into_tensor, ONE rank")
+    assert line["gathered_stream_digest_ok"] is True
+    cg = line["c_gather"]
+    assert cg.get("stream_digest_ok") is True and cg["ms"] > 0, cg
+    assert cg["forced_self_send"] is True and cg["rccl_sends"] == 2 and cg["rccl_recvs"] == 2 and cg["rccl_comm_inits"] == 1, cg
+
+
 def test_bench_two_ranks_survive_an_rccl_failure():
     """`bench.py --gpus 2` with the default nccl backend, both ranks on this box's one GPU and the RCCL
     bring-up forced to fail on every rank (UAES_BENCH_FORCE_NCCL_FAIL): the run must fall back to gloo for the control

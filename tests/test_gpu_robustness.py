@@ -581,6 +581,146 @@ def test_mgpu_ctr_encrypt_gather_rccl(orc):
         _gather_check(orc, [0, 1, 0, 1], 3, n, True)
 
 
+def _gather_stats():
+    out = (C.c_ulong * 5)()
+    uaes.engine().uaes_debug_gather_stats(out)
+    return dict(zip(("sends", "recvs", "groups", "inits", "failures"), out))
+
+
+@pytest.fixture
+def force_rccl(monkeypatch):
+    """UAES_GATHER_FORCE_RCCL=1 for one test (include/uaes_hip.h, "Test hooks of the gather")"""
+    monkeypatch.setenv("UAES_GATHER_FORCE_RCCL", "1")
+    monkeypatch.delenv("UAES_GATHER_FAIL_SEND", raising=False)
+    yield monkeypatch
+
+
+def test_mgpu_ctr_encrypt_gather_through_rccl_on_one_device(orc, force_rccl):
+    """the RCCL leg of the C host's gather (dlopen of librccl, the hand-declared prototypes,
+    ncclUint8 = 1, the communicator cache, grouped send / receive, the drain) had never executed on a one-GPU box:
+    same-device slices took the hipMemcpy shortcut.  Under UAES_GATHER_FORCE_RCCL every slice that has a shard buffer
+    of its own travels rank r -> rank r by ncclSend / ncclRecv on a ONE-rank communicator; the gathered text must
+    still be the single-call result (shard arithmetic: micro_aes.c:421-427, :962-976), and the counters must show
+    that RCCL carried it."""
+    before = _gather_stats()
+    for n in (16, 1000, 100003, (2 << 20) + 7):
+        _gather_check(orc, [0], 0, n, True)               # one slice, one self send / receive
+    mid = _gather_stats()
+    assert mid["sends"] - before["sends"] == 4 and mid["recvs"] - before["recvs"] == 4, (before, mid)
+    assert mid["groups"] - before["groups"] == 4 and mid["failures"] == before["failures"]
+    assert mid["inits"] - before["inits"] <= 1            # the communicator is cached across calls
+    for n in (48, 100003, (8 << 20) + 5):
+        _gather_check(orc, [0, 0, 0], 1, n, True)         # three slices, three pairs in ONE group on the same rank
+    after = _gather_stats()
+    assert after["sends"] - mid["sends"] == 9 and after["groups"] - mid["groups"] == 3
+    assert after["inits"] == mid["inits"], "the device list {0,0,0} reduces to the cached one-rank communicator"
+    # a root slice without a buffer of its own is encrypted straight into place: nothing to send even when forced
+    _gather_check(orc, [0], 0, 4096, False)
+    assert _gather_stats()["sends"] == after["sends"]
+
+
+def test_mgpu_gather_c2_digest_through_rccl(orc, force_rccl):
+    """the whole C2 text (AES-128-CTR, 1 GiB, seed 2) encrypted as four shards on device 0 and gathered through RCCL
+    self send / receive: SHA-256 of the gathered stream == the compiled reference's digest (tests/golden/digests.json)"""
+    import hashlib
+    import json
+    import torch
+    import bench
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "digests.json")) as f:
+        gold = json.load(f)["C2_ctr128_1GiB_seed2"]["sha256"]
+    L = uaes.engine()
+    n, nd = 1 << 30, 4
+    dev = torch.device("cuda", 0)
+    src = bench.splitmix_device(torch, 2, n, 0, dev)
+    shard = n // nd
+    outs_t = [torch.empty(shard, dtype=torch.uint8, device=dev) for _ in range(nd)]
+    full = torch.zeros(n, dtype=torch.uint8, device=dev)
+    ins, outs = (C.c_void_p * nd)(), (C.c_void_p * nd)()
+    for i in range(nd):
+        ins[i], outs[i] = src.data_ptr() + i * shard, outs_t[i].data_ptr()
+    torch.cuda.synchronize()
+    before = _gather_stats()
+    rc = L.uaes_mgpu_ctr_encrypt_gather(nd, (C.c_int * nd)(*([0] * nd)), 128, bench.KEY16, bench.CTR0, 0, ins, n, outs,
+                                        0, C.c_void_p(full.data_ptr()))
+    assert rc == 0, L.uaes_last_error()
+    torch.cuda.synchronize()
+    after = _gather_stats()
+    assert after["sends"] - before["sends"] == nd and after["recvs"] - before["recvs"] == nd
+    h = hashlib.sha256()
+    for o in range(0, n, 1 << 28):
+        h.update(full[o:o + (1 << 28)].cpu().numpy().tobytes())
+    assert h.hexdigest() == gold
+
+
+def test_mgpu_gather_failed_send_returns_an_error_and_drains(orc, force_rccl):
+    """a send RCCL refuses in the middle of an open group (UAES_GATHER_FAIL_SEND: the k-th ncclSend names a rank the
+    communicator does not have): the call returns UAES_E_HIP with RCCL's own message, does not hang, has drained
+    every gather stream before returning (the caller may free or reuse the buffers at once -- done here), and the
+    NEXT call builds fresh communicators and is correct."""
+    import torch
+    L = uaes.engine()
+    n, nd = (4 << 20) + 16, 3
+    key, ctr0 = bytes(range(16)), bytes(range(12)) + b"\0\0\0\1"
+    data = orc.splitmix(77, n)
+    dev = torch.device("cuda", 0)
+    for fail_at in (1, 2, 3):
+        force_rccl.setenv("UAES_GATHER_FAIL_SEND", str(fail_at))
+        before = _gather_stats()
+        blocks = (n + 15) // 16
+        ins, outs, keep = (C.c_void_p * nd)(), (C.c_void_p * nd)(), []
+        for i in range(nd):
+            lo, hi = 16 * (blocks * i // nd), min(n, 16 * (blocks * (i + 1) // nd))
+            t = torch.frombuffer(bytearray(data[lo:hi]), dtype=torch.uint8).to(dev)
+            o = torch.empty(hi - lo, dtype=torch.uint8, device=dev)
+            keep += [t, o]
+            ins[i], outs[i] = t.data_ptr(), o.data_ptr()
+        full = torch.zeros(n, dtype=torch.uint8, device=dev)
+        rc = L.uaes_mgpu_ctr_encrypt_gather(nd, (C.c_int * nd)(0, 0, 0), 128, key, ctr0, 0, ins, n, outs, 0,
+                                            C.c_void_p(full.data_ptr()))
+        assert rc == -1, (fail_at, rc)                    # UAES_E_HIP
+        msg = L.uaes_last_error()
+        assert b"ncclSend" in msg or b"ncclGroupEnd" in msg, msg
+        after = _gather_stats()
+        assert after["failures"] - before["failures"] == 1
+        assert after["sends"] - before["sends"] == fail_at - 1, "the sends before the refused one were accepted"
+        # drained: the buffers go back to the allocator and are overwritten at once; a transfer still in flight
+        # would race with this and, worse, with the next gather
+        del keep, full
+        torch.cuda.synchronize()
+        junk = torch.full(((16 << 20),), 0x5A, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        del junk
+        # every shard WAS encrypted (the failure is in the gather): nothing to assert on `full`, it is undefined
+        force_rccl.delenv("UAES_GATHER_FAIL_SEND")
+        mid = _gather_stats()
+        _gather_check(orc, [0, 0, 0], 2, n, True)
+        end = _gather_stats()
+        assert end["inits"] - mid["inits"] == 1, "the communicators of a failed gather are not reused"
+        assert end["failures"] == mid["failures"]
+
+
+def test_mgpu_gather_says_why_when_rccl_is_missing(orc):
+    """RCCL is a soft dependency (dlopen): a library that does not load is UAES_E_HIP with the loader's message,
+    in a fresh process so that this process' loaded RCCL is not disturbed"""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes as C, sys, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "import micro_aes_amd as uaes\n"
+        "L = uaes.engine()\n"
+        "t = torch.zeros(64, dtype=torch.uint8, device='cuda:0'); o = torch.zeros(64, dtype=torch.uint8, device='cuda:0')\n"
+        "f = torch.zeros(64, dtype=torch.uint8, device='cuda:0')\n"
+        "ins = (C.c_void_p * 1)(t.data_ptr()); outs = (C.c_void_p * 1)(o.data_ptr())\n"
+        "rc = L.uaes_mgpu_ctr_encrypt_gather(1, (C.c_int * 1)(0), 128, bytes(16), bytes(16), 0, ins, 64, outs, 0, C.c_void_p(f.data_ptr()))\n"
+        "print(rc, L.uaes_last_error().decode())\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, UAES_GATHER_FORCE_RCCL="1", UAES_RCCL_LIB="/nonexistent/librccl.so")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.startswith("-1 RCCL is not available"), r.stdout
+
+
 def test_mgpu_calls_from_several_host_threads_share_the_persistent_workers(orc):
     """the per-device workers of uaes_mgpu_* now live for the life of the process and calls queue up per
     worker.  Six host threads call at once with device lists that all name device 0 several times: every call must
