@@ -44,6 +44,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+_LINE_OUT = sys.stdout
 GIB = 1 << 30
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
 KEY16 = bytes(range(16))
@@ -80,6 +81,64 @@ def sha_of(t):
     for o in range(0, t.numel(), step):
         h.update(t[o:o + step].cpu().numpy().tobytes())
     return h.hexdigest()
+
+
+def other_configs(torch, uaes, dev, st, steps=10, settle_ms=120.0):
+    """BASELINE configs[3] and configs[2] beside the headline, AFTER its timed steps and never inside `value`
+    (VERDICT r05 next #2): AES-128-GCM over 1 GiB (seed 4; AES_GCM_encrypt, micro_aes.c:1164-1179) and AES-256-XTS over
+    2^20 sectors of 4 KiB (seed 3; AES_XTS_encrypt per sector, micro_aes.c:1066-1093), each settled for `settle_ms`, then
+    `steps` steps timed with HIP events on the launch stream, then checked against the compiled reference's results
+    (tests/golden/digests.json: the C4 tag; SHA-256 of the whole 4 GiB C3 ciphertext).  frac = 32 B per 16-byte block
+    over the mean step time against the 8 TB/s peak, as in `roofline`."""
+    with open(os.path.join(ROOT, "tests", "golden", "digests.json")) as f:
+        gold = json.load(f)
+
+    def timed(step, n):
+        step()
+        torch.cuda.synchronize()
+        w0 = time.perf_counter()
+        while (time.perf_counter() - w0) * 1e3 < settle_ms:
+            for _ in range(4):
+                step()
+            torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(steps):
+            step()
+        e1.record(st)
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / steps
+        return {"gib_s": round(n / GIB / (ms * 1e-3), 1), "ms_per_step": round(ms, 4), "steps": steps,
+                "frac": round(2.0 * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "bytes": n}
+
+    out = {}
+    try:
+        n = GIB
+        src = splitmix_device(torch, 4, n, 0, dev)
+        dst = torch.empty(n + 16, dtype=torch.uint8, device=dev)
+        r = timed(lambda: uaes.gcm_encrypt_dev(KEY16, NONCE, None, src, n, dst, stream=st), n)
+        tag = bytes(dst[n:].cpu().numpy()).hex()
+        r["workload"] = "AES-128-GCM, 1 GiB + tag, seed 4 (configs[3])"
+        r["verified"] = tag == gold["C4_gcm128_1GiB_seed4"]["tag"]
+        r["check"] = "tag %s against the reference's C4 tag" % tag
+        out["gcm_c4"] = r
+        del src, dst
+    except Exception as e:                                          # noqa: BLE001 -- never costs the headline
+        out["gcm_c4"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+    try:
+        n = 4 * GIB
+        src = splitmix_device(torch, 3, n, 0, dev)
+        dst = torch.empty(n, dtype=torch.uint8, device=dev)
+        r = timed(lambda: uaes.xts_sectors_dev(KEY64, 0, 4096, n // 4096, src, dst, stream=st), n)
+        r["workload"] = "AES-256-XTS, 2^20 sectors x 4 KiB, seed 3 (configs[2])"
+        r["verified"] = sha_of(dst) == gold["C3_xts256_2p20_sectors_seed3"]["sha256"]
+        r["check"] = "SHA-256 of the 4 GiB ciphertext against the reference's C3 digest"
+        out["xts_c3"] = r
+        del src, dst
+    except Exception as e:                                          # noqa: BLE001
+        out["xts_c3"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+    torch.cuda.empty_cache()
+    return out
 
 
 def usable_cores():
@@ -131,7 +190,7 @@ def measure_counters(workload, nbytes, counters=("FETCH_SIZE", "WRITE_SIZE", "SQ
             cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", out, "-o", "pmc", "--",
                    sys.executable, os.path.abspath(__file__), "--gpus", "1", "--workload", workload, "--bytes", str(nbytes),
                    "--steps", str(steps), "--warmup", str(warm), "--settle-ms", "0", "--no-cpu", "--no-verify",
-                   "--no-traffic", "--no-clock-probe", "--sustain-s", "0"]
+                   "--no-traffic", "--no-clock-probe", "--sustain-s", "0", "--no-c-gather", "--no-other-configs"]
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=150)
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
@@ -178,15 +237,16 @@ def valu_per_block_of(counters, nbytes, workload, profiles_dir=None):
     return None, None
 
 
-def cpu_baseline(workload):
+def cpu_baseline(workload, sample=None, all_cores=True):
     """Reference CPU path on this host: 1 core (the reference is single-threaded
-    and non re-entrant, micro_aes.c:72) and, via fork, all cores."""
+    and non re-entrant, micro_aes.c:72) and, via fork, all cores.  `sample` (bytes) and `all_cores=False` shrink it
+    for the tests; the bench line uses the defaults."""
     import numpy as np
     from oracle.pyoracle import Oracle, Reference
     orc = Oracle()
     use_ref = Reference.available(128)
-    sample = {"ctr": 512 << 20, "ecb": 512 << 20, "xts": 512 << 20, "gcm": 64 << 20, "cbc-enc": 256 << 20,
-              "cmac": 256 << 20}.get(workload, 256 << 20)
+    sample = sample or {"ctr": 512 << 20, "ecb": 512 << 20, "xts": 512 << 20, "gcm": 64 << 20, "cbc-enc": 256 << 20,
+                        "cmac": 256 << 20}.get(workload, 256 << 20)
     mac16 = (ctypes.c_uint8 * 16)()
     buf = np.empty(sample, dtype=np.uint8)
     orc.splitmix_into(2, buf)
@@ -225,6 +285,8 @@ def cpu_baseline(workload):
     res = {"value": round(sample / GIB / t1, 5), "unit": "GiB/s", "cores": 1,
            "kind": "reference" if use_ref else "port",
            "sample": "%d MiB of the same synthetic %s workload, single call, gcc -O3" % (sample >> 20, workload)}
+    if not all_cores:
+        return res
     # all cores: fork P processes over contiguous shards (throughput-equivalent;
     # the reference API cannot start a CTR shard at an offset)
     P = usable_cores()
@@ -542,6 +604,8 @@ def build_parser():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --single-device: dry-run the multi-rank code path on a 1-GPU box")
     ap.add_argument("--single-device", action="store_true", help="all ranks use cuda:0 (dry run only)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip `other_configs` (GCM C4 and XTS C3 timed and verified after the headline; 1-GPU CTR 1 GiB line only)")
     ap.add_argument("--force-collective", action="store_true",
                     help="with --gpus 1: bring the collectives up anyway -- a ONE-rank RCCL process group "
                          "(init_process_group / new_group(\"nccl\"), world_size 1) carries the barrier, the reductions and "
@@ -556,6 +620,14 @@ def main():
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(a.gpus)
+
+    # ONE JSON line on stdout and nothing else: libraries below us write to the C-level stdout (RCCL prints its version
+    # banner there when a communicator is first made), so file descriptor 1 is pointed at stderr for the life of the
+    # process and the line goes out through a private duplicate of the real stdout.
+    global _LINE_OUT
+    sys.stdout.flush()
+    _LINE_OUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     import torch
     import micro_aes_amd as uaes
@@ -722,6 +794,18 @@ def main():
         if cg is not None and not still_rccl and "gather" in gather_info:
             cg, cdev = None, torch.device("cpu")                # RCCL misbehaved: the remaining reductions go over gloo
             coll_info["collective_backend"] += "; gloo after the gather failed"
+    rccl_self = (world == 1 and not force and a.workload == "ctr" and a.c_gather is not False and a.gather is not False)
+    if rccl_self:
+        # The plain one-GPU line: no process group at all, but the C host's gather still runs once through RCCL
+        # (ncclSend / ncclRecv to itself, UAES_GATHER_FORCE_RCCL) so that every driver run executes the code that
+        # configs[4] depends on and checks its stream against the reference.  After the timed steps; bounded.
+        os.environ["UAES_GATHER_FORCE_RCCL"] = "1"
+        res, err, stuck = bounded(lambda: c_gather_phase(a, torch, uaes, rank, world, n, dev, src, dst, seed),
+                                  float(os.environ.get("UAES_BENCH_CGATHER_WAIT_S", "120")))
+        os.environ.pop("UAES_GATHER_FORCE_RCCL", None)
+        c_gather = res if err is None else {"error": err, "stuck_thread": stuck}
+        if stuck:
+            stuck_extra = True
     if want_gather and want_c_gather and a.workload == "ctr" and (world > 1 or force):
         if rank == 0:
             res, err, stuck = bounded(lambda: c_gather_phase(a, torch, uaes, rank, world, n, dev, src, dst, seed),
@@ -900,9 +984,14 @@ def main():
         line.update(gather_info)
         if c_gather is not None:
             line["c_gather"] = c_gather
+        if world == 1 and a.workload == "ctr" and n == GIB and not a.no_other_configs:
+            line["other_configs"] = other_configs(torch, uaes, dev, st)
         if not a.no_cpu and world == 1:
             line["cpu_baseline"] = cpu_baseline(a.workload)
-        print(json.dumps(line))
+        print(json.dumps(line), file=_LINE_OUT, flush=True)
+    if stuck_extra and not dist:
+        sys.stdout.flush()
+        os._exit(0)                             # a thread still inside the C host's gather: do not wait for it
     if dist:
         sys.stdout.flush()
         if coll_info.get("rccl_stuck_thread") or stuck_extra:

@@ -510,6 +510,16 @@ int uaes_mgpu_ctr_encrypt_gather(int ndev, const int *devices, int keybits, cons
  * since the library was loaded. */
 void uaes_debug_gather_stats(unsigned long out[5]);
 
+/* Test hooks of the one-launch GCM / GCM-SIV / streamed-piece arrangements (chunk workgroups + one preparing workgroup
+ * in ONE launch; whoever of them arrives last on a counter word folds the chunk hashes and makes the tag -- nobody
+ * waits for anybody, DESIGN.md "GCM").  The preparing workgroup looks at the counter for a bounded time before it
+ * counts itself in (default 1 ms; environment UAES_GCM_LOOK_TICKS): uaes_debug_gcm_look(0) makes it count in at
+ * once, so that a chunk workgroup is usually the last and the fold runs THERE.  uaes_debug_gcm_chunk_folds: how many
+ * folds a chunk workgroup has done on the current device.  UAES_GCM_FOLD=0 in the environment switches the
+ * one-launch arrangements off altogether (chunks, then k_gcm_combine as a second launch). */
+void uaes_debug_gcm_look(unsigned long long ticks_100mhz);
+int uaes_debug_gcm_chunk_folds(unsigned *out);
+
 /* ---- sharded GCM (multi-GPU) ------------------------------------------------
  * One message, cut into 16-byte aligned ciphertext shards, one per GPU.  Each
  * rank encrypts its shard with uaes_ctr_xcrypt_at_dev(ctr0 = nonce || 00000001,

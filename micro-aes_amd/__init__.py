@@ -42,7 +42,7 @@ EXPORTS = [
     "uaes_ocb_encrypt_ex", "uaes_ocb_decrypt_ex",
     "uaes_cmac", "uaes_ccm_encrypt", "uaes_ccm_decrypt", "uaes_gcmsiv_encrypt", "uaes_gcmsiv_decrypt",
     "uaes_ocb_encrypt", "uaes_ocb_decrypt", "uaes_ocb_dev",
-    "uaes_mgpu_ctr_xcrypt_at", "uaes_mgpu_xts_sectors", "uaes_mgpu_ctr_encrypt_gather", "uaes_debug_gather_stats",
+    "uaes_mgpu_ctr_xcrypt_at", "uaes_mgpu_xts_sectors", "uaes_mgpu_ctr_encrypt_gather", "uaes_debug_gather_stats", "uaes_debug_gcm_look", "uaes_debug_gcm_chunk_folds",
     "uaes_mgpu_ecb_encrypt", "uaes_mgpu_ecb_decrypt", "uaes_mgpu_gcm_encrypt", "uaes_mgpu_gcm_decrypt",
     "uaes_set_devices", "uaes_set_producer_stream", "uaes_set_host_policy", "uaes_get_host_policy",
     "uaes_gcm_key_new", "uaes_gcm_key_free", "uaes_gcm_key_encrypt", "uaes_gcm_key_decrypt",
@@ -143,8 +143,12 @@ def engine():
     L.uaes_mgpu_ctr_xcrypt_at.argtypes = [i, C.POINTER(C.c_int), i, vp, vp, u64, vp, sz, vp]
     L.uaes_mgpu_xts_sectors.argtypes = [i, C.POINTER(C.c_int), i, vp, u64, sz, sz, vp, vp, i]
     L.uaes_mgpu_ctr_encrypt_gather.argtypes = [i, C.POINTER(C.c_int), i, vp, vp, u64, C.POINTER(vp), sz, C.POINTER(vp), i, vp]
-    L.uaes_debug_gather_stats.argtypes = [C.POINTER(C.c_ulong)]
-    L.uaes_debug_gather_stats.restype = None
+    if hasattr(L, "uaes_debug_gcm_look"):              # (an older build loaded for an A/B run has no test hooks)
+        L.uaes_debug_gather_stats.argtypes = [C.POINTER(C.c_ulong)]
+        L.uaes_debug_gather_stats.restype = None
+        L.uaes_debug_gcm_look.argtypes = [C.c_ulonglong]
+        L.uaes_debug_gcm_look.restype = None
+        L.uaes_debug_gcm_chunk_folds.argtypes = [C.POINTER(C.c_uint)]
     L.uaes_mgpu_ecb_encrypt.argtypes = [i, C.POINTER(C.c_int), i, vp, i, vp, sz, vp]
     L.uaes_mgpu_ecb_decrypt.argtypes = [i, C.POINTER(C.c_int), i, vp, vp, sz, vp]
     for n in ("uaes_mgpu_gcm_encrypt", "uaes_mgpu_gcm_decrypt"):
@@ -185,7 +189,9 @@ def engine():
     L.uaes_gcm_shard_dev.argtypes = [i, vp, vp, i, vp, u64, vp, sz, u64, u64, vp, vp, vp]
     L.uaes_expand_key.argtypes = [i, vp, vp, vp]
     for n in EXPORTS:
-        if n not in ("uaes_last_error", "uaes_version", "uaes_gcm_key_free", "uaes_gcm_stream_abort", "uaes_debug_gather_stats"):
+        if n.startswith("uaes_debug_") and not hasattr(L, n):
+            continue
+        if n not in ("uaes_last_error", "uaes_version", "uaes_gcm_key_free", "uaes_gcm_stream_abort", "uaes_debug_gather_stats", "uaes_debug_gcm_look"):
             getattr(L, n).restype = i
     _lib = L
     return L

@@ -228,6 +228,10 @@ void uaesk_ticket_arm(void *pinned_flag, void *d_count, unsigned seq);
 /* a device word that is zero between calls and that nothing else writes, for the calling thread's NEXT kernel-level
  * call (uaesk_gcm / uaesk_gcm_keyed take it: with it a medium-sized text is one launch); NULL disarms */
 void uaesk_done_word_arm(unsigned *w);
+/* test hooks: the preparing workgroup's bounded look (100 MHz ticks; 0 = count in without looking) and the number of
+ * folds a CHUNK workgroup has done on the current device (uaes_gcm.hip, "FOLD") */
+void uaesk_debug_gcm_look(unsigned long long ticks);
+int uaesk_debug_gcm_chunk_folds(unsigned *out);
 int  uaesk_ticket_disarm(void);
 
 /* Completion ticket of a synchronous call: a one-wave kernel behind the call's kernels copies nbytes (a multiple

@@ -367,6 +367,30 @@ static unsigned *scratch_done_word(void *buf, size_t cap)
     return (unsigned *)((char *)buf + cap - SCRATCH_TAIL);
 }
 
+/* The word the calling thread armed last (arm_done_word) and the stream its call ran on.  The workgroups of a
+ * one-launch call restore the zero themselves; a call that did NOT run to its end -- a launch the runtime refused, a
+ * sequence abandoned half-way -- may not have, and a count left behind would make the next call on that word fold too
+ * early.  Every failure path therefore puts the zero back, in stream order behind whatever did get queued
+ * (lane_abandon, and any non-zero launch rc). */
+static __thread unsigned *tls_armed_word;
+static void arm_done_word(unsigned *w)
+{
+    if (w) tls_armed_word = w;
+    uaesk_done_word_arm(w);
+}
+static void repair_done_word(void *stream)
+{
+    if (tls_armed_word) (void)hipMemsetAsync(tls_armed_word, 0, SCRATCH_TAIL, (hipStream_t)stream);
+    tls_armed_word = NULL;
+}
+/* the *_dev calls: one kernel-level call on the caller's stream, nothing else can fail afterwards */
+static void disarm_done_word_dev(void *stream, int launch_rc)
+{
+    uaesk_done_word_arm(NULL);
+    if (launch_rc != 0) repair_done_word(stream);
+    tls_armed_word = NULL;
+}
+
 /* for buffers that several streams may have used (the *_dev scratch slots) */
 static int grow(void **buf, size_t *cap, size_t need)
 {
@@ -1037,7 +1061,11 @@ static int lane_abandon(lane *L, int rc)
 {
     if (L) L->armed = 0;
     (void)uaesk_ticket_disarm();
-    if (L && L->stream) (void)hipStreamSynchronize((hipStream_t)L->stream);
+    if (L && L->stream) {
+        (void)hipStreamSynchronize((hipStream_t)L->stream);
+        if (L->scratch) (void)hipMemsetAsync(scratch_done_word(L->scratch, L->scratch_cap), 0, SCRATCH_TAIL, (hipStream_t)L->stream);
+        repair_done_word(L->stream);                  /* a key context's word, if that is what this call armed */
+    }
     return rc;
 }
 
@@ -1212,7 +1240,13 @@ static int dev_ptrs_ok(const void *in, const void *out, size_t len)
 
 /* the synchronous entry points run between enter() and DONE(): the latter drains the lane when the
  * call did not end in finish_io / lane_fetch (an error in the middle)                              */
-#define DONE(L, rc) return ((rc) < 0 ? lane_abandon((L), (rc)) : (rc))
+static int lane_leave(lane *L, int rc)
+{
+    if (rc < 0) rc = lane_abandon(L, rc);
+    tls_armed_word = NULL;                           /* the word may belong to a key context the caller frees next */
+    return rc;
+}
+#define DONE(L, rc) return lane_leave((L), (rc))
 
 /* ------------------------------------------------------------------------ */
 /* housekeeping API                                                           */
@@ -1846,12 +1880,12 @@ int uaes_gcm_encrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, s
             io.copy_back = 1;
         }
         ticket_arm(L, ptextLen);
-        uaesk_done_word_arm(scratch_done_word(L->scratch, L->scratch_cap));
+        arm_done_word(scratch_done_word(L->scratch, L->scratch_cap));
         int k = keyed ? uaesk_gcm_keyed(L->stream, &c->tb, ks.nr, &ks.ek, 0, j0, d_aad, aDataLen,
                                         io.din, ptextLen, io.dout, L->scratch, NULL)
                       : uaesk_gcm(L->stream, &c->tb, ks.nr, &ks.ek, 0, j0, d_aad, aDataLen,
                                   io.din, ptextLen, io.dout, L->scratch, NULL);
-        uaesk_done_word_arm(NULL);
+        arm_done_word(NULL);
         ticket_armed_launch_done(L);
         if (k) { rc = fail(UAES_E_HIP, "gcm launch: %s", hipGetErrorString((hipError_t)k)); break; }
         rc = finish_io(&io, ptextLen + tagLen);
@@ -1946,13 +1980,13 @@ int uaes_gcm_decrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, s
         int *st_where = lane_status(L);
         if (st_where != L->d_status) { *(volatile int *)st_where = -1; ticket_arm(L, crtxtLen); }   /* host-visible status: a
                                                      * one-launch decryption may carry the completion ticket itself */
-        uaesk_done_word_arm(scratch_done_word(L->scratch, L->scratch_cap));
+        arm_done_word(scratch_done_word(L->scratch, L->scratch_cap));
         const int dmode = io.copy_back || io.dout == L->pin[1] ? 2 : gcm_decrypt_mode();
         int k = keyed ? uaesk_gcm_keyed(L->stream, &c->tb, ks.nr, &ks.ek, dmode, j0, d_aad, aDataLen, io.din, crtxtLen, io.dout,
                                         L->scratch, st_where)
                       : uaesk_gcm(L->stream, &c->tb, ks.nr, &ks.ek, dmode, j0, d_aad, aDataLen, io.din, crtxtLen, io.dout,
                                   L->scratch, st_where);
-        uaesk_done_word_arm(NULL);
+        arm_done_word(NULL);
         ticket_armed_launch_done(L);
         if (k) { rc = fail(UAES_E_HIP, "gcm launch: %s", hipGetErrorString((hipError_t)k)); break; }
         if ((rc = lane_read_status(L, st_where, &status)) != 0) break;
@@ -1992,9 +2026,9 @@ int uaes_gcm_encrypt_dev(int keybits, const uint8_t *key, const uint8_t *nonce,
     if ((rc = get_context(&c)) != 0) return rc;
     if ((rc = gcm_scratch_locked(c, stream, &scr, &slot)) != 0) return rc;
     j0_of_nonce12(nonce, j0);
-    uaesk_done_word_arm(scratch_done_word(scr, c->slot[slot].cap));
+    arm_done_word(scratch_done_word(scr, c->slot[slot].cap));
     rc = uaesk_gcm(stream, &c->tb, ks.nr, &ks.ek, 0, j0, d_aad, aad_len, d_in, len, d_out, scr, NULL);
-    uaesk_done_word_arm(NULL);
+    disarm_done_word_dev(stream, rc);
     KCHK_PINNED(c, slot, rc);
     return 0;
 }
@@ -2016,9 +2050,9 @@ int uaes_gcm_decrypt_dev(int keybits, const uint8_t *key, const uint8_t *nonce,
     if ((rc = get_context(&c)) != 0) return rc;
     if ((rc = gcm_scratch_locked(c, stream, &scr, &slot)) != 0) return rc;
     j0_of_nonce12(nonce, j0);
-    uaesk_done_word_arm(scratch_done_word(scr, c->slot[slot].cap));
+    arm_done_word(scratch_done_word(scr, c->slot[slot].cap));
     rc = uaesk_gcm(stream, &c->tb, ks.nr, &ks.ek, gcm_decrypt_mode(), j0, d_aad, aad_len, d_in, len, d_out, scr, d_status);
-    uaesk_done_word_arm(NULL);
+    disarm_done_word_dev(stream, rc);
     KCHK_PINNED(c, slot, rc);
     return 0;
 }
@@ -2109,10 +2143,10 @@ int uaes_gcm_key_encrypt(uaes_gcm_key *k, const uint8_t *nonce, const void *aDat
         if ((rc = stage_aad(L, aData, aDataLen, &d_aad)) != 0) break;
         if ((rc = plan_io(L, pntxt, ptextLen, crtxt, ptextLen + 16, &io)) != 0) break;
         ticket_arm(L, ptextLen);
-        uaesk_done_word_arm(KEY_DONE_WORD(k));
+        arm_done_word(KEY_DONE_WORD(k));
         int kk = uaesk_gcm_keyed(L->stream, &c->tb, k->ks.nr, &k->ks.ek, 0, j0, d_aad, aDataLen,
                                  io.din, ptextLen, io.dout, k->scratch, NULL);
-        uaesk_done_word_arm(NULL);
+        arm_done_word(NULL);
         ticket_armed_launch_done(L);
         if (kk) { rc = fail(UAES_E_HIP, "gcm launch: %s", hipGetErrorString((hipError_t)kk)); break; }
         rc = finish_io(&io, ptextLen + 16);
@@ -2142,11 +2176,11 @@ int uaes_gcm_key_decrypt(uaes_gcm_key *k, const uint8_t *nonce, const void *aDat
         }
         int *st_where = lane_status(L);
         if (st_where != L->d_status) { *(volatile int *)st_where = -1; ticket_arm(L, crtxtLen); }
-        uaesk_done_word_arm(KEY_DONE_WORD(k));
+        arm_done_word(KEY_DONE_WORD(k));
         int kk = uaesk_gcm_keyed(L->stream, &c->tb, k->ks.nr, &k->ks.ek,
                                  io.copy_back || io.dout == L->pin[1] ? 2 : gcm_decrypt_mode(), j0, d_aad, aDataLen,
                                  io.din, crtxtLen, io.dout, k->scratch, st_where);
-        uaesk_done_word_arm(NULL);
+        arm_done_word(NULL);
         ticket_armed_launch_done(L);
         if (kk) { rc = fail(UAES_E_HIP, "gcm launch: %s", hipGetErrorString((hipError_t)kk)); break; }
         if ((rc = lane_read_status(L, st_where, &status)) != 0) break;
@@ -2168,9 +2202,9 @@ int uaes_gcm_key_encrypt_dev(uaes_gcm_key *k, const uint8_t *nonce, const void *
     if ((rc = dev_ptrs_ok(d_in, d_out, len)) != 0) return rc;
     if ((rc = get_context(&c)) != 0) return rc;
     j0_of_nonce12(nonce, j0);
-    uaesk_done_word_arm(KEY_DONE_WORD(k));
+    arm_done_word(KEY_DONE_WORD(k));
     rc = uaesk_gcm_keyed(stream, &c->tb, k->ks.nr, &k->ks.ek, 0, j0, d_aad, aad_len, d_in, len, d_out, k->scratch, NULL);
-    uaesk_done_word_arm(NULL);
+    disarm_done_word_dev(stream, rc);
     KCHK(rc);
     return 0;
 }
@@ -2186,9 +2220,9 @@ int uaes_gcm_key_decrypt_dev(uaes_gcm_key *k, const uint8_t *nonce, const void *
     if ((rc = dev_ptrs_ok(d_in, d_out, len)) != 0) return rc;
     if ((rc = get_context(&c)) != 0) return rc;
     j0_of_nonce12(nonce, j0);
-    uaesk_done_word_arm(KEY_DONE_WORD(k));
+    arm_done_word(KEY_DONE_WORD(k));
     rc = uaesk_gcm_keyed(stream, &c->tb, k->ks.nr, &k->ks.ek, gcm_decrypt_mode(), j0, d_aad, aad_len, d_in, len, d_out, k->scratch, d_status);
-    uaesk_done_word_arm(NULL);
+    disarm_done_word_dev(stream, rc);
     KCHK(rc);
     return 0;
 }
@@ -2833,10 +2867,10 @@ int uaes_gcmsiv_encrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
              * counter made of it stay on the device (uaesk_gcmsiv_long) -- the host waits once, in finish_io */
             keysched master;
             if ((rc = expand_key(&master, key, keybits)) != 0) break;
-            uaesk_done_word_arm(scratch_done_word(L->scratch, L->scratch_cap));
+            arm_done_word(scratch_done_word(L->scratch, L->scratch_cap));
             int kl = uaesk_gcmsiv_long(L->stream, &c->tb, master.nr, &master.ek, 0, nonce, d_aad, aDataLen,
                                        io.din, ptextLen, io.dout, L->scratch, NULL);
-            uaesk_done_word_arm(NULL);
+            arm_done_word(NULL);
             memset(&master, 0, sizeof master);
             if (kl) { rc = fail(UAES_E_HIP, "gcm-siv launch: %s", hipGetErrorString((hipError_t)kl)); break; }
         }
@@ -2896,10 +2930,10 @@ int uaes_gcmsiv_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
             keysched master;
             int status = -1;
             if ((rc = expand_key(&master, key, keybits)) != 0) break;
-            uaesk_done_word_arm(scratch_done_word(L->scratch, L->scratch_cap));
+            arm_done_word(scratch_done_word(L->scratch, L->scratch_cap));
             int kl = uaesk_gcmsiv_long(L->stream, &c->tb, master.nr, &master.ek, 1, nonce, d_aad, aDataLen,
                                        io.din, crtxtLen, io.dout, L->scratch, L->d_status);
-            uaesk_done_word_arm(NULL);
+            arm_done_word(NULL);
             memset(&master, 0, sizeof master);
             if (kl) { rc = fail(UAES_E_HIP, "gcm-siv launch: %s", hipGetErrorString((hipError_t)kl)); break; }
             if ((rc = lane_fetch(L, &status, L->d_status, sizeof status)) != 0) break;
@@ -3680,6 +3714,20 @@ static int gather_fail_send(void)
 }
 
 static struct { unsigned long sends, recvs, groups, inits, failures; } g_gather_stats;
+
+/* ---- test hooks of the one-launch GCM arrangements (include/uaes_hip.h) ---- */
+void uaes_debug_gcm_look(unsigned long long ticks_100mhz) { uaesk_debug_gcm_look(ticks_100mhz); }
+
+int uaes_debug_gcm_chunk_folds(unsigned *out)
+{
+    context *c;
+    int rc;
+    if (!out) return fail(UAES_E_ARG, "NULL pointer");
+    if ((rc = get_context(&c)) != 0) return rc;
+    KCHK(hipDeviceSynchronize());
+    KCHK(uaesk_debug_gcm_chunk_folds(out));
+    return 0;
+}
 
 /* how often each RCCL entry point has run in this process (tests: "the gather really went through RCCL") */
 void uaes_debug_gather_stats(unsigned long out[5])

@@ -29,6 +29,7 @@
  * (16 B/block); everything else is O(2 MiB).
  */
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <string.h>
 #include <stdlib.h>
 #include "uaes_aes.hip.h"
@@ -1507,19 +1508,48 @@ extern "C" int uaesk_gcm_records(void *stream, const uaesk_tables *tb, int nr, c
  * MODE 0: encrypt; 1: hash the ciphertext only (decrypt, tag first: N7); 2: decrypt while hashing (one pass).  */
 #define GMC_MAXW 1024u          /* the combine kernel folds up to 1024 partial hashes: 32 MiB */
 
-/* FOLD (round 5): ONE launch -- the LAST workgroup is the FINISHER (gcm_combine_body: Enc(J0), the tables of Y, then it
- * waits for the others on *done_word, folds their hashes and makes the tag), workgroups 0..W-1 hash the chunks.  (Last,
- * not first: workgroups are dispatched in the order of their numbers, so when the finisher runs every chunk workgroup
- * has its place on the chip already -- a finisher that came first could sit on the only free slot of a crowded or
- * partitioned device while the ones it waits for cannot start.  On an idle device all W + 1 start together.)  The finisher's
- * preparations (6-7 us of a one-shot call) run beside the chunk work instead of behind it, and the launch of a second
- * kernel goes: 64 KiB 21.8 -> 18.9 us per call, 1 MiB 23.5 -> 21.1, with a key context 17.0 -> 15.3.  Nobody waits for the finisher, so it cannot block progress; it
- * sleeps between looks at the counter.  A chunk's hash goes out as four device-scope atomic
- * exchanges whose results are back before the workgroup counts itself in (uaes_ocb.hip explains why not a release
- * fence); the last look resets the counter for the next call (a word that is zero between calls, uaes_device.h).   */
+/* FOLD: ONE launch of W chunk workgroups + one PREPARING workgroup (the last of the grid).  The preparing workgroup
+ * makes what the fold needs beside the chunk work -- Enc(J0) and the tables of Y, 6-7 us of a one-shot call -- and the
+ * fold itself is done by WHOEVER OF THE W + 1 ARRIVES LAST on *done_word (a fetch-add each; the one that reads W is
+ * last), the way k_ocb makes its tag.  No workgroup ever waits for another one to make progress: correctness does not
+ * depend on the order or the concurrency in which the device runs the workgroups (CU masking, a debugger, a
+ * partitioned or oversubscribed device), and nothing traps.  Before it counts itself in, the preparing workgroup LOOKS
+ * at the counter for a bounded time (GMC_LOOK_TICKS of the 100 MHz clock = 1 ms; the chunk work of the largest
+ * one-launch call is ~25 us): on a healthy device every chunk workgroup has arrived by then, the preparing workgroup
+ * is the last and folds with the tables it already holds in LDS -- the fast path, the timing of round 5 (64 KiB
+ * 18.9 us per call, 1 MiB 21.1, with a key context 15.3).  If the look runs out it counts in and leaves; the chunk
+ * workgroup that then arrives last makes the tables itself (gcm_combine_body<NR, false>: 6-7 us more, only then).
+ * A chunk's hash goes out as four device-scope atomic exchanges whose results are back before the workgroup counts
+ * itself in (uaes_ocb.hip explains why not a release fence); the one that folds resets the counter for the next call
+ * (a word that is zero between calls, uaes_device.h; the host layer re-zeroes it after a launch that failed).        */
+#define GMC_LOOK_TICKS 100000ull
+
+/* the look as the kernels get it (GmcFin.look_ticks): GMC_LOOK_TICKS, or UAES_GCM_LOOK_TICKS / uaesk_debug_gcm_look()
+ * -- 0 makes the preparing workgroup count in without looking, so that a chunk workgroup is usually the last
+ * (tests/test_gpu_parity.py runs every one-launch size both ways) */
+static std::atomic<unsigned long long> g_look_ticks{ ~0ull };
+static u64 gcm_look_ticks(void)
+{
+    unsigned long long v = g_look_ticks.load(std::memory_order_relaxed);
+    if (v == ~0ull) {
+        const char *e = getenv("UAES_GCM_LOOK_TICKS");
+        v = e && *e ? strtoull(e, nullptr, 10) : GMC_LOOK_TICKS;
+        g_look_ticks.store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+extern "C" void uaesk_debug_gcm_look(unsigned long long ticks) { g_look_ticks.store(ticks, std::memory_order_relaxed); }
+
+/* how many folds a CHUNK workgroup has done on this device since the module was loaded (diagnostic) */
+__device__ unsigned g_gcm_chunk_folds;
+extern "C" int uaesk_debug_gcm_chunk_folds(unsigned *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gcm_chunk_folds), sizeof *out, 0, hipMemcpyDeviceToHost);
+}
 struct GmcFin {
     uint4 j0;
     unsigned *done_word;
+    u64 look_ticks;                                           /* the preparing workgroup's bounded look (100 MHz ticks) */
     unsigned char *tag_io;
     int *status;
     int mode;                                                 /* 0: write the tag, 1: compare it, 2: a piece of a streamed
@@ -1539,7 +1569,7 @@ __device__ __forceinline__ void gcm_combine_body(const uaesk_rk &ek, const uaesk
                                                  const unsigned char *__restrict__ scratch, u32 build,
                                                  int mode, unsigned char *tag_io, int *status, u32 ylog,
                                                  unsigned char *wipe_out, u64 wipe_len, unsigned *done_word,
-                                                 u64 len_aad, u64 len_ct);
+                                                 u64 len_aad, u64 len_ct, u64 look_ticks = 0);
 
 template <int NR, int MODE, bool FOLD = false>
 __global__ __launch_bounds__(GH_T) void k_gcm_chunks(uaesk_rk rk, uaesk_tables tb, uaesk_ctr ctr,
@@ -1549,7 +1579,8 @@ __global__ __launch_bounds__(GH_T) void k_gcm_chunks(uaesk_rk rk, uaesk_tables t
 {
     if (FOLD && blockIdx.x == gridDim.x - 1u) {
         gcm_combine_body<NR, true>(rk, tb, fin.j0, partial, gridDim.x - 1u, scratch, fin.mode == 2 ? fin.fin_build : build, fin.mode,
-                                   fin.tag_io, fin.status, fin.ylog, nullptr, fin.m, fin.done_word, fin.len_aad, fin.len_ct);
+                                   fin.tag_io, fin.status, fin.ylog, nullptr, fin.m, fin.done_word, fin.len_aad, fin.len_ct,
+                                   fin.look_ticks);
         ticket_release(fin.done);
         return;
     }
@@ -1704,7 +1735,19 @@ __global__ __launch_bounds__(GH_T) void k_gcm_chunks(uaesk_rk rk, uaesk_tables t
 #pragma unroll
         for (int q = 0; q < 4; ++q) old |= __hip_atomic_exchange(row + q, v[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" :: "v"(old) : "memory");
-        (void)__hip_atomic_fetch_add(fin.done_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned arrived = __hip_atomic_fetch_add(fin.done_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (arrived == nwg) __hip_atomic_store(fin.done_word, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        buf[GT_BUF - 4] = make_uint4(arrived == nwg ? 1u : 0u, 0, 0, 0);
+    }
+    __syncthreads();
+    if (buf[GT_BUF - 4].x != 0) {
+        /* the last of the W + 1 to arrive, and it is a chunk workgroup (the preparing workgroup's look ran out): the
+         * whole fold here, tables included */
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (threadIdx.x == 0) (void)__hip_atomic_fetch_add(&g_gcm_chunk_folds, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        gcm_combine_body<NR, false>(rk, tb, fin.j0, partial, nwg, scratch, fin.mode == 2 ? fin.fin_build : build, fin.mode,
+                                    fin.tag_io, fin.status, fin.ylog, nullptr, fin.m, nullptr, fin.len_aad, fin.len_ct);
     }
     ticket_release(fin.done);
 }
@@ -1715,7 +1758,7 @@ __device__ __forceinline__ void gcm_combine_body(const uaesk_rk &ek, const uaesk
                                                  const unsigned char *__restrict__ scratch, u32 build,
                                                  int mode, unsigned char *tag_io, int *status, u32 ylog,
                                                  unsigned char *wipe_out, u64 wipe_len, unsigned *done_word,
-                                                 u64 len_aad, u64 len_ct)
+                                                 u64 len_aad, u64 len_ct, u64 look_ticks)
 {
     uint4 *TC = (uint4 *)uaes_lds;
     uint4 *buf = TC + GT_NTAB * 512u;
@@ -1748,17 +1791,19 @@ __device__ __forceinline__ void gcm_combine_body(const uaesk_rk &ek, const uaesk
     const uint4 ej0 = buf[GT_BUF - 2];
     if (build) gcm_build_nibble_tables<true>(TC, buf, tb.frob, ylog);    /* Y^256, Y^64, Y^16, Y^4, Y in tables 1..5 */
     if (WAIT) {
-        /* the chunk workgroups count themselves in behind their hashes; a look every few hundred cycles; five seconds
-         * without the last one means a workgroup of this launch never ran: give the error to the runtime, not a hang */
+        /* the preparing workgroup of a one-launch call: a bounded look at the counter, then it counts itself in like
+         * everybody else; only the LAST of the W + 1 folds (GMC_LOOK_TICKS above) */
         if (threadIdx.x == 0) {
             const u64 t0 = wall_clock64();
-            while (__hip_atomic_load(done_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != W) {
+            while (__hip_atomic_load(done_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != W &&
+                   wall_clock64() - t0 < look_ticks)
                 __builtin_amdgcn_s_sleep(8);
-                if (wall_clock64() - t0 > 500000000ull) __builtin_trap();
-            }
-            __hip_atomic_store(done_word, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     /* for the next call */
+            const unsigned arrived = __hip_atomic_fetch_add(done_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (arrived == W) __hip_atomic_store(done_word, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     /* for the next call */
+            buf[GT_BUF - 4] = make_uint4(arrived == W ? 1u : 0u, 0, 0, 0);
         }
         __syncthreads();
+        if (buf[GT_BUF - 4].x == 0) return;                   /* a chunk workgroup is still out: IT folds (k_gcm_chunks) */
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         if (threadIdx.x >= GH_T - W) acc = partial[threadIdx.x - (GH_T - W)];
     }
@@ -1893,7 +1938,7 @@ static int launch_medium(hipStream_t st, const uaesk_tables *tb, const uaesk_rk 
     if (uaesk_device_info(&cus_f, nullptr) != 0) cus_f = 0;
     const bool fold = done_word != nullptr && decrypt != 2 && (int)W <= cus_f;
     if (fold) {
-        fin.j0 = j0; fin.done_word = done_word; fin.tag_io = tag_io; fin.status = status; fin.mode = decrypt ? 1 : 0;
+        fin.j0 = j0; fin.done_word = done_word; fin.look_ticks = gcm_look_ticks(); fin.tag_io = tag_io; fin.status = status; fin.mode = decrypt ? 1 : 0;
         fin.ylog = 10u + log2_u32(steps);
         fin.len_aad = src.len_aad; fin.len_ct = src.len_ct;
         if (!decrypt) fin.done = ticket.use();
@@ -2909,7 +2954,7 @@ extern "C" int uaesk_gcm_stream_piece(void *stream, const uaesk_tables *tb, int 
         src.ct = (const unsigned char *)in; src.ct_len = len;          /* the kernel reads the text itself */
         GmcFin fin;
         memset(&fin, 0, sizeof fin);
-        fin.done_word = done_word; fin.mode = 2; fin.ylog = 10u + log2_u32(steps); fin.fin_build = 1; fin.m = nvp;
+        fin.done_word = done_word; fin.look_ticks = gcm_look_ticks(); fin.mode = 2; fin.ylog = 10u + log2_u32(steps); fin.fin_build = 1; fin.m = nvp;
         const void *text = in;
         int rc = 0;
         if (two && !decrypt) {
@@ -3163,7 +3208,7 @@ static int siv_long_nr(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *m
         sm.has_len = 0;
         GmcFin fin;
         memset(&fin, 0, sizeof fin);
-        fin.j0 = nn; fin.done_word = done_word; fin.mode = decrypt ? 4 : 3; fin.ylog = 10u + log2_u32(steps);
+        fin.j0 = nn; fin.done_word = done_word; fin.look_ticks = gcm_look_ticks(); fin.mode = decrypt ? 4 : 3; fin.ylog = 10u + log2_u32(steps);
         fin.tag_io = decrypt ? (unsigned char *)in + len : (unsigned char *)out + len;
         fin.status = status; fin.len_aad = aad_len; fin.len_ct = len;
         uaesk_rk dummy;

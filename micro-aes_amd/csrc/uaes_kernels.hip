@@ -1313,9 +1313,12 @@ static thread_local unsigned *g_done_word = nullptr;
 extern "C" void uaesk_done_word_arm(unsigned *w) { g_done_word = w; }
 unsigned *uaesk_done_word_take()
 {
+    /* UAES_GCM_FOLD=0: the one-launch arrangements of the GCM family (chunk workgroups + a fold inside the same
+     * launch) are off; every such call takes its multi-launch form (chunks, then k_gcm_combine) */
+    static const bool fold_on = [] { const char *e = getenv("UAES_GCM_FOLD"); return !(e && e[0] == '0'); }();
     unsigned *w = g_done_word;
     g_done_word = nullptr;
-    return w;
+    return fold_on ? w : nullptr;
 }
 
 extern "C" int uaesk_ticket_disarm(void)

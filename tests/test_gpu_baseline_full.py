@@ -113,6 +113,8 @@ def _one_json_line(r):
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
+    # ONE JSON line and nothing else on stdout (RCCL's version banner once landed behind it: bench.py main())
+    assert [l for l in r.stdout.splitlines() if l.strip()] == lines, r.stdout[-2000:]
     return json.loads(lines[0])
 
 
@@ -157,6 +159,15 @@ def test_bench_line_measures_its_own_traffic_and_clock():
     assert pp["lds_clk_per_block_per_cu"] < pp["achieved_clk_per_block_per_cu"] < 5.2, pp
     # the sustained rate (>= 2 s of the same step back to back) rides next to `value`; the 12 ms window
     # behind `value` may catch the clocks a little high, never the other way round by more than noise
+    # configs[3] (GCM, 1 GiB) and configs[2] (XTS-256, 2^20 x 4 KiB) ride in the driver's line,
+    # each timed after the headline and checked against the compiled reference's tag / digest
+    oc = line["other_configs"]
+    assert oc["gcm_c4"]["verified"] is True and oc["xts_c3"]["verified"] is True, oc
+    assert oc["gcm_c4"]["bytes"] == GIB and oc["xts_c3"]["bytes"] == 4 * GIB
+    assert 0.25 < oc["gcm_c4"]["frac"] < 0.45 and 0.2 < oc["xts_c3"]["frac"] < 0.35, oc
+    # ... and the C host's gather went through RCCL (ncclSend / ncclRecv to itself) with the C2 digest at the end
+    cg = line["c_gather"]
+    assert cg["forced_self_send"] is True and cg["rccl_sends"] == 2 and cg.get("stream_digest_ok") is True, cg
     sus = line["sustained"]
     assert sus["seconds"] >= 1.9 and sus["steps"] >= 1000 and sus["unit"] == "GiB/s"
     assert sus["value"] <= line["value"] * 1.04, (sus, line["value"])      # (measured: 0.99 .. 1.014 of the window's rate)

@@ -9,6 +9,8 @@ import subprocess
 
 import pytest
 
+from tests.refbuilt import REF_DIR, makefile_targets, missing, need
+
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -19,9 +21,7 @@ EXPECT = {128: {"CMAC": 96, "GCM": 375, "CCM": 10, "OCB": 16, "GCM-SIV": 102, "X
 
 @pytest.mark.parametrize("bits", [128, 192, 256])
 def test_reference_harness_runs_on_the_hip_library(bits, tmp_path, golden_dir):
-    exe = os.path.join(REF, "harness_hip_%d" % bits)
-    if not os.path.exists(exe):
-        pytest.skip("oracle/_ref/harness_hip_%d was not built (needs /root/reference at build time)" % bits)
+    exe = need("harness_hip_%d" % bits)
     for f in os.listdir(golden_dir):
         if f.endswith((".rsp", ".tv")):
             os.symlink(os.path.join(golden_dir, f), tmp_path / f)
@@ -38,9 +38,7 @@ def test_reference_harness_runs_on_the_hip_library(bits, tmp_path, golden_dir):
 def test_reference_harness_with_other_gcm_nonce_lengths(exe, bits, want, tmp_path, golden_dir):
     """the unchanged harness built with -DGCM_NONCE_LEN=1 / 128 picks the [IVlen = 8] / [IVlen = 1024]
     sections of the NIST GCM files (aes_testvectors_GCM.h:86) and must pass all 375 on the HIP library"""
-    path = os.path.join(REF, exe)
-    if not os.path.exists(path):
-        pytest.skip("oracle/_ref/%s was not built" % exe)
+    path = need(exe)
     for f in os.listdir(golden_dir):
         if f.endswith((".rsp", ".tv")):
             os.symlink(os.path.join(golden_dir, f), tmp_path / f)
@@ -59,9 +57,7 @@ def test_reference_harness_with_other_length_constants(exe, bits, want, tmp_path
     -DCCM_NONCE_LEN=7 -DGCM_TAG_LEN=4 (AES-256) against include/micro_aes.h: it then runs the [Nlen = 13] / [Nlen = 7]
     sections of the VNT files, compares 12 / 4 bytes of every GCM tag and takes the seven 12-byte-tag OCB stanzas (one of them an expected failure)
     (aes_testvectors_CCM.h:84, _GCM.h:24,86, _OCB.h:90) -- all on the HIP library"""
-    path = os.path.join(REF, exe)
-    if not os.path.exists(path):
-        pytest.skip("oracle/_ref/%s was not built" % exe)
+    path = need(exe)
     for f in os.listdir(golden_dir):
         if f.endswith((".rsp", ".tv")):
             os.symlink(os.path.join(golden_dir, f), tmp_path / f)
@@ -74,9 +70,7 @@ def test_reference_harness_with_other_length_constants(exe, bits, want, tmp_path
 
 @pytest.mark.parametrize("bits", [128, 192, 256])
 def test_reference_main_c_runs_on_the_hip_library(bits):
-    exe = os.path.join(REF, "main_hip_%d" % bits)
-    if not os.path.exists(exe):
-        pytest.skip("oracle/_ref/main_hip_%d was not built" % bits)
+    exe = need("main_hip_%d" % bits)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "FAILED" not in r.stdout, r.stdout + r.stderr
     passed = re.findall(r"AES-%d (\w+) \w+: PASSED!" % bits, r.stdout)
@@ -91,9 +85,7 @@ def test_reference_main_c_aes192_pkcs7_check_runs_on_the_hip_library():
     """main.c's only AES-192 check on the hot path (main.c:139) is compiled when AES_PADDING is 1:
     the same main.c built with -DAES_PADDING=1 against include/micro_aes.h, which then binds
     AES_ECB_encrypt to the PKCS#7 entry point of libmicro_aes_hip_192.so"""
-    exe = os.path.join(REF, "main_hip_192_pkcs7")
-    if not os.path.exists(exe):
-        pytest.skip("oracle/_ref/main_hip_192_pkcs7 was not built")
+    exe = need("main_hip_192_pkcs7")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "FAILED" not in r.stdout, r.stdout + r.stderr
     assert re.findall(r"AES-192 (\w+) \w+: PASSED!", r.stdout) == ["ECB", "ECB"], r.stdout
@@ -103,9 +95,7 @@ def test_reference_main_c_preset_counter_runs_on_the_hip_library():
     """main.c built with -DPRESET_COUNTER=1 (micro_aes.h:100) passes its 16-byte iVec to AES_CTR_* as the
     whole counter block and checks its own known answer for that case (main.c:45-47); include/micro_aes.h
     then binds AES_CTR_* to the *_preset entry points (uaes_ctr_xcrypt_at with block offset 0)"""
-    exe = os.path.join(REF, "main_hip_128_presetctr")
-    if not os.path.exists(exe):
-        pytest.skip("oracle/_ref/main_hip_128_presetctr was not built")
+    exe = need("main_hip_128_presetctr")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "FAILED" not in r.stdout, r.stdout + r.stderr
     assert re.findall(r"AES-128 (CTR) \w+: PASSED!", r.stdout) == ["CTR", "CTR"], r.stdout
@@ -115,9 +105,19 @@ def test_reference_main_c_without_cts_runs_on_the_hip_library():
     """main.c built with -DCTS=0 (micro_aes.h:56) checks CBC against its zero-padded known answer (main.c:36-40,
     :149-150: the whole padded ciphertext, and decryption of it); include/micro_aes.h then binds AES_CBC_* to the
     *_nocts entry points (padded last chunk, block-parallel whole-block decryption)"""
-    exe = os.path.join(REF, "main_hip_128_nocts")
-    if not os.path.exists(exe):
-        pytest.skip("oracle/_ref/main_hip_128_nocts was not built")
+    exe = need("main_hip_128_nocts")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "FAILED" not in r.stdout, r.stdout + r.stderr
     assert re.findall(r"AES-128 (CBC) \w+: PASSED!", r.stdout) == ["CBC", "CBC"], r.stdout
+
+
+def test_reference_built_evidence_travelled_to_this_box():
+    """on the GPU box every binary the `ref` and `dropin` targets of oracle/Makefile name must be
+    under oracle/_ref/ (it is git-ignored and travels only as an untracked directory), and bench.py's CPU baseline must
+    really be the compiled reference (`kind: reference`), not the restatement it would quietly fall back to."""
+    import bench
+    gone = [n for n in makefile_targets() if not os.path.exists(os.path.join(REF_DIR, n))]
+    if gone:
+        missing("oracle/_ref/{%s}" % ",".join(gone))
+    cb = bench.cpu_baseline("ctr", sample=4 << 20, all_cores=False)
+    assert cb["kind"] == "reference" and cb["cores"] == 1 and cb["value"] > 0, cb

@@ -259,10 +259,8 @@ def test_reference_main_c_with_UAES_DEVICES_in_the_environment():
     call of its known-answer tests -- 57-byte texts -- is cut into three slices, and every verdict stays PASSED"""
     import re
     import subprocess
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "oracle", "_ref", "main_hip_128")
-    if not os.path.exists(exe):
-        pytest.skip("oracle/_ref/main_hip_128 was not built")
+    from tests.refbuilt import need
+    exe = need("main_hip_128")
     base = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     env = dict(os.environ, UAES_DEVICES="0,0,0", UAES_DEVICES_MIN_MIB="0")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)

@@ -505,12 +505,64 @@ def test_ocb_one_launch_paths(orc, bits):
                 assert int(status.item()) == 0 and bytes(back.cpu().numpy()) == data
 
 
-def test_gcm_medium_texts_one_launch(orc):
-    """32 KiB .. 8 MiB: the chunk workgroups and a FINISHER workgroup in one launch (k_gcm_chunks<.., FOLD>): the
-    finisher waits on a counter word that must be back at zero for the next call -- the same lane / stream slot / key
-    context again and again, sizes on both sides of the arrangement's limits (one or two positions per thread; as many
-    chunk workgroups as the finisher still leaves a CU for), AAD, encryption and both decryption orders."""
+def _chunk_folds():
+    out = C.c_uint(0)
+    assert uaes.engine().uaes_debug_gcm_chunk_folds(C.byref(out)) == 0
+    return out.value
+
+
+@pytest.mark.parametrize("look", ["default", "none"])
+def test_gcm_medium_texts_one_launch(orc, look):
+    """32 KiB .. 8 MiB: the chunk workgroups and a PREPARING workgroup in one launch (k_gcm_chunks<.., FOLD>); whoever of
+    them arrives last on a counter word folds the chunk hashes and makes the tag, and puts the word back to zero for the
+    next call -- the same lane / stream slot / key context again and again, sizes on both sides of the arrangement's
+    limits (one or two positions per thread; as many chunk workgroups as there are CUs), AAD, encryption and both
+    decryption orders.  look = "default": the preparing workgroup looks at the counter for up to 1 ms before it counts
+    in, so on this idle device it is the last and folds with its own tables (no fold by a chunk workgroup);
+    look = "none" (uaes_debug_gcm_look(0)): it counts in at once, a chunk workgroup is usually the last and the whole
+    fold -- tables included -- runs there (VERDICT r05 next #4: nobody waits, nothing traps, either order is exact)."""
     import torch
+    L = uaes.engine()
+    L.uaes_debug_gcm_look(0 if look == "none" else 100000)
+    folds0 = _chunk_folds()
+    try:
+        _medium_texts(orc, torch)
+        _siv_and_stream_pieces(orc)
+    finally:
+        L.uaes_debug_gcm_look(100000)
+    folds = _chunk_folds() - folds0
+    if look == "none":
+        assert folds > 20, "with no look the fold must have run in a chunk workgroup many times (%d)" % folds
+    else:
+        assert folds == 0, "on an idle device the preparing workgroup is the last to arrive (%d folds elsewhere)" % folds
+
+
+def _siv_and_stream_pieces(orc):
+    """the other users of the one-launch arrangement: long GCM-SIV messages (POLYVAL by hash-only chunk workgroups, the
+    tag made by the fold) and the pieces of a streamed GCM message (the fold adds the piece's hash to the running one)"""
+    rnd = random.Random(99)
+    key, nonce = rnd.randbytes(32), rnd.randbytes(12)
+    for n in (70000, (1 << 20) + 5, (6 << 20) + 48):
+        data, aad = orc.splitmix(n + 9, n), rnd.randbytes(33)
+        ws = orc.gcmsiv_encrypt(key, nonce, aad, data)
+        for _ in range(2):
+            assert uaes.GCM_SIV_encrypt(key, nonce, aad, data) == ws, n
+        assert uaes.GCM_SIV_decrypt(key, nonce, aad, ws) == (0, data), n
+    key = rnd.randbytes(16)
+    for pieces in ((1 << 20, 1 << 20, 4096 + 5), (262144, 65536, 1 << 21, 16)):
+        data = orc.splitmix(sum(pieces), sum(pieces))
+        aad = rnd.randbytes(21)
+        want = orc.gcm_encrypt(key, nonce, aad, data)
+        stm = uaes.GcmStream(key, nonce, aad)
+        out, o = bytearray(), 0
+        for m in pieces:
+            out += stm.update(data[o:o + m])
+            o += m
+        tag = stm.finish()
+        assert bytes(out) + bytes(tag) == want, pieces
+
+
+def _medium_texts(orc, torch):
     rnd = random.Random(4242)
     key, st = rnd.randbytes(16), torch.cuda.current_stream()
     gk = uaes.GcmKey(key)

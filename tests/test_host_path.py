@@ -211,9 +211,8 @@ def _gpu_less():
 def test_reference_main_c_on_the_drop_in_library_without_a_gpu(exe, want_passed):
     """`main_hip_128` on a GPU-less box.  Default policy: the void functions reach the failure handler
     (abort); with UAES_HOST_FALLBACK=1 every known-answer test of the reference's main.c passes."""
-    path = os.path.join(REF, exe)
-    if not os.path.exists(path):
-        pytest.skip("oracle/_ref/%s was not built (needs /root/reference at build time)" % exe)
+    from tests.refbuilt import need
+    path = need(exe)
     if not _gpu_less():
         pytest.skip("this box has a GPU")
     r = subprocess.run([path], capture_output=True, text=True, timeout=300, env=dict(os.environ, UAES_HOST_FALLBACK="1"))
@@ -229,9 +228,8 @@ def test_reference_testvector_harness_on_the_drop_in_library_without_a_gpu(bits,
     """the reference's testvectors/ harness, unchanged, on libmicro_aes_hip_<bits>.so with the host fallback: the same
     case counts as on the GPU (tests/test_gpu_dropin.py)"""
     from tests.test_gpu_dropin import EXPECT
-    exe = os.path.join(REF, "harness_hip_%d" % bits)
-    if not os.path.exists(exe):
-        pytest.skip("oracle/_ref/harness_hip_%d was not built" % bits)
+    from tests.refbuilt import need
+    exe = need("harness_hip_%d" % bits)
     if not _gpu_less():
         pytest.skip("this box has a GPU")
     for f in os.listdir(golden_dir):

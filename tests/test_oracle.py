@@ -11,6 +11,7 @@ import random
 import pytest
 
 from oracle.pyoracle import Reference
+from tests.refbuilt import REF_DIR, allow_missing, makefile_targets, missing
 from tests.rsp import ccm_cases, cmac_cases, gcm_cases, gcmsiv_cases, ocb_cases, xts_cases
 
 EXPECTED_COUNTS = {("gcm", 128): 375, ("gcm", 192): 375, ("gcm", 256): 375,
@@ -73,7 +74,7 @@ def test_gcm_nonce_length_builds_of_the_reference(orc, bits, iv_bytes):
     """oracle == the reference compiled with GCM_NONCE_LEN patched (oracle/Makefile), random inputs:
     the counter derived from GHASH(nonce) keeps stepping with the 56-bit incBlock (N2)"""
     if not Reference.available(bits, gcm_nonce_len=iv_bytes):
-        pytest.skip("oracle/_ref not built here")
+        missing("a build of the reference under oracle/_ref")
     ref = Reference(bits, gcm_nonce_len=iv_bytes)
     rnd = random.Random(12 + iv_bytes)
     for _ in range(60):
@@ -174,7 +175,7 @@ def test_length_constant_builds_of_the_reference_golden(orc, golden_dir):
 def test_length_constant_builds_of_the_reference_random(orc, name):
     bits = Reference.LENS[name][0]
     if not Reference.available(bits, lens=name):
-        pytest.skip("oracle/_ref/libmicroaes_ref_%d_lens%s.so not built" % (bits, name))
+        missing("a build of the reference under oracle/_ref")
     ref, rnd = Reference(bits, lens=name), random.Random(77)
     for trial in range(40):
         key, pt = rnd.randbytes(bits // 8), rnd.randbytes(rnd.choice([0, 1, 15, 16, 17, 64, 100, 1000]))
@@ -396,7 +397,7 @@ def test_ecb_padding_vectors(orc, golden_dir):
 @pytest.mark.parametrize("bits,padding", [(192, 1), (128, 2)])
 def test_padded_ecb_against_compiled_reference(orc, bits, padding):
     if not Reference.available(bits, padding):
-        pytest.skip("oracle/_ref not built here")
+        missing("a build of the reference under oracle/_ref")
     ref = Reference(bits, padding=padding)
     rnd = random.Random(77 + padding)
     for _ in range(80):
@@ -434,7 +435,7 @@ def test_build_variant_vectors(orc, golden_dir):
 def test_build_variants_against_compiled_reference(orc, variant):
     ref = Reference.of_variant(variant)
     if ref is None:
-        pytest.skip("oracle/_ref/%s not built here" % variant)
+        missing("a build of the reference under oracle/_ref")
     rnd = random.Random(variant)
     for _ in range(60):
         n = rnd.choice([0, 1, 7, 15, 16, 17, 32, 33, 100, 511, 512, 3001])
@@ -455,7 +456,7 @@ def test_against_compiled_reference_random(orc, bits):
     """oracle == the real reference on fresh random inputs (skipped if the
     prebuilt oracle/_ref did not travel to this box)"""
     if not Reference.available(bits):
-        pytest.skip("oracle/_ref not built here")
+        missing("a build of the reference under oracle/_ref")
     ref = Reference(bits)
     rnd = random.Random(1000 + bits)
     kb = bits // 8
@@ -499,7 +500,7 @@ def test_preset_counter_build_of_the_reference(orc, golden_dir):
     the reference built with PRESET_COUNTER 1 (micro_aes.h:100, micro_aes.c:965-966), including counters
     that carry through bytes 9..15 and wrap mod 2^56 (N2), and main.c's own known answer (main.c:45-47)"""
     if not Reference.available(128, preset_counter=True):
-        pytest.skip("oracle/_ref not built here")
+        missing("a build of the reference under oracle/_ref")
     ref = Reference(128, preset_counter=True)
     rnd = random.Random(4242)
     for _ in range(120):
@@ -527,3 +528,15 @@ def test_preset_counter_build_of_the_reference(orc, golden_dir):
         d = json.load(f)
     assert d["C5_shard_0"]["sha256"] == d["C2_ctr128_1GiB_seed2"]["sha256"]
     assert all("C5_shard_%d" % g in d for g in range(8))
+
+
+def test_every_reference_built_file_is_present():
+    """VERDICT r05 next #3 (CPU half): every file oracle/Makefile's `ref` and `dropin` targets name exists under
+    oracle/_ref/ -- the pinned checker and the drop-in binaries -- unless UAES_ALLOW_NO_REF=1 says this checkout is
+    allowed to be without them.  Deleting oracle/_ref/ turns the suite red, not yellow."""
+    names = makefile_targets()
+    assert len(names) >= 28 and "libmicroaes_ref_128.so" in names and "harness_hip_256_lens2" in names and "main_hip_192" in names, names
+    gone = [n for n in names if not os.path.exists(os.path.join(REF_DIR, n))]
+    if gone:
+        missing("oracle/_ref/{%s}" % ",".join(gone))
+    assert Reference.available(128) and Reference.available(192) and Reference.available(256)
