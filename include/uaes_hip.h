@@ -510,6 +510,22 @@ int uaes_mgpu_ctr_encrypt_gather(int ndev, const int *devices, int keybits, cons
  * since the library was loaded. */
 void uaes_debug_gather_stats(unsigned long out[5]);
 
+/* ---- the table of arrangements, as data ------------------------------------------------------------------------
+ * Which kernels a call runs is decided in ONE place per mode (csrc/uaes_plan.h holds the table and the names; the
+ * launchers switch on the same functions).  uaes_debug_plan() returns that decision without running anything:
+ *   mode   0 ECB, 1 CTR, 2 XTS, 3 GCM, 4 OCB, 5 GCM-SIV
+ *   dir    0 encrypt, 1 decrypt (GCM: tag first, N7), 2 GCM decrypt in one pass, 3 GCM tag only
+ *   a, b   bytes of text, bytes of associated data (XTS: bytes per data unit, number of units)
+ *   flags  bit 0 key context, bit 1 explicit XTS tweak, bit 2 no counter word (two-launch forms), bit 3 LE32 counter
+ *   out    [0] arrangement id (uaes_debug_arrangement_name), [1] kernel launches, [2] workgroups of the main kernel,
+ *          [3] GHASH positions per thread (chunk arrangements)
+ * Works without a device (answers for a 256-CU MI355X).  uaes_debug_plan_disable(mask): arrangements whose bit
+ * (1u << id) is set are passed over wherever another one can take the call (measurement and tests; environment
+ * UAES_PLAN_DISABLE gives the initial mask).  tests/test_gpu_plan.py derives its parity cases from this table. */
+int uaes_debug_plan(int mode, int dir, size_t a, size_t b, unsigned flags, int out[4]);
+const char *uaes_debug_arrangement_name(int id);
+void uaes_debug_plan_disable(unsigned mask);
+
 /* Test hooks of the one-launch GCM / GCM-SIV / streamed-piece arrangements (chunk workgroups + one preparing workgroup
  * in ONE launch; whoever of them arrives last on a counter word folds the chunk hashes and makes the tag -- nobody
  * waits for anybody, DESIGN.md "GCM").  The preparing workgroup looks at the counter for a bounded time before it

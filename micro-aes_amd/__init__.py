@@ -43,6 +43,7 @@ EXPORTS = [
     "uaes_cmac", "uaes_ccm_encrypt", "uaes_ccm_decrypt", "uaes_gcmsiv_encrypt", "uaes_gcmsiv_decrypt",
     "uaes_ocb_encrypt", "uaes_ocb_decrypt", "uaes_ocb_dev",
     "uaes_mgpu_ctr_xcrypt_at", "uaes_mgpu_xts_sectors", "uaes_mgpu_ctr_encrypt_gather", "uaes_debug_gather_stats", "uaes_debug_gcm_look", "uaes_debug_gcm_chunk_folds",
+    "uaes_debug_plan", "uaes_debug_arrangement_name", "uaes_debug_plan_disable",
     "uaes_mgpu_ecb_encrypt", "uaes_mgpu_ecb_decrypt", "uaes_mgpu_gcm_encrypt", "uaes_mgpu_gcm_decrypt",
     "uaes_set_devices", "uaes_set_producer_stream", "uaes_set_host_policy", "uaes_get_host_policy",
     "uaes_gcm_key_new", "uaes_gcm_key_free", "uaes_gcm_key_encrypt", "uaes_gcm_key_decrypt",
@@ -149,6 +150,12 @@ def engine():
         L.uaes_debug_gcm_look.argtypes = [C.c_ulonglong]
         L.uaes_debug_gcm_look.restype = None
         L.uaes_debug_gcm_chunk_folds.argtypes = [C.POINTER(C.c_uint)]
+    if hasattr(L, "uaes_debug_plan"):
+        L.uaes_debug_plan.argtypes = [i, i, sz, sz, C.c_uint, C.POINTER(C.c_int)]
+        L.uaes_debug_arrangement_name.argtypes = [i]
+        L.uaes_debug_arrangement_name.restype = C.c_char_p
+        L.uaes_debug_plan_disable.argtypes = [C.c_uint]
+        L.uaes_debug_plan_disable.restype = None
     L.uaes_mgpu_ecb_encrypt.argtypes = [i, C.POINTER(C.c_int), i, vp, i, vp, sz, vp]
     L.uaes_mgpu_ecb_decrypt.argtypes = [i, C.POINTER(C.c_int), i, vp, vp, sz, vp]
     for n in ("uaes_mgpu_gcm_encrypt", "uaes_mgpu_gcm_decrypt"):
@@ -191,7 +198,8 @@ def engine():
     for n in EXPORTS:
         if n.startswith("uaes_debug_") and not hasattr(L, n):
             continue
-        if n not in ("uaes_last_error", "uaes_version", "uaes_gcm_key_free", "uaes_gcm_stream_abort", "uaes_debug_gather_stats", "uaes_debug_gcm_look"):
+        if n not in ("uaes_last_error", "uaes_version", "uaes_gcm_key_free", "uaes_gcm_stream_abort", "uaes_debug_gather_stats", "uaes_debug_gcm_look",
+                     "uaes_debug_arrangement_name", "uaes_debug_plan_disable"):
             getattr(L, n).restype = i
     _lib = L
     return L
@@ -724,6 +732,24 @@ class GcmStream:
         if getattr(self, "_h", None):
             engine().uaes_gcm_stream_abort(self._h)
             self._h = None
+
+
+MODES = {"ecb": 0, "ctr": 1, "xts": 2, "gcm": 3, "ocb": 4, "siv": 5}
+
+
+def plan(mode, a, b=0, direction=0, flags=0):
+    """What a call would run (uaes_debug_plan): (arrangement name, launches, workgroups, positions per thread)."""
+    out = (C.c_int * 4)()
+    _check(engine().uaes_debug_plan(MODES[mode], direction, a, b, flags, out), "uaes_debug_plan")
+    return engine().uaes_debug_arrangement_name(out[0]).decode(), out[1], out[2], out[3]
+
+
+def arrangement_id(name):
+    L = engine()
+    for k in range(64):
+        if L.uaes_debug_arrangement_name(k) == name.encode():
+            return k
+    raise KeyError(name)
 
 
 def ghash(H, aData, crtxt):

@@ -329,15 +329,6 @@ __device__ __forceinline__ void issue16(const u32 (&s)[4], u32 (&t)[16], const L
             t[4 * c + 2] = tlook<0, 2>(cc, lc); t[4 * c + 3] = tlook<0, 3>(d, lc);
         }
     }
-#ifdef UAES_ISSUE_INTERLEAVE
-    /* experiment: force (address, ds_read) pairs instead of the compiler's 16 address
-     * computations followed by 16 reads; UAES_ISSUE_INTERLEAVE = VALU and DS instructions per group     */
-#pragma unroll
-    for (int i = 0; i < 16 / UAES_ISSUE_INTERLEAVE; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x002, UAES_ISSUE_INTERLEAVE, 0);   /* VALU    */
-        __builtin_amdgcn_sched_group_barrier(0x100, UAES_ISSUE_INTERLEAVE, 0);   /* DS read */
-    }
-#endif
 }
 
 /* Si[x0] | Si[x1] << 16 (bytes 1 and 3 are junk) from the Td0 words of x0 and x1:
@@ -430,7 +421,7 @@ __device__ __forceinline__ void enc_rounds_skewed(u32 (&sa)[4], u32 (&sb)[4], co
      * ds_read) runs at priority 1, a wave that is combining results at 0.  Every SIMD holds
      * 4 waves; with equal priorities the oldest wave wins the VALU whatever it is about to do,
      * and the LDS pipe -- the scarcer resource -- idles while combines run.  Measured on 1 GiB,
-     * interleaved A/B (profiles/r02_wave_priority_ab.log): CTR +3.0 %, ECB +2.1 %, ECB decrypt
+     * interleaved A/B (profiles/HISTORY.md): CTR +3.0 %, ECB +2.1 %, ECB decrypt
      * +6.5 %, XTS-256 +3.6 %, GCM +1.4 %, neutral for OCB and CBC/CFB decrypt.  Priority 2 or 3
      * instead of 1 does the same for those and costs OCB / CBC / CFB decrypt 3-5 %.
      * PHI = the priority of the issue phase (the fused GCM kernel uses 2 and runs its GHASH
@@ -463,9 +454,6 @@ __device__ __forceinline__ void enc_rounds_skewed(u32 (&sa)[4], u32 (&sb)[4], co
 }
 
 /* hand-scheduled variants of the same two-block loop (tools/gen_rounds_asm.py), selected at build time */
-#ifdef UAES_ASM_VARIANT
-#include "uaes_rounds_asm.inc.h"
-#endif
 
 /* full cipher on two blocks, skewed (state = plaintext words on entry) */
 struct RkView {

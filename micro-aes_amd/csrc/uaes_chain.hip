@@ -478,14 +478,6 @@ static unsigned cu_count()
     return cus > 0 ? (unsigned)cus : 256u;
 }
 
-/* an integer from the environment, clamped; callers keep it in a function-local `static const` */
-static int env_int_clamped(const char *name, int dflt, int lo, int hi)
-{
-    const char *e = getenv(name);
-    int v = (e && *e) ? atoi(e) : dflt;
-    return v < lo ? lo : v > hi ? hi : v;
-}
-
 template <int NR, bool CFB, int U>
 static int launch_fb_dec_u(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *k, uint4 iv,
                            const void *in, void *out, u64 n, u32 rem, u32 cts_r)
@@ -530,7 +522,7 @@ template <int NR, bool MAC>
 static int launch_batch(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *k, const void *ivs,
                         u64 nmsg, u64 msg_bytes, const void *in, void *out)
 {
-    static const int row_max = env_int_clamped("UAES_BATCH_ROW_MAX", 81919, 0, 1 << 30);
+    const int row_max = 81919;
     if (nmsg <= (u64)row_max) {
         const bool a4 = ((((uintptr_t)in) | ((uintptr_t)out)) & 3u) == 0 && msg_bytes % 4 == 0;
         /* 64 messages per 16-wave workgroup; few messages: 4-wave workgroups, so that they spread over the CUs */

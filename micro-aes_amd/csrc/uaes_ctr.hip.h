@@ -74,7 +74,7 @@ __device__ __forceinline__ void ctr_edge_blocks(const uaesk_rk &rk, const uaesk_
 }
 
 #define CTRS_CHUNK 64u                       /* groups (of 256 counters) per U-buffer refill: one barrier each;
-                                                256 measured no faster (profiles/r01_sweep_ctr_variants.log) */
+                                                256 measured no faster (profiles/HISTORY.md) */
 
 /* ------------------------------------------------------------------------ */
 /* CTR with shared rounds 1-2                                                 */
@@ -167,10 +167,6 @@ __device__ __forceinline__ void ctr_shared_loop(const uaesk_rk &rk, const uaesk_
     /* Block index of (it, u, lane) = ((group0(it) + 4u) << 8) - c0 [uniform] + lane_blk [per lane].
      * The plaintext of iteration it+1 is requested before the rounds of iteration it, so
      * HBM latency hides under ~260 table lookups.                                       */
-#ifdef UAES_CTR_TIMING
-    u64 ctr_tm_wait = 0;
-    const u64 ctr_tm_start = wall_clock64();
-#endif
     u64 it = 0;
     uint4 d_cur[2] = { make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0) };
     if (FOLD::text_ahead && it < geo.iters) {
@@ -222,11 +218,7 @@ __device__ __forceinline__ void ctr_shared_loop(const uaesk_rk &rk, const uaesk_
                 const u32 u3 = xor3(TL(0, 0, c3), TL(2, 2, c1), TL(3, 3, c2)) ^ rk.w[11];
                 buf[(parity * CTRS_CHUNK + gi) * 2 + 0] = make_uint4(u0, u1, u2, u3);
             }
-#ifdef UAES_CTR_TIMING
-            { const u64 t0 = wall_clock64(); __syncthreads(); ctr_tm_wait += wall_clock64() - t0; }
-#else
             __syncthreads();
-#endif
         }
 
     };
@@ -238,17 +230,12 @@ __device__ __forceinline__ void ctr_shared_loop(const uaesk_rk &rk, const uaesk_
         {
             const u64 gn = FOLD::text_ahead ? ctr_geo_group0(geo, it + 1 < geo.iters ? it + 1 : it) : g0;
             uint4 (&d_ld)[2] = FOLD::text_ahead ? d_nxt : d_cur;
-#ifdef UAES_CTR_GLOBAL_LD               /* measurement / bisecting build: plain pointers instead of buffer resources */
-#pragma unroll
-            for (int u = 0; u < 2; ++u) d_ld[u] = (in + (((gn + 4u * u) << 8) - c0))[lane_blk];
-#else
             const __amdgpu_buffer_rsrc_t rin = STRIPE_RSRC(in + ((gn << 8) - c0));
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rin, lane_byte, 16384 * u, 0);
                 d_ld[u] = make_uint4(v.x, v.y, v.z, v.w);
             }
-#endif
         }
 
         u32 s[2][4];
@@ -258,10 +245,6 @@ __device__ __forceinline__ void ctr_shared_loop(const uaesk_rk &rk, const uaesk_
             const uint4 uu = buf[(parity * CTRS_CHUNK + gl) * 2 + 0];
             s[u][0] = L0 ^ uu.x; s[u][1] = L1 ^ uu.y; s[u][2] = L2 ^ uu.z; s[u][3] = L3 ^ uu.w;
         }
-#ifdef UAES_ASM_VARIANT
-        if constexpr (LC::LAY == 0) enc_rounds_asm<NR - 2>(s[0], s[1], rkv.w, lc);
-        else
-#endif
         enc_rounds_skewed<NR, 3, decltype(rkv), false, LC, FOLD::round_prio>(s[0], s[1], rkv, lc);
         uint4 ct[2];
 #pragma unroll
@@ -283,16 +266,7 @@ __device__ __forceinline__ void ctr_shared_loop(const uaesk_rk &rk, const uaesk_
     uint4 d_a[2], d_b[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) d_a[u] = d_cur[u];
-#if defined(UAES_CTR_NO_EXPAND2) || defined(UAES_ASM_VARIANT)
-    /* measurement builds.  The hand-scheduled round blocks (UAES_ASM_VARIANT, tools/gen_rounds_asm.py) are bit-exact
-     * with the body once per trip; with TWO >100-operand asm statements per trip the build's output is wrong and varies
-     * from run to run (profiles/r04_ctr_asm_variants_ab.log, third table): the second statement's clobbers land right
-     * behind the first body's 128-bit store, the buffer_store / VALU-write hazard described at the store above
-     *  -- so the asm variants run the body once per trip.                                          */
-    constexpr bool twice = false;
-#else
     constexpr bool twice = FOLD::expand2;
-#endif
     /* chunk by chunk (8 iterations = 64 groups of the U-buffer): refill, then the chunk's iterations */
     while (it < geo.iters) {
         const u64 end = it + 8 < geo.iters ? it + 8 : geo.iters;
@@ -316,11 +290,6 @@ __device__ __forceinline__ void ctr_shared_loop(const uaesk_rk &rk, const uaesk_
     }
 #undef TL
 #undef STRIPE_RSRC
-#ifdef UAES_CTR_TIMING
-    if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 100))
-        printf("wg %u wave %2u: loop %llu barrier-wait %llu (x10 ns)\n", blockIdx.x, wave,
-               (unsigned long long)(wall_clock64() - ctr_tm_start), (unsigned long long)ctr_tm_wait);
-#endif
 }
 
 #endif

@@ -154,14 +154,6 @@ int uaesk_gcm_stream_piece(void *stream, const uaesk_tables *tb, int nr, const u
                            uint64_t done_bytes, void *out, void *scratch, unsigned *plan_state, unsigned *done_word);
 int uaesk_gcm_stream_tag(void *stream, void *scratch, int compare, void *tag_io, int *status);
 
-/* POLYVAL of RFC 8452 (polyval, micro_aes.c:1421-1432) through the GHASH levels:
- * POLYVAL(H, X) = rev(GHASH(mulX(rev(H)), rev(X_i)...)); hg_host must already be
- * mulX_GHASH(ByteReverse(H)); pv_out16 receives the RAW GHASH value (the caller
- * byte-reverses it).  Length block = LE64(aad bits) || LE64(pt bits).        */
-int uaesk_polyval(void *stream, const uaesk_tables *tb, const uint8_t *hg_host,
-                  const void *aad, size_t aad_len, const void *pt, size_t pt_len,
-                  void *scratch, void *pv_out16);
-
 /* short GCM-SIV message in one launch; -1 = not applicable (too long): take the general path */
 int uaesk_gcmsiv_small(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *master_ek, int decrypt,
                        const uint8_t *nonce12,

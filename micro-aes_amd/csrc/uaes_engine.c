@@ -22,6 +22,7 @@
 
 #include "../../include/uaes_hip.h"
 #include "uaes_device.h"
+#include "uaes_plan.h"
 #include "uaes_host.h"
 
 #define UAES_VERSION "uaes-hip 0.1 gfx950"
@@ -1078,7 +1079,7 @@ static int lane_abandon(lane *L, int rc)
  * data units) a long text is cut into slices and PIPE_WORKERS host threads each take the
  * next slice: copy in, kernel, copy out on the worker's own stream and device slice, so the
  * two DMA directions and the staging copies of different slices overlap: 33 GiB/s with four
- * workers (profiles/r02_host_path_rate.log; 1.29x -- the link gives ~36 GB/s each way when both
+ * workers (profiles/HISTORY.md; 1.29x -- the link gives ~36 GB/s each way when both
  * directions run; staging through our own pinned buffers measured slower, 26-29 GiB/s, the
  * runtime's pageable path copies faster than memcpy() from worker threads does).  The workers
  * touch only c->pipe[w] and read-only context data; one pipelined call at a time per device
@@ -3714,6 +3715,20 @@ static int gather_fail_send(void)
 }
 
 static struct { unsigned long sends, recvs, groups, inits, failures; } g_gather_stats;
+
+/* ---- the table of arrangements as data (csrc/uaes_plan.h; include/uaes_hip.h) ---- */
+int uaes_debug_plan(int mode, int dir, size_t a, size_t b, unsigned flags, int out[4])
+{
+    uaes_plan p;
+    int e;
+    if (!out) return fail(UAES_E_ARG, "NULL pointer");
+    memset(&p, 0, sizeof p);
+    if ((e = uaesk_plan(mode, dir, a, b, flags, &p)) != 0) return fail(UAES_E_ARG, "no plan for mode %d, direction %d", mode, dir);
+    out[0] = p.arrangement; out[1] = p.launches; out[2] = (int)p.grid; out[3] = (int)p.steps;
+    return 0;
+}
+const char *uaes_debug_arrangement_name(int id) { return uaesk_arrangement_name(id); }
+void uaes_debug_plan_disable(unsigned mask) { uaesk_plan_disable(mask); }
 
 /* ---- test hooks of the one-launch GCM arrangements (include/uaes_hip.h) ---- */
 void uaes_debug_gcm_look(unsigned long long ticks_100mhz) { uaesk_debug_gcm_look(ticks_100mhz); }

@@ -36,6 +36,7 @@
 #include "uaes_ctr.hip.h"
 #include "uaes_gf.h"
 #include "uaes_device.h"
+#include "uaes_plan.h"
 
 #define GH_T        1024u           /* threads of the last-levels workgroup   */
 #define GH_PT       1024u           /* threads per bulk-level workgroup       */
@@ -478,12 +479,7 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_setup(uaesk_rk ek, uaesk_tables
                                                        u32 logA, u32 needB, u32 h_given, uint4 hval, u32 want_pow64,
                                                        u32 logF, u32 maxlog)
 {
-#ifdef UAES_GF_TIMING
-    u64 st_ts[8];
-#define ST_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0) st_ts[i] = wall_clock64(); } while (0)
-#else
 #define ST_STAMP(i) do { } while (0)
-#endif
     ST_STAMP(0);
     /* A long one-shot call (logF) is launched on TWO workgroups that both make H and its powers and then split the
      * rest: workgroup 0 the tables, workgroup 1 the fused kernel's weights (latency-bound dependent products that
@@ -669,14 +665,6 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_setup(uaesk_rk ek, uaesk_tables
         gf_to_words(shPow[threadIdx.x], w);
         ((uint4 *)(scratch + GS_POW))[threadIdx.x] = make_uint4(w[0], w[1], w[2], w[3]);
     }
-#ifdef UAES_GF_TIMING
-    ST_STAMP(7);
-    if (threadIdx.x == 0)
-        printf("setup wg %u: aes %llu powers %llu gens %llu byte-tables %llu nibble-tables %llu yz %llu store %llu (x10 ns)\n", blockIdx.x,
-               (unsigned long long)(st_ts[1] - st_ts[0]), (unsigned long long)(st_ts[2] - st_ts[1]), (unsigned long long)(st_ts[3] - st_ts[2]),
-               (unsigned long long)(st_ts[4] - st_ts[3]), (unsigned long long)(st_ts[5] - st_ts[4]), (unsigned long long)(st_ts[6] - st_ts[5]),
-               (unsigned long long)(st_ts[7] - st_ts[6]));
-#endif
 #undef ST_STAMP
 }
 
@@ -746,12 +734,8 @@ struct GhFold {
     static constexpr bool of_input = DEC;
     static constexpr int round_prio = 2;       /* cipher lookups 2 > GHASH lookups 1 > XOR work 0 */
     static constexpr bool expand2 = false;     /* the loop body once per trip: twice would spill (128 VGPRs are all in use) */
-#ifdef UAES_GCM_TEXT_AHEAD
-    static constexpr bool text_ahead = true;
-#else
     static constexpr bool text_ahead = false;  /* one text buffer, loaded at the head of its own iteration: no second buffer,
                                                   no eight v_mov per trip to rotate it (profiles/r05_gcm_text_ab.log) */
-#endif
     uint4 acc[2];
     GhLane gl;
     __device__ __forceinline__ void operator()(const uint4 &c0, const uint4 &c1)
@@ -764,11 +748,7 @@ struct GhFold {
 
 __device__ __forceinline__ Gf gf_from4(uint4 v) { return gf_from_words(v.x, v.y, v.z, v.w); }
 
-#ifdef UAES_GF_TIMING                               /* diagnostic build: phase stamps of workgroup 0 (100 MHz clock) */
-#define GF_STAMP(i) do { if (threadIdx.x == 0) gf_ts[i] = wall_clock64(); } while (0)
-#else
 #define GF_STAMP(i) do { } while (0)
-#endif
 
 template <int NR, bool DEC>
 __global__ __launch_bounds__(UAES_WG) void k_gcm_fused(uaesk_rk rk, uaesk_tables tb, uaesk_ctr ctr,
@@ -777,9 +757,6 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_fused(uaesk_rk rk, uaesk_tables
                                                            GSrc front, u64 nfront,
                                                            unsigned char *__restrict__ scratch)
 {
-#ifdef UAES_GF_TIMING
-    u64 gf_ts[12];
-#endif
     GF_STAMP(0);
     uint4 *T = (uint4 *)uaes_lds;                  /* LDS address 0 (absolute addressing in tabmul8_xor) */
     const uint4 *tab8 = (const uint4 *)(scratch + GS_TAB8_F);
@@ -853,15 +830,6 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_fused(uaesk_rk rk, uaesk_tables
             for (int i = 0; i < 4; ++i) atomicXor(t + i, ww[i]);
         }
     }
-#ifdef UAES_GF_TIMING
-    GF_STAMP(10);
-    if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))
-        printf("wg %u iters %llu: fill %llu edge %llu head %llu loop %llu tc %llu tree %llu weight %llu (x10 ns), start %llu\n",
-               blockIdx.x, (unsigned long long)geo.iters,
-               (unsigned long long)(gf_ts[1] - gf_ts[0]), (unsigned long long)(gf_ts[2] - gf_ts[1]), (unsigned long long)(gf_ts[3] - gf_ts[2]),
-               (unsigned long long)(gf_ts[4] - gf_ts[3]), (unsigned long long)(gf_ts[5] - gf_ts[4]), (unsigned long long)(gf_ts[9] - gf_ts[5]),
-               (unsigned long long)(gf_ts[10] - gf_ts[9]), (unsigned long long)gf_ts[0]);
-#endif
 }
 
 template <int NR, bool DEC>
@@ -991,7 +959,7 @@ __device__ __forceinline__ void gcm_build_nibble_tables(uint4 *TC, uint4 *buf, c
 /* ------------------------------------------------------------------------ */
 /* AAD blocks + text blocks + the length block <= 2047 (a 16 KiB TLS record, a 4 KiB page, a packet):
  * CTR, GHASH and the tag in ONE launch of one 1024-thread workgroup instead of three launches
- * (Enc(J0) / CTR / last GHASH levels) -- per call that is what counts (profiles/r02_call_latency.log).
+ * (Enc(J0) / CTR / last GHASH levels) -- per call that is what counts (profiles/HISTORY.md).
  * The GHASH input sequence is front-padded to 1024 or 2048 positions; thread t owns positions t and
  * t + 1024.  A thread whose position is a text block computes that block's keystream itself, so the
  * ciphertext it hashes is the one it has in registers; thread 0's first position is always padding and
@@ -1012,12 +980,7 @@ __global__ __launch_bounds__(GH_T) void k_gcm_small(uaesk_rk rk, uaesk_tables tb
 {
     /* build != 0: a one-shot call -- the key's nibble tables are not in `scratch`, they are made here from
      * H = Enc(0), which thread 1's padding slot computes (gcm_build_nibble_tables)                        */
-#ifdef UAES_GSM_TIMING                                        /* diagnostic build: phase stamps (100 MHz clock) */
-    u64 sm_ts[6];
-#define SM_STAMP(i) do { if (threadIdx.x == 0) sm_ts[i] = wall_clock64(); } while (0)
-#else
 #define SM_STAMP(i) do { } while (0)
-#endif
     SM_STAMP(0);
     uint4 *TC = (uint4 *)(uaes_lds + GSM_LDS_TAB);            /* the six nibble tables; TC[0..512) = H^1024 */
     uint4 *buf = TC + GT_NTAB * 512u;                         /* GT_BUF entries (the last three: H, Enc(J0), verdict) */
@@ -1136,13 +1099,6 @@ __global__ __launch_bounds__(GH_T) void k_gcm_small(uaesk_rk rk, uaesk_tables tb
             }
         }
     }
-#ifdef UAES_GSM_TIMING
-    SM_STAMP(5);
-    if (threadIdx.x == 0)
-        printf("gcm small (nv %llu, build %u): tables %llu blocks %llu build %llu tree %llu tag+out %llu (x10 ns)\n",
-               (unsigned long long)nv, build, (unsigned long long)(sm_ts[1] - sm_ts[0]), (unsigned long long)(sm_ts[2] - sm_ts[1]),
-               (unsigned long long)(sm_ts[3] - sm_ts[2]), (unsigned long long)(sm_ts[4] - sm_ts[3]), (unsigned long long)(sm_ts[5] - sm_ts[4]));
-#endif
 #undef SM_STAMP
     ticket_release(done);
 }
@@ -1277,12 +1233,7 @@ __global__ __launch_bounds__(GH_T) void k_gcm_records(uaesk_rk rk, uaesk_tables 
     };
     u32 nw[3], rl_next;
     load_nonce((u64)blockIdx.x * G, nw, rl_next);
-#ifdef UAES_GREC_TIMING                                       /* diagnostic build: phase stamps of one turn (100 MHz clock) */
-    u64 rc_ts[6];
-#define RC_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0) rc_ts[i] = wall_clock64(); } while (0)
-#else
 #define RC_STAMP(i) do { } while (0)
-#endif
     for (u64 base = (u64)blockIdx.x * G; base < nrec; base += (u64)gridDim.x * G) {
         RC_STAMP(0);
         /* everything the rounds derive from the lane constants (the odd rounds' per-lane key words above all) is made
@@ -1420,13 +1371,6 @@ __global__ __launch_bounds__(GH_T) void k_gcm_records(uaesk_rk rk, uaesk_tables 
             }
         }
         __syncthreads();                                      /* the Enc(J0) and verdict slots are rewritten by the next turn */
-#ifdef UAES_GREC_TIMING
-        RC_STAMP(5);
-        if (threadIdx.x == 0 && blockIdx.x == 0 && base == 2ull * gridDim.x * G)
-            printf("gcm records turn (nv %llu, %u groups): loads %llu blocks %llu multiply %llu tree %llu tag+out %llu (x10 ns)\n",
-                   (unsigned long long)nv, G, (unsigned long long)(rc_ts[1] - rc_ts[0]), (unsigned long long)(rc_ts[2] - rc_ts[1]),
-                   (unsigned long long)(rc_ts[3] - rc_ts[2]), (unsigned long long)(rc_ts[4] - rc_ts[3]), (unsigned long long)(rc_ts[5] - rc_ts[4]));
-#endif
     }
 #undef RC_STAMP
 }
@@ -2141,6 +2085,14 @@ __global__ __launch_bounds__(GH_T) void k_siv_small(uaesk_rk mk, uaesk_tables tb
 /* ------------------------------------------------------------------------ */
 /* host-side drivers                                                          */
 /* ------------------------------------------------------------------------ */
+#define GCM_NR(CALL)                                              \
+    switch (nr) {                                                 \
+    case 10: { constexpr int NR = 10; rc = CALL; } break;         \
+    case 12: { constexpr int NR = 12; rc = CALL; } break;         \
+    case 14: { constexpr int NR = 14; rc = CALL; } break;         \
+    default: return (int)hipErrorInvalidValue;                    \
+    }
+
 struct GPlan {
     u32 logA;       /* 0 = no bulk level */
     u32 needB;
@@ -2226,79 +2178,170 @@ extern "C" int uaesk_gcm_j0(void *stream, const uaesk_tables *tb, int nr, const 
     const GPlan pl = plan_for(nv);
     const uint4 z = make_uint4(0, 0, 0, 0);
     int rc;
-    switch (nr) {
-    case 10: rc = launch_setup<10>(st, tb, ek, z, sc, pl, 0, z); break;
-    case 12: rc = launch_setup<12>(st, tb, ek, z, sc, pl, 0, z); break;
-    case 14: rc = launch_setup<14>(st, tb, ek, z, sc, pl, 0, z); break;
-    default: return (int)hipErrorInvalidValue;
-    }
+    GCM_NR((launch_setup<NR>(st, tb, ek, z, sc, pl, 0, z)));
     if (rc) return rc;
     return run_ghash_levels(st, msg, nv, pl, sc, 2, (unsigned char *)j0_out16, nullptr);
+}
+
+/* ------------------------------------------------------------------------ */
+/* GCM's rows of the table of arrangements (uaes_plan.h)                        */
+/* ------------------------------------------------------------------------ */
+/* GCM_CHUNKS: a workgroup takes 1024 * steps GHASH positions, steps the smallest power of two with which ONE round of
+ * workgroups covers the text (W <= CUs; W = CUs leaves the preparing workgroup without a CU until the first chunk
+ * workgroup retires, which still beats twice the positions per thread on half the CUs).  An encryption takes it up to
+ * GMC_ONEPASS_MAX_NV positions (16 MiB): there the chunk workgroups -- CTR and GHASH together -- beat the striped pass
+ * and its three launches (35-40 us of fixed cost).  A tag-first decryption hashes with them as far as one round reaches
+ * (2^GMC_MAXLOGSTEPS positions per thread: 512 MiB on 256 CUs) and lets the gated CTR kernel write.
+ * GCM_TWOPHASE: from there to GMC_TWOPHASE_MAX_NV (128 MiB) an encryption runs the bulk CTR kernel and then the
+ * hash-only chunk workgroups over its OUTPUT, which still sits in the last-level cache (64 MiB 84 -> 75 us against the
+ * striped kernel); past that the second pass no longer finds it there.
+ * GCM_STRIPED: CTR and GHASH in one pass over 8-group stripes (k_gcm_fused): needs a power-of-two number of lanes in
+ * the grid (2048 * CUs: 2^19 on MI355X), at least one stripe per workgroup, and the AAD + head blocks in front of one
+ * round.  GCM_LEVELS: setup, CTR kernel, the GHASH levels -- takes anything.                                      */
+#define GMC_MAXLOGSTEPS 7u
+#define GMC_ONEPASS_MAX_NV  ((u64)1 << 20)
+#define GMC_TWOPHASE_MAX_NV ((u64)1 << 23)
+
+bool uaesk_arr_on(int id);                                       /* uaes_kernels.hip: the switch of uaes_plan.h */
+
+static int plan_cus(void)
+{
+    int cus = 0;
+    if (uaesk_device_info(&cus, nullptr) != 0 || cus <= 0) cus = 256;      /* (no device: planned for an MI355X) */
+    return cus;
+}
+
+static u32 medium_steps(u64 nv, int cus)
+{
+    if (cus < 2) return 0;
+    for (u32 lg = 0; lg <= GMC_MAXLOGSTEPS; ++lg)
+        if ((nv + (1024ull << lg) - 1) / (1024ull << lg) <= (u64)cus) return 1u << lg;
+    return 0;
+}
+
+/* the striped region of a text whose keystream starts at counter c: h0 head blocks up to the first group boundary,
+ * n8 stripes of eight 256-counter groups from group g_lo on, h1 = blocks in front of the tail */
+struct GcmStripes { bool ok; u32 logF; u64 h0, g_lo, n8, h1; int cus; };
+static GcmStripes gcm_stripes(const uaesk_ctr &c, u64 len, u64 ablk)
+{
+    GcmStripes g;
+    g.cus = plan_cus();
+    const u64 Sl = 2048ull * (u64)g.cus;
+    g.logF = 0;
+    while (((u64)1 << g.logF) < Sl) ++g.logF;
+    const u64 nfull = len / 16;
+    const u32 c0 = (u32)c.v0 & 0xffu;
+    g.h0 = (256u - c0) & 255u; g.g_lo = c0 ? 1 : 0;
+    const u64 groups = (c0 + nfull) / 256;
+    g.n8 = groups > g.g_lo ? (groups - g.g_lo) / 8 : 0;
+    g.h1 = g.h0 + 2048 * g.n8;
+    g.ok = ((u64)1 << g.logF) == Sl && g.logF <= GF_MAXLOG && g.n8 >= (u64)g.cus && ablk + g.h0 <= Sl &&
+           !ctr_stripes_cross_a(&c, g.g_lo, g.n8);       /* (one in 2^40 blocks: the two-pass path, whose CTR kernel cuts there) */
+    return g;
+}
+
+struct GcmPlan { uaes_plan p; GcmStripes s; };
+/* dir: 0 encrypt, 1 decrypt tag first (N7), 2 decrypt in one pass, 3 tag only.  piece: a piece of a streamed message
+ * (no AAD, no small arrangement; chunk workgroups only with the tables of Y in the stream's scratch: chunks_ready). */
+static GcmPlan gcm_plan(int dir, u64 len, u64 aad_len, const uaesk_ctr &c, bool has_word, bool piece = false, bool chunks_ready = true)
+{
+    GcmPlan g;
+    const u64 ablk = (aad_len + 15) >> 4, nvh = ablk + ((len + 15) >> 4);     /* positions the chunk workgroups hash */
+    g.s = gcm_stripes(c, len, ablk);
+    g.p.arrangement = UAES_ARR_GCM_LEVELS; g.p.launches = 0; g.p.grid = 0; g.p.steps = 0;
+    if (!piece && dir != 3 && nvh + 1 <= GSM_MAXNV && uaesk_arr_on(UAES_ARR_GCM_SMALL)) {
+        g.p.arrangement = UAES_ARR_GCM_SMALL; g.p.launches = 1; g.p.grid = 1;
+        return g;
+    }
+    const u32 steps = medium_steps(nvh, g.s.cus);
+    const bool gmac = len == 0 && dir != 3 && !piece;     /* nothing to encrypt: hash-only chunks whatever the direction */
+    const bool chunks_can = dir != 3 && steps && (!piece || (chunks_ready && has_word && nvh >= 1024));
+    const bool striped_can = (dir == 0 || dir == 2 || piece) && g.s.ok && uaesk_arr_on(UAES_ARR_GCM_STRIPED);
+    if (chunks_can) {
+        g.p.steps = steps;
+        g.p.grid = (unsigned)((nvh + 1024ull * steps - 1) / (1024ull * steps));
+        const bool fold_ok = has_word && (int)g.p.grid <= g.s.cus;       /* one launch: chunk workgroups + fold */
+        if ((dir == 1 && !piece) || gmac || nvh <= GMC_ONEPASS_MAX_NV) {
+            if (uaesk_arr_on(UAES_ARR_GCM_CHUNKS)) {
+                const int dmode = (gmac && dir == 2) ? 1 : dir;            /* (gcm_body) */
+                g.p.arrangement = UAES_ARR_GCM_CHUNKS;
+                g.p.launches = ((fold_ok && dmode != 2) || piece ? 1 : 2) + ((dmode == 1 && !gmac && !piece) ? 1 : 0);
+                return g;
+            }
+        } else if (nvh <= GMC_TWOPHASE_MAX_NV && uaesk_arr_on(UAES_ARR_GCM_TWOPHASE)) {
+            /* encrypt: CTR kernel, hash-only chunks; one-pass decrypt: hash-only chunks, gated CTR kernel, wipe */
+            g.p.arrangement = UAES_ARR_GCM_TWOPHASE;
+            g.p.launches = 1 + (fold_ok || piece ? 1 : 2) + (dir == 2 && !piece ? 1 : 0);
+            return g;
+        }
+        if (piece && !striped_can && uaesk_arr_on(UAES_ARR_GCM_CHUNKS)) {      /* (a piece that cannot be striped) */
+            g.p.arrangement = UAES_ARR_GCM_CHUNKS; g.p.launches = 1;
+            return g;
+        }
+    }
+    if (striped_can) {
+        g.p.arrangement = UAES_ARR_GCM_STRIPED; g.p.launches = 3 + (dir == 2 ? 2 : 0); g.p.grid = (unsigned)g.s.cus; g.p.steps = 0;
+        return g;
+    }
+    g.p.steps = 0; g.p.grid = 0;
+    return g;
+}
+
+static void gcm_counter_from_j0(uaesk_ctr &c, const unsigned char j0b[16], u64 block_offset)
+{
+    memset(&c, 0, sizeof c);
+    memcpy(&c.w0, j0b, 4);
+    memcpy(&c.w1, j0b + 4, 4);
+    c.b8 = j0b[8];
+    uint64_t v = 0;                             /* bytes 9..15 of J0: the reference's 56-bit counter (N2); + 1: pre-increment (N4) */
+    for (int i = 9; i < 16; ++i) v = (v << 8) | j0b[i];
+    c.v0 = (v + 1 + block_offset) & 0x00FFFFFFFFFFFFFFull;
+}
+
+int uaesk_plan_gcm(int dir, size_t len, size_t aad_len, unsigned flags, uaes_plan *p)
+{
+    if (dir < 0 || dir > 3) return (int)hipErrorInvalidValue;
+    unsigned char j0b[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1 };     /* a 12-byte nonce: J0 ends in 00000001 */
+    uaesk_ctr c;
+    gcm_counter_from_j0(c, j0b, 0);
+    *p = gcm_plan(dir, len, aad_len, c, !((flags >> 2) & 1u)).p;
+    if (p->arrangement == UAES_ARR_GCM_LEVELS) {
+        const u64 nv = ((aad_len + 15) >> 4) + ((len + 15) >> 4) + 1;
+        const GPlan pl = plan_for(nv);
+        p->launches = 1 + (dir == 3 ? 0 : 1) + (pl.logA ? 1 : 0) + (pl.needB ? 1 : 0) + 1;
+    }
+    return 0;
+}
+
+/* GCM-SIV: one workgroup up to 2046 POLYVAL positions; then k_siv_prep, the hash-only chunk workgroups whose fold also
+ * makes the tag and the counter (needs the counter word: ONE launch, no two-launch form), the CTR kernel -- as far as one
+ * round of chunk workgroups reaches (512 MiB on 256 CUs); beyond that POLYVAL by the GHASH levels and k_siv_tag. */
+static uaes_plan siv_plan(u64 len, u64 aad_len, bool has_word, bool long_only = false)
+{
+    uaes_plan p = { UAES_ARR_SIV_LEVELS, 0, 0, 0 };
+    const u64 nvh = ((aad_len + 15) >> 4) + ((len + 15) >> 4);
+    if (!long_only && nvh + 1 <= GSM_MAXNV && uaesk_arr_on(UAES_ARR_SIV_SMALL)) { p.arrangement = UAES_ARR_SIV_SMALL; p.launches = 1; p.grid = 1; return p; }
+    const u32 steps = medium_steps(nvh, plan_cus());
+    if (has_word && steps && uaesk_arr_on(UAES_ARR_SIV_CHUNKS)) {
+        p.arrangement = UAES_ARR_SIV_CHUNKS; p.launches = 3; p.steps = steps;
+        p.grid = (unsigned)((nvh + 1024ull * steps - 1) / (1024ull * steps));
+        return p;
+    }
+    const GPlan pl = plan_for(nvh + 1);
+    p.launches = 2 + (pl.logA ? 1 : 0) + (pl.needB ? 1 : 0) + 1 + 1 + 1;      /* prep, setup, levels, final, tag, CTR */
+    return p;
+}
+
+int uaesk_plan_siv(int dir, size_t len, size_t aad_len, unsigned flags, uaes_plan *p)
+{
+    if (dir < 0 || dir > 1) return (int)hipErrorInvalidValue;
+    *p = siv_plan(len, aad_len, !((flags >> 2) & 1u));
+    return 0;
 }
 
 /* keyed != 0: `scratch` belongs to a key context whose tables (nibble tables, H^S table, Y/Z powers, all
  * H^(2^k)) uaesk_gcm_key_tables built; then only Enc(J0) is computed per message unless the text needs
  * a size-dependent bulk table (two-pass texts over 512 KiB), for which the full setup runs as usual. */
-/* Up to this many GHASH positions the chunk workgroups + finisher (k_gcm_chunks) are preferred to the striped one-pass
- * kernel, whose three launches cost ~35 us whatever the size; UAES_GCM_MEDIUM_MAX_KIB overrides it
- * (tools/gcm_size_sweep.py).  A workgroup takes 1024 * steps positions, steps a power of two chosen so that ONE round
- * of workgroups (and the finisher) covers the text: medium_steps().                                              */
-#define GMC_MAXLOGSTEPS 7u                      /* chunks of up to 131 072 positions: 512 MiB on 256 CUs (hash only) */
-#define GMC_TWOPHASE_MAX_NV ((u64)1 << 23)      /* an ENCRYPTION in two phases pays up to 128 MiB: past that the second pass no
-                                                 * longer finds the ciphertext in the last-level cache and the striped one-pass
-                                                 * kernel wins */
-static u32 medium_maxlogsteps(void)             /* UAES_GCM_MAXLOGSTEPS: tests reach the fallbacks with it */
-{
-    static const u32 v = [] {
-        const char *e = getenv("UAES_GCM_MAXLOGSTEPS");
-        long x = e ? atol(e) : (long)GMC_MAXLOGSTEPS;
-        return (u32)(x < 0 ? 0 : x > (long)GMC_MAXLOGSTEPS ? (long)GMC_MAXLOGSTEPS : x);
-    }();
-    return v;
-}
-static u64 medium_max_nv(void)
-{
-    static const u64 w = [] {                          /* initialised once, thread-safe */
-        const char *e = getenv("UAES_GCM_MEDIUM_MAX_KIB");
-        long long v = e ? atoll(e) : 16384;
-        if (v < 16) v = 16;
-        if (v > (1ll << 21)) v = 1ll << 21;
-        return (u64)v * 64u;
-    }();
-    return w;
-}
-
-/* Past that size an encryption runs in TWO PHASES as far as one round of chunk workgroups reaches (128 MiB on 256 CUs):
- * the CTR kernel of the bulk path (shared rounds, 1600 GiB/s), then the hash-only chunk workgroups + finisher over the
- * ciphertext (byte-table stride products, ~3 TB/s of reads, mostly out of the last-level cache the CTR kernel just
- * filled) -- two launches against the striped one-pass kernel's three (setup, pass, last levels) with their 35-40 us of
- * fixed cost: 64 MiB 84 -> 75 us.  UAES_GCM_TWOPHASE=0 switches it off (measurement).                            */
-static bool medium_twophase(u64 nv)
-{
-    static const bool on = [] { const char *e = getenv("UAES_GCM_TWOPHASE"); return !(e && e[0] == '0'); }();
-    return on && nv <= GMC_TWOPHASE_MAX_NV;
-}
-
-/* the smallest power of two of positions per thread with which the W chunk workgroups are one round on `cus` CUs; 0:
- * the text is too long for that.  (W = cus leaves the finisher -- the LAST workgroup, which nobody waits for -- without
- * a CU until the first chunk workgroup retires: its 6 us of preparations then come behind the chunk work instead of
- * beside it, which is still less than twice the positions per thread on half the CUs: the case of every text of
- * exactly 2^k blocks.)                                                                                              */
-static u32 medium_steps(u64 nv, int cus)
-{
-    if (cus < 2) return 0;
-    for (u32 lg = 0; lg <= medium_maxlogsteps(); ++lg)
-        if ((nv + (1024ull << lg) - 1) / (1024ull << lg) <= (u64)cus) return 1u << lg;
-    return 0;
-}
-
-static int medium_cus(void)
-{
-    int cus = 0;
-    if (uaesk_device_info(&cus, nullptr) != 0 || cus <= 0) cus = 64;
-    return cus;
-}
-
 static int gcm_body(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek,
                     int decrypt, const uint8_t *j0_16,
                     const void *aad, size_t aad_len,
@@ -2321,141 +2364,45 @@ static int gcm_body(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk
     /* keystream counter starts at J0 + 1 (pre-increment, N4); the reference's
      * incBlock carries through bytes 15..9, so this is a 56-bit counter      */
     uaesk_ctr c;
-    memset(&c, 0, sizeof c);
-    memcpy(&c.w0, j0b, 4);
-    memcpy(&c.w1, j0b + 4, 4);
-    c.b8 = j0b[8];
-    {
-        uint64_t v = 0;
-        for (int i = 9; i < 16; ++i) v = (v << 8) | j0b[i];
-        c.v0 = (v + 1) & 0x00FFFFFFFFFFFFFFull;
-    }
+    gcm_counter_from_j0(c, j0b, 0);
 
     GSrc msg;
     msg.aad = (const unsigned char *)aad; msg.aad_len = aad_len;
     msg.ct = (const unsigned char *)(decrypt ? in : out); msg.ct_len = len;
     msg.has_len = 1; msg.len_aad = aad_len; msg.len_ct = len; msg.rev = 0;
     const u64 nv = ((aad_len + 15) >> 4) + ((len + 15) >> 4) + 1;
+    const u64 nfull = len / 16, ablk = (aad_len + 15) >> 4;
 
-    int rc;
+    int rc = 0;
     const uint4 z = make_uint4(0, 0, 0, 0);
+    const GcmPlan plan = gcm_plan(decrypt, len, aad_len, c, done_word != nullptr);
+    const GcmStripes &sp = plan.s;
 
-    /* Long text: CTR and GHASH in one pass (k_gcm_fused).  Needs a power-of-two number of lanes in
-     * the grid (S = 2048 * CUs: 2^19 on MI355X), at least one 2048-block stripe per workgroup, and
-     * the AAD + head blocks to fit in front of one round.
-     * Decrypt authenticates BEFORE it writes (N7), so by default it keeps the two-pass order;
-     * decrypt == 2 (the caller accepts a zeroed output on failure, or the output is a private staging
-     * buffer) runs one pass as well: the striped region is decrypted while its ciphertext is hashed,
-     * the tag is checked over [T][tail][lengths] with the tail still ciphertext, then the tail is
-     * decrypted (gated on the status) and, on a mismatch, everything written is zeroed.    */
-    if (decrypt != 1 && decrypt != 3) {
-        int cus = 0;
-        if (uaesk_device_info(&cus, nullptr) != 0) cus = 0;
-        const u64 Sl = 2048ull * (u64)(cus > 0 ? cus : 0);
-        u32 logF = 0;
-        while (((u64)1 << logF) < Sl) ++logF;
-        const u64 nfull = len / 16, ablk = (aad_len + 15) >> 4;
-        const u32 c0 = (u32)c.v0 & 0xffu;
-        const u64 h0 = (256u - c0) & 255u, g_lo = c0 ? 1 : 0;
-        const u64 groups = (c0 + nfull) / 256, n8 = groups > g_lo ? (groups - g_lo) / 8 : 0;
-        if (Sl && ((u64)1 << logF) == Sl && logF <= GF_MAXLOG && n8 >= (u64)cus && ablk + h0 <= Sl &&
-            !ctr_stripes_cross_a(&c, g_lo, n8) &&      /* (one in 2^40 blocks: the two-pass path, whose CTR kernel cuts there) */
-            !(tb->frob && medium_steps(nv - 1, medium_cus()) && (medium_twophase(nv - 1) || nv - 1 <= medium_max_nv()))) {
-            const u64 h1 = h0 + 2048 * n8;
-            GSrc fin;                                   /* [T][tail][lengths] */
-            fin.aad = sc + GS_T; fin.aad_len = 16;
-            fin.ct = (const unsigned char *)(decrypt ? in : out) + h1 * 16; fin.ct_len = len - h1 * 16;
-            fin.has_len = 1; fin.len_aad = aad_len; fin.len_ct = len; fin.rev = 0;
-            const u64 nvf = 1 + ((fin.ct_len + 15) >> 4) + 1;
-            const GPlan plf = plan_for(nvf);
-            GSrc front = msg;                           /* [AAD][head] in front of the striped region */
-            front.ct_len = h0 * 16; front.has_len = 0;
-            if (keyed) {
-                switch (nr) {
-                case 10: rc = launch_ej0<10>(st, tb, ek, j0, sc); break;
-                case 12: rc = launch_ej0<12>(st, tb, ek, j0, sc); break;
-                case 14: rc = launch_ej0<14>(st, tb, ek, j0, sc); break;
-                default: return (int)hipErrorInvalidValue;
-                }
-            } else {
-                switch (nr) {
-                case 10: rc = launch_setup<10>(st, tb, ek, j0, sc, plf, 0, z, 0, logF); break;
-                case 12: rc = launch_setup<12>(st, tb, ek, j0, sc, plf, 0, z, 0, logF); break;
-                case 14: rc = launch_setup<14>(st, tb, ek, j0, sc, plf, 0, z, 0, logF); break;
-                default: return (int)hipErrorInvalidValue;
-                }
-            }
-            if (rc) return rc;
-            if (!decrypt) {
-                rc = launch_fused_nr<false>(nr, st, tb, ek, &c, in, out, (unsigned)cus, g_lo, n8, h1, nfull,
-                                            (u32)(len % 16), front, ablk + h0, sc);
-                if (rc) return rc;
-                return run_ghash_levels(st, fin, nvf, plf, sc, 0, (unsigned char *)out + len, nullptr);
-            }
-            /* the fused kernel leaves the tail alone (h1 = nfull, no ragged bytes) */
-            rc = launch_fused_nr<true>(nr, st, tb, ek, &c, in, out, (unsigned)cus, g_lo, n8, nfull, nfull, 0,
-                                       front, ablk + h0, sc);
-            if (rc) return rc;                          /* nothing has been written yet */
-            /* from here on `out` holds plaintext nobody has authenticated: if anything below cannot be
-             * enqueued, the conditional wipe would never run -- wipe unconditionally instead (N7) */
-            rc = run_ghash_levels(st, fin, nvf, plf, sc, 1, (unsigned char *)in + len, status);
-            if (!rc && len > h1 * 16) {
-                uaesk_ctr ct = c;
-                ct.v0 = (c.v0 + h1) & 0x00FFFFFFFFFFFFFFull;
-                rc = uaesk_ctr_xcrypt(stream, tb, nr, ek, &ct, (const unsigned char *)in + h1 * 16,
-                                      (unsigned char *)out + h1 * 16, len - h1 * 16, status);
-            }
-            if (!rc) {
-                hipLaunchKernelGGL(k_wipe_if_failed, dim3((unsigned)cus * 2u), dim3(1024), 0, st, status,
-                                   (unsigned char *)out, (u64)len);
-                rc = (int)hipGetLastError();
-            }
-            if (rc) (void)hipMemsetAsync(out, 0, len, st);
-            return rc;
-        }
-    }
-
-    const GPlan pl = plan_for(nv);
-    if (nv <= GSM_MAXNV && decrypt != 3) {     /* short message: one workgroup does all of it (k_gcm_small) */
-        /* the nibble tables of this key: a key context has them; a one-shot call makes them inside the same
-         * launch (needs the Frobenius matrices), else k_gcm_setup runs first                              */
-        const u32 build = (!keyed && tb->frob) ? 1u : 0u;
-        if (!keyed && !build) {
-            switch (nr) {
-            case 10: rc = launch_setup<10>(st, tb, ek, j0, sc, pl, 0, z); break;
-            case 12: rc = launch_setup<12>(st, tb, ek, j0, sc, pl, 0, z); break;
-            case 14: rc = launch_setup<14>(st, tb, ek, j0, sc, pl, 0, z); break;
-            default: return (int)hipErrorInvalidValue;
-            }
-            if (rc) return rc;
-        }
+    switch (plan.p.arrangement) {
+    case UAES_ARR_GCM_SMALL: {
+        /* short message: one workgroup does all of it (k_gcm_small).  The nibble tables of this key: a key context has
+         * them, a one-shot call makes them inside the same launch */
+        const u32 build = keyed ? 0u : 1u;
         GSrc sm = msg;
         sm.ct = (const unsigned char *)in;     /* the kernel reads the text itself */
         if (decrypt)                               /* (the host layer arms a ticket only with a host-visible status word) */
             return launch_small_nr<true>(nr, st, tb, ek, &c, j0, sm, in, out, sc, (unsigned char *)in + len, status, build, ticket.use());
         return launch_small_nr<false>(nr, st, tb, ek, &c, j0, sm, in, out, sc, (unsigned char *)out + len, nullptr, build, ticket.use());
     }
-    const u32 msteps = medium_steps(nv - 1, medium_cus());     /* (the finisher takes the length block: nv - 1 positions) */
-    /* (a decryption that must authenticate first has no one-pass alternative: the chunk workgroups hash it as far as
-     * one round of them reaches, 128 MiB on 256 CUs: 16 MiB 92 -> 44 us, 64 MiB 107 -> 96) */
-    const bool gmac = len == 0 && decrypt != 3;               /* nothing to encrypt: hash-only chunks whatever the direction */
-    if (decrypt != 3 && msteps && (decrypt == 1 || gmac || nv - 1 <= medium_max_nv() || medium_twophase(nv - 1)) && tb->frob) {
-        /* a medium-sized text: chunk workgroups + finisher (k_gcm_chunks; two launches with k_gcm_combine where the
-         * one-launch arrangement cannot be used), tables made in the kernels for a one-shot call.  Decrypt mode 1
-         * hashes first and lets the gated CTR kernel write; mode 2 decrypts in the chunk kernel and zeroes the output
-         * if the tag turns out wrong.                                                                             */
-        /* one position per thread while that still gives every workgroup its own CU (up to 4 MiB on 256 CUs): the
-         * chunk kernel then runs one pass of block encryptions and no stride multiplication (1 MiB 24.7 -> 23.5 us);
-         * longer texts double the positions per thread until one round of workgroups covers them                   */
-        const u32 steps = msteps;
-        const u32 W = (u32)((nv - 1 + 1024ull * steps - 1) / (1024ull * steps)), build = keyed ? 0u : 1u;
+    case UAES_ARR_GCM_CHUNKS:
+    case UAES_ARR_GCM_TWOPHASE: {
+        /* chunk workgroups + a fold (k_gcm_chunks; two launches with k_gcm_combine where the one-launch arrangement
+         * cannot be used), tables made in the kernels for a one-shot call.  Decrypt mode 1 hashes first and lets the
+         * gated CTR kernel write; mode 2 decrypts in the chunk kernel and zeroes the output if the tag turns out wrong.
+         * TWOPHASE: an encryption runs the bulk CTR kernel and then hashes its OUTPUT with the hash-only chunks; a
+         * one-pass decryption takes the tag-first order there (the faster one in this range) and keeps its contract
+         * -- a ZEROED output on a forgery -- with the wipe kernel the striped order launches too */
+        const bool gmac = len == 0;
+        const bool two = plan.p.arrangement == UAES_ARR_GCM_TWOPHASE;
+        const u32 steps = plan.p.steps, W = plan.p.grid, build = keyed ? 0u : 1u;
         GSrc sm = msg;
         sm.ct = (const unsigned char *)in;
         sm.has_len = 0;
-        /* two phases past medium_max_nv(): an encryption runs the bulk CTR kernel and then hashes its OUTPUT with the
-         * hash-only chunks; a one-pass decryption takes the tag-first order there (the faster one in this range) and
-         * keeps its contract -- a ZEROED output on a forgery -- with the wipe kernel the striped order launches too */
-        const bool two = !gmac && decrypt != 1 && nv - 1 > medium_max_nv();
         const int dmode = ((gmac || two) && decrypt == 2) ? 1 : decrypt;   /* (without a text there is nothing a one-pass order could write early) */
         const bool hash_only = (gmac || two) && !decrypt;
         const void *text = in;
@@ -2465,50 +2412,77 @@ static int gcm_body(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk
             text = out;
         }
         unsigned char *tagp = decrypt ? (unsigned char *)in + len : (unsigned char *)out + len;
-        switch (nr) {
-        case 10: rc = launch_medium<10>(st, tb, ek, &c, j0, sm, text, out, sc, W, steps, build, dmode, tagp, status, done_word, ticket, hash_only); break;
-        case 12: rc = launch_medium<12>(st, tb, ek, &c, j0, sm, text, out, sc, W, steps, build, dmode, tagp, status, done_word, ticket, hash_only); break;
-        case 14: rc = launch_medium<14>(st, tb, ek, &c, j0, sm, text, out, sc, W, steps, build, dmode, tagp, status, done_word, ticket, hash_only); break;
-        default: return (int)hipErrorInvalidValue;
-        }
-        if (rc && dmode == 2) (void)hipMemsetAsync(out, 0, len, st);   /* the chunk kernel may have been enqueued: see above */
+        GCM_NR((launch_medium<NR>(st, tb, ek, &c, j0, sm, text, out, sc, W, steps, build, dmode, tagp, status, done_word, ticket, hash_only)));
+        if (rc && dmode == 2) (void)hipMemsetAsync(out, 0, len, st);   /* the chunk kernel may have been enqueued: see STRIPED */
         if (rc || !decrypt) return rc;
         if (dmode == 1) {
             rc = uaesk_ctr_xcrypt(stream, tb, nr, ek, &c, in, out, len, status);
             if (!rc && two && decrypt == 2) {                    /* the one-pass contract: zeroed on a forgery */
-                hipLaunchKernelGGL(k_wipe_if_failed, dim3((unsigned)medium_cus() * 2u), dim3(1024), 0, st, status,
+                hipLaunchKernelGGL(k_wipe_if_failed, dim3((unsigned)sp.cus * 2u), dim3(1024), 0, st, status,
                                    (unsigned char *)out, (u64)len);
                 rc = (int)hipGetLastError();
             }
-            return rc;
         }
         return rc;                             /* mode 2: the combine kernel takes a forgery's plaintext back itself */
     }
-    if (keyed && pl.logA == 0) {               /* every table this text needs is in the key context */
-        switch (nr) {
-        case 10: rc = launch_ej0<10>(st, tb, ek, j0, sc); break;
-        case 12: rc = launch_ej0<12>(st, tb, ek, j0, sc); break;
-        case 14: rc = launch_ej0<14>(st, tb, ek, j0, sc); break;
-        default: return (int)hipErrorInvalidValue;
+    case UAES_ARR_GCM_STRIPED: {
+        /* Long text: CTR and GHASH in one pass (k_gcm_fused).  Decrypt authenticates BEFORE it writes (N7), so by
+         * default it never comes here; decrypt == 2 (the caller accepts a zeroed output on failure, or the output is a
+         * private staging buffer) runs one pass as well: the striped region is decrypted while its ciphertext is
+         * hashed, the tag is checked over [T][tail][lengths] with the tail still ciphertext, then the tail is
+         * decrypted (gated on the status) and, on a mismatch, everything written is zeroed.    */
+        GSrc fin;                                   /* [T][tail][lengths] */
+        fin.aad = sc + GS_T; fin.aad_len = 16;
+        fin.ct = (const unsigned char *)(decrypt ? in : out) + sp.h1 * 16; fin.ct_len = len - sp.h1 * 16;
+        fin.has_len = 1; fin.len_aad = aad_len; fin.len_ct = len; fin.rev = 0;
+        const u64 nvf = 1 + ((fin.ct_len + 15) >> 4) + 1;
+        const GPlan plf = plan_for(nvf);
+        GSrc front = msg;                           /* [AAD][head] in front of the striped region */
+        front.ct_len = sp.h0 * 16; front.has_len = 0;
+        if (keyed) { GCM_NR((launch_ej0<NR>(st, tb, ek, j0, sc))); }
+        else       { GCM_NR((launch_setup<NR>(st, tb, ek, j0, sc, plf, 0, z, 0, sp.logF))); }
+        if (rc) return rc;
+        if (!decrypt) {
+            rc = launch_fused_nr<false>(nr, st, tb, ek, &c, in, out, (unsigned)sp.cus, sp.g_lo, sp.n8, sp.h1, nfull,
+                                        (u32)(len % 16), front, ablk + sp.h0, sc);
+            if (rc) return rc;
+            return run_ghash_levels(st, fin, nvf, plf, sc, 0, (unsigned char *)out + len, nullptr);
         }
+        /* the fused kernel leaves the tail alone (h1 = nfull, no ragged bytes) */
+        rc = launch_fused_nr<true>(nr, st, tb, ek, &c, in, out, (unsigned)sp.cus, sp.g_lo, sp.n8, nfull, nfull, 0,
+                                   front, ablk + sp.h0, sc);
+        if (rc) return rc;                          /* nothing has been written yet */
+        /* from here on `out` holds plaintext nobody has authenticated: if anything below cannot be
+         * enqueued, the conditional wipe would never run -- wipe unconditionally instead (N7) */
+        rc = run_ghash_levels(st, fin, nvf, plf, sc, 1, (unsigned char *)in + len, status);
+        if (!rc && len > sp.h1 * 16) {
+            uaesk_ctr ct = c;
+            ct.v0 = (c.v0 + sp.h1) & 0x00FFFFFFFFFFFFFFull;
+            rc = uaesk_ctr_xcrypt(stream, tb, nr, ek, &ct, (const unsigned char *)in + sp.h1 * 16,
+                                  (unsigned char *)out + sp.h1 * 16, len - sp.h1 * 16, status);
+        }
+        if (!rc) {
+            hipLaunchKernelGGL(k_wipe_if_failed, dim3((unsigned)sp.cus * 2u), dim3(1024), 0, st, status,
+                               (unsigned char *)out, (u64)len);
+            rc = (int)hipGetLastError();
+        }
+        if (rc) (void)hipMemsetAsync(out, 0, len, st);
+        return rc;
+    }
+    default:
+        break;
+    }
+
+    /* GCM_LEVELS: setup (or Enc(J0) alone where a key context holds every table this text needs), the CTR kernel, the
+     * GHASH levels.  A one-pass decryption that lands here takes the tag-first order: same results, N7 kept. */
+    const GPlan pl = plan_for(nv);
+    if (keyed && pl.logA == 0) {
+        GCM_NR((launch_ej0<NR>(st, tb, ek, j0, sc)));
     } else {
         /* (a key context keeps its tables: the full setup rewrites them with the same values) */
         const u32 all = keyed ? 1u : 0u;
-        u32 logFk = 0;
-        if (keyed) {
-            int cus = 0;
-            if (uaesk_device_info(&cus, nullptr) == 0 && cus > 0) {
-                const u64 Sl = 2048ull * (u64)cus;
-                while (((u64)1 << logFk) < Sl) ++logFk;
-                if (((u64)1 << logFk) != Sl || logFk > GF_MAXLOG) logFk = 0;
-            }
-        }
-        switch (nr) {
-        case 10: rc = launch_setup<10>(st, tb, ek, j0, sc, pl, 0, z, all, logFk); break;
-        case 12: rc = launch_setup<12>(st, tb, ek, j0, sc, pl, 0, z, all, logFk); break;
-        case 14: rc = launch_setup<14>(st, tb, ek, j0, sc, pl, 0, z, all, logFk); break;
-        default: return (int)hipErrorInvalidValue;
-        }
+        const u32 logFk = (keyed && ((u64)1 << sp.logF) == 2048ull * (u64)sp.cus && sp.logF <= GF_MAXLOG) ? sp.logF : 0u;
+        GCM_NR((launch_setup<NR>(st, tb, ek, j0, sc, pl, 0, z, all, logFk)));
     }
     if (rc) return rc;
 
@@ -2575,13 +2549,8 @@ extern "C" int uaesk_gcm_key_tables(void *stream, const uaesk_tables *tb, int nr
     }
     const uint4 z = make_uint4(0, 0, 0, 0);
     int rc;
-    switch (nr) {
-    case 10: rc = launch_setup<10>(st, tb, ek, z, sc, pl, 0, z, 1, logF); break;
-    case 12: rc = launch_setup<12>(st, tb, ek, z, sc, pl, 0, z, 1, logF); break;
-    case 14: rc = launch_setup<14>(st, tb, ek, z, sc, pl, 0, z, 1, logF); break;
-    default: return (int)hipErrorInvalidValue;
-    }
-    if (rc || !tb->frob) return rc;            /* (without the Frobenius matrices the chunk + combine path is not taken) */
+    GCM_NR((launch_setup<NR>(st, tb, ek, z, sc, pl, 0, z, 1, logF)));
+    if (rc) return rc;
     hipError_t e = uaesk_want_lds((const void *)k_gcm_ytables, (unsigned)GHF_LDS);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(k_gcm_ytables, dim3(GS_YTAB_SETS), dim3(GH_T), GHF_LDS, st, *tb, sc);
@@ -2695,17 +2664,12 @@ extern "C" int uaesk_gcm_shard(void *stream, const uaesk_tables *tb, int nr, con
     int rc;
 
     if (mode != 1) {                            /* CTR and GHASH of a long shard in one pass: gcm_body's conditions */
-        int cus = 0;
-        if (uaesk_device_info(&cus, nullptr) != 0) cus = 0;
-        const u64 Sl = 2048ull * (u64)(cus > 0 ? cus : 0);
-        u32 logF = 0;
-        while (((u64)1 << logF) < Sl) ++logF;
         const u64 nfull = shard_len / 16, ablk = (msg.aad_len + 15) >> 4;
-        const u32 c0 = (u32)c.v0 & 0xffu;
-        const u64 h0 = (256u - c0) & 255u, g_lo = c0 ? 1 : 0;
-        const u64 groups = (c0 + nfull) / 256, n8 = groups > g_lo ? (groups - g_lo) / 8 : 0;
-        if (Sl && ((u64)1 << logF) == Sl && logF <= GF_MAXLOG && n8 >= (u64)cus && ablk + h0 <= Sl &&
-            !ctr_stripes_cross_a(&c, g_lo, n8)) {
+        const GcmStripes sp = gcm_stripes(c, shard_len, ablk);
+        const int cus = sp.cus;
+        const u32 logF = sp.logF;
+        const u64 h0 = sp.h0, g_lo = sp.g_lo, n8 = sp.n8;
+        if (sp.ok) {
             const u64 h1 = h0 + 2048 * n8;
             GSrc fin;                                   /* [T][tail]([lengths] on the last shard) */
             fin.aad = sc + GS_T; fin.aad_len = 16;
@@ -2715,12 +2679,7 @@ extern "C" int uaesk_gcm_shard(void *stream, const uaesk_tables *tb, int nr, con
             const GPlan plf = plan_for(nvf);
             GSrc front = msg;                           /* [AAD][head] in front of the striped region */
             front.ct_len = h0 * 16; front.has_len = 0;
-            switch (nr) {
-            case 10: rc = launch_setup<10>(st, tb, ek, j0, sc, plf, 0, z, 1, logF); break;
-            case 12: rc = launch_setup<12>(st, tb, ek, j0, sc, plf, 0, z, 1, logF); break;
-            case 14: rc = launch_setup<14>(st, tb, ek, j0, sc, plf, 0, z, 1, logF); break;
-            default: return (int)hipErrorInvalidValue;
-            }
+            GCM_NR((launch_setup<NR>(st, tb, ek, j0, sc, plf, 0, z, 1, logF)));
             if (rc) return rc;
             if (mode == 0) {
                 rc = launch_fused_nr<false>(nr, st, tb, ek, &c, in, out, (unsigned)cus, g_lo, n8, h1, nfull,
@@ -2748,12 +2707,7 @@ extern "C" int uaesk_gcm_shard(void *stream, const uaesk_tables *tb, int nr, con
     }
 
     const GPlan pl = plan_for(nv ? nv : 1);
-    switch (nr) {
-    case 10: rc = launch_setup<10>(st, tb, ek, j0, sc, pl, 0, z, 1); break;
-    case 12: rc = launch_setup<12>(st, tb, ek, j0, sc, pl, 0, z, 1); break;
-    case 14: rc = launch_setup<14>(st, tb, ek, j0, sc, pl, 0, z, 1); break;
-    default: return (int)hipErrorInvalidValue;
-    }
+    GCM_NR((launch_setup<NR>(st, tb, ek, j0, sc, pl, 0, z, 1)));
     if (rc) return rc;
     if (mode == 0 && shard_len) {
         rc = uaesk_ctr_xcrypt(stream, tb, nr, ek, &c, in, out, shard_len, nullptr);
@@ -2855,12 +2809,7 @@ extern "C" int uaesk_gcm_stream_absorb(void *stream, const uaesk_tables *tb, int
     const unsigned have = plan_state ? *plan_state : 0u;
     const bool ok = (have >> 31) && (!pl.logA || (have & 0xffu) == pl.logA) && (!pl.needB || ((have >> 8) & 1u));
     if (!ok) {
-        switch (nr) {
-        case 10: rc = launch_setup<10>(st, tb, ek, j0, sc, pl, 0, z, 1); break;
-        case 12: rc = launch_setup<12>(st, tb, ek, j0, sc, pl, 0, z, 1); break;
-        case 14: rc = launch_setup<14>(st, tb, ek, j0, sc, pl, 0, z, 1); break;
-        default: return (int)hipErrorInvalidValue;
-        }
+        GCM_NR((launch_setup<NR>(st, tb, ek, j0, sc, pl, 0, z, 1)));
         if (rc) return rc;
         if (plan_state) *plan_state = 0x80000000u | (*plan_state & 0x200u) | (pl.needB ? 0x100u : 0u) | pl.logA;   /* (bit 9: the striped
                                          * kernel's tables, uaesk_gcm_stream_piece -- another setup leaves them alone) */
@@ -2914,41 +2863,27 @@ extern "C" int uaesk_gcm_stream_piece(void *stream, const uaesk_tables *tb, int 
     hipStream_t st = S(stream);
     unsigned char *sc = (unsigned char *)scratch;
     if (done_bytes % 16 || !plan_state) return (int)hipErrorInvalidValue;
-    int cus = 0;
-    if (uaesk_device_info(&cus, nullptr) != 0 || cus <= 0) return 1;
     uint4 j0;
     unsigned char j0b[16];
     memcpy(j0b, nonce12, 12);
     j0b[12] = j0b[13] = j0b[14] = 0; j0b[15] = 1;
     memcpy(&j0, j0b, 16);
     uaesk_ctr c;
-    memset(&c, 0, sizeof c);
-    memcpy(&c.w0, j0b, 4);
-    memcpy(&c.w1, j0b + 4, 4);
-    c.b8 = j0b[8];
-    {
-        uint64_t v = 0;                         /* bytes 9..15 of J0: the reference's 56-bit counter (N2); + 1: pre-increment (N4) */
-        for (int i = 9; i < 16; ++i) v = (v << 8) | j0b[i];
-        c.v0 = (v + 1 + done_bytes / 16) & 0x00FFFFFFFFFFFFFFull;
-    }
-    const u64 Sl = 2048ull * (u64)cus;
-    u32 logF = 0;
-    while (((u64)1 << logF) < Sl) ++logF;
-    const u64 nfull = len / 16;
-    const u32 c0 = (u32)c.v0 & 0xffu;
-    const u64 h0 = (256u - c0) & 255u, g_lo = c0 ? 1 : 0;
-    const u64 groups = (c0 + nfull) / 256, n8 = groups > g_lo ? (groups - g_lo) / 8 : 0;
-    const bool striped = ((u64)1 << logF) == Sl && logF <= GF_MAXLOG && n8 >= (u64)cus && h0 <= Sl && !ctr_stripes_cross_a(&c, g_lo, n8);
-    const u64 nvp = ((u64)len + 15) >> 4;
-    const u32 steps = medium_steps(nvp, cus);
-    const u64 W = steps ? (nvp + 1024ull * steps - 1) / (1024ull * steps) : 0;
-    const bool chunks_ok = steps && done_word && tb->frob && (*plan_state >> 31) && nvp >= 1024 && W <= (u64)cus;
-    /* as for a one-shot call: up to 16 MiB the chunk workgroups (CTR and GHASH together) beat the striped pass and its
-     * launches, and from there to the end of their round two phases do -- the bulk CTR kernel and the hash-only chunk
-     * workgroups over the piece's ciphertext (a decryption hashes first: in may be out) */
-    if (!striped || (chunks_ok && (nvp <= medium_max_nv() || medium_twophase(nvp)))) {
-        if (!chunks_ok) return 1;
-        const bool two = nvp > medium_max_nv() && striped;
+    gcm_counter_from_j0(c, j0b, done_bytes / 16);
+    /* as for a one-shot call (gcm_plan): up to 16 MiB the chunk workgroups (CTR and GHASH together), from there to the
+     * end of their round two phases -- the bulk CTR kernel and the hash-only chunk workgroups over the piece's
+     * ciphertext (a decryption hashes first: in may be out) --, beyond that the striped pass; a piece none of them
+     * takes goes back to the caller (1: the absorb path) */
+    const GcmPlan plan = gcm_plan(decrypt ? 2 : 0, len, 0, c, done_word != nullptr, true, (*plan_state >> 31) != 0);
+    const GcmStripes &sp = plan.s;
+    const int cus = sp.cus;
+    const u64 nfull = len / 16, h0 = sp.h0, g_lo = sp.g_lo, n8 = sp.n8, h1 = sp.h1;
+    const u32 logF = sp.logF;
+    if (plan.p.arrangement == UAES_ARR_GCM_LEVELS) return 1;
+    if (plan.p.arrangement != UAES_ARR_GCM_STRIPED) {
+        const bool two = plan.p.arrangement == UAES_ARR_GCM_TWOPHASE;
+        const u64 nvp = ((u64)len + 15) >> 4;
+        const u32 steps = plan.p.steps, W = plan.p.grid;
         GSrc src;
         memset(&src, 0, sizeof src);
         src.ct = (const unsigned char *)in; src.ct_len = len;          /* the kernel reads the text itself */
@@ -2962,16 +2897,10 @@ extern "C" int uaesk_gcm_stream_piece(void *stream, const uaesk_tables *tb, int 
             src.ct = (const unsigned char *)out;
             text = out;
         }
-        switch (nr) {
-        case 10: rc = launch_stream_chunks<10>(st, tb, ek, &c, src, text, out, sc, (u32)W, steps, decrypt, fin, two); break;
-        case 12: rc = launch_stream_chunks<12>(st, tb, ek, &c, src, text, out, sc, (u32)W, steps, decrypt, fin, two); break;
-        case 14: rc = launch_stream_chunks<14>(st, tb, ek, &c, src, text, out, sc, (u32)W, steps, decrypt, fin, two); break;
-        default: return (int)hipErrorInvalidValue;
-        }
+        GCM_NR((launch_stream_chunks<NR>(st, tb, ek, &c, src, text, out, sc, W, steps, decrypt, fin, two)));
         if (!rc && two && decrypt) rc = uaesk_ctr_xcrypt(stream, tb, nr, ek, &c, in, out, len, nullptr);
         return rc;
     }
-    const u64 h1 = h0 + 2048 * n8;
     GSrc msg;
     memset(&msg, 0, sizeof msg);
     msg.ct = (const unsigned char *)(decrypt ? in : out); msg.ct_len = len;
@@ -2987,19 +2916,9 @@ extern "C" int uaesk_gcm_stream_piece(void *stream, const uaesk_tables *tb, int 
     int rc;
     if ((*plan_state >> 31) && ((*plan_state >> 9) & 1u) && (!plf.logA || (*plan_state & 0xffu) == plf.logA) &&
         (!plf.needB || ((*plan_state >> 8) & 1u))) {           /* the tables are there: Enc(J0) again and T <- 0 */
-        switch (nr) {
-        case 10: rc = launch_ej0<10>(st, tb, ek, j0, sc); break;
-        case 12: rc = launch_ej0<12>(st, tb, ek, j0, sc); break;
-        case 14: rc = launch_ej0<14>(st, tb, ek, j0, sc); break;
-        default: return (int)hipErrorInvalidValue;
-        }
+        GCM_NR((launch_ej0<NR>(st, tb, ek, j0, sc)));
     } else {
-        switch (nr) {
-        case 10: rc = launch_setup<10>(st, tb, ek, j0, sc, plf, 0, z, 1, logF); break;
-        case 12: rc = launch_setup<12>(st, tb, ek, j0, sc, plf, 0, z, 1, logF); break;
-        case 14: rc = launch_setup<14>(st, tb, ek, j0, sc, plf, 0, z, 1, logF); break;
-        default: return (int)hipErrorInvalidValue;
-        }
+        GCM_NR((launch_setup<NR>(st, tb, ek, j0, sc, plf, 0, z, 1, logF)));
         if (!rc) *plan_state = 0x80000000u | 0x200u | (plf.needB ? 0x100u : 0u) | plf.logA;
     }
     if (rc) return rc;
@@ -3030,37 +2949,15 @@ extern "C" int uaesk_gcm_stream_tag(void *stream, void *scratch, int compare, vo
     return (int)hipGetLastError();
 }
 
-extern "C" int uaesk_polyval(void *stream, const uaesk_tables *tb, const uint8_t *hg_host,
-                             const void *aad, size_t aad_len, const void *pt, size_t pt_len,
-                             void *scratch, void *pv_out16)
-{
-    hipStream_t st = S(stream);
-    unsigned char *sc = (unsigned char *)scratch;
-    GSrc msg;
-    msg.aad = (const unsigned char *)aad; msg.aad_len = aad_len;
-    msg.ct = (const unsigned char *)pt; msg.ct_len = pt_len;
-    msg.has_len = 1; msg.len_aad = aad_len; msg.len_ct = pt_len; msg.rev = 1;
-    const u64 nv = ((aad_len + 15) >> 4) + ((pt_len + 15) >> 4) + 1;
-    const GPlan pl = plan_for(nv);
-    uint4 h;
-    memcpy(&h, hg_host, 16);
-    uaesk_rk dummy_rk;
-    memset(&dummy_rk, 0, sizeof dummy_rk);
-    int rc = launch_setup<10>(st, tb, &dummy_rk, make_uint4(0, 0, 0, 0), sc, pl, 1, h);
-    if (rc) return rc;
-    return run_ghash_levels(st, msg, nv, pl, sc, 2, (unsigned char *)pv_out16, nullptr);
-}
-
 /* GCM-SIV of a short message in one launch (k_siv_small), key derivation included: mk = the schedule of the MASTER
  * key.  encrypt: tag written at out + len; decrypt: tag read at in + len, *status = 0 / 0x1A, the plaintext is
- * written either way.  Returns -1 if the message is too long for this path (or the Frobenius matrices are
- * missing): the caller then derives the keys itself and takes the general path.                              */
+ * written either way.  Returns -1 if the message is too long for this arrangement (siv_plan): the caller then takes
+ * uaesk_gcmsiv_long.                                                                                          */
 extern "C" int uaesk_gcmsiv_small(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *mk, int decrypt,
                                   const uint8_t *nonce12,
                                   const void *aad, size_t aad_len, const void *in, size_t len, void *out, int *status)
 {
-    const u64 nv = ((aad_len + 15) >> 4) + ((len + 15) >> 4) + 1;
-    if (nv > GSM_MAXNV || !tb->frob) return -1;
+    if (siv_plan(len, aad_len, true).arrangement != UAES_ARR_SIV_SMALL) return -1;
     GSrc src;
     src.aad = (const unsigned char *)aad; src.aad_len = aad_len;
     src.ct = (const unsigned char *)in; src.ct_len = len;
@@ -3198,12 +3095,13 @@ static int siv_long_nr(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *m
     msg.ct = (const unsigned char *)(decrypt ? out : in); msg.ct_len = len;
     msg.has_len = 1; msg.len_aad = aad_len; msg.len_ct = len; msg.rev = 1;
     const u64 nv = ((aad_len + 15) >> 4) + ((len + 15) >> 4) + 1;
-    const u32 steps = medium_steps(nv - 1, medium_cus());
-    if (done_word && tb->frob && steps) {
+    const uaes_plan sp = siv_plan(len, aad_len, done_word != nullptr, true);
+    const u32 steps = sp.steps;
+    if (sp.arrangement == UAES_ARR_SIV_CHUNKS) {
         /* as far as one round of chunk workgroups reaches (128 MiB on 256 CUs) POLYVAL and the tag are ONE launch:
          * the hash-only chunk workgroups (byte-reversed blocks, the key from the scratch) and the finisher, which
          * also makes the tag and the counter (gcm_combine_body, modes 3 / 4) */
-        const u32 W = (u32)((nv - 1 + 1024ull * steps - 1) / (1024ull * steps));
+        const u32 W = sp.grid;
         GSrc sm = msg;
         sm.has_len = 0;
         GmcFin fin;

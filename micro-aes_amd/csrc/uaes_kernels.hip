@@ -22,6 +22,8 @@
 #include "uaes_ctr.hip.h"
 #include "uaes_gf.h"
 #include "uaes_device.h"
+#include "uaes_plan.h"
+#include <atomic>
 
 #define UAES_U 4            /* blocks per lane per iteration */
 
@@ -231,8 +233,8 @@ __global__ __launch_bounds__(UAES_WG, 4) void k_ctr_ind(const uaesk_rk *__restri
  * prologue.  The stripes are dealt round-robin over the workgroups, so every workgroup gets
  * floor or ceil of stripes/grid and the kernel's time follows the text size in 32 KiB steps
  * (round 1 dealt 256 KiB chunks: 80 MiB ran 10 % slower than 64 MiB,
- * profiles/r02_ctr_size_sweep_stripes_vs_chunks.log).  A lock-step four-block version
- * measured 4 % slower (profiles/r01_sweep_ctr_variants.log).                            */
+ * profiles/HISTORY.md).  A lock-step four-block version
+ * measured 4 % slower (profiles/HISTORY.md).                            */
 template <int NR>
 __global__ __launch_bounds__(UAES_WG, 4) void k_ctr_shared2(uaesk_rk rk, uaesk_tables tb, uaesk_ctr ctr,
                                                            const uint4 *in, uint4 *out,
@@ -389,33 +391,9 @@ __device__ __forceinline__ void store16(unsigned char *p, uint4 v)
  * four accesses of a chunk use all of it); the memory path has room for that in a kernel that needs 16 + 16 bytes
  * every eight cycles per CU.  Arguments then: chunks_per_sector = blocks per unit, main_blocks = blocks of the whole
  * text, (step_q, step_r) = (256 * waves) / and % blocks per unit, magic = ceil(2^24 / blocks per unit).           */
-/* k_xts_fold's first wave: the tweaks of the chunks of all wpw waves of the workgroup, eight per wave, into LDS rows
- * (chunk = wave number + trip * waves of the grid; the unit's number is the chunk's: copyLint, micro_aes.c:399-404,
- * then Enc_key2, :1026-1027).  Out of line: inlined, its registers are added to the block loop's (14 spilled). */
-template <int NR>
-__device__ __attribute__((noinline)) void xts_fold_tweaks(const u32 *te_plain, uint4 *tw_rows, const uaesk_rk *k2p,
-                                                          u64 first_sector, u64 nsectors, u32 wpw)
-{
-    const u32 lane = threadIdx.x & 63u;
-    const u64 nw = (u64)gridDim.x * wpw;
-    for (u32 idx = lane; idx < 8u * wpw; idx += 64u) {
-        const u64 ch = (u64)blockIdx.x * wpw + (idx >> 3) + (u64)(idx & 7u) * nw;
-        const u64 id = first_sector + (ch < nsectors ? ch : 0);
-        u32 t[4] = { (u32)id, (u32)(id >> 32), 0, 0 };
-        plain_encrypt<NR>(te_plain, *k2p, t);
-        tw_rows[idx] = make_uint4(t[0], t[1], t[2], t[3]);
-    }
-}
-
-/* FOLD (round 5, second half): a chunk per unit and ONE chunk per unit (4 KiB sectors) -- no pre-pass launch: a wave
- * encrypts the tweaks of its next 64 chunks itself, one per lane (plain_encrypt through a 1 KiB copy of Te0 behind the
- * cipher tables, key 2 read through the kernel-argument pointer where it is used), keeps them in four vector
- * registers and takes one out with v_readlane per trip.  Between 4 and 64 MiB a call was bound by the HOST's two
- * launches (8 and 16 MiB: 26 us per enqueued call either way), not by the GPU.  Used while a wave has at most eight
- * chunks (128 MiB on 256 CUs); beyond that the pre-pass is the cheaper way to the tweaks.                    */
 /* ALLFULL: the host knows that every chunk has all 256 blocks (units of a multiple of 4 KiB, the C3 shape): no block
  * count per chunk, no exec-masked stores */
-template <int NR, bool DEC, bool ALIGNED, bool PACKED, bool FOLD, bool ALLFULL = false>
+template <int NR, bool DEC, bool ALIGNED, bool PACKED, bool ALLFULL = false>
 __device__ __forceinline__ void xts_body(const uaesk_rk &k1, const uaesk_tables &tb,
                                          const uint4 *__restrict__ chunk_tw,
                                          u64 nsectors, u64 chunks_per_sector,
@@ -425,27 +403,10 @@ __device__ __forceinline__ void xts_body(const uaesk_rk &k1, const uaesk_tables 
                                          const unsigned char *in,
                                          unsigned char *out,
                                          u64 nmain,            /* chunks [nmain, all) go by quarters (== all: none) */
-                                         u32 magic, const uaesk_rk *k2p, u64 first_sector)
+                                         u32 magic)
 {
     const u32 lane = threadIdx.x & 63u;
-    if (FOLD) {
-        /* the workgroup's first wave encrypts the tweaks of ALL its waves' chunks (up to eight each: the host's limit)
-         * through the plain table -- two blocks per lane at most -- into an LDS row per wave, while the other waves fill
-         * the cipher tables: what every wave did for itself before its first chunk (sixteen waves' dependent lookups in
-         * one unreplicated table) was 5 us of a 16 MiB call's 28 */
-        u32 *te_plain = (u32 *)(uaes_lds + UAES_LDS_ENC);
-        uint4 *tw_rows = (uint4 *)(uaes_lds + UAES_LDS_ENC + 1024u);
-        if (threadIdx.x < 256u) te_plain[threadIdx.x] = tb.te0[threadIdx.x];
-        __syncthreads();
-        const u32 wpw = blockDim.x >> 6;
-        /* (every wave keeps its sixteenth of the fill, the first one comes to it late: taking the first wave out of
-         * the fill -- a run-time step for the others -- cost the block loop 14 registers it does not have) */
-        if (threadIdx.x < 64u) xts_fold_tweaks<NR>(te_plain, tw_rows, k2p, first_sector, nsectors, wpw);
-        fill_enc_tables_share(DEC ? tb.td0 : tb.te0, threadIdx.x, blockDim.x);
-        __syncthreads();
-    } else {
-        if (DEC) fill_dec_tables(tb.td0); else fill_enc_tables(tb.te0);
-    }
+    if (DEC) fill_dec_tables(tb.td0); else fill_enc_tables(tb.te0);
     const LaneConst lc = make_lane_const();
     /* launched with 16 waves per workgroup, or 4 for short texts (more CUs, see launch_xts).  The wave's number is made
      * a SCALAR explicitly: everything that positions a chunk (unit, chunk in the unit, byte offset, block count) then
@@ -470,20 +431,7 @@ __device__ __forceinline__ void xts_body(const uaesk_rk &k1, const uaesk_tables 
         u64 off;                                     /* byte offset of the chunk's first block */
     };
     const u32 lane_off = PACKED ? lane * 64u : lane16, u_off = PACKED ? 16u : 1024u;
-    u32 trip = 0;                                    /* FOLD: this wave's row of tweaks is read trip by trip */
-    auto tweak_of = [&](u64 ch, u32 (&t)[4]) {
-        const u64 id = first_sector + ch;
-        t[0] = (u32)id; t[1] = (u32)(id >> 32); t[2] = 0; t[3] = 0;
-        plain_encrypt<NR>((const u32 *)(uaes_lds + UAES_LDS_ENC), *k2p, t);
-    };
     auto fetch = [&](u64 ch, Fetched &f) {
-        if (FOLD) {
-            const uint4 *row = (const uint4 *)(uaes_lds + UAES_LDS_ENC + 1024u) + 8u * (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-            const uint4 t4 = row[trip & 7u];                     /* (wave-uniform: back into scalar registers) */
-            f.tb = make_uint4((u32)__builtin_amdgcn_readfirstlane((int)t4.x), (u32)__builtin_amdgcn_readfirstlane((int)t4.y),
-                              (u32)__builtin_amdgcn_readfirstlane((int)t4.z), (u32)__builtin_amdgcn_readfirstlane((int)t4.w));
-            ++trip;
-        }
         const u64 sct = sctn;
         const u64 first = PACKED ? ch * XTS_CHUNK : withn * XTS_CHUNK;
         const u32 rb = (u32)withn;
@@ -493,7 +441,7 @@ __device__ __forceinline__ void xts_body(const uaesk_rk &k1, const uaesk_tables 
         f.cnt = ALLFULL ? XTS_CHUNK : (left < XTS_CHUNK ? (u32)left : XTS_CHUNK);
         f.off = PACKED ? first * 16 : sct * sector_bytes + first * 16;
         if (PACKED) { f.rb = rb; f.sb = sct; }                   /* the lane's unit tweak follows later (fetch_tw) */
-        else if (!FOLD) f.tb = chunk_tw[ch];
+        else f.tb = chunk_tw[ch];
         const unsigned char *src = in + f.off;
         if (ALIGNED) {
             /* a buffer resource over exactly the chunk's blocks: base in SGPRs, the lane's constant offset, and the
@@ -609,14 +557,7 @@ __device__ __forceinline__ void xts_body(const uaesk_rk &k1, const uaesk_tables 
         const u64 left = main_blocks - first;
         const u32 cnt = left < XTS_CHUNK ? (u32)left : XTS_CHUNK;
         const u32 j = 64u * k + lane;
-        uint4 tb4;
-        if (FOLD) {
-            u32 tq[4];
-            tweak_of(c, tq);                               /* (every lane the same block: broadcast reads) */
-            tb4 = make_uint4(tq[0], tq[1], tq[2], tq[3]);
-        } else {
-            tb4 = chunk_tw[c];
-        }
+        const uint4 tb4 = chunk_tw[c];
         Tw t;
         t.lo = tb4.x | ((u64)tb4.y << 32);
         t.hi = tb4.z | ((u64)tb4.w << 32);
@@ -640,26 +581,8 @@ __global__ __launch_bounds__(UAES_WG) void k_xts(uaesk_rk k1, uaesk_tables tb,
                                                  u64 step_q, u64 step_r, const unsigned char *in, unsigned char *out,
                                                  u64 nmain, u32 magic)
 {
-    xts_body<NR, DEC, ALIGNED, PACKED, false, ALLFULL>(k1, tb, chunk_tw, nsectors, chunks_per_sector, main_blocks, sector_bytes,
-                                                       step_q, step_r, in, out, nmain, magic, nullptr, 0);
-}
-
-struct XtsFoldArgs {
-    uaesk_rk k1, k2;
-    uaesk_tables tb;
-    u64 nsectors, main_blocks, sector_bytes, step_q, step_r, nmain, first_sector;
-    const unsigned char *in;
-    unsigned char *out;
-};
-
-template <int NR, bool DEC, bool ALLFULL>
-__global__ __launch_bounds__(UAES_WG) void k_xts_fold(XtsFoldArgs)
-{
-    const XtsFoldArgs *const a = (const XtsFoldArgs *)__builtin_amdgcn_kernarg_segment_ptr();
-    const uaesk_rk k1 = a->k1;
-    const uaesk_tables tb = a->tb;
-    xts_body<NR, DEC, true, false, true, ALLFULL>(k1, tb, nullptr, a->nsectors, 1, a->main_blocks, a->sector_bytes, a->step_q, a->step_r,
-                                         a->in, a->out, a->nmain, 0u, &a->k2, a->first_sector);
+    xts_body<NR, DEC, ALIGNED, PACKED, ALLFULL>(k1, tb, chunk_tw, nsectors, chunks_per_sector, main_blocks, sector_bytes,
+                                                step_q, step_r, in, out, nmain, magic);
 }
 
 /* ONE data unit of up to 64 chunks = 256 KiB (the reference API's call shape, a unit per call, micro_aes.c:1066-1093):
@@ -888,14 +811,6 @@ extern "C" int uaesk_device_info(int *cu_count, int *lds_bytes)
     return 0;
 }
 
-/* an integer from the environment, clamped; callers keep it in a function-local `static const` (initialised once, thread-safe) */
-static int env_int_clamped(const char *name, int dflt, int lo, int hi)
-{
-    const char *e = getenv(name);
-    int v = (e && *e) ? atoi(e) : dflt;
-    return v < lo ? lo : v > hi ? hi : v;
-}
-
 static unsigned grid_for(u64 work_items, u64 per_wg)
 {
     if (g_cus <= 0) uaesk_device_info(nullptr, nullptr);
@@ -943,10 +858,76 @@ static hipError_t set_lds(K kern, unsigned bytes)
     default: return (int)hipErrorInvalidValue;        \
     }
 
+/* ------------------------------------------------------------------------ */
+/* the table of arrangements (uaes_plan.h): switch, names, ECB / CTR / XTS planners */
+/* ------------------------------------------------------------------------ */
+static std::atomic<unsigned> g_plan_disabled{ ~0u };
+extern "C" unsigned uaesk_plan_disabled(void)
+{
+    unsigned m = g_plan_disabled.load(std::memory_order_relaxed);
+    if (m == ~0u) {
+        const char *e = getenv("UAES_PLAN_DISABLE");
+        m = (e && *e) ? (unsigned)strtoul(e, nullptr, 0) & 0x7fffffffu : 0u;
+        g_plan_disabled.store(m, std::memory_order_relaxed);
+    }
+    return m;
+}
+extern "C" void uaesk_plan_disable(unsigned mask) { g_plan_disabled.store(mask & 0x7fffffffu, std::memory_order_relaxed); }
+bool uaesk_arr_on(int id) { return !((uaesk_plan_disabled() >> id) & 1u); }
+
+extern "C" const char *uaesk_arrangement_name(int id)
+{
+    static const char *const names[UAES_ARR_COUNT] = {
+        "ecb.single", "ecb.tiled", "ctr.single", "ctr.quad", "ctr.striped", "xts.small", "xts.packed", "xts.bulk",
+        "gcm.small", "gcm.chunks", "gcm.twophase", "gcm.striped", "gcm.levels", "ocb.small", "ocb.runs",
+        "siv.small", "siv.chunks", "siv.levels" };
+    return id >= 0 && id < UAES_ARR_COUNT ? names[id] : "?";
+}
+
 /* short texts: one block per lane, so that up to four times as many CUs take part */
 static bool short_text(u64 nblocks)
 {
     return grid_for(nblocks, (u64)UAES_WG * UAES_U) * 2 <= grid_for(~0ull, 1);
+}
+
+static uaes_plan plan_ecb(u64 items)
+{
+    uaes_plan p = { UAES_ARR_ECB_TILED, 1, 0, 0 };
+    if (short_text(items) && uaesk_arr_on(UAES_ARR_ECB_SINGLE)) { p.arrangement = UAES_ARR_ECB_SINGLE; p.grid = grid_for(items, UAES_WG); }
+    else p.grid = grid_for(items, (u64)UAES_WG * UAES_U);
+    return p;
+}
+
+/* CTR.  The striped kernel (k_ctr_shared2: rounds 1-2 shared by the 256 counters of a group, eight groups per stripe)
+ * from ONE grid of stripes on: below that the generic kernel's one- or four-block work items spread better over the
+ * CUs (8 MiB on 256 CUs; profiles/HISTORY.md "CTR size sweep").  A last round of stripes that covers less than
+ * CTR_TAIL_PCT % of the grid is handed to the kernel's edge path -- one block per thread through the plain rounds,
+ * spread over ALL workgroups (20 MiB = 640 stripes on 256 workgroups: 2.5 rounds would cost 3).  g_lo / n8: the
+ * stripes' first group and their number (uaes_ctr.hip.h). */
+#define CTR_TAIL_PCT 80u
+static uaes_plan plan_ctr(const uaesk_ctr *ctr, size_t len, u64 *g_lo_out, u64 *n8_out)
+{
+    const u64 nfull = len / 16, nblocks = (len + 15) / 16;
+    uaes_plan p = { UAES_ARR_CTR_QUAD, 1, 0, 0 };
+    const unsigned grid = grid_for(~0ull, 1);
+    if (!ctr->le32 && uaesk_arr_on(UAES_ARR_CTR_STRIPED)) {      /* (the shared rounds assume the 56-bit big-endian counter) */
+        const u32 c0 = (u32)ctr->v0 & 0xffu;
+        const u64 g_lo = c0 ? 1 : 0, groups = (c0 + nfull) / 256;
+        u64 n8 = groups > g_lo ? (groups - g_lo) / 8 : 0;
+        if (n8 >= (u64)grid) {
+            const u64 r = n8 % grid;
+            if (r && n8 > grid && r * 100 < (u64)grid * CTR_TAIL_PCT) n8 -= r;
+            p.arrangement = UAES_ARR_CTR_STRIPED; p.grid = grid;
+            /* a text in which counter bits 40..47 move -- once in 2^40 blocks -- is cut there into two launches */
+            if (ctr_stripes_cross_a(ctr, g_lo, n8)) p.launches = 2;
+            if (g_lo_out) *g_lo_out = g_lo;
+            if (n8_out) *n8_out = n8;
+            return p;
+        }
+    }
+    if (short_text(nblocks) && uaesk_arr_on(UAES_ARR_CTR_SINGLE)) { p.arrangement = UAES_ARR_CTR_SINGLE; p.grid = grid_for(nblocks, UAES_WG); }
+    else p.grid = grid_for(nblocks, (u64)UAES_WG * UAES_U);
+    return p;
 }
 
 template <int NR, bool DEC>
@@ -959,11 +940,12 @@ static int launch_ecb(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ke
     if (e != hipSuccess) return (int)e;
     const u64 items = nfull + ((rem || padding) ? 1 : 0);
     const uaesk_done done = uaesk_ticket_take();              /* the call's only kernel: it carries the ticket */
-    if (short_text(items)) {
-        hipLaunchKernelGGL((k_ecb<NR, DEC, 1>), dim3(grid_for(items, UAES_WG)), dim3(UAES_WG), lds, st, *keys, *tb,
+    const uaes_plan pl = plan_ecb(items);
+    if (pl.arrangement == UAES_ARR_ECB_SINGLE) {
+        hipLaunchKernelGGL((k_ecb<NR, DEC, 1>), dim3(pl.grid), dim3(UAES_WG), lds, st, *keys, *tb,
                            (const uint4 *)in, (uint4 *)out, (u64)nfull, (u32)rem, (u32)padding, done, (u64)nfull);
     } else {
-        const unsigned grid = grid_for(items, (u64)UAES_WG * UAES_U);
+        const unsigned grid = pl.grid;
         const u64 tile = (u64)UAES_WG * UAES_U, per_round = tile * grid;
         const u64 rounds = (u64)nfull / per_round, left = (u64)nfull - rounds * per_round;
         /* the remainder of the last round as single blocks when it covers less than 80 % of the grid */
@@ -1004,62 +986,15 @@ static int launch_ctr_u(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *
     return (int)hipGetLastError();
 }
 
-/* the generic kernel: four blocks per lane, or one for short texts (see short_text) */
-template <int NR, int U>
-static int launch_ctr_v(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek, const uaesk_ctr *ctr,
-                        const void *in, void *out, size_t len, const int *gate)
-{
-    if (short_text((len + 15) / 16)) return launch_ctr_u<NR, 1>(st, tb, ek, ctr, in, out, len, gate);
-    return launch_ctr_u<NR, U>(st, tb, ek, ctr, in, out, len, gate);
-}
-
-/* Shared-round kernel: whole 8-group stripes in the pipelined main loop, the ragged
- * prefix/suffix and the byte tail in its prologue.  Below one and a half grids of stripes
- * (12 MiB on MI355X) the generic kernel's one-block work items spread better
- * (profiles/r02_ctr_size_sweep_stripes_vs_chunks.log: 8 MiB 637 vs 598 GiB/s).          */
+/* one launch of the striped kernel over a text whose stripes do not cross a 2^40-block boundary */
 template <int NR>
-static int launch_ctr_shared(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek, const uaesk_ctr *ctr,
-                             const void *in, void *out, size_t len, const int *gate)
+static int launch_ctr_striped(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek, const uaesk_ctr *ctr,
+                              const void *in, void *out, size_t len, const int *gate, unsigned grid, u64 g_lo, u64 n8)
 {
-    const u64 nfull = len / 16;
-    const u32 c0 = (u32)ctr->v0 & 0xffu;
-    unsigned grid = grid_for(~0ull, 1);
-    {   /* measurement only (energy per block): UAES_CTR_GRID = number of workgroups (= CUs used) */
-        static const int want = env_int_clamped("UAES_CTR_GRID", 0, 0, 1 << 20);
-        if (want > 0 && (unsigned)want < grid) grid = (unsigned)want;
-    }
-    const u64 g_lo = c0 ? 1 : 0, groups = (c0 + nfull) / 256;
-    u64 n8 = groups > g_lo ? (groups - g_lo) / 8 : 0;
-    {   /* below `half_rounds` / 2 rounds of stripes the generic kernel spreads better (UAES_CTR_MIN_HALF_ROUNDS, measurement) */
-        static const int half_rounds = env_int_clamped("UAES_CTR_MIN_HALF_ROUNDS", 2, 2, 1 << 20);
-        if (n8 * 2 < (u64)grid * (u64)half_rounds) return launch_ctr_v<NR, 4>(st, tb, ek, ctr, in, out, len, gate);
-    }
-    {   /* A last round of stripes that covers only part of the grid leaves the other workgroups idle for a whole stripe
-         * (20 MiB = 640 stripes on 256 workgroups: 2.5 rounds cost 3).  Below `pct` % of the grid those stripes are
-         * handed to the kernel's edge path instead -- one block per thread through the plain rounds, spread evenly over
-         * ALL workgroups: 160 lookups per block instead of 128, but nobody waits (UAES_CTR_TAIL_PCT, 0 = off). */
-        static const int pct = env_int_clamped("UAES_CTR_TAIL_PCT", 80, 0, 100);
-        const u64 r = n8 % grid;
-        if (r && n8 > grid && r * 100 < (u64)grid * (u64)pct) n8 -= r;
-    }
-    if (ctr_stripes_cross_a(ctr, g_lo, n8)) {
-        /* the striped kernel makes its lane constants once per launch (uaes_ctr.hip.h): a text in which counter bits
-         * 40..47 move -- once in 2^40 blocks -- is cut there into two launches                                     */
-        const u64 nb = ((u64)1 << 40) - (ctr->v0 & (((u64)1 << 40) - 1));          /* blocks up to the boundary */
-        if (nb > 0 && nb < nfull) {
-            uaesk_ctr second = *ctr;
-            second.v0 = (ctr->v0 + nb) & 0x00FFFFFFFFFFFFFFull;
-            int rc = launch_ctr_shared<NR>(st, tb, ek, ctr, in, out, (size_t)(nb * 16), gate);
-            if (rc) return rc;
-            return launch_ctr_shared<NR>(st, tb, ek, &second, (const unsigned char *)in + nb * 16, (unsigned char *)out + nb * 16,
-                                         len - (size_t)(nb * 16), gate);
-        }
-        return launch_ctr_v<NR, 4>(st, tb, ek, ctr, in, out, len, gate);        /* (cannot happen: the boundary lies inside) */
-    }
     hipError_t e = set_lds(k_ctr_shared2<NR>, UAES_LDS_CTRS);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL((k_ctr_shared2<NR>), dim3(grid), dim3(UAES_WG), UAES_LDS_CTRS, st, *ek, *tb, *ctr,
-                       (const uint4 *)in, (uint4 *)out, g_lo, n8, nfull, (u32)(len % 16), gate);
+                       (const uint4 *)in, (uint4 *)out, g_lo, n8, (u64)(len / 16), (u32)(len % 16), gate);
     return (int)hipGetLastError();
 }
 
@@ -1067,9 +1002,23 @@ template <int NR>
 static int launch_ctr(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek, const uaesk_ctr *ctr,
                       const void *in, void *out, size_t len, const int *gate)
 {
-    if (ctr->le32)                             /* the shared-round kernel assumes the 56-bit BE counter */
-        return launch_ctr_v<NR, 4>(st, tb, ek, ctr, in, out, len, gate);
-    return launch_ctr_shared<NR>(st, tb, ek, ctr, in, out, len, gate);
+    u64 g_lo = 0, n8 = 0;
+    const uaes_plan pl = plan_ctr(ctr, len, &g_lo, &n8);
+    if (pl.arrangement == UAES_ARR_CTR_SINGLE) return launch_ctr_u<NR, 1>(st, tb, ek, ctr, in, out, len, gate);
+    if (pl.arrangement == UAES_ARR_CTR_QUAD) return launch_ctr_u<NR, UAES_U>(st, tb, ek, ctr, in, out, len, gate);
+    if (pl.launches == 2) {
+        /* the striped kernel makes its lane constants once per launch (uaes_ctr.hip.h): cut at the block where
+         * counter bits 40..47 move; each half is planned on its own */
+        const u64 nb = ((u64)1 << 40) - (ctr->v0 & (((u64)1 << 40) - 1));          /* blocks up to the boundary */
+        if (nb == 0 || nb >= len / 16) return launch_ctr_u<NR, UAES_U>(st, tb, ek, ctr, in, out, len, gate);   /* (cannot happen) */
+        uaesk_ctr second = *ctr;
+        second.v0 = (ctr->v0 + nb) & 0x00FFFFFFFFFFFFFFull;
+        int rc = launch_ctr<NR>(st, tb, ek, ctr, in, out, (size_t)(nb * 16), gate);
+        if (rc) return rc;
+        return launch_ctr<NR>(st, tb, ek, &second, (const unsigned char *)in + nb * 16, (unsigned char *)out + nb * 16,
+                              len - (size_t)(nb * 16), gate);
+    }
+    return launch_ctr_striped<NR>(st, tb, ek, ctr, in, out, len, gate, pl.grid, g_lo, n8);
 }
 
 template <int NR, int U>
@@ -1146,6 +1095,34 @@ extern "C" size_t uaesk_xts_scratch_bytes(size_t sector_bytes, size_t nsectors)
     return (size_t)(cps * nsectors * 16);
 }
 
+/* XTS (uaes_plan.h).  XTS_SMALL: one unit of up to 8 MiB (one block per lane and a run loop: 5 MiB 27.2 -> 23.8 us,
+ * 8 MiB 31.5 -> 28.5, 12 MiB 32.3 against 39.8 for the pre-pass + bulk kernel), or up to 4 MiB of whole-block units
+ * numbered from first_sector, in ONE launch.  XTS_PACKED: units shorter than a chunk (whole blocks, a multiple of
+ * four) in the flat, packed arrangement.  XTS_BULK: the tweak pre-pass and the chunk kernel -- everything else, the C3
+ * shape (2^20 sectors of 4 KiB) included.  (Round 5 had a fourth arrangement between SMALL and BULK for 4 KiB sectors up
+ * to 128 MiB, the tweaks made inside the chunk kernel: -22 % .. +3.9 % against BULK on two boxes, deleted in round 6:
+ * profiles/r06_plan_ab.log.) */
+static uaes_plan plan_xts(size_t sector_bytes, size_t nsectors, bool explicit_tweak)
+{
+    u64 mb, cps; u32 r;
+    xts_geometry(sector_bytes, &mb, &r, &cps);
+    uaes_plan p = { UAES_ARR_XTS_BULK, 0, 0, 0 };
+    const bool one_unit = nsectors == 1 && mb > 0 && cps <= 2ull * XTS_SMALL_CHUNKS;
+    const bool few_units = nsectors > 1 && !explicit_tweak && r == 0 && mb > 0 &&
+                           (u64)nsectors * ((mb + 63) / 64) <= 4ull * XTS_SMALL_CHUNKS;
+    if ((one_unit || few_units) && uaesk_arr_on(UAES_ARR_XTS_SMALL)) {
+        p.arrangement = UAES_ARR_XTS_SMALL; p.launches = r ? 2 : 1; p.steps = few_units ? 1u : 0u;
+        p.grid = grid_for((u64)nsectors * ((mb + 63) / 64), UAES_WG / 64);
+        return p;
+    }
+    const bool serial = cps <= XTS_SERIAL_CPS;
+    p.launches = 1 + (serial ? 0 : 1) + (mb > 0 ? 1 : 0) + (r ? 1 : 0);
+    if (!explicit_tweak && r == 0 && mb >= 4 && mb < XTS_CHUNK && mb % 4 == 0 && nsectors > 1 && uaesk_arr_on(UAES_ARR_XTS_PACKED)) {
+        p.arrangement = UAES_ARR_XTS_PACKED; p.launches = 2;
+    }
+    return p;
+}
+
 template <int NR, bool DEC>
 static int launch_xts(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *k1, const uaesk_rk *k2,
                       const uint8_t *tweak16, u64 first_sector, size_t sector_bytes, size_t nsectors,
@@ -1162,23 +1139,16 @@ static int launch_xts(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *k1
 
     uint4 raw = make_uint4(0, 0, 0, 0);
     if (tweak16) memcpy(&raw, tweak16, 16);
-    /* one unit of up to 4 MiB, or up to 4 MiB of whole-block units numbered from first_sector: one launch (k_xts_small) */
-    /* (UAES_XTS_SMALL_CHUNKS: measurement -- how long a single unit stays on the one-launch kernel, one block per lane
-     * and a run loop, before the pre-pass + expand + bulk kernel's four blocks per lane win: 8 MiB, two runs per wave
-     * -- 5 MiB 27.2 -> 23.8 us, 8 MiB 31.5 -> 28.5, 12 MiB 32.3 against 39.8; profiles/r05_xts_small_limit.log) */
-    static const int small_chunks = env_int_clamped("UAES_XTS_SMALL_CHUNKS", 2 * (int)XTS_SMALL_CHUNKS, 1, 1 << 16);
-    const bool one_unit = nsectors == 1 && mb > 0 && cps <= (u64)small_chunks;
-    const bool few_units = nsectors > 1 && !tweak16 && r == 0 && mb > 0 &&
-                           (u64)nsectors * ((mb + 63) / 64) <= 4ull * XTS_SMALL_CHUNKS;
-    if (one_unit || few_units) {
+    const uaes_plan pl = plan_xts(sector_bytes, nsectors, tweak16 != nullptr);
+    const bool few_units = pl.arrangement == UAES_ARR_XTS_SMALL && pl.steps == 1u;
+    if (pl.arrangement == UAES_ARR_XTS_SMALL) {
         e = few_units ? set_lds((k_xts_small<NR, DEC, true>), XTS_SMALL_LDS) : set_lds((k_xts_small<NR, DEC, false>), XTS_SMALL_LDS);
         if (e != hipSuccess) return (int)e;
         uaesk_done done = { nullptr, nullptr, 0 };
         if (!r) done = uaesk_ticket_take();                   /* no stealing kernel behind it: it carries the ticket */
         /* a workgroup per 1024 blocks (one per lane), as many as half the CUs: a 64 KiB unit runs on four CUs at the
          * latency of one block */
-        const u64 runs = (u64)nsectors * ((mb + 63) / 64);
-        const unsigned sgrid = grid_for(runs, UAES_WG / 64);
+        const unsigned sgrid = pl.grid;
         if (few_units)
             hipLaunchKernelGGL((k_xts_small<NR, DEC, true>), dim3(sgrid), dim3(UAES_WG), XTS_SMALL_LDS, st, *k1, *k2, *tb, raw,
                                0u, first_sector, (uint4 *)scratch, cps, mb,
@@ -1193,26 +1163,6 @@ static int launch_xts(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *k1
             hipLaunchKernelGGL((k_xts_cts<NR, DEC>), dim3(1), dim3(UAES_WG), lds, st,
                                *k1, *tb, (const uint4 *)scratch, (u64)1, cps, mb, r, (u64)sector_bytes,
                                (const unsigned char *)in, (unsigned char *)out);
-        return (int)hipGetLastError();
-    }
-    /* a chunk per unit, one chunk per unit, whole blocks (4 KiB sectors): the bulk kernel makes its tweaks itself */
-    if (!tweak16 && r == 0 && cps == 1 && mb >= 4 && !(mb < XTS_CHUNK && mb % 4 == 0) && nsectors > 1 &&
-        (u64)nsectors <= 8ull * grid_for(~0ull, 1) * (UAES_WG / 64)) {          /* ... up to eight chunks per wave: 128 MiB */
-        if ((e = set_lds((k_xts_fold<NR, DEC, true>), lds + 3072u)) != hipSuccess) return (int)e;
-        if ((e = set_lds((k_xts_fold<NR, DEC, false>), lds + 3072u)) != hipSuccess) return (int)e;
-        const u64 nchunks = (u64)nsectors;
-        const unsigned wg = grid_for(nchunks, UAES_WG / 64) * 2 <= grid_for(~0ull, 1) ? 256u : UAES_WG;
-        const unsigned xgrid = grid_for(nchunks, wg / 64);
-        const u64 nwaves = (u64)xgrid * (wg / 64);
-        static const int pct = env_int_clamped("UAES_XTS_TAIL_PCT", 80, 0, 100);
-        const u64 rounds = nchunks / nwaves, left = nchunks % nwaves;
-        XtsFoldArgs ka;
-        ka.k1 = *k1; ka.k2 = *k2; ka.tb = *tb; ka.nsectors = nsectors; ka.main_blocks = mb; ka.sector_bytes = sector_bytes;
-        ka.step_q = nwaves; ka.step_r = 0; ka.first_sector = first_sector;
-        ka.nmain = (rounds && left && left * 100 < nwaves * (u64)pct) ? rounds * nwaves : nchunks;
-        ka.in = (const unsigned char *)in; ka.out = (unsigned char *)out;
-        if (mb == XTS_CHUNK) hipLaunchKernelGGL((k_xts_fold<NR, DEC, true>), dim3(xgrid), dim3(wg), lds + 3072u, st, ka);
-        else hipLaunchKernelGGL((k_xts_fold<NR, DEC, false>), dim3(xgrid), dim3(wg), lds + 3072u, st, ka);
         return (int)hipGetLastError();
     }
     const bool serial = cps <= XTS_SERIAL_CPS;
@@ -1231,7 +1181,7 @@ static int launch_xts(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *k1
         hipLaunchKernelGGL(k_xts_expand, dim3(grid_for((u64)nsectors * ((cps + 63) / 64), UAES_WG / 64)),
                            dim3(UAES_WG), 0, st, *xts_pow_table(), (u64)nsectors, cps, (uint4 *)scratch);
     /* units shorter than a chunk (whole blocks, a multiple of four): the flat, packed arrangement (k_xts) */
-    if (!tweak16 && r == 0 && mb >= 4 && mb < XTS_CHUNK && mb % 4 == 0 && nsectors > 1) {
+    if (pl.arrangement == UAES_ARR_XTS_PACKED) {
         if ((e = set_lds((k_xts<NR, DEC, true, true>), lds)) != hipSuccess) return (int)e;
         const u64 total = (u64)nsectors * mb, nchunks = (total + XTS_CHUNK - 1) / XTS_CHUNK;
         const unsigned wg = grid_for(nchunks, UAES_WG / 64) * 2 <= grid_for(~0ull, 1) ? 256u : UAES_WG;
@@ -1251,9 +1201,9 @@ static int launch_xts(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *k1
         const unsigned xgrid = grid_for(nchunks, wg / 64);
         const u64 nwaves = (u64)xgrid * (wg / 64), step_q = nwaves / cps, step_r = nwaves % cps;
         /* the remainder of the last round by quarter chunks when it covers less than 80 % of the waves (k_xts) */
-        static const int pct = env_int_clamped("UAES_XTS_TAIL_PCT", 80, 0, 100);
+        const u64 pct = 80;                                   /* (as CTR_TAIL_PCT) */
         const u64 rounds = nchunks / nwaves, left = nchunks % nwaves;
-        const u64 nmain = (rounds && left && left * 100 < nwaves * (u64)pct) ? rounds * nwaves : nchunks;
+        const u64 nmain = (rounds && left && left * 100 < nwaves * pct) ? rounds * nwaves : nchunks;
         if ((sector_bytes % 16 == 0 || nsectors == 1) && mb % XTS_CHUNK == 0) {        /* every chunk whole: k_xts<.., ALLFULL> */
             if ((e = set_lds((k_xts<NR, DEC, true, false, true>), lds)) != hipSuccess) return (int)e;
             hipLaunchKernelGGL((k_xts<NR, DEC, true, false, true>), dim3(xgrid), dim3(wg), lds, st,
@@ -1388,4 +1338,38 @@ extern "C" int uaesk_selftest(void *stream, const uaesk_tables *tb, const uaesk_
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(k_selftest, dim3(2), dim3(UAES_WG), UAES_LDS_ENC, S(stream), *ek128, *dk128, *tb, d_result);
     return (int)hipGetLastError();
+}
+
+/* ------------------------------------------------------------------------ */
+/* the table as data (uaes_plan.h)                                             */
+/* ------------------------------------------------------------------------ */
+int uaesk_plan_gcm(int dir, size_t len, size_t aad_len, unsigned flags, uaes_plan *p);     /* uaes_gcm.hip */
+int uaesk_plan_siv(int dir, size_t len, size_t aad_len, unsigned flags, uaes_plan *p);     /* uaes_gcm.hip */
+int uaesk_plan_ocb(int dir, size_t len, size_t aad_len, uaes_plan *p);                     /* uaes_ocb.hip */
+
+extern "C" int uaesk_plan(int mode, int dir, size_t a, size_t b, unsigned flags, uaes_plan *p)
+{
+    if (!p) return (int)hipErrorInvalidValue;
+    if (uaesk_device_info(nullptr, nullptr) != 0) g_cus = 0;    /* no device: the table of a 256-CU MI355X (grid_for, plan_cus) */
+    switch (mode) {
+    case UAES_PLAN_ECB:
+        *p = plan_ecb((u64)((a + 15) / 16));
+        return 0;
+    case UAES_PLAN_CTR: {
+        uaesk_ctr c;
+        memset(&c, 0, sizeof c);
+        c.v0 = 1;                                   /* CTR_START_VALUE; the planner looks at the low byte only */
+        c.le32 = (flags >> 3) & 1u;
+        *p = plan_ctr(&c, a, nullptr, nullptr);
+        return 0;
+    }
+    case UAES_PLAN_XTS:
+        if (a < 16 || b == 0) return (int)hipErrorInvalidValue;
+        *p = plan_xts(a, b, (flags >> 1) & 1u);
+        return 0;
+    case UAES_PLAN_GCM: return uaesk_plan_gcm(dir, a, b, flags, p);
+    case UAES_PLAN_SIV: return uaesk_plan_siv(dir, a, b, flags, p);
+    case UAES_PLAN_OCB: return uaesk_plan_ocb(dir, a, b, p);
+    default: return (int)hipErrorInvalidValue;
+    }
 }

@@ -28,6 +28,7 @@
 #include <type_traits>
 #include "uaes_aes.hip.h"
 #include "uaes_device.h"
+#include "uaes_plan.h"
 
 static inline hipStream_t S(void *s) { return (hipStream_t)s; }
 
@@ -354,9 +355,6 @@ __device__ __forceinline__ void ocb_main_body(const uaesk_rk &rk, const LaneCons
         for (int q = 0; q < 4; ++q) atomicXor(acc + q, sum[q]);
     }
     __syncthreads();
-#ifdef UAES_OCB_SHARE_FENCE
-    if (threadIdx.x == 0) *share = *(const uint4 *)(uaes_lds + OCB_LDS_ACC);
-#else
     /* the share goes out as four device-scope atomic exchanges whose results have come back before the workgroup
      * counts itself in (k_ocb): they are performed where every XCD sees them, so the counting needs no release
      * fence -- which on this part writes back the XCD's whole L2, full of ciphertext that nobody is waiting for */
@@ -368,7 +366,6 @@ __device__ __forceinline__ void ocb_main_body(const uaesk_rk &rk, const LaneCons
         for (int q = 0; q < 4; ++q) old |= __hip_atomic_exchange(row + q, acc[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" :: "v"(old) : "memory");
     }
-#endif
 }
 
 /* ------------------------------------------------------------------------ */
@@ -549,9 +546,6 @@ __global__ __launch_bounds__(UAES_WG) void k_ocb(OcbArgs)
     if (gridDim.x > 1) {
         if (threadIdx.x == 0) {                       /* after ocb_main_body's store of the share, same thread */
             unsigned *const done_word = a->done_word;
-#ifdef UAES_OCB_SHARE_FENCE
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-#endif
             const unsigned arrived = __hip_atomic_fetch_add(done_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned l = arrived == gridDim.x - 1u ? 1u : 0u;
             if (l) __hip_atomic_store(done_word, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -597,12 +591,7 @@ __global__ __launch_bounds__(UAES_WG) void k_ocb_small(uaesk_rk ek, uaesk_rk dk,
                                                        const unsigned char *in, unsigned char *out, u64 len,
                                                        int *status, u32 tag_len, uaesk_done done)
 {
-#ifdef UAES_OCB_TIMING
-    u64 ts[6];
-#define OT(i) do { if (threadIdx.x == 0) ts[i] = wall_clock64(); } while (0)
-#else
 #define OT(i) do { } while (0)
-#endif
     OT(0);
     uint4 *const part = (uint4 *)(uaes_lds + OCB_SMALL_SCR);
     const u64 nblocks = len >> 4;
@@ -669,13 +658,6 @@ __global__ __launch_bounds__(UAES_WG) void k_ocb_small(uaesk_rk ek, uaesk_rk dk,
         if (dec_tables) ocb_final_body(EncPlain<NR>{ ek }, part, nparts, part, 0u, 0ull, 1, aad, aad_len, in, out, len, status, tag_len);
         else ocb_final_body(EncRep<NR>{ ek, lc }, part, nparts, part, 0u, 0ull, DEC ? 1 : 0, aad, aad_len, in, out, len, status, tag_len);
     }
-#ifdef UAES_OCB_TIMING
-    OT(5);
-    if (threadIdx.x == 0)
-        printf("ocb small: fill %llu setup %llu main %llu tables %llu final %llu (x10 ns)\n", (unsigned long long)(ts[1] - ts[0]),
-               (unsigned long long)(ts[2] - ts[1]), (unsigned long long)(ts[3] - ts[2]), (unsigned long long)(ts[4] - ts[3]),
-               (unsigned long long)(ts[5] - ts[4]));
-#endif
 #undef OT
     ticket_release(done);
 }
@@ -695,6 +677,23 @@ static hipError_t want_lds(const void *kern)
     return uaesk_want_lds(kern, (unsigned)(OCB_LDS));
 }
 
+/* OCB's rows of the table of arrangements (uaes_plan.h): one workgroup for a short message with short associated data,
+ * else runs of chunks over as many workgroups as there are CUs -- both ONE launch, the last workgroup to arrive makes
+ * the tag */
+bool uaesk_arr_on(int id);                                       /* uaes_kernels.hip */
+static uaes_plan plan_ocb(u64 len, u64 aad_len)
+{
+    uaes_plan p = { UAES_ARR_OCB_RUNS, 1, 0, 0 };
+    if ((len >> 4) <= OCB_SMALL_BLOCKS && aad_len <= OCB_SMALL_AAD && uaesk_arr_on(UAES_ARR_OCB_SMALL)) { p.arrangement = UAES_ARR_OCB_SMALL; p.grid = 1; }
+    return p;
+}
+int uaesk_plan_ocb(int dir, size_t len, size_t aad_len, uaes_plan *p)
+{
+    if (dir < 0 || dir > 1) return (int)hipErrorInvalidValue;
+    *p = plan_ocb(len, aad_len);
+    return 0;
+}
+
 template <int NR>
 static int launch_ocb(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek, const uaesk_rk *dk,
                       int decrypt, uint4 nb, u32 bottom, u32 tag_len, const void *aad, size_t aad_len,
@@ -705,7 +704,7 @@ static int launch_ocb(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek
     /* one launch either way, which can carry the call's completion ticket (a decryption's status word must then
      * be host-visible: the host layer arms a ticket only when it passes a pinned status pointer) */
     const uaesk_done done = uaesk_ticket_take();
-    if ((len >> 4) <= OCB_SMALL_BLOCKS && aad_len <= OCB_SMALL_AAD) {         /* short message: one workgroup */
+    if (plan_ocb(len, aad_len).arrangement == UAES_ARR_OCB_SMALL) {         /* short message: one workgroup */
         const void *ks = decrypt ? (const void *)k_ocb_small<NR, true> : (const void *)k_ocb_small<NR, false>;
         if ((e = uaesk_want_lds(ks, (unsigned)OCB_SMALL_LDS)) != hipSuccess) return (int)e;
         if (decrypt)

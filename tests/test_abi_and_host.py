@@ -267,3 +267,49 @@ def test_ctr_hot_loop_instruction_budget():
         elif op == "ds_read_b32" and on:
             cur += 1
     assert bursts and set(bursts) == {16}, sorted(set(bursts))
+
+
+def test_the_table_of_arrangements_without_a_device():
+    """csrc/uaes_plan.h as data (uaes_debug_plan): without a GPU the planners answer for a 256-CU MI355X.  Every
+    arrangement has a name, the boundaries sit where DESIGN.md's table says, the switch (uaes_debug_plan_disable)
+    makes the next arrangement take the call, and no size threshold is read from the environment any more."""
+    L = uaes.engine()
+    names = [L.uaes_debug_arrangement_name(k).decode() for k in range(18)]
+    assert names == ["ecb.single", "ecb.tiled", "ctr.single", "ctr.quad", "ctr.striped", "xts.small", "xts.packed",
+                     "xts.bulk", "gcm.small", "gcm.chunks", "gcm.twophase", "gcm.striped", "gcm.levels", "ocb.small", "ocb.runs",
+                     "siv.small", "siv.chunks", "siv.levels"]
+    assert L.uaes_debug_arrangement_name(18) == b"?"
+    MIB = 1 << 20
+    table = [("ecb", 4096, 0, 0, "ecb.single"), ("ecb", 1 << 30, 0, 0, "ecb.tiled"),
+             ("ctr", 4096, 0, 0, "ctr.single"), ("ctr", 8 * MIB - 16, 0, 0, "ctr.single"), ("ctr", 9 * MIB, 0, 0, "ctr.striped"),
+             ("ctr", 1 << 30, 0, 0, "ctr.striped"),
+             ("xts", 4096, 1, 0, "xts.small"), ("xts", 8 * MIB, 1, 0, "xts.small"), ("xts", 8 * MIB + 16, 1, 0, "xts.bulk"),
+             ("xts", 4096, 1024, 0, "xts.small"), ("xts", 4096, 1025, 0, "xts.bulk"), ("xts", 4096 + 16, 1025, 0, "xts.bulk"),
+             ("xts", 4096, 1 << 20, 0, "xts.bulk"), ("xts", 512, 1 << 20, 0, "xts.packed"),
+             ("gcm", 0, 0, 0, "gcm.small"), ("gcm", 2045 * 16, 0, 0, "gcm.small"), ("gcm", 2046 * 16, 0, 0, "gcm.chunks"),
+             ("gcm", 16 * MIB, 0, 0, "gcm.chunks"), ("gcm", 16 * MIB + 16, 0, 0, "gcm.twophase"), ("gcm", 128 * MIB, 0, 0, "gcm.twophase"),
+             ("gcm", 128 * MIB + 16, 0, 0, "gcm.striped"), ("gcm", 1 << 30, 0, 0, "gcm.striped"),
+             ("gcm", 16 * MIB + 16, 0, 1, "gcm.chunks"), ("gcm", 512 * MIB, 0, 1, "gcm.chunks"), ("gcm", 512 * MIB + 16, 0, 1, "gcm.levels"),
+             ("gcm", 1 << 30, 0, 2, "gcm.striped"), ("gcm", 1 << 20, 0, 3, "gcm.levels"),
+             ("ocb", 16384, 0, 0, "ocb.small"), ("ocb", 16400, 0, 0, "ocb.runs"), ("ocb", 100, 70000, 0, "ocb.runs"),
+             ("siv", 1000, 0, 0, "siv.small"), ("siv", 1 << 20, 0, 0, "siv.chunks"), ("siv", 600 * MIB, 0, 0, "siv.levels")]
+    for mode, a, b, d, want in table:
+        assert uaes.plan(mode, a, b, d)[0] == want, (mode, a, b, d, uaes.plan(mode, a, b, d))
+    assert uaes.plan("gcm", 1 << 30)[1] == 3 and uaes.plan("gcm", 1 << 20)[1] == 1 and uaes.plan("gcm", 1 << 20, 0, 0, 4)[1] == 2
+    try:
+        L.uaes_debug_plan_disable(1 << uaes.arrangement_id("gcm.twophase"))
+        assert uaes.plan("gcm", 64 * MIB)[0] == "gcm.striped"
+        L.uaes_debug_plan_disable((1 << uaes.arrangement_id("gcm.twophase")) | (1 << uaes.arrangement_id("gcm.striped")))
+        assert uaes.plan("gcm", 64 * MIB)[0] == "gcm.levels"
+        L.uaes_debug_plan_disable(1 << uaes.arrangement_id("ctr.striped"))
+        assert uaes.plan("ctr", 1 << 30)[0] == "ctr.quad"
+        L.uaes_debug_plan_disable(0xffffffff)                 # the catch-all arrangements cannot be switched off
+        assert [uaes.plan(m, 1 << 20)[0] for m in ("ecb", "ctr", "gcm", "ocb", "siv")] == ["ecb.tiled", "ctr.quad", "gcm.levels", "ocb.runs", "siv.levels"]
+        assert uaes.plan("xts", 4096, 64)[0] == "xts.bulk"
+    finally:
+        L.uaes_debug_plan_disable(0)
+    # the kernel layer reads no size threshold from the environment: the only getenv calls left are the documented hooks
+    hooks = set()
+    for f in ("uaes_kernels.hip", "uaes_gcm.hip", "uaes_ocb.hip", "uaes_chain.hip", "uaes_mac.hip"):
+        hooks |= set(re.findall(r'getenv\("(\w+)"\)', open(os.path.join(ROOT, "micro-aes_amd", "csrc", f)).read()))
+    assert hooks == {"UAES_PLAN_DISABLE", "UAES_GCM_FOLD", "UAES_GCM_LOOK_TICKS"}, hooks

@@ -302,38 +302,6 @@ def test_gcmsiv_vs_oracle(orc, bits):
         assert (rc, txt) == orc.gcmsiv_decrypt(key, nonce, aad, bytes(bad)) and rc == 0x1A    # text released, as the reference does
 
 
-def test_paths_behind_the_chunk_workgroups_still_hold(orc):
-    """What a text takes when one round of chunk workgroups does not reach it -- GCM's setup / GHASH levels / last levels
-    for a tag-first decryption and a GMAC, the striped kernel for an encryption, GCM-SIV's POLYVAL by the levels with
-    k_siv_tag -- is beyond 512 MiB on an MI355X now.  UAES_GCM_MAXLOGSTEPS=0 (one position per thread: 4 MiB) brings
-    those paths down to sizes the oracle checks in a second."""
-    import subprocess
-    import sys
-    code = r"""
-import sys, hashlib
-sys.path.insert(0, %r)
-import micro_aes_amd as uaes
-from oracle.pyoracle import Oracle
-orc = Oracle()
-key, n12 = bytes(range(32)), bytes(range(12))
-for n, aad in (((6 << 20) + 5, b"abc"), (9 << 20, b""), (0, bytes(5 << 20))):
-    d = orc.splitmix(n + 1, n)
-    want = orc.gcm_encrypt(key, n12, aad, d)
-    assert uaes.AES_GCM_encrypt(key, n12, aad, d) == want, n
-    assert uaes.AES_GCM_decrypt(key, n12, aad, want) == (0, d), n
-    bad = bytearray(want); bad[len(bad) // 2] ^= 1
-    assert uaes.AES_GCM_decrypt(key, n12, aad, bytes(bad))[0] == 0x1A
-    if n:
-        ws = orc.gcmsiv_encrypt(key, n12, aad, d)
-        assert uaes.GCM_SIV_encrypt(key, n12, aad, d) == ws, n
-        assert uaes.GCM_SIV_decrypt(key, n12, aad, ws) == (0, d), n
-print("ok")
-""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, UAES_GCM_MAXLOGSTEPS="0"), capture_output=True,
-                       text=True, timeout=600)
-    assert r.returncode == 0 and r.stdout.split()[-1] == "ok", r.stderr[-2000:]
-
-
 def test_gcmsiv_long_messages_stay_on_the_device(orc):
     """A GCM-SIV message too long for the one-workgroup kernel: derive_keys, the derived key's expansion, POLYVAL, the
     tag and the counter made of it run as kernels one behind the other and never visit the host (uaesk_gcmsiv_long:
@@ -1192,6 +1160,8 @@ def test_gcm_single_launch_sizes(orc, bits):
               (2045 * 16, 0), (2045 * 16, 16), (2046 * 16 - 1, 0), (2046 * 16, 0), (0, 2046 * 16), (2046 * 16, 1), (2047 * 16, 0),
               (16384, 13), (4096, 0)]
     for n, alen in shapes:
+        # the shapes are hand-picked for the INSIDE of the one-workgroup kernel; the table must still send them there
+        assert uaes.plan("gcm", n, alen)[0] == ("gcm.small" if (alen + 15) // 16 + (n + 15) // 16 + 1 <= 2046 else "gcm.chunks"), (n, alen)
         nonce = rnd.randbytes(12)
         data, aad = rnd.randbytes(n), rnd.randbytes(alen)
         want = orc.gcm_encrypt(key, nonce, aad, data)
@@ -1288,6 +1258,8 @@ def test_gcm_chunk_and_combine_kernels(orc, bits):
         shapes += [(512 * 2048 * B - B, 0), (512 * 2048 * B, 16), (1024 * 2048 * B - B, 0), (1024 * 2048 * B, 0), (0, 40 << 20)]
     try:
         for n, alen in shapes:
+            # hand-picked for the INSIDE of the chunk arrangement (chunk counts, front padding): the table must agree
+            assert uaes.plan("gcm", n, alen)[0] in ("gcm.small", "gcm.chunks", "gcm.twophase"), (n, alen)
             nonce, aad = rnd.randbytes(12), rnd.randbytes(alen)
             pt = orc.splitmix(n % 977 + 3, (n + 7) // 8 * 8)[:n]
             want = orc.gcm_encrypt(key, nonce, aad, pt)
@@ -1766,7 +1738,7 @@ def test_gcm_records_v_slot_tails_hold_no_earlier_message(orc):
 @pytest.mark.parametrize("bits", [128, 256])
 def test_ctr_partial_last_round_of_stripes(orc, bits):
     """k_ctr_shared2 deals 32 KiB stripes round-robin over the workgroups; a last round that covers only part of the grid is
-    handed to the kernel's edge path (one block per thread, plain rounds) when it is below UAES_CTR_TAIL_PCT of the grid.
+    handed to the kernel's edge path (one block per thread, plain rounds) when it is below CTR_TAIL_PCT (80 %) of the grid.
     Sizes on both sides of that rule -- 2.5 rounds, 2 rounds + one stripe, 3 rounds - one stripe, an exact multiple -- with
     ragged ends and a counter that carries, against the oracle."""
     import torch

@@ -1,12 +1,10 @@
 #!/bin/bash
 # tools/build_variants.sh <name>=<XFLAGS> ... -- builds libuaes_hip.so with the given extra hipcc flags into
 # micro-aes_amd/lib/libuaes_hip_<name>.so (own object directory per variant, all in parallel; the product build in
-# micro-aes_amd/lib/libuaes_hip.so is not touched).  For A/B runs with tools/ab_libs.py / tools/ctr_variants.py:
-#     tools/build_variants.sh base= v2=-DUAES_ASM_VARIANT=2
+# micro-aes_amd/lib/libuaes_hip.so is not touched).  For A/B runs with tools/ab_libs.py:
+#     tools/build_variants.sh base= o2=-O2
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-# the hand-scheduled round blocks are generated, not tracked
-case "$*" in *UAES_ASM_VARIANT*) python3 "$ROOT/tools/gen_rounds_asm.py" > /dev/null;; esac
 pids=()
 for spec in "$@"; do
     name=${spec%%=*}; flags=${spec#*=}
