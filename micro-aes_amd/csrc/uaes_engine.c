@@ -33,12 +33,14 @@
 /* ------------------------------------------------------------------------ */
 static __thread char tls_err[256];
 
+static int g_device_suspect;                       /* set by every UAES_E_HIP: the host fallback looks at the device again */
 static int fail(int code, const char *fmt, ...)
 {
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(tls_err, sizeof tls_err, fmt, ap);
     va_end(ap);
+    if (code == UAES_E_HIP) __atomic_store_n(&g_device_suspect, 1, __ATOMIC_RELEASE);
     return code;
 }
 
@@ -592,9 +594,15 @@ static int enter(context **c, lane **L)
     return rc ? rc : get_lane(*c, L);
 }
 
-static int lane_scratch(lane *L, size_t need)
+/* The lane's scratch, for `owner`.  SCRATCH_GCM_KEYED: a GCM call under the lane's cached key -- the only user that
+ * leaves the key's tables valid (lane_gcm_keyed decides whether they are there).  Anybody else (XTS chunk tweaks, OCB
+ * rows, GHASH under a foreign H, GCM-SIV, a GCM shard ...) is about to overwrite them: asking for the buffer IS the
+ * invalidation, no writer has to remember a second call. */
+enum { SCRATCH_OTHER = 0, SCRATCH_GCM_KEYED = 1 };
+static int lane_scratch(lane *L, size_t need, int owner)
 {
     const size_t before = L->scratch_cap;
+    if (owner != SCRATCH_GCM_KEYED) lane_scratch_clobbered(L);
     int rc = grow_on(L->stream, &L->scratch, &L->scratch_cap, need + SCRATCH_TAIL);
     if (rc) return rc;
     if (L->scratch_cap != before) {
@@ -845,7 +853,7 @@ static void auto_devices_from_env(void)          /* once, from env_init() */
  *              (a `void` function of the reference's API cannot report an error).
  * Environment, read once: UAES_HOST_MAX (bytes), UAES_HOST_CHAINS=1, UAES_HOST_FALLBACK=1.  Device pointers always go to
  * the GPU.  The batch / record / key-context / stream / mgpu / *_dev calls have no host path.                      */
-static struct { size_t max_bytes; int chains, fallback, no_device; } g_host = { 0, 0, 0, -1 };
+static struct { size_t max_bytes, gcm_max_bytes; int chains, fallback, no_device; } g_host = { 0, 0, 0, 0, -1 };
 
 int uaes_set_host_policy(size_t max_bytes, int chains, int fallback)
 {
@@ -871,23 +879,46 @@ static void host_policy_from_env(void)             /* once, from env_init() */
     /* UAES_HOST_POLICY=recommended: the measured crossover of this host class (profiles/r05_host_policy.md: the host path
      * is the faster one up to 4 KiB, GCM 2 KiB), single chains on the host, and a GPU-less box served instead of refused;
      * the individual variables refine it */
-    if (p && strcmp(p, "recommended") == 0) { g_host.max_bytes = 4096; g_host.chains = 1; g_host.fallback = 1; }
+    if (p && strcmp(p, "recommended") == 0) { g_host.max_bytes = 4096; g_host.gcm_max_bytes = 2048; g_host.chains = 1; g_host.fallback = 1; }
     if (m && *m) { long long v = strtoll(m, NULL, 10); if (v >= 0) g_host.max_bytes = (size_t)v; }
     g_host.chains = env_int("UAES_HOST_CHAINS", g_host.chains, 0, 1);
     g_host.fallback = env_int("UAES_HOST_FALLBACK", g_host.fallback, 0, 1);
 }
 
-/* does this call run on the host path?  chain != 0: one serial chain */
-static int host_take(const void *in, const void *out, size_t len, int chain)
+/* leaving through the host path: the schedule on the caller's stack is wiped (the reference BURNs its RoundKey after
+ * every call, micro_aes.c:360) and a non-zero code gets its text in uaes_last_error() like the device path's */
+static void burn(void *p, size_t n)
 {
-    const size_t mx = __atomic_load_n(&g_host.max_bytes, __ATOMIC_ACQUIRE);
+    volatile unsigned char *v = (volatile unsigned char *)p;
+    while (n--) *v++ = 0;
+}
+static int host_result(int rc)
+{
+    if (rc == UAES_E_AUTHENTICATION) return fail(rc, "authentication failed (host path)");
+    if (rc == UAES_E_DECRYPTION) return fail(rc, "ciphertext length is no multiple of the block size (host path)");
+    if (rc == UAES_E_DATALENGTH) return fail(rc, "data too short (host path)");
+    if (rc != 0) return fail(rc, "host path failed (%d)", rc);
+    return 0;
+}
+#define HOST_RET(ksv, rc) do { const int hr_ = (rc); burn(&(ksv), sizeof (ksv)); return host_result(hr_); } while (0)
+
+/* does this call run on the host path?  chain != 0: one serial chain; gcm != 0: GCM's own, lower crossover applies */
+static int host_take_mode(const void *in, const void *out, size_t len, int chain, int gcm);
+static int host_take(const void *in, const void *out, size_t len, int chain) { return host_take_mode(in, out, len, chain, 0); }
+static int host_take_mode(const void *in, const void *out, size_t len, int chain, int gcm)
+{
+    size_t mx = __atomic_load_n(&g_host.max_bytes, __ATOMIC_ACQUIRE);
     const int ch = __atomic_load_n(&g_host.chains, __ATOMIC_ACQUIRE), fb = __atomic_load_n(&g_host.fallback, __ATOMIC_ACQUIRE);
     if (!mx && !ch && !fb) {
         env_ready();
         if (!g_host.max_bytes && !g_host.chains && !g_host.fallback) return 0;      /* the default: GPU, always */
-        return host_take(in, out, len, chain);
+        return host_take_mode(in, out, len, chain, gcm);
     }
+    if (gcm && g_host.gcm_max_bytes && g_host.gcm_max_bytes < mx) mx = g_host.gcm_max_bytes;
     if (fb) {
+        /* probed once -- and again after any HIP failure of this process: a GPU that goes away after the first call
+         * must not keep the documented fallback from engaging */
+        if (__atomic_exchange_n(&g_device_suspect, 0, __ATOMIC_ACQ_REL)) __atomic_store_n(&g_host.no_device, -1, __ATOMIC_RELEASE);
         if (g_host.no_device < 0) {
             int n = 0;
             const int none = hipGetDeviceCount(&n) != hipSuccess || n <= 0;
@@ -1391,9 +1422,9 @@ static int ecb_common(int keybits, const uint8_t *key, int decrypt, int padding,
     if ((len && !in) || !out) return fail(UAES_E_ARG, "NULL data pointer");
     if (host_take(in, out, len, 0)) {
         const uaesh_key hk = host_key(&ks);
-        if (!decrypt) { uaesh_ecb_encrypt(&hk, padding, (const uint8_t *)in, len, (uint8_t *)out); return 0; }
+        if (!decrypt) { uaesh_ecb_encrypt(&hk, padding, (const uint8_t *)in, len, (uint8_t *)out); HOST_RET(ks, 0); }
         uaesh_ecb_decrypt(&hk, (const uint8_t *)in, len, (uint8_t *)out);
-        return rem ? UAES_E_DECRYPTION : 0;
+        HOST_RET(ks, rem ? UAES_E_DECRYPTION : 0);
     }
     {
         int devs[MAX_DEVICES];
@@ -1516,7 +1547,7 @@ int uaes_ctr_xcrypt_at(int keybits, const uint8_t *key, const uint8_t ctr0[16],
     if (host_take(in, out, len, 0)) {
         const uaesh_key hk = host_key(&ks);
         uaesh_ctr(&hk, ctr0, block_offset, (const uint8_t *)in, len, (uint8_t *)out);
-        return 0;
+        HOST_RET(ks, 0);
     }
     {
         int devs[MAX_DEVICES];
@@ -1626,7 +1657,7 @@ static int xts_common(int keybits, const uint8_t *keys, const uint8_t *tweak, in
         const uaesh_key h1 = host_key(&k1), h2 = host_key(&k2);
         if (raw_tweak) uaesh_xts_unit(&h1, &h2, encrypt, tweak ? tweak : zero, (const uint8_t *)in, sector_bytes, (uint8_t *)out);
         else uaesh_xts_sectors(&h1, &h2, encrypt, first_sector, sector_bytes, nsectors, (const uint8_t *)in, (uint8_t *)out);
-        return 0;
+        do { burn(&k2, sizeof k2); HOST_RET(k1, 0); } while (0);
     }
     if (!raw_tweak && nsectors > 1) {
         int devs[MAX_DEVICES];
@@ -1638,8 +1669,7 @@ static int xts_common(int keybits, const uint8_t *keys, const uint8_t *tweak, in
         xts_pipe_arg pa;
         pa.c = c; pa.k1 = &k1; pa.k2 = &k2; pa.encrypt = encrypt; pa.first_sector = first_sector; pa.sector_bytes = sector_bytes;
         if (!raw_tweak && nsectors > 1 && run_pipelined(c, in, out, total, sector_bytes, 0, xts_pipe_launch, &pa, &rc)) return rc;
-        lane_scratch_clobbered(L);
-        if ((rc = lane_scratch(L, uaesk_xts_scratch_bytes(sector_bytes, nsectors))) != 0) break;
+        if ((rc = lane_scratch(L, uaesk_xts_scratch_bytes(sector_bytes, nsectors), SCRATCH_OTHER)) != 0) break;
         if ((rc = plan_io(L, in, total, out, total, &io)) != 0) break;
         ticket_arm(L, total);
         rc = xts_run(c, L->stream, &k1, &k2, encrypt, raw_tweak ? (tweak ? tweak : zero) : NULL,
@@ -1686,9 +1716,9 @@ int uaes_xts_sectors_dev(int keybits, const uint8_t *keys, uint64_t first_sector
 /* ------------------------------------------------------------------------ */
 /* GCM                                                                        */
 /* ------------------------------------------------------------------------ */
-static int gcm_scratch(lane *L)                  /* synchronous API: the thread's own scratch */
+static int gcm_scratch(lane *L, int owner)       /* synchronous API: the thread's own scratch */
 {
-    return lane_scratch(L, uaesk_gcm_scratch_bytes());
+    return lane_scratch(L, uaesk_gcm_scratch_bytes(), owner);
 }
 
 /* 1: the tables of `key` are in the lane's scratch (this call may run as a call on a key context, uaesk_gcm_keyed),
@@ -1852,9 +1882,9 @@ int uaes_gcm_encrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, s
     if (tagLen < 1 || tagLen > 16) return fail(UAES_E_ARG, "GCM tag length %zu (1..16)", tagLen);
     if (nonceLen == 0) return fail(UAES_E_ARG, "empty GCM nonce");
     if (aDataLen && !aData) return fail(UAES_E_ARG, "NULL aData with aDataLen != 0");
-    if (host_take(pntxt, crtxt, ptextLen, 0) && !is_device_ptr(aData)) {
+    if (host_take_mode(pntxt, crtxt, ptextLen, 0, 1) && !is_device_ptr(aData)) {
         const uaesh_key hk = host_key(&ks);
-        return uaesh_gcm(&hk, 0, nonce, nonceLen, tagLen, (const uint8_t *)aData, aDataLen, (const uint8_t *)pntxt, ptextLen, (uint8_t *)crtxt);
+        HOST_RET(ks, uaesh_gcm(&hk, 0, nonce, nonceLen, tagLen, (const uint8_t *)aData, aDataLen, (const uint8_t *)pntxt, ptextLen, (uint8_t *)crtxt));
     }
     if (nonceLen == 12 && tagLen == 16) {
         int devs[MAX_DEVICES];
@@ -1864,7 +1894,7 @@ int uaes_gcm_encrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, s
     }
     if ((rc = enter(&c, &L)) != 0) return rc;
     do {
-        if ((rc = gcm_scratch(L)) != 0) break;
+        if ((rc = gcm_scratch(L, SCRATCH_GCM_KEYED)) != 0) break;
         /* (before anything of this call writes the scratch under its key.  A one-shot setup builds only the tables its
          * message reaches and leaves the others undefined: with a nonce whose J0 is a GHASH of its own, which runs such
          * a setup, the call stays one-shot and the cache starts over) */
@@ -1924,9 +1954,9 @@ int uaes_gcm_decrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, s
     if (tagLen < 1 || tagLen > 16) return fail(UAES_E_ARG, "GCM tag length %zu (1..16)", tagLen);
     if (nonceLen == 0) return fail(UAES_E_ARG, "empty GCM nonce");
     if (aDataLen && !aData) return fail(UAES_E_ARG, "NULL aData with aDataLen != 0");
-    if (host_take(crtxt, pntxt, crtxtLen, 0) && !is_device_ptr(aData)) {
+    if (host_take_mode(crtxt, pntxt, crtxtLen, 0, 1) && !is_device_ptr(aData)) {
         const uaesh_key hk = host_key(&ks);
-        return uaesh_gcm(&hk, 1, nonce, nonceLen, tagLen, (const uint8_t *)aData, aDataLen, (const uint8_t *)crtxt, crtxtLen, (uint8_t *)pntxt);
+        HOST_RET(ks, uaesh_gcm(&hk, 1, nonce, nonceLen, tagLen, (const uint8_t *)aData, aDataLen, (const uint8_t *)crtxt, crtxtLen, (uint8_t *)pntxt));
     }
     if (nonceLen == 12 && tagLen == 16) {
         int devs[MAX_DEVICES];
@@ -1935,7 +1965,7 @@ int uaes_gcm_decrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, s
     }
     if ((rc = enter(&c, &L)) != 0) return rc;
     do {
-        if ((rc = gcm_scratch(L)) != 0) break;
+        if ((rc = gcm_scratch(L, SCRATCH_GCM_KEYED)) != 0) break;
         /* (before anything of this call writes the scratch under its key.  A one-shot setup builds only the tables its
          * message reaches and leaves the others undefined: with a nonce whose J0 is a GHASH of its own, which runs such
          * a setup, the call stays one-shot and the cache starts over) */
@@ -2541,8 +2571,7 @@ int uaes_ghash(const uint8_t H[16], const void *aData, size_t aDataLen,
     if (!H || !gh) return fail(UAES_E_ARG, "NULL pointer");
     if ((rc = enter(&c, &L)) != 0) return rc;
     do {
-        lane_scratch_clobbered(L);
-        if ((rc = gcm_scratch(L)) != 0) break;
+        if ((rc = gcm_scratch(L, SCRATCH_OTHER)) != 0) break;
         if ((rc = stage_aad(L, aData, aDataLen, &d_aad)) != 0) break;
         if ((rc = plan_io(L, crtxt, crtxtLen, NULL, 0, &io)) != 0) break;
         int k = uaesk_ghash(L->stream, &c->tb, H, d_aad, aDataLen, io.din, crtxtLen, L->scratch, L->d_status + 4);
@@ -2567,7 +2596,7 @@ int uaes_cmac(int keybits, const uint8_t *key, const void *data, size_t dataSize
     if (host_take(data, NULL, dataSize, 1)) {
         const uaesh_key hk = host_key(&ks);
         uaesh_cmac(&hk, (const uint8_t *)data, dataSize, mac);
-        return 0;
+        HOST_RET(ks, 0);
     }
     if ((rc = enter(&c, &L)) != 0) return rc;
     do {
@@ -2603,7 +2632,7 @@ int uaes_ccm_encrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, s
     if (aDataLen && !aData) return fail(UAES_E_ARG, "NULL aData with aDataLen != 0");
     if (host_take(pntxt, crtxt, ptextLen, 1) && !is_device_ptr(aData)) {
         const uaesh_key hk = host_key(&ks);
-        return uaesh_ccm(&hk, 0, nonce, nonceLen, tagLen, (const uint8_t *)aData, aDataLen, (const uint8_t *)pntxt, ptextLen, (uint8_t *)crtxt);
+        HOST_RET(ks, uaesh_ccm(&hk, 0, nonce, nonceLen, tagLen, (const uint8_t *)aData, aDataLen, (const uint8_t *)pntxt, ptextLen, (uint8_t *)crtxt));
     }
     if ((rc = enter(&c, &L)) != 0) return rc;
     do {
@@ -2642,7 +2671,7 @@ int uaes_ccm_decrypt_ex(int keybits, const uint8_t *key, const uint8_t *nonce, s
         const uaesh_key hk = host_key(&ks);
         rc = uaesh_ccm(&hk, 1, nonce, nonceLen, tagLen, (const uint8_t *)aData, aDataLen, (const uint8_t *)crtxt, crtxtLen, (uint8_t *)pntxt);
         if (rc && wipe_on_auth_failure()) memset(pntxt, 0, crtxtLen);       /* (the default leaves the text, as the reference does) */
-        return rc;
+        HOST_RET(ks, rc);
     }
     if ((rc = enter(&c, &L)) != 0) return rc;
     do {
@@ -2698,13 +2727,13 @@ static int feedback_common(int keybits, const uint8_t *key, const uint8_t *iVec,
         const uint8_t *x = (const uint8_t *)in;
         uint8_t *y = (uint8_t *)out;
         switch (mode) {
-        case 0: return uaesh_cbc_encrypt(&hk, iVec, 1, 0, x, len, y);
-        case 1: return uaesh_cbc_decrypt(&hk, iVec, 1, x, len, y);
-        case 2: uaesh_cfb(&hk, iVec, 1, x, len, y); return 0;
-        case 3: uaesh_cfb(&hk, iVec, 0, x, len, y); return 0;
-        case 4: uaesh_ofb(&hk, iVec, x, len, y); return 0;
-        case 8: return uaesh_cbc_decrypt(&hk, iVec, 0, x, len, y);
-        default: return uaesh_cbc_encrypt(&hk, iVec, 0, mode - 5, x, len, y);
+        case 0: HOST_RET(ks, uaesh_cbc_encrypt(&hk, iVec, 1, 0, x, len, y));
+        case 1: HOST_RET(ks, uaesh_cbc_decrypt(&hk, iVec, 1, x, len, y));
+        case 2: uaesh_cfb(&hk, iVec, 1, x, len, y); HOST_RET(ks, 0);
+        case 3: uaesh_cfb(&hk, iVec, 0, x, len, y); HOST_RET(ks, 0);
+        case 4: uaesh_ofb(&hk, iVec, x, len, y); HOST_RET(ks, 0);
+        case 8: HOST_RET(ks, uaesh_cbc_decrypt(&hk, iVec, 0, x, len, y));
+        default: HOST_RET(ks, uaesh_cbc_encrypt(&hk, iVec, 0, mode - 5, x, len, y));
         }
     }
     if ((rc = enter(&c, &L)) != 0) return rc;
@@ -2845,13 +2874,12 @@ int uaes_gcmsiv_encrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
         if ((rc = expand_key(&mk, key, keybits)) != 0) return rc;
         hk = host_key(&mk);
         rc = uaesh_gcmsiv(&hk, keybits, 0, nonce, (const uint8_t *)aData, aDataLen, (const uint8_t *)pntxt, ptextLen, (uint8_t *)crtxt, uaes_expand_key);
-        memset(&mk, 0, sizeof mk);
-        return rc;
+        burn(&mk, sizeof mk);
+        return host_result(rc);
     }
     if ((rc = enter(&c, &L)) != 0) return rc;
     do {
-        lane_scratch_clobbered(L);
-        if ((rc = gcm_scratch(L)) != 0) break;
+        if ((rc = gcm_scratch(L, SCRATCH_OTHER)) != 0) break;
         if ((rc = stage_aad(L, aData, aDataLen, &d_aad)) != 0) break;
         if ((rc = plan_io(L, pntxt, ptextLen, crtxt, ptextLen + 16, &io)) != 0) break;
         {   /* a short message is ONE launch (k_siv_small): key derivation, POLYVAL, tag and keystream in one
@@ -2899,14 +2927,13 @@ int uaes_gcmsiv_decrypt(int keybits, const uint8_t *key, const uint8_t *nonce,
         if ((rc = expand_key(&mk, key, keybits)) != 0) return rc;
         hk = host_key(&mk);
         rc = uaesh_gcmsiv(&hk, keybits, 1, nonce, (const uint8_t *)aData, aDataLen, (const uint8_t *)crtxt, crtxtLen, (uint8_t *)pntxt, uaes_expand_key);
-        memset(&mk, 0, sizeof mk);
+        burn(&mk, sizeof mk);
         if (rc == UAES_E_AUTHENTICATION && wipe_on_auth_failure()) memset(pntxt, 0, crtxtLen);
-        return rc;
+        return host_result(rc);
     }
     if ((rc = enter(&c, &L)) != 0) return rc;
     do {
-        lane_scratch_clobbered(L);
-        if ((rc = gcm_scratch(L)) != 0) break;
+        if ((rc = gcm_scratch(L, SCRATCH_OTHER)) != 0) break;
         if ((rc = stage_aad(L, aData, aDataLen, &d_aad)) != 0) break;
         if ((rc = plan_io(L, crtxt, crtxtLen + 16, pntxt, crtxtLen, &io)) != 0) break;
         {   /* a short message is ONE launch (k_siv_small), key derivation included */
@@ -2970,12 +2997,11 @@ static int ocb_common(int keybits, const uint8_t *key, const uint8_t *nonce, siz
         rc = uaesh_ocb(&hk, decrypt, nonce, nonceLen, tagLen, (const uint8_t *)aData, aDataLen, (const uint8_t *)in, len, (uint8_t *)out);
         if (rc < 0) return fail(UAES_E_HIP, "out of host memory");
         if (rc == UAES_E_AUTHENTICATION && wipe_on_auth_failure()) memset(out, 0, len);
-        return rc;
+        HOST_RET(ks, rc);
     }
     if ((rc = enter(&c, &L)) != 0) return rc;
     do {
-        lane_scratch_clobbered(L);
-        if ((rc = gcm_scratch(L)) != 0) break;        /* >= uaesk_ocb_scratch_bytes() */
+        if ((rc = gcm_scratch(L, SCRATCH_OTHER)) != 0) break;        /* >= uaesk_ocb_scratch_bytes() */
         if ((rc = stage_aad(L, aData, aDataLen, &d_aad)) != 0) break;
         if ((rc = plan_io(L, in, len + (decrypt ? tagLen : 0), out, len + (decrypt ? 0 : tagLen), &io)) != 0) break;
         int *st_where = lane_status(L);
@@ -3393,6 +3419,12 @@ static int mgpu_run(mgpu_job *jobs, int n)
     pthread_mutex_t done_mu = PTHREAD_MUTEX_INITIALIZER;
     pthread_cond_t done_cv = PTHREAD_COND_INITIALIZER;
     int i, left = 0, rc = 0;
+    /* uaes_set_producer_stream() is thread-local to the CALLER; the slices run on the persistent workers, whose own
+     * producer stream is NULL (they wait for their device's default stream only).  Device-resident input that the
+     * caller produced on a non-blocking stream is therefore waited for HERE, once, before any worker may read it
+     * (ADVICE r05). */
+    if (tls_producer_stream && hipStreamSynchronize((hipStream_t)tls_producer_stream) != hipSuccess)
+        return fail(UAES_E_HIP, "waiting for the caller's producer stream failed: %s", hipGetErrorString(hipGetLastError()));
     for (i = 0; i < n; ++i)
         if (!mgpu_pool_ensure(jobs[i].device)) return fail(UAES_E_HIP, "pthread_create failed");
     pthread_mutex_lock(&done_mu);
@@ -3533,8 +3565,7 @@ static int gcm_shard_sync(int keybits, const uint8_t *key, const uint8_t *nonce,
     if ((rc = enter(&c, &L)) != 0) return rc;
     do {
         int k;
-        lane_scratch_clobbered(L);
-        if ((rc = gcm_scratch(L)) != 0) break;
+        if ((rc = gcm_scratch(L, SCRATCH_OTHER)) != 0) break;
         if (off == 0 && (rc = stage_aad(L, aData, (size_t)aDataLen, &d_aad)) != 0) break;
         if ((rc = plan_io(L, in, len, mode == 1 ? NULL : out, mode == 1 ? 0 : len, &io)) != 0) break;
         k = uaesk_gcm_shard(L->stream, &c->tb, ks.nr, &ks.ek, mode, nonce, d_aad, aDataLen, io.din, len, off, total,

@@ -148,6 +148,19 @@ def _xor_shares(shares):
     return tag
 
 
+def _dev_cipher(k, c, off, s, d, n):
+    from . import ctr_xcrypt_dev
+    ctr_xcrypt_dev(k, c, off, s, d, nbytes=n)
+
+
+def _dev_partial(k, no, a, ta, ct, n, start, total):
+    import torch
+    from . import gcm_partial_dev
+    out = torch.zeros(16, dtype=torch.uint8, device=ct.device)
+    gcm_partial_dev(k, no, a, ta, ct, n, start, total, out)
+    return out
+
+
 def _exchange(share, world, device, gather):
     """all ranks' 16-byte shares (this rank's may be None = zeros)"""
     if gather is None:
@@ -187,6 +200,9 @@ def gcm_encrypt_sharded(key, nonce, aad, total_aad_len, total_len, local_src, lo
             gcm_shard_dev(key, nonce, 0, aad if rank == 0 else None, total_aad_len, local_src, n, start, total_len,
                           local_dst, share)
     else:
+        # each callable defaults on its own: only one injected -> the other is the HIP engine's
+        cipher = cipher or _dev_cipher
+        partial = partial or _dev_partial
         ctr0 = bytes(nonce) + b"\x00\x00\x00\x01"
         if n:
             cipher(key, ctr0, 1 + start // 16, local_src, local_dst, n)
@@ -200,17 +216,8 @@ def gcm_decrypt_sharded(key, nonce, aad, total_aad_len, total_len, tag, local_sr
     """Decrypt this rank's shard of ONE GCM message: 0, or 0x1A with local_dst untouched on EVERY rank (N7 across
     ranks, micro_aes.c:1200-1208).  Phase 1: every rank's share over its shard of the received ciphertext and the
     16-byte exchange; every rank compares the XOR with `tag` (16 bytes); phase 2, only on a match: the CTR pass."""
-    if cipher is None or partial is None:
-        import torch
-        from . import ctr_xcrypt_dev, gcm_partial_dev
-
-        def cipher(k, c, off, s, d, n):
-            ctr_xcrypt_dev(k, c, off, s, d, nbytes=n)
-
-        def partial(k, no, a, ta, ct, n, start, total):
-            out = torch.zeros(16, dtype=torch.uint8, device=ct.device)
-            gcm_partial_dev(k, no, a, ta, ct, n, start, total, out)
-            return out
+    cipher = cipher or _dev_cipher                               # each defaults on its own: a supplied one is kept
+    partial = partial or _dev_partial
     start, n, takes_part = gcm_shard_roles(total_len, rank, world)
     share = partial(key, nonce, aad if rank == 0 else None, total_aad_len, local_src, n, start, total_len) \
         if takes_part else None

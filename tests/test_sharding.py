@@ -211,6 +211,55 @@ def test_sharded_gcm_decrypt_authenticates_before_any_rank_writes(orc, total, wo
         assert b"".join(outs) == (b"\xAB" * total if forged else data)
 
 
+def test_sharded_gcm_callables_default_independently(orc, monkeypatch):
+    """`cipher` and `partial` default one by one.  A caller that injects only ONE of them keeps it -- the
+    other becomes the engine's (here: stand-ins patched over sharding._dev_cipher / _dev_partial, no GPU) -- in both
+    directions; encryption used to crash on the missing one, decryption used to throw the supplied one away."""
+    key, nonce, aad, total, world = bytes(range(16)), bytes(range(12)), b"hdr", 1000, 2
+    data = orc.splitmix(3, total)
+    msg = orc.gcm_encrypt(key, nonce, aad, data)
+    calls = {"my_cipher": 0, "my_partial": 0, "dev_cipher": 0, "dev_partial": 0}
+
+    def make(name, fn):
+        def wrapped(*a):
+            calls[name] += 1
+            return fn(*a)
+        return wrapped
+
+    def cipher(k, c, off, s, d, n):
+        d[:n] = orc.ctr_xcrypt_at(k, c, off, bytes(s[:n]))
+
+    def partial(k, no, a, ta, ct, n, start, tot):
+        return _oracle_partial(orc, k, no, a, ta, bytes(ct[:n]), n, start, tot)
+
+    monkeypatch.setattr(sh, "_dev_cipher", make("dev_cipher", cipher))
+    monkeypatch.setattr(sh, "_dev_partial", make("dev_partial", partial))
+    for kw in ({"cipher": make("my_cipher", cipher)}, {"partial": make("my_partial", partial)}):
+        for k in calls:
+            calls[k] = 0
+        shares, pieces = [], []
+        for rank in range(world):
+            start, n, _ = sh.gcm_shard_roles(total, rank, world)
+            src, dst = bytearray(data[start:start + n]), bytearray(n)
+            tag = sh.gcm_encrypt_sharded(key, nonce, aad, len(aad), total, src, dst, rank, world,
+                                         gather=lambda share: shares.append(share) or list(shares), **kw)
+            pieces.append(bytes(dst))
+        assert b"".join(pieces) + tag == msg
+        mine, other = ("my_cipher", "dev_partial") if "cipher" in kw else ("my_partial", "dev_cipher")
+        assert calls[mine] == world and calls[other] == world and calls["dev_cipher" if "cipher" in kw else "dev_partial"] == 0, calls
+        for k in calls:
+            calls[k] = 0
+        outs = []
+        for rank in range(world):
+            start, n, _ = sh.gcm_shard_roles(total, rank, world)
+            src, dst = bytearray(msg[start:start + n]), bytearray(n)
+            assert sh.gcm_decrypt_sharded(key, nonce, aad, len(aad), total, msg[-16:], src, dst, rank, world,
+                                          gather=lambda share: list(shares), **kw) == 0
+            outs.append(bytes(dst))
+        assert b"".join(outs) == data
+        assert calls[mine] == world and calls[other] == world, calls
+
+
 @pytest.mark.parametrize("total,world", [(0, 2), (5, 3), (16, 2), (4096 + 7, 4), (100000, 8)])
 def test_sharded_ecb(orc, total, world):
     """ecb_shard_args / ecb_sharded: whole blocks per rank, the rank that holds the end of the text takes the ragged
