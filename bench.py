@@ -910,7 +910,7 @@ def main():
                     traffic_source = "recorded in %s (not measured in this run%s)" % (t["source"], ": " + why if why else "")
             except Exception:
                 pass
-        # What actually bounds table-driven AES on this chip (DESIGN section 4): the LDS serves 32 table lookups per
+        # What actually bounds table-driven AES on this chip (DESIGN.md section 6): the LDS serves 32 table lookups per
         # clock per CU.  Lookups per 16-byte block: 16 per round, minus the two rounds CTR shares between counters;
         # GCM adds 16 ds_read_b128 of GHASH per block = 32 lookup slots.  The ceiling is quoted at the clock measured
         # under this very load, so achieved / ceiling is the kernel's distance from its own bound.
@@ -923,7 +923,7 @@ def main():
             lds_ceiling = {"lookups_per_block": lookups, "lookups_per_clk_per_cu": 32, "cus": cus,
                            "sclk_mhz_under_load": round(sclk_mhz, 0), "ceiling_gbs": round(ceil_gbs, 1),
                            "frac_of_ceiling": round(achieved / ceil_gbs, 4)}
-        # Both pipes, in shader clocks per 16-byte block per CU (DESIGN section 4, round 4): the LDS serves 32 lookups per
+        # Both pipes, in shader clocks per 16-byte block per CU (DESIGN.md section 6, round 4): the LDS serves 32 lookups per
         # clock, and every VALU instruction of a stream that contains v_perm_b32 costs 4.43 SIMD-cycles
         # (profiles/r04_issuebench.log); VALU instructions per block = SQ_INSTS_VALU x 64 / blocks, from the PMC pass of
         # THIS run (or, where no pass could run, the recorded figure, labelled).  The two do not overlap freely (they

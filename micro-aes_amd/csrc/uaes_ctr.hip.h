@@ -178,7 +178,7 @@ __device__ __forceinline__ void ctr_shared_loop(const uaesk_rk &rk, const uaesk_
     /* One iteration = two blocks per lane.  The body is written once and expanded twice per trip with the two text
      * buffers swapped, so that "next becomes current" is a renaming, not eight register moves; the text addresses are a
      * wave-uniform 64-bit base (SGPRs, advanced by scalar instructions) plus the lane's constant 32-bit offset, so no
-     * 64-bit vector adds either: the VALU is the second-busiest unit of this kernel (DESIGN section 4).          */
+     * 64-bit vector adds either: the VALU is the second-busiest unit of this kernel (DESIGN.md section 6).          */
     const u32 lane_byte = lane_blk * 16u;
     /* the text of a stripe through a buffer resource whose base is the stripe (four SGPRs, rebuilt by scalar
      * instructions every iteration) + the lane's constant byte offset + 16 KiB for the second block of the lane */

@@ -411,7 +411,7 @@ __device__ __forceinline__ void xts_body(const uaesk_rk &k1, const uaesk_tables 
     /* launched with 16 waves per workgroup, or 4 for short texts (more CUs, see launch_xts).  The wave's number is made
      * a SCALAR explicitly: everything that positions a chunk (unit, chunk in the unit, byte offset, block count) then
      * lives in SGPRs and is stepped by scalar instructions -- as vector arithmetic it was ~20 VALU instructions per
-     * chunk in a kernel whose VALU is as busy as its LDS (DESIGN section 4).                                        */
+     * chunk in a kernel whose VALU is as busy as its LDS (DESIGN.md section 6).                                        */
     const u64 wave = (u64)blockIdx.x * (blockDim.x >> 6) + (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const u64 nwaves = (u64)gridDim.x * (blockDim.x >> 6);
     const u64 nchunks = nmain;                         /* the main loop's share; the rest follows behind it */
@@ -1111,7 +1111,7 @@ static uaes_plan plan_xts(size_t sector_bytes, size_t nsectors, bool explicit_tw
     const bool few_units = nsectors > 1 && !explicit_tweak && r == 0 && mb > 0 &&
                            (u64)nsectors * ((mb + 63) / 64) <= 4ull * XTS_SMALL_CHUNKS;
     if ((one_unit || few_units) && uaesk_arr_on(UAES_ARR_XTS_SMALL)) {
-        p.arrangement = UAES_ARR_XTS_SMALL; p.launches = r ? 2 : 1; p.steps = few_units ? 1u : 0u;
+        p.arrangement = UAES_ARR_XTS_SMALL; p.launches = r ? 2 : 1;
         p.grid = grid_for((u64)nsectors * ((mb + 63) / 64), UAES_WG / 64);
         return p;
     }
@@ -1140,7 +1140,7 @@ static int launch_xts(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *k1
     uint4 raw = make_uint4(0, 0, 0, 0);
     if (tweak16) memcpy(&raw, tweak16, 16);
     const uaes_plan pl = plan_xts(sector_bytes, nsectors, tweak16 != nullptr);
-    const bool few_units = pl.arrangement == UAES_ARR_XTS_SMALL && pl.steps == 1u;
+    const bool few_units = pl.arrangement == UAES_ARR_XTS_SMALL && nsectors > 1;     /* (one unit, or several whole-block ones) */
     if (pl.arrangement == UAES_ARR_XTS_SMALL) {
         e = few_units ? set_lds((k_xts_small<NR, DEC, true>), XTS_SMALL_LDS) : set_lds((k_xts_small<NR, DEC, false>), XTS_SMALL_LDS);
         if (e != hipSuccess) return (int)e;
@@ -1310,7 +1310,7 @@ extern "C" int uaesk_ticket(void *stream, void *pinned_flag, unsigned seq, const
 /* ------------------------------------------------------------------------ */
 /* One wave spins for `ticks` periods of the 100 MHz reference counter (s_memrealtime) and reports how many shader
  * cycles (s_memtime) went by: the clock the chip actually runs at while other streams keep it busy.  bench.py
- * launches it on a second stream beside the measured workload (DESIGN section 4: under the 1.4 kW cap a cipher
+ * launches it on a second stream beside the measured workload (DESIGN.md section 6: under the 1.4 kW cap a cipher
  * kernel settles near 2.1 GHz, not at the 2.4 GHz the device properties quote).                              */
 __global__ __launch_bounds__(64) void k_clock_probe(unsigned long long *out, unsigned long long ticks)
 {

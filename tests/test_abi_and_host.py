@@ -235,7 +235,7 @@ def test_bulk_kernels_have_no_private_segment_and_only_gfx950_code():
 
 
 def test_ctr_hot_loop_instruction_budget():
-    """DESIGN section 4 prices AES-128-CTR in instructions per block: 128 table lookups and about 210 VALU operations.
+    """DESIGN.md section 6 prices AES-128-CTR in instructions per block: 128 table lookups and about 210 VALU operations.
     Re-derived here from the SHIPPED code object (llvm-objdump of libuaes_hip.so, tools/kernel_resources.py --disasm),
     so that a compiler upgrade or an innocent edit cannot add instructions to the loop unnoticed.  One trip of the hot
     loop of k_ctr_shared2<10> = the body twice = 4 blocks per lane: 2 x 2 x 8 rounds x 16 lookups and nothing else --

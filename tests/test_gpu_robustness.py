@@ -129,7 +129,7 @@ def test_record_calls_from_several_threads_share_one_key_context(orc):
 
 
 def test_completion_tickets_and_the_plain_wait_agree(orc):
-    """a synchronous call ends with a completion ticket (DESIGN section 6): carried by the call's only kernel (ECB,
+    """a synchronous call ends with a completion ticket (DESIGN.md section 7): carried by the call's only kernel (ECB,
     short CTR, a one-launch XTS unit, a one-launch GCM encryption), by the ticket kernel behind a multi-launch call,
     or -- a call that runs longer than the spin window -- by hipStreamSynchronize after all.  All three, and the
     build with UAES_TICKET=0, must hand over the same bytes; many short calls from many threads exercise the

@@ -11,14 +11,16 @@ run() { name=$1; shift; timeout 900 "$@" > $OUT/$name 2> $OUT/$name.err || echo 
 run bench_ctr.json   python bench.py
 run bench_ecb.json   python bench.py --workload ecb --no-traffic
 run bench_xts.json   python bench.py --workload xts --no-traffic
-run bench_xts_c3.json python bench.py --workload xts --bytes 4294967296 --no-cpu --no-traffic
+run bench_xts_c3.json python bench.py --workload xts --bytes 4294967296 --no-cpu
 run bench_gcm.json   python bench.py --workload gcm
 run bench_ocb.json   python bench.py --workload ocb --no-traffic
 run bench_cbc_enc.json python bench.py --workload cbc-enc --bytes 4194304 --steps 3 --warmup 1 --settle-ms 0 --sustain-s 0 --no-traffic --no-clock-probe
 run bench_cmac.json  python bench.py --workload cmac --bytes 4194304 --steps 3 --warmup 1 --settle-ms 0 --sustain-s 0 --no-traffic --no-clock-probe
 run call_latency.log python tools/call_latency.py
-run serial_rate.log  python tools/serial_rate.py
-run keysize_rates.log python tools/keysize_rates.py
+run all_modes_rate.log python tools/all_modes_rate.py
+run gcm_size_sweep.log python tools/gcm_size_sweep.py
+run plan_table.txt   python tools/plan_table.py
+run bench_one_rank_force_collective.json python bench.py --gpus 1 --force-collective --no-other-configs
 bash tools/profile.sh ${TAG}_ctr > $OUT/profile_ctr.txt 2>&1
 bash tools/profile.sh ${TAG}_gcm --workload gcm > $OUT/profile_gcm.txt 2>&1
 bash tools/profile.sh ${TAG}_xts --workload xts > $OUT/profile_xts.txt 2>&1

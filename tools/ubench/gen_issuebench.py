@@ -18,7 +18,7 @@ Groups:
      -- v_perm_b32 (SGPR / VGPR selector), v_and_or_b32, v_bfe_u32 + v_lshl_or_b32, SDWA, v_alignbyte, v_lshrrev + and-or --
      to be run with `--sustain S`: every row is launched back to back for S seconds on all 256 CUs so that the power
      manager settles, and the row reports the SETTLED clock and instructions (block-rounds) per second at that clock.
-     At the 1.4 kW cap throughput is energy per block, not cycles per block (DESIGN section 4).
+     At the 1.4 kW cap throughput is energy per block, not cycles per block (DESIGN.md section 6).
 
     python tools/ubench/gen_issuebench.py && hipcc --offload-arch=gfx950 -O2 -o tools/ubench/issuebench tools/ubench/issuebench.hip
     gpurun -- 'tools/ubench/issuebench [name filter]'          # neither the .hip nor the binary is tracked
