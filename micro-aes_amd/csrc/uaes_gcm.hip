@@ -32,281 +32,7 @@
 #include <atomic>
 #include <string.h>
 #include <stdlib.h>
-#include "uaes_aes.hip.h"
-#include "uaes_ctr.hip.h"
-#include "uaes_gf.h"
-#include "uaes_device.h"
-#include "uaes_plan.h"
-
-#define GH_T        1024u           /* threads of the last-levels workgroup   */
-#define GH_PT       1024u           /* threads per bulk-level workgroup       */
-#define GH_MAXLOG   18u             /* largest bulk stride 2^18 (256 x 1024)  */
-#define GH_LOGB     14u             /* second-level stride 2^14 (16 x 1024)   */
-#define GH_DIRECT   32768u          /* <= this many blocks: last kernel alone */
-
-/* scratch layout (bytes) */
-#define GS_H        0u
-#define GS_EJ0      16u
-#define GS_POW      64u                         /* 18 x 16                    */
-#define GS_TAB4     1024u                       /* six 8 KiB nibble tables: H^1024, H^256, H^64, H^16, H^4, H */
-#define GT_NTAB     6u
-#define GS_TAB8_A   (GS_TAB4 + GT_NTAB * 8192u) /* H^(2^logA), 64 KiB         */
-#define GS_TAB8_B   (GS_TAB8_A + 65536u)        /* H^(2^14), 64 KiB           */
-#define GS_ACC1     (GS_TAB8_B + 65536u)        /* 2^17 x 16 = 2 MiB          */
-#define GS_ACC2     (GS_ACC1 + (16u << GH_MAXLOG))
-#define GS_POW64    (GS_ACC2 + (16u << GH_LOGB))   /* H^(2^k), k = 0..63 (sharded GCM) */
-#define GS_PART     (GS_POW64 + 1024u)              /* raw GHASH of a shard             */
-#define GS_RUN      (GS_PART + 16u)                 /* running GHASH of a streamed message */
-#define GS_SMALL    (GS_PART + 64u)                 /* everything the streamed / sharded paths need */
-#define GF_MAXLOG   20u                             /* fused encrypt: lanes of the whole grid, 2048 per workgroup */
-#define GS_TAB8_F   GS_SMALL                        /* H^(2048 * workgroups), 64 KiB (fused encrypt) */
-#define GS_YLO      (GS_TAB8_F + 65536u)            /* Y^0..Y^15, Y = H^2048 (workgroup weights)     */
-#define GS_ZHI      (GS_YLO + 256u)                 /* Z^0..Z^15, Z = Y^16                           */
-#define GS_T        (GS_ZHI + 256u)                 /* XOR of the workgroups' weighted partial hashes */
-#define GS_YTAB     (GS_T + 64u)                    /* key contexts: the combine kernel's nibble tables of Y^256 .. Y, 40 KiB
-                                                       each for Y = H^1024, H^2048 .. H^131072 (k_gcm_ytables)                */
-#define GS_YTAB_SET (5u * 8192u)
-#define GS_YTAB_SETS 8u                         /* Y = H^1024 .. H^131072 (GMC_MAXLOGSTEPS + 1) */
-#define GS_SIV      (GS_YTAB + GS_YTAB_SETS * GS_YTAB_SET)   /* a long GCM-SIV message's per-nonce values, made and used on the device: */
-#define GS_SIV_RK   GS_SIV                          /*   the message-encryption key's schedule (uaesk_rk, 240 B) */
-#define GS_SIV_HG   (GS_SIV + 256u)                 /*   the POLYVAL key in GHASH form                           */
-#define GS_SIV_PV   (GS_SIV + 272u)                 /*   the raw hash                                            */
-#define GS_SIV_CTR  (GS_SIV + 288u)                 /*   the keystream's counter description (uaesk_ctr)         */
-#define GS_TOTAL    (GS_SIV + 512u)
-
-static inline hipStream_t S(void *s) { return (hipStream_t)s; }
-
-/* the sequence of GHASH input blocks: AAD blocks, CT blocks, length block */
-struct GSrc {
-    const unsigned char *aad;
-    u64 aad_len;
-    const unsigned char *ct;      /* 16-byte aligned */
-    u64 ct_len;
-    u32 has_len;
-    u64 len_aad, len_ct;          /* byte lengths written into the length block (totals of the
-                                     whole message when this is one shard of it) */
-    u32 rev;                      /* POLYVAL: every input block byte-reversed, LE length block */
-};
-
-__device__ __forceinline__ uint4 load_bytes_padded(const unsigned char *p, u64 avail)
-{
-    u32 w[4] = { 0, 0, 0, 0 };
-    const u32 n = avail < 16 ? (u32)avail : 16u;
-    for (u32 i = 0; i < n; ++i) w[i >> 2] |= (u32)p[i] << (8 * (i & 3));
-    return make_uint4(w[0], w[1], w[2], w[3]);
-}
-
-__device__ __forceinline__ uint4 rev16(uint4 b)
-{
-    return make_uint4(bswap32(b.w), bswap32(b.z), bswap32(b.y), bswap32(b.x));
-}
-
-__device__ __forceinline__ uint4 load_vblock_fwd(const GSrc &s, u64 v)
-{
-    const u64 ab = (s.aad_len + 15) >> 4, cb = (s.ct_len + 15) >> 4;
-    if (v < ab) {                                   /* whole blocks of 16-byte aligned AAD: one load (GMAC of a bulk text) */
-        if ((v + 1) * 16 <= s.aad_len && (((uintptr_t)s.aad) & 15u) == 0) return ((const uint4 *)s.aad)[v];
-        return load_bytes_padded(s.aad + v * 16, s.aad_len - v * 16);
-    }
-    v -= ab;
-    if (v < cb) {
-        if ((v + 1) * 16 <= s.ct_len) return ((const uint4 *)s.ct)[v];
-        return load_bytes_padded(s.ct + v * 16, s.ct_len - v * 16);
-    }
-    const u64 abits = s.len_aad * 8, cbits = s.len_ct * 8;      /* N6 */
-    if (s.rev)                                                  /* POLYVAL: two little-endian 64-bit lengths */
-        return make_uint4((u32)abits, (u32)(abits >> 32), (u32)cbits, (u32)(cbits >> 32));
-    return make_uint4(bswap32((u32)(abits >> 32)), bswap32((u32)abits),
-                      bswap32((u32)(cbits >> 32)), bswap32((u32)cbits));
-}
-
-__device__ __forceinline__ uint4 load_vblock(const GSrc &s, u64 v)
-{
-    const uint4 b = load_vblock_fwd(s, v);
-    return s.rev ? rev16(b) : b;
-}
-
-__device__ __forceinline__ uint4 x4(uint4 a, uint4 b)
-{
-    return make_uint4(a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w);
-}
-
-/* a * M through the byte-indexed table of M held in LDS, bank-conflict free.
- *
- * Layout: row v (256 B) holds the sixteen 16-byte entries Tab_j[v], j = slot.
- * ds_read_b128 is serviced in four 16-lane groups and a 16-byte slot is
- * (addr/16) mod 16 (MI355X_MICROARCH.md, LDS), so a data-dependent row is free
- * but two lanes of a group must not share a SLOT.  Lane l therefore walks the
- * 16 bytes of its block in its own order -- byte g ^ t at step t, where g =
- * position of the lane inside its service group -- so at every step the 16
- * lanes of a group read 16 different tables = 16 different slots.  (A naive
- * [j][v] layout puts the slot at v mod 16: random, ~2.9x serialisation.)
- *
- * Why g ^ t and not (g + t) mod 16 (rounds 2-4): XOR has no carries.  The WORD a lane needs at step t is word
- * (g >> 2) ^ (t >> 2) -- the accumulator's words permuted once per product by two levels of v_cndmask -- and the BYTE
- * inside it is (g & 3) ^ (t & 3), which the lane's own v_perm selector (a VGPR, one per t & 3) picks: 8 VALU per
- * product where rotating the block by g bytes took 12 (8 selects + 4 v_alignbyte).  1 GiB GCM 1262 -> 1268 GiB/s
- * (profiles/r05_gcm_rotate_ab.log, which also says why the other 8 cannot go).                                    */
-struct GhLane {
-    u32 so[4];          /* byte m of so[q] = slot offset (g ^ (4q + m)) << 4 */
-    u32 sel[4];         /* v_perm selector of the steps with t & 3 = m: byte 1 <- data byte (g & 3) ^ m, byte 0 <- so byte m */
-    u32 g;
-};
-
-/* position of lane (l & 31) inside its ds_read_b128 service group:
- * groups {0-3,12-15,20-27} and {4-11,16-19,28-31} (and the same +32)      */
-__device__ __forceinline__ u32 b128_group_pos(u32 tid = threadIdx.x)
-{
-    const u32 l = tid & 31u;
-    const u64 pack_lo = 0x7654765432103210ull;     /* lanes 0..15  */
-    const u64 pack_hi = 0xfedcfedcba98ba98ull;     /* lanes 16..31 */
-    return (u32)(((l & 16u) ? pack_hi : pack_lo) >> (4 * (l & 15u))) & 15u;
-}
-
-__device__ __forceinline__ GhLane gh_lane_setup()
-{
-    GhLane gl;
-    gl.g = b128_group_pos();
-#pragma unroll
-    for (u32 q = 0; q < 4; ++q) {
-        u32 v = 0;
-#pragma unroll
-        for (u32 m = 0; m < 4; ++m) v |= ((gl.g ^ (4 * q + m)) << 4) << (8 * m);
-        gl.so[q] = v;
-    }
-#pragma unroll
-    for (u32 m = 0; m < 4; ++m) gl.sel[m] = 0x0c0c0000u | ((4u + ((gl.g & 3u) ^ m)) << 8) | m;
-    return gl;
-}
-
-/* r[q] = word q ^ (g >> 2) of a */
-__device__ __forceinline__ void gh_words(const uint4 a, u32 g, u32 (&r)[4])
-{
-    const bool w1 = (g & 4u) != 0, w2 = (g & 8u) != 0;
-    const u32 t0 = w1 ? a.y : a.x, t1 = w1 ? a.x : a.y, t2 = w1 ? a.w : a.z, t3 = w1 ? a.z : a.w;
-    r[0] = w2 ? t2 : t0; r[1] = w2 ? t3 : t1; r[2] = w2 ? t0 : t2; r[3] = w2 ? t1 : t3;
-}
-
-/* bytes of a rotated left by g: result byte k = a byte (k + g) mod 16 (the nibble-table products below) */
-__device__ __forceinline__ void gh_rotate(const uint4 a, u32 g, u32 (&r)[4])
-{
-    const bool w1 = (g & 4u) != 0, w2 = (g & 8u) != 0;
-    const u32 t0 = w1 ? a.y : a.x, t1 = w1 ? a.z : a.y, t2 = w1 ? a.w : a.z, t3 = w1 ? a.x : a.w;
-    const u32 u0 = w2 ? t2 : t0, u1 = w2 ? t3 : t1, u2 = w2 ? t0 : t2, u3 = w2 ? t1 : t3;
-    const u32 sh = g & 3u;
-    r[0] = __builtin_amdgcn_alignbyte(u1, u0, sh);
-    r[1] = __builtin_amdgcn_alignbyte(u2, u1, sh);
-    r[2] = __builtin_amdgcn_alignbyte(u3, u2, sh);
-    r[3] = __builtin_amdgcn_alignbyte(u0, u3, sh);
-}
-
-typedef u32 u32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) const u32x4 lds_cu128;
-
-/* (a * M) ^ x; the table occupies LDS bytes [0, 65536) */
-__device__ __forceinline__ uint4 tabmul8_xor(uint4 a, uint4 x, const GhLane &gl)
-{
-    u32 r[4];
-    gh_words(a, gl.g, r);
-    u32x4 e[16];
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        /* address = (byte g ^ t of the block) << 8 | slot offset of step t */
-        const u32 addr = __builtin_amdgcn_perm(r[t >> 2], gl.so[t >> 2], gl.sel[t & 3]);
-        e[t] = *(lds_cu128 *)(uintptr_t)addr;
-    }
-    /* 17 inputs per dword -> 8 three-input XORs */
-    u32 z[4] = { x.x, x.y, x.z, x.w };
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-#pragma unroll
-        for (int t = 0; t < 16; t += 2) z[w] = xor3(z[w], e[t][w], e[t + 1][w]);
-    }
-    return make_uint4(z[0], z[1], z[2], z[3]);
-}
-
-/* ---- nibble-indexed tables: a * M = the XOR of 32 entries, one per nibble of a --------------------------------
- * Layout of one table (512 entries of 16 B = 8 KiB, anywhere in LDS): ROW v (512 B) holds the entries of nibble
- * VALUE v for the 32 nibble positions -- entry index nib_entry(p, v) = 32 v + slot(p), slot = j for the high
- * nibble of byte j (p = 2j), 16 + j for its low nibble (p = 2j + 1).  As with the byte tables above, the 16-byte
- * slot of an LDS address is (addr / 16) mod 16 and a ds_read_b128 serves 16 lanes at a time: the data-dependent
- * part of the address (the row) is free, the lanes of a service group only must not share a slot, so every lane
- * walks the bytes of its block in an order rotated by its position in the group and the sixteen lanes read
- * sixteen different positions at every step.  (Round 2's [position][value] layout put the VALUE into the slot:
- * random, ~2.9x serialisation of every multiplication.)                                                      */
-__device__ __forceinline__ u32 nib_entry(u32 p, u32 v)
-{
-    return v * 32u + (p >> 1) + ((p & 1u) << 4);
-}
-
-/* a * M, every lane its own product */
-/* (tid: a kernel that loops hands in an opaque copy of threadIdx.x, or the sixteen per-step slot constants are
- * hoisted out of its loop and spilled) */
-template <int PARTS = 2>                                       /* 4: eight lookups in flight (32 registers) -- inside a loop
-                                                                * that keeps a cipher's state and keys alive around it */
-__device__ __forceinline__ uint4 tabmul4(const uint4 *T, uint4 a, u32 tid = threadIdx.x)
-{
-    const u32 g = b128_group_pos(tid);
-    u32 r[4];
-    gh_rotate(a, g, r);                                        /* byte k of r = byte (k + g) mod 16 of a */
-    const u32 base = (u32)(uintptr_t)(__attribute__((address_space(3))) const uint4 *)T;
-    /* two halves of sixteen lookups, the second not started before the first is folded: 64 instead of 128 registers
-     * of entries in flight (a caller with live state around the product would spill it otherwise) */
-    u32 z[4] = { 0, 0, 0, 0 };
-    constexpr int NQ = 16 / PARTS;                             /* bytes per part */
-#pragma unroll
-    for (int h = 0; h < PARTS; ++h) {
-        u32x4 e[2 * NQ];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int k = NQ * h + q;
-            const u32 c = base + (((g + (u32)k) & 15u) << 4);  /* slot of byte (k + g) mod 16 */
-            e[2 * q] = *(lds_cu128 *)(uintptr_t)(c + (__builtin_amdgcn_ubfe(r[k >> 2], 8u * (k & 3) + 4u, 4u) << 9));
-            e[2 * q + 1] = *(lds_cu128 *)(uintptr_t)(c + 256u + (__builtin_amdgcn_ubfe(r[k >> 2], 8u * (k & 3), 4u) << 9));
-        }
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            u32 t = xor3(z[d], e[0][d], e[1][d]);
-#pragma unroll
-            for (int k = 2; k < 2 * NQ; k += 2) t = xor3(t, e[k][d], e[k + 1][d]);
-            z[d] = t;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    return make_uint4(z[0], z[1], z[2], z[3]);
-}
-
-/* The same product shared by the four lanes of a quad: in a dependent chain (the last levels)
- * what counts is the latency of one multiplication, and one lane alone issues 32 lookups, their
- * addresses and a 31-term XOR per dword.  Lane c of the quad takes word c of `a` (8 nibbles),
- * the quad XORs its four partial products with two DPP exchanges per dword; every lane returns
- * the full product.  `a` must be the same in the four lanes.  A service group is four whole quads:
- * quad number qd of the group starts its four bytes at byte qd, so that at every step the sixteen lanes
- * are at sixteen different bytes.                                                              */
-__device__ __forceinline__ uint4 tabmul4q(const uint4 *T, uint4 a, u32 tid = threadIdx.x)
-{
-    const u32 c = tid & 3u, qd = b128_group_pos(tid) >> 2;
-    const u32 w = c == 0 ? a.x : c == 1 ? a.y : c == 2 ? a.z : a.w;
-    const u32 wr = __builtin_amdgcn_alignbit(w, w, 8u * qd);                /* byte s of wr = byte (s + qd) mod 4 of w */
-    const u32 base = (u32)(uintptr_t)(__attribute__((address_space(3))) const uint4 *)T + c * 64u;   /* byte j = 4c + kk */
-    u32x4 e[8];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const u32 ca = base + ((((u32)s + qd) & 3u) << 4);
-        e[2 * s] = *(lds_cu128 *)(uintptr_t)(ca + (__builtin_amdgcn_ubfe(wr, 8u * s + 4u, 4u) << 9));
-        e[2 * s + 1] = *(lds_cu128 *)(uintptr_t)(ca + 256u + (__builtin_amdgcn_ubfe(wr, 8u * s, 4u) << 9));
-    }
-    u32 z[4];
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        u32 t = xor3(xor3(e[0][d], e[1][d], e[2][d]), e[3][d], e[4][d]);
-        t = xor3(t, e[5][d], e[6][d]) ^ e[7][d];
-        t ^= (u32)__builtin_amdgcn_mov_dpp((int)t, 0xB1, 0xf, 0xf, true);      /* quad_perm [1,0,3,2] */
-        t ^= (u32)__builtin_amdgcn_mov_dpp((int)t, 0x4E, 0xf, 0xf, true);      /* quad_perm [2,3,0,1] */
-        z[d] = t;
-    }
-    return make_uint4(z[0], z[1], z[2], z[3]);
-}
+#include "uaes_ghash.hip.h"
 
 /* ------------------------------------------------------------------------ */
 /* bulk level: stride S = gridDim.x * 256                                     */
@@ -346,53 +72,6 @@ __global__ __launch_bounds__(GH_PT) void k_ghash_pass(GSrc src, u64 nv, const ui
     accs[j] = acc;
 }
 
-/* The last levels, shared by k_ghash_final, k_gcm_small and the fused kernel's epilogue: 1024
- * accumulators (one per thread; the last `live` of them are not padding) -> 256 -> 64 -> 16 -> 4 -> 1,
- * radix 4: level l folds rows k = 0..3 of its input (row k = entries [k m, (k+1) m)) with the nibble
- * table of H^m,  out_j = ((in_j H^m ^ in_{m+j}) H^m ^ in_{2m+j}) H^m ^ in_{3m+j}.  These are DEPENDENT
- * multiplications of one wave each (~270 ns: ~80 dependent VALU instructions), so their number is what
- * a short call pays: 3+3+3+3+4 = 16 here against 15+15+4 = 34 with the radix-16 levels of round 1
- * (k_ghash_final 12 -> 7 us).  A quad of lanes shares each product (tabmul4q).  Leading rows that hold
- * only padding are skipped.  GHASH_LAST: the last level multiplies AFTER adding (every block of a GHASH
- * carries at least one factor H); otherwise the result is sum in_q H^(1023-q) (a workgroup's share).
- * T: the six nibble tables (T[0..512) = H^1024 is not used here).  buf: GT_BUF entries.  The result is
- * valid in thread 0.                                                                              */
-#define GT_BUF  (1024u + 256u + 64u + 16u + 4u + 4u)
-
-template <bool GHASH_LAST>
-__device__ __forceinline__ uint4 gh_tree(uint4 *buf, const uint4 *T, uint4 acc, u32 live)
-{
-    buf[threadIdx.x] = acc;
-    __syncthreads();
-    const u32 qi = threadIdx.x >> 2;                           /* accumulator this quad works on */
-    u32 n = 1024u, off = 0;
-#pragma unroll
-    for (u32 lvl = 1; lvl <= 4; ++lvl) {                       /* tables H^256, H^64, H^16, H^4 */
-        const u32 m = n >> 2;
-        const uint4 *Tl = T + 512u * lvl;
-        if (threadIdx.x < n) {
-            const u32 k0 = 4u - (live + m - 1u) / m;           /* first row with a live entry */
-            acc = buf[off + k0 * m + qi];
-            for (u32 k = k0 + 1; k < 4; ++k) acc = x4(tabmul4q(Tl, acc), buf[off + k * m + qi]);
-            if ((threadIdx.x & 3u) == 0) buf[off + n + qi] = acc;
-        }
-        __syncthreads();
-        off += n;
-        n = m;
-        live = live < m ? live : m;
-    }
-    if (threadIdx.x < 4) {
-        const uint4 *TF = T + 512u * 5u;
-        if (GHASH_LAST) {
-            acc = make_uint4(0, 0, 0, 0);
-            for (u32 k = 4u - live; k < 4; ++k) acc = tabmul4q(TF, x4(acc, buf[off + k]));
-        } else {
-            acc = buf[off + 4u - live];
-            for (u32 k = 5u - live; k < 4; ++k) acc = x4(tabmul4q(TF, acc), buf[off + k]);
-        }
-    }
-    return acc;
-}
 
 /* ------------------------------------------------------------------------ */
 /* last levels (strides 256, 16, 1) + tag handling; one workgroup             */
@@ -401,7 +80,6 @@ __device__ __forceinline__ uint4 gh_tree(uint4 *buf, const uint4 *T, uint4 acc, 
  * mode 1: compare with the 16 bytes at tag_io, *status = 0 / 0x1A (decrypt)
  * mode 2: write the raw GHASH value to tag_io (tests)
  * Levels inside the workgroup: stride 1024, then the radix-4 tree (gh_tree).    */
-#define GHF_LDS ((GT_NTAB * 512u + GT_BUF) * 16u)
 
 /* TC: the six nibble tables in LDS, buf: GT_BUF entries behind them, ej0 = Enc(J0) */
 __device__ __forceinline__ void ghash_final_body(const GSrc &src, u64 nv, uint4 *TC, uint4 *buf, uint4 ej0,
@@ -450,24 +128,6 @@ __global__ __launch_bounds__(GH_T) void k_ghash_final(GSrc src, u64 nv, const un
 /* ------------------------------------------------------------------------ */
 /* setup: H, Enc(J0), powers H^(2^k), multiplication tables                   */
 /* ------------------------------------------------------------------------ */
-__device__ __forceinline__ u64 shfl_xor64(u64 v, int off)
-{
-    const u32 lo = __shfl_xor((u32)v, off, 64), hi = __shfl_xor((u32)(v >> 32), off, 64);
-    return ((u64)hi << 32) | lo;
-}
-
-/* x*y computed by one whole wave; every lane returns the product */
-__device__ __forceinline__ Gf wave_gfmul(Gf x, Gf y, u32 lane)
-{
-    Gf z = gf_mul_slice(x, y, gf_mul_x64(y), lane);
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        z.hi ^= shfl_xor64(z.hi, off);
-        z.lo ^= shfl_xor64(z.lo, off);
-    }
-    return z;
-}
-
 #define SETUP_LDS   (UAES_LDS_ENC + 24576u)
 
 /* logA: log2 of the bulk stride (12..17), 0 = no bulk level.  needB: build the
@@ -479,8 +139,6 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_setup(uaesk_rk ek, uaesk_tables
                                                        u32 logA, u32 needB, u32 h_given, uint4 hval, u32 want_pow64,
                                                        u32 logF, u32 maxlog)
 {
-#define ST_STAMP(i) do { } while (0)
-    ST_STAMP(0);
     /* A long one-shot call (logF) is launched on TWO workgroups that both make H and its powers and then split the
      * rest: workgroup 0 the tables, workgroup 1 the fused kernel's weights (latency-bound dependent products that
      * would otherwise wait behind the table stores: 10.7 -> ~7.5 us).  Every output has exactly one writer.      */
@@ -512,7 +170,6 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_setup(uaesk_rk ek, uaesk_tables
     }
     __syncthreads();
 
-    ST_STAMP(1);
     /* the highest power any requested table needs; the workgroup weights take Y^(2^i), Z^(2^i), i < 4 = H^(2^(11..18)) */
     const u32 last = want_pow64 ? 63u : (logF && maxlog < 18u ? 18u : maxlog);
     if (tb.frob) {
@@ -560,7 +217,6 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_setup(uaesk_rk ek, uaesk_tables
     }
     __syncthreads();
 
-    ST_STAMP(2);
     if (tables_wg) {
     /* generators M*x^q of the tables: A (2^logA), B (2^14), the six nibble tables (2^10, 2^8, 2^6, 2^4, 2^2,
      * 2^0), fused (2^logF)                                                                              */
@@ -571,7 +227,6 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_setup(uaesk_rk ek, uaesk_tables
     }
     __syncthreads();
 
-    ST_STAMP(3);
     /* byte-indexed tables: entry (j, v) = sum_i bit(v, 7-i) * gen[8j+i] */
     for (u32 t = 0; t < 3; ++t) {
         if ((t == 0 && !logA) || (t == 1 && !needB) || (t == 2 && !logF)) continue;
@@ -599,7 +254,6 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_setup(uaesk_rk ek, uaesk_tables
             dst[v * 16 + j] = make_uint4(w[0], w[1], w[2], w[3]);      /* row v, slot j */
         }
     }
-    ST_STAMP(4);
     /* nibble-indexed tables: entry (p, v) = sum_i bit(v, 3-i) * gen[4p+i] */
     if (threadIdx.x < 512) {
         const u32 p = threadIdx.x >> 4, v = threadIdx.x & 15u;
@@ -619,7 +273,6 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_setup(uaesk_rk ek, uaesk_tables
         }
     }
     }                                          /* tables_wg */
-    ST_STAMP(5);
     if (logF && weights_wg) {
         /* weights of the fused kernel's workgroups: Y^k and Z^k = Y^(16k), k < 16 (Y = H^2048).  The squarings
          * Y^(2^i) = H^(2^(11+i)), Z^(2^i) = H^(2^(15+i)) are among the powers made above, so every other exponent
@@ -659,13 +312,11 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_setup(uaesk_rk ek, uaesk_tables
         }
         if (threadIdx.x == 32) *(uint4 *)(scratch + GS_T) = make_uint4(0, 0, 0, 0);
     }
-    ST_STAMP(6);
     if (tables_wg && threadIdx.x <= (want_pow64 ? GH_MAXLOG : (maxlog < GH_MAXLOG ? maxlog : GH_MAXLOG))) {
         u32 w[4];
         gf_to_words(shPow[threadIdx.x], w);
         ((uint4 *)(scratch + GS_POW))[threadIdx.x] = make_uint4(w[0], w[1], w[2], w[3]);
     }
-#undef ST_STAMP
 }
 
 /* ------------------------------------------------------------------------ */
@@ -746,9 +397,7 @@ struct GhFold {
     }
 };
 
-__device__ __forceinline__ Gf gf_from4(uint4 v) { return gf_from_words(v.x, v.y, v.z, v.w); }
 
-#define GF_STAMP(i) do { } while (0)
 
 template <int NR, bool DEC>
 __global__ __launch_bounds__(UAES_WG) void k_gcm_fused(uaesk_rk rk, uaesk_tables tb, uaesk_ctr ctr,
@@ -757,19 +406,16 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_fused(uaesk_rk rk, uaesk_tables
                                                            GSrc front, u64 nfront,
                                                            unsigned char *__restrict__ scratch)
 {
-    GF_STAMP(0);
     uint4 *T = (uint4 *)uaes_lds;                  /* LDS address 0 (absolute addressing in tabmul8_xor) */
     const uint4 *tab8 = (const uint4 *)(scratch + GS_TAB8_F);
     for (u32 i = threadIdx.x; i < 4096u; i += UAES_WG) T[i] = tab8[i];
     fill_tables64(tb.te0, GF_LDS_AES);             /* ends with a barrier */
-    GF_STAMP(1);
     const LaneConst2 lc = make_lane_const2(GF_LDS_AES);
     GhFold<DEC> fold;
     fold.gl = gh_lane_setup();
 
     /* tail blocks [h1, nfull) and the ragged bytes */
     ctr_edge_blocks<NR>(rk, ctr, in, out, 0, h1, nfull, rem, lc);
-    GF_STAMP(2);
 
     const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const u32 p = ((wave & 3u) << 6) | lane, quad = wave >> 2;
@@ -790,12 +436,10 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_fused(uaesk_rk rk, uaesk_tables
             }
         }
     }
-    GF_STAMP(3);
     CtrGeo geo;
     geo.first = g_lo;
     geo.iters = stripes / gridDim.x + (blockIdx.x < stripes % gridDim.x ? 1 : 0);
     ctr_shared_loop<NR>(rk, ctr, in, out, geo, GF_LDS_BUF, lc, fold);
-    GF_STAMP(4);
 
     /* ---- the workgroup's 2048 accumulators -> R_b -> weighted share into T ---- */
     /* the six nibble tables go over the AES tables: requested BEFORE the barrier (the loads touch no LDS), stored
@@ -810,12 +454,10 @@ __global__ __launch_bounds__(UAES_WG) void k_gcm_fused(uaesk_rk rk, uaesk_tables
         TC[threadIdx.x] = e0; TC[threadIdx.x + UAES_WG] = e1; TC[threadIdx.x + 2u * UAES_WG] = e2;
     }
     __syncthreads();
-    GF_STAMP(5);
     /* thread q' = 256 quad + p holds accumulators q' and q' + 1024; then the radix-4 tree, last term H^0 */
     uint4 acc = gh_tree<false>(buf, TC, x4(tabmul4(TC, fold.acc[0]), fold.acc[1]), 1024u);
     if (threadIdx.x == 0) buf[GT_BUF - 1] = acc;
     __syncthreads();
-    GF_STAMP(9);
     if (threadIdx.x < 64) {                        /* wave 0: R_b * Ylo[k & 15] * Zhi[k >> 4] */
         const u64 last = (u64)blockIdx.x + (u64)gridDim.x * (geo.iters - 1);        /* this workgroup's last stripe */
         const u32 k = (u32)(stripes - 1 - last);
@@ -898,61 +540,6 @@ static int launch_ej0(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek
     return (int)hipGetLastError();
 }
 
-/* The six nibble tables of a key made INSIDE a kernel, from H in buf[GT_BUF - 3] (k_gcm_small, one-shot calls:
- * no k_gcm_setup launch in front).  Same arithmetic as k_gcm_setup: H^(2^k) = F^k H by the constant Frobenius
- * matrices (one wave per power), the 128 generators M x^q of every table, then entry (p, v) = the XOR of the
- * generators the nibble v selects.  buf is scratch here (the reduction buffer is not in use yet).  All 1024
- * threads call it; ends with a barrier.                                                                    */
-/* YPOW = false: table t holds H^(2^(10 - 2t)) (the last levels of a sequence of blocks).
- * YPOW = true : table t (t >= 2) holds Y^(4^(5 - t)), Y = H^2048, i.e. H^(2^(21 - 2t)) = H^(2^17), H^(2^15), H^(2^13),
- *               H^(2^11), and table 1 holds Y^256 = H^(2^19): the same radix-4 tree over the partial hashes of
- *               2048-block chunks (k_gcm_combine); table 0 holds H (the finisher's length-block step).                                        */
-template <bool YPOW = false>
-__device__ __forceinline__ void gcm_build_nibble_tables(uint4 *TC, uint4 *buf, const uint64_t *__restrict__ frob, u32 ylog = 11)
-{
-    Gf *shPow = (Gf *)buf;                         /* 6 powers                  */
-    Gf *shGen = (Gf *)(buf + 16);                  /* 6 x 128 generators, one slot of skew per eight: 13.5 KiB */
-    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    if (wave < GT_NTAB) {
-        const u32 k = YPOW ? (wave ? ylog + 10u - 2u * wave : 0u) : 10u - 2u * wave;   /* Y = H^(2^ylog): chunks of 2^ylog positions */
-        const Gf h = gf_from4(buf[GT_BUF - 3]);
-        Gf pw = h;
-        if (k) {
-            const uint64_t *rows = frob + (u64)(k - 1) * 256u;
-            const u32 b0 = (u32)(__popcll(rows[2 * lane] & h.hi) + __popcll(rows[2 * lane + 1] & h.lo)) & 1u;
-            const u32 b1 = (u32)(__popcll(rows[128 + 2 * lane] & h.hi) + __popcll(rows[128 + 2 * lane + 1] & h.lo)) & 1u;
-            pw.hi = __ballot(b0);
-            pw.lo = __ballot(b1);
-        }
-        if (lane == 0) shPow[wave] = pw;
-    }
-    __syncthreads();
-    /* (generator g sits at slot g + g / 8: the lanes of the loop below read generators eight apart, 128 bytes, which
-     * without the skew are two bank sets for sixteen lanes) */
-    for (u32 idx = threadIdx.x; idx < GT_NTAB * 128u; idx += GH_T) shGen[idx + (idx >> 3)] = gf_mul_xq128(shPow[idx >> 7], idx & 127u);
-    __syncthreads();
-    for (u32 e = threadIdx.x; e < GT_NTAB * 512u; e += GH_T) {
-        /* e IS the entry's place in its table (nib_entry: 32 v + slot): neighbouring lanes store neighbouring 16-byte
-         * slots.  (Counting e = 16 p + v instead put the eight lanes of a store group 512 bytes apart: an 8-way bank
-         * conflict on every one of the 3072 stores, ~2 us of the 4.5 us this function took.) */
-        const u32 t = e >> 9, v = (e >> 5) & 15u, sl = e & 31u, p = sl < 16u ? 2u * sl : 2u * (sl - 16u) + 1u;
-        const u32 g0 = 128u * t + 4u * p;                     /* four generators, never across a multiple of eight */
-        const Gf *gen = shGen + g0 + (g0 >> 3);
-        Gf x = { 0, 0 };
-#pragma unroll
-        for (u32 i = 0; i < 4; ++i) {
-            const u64 m = 0 - (u64)((v >> (3 - i)) & 1u);
-            x.hi ^= gen[i].hi & m;
-            x.lo ^= gen[i].lo & m;
-        }
-        u32 w[4];
-        gf_to_words(x, w);
-        TC[e] = make_uint4(w[0], w[1], w[2], w[3]);           /* = TC[512 t + nib_entry(p, v)] */
-    }
-    __syncthreads();
-}
-
-#define GHFB_LDS (GHF_LDS + 1024u)      /* the last-levels layout + an unreplicated Te0 copy (k_gcm_combine) */
 
 /* ------------------------------------------------------------------------ */
 /* short messages: the whole of GCM in one workgroup                           */
@@ -968,9 +555,6 @@ __device__ __forceinline__ void gcm_build_nibble_tables(uint4 *TC, uint4 *buf, c
  * writes it only after the tag has matched (N7, micro_aes.c:1200-1208) -- in the same launch.
  * The six nibble tables (H^1024 .. H) come from `scratch` (a key context, k_gcm_setup) or are made here.
  * LDS: [0, 64K) the split-halves AES tables, then the six nibble tables and the reduction buffer.    */
-#define GSM_MAXNV      2046u           /* two padding positions in front: Enc(J0) and (one-shot calls) H = Enc(0) */
-#define GSM_LDS_TAB    65536u
-#define GSM_LDS_TOTAL  (GSM_LDS_TAB + (GT_NTAB * 512u + GT_BUF) * 16u)
 
 template <int NR, bool DEC>
 __global__ __launch_bounds__(GH_T) void k_gcm_small(uaesk_rk rk, uaesk_tables tb, uaesk_ctr ctr, uint4 j0,
@@ -980,8 +564,6 @@ __global__ __launch_bounds__(GH_T) void k_gcm_small(uaesk_rk rk, uaesk_tables tb
 {
     /* build != 0: a one-shot call -- the key's nibble tables are not in `scratch`, they are made here from
      * H = Enc(0), which thread 1's padding slot computes (gcm_build_nibble_tables)                        */
-#define SM_STAMP(i) do { } while (0)
-    SM_STAMP(0);
     uint4 *TC = (uint4 *)(uaes_lds + GSM_LDS_TAB);            /* the six nibble tables; TC[0..512) = H^1024 */
     uint4 *buf = TC + GT_NTAB * 512u;                         /* GT_BUF entries (the last three: H, Enc(J0), verdict) */
     const u64 len = src.ct_len;
@@ -1017,7 +599,6 @@ __global__ __launch_bounds__(GH_T) void k_gcm_small(uaesk_rk rk, uaesk_tables tb
         for (u32 i = threadIdx.x; i < GT_NTAB * 512u; i += GH_T) TC[i] = g4[i];
     }
     fill_tables64(tb.te0, 0);                                 /* ends with a barrier */
-    SM_STAMP(1);
     const LaneConst2 lc = make_lane_const2(0);
 
     uint4 hold[2];                                            /* decrypt: plaintext waiting for the verdict */
@@ -1060,17 +641,14 @@ __global__ __launch_bounds__(GH_T) void k_gcm_small(uaesk_rk rk, uaesk_tables tb
             }
         }
     }
-    SM_STAMP(2);
     if (build) {
         __syncthreads();                                      /* H is in its slot */
         gcm_build_nibble_tables(TC, buf, tb.frob);
     }
-    SM_STAMP(3);
     uint4 acc = xk[0];
     if (steps == 2) acc = x4(tabmul4(TC, acc), xk[1]);
     const u32 live_n = steps == 1 ? (u32)nv : GH_T;
     acc = gh_tree<true>(buf, TC, acc, live_n);
-    SM_STAMP(4);
     if (threadIdx.x == 0) {
         acc = x4(acc, buf[GT_BUF - 2]);
         const u32 w[4] = { acc.x, acc.y, acc.z, acc.w };
@@ -1099,7 +677,6 @@ __global__ __launch_bounds__(GH_T) void k_gcm_small(uaesk_rk rk, uaesk_tables tb
             }
         }
     }
-#undef SM_STAMP
     ticket_release(done);
 }
 
@@ -1128,314 +705,6 @@ static int launch_small_nr(int nr, hipStream_t st, const uaesk_tables *tb, const
     }
 }
 
-/* ------------------------------------------------------------------------ */
-/* many short messages under one key: one launch, 1 / 4 / 16 records per workgroup at a time */
-/* ------------------------------------------------------------------------ */
-/* The GCM counterpart of the XTS sector call ("necessary extensions": a message per API call is
- * 12 us whatever its size, so a stream of TLS records or packets has to arrive as ONE call to run at the
- * GPU's rate).  Record r has its own 12-byte nonce, its own (or the shared) AAD, `rec_len` bytes of text at
- * in + r * in_stride; its output is text || 16-byte tag at out + r * out_stride (decrypt: input is
- * text || tag, output the text -- untouched when the tag is wrong, N7 -- and verdicts[r] = 0 / 0x1A).
- *
- * A workgroup is k_gcm_small's body in a loop: the AES tables and the key's nibble tables are brought into LDS
- * once per workgroup, not once per record.  One record's hash is a chain of DEPENDENT multiplications (the radix-4
- * tree: ~0.3 us per level whatever the width), so a short record leaves the workgroup idle: the 1024 threads are
- * therefore cut into G = 1, 4 or 16 groups of S = 1024, 256 or 64 threads, a record per group -- S is the smallest
- * of the three with room for the record's GHASH positions + one slot for Enc(J0) at two positions per thread --
- * and the G trees run side by
- * side as ONE tree whose first (1024-wide) level is already the groups' own first level (gh_tree_groups).  */
-#define GREC_SLOTS     (GT_BUF)                 /* 16 Enc(J0) slots, 16 verdict slots behind the tree buffer */
-#define GREC_LDS_TOTAL (GSM_LDS_TOTAL + 32u * 16u + 128u)   /* ... and sixteen live counts, sixteen lengths */
-
-/* gh_tree for 4^(5-lg) independent groups of S = 4^lg consecutive entries each (lg = 5, 4, 3); every group's last
- * `live` entries are not padding.  Group g's hash comes back in the four threads 4g .. 4g+3.            */
-__device__ __forceinline__ uint4 gh_tree_groups(uint4 *buf, const uint4 *T, uint4 acc, u32 live, u32 lg, u32 tid,
-                                                const u32 *lives = nullptr)
-{
-    /* lives != nullptr: records of different lengths -- group g's count of non-padding entries is lives[g] (LDS, written
-     * before this call; the first barrier below orders it), and a quad looks up the count of the group ITS accumulator
-     * belongs to at every level */
-    buf[tid] = acc;
-    __syncthreads();
-    const u32 o = tid >> 2;                            /* the accumulator this quad makes at every level */
-    u32 n = 1024u, off = 0;
-#pragma unroll
-    for (u32 lvl = 1; lvl <= 4; ++lvl) {                       /* tables H^256, H^64, H^16, H^4: m = 4^(5 - lvl) */
-        if (lvl + lg < 6u) continue;                           /* the groups are shorter than 4 m (uniform) */
-        const u32 m = 1u << (2u * (5u - lvl));
-        const uint4 *Tl = T + 512u * lvl;
-        if (tid < n) {
-            const u32 g = o >> (2u * (5u - lvl)), ql = o & (m - 1u);
-            const uint4 *row = buf + off + g * 4u * m + ql;
-            u32 lv = lives ? lives[g] : live;
-            lv = lv < 4u * m ? lv : 4u * m;
-            const u32 k0 = 4u - (lv + m - 1u) / m;             /* first row with a live entry (4: none, the sum is zero) */
-            acc = k0 < 4u ? row[k0 * m] : make_uint4(0, 0, 0, 0);
-            for (u32 k = k0 + 1; k < 4; ++k) acc = x4(tabmul4q(Tl, acc, tid), row[k * m]);
-            if ((tid & 3u) == 0) buf[off + n + o] = acc;
-        }
-        __syncthreads();
-        off += n;
-        n >>= 2;
-    }
-    if (tid < n) {                                     /* n = 4 G: a quad per group, GHASH's last level */
-        const uint4 *TF = T + 512u * 5u;
-        const uint4 *row = buf + off + 4u * o;
-        u32 lv = lives ? lives[o] : live;
-        lv = lv < 4u ? lv : 4u;
-        acc = make_uint4(0, 0, 0, 0);
-        for (u32 k = 4u - lv; k < 4; ++k) acc = tabmul4q(TF, x4(acc, row[k]), tid);
-    }
-    return acc;
-}
-
-template <int NR, bool DEC>
-__global__ __launch_bounds__(GH_T) void k_gcm_records(uaesk_rk rk, uaesk_tables tb, const unsigned char *__restrict__ nonces,
-                                                      const unsigned char *aad, u64 aad_len, u64 aad_stride,
-                                                      const unsigned char *in, u64 rec_len, u64 in_stride,
-                                                      unsigned char *out, u64 out_stride, u64 nrec, u32 lg,
-                                                      const u32 *__restrict__ lens,
-                                                      const unsigned char *__restrict__ scratch,
-                                                      unsigned char *verdicts, int *status)
-{
-    uint4 *TC = (uint4 *)(uaes_lds + GSM_LDS_TAB);
-    uint4 *buf = TC + GT_NTAB * 512u;
-    uint4 *slots = buf + GREC_SLOTS;
-    u32 *lives = (u32 *)(slots + 32);                         /* records of different lengths: a group's live positions ... */
-    u32 *rls = lives + 16;                                    /* ... and its record's length */
-    {
-        const uint4 *g4 = (const uint4 *)(scratch + GS_TAB4);
-        for (u32 i = threadIdx.x; i < GT_NTAB * 512u; i += GH_T) TC[i] = g4[i];
-    }
-    fill_tables64(tb.te0, 0);                                 /* ends with a barrier */
-    const LaneConst2 lc = make_lane_const2(0);
-    /* rec_len is the longest record (lens != nullptr: record r has min(lens[r], rec_len) bytes); the arrangement --
-     * groups, positions per thread -- is the one the longest record needs, a shorter one only has more padding */
-    const u64 ablk = (aad_len + 15) >> 4, nv_max = ablk + ((rec_len + 15) >> 4) + 1;
-    const u32 G = GH_T >> (2u * lg);                          /* groups = records per turn */
-    const u32 grp = threadIdx.x >> (2u * lg);
-    /* the nonce of the group's record in the turn that starts at `base` (three little-endian words); fetched one turn
-     * ahead, as are a turn's texts before its block encryptions: nothing else hides a load's latency here */
-    const bool nonce_words = (((uintptr_t)nonces) & 3u) == 0;
-    auto load_nonce = [&](u64 base, u32 (&nw)[3], u32 &rl) {
-        const u64 r = base + grp;
-        const u64 rr = r < nrec ? r : 0;
-        const unsigned char *np = nonces + 12 * rr;
-        rl = (u32)rec_len;
-        if (lens) { const u32 l = lens[rr]; rl = l < rl ? l : rl; }
-        if (nonce_words) {
-            nw[0] = ((const u32 *)np)[0]; nw[1] = ((const u32 *)np)[1]; nw[2] = ((const u32 *)np)[2];
-        } else {
-#pragma unroll
-            for (u32 q = 0; q < 3; ++q)
-                nw[q] = (u32)np[4 * q] | (u32)np[4 * q + 1] << 8 | (u32)np[4 * q + 2] << 16 | (u32)np[4 * q + 3] << 24;
-        }
-    };
-    u32 nw[3], rl_next;
-    load_nonce((u64)blockIdx.x * G, nw, rl_next);
-#define RC_STAMP(i) do { } while (0)
-    for (u64 base = (u64)blockIdx.x * G; base < nrec; base += (u64)gridDim.x * G) {
-        RC_STAMP(0);
-        /* everything the rounds derive from the lane constants (the odd rounds' per-lane key words above all) is made
-         * again in every turn: held across the turn it is forty registers that end up in scratch memory */
-        LaneConst2 lcv = lc;
-        u32 tid = threadIdx.x, lgv = lg;
-        asm volatile("" : "+v"(lcv.hmask), "+v"(lcv.t[0]), "+v"(lcv.t[1]), "+v"(lcv.t[2]), "+v"(lcv.t[3]), "+v"(tid), "+s"(lgv));
-        const u32 S = 1u << (2u * lgv), t = tid & (S - 1u);    /* group size, position in the group */
-        const u32 steps = nv_max + 1 > S ? 2u : 1u;           /* positions per thread (launch_records: nv_max + 1 <= 2 S) */
-        const u64 len_r = rl_next;                            /* this turn's record of the group */
-        const u64 cblk = (len_r + 15) >> 4, nv = ablk + cblk + 1;
-        const u64 pad = (u64)steps * S - nv;                  /* >= 1: the group's position 0 is Enc(J0)'s */
-        const u32 live_n = nv < S ? (u32)nv : S;
-        const u64 r = base + grp;
-        const bool have = r < nrec;                           /* the last turn may leave groups without a record */
-        const u64 rr = have ? r : 0;
-        const uint4 *rin = (const uint4 *)(in + rr * in_stride);
-        uint4 *rout = (uint4 *)(out + rr * out_stride);
-        GSrc rest;                                            /* AAD blocks and the length block */
-        rest.aad = aad + rr * aad_stride;
-        rest.aad_len = aad_len;
-        rest.ct = nullptr;
-        rest.ct_len = 0;
-        rest.has_len = 1;
-        rest.len_aad = aad_len;
-        rest.len_ct = len_r;
-        rest.rev = 0;
-        uint4 xk[2] = { make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0) };   /* the position's GHASH input; first the text read */
-        bool is_text[2] = { false, false };
-        u32 ti[2] = { 0, 0 }, tn[2] = { 0, 0 };                /* text block index, bytes in it */
-#pragma unroll                                                /* constant indices: the per-step arrays stay in registers */
-        for (u32 k = 0; k < 2; ++k) {
-            if (k >= steps) break;
-            const u64 u = (u64)k * S + t;
-            const bool live = have && u >= pad;
-            const u64 v = live ? u - pad : 0;
-            is_text[k] = live && v >= ablk && v < ablk + cblk;
-            if (is_text[k]) {
-                ti[k] = (u32)(v - ablk);
-                const u64 avail = len_r - 16ull * ti[k];
-                tn[k] = avail < 16 ? (u32)avail : 16u;
-                xk[k] = tn[k] == 16 ? rin[ti[k]] : load_bytes_padded((const unsigned char *)(rin + ti[k]), tn[k]);
-            } else if (live) {
-                xk[k] = load_vblock_fwd(rest, v < ablk ? v : ablk);
-            }
-        }
-        /* J0 = nonce || 00 00 00 01 (GCMsetup, micro_aes.c:1140-1152); text block i takes J0 + 1 + i (N4) */
-        uaesk_ctr ctr;
-        ctr.w0 = nw[0];
-        ctr.w1 = nw[1];
-        ctr.w2 = 0; ctr.w3 = 0;
-        ctr.b8 = nw[2] & 0xffu;
-        const u32 n911 = bswap32(nw[2]) & 0x00ffffffu;        /* nonce bytes 9, 10, 11: the top of the 56-bit counter */
-        ctr.v0 = ((u64)n911 << 32) + 2u;
-        ctr.le32 = 0;
-        const u32 j0w2 = nw[2];
-        load_nonce(base + (u64)gridDim.x * G, nw, rl_next);   /* the next turn's */
-        RC_STAMP(1);
-        uint4 hold[2];
-#pragma unroll                                                /* constant indices: the per-step arrays stay in registers */
-        for (u32 k = 0; k < 2; ++k) {
-            if (k >= steps) break;
-            const bool is_j0 = have && k == 0 && t == 0;      /* the group's position 0 is padding: Enc(J0) rides there */
-            u32 s1[1][4];
-            ctr_words(ctr, ti[k], s1[0]);
-            if (is_j0) {                                      /* words 0-1 are the nonce's already */
-                s1[0][2] = j0w2;
-                s1[0][3] = 0x01000000u;
-            }
-            if (__builtin_amdgcn_ballot_w64(is_text[k] || is_j0) != 0) enc_blocks<NR, 1>(s1, rk, lcv);
-            if (is_j0) slots[grp] = make_uint4(s1[0][0], s1[0][1], s1[0][2], s1[0][3]);
-            if (k == 0 && t == 0) { lives[grp] = have ? live_n : 0u; rls[grp] = (u32)len_r; }
-            if (is_text[k]) {
-                const uint4 d = xk[k];
-                const u32 nb = tn[k];
-                u32 o[4] = { d.x ^ s1[0][0], d.y ^ s1[0][1], d.z ^ s1[0][2], d.w ^ s1[0][3] };
-                if (nb < 16) {
-#pragma unroll
-                    for (u32 w = 0; w < 4; ++w) {
-                        const u32 keep = nb >= 4 * w + 4 ? 0xffffffffu : nb <= 4 * w ? 0u : (1u << (8 * (nb - 4 * w))) - 1u;
-                        o[w] &= keep;
-                    }
-                }
-                const uint4 ov = make_uint4(o[0], o[1], o[2], o[3]);
-                if (DEC) {
-                    hold[k] = ov;                             /* GHASH takes the ciphertext read (xk[k] stays) */
-                } else {
-                    xk[k] = ov;
-                    if (nb == 16) {
-                        rout[ti[k]] = ov;
-                    } else {
-                        unsigned char *dst = (unsigned char *)(rout + ti[k]);
-                        for (u32 b = 0; b < nb; ++b) dst[b] = (unsigned char)(o[b >> 2] >> (8 * (b & 3)));
-                    }
-                }
-            }
-        }
-        RC_STAMP(2);
-        uint4 acc = xk[0];
-        if (steps == 2) acc = x4(tabmul4(TC + 512u * (5u - lgv), acc, tid), xk[1]);   /* by H^S: tables H^1024, H^256, H^64 */
-        RC_STAMP(3);
-        acc = gh_tree_groups(buf, TC, acc, live_n, lgv, tid, lens ? lives : nullptr);       /* group q's hash: threads 4q .. 4q+3 */
-        RC_STAMP(4);
-        const u32 q = tid >> 2;
-        if ((tid & 3u) == 0 && q < G && base + q < nrec) {
-            const u64 rq = base + q;
-            acc = x4(acc, slots[q]);
-            const u32 w[4] = { acc.x, acc.y, acc.z, acc.w };
-            if (DEC) {
-                const unsigned char *tag = in + rq * in_stride + rls[q];
-                u32 diff = 0;
-                for (u32 b = 0; b < 16; ++b) diff |= (u32)tag[b] ^ ((w[b >> 2] >> (8 * (b & 3))) & 0xffu);
-                if (verdicts) verdicts[rq] = diff ? 0x1A : 0;
-                if (diff) atomicOr(status, 0x1A);
-                slots[16 + q] = make_uint4(diff, 0, 0, 0);
-            } else {
-                unsigned char *tag = out + rq * out_stride + rls[q];
-                for (u32 b = 0; b < 16; ++b) tag[b] = (unsigned char)(w[b >> 2] >> (8 * (b & 3)));
-            }
-        }
-        if (DEC) {
-            __syncthreads();
-            if (have && slots[16 + grp].x == 0) {
-#pragma unroll
-                for (u32 k = 0; k < 2; ++k) {
-                    if (!is_text[k]) continue;
-                    if (tn[k] == 16) {
-                        rout[ti[k]] = hold[k];
-                    } else {
-                        const u32 o[4] = { hold[k].x, hold[k].y, hold[k].z, hold[k].w };
-                        unsigned char *dst = (unsigned char *)(rout + ti[k]);
-                        for (u32 b = 0; b < tn[k]; ++b) dst[b] = (unsigned char)(o[b >> 2] >> (8 * (b & 3)));
-                    }
-                }
-            }
-        }
-        __syncthreads();                                      /* the Enc(J0) and verdict slots are rewritten by the next turn */
-    }
-#undef RC_STAMP
-}
-
-template <int NR>
-static int launch_records(hipStream_t st, const uaesk_tables *tb, const uaesk_rk *ek, int decrypt, const void *nonces,
-                          const void *aad, size_t aad_len, size_t aad_stride, const void *in, size_t rec_len,
-                          size_t in_stride, void *out, size_t out_stride, size_t nrec, const void *sc,
-                          unsigned char *verdicts, int *status, const void *lens)
-{
-    int cus = 0;
-    uaesk_device_info(&cus, nullptr);
-    const u64 nv = (aad_len + 15) / 16 + (rec_len + 15) / 16 + 1;
-    const u32 lg = nv + 1 <= 128 ? 3u : nv + 1 <= 512 ? 4u : 5u;   /* one or two positions per thread */
-    const u64 turns = (nrec + (GH_T >> (2 * lg)) - 1) / (GH_T >> (2 * lg));
-    const u64 cap = cus > 0 ? (u64)cus : 256u;
-    const unsigned grid = (unsigned)(turns < cap ? turns : cap);
-    hipError_t e;
-    if (decrypt) {
-        e = uaesk_want_lds((const void *)k_gcm_records<NR, true>, (unsigned)GREC_LDS_TOTAL);
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL((k_gcm_records<NR, true>), dim3(grid), dim3(GH_T), GREC_LDS_TOTAL, st, *ek, *tb,
-                           (const unsigned char *)nonces, (const unsigned char *)aad, (u64)aad_len, (u64)aad_stride,
-                           (const unsigned char *)in, (u64)rec_len, (u64)in_stride, (unsigned char *)out, (u64)out_stride,
-                           (u64)nrec, lg, (const u32 *)lens, (const unsigned char *)sc, verdicts, status);
-    } else {
-        e = uaesk_want_lds((const void *)k_gcm_records<NR, false>, (unsigned)GREC_LDS_TOTAL);
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL((k_gcm_records<NR, false>), dim3(grid), dim3(GH_T), GREC_LDS_TOTAL, st, *ek, *tb,
-                           (const unsigned char *)nonces, (const unsigned char *)aad, (u64)aad_len, (u64)aad_stride,
-                           (const unsigned char *)in, (u64)rec_len, (u64)in_stride, (unsigned char *)out, (u64)out_stride,
-                           (u64)nrec, lg, (const u32 *)lens, (const unsigned char *)sc, verdicts, status);
-    }
-    return (int)hipGetLastError();
-}
-
-/* records of up to uaesk_gcm_record_max(aad_len) bytes; texts and strides 16-byte aligned; decrypt: *status must be
- * zero when the kernel starts (it ORs 0x1A in), verdicts may be NULL */
-extern "C" size_t uaesk_gcm_record_max(size_t aad_len)
-{
-    const size_t ablk = (aad_len + 15) / 16;
-    return ablk + 2 > GSM_MAXNV ? 0 : (GSM_MAXNV - 1 - ablk) * 16;
-}
-
-extern "C" int uaesk_gcm_records(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *ek, int decrypt,
-                                 const void *nonces12, const void *aad, size_t aad_len, size_t aad_stride,
-                                 const void *in, size_t rec_len, size_t in_stride, void *out, size_t out_stride,
-                                 size_t nrec, const void *key_scratch, unsigned char *verdicts, int *status,
-                                 const void *lens)
-{
-    if (!nrec) return 0;
-    if (((aad_len + 15) / 16) + ((rec_len + 15) / 16) + 1 > GSM_MAXNV) return (int)hipErrorInvalidValue;
-    if ((((uintptr_t)in | (uintptr_t)out | in_stride | out_stride) & 15u) != 0) return (int)hipErrorInvalidValue;
-    if (decrypt && !status) return (int)hipErrorInvalidValue;
-    if (((uintptr_t)lens) & 3u) return (int)hipErrorInvalidValue;
-    switch (nr) {
-    case 10: return launch_records<10>(S(stream), tb, ek, decrypt, nonces12, aad, aad_len, aad_stride, in, rec_len, in_stride,
-                                       out, out_stride, nrec, key_scratch, verdicts, status, lens);
-    case 12: return launch_records<12>(S(stream), tb, ek, decrypt, nonces12, aad, aad_len, aad_stride, in, rec_len, in_stride,
-                                       out, out_stride, nrec, key_scratch, verdicts, status, lens);
-    case 14: return launch_records<14>(S(stream), tb, ek, decrypt, nonces12, aad, aad_len, aad_stride, in, rec_len, in_stride,
-                                       out, out_stride, nrec, key_scratch, verdicts, status, lens);
-    default: return (int)hipErrorInvalidValue;
-    }
-}
 
 /* ------------------------------------------------------------------------ */
 /* medium messages (up to 256 chunks of 2048 GHASH blocks: 8 MiB): chunk kernel + combine kernel */
@@ -1908,190 +1177,10 @@ static int launch_medium(hipStream_t st, const uaesk_tables *tb, const uaesk_rk 
     return (int)hipGetLastError();
 }
 
-/* ------------------------------------------------------------------------ */
-/* short GCM-SIV messages (RFC 8452; GCM_SIV_encrypt/decrypt, micro_aes.c:1421-1515) in one workgroup */
-/* ------------------------------------------------------------------------ */
-/* The same shape as k_gcm_small with the order of GCM-SIV: the tag comes from the PLAINTEXT
- * (POLYVAL = the GHASH levels on byte-reversed blocks under the key mulX(rev(H)), which the host passes as
- * `hg`), and the counter of the keystream is the tag.  Encrypt: POLYVAL over AAD || plaintext || lengths,
- * tag = Enc((rev(S) ^ nonce) with the top bit cleared), then every thread encrypts the counter blocks of its
- * text positions.  Decrypt: keystream from the RECEIVED tag first, the plaintext is written (the reference
- * releases it before it authenticates, :1500-1511), then the same POLYVAL and the comparison.  The key's
- * nibble tables are made in the kernel (gcm_build_nibble_tables; the message-authentication key is per NONCE
- * here, so there is nothing to keep), and so are the per-nonce keys themselves (derive_keys under the master
- * key + KeyExpansion of the derived key).  One launch instead of key-derivation ECB + POLYVAL setup / levels +
- * tag ECB + CTR with three host round trips in between: a 4 KiB call 100 -> 30 us.                        */
-#define SIV_LDS_KEYS   GSM_LDS_TOTAL                    /* 8 derived + 60 schedule words, then a plain copy of Te0 */
-#define SIV_LDS_TE     (SIV_LDS_KEYS + 512u)
-#define SIV_LDS_TOTAL  (SIV_LDS_TE + 1024u)
-
-template <int NR, bool DEC>
-__global__ __launch_bounds__(GH_T) void k_siv_small(uaesk_rk mk, uaesk_tables tb, uint4 nonce,
-                                                    GSrc src, const uint4 *in, uint4 *out,
-                                                    unsigned char *tag_io, int *status)
-{
-    uint4 *TC = (uint4 *)(uaes_lds + GSM_LDS_TAB);
-    uint4 *buf = TC + GT_NTAB * 512u;
-    u32 *drv = (u32 *)(uaes_lds + SIV_LDS_KEYS);              /* [0..11] derived words, [16..75] the schedule */
-    u32 *ekl = drv + 16;
-    u32 *te_plain = (u32 *)(uaes_lds + SIV_LDS_TE);
-    if (threadIdx.x < 256) te_plain[threadIdx.x] = tb.te0[threadIdx.x];
-    fill_tables64(tb.te0, 0);                                 /* ends with a barrier */
-    const LaneConst2 lc = make_lane_const2(0);
-
-    /* derive_keys (RFC 8452 sec. 4; GCM_SIV_init, micro_aes.c:1421-1450) in the kernel: blocks LE32(i) || nonce
-     * under the MASTER key, i < 2 + keybits/64, one lane each; their low halves are the message-authentication
-     * key (blocks 0, 1) and the message-encryption key (blocks 2..), whose schedule thread 0 expands here
-     * (KeyExpansion :144-178; S[x] = byte 1 of Te0[x]).  The host only expands the master key.            */
-    constexpr u32 NK = NR - 6, NB = 2 + NK / 2;
-    if (threadIdx.x < 64) {
-        u32 s1[1][4] = { { threadIdx.x, nonce.x, nonce.y, nonce.z } };
-        enc_blocks<NR, 1>(s1, mk, lc);
-        if (threadIdx.x < NB) { drv[2 * threadIdx.x] = s1[0][0]; drv[2 * threadIdx.x + 1] = s1[0][1]; }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint4 auth = make_uint4(drv[0], drv[1], drv[2], drv[3]);
-        u32 hw[4];
-        gf_to_words(gf_mul_xk(gf_from4(rev16(auth)), 1), hw);    /* POLYVAL key in GHASH form: mulX(rev(H)) */
-        buf[GT_BUF - 3] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
-        auto subword = [&](u32 w) -> u32 {
-            return ((te_plain[w & 0xffu] >> 8) & 0xffu) | (te_plain[(w >> 8) & 0xffu] & 0xff00u) |
-                   ((te_plain[(w >> 16) & 0xffu] & 0xff00u) << 8) | ((te_plain[w >> 24] & 0xff00u) << 16);
-        };
-        /* the schedule grows in REGISTERS (fully unrolled: constant indices) and goes to LDS at the end: with ekl[] as
-         * the working array every word waited for an LDS store and two loads, ~200 cycles x 40..52 words = 3.7 us */
-        u32 w[4 * (NR + 1)];
-#pragma unroll
-        for (u32 i = 0; i < NK; ++i) w[i] = drv[4 + i];
-        u32 rcon = 1;
-#pragma unroll
-        for (u32 i = NK; i < 4u * (NR + 1); ++i) {
-            u32 t = w[i - 1];
-            if (i % NK == 0) {
-                t = subword((t >> 8) | (t << 24)) ^ rcon;         /* RotWord on LE words */
-                rcon = ((rcon << 1) ^ ((rcon >> 7) * 0x1bu)) & 0xffu;
-            } else if (NK == 8 && i % NK == 4) {
-                t = subword(t);
-            }
-            w[i] = w[i - NK] ^ t;
-        }
-#pragma unroll
-        for (u32 i = 0; i < 4u * (NR + 1); ++i) ekl[i] = w[i];
-    }
-    __syncthreads();
-    uaesk_rk rk;
-#pragma unroll
-    for (int i = 0; i < 4 * (NR + 1); ++i) rk.w[i] = (u32)__builtin_amdgcn_readfirstlane((int)ekl[i]);
-    gcm_build_nibble_tables(TC, buf, tb.frob);
-
-    const u64 len = src.ct_len;
-    const u64 ablk = (src.aad_len + 15) >> 4, cblk = (len + 15) >> 4, nv = ablk + cblk + 1;
-    const u32 steps = nv + 2 > GH_T ? 2u : 1u;
-    const u64 pad = (u64)steps * GH_T - nv;
-    GSrc rest = src;                                          /* AAD blocks and the length block */
-    rest.ct_len = 0;
-
-    uaesk_ctr ctr;                                            /* the keystream counter = the tag, byte 15 |= 0x80, LE32 in bytes 0..3 (:935-938) */
-    ctr.le32 = 1; ctr.v0 = 0; ctr.b8 = 0;
-    if (DEC) {
-        u32 w[4] = { 0, 0, 0, 0 };
-        for (u32 b = 0; b < 16; ++b) w[b >> 2] |= (u32)tag_io[b] << (8 * (b & 3));
-        ctr.w0 = w[0]; ctr.w1 = w[1]; ctr.w2 = w[2]; ctr.w3 = w[3] | 0x80000000u;
-    }
-
-    /* one text block: out = in ^ Enc(counter i); returns the PLAINTEXT block, zero padded */
-    auto crypt_block = [&](u64 i) -> uint4 {
-        const u64 avail = len - 16 * i;
-        const u32 nb = avail < 16 ? (u32)avail : 16u;
-        u32 s1[1][4];
-        ctr_words(ctr, i, s1[0]);
-        enc_blocks<NR, 1>(s1, rk, lc);
-        const uint4 d = nb == 16 ? in[i] : load_bytes_padded((const unsigned char *)(in + i), nb);
-        u32 o[4] = { d.x ^ s1[0][0], d.y ^ s1[0][1], d.z ^ s1[0][2], d.w ^ s1[0][3] };
-        if (nb < 16) {
-#pragma unroll
-            for (u32 w = 0; w < 4; ++w) {
-                const u32 keep = nb >= 4 * w + 4 ? 0xffffffffu : nb <= 4 * w ? 0u : (1u << (8 * (nb - 4 * w))) - 1u;
-                o[w] &= keep;
-            }
-            unsigned char *dst = (unsigned char *)(out + i);
-            for (u32 b = 0; b < nb; ++b) dst[b] = (unsigned char)(o[b >> 2] >> (8 * (b & 3)));
-        } else {
-            out[i] = make_uint4(o[0], o[1], o[2], o[3]);
-        }
-        return DEC ? make_uint4(o[0], o[1], o[2], o[3]) : d;
-    };
-
-    /* POLYVAL input of this thread's positions (decrypt: produced by decrypting them) */
-    uint4 xk[2] = { make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0) };
-#pragma unroll                                                /* constant indices: the per-step arrays stay in registers */
-    for (u32 k = 0; k < 2; ++k) {
-        if (k >= steps) break;
-        const u64 u = (u64)k * GH_T + threadIdx.x;
-        if (u < pad) continue;
-        const u64 v = u - pad;
-        if (v >= ablk && v < ablk + cblk) {
-            const u64 i = v - ablk;
-            uint4 p;
-            if (DEC) {
-                p = crypt_block(i);
-            } else {
-                const u64 avail = len - 16 * i;
-                p = avail >= 16 ? in[i] : load_bytes_padded((const unsigned char *)(in + i), (u32)avail);
-            }
-            xk[k] = rev16(p);
-        } else {
-            xk[k] = load_vblock(rest, v < ablk ? v : ablk);
-        }
-    }
-    uint4 acc = xk[0];
-    if (steps == 2) acc = x4(tabmul4(TC, acc), xk[1]);
-    acc = gh_tree<true>(buf, TC, acc, steps == 1 ? (u32)nv : GH_T);
-    if (threadIdx.x == 0) {                                   /* S = POLYVAL ^ nonce, top bit cleared (GCM_SIVtag :1453-1460) */
-        uint4 sv = rev16(acc);
-        sv.x ^= nonce.x; sv.y ^= nonce.y; sv.z ^= nonce.z;
-        sv.w &= 0x7fffffffu;
-        buf[GT_BUF - 2] = sv;
-    }
-    __syncthreads();
-    u32 t1[1][4];
-    {
-        const uint4 sv = buf[GT_BUF - 2];
-        t1[0][0] = sv.x; t1[0][1] = sv.y; t1[0][2] = sv.z; t1[0][3] = sv.w;
-    }
-    enc_blocks<NR, 1>(t1, rk, lc);                            /* every thread: the tag */
-    if (DEC) {
-        if (threadIdx.x == 0) {
-            u32 diff = 0;
-            for (u32 b = 0; b < 16; ++b) diff |= (u32)tag_io[b] ^ ((t1[0][b >> 2] >> (8 * (b & 3))) & 0xffu);
-            *status = diff ? 0x1A : 0;
-        }
-        return;
-    }
-    ctr.w0 = t1[0][0]; ctr.w1 = t1[0][1]; ctr.w2 = t1[0][2]; ctr.w3 = t1[0][3] | 0x80000000u;
-#pragma unroll                                                /* constant indices: the per-step arrays stay in registers */
-    for (u32 k = 0; k < 2; ++k) {
-        if (k >= steps) break;
-        const u64 u = (u64)k * GH_T + threadIdx.x;
-        if (u < pad) continue;
-        const u64 v = u - pad;
-        if (v >= ablk && v < ablk + cblk) (void)crypt_block(v - ablk);
-    }
-    if (threadIdx.x == 0)
-        for (u32 b = 0; b < 16; ++b) tag_io[b] = (unsigned char)(t1[0][b >> 2] >> (8 * (b & 3)));
-}
 
 /* ------------------------------------------------------------------------ */
 /* host-side drivers                                                          */
 /* ------------------------------------------------------------------------ */
-#define GCM_NR(CALL)                                              \
-    switch (nr) {                                                 \
-    case 10: { constexpr int NR = 10; rc = CALL; } break;         \
-    case 12: { constexpr int NR = 12; rc = CALL; } break;         \
-    case 14: { constexpr int NR = 14; rc = CALL; } break;         \
-    default: return (int)hipErrorInvalidValue;                    \
-    }
 
 struct GPlan {
     u32 logA;       /* 0 = no bulk level */
@@ -2949,40 +2038,6 @@ extern "C" int uaesk_gcm_stream_tag(void *stream, void *scratch, int compare, vo
     return (int)hipGetLastError();
 }
 
-/* GCM-SIV of a short message in one launch (k_siv_small), key derivation included: mk = the schedule of the MASTER
- * key.  encrypt: tag written at out + len; decrypt: tag read at in + len, *status = 0 / 0x1A, the plaintext is
- * written either way.  Returns -1 if the message is too long for this arrangement (siv_plan): the caller then takes
- * uaesk_gcmsiv_long.                                                                                          */
-extern "C" int uaesk_gcmsiv_small(void *stream, const uaesk_tables *tb, int nr, const uaesk_rk *mk, int decrypt,
-                                  const uint8_t *nonce12,
-                                  const void *aad, size_t aad_len, const void *in, size_t len, void *out, int *status)
-{
-    if (siv_plan(len, aad_len, true).arrangement != UAES_ARR_SIV_SMALL) return -1;
-    GSrc src;
-    src.aad = (const unsigned char *)aad; src.aad_len = aad_len;
-    src.ct = (const unsigned char *)in; src.ct_len = len;
-    src.has_len = 1; src.len_aad = aad_len; src.len_ct = len; src.rev = 1;
-    uint4 nn = make_uint4(0, 0, 0, 0);
-    memcpy(&nn, nonce12, 12);
-    hipStream_t st = S(stream);
-    hipError_t e;
-#define SIV_LAUNCH(NRV, D)                                                                                          \
-    do {                                                                                                            \
-        e = uaesk_want_lds((const void *)k_siv_small<NRV, D>, (unsigned)(SIV_LDS_TOTAL));                           \
-        if (e != hipSuccess) return (int)e;                                                                         \
-        hipLaunchKernelGGL((k_siv_small<NRV, D>), dim3(1), dim3(GH_T), SIV_LDS_TOTAL, st, *mk, *tb, nn, src,        \
-                           (const uint4 *)in, (uint4 *)out,                                                         \
-                           (D) ? (unsigned char *)in + len : (unsigned char *)out + len, status);                   \
-    } while (0)
-    switch (nr) {
-    case 10: if (decrypt) SIV_LAUNCH(10, true); else SIV_LAUNCH(10, false); break;
-    case 12: if (decrypt) SIV_LAUNCH(12, true); else SIV_LAUNCH(12, false); break;
-    case 14: if (decrypt) SIV_LAUNCH(14, true); else SIV_LAUNCH(14, false); break;
-    default: return (int)hipErrorInvalidValue;
-    }
-#undef SIV_LAUNCH
-    return (int)hipGetLastError();
-}
 
 /* ------------------------------------------------------------------------ */
 /* long GCM-SIV messages: nothing per-nonce visits the host                    */

@@ -310,6 +310,7 @@ def test_the_table_of_arrangements_without_a_device():
         L.uaes_debug_plan_disable(0)
     # the kernel layer reads no size threshold from the environment: the only getenv calls left are the documented hooks
     hooks = set()
-    for f in ("uaes_kernels.hip", "uaes_gcm.hip", "uaes_ocb.hip", "uaes_chain.hip", "uaes_mac.hip"):
+    for f in ("uaes_kernels.hip", "uaes_gcm.hip", "uaes_gcm_records.hip", "uaes_siv.hip", "uaes_ghash.hip.h", "uaes_ocb.hip",
+              "uaes_chain.hip", "uaes_mac.hip"):
         hooks |= set(re.findall(r'getenv\("(\w+)"\)', open(os.path.join(ROOT, "micro-aes_amd", "csrc", f)).read()))
     assert hooks == {"UAES_PLAN_DISABLE", "UAES_GCM_FOLD", "UAES_GCM_LOOK_TICKS"}, hooks
