@@ -830,3 +830,46 @@ def test_one_launch_gcm_under_oversubscription(orc):
     assert L.uaes_debug_gcm_chunk_folds(C.byref(folds1)) == 0
     # informational: how often a chunk workgroup (not the preparing one) was the last to arrive under this load
     print("folds done by a chunk workgroup under oversubscription: %d" % (folds1.value - folds0.value))
+
+
+def test_dev_calls_are_capturable_into_a_hip_graph(orc):
+    """The *_dev entry points only enqueue kernels on the caller's stream -- no allocation after the first call on a
+    stream, no synchronisation, round keys and counters passed by value -- so a launch-bound sequence of small calls can
+    be captured into a hipGraph once and replayed (the one-launch GCM arrangement restores its arrival counter itself,
+    so a replay finds it at zero).  Sixteen calls of each bulk mode, captured and replayed three times over fresh
+    input: every replay's output against the oracle."""
+    import torch
+    key, keys2, nonce = bytes(range(16)), bytes(range(64)), bytes(range(12))
+    ctr0 = nonce + b"\0\0\0\1"
+    N, M = 16, 64 << 10
+    src = torch.zeros(N, M, dtype=torch.uint8, device="cuda:0")
+    out = {m: torch.zeros(N, M + 16, dtype=torch.uint8, device="cuda:0") for m in ("ctr", "xts", "gcm", "ocb")}
+    side = torch.cuda.Stream()
+
+    def sequence(st):
+        for i in range(N):
+            uaes.ctr_xcrypt_dev(key, ctr0, i * (M // 16), src[i], out["ctr"][i, :M], nbytes=M, stream=st)
+            uaes.xts_sectors_dev(keys2, i * (M // 4096), 4096, M // 4096, src[i], out["xts"][i, :M], stream=st)
+            uaes.gcm_encrypt_dev(key, nonce, None, src[i], M, out["gcm"][i], stream=st)
+            uaes.ocb_dev(key, nonce, None, src[i], M, out["ocb"][i], stream=st)
+
+    with torch.cuda.stream(side):
+        sequence(side)                                      # warm-up on THIS stream: its scratch slot, LDS attributes
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        sequence(torch.cuda.current_stream())
+    for rep in range(3):
+        data = orc.splitmix(900 + rep, N * M)
+        src.copy_(torch.frombuffer(bytearray(data), dtype=torch.uint8).view(N, M))
+        for t in out.values():
+            t.zero_()
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        for i in (0, 7, N - 1):
+            piece = data[i * M:(i + 1) * M]
+            assert bytes(out["ctr"][i, :M].cpu().numpy()) == orc.ctr_xcrypt_at(key, ctr0, i * (M // 16), piece), (rep, i)
+            assert bytes(out["xts"][i, :M].cpu().numpy()) == orc.xts_sectors(keys2, i * (M // 4096), 4096, piece, True)[1], (rep, i)
+            assert bytes(out["gcm"][i].cpu().numpy()) == orc.gcm_encrypt(key, nonce, b"", piece), (rep, i)
+            assert bytes(out["ocb"][i].cpu().numpy()) == orc.ocb_encrypt(key, nonce, b"", piece), (rep, i)
